@@ -1,0 +1,313 @@
+/* quisk_oracle.c -- TEST INFRASTRUCTURE ONLY.  See quisk_oracle.h.
+ *
+ * The arithmetic order of every multiply-accumulate follows the reference so that
+ * the comparison with oracle/_ref/libquisk_filter_ref.so can be bit-exact:
+ * tap k multiplies the sample k positions back, k ascending, accumulator starts at 0,
+ * complex x real products are (re*c, im*c).  Build with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "quisk_oracle.h"
+
+#define QO_OUT_CAP (QO_SAMP_BUFFER_SIZE * 8 / 10)    /* filter.c:158,194,315 */
+
+void qo_fir_init(qo_fir *f, const double *taps, int ntaps, int is_complex)
+{
+    f->taps = taps;
+    f->ctaps = NULL;
+    f->ntaps = ntaps;
+    f->phase = 0;
+    f->pos = 0;
+    f->is_complex = is_complex;
+    f->hist = (double *)calloc((size_t)ntaps * (is_complex ? 2 : 1), sizeof(double));
+}
+
+void qo_fir_free(qo_fir *f)
+{
+    free(f->hist); free(f->ctaps);
+    f->hist = NULL; f->ctaps = NULL;
+}
+
+void qo_fir_tune(qo_fir *f, double freq, int ssb_upper)
+{
+    int i;
+    double D, w;
+    if (!f->ctaps) f->ctaps = (double *)malloc((size_t)f->ntaps * 2 * sizeof(double));
+    w = 2.0 * M_PI * freq;                          /* tune = I * 2.0 * M_PI * freq */
+    D = (f->ntaps - 1.0) / 2.0;
+    for (i = 0; i < f->ntaps; i++) {
+        double a = w * (i - D);
+        double re = cos(a) * f->taps[i];
+        double im = sin(a) * f->taps[i];
+        if (ssb_upper) { f->ctaps[2 * i] = re; f->ctaps[2 * i + 1] = im; }
+        else           { f->ctaps[2 * i] = im; f->ctaps[2 * i + 1] = re; }
+    }
+}
+
+/* one complex output: sum_k h[k0 + k*kstep] * hist[pos - k], nk terms */
+static inline void cmac_real(const qo_fir *f, int k0, int kstep, int nk, double *re, double *im)
+{
+    int k, idx = f->pos;
+    double ar = 0.0, ai = 0.0;
+    const double *h = f->taps + k0;
+    for (k = 0; k < nk; k++, h += kstep) {
+        ar += f->hist[2 * idx] * *h;
+        ai += f->hist[2 * idx + 1] * *h;
+        if (--idx < 0) idx = f->ntaps - 1;
+    }
+    *re = ar; *im = ai;
+}
+
+static inline double dmac_real(const qo_fir *f, int k0, int kstep, int nk)
+{
+    int k, idx = f->pos;
+    double a = 0.0;
+    const double *h = f->taps + k0;
+    for (k = 0; k < nk; k++, h += kstep) {
+        a += f->hist[idx] * *h;
+        if (--idx < 0) idx = f->ntaps - 1;
+    }
+    return a;
+}
+
+static inline void advance(qo_fir *f) { if (++f->pos >= f->ntaps) f->pos = 0; }
+
+int qo_cDecimate(double *x, int count, qo_fir *f, int decim)
+{
+    int i, nout = 0;
+    for (i = 0; i < count; i++) {
+        f->hist[2 * f->pos] = x[2 * i];
+        f->hist[2 * f->pos + 1] = x[2 * i + 1];
+        if (++f->phase >= decim) {
+            double re, im;
+            f->phase = 0;
+            cmac_real(f, 0, 1, f->ntaps, &re, &im);
+            x[2 * nout] = re; x[2 * nout + 1] = im;
+            nout++;
+        }
+        advance(f);
+    }
+    return nout;
+}
+
+int qo_cCDecimate(double *x, int count, qo_fir *f, int decim)
+{
+    int i, k, nout = 0;
+    for (i = 0; i < count; i++) {
+        f->hist[2 * f->pos] = x[2 * i];
+        f->hist[2 * f->pos + 1] = x[2 * i + 1];
+        if (++f->phase >= decim) {
+            int idx = f->pos;
+            double ar = 0.0, ai = 0.0;
+            f->phase = 0;
+            for (k = 0; k < f->ntaps; k++) {
+                double xr = f->hist[2 * idx], xi = f->hist[2 * idx + 1];
+                double cr = f->ctaps[2 * k], ci = f->ctaps[2 * k + 1];
+                ar += xr * cr - xi * ci;
+                ai += xr * ci + xi * cr;
+                if (--idx < 0) idx = f->ntaps - 1;
+            }
+            x[2 * nout] = ar; x[2 * nout + 1] = ai;
+            nout++;
+        }
+        advance(f);
+    }
+    return nout;
+}
+
+int qo_dDecimate(double *x, int count, qo_fir *f, int decim)
+{
+    int i, nout = 0;
+    for (i = 0; i < count; i++) {
+        f->hist[f->pos] = x[i];
+        if (++f->phase >= decim) {
+            f->phase = 0;
+            x[nout++] = dmac_real(f, 0, 1, f->ntaps);
+        }
+        advance(f);
+    }
+    return nout;
+}
+
+int qo_cInterpolate(double *x, int count, qo_fir *f, int interp)
+{
+    int i, j, nout = 0;
+    double *tmp = (double *)malloc((size_t)(count > 0 ? count : 1) * 2 * sizeof(double));
+    memcpy(tmp, x, (size_t)count * 2 * sizeof(double));
+    for (i = 0; i < count; i++) {
+        f->hist[2 * f->pos] = tmp[2 * i];
+        f->hist[2 * f->pos + 1] = tmp[2 * i + 1];
+        for (j = 0; j < interp; j++) {
+            double re, im;
+            cmac_real(f, j, interp, f->ntaps / interp, &re, &im);
+            if (nout < QO_OUT_CAP) {
+                x[2 * nout] = re * interp; x[2 * nout + 1] = im * interp;
+                nout++;
+            }
+        }
+        advance(f);
+    }
+    free(tmp);
+    return nout;
+}
+
+int qo_dInterpolate(double *x, int count, qo_fir *f, int interp)
+{
+    int i, j, nout = 0;
+    double *tmp = (double *)malloc((size_t)(count > 0 ? count : 1) * sizeof(double));
+    memcpy(tmp, x, (size_t)count * sizeof(double));
+    for (i = 0; i < count; i++) {
+        f->hist[f->pos] = tmp[i];
+        for (j = 0; j < interp; j++) {
+            double v = dmac_real(f, j, interp, f->ntaps / interp);
+            if (nout < QO_OUT_CAP) x[nout++] = v * interp;
+        }
+        advance(f);
+    }
+    free(tmp);
+    return nout;
+}
+
+int qo_cInterpDecim(double *x, int count, qo_fir *f, int interp, int decim)
+{
+    int i, nout = 0;
+    double *tmp = (double *)malloc((size_t)(count > 0 ? count : 1) * 2 * sizeof(double));
+    memcpy(tmp, x, (size_t)count * 2 * sizeof(double));
+    for (i = 0; i < count; i++) {
+        f->hist[2 * f->pos] = tmp[2 * i];
+        f->hist[2 * f->pos + 1] = tmp[2 * i + 1];
+        while (f->phase < interp) {
+            double re, im;
+            cmac_real(f, f->phase, interp, f->ntaps / interp, &re, &im);
+            if (nout < QO_OUT_CAP) {
+                x[2 * nout] = re * interp; x[2 * nout + 1] = im * interp;
+                nout++;
+            }
+            f->phase += decim;
+        }
+        advance(f);
+        f->phase -= interp;
+    }
+    free(tmp);
+    return nout;
+}
+
+int qo_dFilter(double *x, int count, qo_fir *f)
+{
+    int i;
+    for (i = 0; i < count; i++) {
+        f->hist[f->pos] = x[i];
+        x[i] = dmac_real(f, 0, 1, f->ntaps);
+        advance(f);
+    }
+    return count;
+}
+
+double qo_dD_out(double sample, qo_fir *f)
+{
+    double v;
+    f->hist[f->pos] = sample;
+    v = dmac_real(f, 0, 1, f->ntaps);
+    advance(f);
+    return v;
+}
+
+void qo_dC_out(double sample, qo_fir *f, double *out)
+{
+    int k, idx;
+    double ar = 0.0, ai = 0.0;
+    f->hist[f->pos] = sample;
+    idx = f->pos;
+    for (k = 0; k < f->ntaps; k++) {
+        ar += f->hist[idx] * f->ctaps[2 * k];
+        ai += f->hist[idx] * f->ctaps[2 * k + 1];
+        if (--idx < 0) idx = f->ntaps - 1;
+    }
+    advance(f);
+    out[0] = ar; out[1] = ai;
+}
+
+/* ---------------------------------------------------------------- half-band, 45 taps */
+/* Rate 96, cutoff 16-24-32, 120 dB; coef[0] and [44] of the full filter are zero. */
+const double qo_hb45_coef[12] = {
+    0.000018566625444266, -0.000118469698701817, 0.000457318798253456,
+    -0.001347840471412094, 0.003321838571445455, -0.007198422696929033,
+    0.014211106939802483, -0.026424776824073383, 0.048414810444971007,
+    -0.096214669073304823, 0.314881034738348550, 0.500000000000000000 };
+
+void qo_hb45_init(qo_hb45 *f) { memset(f, 0, sizeof(*f)); }
+
+int qo_cDecim2HB45(double *x, int count, qo_hb45 *f)
+{
+    int i, k, nout = 0;
+    for (i = 0; i < count; i++) {
+        if (f->toggle == 0) {
+            f->toggle = 1;
+            memmove(f->center + 2, f->center, sizeof(double) * 2 * 10);
+            f->center[0] = x[2 * i]; f->center[1] = x[2 * i + 1];
+        } else {
+            double ar, ai;
+            f->toggle = 0;
+            memmove(f->samples + 2, f->samples, sizeof(double) * 2 * 21);
+            f->samples[0] = x[2 * i]; f->samples[1] = x[2 * i + 1];
+            ar = (f->samples[0] + f->samples[2 * 21]) * qo_hb45_coef[0];
+            ai = (f->samples[1] + f->samples[2 * 21 + 1]) * qo_hb45_coef[0];
+            for (k = 1; k < 11; k++) {
+                ar += (f->samples[2 * k] + f->samples[2 * (21 - k)]) * qo_hb45_coef[k];
+                ai += (f->samples[2 * k + 1] + f->samples[2 * (21 - k) + 1]) * qo_hb45_coef[k];
+            }
+            ar += f->center[2 * 10] * qo_hb45_coef[11];
+            ai += f->center[2 * 10 + 1] * qo_hb45_coef[11];
+            x[2 * nout] = ar; x[2 * nout + 1] = ai;
+            nout++;
+        }
+    }
+    return nout;
+}
+
+int qo_cInterp2HB45(double *x, int count, qo_hb45 *f)
+{
+    int i, k, nout = 0;
+    const int ncoef = 12, nsamp = 22;
+    double *tmp = (double *)malloc((size_t)(count > 0 ? count : 1) * 2 * sizeof(double));
+    memcpy(tmp, x, (size_t)count * 2 * sizeof(double));
+    for (i = 0; i < count; i++) {
+        double ar = 0.0, ai = 0.0;
+        memmove(f->samples + 2, f->samples, (size_t)(nsamp - 1) * 2 * sizeof(double));
+        f->samples[0] = tmp[2 * i]; f->samples[1] = tmp[2 * i + 1];
+        if (nout > QO_OUT_CAP) continue;
+        x[2 * nout] = f->samples[2 * (ncoef - 1)] * qo_hb45_coef[ncoef - 1] * 2;
+        x[2 * nout + 1] = f->samples[2 * (ncoef - 1) + 1] * qo_hb45_coef[ncoef - 1] * 2;
+        nout++;
+        for (k = 0; k < nsamp / 2; k++) {
+            ar += (f->samples[2 * k] + f->samples[2 * (nsamp - 1 - k)]) * qo_hb45_coef[k];
+            ai += (f->samples[2 * k + 1] + f->samples[2 * (nsamp - 1 - k) + 1]) * qo_hb45_coef[k];
+        }
+        x[2 * nout] = ar * 2; x[2 * nout + 1] = ai * 2;
+        nout++;
+    }
+    free(tmp);
+    return nout;
+}
+
+int qo_dInterp2HB45(double *x, int count, qo_hb45 *f)
+{
+    /* real data: uses samples[0..21] as 22 doubles (struct quisk_dHB45Filter, filter.h:31-37) */
+    int i, k, nout = 0;
+    const int ncoef = 12, nsamp = 22;
+    double *tmp = (double *)malloc((size_t)(count > 0 ? count : 1) * sizeof(double));
+    memcpy(tmp, x, (size_t)count * sizeof(double));
+    for (i = 0; i < count; i++) {
+        double a = 0.0;
+        memmove(f->samples + 1, f->samples, (size_t)(nsamp - 1) * sizeof(double));
+        f->samples[0] = tmp[i];
+        if (nout > QO_OUT_CAP) continue;
+        x[nout++] = f->samples[ncoef - 1] * qo_hb45_coef[ncoef - 1] * 2;
+        for (k = 0; k < nsamp / 2; k++)
+            a += (f->samples[k] + f->samples[nsamp - 1 - k]) * qo_hb45_coef[k];
+        x[nout++] = a * 2;
+    }
+    free(tmp);
+    return nout;
+}

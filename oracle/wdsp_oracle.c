@@ -1,0 +1,1125 @@
+/* wdsp_oracle.c -- TEST INFRASTRUCTURE ONLY.  See wdsp_oracle.h for scope and the
+ * "parity unpinned" statement.  Every block cites the reference lines it restates
+ * (paths relative to /root/reference).  State that the reference keeps in per-channel
+ * globals (rxa[], ch[]) lives in one heap struct so that many channels can run
+ * side by side and on several host threads.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fft_oracle.h"
+#include "wdsp_oracle.h"
+
+#define WO_PI    3.1415926535897932   /* wdsp/comm.h:146 */
+#define WO_TWOPI 6.2831853071795864   /* wdsp/comm.h:147 */
+#define WO_DSP_MULT 2                 /* wdsp/comm.h:118 */
+
+static void *zalloc(size_t n) { void *p = calloc(1, n ? n : 1); return p; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------ fir_bandpass */
+/* wdsp/fir.c:187-254.  rtype 0: N real taps; rtype 1: N complex taps (re, -im*sin). */
+double *wo_fir_bandpass(int N, double f_low, double f_high, double samplerate, int wintype, int rtype, double scale)
+{
+    double *c_impulse = (double *)zalloc((size_t)N * 2 * sizeof(double));
+    double ft = (f_high - f_low) / (2.0 * samplerate);
+    double ft_rad = WO_TWOPI * ft;
+    double w_osc = WO_PI * (f_high + f_low) / samplerate;
+    int i, j;
+    double m = 0.5 * (double)(N - 1);
+    double delta = WO_PI / m;
+    double cosphi, posi, posj, sinc, window = 0.0, coef;
+
+    if (N & 1) {
+        switch (rtype) {
+        case 0: c_impulse[N >> 1] = scale * 2.0 * ft; break;
+        case 1: c_impulse[N - 1] = scale * 2.0 * ft; c_impulse[N] = 0.0; break;
+        }
+    }
+    for (i = (N + 1) / 2, j = N / 2 - 1; i < N; i++, j--) {
+        posi = (double)i - m;
+        posj = (double)j - m;
+        sinc = sin(ft_rad * posi) / (WO_PI * posi);
+        cosphi = cos(delta * i);
+        switch (wintype) {
+        case 0: /* Blackman-Harris 4-term, fir.c:220-225 */
+            window = +0.21747 + cosphi * (-0.45325 + cosphi * (+0.28256 + cosphi * (-0.04672)));
+            break;
+        case 1: /* Blackman-Harris 7-term, fir.c:227-236 */
+            window = +6.3964424114390378e-02
+                   + cosphi * (-2.3993864599352804e-01
+                   + cosphi * (+3.5015956323820469e-01
+                   + cosphi * (-2.4774111897080783e-01
+                   + cosphi * (+8.5438256055858031e-02
+                   + cosphi * (-1.2320203369293225e-02
+                   + cosphi * (+4.3778825791773474e-04))))));
+            break;
+        }
+        coef = scale * sinc * window;
+        switch (rtype) {
+        case 0:
+            c_impulse[i] = +coef * cos(posi * w_osc);
+            c_impulse[j] = +coef * cos(posj * w_osc);
+            break;
+        case 1:
+            c_impulse[2 * i + 0] = +coef * cos(posi * w_osc);
+            c_impulse[2 * i + 1] = -coef * sin(posi * w_osc);
+            c_impulse[2 * j + 0] = +coef * cos(posj * w_osc);
+            c_impulse[2 * j + 1] = -coef * sin(posj * w_osc);
+            break;
+        }
+    }
+    return c_impulse;
+}
+
+/* get_fsamp_window(), wdsp/fir.c:44-81 */
+static double *wo_fsamp_window(int N, int wintype)
+{
+    int i;
+    double arg0, arg1;
+    double *window = (double *)zalloc((size_t)N * sizeof(double));
+    switch (wintype) {
+    case 0:
+        arg0 = 2.0 * WO_PI / ((double)N - 1.0);
+        for (i = 0; i < N; i++) {
+            arg1 = cos(arg0 * (double)i);
+            window[i] = +0.21747 + arg1 * (-0.45325 + arg1 * (+0.28256 + arg1 * (-0.04672)));
+        }
+        break;
+    case 1:
+        arg0 = 2.0 * WO_PI / ((double)N - 1.0);
+        for (i = 0; i < N; ++i) {
+            arg1 = cos(arg0 * (double)i);
+            window[i] = +6.3964424114390378e-02
+                      + arg1 * (-2.3993864599352804e-01
+                      + arg1 * (+3.5015956323820469e-01
+                      + arg1 * (-2.4774111897080783e-01
+                      + arg1 * (+8.5438256055858031e-02
+                      + arg1 * (-1.2320203369293225e-02
+                      + arg1 * (+4.3778825791773474e-04))))));
+        }
+        break;
+    default:
+        for (i = 0; i < N; i++) window[i] = 1.0;
+    }
+    return window;
+}
+
+/* fir_fsamp(), wdsp/fir.c:129-185 (frequency-sampling design, rtype 1 only is used on this path) */
+static double *wo_fir_fsamp(int N, const double *A, int rtype, double scale, int wintype)
+{
+    int n, i, j, k;
+    double sum;
+    double *window;
+    double *c_impulse = (double *)zalloc((size_t)N * 2 * sizeof(double));
+    if (N & 1) {
+        int M = (N - 1) / 2;
+        for (n = 0; n < M + 1; n++) {
+            sum = 0.0;
+            for (k = 1; k < M + 1; k++)
+                sum += 2.0 * A[k] * cos(WO_TWOPI * (n - M) * k / N);
+            c_impulse[2 * n + 0] = (1.0 / N) * (A[0] + sum);
+            c_impulse[2 * n + 1] = 0.0;
+        }
+        for (n = M + 1, j = 1; n < N; n++, j++) {
+            c_impulse[2 * n + 0] = c_impulse[2 * (M - j) + 0];
+            c_impulse[2 * n + 1] = 0.0;
+        }
+    } else {
+        double M = (double)(N - 1) / 2.0;
+        for (n = 0; n < N / 2; n++) {
+            sum = 0.0;
+            for (k = 1; k < N / 2; k++)
+                sum += 2.0 * A[k] * cos(WO_TWOPI * (n - M) * k / N);
+            c_impulse[2 * n + 0] = (1.0 / N) * (A[0] + sum);
+            c_impulse[2 * n + 1] = 0.0;
+        }
+        for (n = N / 2, j = 1; n < N; n++, j++) {
+            c_impulse[2 * n + 0] = c_impulse[2 * (N / 2 - j) + 0];
+            c_impulse[2 * n + 1] = 0.0;
+        }
+    }
+    window = wo_fsamp_window(N, wintype);
+    switch (rtype) {
+    case 0:
+        for (i = 0; i < N; i++) c_impulse[i] = scale * c_impulse[2 * i] * window[i];
+        break;
+    case 1:
+        for (i = 0; i < N; i++) {
+            c_impulse[2 * i + 0] *= scale * window[i];
+            c_impulse[2 * i + 1] = 0.0;
+        }
+        break;
+    }
+    free(window);
+    return c_impulse;
+}
+
+/* fc_impulse(), wdsp/fcurve.c:29-145.  Only the even-nc branch reaches fir_fsamp();
+ * odd nc would need fir_fsamp_odd() (an N-point, N odd, backward FFT: fir.c:83-127),
+ * which RXA never requests (nc is a power of two, RXA.c:209,211). */
+static double *wo_fc_impulse(int nc, double f0, double f1, double g0, double g1, int curve,
+                             double samplerate, double scale, int ctfmode, int wintype)
+{
+    double *A = (double *)zalloc((size_t)(nc / 2 + 1) * sizeof(double));
+    int i;
+    double fn, f;
+    double *impulse;
+    int mid = nc / 2;
+    double g0_lin = pow(10.0, g0 / 20.0);
+    (void)g1;
+    if (nc & 1) { free(A); return NULL; }
+    for (i = 0; i < mid; i++) {
+        fn = ((double)i + 0.5) / (double)mid;
+        f = fn * samplerate / 2.0;
+        switch (curve) {
+        case 0: A[i] = (f0 > 0.0) ? scale * (g0_lin * f / f0) : 0.0; break;
+        case 1: A[i] = (f > 0.0) ? scale * (g0_lin * f0 / f) : 0.0; break;
+        }
+    }
+    if (ctfmode == 0) {
+        int k, low, high;
+        double lowmag, highmag, flow4, fhigh4;
+        low = (int)(2.0 * f0 / samplerate * mid - 0.5);
+        high = (int)(2.0 * f1 / samplerate * mid - 0.5);
+        lowmag = A[low];
+        highmag = A[high];
+        flow4 = pow((double)low / (double)mid, 4.0);
+        fhigh4 = pow((double)high / (double)mid, 4.0);
+        k = low;
+        while (--k >= 0) {
+            f = (double)k / (double)mid;
+            lowmag *= (f * f * f * f) / flow4;
+            if (lowmag < 1.0e-100) lowmag = 1.0e-100;
+            A[k] = lowmag;
+        }
+        k = high;
+        while (++k < mid) {
+            f = (double)k / (double)mid;
+            highmag *= fhigh4 / (f * f * f * f);
+            if (highmag < 1.0e-100) highmag = 1.0e-100;
+            A[k] = highmag;
+        }
+    }
+    impulse = wo_fir_fsamp(nc, A, 1, 1.0, wintype);
+    free(A);
+    return impulse;
+}
+
+/* ------------------------------------------------------------------ fircore */
+/* wdsp/firmin.h:138-161, firmin.c:290-430 (mp = 0 only; min-phase is out of scope) */
+struct wo_fircore {
+    int size, nc, nfor, buffidx, idxmask;
+    double *imp;      /* nc complex */
+    double *fftin;    /* 2*size complex */
+    double **fftout;  /* nfor x 2*size complex */
+    double **fmask;   /* nfor x 2*size complex (single mask set: setters here run between blocks) */
+    double *accum;    /* 2*size complex */
+    double *maskgen;
+};
+
+static void fircore_plan(wo_fircore *a)        /* plan_fircore, firmin.c:290-320 */
+{
+    int i;
+    a->nfor = a->nc / a->size;
+    a->buffidx = 0;
+    a->idxmask = a->nfor - 1;
+    a->fftin = (double *)zalloc((size_t)2 * a->size * 2 * sizeof(double));
+    a->fftout = (double **)zalloc((size_t)a->nfor * sizeof(double *));
+    a->fmask = (double **)zalloc((size_t)a->nfor * sizeof(double *));
+    a->maskgen = (double *)zalloc((size_t)2 * a->size * 2 * sizeof(double));
+    for (i = 0; i < a->nfor; i++) {
+        a->fftout[i] = (double *)zalloc((size_t)2 * a->size * 2 * sizeof(double));
+        a->fmask[i] = (double *)zalloc((size_t)2 * a->size * 2 * sizeof(double));
+    }
+    a->accum = (double *)zalloc((size_t)2 * a->size * 2 * sizeof(double));
+}
+
+static void fircore_deplan(wo_fircore *a)      /* deplan_fircore, firmin.c:364-388 */
+{
+    int i;
+    for (i = 0; i < a->nfor; i++) { free(a->fftout[i]); free(a->fmask[i]); }
+    free(a->fftout); free(a->fmask); free(a->fftin); free(a->maskgen); free(a->accum);
+}
+
+static void fircore_calc(wo_fircore *a)        /* calc_fircore, firmin.c:322-346 */
+{
+    int i;
+    for (i = 0; i < a->nfor; i++) {
+        /* impulse partition right-justified in the 2*size buffer (firmin.c:335) */
+        memset(a->maskgen, 0, (size_t)2 * a->size * 2 * sizeof(double));
+        memcpy(&a->maskgen[2 * a->size], &a->imp[2 * a->size * i], (size_t)a->size * 2 * sizeof(double));
+        fo_fft_oop(a->maskgen, a->fmask[i], 2 * a->size, -1);
+    }
+}
+
+wo_fircore *wo_fircore_create(int size, int nc, const double *impulse)  /* create_fircore, firmin.c:348-362 */
+{
+    wo_fircore *a = (wo_fircore *)zalloc(sizeof(*a));
+    a->size = size;
+    a->nc = nc;
+    fircore_plan(a);
+    a->imp = (double *)zalloc((size_t)nc * 2 * sizeof(double));
+    memcpy(a->imp, impulse, (size_t)nc * 2 * sizeof(double));
+    fircore_calc(a);
+    return a;
+}
+
+void wo_fircore_destroy(wo_fircore *a)
+{
+    if (!a) return;
+    fircore_deplan(a);
+    free(a->imp);
+    free(a);
+}
+
+static void fircore_flush(wo_fircore *a)        /* flush_fircore, firmin.c:399-407 */
+{
+    int i;
+    memset(a->fftin, 0, (size_t)2 * a->size * 2 * sizeof(double));
+    for (i = 0; i < a->nfor; i++) memset(a->fftout[i], 0, (size_t)2 * a->size * 2 * sizeof(double));
+    a->buffidx = 0;
+}
+
+static void fircore_set_impulse(wo_fircore *a, const double *impulse)  /* setImpulse_fircore, firmin.c:448-452 */
+{
+    memcpy(a->imp, impulse, (size_t)a->nc * 2 * sizeof(double));
+    fircore_calc(a);
+}
+
+static void fircore_set_nc(wo_fircore *a, int nc, const double *impulse) /* setNc_fircore, firmin.c:454-466 */
+{
+    fircore_deplan(a);
+    free(a->imp);
+    a->nc = nc;
+    fircore_plan(a);
+    a->imp = (double *)zalloc((size_t)nc * 2 * sizeof(double));
+    memcpy(a->imp, impulse, (size_t)nc * 2 * sizeof(double));
+    fircore_calc(a);
+}
+
+void wo_fircore_exec(wo_fircore *a, const double *in, double *out)   /* xfircore, firmin.c:409-430 */
+{
+    int i, j, k;
+    int n2 = 2 * a->size;
+    memcpy(&a->fftin[2 * a->size], in, (size_t)a->size * 2 * sizeof(double));
+    fo_fft_oop(a->fftin, a->fftout[a->buffidx], n2, -1);
+    k = a->buffidx;
+    memset(a->accum, 0, (size_t)n2 * 2 * sizeof(double));
+    for (j = 0; j < a->nfor; j++) {
+        const double *fo = a->fftout[k];
+        const double *fm = a->fmask[j];
+        for (i = 0; i < n2; i++) {
+            a->accum[2 * i + 0] += fo[2 * i + 0] * fm[2 * i + 0] - fo[2 * i + 1] * fm[2 * i + 1];
+            a->accum[2 * i + 1] += fo[2 * i + 0] * fm[2 * i + 1] + fo[2 * i + 1] * fm[2 * i + 0];
+        }
+        k = (k + a->idxmask) & a->idxmask;
+    }
+    a->buffidx = (a->buffidx + 1) & a->idxmask;
+    fo_fft(a->accum, n2, +1);                       /* crev: backward, unnormalised */
+    memcpy(out, a->accum, (size_t)a->size * 2 * sizeof(double));   /* left half is the result */
+    memcpy(a->fftin, &a->fftin[2 * a->size], (size_t)a->size * 2 * sizeof(double));
+}
+
+/* ------------------------------------------------------------------ resample */
+/* wdsp/resample.h, resample.c:35-157 */
+struct wo_resample {
+    int run, in_rate, out_rate, L, M, ncoef, cpp, ringsize, idx_in, phnum;
+    double *h, *ring;
+};
+
+double *wo_calc_resample_taps(int in_rate, int out_rate, double fc, int ncoef_in, double gain,
+                              int *pL, int *pM, int *pncoef, int *pcpp)   /* calc_resample, resample.c:35-72 */
+{
+    int x, y, z, i, j, k, min_rate, L, M, ncoef, cpp;
+    double full_rate, fc_norm_high, fc_norm_low;
+    double *impulse, *h;
+    x = in_rate; y = out_rate;
+    while (y != 0) { z = y; y = x % y; x = z; }
+    L = out_rate / x;
+    M = in_rate / x;
+    min_rate = (in_rate < out_rate) ? in_rate : out_rate;
+    if (fc == 0.0) fc = 0.45 * (double)min_rate;
+    full_rate = (double)(in_rate * L);
+    fc_norm_high = fc / full_rate;
+    fc_norm_low = -fc_norm_high;                    /* fc_low = -1.0 < 0, resample.c:55-56,97 */
+    ncoef = ncoef_in;
+    if (ncoef == 0) ncoef = (int)(140.0 * full_rate / min_rate);
+    ncoef = (ncoef / L + 1) * L;
+    cpp = ncoef / L;
+    h = (double *)zalloc((size_t)ncoef * sizeof(double));
+    impulse = wo_fir_bandpass(ncoef, fc_norm_low, fc_norm_high, 1.0, 1, 0, gain * (double)L);
+    i = 0;
+    for (j = 0; j < L; j++)
+        for (k = 0; k < ncoef; k += L)
+            h[i++] = impulse[j + k];
+    free(impulse);
+    *pL = L; *pM = M; *pncoef = ncoef; *pcpp = cpp;
+    return h;
+}
+
+wo_resample *wo_resample_create(int in_rate, int out_rate, double fc, int ncoef, double gain)
+{
+    wo_resample *a = (wo_resample *)zalloc(sizeof(*a));
+    a->run = 1;
+    a->in_rate = in_rate;
+    a->out_rate = out_rate;
+    a->h = wo_calc_resample_taps(in_rate, out_rate, fc, ncoef, gain, &a->L, &a->M, &a->ncoef, &a->cpp);
+    a->ringsize = a->cpp;
+    a->ring = (double *)zalloc((size_t)a->ringsize * 2 * sizeof(double));
+    a->idx_in = a->ringsize - 1;
+    a->phnum = 0;
+    return a;
+}
+
+void wo_resample_destroy(wo_resample *a)
+{
+    if (!a) return;
+    free(a->h); free(a->ring); free(a);
+}
+
+int wo_resample_exec(wo_resample *a, const double *in, int size, double *out)   /* xresample, resample.c:120-157 */
+{
+    int outsamps = 0;
+    int i, j, n, idx_out;
+    double I, Q;
+    for (i = 0; i < size; i++) {
+        a->ring[2 * a->idx_in + 0] = in[2 * i + 0];
+        a->ring[2 * a->idx_in + 1] = in[2 * i + 1];
+        while (a->phnum < a->L) {
+            I = 0.0; Q = 0.0;
+            n = a->cpp * a->phnum;
+            for (j = 0; j < a->cpp; j++) {
+                if ((idx_out = a->idx_in + j) >= a->ringsize) idx_out -= a->ringsize;
+                I += a->h[n + j] * a->ring[2 * idx_out + 0];
+                Q += a->h[n + j] * a->ring[2 * idx_out + 1];
+            }
+            out[2 * outsamps + 0] = I;
+            out[2 * outsamps + 1] = Q;
+            outsamps++;
+            a->phnum += a->M;
+        }
+        a->phnum -= a->L;
+        if (--a->idx_in < 0) a->idx_in = a->ringsize - 1;
+    }
+    return outsamps;
+}
+
+/* ------------------------------------------------------------------ meter */
+typedef struct {           /* wdsp/meter.c:29-108 */
+    double rate, mult_average, mult_peak, avg, peak;
+    int enum_av, enum_pk, enum_gain;
+} wo_meter;
+
+static void meter_init(wo_meter *m, int rate, double tau_av, double tau_decay, int eav, int epk, int egain, double *result)
+{
+    m->rate = (double)rate;
+    m->mult_average = exp(-1.0 / (m->rate * tau_av));
+    m->mult_peak = exp(-1.0 / (m->rate * tau_decay));
+    m->avg = 0.0; m->peak = 0.0;
+    m->enum_av = eav; m->enum_pk = epk; m->enum_gain = egain;
+    result[eav] = -400.0; result[epk] = -400.0;
+    if (egain >= 0) result[egain] = -400.0;
+}
+
+static void meter_exec(wo_meter *m, const double *buff, int size, double *result, const double *pgain)
+{
+    int i;
+    double smag, np = 0.0;
+    for (i = 0; i < size; i++) {
+        smag = buff[2 * i + 0] * buff[2 * i + 0] + buff[2 * i + 1] * buff[2 * i + 1];
+        m->avg = m->avg * m->mult_average + (1.0 - m->mult_average) * smag;
+        m->peak *= m->mult_peak;
+        if (smag > np) np = smag;
+    }
+    if (np > m->peak) m->peak = np;
+    /* mlog10 (wdsp/meterlog10.c:547) is a table-interpolated log10; plain log10 is used here,
+       so meter values agree with the reference only to the table's interpolation error. */
+    result[m->enum_av] = 10.0 * log10(m->avg + 1.0e-40);
+    result[m->enum_pk] = 10.0 * log10(m->peak + 1.0e-40);
+    if (pgain && m->enum_gain >= 0) result[m->enum_gain] = 20.0 * log10(*pgain + 1.0e-40);
+}
+
+/* meter indices, wdsp/RXA.h:47-57 */
+enum { WO_S_PK = 0, WO_S_AV, WO_ADC_PK, WO_ADC_AV, WO_AGC_GAIN, WO_AGC_PK, WO_AGC_AV, WO_METERTYPE_LAST };
+
+/* ------------------------------------------------------------------ channel */
+#define AMD_STAGES 7
+#define AMD_OUT_IDX (3 * AMD_STAGES)
+
+struct wo_channel {
+    /* ch[] fields, wdsp/channel.h */
+    int in_size, dsp_size, in_rate, dsp_rate, out_rate;
+    int dsp_insize, dsp_outsize, out_size;
+    double tdelayup, tslewup, tdelaydown, tslewdown;
+    int mode;
+    double *inbuff, *midbuff, *outbuff;
+    double meter[WO_METERTYPE_LAST];
+    /* shift, wdsp/shift.h */
+    struct { int run; double rate, shift, phase, delta, cos_delta, sin_delta; } shift;
+    wo_resample *rsmpin, *rsmpout;
+    wo_meter adcmeter, smeter, agcmeter;
+    /* nbp0 (notches never run on this path: ndb master_run = 0, RXA.c:84-87) */
+    struct { int run, nc, wintype; double flow, fhigh, gain, rate; wo_fircore *p; } nbp0;
+    /* amd, wdsp/amd.h */
+    struct {
+        int run, mode, levelfade, sbmode;
+        double sample_rate, omega_min, omega_max, g1, g2, phs, fil_out, omega;
+        double dc, dc_insert, mtauR, onem_mtauR, mtauI, onem_mtauI;
+        double a[3 * AMD_STAGES + 3], b[3 * AMD_STAGES + 3], c[3 * AMD_STAGES + 3], d[3 * AMD_STAGES + 3];
+        double c0[AMD_STAGES], c1[AMD_STAGES], dsI, dsQ;
+    } amd;
+    /* fmd, wdsp/fmd.h */
+    struct {
+        int run, nc_de, nc_aud, sntch_run;
+        double rate, deviation, f_low, f_high, fmin, fmax, zeta, omegaN, tau, afgain, ctcss_freq;
+        double omega_min, omega_max, g1, g2, phs, fil_out, omega, mtau, onem_mtau, fmdc, again;
+        double *audio;
+        wo_fircore *pde, *paud;
+        /* snotch, wdsp/iir.c:35-95 */
+        double a0, a1, a2, b1, b2, x1, x2, y1, y2;
+    } fmd;
+    struct { int run, mode; double fixed_gain, gain; } agc;
+    struct { int run, nc, wintype; double f_low, f_high, gain; wo_fircore *p; } bp1;
+    struct { int run, inselect, copy; double gain1, gain2I, gain2Q; } panel;
+    /* iobuffs, wdsp/iobuffs.h */
+    struct {
+        int r1_outsize, r1_size, r2_insize, r2_size, r1_active, r2_active;
+        double *r1, *r2;
+        int r1_inidx, r1_outidx, r1_unqueued, r2_inidx, r2_outidx, r2_havesamps, r2_unqueued;
+        int sem_buffready, sem_outready;
+        int ustate, ucount, ndelup, ntup, upflag;
+        double *cup;
+    } iob;
+};
+
+int wo_dsp_insize(const wo_channel *c) { return c->dsp_insize; }
+int wo_dsp_outsize(const wo_channel *c) { return c->dsp_outsize; }
+int wo_out_size(const wo_channel *c) { return c->out_size; }
+
+/* ---- shift (wdsp/shift.c:29-85) */
+static void calc_shift(wo_channel *c)
+{
+    c->shift.delta = WO_TWOPI * c->shift.shift / c->shift.rate;
+    c->shift.cos_delta = cos(c->shift.delta);
+    c->shift.sin_delta = sin(c->shift.delta);
+}
+
+static void xshift(wo_channel *c, double *buf, int size)
+{
+    if (c->shift.run) {
+        int i;
+        double I1, Q1, t1, t2;
+        double cos_phase = cos(c->shift.phase);
+        double sin_phase = sin(c->shift.phase);
+        for (i = 0; i < size; i++) {
+            I1 = buf[2 * i + 0];
+            Q1 = buf[2 * i + 1];
+            buf[2 * i + 0] = I1 * cos_phase - Q1 * sin_phase;
+            buf[2 * i + 1] = I1 * sin_phase + Q1 * cos_phase;
+            t1 = cos_phase; t2 = sin_phase;
+            cos_phase = t1 * c->shift.cos_delta - t2 * c->shift.sin_delta;
+            sin_phase = t1 * c->shift.sin_delta + t2 * c->shift.cos_delta;
+            c->shift.phase += c->shift.delta;
+            if (c->shift.phase >= WO_TWOPI) c->shift.phase -= WO_TWOPI;
+            if (c->shift.phase < 0.0) c->shift.phase += WO_TWOPI;
+        }
+    }
+}
+
+/* ---- nbp0 impulse without notches (calc_nbp_impulse else-branch, wdsp/nbp.c:234-238) */
+static double *nbp0_impulse(wo_channel *c)
+{
+    return wo_fir_bandpass(c->nbp0.nc, c->nbp0.flow, c->nbp0.fhigh, c->nbp0.rate, c->nbp0.wintype, 1,
+                           c->nbp0.gain / (double)(2 * c->dsp_size));
+}
+
+static double *bp1_impulse(wo_channel *c)      /* bandpass.c:302 */
+{
+    return wo_fir_bandpass(c->bp1.nc, c->bp1.f_low, c->bp1.f_high, (double)c->dsp_rate, c->bp1.wintype, 1,
+                           c->bp1.gain / (double)(2 * c->dsp_size));
+}
+
+/* ---- amd (wdsp/amd.c:72-239) */
+static void init_amd(wo_channel *c)
+{
+    static const double c0[AMD_STAGES] = { -0.328201924180698, -0.744171491539427, -0.923022915444215,
+        -0.978490468768238, -0.994128272402075, -0.998458978159551, -0.999790306259206 };
+    static const double c1[AMD_STAGES] = { -0.0991227952747244, -0.565619728761389, -0.857467122550052,
+        -0.959123933111275, -0.988739372718090, -0.996959189310611, -0.999282492800792 };
+    double fs = c->amd.sample_rate;
+    double fmin = -2000.0, fmax = +2000.0, zeta = 1.0, omegaN = 250.0, tauR = 0.02, tauI = 1.4;  /* RXA.c:183-189 */
+    c->amd.omega_min = WO_TWOPI * fmin / fs;
+    c->amd.omega_max = WO_TWOPI * fmax / fs;
+    c->amd.g1 = 1.0 - exp(-2.0 * omegaN * zeta / fs);
+    c->amd.g2 = -c->amd.g1 + 2.0 * (1 - exp(-omegaN * zeta / fs) * cos(omegaN / fs * sqrt(1.0 - zeta * zeta)));
+    c->amd.phs = 0.0; c->amd.fil_out = 0.0; c->amd.omega = 0.0;
+    c->amd.dc = 0.0; c->amd.dc_insert = 0.0;
+    c->amd.mtauR = exp(-1.0 / (fs * tauR));
+    c->amd.onem_mtauR = 1.0 - c->amd.mtauR;
+    c->amd.mtauI = exp(-1.0 / (fs * tauI));
+    c->amd.onem_mtauI = 1.0 - c->amd.mtauI;
+    memcpy(c->amd.c0, c0, sizeof(c0));
+    memcpy(c->amd.c1, c1, sizeof(c1));
+}
+
+static void xamd(wo_channel *c, double *buf, int size)
+{
+    int i, j, k;
+    double audio, vco[2], corr[2], det, del_out;
+    double ai, bi, aq, bq;
+    double ai_ps = 0, bi_ps = 0, aq_ps = 0, bq_ps = 0;
+    if (!c->amd.run) return;
+    switch (c->amd.mode) {
+    case 0:     /* AM, amd.c:131-146 */
+        for (i = 0; i < size; i++) {
+            audio = sqrt(buf[2 * i + 0] * buf[2 * i + 0] + buf[2 * i + 1] * buf[2 * i + 1]);
+            if (c->amd.levelfade) {
+                c->amd.dc = c->amd.mtauR * c->amd.dc + c->amd.onem_mtauR * audio;
+                c->amd.dc_insert = c->amd.mtauI * c->amd.dc_insert + c->amd.onem_mtauI * audio;
+                audio += c->amd.dc_insert - c->amd.dc;
+            }
+            buf[2 * i + 0] = audio;
+            buf[2 * i + 1] = audio;
+        }
+        break;
+    case 1:     /* SAM, amd.c:148-232 */
+        for (i = 0; i < size; i++) {
+            vco[0] = cos(c->amd.phs);
+            vco[1] = sin(c->amd.phs);
+            ai = buf[2 * i + 0] * vco[0];
+            bi = buf[2 * i + 0] * vco[1];
+            aq = buf[2 * i + 1] * vco[0];
+            bq = buf[2 * i + 1] * vco[1];
+            if (c->amd.sbmode != 0) {
+                double *a = c->amd.a, *b = c->amd.b, *cc = c->amd.c, *d = c->amd.d;
+                a[0] = c->amd.dsI; b[0] = bi; cc[0] = c->amd.dsQ; d[0] = aq;
+                c->amd.dsI = ai; c->amd.dsQ = bq;
+                for (j = 0; j < AMD_STAGES; j++) {
+                    k = 3 * j;
+                    a[k + 3] = c->amd.c0[j] * (a[k] - a[k + 5]) + a[k + 2];
+                    b[k + 3] = c->amd.c1[j] * (b[k] - b[k + 5]) + b[k + 2];
+                    cc[k + 3] = c->amd.c0[j] * (cc[k] - cc[k + 5]) + cc[k + 2];
+                    d[k + 3] = c->amd.c1[j] * (d[k] - d[k + 5]) + d[k + 2];
+                }
+                ai_ps = a[AMD_OUT_IDX]; bi_ps = b[AMD_OUT_IDX]; bq_ps = cc[AMD_OUT_IDX]; aq_ps = d[AMD_OUT_IDX];
+                for (j = AMD_OUT_IDX + 2; j > 0; j--) {
+                    a[j] = a[j - 1]; b[j] = b[j - 1]; cc[j] = cc[j - 1]; d[j] = d[j - 1];
+                }
+            }
+            corr[0] = +ai + bq;
+            corr[1] = -bi + aq;
+            switch (c->amd.sbmode) {
+            default:
+            case 0: audio = corr[0]; break;
+            case 1: audio = (ai_ps - bi_ps) + (aq_ps + bq_ps); break;
+            case 2: audio = (ai_ps + bi_ps) - (aq_ps - bq_ps); break;
+            }
+            if (c->amd.levelfade) {
+                c->amd.dc = c->amd.mtauR * c->amd.dc + c->amd.onem_mtauR * audio;
+                c->amd.dc_insert = c->amd.mtauI * c->amd.dc_insert + c->amd.onem_mtauI * corr[0];
+                audio += c->amd.dc_insert - c->amd.dc;
+            }
+            buf[2 * i + 0] = audio;
+            buf[2 * i + 1] = audio;
+            if ((corr[0] == 0.0) && (corr[1] == 0.0)) corr[0] = 1.0;
+            det = atan2(corr[1], corr[0]);
+            del_out = c->amd.fil_out;
+            c->amd.omega += c->amd.g2 * det;
+            if (c->amd.omega < c->amd.omega_min) c->amd.omega = c->amd.omega_min;
+            if (c->amd.omega > c->amd.omega_max) c->amd.omega = c->amd.omega_max;
+            c->amd.fil_out = c->amd.g1 * det + c->amd.omega;
+            c->amd.phs += del_out;
+            while (c->amd.phs >= WO_TWOPI) c->amd.phs -= WO_TWOPI;
+            while (c->amd.phs < 0.0) c->amd.phs += WO_TWOPI;
+        }
+        break;
+    }
+}
+
+/* ---- fmd (wdsp/fmd.c:29-188) */
+static void calc_snotch(wo_channel *c)          /* iir.c:35-49 */
+{
+    double fn, qk, qr, csn, bw = 0.0002;       /* fmd.c:47 */
+    fn = c->fmd.ctcss_freq / (double)(int)c->fmd.rate;
+    csn = cos(WO_TWOPI * fn);
+    qr = 1.0 - 3.0 * bw;
+    qk = (1.0 - 2.0 * qr * csn + qr * qr) / (2.0 * (1.0 - csn));
+    c->fmd.a0 = +qk;
+    c->fmd.a1 = -2.0 * qk * csn;
+    c->fmd.a2 = +qk;
+    c->fmd.b1 = +2.0 * qr * csn;
+    c->fmd.b2 = -qr * qr;
+    c->fmd.x1 = c->fmd.x2 = c->fmd.y1 = c->fmd.y2 = 0.0;
+}
+
+static void calc_fmd(wo_channel *c)             /* fmd.c:29-47 */
+{
+    double zeta = c->fmd.zeta, omegaN = c->fmd.omegaN, rate = c->fmd.rate;
+    c->fmd.omega_min = WO_TWOPI * c->fmd.fmin / rate;
+    c->fmd.omega_max = WO_TWOPI * c->fmd.fmax / rate;
+    c->fmd.g1 = 1.0 - exp(-2.0 * omegaN * zeta / rate);
+    c->fmd.g2 = -c->fmd.g1 + 2.0 * (1 - exp(-omegaN * zeta / rate) * cos(omegaN / rate * sqrt(1.0 - zeta * zeta)));
+    c->fmd.phs = 0.0; c->fmd.fil_out = 0.0; c->fmd.omega = 0.0;
+    c->fmd.mtau = exp(-1.0 / (rate * c->fmd.tau));
+    c->fmd.onem_mtau = 1.0 - c->fmd.mtau;
+    c->fmd.fmdc = 0.0;
+    c->fmd.again = rate / (c->fmd.deviation * WO_TWOPI);
+    calc_snotch(c);
+}
+
+static double *fmd_de_impulse(wo_channel *c)    /* fmd.c:110 */
+{
+    return wo_fc_impulse(c->fmd.nc_de, c->fmd.f_low, c->fmd.f_high, +20.0 * log10(c->fmd.f_high / c->fmd.f_low),
+                         0.0, 1, c->fmd.rate, 1.0 / (2.0 * c->dsp_size), 0, 0);
+}
+
+static double *fmd_aud_impulse(wo_channel *c)   /* fmd.c:114 */
+{
+    return wo_fir_bandpass(c->fmd.nc_aud, 0.8 * c->fmd.f_low, 1.1 * c->fmd.f_high, c->fmd.rate, 0, 1,
+                           c->fmd.afgain / (2.0 * c->dsp_size));
+}
+
+static void xfmd(wo_channel *c, double *buf, int size)   /* fmd.c:144-188 (lim_run = 0) */
+{
+    int i;
+    double det, del_out, vco[2], corr[2], x0;
+    if (!c->fmd.run) return;
+    for (i = 0; i < size; i++) {
+        vco[0] = cos(c->fmd.phs);
+        vco[1] = sin(c->fmd.phs);
+        corr[0] = +buf[2 * i + 0] * vco[0] + buf[2 * i + 1] * vco[1];
+        corr[1] = -buf[2 * i + 0] * vco[1] + buf[2 * i + 1] * vco[0];
+        if ((corr[0] == 0.0) && (corr[1] == 0.0)) corr[0] = 1.0;
+        det = atan2(corr[1], corr[0]);
+        del_out = c->fmd.fil_out;
+        c->fmd.omega += c->fmd.g2 * det;
+        if (c->fmd.omega < c->fmd.omega_min) c->fmd.omega = c->fmd.omega_min;
+        if (c->fmd.omega > c->fmd.omega_max) c->fmd.omega = c->fmd.omega_max;
+        c->fmd.fil_out = c->fmd.g1 * det + c->fmd.omega;
+        c->fmd.phs += del_out;
+        while (c->fmd.phs >= WO_TWOPI) c->fmd.phs -= WO_TWOPI;
+        while (c->fmd.phs < 0.0) c->fmd.phs += WO_TWOPI;
+        c->fmd.fmdc = c->fmd.mtau * c->fmd.fmdc + c->fmd.onem_mtau * c->fmd.fil_out;
+        c->fmd.audio[2 * i + 0] = c->fmd.again * (c->fmd.fil_out - c->fmd.fmdc);
+        c->fmd.audio[2 * i + 1] = c->fmd.audio[2 * i + 0];
+    }
+    wo_fircore_exec(c->fmd.pde, c->fmd.audio, buf);   /* de-emphasis: audio -> out */
+    wo_fircore_exec(c->fmd.paud, buf, buf);           /* audio filter, in place */
+    if (c->fmd.sntch_run) {                           /* xsnotch, iir.c:76-95: filters the I part only */
+        for (i = 0; i < size; i++) {
+            x0 = buf[2 * i + 0];
+            buf[2 * i + 0] = c->fmd.a0 * x0 + c->fmd.a1 * c->fmd.x1 + c->fmd.a2 * c->fmd.x2
+                           + c->fmd.b1 * c->fmd.y1 + c->fmd.b2 * c->fmd.y2;
+            c->fmd.y2 = c->fmd.y1;
+            c->fmd.y1 = buf[2 * i + 0];
+            c->fmd.x2 = c->fmd.x1;
+            c->fmd.x1 = x0;
+        }
+    }
+}
+
+/* ---- agc mode 0 (wcpAGC.c:161-175); modes 1-5 are SURVEY section 8(f) "next" */
+static void xwcpagc(wo_channel *c, double *buf, int size)
+{
+    int i;
+    if (!c->agc.run) return;
+    if (c->agc.mode == 0) {
+        for (i = 0; i < size; i++) {
+            buf[2 * i + 0] = c->agc.fixed_gain * buf[2 * i + 0];
+            buf[2 * i + 1] = c->agc.fixed_gain * buf[2 * i + 1];
+        }
+    }
+}
+
+/* ---- panel (patchpanel.c:55-101): the run flag is not examined */
+static void xpanel(wo_channel *c, double *buf, int size)
+{
+    int i;
+    double I, Q;
+    double gainI = c->panel.gain1 * c->panel.gain2I;
+    double gainQ = c->panel.gain1 * c->panel.gain2Q;
+    switch (c->panel.copy) {
+    case 0:
+        for (i = 0; i < size; i++) {
+            I = buf[2 * i + 0] * (c->panel.inselect >> 1);
+            Q = buf[2 * i + 1] * (c->panel.inselect & 1);
+            buf[2 * i + 0] = gainI * I; buf[2 * i + 1] = gainQ * Q;
+        }
+        break;
+    case 1:
+        for (i = 0; i < size; i++) {
+            I = buf[2 * i + 0] * (c->panel.inselect >> 1);
+            Q = I;
+            buf[2 * i + 0] = gainI * I; buf[2 * i + 1] = gainQ * Q;
+        }
+        break;
+    case 2:
+        for (i = 0; i < size; i++) {
+            Q = buf[2 * i + 1] * (c->panel.inselect & 1);
+            I = Q;
+            buf[2 * i + 0] = gainI * I; buf[2 * i + 1] = gainQ * Q;
+        }
+        break;
+    case 3:
+        for (i = 0; i < size; i++) {
+            Q = buf[2 * i + 0] * (c->panel.inselect >> 1);
+            I = buf[2 * i + 1] * (c->panel.inselect & 1);
+            buf[2 * i + 0] = gainI * I; buf[2 * i + 1] = gainQ * Q;
+        }
+        break;
+    }
+}
+
+/* ---- RXAbp1Check / RXAbp1Set (RXA.c:800-827) */
+static void bp1_check(wo_channel *c, int amd_run)
+{
+    double gain = amd_run ? 2.0 : 1.0;          /* snba/emnr/anf/anr never run on this path */
+    if (c->bp1.gain != gain) {
+        double *imp;
+        c->bp1.gain = gain;
+        imp = bp1_impulse(c);
+        fircore_set_impulse(c->bp1.p, imp);
+        free(imp);
+    }
+}
+
+static void bp1_set(wo_channel *c)
+{
+    int old = c->bp1.run;
+    c->bp1.run = (c->amd.run == 1) ? 1 : 0;
+    if (!old && c->bp1.run) fircore_flush(c->bp1.p);
+}
+
+/* ---- xrxa (RXA.c:561-598); blocks that are run=0 on this path are omitted */
+static void xrxa(wo_channel *c)
+{
+    int n = c->dsp_size;
+    xshift(c, c->inbuff, c->dsp_insize);
+    if (c->rsmpin->run) wo_resample_exec(c->rsmpin, c->inbuff, c->dsp_insize, c->midbuff);
+    else memcpy(c->midbuff, c->inbuff, (size_t)c->dsp_insize * 2 * sizeof(double));
+    meter_exec(&c->adcmeter, c->midbuff, n, c->meter, NULL);
+    if (c->nbp0.run) wo_fircore_exec(c->nbp0.p, c->midbuff, c->midbuff);
+    meter_exec(&c->smeter, c->midbuff, n, c->meter, NULL);
+    xamd(c, c->midbuff, n);
+    xfmd(c, c->midbuff, n);
+    if (c->bp1.run) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);     /* position 0 */
+    xwcpagc(c, c->midbuff, n);
+    meter_exec(&c->agcmeter, c->midbuff, n, c->meter, &c->agc.gain);
+    xpanel(c, c->midbuff, n);
+    if (c->rsmpout->run) wo_resample_exec(c->rsmpout, c->midbuff, n, c->outbuff);
+    else memcpy(c->outbuff, c->midbuff, (size_t)n * 2 * sizeof(double));
+}
+
+void wo_xrxa_block(wo_channel *c, const double *in, double *out)
+{
+    memcpy(c->inbuff, in, (size_t)c->dsp_insize * 2 * sizeof(double));
+    xrxa(c);
+    memcpy(out, c->outbuff, (size_t)c->dsp_outsize * 2 * sizeof(double));
+}
+
+/* ---- slews (iobuffs.c:47-160) */
+enum { SL_BEGIN = 0, SL_DELAYUP, SL_UPSLEW, SL_ON };
+
+static void create_slews(wo_channel *c)
+{
+    int i;
+    double delta, theta;
+    c->iob.ustate = SL_BEGIN;
+    c->iob.ucount = 0;
+    c->iob.ndelup = (int)(c->tdelayup * c->in_rate);
+    c->iob.ntup = (int)(c->tslewup * c->in_rate);
+    c->iob.cup = (double *)zalloc((size_t)(c->iob.ntup + 1) * sizeof(double));
+    delta = WO_PI / (double)c->iob.ntup;
+    theta = 0.0;
+    for (i = 0; i <= c->iob.ntup; i++) {
+        c->iob.cup[i] = 0.5 * (1.0 - cos(theta));
+        theta += delta;
+    }
+    c->iob.upflag = 0;
+}
+
+static void upslew0(wo_channel *c, const double *pin)
+{
+    int i;
+    double *pout = c->iob.r1 + 2 * c->iob.r1_inidx;
+    double I, Q;
+    for (i = 0; i < c->in_size; i++) {
+        I = pin[2 * i + 0];
+        Q = pin[2 * i + 1];
+        switch (c->iob.ustate) {
+        case SL_BEGIN:
+            pout[2 * i + 0] = 0.0; pout[2 * i + 1] = 0.0;
+            if ((I != 0.0) || (Q != 0.0)) {
+                if (c->iob.ndelup > 0) { c->iob.ustate = SL_DELAYUP; c->iob.ucount = c->iob.ndelup; }
+                else if (c->iob.ntup > 0) { c->iob.ustate = SL_UPSLEW; c->iob.ucount = c->iob.ntup; }
+                else c->iob.ustate = SL_ON;
+            }
+            break;
+        case SL_DELAYUP:
+            pout[2 * i + 0] = 0.0; pout[2 * i + 1] = 0.0;
+            if (c->iob.ucount-- == 0) {
+                if (c->iob.ntup > 0) { c->iob.ustate = SL_UPSLEW; c->iob.ucount = c->iob.ntup; }
+                else c->iob.ustate = SL_ON;
+            }
+            break;
+        case SL_UPSLEW:
+            pout[2 * i + 0] = I * c->iob.cup[c->iob.ntup - c->iob.ucount];
+            pout[2 * i + 1] = Q * c->iob.cup[c->iob.ntup - c->iob.ucount];
+            if (c->iob.ucount-- == 0) c->iob.ustate = SL_ON;
+            break;
+        case SL_ON:
+            pout[2 * i + 0] = I; pout[2 * i + 1] = Q;
+            if (i == c->in_size - 1) { c->iob.ustate = SL_BEGIN; c->iob.upflag = 0; }
+            break;
+        }
+    }
+}
+
+/* ---- dexchange (iobuffs.c:583-604) run synchronously for every queued block */
+static void dexchange(wo_channel *c)
+{
+    int n;
+    c->iob.r2_havesamps += c->iob.r2_insize;
+    memcpy(c->iob.r2 + 2 * c->iob.r2_inidx, c->outbuff, (size_t)c->iob.r2_insize * 2 * sizeof(double));
+    if ((c->iob.r2_inidx += c->iob.r2_insize) == c->iob.r2_active) c->iob.r2_inidx = 0;
+    if ((c->iob.r2_unqueued += c->iob.r2_insize) >= c->out_size) {      /* bfo = 1 */
+        n = c->iob.r2_unqueued / c->out_size;
+        c->iob.sem_outready += n;
+        c->iob.r2_unqueued -= n * c->out_size;
+    }
+    memcpy(c->inbuff, c->iob.r1 + 2 * c->iob.r1_outidx, (size_t)c->iob.r1_outsize * 2 * sizeof(double));
+    if ((c->iob.r1_outidx += c->iob.r1_outsize) == c->iob.r1_active) c->iob.r1_outidx = 0;
+}
+
+void wo_fexchange0(wo_channel *c, const double *in, double *out, int *error)   /* iobuffs.c:464-516, bfo = 1 */
+{
+    int n;
+    *error = 0;
+    if (c->iob.upflag) upslew0(c, in);
+    else memcpy(c->iob.r1 + 2 * c->iob.r1_inidx, in, (size_t)c->in_size * 2 * sizeof(double));
+    if ((c->iob.r1_unqueued += c->in_size) >= c->iob.r1_outsize) {
+        n = c->iob.r1_unqueued / c->iob.r1_outsize;
+        c->iob.sem_buffready += n;
+        c->iob.r1_unqueued -= n * c->iob.r1_outsize;
+    }
+    if ((c->iob.r1_inidx += c->in_size) == c->iob.r1_active) c->iob.r1_inidx = 0;
+    /* DSP thread (main.c:40-58): one dexchange + xrxa per released BuffReady count */
+    while (c->iob.sem_buffready > 0) {
+        c->iob.sem_buffready--;
+        dexchange(c);
+        xrxa(c);
+    }
+    if ((c->iob.r2_havesamps -= c->out_size) < 0) c->iob.r2_havesamps = 0;
+    if (c->iob.sem_outready > 0) {
+        c->iob.sem_outready--;                  /* WaitForSingleObject(Sem_OutReady) returns */
+        memcpy(out, c->iob.r2 + 2 * c->iob.r2_outidx, (size_t)c->out_size * 2 * sizeof(double));
+    } else {
+        /* the reference would block here for ever; report it the way the non-bfo path does */
+        memset(out, 0, (size_t)c->out_size * 2 * sizeof(double));
+        *error += -2;
+    }
+    if ((c->iob.r2_outidx += c->out_size) == c->iob.r2_active) c->iob.r2_outidx = 0;
+}
+
+/* ---- create (channel.c:37-103, iobuffs.c:384-423, RXA.c:31-490) */
+wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int out_rate,
+                    double tdelayup, double tslewup, double tdelaydown, double tslewdown)
+{
+    wo_channel *c = (wo_channel *)zalloc(sizeof(*c));
+    double *imp;
+    int n, nc;
+    c->in_size = in_size; c->dsp_size = dsp_size;
+    c->in_rate = in_rate; c->dsp_rate = dsp_rate; c->out_rate = out_rate;
+    c->tdelayup = tdelayup; c->tslewup = tslewup; c->tdelaydown = tdelaydown; c->tslewdown = tslewdown;
+    /* pre_main_build, channel.c:39-52 */
+    if (in_rate >= dsp_rate) c->dsp_insize = dsp_size * (in_rate / dsp_rate);
+    else c->dsp_insize = dsp_size / (dsp_rate / in_rate);
+    if (out_rate >= dsp_rate) c->dsp_outsize = dsp_size * (out_rate / dsp_rate);
+    else c->dsp_outsize = dsp_size / (dsp_rate / out_rate);
+    if (in_rate >= out_rate) c->out_size = in_size / (in_rate / out_rate);
+    else c->out_size = in_size * (out_rate / in_rate);
+    /* create_iobuffs, iobuffs.c:384-423 */
+    c->iob.r1_outsize = c->dsp_insize;
+    c->iob.r1_size = imax(c->iob.r1_outsize, in_size);
+    c->iob.r2_insize = c->dsp_outsize;
+    c->iob.r2_size = imax(c->out_size, c->iob.r2_insize);
+    c->iob.r1_active = WO_DSP_MULT * c->iob.r1_size;
+    c->iob.r2_active = WO_DSP_MULT * c->iob.r2_size;
+    c->iob.r1 = (double *)zalloc((size_t)c->iob.r1_active * 2 * sizeof(double));
+    c->iob.r2 = (double *)zalloc((size_t)c->iob.r2_active * 2 * sizeof(double));
+    c->iob.r2_inidx = (WO_DSP_MULT - 1) * c->iob.r2_size;
+    c->iob.r2_havesamps = (WO_DSP_MULT - 1) * c->iob.r2_size;
+    n = c->iob.r2_havesamps / c->out_size;
+    c->iob.r2_unqueued = c->iob.r2_havesamps - n * c->out_size;
+    c->iob.sem_buffready = 0;
+    c->iob.sem_outready = n;
+    create_slews(c);
+    c->iob.upflag = 1;                          /* OpenChannel with state 1, channel.c:94-95 */
+    /* create_rxa, RXA.c:31-490 */
+    c->mode = WO_LSB;
+    c->inbuff = (double *)zalloc((size_t)c->dsp_insize * 2 * sizeof(double));
+    c->outbuff = (double *)zalloc((size_t)c->dsp_outsize * 2 * sizeof(double));
+    c->midbuff = (double *)zalloc((size_t)2 * imax(c->dsp_size, c->dsp_insize) * 2 * sizeof(double));
+    c->shift.run = 1; c->shift.rate = (double)in_rate; c->shift.shift = 0.0; c->shift.phase = 0.0;
+    calc_shift(c);
+    c->rsmpin = wo_resample_create(in_rate, dsp_rate, 0.0, 0, 1.0);
+    c->rsmpout = wo_resample_create(dsp_rate, out_rate, 0.0, 0, 1.0);
+    c->rsmpin->run = (in_rate != dsp_rate);     /* RXAResCheck, RXA.c:789-798 */
+    c->rsmpout->run = (dsp_rate != out_rate);
+    meter_init(&c->adcmeter, dsp_rate, 0.100, 0.100, WO_ADC_AV, WO_ADC_PK, -1, c->meter);
+    meter_init(&c->smeter, dsp_rate, 0.100, 0.100, WO_S_AV, WO_S_PK, -1, c->meter);
+    meter_init(&c->agcmeter, dsp_rate, 0.100, 0.100, WO_AGC_AV, WO_AGC_PK, WO_AGC_GAIN, c->meter);
+    nc = imax(2048, dsp_size);
+    c->nbp0.run = 1; c->nbp0.nc = nc; c->nbp0.wintype = 0; c->nbp0.gain = 1.0;
+    c->nbp0.flow = -4150.0; c->nbp0.fhigh = -150.0; c->nbp0.rate = (double)dsp_rate;
+    imp = nbp0_impulse(c);
+    c->nbp0.p = wo_fircore_create(dsp_size, nc, imp);
+    free(imp);
+    c->amd.run = 0; c->amd.mode = 0; c->amd.levelfade = 1; c->amd.sbmode = 0; c->amd.sample_rate = (double)dsp_rate;
+    init_amd(c);
+    c->fmd.run = 0; c->fmd.rate = (double)dsp_rate; c->fmd.deviation = 5000.0;
+    c->fmd.f_low = 300.0; c->fmd.f_high = 3000.0; c->fmd.fmin = -8000.0; c->fmd.fmax = +8000.0;
+    c->fmd.zeta = 1.0; c->fmd.omegaN = 20000.0; c->fmd.tau = 0.02; c->fmd.afgain = 0.5;
+    c->fmd.sntch_run = 1; c->fmd.ctcss_freq = 254.1; c->fmd.nc_de = nc; c->fmd.nc_aud = nc;
+    calc_fmd(c);
+    c->fmd.audio = (double *)zalloc((size_t)dsp_size * 2 * sizeof(double));
+    imp = fmd_de_impulse(c);
+    c->fmd.pde = wo_fircore_create(dsp_size, nc, imp);
+    free(imp);
+    imp = fmd_aud_impulse(c);
+    c->fmd.paud = wo_fircore_create(dsp_size, nc, imp);
+    free(imp);
+    c->agc.run = 1; c->agc.mode = 3; c->agc.fixed_gain = 1000.0; c->agc.gain = 0.0;
+    c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0;
+    c->bp1.f_low = -4150.0; c->bp1.f_high = -150.0;
+    imp = bp1_impulse(c);
+    c->bp1.p = wo_fircore_create(dsp_size, nc, imp);
+    free(imp);
+    c->panel.run = 1; c->panel.gain1 = 4.0; c->panel.gain2I = 1.0; c->panel.gain2Q = 1.0;
+    c->panel.inselect = 3; c->panel.copy = 0;
+    return c;
+}
+
+void wo_close(wo_channel *c)
+{
+    if (!c) return;
+    wo_resample_destroy(c->rsmpin); wo_resample_destroy(c->rsmpout);
+    wo_fircore_destroy(c->nbp0.p); wo_fircore_destroy(c->bp1.p);
+    wo_fircore_destroy(c->fmd.pde); wo_fircore_destroy(c->fmd.paud);
+    free(c->fmd.audio);
+    free(c->inbuff); free(c->midbuff); free(c->outbuff);
+    free(c->iob.r1); free(c->iob.r2); free(c->iob.cup);
+    free(c);
+}
+
+/* ---- setters */
+void wo_SetRXAMode(wo_channel *c, int mode)     /* RXA.c:748-787 */
+{
+    if (c->mode != mode) {
+        int amd_run = (mode == WO_AM) || (mode == WO_SAM);
+        bp1_check(c, amd_run);
+        c->mode = mode;
+        c->amd.run = 0;
+        c->fmd.run = 0;
+        c->agc.run = 1;
+        switch (mode) {
+        case WO_AM: c->amd.run = 1; c->amd.mode = 0; break;
+        case WO_SAM: c->amd.run = 1; c->amd.mode = 1; break;
+        case WO_FM: c->fmd.run = 1; c->agc.run = 0; break;
+        default: break;
+        }
+        bp1_set(c);
+    }
+}
+
+void wo_SetRXABandpassFreqs(wo_channel *c, double f_low, double f_high)
+{
+    if ((f_low != c->bp1.f_low) || (f_high != c->bp1.f_high)) {
+        double *imp;
+        c->bp1.f_low = f_low; c->bp1.f_high = f_high;
+        imp = bp1_impulse(c);
+        fircore_set_impulse(c->bp1.p, imp);
+        free(imp);
+    }
+}
+
+void wo_RXANBPSetFreqs(wo_channel *c, double flow, double fhigh)
+{
+    if ((flow != c->nbp0.flow) || (fhigh != c->nbp0.fhigh)) {
+        double *imp;
+        c->nbp0.flow = flow; c->nbp0.fhigh = fhigh;
+        imp = nbp0_impulse(c);
+        fircore_set_impulse(c->nbp0.p, imp);
+        free(imp);
+    }
+}
+
+void wo_RXASetPassband(wo_channel *c, double f_low, double f_high)
+{
+    wo_SetRXABandpassFreqs(c, f_low, f_high);
+    /* SetRXASNBAOutputBandwidth: snba run = 0, no effect on the data */
+    wo_RXANBPSetFreqs(c, f_low, f_high);
+}
+
+void wo_RXASetNC(wo_channel *c, int nc)         /* RXA.c:934-946 */
+{
+    double *imp;
+    if (c->nbp0.nc != nc) {                     /* RXANBPSetNC, nbp.c:580-593 */
+        c->nbp0.nc = nc;
+        imp = nbp0_impulse(c);
+        fircore_set_nc(c->nbp0.p, nc, imp);
+        free(imp);
+    }
+    if (c->bp1.nc != nc) {                      /* SetRXABandpassNC, bandpass.c:428-444 */
+        c->bp1.nc = nc;
+        imp = bp1_impulse(c);
+        fircore_set_nc(c->bp1.p, nc, imp);
+        free(imp);
+    }
+    if (c->fmd.nc_de != nc) {                   /* SetRXAFMNCde, fmd.c:269-284 */
+        c->fmd.nc_de = nc;
+        imp = fmd_de_impulse(c);
+        fircore_set_nc(c->fmd.pde, nc, imp);
+        free(imp);
+    }
+    if (c->fmd.nc_aud != nc) {                  /* SetRXAFMNCaud, fmd.c:298-313 */
+        c->fmd.nc_aud = nc;
+        imp = fmd_aud_impulse(c);
+        fircore_set_nc(c->fmd.paud, nc, imp);
+        free(imp);
+    }
+}
+
+void wo_SetRXAShiftRun(wo_channel *c, int run) { c->shift.run = run; }
+void wo_SetRXAShiftFreq(wo_channel *c, double fshift) { c->shift.shift = fshift; calc_shift(c); }
+void wo_RXANBPSetRun(wo_channel *c, int run) { c->nbp0.run = run; }
+void wo_SetRXABandpassRun(wo_channel *c, int run) { c->bp1.run = run; }
+
+void wo_SetRXAAGCMode(wo_channel *c, int mode)
+{
+    c->agc.mode = (mode >= 0 && mode <= 4) ? mode : 5;
+}
+
+void wo_SetRXAAGCFixed(wo_channel *c, double fixed_agc_db)
+{
+    c->agc.fixed_gain = pow(10.0, fixed_agc_db / 20.0);
+}
+
+void wo_SetRXAPanelRun(wo_channel *c, int run) { c->panel.run = run; }
+void wo_SetRXAPanelGain1(wo_channel *c, double gain) { c->panel.gain1 = gain; }
+void wo_SetRXAPanelGain2(wo_channel *c, double gainI, double gainQ) { c->panel.gain2I = gainI; c->panel.gain2Q = gainQ; }
+void wo_SetRXAPanelSelect(wo_channel *c, int select) { c->panel.inselect = select; }
+void wo_SetRXAPanelCopy(wo_channel *c, int copy) { c->panel.copy = copy; }
+void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode) { c->amd.sbmode = sbmode; }
+void wo_SetRXAAMDFadeLevel(wo_channel *c, int levelfade) { c->amd.levelfade = levelfade; }
+
+void wo_SetRXAFMDeviation(wo_channel *c, double deviation)
+{
+    c->fmd.deviation = deviation;
+    c->fmd.again = c->fmd.rate / (c->fmd.deviation * WO_TWOPI);
+}
+
+void wo_SetRXACTCSSFreq(wo_channel *c, double freq) { c->fmd.ctcss_freq = freq; calc_snotch(c); }
+void wo_SetRXACTCSSRun(wo_channel *c, int run) { c->fmd.sntch_run = run; }
+double wo_GetRXAMeter(wo_channel *c, int mt) { return c->meter[mt]; }
