@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the WDSP-RXA SSB receive chain on MI355X.
+
+Workload (BASELINE.json configs[1]): 256 channels x 192 kHz IQ -> 48 kHz, fp64,
+shift -> 561-tap resampler /4 -> NBP fircore (nc 2048, 300..3000 Hz) -> fixed-gain AGC -> panel,
+one pass ("step") = 2^22 input samples per channel, inputs resident in HBM.
+With --gpus N every rank runs its own 256 channels (independent receivers shard by channel, no
+collective on the data path): weak scaling, value = all ranks' input samples / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NCH = 256
+LOG2_SAMPLES = 22
+IN_RATE, DSP_RATE = 192000, 48000
+DSP_SIZE = 256
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(log2_samples=23):
+    """The CPU oracle (a restatement of the reference's WDSP path, oracle/wdsp_oracle.c) timed on the
+    host cores of this box: one channel per core, each 2^log2_samples input samples."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as po
+    from quisk_amd import synth
+    po.build(ref=False)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    n = 1 << log2_samples
+    po.fft(np.zeros(512, dtype=np.complex128))                  # warm the oracle's twiddle cache before threading
+    x = synth.make_input_numpy(1, n)[0]
+    chans = []
+    for c in range(cores):
+        ch = po.WdspChannel(1024, DSP_SIZE, IN_RATE, DSP_RATE, DSP_RATE)
+        ch.SetRXAShiftRun(1)
+        ch.SetRXAShiftFreq(synth.shift_freq(c))
+        ch.RXANBPSetRun(1)
+        ch.SetRXAMode(1)
+        ch.RXASetPassband(300.0, 3000.0)
+        ch.SetRXAAGCMode(0)
+        ch.SetRXAAGCFixed(0.0)
+        chans.append(ch)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda ch: ch.xrxa(x), chans))              # ctypes releases the GIL inside the C call
+    dt = time.perf_counter() - t0
+    return {"value": cores * n / dt / 1e6, "unit": "Mcomplex-samples/s", "cores": cores, "kind": "port",
+            "sample": "%d channels (one per core) x 2^%d input samples, oracle/wdsp_oracle.c -O3, own radix-2 FFT (not FFTW)"
+                      % (cores, log2_samples)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=NCH, help="channels per GPU")
+    ap.add_argument("--log2-samples", type=int, default=LOG2_SAMPLES, help="input samples per channel per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from quisk_amd import RxaEngine, synth, build as qbuild
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the RXA chain has no CPU path")
+    if rank == 0:
+        qbuild.build()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
+
+    nch = args.channels
+    n_in = 1 << args.log2_samples
+    nblk = n_in // (DSP_SIZE * (IN_RATE // DSP_RATE))
+    n_out = nblk * DSP_SIZE
+    first = rank * nch                                          # rank r owns channels [r*nch, (r+1)*nch)
+
+    stream = torch.cuda.current_stream(dev)
+    eng = RxaEngine(nch, dsp_size=DSP_SIZE, in_rate=IN_RATE, dsp_rate=DSP_RATE, out_rate=DSP_RATE,
+                    device=local_rank, stream=stream.cuda_stream)
+    eng.SetRXAShiftRun(-1, 1)
+    for c in range(nch):
+        eng.SetRXAShiftFreq(c, synth.shift_freq(first + c))
+    eng.RXANBPSetRun(-1, 1)
+    eng.SetRXAMode(-1, 1)
+    eng.RXASetPassband(-1, 300.0, 3000.0)
+    eng.SetRXAAGCMode(-1, 0)
+    eng.SetRXAAGCFixed(-1, 0.0)
+
+    x = synth.make_input_torch(nch, n_in, dev, fs=float(IN_RATE), first_channel=first)
+    y = torch.empty((nch, n_out), dtype=torch.complex128, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), n_out, nblk)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel durations with HIP events on the engine's stream (separate short run, not in the timed region)
+    eng.enable_timing(True)
+    kt = [0.0, 0.0, 0.0]
+    reps = 5
+    for _ in range(reps):
+        step()
+        t = eng.timing_ms()
+        kt = [a + b for a, b in zip(kt, t)]
+    kt = [v / reps for v in kt]
+    eng.enable_timing(False)
+
+    # sanity: the in-band tone must come out with the panel gain of 4.0
+    tail = y[0, -4096:]
+    gain = float(tail.abs().mean().item()) / 0.1
+
+    if rank == 0:
+        samples_per_step = float(nch) * n_in
+        total = samples_per_step * world * args.steps
+        value = total / dt / 1e6
+        # dominant kernel and its algorithmic bytes per launch:
+        #   front  (shift + resample /4): reads 16 B, writes 16/4 B per input sample        = 20 B / input sample
+        #   band   (NBP overlap-save)   : reads 16 B, writes 16 B per DSP-rate sample (x1/4) =  8 B / input sample
+        names = ["osfir_kernel<f64,4096,D=4,mix> (shift+resample)", "osfir_kernel<f64,4096,D=1> (nbp fircore)"]
+        algo = [20.0, 8.0]
+        k = 0 if kt[0] >= kt[1] else 1
+        achieved = algo[k] * samples_per_step / (kt[k] * 1e-3) / 1e9
+        line = {
+            "metric": "Mcomplex-samples/s through RXA chain",
+            "value": value,
+            "unit": "Mcomplex-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%d channels/GPU x 192 kHz IQ -> 48 kHz SSB RXA chain (shift + 561-tap resample/4 + NBP nc 2048 + "
+                                   "fixed AGC + panel), 2^%d input samples per channel per step" % (nch, args.log2_samples),
+                       "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
+                       "parallelism": "channel-sharded x%d, no collective" % world},
+            "chain_algorithmic_GBps": 20.0 * total / dt / 1e9,
+            "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
+            "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None},
+            "check_inband_gain": gain,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:                             # the baseline is reported, never required
+                line["cpu_baseline"] = {"value": None, "unit": "Mcomplex-samples/s", "cores": 0, "kind": "port",
+                                        "sample": "failed: %r" % (exc,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/* quiskhip.h -- C ABI of libquiskhip.so: MI355X (gfx950) receive DSP for Quisk / WDSP.
+ *
+ * Plain C, plain pointers and sizes; no C++ or torch types.  Three groups of entry points:
+ *
+ *  1. qh_rxa_*    batched many-channel RXA engine (device-resident buffers).  The reference has
+ *                 no batched form: it runs one DSP thread per channel (wdsp/channel.c:31-35) and
+ *                 caps channels at 32 (wdsp/comm.h:117).  This is what bench.py measures.
+ *  2. WDSP names  OpenChannel / fexchange0 / SetRXA* ... with the reference's exact signatures,
+ *                 so that quisk_wdsp.py's ctypes.CDLL("./wdsp/libwdsp.so") (quisk_wdsp.py:27-41)
+ *                 and quisk_wdsp.c's function pointer (quisk_wdsp.c:22,57) bind unchanged.
+ *  3. qh_fir_*    batched FIR / decimator primitives equivalent to filter.c (filter.h:39-55).
+ *
+ * All functions returning int return 0 on success and a negative qh_status on failure;
+ * qh_last_error() gives the message.  Nothing here falls back to the CPU: without a usable
+ * HIP device every compute entry point fails with QH_ERR_NO_DEVICE.
+ */
+#ifndef QUISKHIP_H
+#define QUISKHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    QH_OK = 0,
+    QH_ERR_NO_DEVICE = -1,
+    QH_ERR_INVALID = -2,
+    QH_ERR_UNSUPPORTED = -3,
+    QH_ERR_HIP = -4
+} qh_status;
+
+/* ------------------------------------------------------------------ library */
+int qh_version(void);                       /* 100 * major + minor */
+const char *qh_last_error(void);            /* thread-local message of the last failure */
+int qh_device_count(void);                  /* number of visible HIP devices (0 without a GPU) */
+
+/* RXA demodulator modes, numerically identical to wdsp/RXA.h:31-45 */
+enum { QH_LSB = 0, QH_USB, QH_DSB, QH_CWL, QH_CWU, QH_FM, QH_AM, QH_DIGU, QH_SPEC, QH_DIGL, QH_SAM, QH_DRM };
+
+/* ------------------------------------------------------------------ 1. batched RXA engine */
+typedef struct qh_rxa qh_rxa;
+
+/* Creates `nch` independent receiver channels, each configured exactly like
+ * OpenChannel(ch, *, dsp_size, in_rate, dsp_rate, out_rate, type 0, ...) followed by create_rxa()
+ * (wdsp/channel.c:75-103, wdsp/RXA.c:31-490): shift run=1 at 0 Hz, nbp0 -4150..-150 Hz nc 2048,
+ * AGC mode 3, panel gain 4.  `stream` is a hipStream_t (NULL = the engine creates its own).
+ * in_rate must be an integer multiple (1, 2, 4, 8) of dsp_rate and out_rate == dsp_rate. */
+qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_rate, int out_rate, void *stream);
+void qh_rxa_destroy(qh_rxa *e);
+
+int qh_rxa_nch(const qh_rxa *e);
+int qh_rxa_dsp_insize(const qh_rxa *e);     /* complex input samples per DSP block  (wdsp/channel.c:39-42) */
+int qh_rxa_dsp_outsize(const qh_rxa *e);    /* complex output samples per DSP block (wdsp/channel.c:44-47) */
+
+/* Per-channel setters; `ch` indexes the batch, or -1 for every channel.  Same meaning as the WDSP
+ * export of the same name (cited in section 2).  They take effect at the next qh_rxa_process call,
+ * i.e. on a DSP-block boundary, which is when the reference applies them (csDSP, wdsp/main.c:41). */
+int qh_rxa_SetRXAMode(qh_rxa *e, int ch, int mode);
+int qh_rxa_RXASetPassband(qh_rxa *e, int ch, double f_low, double f_high);
+int qh_rxa_RXASetNC(qh_rxa *e, int ch, int nc);
+int qh_rxa_SetRXAShiftRun(qh_rxa *e, int ch, int run);
+int qh_rxa_SetRXAShiftFreq(qh_rxa *e, int ch, double fshift);
+int qh_rxa_RXANBPSetRun(qh_rxa *e, int ch, int run);
+int qh_rxa_RXANBPSetFreqs(qh_rxa *e, int ch, double flow, double fhigh);
+int qh_rxa_SetRXABandpassRun(qh_rxa *e, int ch, int run);
+int qh_rxa_SetRXABandpassFreqs(qh_rxa *e, int ch, double f_low, double f_high);
+int qh_rxa_SetRXAAGCMode(qh_rxa *e, int ch, int mode);
+int qh_rxa_SetRXAAGCFixed(qh_rxa *e, int ch, double fixed_agc_db);
+int qh_rxa_SetRXAPanelGain1(qh_rxa *e, int ch, double gain);
+int qh_rxa_SetRXAPanelGain2(qh_rxa *e, int ch, double gainI, double gainQ);
+int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
+int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
+
+/* Runs xrxa() (wdsp/RXA.c:561-598) over `nblk` consecutive DSP blocks of every channel.
+ *   d_in  : device pointer, [nch][in_stride] interleaved complex double, nblk*dsp_insize samples used
+ *   d_out : device pointer, [nch][out_stride] interleaved complex double, nblk*dsp_outsize samples written
+ * Strides are in complex samples.  Filter/NCO state is carried to the next call exactly as the
+ * reference carries it from block to block.  Asynchronous on the engine's stream. */
+int qh_rxa_process(qh_rxa *e, const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
+
+/* Same with host buffers (synchronous; pageable memory; includes the PCIe copies). */
+int qh_rxa_process_host(qh_rxa *e, const double *h_in, long long in_stride, double *h_out, long long out_stride, int nblk);
+
+int qh_rxa_synchronize(qh_rxa *e);
+
+/* flush_rxa (wdsp/RXA.c:527-559): zero the NCO phase and every filter history of every channel. */
+int qh_rxa_flush(qh_rxa *e);
+
+/* Timing of the kernels of qh_rxa_process with HIP events on the engine's stream.
+ * enable != 0 brackets every kernel of later process calls with events; qh_rxa_timing() waits for
+ * the last call and returns, for kernel k (0 = shift+resample stage, 1 = bandpass stage, 2 = state
+ * bookkeeping), the milliseconds of the last call in ms[k].  Returns the number of entries. */
+int qh_rxa_enable_timing(qh_rxa *e, int enable);
+int qh_rxa_timing(qh_rxa *e, double *ms, int n);
+
+/* Bytes of device memory the engine holds (state, masks, intermediate buffers). */
+long long qh_rxa_device_bytes(const qh_rxa *e);
+
+/* ------------------------------------------------------------------ 2. WDSP drop-in exports */
+/* Signatures are the reference's: wdsp/channel.h:62, wdsp/iobuffs.h:89-90, and the PORT functions
+ * cited per line.  Channel numbers 0..31 (wdsp/comm.h:117).  Each open channel is a 1-channel
+ * qh_rxa engine plus the host-side ring logic of wdsp/iobuffs.c (two-block latency, upslew). */
+int GetWDSPVersion(void);                                                        /* wdsp/version.c */
+void OpenChannel(int channel, int in_size, int dsp_size, int input_samplerate, int dsp_rate,
+                 int output_samplerate, int type, int state, double tdelayup, double tslewup,
+                 double tdelaydown, double tslewdown, int bfo);                  /* wdsp/channel.c:75-103 */
+void CloseChannel(int channel);                                                  /* wdsp/channel.c:122-128 */
+int SetChannelState(int channel, int state, int dmode);                          /* wdsp/channel.c:260-298 */
+void fexchange0(int channel, double *in, double *out, int *error);               /* wdsp/iobuffs.c:464-516 */
+void SetRXAMode(int channel, int mode);                                          /* wdsp/RXA.c:748-787 */
+void RXASetPassband(int channel, double f_low, double f_high);                   /* wdsp/RXA.c:926-932 */
+void RXASetNC(int channel, int nc);                                              /* wdsp/RXA.c:934-946 */
+void RXASetMP(int channel, int mp);                                              /* wdsp/RXA.c:948-958 */
+void SetRXAShiftRun(int channel, int run);                                       /* wdsp/shift.c:110-117 */
+void SetRXAShiftFreq(int channel, double fshift);                                /* wdsp/shift.c:119-127 */
+void RXANBPSetRun(int channel, int run);                                         /* wdsp/nbp.c:528-536 */
+void RXANBPSetFreqs(int channel, double flow, double fhigh);                     /* wdsp/nbp.c:538-552 */
+void SetRXABandpassRun(int channel, int run);                                    /* wdsp/bandpass.c:381-387 */
+void SetRXABandpassFreqs(int channel, double f_low, double f_high);              /* wdsp/bandpass.c:389-407 */
+void SetRXAAGCMode(int channel, int mode);                                       /* wdsp/wcpAGC.c:369-411 */
+void SetRXAAGCFixed(int channel, double fixed_agc);                              /* wdsp/wcpAGC.c:541-548 */
+void SetRXAPanelRun(int channel, int run);                                       /* wdsp/patchpanel.c:123-129 */
+void SetRXAPanelGain1(int channel, double gain);                                 /* wdsp/patchpanel.c:139-145 */
+void SetRXAPanelGain2(int channel, double gainI, double gainQ);                  /* wdsp/patchpanel.c:147-154 */
+void SetRXAPanelSelect(int channel, int select);                                 /* wdsp/patchpanel.c:131-137 */
+void SetRXAPanelCopy(int channel, int copy);                                     /* wdsp/patchpanel.c:175-181 */
+/* accepted and ignored: these blocks are run = 0 on the hot path */
+void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c */
+void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */
+void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c */
+
+/* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */
+int qh_wdsp_status(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -37,6 +37,7 @@ def lib():
         L.wo_close.argtypes = [C.c_void_p]
         L.wo_fexchange0.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.wo_xrxa_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wo_xrxa_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         for n in ("wo_dsp_insize", "wo_dsp_outsize", "wo_out_size"):
             getattr(L, n).argtypes = [C.c_void_p]
             getattr(L, n).restype = C.c_int
@@ -174,8 +175,7 @@ class WdspChannel:
         assert x.size % self.dsp_insize == 0
         nb = x.size // self.dsp_insize
         out = np.empty(nb * self.dsp_outsize, dtype=np.complex128)
-        for b in range(nb):
-            self.L.wo_xrxa_block(self.h, x[b * self.dsp_insize:].ctypes.data, out[b * self.dsp_outsize:].ctypes.data)
+        self.L.wo_xrxa_blocks(self.h, x.ctypes.data, out.ctypes.data, nb)
         return out
 
     def close(self):

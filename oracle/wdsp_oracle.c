@@ -818,6 +818,14 @@ void wo_xrxa_block(wo_channel *c, const double *in, double *out)
     memcpy(out, c->outbuff, (size_t)c->dsp_outsize * 2 * sizeof(double));
 }
 
+/* many blocks in one call (lets a Python caller release the GIL for the whole run) */
+void wo_xrxa_blocks(wo_channel *c, const double *in, double *out, int nblk)
+{
+    int b;
+    for (b = 0; b < nblk; b++)
+        wo_xrxa_block(c, in + (size_t)b * c->dsp_insize * 2, out + (size_t)b * c->dsp_outsize * 2);
+}
+
 /* ---- slews (iobuffs.c:47-160) */
 enum { SL_BEGIN = 0, SL_DELAYUP, SL_UPSLEW, SL_ON };
 

@@ -43,6 +43,7 @@ void wo_fexchange0(wo_channel *c, const double *in, double *out, int *error);
 
 /* xrxa() on one DSP block without the iobuffs latency/slew: in = dsp_insize, out = dsp_outsize complex */
 void wo_xrxa_block(wo_channel *c, const double *in, double *out);
+void wo_xrxa_blocks(wo_channel *c, const double *in, double *out, int nblk);
 
 int wo_dsp_insize(const wo_channel *c);
 int wo_dsp_outsize(const wo_channel *c);

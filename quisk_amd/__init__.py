@@ -1,0 +1,10 @@
+"""quisk_amd -- MI355X (gfx950) receive DSP for Quisk / WDSP.
+
+The product is the C-ABI shared library quisk_amd/lib/libquiskhip.so (include/quiskhip.h);
+this package is the thin Python host side that mirrors the reference's own Python binding
+(quisk_wdsp.py) on top of it.  There is no CPU fallback: every compute call needs a HIP device.
+"""
+from .lib import load, QuiskHipError          # noqa: F401
+from .rxa import RxaEngine                    # noqa: F401
+
+__all__ = ["load", "QuiskHipError", "RxaEngine"]

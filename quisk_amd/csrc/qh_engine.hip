@@ -1,0 +1,663 @@
+// qh_engine.hip -- batched RXA receive engine for MI355X and its C ABI (include/quiskhip.h, group 1).
+//
+// Mirrors create_rxa()/xrxa() of the reference (wdsp/RXA.c:31-598) for the blocks on the hot path.
+// Per-channel differences are data (NCO step, masks, 2x2 output matrix), not control flow, so one
+// launch per stage covers every channel:
+//
+//   front   : xshift + xresample(in)      -> qh::osfir_kernel<NFFT, D = in_rate/dsp_rate, MIX>
+//   nbp0    : xnbp (fircore)              -> qh::osfir_kernel<NFFT, 1>
+//   bp1     : xbandpass (fircore)         -> qh::osfir_kernel<NFFT, 1>      (only when some channel runs it)
+//   epilogue: xwcpagc mode 0 + xpanel     -> fused into the last launch (2x2 real matrix per channel)
+//
+// State carried between calls (all device resident, right-aligned rows of the most recent samples):
+//   hist_front [2][nch][HF]  mixed input samples (the reference's resampler ring)
+//   hist_nbp   [2][nch][HB]  nbp0 input samples  (the reference's fircore delay line)
+//   hist_bp1   [2][nch][HB]
+//   nco_phase  [nch]         64-bit fixed-point turns
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/quiskhip.h"
+#include "qh_design.hpp"
+#include "qh_kernels.hpp"
+#include "qh_internal.hpp"
+
+namespace qh {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define QH_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return set_error(QH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+static constexpr int kNfft = 4096;          // FFT size of every overlap-save stage in this engine
+static constexpr int kHistBand = 2047;      // fircore history capacity: nc up to 2048
+static constexpr int kHistFront = 1120;     // resampler history capacity: 140 * D taps, D <= 8
+
+template <typename T> static hipError_t dev_alloc(T **p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+}
+
+struct ChanCfg {
+    int mode = QH_LSB;                                          // RXA.c:33
+    int shift_run = 1; double shift_freq = 0.0;                 // RXA.c:39-45
+    int nbp_run = 1, nbp_nc = 2048, nbp_wintype = 0;            // RXA.c:90-106
+    double nbp_flow = -4150.0, nbp_fhigh = -150.0, nbp_gain = 1.0;
+    int amd_run = 0, amd_mode = 0, fmd_run = 0;                 // RXA.c:175-212
+    int agc_run = 1, agc_mode = 3; double agc_fixed = 1000.0;   // RXA.c:335-358
+    int bp1_run = 1, bp1_nc = 2048, bp1_wintype = 1;            // RXA.c:377-389
+    double bp1_flow = -4150.0, bp1_fhigh = -150.0, bp1_gain = 1.0;
+    double gain1 = 4.0, gain2I = 1.0, gain2Q = 1.0;             // RXA.c:464-474
+    int inselect = 3, copy = 0;
+    bool nbp_dirty = true, bp1_dirty = true, nco_dirty = true, epi_dirty = true;
+    bool nbp_flush = false, bp1_flush = false;
+};
+
+struct Engine {
+    int device = 0, nch = 0, dsp_size = 0, in_rate = 0, dsp_rate = 0, out_rate = 0;
+    int D = 1, dsp_insize = 0, dsp_outsize = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<ChanCfg> cfg;
+    // front (resampler) design
+    int front_ntaps = 0, front_P = 0, front_L = 0;
+    // device state
+    double2 *mask_front = nullptr, *mask_nbp = nullptr, *mask_bp1 = nullptr;
+    double2 *tw4096 = nullptr, *tw_inv_front = nullptr;
+    unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr;
+    double2 *nco_step = nullptr;
+    EpiParam *epi = nullptr;
+    double2 *hist_front[2] = { nullptr, nullptr }, *hist_nbp[2] = { nullptr, nullptr }, *hist_bp1[2] = { nullptr, nullptr };
+    int cur_front = 0, cur_nbp = 0, cur_bp1 = 0;
+    double2 *buf[2] = { nullptr, nullptr };
+    long long buf_cap = 0;                  // complex samples per channel
+    long long dev_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_cat;
+    int ev_used = 0;
+    double last_ms[3] = { 0, 0, 0 };
+
+    ~Engine();
+    int init();
+    int refresh_params();
+    int ensure_buffers(long long n_mid);
+    int process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
+    void tick(int cat);
+};
+
+Engine::~Engine()
+{
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
+    (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
+    for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+static int upload(double2 *dst, const std::vector<cd> &v, hipStream_t s)
+{
+    QH_HIP(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(cd), hipMemcpyHostToDevice, s));
+    QH_HIP(hipStreamSynchronize(s));        // the host vector dies with the caller's scope
+    return QH_OK;
+}
+
+int Engine::init()
+{
+    QH_HIP(hipSetDevice(device));
+    if (!stream) { QH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+    // pre_main_build, wdsp/channel.c:39-47
+    dsp_insize = dsp_size * D;
+    dsp_outsize = dsp_size;
+    cfg.assign((size_t)nch, ChanCfg());
+
+    std::vector<cd> tw = fft_twiddle_table(kNfft);
+    QH_HIP(dev_alloc(&tw4096, tw.size()));
+    if (int rc = upload(tw4096, tw, stream)) return rc;
+    dev_bytes += tw.size() * sizeof(cd);
+
+    if (D > 1) {
+        // calc_resample, wdsp/resample.c:35-72 (L = 1): y[m] = sum_j h[j] x[D*m - j]
+        ResamplerDesign rd = design_resampler(in_rate, dsp_rate, 0.0, 0, 1.0);
+        if (rd.L != 1 || rd.M != D) return set_error(QH_ERR_UNSUPPORTED, "resampler L/M = %d/%d not supported", rd.L, rd.M);
+        front_ntaps = rd.ncoef;
+        front_P = ((front_ntaps - 1 + D - 1) / D) * D;
+        front_L = (kNfft - front_P) / D;
+        if (front_P > kHistFront) return set_error(QH_ERR_UNSUPPORTED, "resampler history %d too long", front_P);
+        std::vector<cd> h((size_t)front_ntaps);
+        for (int i = 0; i < front_ntaps; i++) h[i] = cd(rd.h[i], 0.0);
+        std::vector<cd> m = make_mask(h, kNfft);
+        QH_HIP(dev_alloc(&mask_front, m.size()));
+        if (int rc = upload(mask_front, m, stream)) return rc;
+        std::vector<cd> twi = fft_twiddle_table(kNfft / D);
+        QH_HIP(dev_alloc(&tw_inv_front, twi.size()));
+        if (int rc = upload(tw_inv_front, twi, stream)) return rc;
+        dev_bytes += (m.size() + twi.size()) * sizeof(cd);
+        for (int i = 0; i < 2; i++) {
+            QH_HIP(dev_alloc(&hist_front[i], (size_t)nch * kHistFront));
+            QH_HIP(hipMemsetAsync(hist_front[i], 0, (size_t)nch * kHistFront * sizeof(double2), stream));
+            dev_bytes += (size_t)nch * kHistFront * sizeof(double2);
+        }
+    }
+    QH_HIP(dev_alloc(&mask_nbp, (size_t)nch * kNfft));
+    QH_HIP(dev_alloc(&mask_bp1, (size_t)nch * kNfft));
+    dev_bytes += 2ll * nch * kNfft * sizeof(double2);
+    for (int i = 0; i < 2; i++) {
+        QH_HIP(dev_alloc(&hist_nbp[i], (size_t)nch * kHistBand));
+        QH_HIP(dev_alloc(&hist_bp1[i], (size_t)nch * kHistBand));
+        QH_HIP(hipMemsetAsync(hist_nbp[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+        QH_HIP(hipMemsetAsync(hist_bp1[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+        dev_bytes += 2ll * nch * kHistBand * sizeof(double2);
+    }
+    QH_HIP(dev_alloc(&nco_phase, (size_t)nch));
+    QH_HIP(dev_alloc(&nco_dphase, (size_t)nch));
+    QH_HIP(dev_alloc(&nco_step, (size_t)nch));
+    QH_HIP(dev_alloc(&epi, (size_t)nch));
+    QH_HIP(hipMemsetAsync(nco_phase, 0, (size_t)nch * sizeof(unsigned long long), stream));
+    dev_bytes += (size_t)nch * (16 + 16 + sizeof(EpiParam));
+
+    // allow the 64 KiB dynamic LDS of the overlap-save kernels
+    const int lds = kNfft * (int)sizeof(double2);
+#define QH_SET_LDS(K) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+    QH_SET_LDS((osfir_kernel<double, 4096, 1, false>));
+    QH_SET_LDS((osfir_kernel<double, 4096, 2, true>));
+    QH_SET_LDS((osfir_kernel<double, 4096, 4, true>));
+    QH_SET_LDS((osfir_kernel<double, 4096, 8, true>));
+#undef QH_SET_LDS
+    QH_HIP(hipStreamSynchronize(stream));
+    return QH_OK;
+}
+
+// fixed-point turns for a frequency ratio f / rate
+static unsigned long long turns_fx(double f, double rate)
+{
+    long double t = (long double)f / (long double)rate;
+    t -= floorl(t);
+    long double s = t * 18446744073709551616.0L;
+    if (s >= 18446744073709551616.0L) s = 0;
+    return (unsigned long long)s;
+}
+
+int Engine::refresh_params()
+{
+    // one pass over the channels; upload only what changed
+    std::vector<cd> last_nbp, last_bp1;
+    const ChanCfg *last_nbp_cfg = nullptr, *last_bp1_cfg = nullptr;
+    for (int ch = 0; ch < nch; ch++) {
+        ChanCfg &c = cfg[(size_t)ch];
+        if (c.nco_dirty) {
+            // calc_shift, wdsp/shift.c:29-34: delta = 2*pi*shift/rate per input sample
+            unsigned long long d = c.shift_run ? turns_fx(c.shift_freq, (double)in_rate) : 0ull;
+            long double ang = 2.0L * 3.14159265358979323846264338327950288L *
+                              ((long double)(d * (unsigned long long)NT) / 18446744073709551616.0L);
+            double2 st; st.x = (double)cosl(ang); st.y = (double)sinl(ang);
+            QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, sizeof(d), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemcpyAsync(nco_step + ch, &st, sizeof(st), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.nco_dirty = false;
+        }
+        if (c.epi_dirty) {
+            // xwcpagc mode 0 (wcpAGC.c:167-175) then xpanel (patchpanel.c:55-101) as one 2x2 real matrix
+            const double g = (c.agc_run && c.agc_mode == 0) ? c.agc_fixed : 1.0;
+            const double gI = c.gain1 * c.gain2I, gQ = c.gain1 * c.gain2Q;
+            const double sI = (double)(c.inselect >> 1), sQ = (double)(c.inselect & 1);
+            EpiParam e;
+            switch (c.copy) {
+            default:
+            case 0: e.a = gI * sI * g; e.b = 0; e.c = 0; e.d = gQ * sQ * g; break;
+            case 1: e.a = gI * sI * g; e.b = 0; e.c = gQ * sI * g; e.d = 0; break;
+            case 2: e.a = 0; e.b = gI * sQ * g; e.c = 0; e.d = gQ * sQ * g; break;
+            case 3: e.a = 0; e.b = gI * sQ * g; e.c = gQ * sI * g; e.d = 0; break;
+            }
+            QH_HIP(hipMemcpyAsync(epi + ch, &e, sizeof(e), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.epi_dirty = false;
+        }
+        if (c.nbp_dirty) {
+            // calc_nbp_impulse without notches, wdsp/nbp.c:234-238; identity when the filter is off
+            bool same = last_nbp_cfg && last_nbp_cfg->nbp_run == c.nbp_run && last_nbp_cfg->nbp_nc == c.nbp_nc &&
+                        last_nbp_cfg->nbp_wintype == c.nbp_wintype && last_nbp_cfg->nbp_flow == c.nbp_flow &&
+                        last_nbp_cfg->nbp_fhigh == c.nbp_fhigh && last_nbp_cfg->nbp_gain == c.nbp_gain;
+            if (!same) {
+                std::vector<cd> h;
+                if (c.nbp_run)
+                    h = fir_bandpass(c.nbp_nc, c.nbp_flow, c.nbp_fhigh, (double)dsp_rate, c.nbp_wintype, 1,
+                                     c.nbp_gain / (double)(2 * dsp_size));
+                else
+                    h.assign(1, cd(1.0, 0.0));
+                // the reference's unnormalised inverse FFT of 2*size points restores the 1/(2*size)
+                if (c.nbp_run) for (auto &v : h) v *= (double)(2 * dsp_size);
+                last_nbp = make_mask(h, kNfft);
+                last_nbp_cfg = &c;
+            }
+            QH_HIP(hipMemcpyAsync(mask_nbp + (size_t)ch * kNfft, last_nbp.data(), kNfft * sizeof(cd), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.nbp_dirty = false;
+        }
+        if (c.bp1_dirty) {
+            bool same = last_bp1_cfg && last_bp1_cfg->bp1_run == c.bp1_run && last_bp1_cfg->bp1_nc == c.bp1_nc &&
+                        last_bp1_cfg->bp1_wintype == c.bp1_wintype && last_bp1_cfg->bp1_flow == c.bp1_flow &&
+                        last_bp1_cfg->bp1_fhigh == c.bp1_fhigh && last_bp1_cfg->bp1_gain == c.bp1_gain;
+            if (!same) {
+                std::vector<cd> h;
+                if (c.bp1_run) {
+                    h = fir_bandpass(c.bp1_nc, c.bp1_flow, c.bp1_fhigh, (double)dsp_rate, c.bp1_wintype, 1,
+                                     c.bp1_gain / (double)(2 * dsp_size));     // wdsp/bandpass.c:302
+                    for (auto &v : h) v *= (double)(2 * dsp_size);
+                } else {
+                    h.assign(1, cd(1.0, 0.0));
+                }
+                last_bp1 = make_mask(h, kNfft);
+                last_bp1_cfg = &c;
+            }
+            QH_HIP(hipMemcpyAsync(mask_bp1 + (size_t)ch * kNfft, last_bp1.data(), kNfft * sizeof(cd), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.bp1_dirty = false;
+        }
+        if (c.nbp_flush) {      // setNc_fircore re-plans and so zeroes the delay line, wdsp/firmin.c:454-466
+            for (int i = 0; i < 2; i++)
+                QH_HIP(hipMemsetAsync(hist_nbp[i] + (size_t)ch * kHistBand, 0, kHistBand * sizeof(double2), stream));
+            c.nbp_flush = false;
+        }
+        if (c.bp1_flush) {      // flush_bandpass on off->on (RXA.c:825) and setNc_fircore
+            for (int i = 0; i < 2; i++)
+                QH_HIP(hipMemsetAsync(hist_bp1[i] + (size_t)ch * kHistBand, 0, kHistBand * sizeof(double2), stream));
+            c.bp1_flush = false;
+        }
+    }
+    return QH_OK;
+}
+
+int Engine::ensure_buffers(long long n_mid)
+{
+    if (n_mid <= buf_cap) return QH_OK;
+    QH_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < 2; i++) {
+        if (buf[i]) { QH_HIP(hipFree(buf[i])); dev_bytes -= buf_cap * nch * (long long)sizeof(double2); buf[i] = nullptr; }
+    }
+    for (int i = 0; i < 2; i++) {
+        QH_HIP(dev_alloc(&buf[i], (size_t)nch * (size_t)n_mid));
+        dev_bytes += n_mid * nch * (long long)sizeof(double2);
+    }
+    buf_cap = n_mid;
+    return QH_OK;
+}
+
+void Engine::tick(int cat)
+{
+    if (!timing) return;
+    if (ev_used >= (int)ev.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        ev.push_back(e);
+        ev_cat.push_back(0);
+    }
+    ev_cat[(size_t)ev_used] = cat;
+    (void)hipEventRecord(ev[(size_t)ev_used], stream);
+    ev_used++;
+}
+
+template <int D, bool MIX>
+static void launch_osfir(const OsfirArgs<double> &a, int ntiles, int nch, hipStream_t s)
+{
+    dim3 grid((unsigned)ntiles, (unsigned)nch), block(NT);
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX>), grid, block, kNfft * sizeof(double2), s, a);
+}
+
+int Engine::process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
+{
+    if (nblk <= 0) return QH_OK;
+    QH_HIP(hipSetDevice(device));
+    // what the chain of every channel needs
+    bool any_nbp = false, any_bp1 = false;
+    int nc_max = 1;
+    for (const ChanCfg &c : cfg) {
+        if (c.agc_run && c.agc_mode != 0)
+            return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not on the GPU path yet: call SetRXAAGCMode(ch, 0)", c.agc_mode);
+        if (c.amd_run || c.fmd_run)
+            return set_error(QH_ERR_UNSUPPORTED, "AM/SAM/FM demodulators are not on the GPU path yet");
+        if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
+        if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
+    }
+    if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
+    if (int rc = refresh_params()) return rc;
+
+    const long long n_in = (long long)nblk * dsp_insize;
+    const long long n_mid = (long long)nblk * dsp_size;
+    if (n_in > 0x7fffffffLL) return set_error(QH_ERR_INVALID, "too many samples in one call");
+    if (int rc = ensure_buffers(n_mid)) return rc;
+    ev_used = 0;
+
+    const double2 *in = reinterpret_cast<const double2 *>(d_in);
+    double2 *out = reinterpret_cast<double2 *>(d_out);
+    const int nstage = 1 + (any_nbp ? 1 : 0) + (any_bp1 ? 1 : 0);
+    int stage = 0;
+    const double2 *cur = in;
+    long long cur_stride = in_stride;
+    int which = 0;
+    auto dst_of = [&](int st, long long &stride) -> double2 * {
+        if (st == nstage - 1) { stride = out_stride; return out; }
+        stride = buf_cap;
+        double2 *p = buf[which];
+        which ^= 1;
+        return p;
+    };
+
+    // ---- front: xshift + xresample(in)
+    tick(0);
+    {
+        long long dst_stride;
+        double2 *dst = dst_of(stage, dst_stride);
+        const EpiParam *ep = (stage == nstage - 1) ? epi : nullptr;
+        if (D > 1) {
+            OsfirArgs<double> a{};
+            a.in = cur; a.in_stride = cur_stride;
+            a.hist = hist_front[cur_front]; a.hist_stride = kHistFront; a.hist_len = kHistFront;
+            a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
+            a.mask = mask_front; a.mask_stride = 0;
+            a.tw_fwd = tw4096; a.tw_inv = tw_inv_front;
+            a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
+            a.epi = ep;
+            a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L;
+            const int ntiles = (int)((n_mid + front_L - 1) / front_L);
+            switch (D) {
+            case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
+            default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
+            }
+            tick(2);
+            dim3 g((kHistFront + NT - 1) / NT, (unsigned)nch);
+            hipLaunchKernelGGL((hist_update_kernel<double, true>), g, dim3(NT), 0, stream, cur, cur_stride, (int)n_in,
+                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase);
+            cur_front ^= 1;
+        } else {
+            long long per = (n_in + NT - 1) / NT;
+            dim3 g((unsigned)(per < 4096 ? per : 4096), (unsigned)nch);
+            hipLaunchKernelGGL((pointwise_kernel<double, true>), g, dim3(NT), 0, stream, cur, cur_stride, dst, dst_stride,
+                               (int)n_in, nco_phase, nco_dphase, ep);
+            tick(2);
+        }
+        hipLaunchKernelGGL(nco_advance_kernel, dim3((nch + 255) / 256), dim3(256), 0, stream, nco_phase, nco_dphase, nch, n_in);
+        cur = dst; cur_stride = dst_stride;
+        stage++;
+    }
+
+    // ---- nbp0 and bp1: fircore stages at the DSP rate
+    const int P = nc_max - 1;
+    const int Lout = kNfft - P;
+    const int ntiles = (int)((n_mid + Lout - 1) / Lout);
+    for (int f = 0; f < 2; f++) {
+        if (f == 0 ? !any_nbp : !any_bp1) continue;
+        double2 **hist = f == 0 ? hist_nbp : hist_bp1;
+        int &hc = f == 0 ? cur_nbp : cur_bp1;
+        long long dst_stride;
+        double2 *dst = dst_of(stage, dst_stride);
+        OsfirArgs<double> a{};
+        a.in = cur; a.in_stride = cur_stride;
+        a.hist = hist[hc]; a.hist_stride = kHistBand; a.hist_len = kHistBand;
+        a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
+        a.mask = f == 0 ? mask_nbp : mask_bp1; a.mask_stride = kNfft;
+        a.tw_fwd = tw4096; a.tw_inv = tw4096;
+        a.epi = (stage == nstage - 1) ? epi : nullptr;
+        a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
+        tick(1);
+        launch_osfir<1, false>(a, ntiles, nch, stream);
+        tick(2);
+        dim3 g((kHistBand + NT - 1) / NT, (unsigned)nch);
+        hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, cur, cur_stride, (int)n_mid,
+                           hist[hc], hist[hc ^ 1], kHistBand, (const unsigned long long *)nullptr,
+                           (const unsigned long long *)nullptr);
+        hc ^= 1;
+        cur = dst; cur_stride = dst_stride;
+        stage++;
+    }
+    tick(3);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+}  // namespace qh
+
+// ------------------------------------------------------------------------------------------ C ABI
+using namespace qh;
+
+struct qh_rxa { Engine e; };
+
+extern "C" {
+
+int qh_version(void) { return 100; }
+const char *qh_last_error(void) { return g_last_error.c_str(); }
+
+int qh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_rate, int out_rate, void *stream)
+{
+    if (nch <= 0 || dsp_size <= 0 || (dsp_size & (dsp_size - 1)) || in_rate <= 0 || dsp_rate <= 0) {
+        set_error(QH_ERR_INVALID, "qh_rxa_create: bad arguments");
+        return nullptr;
+    }
+    if (out_rate != dsp_rate) { set_error(QH_ERR_UNSUPPORTED, "out_rate must equal dsp_rate"); return nullptr; }
+    if (in_rate % dsp_rate) { set_error(QH_ERR_UNSUPPORTED, "in_rate must be a multiple of dsp_rate"); return nullptr; }
+    const int D = in_rate / dsp_rate;
+    if (D != 1 && D != 2 && D != 4 && D != 8) { set_error(QH_ERR_UNSUPPORTED, "in_rate/dsp_rate must be 1, 2, 4 or 8"); return nullptr; }
+    if (qh_device_count() <= device || device < 0) {
+        set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
+        return nullptr;
+    }
+    qh_rxa *h = new qh_rxa();
+    h->e.device = device; h->e.nch = nch; h->e.dsp_size = dsp_size;
+    h->e.in_rate = in_rate; h->e.dsp_rate = dsp_rate; h->e.out_rate = out_rate; h->e.D = D;
+    h->e.stream = (hipStream_t)stream;
+    if (h->e.init() != QH_OK) { delete h; return nullptr; }
+    return h;
+}
+
+void qh_rxa_destroy(qh_rxa *h) { delete h; }
+int qh_rxa_nch(const qh_rxa *h) { return h->e.nch; }
+int qh_rxa_dsp_insize(const qh_rxa *h) { return h->e.dsp_insize; }
+int qh_rxa_dsp_outsize(const qh_rxa *h) { return h->e.dsp_outsize; }
+long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
+
+#define FOR_CH(h, ch, body)                                                                       \
+    do {                                                                                          \
+        if (!(h)) return set_error(QH_ERR_INVALID, "null engine");                                \
+        if ((ch) < -1 || (ch) >= (h)->e.nch) return set_error(QH_ERR_INVALID, "channel %d out of range", (ch)); \
+        int _lo = (ch) < 0 ? 0 : (ch), _hi = (ch) < 0 ? (h)->e.nch : (ch) + 1;                    \
+        for (int _i = _lo; _i < _hi; _i++) { ChanCfg &c = (h)->e.cfg[(size_t)_i]; body }         \
+        return QH_OK;                                                                             \
+    } while (0)
+
+// RXAbp1Check + RXAbp1Set, wdsp/RXA.c:800-827 (snba/emnr/anf/anr never run here)
+static void bp1_check_set(ChanCfg &c, int amd_run)
+{
+    const double gain = amd_run ? 2.0 : 1.0;
+    if (c.bp1_gain != gain) { c.bp1_gain = gain; c.bp1_dirty = true; }
+}
+static void bp1_set(ChanCfg &c)
+{
+    const int old = c.bp1_run;
+    c.bp1_run = c.amd_run ? 1 : 0;
+    if (old != c.bp1_run) c.bp1_dirty = true;
+    if (!old && c.bp1_run) c.bp1_flush = true;
+}
+
+int qh_rxa_SetRXAMode(qh_rxa *h, int ch, int mode)
+{
+    FOR_CH(h, ch, {
+        if (c.mode != mode) {       // wdsp/RXA.c:748-787
+            const int amd_run = (mode == QH_AM) || (mode == QH_SAM);
+            bp1_check_set(c, amd_run);
+            c.mode = mode;
+            c.amd_run = 0; c.fmd_run = 0; c.agc_run = 1;
+            if (mode == QH_AM) { c.amd_run = 1; c.amd_mode = 0; }
+            else if (mode == QH_SAM) { c.amd_run = 1; c.amd_mode = 1; }
+            else if (mode == QH_FM) { c.fmd_run = 1; c.agc_run = 0; }
+            bp1_set(c);
+            c.epi_dirty = true;
+        }
+    });
+}
+
+int qh_rxa_SetRXABandpassFreqs(qh_rxa *h, int ch, double f_low, double f_high)
+{
+    FOR_CH(h, ch, {
+        if (f_low != c.bp1_flow || f_high != c.bp1_fhigh) { c.bp1_flow = f_low; c.bp1_fhigh = f_high; c.bp1_dirty = true; }
+    });
+}
+
+int qh_rxa_RXANBPSetFreqs(qh_rxa *h, int ch, double flow, double fhigh)
+{
+    FOR_CH(h, ch, {
+        if (flow != c.nbp_flow || fhigh != c.nbp_fhigh) { c.nbp_flow = flow; c.nbp_fhigh = fhigh; c.nbp_dirty = true; }
+    });
+}
+
+int qh_rxa_RXASetPassband(qh_rxa *h, int ch, double f_low, double f_high)
+{
+    int rc = qh_rxa_SetRXABandpassFreqs(h, ch, f_low, f_high);
+    if (rc) return rc;
+    return qh_rxa_RXANBPSetFreqs(h, ch, f_low, f_high);
+}
+
+int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
+{
+    if (nc < 1 || (nc & (nc - 1)) || nc > kHistBand + 1 || (h && nc < h->e.dsp_size))
+        return set_error(QH_ERR_UNSUPPORTED, "nc must be a power of two in [dsp_size, %d]", kHistBand + 1);
+    FOR_CH(h, ch, {
+        if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; }
+        if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; }
+    });
+}
+
+int qh_rxa_SetRXAShiftRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.shift_run = run; c.nco_dirty = true; }); }
+int qh_rxa_SetRXAShiftFreq(qh_rxa *h, int ch, double f) { FOR_CH(h, ch, { c.shift_freq = f; c.nco_dirty = true; }); }
+int qh_rxa_RXANBPSetRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.nbp_run != run) { c.nbp_run = run; c.nbp_dirty = true; } }); }
+int qh_rxa_SetRXABandpassRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.bp1_run != run) { c.bp1_run = run; c.bp1_dirty = true; } }); }
+
+int qh_rxa_SetRXAAGCMode(qh_rxa *h, int ch, int mode)
+{
+    FOR_CH(h, ch, { c.agc_mode = (mode >= 0 && mode <= 4) ? mode : 5; c.epi_dirty = true; });
+}
+
+int qh_rxa_SetRXAAGCFixed(qh_rxa *h, int ch, double db)
+{
+    FOR_CH(h, ch, { c.agc_fixed = std::pow(10.0, db / 20.0); c.epi_dirty = true; });
+}
+
+int qh_rxa_SetRXAPanelGain1(qh_rxa *h, int ch, double g) { FOR_CH(h, ch, { c.gain1 = g; c.epi_dirty = true; }); }
+int qh_rxa_SetRXAPanelGain2(qh_rxa *h, int ch, double gI, double gQ) { FOR_CH(h, ch, { c.gain2I = gI; c.gain2Q = gQ; c.epi_dirty = true; }); }
+int qh_rxa_SetRXAPanelSelect(qh_rxa *h, int ch, int s) { FOR_CH(h, ch, { c.inselect = s; c.epi_dirty = true; }); }
+int qh_rxa_SetRXAPanelCopy(qh_rxa *h, int ch, int cp) { FOR_CH(h, ch, { c.copy = cp; c.epi_dirty = true; }); }
+
+int qh_rxa_process(qh_rxa *h, const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    if (!d_in || !d_out) return set_error(QH_ERR_INVALID, "null buffer");
+    if (in_stride < (long long)nblk * h->e.dsp_insize || out_stride < (long long)nblk * h->e.dsp_outsize)
+        return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
+    return h->e.process(d_in, in_stride, d_out, out_stride, nblk);
+}
+
+// flush_rxa (wdsp/RXA.c:527-559): NCO phase, resampler ring and fircore delay lines back to zero
+int qh_rxa_flush(qh_rxa *h)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    Engine &e = h->e;
+    QH_HIP(hipSetDevice(e.device));
+    QH_HIP(hipMemsetAsync(e.nco_phase, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
+    for (int i = 0; i < 2; i++) {
+        if (e.hist_front[i]) QH_HIP(hipMemsetAsync(e.hist_front[i], 0, (size_t)e.nch * kHistFront * sizeof(double2), e.stream));
+        QH_HIP(hipMemsetAsync(e.hist_nbp[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
+        QH_HIP(hipMemsetAsync(e.hist_bp1[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
+    }
+    return QH_OK;
+}
+
+int qh_rxa_synchronize(qh_rxa *h)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_HIP(hipSetDevice(h->e.device));
+    QH_HIP(hipStreamSynchronize(h->e.stream));
+    return QH_OK;
+}
+
+int qh_rxa_process_host(qh_rxa *h, const double *h_in, long long in_stride, double *h_out, long long out_stride, int nblk)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    if (!h_in || !h_out) return set_error(QH_ERR_INVALID, "null buffer");
+    Engine &e = h->e;
+    QH_HIP(hipSetDevice(e.device));
+    const long long n_in = (long long)nblk * e.dsp_insize, n_out = (long long)nblk * e.dsp_outsize;
+    double2 *din = nullptr, *dout = nullptr;
+    QH_HIP(dev_alloc(&din, (size_t)e.nch * (size_t)n_in));
+    QH_HIP(dev_alloc(&dout, (size_t)e.nch * (size_t)n_out));
+    int rc = QH_OK;
+    hipError_t err = hipMemcpy2DAsync(din, (size_t)n_in * sizeof(double2), h_in, (size_t)in_stride * sizeof(double2),
+                                      (size_t)n_in * sizeof(double2), (size_t)e.nch, hipMemcpyHostToDevice, e.stream);
+    if (err == hipSuccess) {
+        rc = e.process(reinterpret_cast<const double *>(din), n_in, reinterpret_cast<double *>(dout), n_out, nblk);
+        if (rc == QH_OK)
+            err = hipMemcpy2DAsync(h_out, (size_t)out_stride * sizeof(double2), dout, (size_t)n_out * sizeof(double2),
+                                   (size_t)n_out * sizeof(double2), (size_t)e.nch, hipMemcpyDeviceToHost, e.stream);
+    }
+    hipError_t err2 = hipStreamSynchronize(e.stream);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (rc != QH_OK) return rc;
+    if (err != hipSuccess) return set_error(QH_ERR_HIP, "copy failed: %s", hipGetErrorString(err));
+    if (err2 != hipSuccess) return set_error(QH_ERR_HIP, "synchronize failed: %s", hipGetErrorString(err2));
+    return QH_OK;
+}
+
+int qh_rxa_enable_timing(qh_rxa *h, int enable)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    h->e.timing = enable != 0;
+    return QH_OK;
+}
+
+int qh_rxa_timing(qh_rxa *h, double *ms, int n)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    Engine &e = h->e;
+    QH_HIP(hipSetDevice(e.device));
+    QH_HIP(hipStreamSynchronize(e.stream));
+    double acc[3] = { 0, 0, 0 };
+    for (int i = 0; i + 1 < e.ev_used; i++) {
+        float t = 0;
+        QH_HIP(hipEventElapsedTime(&t, e.ev[(size_t)i], e.ev[(size_t)i + 1]));
+        int cat = e.ev_cat[(size_t)i];
+        if (cat >= 0 && cat < 3) acc[cat] += t;
+    }
+    for (int k = 0; k < 3; k++) { e.last_ms[k] = acc[k]; if (k < n) ms[k] = acc[k]; }
+    return n < 3 ? n : 3;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// qh_fft.hpp -- fp64 / fp32 complex FFT building blocks for gfx950 (CDNA4), LDS resident.
+//
+// Replaces the FFTW3 calls of the reference hot path (fftw_plan_dft_1d + fftw_execute at
+// wdsp/firmin.c:313-318,412,428 and quisk.c:5215,5999): unnormalised DFT, sign -1 forward.
+//
+// Design (MI355X): one workgroup of NT = 256 threads (4 wavefronts of 64) transforms N points
+// held in LDS as interleaved complex (ds_read_b128 / ds_write_b128 per element).  Stockham
+// autosort passes with large radices (16 for N = 4096) keep the number of LDS round trips at
+// log16(N) - 1; the first pass takes its inputs from registers and the last pass leaves its
+// outputs in registers, both in the "strided register layout"
+//        thread t holds elements  t + NT * i,   i = 0 .. N/NT - 1,
+// so that global loads/stores are coalesced (consecutive lanes, 16 B each) and so that a
+// frequency-domain mask multiply, a spectral fold (decimation) and the first inverse pass
+// need no LDS traffic at all.  LDS element i lives at i ^ ((i >> 4) & 15): the XOR swizzle
+// makes the stride-R scatter of the early passes bank-conflict free for ds_write_b128 while
+// consecutive-lane reads stay conflict free.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace qh {
+
+constexpr int NT = 256;     // threads per workgroup for every kernel in this file
+
+template <typename T> struct cplx_of;
+template <> struct cplx_of<double> { using type = double2; };
+template <> struct cplx_of<float>  { using type = float2; };
+template <typename T> using cplx = typename cplx_of<T>::type;
+
+template <typename T> __device__ __forceinline__ cplx<T> mk(T x, T y) { cplx<T> r; r.x = x; r.y = y; return r; }
+template <typename C> __device__ __forceinline__ C cadd(C a, C b) { C r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+template <typename C> __device__ __forceinline__ C csub(C a, C b) { C r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+template <typename C> __device__ __forceinline__ C cmul(C a, C b)
+{
+    C r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+template <typename C> __device__ __forceinline__ C cconj(C a) { C r; r.x = a.x; r.y = -a.y; return r; }
+// a * (-i) (forward) or a * (+i) (inverse)
+template <bool INV, typename C> __device__ __forceinline__ C mul_mi(C a)
+{
+    C r;
+    if (INV) { r.x = -a.y; r.y = a.x; } else { r.x = a.y; r.y = -a.x; }
+    return r;
+}
+
+// cos(2*pi*a/32), a = 0..8
+__device__ __forceinline__ constexpr double cos32(int a)
+{
+    constexpr double t[9] = { 1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                              0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                              0.19509032201612826785, 0.0 };
+    return t[a];
+}
+
+// multiply by W_R^i = exp(-+ 2*pi*i*I/R), I a compile-time index in [0, R/2)
+template <int R, int I, bool INV, typename C> __device__ __forceinline__ C mul_wconst(C a)
+{
+    using T = decltype(a.x);
+    constexpr int A = I * (32 / R);            // angle in units of 2*pi/32, 0 <= A < 16
+    if constexpr (A == 0) {
+        return a;
+    } else if constexpr (A == 8) {
+        return mul_mi<INV>(a);
+    } else if constexpr (A == 4) {             // (1 -+ i)/sqrt2
+        const T s = (T)0.70710678118654752440;
+        C r;
+        if (INV) { r.x = (a.x - a.y) * s; r.y = (a.x + a.y) * s; }
+        else     { r.x = (a.x + a.y) * s; r.y = (a.y - a.x) * s; }
+        return r;
+    } else if constexpr (A == 12) {            // (-1 -+ i)/sqrt2
+        const T s = (T)0.70710678118654752440;
+        C r;
+        if (INV) { r.x = -(a.x + a.y) * s; r.y = (a.x - a.y) * s; }
+        else     { r.x = (a.y - a.x) * s;  r.y = -(a.x + a.y) * s; }
+        return r;
+    } else {
+        constexpr double c = (A <= 8) ? cos32(A) : -cos32(16 - A);
+        constexpr double s = (A <= 8) ? cos32(8 - A) : cos32(A - 8);     // sin(2*pi*A/32) >= 0
+        C w;
+        w.x = (T)c;
+        w.y = INV ? (T)s : (T)(-s);
+        return cmul(a, w);
+    }
+}
+
+// In-register DFT of R points (R = 1, 2, 4, 8, 16, 32), natural order in and out.
+// Radix-2 decimation-in-frequency recursion, fully unrolled; twiddles are literals.
+template <int R, bool INV, typename C> struct Dft {
+    template <int I> static __device__ __forceinline__ void stage(C (&x)[R], C (&a)[R / 2], C (&b)[R / 2])
+    {
+        if constexpr (I < R / 2) {
+            a[I] = cadd(x[I], x[I + R / 2]);
+            b[I] = mul_wconst<R, I, INV>(csub(x[I], x[I + R / 2]));
+            stage<I + 1>(x, a, b);
+        }
+    }
+    static __device__ __forceinline__ void run(C (&x)[R])
+    {
+        C a[R / 2], b[R / 2];
+        stage<0>(x, a, b);
+        Dft<R / 2, INV, C>::run(a);
+        Dft<R / 2, INV, C>::run(b);
+#pragma unroll
+        for (int q = 0; q < R / 2; q++) { x[2 * q] = a[q]; x[2 * q + 1] = b[q]; }
+    }
+};
+template <bool INV, typename C> struct Dft<1, INV, C> { static __device__ __forceinline__ void run(C (&)[1]) {} };
+
+__device__ __forceinline__ int lds_phys(int i) { return i ^ ((i >> 4) & 15); }
+
+// Powers w^1 .. w^(R-1) applied to x[1..R-1]; products formed by squaring/multiplying with
+// depth <= log2(R) so the rounding error stays at a few ulp.
+template <int R, typename C> __device__ __forceinline__ void apply_twiddle_powers(C (&x)[R], C w1)
+{
+    C w[R];
+    w[1] = w1;
+#pragma unroll
+    for (int r = 2; r < R; r++) {
+        // r = hi + lo with hi the top set bit: w^r = w^hi * w^lo; w^hi by squaring
+        int hi = 1;
+        while (hi * 2 <= r) hi *= 2;
+        int lo = r - hi;
+        w[r] = (lo == 0) ? cmul(w[hi / 2], w[hi / 2]) : cmul(w[hi], w[lo]);
+    }
+#pragma unroll
+    for (int r = 1; r < R; r++) x[r] = cmul(x[r], w[r]);
+}
+
+// One Stockham pass of radix R over N points for butterfly j, data in registers x[r] = in[j + r*N/R].
+// Applies the inter-pass twiddle (Ns = product of the radices of the earlier passes), the R-point DFT,
+// and returns the output position of x[0]; x[r] belongs at  base + r*Ns.
+template <int N, int R, int Ns, bool INV, typename C>
+__device__ __forceinline__ int stockham_butterfly(C (&x)[R], int j, const C *__restrict__ tw_pass)
+{
+    int k = j & (Ns - 1);
+    if constexpr (Ns > 1) {
+        C w1 = tw_pass[k];                  // exp(-2*pi*i*k/(Ns*R))
+        if (INV) w1 = cconj(w1);
+        apply_twiddle_powers<R>(x, w1);
+    }
+    Dft<R, INV, C>::run(x);
+    return (j - k) * R + k;
+}
+
+// pass: registers (strided layout, requires R == N/NT, Ns == 1) -> LDS
+template <int N, int R, bool INV, typename C>
+__device__ __forceinline__ void pass_regs_to_lds(C (&x)[R], C *lds)
+{
+    static_assert(R == N / NT, "first pass radix must equal N/NT");
+    const int j = threadIdx.x;
+    Dft<R, INV, C>::run(x);
+#pragma unroll
+    for (int r = 0; r < R; r++) lds[lds_phys(j * R + r)] = x[r];
+}
+
+// pass: LDS -> LDS (in place; barrier between the read and the write phase)
+template <int N, int R, int Ns, bool INV, typename C>
+__device__ __forceinline__ void pass_lds_to_lds(C *lds, const C *__restrict__ tw_pass)
+{
+    constexpr int NB = N / R;               // butterflies in this pass
+    constexpr int PER = (NB + NT - 1) / NT; // per thread
+    C x[PER][R];
+    int base[PER];
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        int j = threadIdx.x + p * NT;
+        if (NB >= NT || j < NB) {
+#pragma unroll
+            for (int r = 0; r < R; r++) x[p][r] = lds[lds_phys(j + r * NB)];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        int j = threadIdx.x + p * NT;
+        if (NB >= NT || j < NB) base[p] = stockham_butterfly<N, R, Ns, INV>(x[p], j, tw_pass);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        int j = threadIdx.x + p * NT;
+        if (NB >= NT || j < NB) {
+#pragma unroll
+            for (int r = 0; r < R; r++) lds[lds_phys(base[p] + r * Ns)] = x[p][r];
+        }
+    }
+}
+
+// pass: LDS -> registers (strided layout; requires R == N/NT and Ns == N/R, the last pass)
+template <int N, int R, bool INV, typename C>
+__device__ __forceinline__ void pass_lds_to_regs(const C *lds, C (&x)[R], const C *__restrict__ tw_pass)
+{
+    static_assert(R == N / NT, "last pass radix must equal N/NT");
+    const int j = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; r++) x[r] = lds[lds_phys(j + r * NT)];
+    stockham_butterfly<N, R, N / R, INV>(x, j, tw_pass);   // output of x[r] is element j + r*NT
+}
+
+// ---------------------------------------------------------------------------------------------
+// Radix plans.  first == last == N/NT; the middle radices multiply to NT*NT/N ... (N/first/last).
+// Twiddle tables: one per pass with Ns > 1, concatenated; entry k of a pass is exp(-2*pi*i*k/(Ns*R)).
+// Offsets below must match qh::fft_twiddle_table() in qh_design.cpp.
+template <int N> struct Plan;
+//            N      passes (radix)                  Ns per pass          table offsets
+template <> struct Plan<4096> { static constexpr int first = 16; };   // 16,16,16        1,16,256            [0,16)  [16,272)
+template <> struct Plan<2048> { static constexpr int first = 8; };    // 8,4,8,8         1,8,32,256          [0,8) [8,40) [40,296)
+template <> struct Plan<1024> { static constexpr int first = 4; };    // 4,4,4,4,4       1,4,16,64,256       [0,4) [4,20) [20,84) [84,340)
+template <> struct Plan<512>  { static constexpr int first = 2; };    // 2,16,8,2        1,2,32,256          [0,2) [2,34) [34,290)
+template <> struct Plan<8192> { static constexpr int first = 32; };   // 32,8,32         1,32,256            [0,32) [32,288)
+
+// Forward or inverse FFT: registers (strided layout) -> registers (strided layout), through LDS.
+// x has N/NT entries.  `tw` points at this N's concatenated pass tables.
+template <int N, bool INV, typename C> struct FftRR;
+
+template <bool INV, typename C> struct FftRR<4096, INV, C> {
+    static __device__ __forceinline__ void run(C (&x)[16], C *lds, const C *__restrict__ tw)
+    {
+        pass_regs_to_lds<4096, 16, INV>(x, lds);
+        __syncthreads();
+        pass_lds_to_lds<4096, 16, 16, INV>(lds, tw);
+        __syncthreads();
+        pass_lds_to_regs<4096, 16, INV>(lds, x, tw + 16);
+    }
+};
+
+template <bool INV, typename C> struct FftRR<2048, INV, C> {
+    static __device__ __forceinline__ void run(C (&x)[8], C *lds, const C *__restrict__ tw)
+    {
+        pass_regs_to_lds<2048, 8, INV>(x, lds);
+        __syncthreads();
+        pass_lds_to_lds<2048, 4, 8, INV>(lds, tw);
+        __syncthreads();
+        pass_lds_to_lds<2048, 8, 32, INV>(lds, tw + 8);
+        __syncthreads();
+        pass_lds_to_regs<2048, 8, INV>(lds, x, tw + 40);
+    }
+};
+
+template <bool INV, typename C> struct FftRR<1024, INV, C> {
+    static __device__ __forceinline__ void run(C (&x)[4], C *lds, const C *__restrict__ tw)
+    {
+        pass_regs_to_lds<1024, 4, INV>(x, lds);
+        __syncthreads();
+        pass_lds_to_lds<1024, 4, 4, INV>(lds, tw);
+        __syncthreads();
+        pass_lds_to_lds<1024, 4, 16, INV>(lds, tw + 4);
+        __syncthreads();
+        pass_lds_to_lds<1024, 4, 64, INV>(lds, tw + 20);
+        __syncthreads();
+        pass_lds_to_regs<1024, 4, INV>(lds, x, tw + 84);
+    }
+};
+
+template <bool INV, typename C> struct FftRR<512, INV, C> {
+    static __device__ __forceinline__ void run(C (&x)[2], C *lds, const C *__restrict__ tw)
+    {
+        pass_regs_to_lds<512, 2, INV>(x, lds);
+        __syncthreads();
+        pass_lds_to_lds<512, 16, 2, INV>(lds, tw);
+        __syncthreads();
+        pass_lds_to_lds<512, 8, 32, INV>(lds, tw + 2);
+        __syncthreads();
+        pass_lds_to_regs<512, 2, INV>(lds, x, tw + 34);
+    }
+};
+
+template <bool INV, typename C> struct FftRR<8192, INV, C> {
+    static __device__ __forceinline__ void run(C (&x)[32], C *lds, const C *__restrict__ tw)
+    {
+        pass_regs_to_lds<8192, 32, INV>(x, lds);
+        __syncthreads();
+        pass_lds_to_lds<8192, 8, 32, INV>(lds, tw);
+        __syncthreads();
+        pass_lds_to_regs<8192, 32, INV>(lds, x, tw + 32);
+    }
+};
+
+}  // namespace qh

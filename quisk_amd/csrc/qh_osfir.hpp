@@ -1,0 +1,157 @@
+// qh_osfir.hpp -- batched overlap-save complex FIR + integer decimation for gfx950.
+//
+// One workgroup (256 threads) computes one tile of one receiver channel:
+//
+//     y[m] = sum_k h[k] * x'[D*m + off - k],      x'[n] = x[n] * exp(j*(phase0 + n*delta))   (MIX)
+//
+// which is, with D = 1: WDSP's partitioned overlap-save "fircore" (wdsp/firmin.c:409-430: the
+// partitions sum to one causal linear convolution with the nc-tap complex impulse), and with
+// real taps and D > 1: WDSP's polyphase resampler for L = 1 (wdsp/resample.c:120-157, preceded
+// by xshift, wdsp/shift.c:60-85, when MIX) and Quisk's quisk_cDecimate / quisk_cCDecimate
+// (filter.c:203-257; off = decim - 1 - decim_index).
+//
+// Per tile: NFFT inputs (P = pre-roll >= ntaps-1 samples of history + Lout*D new ones) are
+// loaded straight from HBM into registers (16 B per lane, consecutive lanes), rotated by the
+// NCO, transformed (qh_fft.hpp), multiplied by the frequency-domain mask H = FFT(h)/NFFT and
+// folded D-fold (decimation in time == aliasing sum in frequency) without leaving registers,
+// inverse transformed at NFFT/D points, and the Lout valid outputs are stored straight from
+// registers through a per-channel 2x2 real epilogue (fixed AGC gain and the patch panel,
+// wdsp/wcpAGC.c:167-175, wdsp/patchpanel.c:55-101).
+//
+// HBM traffic per tile = NFFT*16 B read (P/NFFT of it re-read history) + Lout*16 B written;
+// masks and twiddles are L2 resident.
+#pragma once
+#include "qh_fft.hpp"
+
+namespace qh {
+
+// NCO state, one entry per channel (struct of arrays so that the phase can live on the device):
+//   phase  : phase at input index 0 of the call, in turns * 2^64 (wraps exactly like angle mod 2*pi)
+//   dphase : phase step per input sample, turns * 2^64
+//   step   : exp(j*2*pi*NT*dphase), the rotation for a jump of NT samples
+
+struct EpiParam {                 // per channel 2x2 real output matrix: [re';im'] = [[a,b],[c,d]] [re;im]
+    double a, b, c, d;
+};
+
+template <typename T> struct OsfirArgs {
+    const cplx<T> *in;            // [nch][in_stride]; element 0 = first new sample of this call
+    const cplx<T> *hist;          // [nch][hist_stride]; the hist_len samples that precede in[0] (already mixed)
+    cplx<T> *out;                 // [nch][out_stride]; output m is written at out_offset + m
+    const cplx<T> *mask;          // [nch or 1][NFFT]  FFT(h)/NFFT
+    const cplx<T> *tw_fwd;        // pass tables for NFFT
+    const cplx<T> *tw_inv;        // pass tables for NFFT/D
+    const unsigned long long *nco_phase;   // [nch] (MIX only)
+    const unsigned long long *nco_dphase;  // [nch]
+    const double2 *nco_step;               // [nch]
+    const EpiParam *epi;          // [nch] or null
+    long long in_stride, hist_stride, out_stride, mask_stride;
+    long long out_offset;
+    int hist_len;
+    int n_in;                     // new samples available in `in`
+    int n_out;                    // outputs to produce
+    int off;                      // decimation phase
+    int P;                        // pre-roll, multiple of D, >= ntaps - 1
+    int Lout;                     // outputs per tile, <= (NFFT - P) / D
+};
+
+template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
+template <> __device__ __forceinline__ void sincos_turns<double>(unsigned long long ph, double &c, double &s)
+{
+    // top 53 bits -> turns in [0,1); sincospi(2*turns)
+    double t = (double)(ph >> 11) * (1.0 / 9007199254740992.0);
+    sincospi(2.0 * t, &s, &c);
+}
+template <> __device__ __forceinline__ void sincos_turns<float>(unsigned long long ph, float &c, float &s)
+{
+    double t = (double)(ph >> 11) * (1.0 / 9007199254740992.0);
+    double sd, cd;
+    sincospi(2.0 * t, &sd, &cd);           // keep the phase in double; only the product is fp32
+    c = (float)cd; s = (float)sd;
+}
+
+template <typename T, int NFFT, int D, bool MIX>
+__global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
+{
+    using C = cplx<T>;
+    constexpr int E = NFFT / NT;            // elements per thread, forward
+    constexpr int NOUT = NFFT / D;
+    constexpr int EO = E / D;               // elements per thread, inverse
+    static_assert(E % D == 0 && EO >= 1, "decimation must divide NFFT/256");
+    static_assert(NOUT >= 2 * NT, "NFFT/D must be >= 512");
+    extern __shared__ __align__(16) unsigned char smem[];
+    C *lds = reinterpret_cast<C *>(smem);
+
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int ch = blockIdx.y;
+    const long long g0 = (long long)D * tile * a.Lout + a.off - a.P;   // input index of tile element 0
+
+    const C *in = a.in + (long long)ch * a.in_stride;
+    const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
+
+    // ---- load NFFT inputs, strided register layout
+    C x[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        long long g = g0 + t + r * NT;
+        C v = mk<T>(0, 0);
+        if (g >= 0) {
+            if (g < a.n_in) v = in[g];
+        } else if (hist && g + a.hist_len >= 0) {
+            v = hist[g + a.hist_len];
+        }
+        x[r] = v;
+    }
+    if constexpr (MIX) {
+        unsigned long long ph = a.nco_phase[ch] + a.nco_dphase[ch] * (unsigned long long)(g0 + t);
+        C rot;
+        sincos_turns<T>(ph, rot.x, rot.y);
+        const double2 st = a.nco_step[ch];
+        const C step = mk<T>((T)st.x, (T)st.y);
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            long long g = g0 + t + r * NT;
+            if (g >= 0) x[r] = cmul(x[r], rot);      // history is stored already mixed
+            rot = cmul(rot, step);
+        }
+    }
+
+    // ---- forward FFT, registers -> registers
+    FftRR<NFFT, false, C>::run(x, lds, a.tw_fwd);
+
+    // ---- mask multiply + D-fold: thread holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
+    const C *mask = a.mask + (long long)ch * a.mask_stride;
+    C z[EO];
+#pragma unroll
+    for (int i = 0; i < EO; i++) {
+        C acc = cmul(x[i], mask[t + NT * i]);
+#pragma unroll
+        for (int q = 1; q < D; q++) acc = cadd(acc, cmul(x[i + EO * q], mask[t + NT * (i + EO * q)]));
+        z[i] = acc;
+    }
+
+    // ---- inverse FFT at NOUT points
+    __syncthreads();                        // all lanes are done reading LDS in the last forward pass
+    FftRR<NOUT, true, C>::run(z, lds, a.tw_inv);
+
+    // ---- epilogue + store of the Lout valid outputs
+    C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
+    const int j0 = a.P / D;
+    EpiParam ep;
+    if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+#pragma unroll
+    for (int i = 0; i < EO; i++) {
+        int j = t + NT * i;
+        int rel = j - j0;
+        long long m = (long long)tile * a.Lout + rel;
+        if (rel >= 0 && rel < a.Lout && m < a.n_out) {
+            C v;
+            v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
+            v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
+            out[m] = v;
+        }
+    }
+}
+
+}  // namespace qh

@@ -1,0 +1,401 @@
+// qh_wdsp_compat.cpp -- the WDSP exports Quisk binds (include/quiskhip.h group 2) on top of the
+// MI355X engine.  quisk_wdsp.py loads the library by name and calls these through ctypes
+// (quisk_wdsp.py:27-41,79-91); quisk_wdsp.c calls fexchange0 through a function pointer
+// (quisk_wdsp.c:22,57).
+//
+// Each open channel = a one-channel qh_rxa engine + the host-side double ring of wdsp/iobuffs.c.
+// The reference runs xrxa() on a DSP thread that is woken by fexchange0 and publishes the PREVIOUS
+// block's result before it processes the next one (dexchange before xrxa, wdsp/main.c:48-49); with
+// bfo = 1 the caller blocks until output is available, so in sample terms the behaviour is
+// deterministic: output lags input by (DSP_MULT-1)*r2_size + dsp_outsize samples.  The same
+// sequence is executed here synchronously on the calling thread.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "../../include/quiskhip.h"
+#include "qh_internal.hpp"
+
+extern "C" int qh_rxa_flush(qh_rxa *e);
+
+namespace {
+
+constexpr int kMaxChannels = 32;    // wdsp/comm.h:117
+constexpr int kDspMult = 2;         // wdsp/comm.h:118
+constexpr double kPi = 3.1415926535897932;
+
+enum { SL_BEGIN = 0, SL_DELAYUP, SL_UPSLEW, SL_ON, SL_DELAYDOWN, SL_DOWNSLEW, SL_ZERO, SL_OFF };  // iobuffs.c:36-46
+
+struct Chan {
+    bool open = false;
+    qh_rxa *eng = nullptr;
+    int in_size = 0, dsp_size = 0, in_rate = 0, dsp_rate = 0, out_rate = 0;
+    int dsp_insize = 0, dsp_outsize = 0, out_size = 0;
+    int state = 0, exchange = 0, bfo = 1;
+    double tdelayup = 0, tslewup = 0, tdelaydown = 0, tslewdown = 0;
+    // iobuffs (wdsp/iobuffs.h)
+    int r1_outsize = 0, r1_size = 0, r2_insize = 0, r2_size = 0, r1_active = 0, r2_active = 0;
+    std::vector<double> r1, r2, outbuff;
+    int r1_inidx = 0, r1_outidx = 0, r1_unqueued = 0, r2_inidx = 0, r2_outidx = 0, r2_havesamps = 0, r2_unqueued = 0;
+    int sem_buffready = 0, sem_outready = 0;
+    // slews
+    int ustate = SL_BEGIN, dstate = SL_BEGIN, ucount = 0, dcount = 0, ndelup = 0, ndeldown = 0, ntup = 0, ntdown = 0;
+    int upflag = 0, downflag = 0;
+    std::vector<double> cup, cdown;
+    // staging: pinned host + device block buffers
+    double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+};
+
+Chan g_ch[kMaxChannels];
+std::recursive_mutex g_mtx[kMaxChannels];   // csEXCH + csDSP: setters may come from another thread
+thread_local int g_status = QH_OK;
+
+bool valid(int channel)
+{
+    if (channel < 0 || channel >= kMaxChannels) {
+        g_status = qh::set_error(QH_ERR_INVALID, "WDSP channel %d out of range", channel);
+        return false;
+    }
+    return true;
+}
+
+void create_slews(Chan &c)          // wdsp/iobuffs.c:47-82
+{
+    c.ustate = SL_BEGIN; c.dstate = SL_BEGIN; c.ucount = 0; c.dcount = 0;
+    c.ndelup = (int)(c.tdelayup * c.in_rate);
+    c.ndeldown = (int)(c.tdelaydown * c.out_rate);
+    c.ntup = (int)(c.tslewup * c.in_rate);
+    c.ntdown = (int)(c.tslewdown * c.out_rate);
+    c.cup.assign((size_t)c.ntup + 1, 0.0);
+    c.cdown.assign((size_t)c.ntdown + 1, 0.0);
+    double delta = kPi / (double)c.ntup, theta = 0.0;
+    for (int i = 0; i <= c.ntup; i++) { c.cup[(size_t)i] = 0.5 * (1.0 - std::cos(theta)); theta += delta; }
+    delta = kPi / (double)c.ntdown; theta = 0.0;
+    for (int i = 0; i <= c.ntdown; i++) { c.cdown[(size_t)i] = 0.5 * (1.0 + std::cos(theta)); theta += delta; }
+    c.upflag = 0; c.downflag = 0;
+}
+
+void flush_slews(Chan &c)           // wdsp/iobuffs.c:90-98
+{
+    c.ustate = SL_BEGIN; c.dstate = SL_BEGIN; c.ucount = 0; c.dcount = 0; c.upflag = 0; c.downflag = 0;
+}
+
+void init_rings(Chan &c)            // create_iobuffs / flush_iobuffs, wdsp/iobuffs.c:384-455
+{
+    c.r1.assign((size_t)c.r1_active * 2, 0.0);
+    c.r2.assign((size_t)c.r2_active * 2, 0.0);
+    c.outbuff.assign((size_t)c.dsp_outsize * 2, 0.0);
+    c.r1_inidx = 0; c.r1_outidx = 0; c.r1_unqueued = 0;
+    c.r2_inidx = (kDspMult - 1) * c.r2_size;
+    c.r2_outidx = 0;
+    c.r2_havesamps = (kDspMult - 1) * c.r2_size;
+    const int n = c.r2_havesamps / c.out_size;
+    c.r2_unqueued = c.r2_havesamps - n * c.out_size;
+    c.sem_buffready = 0;
+    c.sem_outready = n;
+}
+
+void upslew0(Chan &c, const double *pin)    // wdsp/iobuffs.c:98-160
+{
+    double *pout = c.r1.data() + 2 * c.r1_inidx;
+    for (int i = 0; i < c.in_size; i++) {
+        const double I = pin[2 * i], Q = pin[2 * i + 1];
+        switch (c.ustate) {
+        case SL_BEGIN:
+            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
+            if (I != 0.0 || Q != 0.0) {
+                if (c.ndelup > 0) { c.ustate = SL_DELAYUP; c.ucount = c.ndelup; }
+                else if (c.ntup > 0) { c.ustate = SL_UPSLEW; c.ucount = c.ntup; }
+                else c.ustate = SL_ON;
+            }
+            break;
+        case SL_DELAYUP:
+            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
+            if (c.ucount-- == 0) {
+                if (c.ntup > 0) { c.ustate = SL_UPSLEW; c.ucount = c.ntup; }
+                else c.ustate = SL_ON;
+            }
+            break;
+        case SL_UPSLEW:
+            pout[2 * i] = I * c.cup[(size_t)(c.ntup - c.ucount)];
+            pout[2 * i + 1] = Q * c.cup[(size_t)(c.ntup - c.ucount)];
+            if (c.ucount-- == 0) c.ustate = SL_ON;
+            break;
+        case SL_ON:
+            pout[2 * i] = I; pout[2 * i + 1] = Q;
+            if (i == c.in_size - 1) { c.ustate = SL_BEGIN; c.upflag = 0; }
+            break;
+        }
+    }
+}
+
+void downslew0(Chan &c, double *pout)       // wdsp/iobuffs.c:226-300
+{
+    const double *pin = c.r2.data() + 2 * c.r2_outidx;
+    for (int i = 0; i < c.out_size; i++) {
+        const double I = pin[2 * i], Q = pin[2 * i + 1];
+        switch (c.dstate) {
+        case SL_BEGIN:
+            pout[2 * i] = I; pout[2 * i + 1] = Q;
+            if (c.ndeldown > 0) { c.dstate = SL_DELAYDOWN; c.dcount = c.ndeldown; }
+            else if (c.ntdown > 0) { c.dstate = SL_DOWNSLEW; c.dcount = c.ntdown; }
+            else { c.dstate = SL_ZERO; c.dcount = c.out_size; }
+            break;
+        case SL_DELAYDOWN:
+            pout[2 * i] = I; pout[2 * i + 1] = Q;
+            if (c.dcount-- == 0) {
+                if (c.ntdown > 0) { c.dstate = SL_DOWNSLEW; c.dcount = c.ntdown; }
+                else { c.dstate = SL_ZERO; c.dcount = c.out_size; }
+            }
+            break;
+        case SL_DOWNSLEW:
+            pout[2 * i] = I * c.cdown[(size_t)(c.ntdown - c.dcount)];
+            pout[2 * i + 1] = Q * c.cdown[(size_t)(c.ntdown - c.dcount)];
+            if (c.dcount-- == 0) { c.dstate = SL_ZERO; c.dcount = c.out_size; }
+            break;
+        case SL_ZERO:
+            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
+            if (c.dcount-- == 0) c.dstate = SL_OFF;
+            break;
+        case SL_OFF:
+            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
+            if (i == c.out_size - 1) { c.dstate = SL_BEGIN; c.downflag = 0; }
+            break;
+        }
+    }
+}
+
+// one DSP-thread iteration: dexchange (wdsp/iobuffs.c:583-604) then xrxa on the GPU
+int dsp_iteration(Chan &c)
+{
+    c.r2_havesamps += c.r2_insize;
+    std::memcpy(c.r2.data() + 2 * c.r2_inidx, c.outbuff.data(), (size_t)c.r2_insize * 2 * sizeof(double));
+    if ((c.r2_inidx += c.r2_insize) == c.r2_active) c.r2_inidx = 0;
+    if (c.bfo && (c.r2_unqueued += c.r2_insize) >= c.out_size) {
+        const int n = c.r2_unqueued / c.out_size;
+        c.sem_outready += n;
+        c.r2_unqueued -= n * c.out_size;
+    }
+    std::memcpy(c.h_in, c.r1.data() + 2 * c.r1_outidx, (size_t)c.r1_outsize * 2 * sizeof(double));
+    if ((c.r1_outidx += c.r1_outsize) == c.r1_active) c.r1_outidx = 0;
+    // xrxa: one block through the engine
+    if (hipMemcpy(c.d_in, c.h_in, (size_t)c.dsp_insize * 2 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return qh::set_error(QH_ERR_HIP, "fexchange0: host to device copy failed");
+    int rc = qh_rxa_process(c.eng, c.d_in, c.dsp_insize, c.d_out, c.dsp_outsize, 1);
+    if (rc) return rc;
+    rc = qh_rxa_synchronize(c.eng);
+    if (rc) return rc;
+    if (hipMemcpy(c.h_out, c.d_out, (size_t)c.dsp_outsize * 2 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return qh::set_error(QH_ERR_HIP, "fexchange0: device to host copy failed");
+    std::memcpy(c.outbuff.data(), c.h_out, (size_t)c.dsp_outsize * 2 * sizeof(double));
+    return QH_OK;
+}
+
+void free_staging(Chan &c)
+{
+    if (c.d_in) (void)hipFree(c.d_in);
+    if (c.d_out) (void)hipFree(c.d_out);
+    if (c.h_in) (void)hipHostFree(c.h_in);
+    if (c.h_out) (void)hipHostFree(c.h_out);
+    c.d_in = c.d_out = c.h_in = c.h_out = nullptr;
+}
+
+struct Locked {
+    Chan *c = nullptr;
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit Locked(int channel)
+    {
+        if (!valid(channel)) return;
+        lk = std::unique_lock<std::recursive_mutex>(g_mtx[channel]);
+        if (!g_ch[channel].open) {
+            g_status = qh::set_error(QH_ERR_INVALID, "WDSP channel %d is not open", channel);
+            return;
+        }
+        c = &g_ch[channel];
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int qh_wdsp_status(void) { return g_status; }
+
+int GetWDSPVersion(void) { return 125; }    // the WDSP release Quisk 4.2.52 bundles
+
+void OpenChannel(int channel, int in_size, int dsp_size, int input_samplerate, int dsp_rate, int output_samplerate,
+                 int type, int state, double tdelayup, double tslewup, double tdelaydown, double tslewdown, int bfo)
+{
+    g_status = QH_OK;
+    if (!valid(channel)) return;
+    std::unique_lock<std::recursive_mutex> lk(g_mtx[channel]);
+    Chan &c = g_ch[channel];
+    if (c.open) { g_status = qh::set_error(QH_ERR_INVALID, "WDSP channel %d is already open", channel); return; }
+    if (type != 0) { g_status = qh::set_error(QH_ERR_UNSUPPORTED, "only RXA channels (type 0) are provided"); return; }
+    if (in_size <= 0 || dsp_size <= 0) { g_status = qh::set_error(QH_ERR_INVALID, "bad buffer sizes"); return; }
+    c.eng = qh_rxa_create(0, 1, dsp_size, input_samplerate, dsp_rate, output_samplerate, nullptr);
+    if (!c.eng) { g_status = QH_ERR_NO_DEVICE; return; }       // message already set
+    c.in_size = in_size; c.dsp_size = dsp_size;
+    c.in_rate = input_samplerate; c.dsp_rate = dsp_rate; c.out_rate = output_samplerate;
+    c.tdelayup = tdelayup; c.tslewup = tslewup; c.tdelaydown = tdelaydown; c.tslewdown = tslewdown;
+    c.bfo = bfo; c.state = state;
+    // pre_main_build, wdsp/channel.c:39-52
+    c.dsp_insize = qh_rxa_dsp_insize(c.eng);
+    c.dsp_outsize = qh_rxa_dsp_outsize(c.eng);
+    if (c.in_rate >= c.out_rate) c.out_size = in_size / (c.in_rate / c.out_rate);
+    else c.out_size = in_size * (c.out_rate / c.in_rate);
+    // create_iobuffs, wdsp/iobuffs.c:384-423
+    c.r1_outsize = c.dsp_insize;
+    c.r1_size = c.r1_outsize > in_size ? c.r1_outsize : in_size;
+    c.r2_insize = c.dsp_outsize;
+    c.r2_size = c.out_size > c.r2_insize ? c.out_size : c.r2_insize;
+    c.r1_active = kDspMult * c.r1_size;
+    c.r2_active = kDspMult * c.r2_size;
+    init_rings(c);
+    create_slews(c);
+    if (hipMalloc((void **)&c.d_in, (size_t)c.dsp_insize * 2 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&c.d_out, (size_t)c.dsp_outsize * 2 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void **)&c.h_in, (size_t)c.dsp_insize * 2 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&c.h_out, (size_t)c.dsp_outsize * 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        g_status = qh::set_error(QH_ERR_HIP, "OpenChannel: staging allocation failed");
+        free_staging(c);
+        qh_rxa_destroy(c.eng);
+        c.eng = nullptr;
+        return;
+    }
+    c.exchange = 0;
+    c.open = true;
+    if (state) { c.upflag = 1; c.exchange = 1; }    // wdsp/channel.c:92-98
+}
+
+void CloseChannel(int channel)
+{
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return;
+    Chan &c = *L.c;
+    free_staging(c);
+    qh_rxa_destroy(c.eng);
+    c.eng = nullptr;
+    c.open = false;
+}
+
+int SetChannelState(int channel, int state, int dmode)
+{
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return 0;
+    Chan &c = *L.c;
+    const int prior = c.state;
+    if (c.state != state) {
+        c.state = state;
+        if (state == 0) {
+            // wdsp/channel.c:269-288.  With dmode the reference waits up to 100 ms for another thread's
+            // fexchange0 calls to finish the down-slew; when none arrive (the single-threaded use Quisk
+            // makes of it, quisk_wdsp.py:117-139) it times out: exchange off, no flush.  That outcome is
+            // produced here at once.
+            if (dmode) { c.exchange = 0; c.downflag = 0; }
+            else c.downflag = 1;
+        } else {
+            c.upflag = 1;
+            c.exchange = 1;
+        }
+    }
+    return prior;
+}
+
+void fexchange0(int channel, double *in, double *out, int *error)
+{
+    g_status = QH_OK;
+    *error = 0;
+    Locked L(channel);
+    if (!L.c) { *error = -1; return; }
+    Chan &c = *L.c;
+    if (!c.exchange) return;                        // wdsp/iobuffs.c:471: `out` is left untouched
+    if (c.upflag) upslew0(c, in);
+    else std::memcpy(c.r1.data() + 2 * c.r1_inidx, in, (size_t)c.in_size * 2 * sizeof(double));
+    if ((c.r1_unqueued += c.in_size) >= c.r1_outsize) {
+        const int n = c.r1_unqueued / c.r1_outsize;
+        c.sem_buffready += n;
+        c.r1_unqueued -= n * c.r1_outsize;
+    }
+    if ((c.r1_inidx += c.in_size) == c.r1_active) c.r1_inidx = 0;
+    while (c.sem_buffready > 0) {                   // the DSP thread's loop, wdsp/main.c:40-58
+        c.sem_buffready--;
+        int rc = dsp_iteration(c);
+        if (rc) { g_status = rc; *error = -1; std::memset(out, 0, (size_t)c.out_size * 2 * sizeof(double)); return; }
+    }
+    int doit = c.r2_havesamps >= c.out_size;
+    if ((c.r2_havesamps -= c.out_size) < 0) c.r2_havesamps = 0;
+    int ready = 0;
+    if (c.bfo) { if (c.sem_outready > 0) { c.sem_outready--; ready = 1; } }
+    else ready = doit;
+    if (ready) {
+        if (c.downflag) {
+            downslew0(c, out);
+            if (!c.downflag) {                      // slew finished: stop and flush, wdsp/iobuffs.c:499-503
+                c.exchange = 0;
+                init_rings(c);
+                flush_slews(c);
+                (void)qh_rxa_flush(c.eng);
+                return;
+            }
+        } else {
+            std::memcpy(out, c.r2.data() + 2 * c.r2_outidx, (size_t)c.out_size * 2 * sizeof(double));
+        }
+    } else {
+        std::memset(out, 0, (size_t)c.out_size * 2 * sizeof(double));
+        *error += -2;
+    }
+    if ((c.r2_outidx += c.out_size) == c.r2_active) c.r2_outidx = 0;
+}
+
+#define WDSP_SETTER(call)                                   \
+    do {                                                    \
+        g_status = QH_OK;                                   \
+        Locked L(channel);                                  \
+        if (!L.c) return;                                   \
+        int rc = (call);                                    \
+        if (rc) g_status = rc;                              \
+    } while (0)
+
+void SetRXAMode(int channel, int mode) { WDSP_SETTER(qh_rxa_SetRXAMode(L.c->eng, 0, mode)); }
+void RXASetPassband(int channel, double f_low, double f_high) { WDSP_SETTER(qh_rxa_RXASetPassband(L.c->eng, 0, f_low, f_high)); }
+void RXASetNC(int channel, int nc) { WDSP_SETTER(qh_rxa_RXASetNC(L.c->eng, 0, nc)); }
+void SetRXAShiftRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAShiftRun(L.c->eng, 0, run)); }
+void SetRXAShiftFreq(int channel, double fshift) { WDSP_SETTER(qh_rxa_SetRXAShiftFreq(L.c->eng, 0, fshift)); }
+void RXANBPSetRun(int channel, int run) { WDSP_SETTER(qh_rxa_RXANBPSetRun(L.c->eng, 0, run)); }
+void RXANBPSetFreqs(int channel, double flow, double fhigh) { WDSP_SETTER(qh_rxa_RXANBPSetFreqs(L.c->eng, 0, flow, fhigh)); }
+void SetRXABandpassRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXABandpassRun(L.c->eng, 0, run)); }
+void SetRXABandpassFreqs(int channel, double f_low, double f_high) { WDSP_SETTER(qh_rxa_SetRXABandpassFreqs(L.c->eng, 0, f_low, f_high)); }
+void SetRXAAGCMode(int channel, int mode) { WDSP_SETTER(qh_rxa_SetRXAAGCMode(L.c->eng, 0, mode)); }
+void SetRXAAGCFixed(int channel, double fixed_agc) { WDSP_SETTER(qh_rxa_SetRXAAGCFixed(L.c->eng, 0, fixed_agc)); }
+void SetRXAPanelGain1(int channel, double gain) { WDSP_SETTER(qh_rxa_SetRXAPanelGain1(L.c->eng, 0, gain)); }
+void SetRXAPanelGain2(int channel, double gainI, double gainQ) { WDSP_SETTER(qh_rxa_SetRXAPanelGain2(L.c->eng, 0, gainI, gainQ)); }
+void SetRXAPanelSelect(int channel, int select) { WDSP_SETTER(qh_rxa_SetRXAPanelSelect(L.c->eng, 0, select)); }
+void SetRXAPanelCopy(int channel, int copy) { WDSP_SETTER(qh_rxa_SetRXAPanelCopy(L.c->eng, 0, copy)); }
+
+// xpanel never looks at its run flag (wdsp/patchpanel.c:55-101): accepted, no effect on the data.
+void SetRXAPanelRun(int channel, int run) { (void)run; g_status = QH_OK; (void)valid(channel); }
+// minimum-phase impulse responses (mp_imp, wdsp/fir.c:319-368) are not provided: only mp = 0.
+void RXASetMP(int channel, int mp)
+{
+    g_status = QH_OK;
+    if (!valid(channel)) return;
+    if (mp) g_status = qh::set_error(QH_ERR_UNSUPPORTED, "RXASetMP(%d, %d): minimum-phase filters are not provided", channel, mp);
+}
+// blocks that are run = 0 on the hot path: run = 0 is accepted, run = 1 is reported as unsupported
+#define WDSP_OFF_ONLY(name)                                                                        \
+    void name(int channel, int run)                                                                \
+    {                                                                                              \
+        g_status = QH_OK;                                                                          \
+        if (!valid(channel)) return;                                                               \
+        if (run) g_status = qh::set_error(QH_ERR_UNSUPPORTED, #name "(%d, 1): block is outside the GPU hot path", channel); \
+    }
+WDSP_OFF_ONLY(SetRXAAMSQRun)
+WDSP_OFF_ONLY(SetRXAEMNRRun)
+WDSP_OFF_ONLY(SetRXASNBARun)
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""ctypes loader for libquiskhip.so.  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libquiskhip.so")
+_lib = None
+
+
+class QuiskHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library (ctypes.CDLL) with argument types declared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QuiskHipError(
+            "%s is missing: build it with `python -m quisk_amd.build` (needs hipcc). "
+            "quisk_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, d, ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
+    L.qh_version.restype = i
+    L.qh_last_error.restype = C.c_char_p
+    L.qh_device_count.restype = i
+    L.qh_rxa_create.restype = vp
+    L.qh_rxa_create.argtypes = [i, i, i, i, i, i, vp]
+    L.qh_rxa_destroy.argtypes = [vp]
+    L.qh_rxa_destroy.restype = None
+    for n in ("qh_rxa_nch", "qh_rxa_dsp_insize", "qh_rxa_dsp_outsize"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = i
+    L.qh_rxa_device_bytes.argtypes = [vp]
+    L.qh_rxa_device_bytes.restype = ll
+    for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
+              "SetRXAPanelSelect", "SetRXAPanelCopy"):
+        f = getattr(L, "qh_rxa_" + n)
+        f.argtypes = [vp, i, i]
+        f.restype = i
+    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1"):
+        f = getattr(L, "qh_rxa_" + n)
+        f.argtypes = [vp, i, d]
+        f.restype = i
+    for n in ("RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2"):
+        f = getattr(L, "qh_rxa_" + n)
+        f.argtypes = [vp, i, d, d]
+        f.restype = i
+    L.qh_rxa_process.argtypes = [vp, vp, ll, vp, ll, i]
+    L.qh_rxa_process.restype = i
+    L.qh_rxa_process_host.argtypes = [vp, vp, ll, vp, ll, i]
+    L.qh_rxa_process_host.restype = i
+    L.qh_rxa_synchronize.argtypes = [vp]
+    L.qh_rxa_synchronize.restype = i
+    L.qh_rxa_flush.argtypes = [vp]
+    L.qh_rxa_flush.restype = i
+    L.qh_rxa_enable_timing.argtypes = [vp, i]
+    L.qh_rxa_enable_timing.restype = i
+    L.qh_rxa_timing.argtypes = [vp, C.POINTER(d), i]
+    L.qh_rxa_timing.restype = i
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise QuiskHipError("libquiskhip error %d: %s" % (rc, load().qh_last_error().decode(errors="replace")))

@@ -1,0 +1,76 @@
+"""Python host side of the batched RXA engine (include/quiskhip.h group 1).
+
+Method names are the WDSP export names the reference binds through ctypes
+(quisk_wdsp.py:79-91, quisk.py:6017-6052); the first argument is the channel index inside the
+batch, or -1 for all channels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .lib import load, check, QuiskHipError
+
+_SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
+            "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1",
+            "RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2")
+
+
+class RxaEngine:
+    """nch independent WDSP-RXA receiver channels on one MI355X."""
+
+    def __init__(self, nch, dsp_size=256, in_rate=192000, dsp_rate=48000, out_rate=48000, device=0, stream=None):
+        self._L = load()
+        self._h = self._L.qh_rxa_create(device, nch, dsp_size, in_rate, dsp_rate, out_rate, stream)
+        if not self._h:
+            raise QuiskHipError("qh_rxa_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch = nch
+        self.dsp_insize = self._L.qh_rxa_dsp_insize(self._h)
+        self.dsp_outsize = self._L.qh_rxa_dsp_outsize(self._h)
+
+    def __getattr__(self, name):
+        if name in _SETTERS:
+            f = getattr(self._L, "qh_rxa_" + name)
+
+            def call(ch, *args):
+                check(f(self._h, ch, *args))
+            return call
+        raise AttributeError(name)
+
+    def process_ptr(self, d_in, in_stride, d_out, out_stride, nblk):
+        """Device pointers (ints), strides in complex samples.  Asynchronous on the engine's stream."""
+        check(self._L.qh_rxa_process(self._h, d_in, in_stride, d_out, out_stride, nblk))
+
+    def process_host(self, x):
+        """x: complex128 [nch, nblk*dsp_insize] on the host -> complex128 [nch, nblk*dsp_outsize]."""
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        if x.ndim != 2 or x.shape[0] != self.nch or x.shape[1] % self.dsp_insize:
+            raise ValueError("expected [nch, k*dsp_insize] complex128")
+        nblk = x.shape[1] // self.dsp_insize
+        out = np.empty((self.nch, nblk * self.dsp_outsize), dtype=np.complex128)
+        check(self._L.qh_rxa_process_host(self._h, x.ctypes.data, x.shape[1], out.ctypes.data, out.shape[1], nblk))
+        return out
+
+    def synchronize(self):
+        check(self._L.qh_rxa_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        check(self._L.qh_rxa_enable_timing(self._h, 1 if on else 0))
+
+    def timing_ms(self):
+        buf = (C.c_double * 3)()
+        n = self._L.qh_rxa_timing(self._h, buf, 3)
+        return [buf[k] for k in range(n)]
+
+    def device_bytes(self):
+        return self._L.qh_rxa_device_bytes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_rxa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

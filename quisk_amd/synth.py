@@ -1,0 +1,55 @@
+"""Synthetic IQ input shared by bench.py and the tests.
+
+Per channel c:  x[n] = A1*exp(j*2*pi*f1*n/fs) + A2*exp(j*2*pi*f2*n/fs) + sigma*(g_re + j*g_im)
+WDSP scale (+-1.0): A1 = 0.1 in the passband after the shift, A2 = 0.05 out of band, sigma = 0.01.
+The shift is +10 kHz + 37*c Hz, so the in-band tone sits at (-1000 - shift) Hz before the shift
+(WDSP's "USB 300..3000" passes conventional -3000..-300 Hz: wdsp/fir.c:246-249).
+"""
+import numpy as np
+
+
+def shift_freq(c):
+    return 10000.0 + 37.0 * c
+
+
+def channel_tones(c, fs):
+    f1 = -1000.0 - shift_freq(c)        # lands at -1000 Hz after the +shift: inside the USB passband
+    f2 = 30000.0 - shift_freq(c)        # far out of band
+    return f1, f2
+
+
+def make_input_numpy(nch, n, fs=192000.0, first_channel=0, a1=0.1, a2=0.05, sigma=0.01):
+    """complex128 [nch, n]; noise from numpy.random.default_rng(1000 + c)."""
+    t = np.arange(n, dtype=np.float64)
+    x = np.empty((nch, n), dtype=np.complex128)
+    for i in range(nch):
+        c = first_channel + i
+        f1, f2 = channel_tones(c, fs)
+        rng = np.random.default_rng(1000 + c)
+        g = rng.standard_normal((n, 2))
+        x[i] = (a1 * np.exp(2j * np.pi * ((f1 / fs) * t % 1.0)) + a2 * np.exp(2j * np.pi * ((f2 / fs) * t % 1.0))
+                + sigma * (g[:, 0] + 1j * g[:, 1]))
+    return x
+
+
+def make_input_torch(nch, n, device, fs=192000.0, first_channel=0, a1=0.1, a2=0.05, sigma=0.01, chunk=16):
+    """Same signal model generated on the GPU (torch generator seeded 1000 + c); complex128 [nch, n]."""
+    import torch
+    x = torch.empty((nch, n), dtype=torch.complex128, device=device)
+    t = torch.arange(n, dtype=torch.float64, device=device)
+    for i0 in range(0, nch, chunk):
+        i1 = min(nch, i0 + chunk)
+        for i in range(i0, i1):
+            c = first_channel + i
+            f1, f2 = channel_tones(c, fs)
+            gen = torch.Generator(device=device)
+            gen.manual_seed(1000 + c)
+            ph1 = torch.remainder(t * (f1 / fs), 1.0) * (2.0 * np.pi)
+            ph2 = torch.remainder(t * (f2 / fs), 1.0) * (2.0 * np.pi)
+            re = a1 * torch.cos(ph1) + a2 * torch.cos(ph2)
+            im = a1 * torch.sin(ph1) + a2 * torch.sin(ph2)
+            re += sigma * torch.randn(n, dtype=torch.float64, device=device, generator=gen)
+            im += sigma * torch.randn(n, dtype=torch.float64, device=device, generator=gen)
+            x[i] = torch.complex(re, im)
+            del ph1, ph2, re, im
+    return x
