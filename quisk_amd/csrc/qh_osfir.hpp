@@ -91,17 +91,26 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
 
     // ---- load NFFT inputs, strided register layout
+    // Branch-free: every lane always issues its E loads back to back (clamped address, value
+    // zeroed afterwards when out of range) so that all E requests are in flight together.
     C x[E];
+    {
+        const C *hsafe = hist ? hist : in;
+        const long long hlen = hist ? a.hist_len : 0;
+        const long long last = a.n_in - 1;
+        bool ok[E];
 #pragma unroll
-    for (int r = 0; r < E; r++) {
-        long long g = g0 + t + r * NT;
-        C v = mk<T>(0, 0);
-        if (g >= 0) {
-            if (g < a.n_in) v = in[g];
-        } else if (hist && g + a.hist_len >= 0) {
-            v = hist[g + a.hist_len];
+        for (int r = 0; r < E; r++) {
+            const long long g = g0 + t + r * NT;
+            const long long gi = g < 0 ? 0 : (g > last ? last : g);
+            const long long gh = g + hlen < 0 ? 0 : g + hlen;
+            const C *p = g >= 0 ? in + gi : hsafe + (gh < hlen ? gh : 0);
+            ok[r] = g >= 0 ? g <= last : (g + hlen >= 0);
+            x[r] = *p;
         }
-        x[r] = v;
+#pragma unroll
+        for (int r = 0; r < E; r++)
+            if (!ok[r]) x[r] = mk<T>(0, 0);
     }
     if constexpr (MIX) {
         unsigned long long ph = a.nco_phase[ch] + a.nco_dphase[ch] * (unsigned long long)(g0 + t);
