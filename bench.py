@@ -70,7 +70,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from quisk_amd import RxaEngine, synth, build as qbuild
+    from quisk_amd import RxaEngine, synth, shard, build as qbuild
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +92,7 @@ def main():
     n_in = 1 << args.log2_samples
     nblk = n_in // (DSP_SIZE * (IN_RATE // DSP_RATE))
     n_out = nblk * DSP_SIZE
-    first = rank * nch                                          # rank r owns channels [r*nch, (r+1)*nch)
+    first = shard.channel_range(rank, world, nch)[0]           # rank r owns channels [r*nch, (r+1)*nch)
 
     stream = torch.cuda.current_stream(dev)
     eng = RxaEngine(nch, dsp_size=DSP_SIZE, in_rate=IN_RATE, dsp_rate=DSP_RATE, out_rate=DSP_RATE,
@@ -127,10 +127,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(dt, dev)
 
     # per-kernel durations with HIP events on the engine's stream (separate short run, not in the timed region)
     eng.enable_timing(True)
@@ -150,7 +147,7 @@ def main():
     if rank == 0:
         samples_per_step = float(nch) * n_in
         total = samples_per_step * world * args.steps
-        value = total / dt / 1e6
+        value = shard.job_throughput(samples_per_step, world, args.steps, dt) / 1e6
         # dominant kernel and its algorithmic bytes per launch:
         #   front  (shift + resample /4): reads 16 B, writes 16/4 B per input sample        = 20 B / input sample
         #   band   (NBP overlap-save)   : reads 16 B, writes 16 B per DSP-rate sample (x1/4) =  8 B / input sample

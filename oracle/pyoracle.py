@@ -199,3 +199,149 @@ def ref_filter_lib():
             return None
         _REF = C.CDLL(path)
     return _REF
+
+
+# ---------------------------------------------------------------------------------------------
+# Quisk filter.c primitives: the restatement (quisk_oracle.c) and the reference build (_ref)
+# ---------------------------------------------------------------------------------------------
+class QoFir(C.Structure):       # oracle/quisk_oracle.h: qo_fir
+    _fields_ = [("taps", c_double_p), ("ctaps", c_double_p), ("ntaps", C.c_int), ("phase", C.c_int),
+                ("pos", C.c_int), ("hist", c_double_p), ("is_complex", C.c_int)]
+
+
+class QoHb45(C.Structure):      # oracle/quisk_oracle.h: qo_hb45
+    _fields_ = [("toggle", C.c_int), ("samples", C.c_double * 44), ("center", C.c_double * 22)]
+
+
+class RefCFilter(C.Structure):  # struct quisk_cFilter / quisk_dFilter, /root/reference/filter.h:1-21 (same layout)
+    _fields_ = [("dCoefs", c_double_p), ("cpxCoefs", C.c_void_p), ("nBuf", C.c_int), ("nTaps", C.c_int),
+                ("decim_index", C.c_int), ("samples", C.c_void_p), ("ptSamp", C.c_void_p), ("buf", C.c_void_p)]
+
+
+class RefCHB45(C.Structure):    # struct quisk_cHB45Filter, filter.h:23-29
+    _fields_ = [("cBuf", C.c_void_p), ("nBuf", C.c_int), ("toggle", C.c_int),
+                ("samples", C.c_double * 44), ("center", C.c_double * 22)]
+
+
+class RefDHB45(C.Structure):    # struct quisk_dHB45Filter, filter.h:31-37
+    _fields_ = [("dBuf", C.c_void_p), ("nBuf", C.c_int), ("toggle", C.c_int),
+                ("samples", C.c_double * 22), ("center", C.c_double * 11)]
+
+
+class OracleFir:
+    """qo_fir wrapper.  Methods take/return numpy arrays (complex128 or float64) and keep state."""
+
+    def __init__(self, taps, is_complex=True):
+        self.L = lib()
+        self.taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self.f = QoFir()
+        self.is_complex = is_complex
+        self.L.qo_fir_init(C.byref(self.f), self.taps.ctypes.data_as(c_double_p), self.taps.size, 1 if is_complex else 0)
+
+    def tune(self, freq, ssb_upper):
+        self.L.qo_fir_tune.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        self.L.qo_fir_tune(C.byref(self.f), freq, ssb_upper)
+
+    def _run(self, name, x, *args, grow=1):
+        dt = np.complex128 if self.is_complex else np.float64
+        x = np.ascontiguousarray(x, dtype=dt)
+        buf = np.zeros(max(x.size * grow, 1) + 8, dtype=dt)
+        buf[:x.size] = x
+        fn = getattr(self.L, name)
+        fn.restype = C.c_int
+        n = fn(buf.ctypes.data_as(C.c_void_p), C.c_int(x.size), C.byref(self.f), *[C.c_int(a) for a in args])
+        return buf[:n].copy()
+
+    def cDecimate(self, x, decim): return self._run("qo_cDecimate", x, decim)
+    def cCDecimate(self, x, decim): return self._run("qo_cCDecimate", x, decim)
+    def dDecimate(self, x, decim): return self._run("qo_dDecimate", x, decim)
+    def cInterpolate(self, x, interp): return self._run("qo_cInterpolate", x, interp, grow=interp)
+    def dInterpolate(self, x, interp): return self._run("qo_dInterpolate", x, interp, grow=interp)
+    def cInterpDecim(self, x, interp, decim): return self._run("qo_cInterpDecim", x, interp, decim, grow=interp)
+    def dFilter(self, x): return self._run("qo_dFilter", x)
+
+
+class OracleHB45:
+    def __init__(self):
+        self.L = lib()
+        self.f = QoHb45()
+
+    def _run(self, name, x, dt, grow=1):
+        x = np.ascontiguousarray(x, dtype=dt)
+        buf = np.zeros(max(x.size * grow, 1) + 8, dtype=dt)
+        buf[:x.size] = x
+        fn = getattr(self.L, name)
+        fn.restype = C.c_int
+        n = fn(buf.ctypes.data_as(C.c_void_p), C.c_int(x.size), C.byref(self.f))
+        return buf[:n].copy()
+
+    def cDecim2(self, x): return self._run("qo_cDecim2HB45", x, np.complex128)
+    def cInterp2(self, x): return self._run("qo_cInterp2HB45", x, np.complex128, grow=2)
+    def dInterp2(self, x): return self._run("qo_dInterp2HB45", x, np.float64, grow=2)
+
+
+class RefFir:
+    """The reference's own filter.c (oracle/_ref) behind the same interface as OracleFir."""
+
+    def __init__(self, taps, is_complex=True):
+        self.R = ref_filter_lib()
+        if self.R is None:
+            raise RuntimeError("oracle/_ref/libquisk_filter_ref.so is not built (needs /root/reference)")
+        self.taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self.f = RefCFilter()
+        self.is_complex = is_complex
+        init = self.R.quisk_filt_cInit if is_complex else self.R.quisk_filt_dInit
+        init(C.byref(self.f), self.taps.ctypes.data_as(c_double_p), C.c_int(self.taps.size))
+
+    def tune(self, freq, ssb_upper):
+        self.R.quisk_filt_tune.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        self.R.quisk_filt_tune(C.byref(self.f), freq, ssb_upper)
+
+    def _run(self, name, x, *args, grow=1):
+        dt = np.complex128 if self.is_complex else np.float64
+        x = np.ascontiguousarray(x, dtype=dt)
+        buf = np.zeros(max(x.size * grow, 1) + 8, dtype=dt)
+        buf[:x.size] = x
+        fn = getattr(self.R, name)
+        fn.restype = C.c_int
+        n = fn(buf.ctypes.data_as(C.c_void_p), C.c_int(x.size), C.byref(self.f), *[C.c_int(a) for a in args])
+        return buf[:n].copy()
+
+    def cDecimate(self, x, decim): return self._run("quisk_cDecimate", x, decim)
+    def cCDecimate(self, x, decim): return self._run("quisk_cCDecimate", x, decim)
+    def dDecimate(self, x, decim): return self._run("quisk_dDecimate", x, decim)
+    def cInterpolate(self, x, interp): return self._run("quisk_cInterpolate", x, interp, grow=interp)
+    def dInterpolate(self, x, interp): return self._run("quisk_dInterpolate", x, interp, grow=interp)
+    def cInterpDecim(self, x, interp, decim): return self._run("quisk_cInterpDecim", x, interp, decim, grow=interp)
+    def dFilter(self, x): return self._run("quisk_dFilter", x)
+
+
+class RefHB45:
+    def __init__(self):
+        self.R = ref_filter_lib()
+        if self.R is None:
+            raise RuntimeError("oracle/_ref/libquisk_filter_ref.so is not built (needs /root/reference)")
+        self.fc = RefCHB45()
+        self.fd = RefDHB45()
+
+    def _run(self, name, f, x, dt, grow=1):
+        x = np.ascontiguousarray(x, dtype=dt)
+        buf = np.zeros(max(x.size * grow, 1) + 8, dtype=dt)
+        buf[:x.size] = x
+        fn = getattr(self.R, name)
+        fn.restype = C.c_int
+        n = fn(buf.ctypes.data_as(C.c_void_p), C.c_int(x.size), C.byref(f))
+        return buf[:n].copy()
+
+    def cDecim2(self, x): return self._run("quisk_cDecim2HB45", self.fc, x, np.complex128)
+    def cInterp2(self, x): return self._run("quisk_cInterp2HB45", self.fc, x, np.complex128, grow=2)
+    def dInterp2(self, x): return self._run("quisk_dInterp2HB45", self.fd, x, np.float64, grow=2)
+
+
+def ref_table(name, n):
+    """A coefficient table exported by the reference build (filters.h via filter.c), e.g. quiskFilt48dec24Coefs."""
+    R = ref_filter_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref is not built")
+    arr = (C.c_double * n).in_dll(R, name)
+    return np.array(arr, dtype=np.float64)

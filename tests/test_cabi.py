@@ -1,0 +1,46 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/quiskhip.h declares, and refuses to
+compute (loudly) when no HIP device is present.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "quiskhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_symbols_are_exported(qh):
+    lib = qh.load()
+    names = declared_functions()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_device_is_an_error_not_a_fallback(qh):
+    lib = qh.load()
+    if lib.qh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(qh.QuiskHipError) as e:
+        qh.RxaEngine(1)
+    assert "no HIP device" in str(e.value) or "CPU fallback" in str(e.value)
+    # the WDSP-named layer reports the same condition through qh_wdsp_status()
+    lib.OpenChannel.argtypes = [ctypes.c_int] * 8 + [ctypes.c_double] * 4 + [ctypes.c_int]
+    lib.OpenChannel(1, 256, 256, 48000, 48000, 48000, 0, 1, 0.010, 0.025, 0.0, 0.010, 1)
+    assert lib.qh_wdsp_status() != 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "quisk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.replace("the CPU oracle", ""), os.path.join(dirpath, f)

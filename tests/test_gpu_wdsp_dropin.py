@@ -1,0 +1,111 @@
+"""The WDSP-named exports, bound the way quisk_wdsp.py binds libwdsp (ctypes, ints as int, floats as
+c_double: quisk_wdsp.py:79-91,128-139), against the oracle's fexchange0.  -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from quisk_amd import synth
+
+pytestmark = pytest.mark.gpu
+D = C.c_double
+
+
+def _open(lib, channel, in_size, dsp_size, in_rate, nbp, shift_freq=None, nc=None):
+    # the call sequence of quisk_wdsp.Cwdsp.open (quisk_wdsp.py:69-99) with the bench's shift/NBP options
+    lib.OpenChannel(channel, in_size, dsp_size, in_rate, 48000, 48000, 0, 1, D(0.010), D(0.025), D(0.0), D(0.010), 1)
+    assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
+    lib.SetRXAShiftRun(channel, 1 if shift_freq is not None else 0)
+    if shift_freq is not None:
+        lib.SetRXAShiftFreq(channel, D(shift_freq))
+    lib.RXANBPSetRun(channel, 1 if nbp else 0)
+    lib.SetRXAAMSQRun(channel, 0)
+    lib.SetRXAMode(channel, 1)
+    lib.RXASetPassband(channel, D(300.0), D(3000.0))
+    if nc:
+        lib.RXASetNC(channel, nc)
+    lib.RXASetMP(channel, 0)
+    lib.SetRXAAGCMode(channel, 0)
+    lib.SetRXAAGCFixed(channel, D(0.0))
+    lib.SetRXAPanelRun(channel, 0)
+    lib.SetRXAEMNRRun(channel, 0)
+    assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
+
+
+def _run(lib, channel, x, in_size, out_size):
+    nb = x.size // in_size
+    out = np.zeros(nb * out_size, dtype=np.complex128)
+    err = C.c_int(0)
+    for b in range(nb):
+        blk = np.ascontiguousarray(x[b * in_size:(b + 1) * in_size])
+        lib.fexchange0(channel, blk.ctypes.data_as(C.c_void_p), out[b * out_size:].ctypes.data_as(C.c_void_p), C.byref(err))
+        assert err.value == 0
+    return out
+
+
+def _oracle(po, in_size, dsp_size, in_rate, nbp, shift_freq=None, nc=None):
+    ch = po.WdspChannel(in_size, dsp_size, in_rate, 48000, 48000)
+    ch.SetRXAShiftRun(1 if shift_freq is not None else 0)
+    if shift_freq is not None:
+        ch.SetRXAShiftFreq(shift_freq)
+    ch.RXANBPSetRun(1 if nbp else 0)
+    ch.SetRXAMode(1)
+    ch.RXASetPassband(300.0, 3000.0)
+    if nc:
+        ch.RXASetNC(nc)
+    ch.SetRXAAGCMode(0)
+    ch.SetRXAAGCFixed(0.0)
+    return ch
+
+
+@pytest.mark.parametrize("in_size,in_rate,nc", [(1024, 192000, None), (64, 192000, None), (256, 48000, 256), (4096, 192000, None)])
+def test_fexchange0_matches_oracle_including_latency_and_slew(qh, oracle, in_size, in_rate, nc):
+    lib = qh.load()
+    assert lib.GetWDSPVersion() == 125
+    ch = 3
+    d = in_rate // 48000
+    n = max(in_size, 256 * d) * 24
+    x = synth.make_input_numpy(1, n, fs=float(in_rate))[0]
+    x[:37] = 0.0                                   # leading zeros: the upslew triggers on the first non-zero sample
+    _open(lib, ch, in_size, 256, in_rate, nbp=True, shift_freq=10000.0, nc=nc)
+    try:
+        y = _run(lib, ch, x, in_size, in_size // d)
+    finally:
+        lib.CloseChannel(ch)
+    ref, errs = _oracle(oracle, in_size, 256, in_rate, True, 10000.0, nc).fexchange0(x)
+    assert errs == 0
+    assert rel_rms(y, ref) < 1e-9
+    # the output is silent for the two-block latency plus the 10 ms delay, like the reference
+    assert np.abs(y[:512]).max() < 1e-12
+
+
+def test_two_channels_are_independent(qh, oracle):
+    lib = qh.load()
+    x0 = synth.make_input_numpy(1, 1024 * 10)[0]
+    x1 = synth.make_input_numpy(1, 1024 * 10, first_channel=1)[0]
+    _open(lib, 0, 1024, 256, 192000, nbp=True, shift_freq=10000.0)
+    _open(lib, 1, 1024, 256, 192000, nbp=False)
+    try:
+        y0, y1 = np.zeros(2560, dtype=np.complex128), np.zeros(2560, dtype=np.complex128)
+        err = C.c_int(0)
+        for b in range(10):                         # interleaved calls, like two receivers in one loop
+            for chan, xs, ys in ((0, x0, y0), (1, x1, y1)):
+                blk = np.ascontiguousarray(xs[b * 1024:(b + 1) * 1024])
+                lib.fexchange0(chan, blk.ctypes.data_as(C.c_void_p), ys[b * 256:].ctypes.data_as(C.c_void_p), C.byref(err))
+    finally:
+        lib.CloseChannel(0)
+        lib.CloseChannel(1)
+    r0, _ = _oracle(oracle, 1024, 256, 192000, True, 10000.0).fexchange0(x0)
+    r1, _ = _oracle(oracle, 1024, 256, 192000, False).fexchange0(x1)
+    assert rel_rms(y0, r0) < 1e-9 and rel_rms(y1, r1) < 1e-9
+
+
+def test_closed_channel_and_unsupported_requests_are_reported(qh):
+    lib = qh.load()
+    err = C.c_int(0)
+    buf = np.zeros(256, dtype=np.complex128)
+    lib.fexchange0(7, buf.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), C.byref(err))
+    assert err.value != 0 and lib.qh_wdsp_status() != 0
+    lib.SetRXAEMNRRun(7, 1)
+    assert lib.qh_wdsp_status() != 0            # NR2 is outside the GPU hot path: reported, not silently ignored

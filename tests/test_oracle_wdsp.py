@@ -1,0 +1,122 @@
+"""Pins for the WDSP restatement that do not need the (unbuildable) reference: independent closed forms,
+numpy/scipy recomputations, and the behaviours probed from the real reference recorded in SURVEY.md 8."""
+import numpy as np
+
+from conftest import rel_rms
+
+
+def _bh4(N):
+    i = np.arange(N)
+    c = np.cos(np.pi / (0.5 * (N - 1)) * i)
+    return 0.21747 + c * (-0.45325 + c * (0.28256 + c * (-0.04672)))
+
+
+def test_fir_bandpass_closed_form(oracle):
+    """fir_bandpass(rtype 1) = scale * sinc lowpass of half-width (fh-fl)/2 * BH window * exp(-j*w0*(n-m)),
+    symmetric about m = (N-1)/2 (wdsp/fir.c:187-254)."""
+    N, fl, fh, fs = 2048, 300.0, 3000.0, 48000.0
+    h = oracle.fir_bandpass(N, fl, fh, fs, 0, 1, 1.0)
+    m = 0.5 * (N - 1)
+    pos = np.arange(N) - m
+    ft = (fh - fl) / (2 * fs)
+    proto = np.sin(2 * np.pi * ft * pos) / (np.pi * pos) * _bh4(N)
+    want = proto * np.exp(-1j * np.pi * (fh + fl) / fs * pos)
+    assert np.abs(h - want).max() < 1e-15
+    # passband sits at conventional [-fh, -fl]: unity gain at -1000 Hz, > 100 dB down at +1000 Hz
+    n = np.arange(N)
+    g_neg = abs(np.sum(h * np.exp(+2j * np.pi * 1000.0 / fs * n)))
+    g_pos = abs(np.sum(h * np.exp(-2j * np.pi * 1000.0 / fs * n)))
+    assert abs(g_neg - 1.0) < 1e-4 and g_pos < 1e-5
+
+
+def test_resampler_taps_and_output(oracle):
+    h, L, M, ncoef, cpp = oracle.resample_taps(192000, 48000)
+    assert (L, M, ncoef, cpp) == (1, 4, 561, 561)
+    assert abs(h.sum() - 1.0) < 1e-8 and np.allclose(h, h[::-1], atol=1e-18)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(4096) + 1j * rng.standard_normal(4096)
+    r = oracle.Resample(192000, 48000)
+    y = np.concatenate([r(x[:1000]), r(x[1000:1004]), r(x[1004:])])
+    want = np.convolve(x, h)[:4096][0::4]                       # y[m] = sum_j h[j] x[4m - j]
+    assert y.size == 1024 and rel_rms(y, want) < 1e-13
+    for rate, nco in ((96000, 281), (384000, 1121)):
+        assert oracle.resample_taps(rate, 48000)[3] == nco
+
+
+def test_fircore_is_linear_convolution(oracle):
+    """Partitioned overlap-save == causal linear convolution with the nc-tap impulse times 2*size
+    (the unnormalised inverse FFT, wdsp/firmin.c:409-430)."""
+    rng = np.random.default_rng(2)
+    size, nc = 64, 256
+    imp = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+    x = rng.standard_normal(size * 20) + 1j * rng.standard_normal(size * 20)
+    y = oracle.Fircore(size, nc, imp)(x)
+    want = np.convolve(x, imp)[:x.size] * (2 * size)
+    assert rel_rms(y, want) < 1e-13
+
+
+def _usb_channel(po, in_size, in_rate, slew=True, nbp=True):
+    a = (0.010, 0.025, 0.0, 0.010) if slew else (0.0, 0.0, 0.0, 0.0)
+    ch = po.WdspChannel(in_size, 256, in_rate, 48000, 48000, *a)
+    ch.SetRXAShiftRun(0)
+    ch.RXANBPSetRun(1 if nbp else 0)
+    ch.SetRXAMode(1)
+    ch.RXASetPassband(300.0, 3000.0)
+    ch.SetRXAAGCMode(0)
+    ch.SetRXAAGCFixed(0.0)
+    return ch
+
+
+def test_probed_latency_and_slew(oracle):
+    """SURVEY.md 8 row b2, probed from the compiled reference: two-block latency (first non-zero output 513
+    without slew for in_size 64/256/1024), 993 at 192k->48k and 995 at 48k with Quisk's 0.010/0.025 s slew."""
+    x = np.full(1024 * 24, 0.25 - 0.125j)
+    for in_size in (64, 256, 1024):
+        y, errs = _usb_channel(oracle, in_size, 192000, slew=False, nbp=False).fexchange0(x)
+        assert errs == 0 and np.nonzero(np.abs(y) > 0)[0][0] == 513
+    y, _ = _usb_channel(oracle, 1024, 192000, nbp=False).fexchange0(x)
+    assert np.nonzero(np.abs(y) > 0)[0][0] == 993
+    y, _ = _usb_channel(oracle, 256, 48000, nbp=False).fexchange0(x[:256 * 24])
+    assert np.nonzero(np.abs(y) > 0)[0][0] == 995
+    # steady state: DC 0.25-0.125j -> 1-0.5j (panel gain 4.0 applies even after SetRXAPanelRun(0))
+    y, _ = _usb_channel(oracle, 1024, 192000, slew=False, nbp=False).fexchange0(x)
+    assert abs(y[-1] - (1.0 - 0.5j)) < 1e-8
+
+
+def test_probed_gain_and_sign_convention(oracle):
+    """SURVEY.md hard part 6: a -1000 Hz tone passes 'USB 300..3000' with gain 4.0; +1000 Hz is rejected."""
+    n = 1024 * 40
+    t = np.arange(n)
+    for f, lo, hi in ((-1000.0, 3.99, 4.01), (+1000.0, 0.0, 1e-5)):
+        y, _ = _usb_channel(oracle, 1024, 192000).fexchange0(0.1 * np.exp(2j * np.pi * f * t / 192000.0))
+        g = np.abs(y[-500:]).mean() / 0.1
+        assert lo <= g <= hi, (f, g)
+
+
+def test_chain_equals_independent_linear_model(oracle):
+    """shift -> resample -> nbp -> gain recomputed with numpy from the designed taps only."""
+    fs, shift = 192000.0, 10037.0
+    rng = np.random.default_rng(5)
+    n = 1024 * 12
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ch = _usb_channel(oracle, 1024, 192000)
+    ch.SetRXAShiftRun(1)
+    ch.SetRXAShiftFreq(shift)
+    y = ch.xrxa(x)
+    h1 = oracle.resample_taps(192000, 48000)[0]
+    h2 = oracle.fir_bandpass(2048, 300.0, 3000.0, 48000.0, 0, 1, 1.0)
+    xs = x * np.exp(2j * np.pi * ((shift / fs) * np.arange(n) % 1.0))
+    mid = np.convolve(xs, h1)[:n][0::4]
+    want = 4.0 * np.convolve(mid, h2)[:mid.size]
+    assert rel_rms(y, want) < 1e-11
+
+
+def test_mode_quirks(oracle):
+    """bp1 is created run=1 and only re-evaluated on a mode CHANGE (RXA.c:378,751,815-827): opening and
+    setting mode LSB (the default) leaves both filters in the chain; USB drops bp1."""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(1024 * 8) + 1j * rng.standard_normal(1024 * 8)
+    a = oracle.WdspChannel(1024, 256, 192000, 48000, 48000); a.SetRXAAGCMode(0); a.SetRXAMode(0)
+    b = oracle.WdspChannel(1024, 256, 192000, 48000, 48000); b.SetRXAAGCMode(0); b.SetRXAMode(1); b.SetRXAMode(0)
+    ya, yb = a.xrxa(x), b.xrxa(x)
+    assert rel_rms(ya, yb) > 1e-3           # a still runs bp1 (BH-7 window) after nbp0, b does not
