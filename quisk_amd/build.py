@@ -26,16 +26,18 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: experiment builds (tools/ab_bench.py) with -D overrides into another file."""
+    target = out or LIB
+    if not force and not out and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(os.path.dirname(target), exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-x", "hip", "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-x", "hip", "-o", target] + ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

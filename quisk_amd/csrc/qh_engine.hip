@@ -179,7 +179,7 @@ int Engine::init()
     dev_bytes += (size_t)nch * (16 + 16 + sizeof(EpiParam));
 
     // allow the 64 KiB dynamic LDS of the overlap-save kernels
-    const int lds = kNfft * (int)sizeof(double2);
+    const int lds = lds_elems<kNfft>() * (int)sizeof(double2);
 #define QH_SET_LDS(K) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     QH_SET_LDS((osfir_kernel<double, 4096, 1, false>));
     QH_SET_LDS((osfir_kernel<double, 4096, 2, true>));
@@ -320,10 +320,11 @@ void Engine::tick(int cat)
 }
 
 template <int D, bool MIX>
-static void launch_osfir(const OsfirArgs<double> &a, int ntiles, int nch, hipStream_t s)
+static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
+    a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles, (unsigned)nch), block(NT);
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX>), grid, block, kNfft * sizeof(double2), s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX>), grid, block, lds_elems<kNfft>() * sizeof(double2), s, a);
 }
 
 int Engine::process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)

@@ -11,9 +11,7 @@
 //        thread t holds elements  t + NT * i,   i = 0 .. N/NT - 1,
 // so that global loads/stores are coalesced (consecutive lanes, 16 B each) and so that a
 // frequency-domain mask multiply, a spectral fold (decimation) and the first inverse pass
-// need no LDS traffic at all.  LDS element i lives at i ^ ((i >> 4) & 15): the XOR swizzle
-// makes the stride-R scatter of the early passes bank-conflict free for ds_write_b128 while
-// consecutive-lane reads stay conflict free.
+// need no LDS traffic at all.  The LDS image is padded (row pitch 17 elements, lds_phys below).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -108,7 +106,12 @@ template <int R, bool INV, typename C> struct Dft {
 };
 template <bool INV, typename C> struct Dft<1, INV, C> { static __device__ __forceinline__ void run(C (&)[1]) {} };
 
-__device__ __forceinline__ int lds_phys(int i) { return i ^ ((i >> 4) & 15); }
+// LDS image: element i lives at i + (i >> 4) (one 16-byte pad after every 16 elements = row pitch 17).
+// The stride-R scatter of the early passes then hits distinct banks (ds_write_b128 is served 8 lanes at a
+// time over 32 banks; pitch 17 elements = 68 dwords = 4 mod 32), and every access of a pass is
+// "lane base + compile-time offset", so the address arithmetic is one value per pass, not one per access.
+__device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }
+template <int N> constexpr int lds_elems() { return N + N / 16; }
 
 // Powers w^1 .. w^(R-1) applied to x[1..R-1]; products formed by squaring/multiplying with
 // depth <= log2(R) so the rounding error stays at a few ulp.
@@ -129,19 +132,24 @@ template <int R, typename C> __device__ __forceinline__ void apply_twiddle_power
 }
 
 // One Stockham pass of radix R over N points for butterfly j, data in registers x[r] = in[j + r*N/R].
-// Applies the inter-pass twiddle (Ns = product of the radices of the earlier passes), the R-point DFT,
-// and returns the output position of x[0]; x[r] belongs at  base + r*Ns.
+// Applies the inter-pass twiddle w1 = exp(-+2*pi*i*k/(Ns*R)), k = j mod Ns (Ns = product of the radices of
+// the earlier passes), then the R-point DFT, and returns the output position of x[0]; x[r] belongs at
+// base + r*Ns.  w1 depends on the lane only, so callers load it once per kernel (pass_twiddle below).
 template <int N, int R, int Ns, bool INV, typename C>
-__device__ __forceinline__ int stockham_butterfly(C (&x)[R], int j, const C *__restrict__ tw_pass)
+__device__ __forceinline__ int stockham_butterfly(C (&x)[R], int j, C w1)
 {
     int k = j & (Ns - 1);
-    if constexpr (Ns > 1) {
-        C w1 = tw_pass[k];                  // exp(-2*pi*i*k/(Ns*R))
-        if (INV) w1 = cconj(w1);
-        apply_twiddle_powers<R>(x, w1);
-    }
+    if constexpr (Ns > 1) apply_twiddle_powers<R>(x, w1);
     Dft<R, INV, C>::run(x);
     return (j - k) * R + k;
+}
+
+// the lane's twiddle for butterfly j of a pass whose table (Ns entries) starts at tw_pass
+template <int Ns, bool INV, typename C>
+__device__ __forceinline__ C pass_twiddle(const C *__restrict__ tw_pass, int j)
+{
+    C w = tw_pass[j & (Ns - 1)];
+    return INV ? cconj(w) : w;
 }
 
 // pass: registers (strided layout, requires R == N/NT, Ns == 1) -> LDS
@@ -151,129 +159,193 @@ __device__ __forceinline__ void pass_regs_to_lds(C (&x)[R], C *lds)
     static_assert(R == N / NT, "first pass radix must equal N/NT");
     const int j = threadIdx.x;
     Dft<R, INV, C>::run(x);
+    static_assert(16 % R == 0, "first pass radix must divide 16");
+    C *p = lds + lds_phys(j * R);           // (j*R + r) >> 4 == (j*R) >> 4 for r < R when R divides 16
 #pragma unroll
-    for (int r = 0; r < R; r++) lds[lds_phys(j * R + r)] = x[r];
+    for (int r = 0; r < R; r++) p[r] = x[r];
 }
+
+template <int N, int R> struct PassGeom {
+    static constexpr int NB = N / R;                    // butterflies in the pass
+    static constexpr int PER = (NB + NT - 1) / NT;      // per thread
+};
 
 // pass: LDS -> LDS (in place; barrier between the read and the write phase)
 template <int N, int R, int Ns, bool INV, typename C>
-__device__ __forceinline__ void pass_lds_to_lds(C *lds, const C *__restrict__ tw_pass)
+__device__ __forceinline__ void pass_lds_to_lds(C *lds, const C (&w1)[PassGeom<N, R>::PER])
 {
-    constexpr int NB = N / R;               // butterflies in this pass
-    constexpr int PER = (NB + NT - 1) / NT; // per thread
+    constexpr int NB = PassGeom<N, R>::NB;
+    constexpr int PER = PassGeom<N, R>::PER;
     C x[PER][R];
     int base[PER];
+    static_assert(NB % 16 == 0, "pass geometry");
 #pragma unroll
     for (int p = 0; p < PER; p++) {
         int j = threadIdx.x + p * NT;
         if (NB >= NT || j < NB) {
+            const C *q = lds + lds_phys(j);
 #pragma unroll
-            for (int r = 0; r < R; r++) x[p][r] = lds[lds_phys(j + r * NB)];
+            for (int r = 0; r < R; r++) x[p][r] = q[r * (NB + NB / 16)];
         }
     }
 #pragma unroll
     for (int p = 0; p < PER; p++) {
         int j = threadIdx.x + p * NT;
-        if (NB >= NT || j < NB) base[p] = stockham_butterfly<N, R, Ns, INV>(x[p], j, tw_pass);
+        if (NB >= NT || j < NB) base[p] = stockham_butterfly<N, R, Ns, INV>(x[p], j, w1[p]);
     }
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < PER; p++) {
         int j = threadIdx.x + p * NT;
         if (NB >= NT || j < NB) {
+            if constexpr (Ns % 16 == 0) {
+                C *q = lds + lds_phys(base[p]);
 #pragma unroll
-            for (int r = 0; r < R; r++) lds[lds_phys(base[p] + r * Ns)] = x[p][r];
+                for (int r = 0; r < R; r++) q[r * (Ns + Ns / 16)] = x[p][r];
+            } else if constexpr (16 % (Ns * R) == 0) {
+                C *q = lds + lds_phys(base[p]);     // the R outputs stay inside one 16-element row
+#pragma unroll
+                for (int r = 0; r < R; r++) q[r * Ns] = x[p][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) lds[lds_phys(base[p] + r * Ns)] = x[p][r];
+            }
         }
     }
 }
 
 // pass: LDS -> registers (strided layout; requires R == N/NT and Ns == N/R, the last pass)
 template <int N, int R, bool INV, typename C>
-__device__ __forceinline__ void pass_lds_to_regs(const C *lds, C (&x)[R], const C *__restrict__ tw_pass)
+__device__ __forceinline__ void pass_lds_to_regs(const C *lds, C (&x)[R], C w1)
 {
     static_assert(R == N / NT, "last pass radix must equal N/NT");
     const int j = threadIdx.x;
+    const C *q = lds + lds_phys(j);
 #pragma unroll
-    for (int r = 0; r < R; r++) x[r] = lds[lds_phys(j + r * NT)];
-    stockham_butterfly<N, R, N / R, INV>(x, j, tw_pass);   // output of x[r] is element j + r*NT
+    for (int r = 0; r < R; r++) x[r] = q[r * (NT + NT / 16)];
+    stockham_butterfly<N, R, N / R, INV>(x, j, w1);     // output of x[r] is element j + r*NT
 }
 
 // ---------------------------------------------------------------------------------------------
-// Radix plans.  first == last == N/NT; the middle radices multiply to NT*NT/N ... (N/first/last).
-// Twiddle tables: one per pass with Ns > 1, concatenated; entry k of a pass is exp(-2*pi*i*k/(Ns*R)).
-// Offsets below must match qh::fft_twiddle_table() in qh_design.cpp.
-template <int N> struct Plan;
-//            N      passes (radix)                  Ns per pass          table offsets
-template <> struct Plan<4096> { static constexpr int first = 16; };   // 16,16,16        1,16,256            [0,16)  [16,272)
-template <> struct Plan<2048> { static constexpr int first = 8; };    // 8,4,8,8         1,8,32,256          [0,8) [8,40) [40,296)
-template <> struct Plan<1024> { static constexpr int first = 4; };    // 4,4,4,4,4       1,4,16,64,256       [0,4) [4,20) [20,84) [84,340)
-template <> struct Plan<512>  { static constexpr int first = 2; };    // 2,16,8,2        1,2,32,256          [0,2) [2,34) [34,290)
-template <> struct Plan<8192> { static constexpr int first = 32; };   // 32,8,32         1,32,256            [0,32) [32,288)
-
-// Forward or inverse FFT: registers (strided layout) -> registers (strided layout), through LDS.
-// x has N/NT entries.  `tw` points at this N's concatenated pass tables.
+// FFT of N points: registers (strided layout) -> registers (strided layout), through LDS.
+//   first(x, lds)      pass 1: consumes x (dead afterwards), leaves the data in LDS
+//   rest(lds, x, tw)   barrier + remaining passes; result in x
+// Radix plans (first == last == N/NT).  Twiddle tables: one per pass with Ns > 1, concatenated; entry k
+// of a pass is exp(-2*pi*i*k/(Ns*R)).  Offsets must match qh::fft_twiddle_table() in qh_design.cpp.
+//      N      radices        Ns per pass        table offsets
+//      4096   16,16,16       1,16,256           [0,16) [16,272)
+//      2048   8,4,8,8        1,8,32,256         [0,8) [8,40) [40,296)
+//      1024   4,4,4,4,4      1,4,16,64,256      [0,4) [4,20) [20,84) [84,340)
+//      512    2,16,8,2       1,2,32,256         [0,2) [2,34) [34,290)
+//      8192   32,8,32        1,32,256           [0,32) [32,288)
 template <int N, bool INV, typename C> struct FftRR;
 
 template <bool INV, typename C> struct FftRR<4096, INV, C> {
-    static __device__ __forceinline__ void run(C (&x)[16], C *lds, const C *__restrict__ tw)
+    struct Tw { C a[1], b; };
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw)
     {
-        pass_regs_to_lds<4096, 16, INV>(x, lds);
+        Tw t;
+        t.a[0] = pass_twiddle<16, INV>(tw, threadIdx.x);
+        t.b = pass_twiddle<256, INV>(tw + 16, threadIdx.x);
+        return t;
+    }
+    static __device__ __forceinline__ void first(C (&x)[16], C *lds) { pass_regs_to_lds<4096, 16, INV>(x, lds); }
+    static __device__ __forceinline__ void rest(C *lds, C (&x)[16], const Tw &t)
+    {
         __syncthreads();
-        pass_lds_to_lds<4096, 16, 16, INV>(lds, tw);
+        pass_lds_to_lds<4096, 16, 16, INV>(lds, t.a);
         __syncthreads();
-        pass_lds_to_regs<4096, 16, INV>(lds, x, tw + 16);
+        pass_lds_to_regs<4096, 16, INV>(lds, x, t.b);
     }
 };
 
 template <bool INV, typename C> struct FftRR<2048, INV, C> {
-    static __device__ __forceinline__ void run(C (&x)[8], C *lds, const C *__restrict__ tw)
+    struct Tw { C a[2], b[1], c; };
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw)
     {
-        pass_regs_to_lds<2048, 8, INV>(x, lds);
+        Tw t;
+        t.a[0] = pass_twiddle<8, INV>(tw, threadIdx.x);
+        t.a[1] = pass_twiddle<8, INV>(tw, threadIdx.x + NT);
+        t.b[0] = pass_twiddle<32, INV>(tw + 8, threadIdx.x);
+        t.c = pass_twiddle<256, INV>(tw + 40, threadIdx.x);
+        return t;
+    }
+    static __device__ __forceinline__ void first(C (&x)[8], C *lds) { pass_regs_to_lds<2048, 8, INV>(x, lds); }
+    static __device__ __forceinline__ void rest(C *lds, C (&x)[8], const Tw &t)
+    {
         __syncthreads();
-        pass_lds_to_lds<2048, 4, 8, INV>(lds, tw);
+        pass_lds_to_lds<2048, 4, 8, INV>(lds, t.a);
         __syncthreads();
-        pass_lds_to_lds<2048, 8, 32, INV>(lds, tw + 8);
+        pass_lds_to_lds<2048, 8, 32, INV>(lds, t.b);
         __syncthreads();
-        pass_lds_to_regs<2048, 8, INV>(lds, x, tw + 40);
+        pass_lds_to_regs<2048, 8, INV>(lds, x, t.c);
     }
 };
 
 template <bool INV, typename C> struct FftRR<1024, INV, C> {
-    static __device__ __forceinline__ void run(C (&x)[4], C *lds, const C *__restrict__ tw)
+    struct Tw { C a[1], b[1], c[1], d; };
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw)
     {
-        pass_regs_to_lds<1024, 4, INV>(x, lds);
+        Tw t;
+        t.a[0] = pass_twiddle<4, INV>(tw, threadIdx.x);
+        t.b[0] = pass_twiddle<16, INV>(tw + 4, threadIdx.x);
+        t.c[0] = pass_twiddle<64, INV>(tw + 20, threadIdx.x);
+        t.d = pass_twiddle<256, INV>(tw + 84, threadIdx.x);
+        return t;
+    }
+    static __device__ __forceinline__ void first(C (&x)[4], C *lds) { pass_regs_to_lds<1024, 4, INV>(x, lds); }
+    static __device__ __forceinline__ void rest(C *lds, C (&x)[4], const Tw &t)
+    {
         __syncthreads();
-        pass_lds_to_lds<1024, 4, 4, INV>(lds, tw);
+        pass_lds_to_lds<1024, 4, 4, INV>(lds, t.a);
         __syncthreads();
-        pass_lds_to_lds<1024, 4, 16, INV>(lds, tw + 4);
+        pass_lds_to_lds<1024, 4, 16, INV>(lds, t.b);
         __syncthreads();
-        pass_lds_to_lds<1024, 4, 64, INV>(lds, tw + 20);
+        pass_lds_to_lds<1024, 4, 64, INV>(lds, t.c);
         __syncthreads();
-        pass_lds_to_regs<1024, 4, INV>(lds, x, tw + 84);
+        pass_lds_to_regs<1024, 4, INV>(lds, x, t.d);
     }
 };
 
 template <bool INV, typename C> struct FftRR<512, INV, C> {
-    static __device__ __forceinline__ void run(C (&x)[2], C *lds, const C *__restrict__ tw)
+    struct Tw { C a[1], b[1], c; };
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw)
     {
-        pass_regs_to_lds<512, 2, INV>(x, lds);
+        Tw t;
+        t.a[0] = pass_twiddle<2, INV>(tw, threadIdx.x);
+        t.b[0] = pass_twiddle<32, INV>(tw + 2, threadIdx.x);
+        t.c = pass_twiddle<256, INV>(tw + 34, threadIdx.x);
+        return t;
+    }
+    static __device__ __forceinline__ void first(C (&x)[2], C *lds) { pass_regs_to_lds<512, 2, INV>(x, lds); }
+    static __device__ __forceinline__ void rest(C *lds, C (&x)[2], const Tw &t)
+    {
         __syncthreads();
-        pass_lds_to_lds<512, 16, 2, INV>(lds, tw);
+        pass_lds_to_lds<512, 16, 2, INV>(lds, t.a);
         __syncthreads();
-        pass_lds_to_lds<512, 8, 32, INV>(lds, tw + 2);
+        pass_lds_to_lds<512, 8, 32, INV>(lds, t.b);
         __syncthreads();
-        pass_lds_to_regs<512, 2, INV>(lds, x, tw + 34);
+        pass_lds_to_regs<512, 2, INV>(lds, x, t.c);
     }
 };
 
 template <bool INV, typename C> struct FftRR<8192, INV, C> {
-    static __device__ __forceinline__ void run(C (&x)[32], C *lds, const C *__restrict__ tw)
+    struct Tw { C a[4], b; };
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw)
     {
-        pass_regs_to_lds<8192, 32, INV>(x, lds);
+        Tw t;
+#pragma unroll
+        for (int p = 0; p < 4; p++) t.a[p] = pass_twiddle<32, INV>(tw, threadIdx.x + p * NT);
+        t.b = pass_twiddle<256, INV>(tw + 32, threadIdx.x);
+        return t;
+    }
+    static __device__ __forceinline__ void first(C (&x)[32], C *lds) { pass_regs_to_lds<8192, 32, INV>(x, lds); }
+    static __device__ __forceinline__ void rest(C *lds, C (&x)[32], const Tw &t)
+    {
         __syncthreads();
-        pass_lds_to_lds<8192, 8, 32, INV>(lds, tw);
+        pass_lds_to_lds<8192, 8, 32, INV>(lds, t.a);
         __syncthreads();
-        pass_lds_to_regs<8192, 32, INV>(lds, x, tw + 32);
+        pass_lds_to_regs<8192, 32, INV>(lds, x, t.b);
     }
 };
 

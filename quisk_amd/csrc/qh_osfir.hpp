@@ -53,6 +53,7 @@ template <typename T> struct OsfirArgs {
     int off;                      // decimation phase
     int P;                        // pre-roll, multiple of D, >= ntaps - 1
     int Lout;                     // outputs per tile, <= (NFFT - P) / D
+    int ntiles;                   // ceil(n_out / Lout)
 };
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
@@ -70,6 +71,34 @@ template <> __device__ __forceinline__ void sincos_turns<float>(unsigned long lo
     c = (float)cd; s = (float)sd;
 }
 
+// Issue the NFFT/NT loads of one tile for this lane.  Branch-free: every lane always issues all its
+// loads back to back (clamped address; `okbits` says which values are real) so the requests are all in
+// flight together and nothing waits until the values are used.
+template <typename T, int E>
+__device__ __forceinline__ unsigned load_tile(cplx<T> (&x)[E], const cplx<T> *__restrict__ in,
+                                              const cplx<T> *__restrict__ hist, int hist_len, int n_in, int g0)
+{
+    using C = cplx<T>;
+    const C *hsafe = hist ? hist : in;
+    const int hlen = hist ? hist_len : 0;
+    const int last = n_in - 1;
+    unsigned okbits = 0;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int g = g0 + (int)threadIdx.x + r * NT;
+        const int gi = g < 0 ? 0 : (g > last ? last : g);
+        const int gh = g + hlen < 0 ? 0 : g + hlen;
+        const C *p = g >= 0 ? in + gi : hsafe + (g < 0 ? gh : 0);
+        const bool ok = g >= 0 ? g <= last : (g + hlen >= 0);
+        okbits |= (ok ? 1u : 0u) << r;
+        x[r] = *p;
+    }
+    return okbits;
+}
+
+// One workgroup = one tile (blockIdx.x) of one channel (blockIdx.y).  Straight-line code: a persistent
+// tile loop with register prefetch was tried and costs more in registers (spills at 2 workgroups/CU) than
+// it gains (tools/ab_bench.py, profiles/r01_notes.md); latency is hidden by the two workgroups per CU.
 template <typename T, int NFFT, int D, bool MIX>
 __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
 {
@@ -79,57 +108,55 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     constexpr int EO = E / D;               // elements per thread, inverse
     static_assert(E % D == 0 && EO >= 1, "decimation must divide NFFT/256");
     static_assert(NOUT >= 2 * NT, "NFFT/D must be >= 512");
+    static_assert(E <= 32, "validity bits are kept in one word");
+    using Fwd = FftRR<NFFT, false, C>;
+    using Inv = FftRR<NOUT, true, C>;
     extern __shared__ __align__(16) unsigned char smem[];
     C *lds = reinterpret_cast<C *>(smem);
 
     const int t = threadIdx.x;
     const int tile = blockIdx.x;
     const int ch = blockIdx.y;
-    const long long g0 = (long long)D * tile * a.Lout + a.off - a.P;   // input index of tile element 0
-
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
+    const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile
 
-    // ---- load NFFT inputs, strided register layout
-    // Branch-free: every lane always issues its E loads back to back (clamped address, value
-    // zeroed afterwards when out of range) so that all E requests are in flight together.
+    // Interior tiles (all NFFT inputs inside this call's buffer: every tile but the first and the last
+    // one or two of a channel) take plain loads; edge tiles take the clamped, history-aware path.
     C x[E];
-    {
-        const C *hsafe = hist ? hist : in;
-        const long long hlen = hist ? a.hist_len : 0;
-        const long long last = a.n_in - 1;
-        bool ok[E];
+    const bool interior = (g0 >= 0) && (g0 + NFFT <= a.n_in);       // workgroup-uniform
+    if (interior) {
+        const C *p = in + g0 + t;
 #pragma unroll
-        for (int r = 0; r < E; r++) {
-            const long long g = g0 + t + r * NT;
-            const long long gi = g < 0 ? 0 : (g > last ? last : g);
-            const long long gh = g + hlen < 0 ? 0 : g + hlen;
-            const C *p = g >= 0 ? in + gi : hsafe + (gh < hlen ? gh : 0);
-            ok[r] = g >= 0 ? g <= last : (g + hlen >= 0);
-            x[r] = *p;
-        }
+        for (int r = 0; r < E; r++) x[r] = p[r * NT];
+    } else {
+        const unsigned ok = load_tile<T, E>(x, in, hist, a.hist_len, a.n_in, g0);
 #pragma unroll
         for (int r = 0; r < E; r++)
-            if (!ok[r]) x[r] = mk<T>(0, 0);
+            if (!((ok >> r) & 1u)) x[r] = mk<T>(0, 0);
     }
     if constexpr (MIX) {
-        unsigned long long ph = a.nco_phase[ch] + a.nco_dphase[ch] * (unsigned long long)(g0 + t);
         C rot;
-        sincos_turns<T>(ph, rot.x, rot.y);
+        sincos_turns<T>(a.nco_phase[ch] + a.nco_dphase[ch] * (unsigned long long)(long long)(g0 + t), rot.x, rot.y);
         const double2 st = a.nco_step[ch];
         const C step = mk<T>((T)st.x, (T)st.y);
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < E; r++) {
-            long long g = g0 + t + r * NT;
-            if (g >= 0) x[r] = cmul(x[r], rot);      // history is stored already mixed
-            rot = cmul(rot, step);
+            for (int r = 0; r < E; r++) { x[r] = cmul(x[r], rot); rot = cmul(rot, step); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                if (g0 + t + r * NT >= 0) x[r] = cmul(x[r], rot);      // history is stored already mixed
+                rot = cmul(rot, step);
+            }
         }
     }
 
     // ---- forward FFT, registers -> registers
-    FftRR<NFFT, false, C>::run(x, lds, a.tw_fwd);
+    Fwd::first(x, lds);
+    Fwd::rest(lds, x, Fwd::load(a.tw_fwd));
 
-    // ---- mask multiply + D-fold: thread holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
+    // ---- mask multiply + D-fold: lane holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
     const C *mask = a.mask + (long long)ch * a.mask_stride;
     C z[EO];
 #pragma unroll
@@ -141,8 +168,9 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     }
 
     // ---- inverse FFT at NOUT points
-    __syncthreads();                        // all lanes are done reading LDS in the last forward pass
-    FftRR<NOUT, true, C>::run(z, lds, a.tw_inv);
+    __syncthreads();                        // every lane has finished reading LDS in the last forward pass
+    Inv::first(z, lds);
+    Inv::rest(lds, z, Inv::load(a.tw_inv));
 
     // ---- epilogue + store of the Lout valid outputs
     C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
@@ -151,9 +179,8 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
 #pragma unroll
     for (int i = 0; i < EO; i++) {
-        int j = t + NT * i;
-        int rel = j - j0;
-        long long m = (long long)tile * a.Lout + rel;
+        const int rel = t + NT * i - j0;
+        const long long m = (long long)tile * a.Lout + rel;
         if (rel >= 0 && rel < a.Lout && m < a.n_out) {
             C v;
             v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;

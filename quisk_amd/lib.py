@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libquiskhip.so")
+# QUISKHIP_LIB selects another build of the same library (kernel A/B experiments, tools/ab_bench.py)
+LIB_PATH = os.environ.get("QUISKHIP_LIB") or os.path.join(_HERE, "lib", "libquiskhip.so")
 _lib = None
 
 
