@@ -132,6 +132,29 @@ void SetRXASNBARun(int channel, int run);                                       
 /* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */
 int qh_wdsp_status(void);
 
+/* ------------------------------------------------------------------ 3. batched FIR decimator bank */
+/* GPU form of quisk_cDecimate / quisk_cCDecimate / quisk_cFilter (filter.c:203-257,372-375; filter.h:47-55)
+ * over `nch` independent complex streams that share one filter:
+ *     y[m] = sum_k h[k] * x[decim*m + (decim-1-phase) - k],   phase = the reference's decim_index, kept
+ * between calls like struct quisk_cFilter keeps it (filter.h:1-10), as is the ntaps-1 sample history.
+ * taps_im == NULL: real taps (quisk_cDecimate); else complex taps as quisk_filt_tune() builds them
+ * (quisk_cCDecimate).  With qh_hb45_taps() and decim 2 it is quisk_cDecim2HB45 (filter.c:377-417). */
+typedef struct qh_fir qh_fir;
+enum { QH_F64 = 0, QH_F32 = 1 };            /* sample type: interleaved complex double / complex float */
+
+qh_fir *qh_fir_create(int device, int nch, const double *taps_re, const double *taps_im, int ntaps, int decim,
+                      int dtype, void *stream);
+void qh_fir_destroy(qh_fir *f);
+int qh_fir_reset(qh_fir *f);                                   /* history and phase back to zero */
+int qh_fir_out_count(const qh_fir *f, int n_in);               /* outputs the next call with n_in samples produces */
+/* d_in [nch][in_stride], d_out [nch][out_stride] device pointers (strides in complex samples); *n_out = outputs
+ * per channel (may be 0).  Asynchronous on the filter's stream.  In-place (d_out == d_in) is not supported. */
+int qh_fir_process(qh_fir *f, const void *d_in, long long in_stride, int n_in, void *d_out, long long out_stride, int *n_out);
+int qh_fir_process_host(qh_fir *f, const void *h_in, long long in_stride, int n_in, void *h_out, long long out_stride, int *n_out);
+int qh_fir_synchronize(qh_fir *f);
+/* The 43 taps (delays 0..42) of Quisk's 45-tap half-band whose outer taps are zero (filter.c:382-385). */
+void qh_hb45_taps(double *taps43);
+
 #ifdef __cplusplus
 }
 #endif

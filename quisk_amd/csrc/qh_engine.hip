@@ -41,21 +41,9 @@ int set_error(int code, const char *fmt, ...)
     return code;
 }
 
-#define QH_HIP(expr)                                                                                  \
-    do {                                                                                              \
-        hipError_t _e = (expr);                                                                       \
-        if (_e != hipSuccess)                                                                         \
-            return set_error(QH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-
 static constexpr int kNfft = 4096;          // FFT size of every overlap-save stage in this engine
 static constexpr int kHistBand = 2047;      // fircore history capacity: nc up to 2048
 static constexpr int kHistFront = 1120;     // resampler history capacity: 140 * D taps, D <= 8
-
-template <typename T> static hipError_t dev_alloc(T **p, size_t n)
-{
-    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
-}
 
 struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33

@@ -54,6 +54,7 @@ template <typename T> struct OsfirArgs {
     int P;                        // pre-roll, multiple of D, >= ntaps - 1
     int Lout;                     // outputs per tile, <= (NFFT - P) / D
     int ntiles;                   // ceil(n_out / Lout)
+    int pick;                     // 0/1: every folded sample is an output; k > 1: every k-th (n_out counts final outputs)
 };
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     const int ch = blockIdx.y;
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
-    const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile
+    const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile (Lout counts folded samples)
 
     // Interior tiles (all NFFT inputs inside this call's buffer: every tile but the first and the last
     // one or two of a channel) take plain loads; edge tiles take the clamped, history-aware path.
@@ -177,15 +178,32 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     const int j0 = a.P / D;
     EpiParam ep;
     if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+    if (a.pick <= 1) {
 #pragma unroll
-    for (int i = 0; i < EO; i++) {
-        const int rel = t + NT * i - j0;
-        const long long m = (long long)tile * a.Lout + rel;
-        if (rel >= 0 && rel < a.Lout && m < a.n_out) {
-            C v;
-            v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
-            v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
-            out[m] = v;
+        for (int i = 0; i < EO; i++) {
+            const int rel = t + NT * i - j0;
+            const long long m = (long long)tile * a.Lout + rel;
+            if (rel >= 0 && rel < a.Lout && m < a.n_out) {
+                C v;
+                v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
+                v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
+                out[m] = v;
+            }
+        }
+    } else {
+        // total decimation D * pick: keep every pick-th sample of the D-folded result (Lout % pick == 0)
+        const int lpt = a.Lout / a.pick;    // final outputs per tile
+#pragma unroll
+        for (int i = 0; i < EO; i++) {
+            const int rel = t + NT * i - j0;
+            const int q = rel / a.pick;
+            const long long m = (long long)tile * lpt + q;
+            if (rel >= 0 && rel < a.Lout && q * a.pick == rel && m < a.n_out) {
+                C v;
+                v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
+                v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
+                out[m] = v;
+            }
         }
     }
 }

@@ -9,13 +9,11 @@
 // bfo = 1 the caller blocks until output is available, so in sample terms the behaviour is
 // deterministic: output lags input by (DSP_MULT-1)*r2_size + dsp_outsize samples.  The same
 // sequence is executed here synchronously on the calling thread.
-#include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
-#include "../../include/quiskhip.h"
 #include "qh_internal.hpp"
 
 extern "C" int qh_rxa_flush(qh_rxa *e);

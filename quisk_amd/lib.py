@@ -60,6 +60,17 @@ def load():
     L.qh_rxa_enable_timing.restype = i
     L.qh_rxa_timing.argtypes = [vp, C.POINTER(d), i]
     L.qh_rxa_timing.restype = i
+    L.qh_fir_create.restype = vp
+    L.qh_fir_create.argtypes = [i, i, vp, vp, i, i, i, vp]
+    L.qh_fir_destroy.argtypes = [vp]
+    L.qh_fir_destroy.restype = None
+    L.qh_fir_reset.argtypes = [vp]
+    L.qh_fir_out_count.argtypes = [vp, i]
+    L.qh_fir_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_fir_process_host.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_fir_synchronize.argtypes = [vp]
+    L.qh_hb45_taps.argtypes = [vp]
+    L.qh_hb45_taps.restype = None
     _lib = L
     return L
 
