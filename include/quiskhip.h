@@ -146,6 +146,9 @@ qh_fir *qh_fir_create(int device, int nch, const double *taps_re, const double *
                       int dtype, void *stream);
 void qh_fir_destroy(qh_fir *f);
 int qh_fir_reset(qh_fir *f);                                   /* history and phase back to zero */
+/* Load state from the host: hist = the ntaps-1 most recent samples per channel, oldest first ([nch][ntaps-1],
+ * NULL = zeros); phase = decim_index (0 .. decim-1). */
+int qh_fir_set_state(qh_fir *f, const void *hist, int phase);
 int qh_fir_out_count(const qh_fir *f, int n_in);               /* outputs the next call with n_in samples produces */
 /* d_in [nch][in_stride], d_out [nch][out_stride] device pointers (strides in complex samples); *n_out = outputs
  * per channel (may be 0).  Asynchronous on the filter's stream.  In-place (d_out == d_in) is not supported. */
@@ -154,6 +157,37 @@ int qh_fir_process_host(qh_fir *f, const void *h_in, long long in_stride, int n_
 int qh_fir_synchronize(qh_fir *f);
 /* The 43 taps (delays 0..42) of Quisk's 45-tap half-band whose outer taps are zero (filter.c:382-385). */
 void qh_hb45_taps(double *taps43);
+
+/* ------------------------------------------------------------------ 4. filter.h drop-in exports */
+/* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library
+ * instead of filter.o.  `double *` stands for `complex double *` (same ABI: interleaved re, im).  Each call
+ * takes the filter state from the caller's struct (circular history, ptcSamp, decim_index / toggle), runs the
+ * block on the GPU and writes the state back in the reference's format, so calls may be mixed freely with the
+ * reference's own functions on the same struct.  Errors (no device ...) return 0 samples and set
+ * qh_last_error(); nothing is computed on the CPU. */
+struct quisk_cFilter {                      /* filter.h:1-10 */
+    double *dCoefs;
+    double *cpxCoefs;                       /* complex double * */
+    int nBuf;
+    int nTaps;
+    int decim_index;
+    double *cSamples;                       /* complex double *, nTaps entries */
+    double *ptcSamp;                        /* next write position inside cSamples */
+    double *cBuf;
+};
+struct quisk_cHB45Filter {                  /* filter.h:23-29 */
+    double *cBuf;
+    int nBuf;
+    int toggle;
+    double samples[2 * 22];                 /* complex double samples[22] */
+    double center[2 * 11];                  /* complex double center[11]  */
+};
+void quisk_filt_cInit(struct quisk_cFilter *filter, double *coefs, int taps);               /* filter.c:9-20 */
+void quisk_filt_tune(struct quisk_cFilter *filter, double freq, int ssb_upper);             /* filter.c:58-81 */
+int quisk_cDecimate(double *cSamples, int count, struct quisk_cFilter *filter, int decim);  /* filter.c:203-229 */
+int quisk_cCDecimate(double *cSamples, int count, struct quisk_cFilter *filter, int decim); /* filter.c:231-257 */
+int quisk_cFilter(double *cSamples, int count, struct quisk_cFilter *filter);               /* filter.c:372-375 */
+int quisk_cDecim2HB45(double *cSamples, int count, struct quisk_cHB45Filter *filter);       /* filter.c:377-417 */
 
 #ifdef __cplusplus
 }

@@ -207,6 +207,24 @@ int qh_fir_reset(qh_fir *h)
     return QH_OK;
 }
 
+// Load the filter state from host memory: `hist` = the ntaps-1 most recent input samples of every channel,
+// oldest first, [nch][ntaps-1] in the bank's sample type (NULL = zeros); phase = decim_index.
+int qh_fir_set_state(qh_fir *h, const void *hist, int phase)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null filter");
+    FirBank &b = h->b;
+    if (phase < 0 || phase >= b.decim) return set_error(QH_ERR_INVALID, "phase out of range");
+    QH_HIP(hipSetDevice(b.device));
+    QH_HIP(hipMemsetAsync(b.hist[b.cur], 0, (size_t)b.nch * b.P * b.esize, b.stream));
+    const int nh = b.ntaps - 1;
+    if (hist && nh > 0)
+        QH_HIP(hipMemcpy2DAsync(static_cast<char *>(b.hist[b.cur]) + (size_t)(b.P - nh) * b.esize, (size_t)b.P * b.esize, hist,
+                                (size_t)nh * b.esize, (size_t)nh * b.esize, (size_t)b.nch, hipMemcpyHostToDevice, b.stream));
+    QH_HIP(hipStreamSynchronize(b.stream));
+    b.phase = phase;
+    return QH_OK;
+}
+
 int qh_fir_process(qh_fir *h, const void *d_in, long long in_stride, int n_in, void *d_out, long long out_stride, int *n_out)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null filter");
