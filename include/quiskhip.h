@@ -70,6 +70,11 @@ int qh_rxa_SetRXAPanelGain1(qh_rxa *e, int ch, double gain);
 int qh_rxa_SetRXAPanelGain2(qh_rxa *e, int ch, double gainI, double gainQ);
 int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
 int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
+int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
+int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *e, int ch, int levelfade);
+int qh_rxa_SetRXAFMDeviation(qh_rxa *e, int ch, double deviation);
+int qh_rxa_SetRXACTCSSFreq(qh_rxa *e, int ch, double freq);
+int qh_rxa_SetRXACTCSSRun(qh_rxa *e, int ch, int run);
 
 /* Runs xrxa() (wdsp/RXA.c:561-598) over `nblk` consecutive DSP blocks of every channel.
  *   d_in  : device pointer, [nch][in_stride] interleaved complex double, nblk*dsp_insize samples used
@@ -124,6 +129,11 @@ void SetRXAPanelGain1(int channel, double gain);                                
 void SetRXAPanelGain2(int channel, double gainI, double gainQ);                  /* wdsp/patchpanel.c:147-154 */
 void SetRXAPanelSelect(int channel, int select);                                 /* wdsp/patchpanel.c:131-137 */
 void SetRXAPanelCopy(int channel, int copy);                                     /* wdsp/patchpanel.c:175-181 */
+void SetRXAAMDSBMode(int channel, int sbmode);                                   /* wdsp/amd.c:277-283 */
+void SetRXAAMDFadeLevel(int channel, int levelfade);                             /* wdsp/amd.c:285-291 */
+void SetRXAFMDeviation(int channel, double deviation);                           /* wdsp/fmd.c:236-246 */
+void SetRXACTCSSFreq(int channel, double freq);                                  /* wdsp/fmd.c:248-258 */
+void SetRXACTCSSRun(int channel, int run);                                       /* wdsp/fmd.c:260-267 */
 /* accepted and ignored: these blocks are run = 0 on the hot path */
 void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c */
 void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */

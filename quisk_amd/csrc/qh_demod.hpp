@@ -1,0 +1,288 @@
+// qh_demod.hpp -- WDSP demodulators for gfx950: AM envelope + fade leveler, SAM / FM phase-locked loops,
+// CTCSS notch.  One 64-lane wavefront per receiver channel, samples taken 64 at a time (coalesced).
+//
+//   am_detect_kernel   xamd mode 0 (wdsp/amd.c:131-146): |z| and two one-pole averages.  The averages are
+//                      linear recurrences, solved inside the wavefront by a Kogge-Stone scan with constant
+//                      coefficients (v_i += m^d * v_{i-d}), the carry passing from one 64-sample group to the next.
+//   pll_kernel         xamd mode 1 (amd.c:148-232) and the discriminator of xfmd (fmd.c:151-172).  A PLL is a
+//                      non-linear recurrence: strictly sequential per channel (SURVEY.md hard part 3).  Every
+//                      lane runs the same recurrence; lane i keeps the i-th result, so loads and stores stay
+//                      coalesced and no lane diverges.  Parallelism = channels.
+//   snotch_kernel      xsnotch (wdsp/iir.c:76-95): bi-quad on the I component only; 2x2 constant-matrix scan.
+#pragma once
+#include "qh_fft.hpp"
+
+namespace qh {
+
+static constexpr double kTwoPiRef = 6.2831853071795864;     // wdsp/comm.h:147
+
+struct AmParam {            // per engine (depends on the DSP rate only), init_amd wdsp/amd.c:86-89
+    double mtauR, onem_mtauR, mtauI, onem_mtauI;
+};
+
+struct AmState { double dc, dc_insert; };
+
+// x^(lane+1) for lane = 0..63 (wave-wide), by repeated squaring per lane
+__device__ __forceinline__ double lane_pow(double x, int e)
+{
+    double r = 1.0, b = x;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        if (e & (1 << k)) r *= b;
+        b *= b;
+    }
+    return r;
+}
+
+// inclusive scan of v_i = m*v_{i-1} + u_i over the 64 lanes with zero carry-in: returns sum_j m^(i-j) u_j
+__device__ __forceinline__ double scan_pole(double u, double m, int lane)
+{
+    double md = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double up = __shfl_up(u, d, 64);
+        if (lane >= d) u = __builtin_fma(md, up, u);
+        md *= md;
+    }
+    return u;
+}
+
+// buf: [nch][stride] complex, n samples per channel, in place.  One wave per listed channel.
+static __global__ __launch_bounds__(64) void am_detect_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                       const int *levelfade, AmState *state, AmParam prm)
+{
+    const int ch = chan_list[blockIdx.x];
+    const int lane = threadIdx.x;
+    double2 *p = buf + (long long)ch * stride;
+    AmState st = state[ch];
+    const bool lf = levelfade[ch] != 0;
+    const double pR = lane_pow(prm.mtauR, lane + 1), pI = lane_pow(prm.mtauI, lane + 1);
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        const int i = base + lane;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[i];
+        double audio = sqrt(z.x * z.x + z.y * z.y);
+        if (lf) {
+            // dc = mtauR*dc + onem_mtauR*audio ; dc_insert = mtauI*dc_insert + onem_mtauI*audio
+            double dc = scan_pole(prm.onem_mtauR * audio, prm.mtauR, lane) + pR * st.dc;
+            double di = scan_pole(prm.onem_mtauI * audio, prm.mtauI, lane) + pI * st.dc_insert;
+            audio += di - dc;
+            st.dc = __shfl(dc, cnt - 1, 64);
+            st.dc_insert = __shfl(di, cnt - 1, 64);
+        }
+        if (lane < cnt) p[i] = make_double2(audio, audio);
+    }
+    if (lane == 0) state[ch] = st;
+}
+
+// ------------------------------------------------------------------------------------------------ PLLs
+struct PllParam {           // calc_fmd wdsp/fmd.c:29-44 ; init_amd wdsp/amd.c:72-89
+    double omega_min, omega_max, g1, g2;
+    double mtau, onem_mtau, again;                  // FM: dc removal and audio gain
+    double mtauR, onem_mtauR, mtauI, onem_mtauI;    // SAM: fade leveler
+};
+
+struct PllState {
+    double phs, fil_out, omega;
+    double fmdc;                                    // FM
+    double dc, dc_insert;                           // SAM
+    double dsI, dsQ;                                // SAM sideband separation
+    double a[24], b[24], c[24], d[24];              // SAM all-pass chains (3*STAGES + 3, wdsp/amd.h:64-67)
+};
+
+struct SamChanParam { int sbmode, levelfade; };
+
+// FM discriminator: in place, z -> (audio, audio).  One wave per listed channel.
+static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                    PllState *state, const double *again, PllParam q)
+{
+    const int ch = chan_list[blockIdx.x];
+    const int lane = threadIdx.x;
+    double2 *p = buf + (long long)ch * stride;
+    PllState *sp = state + ch;
+    double phs = sp->phs, fil_out = sp->fil_out, omega = sp->omega, fmdc = sp->fmdc;
+    const double gain = again[ch];
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[base + lane];
+        double mine = 0.0;
+        for (int i = 0; i < cnt; i++) {
+            const double I = __shfl(z.x, i, 64), Q = __shfl(z.y, i, 64);
+            double sn, cs;
+            sincos(phs, &sn, &cs);
+            double c0 = I * cs + Q * sn;
+            const double c1 = -I * sn + Q * cs;
+            if (c0 == 0.0 && c1 == 0.0) c0 = 1.0;
+            const double det = atan2(c1, c0);
+            const double del_out = fil_out;
+            omega += q.g2 * det;
+            if (omega < q.omega_min) omega = q.omega_min;
+            if (omega > q.omega_max) omega = q.omega_max;
+            fil_out = q.g1 * det + omega;
+            phs += del_out;
+            while (phs >= kTwoPiRef) phs -= kTwoPiRef;
+            while (phs < 0.0) phs += kTwoPiRef;
+            fmdc = q.mtau * fmdc + q.onem_mtau * fil_out;
+            const double audio = gain * (fil_out - fmdc);
+            if (lane == i) mine = audio;
+        }
+        if (lane < cnt) p[base + lane] = make_double2(mine, mine);
+    }
+    if (lane == 0) { sp->phs = phs; sp->fil_out = fil_out; sp->omega = omega; sp->fmdc = fmdc; }
+}
+
+// all-pass coefficients of the SAM sideband separator, wdsp/amd.c:91-106
+static __constant__ double kSamC0[7] = { -0.328201924180698, -0.744171491539427, -0.923022915444215, -0.978490468768238,
+                                  -0.994128272402075, -0.998458978159551, -0.999790306259206 };
+static __constant__ double kSamC1[7] = { -0.0991227952747244, -0.565619728761389, -0.857467122550052, -0.959123933111275,
+                                  -0.988739372718090, -0.996959189310611, -0.999282492800792 };
+
+// Synchronous AM: in place.  The all-pass state lives in LDS (uniform addresses: every lane reads and writes
+// the same words, which is a broadcast / same-value store).
+static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                     PllState *state, const SamChanParam *cprm, PllParam q)
+{
+    constexpr int STAGES = 7, OUT_IDX = 3 * STAGES;
+    const double *c0 = kSamC0, *c1 = kSamC1;
+    __shared__ double fa[24], fb[24], fc[24], fd[24];
+    const int ch = chan_list[blockIdx.x];
+    const int lane = threadIdx.x;
+    double2 *p = buf + (long long)ch * stride;
+    PllState *sp = state + ch;
+    const int sbmode = cprm[ch].sbmode, levelfade = cprm[ch].levelfade;
+    double phs = sp->phs, fil_out = sp->fil_out, omega = sp->omega, dc = sp->dc, dc_insert = sp->dc_insert;
+    double dsI = sp->dsI, dsQ = sp->dsQ;
+    if (lane < 24) { fa[lane] = sp->a[lane]; fb[lane] = sp->b[lane]; fc[lane] = sp->c[lane]; fd[lane] = sp->d[lane]; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[base + lane];
+        double mine = 0.0;
+        for (int i = 0; i < cnt; i++) {
+            const double I = __shfl(z.x, i, 64), Q = __shfl(z.y, i, 64);
+            double sn, cs;
+            sincos(phs, &sn, &cs);
+            const double ai = I * cs, bi = I * sn, aq = Q * cs, bq = Q * sn;
+            double ai_ps = 0, bi_ps = 0, aq_ps = 0, bq_ps = 0;
+            if (sbmode != 0) {
+                fa[0] = dsI; fb[0] = bi; fc[0] = dsQ; fd[0] = aq;
+                dsI = ai; dsQ = bq;
+                for (int j = 0; j < STAGES; j++) {
+                    const int k = 3 * j;
+                    fa[k + 3] = c0[j] * (fa[k] - fa[k + 5]) + fa[k + 2];
+                    fb[k + 3] = c1[j] * (fb[k] - fb[k + 5]) + fb[k + 2];
+                    fc[k + 3] = c0[j] * (fc[k] - fc[k + 5]) + fc[k + 2];
+                    fd[k + 3] = c1[j] * (fd[k] - fd[k + 5]) + fd[k + 2];
+                }
+                ai_ps = fa[OUT_IDX]; bi_ps = fb[OUT_IDX]; bq_ps = fc[OUT_IDX]; aq_ps = fd[OUT_IDX];
+                for (int j = OUT_IDX + 2; j > 0; j--) { fa[j] = fa[j - 1]; fb[j] = fb[j - 1]; fc[j] = fc[j - 1]; fd[j] = fd[j - 1]; }
+            }
+            double corr0 = ai + bq;
+            const double corr1 = -bi + aq;
+            double audio;
+            if (sbmode == 1) audio = (ai_ps - bi_ps) + (aq_ps + bq_ps);
+            else if (sbmode == 2) audio = (ai_ps + bi_ps) - (aq_ps - bq_ps);
+            else audio = corr0;
+            if (levelfade) {
+                dc = q.mtauR * dc + q.onem_mtauR * audio;
+                dc_insert = q.mtauI * dc_insert + q.onem_mtauI * corr0;
+                audio += dc_insert - dc;
+            }
+            if (lane == i) mine = audio;
+            if (corr0 == 0.0 && corr1 == 0.0) corr0 = 1.0;
+            const double det = atan2(corr1, corr0);
+            const double del_out = fil_out;
+            omega += q.g2 * det;
+            if (omega < q.omega_min) omega = q.omega_min;
+            if (omega > q.omega_max) omega = q.omega_max;
+            fil_out = q.g1 * det + omega;
+            phs += del_out;
+            while (phs >= kTwoPiRef) phs -= kTwoPiRef;
+            while (phs < 0.0) phs += kTwoPiRef;
+        }
+        if (lane < cnt) p[base + lane] = make_double2(mine, mine);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sp->phs = phs; sp->fil_out = fil_out; sp->omega = omega; sp->dc = dc; sp->dc_insert = dc_insert;
+        sp->dsI = dsI; sp->dsQ = dsQ;
+    }
+    if (lane < 24) { sp->a[lane] = fa[lane]; sp->b[lane] = fb[lane]; sp->c[lane] = fc[lane]; sp->d[lane] = fd[lane]; }
+}
+
+// ------------------------------------------------------------------------------------------------ CTCSS notch
+struct SnotchParam { double a0, a1, a2, b1, b2; int run; int pad; };     // calc_snotch wdsp/iir.c:35-49
+struct SnotchState { double x1, x2, y1, y2; };
+
+struct M2 { double a, b, c, d; };   // [[a, b], [c, d]]
+__device__ __forceinline__ M2 mmul(M2 x, M2 y)
+{
+    M2 r;
+    r.a = x.a * y.a + x.b * y.c; r.b = x.a * y.b + x.b * y.d;
+    r.c = x.c * y.a + x.d * y.c; r.d = x.c * y.b + x.d * y.d;
+    return r;
+}
+
+// y_i = b1*y_{i-1} + b2*y_{i-2} + f_i,  f_i = a0*x_i + a1*x_{i-1} + a2*x_{i-2};  only .x is filtered.
+static __global__ __launch_bounds__(64) void snotch_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                    const SnotchParam *prm, SnotchState *state)
+{
+    const int ch = chan_list[blockIdx.x];
+    const SnotchParam q = prm[ch];
+    if (!q.run) return;
+    const int lane = threadIdx.x;
+    double2 *p = buf + (long long)ch * stride;
+    SnotchState st = state[ch];
+    // A^(2^k), k = 0..5, and A^(lane+1)
+    M2 A; A.a = q.b1; A.b = q.b2; A.c = 1.0; A.d = 0.0;
+    M2 Apow[6];
+    Apow[0] = A;
+#pragma unroll
+    for (int k = 1; k < 6; k++) Apow[k] = mmul(Apow[k - 1], Apow[k - 1]);
+    M2 Al; Al.a = 1; Al.b = 0; Al.c = 0; Al.d = 1;
+    {
+        M2 b = A;
+        const int e = lane + 1;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            if (e & (1 << k)) Al = mmul(b, Al);
+            b = mmul(b, b);
+        }
+    }
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[base + lane];
+        const double x0 = z.x;
+        double xm1 = __shfl_up(x0, 1, 64), xm2 = __shfl_up(x0, 2, 64);
+        if (lane == 0) { xm1 = st.x1; xm2 = st.x2; }
+        if (lane == 1) xm2 = st.x1;
+        // state vector u = [y_i, y_{i-1}] driven by [f_i, 0]
+        double u0 = q.a0 * x0 + q.a1 * xm1 + q.a2 * xm2, u1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int d = 1 << k;
+            const double v0 = __shfl_up(u0, d, 64), v1 = __shfl_up(u1, d, 64);
+            if (lane >= d) {
+                u0 += Apow[k].a * v0 + Apow[k].b * v1;
+                u1 += Apow[k].c * v0 + Apow[k].d * v1;
+            }
+        }
+        const double y = u0 + Al.a * st.y1 + Al.b * st.y2;
+        if (lane < cnt) p[base + lane] = make_double2(y, z.y);
+        const double ym1 = __shfl_up(y, 1, 64);
+        // carry: the last valid sample's (x, y) pairs
+        const int last = cnt - 1;
+        const double ny1 = __shfl(y, last, 64);
+        const double ny2 = last >= 1 ? __shfl(ym1, last, 64) : st.y1;
+        const double nx1 = __shfl(x0, last, 64);
+        const double nx2 = last >= 1 ? __shfl(xm1, last, 64) : st.x1;
+        st.x1 = nx1; st.x2 = nx2; st.y1 = ny1; st.y2 = ny2;
+    }
+    if (lane == 0) state[ch] = st;
+}
+
+}  // namespace qh

@@ -24,6 +24,7 @@
 #include "../../include/quiskhip.h"
 #include "qh_design.hpp"
 #include "qh_kernels.hpp"
+#include "qh_demod.hpp"
 #include "qh_internal.hpp"
 
 namespace qh {
@@ -56,6 +57,10 @@ struct ChanCfg {
     double bp1_flow = -4150.0, bp1_fhigh = -150.0, bp1_gain = 1.0;
     double gain1 = 4.0, gain2I = 1.0, gain2Q = 1.0;             // RXA.c:464-474
     int inselect = 3, copy = 0;
+    int levelfade = 1, sbmode = 0;                              // RXA.c:180-181
+    double fm_dev = 5000.0, ctcss_freq = 254.1;                 // RXA.c:198,208
+    int ctcss_run = 1, fm_nc = 2048;                            // RXA.c:207,209-212
+    bool demod_dirty = true, ctcss_flush = false;
     bool nbp_dirty = true, bp1_dirty = true, nco_dirty = true, epi_dirty = true;
     bool nbp_flush = false, bp1_flush = false;
 };
@@ -86,9 +91,31 @@ struct Engine {
     int ev_used = 0;
     double last_ms[3] = { 0, 0, 0 };
 
+    // demodulators (allocated on first use)
+    bool demod_alloc = false, lists_dirty = true;
+    int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
+    int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0;
+    int *levelfade = nullptr;
+    AmState *am_state = nullptr;
+    AmParam am_prm{};
+    PllState *pll_state = nullptr;
+    double *fm_again = nullptr;
+    SamChanParam *sam_prm = nullptr;
+    PllParam sam_pll_prm{}, fm_pll_prm{};
+    SnotchParam *sn_prm = nullptr;
+    SnotchState *sn_state = nullptr;
+    double2 *mask_de = nullptr, *mask_aud = nullptr, *hist_de[2] = { nullptr, nullptr }, *hist_aud[2] = { nullptr, nullptr };
+    int cur_de = 0, cur_aud = 0, fm_nc_built = 0;
+
     ~Engine();
     int init();
     int refresh_params();
+    int refresh_demod();
+    int run_front(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
+                  long long n_in, long long n_mid);
+    void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
+                  long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
+                  const int *list, int nlist);
     int ensure_buffers(long long n_mid);
     int process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     void tick(int cat);
@@ -101,6 +128,9 @@ Engine::~Engine()
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
+    (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
+    for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -278,6 +308,125 @@ int Engine::refresh_params()
     return QH_OK;
 }
 
+// Demodulator state, channel lists and FM filters (only engines that run AM/SAM/FM channels get here).
+int Engine::refresh_demod()
+{
+    const double rate = (double)dsp_rate;
+    if (!demod_alloc) {
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 5));
+        list_am = list_buf; list_sam = list_buf + nch; list_fm = list_buf + 2 * nch; list_bp1 = list_buf + 3 * nch;
+        list_plain = list_buf + 4 * nch;
+        QH_HIP(dev_alloc(&levelfade, (size_t)nch));
+        QH_HIP(dev_alloc(&am_state, (size_t)nch));
+        QH_HIP(dev_alloc(&pll_state, (size_t)nch));
+        QH_HIP(dev_alloc(&fm_again, (size_t)nch));
+        QH_HIP(dev_alloc(&sam_prm, (size_t)nch));
+        QH_HIP(dev_alloc(&sn_prm, (size_t)nch));
+        QH_HIP(dev_alloc(&sn_state, (size_t)nch));
+        QH_HIP(hipMemsetAsync(am_state, 0, (size_t)nch * sizeof(AmState), stream));
+        QH_HIP(hipMemsetAsync(pll_state, 0, (size_t)nch * sizeof(PllState), stream));
+        QH_HIP(hipMemsetAsync(sn_state, 0, (size_t)nch * sizeof(SnotchState), stream));
+        QH_HIP(dev_alloc(&mask_de, (size_t)kNfft));
+        QH_HIP(dev_alloc(&mask_aud, (size_t)kNfft));
+        for (int i = 0; i < 2; i++) {
+            QH_HIP(dev_alloc(&hist_de[i], (size_t)nch * kHistBand));
+            QH_HIP(dev_alloc(&hist_aud[i], (size_t)nch * kHistBand));
+            QH_HIP(hipMemsetAsync(hist_de[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+            QH_HIP(hipMemsetAsync(hist_aud[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+        }
+        dev_bytes += (long long)nch * (5 * 4 + 4 + sizeof(AmState) + sizeof(PllState) + 8 + sizeof(SamChanParam) +
+                                      sizeof(SnotchParam) + sizeof(SnotchState) + 4 * kHistBand * sizeof(double2)) +
+                     2ll * kNfft * sizeof(double2);
+        // init_amd (wdsp/amd.c:72-89) with create_rxa's constants (RXA.c:183-189)
+        {
+            const double zeta = 1.0, omegaN = 250.0, tauR = 0.02, tauI = 1.4;
+            PllParam &q = sam_pll_prm;
+            q.omega_min = kTwoPiRef * -2000.0 / rate; q.omega_max = kTwoPiRef * 2000.0 / rate;
+            q.g1 = 1.0 - std::exp(-2.0 * omegaN * zeta / rate);
+            q.g2 = -q.g1 + 2.0 * (1 - std::exp(-omegaN * zeta / rate) * std::cos(omegaN / rate * std::sqrt(1.0 - zeta * zeta)));
+            q.mtauR = std::exp(-1.0 / (rate * tauR)); q.onem_mtauR = 1.0 - q.mtauR;
+            q.mtauI = std::exp(-1.0 / (rate * tauI)); q.onem_mtauI = 1.0 - q.mtauI;
+            am_prm.mtauR = q.mtauR; am_prm.onem_mtauR = q.onem_mtauR; am_prm.mtauI = q.mtauI; am_prm.onem_mtauI = q.onem_mtauI;
+        }
+        // calc_fmd (wdsp/fmd.c:29-44) with create_rxa's constants (RXA.c:199-204)
+        {
+            const double zeta = 1.0, omegaN = 20000.0, tau = 0.02;
+            PllParam &q = fm_pll_prm;
+            q.omega_min = kTwoPiRef * -8000.0 / rate; q.omega_max = kTwoPiRef * 8000.0 / rate;
+            q.g1 = 1.0 - std::exp(-2.0 * omegaN * zeta / rate);
+            q.g2 = -q.g1 + 2.0 * (1 - std::exp(-omegaN * zeta / rate) * std::cos(omegaN / rate * std::sqrt(1.0 - zeta * zeta)));
+            q.mtau = std::exp(-1.0 / (rate * tau)); q.onem_mtau = 1.0 - q.mtau;
+        }
+        demod_alloc = true;
+        lists_dirty = true;
+        for (ChanCfg &c : cfg) c.demod_dirty = true;
+    }
+    if (lists_dirty) {
+        std::vector<int> la, ls, lf, lb, lp;
+        for (int ch = 0; ch < nch; ch++) {
+            const ChanCfg &c = cfg[(size_t)ch];
+            if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
+            if (c.amd_run && c.amd_mode == 1) ls.push_back(ch);
+            if (c.fmd_run) lf.push_back(ch);
+            if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
+        }
+        n_am = (int)la.size(); n_sam = (int)ls.size(); n_fm = (int)lf.size(); n_bp1 = (int)lb.size(); n_plain = (int)lp.size();
+        auto put = [&](int *dst, const std::vector<int> &v) -> hipError_t {
+            return v.empty() ? hipSuccess : hipMemcpyAsync(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+        };
+        QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
+        QH_HIP(hipStreamSynchronize(stream));
+        lists_dirty = false;
+    }
+    int want_nc = 0;
+    for (int ch = 0; ch < nch; ch++) {
+        ChanCfg &c = cfg[(size_t)ch];
+        if (c.fmd_run) {
+            if (want_nc && want_nc != c.fm_nc) return set_error(QH_ERR_UNSUPPORTED, "FM channels with different nc in one engine");
+            want_nc = c.fm_nc;
+        }
+        if (!c.demod_dirty) continue;
+        const int lf = c.levelfade;
+        const double again = rate / (c.fm_dev * kTwoPiRef);                 // wdsp/fmd.c:44
+        SamChanParam sp{ c.sbmode, c.levelfade };
+        SnotchParam sn{};
+        {   // calc_snotch, wdsp/iir.c:35-49 (bw 0.0002, fmd.c:47)
+            const double fn = c.ctcss_freq / (double)dsp_rate, csn = std::cos(kTwoPiRef * fn), qr = 1.0 - 3.0 * 0.0002;
+            const double qk = (1.0 - 2.0 * qr * csn + qr * qr) / (2.0 * (1.0 - csn));
+            sn.a0 = qk; sn.a1 = -2.0 * qk * csn; sn.a2 = qk; sn.b1 = 2.0 * qr * csn; sn.b2 = -qr * qr; sn.run = c.ctcss_run;
+        }
+        QH_HIP(hipMemcpyAsync(levelfade + ch, &lf, sizeof(int), hipMemcpyHostToDevice, stream));
+        QH_HIP(hipMemcpyAsync(fm_again + ch, &again, sizeof(double), hipMemcpyHostToDevice, stream));
+        QH_HIP(hipMemcpyAsync(sam_prm + ch, &sp, sizeof(sp), hipMemcpyHostToDevice, stream));
+        QH_HIP(hipMemcpyAsync(sn_prm + ch, &sn, sizeof(sn), hipMemcpyHostToDevice, stream));
+        if (c.ctcss_flush) {                    // calc_snotch ends with flush_snotch, wdsp/iir.c:48
+            QH_HIP(hipMemsetAsync(sn_state + ch, 0, sizeof(SnotchState), stream));
+            c.ctcss_flush = false;
+        }
+        QH_HIP(hipStreamSynchronize(stream));
+        c.demod_dirty = false;
+    }
+    if (want_nc && want_nc != fm_nc_built) {
+        // create_fmd, wdsp/fmd.c:108-116: de-emphasis by frequency sampling, audio band-pass 0.8*f_low .. 1.1*f_high
+        const double f_low = 300.0, f_high = 3000.0, afgain = 0.5;
+        std::vector<cd> de = fc_impulse(want_nc, f_low, f_high, +20.0 * std::log10(f_high / f_low), 0.0, 1, rate,
+                                        1.0 / (2.0 * dsp_size), 0, 0);
+        std::vector<cd> au = fir_bandpass(want_nc, 0.8 * f_low, 1.1 * f_high, rate, 0, 1, afgain / (2.0 * dsp_size));
+        for (auto &v : de) v *= (double)(2 * dsp_size);
+        for (auto &v : au) v *= (double)(2 * dsp_size);
+        if (int rc = upload(mask_de, make_mask(de, kNfft), stream)) return rc;
+        if (int rc = upload(mask_aud, make_mask(au, kNfft), stream)) return rc;
+        if (fm_nc_built) {      // setNc_fircore zeroes the delay lines, wdsp/firmin.c:454-466
+            for (int i = 0; i < 2; i++) {
+                QH_HIP(hipMemsetAsync(hist_de[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+                QH_HIP(hipMemsetAsync(hist_aud[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+            }
+        }
+        fm_nc_built = want_nc;
+    }
+    return QH_OK;
+}
+
 int Engine::ensure_buffers(long long n_mid)
 {
     if (n_mid <= buf_cap) return QH_OK;
@@ -315,23 +464,91 @@ static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s
     hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX>), grid, block, lds_elems<kNfft>() * sizeof(double2), s, a);
 }
 
+// ---- stage helpers ---------------------------------------------------------------------------
+// front: xshift + xresample(in) over all channels
+int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
+                      long long n_in, long long n_mid)
+{
+    tick(0);
+    if (D > 1) {
+        OsfirArgs<double> a{};
+        a.in = src; a.in_stride = src_stride;
+        a.hist = hist_front[cur_front]; a.hist_stride = kHistFront; a.hist_len = kHistFront;
+        a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
+        a.mask = mask_front; a.mask_stride = 0;
+        a.tw_fwd = tw4096; a.tw_inv = tw_inv_front;
+        a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
+        a.epi = ep;
+        a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L;
+        const int ntiles = (int)((n_mid + front_L - 1) / front_L);
+        switch (D) {
+        case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
+        case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
+        case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
+        default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
+        }
+        tick(2);
+        dim3 g((kHistFront + NT - 1) / NT, (unsigned)nch);
+        hipLaunchKernelGGL((hist_update_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
+                           hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase,
+                           (const int *)nullptr);
+        cur_front ^= 1;
+    } else {
+        long long per = (n_in + NT - 1) / NT;
+        dim3 g((unsigned)(per < 4096 ? per : 4096), (unsigned)nch);
+        hipLaunchKernelGGL((pointwise_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, dst, dst_stride,
+                           (int)n_in, nco_phase, nco_dphase, ep, (const int *)nullptr);
+        tick(2);
+    }
+    hipLaunchKernelGGL(nco_advance_kernel, dim3((nch + 255) / 256), dim3(256), 0, stream, nco_phase, nco_dphase, nch, n_in);
+    return QH_OK;
+}
+
+// one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
+void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
+                      long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
+                      const int *list, int nlist)
+{
+    const int Lout = kNfft - P;
+    const int ntiles = (int)((n_mid + Lout - 1) / Lout);
+    OsfirArgs<double> a{};
+    a.in = src; a.in_stride = src_stride;
+    a.hist = hist[hc]; a.hist_stride = kHistBand; a.hist_len = kHistBand;
+    a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
+    a.mask = mask; a.mask_stride = mask_stride;
+    a.tw_fwd = tw4096; a.tw_inv = tw4096;
+    a.epi = ep;
+    a.chan_list = list;
+    a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
+    tick(1);
+    launch_osfir<1, false>(a, ntiles, list ? nlist : nch, stream);
+    tick(2);
+    dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
+    hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
+                       hist[hc], hist[hc ^ 1], kHistBand, (const unsigned long long *)nullptr,
+                       (const unsigned long long *)nullptr, list);
+    // (a listed stage reads and writes the history rows of its own channels only)
+    hc ^= 1;
+}
+
 int Engine::process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
 {
     if (nblk <= 0) return QH_OK;
     QH_HIP(hipSetDevice(device));
     // what the chain of every channel needs
-    bool any_nbp = false, any_bp1 = false;
+    bool any_nbp = false, any_bp1 = false, mixed = false;
     int nc_max = 1;
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode != 0)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not on the GPU path yet: call SetRXAAGCMode(ch, 0)", c.agc_mode);
-        if (c.amd_run || c.fmd_run)
-            return set_error(QH_ERR_UNSUPPORTED, "AM/SAM/FM demodulators are not on the GPU path yet");
+        if (c.amd_run || c.fmd_run) mixed = true;
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
+        if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
     }
     if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
     if (int rc = refresh_params()) return rc;
+    if (mixed) if (int rc = refresh_demod()) return rc;
 
     const long long n_in = (long long)nblk * dsp_insize;
     const long long n_mid = (long long)nblk * dsp_size;
@@ -341,88 +558,73 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
 
     const double2 *in = reinterpret_cast<const double2 *>(d_in);
     double2 *out = reinterpret_cast<double2 *>(d_out);
-    const int nstage = 1 + (any_nbp ? 1 : 0) + (any_bp1 ? 1 : 0);
-    int stage = 0;
-    const double2 *cur = in;
-    long long cur_stride = in_stride;
-    int which = 0;
-    auto dst_of = [&](int st, long long &stride) -> double2 * {
-        if (st == nstage - 1) { stride = out_stride; return out; }
-        stride = buf_cap;
-        double2 *p = buf[which];
-        which ^= 1;
-        return p;
-    };
-
-    // ---- front: xshift + xresample(in)
-    tick(0);
-    {
-        long long dst_stride;
-        double2 *dst = dst_of(stage, dst_stride);
-        const EpiParam *ep = (stage == nstage - 1) ? epi : nullptr;
-        if (D > 1) {
-            OsfirArgs<double> a{};
-            a.in = cur; a.in_stride = cur_stride;
-            a.hist = hist_front[cur_front]; a.hist_stride = kHistFront; a.hist_len = kHistFront;
-            a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
-            a.mask = mask_front; a.mask_stride = 0;
-            a.tw_fwd = tw4096; a.tw_inv = tw_inv_front;
-            a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
-            a.epi = ep;
-            a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L;
-            const int ntiles = (int)((n_mid + front_L - 1) / front_L);
-            switch (D) {
-            case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
-            default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
-            }
-            tick(2);
-            dim3 g((kHistFront + NT - 1) / NT, (unsigned)nch);
-            hipLaunchKernelGGL((hist_update_kernel<double, true>), g, dim3(NT), 0, stream, cur, cur_stride, (int)n_in,
-                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase);
-            cur_front ^= 1;
-        } else {
-            long long per = (n_in + NT - 1) / NT;
-            dim3 g((unsigned)(per < 4096 ? per : 4096), (unsigned)nch);
-            hipLaunchKernelGGL((pointwise_kernel<double, true>), g, dim3(NT), 0, stream, cur, cur_stride, dst, dst_stride,
-                               (int)n_in, nco_phase, nco_dphase, ep);
-            tick(2);
-        }
-        hipLaunchKernelGGL(nco_advance_kernel, dim3((nch + 255) / 256), dim3(256), 0, stream, nco_phase, nco_dphase, nch, n_in);
-        cur = dst; cur_stride = dst_stride;
-        stage++;
-    }
-
-    // ---- nbp0 and bp1: fircore stages at the DSP rate
     const int P = nc_max - 1;
-    const int Lout = kNfft - P;
-    const int ntiles = (int)((n_mid + Lout - 1) / Lout);
-    for (int f = 0; f < 2; f++) {
-        if (f == 0 ? !any_nbp : !any_bp1) continue;
-        double2 **hist = f == 0 ? hist_nbp : hist_bp1;
-        int &hc = f == 0 ? cur_nbp : cur_bp1;
-        long long dst_stride;
-        double2 *dst = dst_of(stage, dst_stride);
-        OsfirArgs<double> a{};
-        a.in = cur; a.in_stride = cur_stride;
-        a.hist = hist[hc]; a.hist_stride = kHistBand; a.hist_len = kHistBand;
-        a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
-        a.mask = f == 0 ? mask_nbp : mask_bp1; a.mask_stride = kNfft;
-        a.tw_fwd = tw4096; a.tw_inv = tw4096;
-        a.epi = (stage == nstage - 1) ? epi : nullptr;
-        a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
-        tick(1);
-        launch_osfir<1, false>(a, ntiles, nch, stream);
-        tick(2);
-        dim3 g((kHistBand + NT - 1) / NT, (unsigned)nch);
-        hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, cur, cur_stride, (int)n_mid,
-                           hist[hc], hist[hc ^ 1], kHistBand, (const unsigned long long *)nullptr,
-                           (const unsigned long long *)nullptr);
-        hc ^= 1;
-        cur = dst; cur_stride = dst_stride;
-        stage++;
+
+    if (!mixed) {
+        // ---- every channel is a linear chain: the epilogue rides on the last stage, no extra pass
+        const int nstage = 1 + (any_nbp ? 1 : 0) + (any_bp1 ? 1 : 0);
+        int stage = 0, which = 0;
+        const double2 *cur = in;
+        long long cur_stride = in_stride;
+        auto dst_of = [&](int st, long long &stride) -> double2 * {
+            if (st == nstage - 1) { stride = out_stride; return out; }
+            stride = buf_cap;
+            double2 *p = buf[which];
+            which ^= 1;
+            return p;
+        };
+        {
+            long long dst_stride;
+            double2 *dst = dst_of(stage, dst_stride);
+            if (int rc = run_front(cur, cur_stride, dst, dst_stride, stage == nstage - 1 ? epi : nullptr, n_in, n_mid)) return rc;
+            cur = dst; cur_stride = dst_stride; stage++;
+        }
+        for (int f = 0; f < 2; f++) {
+            if (f == 0 ? !any_nbp : !any_bp1) continue;
+            long long dst_stride;
+            double2 *dst = dst_of(stage, dst_stride);
+            run_band(cur, cur_stride, dst, dst_stride, stage == nstage - 1 ? epi : nullptr, n_mid,
+                     f == 0 ? mask_nbp : mask_bp1, kNfft, f == 0 ? hist_nbp : hist_bp1, f == 0 ? cur_nbp : cur_bp1, P,
+                     nullptr, 0);
+            cur = dst; cur_stride = dst_stride; stage++;
+        }
+        tick(3);
+        QH_HIP(hipGetLastError());
+        return QH_OK;
     }
+
+    // ---- mixed modes: per-mode stages run on channel lists; gains/panel in a final pointwise pass
+    double2 *cur = buf[0], *other = buf[1];
+    if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid)) return rc;
+    if (any_nbp) {
+        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kNfft, hist_nbp, cur_nbp, P, nullptr, 0);
+        std::swap(cur, other);
+    }
+    tick(1);
+    if (n_am) hipLaunchKernelGGL(am_detect_kernel, dim3((unsigned)n_am), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+                                 list_am, levelfade, am_state, am_prm);
+    if (n_sam) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)n_sam), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+                                  list_sam, pll_state, sam_prm, sam_pll_prm);
+    if (n_fm) {
+        hipLaunchKernelGGL(fm_pll_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
+                           pll_state, fm_again, fm_pll_prm);
+        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm);      // de-emphasis
+        run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_aud, 0, hist_aud, cur_aud, P, list_fm, n_fm);   // audio filter
+        tick(1);
+        hipLaunchKernelGGL(snotch_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
+                           sn_prm, sn_state);
+    }
+    if (n_bp1) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, cur_bp1, P, list_bp1, n_bp1);
+    tick(2);
+    // xwcpagc mode 0 + xpanel
+    long long per = (n_mid + NT - 1) / NT;
+    const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
+    if (n_plain) hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3(gx, (unsigned)n_plain), dim3(NT), 0, stream, cur,
+                                    buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
+                                    (const unsigned long long *)nullptr, epi, list_plain);
+    if (n_bp1) hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3(gx, (unsigned)n_bp1), dim3(NT), 0, stream, other,
+                                  buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
+                                  (const unsigned long long *)nullptr, epi, list_bp1);
     tick(3);
     QH_HIP(hipGetLastError());
     return QH_OK;
@@ -511,6 +713,7 @@ int qh_rxa_SetRXAMode(qh_rxa *h, int ch, int mode)
             else if (mode == QH_FM) { c.fmd_run = 1; c.agc_run = 0; }
             bp1_set(c);
             c.epi_dirty = true;
+            h->e.lists_dirty = true;
         }
     });
 }
@@ -543,13 +746,19 @@ int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
     FOR_CH(h, ch, {
         if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; }
         if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; }
+        c.fm_nc = nc;                           // SetRXAFMNCde / SetRXAFMNCaud, wdsp/RXA.c:942-943
     });
 }
 
 int qh_rxa_SetRXAShiftRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.shift_run = run; c.nco_dirty = true; }); }
 int qh_rxa_SetRXAShiftFreq(qh_rxa *h, int ch, double f) { FOR_CH(h, ch, { c.shift_freq = f; c.nco_dirty = true; }); }
 int qh_rxa_RXANBPSetRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.nbp_run != run) { c.nbp_run = run; c.nbp_dirty = true; } }); }
-int qh_rxa_SetRXABandpassRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.bp1_run != run) { c.bp1_run = run; c.bp1_dirty = true; } }); }
+int qh_rxa_SetRXABandpassRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.bp1_run != run) { c.bp1_run = run; c.bp1_dirty = true; h->e.lists_dirty = true; } }); }
+int qh_rxa_SetRXAAMDSBMode(qh_rxa *h, int ch, int sbmode) { FOR_CH(h, ch, { c.sbmode = sbmode; c.demod_dirty = true; }); }
+int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *h, int ch, int levelfade) { FOR_CH(h, ch, { c.levelfade = levelfade; c.demod_dirty = true; }); }
+int qh_rxa_SetRXAFMDeviation(qh_rxa *h, int ch, double deviation) { FOR_CH(h, ch, { c.fm_dev = deviation; c.demod_dirty = true; }); }
+int qh_rxa_SetRXACTCSSFreq(qh_rxa *h, int ch, double freq) { FOR_CH(h, ch, { c.ctcss_freq = freq; c.demod_dirty = true; c.ctcss_flush = true; }); }
+int qh_rxa_SetRXACTCSSRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.ctcss_run = run; c.demod_dirty = true; }); }
 
 int qh_rxa_SetRXAAGCMode(qh_rxa *h, int ch, int mode)
 {
@@ -586,6 +795,15 @@ int qh_rxa_flush(qh_rxa *h)
         if (e.hist_front[i]) QH_HIP(hipMemsetAsync(e.hist_front[i], 0, (size_t)e.nch * kHistFront * sizeof(double2), e.stream));
         QH_HIP(hipMemsetAsync(e.hist_nbp[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
         QH_HIP(hipMemsetAsync(e.hist_bp1[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
+        if (e.demod_alloc) {
+            QH_HIP(hipMemsetAsync(e.hist_de[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
+            QH_HIP(hipMemsetAsync(e.hist_aud[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
+        }
+    }
+    if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch
+        QH_HIP(hipMemsetAsync(e.am_state, 0, (size_t)e.nch * sizeof(AmState), e.stream));
+        QH_HIP(hipMemsetAsync(e.pll_state, 0, (size_t)e.nch * sizeof(PllState), e.stream));
+        QH_HIP(hipMemsetAsync(e.sn_state, 0, (size_t)e.nch * sizeof(SnotchState), e.stream));
     }
     return QH_OK;
 }

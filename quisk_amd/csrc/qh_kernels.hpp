@@ -13,10 +13,11 @@ template <typename T, bool MIX>
 __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long long in_stride, int n_in,
                                                          const cplx<T> *old_hist, cplx<T> *new_hist, int H,
                                                          const unsigned long long *nco_phase,
-                                                         const unsigned long long *nco_dphase)
+                                                         const unsigned long long *nco_dphase,
+                                                         const int *chan_list = nullptr)
 {
     using C = cplx<T>;
-    const int ch = blockIdx.y;
+    const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
     const int j = blockIdx.x * NT + threadIdx.x;
     if (j >= H) return;
     const long long g = (long long)n_in - H + j;
@@ -49,10 +50,10 @@ __global__ __launch_bounds__(NT) void pointwise_kernel(const cplx<T> *in, long l
                                                        long long out_stride, int n,
                                                        const unsigned long long *nco_phase,
                                                        const unsigned long long *nco_dphase,
-                                                       const EpiParam *epi)
+                                                       const EpiParam *epi, const int *chan_list = nullptr)
 {
     using C = cplx<T>;
-    const int ch = blockIdx.y;
+    const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
     EpiParam ep;
     if (epi) ep = epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
     for (long long g = (long long)blockIdx.x * NT + threadIdx.x; g < n; g += (long long)gridDim.x * NT) {

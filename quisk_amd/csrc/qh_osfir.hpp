@@ -45,6 +45,7 @@ template <typename T> struct OsfirArgs {
     const unsigned long long *nco_dphase;  // [nch]
     const double2 *nco_step;               // [nch]
     const EpiParam *epi;          // [nch] or null
+    const int *chan_list;         // null: channel = blockIdx.y; else channel = chan_list[blockIdx.y] (sub-set launches)
     long long in_stride, hist_stride, out_stride, mask_stride;
     long long out_offset;
     int hist_len;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
 
     const int t = threadIdx.x;
     const int tile = blockIdx.x;
-    const int ch = blockIdx.y;
+    const int ch = a.chan_list ? a.chan_list[blockIdx.y] : (int)blockIdx.y;
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
     const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile (Lout counts folded samples)

@@ -374,6 +374,11 @@ void SetRXAPanelGain1(int channel, double gain) { WDSP_SETTER(qh_rxa_SetRXAPanel
 void SetRXAPanelGain2(int channel, double gainI, double gainQ) { WDSP_SETTER(qh_rxa_SetRXAPanelGain2(L.c->eng, 0, gainI, gainQ)); }
 void SetRXAPanelSelect(int channel, int select) { WDSP_SETTER(qh_rxa_SetRXAPanelSelect(L.c->eng, 0, select)); }
 void SetRXAPanelCopy(int channel, int copy) { WDSP_SETTER(qh_rxa_SetRXAPanelCopy(L.c->eng, 0, copy)); }
+void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMode(L.c->eng, 0, sbmode)); }
+void SetRXAAMDFadeLevel(int channel, int levelfade) { WDSP_SETTER(qh_rxa_SetRXAAMDFadeLevel(L.c->eng, 0, levelfade)); }
+void SetRXAFMDeviation(int channel, double deviation) { WDSP_SETTER(qh_rxa_SetRXAFMDeviation(L.c->eng, 0, deviation)); }
+void SetRXACTCSSFreq(int channel, double freq) { WDSP_SETTER(qh_rxa_SetRXACTCSSFreq(L.c->eng, 0, freq)); }
+void SetRXACTCSSRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXACTCSSRun(L.c->eng, 0, run)); }
 
 // xpanel never looks at its run flag (wdsp/patchpanel.c:55-101): accepted, no effect on the data.
 void SetRXAPanelRun(int channel, int run) { (void)run; g_status = QH_OK; (void)valid(channel); }

@@ -36,11 +36,11 @@ def load():
     L.qh_rxa_device_bytes.argtypes = [vp]
     L.qh_rxa_device_bytes.restype = ll
     for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
-              "SetRXAPanelSelect", "SetRXAPanelCopy"):
+              "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
         f.restype = i
-    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1"):
+    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]
         f.restype = i

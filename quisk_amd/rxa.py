@@ -12,7 +12,8 @@ from .lib import load, check, QuiskHipError
 
 _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
             "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1",
-            "RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2")
+            "RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2", "SetRXAAMDSBMode",
+            "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun")
 
 
 class RxaEngine:

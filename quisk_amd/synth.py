@@ -53,3 +53,22 @@ def make_input_torch(nch, n, device, fs=192000.0, first_channel=0, a1=0.1, a2=0.
             x[i] = torch.complex(re, im)
             del ph1, ph2, re, im
     return x
+
+
+def make_mode_input_numpy(mode, c, n, fs=192000.0, sigma=0.01):
+    """BASELINE config 4 inputs: 'usb' as make_input_numpy; 'am': carrier with m = 0.5, 1 kHz
+    modulation; 'fm': carrier with 1 kHz tone at +-3 kHz deviation; all at -shift_freq(c) so that the shift
+    brings the carrier to 0 Hz.  complex128 [n], noise from default_rng(1000 + c)."""
+    t = np.arange(n, dtype=np.float64)
+    rng = np.random.default_rng(1000 + c)
+    g = rng.standard_normal((n, 2))
+    noise = sigma * (g[:, 0] + 1j * g[:, 1])
+    fc = -shift_freq(c)
+    car = np.exp(2j * np.pi * ((fc / fs) * t % 1.0))
+    if mode == "usb":
+        return make_input_numpy(1, n, fs=fs, first_channel=c, sigma=sigma)[0]
+    if mode == "am":
+        return 0.1 * (1.0 + 0.5 * np.cos(2 * np.pi * 1000.0 / fs * t)) * car + noise
+    if mode == "fm":
+        return 0.1 * car * np.exp(1j * (3000.0 / 1000.0) * np.sin(2 * np.pi * 1000.0 / fs * t)) + noise
+    raise ValueError(mode)

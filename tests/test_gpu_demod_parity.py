@@ -1,0 +1,111 @@
+"""AM / SAM / FM demodulator chains on the GPU against the CPU oracle, and a mixed-mode engine in the shape of
+BASELINE config 4 (mode by channel mod 3).  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from quisk_amd import synth
+
+pytestmark = pytest.mark.gpu
+AM, FM, SAM, USB = 6, 5, 10, 1
+TOL = 1e-8          # north_star gate: 1e-6 relative RMS (float64)
+
+
+def _cfg_oracle(po, c, mode, **kw):
+    ch = po.WdspChannel(1024, 256, 192000, 48000, 48000)
+    ch.SetRXAShiftRun(1)
+    ch.SetRXAShiftFreq(synth.shift_freq(c))
+    ch.RXANBPSetRun(1)
+    ch.SetRXAMode(mode)
+    ch.SetRXAAGCMode(0)
+    ch.SetRXAAGCFixed(0.0)
+    _apply(lambda name, *a: getattr(ch, name)(*a), mode, kw)
+    return ch
+
+
+def _apply(call, mode, kw):
+    if mode == USB:
+        call("RXASetPassband", 300.0, 3000.0)
+    elif mode in (AM, SAM):
+        call("RXASetPassband", -4000.0, 4000.0)
+    elif mode == FM:
+        call("RXASetPassband", -8000.0, 8000.0)
+    if "sbmode" in kw:
+        call("SetRXAAMDSBMode", kw["sbmode"])
+    if "levelfade" in kw:
+        call("SetRXAAMDFadeLevel", kw["levelfade"])
+    if "deviation" in kw:
+        call("SetRXAFMDeviation", kw["deviation"])
+    if "ctcss_run" in kw:
+        call("SetRXACTCSSRun", kw["ctcss_run"])
+    if "ctcss_freq" in kw:
+        call("SetRXACTCSSFreq", kw["ctcss_freq"])
+
+
+def _cfg_engine(e, c, mode, **kw):
+    e.SetRXAShiftRun(c, 1)
+    e.SetRXAShiftFreq(c, synth.shift_freq(c))
+    e.RXANBPSetRun(c, 1)
+    e.SetRXAMode(c, mode)
+    e.SetRXAAGCMode(c, 0)
+    e.SetRXAAGCFixed(c, 0.0)
+    _apply(lambda name, *a: getattr(e, name)(c, *a), mode, kw)
+
+
+# PLL modes (SAM, FM): while the filters fill up the detector input is FFT round-off noise (1e-28), and atan2 is
+# scale invariant, so the loop's trajectory during acquisition depends on the last bit of whichever FFT is in
+# use -- in the reference as much as here (a 1e-15 relative change of the INPUT moves the oracle's own SAM output
+# by 1e-2 in the first blocks).  Differences then decay with the loop / dc-removal / fade-leveler time constants
+# (FM 0.02 s, SAM fade leveler 1.4 s), so these modes are compared after `settle` DSP blocks.
+@pytest.mark.parametrize("mode,sig,kw,nblk,settle", [
+    (AM, "am", {}, 48, 0), (AM, "am", {"levelfade": 0}, 48, 0),
+    (SAM, "am", {"levelfade": 0}, 160, 100), (SAM, "am", {"sbmode": 1, "levelfade": 0}, 160, 100),
+    (SAM, "am", {"sbmode": 2, "levelfade": 0}, 160, 100), (SAM, "am", {}, 4000, 3900),
+    (FM, "fm", {}, 192, 144), (FM, "fm", {"deviation": 2500.0, "ctcss_run": 0}, 192, 144),
+    (FM, "fm", {"ctcss_freq": 100.0}, 192, 144),
+])
+def test_single_mode_chain(qh, oracle, mode, sig, kw, nblk, settle):
+    x = synth.make_mode_input_numpy(sig, 0, nblk * 1024)
+    e = qh.RxaEngine(1)
+    _cfg_engine(e, 0, mode, **kw)
+    # three calls of uneven length (state carried through the scans and the PLL)
+    y = np.concatenate([e.process_host(x[None, :5 * 1024]), e.process_host(x[None, 5 * 1024:6 * 1024]),
+                        e.process_host(x[None, 6 * 1024:])], axis=1)[0]
+    ref = _cfg_oracle(oracle, 0, mode, **kw).xrxa(x)
+    err = rel_rms(y[settle * 256:], ref[settle * 256:])
+    assert err < (TOL if settle == 0 else 1e-6), err
+    # the demodulated 1 kHz tone is really there (not a trivially small output)
+    assert np.abs(ref[-4096:]).max() > 1e-3
+
+
+def test_mixed_modes_config4_shape(qh, oracle):
+    """12 channels, mode by c mod 3: USB / AM / FM (BASELINE config 4), two calls."""
+    nch, nblk = 12, 192
+    modes = [(USB, "usb"), (AM, "am"), (FM, "fm")]
+    x = np.stack([synth.make_mode_input_numpy(modes[c % 3][1], c, nblk * 1024) for c in range(nch)])
+    e = qh.RxaEngine(nch)
+    for c in range(nch):
+        _cfg_engine(e, c, modes[c % 3][0])
+    y = np.concatenate([e.process_host(x[:, :7 * 1024]), e.process_host(x[:, 7 * 1024:])], axis=1)
+    for c in range(nch):
+        ref = _cfg_oracle(oracle, c, modes[c % 3][0]).xrxa(x[c])
+        if modes[c % 3][0] == FM:       # after lock (see the note above)
+            err = rel_rms(y[c][144 * 256:], ref[144 * 256:])
+            assert err < 1e-6, (c, err)
+        else:
+            err = rel_rms(y[c], ref)
+            assert err < TOL, (c, err)
+
+
+def test_mode_switch_mid_stream(qh, oracle):
+    """USB -> AM -> USB on a running channel: bp1 is flushed when it starts (RXA.c:825) and its gain doubles."""
+    x = synth.make_mode_input_numpy("am", 0, 30 * 1024)
+    e = qh.RxaEngine(1)
+    _cfg_engine(e, 0, USB)
+    o = _cfg_oracle(oracle, 0, USB)
+    ys, rs = [], []
+    for k, mode in enumerate((USB, AM, USB)):
+        e.SetRXAMode(0, mode); o.SetRXAMode(mode)
+        seg = x[k * 10240:(k + 1) * 10240]
+        ys.append(e.process_host(seg[None, :])[0]); rs.append(o.xrxa(seg))
+    assert rel_rms(np.concatenate(ys), np.concatenate(rs)) < TOL
