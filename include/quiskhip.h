@@ -168,6 +168,27 @@ int qh_fir_synchronize(qh_fir *f);
 /* The 43 taps (delays 0..42) of Quisk's 45-tap half-band whose outer taps are zero (filter.c:382-385). */
 void qh_hb45_taps(double *taps43);
 
+/* ------------------------------------------------------------------ 5. batched panadapter */
+/* Quisk's spectrum display path for `nch` receivers: the FFT ring producer of quisk_process_samples
+ * (quisk.c:2454-2475), record_app's Hanning window (quisk.c:6003-6009) and get_graph job 1
+ * (quisk.c:5142-5331: window, complex FFT, RMS S-meter over the passband bins, fftshift, |X| average,
+ * box sum per pixel, 20*log10 - 20*(log10 count + log10 N + 31 log10 2), clamp [-200, 0]).
+ * Every completed block of fft_size samples is transformed (the reference drops blocks when the GUI is
+ * slow).  fft_size: 1024 .. 16384, power of two. */
+typedef struct qh_pan qh_pan;
+qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double sample_rate, void *stream);
+void qh_pan_destroy(qh_pan *p);
+/* S-meter passband of channel ch (-1 = all): starts at f_start = rx_tune_freq + filter_start_offset (Hz, signed),
+ * width = filter_bandwidth (quisk.c:5223-5229). */
+int qh_pan_set_smeter_band(qh_pan *p, int ch, double f_start, double bandwidth);
+/* Append n raw (pre-tune) IQ samples per channel, device pointer [nch][in_stride] complex double. */
+int qh_pan_feed(qh_pan *p, const double *d_in, long long in_stride, int n);
+int qh_pan_feed_host(qh_pan *p, const double *h_in, long long in_stride, int n);
+int qh_pan_count(const qh_pan *p);          /* FFTs averaged since the last qh_pan_graph */
+/* The refresh branch of get_graph: h_pixels [nch][data_width] dB, h_smeter [nch] dB (either may be NULL),
+ * *count = FFTs that were averaged (0: nothing was written, like get_graph returning None). */
+int qh_pan_graph(qh_pan *p, double zoom, double deltaf, double *h_pixels, double *h_smeter, int *count);
+
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library
  * instead of filter.o.  `double *` stands for `complex double *` (same ABI: interleaved re, im).  Each call

@@ -345,3 +345,36 @@ def ref_table(name, n):
         raise RuntimeError("oracle/_ref is not built")
     arr = (C.c_double * n).in_dll(R, name)
     return np.array(arr, dtype=np.float64)
+
+
+class OracleGraph:
+    """qo_graph wrapper: feed(x) then get(zoom, deltaf) -> (pixels, smeter_db, count) or None."""
+
+    def __init__(self, fft_size, data_width, rate):
+        L = lib()
+        L.qo_graph_create.restype = C.c_void_p
+        L.qo_graph_create.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.qo_graph_free.argtypes = [C.c_void_p]
+        L.qo_graph_set_smeter_band.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.qo_graph_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.qo_graph_get.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
+        self.L, self.data_width = L, data_width
+        self.h = L.qo_graph_create(fft_size, data_width, rate)
+
+    def set_smeter_band(self, f_start, bandwidth):
+        self.L.qo_graph_set_smeter_band(self.h, f_start, bandwidth)
+
+    def feed(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        return self.L.qo_graph_feed(self.h, x.ctypes.data, x.size)
+
+    def get(self, zoom=1.0, deltaf=0.0):
+        pix = np.empty(self.data_width, dtype=np.float64)
+        sm = C.c_double(0)
+        n = self.L.qo_graph_get(self.h, zoom, deltaf, pix.ctypes.data, C.byref(sm))
+        return None if n <= 0 else (pix, sm.value, n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_graph_free(self.h)
+            self.h = None

@@ -311,3 +311,111 @@ int qo_dInterp2HB45(double *x, int count, qo_hb45 *f)
     free(tmp);
     return nout;
 }
+
+/* ---------------------------------------------------------------- panadapter */
+#include "fft_oracle.h"
+
+struct qo_graph {
+    int fft_size, data_width, index, count_fft;
+    double rate, f_start, bandwidth, meter;
+    double *samples;    /* one FFT buffer (fft_data.samples) */
+    double *window, *avg;
+};
+
+qo_graph *qo_graph_create(int fft_size, int data_width, double fft_sample_rate)
+{
+    int i, j;
+    qo_graph *g = (qo_graph *)calloc(1, sizeof(*g));
+    g->fft_size = fft_size; g->data_width = data_width; g->rate = fft_sample_rate;
+    g->samples = (double *)calloc((size_t)fft_size * 2, sizeof(double));
+    g->window = (double *)malloc((size_t)fft_size * sizeof(double));
+    g->avg = (double *)calloc((size_t)fft_size, sizeof(double));
+    for (i = 0, j = -fft_size / 2; i < fft_size; i++, j++)          /* quisk.c:6003-6009, Hanning */
+        g->window[i] = 0.5 + 0.5 * cos(2. * M_PI * j / fft_size);
+    return g;
+}
+
+void qo_graph_free(qo_graph *g)
+{
+    if (!g) return;
+    free(g->samples); free(g->window); free(g->avg); free(g);
+}
+
+void qo_graph_set_smeter_band(qo_graph *g, double f_start, double bandwidth)
+{
+    g->f_start = f_start; g->bandwidth = bandwidth;
+}
+
+static void graph_block(qo_graph *g)       /* quisk.c:5211-5278 */
+{
+    int i, j, k, n, N = g->fft_size;
+    double d2, cr, ci;
+    for (i = 0; i < N; i++) { g->samples[2 * i] *= g->window[i]; g->samples[2 * i + 1] *= g->window[i]; }
+    fo_fft(g->samples, N, -1);
+    d2 = g->bandwidth * N / g->rate;
+    i = (int)(g->f_start * N / g->rate + 0.5);
+    n = (int)(floor(d2) + 0.01);
+    if (i > -N / 2 && i + n + 1 < N / 2) {
+        for (j = 0; j < n; i++, j++) {
+            k = i < 0 ? N + i : i;
+            cr = g->samples[2 * k]; ci = g->samples[2 * k + 1];
+            g->meter = g->meter + (cr * cr + ci * ci);
+        }
+        k = i < 0 ? N + i : i;
+        cr = g->samples[2 * k]; ci = g->samples[2 * k + 1];
+        g->meter = g->meter + (cr * cr + ci * ci) * (d2 - n);
+    }
+    g->count_fft++;
+    k = 0;
+    for (i = N / 2; i < N; i++) g->avg[k++] += hypot(g->samples[2 * i], g->samples[2 * i + 1]);   /* cabs */
+    for (i = 0; i < N / 2; i++) g->avg[k++] += hypot(g->samples[2 * i], g->samples[2 * i + 1]);
+}
+
+int qo_graph_feed(qo_graph *g, const double *x, int n)      /* quisk.c:2454-2475 */
+{
+    int i, done = 0;
+    for (i = 0; i < n; i++) {
+        g->samples[2 * g->index] = x[2 * i];
+        g->samples[2 * g->index + 1] = x[2 * i + 1];
+        if (++g->index >= g->fft_size) {
+            graph_block(g);
+            g->index = 0;
+            done++;
+        }
+    }
+    return done;
+}
+
+int qo_graph_get(qo_graph *g, double zoom, double deltaf, double *pixels, double *smeter_db)   /* quisk.c:5279-5327 */
+{
+    int i, j, k, n, N = g->fft_size, count = g->count_fft;
+    double d2, scale, smeter_scale, Smeter;
+    if (count <= 0) return 0;
+    scale = log10(count) + log10(N) + 31.0 * log10(2.0);
+    scale *= 20.0;
+    n = (int)(zoom * (double)N / g->data_width + 0.5);
+    if (n < 1) n = 1;
+    for (i = 0; i < g->data_width; i++) {       /* in place on fft_avg, like the reference */
+        k = (int)(N * (deltaf / g->rate + zoom * ((double)i / g->data_width - 0.5) + 0.5) + 0.1);
+        d2 = 0.0;
+        for (j = 0; j < n; j++, k++)
+            if (k >= 0 && k < N) d2 += g->avg[k];
+        g->avg[i] = d2;
+    }
+    smeter_scale = 1.0 / 2147483647.0 / N;
+    Smeter = g->meter * smeter_scale * smeter_scale / count;
+    g->meter = 0;
+    if (Smeter > 1E-16) Smeter = 10.0 * log10(Smeter);
+    else Smeter = -160.0;
+    Smeter += 4.25969;
+    if (smeter_db) *smeter_db = Smeter;
+    for (i = 0; i < g->data_width; i++) {
+        d2 = 20.0 * log10(g->avg[i]) - scale;
+        if (d2 < -200) d2 = -200;
+        else if (d2 > 0) d2 = 0;
+        pixels[i] = d2;
+    }
+    for (i = 0; i < N; i++) g->avg[i] = 0;
+    g->count_fft = 0;
+    return count;
+}

@@ -68,4 +68,26 @@ extern const double qo_hb45_coef[12];                                          /
 #ifdef __cplusplus
 }
 #endif
+
+/* ---------------------------------------------------------------- panadapter (quisk.c, PARITY UNPINNED) */
+/* Restates the FFT ring producer in quisk_process_samples (quisk.c:2454-2475, every full block is
+ * processed; the reference drops blocks when its 4-deep ring is full), record_app's Hanning window
+ * (quisk.c:6003-6009) and get_graph job 1 (quisk.c:5142-5331; scan_blocks = 0, no remote head). */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct qo_graph qo_graph;
+qo_graph *qo_graph_create(int fft_size, int data_width, double fft_sample_rate);
+void qo_graph_free(qo_graph *g);
+/* passband for the RMS S-meter: first bin from (rx_tune_freq + filter_start_offset), width filter_bandwidth */
+void qo_graph_set_smeter_band(qo_graph *g, double f_start, double bandwidth);
+/* append n complex samples; windows/transforms/averages every completed block.  Returns blocks completed. */
+int qo_graph_feed(qo_graph *g, const double *x, int n);
+/* the `1/graph_refresh has elapsed` branch: pixel row (data_width doubles, dB, clamped to [-200, 0]) and the
+ * S-meter in dB; resets the average.  Returns the number of FFTs that were averaged (0: nothing to return). */
+int qo_graph_get(qo_graph *g, double zoom, double deltaf, double *pixels, double *smeter_db);
+#ifdef __cplusplus
+}
+#endif
+
 #endif

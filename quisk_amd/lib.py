@@ -71,6 +71,15 @@ def load():
     L.qh_fir_synchronize.argtypes = [vp]
     L.qh_hb45_taps.argtypes = [vp]
     L.qh_hb45_taps.restype = None
+    L.qh_pan_create.restype = vp
+    L.qh_pan_create.argtypes = [i, i, i, i, d, vp]
+    L.qh_pan_destroy.argtypes = [vp]
+    L.qh_pan_destroy.restype = None
+    L.qh_pan_set_smeter_band.argtypes = [vp, i, d, d]
+    L.qh_pan_feed.argtypes = [vp, vp, ll, i]
+    L.qh_pan_feed_host.argtypes = [vp, vp, ll, i]
+    L.qh_pan_count.argtypes = [vp]
+    L.qh_pan_graph.argtypes = [vp, d, d, vp, vp, C.POINTER(i)]
     _lib = L
     return L
 
