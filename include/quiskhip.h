@@ -189,6 +189,28 @@ int qh_pan_count(const qh_pan *p);          /* FFTs averaged since the last qh_p
  * *count = FFTs that were averaged (0: nothing was written, like get_graph returning None). */
 int qh_pan_graph(qh_pan *p, double zoom, double deltaf, double *h_pixels, double *h_smeter, int *count);
 
+/* ------------------------------------------------------------------ 6. Quisk-native receiver bank */
+/* The receive path of quisk_process_samples (quisk.c:2289-2742) for `nch` receivers that share the sample rate
+ * and the mode: NCO tune (quisk.c:2477-2488) -> quisk_process_decimate (quisk.c:1673-1846, PlanDecimation rates:
+ * 48000 * 2^a 3^b 5^c) -> quisk_process_demodulate (quisk.c:1848-2068: CWL 0, CWU 1, LSB 2, USB 3, AM 4, FM 5, the
+ * rx_mode_type values of quisk.h:55-70) with the Rx filter of set_filters -> mono to both channels.  Output: 48 ksps
+ * complex (d + I*d).  process_agc, squelch, auto-notch and the noise blanker are not applied.
+ * The seven coefficient tables are those of filters.h (98, 147, 245, 50, 36, 186, 309 values). */
+typedef struct qh_qrx qh_qrx;
+qh_qrx *qh_qrx_create(int device, int nch, int sample_rate, int mode, const double *quiskFilt48dec24Coefs,
+                      const double *quiskFilt144D3Coefs, const double *quiskFilt240D5CoefsSharp,
+                      const double *quiskAudio24p4Coefs, const double *quiskAudio24p6Coefs,
+                      const double *quiskLpFilt48Coefs, const double *quiskAudioFmHpCoefs, void *stream);
+void qh_qrx_destroy(qh_qrx *r);
+int qh_qrx_filter_rate(const qh_qrx *r);                                   /* get_filter_rate, quisk.c:2787-2859 */
+int qh_qrx_set_tune(qh_qrx *r, int ch, int rx_tune_freq);                   /* set_tune, quisk.c:4702; ch -1 = all */
+int qh_qrx_set_filters(qh_qrx *r, int ch, const double *filtI, const double *filtQ, int size);  /* set_filters, quisk.c:4551 */
+int qh_qrx_out_count(const qh_qrx *r, int n_in);                            /* 48 ksps samples the next call returns */
+/* d_in [nch][in_stride] complex double at sample_rate, d_out [nch][out_stride] at 48 ksps; any n_in. */
+int qh_qrx_process(qh_qrx *r, const double *d_in, long long in_stride, int n_in, double *d_out, long long out_stride, int *n_out);
+int qh_qrx_process_host(qh_qrx *r, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out);
+int qh_qrx_synchronize(qh_qrx *r);
+
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library
  * instead of filter.o.  `double *` stands for `complex double *` (same ABI: interleaved re, im).  Each call

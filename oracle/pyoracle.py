@@ -378,3 +378,51 @@ class OracleGraph:
         if getattr(self, "h", None):
             self.L.qo_graph_free(self.h)
             self.h = None
+
+
+class QoRxTables(C.Structure):      # oracle/quisk_rx_oracle.h: qo_rx_tables
+    _fields_ = [(n, c_double_p) for n in ("f48dec24", "f144d3", "f240d5", "audio24p4", "audio24p6", "lp48", "fmhp")]
+
+
+class OracleQuiskRx:
+    """qo_rx wrapper: one Quisk-native receiver; process(x) returns the 48 ksps complex output."""
+
+    def __init__(self, sample_rate, tables):
+        L = lib()
+        L.qo_rx_create.restype = C.c_void_p
+        L.qo_rx_create.argtypes = [C.c_int, C.c_void_p]
+        L.qo_rx_free.argtypes = [C.c_void_p]
+        L.qo_rx_set_tune.argtypes = [C.c_void_p, C.c_int]
+        L.qo_rx_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.qo_rx_set_filters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.qo_rx_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.qo_rx_filter_srate.argtypes = [C.c_void_p]
+        self.L = L
+        keys = ("quiskFilt48dec24Coefs", "quiskFilt144D3Coefs", "quiskFilt240D5CoefsSharp", "quiskAudio24p4Coefs",
+                "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs")
+        self._keep = [np.ascontiguousarray(tables[k], dtype=np.float64) for k in keys]
+        self._t = QoRxTables(*[a.ctypes.data_as(c_double_p) for a in self._keep])
+        self.h = L.qo_rx_create(sample_rate, C.byref(self._t))
+        if not self.h:
+            raise ValueError("sample rate %d does not plan to 48000" % sample_rate)
+        self.rate = sample_rate
+
+    def set_tune(self, f): self.L.qo_rx_set_tune(self.h, int(f))
+    def set_mode(self, m): self.L.qo_rx_set_mode(self.h, int(m))
+
+    def set_filters(self, fI, fQ):
+        fI = np.ascontiguousarray(fI, dtype=np.float64)
+        fQ = np.ascontiguousarray(fQ, dtype=np.float64)
+        self.L.qo_rx_set_filters(self.h, fI.ctypes.data, fQ.ctypes.data, fI.size)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        buf = np.zeros(max(x.size, 16) * 2, dtype=np.complex128)
+        buf[:x.size] = x
+        n = self.L.qo_rx_process(self.h, buf.ctypes.data, x.size)
+        return buf[:n].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_rx_free(self.h)
+            self.h = None

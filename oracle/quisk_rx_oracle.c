@@ -1,0 +1,247 @@
+/* quisk_rx_oracle.c -- TEST INFRASTRUCTURE ONLY.  See quisk_rx_oracle.h. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "quisk_oracle.h"
+#include "quisk_rx_oracle.h"
+
+#define MAX_FILTER_SIZE 10001       /* quisk.h */
+#define FM_FILTER_DEMPH 300.0       /* quisk.c:40 */
+
+struct qo_rx {
+    int sample_rate, decim2, decim3, decim5, decim_srate, filter_srate, mode, tune;
+    qo_rx_tables t;
+    double tv_re, tv_im;            /* rxTuneVector, quisk.c:2308 */
+    /* quisk_process_decimate storage, quisk.c:1678-1698 */
+    qo_hb45 hb[5];
+    qo_fir d3[3], d5[3], d48to24;
+    /* quisk_process_demodulate storage, quisk.c:1855-1875 */
+    qo_hb45 dHB4, dHB5, dHB6, dHB7;
+    qo_fir dm48to24, audio24p4, audio12p2, audio24p6, audio48p3, fmhp;
+    double fm1_re, fm1_im, dc_remove, FM_a_0, FM_a_1, FM_b_1, FM_x_1, FM_y_1;
+    /* cRxFilterOut / dRxFilterOut storage, quisk.c:1190-1193,1225-1229 */
+    int sizeFilter, indexC, indexD;
+    double *filtI, *filtQ, *bufI, *bufQ, *bufC;
+    double *dsamples;
+    int dcap;
+};
+
+int qo_rx_decim_srate(const qo_rx *r) { return r->decim_srate; }
+int qo_rx_filter_srate(const qo_rx *r) { return r->filter_srate; }
+
+static int plan_decimation(int rate, int *p2, int *p3, int *p5)     /* quisk.c:1633-1671 */
+{
+    int i, best = rate, try_, i2, i3, i5, d2 = 0, d3 = 0, d5 = 0;
+    for (i2 = 0; i2 <= 6; i2++)
+        for (i3 = 0; i3 <= 3; i3++)
+            for (i5 = 0; i5 <= 3; i5++) {
+                try_ = rate;
+                for (i = 0; i < i2; i++) try_ /= 2;
+                for (i = 0; i < i3; i++) try_ /= 3;
+                for (i = 0; i < i5; i++) try_ /= 5;
+                if (try_ >= 48000 && try_ < best) { d2 = i2; d3 = i3; d5 = i5; best = try_; }
+            }
+    if (best >= 50000) best = best * 24 / 25;
+    *p2 = d2; *p3 = d3; *p5 = d5;
+    return best;
+}
+
+qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t)
+{
+    int i, d2, d3, d5, try_;
+    double www, nnn;
+    qo_rx *r;
+    plan_decimation(sample_rate, &d2, &d3, &d5);
+    try_ = sample_rate;
+    for (i = 0; i < d2; i++) try_ /= 2;
+    for (i = 0; i < d3; i++) try_ /= 3;
+    for (i = 0; i < d5; i++) try_ /= 5;
+    if (try_ != 48000) return NULL;         /* the 6/5 * 4/5 rational stage (quisk.c:1834-1838) is not restated */
+    r = (qo_rx *)calloc(1, sizeof(*r));
+    r->sample_rate = sample_rate; r->decim2 = d2; r->decim3 = d3; r->decim5 = d5;
+    r->t = *t;
+    r->tv_re = 1.0; r->tv_im = 0.0;
+    r->mode = QO_USB;
+    for (i = 0; i < 5; i++) qo_hb45_init(&r->hb[i]);
+    for (i = 0; i < 3; i++) { qo_fir_init(&r->d3[i], t->f144d3, 147, 1); qo_fir_init(&r->d5[i], t->f240d5, 245, 1); }
+    qo_fir_init(&r->d48to24, t->f48dec24, 98, 1);
+    qo_hb45_init(&r->dHB4); qo_hb45_init(&r->dHB5); qo_hb45_init(&r->dHB6); qo_hb45_init(&r->dHB7);
+    qo_fir_init(&r->dm48to24, t->f48dec24, 98, 1);
+    qo_fir_init(&r->audio24p4, t->audio24p4, 50, 0);
+    qo_fir_init(&r->audio12p2, t->audio24p4, 50, 0);            /* quisk.c:1884: same table */
+    qo_fir_init(&r->audio24p6, t->audio24p6, 36, 0);
+    qo_fir_init(&r->audio48p3, t->lp48, 186, 0);
+    qo_fir_init(&r->fmhp, t->fmhp, 309, 0);
+    r->fm1_re = 10; r->fm1_im = 0;                              /* quisk.c:1893 */
+    www = tan(M_PI * FM_FILTER_DEMPH / 48000);                  /* quisk.c:1894-1898 */
+    nnn = 1.0 / (1.0 + www);
+    r->FM_a_0 = www * nnn; r->FM_a_1 = r->FM_a_0; r->FM_b_1 = nnn * (www - 1.0);
+    r->filtI = (double *)calloc(MAX_FILTER_SIZE, sizeof(double));
+    r->filtQ = (double *)calloc(MAX_FILTER_SIZE, sizeof(double));
+    r->bufI = (double *)calloc(MAX_FILTER_SIZE, sizeof(double));
+    r->bufQ = (double *)calloc(MAX_FILTER_SIZE, sizeof(double));
+    r->bufC = (double *)calloc(2 * MAX_FILTER_SIZE, sizeof(double));
+    return r;
+}
+
+void qo_rx_free(qo_rx *r)
+{
+    int i;
+    if (!r) return;
+    for (i = 0; i < 3; i++) { qo_fir_free(&r->d3[i]); qo_fir_free(&r->d5[i]); }
+    qo_fir_free(&r->d48to24); qo_fir_free(&r->dm48to24); qo_fir_free(&r->audio24p4); qo_fir_free(&r->audio12p2);
+    qo_fir_free(&r->audio24p6); qo_fir_free(&r->audio48p3); qo_fir_free(&r->fmhp);
+    free(r->filtI); free(r->filtQ); free(r->bufI); free(r->bufQ); free(r->bufC); free(r->dsamples);
+    free(r);
+}
+
+void qo_rx_set_tune(qo_rx *r, int f) { r->tune = f; }
+void qo_rx_set_mode(qo_rx *r, int mode) { r->mode = mode; }
+
+void qo_rx_set_filters(qo_rx *r, const double *fI, const double *fQ, int size)
+{
+    memcpy(r->filtI, fI, (size_t)size * sizeof(double));
+    memcpy(r->filtQ, fQ, (size_t)size * sizeof(double));
+    r->sizeFilter = size;
+}
+
+static void cRxFilterOut(qo_rx *r, double re, double im, double *ore, double *oim)     /* quisk.c:1218-1256 */
+{
+    int j, k;
+    double accI = 0, accQ = 0;
+    if (!r->sizeFilter) { *ore = re; *oim = im; return; }
+    if (r->indexC >= r->sizeFilter) r->indexC = 0;
+    r->bufI[r->indexC] = re;
+    r->bufQ[r->indexC] = im;
+    j = r->indexC;
+    for (k = 0; k < r->sizeFilter; k++) {
+        accI += r->bufI[j] * r->filtI[k];
+        accQ += r->bufQ[j] * r->filtQ[k];
+        if (++j >= r->sizeFilter) j = 0;
+    }
+    r->indexC++;
+    *ore = accI; *oim = accQ;
+}
+
+static void dRxFilterOut(qo_rx *r, double re, double im, double *ore, double *oim)     /* quisk.c:1182-1216 */
+{
+    int j, k;
+    double ar = 0, ai = 0;
+    if (!r->sizeFilter) { *ore = re; *oim = im; return; }
+    if (r->indexD >= r->sizeFilter) r->indexD = 0;
+    r->bufC[2 * r->indexD] = re;
+    r->bufC[2 * r->indexD + 1] = im;
+    j = r->indexD;
+    for (k = 0; k < r->sizeFilter; k++) {
+        ar += r->bufC[2 * j] * r->filtI[k];
+        ai += r->bufC[2 * j + 1] * r->filtI[k];
+        if (++j >= r->sizeFilter) j = 0;
+    }
+    r->indexD++;
+    *ore = ar; *oim = ai;
+}
+
+static int process_decimate(qo_rx *r, double *x, int n)        /* quisk.c:1769-1843 */
+{
+    int i2 = r->decim2, i3 = r->decim3, i5 = r->decim5, k = 0;
+    r->decim_srate = r->sample_rate;
+    while (i2 > 1 && k < 5) { n = qo_cDecim2HB45(x, n, &r->hb[k++]); r->decim_srate /= 2; i2--; }
+    k = 0;
+    while (i3 > 0) { n = qo_cDecimate(x, n, &r->d3[k++], 3); r->decim_srate /= 3; i3--; }
+    k = 0;
+    while (i5 > 0) { n = qo_cDecimate(x, n, &r->d5[k++], 5); r->decim_srate /= 5; i5--; }
+    if (i2 > 0) { n = qo_cDecimate(x, n, &r->d48to24, 2); r->decim_srate /= 2; i2--; }
+    return n;
+}
+
+static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk.c:1906-2068 */
+{
+    int i;
+    double re, im, d, di;
+    switch (r->mode) {
+    case QO_CWL: case QO_CWU:
+        r->filter_srate = r->decim_srate / 8;
+        n = qo_cDecim2HB45(x, n, &r->dHB5);
+        n = qo_cDecim2HB45(x, n, &r->dHB4);
+        n = qo_cDecimate(x, n, &r->dm48to24, 2);
+        for (i = 0; i < n; i++) {
+            cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
+            ds[i] = r->mode == QO_CWL ? re + im : re - im;
+        }
+        n = qo_dInterpolate(ds, n, &r->audio12p2, 2);
+        n = qo_dInterp2HB45(ds, n, &r->dHB6);
+        n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        break;
+    case QO_LSB: case QO_USB: default:
+        r->filter_srate = r->decim_srate / 4;
+        n = qo_cDecim2HB45(x, n, &r->dHB5);
+        n = qo_cDecimate(x, n, &r->dm48to24, 2);
+        for (i = 0; i < n; i++) {
+            cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
+            ds[i] = r->mode == QO_LSB ? re + im : re - im;
+        }
+        n = qo_dInterpolate(ds, n, &r->audio24p4, 2);
+        n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        break;
+    case QO_AM:
+        r->filter_srate = r->decim_srate / 2;
+        n = qo_cDecimate(x, n, &r->dm48to24, 2);
+        for (i = 0; i < n; i++) {
+            dRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
+            di = hypot(re, im);                                 /* cabs */
+            d = di + r->dc_remove * 0.99;
+            di = d - r->dc_remove;
+            r->dc_remove = d;
+            ds[i] = di;
+        }
+        n = qo_dFilter(ds, n, &r->audio24p6);
+        n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        break;
+    case QO_FM:
+        r->filter_srate = r->decim_srate;
+        for (i = 0; i < n; i++) {
+            double pr, pi;
+            dRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
+            pr = re * r->fm1_re + im * r->fm1_im;               /* cx * conj(fm_1) */
+            pi = im * r->fm1_re - re * r->fm1_im;
+            di = atan2(pi, pr);                                 /* carg */
+            r->fm1_re = re; r->fm1_im = im;
+            ds[i] = di;
+        }
+        for (i = 0; i < n; i++) {
+            ds[i] *= 20e5;
+            di = ds[i];
+            ds[i] = r->FM_y_1 = di * r->FM_a_0 + r->FM_x_1 * r->FM_a_1 - r->FM_y_1 * r->FM_b_1;
+            r->FM_x_1 = di;
+        }
+        n = qo_dDecimate(ds, n, &r->audio48p3, 4);
+        n = qo_dFilter(ds, n, &r->fmhp);
+        n = qo_dInterp2HB45(ds, n, &r->dHB6);
+        n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        break;
+    }
+    return n;
+}
+
+int qo_rx_process(qo_rx *r, double *x, int n)
+{
+    int i;
+    if (n <= 0) return n;
+    if (n * 2 > r->dcap) { r->dcap = n * 2 + 64; free(r->dsamples); r->dsamples = (double *)malloc((size_t)r->dcap * sizeof(double)); }
+    if (r->tune != 0) {                                         /* quisk.c:2477-2488 */
+        double a = -2.0 * M_PI * r->tune / r->sample_rate;      /* cexp((I * -2.0 * M_PI * tune) / sample_rate) */
+        double pr = cos(a), pi = sin(a), t;
+        for (i = 0; i < n; i++) {
+            t = x[2 * i] * r->tv_re - x[2 * i + 1] * r->tv_im;
+            x[2 * i + 1] = x[2 * i] * r->tv_im + x[2 * i + 1] * r->tv_re;
+            x[2 * i] = t;
+            t = r->tv_re * pr - r->tv_im * pi;
+            r->tv_im = r->tv_re * pi + r->tv_im * pr;
+            r->tv_re = t;
+        }
+    }
+    n = process_decimate(r, x, n);
+    n = process_demodulate(r, x, r->dsamples, n);
+    for (i = 0; i < n; i++) { x[2 * i] = r->dsamples[i]; x[2 * i + 1] = r->dsamples[i]; }     /* quisk.c:2622-2627 */
+    return n;
+}

@@ -1,0 +1,45 @@
+/* quisk_rx_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the receive path of quisk_process_samples (quisk.c:2289-2742) for one receiver (bank 0):
+ *   NCO tune (quisk.c:2477-2488) -> quisk_process_decimate (quisk.c:1673-1846, the PlanDecimation branch)
+ *   -> quisk_process_demodulate (quisk.c:1848-2160: CWL/CWU/LSB/USB/AM/FM) with cRxFilterOut / dRxFilterOut
+ *   (quisk.c:1182-1256) -> mono to both channels (quisk.c:2622-2627).
+ * Stops before process_agc; squelch, auto-notch, noise blanker, test tone and key-down
+ * handling are off, as they are by default.  The stages call the filter.c restatement (quisk_oracle.c), which is
+ * pinned bit-exactly to the reference build; the control flow above them is PARITY UNPINNED (quisk.c needs
+ * <fftw3.h>, quisk.c:6, and cannot be built here).
+ */
+#ifndef QUISK_RX_ORACLE_H
+#define QUISK_RX_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { QO_CWL = 0, QO_CWU, QO_LSB, QO_USB, QO_AM, QO_FM };     /* rx_mode_type, quisk.h:55-70 */
+
+typedef struct {                /* the filters.h tables the path uses */
+    const double *f48dec24;     /* quiskFilt48dec24Coefs[98]      */
+    const double *f144d3;       /* quiskFilt144D3Coefs[147]       */
+    const double *f240d5;       /* quiskFilt240D5CoefsSharp[245]  */
+    const double *audio24p4;    /* quiskAudio24p4Coefs[50]        */
+    const double *audio24p6;    /* quiskAudio24p6Coefs[36]        */
+    const double *lp48;         /* quiskLpFilt48Coefs[186]        */
+    const double *fmhp;         /* quiskAudioFmHpCoefs[309]       */
+} qo_rx_tables;
+
+typedef struct qo_rx qo_rx;
+qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t);    /* NULL when the rate does not plan to 48000 */
+void qo_rx_free(qo_rx *r);
+void qo_rx_set_tune(qo_rx *r, int rx_tune_freq);                /* set_tune, quisk.c:4702 */
+void qo_rx_set_mode(qo_rx *r, int mode);                        /* set_rx_mode, quisk.c:4621 */
+void qo_rx_set_filters(qo_rx *r, const double *filtI, const double *filtQ, int size);   /* set_filters, quisk.c:4551 */
+/* in place on n interleaved complex samples; returns the number of 48 ksps output samples (may exceed n: the
+ * buffer must hold max(n, returned)).  */
+int qo_rx_process(qo_rx *r, double *cSamples, int n);
+int qo_rx_decim_srate(const qo_rx *r);
+int qo_rx_filter_srate(const qo_rx *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -8,5 +8,6 @@ from .lib import load, QuiskHipError          # noqa: F401
 from .rxa import RxaEngine                    # noqa: F401
 from .fir import FirBank, hb45_taps           # noqa: F401
 from .pan import Panadapter                   # noqa: F401
+from .qrx import QuiskRxBank                  # noqa: F401
 
-__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "hb45_taps", "Panadapter"]
+__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "hb45_taps", "Panadapter", "QuiskRxBank"]

@@ -209,4 +209,63 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     }
 }
 
+// Interpolating overlap-save FIR:  y[n] = sum_m h[m] * u[n - m],  u[U*i] = x[i], zero elsewhere  -- the audio-rate
+// interpolators quisk_dInterpolate / quisk_cInterpolate / quisk_*Interp2HB45 (filter.c:131-201,420-488; the gain
+// factor `interp` is folded into the taps).  Zero stuffing replicates the spectrum, so the tile takes an FFT of
+// NFFT/U low-rate samples, reads it U times against the NFFT-point mask (the replicas of bin k all live in the lane
+// that holds k) and inverse transforms at NFFT points.  Args: Lout / P / n_out in HIGH-rate samples (both multiples
+// of U), n_in / hist in low-rate samples; off unused.
+template <typename T, int NFFT, int U>
+__global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
+{
+    using C = cplx<T>;
+    constexpr int NF = NFFT / U;            // forward size
+    constexpr int EF = NF / NT, E = NFFT / NT;
+    static_assert(NF >= 2 * NT && U > 1, "NFFT/U must be >= 512");
+    using Fwd = FftRR<NF, false, C>;
+    using Inv = FftRR<NFFT, true, C>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    C *lds = reinterpret_cast<C *>(smem);
+
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int ch = a.chan_list ? a.chan_list[blockIdx.y] : (int)blockIdx.y;
+    const C *in = a.in + (long long)ch * a.in_stride;
+    const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
+    const int g0 = tile * (a.Lout / U) - a.P / U;           // low-rate index of tile element 0
+
+    C x[EF];
+    const unsigned ok = load_tile<T, EF>(x, in, hist, a.hist_len, a.n_in, g0);
+#pragma unroll
+    for (int r = 0; r < EF; r++)
+        if (!((ok >> r) & 1u)) x[r] = mk<T>(0, 0);
+
+    Fwd::first(x, lds);
+    Fwd::rest(lds, x, Fwd::load(a.tw_fwd));
+
+    const C *mask = a.mask + (long long)ch * a.mask_stride;
+    C z[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) z[i] = cmul(x[i % EF], mask[t + NT * i]);
+
+    __syncthreads();
+    Inv::first(z, lds);
+    Inv::rest(lds, z, Inv::load(a.tw_inv));
+
+    C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
+    EpiParam ep;
+    if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int rel = t + NT * i - a.P;
+        const long long m = (long long)tile * a.Lout + rel;
+        if (rel >= 0 && rel < a.Lout && m < a.n_out) {
+            C v;
+            v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
+            v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
+            out[m] = v;
+        }
+    }
+}
+
 }  // namespace qh

@@ -1,0 +1,269 @@
+// qh_stage.hpp -- one overlap-save FIR stage over `nch` streams with its state, shared by the FIR bank
+// (qh_fir.hip) and the Quisk receiver bank (qh_qrx.hip).
+//
+//   decimating   y[m] = sum_k h[k] x'[decim*m + (decim-1-phase) - k]      (x' = x * NCO when mix)
+//   interpolating y[n] = sum_m h[m] u[n-m], u[interp*i] = x[i]
+// Taps: one set for all channels or one set per channel; optional per-channel 2x2 real output matrix.
+#pragma once
+#include <cmath>
+#include <vector>
+#include "qh_design.hpp"
+#include "qh_internal.hpp"
+#include "qh_kernels.hpp"
+
+namespace qh {
+
+static constexpr int kStageNfft = 4096;
+
+struct Stage {
+    int device = 0, nch = 0, ntaps = 0, decim = 1, interp = 1, dtype = QH_F64;
+    bool mix = false, per_channel = false;
+    int fold = 1, pick = 1, P = 0, Lf = 0;      // decimating: Lf folded outputs per tile; interpolating: Lf high-rate outputs per tile
+    int hist_len = 0;                           // history rows (input-rate samples)
+    int phase = 0;                              // decim_index
+    hipStream_t stream = nullptr;
+    void *mask = nullptr, *tw_fwd = nullptr, *tw_inv = nullptr, *hist[2] = { nullptr, nullptr };
+    unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr;
+    double2 *nco_step = nullptr;
+    EpiParam *epi = nullptr;
+    int cur = 0;
+    size_t esize = 16;
+
+    void destroy()
+    {
+        (void)hipFree(mask); (void)hipFree(tw_fwd); (void)hipFree(tw_inv); (void)hipFree(hist[0]); (void)hipFree(hist[1]);
+        (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
+        mask = tw_fwd = tw_inv = hist[0] = hist[1] = nullptr;
+        nco_phase = nco_dphase = nullptr; nco_step = nullptr; epi = nullptr;
+    }
+
+    int upload_cplx(void *dst, const std::vector<cd> &v)
+    {
+        if (dtype == QH_F64) {
+            QH_HIP(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        } else {
+            std::vector<float> f(v.size() * 2);
+            for (size_t i = 0; i < v.size(); i++) { f[2 * i] = (float)v[i].real(); f[2 * i + 1] = (float)v[i].imag(); }
+            QH_HIP(hipMemcpyAsync(dst, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
+        return QH_OK;
+    }
+
+    // geometry + buffers; taps are set afterwards with set_taps
+    int init(int device_, int nch_, int ntaps_, int decim_, int interp_, int dtype_, bool mix_, bool per_channel_, bool with_epi,
+             hipStream_t s)
+    {
+        device = device_; nch = nch_; ntaps = ntaps_; decim = decim_; interp = interp_; dtype = dtype_; mix = mix_;
+        per_channel = per_channel_; stream = s;
+        esize = dtype == QH_F64 ? 16 : 8;
+        if (interp > 1) {
+            if (decim != 1 || (interp != 2 && interp != 4 && interp != 8))
+                return set_error(QH_ERR_UNSUPPORTED, "interpolation must be 2, 4 or 8 without decimation");
+            P = ((ntaps - 1 + interp - 1) / interp) * interp;
+            if (P < interp) P = interp;
+            Lf = ((kStageNfft - P) / interp) * interp;
+            hist_len = P / interp;
+            fold = 1; pick = 1;
+        } else {
+            fold = (decim % 8 == 0) ? 8 : (decim % 4 == 0) ? 4 : (decim % 2 == 0) ? 2 : 1;
+            pick = decim / fold;
+            P = ((ntaps - 1 + fold - 1) / fold) * fold;
+            if (P < fold) P = fold;
+            Lf = (((kStageNfft - P) / fold) / pick) * pick;
+            hist_len = P;
+        }
+        if (Lf <= 0) return set_error(QH_ERR_UNSUPPORTED, "%d taps with decimation %d / interpolation %d do not fit a %d-point tile",
+                                      ntaps, decim, interp, kStageNfft);
+        QH_HIP(hipSetDevice(device));
+        const size_t nmask = (size_t)(per_channel ? nch : 1) * kStageNfft;
+        QH_HIP(hipMalloc(&mask, nmask * esize));
+        QH_HIP(hipMemsetAsync(mask, 0, nmask * esize, stream));
+        const int nfwd = interp > 1 ? kStageNfft / interp : kStageNfft;
+        const int ninv = interp > 1 ? kStageNfft : kStageNfft / fold;
+        std::vector<cd> t1 = fft_twiddle_table(nfwd), t2 = fft_twiddle_table(ninv);
+        QH_HIP(hipMalloc(&tw_fwd, t1.size() * esize));
+        QH_HIP(hipMalloc(&tw_inv, t2.size() * esize));
+        if (int rc = upload_cplx(tw_fwd, t1)) return rc;
+        if (int rc = upload_cplx(tw_inv, t2)) return rc;
+        for (int i = 0; i < 2; i++) {
+            QH_HIP(hipMalloc(&hist[i], (size_t)nch * hist_len * esize));
+            QH_HIP(hipMemsetAsync(hist[i], 0, (size_t)nch * hist_len * esize, stream));
+        }
+        if (mix) {
+            QH_HIP(dev_alloc(&nco_phase, (size_t)nch));
+            QH_HIP(dev_alloc(&nco_dphase, (size_t)nch));
+            QH_HIP(dev_alloc(&nco_step, (size_t)nch));
+            QH_HIP(hipMemsetAsync(nco_phase, 0, (size_t)nch * 8, stream));
+            QH_HIP(hipMemsetAsync(nco_dphase, 0, (size_t)nch * 8, stream));
+            std::vector<double2> one((size_t)nch, make_double2(1.0, 0.0));
+            QH_HIP(hipMemcpyAsync(nco_step, one.data(), (size_t)nch * 16, hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
+        if (with_epi) {
+            QH_HIP(dev_alloc(&epi, (size_t)nch));
+            std::vector<EpiParam> id((size_t)nch, EpiParam{ 1, 0, 0, 1 });
+            QH_HIP(hipMemcpyAsync(epi, id.data(), (size_t)nch * sizeof(EpiParam), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
+        if (int rc = set_attr()) return rc;
+        QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+
+    // ch = -1 (shared taps) or a channel index (per-channel stages).  `taps` are the convolution taps h[k].
+    int set_taps(int ch, const std::vector<cd> &taps)
+    {
+        if ((int)taps.size() > ntaps) return set_error(QH_ERR_INVALID, "more taps than the stage was created for");
+        QH_HIP(hipSetDevice(device));
+        std::vector<cd> m = make_mask(taps, kStageNfft);
+        char *dst = static_cast<char *>(mask);
+        if (per_channel) {
+            if (ch < 0) {
+                for (int c = 0; c < nch; c++)
+                    if (int rc = upload_cplx(dst + (size_t)c * kStageNfft * esize, m)) return rc;
+                return QH_OK;
+            }
+            return upload_cplx(dst + (size_t)ch * kStageNfft * esize, m);
+        }
+        return upload_cplx(dst, m);
+    }
+
+    // NCO of channel ch: frequency ratio f/rate in turns per input sample (negative = tune down)
+    int set_nco(int ch, double freq, double rate)
+    {
+        if (!mix) return set_error(QH_ERR_INVALID, "stage has no NCO");
+        QH_HIP(hipSetDevice(device));
+        long double t = (long double)freq / (long double)rate;
+        t -= floorl(t);
+        long double sc = t * 18446744073709551616.0L;
+        unsigned long long d = sc >= 18446744073709551616.0L ? 0ull : (unsigned long long)sc;
+        long double ang = 2.0L * 3.14159265358979323846264338327950288L * ((long double)(d * (unsigned long long)NT) / 18446744073709551616.0L);
+        double2 st = make_double2((double)cosl(ang), (double)sinl(ang));
+        QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, 8, hipMemcpyHostToDevice, stream));
+        QH_HIP(hipMemcpyAsync(nco_step + ch, &st, 16, hipMemcpyHostToDevice, stream));
+        QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+
+    int set_epi(int ch, EpiParam e)
+    {
+        if (!epi) return set_error(QH_ERR_INVALID, "stage has no output matrix");
+        QH_HIP(hipSetDevice(device));
+        QH_HIP(hipMemcpyAsync(epi + ch, &e, sizeof(e), hipMemcpyHostToDevice, stream));
+        QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+
+    int reset()
+    {
+        QH_HIP(hipSetDevice(device));
+        for (int i = 0; i < 2; i++) QH_HIP(hipMemsetAsync(hist[i], 0, (size_t)nch * hist_len * esize, stream));
+        if (mix) QH_HIP(hipMemsetAsync(nco_phase, 0, (size_t)nch * 8, stream));
+        phase = 0;
+        return QH_OK;
+    }
+
+    int out_count(int n_in) const { return interp > 1 ? n_in * interp : (phase + n_in) / decim; }
+
+    template <typename T, int FOLD, bool MIX> int attr_one()
+    {
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<T, kStageNfft, FOLD, MIX>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_elems<kStageNfft>() * (int)sizeof(cplx<T>)));
+        return QH_OK;
+    }
+    template <typename T, int U> int attr_up()
+    {
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_interp_kernel<T, kStageNfft, U>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_elems<kStageNfft>() * (int)sizeof(cplx<T>)));
+        return QH_OK;
+    }
+    template <typename T> int set_attr_t()
+    {
+        if (interp > 1) return interp == 2 ? attr_up<T, 2>() : interp == 4 ? attr_up<T, 4>() : attr_up<T, 8>();
+        if (mix) return fold == 1 ? attr_one<T, 1, true>() : fold == 2 ? attr_one<T, 2, true>() : fold == 4 ? attr_one<T, 4, true>() : attr_one<T, 8, true>();
+        return fold == 1 ? attr_one<T, 1, false>() : fold == 2 ? attr_one<T, 2, false>() : fold == 4 ? attr_one<T, 4, false>() : attr_one<T, 8, false>();
+    }
+    int set_attr() { return dtype == QH_F64 ? set_attr_t<double>() : set_attr_t<float>(); }
+
+    template <typename T, int FOLD, bool MIX> void launch_dec(const OsfirArgs<T> &a)
+    {
+        dim3 grid((unsigned)a.ntiles, (unsigned)nch), block(NT);
+        hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX>), grid, block, lds_elems<kStageNfft>() * sizeof(cplx<T>), stream, a);
+    }
+    template <typename T, int U> void launch_up(const OsfirArgs<T> &a)
+    {
+        dim3 grid((unsigned)a.ntiles, (unsigned)nch), block(NT);
+        hipLaunchKernelGGL((osfir_interp_kernel<T, kStageNfft, U>), grid, block, lds_elems<kStageNfft>() * sizeof(cplx<T>), stream, a);
+    }
+
+    template <typename T> int process_t(const void *in, long long in_stride, int n_in, void *out, long long out_stride, int *n_out)
+    {
+        QH_HIP(hipSetDevice(device));
+        const int nout = out_count(n_in);
+        if (n_out) *n_out = nout;
+        if (n_in <= 0) return QH_OK;
+        OsfirArgs<T> a{};
+        a.in = static_cast<const cplx<T> *>(in); a.in_stride = in_stride;
+        a.hist = static_cast<const cplx<T> *>(hist[cur]); a.hist_stride = hist_len; a.hist_len = hist_len;
+        a.out = static_cast<cplx<T> *>(out); a.out_stride = out_stride; a.out_offset = 0;
+        a.mask = static_cast<const cplx<T> *>(mask); a.mask_stride = per_channel ? kStageNfft : 0;
+        a.tw_fwd = static_cast<const cplx<T> *>(tw_fwd); a.tw_inv = static_cast<const cplx<T> *>(tw_inv);
+        a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
+        a.epi = epi;
+        a.n_in = n_in; a.n_out = nout; a.P = P; a.Lout = Lf;
+        if (nout > 0) {
+            if (interp > 1) {
+                a.ntiles = (nout + Lf - 1) / Lf;
+                switch (interp) { case 2: launch_up<T, 2>(a); break; case 4: launch_up<T, 4>(a); break; default: launch_up<T, 8>(a); }
+            } else {
+                a.off = decim - 1 - phase; a.pick = pick;
+                const int per_tile = Lf / pick;
+                a.ntiles = (nout + per_tile - 1) / per_tile;
+                if (mix) switch (fold) { case 1: launch_dec<T, 1, true>(a); break; case 2: launch_dec<T, 2, true>(a); break;
+                                         case 4: launch_dec<T, 4, true>(a); break; default: launch_dec<T, 8, true>(a); }
+                else switch (fold) { case 1: launch_dec<T, 1, false>(a); break; case 2: launch_dec<T, 2, false>(a); break;
+                                     case 4: launch_dec<T, 4, false>(a); break; default: launch_dec<T, 8, false>(a); }
+            }
+        }
+        dim3 g((unsigned)((hist_len + NT - 1) / NT), (unsigned)nch);
+        if (mix) {
+            hipLaunchKernelGGL((hist_update_kernel<T, true>), g, dim3(NT), 0, stream, a.in, in_stride, n_in, a.hist,
+                               static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, nco_phase, nco_dphase, (const int *)nullptr);
+            hipLaunchKernelGGL(nco_advance_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, stream, nco_phase, nco_dphase,
+                               nch, (long long)n_in);
+        } else {
+            hipLaunchKernelGGL((hist_update_kernel<T, false>), g, dim3(NT), 0, stream, a.in, in_stride, n_in, a.hist,
+                               static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, (const unsigned long long *)nullptr,
+                               (const unsigned long long *)nullptr, (const int *)nullptr);
+        }
+        cur ^= 1;
+        if (interp == 1) phase = (phase + n_in) % decim;
+        QH_HIP(hipGetLastError());
+        return QH_OK;
+    }
+
+    int process(const void *in, long long in_stride, int n_in, void *out, long long out_stride, int *n_out)
+    {
+        return dtype == QH_F64 ? process_t<double>(in, in_stride, n_in, out, out_stride, n_out)
+                               : process_t<float>(in, in_stride, n_in, out, out_stride, n_out);
+    }
+
+    // state from the host: hist = ntaps-1 most recent samples per channel, oldest first
+    int set_state(const void *h, int phase_)
+    {
+        if (phase_ < 0 || phase_ >= decim) return set_error(QH_ERR_INVALID, "phase out of range");
+        QH_HIP(hipSetDevice(device));
+        QH_HIP(hipMemsetAsync(hist[cur], 0, (size_t)nch * hist_len * esize, stream));
+        const int nh = ntaps - 1;
+        if (h && nh > 0)
+            QH_HIP(hipMemcpy2DAsync(static_cast<char *>(hist[cur]) + (size_t)(hist_len - nh) * esize, (size_t)hist_len * esize, h,
+                                    (size_t)nh * esize, (size_t)nh * esize, (size_t)nch, hipMemcpyHostToDevice, stream));
+        QH_HIP(hipStreamSynchronize(stream));
+        phase = phase_;
+        return QH_OK;
+    }
+};
+
+}  // namespace qh

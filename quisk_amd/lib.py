@@ -80,6 +80,17 @@ def load():
     L.qh_pan_feed_host.argtypes = [vp, vp, ll, i]
     L.qh_pan_count.argtypes = [vp]
     L.qh_pan_graph.argtypes = [vp, d, d, vp, vp, C.POINTER(i)]
+    L.qh_qrx_create.restype = vp
+    L.qh_qrx_create.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.qh_qrx_destroy.argtypes = [vp]
+    L.qh_qrx_destroy.restype = None
+    L.qh_qrx_filter_rate.argtypes = [vp]
+    L.qh_qrx_set_tune.argtypes = [vp, i, i]
+    L.qh_qrx_set_filters.argtypes = [vp, i, vp, vp, i]
+    L.qh_qrx_out_count.argtypes = [vp, i]
+    L.qh_qrx_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_qrx_process_host.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_qrx_synchronize.argtypes = [vp]
     _lib = L
     return L
 

@@ -1,0 +1,67 @@
+"""Python host side of the Quisk-native receiver bank (include/quiskhip.h group 6).
+
+Method names follow the _quisk calls the GUI makes: set_tune (quisk.c:4702), set_filters (quisk.c:4551),
+get_filter_rate (quisk.c:2787).  Rx filter taps come from quisk_amd.rxfilter.make_filter_coef, the restatement of
+quisk.py's MakeFilterCoef.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import rxfilter
+from .lib import load, check, QuiskHipError
+
+
+class QuiskRxBank:
+    def __init__(self, nch, sample_rate, mode, device=0, stream=None):
+        self._L = load()
+        t = rxfilter.coefficient_tables()
+        self._tabs = [np.ascontiguousarray(t[k], dtype=np.float64) for k in (
+            "quiskFilt48dec24Coefs", "quiskFilt144D3Coefs", "quiskFilt240D5CoefsSharp", "quiskAudio24p4Coefs",
+            "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs")]
+        self._h = self._L.qh_qrx_create(device, nch, sample_rate, mode, *[a.ctypes.data for a in self._tabs], stream)
+        if not self._h:
+            raise QuiskHipError("qh_qrx_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch, self.sample_rate, self.mode = nch, sample_rate, mode
+
+    def get_filter_rate(self):
+        return self._L.qh_qrx_filter_rate(self._h)
+
+    def set_tune(self, ch, rx_tune_freq):
+        check(self._L.qh_qrx_set_tune(self._h, ch, int(rx_tune_freq)))
+
+    def set_filters(self, ch, filtI, filtQ):
+        fI = np.ascontiguousarray(filtI, dtype=np.float64)
+        fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
+        if fI.size != fQ.size:
+            raise ValueError("The size of filters I and Q must be equal")
+        check(self._L.qh_qrx_set_filters(self._h, ch, fI.ctypes.data, fQ.ctypes.data, fI.size))
+
+    def out_count(self, n_in):
+        return self._L.qh_qrx_out_count(self._h, n_in)
+
+    def process_ptr(self, d_in, in_stride, n_in, d_out, out_stride):
+        n = C.c_int(0)
+        check(self._L.qh_qrx_process(self._h, d_in, in_stride, n_in, d_out, out_stride, C.byref(n)))
+        return n.value
+
+    def process_host(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        if x.ndim != 2 or x.shape[0] != self.nch:
+            raise ValueError("expected [nch, n] complex128")
+        cap = max(self.out_count(x.shape[1]), 1)
+        out = np.empty((self.nch, cap), dtype=np.complex128)
+        n = C.c_int(0)
+        check(self._L.qh_qrx_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1], out.ctypes.data, cap, C.byref(n)))
+        return out[:, :n.value].copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_qrx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

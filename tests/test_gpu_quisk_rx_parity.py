@@ -1,0 +1,93 @@
+"""Quisk-native receiver bank on the GPU (equivalent-filter form) against the staged CPU restatement of
+quisk_process_samples.  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from quisk_amd import rxfilter
+
+pytestmark = pytest.mark.gpu
+NAMES = {0: "CWL", 1: "CWU", 2: "LSB", 3: "USB", 4: "AM", 5: "FM"}
+
+
+def signal(mode, c, n, fs, tune):
+    rng = np.random.default_rng(2000 + c)
+    t = np.arange(n)
+    noise = 2.0 ** 16 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    car = lambda f: np.exp(2j * np.pi * ((f / fs) * t % 1.0))
+    a = 2.0 ** 26
+    if mode in (2, 0):          # LSB / CWL: tone below the tune frequency
+        return a * car(tune - 700.0 - 31 * c) + noise
+    if mode in (3, 1):
+        return a * car(tune + 700.0 + 31 * c) + noise
+    if mode == 4:
+        return a * (1 + 0.5 * np.cos(2 * np.pi * 1000.0 / fs * t)) * car(tune) + noise
+    return a * car(tune) * np.exp(3j * np.sin(2 * np.pi * 1000.0 / fs * t)) + noise
+
+
+def default_filter(mode, rate):
+    bw = {0: 500, 1: 500, 2: 2700, 3: 2700, 4: 6000, 5: 12000}[mode]
+    return rxfilter.make_filter_coef(rate, None, bw, rxfilter.get_filter_center(NAMES[mode], bw))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("fs", [192000, 48000])
+def test_modes_and_rates(qh, oracle, mode, fs):
+    nch, n = 3, fs // 2 + 777                   # half a second, ragged length
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(nch, fs, mode)
+    frate = bank.get_filter_rate()
+    assert frate == rxfilter.get_filter_rate(fs, mode)
+    x = np.stack([signal(mode, c, n, fs, 10000.0 + 250 * c) for c in range(nch)])
+    refs = []
+    for c in range(nch):
+        bank.set_tune(c, 10000 + 250 * c)
+        fI, fQ = default_filter(mode, frate)
+        bank.set_filters(c, fI, fQ)
+        r = oracle.OracleQuiskRx(fs, tabs)
+        r.set_mode(mode); r.set_tune(10000 + 250 * c); r.set_filters(fI, fQ)
+        refs.append(r)
+    cuts = [0, 1000, 1001, n // 3, n]          # ragged calls: every stage's decimation phase carries over
+    ys = [bank.process_host(x[:, a:b]) for a, b in zip(cuts, cuts[1:])]
+    y = np.concatenate(ys, axis=1)
+    for c in range(nch):
+        want = np.concatenate([refs[c].process(x[c, a:b]) for a, b in zip(cuts, cuts[1:])])
+        assert y.shape[1] == want.size
+        assert np.abs(want).max() > 2.0 ** 10
+        if mode == 5:
+            # arg() is scale invariant: while the filters fill, the detector sees values near the FFT round-off
+            # floor (1e-16 of full scale) and turns them into phase noise; once the signal is there, parity is tight
+            assert rel_rms(y[c], want) < 1e-5
+            assert rel_rms(y[c][2000:], want[2000:]) < 1e-9, (fs, c, rel_rms(y[c][2000:], want[2000:]))
+        else:
+            assert rel_rms(y[c], want) < 1e-9, (mode, fs, c, rel_rms(y[c], want))
+
+
+@pytest.mark.parametrize("fs,mode", [(1536000, 3), (240000, 3), (144000, 4), (96000, 1)])
+def test_other_decimation_plans(qh, oracle, fs, mode):
+    """Rates that need several equivalent-decimator groups (1.536 M: /32) or the /3 and /5 filters."""
+    n = fs // 4
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(1, fs, mode)
+    frate = bank.get_filter_rate()
+    fI, fQ = default_filter(mode, frate)
+    bank.set_tune(0, -20000); bank.set_filters(0, fI, fQ)
+    r = oracle.OracleQuiskRx(fs, tabs); r.set_mode(mode); r.set_tune(-20000); r.set_filters(fI, fQ)
+    x = signal(mode, 0, n, fs, -20000.0)
+    y = np.concatenate([bank.process_host(x[None, :n // 2 + 5]), bank.process_host(x[None, n // 2 + 5:])], axis=1)[0]
+    want = np.concatenate([r.process(x[:n // 2 + 5]), r.process(x[n // 2 + 5:])])
+    assert y.size == want.size and rel_rms(y, want) < 1e-9
+
+
+def test_unset_filter_passes_through_like_reference(qh, oracle):
+    """sizeFilter == 0: cRxFilterOut returns the sample, so USB gives re - im of the decimated stream."""
+    fs, n = 192000, 40000
+    bank = qh.QuiskRxBank(1, fs, 3)
+    r = oracle.OracleQuiskRx(fs, rxfilter.coefficient_tables()); r.set_mode(3)
+    x = signal(3, 0, n, fs, 0.0)
+    assert rel_rms(bank.process_host(x[None, :])[0], r.process(x)) < 1e-9
+
+
+def test_unsupported_rate_is_refused(qh):
+    with pytest.raises(qh.QuiskHipError):
+        qh.QuiskRxBank(1, 250000, 3)
