@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configurations (3, 4, 5) with the kernels this round ships.  One JSON
+line per configuration; results are recorded in profiles/ and DESIGN.md (bench.py stays the one-line contract for
+configuration 2).  Runs on one GPU."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, sync, steps=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def config3(torch, qh, dev):
+    nch, n, fs = 64, 1 << 20, 1536000.0
+    k = np.arange(1023) - 511
+    taps = np.sinc(k / 32.0) / 32.0 * np.blackman(1023)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    bank = qh.FirBank(nch, taps, 32, stream=s)
+    pan = qh.Panadapter(nch, 16384, 1024, fs, stream=s)
+    x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 20
+    y = torch.empty((nch, n // 32), dtype=torch.complex128, device=dev)
+    sync = lambda: torch.cuda.synchronize(dev)
+    t_fir = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 32), sync)
+    t_pan = timed(lambda: pan.feed_ptr(x.data_ptr(), n, n), sync)
+    t_both = timed(lambda: (bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 32), pan.feed_ptr(x.data_ptr(), n, n)), sync)
+    tot = nch * n
+    return {"config": "3: 64 ch x 1.536 Msps fp64, 1023-tap FIR /32 + 16384-pt panadapter every block", "samples_per_step": tot,
+            "fir_ms": t_fir * 1e3, "pan_ms": t_pan * 1e3, "both_ms": t_both * 1e3, "Msamp_per_s": tot / t_both / 1e6,
+            "fir_Msamp_per_s": tot / t_fir / 1e6, "pan_Msamp_per_s": tot / t_pan / 1e6,
+            "algorithmic_GBps": 24.5 * tot / t_both / 1e9}
+
+
+def config4(torch, qh, dev):
+    from quisk_amd import synth
+    nch, nblk = 256, 256        # 2^18 input samples per channel per step
+    n_in = nblk * 1024
+    eng = qh.RxaEngine(nch, stream=torch.cuda.current_stream(dev).cuda_stream)
+    modes = [1, 6, 5]
+    for c in range(nch):
+        m = modes[c % 3]
+        eng.SetRXAShiftRun(c, 1); eng.SetRXAShiftFreq(c, synth.shift_freq(c)); eng.RXANBPSetRun(c, 1)
+        eng.SetRXAMode(c, m); eng.SetRXAAGCMode(c, 0); eng.SetRXAAGCFixed(c, 0.0)
+        if m == 1: eng.RXASetPassband(c, 300.0, 3000.0)
+        elif m == 6: eng.RXASetPassband(c, -4000.0, 4000.0)
+        else: eng.RXASetPassband(c, -8000.0, 8000.0)
+    x = synth.make_input_torch(nch, n_in, dev)
+    y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
+    sync = lambda: torch.cuda.synchronize(dev)
+    t = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=5, warmup=1)
+    tot = nch * n_in
+    return {"config": "4 (one GPU's share): 256 ch x 192 k, mode by c mod 3 = USB / AM / FM, fp64", "samples_per_step": tot,
+            "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6,
+            "note": "FM (85 channels) runs a PLL that is sequential per channel: it bounds the step"}
+
+
+def config5(torch, qh, dev):
+    n = 1 << 26                 # 61.44 Msps stream, ~1.09 s of signal, fp32
+    s = torch.cuda.current_stream(dev).cuda_stream
+    tabs = __import__("quisk_amd.rxfilter", fromlist=["x"]).coefficient_tables()
+    hb = [qh.FirBank(1, qh.hb45_taps(), 2, dtype=1, stream=s) for _ in range(8)]
+    d5 = qh.FirBank(1, tabs["quiskFilt240D5CoefsSharp"], 5, dtype=1, stream=s)
+    # WDSP bandpass 300..3000 at 48 k, nc 2048 (fir_bandpass via the library's own design is internal; the bank takes taps)
+    m = 0.5 * 2047
+    pos = np.arange(2048) - m
+    c = np.cos(np.pi / m * np.arange(2048))
+    win = 0.21747 + c * (-0.45325 + c * (0.28256 + c * (-0.04672)))
+    ft = (3000.0 - 300.0) / (2 * 48000.0)
+    bp = np.sin(2 * np.pi * ft * pos) / (np.pi * pos) * win * np.exp(-1j * np.pi * 3300.0 / 48000.0 * pos)
+    core = qh.FirBank(1, bp, 1, dtype=1, stream=s)
+    x = torch.randn((1, n), dtype=torch.float32, device=dev) + 1j * torch.randn((1, n), dtype=torch.float32, device=dev)
+    bufs = [torch.empty((1, n >> (k + 1)), dtype=torch.complex64, device=dev) for k in range(8)]
+    y5 = torch.empty((1, (n >> 8) // 5 + 8), dtype=torch.complex64, device=dev)
+    yo = torch.empty_like(y5)
+
+    def step():
+        cur, cn = x, n
+        for k in range(8):
+            m_ = hb[k].process_ptr(cur.data_ptr(), cur.shape[1], cn, bufs[k].data_ptr(), bufs[k].shape[1])
+            cur, cn = bufs[k], m_
+        m_ = d5.process_ptr(cur.data_ptr(), cur.shape[1], cn, y5.data_ptr(), y5.shape[1])
+        core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
+    sync = lambda: torch.cuda.synchronize(dev)
+    t = timed(step, sync, steps=10, warmup=2)
+    t1 = timed(lambda: hb[0].process_ptr(x.data_ptr(), n, n, bufs[0].data_ptr(), bufs[0].shape[1]), sync, steps=10, warmup=2)
+    return {"config": "5 (one GPU's channel): 1 ch x 61.44 Msps fp32, 8 x HB45 + 245-tap /5 + bandpass nc 2048, 2^26 samples per step",
+            "samples_per_step": n, "ms": t * 1e3, "Msamp_per_s": n / t / 1e6, "first_stage_ms": t1 * 1e3,
+            "algorithmic_GBps": 8.0 * n / t / 1e9,
+            "note": "unfused cascade of overlap-save banks; the first half-band alone moves 12 B/sample"}
+
+
+def main():
+    import torch
+    import quisk_amd as qh
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    which = sys.argv[1:] or ["3", "4", "5"]
+    for w in which:
+        r = {"3": config3, "4": config4, "5": config5}[w](torch, qh, dev)
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
