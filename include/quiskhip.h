@@ -66,6 +66,12 @@ int qh_rxa_SetRXABandpassRun(qh_rxa *e, int ch, int run);
 int qh_rxa_SetRXABandpassFreqs(qh_rxa *e, int ch, double f_low, double f_high);
 int qh_rxa_SetRXAAGCMode(qh_rxa *e, int ch, int mode);
 int qh_rxa_SetRXAAGCFixed(qh_rxa *e, int ch, double fixed_agc_db);
+int qh_rxa_SetRXAAGCAttack(qh_rxa *e, int ch, int attack_ms);
+int qh_rxa_SetRXAAGCDecay(qh_rxa *e, int ch, int decay_ms);
+int qh_rxa_SetRXAAGCHang(qh_rxa *e, int ch, int hang_ms);
+int qh_rxa_SetRXAAGCTop(qh_rxa *e, int ch, double max_agc_db);
+int qh_rxa_SetRXAAGCSlope(qh_rxa *e, int ch, int slope);
+int qh_rxa_SetRXAAGCHangThreshold(qh_rxa *e, int ch, int hangthreshold);
 int qh_rxa_SetRXAPanelGain1(qh_rxa *e, int ch, double gain);
 int qh_rxa_SetRXAPanelGain2(qh_rxa *e, int ch, double gainI, double gainQ);
 int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
@@ -124,6 +130,12 @@ void SetRXABandpassRun(int channel, int run);                                   
 void SetRXABandpassFreqs(int channel, double f_low, double f_high);              /* wdsp/bandpass.c:389-407 */
 void SetRXAAGCMode(int channel, int mode);                                       /* wdsp/wcpAGC.c:369-411 */
 void SetRXAAGCFixed(int channel, double fixed_agc);                              /* wdsp/wcpAGC.c:541-548 */
+void SetRXAAGCAttack(int channel, int attack);                                   /* wdsp/wcpAGC.c:413-420 */
+void SetRXAAGCDecay(int channel, int decay);                                     /* wdsp/wcpAGC.c:422-429 */
+void SetRXAAGCHang(int channel, int hang);                                       /* wdsp/wcpAGC.c:431-438 */
+void SetRXAAGCTop(int channel, double max_agc);                                  /* wdsp/wcpAGC.c:520-527 */
+void SetRXAAGCSlope(int channel, int slope);                                     /* wdsp/wcpAGC.c:529-536 */
+void SetRXAAGCHangThreshold(int channel, int hangthreshold);                     /* wdsp/wcpAGC.c:480-487 */
 void SetRXAPanelRun(int channel, int run);                                       /* wdsp/patchpanel.c:123-129 */
 void SetRXAPanelGain1(int channel, double gain);                                 /* wdsp/patchpanel.c:139-145 */
 void SetRXAPanelGain2(int channel, double gainI, double gainQ);                  /* wdsp/patchpanel.c:147-154 */

@@ -41,6 +41,11 @@ def lib():
         for n in ("wo_dsp_insize", "wo_dsp_outsize", "wo_out_size"):
             getattr(L, n).argtypes = [C.c_void_p]
             getattr(L, n).restype = C.c_int
+        for n in ("wo_SetRXAAGCAttack", "wo_SetRXAAGCDecay", "wo_SetRXAAGCHang", "wo_SetRXAAGCSlope", "wo_SetRXAAGCHangThreshold"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, n).restype = None
+        L.wo_SetRXAAGCTop.argtypes = [C.c_void_p, C.c_double]
+        L.wo_SetRXAAGCTop.restype = None
         for n in ("wo_SetRXAMode", "wo_RXASetNC", "wo_SetRXAShiftRun", "wo_RXANBPSetRun", "wo_SetRXABandpassRun",
                   "wo_SetRXAAGCMode", "wo_SetRXAPanelRun", "wo_SetRXAPanelSelect", "wo_SetRXAPanelCopy",
                   "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun"):

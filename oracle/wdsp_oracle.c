@@ -9,6 +9,7 @@
 #include <string.h>
 #include "fft_oracle.h"
 #include "wdsp_oracle.h"
+#include "wcpagc_oracle.h"
 
 #define WO_PI    3.1415926535897932   /* wdsp/comm.h:146 */
 #define WO_TWOPI 6.2831853071795864   /* wdsp/comm.h:147 */
@@ -479,7 +480,7 @@ struct wo_channel {
         /* snotch, wdsp/iir.c:35-95 */
         double a0, a1, a2, b1, b2, x1, x2, y1, y2;
     } fmd;
-    struct { int run, mode; double fixed_gain, gain; } agc;
+    wo_agc agc;
     struct { int run, nc, wintype; double f_low, f_high, gain; wo_fircore *p; } bp1;
     struct { int run, inselect, copy; double gain1, gain2I, gain2Q; } panel;
     /* iobuffs, wdsp/iobuffs.h */
@@ -719,17 +720,10 @@ static void xfmd(wo_channel *c, double *buf, int size)   /* fmd.c:144-188 (lim_r
     }
 }
 
-/* ---- agc mode 0 (wcpAGC.c:161-175); modes 1-5 are SURVEY section 8(f) "next" */
+/* ---- agc (wcpAGC.c:161-342, restated in wcpagc_oracle.c) */
 static void xwcpagc(wo_channel *c, double *buf, int size)
 {
-    int i;
-    if (!c->agc.run) return;
-    if (c->agc.mode == 0) {
-        for (i = 0; i < size; i++) {
-            buf[2 * i + 0] = c->agc.fixed_gain * buf[2 * i + 0];
-            buf[2 * i + 1] = c->agc.fixed_gain * buf[2 * i + 1];
-        }
-    }
+    wo_agc_exec(&c->agc, buf, size);
 }
 
 /* ---- panel (patchpanel.c:55-101): the run flag is not examined */
@@ -998,7 +992,8 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     imp = fmd_aud_impulse(c);
     c->fmd.paud = wo_fircore_create(dsp_size, nc, imp);
     free(imp);
-    c->agc.run = 1; c->agc.mode = 3; c->agc.fixed_gain = 1000.0; c->agc.gain = 0.0;
+    /* create_wcpagc arguments of create_rxa, RXA.c:335-358 */
+    wo_agc_init(&c->agc, 1, 3, 1, dsp_rate, 0.001, 0.250, 4, 10000.0, 1.5, 1000.0, 1.0, 1.0, 0.250, 0.005, 5.0, 1, 0.500, 0.250, 0.250, 0.100);
     c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0;
     c->bp1.f_low = -4150.0; c->bp1.f_high = -150.0;
     imp = bp1_impulse(c);
@@ -1018,6 +1013,7 @@ void wo_close(wo_channel *c)
     free(c->fmd.audio);
     free(c->inbuff); free(c->midbuff); free(c->outbuff);
     free(c->iob.r1); free(c->iob.r2); free(c->iob.cup);
+    wo_agc_free(&c->agc);
     free(c);
 }
 
@@ -1104,14 +1100,18 @@ void wo_SetRXAShiftFreq(wo_channel *c, double fshift) { c->shift.shift = fshift;
 void wo_RXANBPSetRun(wo_channel *c, int run) { c->nbp0.run = run; }
 void wo_SetRXABandpassRun(wo_channel *c, int run) { c->bp1.run = run; }
 
-void wo_SetRXAAGCMode(wo_channel *c, int mode)
-{
-    c->agc.mode = (mode >= 0 && mode <= 4) ? mode : 5;
-}
+void wo_SetRXAAGCMode(wo_channel *c, int mode) { wo_agc_set_mode(&c->agc, mode); }
+void wo_SetRXAAGCAttack(wo_channel *c, int attack) { c->agc.tau_attack = (double)attack / 1000.0; wo_agc_load(&c->agc); }
+void wo_SetRXAAGCDecay(wo_channel *c, int decay) { c->agc.tau_decay = (double)decay / 1000.0; wo_agc_load(&c->agc); }
+void wo_SetRXAAGCHang(wo_channel *c, int hang) { c->agc.hangtime = (double)hang / 1000.0; wo_agc_load(&c->agc); }
+void wo_SetRXAAGCTop(wo_channel *c, double max_agc) { c->agc.max_gain = pow(10.0, max_agc / 20.0); wo_agc_load(&c->agc); }
+void wo_SetRXAAGCSlope(wo_channel *c, int slope) { c->agc.var_gain = pow(10.0, (double)slope / 20.0 / 10.0); wo_agc_load(&c->agc); }
+void wo_SetRXAAGCHangThreshold(wo_channel *c, int t) { c->agc.hang_thresh = (double)t / 100.0; wo_agc_load(&c->agc); }
 
 void wo_SetRXAAGCFixed(wo_channel *c, double fixed_agc_db)
 {
     c->agc.fixed_gain = pow(10.0, fixed_agc_db / 20.0);
+    wo_agc_load(&c->agc);
 }
 
 void wo_SetRXAPanelRun(wo_channel *c, int run) { c->panel.run = run; }

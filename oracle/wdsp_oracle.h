@@ -61,6 +61,12 @@ void wo_SetRXABandpassRun(wo_channel *c, int run);              /* bandpass.c:38
 void wo_SetRXABandpassFreqs(wo_channel *c, double f_low, double f_high); /* bandpass.c:389-407 */
 void wo_SetRXAAGCMode(wo_channel *c, int mode);                 /* wcpAGC.c:369-411 */
 void wo_SetRXAAGCFixed(wo_channel *c, double fixed_agc_db);     /* wcpAGC.c:541-548 */
+void wo_SetRXAAGCAttack(wo_channel *c, int attack_ms);          /* wcpAGC.c:413-420 */
+void wo_SetRXAAGCDecay(wo_channel *c, int decay_ms);            /* wcpAGC.c:422-429 */
+void wo_SetRXAAGCHang(wo_channel *c, int hang_ms);              /* wcpAGC.c:431-438 */
+void wo_SetRXAAGCTop(wo_channel *c, double max_agc_db);         /* wcpAGC.c:520-527 */
+void wo_SetRXAAGCSlope(wo_channel *c, int slope);               /* wcpAGC.c:529-536 */
+void wo_SetRXAAGCHangThreshold(wo_channel *c, int threshold);   /* wcpAGC.c:480-487 */
 void wo_SetRXAPanelRun(wo_channel *c, int run);                 /* patchpanel.c:123-129 */
 void wo_SetRXAPanelGain1(wo_channel *c, double gain);
 void wo_SetRXAPanelGain2(wo_channel *c, double gainI, double gainQ);

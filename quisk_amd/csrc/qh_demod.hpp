@@ -285,6 +285,116 @@ static __global__ __launch_bounds__(64) void snotch_kernel(double2 *buf, long lo
     if (lane == 0) state[ch] = st;
 }
 
+// ------------------------------------------------------------------------------------------------ WDSP AGC
+// xwcpagc modes 1-5 (wdsp/wcpAGC.c:177-338): look-ahead ring of attack_buffsize samples, running maximum over the
+// ring (re-scanned, here by the 64 lanes in parallel, when the outgoing sample was the maximum), five-state
+// attack / fast-decay / hang / decay machine on `volts`, log-slope gain.  A data-dependent recurrence: sequential
+// per channel, one wave per channel, every lane runs the same scalar flow and lane i keeps output i.
+struct AgcParam {                   // loadWcpAGC, wcpAGC.c:115-146
+    double attack_mult, decay_mult, fast_decay_mult, fast_backmult, onemfast_backmult, out_target, min_volts, inv_out_target;
+    double slope_constant, inv_max_input, hang_level, hang_backmult, onemhang_backmult, hang_decay_mult, pop_ratio;
+    int attack_buffsize, hang_count_init, hang_enable, pmode;
+};
+static constexpr int kAgcRing = 2048;       // LDS ring entries (>= attack_buffsize + 2)
+struct AgcState {
+    double ring_max, volts, save_volts, fast_backaverage, hang_backaverage, gain;
+    int out_index, hang_counter, decay_type, state, attack_buffsize, pad;
+    double2 ring[kAgcRing];
+    double abs_ring[kAgcRing];
+};
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                           const AgcParam *prm, AgcState *state)
+{
+    __shared__ double2 ring[kAgcRing];
+    __shared__ double abs_ring[kAgcRing];
+    const int ch = chan_list[blockIdx.x];
+    const int lane = threadIdx.x;
+    const AgcParam q = prm[ch];
+    AgcState *sp = state + ch;
+    for (int i = lane; i < kAgcRing; i += 64) { ring[i] = sp->ring[i]; abs_ring[i] = sp->abs_ring[i]; }
+    double ring_max = sp->ring_max, volts = sp->volts, save_volts = sp->save_volts, fba = sp->fast_backaverage,
+           hba = sp->hang_backaverage, gain = sp->gain;
+    int out_index = sp->out_index, hang_counter = sp->hang_counter, decay_type = sp->decay_type, st = sp->state;
+    // loadWcpAGC re-derives in_index from out_index whenever a parameter changes (wcpAGC.c:120); keeping only
+    // out_index and the current attack_buffsize is equivalent
+    const int A = q.attack_buffsize;
+    __syncthreads();
+    double2 *p = buf + (long long)ch * stride;
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[base + lane];
+        double2 mine = make_double2(0, 0);
+        for (int i = 0; i < cnt; i++) {
+            const double I = __shfl(z.x, i, 64), Q = __shfl(z.y, i, 64);
+            out_index = (out_index + 1) & (kAgcRing - 1);
+            const int in_index = (out_index + A) & (kAgcRing - 1);
+            const double2 o = ring[out_index];
+            const double abs_out = abs_ring[out_index];
+            const double abs_in = q.pmode == 0 ? fmax(fabs(I), fabs(Q)) : sqrt(I * I + Q * Q);
+            ring[in_index] = make_double2(I, Q);
+            abs_ring[in_index] = abs_in;
+            fba = q.fast_backmult * abs_out + q.onemfast_backmult * fba;
+            hba = q.hang_backmult * abs_out + q.onemhang_backmult * hba;
+            if (abs_out >= ring_max && abs_out > 0.0) {
+                double m = 0.0;
+                for (int j = lane; j < A; j += 64) m = fmax(m, abs_ring[(out_index + 1 + j) & (kAgcRing - 1)]);
+                ring_max = wave_max(m);
+            }
+            if (abs_in > ring_max) ring_max = abs_in;
+            if (hang_counter > 0) --hang_counter;
+            const bool up = ring_max >= volts;
+            switch (st) {
+            case 0:
+                if (up) volts += (ring_max - volts) * q.attack_mult;
+                else if (volts > q.pop_ratio * fba) { st = 1; volts += (ring_max - volts) * q.fast_decay_mult; }
+                else if (q.hang_enable && hba > q.hang_level) { st = 2; hang_counter = q.hang_count_init; decay_type = 1; }
+                else { st = 3; volts += (ring_max - volts) * q.decay_mult; decay_type = 0; }
+                break;
+            case 1:
+                if (up) { st = 0; volts += (ring_max - volts) * q.attack_mult; }
+                else if (volts > save_volts) volts += (ring_max - volts) * q.fast_decay_mult;
+                else if (hang_counter > 0) st = 2;
+                else if (decay_type == 0) { st = 3; volts += (ring_max - volts) * q.decay_mult; }
+                else { st = 4; volts += (ring_max - volts) * q.hang_decay_mult; }
+                break;
+            case 2:
+                if (up) { st = 0; save_volts = volts; volts += (ring_max - volts) * q.attack_mult; }
+                else if (hang_counter == 0) { st = 4; volts += (ring_max - volts) * q.hang_decay_mult; }
+                break;
+            case 3:
+                if (up) { st = 0; save_volts = volts; volts += (ring_max - volts) * q.attack_mult; }
+                else volts += (ring_max - volts) * q.decay_mult;
+                break;
+            default:
+                if (up) { st = 0; save_volts = volts; volts += (ring_max - volts) * q.attack_mult; }
+                else volts += (ring_max - volts) * q.hang_decay_mult;
+                break;
+            }
+            if (volts < q.min_volts) volts = q.min_volts;
+            gain = volts * q.inv_out_target;
+            const double mult = (q.out_target - q.slope_constant * fmin(0.0, log10(q.inv_max_input * volts))) / volts;
+            if (lane == i) mine = make_double2(o.x * mult, o.y * mult);
+        }
+        if (lane < cnt) p[base + lane] = mine;
+    }
+    __syncthreads();
+    for (int i = lane; i < kAgcRing; i += 64) { sp->ring[i] = ring[i]; sp->abs_ring[i] = abs_ring[i]; }
+    if (lane == 0) {
+        sp->ring_max = ring_max; sp->volts = volts; sp->save_volts = save_volts; sp->fast_backaverage = fba;
+        sp->hang_backaverage = hba; sp->gain = gain; sp->out_index = out_index; sp->hang_counter = hang_counter;
+        sp->decay_type = decay_type; sp->state = st;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Quisk detectors
 // Quisk's AM detector (quisk.c:2005-2012): di = |z|; d = di + 0.99*dc; out = d - dc; dc = d.  The DC remover is the
 // linear recurrence dc_n = di_n + 0.99*dc_{n-1}: wave scan.  In place, (out, out).  One wave per channel.

@@ -53,6 +53,9 @@ struct ChanCfg {
     double nbp_flow = -4150.0, nbp_fhigh = -150.0, nbp_gain = 1.0;
     int amd_run = 0, amd_mode = 0, fmd_run = 0;                 // RXA.c:175-212
     int agc_run = 1, agc_mode = 3; double agc_fixed = 1000.0;   // RXA.c:335-358
+    double agc_tau_attack = 0.001, agc_tau_decay = 0.250, agc_max_gain = 10000.0, agc_var_gain = 1.5;
+    double agc_hangtime = 0.250, agc_hang_thresh = 0.250;
+    bool agc_dirty = true;
     int bp1_run = 1, bp1_nc = 2048, bp1_wintype = 1;            // RXA.c:377-389
     double bp1_flow = -4150.0, bp1_fhigh = -150.0, bp1_gain = 1.0;
     double gain1 = 4.0, gain2I = 1.0, gain2Q = 1.0;             // RXA.c:464-474
@@ -106,6 +109,10 @@ struct Engine {
     SnotchState *sn_state = nullptr;
     double2 *mask_de = nullptr, *mask_aud = nullptr, *hist_de[2] = { nullptr, nullptr }, *hist_aud[2] = { nullptr, nullptr };
     int cur_de = 0, cur_aud = 0, fm_nc_built = 0;
+    AgcParam *agc_prm = nullptr;
+    AgcState *agc_state = nullptr;
+    int *list_agc_cur = nullptr, *list_agc_other = nullptr;
+    int n_agc_cur = 0, n_agc_other = 0;
 
     ~Engine();
     int init();
@@ -129,6 +136,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
+    (void)hipFree(agc_prm); (void)hipFree(agc_state);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -313,9 +321,19 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 5));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 7));
         list_am = list_buf; list_sam = list_buf + nch; list_fm = list_buf + 2 * nch; list_bp1 = list_buf + 3 * nch;
-        list_plain = list_buf + 4 * nch;
+        list_plain = list_buf + 4 * nch; list_agc_cur = list_buf + 5 * nch; list_agc_other = list_buf + 6 * nch;
+        QH_HIP(dev_alloc(&agc_prm, (size_t)nch));
+        QH_HIP(dev_alloc(&agc_state, (size_t)nch));
+        QH_HIP(hipMemsetAsync(agc_state, 0, (size_t)nch * sizeof(AgcState), stream));
+        {
+            std::vector<int> oi((size_t)nch, kAgcRing - 1);         // out_index = -1 (calc_wcpagc, wcpAGC.c:34)
+            for (int c = 0; c < nch; c++)
+                QH_HIP(hipMemcpyAsync(&agc_state[c].out_index, &oi[(size_t)c], sizeof(int), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
+        dev_bytes += (long long)nch * (sizeof(AgcParam) + sizeof(AgcState));
         QH_HIP(dev_alloc(&levelfade, (size_t)nch));
         QH_HIP(dev_alloc(&am_state, (size_t)nch));
         QH_HIP(dev_alloc(&pll_state, (size_t)nch));
@@ -362,19 +380,22 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
             if (c.amd_run && c.amd_mode == 1) ls.push_back(ch);
             if (c.fmd_run) lf.push_back(ch);
             if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
+            if (c.agc_run && c.agc_mode != 0) (c.bp1_run ? lgo : lgc).push_back(ch);
         }
         n_am = (int)la.size(); n_sam = (int)ls.size(); n_fm = (int)lf.size(); n_bp1 = (int)lb.size(); n_plain = (int)lp.size();
+        n_agc_cur = (int)lgc.size(); n_agc_other = (int)lgo.size();
         auto put = [&](int *dst, const std::vector<int> &v) -> hipError_t {
             return v.empty() ? hipSuccess : hipMemcpyAsync(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream);
         };
         QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
+        QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo));
         QH_HIP(hipStreamSynchronize(stream));
         lists_dirty = false;
     }
@@ -384,6 +405,40 @@ int Engine::refresh_demod()
         if (c.fmd_run) {
             if (want_nc && want_nc != c.fm_nc) return set_error(QH_ERR_UNSUPPORTED, "FM channels with different nc in one engine");
             want_nc = c.fm_nc;
+        }
+        if (c.agc_dirty) {
+            // loadWcpAGC, wdsp/wcpAGC.c:115-146, with create_rxa's constants (RXA.c:335-358)
+            const double n_tau = 4.0, max_input = 1.0, out_targ = 1.0, tau_fast_back = 0.250, tau_fast_decay = 0.005;
+            const double tau_hang_backmult = 0.500, tau_hang_decay = 0.100;
+            AgcParam q{};
+            q.attack_buffsize = (int)std::ceil(rate * n_tau * c.agc_tau_attack);
+            if (q.attack_buffsize + 2 > kAgcRing)
+                return set_error(QH_ERR_UNSUPPORTED, "AGC attack of %g s needs a look-ahead of %d samples (limit %d)", c.agc_tau_attack,
+                                 q.attack_buffsize, kAgcRing - 2);
+            q.attack_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_attack));
+            q.decay_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_decay));
+            q.fast_decay_mult = 1.0 - std::exp(-1.0 / (rate * tau_fast_decay));
+            q.fast_backmult = 1.0 - std::exp(-1.0 / (rate * tau_fast_back));
+            q.onemfast_backmult = 1.0 - q.fast_backmult;
+            q.out_target = out_targ * (1.0 - std::exp(-n_tau)) * 0.9999;
+            q.min_volts = q.out_target / (c.agc_var_gain * c.agc_max_gain);
+            q.inv_out_target = 1.0 / q.out_target;
+            double tmp = std::log10(q.out_target / (max_input * c.agc_var_gain * c.agc_max_gain));
+            if (tmp == 0.0) tmp = 1e-16;
+            q.slope_constant = (q.out_target * (1.0 - 1.0 / c.agc_var_gain)) / tmp;
+            q.inv_max_input = 1.0 / max_input;
+            tmp = std::pow(10.0, (c.agc_hang_thresh - 1.0) / 0.125);
+            q.hang_level = (max_input * tmp + (q.out_target / (c.agc_var_gain * c.agc_max_gain)) * (1.0 - tmp)) * 0.637;
+            q.hang_backmult = 1.0 - std::exp(-1.0 / (rate * tau_hang_backmult));
+            q.onemhang_backmult = 1.0 - q.hang_backmult;
+            q.hang_decay_mult = 1.0 - std::exp(-1.0 / (rate * tau_hang_decay));
+            q.pop_ratio = 5.0;
+            q.hang_count_init = (int)(c.agc_hangtime * rate);
+            q.hang_enable = 1;
+            q.pmode = 1;
+            QH_HIP(hipMemcpyAsync(agc_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.agc_dirty = false;
         }
         if (!c.demod_dirty) continue;
         const int lf = c.levelfade;
@@ -539,9 +594,9 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
     bool any_nbp = false, any_bp1 = false, mixed = false;
     int nc_max = 1;
     for (const ChanCfg &c : cfg) {
-        if (c.agc_run && c.agc_mode != 0)
-            return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not on the GPU path yet: call SetRXAAGCMode(ch, 0)", c.agc_mode);
-        if (c.amd_run || c.fmd_run) mixed = true;
+        if (c.agc_run && c.agc_mode > 4)
+            return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0)) mixed = true;
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
@@ -615,6 +670,12 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
                            sn_prm, sn_state);
     }
     if (n_bp1) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, cur_bp1, P, list_bp1, n_bp1);
+    // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below
+    tick(1);
+    if (n_agc_cur) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+                                      list_agc_cur, agc_prm, agc_state);
+    if (n_agc_other) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
+                                        list_agc_other, agc_prm, agc_state);
     tick(2);
     // xwcpagc mode 0 + xpanel
     long long per = (n_mid + NT - 1) / NT;
@@ -762,8 +823,24 @@ int qh_rxa_SetRXACTCSSRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.ctcss_
 
 int qh_rxa_SetRXAAGCMode(qh_rxa *h, int ch, int mode)
 {
-    FOR_CH(h, ch, { c.agc_mode = (mode >= 0 && mode <= 4) ? mode : 5; c.epi_dirty = true; });
+    FOR_CH(h, ch, {                 // wdsp/wcpAGC.c:369-411
+        switch (mode) {
+        case 0: c.agc_mode = 0; break;
+        case 1: c.agc_mode = 1; c.agc_hangtime = 2.000; c.agc_tau_decay = 2.000; break;
+        case 2: c.agc_mode = 2; c.agc_hangtime = 1.000; c.agc_tau_decay = 0.500; break;
+        case 3: c.agc_mode = 3; c.agc_hang_thresh = 1.0; c.agc_hangtime = 0.000; c.agc_tau_decay = 0.250; break;
+        case 4: c.agc_mode = 4; c.agc_hang_thresh = 1.0; c.agc_hangtime = 0.000; c.agc_tau_decay = 0.050; break;
+        default: c.agc_mode = 5; break;
+        }
+        c.epi_dirty = true; c.agc_dirty = true; h->e.lists_dirty = true;
+    });
 }
+int qh_rxa_SetRXAAGCAttack(qh_rxa *h, int ch, int attack_ms) { FOR_CH(h, ch, { c.agc_tau_attack = (double)attack_ms / 1000.0; c.agc_dirty = true; }); }
+int qh_rxa_SetRXAAGCDecay(qh_rxa *h, int ch, int decay_ms) { FOR_CH(h, ch, { c.agc_tau_decay = (double)decay_ms / 1000.0; c.agc_dirty = true; }); }
+int qh_rxa_SetRXAAGCHang(qh_rxa *h, int ch, int hang_ms) { FOR_CH(h, ch, { c.agc_hangtime = (double)hang_ms / 1000.0; c.agc_dirty = true; }); }
+int qh_rxa_SetRXAAGCTop(qh_rxa *h, int ch, double max_agc_db) { FOR_CH(h, ch, { c.agc_max_gain = std::pow(10.0, max_agc_db / 20.0); c.agc_dirty = true; }); }
+int qh_rxa_SetRXAAGCSlope(qh_rxa *h, int ch, int slope) { FOR_CH(h, ch, { c.agc_var_gain = std::pow(10.0, (double)slope / 20.0 / 10.0); c.agc_dirty = true; }); }
+int qh_rxa_SetRXAAGCHangThreshold(qh_rxa *h, int ch, int t) { FOR_CH(h, ch, { c.agc_hang_thresh = (double)t / 100.0; c.agc_dirty = true; }); }
 
 int qh_rxa_SetRXAAGCFixed(qh_rxa *h, int ch, double db)
 {
@@ -798,6 +875,13 @@ int qh_rxa_flush(qh_rxa *h)
         if (e.demod_alloc) {
             QH_HIP(hipMemsetAsync(e.hist_de[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
             QH_HIP(hipMemsetAsync(e.hist_aud[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
+        }
+    }
+    if (e.demod_alloc) {                        // flush_wcpagc zeroes the ring (wcpAGC.c:154-159)
+        for (int c = 0; c < e.nch; c++) {
+            QH_HIP(hipMemsetAsync(e.agc_state[c].ring, 0, sizeof(e.agc_state[c].ring), e.stream));
+            QH_HIP(hipMemsetAsync(e.agc_state[c].abs_ring, 0, sizeof(e.agc_state[c].abs_ring), e.stream));
+            QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
         }
     }
     if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch

@@ -370,6 +370,12 @@ void SetRXABandpassRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXABandpass
 void SetRXABandpassFreqs(int channel, double f_low, double f_high) { WDSP_SETTER(qh_rxa_SetRXABandpassFreqs(L.c->eng, 0, f_low, f_high)); }
 void SetRXAAGCMode(int channel, int mode) { WDSP_SETTER(qh_rxa_SetRXAAGCMode(L.c->eng, 0, mode)); }
 void SetRXAAGCFixed(int channel, double fixed_agc) { WDSP_SETTER(qh_rxa_SetRXAAGCFixed(L.c->eng, 0, fixed_agc)); }
+void SetRXAAGCAttack(int channel, int attack) { WDSP_SETTER(qh_rxa_SetRXAAGCAttack(L.c->eng, 0, attack)); }
+void SetRXAAGCDecay(int channel, int decay) { WDSP_SETTER(qh_rxa_SetRXAAGCDecay(L.c->eng, 0, decay)); }
+void SetRXAAGCHang(int channel, int hang) { WDSP_SETTER(qh_rxa_SetRXAAGCHang(L.c->eng, 0, hang)); }
+void SetRXAAGCTop(int channel, double max_agc) { WDSP_SETTER(qh_rxa_SetRXAAGCTop(L.c->eng, 0, max_agc)); }
+void SetRXAAGCSlope(int channel, int slope) { WDSP_SETTER(qh_rxa_SetRXAAGCSlope(L.c->eng, 0, slope)); }
+void SetRXAAGCHangThreshold(int channel, int t) { WDSP_SETTER(qh_rxa_SetRXAAGCHangThreshold(L.c->eng, 0, t)); }
 void SetRXAPanelGain1(int channel, double gain) { WDSP_SETTER(qh_rxa_SetRXAPanelGain1(L.c->eng, 0, gain)); }
 void SetRXAPanelGain2(int channel, double gainI, double gainQ) { WDSP_SETTER(qh_rxa_SetRXAPanelGain2(L.c->eng, 0, gainI, gainQ)); }
 void SetRXAPanelSelect(int channel, int select) { WDSP_SETTER(qh_rxa_SetRXAPanelSelect(L.c->eng, 0, select)); }

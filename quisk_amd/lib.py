@@ -36,11 +36,12 @@ def load():
     L.qh_rxa_device_bytes.argtypes = [vp]
     L.qh_rxa_device_bytes.restype = ll
     for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
-              "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun"):
+              "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
+              "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
         f.restype = i
-    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq"):
+    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]
         f.restype = i

@@ -13,7 +13,8 @@ from .lib import load, check, QuiskHipError
 _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
             "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1",
             "RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2", "SetRXAAMDSBMode",
-            "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun")
+            "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun", "SetRXAAGCAttack",
+            "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold")
 
 
 class RxaEngine:

@@ -123,8 +123,61 @@ def test_parameter_change_between_calls(qh, oracle):
     assert rel_rms(y, r) < TOL
 
 
-def test_unsupported_modes_fail_loudly(qh):
+def test_unsupported_requests_fail_loudly(qh):
     e = qh.RxaEngine(1)
+    e.SetRXAAGCMode(0, 7)                       # maps to WDSP's mode 5 (wcpAGC.c:406-408), which RXA never runs
     x = np.zeros((1, 1024), dtype=np.complex128)
-    with pytest.raises(qh.QuiskHipError):       # AGC mode 3 is WDSP's default and is not on the GPU path yet
+    with pytest.raises(qh.QuiskHipError):
         e.process_host(x)
+    with pytest.raises(qh.QuiskHipError):
+        e.RXASetNC(0, 4096)                     # nc > 2048 is not provided
+    with pytest.raises(qh.QuiskHipError):
+        qh.RxaEngine(1, in_rate=44100)          # in_rate must be 1/2/4/8 x dsp_rate
+
+
+def _agc_signal(n, fs=192000.0):
+    """In-band tone whose level steps 0.001 -> 0.3 -> 0.01 -> silence -> 0.1 (exercises attack, hang, decay)."""
+    t = np.arange(n)
+    env = np.full(n, 0.001)
+    env[n // 6:2 * n // 6] = 0.3
+    env[2 * n // 6:3 * n // 6] = 0.01
+    env[3 * n // 6:4 * n // 6] = 0.0
+    env[4 * n // 6:] = 0.1
+    rng = np.random.default_rng(17)
+    f1 = synth.channel_tones(0, fs)[0]
+    return env * np.exp(2j * np.pi * ((f1 / fs) * t % 1.0)) + 1e-5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_agc_modes(qh, oracle, mode):
+    """WDSP's AGC state machine (long / slow / medium / fast) after the SSB chain; medium is WDSP's default."""
+    nblk = 240
+    x = _agc_signal(nblk * 1024)
+    e = _engine(qh, 1)
+    o = _oracle_channel(oracle, 0)
+    e.SetRXAAGCMode(0, mode); o.SetRXAAGCMode(mode)
+    y = np.concatenate([e.process_host(x[None, :100 * 1024]), e.process_host(x[None, 100 * 1024:])], axis=1)[0]
+    ref = o.xrxa(x)
+    assert rel_rms(y, ref) < 1e-7, rel_rms(y, ref)
+    # the AGC really acted: strong and weak segments come out within 12 dB of each other, not 30 dB apart
+    strong = np.abs(ref[60 * 256:75 * 256]).mean()
+    weak = np.abs(ref[110 * 256:118 * 256]).mean()
+    if mode >= 3:                               # long / slow hold the gain down for seconds
+        assert weak > 0.05 * strong
+
+
+def test_agc_parameter_setters(qh, oracle):
+    nblk = 120
+    x = _agc_signal(nblk * 1024)
+    e = _engine(qh, 1)
+    o = _oracle_channel(oracle, 0)
+    for obj, call in ((e, lambda n, *a: getattr(e, n)(0, *a)), (o, lambda n, *a: getattr(o, n)(*a))):
+        call("SetRXAAGCMode", 2)
+        call("SetRXAAGCAttack", 2)
+        call("SetRXAAGCDecay", 300)
+        call("SetRXAAGCHang", 100)
+        call("SetRXAAGCTop", 90.0)
+        call("SetRXAAGCSlope", 35)
+        call("SetRXAAGCHangThreshold", 40)
+    y = e.process_host(x[None, :])[0]
+    assert rel_rms(y, o.xrxa(x)) < 1e-7

@@ -120,3 +120,23 @@ def test_mode_quirks(oracle):
     b = oracle.WdspChannel(1024, 256, 192000, 48000, 48000); b.SetRXAAGCMode(0); b.SetRXAMode(1); b.SetRXAMode(0)
     ya, yb = a.xrxa(x), b.xrxa(x)
     assert rel_rms(ya, yb) > 1e-3           # a still runs bp1 (BH-7 window) after nbp0, b does not
+
+
+def test_agc_known_answers(oracle):
+    """Independent checks of the wcpAGC restatement: (1) the look-ahead delay equals attack_buffsize =
+    ceil(rate * n_tau * tau_attack) = 192 samples; (2) for a steady tone of amplitude A the gain settles to
+    (out_target - slope_constant * min(0, log10(A'))) / A' with A' the level at the AGC input (wcpAGC.c:335)."""
+    ch = oracle.WdspChannel(256, 256, 48000, 48000, 48000)
+    ch.SetRXAShiftRun(0); ch.RXANBPSetRun(0); ch.SetRXAMode(1); ch.SetRXAAGCMode(4)      # fast
+    ch.SetRXAPanelGain1(1.0)
+    n = 256 * 400
+    x = np.zeros(n, dtype=np.complex128)
+    x[1000:] = 0.05 * np.exp(2j * np.pi * 0.01 * np.arange(n - 1000))
+    y = ch.xrxa(x)
+    first = np.nonzero(np.abs(y) > 0)[0][0]
+    assert first == 1000 + 192
+    out_target = 1.0 * (1.0 - np.exp(-4.0)) * 0.9999
+    var_gain, max_gain = 1.5, 10000.0
+    slope = (out_target * (1.0 - 1.0 / var_gain)) / np.log10(out_target / (1.0 * var_gain * max_gain))
+    want = out_target - slope * min(0.0, np.log10(0.05))
+    assert abs(np.abs(y[-2000:]).mean() - want) < 1e-6 * want
