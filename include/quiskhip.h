@@ -94,6 +94,11 @@ int qh_rxa_process_host(qh_rxa *e, const double *h_in, long long in_stride, doub
 
 int qh_rxa_synchronize(qh_rxa *e);
 
+/* Meters (wdsp/meter.c:75-142).  They cost an extra pass, so they are off until enabled.  mt as wdsp/RXA.h:47-57:
+ * 0 S_PK, 1 S_AV, 2 ADC_PK, 3 ADC_AV, 4 AGC_GAIN, 5 AGC_PK, 6 AGC_AV; values in dB, -400 before the first block. */
+int qh_rxa_enable_meters(qh_rxa *e, int enable);
+int qh_rxa_GetRXAMeter(qh_rxa *e, int ch, int mt, double *value);
+
 /* flush_rxa (wdsp/RXA.c:527-559): zero the NCO phase and every filter history of every channel. */
 int qh_rxa_flush(qh_rxa *e);
 
@@ -146,6 +151,12 @@ void SetRXAAMDFadeLevel(int channel, int levelfade);                            
 void SetRXAFMDeviation(int channel, double deviation);                           /* wdsp/fmd.c:236-246 */
 void SetRXACTCSSFreq(int channel, double freq);                                  /* wdsp/fmd.c:248-258 */
 void SetRXACTCSSRun(int channel, int run);                                       /* wdsp/fmd.c:260-267 */
+double GetRXAMeter(int channel, int mt);                                         /* wdsp/meter.c:133-142 */
+/* Quisk's re-blocking shim around fexchange0 (quisk_wdsp.c:24-69): any nSamples in, scaled by 1/CLIP32 into
+ * in_size blocks, results scaled back; returns the number of samples written to cSamples.  qh_wdsp_set_parameter
+ * is the C form of quisk_wdsp_set_parameter (quisk_wdsp.c:71-91; in_size <= 0 / in_use < 0 leave the value). */
+int wdspFexchange0(int channel, double *cSamples, int nSamples);
+void qh_wdsp_set_parameter(int channel, int in_size, int in_use);
 /* accepted and ignored: these blocks are run = 0 on the hot path */
 void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c */
 void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */

@@ -412,6 +412,18 @@ typedef struct {           /* wdsp/meter.c:29-108 */
     int enum_av, enum_pk, enum_gain;
 } wo_meter;
 
+/* mlog10, wdsp/meterlog10.c:29-32,547-554: log10(2) * (exponent + mtable[top 11 mantissa bits]) where
+ * mtable[m] = log2(1 + m/2048) (the 2048-entry table is that function tabulated to 17 digits). */
+static double wo_mlog10(double val)
+{
+    unsigned long long N;
+    int e, m;
+    memcpy(&N, &val, 8);
+    e = (int)((N >> 52) & 2047) - 1023;
+    m = (int)((N >> (52 - 11)) & 2047);
+    return 0.301029995663981 * (e + log2(1.0 + m / 2048.0));
+}
+
 static void meter_init(wo_meter *m, int rate, double tau_av, double tau_decay, int eav, int epk, int egain, double *result)
 {
     m->rate = (double)rate;
@@ -434,11 +446,9 @@ static void meter_exec(wo_meter *m, const double *buff, int size, double *result
         if (smag > np) np = smag;
     }
     if (np > m->peak) m->peak = np;
-    /* mlog10 (wdsp/meterlog10.c:547) is a table-interpolated log10; plain log10 is used here,
-       so meter values agree with the reference only to the table's interpolation error. */
-    result[m->enum_av] = 10.0 * log10(m->avg + 1.0e-40);
-    result[m->enum_pk] = 10.0 * log10(m->peak + 1.0e-40);
-    if (pgain && m->enum_gain >= 0) result[m->enum_gain] = 20.0 * log10(*pgain + 1.0e-40);
+    result[m->enum_av] = 10.0 * wo_mlog10(m->avg + 1.0e-40);
+    result[m->enum_pk] = 10.0 * wo_mlog10(m->peak + 1.0e-40);
+    if (pgain && m->enum_gain >= 0) result[m->enum_gain] = 20.0 * wo_mlog10(*pgain + 1.0e-40);
 }
 
 /* meter indices, wdsp/RXA.h:47-57 */

@@ -22,6 +22,13 @@ struct AmParam {            // per engine (depends on the DSP rate only), init_a
 
 struct AmState { double dc, dc_insert; };
 
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
 // x^(lane+1) for lane = 0..63 (wave-wide), by repeated squaring per lane
 __device__ __forceinline__ double lane_pow(double x, int e)
 {
@@ -285,6 +292,48 @@ static __global__ __launch_bounds__(64) void snotch_kernel(double2 *buf, long lo
     if (lane == 0) state[ch] = st;
 }
 
+// ------------------------------------------------------------------------------------------------ WDSP meters
+// xmeter (wdsp/meter.c:75-108) over nblk DSP blocks: running average of |z|^2 (one pole per sample) and a peak that
+// decays per sample and is topped up with the block maximum at the end of every block.  result[0] = average,
+// result[1] = peak, both in dB through mlog10 (wdsp/meterlog10.c:547-554: log10(2) * (exponent + log2 of the
+// mantissa truncated to 11 bits)).  One wave per channel.
+struct MeterParam { double mult_average, mult_peak; };
+struct MeterState { double avg, peak, res_av, res_pk; };
+
+__device__ __forceinline__ double mlog10_dev(double val)
+{
+    const unsigned long long N = (unsigned long long)__double_as_longlong(val);
+    const int e = (int)((N >> 52) & 2047) - 1023;
+    const int m = (int)((N >> (52 - 11)) & 2047);
+    return 0.301029995663981 * ((double)e + log2(1.0 + (double)m / 2048.0));
+}
+
+static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, long long stride, int nblk, int size,
+                                                          MeterState *state, MeterParam q, const int *chan_list)
+{
+    const int ch = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
+    const double2 *p = buf + (long long)ch * stride;
+    MeterState st = state[ch];
+    const double pw = lane_pow(q.mult_average, lane + 1);
+    const double pk_blk = pow(q.mult_peak, (double)size);
+    for (int b = 0; b < nblk; b++) {
+        double np = 0.0;
+        for (int base = 0; base < size; base += 64) {
+            const int cnt = size - base < 64 ? size - base : 64;
+            double smag = 0.0;
+            if (lane < cnt) { const double2 z = p[(long long)b * size + base + lane]; smag = z.x * z.x + z.y * z.y; }
+            const double a = scan_pole((1.0 - q.mult_average) * smag, q.mult_average, lane) + pw * st.avg;
+            st.avg = __shfl(a, cnt - 1, 64);
+            np = fmax(np, wave_max_d(smag));
+        }
+        st.peak *= pk_blk;
+        if (np > st.peak) st.peak = np;
+        st.res_av = 10.0 * mlog10_dev(st.avg + 1.0e-40);
+        st.res_pk = 10.0 * mlog10_dev(st.peak + 1.0e-40);
+    }
+    if (lane == 0) state[ch] = st;
+}
+
 // ------------------------------------------------------------------------------------------------ WDSP AGC
 // xwcpagc modes 1-5 (wdsp/wcpAGC.c:177-338): look-ahead ring of attack_buffsize samples, running maximum over the
 // ring (re-scanned, here by the 64 lanes in parallel, when the outgoing sample was the maximum), five-state
@@ -302,13 +351,6 @@ struct AgcState {
     double2 ring[kAgcRing];
     double abs_ring[kAgcRing];
 };
-
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
-    return v;
-}
 
 static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                            const AgcParam *prm, AgcState *state)
@@ -347,7 +389,7 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
             if (abs_out >= ring_max && abs_out > 0.0) {
                 double m = 0.0;
                 for (int j = lane; j < A; j += 64) m = fmax(m, abs_ring[(out_index + 1 + j) & (kAgcRing - 1)]);
-                ring_max = wave_max(m);
+                ring_max = wave_max_d(m);
             }
             if (abs_in > ring_max) ring_max = abs_in;
             if (hang_counter > 0) --hang_counter;

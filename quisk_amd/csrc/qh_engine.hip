@@ -111,6 +111,9 @@ struct Engine {
     int cur_de = 0, cur_aud = 0, fm_nc_built = 0;
     AgcParam *agc_prm = nullptr;
     AgcState *agc_state = nullptr;
+    bool meters_on = false;
+    MeterState *m_adc = nullptr, *m_s = nullptr, *m_agc = nullptr;
+    MeterParam m_prm{};
     int *list_agc_cur = nullptr, *list_agc_other = nullptr;
     int n_agc_cur = 0, n_agc_other = 0;
 
@@ -136,7 +139,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
-    (void)hipFree(agc_prm); (void)hipFree(agc_state);
+    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -324,6 +327,16 @@ int Engine::refresh_demod()
         QH_HIP(dev_alloc(&list_buf, (size_t)nch * 7));
         list_am = list_buf; list_sam = list_buf + nch; list_fm = list_buf + 2 * nch; list_bp1 = list_buf + 3 * nch;
         list_plain = list_buf + 4 * nch; list_agc_cur = list_buf + 5 * nch; list_agc_other = list_buf + 6 * nch;
+        {   // create_meter x3 (RXA.c:69-82,142-155,361-374): tau 0.1 s for average and peak decay; flush_meter -> -400 dB
+            std::vector<MeterState> init((size_t)nch, MeterState{ 0.0, 0.0, -400.0, -400.0 });
+            for (MeterState **pm : { &m_adc, &m_s, &m_agc }) {
+                QH_HIP(dev_alloc(pm, (size_t)nch));
+                QH_HIP(hipMemcpyAsync(*pm, init.data(), (size_t)nch * sizeof(MeterState), hipMemcpyHostToDevice, stream));
+            }
+            QH_HIP(hipStreamSynchronize(stream));
+            m_prm.mult_average = std::exp(-1.0 / (rate * 0.100));
+            m_prm.mult_peak = std::exp(-1.0 / (rate * 0.100));
+        }
         QH_HIP(dev_alloc(&agc_prm, (size_t)nch));
         QH_HIP(dev_alloc(&agc_state, (size_t)nch));
         QH_HIP(hipMemsetAsync(agc_state, 0, (size_t)nch * sizeof(AgcState), stream));
@@ -596,7 +609,7 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
-        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0)) mixed = true;
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || meters_on) mixed = true;
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
@@ -651,10 +664,14 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
     // ---- mixed modes: per-mode stages run on channel lists; gains/panel in a final pointwise pass
     double2 *cur = buf[0], *other = buf[1];
     if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid)) return rc;
+    if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_adc,
+                                      m_prm, (const int *)nullptr);
     if (any_nbp) {
         run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kNfft, hist_nbp, cur_nbp, P, nullptr, 0);
         std::swap(cur, other);
     }
+    if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_s,
+                                      m_prm, (const int *)nullptr);
     tick(1);
     if (n_am) hipLaunchKernelGGL(am_detect_kernel, dim3((unsigned)n_am), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                  list_am, levelfade, am_state, am_prm);
@@ -676,6 +693,13 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
                                       list_agc_cur, agc_prm, agc_state);
     if (n_agc_other) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
                                         list_agc_other, agc_prm, agc_state);
+    if (meters_on) {    // agcmeter sits after xwcpagc (RXA.c:589); mode 0's gain multiply is applied below, so its
+                        // level reading is taken on the fixed-gain input and corrected in qh_rxa_GetRXAMeter
+        if (n_plain) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)n_plain), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size,
+                                        m_agc, m_prm, list_plain);
+        if (n_bp1) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)n_bp1), dim3(64), 0, stream, other, buf_cap, nblk, dsp_size,
+                                      m_agc, m_prm, list_bp1);
+    }
     tick(2);
     // xwcpagc mode 0 + xpanel
     long long per = (n_mid + NT - 1) / NT;
@@ -889,6 +913,43 @@ int qh_rxa_flush(qh_rxa *h)
         QH_HIP(hipMemsetAsync(e.pll_state, 0, (size_t)e.nch * sizeof(PllState), e.stream));
         QH_HIP(hipMemsetAsync(e.sn_state, 0, (size_t)e.nch * sizeof(SnotchState), e.stream));
     }
+    return QH_OK;
+}
+
+// Meters (wdsp/meter.c): enable != 0 makes later process calls maintain the ADC, S and AGC meters.
+int qh_rxa_enable_meters(qh_rxa *h, int enable)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    h->e.meters_on = enable != 0;
+    return QH_OK;
+}
+
+// GetRXAMeter (wdsp/meter.c:133-142); mt as wdsp/RXA.h:47-57: 0 S_PK, 1 S_AV, 2 ADC_PK, 3 ADC_AV, 4 AGC_GAIN, 5 AGC_PK, 6 AGC_AV
+int qh_rxa_GetRXAMeter(qh_rxa *h, int ch, int mt, double *value)
+{
+    if (!h || !value) return set_error(QH_ERR_INVALID, "null argument");
+    Engine &e = h->e;
+    if (ch < 0 || ch >= e.nch || mt < 0 || mt > 6) return set_error(QH_ERR_INVALID, "channel or meter index out of range");
+    if (!e.meters_on || !e.demod_alloc) { *value = -400.0; return QH_OK; }      // flush_meter's initial reading
+    QH_HIP(hipSetDevice(e.device));
+    QH_HIP(hipStreamSynchronize(e.stream));
+    const ChanCfg &c = e.cfg[(size_t)ch];
+    MeterState st;
+    const MeterState *src = mt <= 1 ? e.m_s : mt <= 3 ? e.m_adc : e.m_agc;
+    QH_HIP(hipMemcpy(&st, src + ch, sizeof(st), hipMemcpyDeviceToHost));
+    if (mt == 4) {
+        double g = 0.0;
+        QH_HIP(hipMemcpy(&g, &e.agc_state[ch].gain, sizeof(double), hipMemcpyDeviceToHost));
+        const double v = g + 1.0e-40;
+        unsigned long long N; std::memcpy(&N, &v, 8);
+        const int ex = (int)((N >> 52) & 2047) - 1023, m = (int)((N >> 41) & 2047);
+        *value = 20.0 * 0.301029995663981 * ((double)ex + std::log2(1.0 + (double)m / 2048.0));
+        return QH_OK;
+    }
+    double r = (mt == 0 || mt == 2 || mt == 5) ? st.res_pk : st.res_av;
+    if (mt >= 5 && c.agc_run && c.agc_mode == 0 && r > -399.0)
+        r += 20.0 * std::log10(c.agc_fixed);                // |g z|^2 = g^2 |z|^2; exact up to mlog10's 11-bit mantissa steps
+    *value = r;
     return QH_OK;
 }
 

@@ -266,6 +266,7 @@ void OpenChannel(int channel, int in_size, int dsp_size, int input_samplerate, i
     c.exchange = 0;
     c.open = true;
     if (state) { c.upflag = 1; c.exchange = 1; }    // wdsp/channel.c:92-98
+    (void)qh_rxa_enable_meters(c.eng, 1);           // WDSP's meters always run (RXA.c:69-82)
 }
 
 void CloseChannel(int channel)
@@ -385,6 +386,58 @@ void SetRXAAMDFadeLevel(int channel, int levelfade) { WDSP_SETTER(qh_rxa_SetRXAA
 void SetRXAFMDeviation(int channel, double deviation) { WDSP_SETTER(qh_rxa_SetRXAFMDeviation(L.c->eng, 0, deviation)); }
 void SetRXACTCSSFreq(int channel, double freq) { WDSP_SETTER(qh_rxa_SetRXACTCSSFreq(L.c->eng, 0, freq)); }
 void SetRXACTCSSRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXACTCSSRun(L.c->eng, 0, run)); }
+
+double GetRXAMeter(int channel, int mt)
+{
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return -400.0;
+    double v = -400.0;
+    int rc = qh_rxa_GetRXAMeter(L.c->eng, 0, mt, &v);
+    if (rc) g_status = rc;
+    return v;
+}
+
+// ---- quisk_wdsp.c:12-69: re-block an arbitrary count into in_size blocks through a ring, CLIP32 scaling
+namespace {
+struct Shim { std::vector<double> buf; int sizeBuf = 0, nBuf = 0, in_size = 0, in_use = 0, W = 0, R = 0; };
+Shim g_shim[kMaxChannels];
+}
+
+void qh_wdsp_set_parameter(int channel, int in_size, int in_use)
+{
+    if (!valid(channel)) return;
+    if (in_size > 0) g_shim[channel].in_size = in_size;
+    if (in_use >= 0) g_shim[channel].in_use = in_use;
+}
+
+int wdspFexchange0(int channel, double *cSamples, int nSamples)
+{
+    const double CLIP32 = 2147483647.0;
+    if (!valid(channel)) return nSamples;
+    Shim &s = g_shim[channel];
+    if (!s.in_use) { s.W = 0; s.R = 0; s.nBuf = 0; return nSamples; }
+    if (nSamples <= 0 || s.in_size <= 0) return nSamples;
+    const int in_size = s.in_size;
+    int i = nSamples / in_size + 3;                 // blocks needed for the samples plus a partial block
+    if (i * in_size > s.sizeBuf) { s.sizeBuf = i * in_size; s.buf.resize((size_t)s.sizeBuf * 2); }
+    for (i = 0; i < nSamples; i++) {
+        s.buf[2 * (size_t)s.W] = cSamples[2 * i] / CLIP32;
+        s.buf[2 * (size_t)s.W + 1] = cSamples[2 * i + 1] / CLIP32;
+        if (++s.W >= s.sizeBuf) s.W = 0;
+    }
+    s.nBuf += nSamples;
+    int nout = 0, error = 0;
+    while (s.nBuf >= in_size) {
+        fexchange0(channel, s.buf.data() + 2 * (size_t)s.R, cSamples + 2 * (size_t)nout, &error);
+        s.R += in_size;
+        if (s.R >= s.sizeBuf) s.R = 0;
+        nout += in_size;
+        s.nBuf -= in_size;
+    }
+    for (i = 0; i < nout; i++) { cSamples[2 * i] *= CLIP32; cSamples[2 * i + 1] *= CLIP32; }
+    return nout;
+}
 
 // xpanel never looks at its run flag (wdsp/patchpanel.c:55-101): accepted, no effect on the data.
 void SetRXAPanelRun(int channel, int run) { (void)run; g_status = QH_OK; (void)valid(channel); }

@@ -55,6 +55,8 @@ def load():
     L.qh_rxa_process_host.restype = i
     L.qh_rxa_synchronize.argtypes = [vp]
     L.qh_rxa_synchronize.restype = i
+    L.qh_rxa_enable_meters.argtypes = [vp, i]
+    L.qh_rxa_GetRXAMeter.argtypes = [vp, i, i, C.POINTER(d)]
     L.qh_rxa_flush.argtypes = [vp]
     L.qh_rxa_flush.restype = i
     L.qh_rxa_enable_timing.argtypes = [vp, i]

@@ -52,6 +52,14 @@ class RxaEngine:
         check(self._L.qh_rxa_process_host(self._h, x.ctypes.data, x.shape[1], out.ctypes.data, out.shape[1], nblk))
         return out
 
+    def enable_meters(self, on=True):
+        check(self._L.qh_rxa_enable_meters(self._h, 1 if on else 0))
+
+    def GetRXAMeter(self, ch, mt):
+        v = C.c_double(0)
+        check(self._L.qh_rxa_GetRXAMeter(self._h, ch, mt, C.byref(v)))
+        return v.value
+
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))
 

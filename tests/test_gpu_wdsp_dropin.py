@@ -109,3 +109,39 @@ def test_closed_channel_and_unsupported_requests_are_reported(qh):
     assert err.value != 0 and lib.qh_wdsp_status() != 0
     lib.SetRXAEMNRRun(7, 1)
     assert lib.qh_wdsp_status() != 0            # NR2 is outside the GPU hot path: reported, not silently ignored
+
+
+def test_meters_and_quisk_shim(qh, oracle):
+    """GetRXAMeter after a run, and quisk_wdsp.c's re-blocking shim wdspFexchange0 (CLIP32 scaling, ragged n)."""
+    lib = qh.load()
+    lib.GetRXAMeter.restype = C.c_double
+    x = synth.make_input_numpy(1, 1024 * 30)[0]
+    _open(lib, 5, 1024, 256, 192000, nbp=True, shift_freq=10000.0)
+    try:
+        lib.qh_wdsp_set_parameter(5, 1024, 1)
+        buf = (x * 2147483647.0).copy()
+        outs, pos = [], 0
+        for k in (100, 1024, 3000, 5, 2048 * 4 + 17, x.size - (100 + 1024 + 3000 + 5 + 2048 * 4 + 17)):
+            seg = np.ascontiguousarray(buf[pos:pos + k]).copy()
+            work = np.zeros(max(k, 1) + 2048, dtype=np.complex128)
+            work[:k] = seg
+            n = lib.wdspFexchange0(5, work.ctypes.data_as(C.c_void_p), k)
+            outs.append(work[:n].copy())
+            pos += k
+        y = np.concatenate(outs) / 2147483647.0
+        meters = [lib.GetRXAMeter(5, mt) for mt in range(7)]
+    finally:
+        lib.qh_wdsp_set_parameter(5, 0, 0)
+        lib.CloseChannel(5)
+    o = _oracle(oracle, 1024, 256, 192000, True, 10000.0)
+    ref, _ = o.fexchange0(x)
+    # the shim returns whole in_size blocks worth of input: 29 of the 30 blocks have been consumed in order
+    n = y.size
+    assert n % 1024 == 0 and n >= 1024 * 29
+    # the shim hands back in_size samples per block although WDSP produced out_size = in_size/4 (quisk_wdsp.c:61-64
+    # advances by in_size): the first out_size entries of every in_size chunk are the data
+    got = y.reshape(-1, 1024)[:, :256].reshape(-1)
+    assert rel_rms(got, ref[:got.size]) < 1e-9
+    want = [o.GetRXAMeter(mt) for mt in range(7)]
+    for mt in (0, 1, 2, 3, 5, 6):
+        assert abs(meters[mt] - want[mt]) < 1e-3, (mt, meters[mt], want[mt])
