@@ -191,6 +191,19 @@ int qh_fir_synchronize(qh_fir *f);
 /* The 43 taps (delays 0..42) of Quisk's 45-tap half-band whose outer taps are zero (filter.c:382-385). */
 void qh_hb45_taps(double *taps43);
 
+/* ------------------------------------------------------------------ 3b. fused half-band cascade */
+/* `nstage` (1..8) consecutive quisk_cDecim2HB45 stages (filter.c:377-417; chained at quisk.c:1772-1796) over
+ * `nch` complex streams in ONE pass over HBM: decimation 2^nstage, state (the input history) carried between
+ * calls.  n_in must be a multiple of 2^nstage; n_in / 2^nstage outputs per channel.  dtype QH_F64 / QH_F32.
+ * Results equal nstage calls of quisk_cDecim2HB45 to rounding (time-domain sums, not FFT). */
+typedef struct qh_hbc qh_hbc;
+qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream);
+void qh_hbc_destroy(qh_hbc *h);
+int qh_hbc_reset(qh_hbc *h);
+int qh_hbc_process(qh_hbc *h, const void *d_in, long long in_stride, int n_in, void *d_out, long long out_stride);
+int qh_hbc_process_host(qh_hbc *h, const void *h_in, long long in_stride, int n_in, void *h_out, long long out_stride);
+int qh_hbc_synchronize(qh_hbc *h);
+
 /* ------------------------------------------------------------------ 5. batched panadapter */
 /* Quisk's spectrum display path for `nch` receivers: the FFT ring producer of quisk_process_samples
  * (quisk.c:2454-2475), record_app's Hanning window (quisk.c:6003-6009) and get_graph job 1

@@ -1,0 +1,167 @@
+// qh_hbcascade.hip -- batched cascade of 45-tap half-band decimators in one HBM pass (include/quiskhip.h group 3b).
+//
+// GPU form of `nstage` consecutive quisk_cDecim2HB45 calls (filter.c:377-417) as quisk_process_decimate chains
+// them (quisk.c:1772-1796: HalfBand1..5) and as BASELINE config 5 chains eight of them (61.44 Msps -> 240 ksps).
+// See qh_hbcascade.hpp for the kernel.
+#include <cstdlib>
+#include <vector>
+#include "qh_hbcascade.hpp"
+#include "qh_internal.hpp"
+
+using namespace qh;
+
+struct qh_hbc {
+    int device = 0, nch = 0, nstage = 0, dtype = QH_F64;
+    int warm = 0;
+    size_t esize = 16;
+    void *hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ~qh_hbc()
+    {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto &h : hist) if (h) (void)hipFree(h);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <typename T, int NS>
+int launch(qh_hbc *h, const void *in, long long in_stride, int n_in, void *out, long long out_stride)
+{
+    using G = HbGeom<NS>;
+    // segments: long enough that the warm-up is a few per cent, short enough to fill 256 CUs x 4 workgroups
+    long long seg = 64LL * G::STEP;
+    while (seg > 16 * G::STEP && (long long)h->nch * ((n_in + seg - 1) / seg) < 1024) seg >>= 1;
+    if (const char *e = getenv("QH_HBC_SEG_STEPS")) { const int v = atoi(e); if (v > 0) seg = (long long)v * G::STEP; }
+    const int nseg = (int)((n_in + seg - 1) / seg);
+    const size_t lds = (size_t)G::ring_pairs() * sizeof(HbPair<T>);
+    auto k = hb45_cascade_kernel<T, NS>;
+    QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)h->nch), dim3(NT), lds, h->stream, (const cplx<T> *)in, in_stride,
+                       (const cplx<T> *)h->hist[h->cur], n_in, (cplx<T> *)out, out_stride, (int)seg);
+    QH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hb45_hist_kernel<T>, dim3((unsigned)((G::WARM + NT - 1) / NT), (unsigned)h->nch), dim3(NT), 0, h->stream,
+                       (const cplx<T> *)in, in_stride, n_in, (const cplx<T> *)h->hist[h->cur], (cplx<T> *)h->hist[h->cur ^ 1],
+                       G::WARM);
+    QH_HIP(hipGetLastError());
+    h->cur ^= 1;
+    return QH_OK;
+}
+
+template <typename T>
+int dispatch(qh_hbc *h, const void *in, long long is, int n, void *out, long long os)
+{
+    switch (h->nstage) {
+    case 1: return launch<T, 1>(h, in, is, n, out, os);
+    case 2: return launch<T, 2>(h, in, is, n, out, os);
+    case 3: return launch<T, 3>(h, in, is, n, out, os);
+    case 4: return launch<T, 4>(h, in, is, n, out, os);
+    case 5: return launch<T, 5>(h, in, is, n, out, os);
+    case 6: return launch<T, 6>(h, in, is, n, out, os);
+    case 7: return launch<T, 7>(h, in, is, n, out, os);
+    case 8: return launch<T, 8>(h, in, is, n, out, os);
+    }
+    return set_error(QH_ERR_INVALID, "qh_hbc: nstage out of range");
+}
+
+int warm_of(int ns)
+{
+    const int step = 2048;
+    return (42 * ((1 << ns) - 1) + step - 1) / step * step;
+}
+
+}  // namespace
+
+extern "C" {
+
+qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream)
+{
+    if (nch <= 0 || nstage < 1 || nstage > 8 || (dtype != QH_F64 && dtype != QH_F32)) {
+        set_error(QH_ERR_INVALID, "qh_hbc_create: bad arguments");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
+        return nullptr;
+    }
+    qh_hbc *h = new qh_hbc();
+    h->device = device; h->nch = nch; h->nstage = nstage; h->dtype = dtype;
+    h->esize = dtype == QH_F64 ? 16 : 8;
+    h->warm = warm_of(nstage);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); delete h; return nullptr; }
+    if (!s) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { set_error(QH_ERR_HIP, "stream creation failed"); delete h; return nullptr; }
+        h->own_stream = true;
+    }
+    h->stream = s;
+    const size_t bytes = (size_t)nch * (size_t)h->warm * h->esize;
+    for (auto &p : h->hist) {
+        if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
+            set_error(QH_ERR_HIP, "qh_hbc_create: history allocation failed");
+            delete h;
+            return nullptr;
+        }
+    }
+    return h;
+}
+
+void qh_hbc_destroy(qh_hbc *h) { delete h; }
+
+int qh_hbc_reset(qh_hbc *h)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "qh_hbc_reset: null handle");
+    QH_HIP(hipSetDevice(h->device));
+    for (auto &p : h->hist) QH_HIP(hipMemsetAsync(p, 0, (size_t)h->nch * (size_t)h->warm * h->esize, h->stream));
+    return QH_OK;
+}
+
+int qh_hbc_process(qh_hbc *h, const void *d_in, long long in_stride, int n_in, void *d_out, long long out_stride)
+{
+    if (!h || !d_in || !d_out || n_in < 0) return set_error(QH_ERR_INVALID, "qh_hbc_process: bad arguments");
+    if (n_in % (1 << h->nstage)) return set_error(QH_ERR_INVALID, "qh_hbc_process: n_in must be a multiple of 2^nstage = %d", 1 << h->nstage);
+    if (in_stride < n_in || out_stride < (n_in >> h->nstage)) return set_error(QH_ERR_INVALID, "qh_hbc_process: stride shorter than the data");
+    if (n_in == 0) return QH_OK;
+    QH_HIP(hipSetDevice(h->device));
+    return h->dtype == QH_F64 ? dispatch<double>(h, d_in, in_stride, n_in, d_out, out_stride)
+                              : dispatch<float>(h, d_in, in_stride, n_in, d_out, out_stride);
+}
+
+int qh_hbc_process_host(qh_hbc *h, const void *h_in, long long in_stride, int n_in, void *h_out, long long out_stride)
+{
+    if (!h || !h_in || !h_out || n_in < 0) return set_error(QH_ERR_INVALID, "qh_hbc_process_host: bad arguments");
+    QH_HIP(hipSetDevice(h->device));
+    const int n_out = n_in >> h->nstage;
+    void *di = nullptr, *dout = nullptr;
+    const size_t ib = (size_t)h->nch * (size_t)n_in * h->esize, ob = (size_t)h->nch * (size_t)(n_out > 0 ? n_out : 1) * h->esize;
+    QH_HIP(hipMalloc(&di, ib ? ib : 16));
+    if (hipMalloc(&dout, ob) != hipSuccess) { (void)hipFree(di); return set_error(QH_ERR_HIP, "qh_hbc_process_host: hipMalloc failed"); }
+    int rc = QH_OK;
+    hipError_t e = hipMemcpy2DAsync(di, (size_t)n_in * h->esize, h_in, (size_t)in_stride * h->esize, (size_t)n_in * h->esize,
+                                    (size_t)h->nch, hipMemcpyHostToDevice, h->stream);
+    if (n_in > 0 && e != hipSuccess) rc = set_error(QH_ERR_HIP, "qh_hbc_process_host: upload failed");
+    if (rc == QH_OK) rc = qh_hbc_process(h, di, n_in, n_in, dout, n_out > 0 ? n_out : 1);
+    if (rc == QH_OK && n_out > 0) {
+        e = hipMemcpy2DAsync(h_out, (size_t)out_stride * h->esize, dout, (size_t)n_out * h->esize, (size_t)n_out * h->esize,
+                             (size_t)h->nch, hipMemcpyDeviceToHost, h->stream);
+        if (e != hipSuccess) rc = set_error(QH_ERR_HIP, "qh_hbc_process_host: download failed");
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess && rc == QH_OK) rc = set_error(QH_ERR_HIP, "qh_hbc_process_host: synchronize failed");
+    (void)hipFree(di); (void)hipFree(dout);
+    return rc;
+}
+
+int qh_hbc_synchronize(qh_hbc *h)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "qh_hbc_synchronize: null handle");
+    QH_HIP(hipSetDevice(h->device));
+    QH_HIP(hipStreamSynchronize(h->stream));
+    return QH_OK;
+}
+
+}  // extern "C"

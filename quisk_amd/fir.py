@@ -66,3 +66,46 @@ class FirBank:
             self.close()
         except Exception:
             pass
+
+
+class HalfBandCascade:
+    """`nstage` chained quisk_cDecim2HB45 decimators (filter.c:377-417, chained at quisk.c:1772-1796) for `nch`
+    streams in one pass over HBM (C ABI group 3b).  Calls take multiples of 2**nstage samples."""
+
+    def __init__(self, nch, nstage, dtype=F64, device=0, stream=None):
+        self._L = load()
+        self._h = self._L.qh_hbc_create(device, nch, nstage, dtype, stream)
+        if not self._h:
+            raise QuiskHipError("qh_hbc_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch, self.nstage, self.decim, self.dtype = nch, nstage, 1 << nstage, dtype
+        self.np_dtype = np.complex128 if dtype == F64 else np.complex64
+
+    def process_ptr(self, d_in, in_stride, n_in, d_out, out_stride):
+        check(self._L.qh_hbc_process(self._h, d_in, in_stride, n_in, d_out, out_stride))
+        return n_in >> self.nstage
+
+    def process_host(self, x):
+        x = np.ascontiguousarray(x, dtype=self.np_dtype)
+        if x.ndim != 2 or x.shape[0] != self.nch:
+            raise ValueError("expected [nch, n]")
+        n_out = x.shape[1] >> self.nstage
+        out = np.empty((self.nch, max(n_out, 1)), dtype=self.np_dtype)
+        check(self._L.qh_hbc_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1], out.ctypes.data, max(n_out, 1)))
+        return out[:, :n_out].copy()
+
+    def reset(self):
+        check(self._L.qh_hbc_reset(self._h))
+
+    def synchronize(self):
+        check(self._L.qh_hbc_synchronize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_hbc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -72,6 +72,14 @@ def load():
     L.qh_fir_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
     L.qh_fir_process_host.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
     L.qh_fir_synchronize.argtypes = [vp]
+    L.qh_hbc_create.restype = vp
+    L.qh_hbc_create.argtypes = [i, i, i, i, vp]
+    L.qh_hbc_destroy.argtypes = [vp]
+    L.qh_hbc_destroy.restype = None
+    L.qh_hbc_reset.argtypes = [vp]
+    L.qh_hbc_process.argtypes = [vp, vp, ll, i, vp, ll]
+    L.qh_hbc_process_host.argtypes = [vp, vp, ll, i, vp, ll]
+    L.qh_hbc_synchronize.argtypes = [vp]
     L.qh_hb45_taps.argtypes = [vp]
     L.qh_hb45_taps.restype = None
     L.qh_pan_create.restype = vp

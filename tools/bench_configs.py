@@ -93,10 +93,20 @@ def config5(torch, qh, dev):
             cur, cn = bufs[k], m_
         m_ = d5.process_ptr(cur.data_ptr(), cur.shape[1], cn, y5.data_ptr(), y5.shape[1])
         core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
+    casc = qh.HalfBandCascade(1, 8, dtype=1, stream=s)
+
+    def step_fused():
+        m_ = casc.process_ptr(x.data_ptr(), n, n, bufs[7].data_ptr(), bufs[7].shape[1])
+        m_ = d5.process_ptr(bufs[7].data_ptr(), bufs[7].shape[1], m_, y5.data_ptr(), y5.shape[1])
+        core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
     sync = lambda: torch.cuda.synchronize(dev)
     t = timed(step, sync, steps=10, warmup=2)
     t1 = timed(lambda: hb[0].process_ptr(x.data_ptr(), n, n, bufs[0].data_ptr(), bufs[0].shape[1]), sync, steps=10, warmup=2)
-    return {"config": "5 (one GPU's channel): 1 ch x 61.44 Msps fp32, 8 x HB45 + 245-tap /5 + bandpass nc 2048, 2^26 samples per step",
+    tf = timed(step_fused, sync, steps=10, warmup=2)
+    tc = timed(lambda: casc.process_ptr(x.data_ptr(), n, n, bufs[7].data_ptr(), bufs[7].shape[1]), sync, steps=10, warmup=2)
+    return {"fused_ms": tf * 1e3, "fused_Msamp_per_s": n / tf / 1e6, "fused_cascade_only_ms": tc * 1e3,
+            "fused_algorithmic_GBps": 8.0 * n / tf / 1e9,
+            "config": "5 (one GPU's channel): 1 ch x 61.44 Msps fp32, 8 x HB45 + 245-tap /5 + bandpass nc 2048, 2^26 samples per step",
             "samples_per_step": n, "ms": t * 1e3, "Msamp_per_s": n / t / 1e6, "first_stage_ms": t1 * 1e3,
             "algorithmic_GBps": 8.0 * n / t / 1e9,
             "note": "unfused cascade of overlap-save banks; the first half-band alone moves 12 B/sample"}

@@ -2,7 +2,7 @@
 """Run on the GPU box: one rocprofv3 --pmc pass per counter group over a short bench.py run, keep only the
 per-kernel averages of our kernels (the raw CSVs are far too large to copy back).
 
-usage: tools/pmc_pass.py <out.json> [bench args...]
+usage: tools/pmc_pass.py <out.json> [script.py] [args...]      (script defaults to bench.py)
 """
 import collections
 import csv
@@ -27,13 +27,19 @@ GROUPS = [
 
 def main():
     out = sys.argv[1]
-    bench_args = sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--log2-samples", "20", "--no-cpu-baseline"]
+    script = os.path.join(ROOT, "bench.py")
+    rest = sys.argv[2:]
+    if rest and rest[0].endswith(".py"):
+        script, rest = os.path.abspath(rest[0]), rest[1:]
+        bench_args = rest
+    else:
+        bench_args = rest or ["--steps", "2", "--warmup", "1", "--log2-samples", "20", "--no-cpu-baseline"]
     res = collections.defaultdict(dict)
     tmp = "/tmp/pmc_pass"
     for gi, grp in enumerate(GROUPS):
         shutil.rmtree(tmp, ignore_errors=True)
         cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--",
-                                              sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+                                              sys.executable, script] + bench_args
         r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"))
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
