@@ -204,6 +204,23 @@ int qh_hbc_process(qh_hbc *h, const void *d_in, long long in_stride, int n_in, v
 int qh_hbc_process_host(qh_hbc *h, const void *h_in, long long in_stride, int n_in, void *h_out, long long out_stride);
 int qh_hbc_synchronize(qh_hbc *h);
 
+/* ------------------------------------------------------------------ 3c. polyphase rational resampler */
+/* quisk_cInterpDecim (filter.c:287-324) for `nch` complex streams, real taps; decim = 1 is quisk_cInterpolate
+ * (filter.c:131-165); two real streams ride as the real and imaginary parts (quisk_dInterpolate, filter.c:167-201).
+ * Output m sits at upsampled position p = phase + m*decim:  y[m] = interp * sum_k taps[p % interp + k*interp] *
+ * x[p / interp - k].  `phase` (the reference's decim_index) and the last ceil(ntaps/interp)-1 inputs carry over. */
+typedef struct qh_rat qh_rat;
+qh_rat *qh_rat_create(int device, int nch, const double *taps, int ntaps, int interp, int decim, int dtype, void *stream);
+void qh_rat_destroy(qh_rat *h);
+int qh_rat_reset(qh_rat *h);
+/* hist: [nch][ceil(ntaps/interp) - 1] complex samples of the stream's dtype, oldest first (NULL = zeros). */
+int qh_rat_set_state(qh_rat *h, const void *hist, int phase);
+int qh_rat_phase(const qh_rat *h);
+int qh_rat_out_count(const qh_rat *h, int n_in);
+int qh_rat_process(qh_rat *h, const void *d_in, long long in_stride, int n_in, void *d_out, long long out_stride, int *n_out);
+int qh_rat_process_host(qh_rat *h, const void *h_in, long long in_stride, int n_in, void *h_out, long long out_stride, int *n_out);
+int qh_rat_synchronize(qh_rat *h);
+
 /* ------------------------------------------------------------------ 5. batched panadapter */
 /* Quisk's spectrum display path for `nch` receivers: the FFT ring producer of quisk_process_samples
  * (quisk.c:2454-2475), record_app's Hanning window (quisk.c:6003-6009) and get_graph job 1

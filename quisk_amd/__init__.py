@@ -6,8 +6,8 @@ this package is the thin Python host side that mirrors the reference's own Pytho
 """
 from .lib import load, QuiskHipError          # noqa: F401
 from .rxa import RxaEngine                    # noqa: F401
-from .fir import FirBank, HalfBandCascade, hb45_taps           # noqa: F401
+from .fir import FirBank, HalfBandCascade, RationalFir, hb45_taps           # noqa: F401
 from .pan import Panadapter                   # noqa: F401
 from .qrx import QuiskRxBank                  # noqa: F401
 
-__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "hb45_taps", "Panadapter", "QuiskRxBank"]
+__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "QuiskRxBank"]

@@ -109,3 +109,54 @@ class HalfBandCascade:
             self.close()
         except Exception:
             pass
+
+
+class RationalFir:
+    """quisk_cInterpDecim / quisk_cInterpolate (filter.c:287-324,131-165) for `nch` complex streams (C ABI group
+    3c): interpolate by `interp`, real taps, keep every `decim`-th; gain `interp`.  Two real streams can ride as
+    the real and imaginary parts (quisk_dInterpolate)."""
+
+    def __init__(self, nch, taps, interp, decim=1, dtype=F64, device=0, stream=None):
+        self._L = load()
+        t = np.ascontiguousarray(taps, dtype=np.float64)
+        self._h = self._L.qh_rat_create(device, nch, t.ctypes.data, t.size, interp, decim, dtype, stream)
+        if not self._h:
+            raise QuiskHipError("qh_rat_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch, self.interp, self.decim, self.dtype = nch, interp, decim, dtype
+        self.np_dtype = np.complex128 if dtype == F64 else np.complex64
+
+    def out_count(self, n_in):
+        return self._L.qh_rat_out_count(self._h, n_in)
+
+    @property
+    def phase(self):
+        return self._L.qh_rat_phase(self._h)
+
+    def process_ptr(self, d_in, in_stride, n_in, d_out, out_stride):
+        n = C.c_int(0)
+        check(self._L.qh_rat_process(self._h, d_in, in_stride, n_in, d_out, out_stride, C.byref(n)))
+        return n.value
+
+    def process_host(self, x):
+        x = np.ascontiguousarray(x, dtype=self.np_dtype)
+        if x.ndim != 2 or x.shape[0] != self.nch:
+            raise ValueError("expected [nch, n]")
+        nmax = max(self.out_count(x.shape[1]), 1)
+        out = np.empty((self.nch, nmax), dtype=self.np_dtype)
+        n = C.c_int(0)
+        check(self._L.qh_rat_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1], out.ctypes.data, nmax, C.byref(n)))
+        return out[:, :n.value].copy()
+
+    def reset(self):
+        check(self._L.qh_rat_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_rat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

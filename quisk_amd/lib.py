@@ -72,6 +72,17 @@ def load():
     L.qh_fir_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
     L.qh_fir_process_host.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
     L.qh_fir_synchronize.argtypes = [vp]
+    L.qh_rat_create.restype = vp
+    L.qh_rat_create.argtypes = [i, i, vp, i, i, i, i, vp]
+    L.qh_rat_destroy.argtypes = [vp]
+    L.qh_rat_destroy.restype = None
+    L.qh_rat_reset.argtypes = [vp]
+    L.qh_rat_set_state.argtypes = [vp, vp, i]
+    L.qh_rat_phase.argtypes = [vp]
+    L.qh_rat_out_count.argtypes = [vp, i]
+    L.qh_rat_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_rat_process_host.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_rat_synchronize.argtypes = [vp]
     L.qh_hbc_create.restype = vp
     L.qh_hbc_create.argtypes = [i, i, i, i, vp]
     L.qh_hbc_destroy.argtypes = [vp]
