@@ -294,6 +294,29 @@ int quisk_cDecimate(double *cSamples, int count, struct quisk_cFilter *filter, i
 int quisk_cCDecimate(double *cSamples, int count, struct quisk_cFilter *filter, int decim); /* filter.c:231-257 */
 int quisk_cFilter(double *cSamples, int count, struct quisk_cFilter *filter);               /* filter.c:372-375 */
 int quisk_cDecim2HB45(double *cSamples, int count, struct quisk_cHB45Filter *filter);       /* filter.c:377-417 */
+/* struct quisk_dFilter (filter.h:12-21) has the layout of struct quisk_cFilter; its history ring holds doubles. */
+struct quisk_dHB45Filter {                  /* filter.h:31-37 */
+    double *dBuf;
+    int nBuf;
+    int toggle;
+    double samples[22];
+    double center[11];
+};
+void quisk_filt_dInit(struct quisk_cFilter *filter, double *coefs, int taps);               /* filter.c:22-33 */
+void quisk_filt_differInit(struct quisk_cFilter *filter, int taps);                         /* filter.c:35-56 */
+int quisk_cInterpolate(double *cSamples, int count, struct quisk_cFilter *filter, int interp);      /* filter.c:131-165 */
+int quisk_dInterpolate(double *dSamples, int count, struct quisk_cFilter *filter, int interp);      /* filter.c:167-201 */
+int quisk_cInterpDecim(double *cSamples, int count, struct quisk_cFilter *filter, int interp, int decim);  /* filter.c:287-324 */
+int quisk_dDecimate(double *dSamples, int count, struct quisk_cFilter *filter, int decim);  /* filter.c:259-285 */
+int quisk_dFilter(double *dSamples, int count, struct quisk_cFilter *filter);               /* filter.c:347-370 */
+double quisk_dD_out(double sample, struct quisk_cFilter *filter);                           /* filter.c:326-345 */
+int quisk_cInterp2HB45(double *cSamples, int count, struct quisk_cHB45Filter *filter);      /* filter.c:455-488 */
+int quisk_dInterp2HB45(double *dSamples, int count, struct quisk_dHB45Filter *filter);      /* filter.c:420-453 */
+/* quisk_dC_out (filter.c:83-104) returns `complex double` by value, which C++ cannot spell in an extern "C"
+ * signature; this is the same computation with the result written through a pointer.  A C translation unit
+ * binds the reference's name with:  static inline complex double quisk_dC_out(double s, struct quisk_dFilter *f)
+ * { double o[2]; qh_quisk_dC_out(s, (struct quisk_cFilter *)f, o); return o[0] + I * o[1]; } */
+void qh_quisk_dC_out(double sample, struct quisk_cFilter *filter, double *out_re_im);
 
 #ifdef __cplusplus
 }

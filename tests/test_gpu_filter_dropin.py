@@ -83,3 +83,115 @@ def test_hb45_struct_state_roundtrip(qh, oracle):
         parts.append(call(fn, x[a:b], st2))
     mixed = np.concatenate(parts)
     assert mixed.size == want.size and rel_rms(mixed, want) < 1e-12
+
+
+def call_real(fn, x, st, *args, grow=1):
+    buf = np.zeros(max(len(x) * grow, 1) + 8)
+    buf[:len(x)] = x
+    fn.restype = C.c_int
+    n = fn(buf.ctypes.data_as(C.c_void_p), C.c_int(len(x)), C.byref(st), *[C.c_int(a) for a in args])
+    return buf[:n].copy()
+
+
+def call_grow(fn, x, st, *args, grow=1):
+    buf = np.zeros(max(len(x) * grow, 1) + 8, dtype=np.complex128)
+    buf[:len(x)] = x
+    fn.restype = C.c_int
+    n = fn(buf.ctypes.data_as(C.c_void_p), C.c_int(len(x)), C.byref(st), *[C.c_int(a) for a in args])
+    return buf[:n].copy()
+
+
+CUTS = [0, 700, 701, 1500, 1507, 3000]
+
+
+def alternate(fns, run, st):
+    return np.concatenate([run(fns[i % 2], a, b, st) for i, (a, b) in enumerate(zip(CUTS, CUTS[1:]))])
+
+
+@pytest.mark.parametrize("interp,decim", [(2, 1), (3, 1), (6, 5), (4, 5), (2, 3)])
+def test_cinterpolate_cinterpdecim_struct_state(qh, oracle, interp, decim):
+    lib, ref = qh.load(), oracle.ref_filter_lib()
+    taps = np.ascontiguousarray(np.random.default_rng(interp + decim).standard_normal(120))
+    x = stream(8, 3000)
+    f = oracle.OracleFir(taps)
+    want = f.cInterpolate(x, interp) if decim == 1 else f.cInterpDecim(x, interp, decim)
+    name, args = ("quisk_cInterpolate", (interp,)) if decim == 1 else ("quisk_cInterpDecim", (interp, decim))
+    st = oracle.RefCFilter()
+    lib.quisk_filt_cInit(C.byref(st), taps.ctypes.data_as(c_double_p), C.c_int(120))
+    ours = np.concatenate([call_grow(getattr(lib, name), x[a:b], st, *args, grow=interp) for a, b in zip(CUTS, CUTS[1:])])
+    assert ours.size == want.size and rel_rms(ours, want) < 1e-12
+    if ref is None:
+        pytest.skip("oracle/_ref not present")
+    st2 = oracle.RefCFilter()
+    ref.quisk_filt_cInit(C.byref(st2), taps.ctypes.data_as(c_double_p), C.c_int(120))
+    mixed = alternate([getattr(lib, name), getattr(ref, name)], lambda fn, a, b, s: call_grow(fn, x[a:b], s, *args, grow=interp), st2)
+    assert mixed.size == want.size and rel_rms(mixed, want) < 1e-12
+
+
+def test_real_primitives_struct_state(qh, oracle):
+    lib, ref = qh.load(), oracle.ref_filter_lib()
+    rng = np.random.default_rng(4)
+    taps = np.ascontiguousarray(rng.standard_normal(147))
+    x = rng.standard_normal(3000)
+    for name, args, grow, want in (
+            ("quisk_dDecimate", (3,), 1, oracle.OracleFir(taps, is_complex=False).dDecimate(x, 3)),
+            ("quisk_dFilter", (), 1, oracle.OracleFir(taps, is_complex=False).dFilter(x)),
+            ("quisk_dInterpolate", (3,), 3, oracle.OracleFir(taps, is_complex=False).dInterpolate(x, 3))):
+        st = oracle.RefCFilter()
+        lib.quisk_filt_dInit(C.byref(st), taps.ctypes.data_as(c_double_p), C.c_int(147))
+        ours = np.concatenate([call_real(getattr(lib, name), x[a:b], st, *args, grow=grow) for a, b in zip(CUTS, CUTS[1:])])
+        assert ours.size == want.size and rel_rms(ours, want) < 1e-12, name
+        if ref is not None:
+            st2 = oracle.RefCFilter()
+            ref.quisk_filt_dInit(C.byref(st2), taps.ctypes.data_as(c_double_p), C.c_int(147))
+            mixed = alternate([getattr(ref, name), getattr(lib, name)], lambda fn, a, b, s: call_real(fn, x[a:b], s, *args, grow=grow), st2)
+            assert mixed.size == want.size and rel_rms(mixed, want) < 1e-12, name
+
+
+def test_per_sample_outputs(qh, oracle):
+    """quisk_dD_out and quisk_dC_out: one sample per call (each is one GPU launch -- link compatibility only)."""
+    lib = qh.load()
+    rng = np.random.default_rng(9)
+    taps = np.ascontiguousarray(rng.standard_normal(31))
+    x = rng.standard_normal(40)
+    st = oracle.RefCFilter()
+    lib.quisk_filt_dInit(C.byref(st), taps.ctypes.data_as(c_double_p), C.c_int(31))
+    lib.quisk_dD_out.restype = C.c_double
+    got = np.array([lib.quisk_dD_out(C.c_double(v), C.byref(st)) for v in x])
+    want = oracle.OracleFir(taps, is_complex=False).dFilter(x)
+    assert rel_rms(got, want) < 1e-12
+    st = oracle.RefCFilter()
+    lib.quisk_filt_dInit(C.byref(st), taps.ctypes.data_as(c_double_p), C.c_int(31))
+    lib.quisk_filt_tune.argtypes = [C.c_void_p, C.c_double, C.c_int]
+    lib.quisk_filt_tune(C.byref(st), 0.07, 1)
+    out = (C.c_double * 2)()
+    got = []
+    for v in x:
+        lib.qh_quisk_dC_out(C.c_double(v), C.byref(st), out)
+        got.append(out[0] + 1j * out[1])
+    f = oracle.OracleFir(taps)
+    f.tune(0.07, 1)
+    want = f.cCDecimate(x + 0j, 1)                      # complex taps on a real stream
+    assert rel_rms(np.array(got), want) < 1e-12
+
+
+def test_interp2hb45_struct_state(qh, oracle):
+    lib, ref = qh.load(), oracle.ref_filter_lib()
+    x = stream(10, 3000)
+    want = oracle.OracleHB45().cInterp2(x)
+    st = oracle.RefCHB45()
+    ours = np.concatenate([call_grow(lib.quisk_cInterp2HB45, x[a:b], st, grow=2) for a, b in zip(CUTS, CUTS[1:])])
+    assert ours.size == want.size and rel_rms(ours, want) < 1e-12
+    xr = x.real.copy()
+    wantr = oracle.OracleHB45().dInterp2(xr)
+    st = oracle.RefDHB45()
+    ours = np.concatenate([call_real(lib.quisk_dInterp2HB45, xr[a:b], st, grow=2) for a, b in zip(CUTS, CUTS[1:])])
+    assert ours.size == wantr.size and rel_rms(ours, wantr) < 1e-12
+    if ref is None:
+        pytest.skip("oracle/_ref not present")
+    st2 = oracle.RefCHB45()
+    mixed = alternate([ref.quisk_cInterp2HB45, lib.quisk_cInterp2HB45], lambda fn, a, b, s: call_grow(fn, x[a:b], s, grow=2), st2)
+    assert mixed.size == want.size and rel_rms(mixed, want) < 1e-12
+    st3 = oracle.RefDHB45()
+    mixed = alternate([lib.quisk_dInterp2HB45, ref.quisk_dInterp2HB45], lambda fn, a, b, s: call_real(fn, xr[a:b], s, grow=2), st3)
+    assert mixed.size == wantr.size and rel_rms(mixed, wantr) < 1e-12
