@@ -259,6 +259,20 @@ int qh_qrx_filter_rate(const qh_qrx *r);                                   /* ge
 int qh_qrx_set_tune(qh_qrx *r, int ch, int rx_tune_freq);                   /* set_tune, quisk.c:4702; ch -1 = all */
 int qh_qrx_set_filters(qh_qrx *r, int ch, const double *filtI, const double *filtQ, int size);  /* set_filters, quisk.c:4551 */
 int qh_qrx_out_count(const qh_qrx *r, int n_in);                            /* 48 ksps samples the next call returns */
+/* Every rate and mode of the path: the filters.h tables by name (the last six may be NULL when the sample rate
+ * does not need them: quiskFilt300D5Coefs for rates that land on 50-60 ksps and take the 6/5 x 4/5 stage,
+ * quisk.c:1834-1838; the SDR-IQ tables for 53/111/133/185/370/740/1333 ksps, quisk.c:1732-1768).  `bandwidth` is
+ * set_filters' third argument (quisk.c:4581): DGT-U/L and FDV-U/L filter at decim_rate/8 below 3000 Hz and at
+ * decim_rate otherwise (quisk.c:2089), DGT-IQ is unfiltered from 19000 Hz up (quisk.c:2143).  Modes: rx_mode_type
+ * (quisk.h:55-70) 0..13 except EXT (6, a user plugin); IMD takes the SSB path as in the reference; FDV-U/L stop at
+ * the audio that the reference hands to the codec.  Output rate = qh_qrx_decim_rate() (48000 except SDR-IQ rates);
+ * DGT-IQ output is the filtered IQ stream, every other mode (d, d). */
+typedef struct qh_qrx_tables {
+    const double *f48dec24, *f144d3, *f240d5, *audio24p4, *audio24p6, *lp48, *fmhp;         /* 98 147 245 50 36 186 309 */
+    const double *f300d5, *sdriq53, *sdriq111, *sdriq133, *sdriq167, *sdriq185;             /* 125 55 114 136 174 189 */
+} qh_qrx_tables;
+qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int bandwidth, const qh_qrx_tables *tables, void *stream);
+int qh_qrx_decim_rate(const qh_qrx *r);
 /* d_in [nch][in_stride] complex double at sample_rate, d_out [nch][out_stride] at 48 ksps; any n_in. */
 int qh_qrx_process(qh_qrx *r, const double *d_in, long long in_stride, int n_in, double *d_out, long long out_stride, int *n_out);
 int qh_qrx_process_host(qh_qrx *r, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out);

@@ -386,7 +386,8 @@ class OracleGraph:
 
 
 class QoRxTables(C.Structure):      # oracle/quisk_rx_oracle.h: qo_rx_tables
-    _fields_ = [(n, c_double_p) for n in ("f48dec24", "f144d3", "f240d5", "audio24p4", "audio24p6", "lp48", "fmhp")]
+    _fields_ = [(n, c_double_p) for n in ("f48dec24", "f144d3", "f240d5", "audio24p4", "audio24p6", "lp48", "fmhp",
+                                          "f300d5", "sdriq53", "sdriq111", "sdriq133", "sdriq167", "sdriq185")]
 
 
 class OracleQuiskRx:
@@ -404,16 +405,23 @@ class OracleQuiskRx:
         L.qo_rx_filter_srate.argtypes = [C.c_void_p]
         self.L = L
         keys = ("quiskFilt48dec24Coefs", "quiskFilt144D3Coefs", "quiskFilt240D5CoefsSharp", "quiskAudio24p4Coefs",
-                "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs")
+                "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs", "quiskFilt300D5Coefs",
+                "quiskFilt53D1Coefs", "quiskFilt111D2Coefs", "quiskFilt133D2Coefs", "quiskFilt167D3Coefs",
+                "quiskFilt185D3Coefs")
         self._keep = [np.ascontiguousarray(tables[k], dtype=np.float64) for k in keys]
         self._t = QoRxTables(*[a.ctypes.data_as(c_double_p) for a in self._keep])
         self.h = L.qo_rx_create(sample_rate, C.byref(self._t))
         if not self.h:
-            raise ValueError("sample rate %d does not plan to 48000" % sample_rate)
+            raise ValueError("qo_rx_create failed for rate %d" % sample_rate)
+        L.qo_rx_set_bandwidth.argtypes = [C.c_void_p, C.c_int]
+        L.qo_rx_decim_srate.argtypes = [C.c_void_p]
         self.rate = sample_rate
 
     def set_tune(self, f): self.L.qo_rx_set_tune(self.h, int(f))
     def set_mode(self, m): self.L.qo_rx_set_mode(self.h, int(m))
+    def set_bandwidth(self, bw): self.L.qo_rx_set_bandwidth(self.h, int(bw))
+    def decim_srate(self): return self.L.qo_rx_decim_srate(self.h)
+    def filter_srate(self): return self.L.qo_rx_filter_srate(self.h)
 
     def set_filters(self, fI, fQ):
         fI = np.ascontiguousarray(fI, dtype=np.float64)

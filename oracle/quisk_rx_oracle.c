@@ -9,12 +9,12 @@
 #define FM_FILTER_DEMPH 300.0       /* quisk.c:40 */
 
 struct qo_rx {
-    int sample_rate, decim2, decim3, decim5, decim_srate, filter_srate, mode, tune;
+    int sample_rate, decim2, decim3, decim5, decim_srate, filter_srate, mode, tune, bandwidth;
     qo_rx_tables t;
     double tv_re, tv_im;            /* rxTuneVector, quisk.c:2308 */
     /* quisk_process_decimate storage, quisk.c:1678-1698 */
     qo_hb45 hb[5];
-    qo_fir d3[3], d5[3], d48to24;
+    qo_fir d3[3], d5[3], d48to24, f300d5, d5s, sdriq53, sdriq111, sdriq133, sdriq167, sdriq185;
     /* quisk_process_demodulate storage, quisk.c:1855-1875 */
     qo_hb45 dHB4, dHB5, dHB6, dHB7;
     qo_fir dm48to24, audio24p4, audio12p2, audio24p6, audio48p3, fmhp;
@@ -48,15 +48,10 @@ static int plan_decimation(int rate, int *p2, int *p3, int *p5)     /* quisk.c:1
 
 qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t)
 {
-    int i, d2, d3, d5, try_;
+    int i, d2, d3, d5;
     double www, nnn;
     qo_rx *r;
     plan_decimation(sample_rate, &d2, &d3, &d5);
-    try_ = sample_rate;
-    for (i = 0; i < d2; i++) try_ /= 2;
-    for (i = 0; i < d3; i++) try_ /= 3;
-    for (i = 0; i < d5; i++) try_ /= 5;
-    if (try_ != 48000) return NULL;         /* the 6/5 * 4/5 rational stage (quisk.c:1834-1838) is not restated */
     r = (qo_rx *)calloc(1, sizeof(*r));
     r->sample_rate = sample_rate; r->decim2 = d2; r->decim3 = d3; r->decim5 = d5;
     r->t = *t;
@@ -65,6 +60,12 @@ qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t)
     for (i = 0; i < 5; i++) qo_hb45_init(&r->hb[i]);
     for (i = 0; i < 3; i++) { qo_fir_init(&r->d3[i], t->f144d3, 147, 1); qo_fir_init(&r->d5[i], t->f240d5, 245, 1); }
     qo_fir_init(&r->d48to24, t->f48dec24, 98, 1);
+    qo_fir_init(&r->f300d5, t->f300d5, 125, 1);                 /* quisk.c:1720 */
+    qo_fir_init(&r->d5s, t->f240d5, 245, 1);                    /* filtDecim5S, quisk.c:1717 */
+    qo_fir_init(&r->sdriq53, t->sdriq53, 55, 1); qo_fir_init(&r->sdriq111, t->sdriq111, 114, 1);
+    qo_fir_init(&r->sdriq133, t->sdriq133, 136, 1); qo_fir_init(&r->sdriq167, t->sdriq167, 174, 1);
+    qo_fir_init(&r->sdriq185, t->sdriq185, 189, 1);
+    r->bandwidth = 2700;
     qo_hb45_init(&r->dHB4); qo_hb45_init(&r->dHB5); qo_hb45_init(&r->dHB6); qo_hb45_init(&r->dHB7);
     qo_fir_init(&r->dm48to24, t->f48dec24, 98, 1);
     qo_fir_init(&r->audio24p4, t->audio24p4, 50, 0);
@@ -89,6 +90,8 @@ void qo_rx_free(qo_rx *r)
     int i;
     if (!r) return;
     for (i = 0; i < 3; i++) { qo_fir_free(&r->d3[i]); qo_fir_free(&r->d5[i]); }
+    qo_fir_free(&r->f300d5); qo_fir_free(&r->d5s); qo_fir_free(&r->sdriq53); qo_fir_free(&r->sdriq111);
+    qo_fir_free(&r->sdriq133); qo_fir_free(&r->sdriq167); qo_fir_free(&r->sdriq185);
     qo_fir_free(&r->d48to24); qo_fir_free(&r->dm48to24); qo_fir_free(&r->audio24p4); qo_fir_free(&r->audio12p2);
     qo_fir_free(&r->audio24p6); qo_fir_free(&r->audio48p3); qo_fir_free(&r->fmhp);
     free(r->filtI); free(r->filtQ); free(r->bufI); free(r->bufQ); free(r->bufC); free(r->dsamples);
@@ -97,6 +100,7 @@ void qo_rx_free(qo_rx *r)
 
 void qo_rx_set_tune(qo_rx *r, int f) { r->tune = f; }
 void qo_rx_set_mode(qo_rx *r, int mode) { r->mode = mode; }
+void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
 
 void qo_rx_set_filters(qo_rx *r, const double *fI, const double *fQ, int size)
 {
@@ -141,16 +145,62 @@ static void dRxFilterOut(qo_rx *r, double re, double im, double *ore, double *oi
     *ore = ar; *oim = ai;
 }
 
-static int process_decimate(qo_rx *r, double *x, int n)        /* quisk.c:1769-1843 */
+static int process_decimate(qo_rx *r, double *x, int n)        /* quisk.c:1729-1843 */
 {
     int i2 = r->decim2, i3 = r->decim3, i5 = r->decim5, k = 0;
-    r->decim_srate = r->sample_rate;
-    while (i2 > 1 && k < 5) { n = qo_cDecim2HB45(x, n, &r->hb[k++]); r->decim_srate /= 2; i2--; }
-    k = 0;
-    while (i3 > 0) { n = qo_cDecimate(x, n, &r->d3[k++], 3); r->decim_srate /= 3; i3--; }
-    k = 0;
-    while (i5 > 0) { n = qo_cDecimate(x, n, &r->d5[k++], 5); r->decim_srate /= 5; i5--; }
-    if (i2 > 0) { n = qo_cDecimate(x, n, &r->d48to24, 2); r->decim_srate /= 2; i2--; }
+    switch ((r->sample_rate + 100) / 1000) {
+    case 41:
+        r->decim_srate = 48000;
+        break;
+    case 53:
+        r->decim_srate = r->sample_rate;
+        n = qo_cDecimate(x, n, &r->sdriq53, 1);
+        break;
+    case 111:
+        r->decim_srate = r->sample_rate / 2;
+        n = qo_cDecimate(x, n, &r->sdriq111, 2);
+        break;
+    case 133:
+        r->decim_srate = r->sample_rate / 2;
+        n = qo_cDecimate(x, n, &r->sdriq133, 2);
+        break;
+    case 185:
+        r->decim_srate = r->sample_rate / 3;
+        n = qo_cDecimate(x, n, &r->sdriq185, 3);
+        break;
+    case 370:
+        r->decim_srate = r->sample_rate / 6;
+        n = qo_cDecim2HB45(x, n, &r->hb[1]);
+        n = qo_cDecimate(x, n, &r->sdriq185, 3);
+        break;
+    case 740:
+        r->decim_srate = r->sample_rate / 12;
+        n = qo_cDecim2HB45(x, n, &r->hb[1]);
+        n = qo_cDecim2HB45(x, n, &r->hb[2]);
+        n = qo_cDecimate(x, n, &r->sdriq185, 3);
+        break;
+    case 1333:
+        r->decim_srate = r->sample_rate / 24;
+        n = qo_cDecim2HB45(x, n, &r->hb[0]);
+        n = qo_cDecim2HB45(x, n, &r->hb[1]);
+        n = qo_cDecim2HB45(x, n, &r->hb[2]);
+        n = qo_cDecimate(x, n, &r->sdriq167, 3);
+        break;
+    default:
+        r->decim_srate = r->sample_rate;
+        while (i2 > 1 && k < 5) { n = qo_cDecim2HB45(x, n, &r->hb[k++]); r->decim_srate /= 2; i2--; }
+        k = 0;
+        while (i3 > 0) { n = qo_cDecimate(x, n, &r->d3[k++], 3); r->decim_srate /= 3; i3--; }
+        k = 0;
+        while (i5 > 0) { n = qo_cDecimate(x, n, &r->d5[k++], 5); r->decim_srate /= 5; i5--; }
+        if (i2 > 0) { n = qo_cDecimate(x, n, &r->d48to24, 2); r->decim_srate /= 2; i2--; }
+        if (r->decim_srate >= 50000) {                          /* quisk.c:1834-1838 */
+            r->decim_srate = r->decim_srate * 24 / 25;
+            n = qo_cInterpDecim(x, n, &r->f300d5, 6, 5);
+            n = qo_cInterpDecim(x, n, &r->d5s, 4, 5);
+        }
+        break;
+    }
     return n;
 }
 
@@ -197,7 +247,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
         n = qo_dFilter(ds, n, &r->audio24p6);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
         break;
-    case QO_FM:
+    case QO_FM: case QO_DGT_FM:
         r->filter_srate = r->decim_srate;
         for (i = 0; i < n; i++) {
             double pr, pi;
@@ -218,6 +268,30 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
         n = qo_dFilter(ds, n, &r->fmhp);
         n = qo_dInterp2HB45(ds, n, &r->dHB6);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        break;
+    case QO_DGT_U: case QO_FDV_U: case QO_DGT_L: case QO_FDV_L:         /* quisk.c:2087-2140 */
+        if (r->bandwidth < 3000) {                                       /* DGT_NARROW_FREQ, quisk.c:52 */
+            r->filter_srate = r->decim_srate / 8;
+            n = qo_cDecim2HB45(x, n, &r->dHB5);
+            n = qo_cDecim2HB45(x, n, &r->dHB4);
+            n = qo_cDecimate(x, n, &r->dm48to24, 2);
+        } else {
+            r->filter_srate = r->decim_srate;
+        }
+        for (i = 0; i < n; i++) {
+            cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
+            ds[i] = (r->mode == QO_DGT_L || r->mode == QO_FDV_L) ? re + im : re - im;
+        }
+        if (r->bandwidth < 3000) {
+            n = qo_dInterpolate(ds, n, &r->audio12p2, 2);
+            n = qo_dInterp2HB45(ds, n, &r->dHB6);
+            n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        }
+        break;
+    case QO_DGT_IQ:                                                      /* quisk.c:2141-2153 */
+        r->filter_srate = r->decim_srate;
+        if (r->bandwidth < 19000)
+            for (i = 0; i < n; i++) dRxFilterOut(r, x[2 * i], x[2 * i + 1], &x[2 * i], &x[2 * i + 1]);
         break;
     }
     return n;
@@ -242,6 +316,7 @@ int qo_rx_process(qo_rx *r, double *x, int n)
     }
     n = process_decimate(r, x, n);
     n = process_demodulate(r, x, r->dsamples, n);
-    for (i = 0; i < n; i++) { x[2 * i] = r->dsamples[i]; x[2 * i + 1] = r->dsamples[i]; }     /* quisk.c:2622-2627 */
+    if (r->mode != QO_DGT_IQ)                                   /* "This mode is already stereo", quisk.c:2534 */
+        for (i = 0; i < n; i++) { x[2 * i] = r->dsamples[i]; x[2 * i + 1] = r->dsamples[i]; }     /* quisk.c:2622-2627 */
     return n;
 }

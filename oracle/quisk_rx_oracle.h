@@ -1,8 +1,9 @@
 /* quisk_rx_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
  * CPU restatement of the receive path of quisk_process_samples (quisk.c:2289-2742) for one receiver (bank 0):
- *   NCO tune (quisk.c:2477-2488) -> quisk_process_decimate (quisk.c:1673-1846, the PlanDecimation branch)
- *   -> quisk_process_demodulate (quisk.c:1848-2160: CWL/CWU/LSB/USB/AM/FM) with cRxFilterOut / dRxFilterOut
+ *   NCO tune (quisk.c:2477-2488) -> quisk_process_decimate (quisk.c:1673-1846: the SDR-IQ rates, the PlanDecimation
+ *   branch and its 6/5 x 4/5 rational stage) -> quisk_process_demodulate (quisk.c:1848-2160: CWL/CWU/LSB/USB/AM/FM/
+ *   DGT-U/DGT-L/DGT-IQ/DGT-FM; IMD, FDV-U/L up to the audio, i.e. without the codec) with cRxFilterOut / dRxFilterOut
  *   (quisk.c:1182-1256) -> mono to both channels (quisk.c:2622-2627).
  * Stops before process_agc; squelch, auto-notch, noise blanker, test tone and key-down
  * handling are off, as they are by default.  The stages call the filter.c restatement (quisk_oracle.c), which is
@@ -15,7 +16,8 @@
 extern "C" {
 #endif
 
-enum { QO_CWL = 0, QO_CWU, QO_LSB, QO_USB, QO_AM, QO_FM };     /* rx_mode_type, quisk.h:55-70 */
+enum { QO_CWL = 0, QO_CWU, QO_LSB, QO_USB, QO_AM, QO_FM, QO_EXT, QO_DGT_U, QO_DGT_L, QO_DGT_IQ, QO_IMD, QO_FDV_U,
+       QO_FDV_L, QO_DGT_FM };                                   /* rx_mode_type, quisk.h:55-70 */
 
 typedef struct {                /* the filters.h tables the path uses */
     const double *f48dec24;     /* quiskFilt48dec24Coefs[98]      */
@@ -25,10 +27,17 @@ typedef struct {                /* the filters.h tables the path uses */
     const double *audio24p6;    /* quiskAudio24p6Coefs[36]        */
     const double *lp48;         /* quiskLpFilt48Coefs[186]        */
     const double *fmhp;         /* quiskAudioFmHpCoefs[309]       */
+    const double *f300d5;       /* quiskFilt300D5Coefs[125]       (6/5 stage, quisk.c:1836)      */
+    const double *sdriq53;      /* quiskFilt53D1Coefs[55]         (SDR-IQ rates, quisk.c:1706-1710) */
+    const double *sdriq111;     /* quiskFilt111D2Coefs[114]       */
+    const double *sdriq133;     /* quiskFilt133D2Coefs[136]       */
+    const double *sdriq167;     /* quiskFilt167D3Coefs[174]       */
+    const double *sdriq185;     /* quiskFilt185D3Coefs[189]       */
 } qo_rx_tables;
 
 typedef struct qo_rx qo_rx;
-qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t);    /* NULL when the rate does not plan to 48000 */
+qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t);
+void qo_rx_set_bandwidth(qo_rx *r, int bw);                     /* filter_bandwidth[0], third argument of set_filters */
 void qo_rx_free(qo_rx *r);
 void qo_rx_set_tune(qo_rx *r, int rx_tune_freq);                /* set_tune, quisk.c:4702 */
 void qo_rx_set_mode(qo_rx *r, int mode);                        /* set_rx_mode, quisk.c:4621 */

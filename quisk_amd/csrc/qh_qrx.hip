@@ -17,8 +17,10 @@
 
 namespace qh {
 
-enum { Q_CWL = 0, Q_CWU, Q_LSB, Q_USB, Q_AM, Q_FM };    // rx_mode_type, quisk.h:55-70
+// rx_mode_type, quisk.h:55-70
+enum { Q_CWL = 0, Q_CWU, Q_LSB, Q_USB, Q_AM, Q_FM, Q_EXT, Q_DGT_U, Q_DGT_L, Q_DGT_IQ, Q_IMD, Q_FDV_U, Q_FDV_L, Q_DGT_FM };
 static constexpr int kMaxEqTaps = 2049;
+static constexpr int kDgtNarrowFreq = 3000;     // DGT_NARROW_FREQ, quisk.c:52
 
 struct FirStageSpec { std::vector<double> h; int decim; };
 
@@ -64,15 +66,28 @@ static std::vector<double> dinterp_taps(const double *h, int ntaps, int interp)
     return g;
 }
 
+// mode classes of quisk_process_demodulate (quisk.c:1906-2153); modes without a case of their own take the SSB path
+static bool is_cw(int m) { return m == Q_CWL || m == Q_CWU; }
+static bool is_am(int m) { return m == Q_AM; }
+static bool is_fm(int m) { return m == Q_FM || m == Q_DGT_FM; }
+static bool is_dgt(int m) { return m == Q_DGT_U || m == Q_DGT_L || m == Q_FDV_U || m == Q_FDV_L; }
+static bool is_iq(int m) { return m == Q_DGT_IQ; }
+static bool is_ssb(int m) { return !is_cw(m) && !is_am(m) && !is_fm(m) && !is_dgt(m) && !is_iq(m); }
+static bool lower(int m) { return m == Q_CWL || m == Q_LSB || m == Q_DGT_L || m == Q_FDV_L; }     // re + im
+static bool sideband(int m) { return is_cw(m) || is_ssb(m) || is_dgt(m); }                          // cRxFilterOut, re -+ im
+
+struct Step {
+    enum Kind { FIR, RAT, AM_ENV, FM_DISC } kind;
+    Stage *st = nullptr;
+    qh_rat *rat = nullptr;
+};
+
 struct Qrx {
-    int device = 0, nch = 0, sample_rate = 0, mode = Q_USB, decim_srate = 0, filter_srate = 0;
+    int device = 0, nch = 0, sample_rate = 0, mode = Q_USB, bandwidth = 2700, decim_srate = 0, filter_srate = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    std::vector<Stage *> dec;       // equivalent decimators; dec[0] carries the NCO
-    Stage *rxf = nullptr;           // Rx filter (per-channel taps)
-    Stage *post = nullptr;          // FM only: 186-tap /4 + 309-tap high-pass as one decimator
-    Stage *up = nullptr;            // equivalent interpolator to 48 ksps, output (d, d)
-    std::vector<int> rx_size;       // sizeFilter per channel (0 = pass through like the reference)
+    std::vector<Step> steps;        // in order; steps[0] is an overlap-save stage that carries the NCO
+    Stage *rxf = nullptr;           // Rx filter (per-channel taps); owned by its step
     double *dc_state = nullptr;     // AM
     double4 *fm_state = nullptr;    // FM
     QFmParam fm_prm{};
@@ -83,83 +98,19 @@ struct Qrx {
     {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (Stage *s : dec) { s->destroy(); delete s; }
-        for (Stage *s : { rxf, post, up }) if (s) { s->destroy(); delete s; }
+        for (Step &s : steps) {
+            if (s.st) { s.st->destroy(); delete s.st; }
+            if (s.rat) qh_rat_destroy(s.rat);
+        }
         (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
-};
 
-}  // namespace qh
-
-using namespace qh;
-struct qh_qrx { Qrx q; };
-
-extern "C" {
-
-qh_qrx *qh_qrx_create(int device, int nch, int sample_rate, int mode, const double *f48dec24, const double *f144d3,
-                      const double *f240d5, const double *audio24p4, const double *audio24p6, const double *lp48,
-                      const double *fmhp, void *stream)
-{
-    if (nch <= 0 || sample_rate <= 0 || mode < Q_CWL || mode > Q_FM || !f48dec24 || !f144d3 || !f240d5 || !audio24p4 ||
-        !audio24p6 || !lp48 || !fmhp) {
-        set_error(QH_ERR_INVALID, "qh_qrx_create: bad arguments");
-        return nullptr;
-    }
-    // PlanDecimation, quisk.c:1633-1671
-    int best = sample_rate, d2 = 0, d3 = 0, d5 = 0;
-    for (int i2 = 0; i2 <= 6; i2++)
-        for (int i3 = 0; i3 <= 3; i3++)
-            for (int i5 = 0; i5 <= 3; i5++) {
-                int t = sample_rate;
-                for (int i = 0; i < i2; i++) t /= 2;
-                for (int i = 0; i < i3; i++) t /= 3;
-                for (int i = 0; i < i5; i++) t /= 5;
-                if (t >= 48000 && t < best) { d2 = i2; d3 = i3; d5 = i5; best = t; }
-            }
+    // greedy grouping of consecutive FIR decimators into equivalent ones of at most kMaxEqTaps taps
+    int add_groups(const std::vector<FirStageSpec> &st, bool nco, bool even_if_empty)
     {
-        int t = sample_rate;
-        for (int i = 0; i < d2; i++) t /= 2;
-        for (int i = 0; i < d3; i++) t /= 3;
-        for (int i = 0; i < d5; i++) t /= 5;
-        if (t != 48000) {
-            set_error(QH_ERR_UNSUPPORTED, "sample rate %d does not decimate to 48000 by 2, 3 and 5 (the 6/5 x 4/5 stage is not provided)", sample_rate);
-            return nullptr;
-        }
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-        set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
-        return nullptr;
-    }
-    qh_qrx *h = new qh_qrx();
-    Qrx &q = h->q;
-    q.device = device; q.nch = nch; q.sample_rate = sample_rate; q.mode = mode; q.decim_srate = 48000;
-    q.rx_size.assign((size_t)nch, 0);
-    auto fail = [&]() -> qh_qrx * { delete h; return nullptr; };
-    if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); return fail(); }
-    q.stream = (hipStream_t)stream;
-    if (!q.stream) {
-        if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess) { set_error(QH_ERR_HIP, "stream creation failed"); return fail(); }
-        q.own_stream = true;
-    }
-    // ---- the reference's decimating stages in order (quisk.c:1769-1833, then the mode's front end 1906-2030)
-    std::vector<FirStageSpec> st;
-    const std::vector<double> hb = hb45_dec_taps();
-    const std::vector<double> v48(f48dec24, f48dec24 + 98), v3(f144d3, f144d3 + 147), v5(f240d5, f240d5 + 245);
-    for (int i = 0; i < d2 - 1 && i < 5; i++) st.push_back({ hb, 2 });
-    for (int i = 0; i < d3; i++) st.push_back({ v3, 3 });
-    for (int i = 0; i < d5; i++) st.push_back({ v5, 5 });
-    if (d2 > 0) st.push_back({ v48, 2 });
-    switch (mode) {
-    case Q_CWL: case Q_CWU: q.filter_srate = 6000;  st.push_back({ hb, 2 }); st.push_back({ hb, 2 }); st.push_back({ v48, 2 }); break;
-    case Q_LSB: case Q_USB: q.filter_srate = 12000; st.push_back({ hb, 2 }); st.push_back({ v48, 2 }); break;
-    case Q_AM:              q.filter_srate = 24000; st.push_back({ v48, 2 }); break;
-    default:                q.filter_srate = 48000; break;
-    }
-    // ---- greedy grouping into equivalent decimators of at most kMaxEqTaps taps
-    std::vector<FirStageSpec> groups;
-    {
+        if (st.empty() && !even_if_empty) return QH_OK;
+        std::vector<FirStageSpec> groups;
         std::vector<double> heq(1, 1.0);
         int deq = 1;
         for (const FirStageSpec &s : st) {
@@ -171,64 +122,191 @@ qh_qrx *qh_qrx_create(int device, int nch, int sample_rate, int mode, const doub
             heq = conv(heq, upsample(s.h, deq));
             deq *= s.decim;
         }
-        groups.push_back({ heq, deq });         // possibly the identity (FM at 48 ksps): still carries the NCO
+        groups.push_back({ heq, deq });         // possibly the identity: it still carries the NCO
+        for (size_t g = 0; g < groups.size(); g++) {
+            Step step;
+            step.kind = Step::FIR;
+            step.st = new Stage();
+            steps.push_back(step);
+            if (int rc = step.st->init(device, nch, (int)groups[g].h.size(), groups[g].decim, 1, QH_F64, nco && g == 0, false, false, stream)) return rc;
+            std::vector<cd> taps(groups[g].h.size());
+            for (size_t i = 0; i < taps.size(); i++) taps[i] = cd(groups[g].h[i], 0.0);
+            if (int rc = step.st->set_taps(-1, taps)) return rc;
+        }
+        return QH_OK;
     }
-    for (size_t g = 0; g < groups.size(); g++) {
-        Stage *s = new Stage();
-        q.dec.push_back(s);
-        if (s->init(device, nch, (int)groups[g].h.size(), groups[g].decim, 1, QH_F64, g == 0, false, false, q.stream)) return fail();
-        std::vector<cd> taps(groups[g].h.size());
-        for (size_t i = 0; i < taps.size(); i++) taps[i] = cd(groups[g].h[i], 0.0);
-        if (s->set_taps(-1, taps)) return fail();
+
+    int add_rat(const double *taps, int ntaps, int interp, int decim)
+    {
+        Step step;
+        step.kind = Step::RAT;
+        step.rat = qh_rat_create(device, nch, taps, (ntaps / interp) * interp, interp, decim, QH_F64, stream);   // filter.c:308
+        if (!step.rat) return QH_ERR_HIP;
+        steps.push_back(step);
+        return QH_OK;
+    }
+
+    cd rx_identity() const      // sizeFilter == 0: c/dRxFilterOut return the sample itself (quisk.c:1201,1239)
+    {
+        if (!sideband(mode)) return cd(1.0, 0.0);
+        return lower(mode) ? cd(1.0, -1.0) : cd(1.0, 1.0);
+    }
+};
+
+}  // namespace qh
+
+using namespace qh;
+struct qh_qrx { Qrx q; };
+
+extern "C" {
+
+qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int bandwidth, const qh_qrx_tables *t, void *stream)
+{
+    if (nch <= 0 || sample_rate <= 0 || mode < Q_CWL || mode > Q_DGT_FM || !t || !t->f48dec24 || !t->f144d3 || !t->f240d5 ||
+        !t->audio24p4 || !t->audio24p6 || !t->lp48 || !t->fmhp) {
+        set_error(QH_ERR_INVALID, "qh_qrx_create: bad arguments");
+        return nullptr;
+    }
+    if (mode == Q_EXT) {
+        set_error(QH_ERR_UNSUPPORTED, "mode EXT hands the samples to a user plugin (quisk_extern_demod, quisk.c:2490) and has no GPU form");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
+        return nullptr;
+    }
+    qh_qrx *h = new qh_qrx();
+    Qrx &q = h->q;
+    q.device = device; q.nch = nch; q.sample_rate = sample_rate; q.mode = mode; q.bandwidth = bandwidth;
+    auto fail = [&]() -> qh_qrx * { delete h; return nullptr; };
+    if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); return fail(); }
+    q.stream = (hipStream_t)stream;
+    if (!q.stream) {
+        if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess) { set_error(QH_ERR_HIP, "stream creation failed"); return fail(); }
+        q.own_stream = true;
+    }
+    // ---- quisk_process_decimate (quisk.c:1729-1843)
+    std::vector<FirStageSpec> st;
+    const std::vector<double> hb = hb45_dec_taps();
+    const std::vector<double> v48(t->f48dec24, t->f48dec24 + 98), v3(t->f144d3, t->f144d3 + 147), v5(t->f240d5, t->f240d5 + 245);
+    bool rational = false;
+    auto need = [&](const double *p, const char *name) {
+        if (!p) set_error(QH_ERR_INVALID, "sample rate %d needs the table %s", sample_rate, name);
+        return p != nullptr;
+    };
+    switch ((sample_rate + 100) / 1000) {
+    case 41: q.decim_srate = 48000; break;
+    case 53:
+        if (!need(t->sdriq53, "quiskFilt53D1Coefs")) return fail();
+        q.decim_srate = sample_rate; st.push_back({ std::vector<double>(t->sdriq53, t->sdriq53 + 55), 1 }); break;
+    case 111:
+        if (!need(t->sdriq111, "quiskFilt111D2Coefs")) return fail();
+        q.decim_srate = sample_rate / 2; st.push_back({ std::vector<double>(t->sdriq111, t->sdriq111 + 114), 2 }); break;
+    case 133:
+        if (!need(t->sdriq133, "quiskFilt133D2Coefs")) return fail();
+        q.decim_srate = sample_rate / 2; st.push_back({ std::vector<double>(t->sdriq133, t->sdriq133 + 136), 2 }); break;
+    case 185: case 370: case 740:
+        if (!need(t->sdriq185, "quiskFilt185D3Coefs")) return fail();
+        q.decim_srate = sample_rate / 3;
+        for (int k = (sample_rate + 100) / 1000; k > 185; k /= 2) { st.push_back({ hb, 2 }); q.decim_srate /= 2; }
+        st.push_back({ std::vector<double>(t->sdriq185, t->sdriq185 + 189), 3 }); break;
+    case 1333:
+        if (!need(t->sdriq167, "quiskFilt167D3Coefs")) return fail();
+        q.decim_srate = sample_rate / 24;
+        for (int k = 0; k < 3; k++) st.push_back({ hb, 2 });
+        st.push_back({ std::vector<double>(t->sdriq167, t->sdriq167 + 174), 3 }); break;
+    default: {
+        // PlanDecimation, quisk.c:1633-1671
+        int best = sample_rate, d2 = 0, d3 = 0, d5 = 0;
+        for (int i2 = 0; i2 <= 6; i2++)
+            for (int i3 = 0; i3 <= 3; i3++)
+                for (int i5 = 0; i5 <= 3; i5++) {
+                    int r = sample_rate;
+                    for (int i = 0; i < i2; i++) r /= 2;
+                    for (int i = 0; i < i3; i++) r /= 3;
+                    for (int i = 0; i < i5; i++) r /= 5;
+                    if (r >= 48000 && r < best) { d2 = i2; d3 = i3; d5 = i5; best = r; }
+                }
+        q.decim_srate = best;
+        for (int i = 0; i < d2 - 1 && i < 5; i++) st.push_back({ hb, 2 });
+        for (int i = 0; i < d3; i++) st.push_back({ v3, 3 });
+        for (int i = 0; i < d5; i++) st.push_back({ v5, 5 });
+        if (d2 > 0) st.push_back({ v48, 2 });
+        if (q.decim_srate >= 50000) {           // 6/5 then 4/5, quisk.c:1834-1838
+            if (!need(t->f300d5, "quiskFilt300D5Coefs")) return fail();
+            rational = true;
+            q.decim_srate = q.decim_srate * 24 / 25;
+        }
+        break;
+    }
+    }
+    // ---- the mode's own decimators in front of the Rx filter (quisk.c:1906-2030,2087-2126)
+    std::vector<FirStageSpec> fe;
+    const bool dgt_narrow = is_dgt(mode) && bandwidth < kDgtNarrowFreq;
+    if (is_cw(mode) || dgt_narrow) { q.filter_srate = q.decim_srate / 8; fe.push_back({ hb, 2 }); fe.push_back({ hb, 2 }); fe.push_back({ v48, 2 }); }
+    else if (is_ssb(mode))         { q.filter_srate = q.decim_srate / 4; fe.push_back({ hb, 2 }); fe.push_back({ v48, 2 }); }
+    else if (is_am(mode))          { q.filter_srate = q.decim_srate / 2; fe.push_back({ v48, 2 }); }
+    else                           { q.filter_srate = q.decim_srate; }
+    if (rational) {
+        if (q.add_groups(st, true, true)) return fail();
+        if (q.add_rat(t->f300d5, 125, 6, 5) || q.add_rat(t->f240d5, 245, 4, 5)) return fail();
+        if (q.add_groups(fe, false, false)) return fail();
+    } else {
+        st.insert(st.end(), fe.begin(), fe.end());
+        if (q.add_groups(st, true, true)) return fail();
     }
     // ---- Rx filter: per-channel taps, up to 2048; identity until set_filters is called (sizeFilter == 0)
-    q.rxf = new Stage();
-    const bool real_out = mode <= Q_USB;
-    if (q.rxf->init(device, nch, 2048, 1, 1, QH_F64, false, true, real_out, q.stream)) return fail();
-    // sizeFilter == 0: c/dRxFilterOut return the sample itself (quisk.c:1201,1239), so SSB/CW give re -+ im
+    const bool direct_out = (is_dgt(mode) && !dgt_narrow) || is_iq(mode);       // nothing follows the Rx filter
     {
-        cd id(1.0, 0.0);
-        if (mode == Q_CWU || mode == Q_USB) id = cd(1.0, 1.0);
-        if (mode == Q_CWL || mode == Q_LSB) id = cd(1.0, -1.0);
-        if (q.rxf->set_taps(-1, std::vector<cd>(1, id))) return fail();
+        Step step;
+        step.kind = Step::FIR;
+        step.st = q.rxf = new Stage();
+        q.steps.push_back(step);
+        if (q.rxf->init(device, nch, 2048, 1, 1, QH_F64, false, true, sideband(mode), q.stream)) return fail();
+        if (q.rxf->set_taps(-1, std::vector<cd>(1, q.rx_identity()))) return fail();
+        if (sideband(mode))
+            for (int c = 0; c < nch; c++)       // re -+ im collapses to the real part; (d, d) when it is the last stage (quisk.c:2625)
+                if (q.rxf->set_epi(c, direct_out ? EpiParam{ 1, 0, 1, 0 } : EpiParam{ 1, 0, 0, 0 })) return fail();
     }
-    // ---- back to 48 ksps
+    // ---- detector and the way back to decim_srate
     const std::vector<double> g45 = hb45_interp_taps();
     std::vector<double> ueq;
     int U = 1;
-    if (mode == Q_CWL || mode == Q_CWU) {           // dInterpolate(Audio24p4 table, 2), HB45, HB45 (quisk.c:1930-1932)
-        ueq = conv(conv(upsample(dinterp_taps(audio24p4, 50, 2), 4), upsample(g45, 2)), g45); U = 8;
-    } else if (mode == Q_LSB || mode == Q_USB) {    // dInterpolate(Audio24p4, 2), HB45 (quisk.c:1975-1976)
-        ueq = conv(upsample(dinterp_taps(audio24p4, 50, 2), 2), g45); U = 4;
-    } else if (mode == Q_AM) {                      // dFilter(Audio24p6), HB45 (quisk.c:2017,2024)
-        ueq = conv(upsample(std::vector<double>(audio24p6, audio24p6 + 36), 2), g45); U = 2;
-    } else {                                        // FM: HB45, HB45 after the /4 (quisk.c:2067-2068)
+    if (is_cw(mode) || dgt_narrow) {                // dInterpolate(Audio24p4 table, 2), HB45, HB45 (quisk.c:1930-1932,2108-2112)
+        ueq = conv(conv(upsample(dinterp_taps(t->audio24p4, 50, 2), 4), upsample(g45, 2)), g45); U = 8;
+    } else if (is_ssb(mode)) {                      // dInterpolate(Audio24p4, 2), HB45 (quisk.c:1975-1976)
+        ueq = conv(upsample(dinterp_taps(t->audio24p4, 50, 2), 2), g45); U = 4;
+    } else if (is_am(mode)) {                       // dFilter(Audio24p6), HB45 (quisk.c:2017,2024)
+        Step det; det.kind = Step::AM_ENV; q.steps.push_back(det);
+        ueq = conv(upsample(std::vector<double>(t->audio24p6, t->audio24p6 + 36), 2), g45); U = 2;
+    } else if (is_fm(mode)) {                       // HB45, HB45 after the /4 (quisk.c:2067-2068)
+        Step det; det.kind = Step::FM_DISC; q.steps.push_back(det);
         ueq = conv(upsample(g45, 2), g45); U = 4;
         // dDecimate(LpFilt48, 4) then dFilter(AudioFmHp) (quisk.c:2065-2066) as one decimator
-        std::vector<double> p = conv(std::vector<double>(lp48, lp48 + 186), upsample(std::vector<double>(fmhp, fmhp + 309), 4));
-        q.post = new Stage();
-        if (q.post->init(device, nch, (int)p.size(), 4, 1, QH_F64, false, false, false, q.stream)) return fail();
-        std::vector<cd> taps(p.size());
-        for (size_t i = 0; i < p.size(); i++) taps[i] = cd(p[i], 0.0);
-        if (q.post->set_taps(-1, taps)) return fail();
+        std::vector<FirStageSpec> post;
+        post.push_back({ std::vector<double>(t->lp48, t->lp48 + 186), 4 });
+        post.push_back({ std::vector<double>(t->fmhp, t->fmhp + 309), 1 });
+        if (q.add_groups(post, false, false)) return fail();
     }
-    q.up = new Stage();
-    if (q.up->init(device, nch, (int)ueq.size(), 1, U, QH_F64, false, false, true, q.stream)) return fail();
-    {
+    if (U > 1) {
+        Step step;
+        step.kind = Step::FIR;
+        step.st = new Stage();
+        q.steps.push_back(step);
+        if (step.st->init(device, nch, (int)ueq.size(), 1, U, QH_F64, false, false, true, q.stream)) return fail();
         std::vector<cd> taps(ueq.size());
         for (size_t i = 0; i < taps.size(); i++) taps[i] = cd(ueq[i], 0.0);
-        if (q.up->set_taps(-1, taps)) return fail();
-        for (int c = 0; c < nch; c++) {
-            if (q.up->set_epi(c, EpiParam{ 1, 0, 1, 0 })) return fail();                    // d + I*d, quisk.c:2625
-            if (real_out && q.rxf->set_epi(c, EpiParam{ 1, 0, 0, 0 })) return fail();       // re -+ im collapses to the real part
-        }
+        if (step.st->set_taps(-1, taps)) return fail();
+        for (int c = 0; c < nch; c++)
+            if (step.st->set_epi(c, EpiParam{ 1, 0, 1, 0 })) return fail();                 // d + I*d, quisk.c:2625
     }
-    if (mode == Q_AM) {
+    if (is_am(mode)) {
         if (hipMalloc((void **)&q.dc_state, (size_t)nch * 8) != hipSuccess || hipMemset(q.dc_state, 0, (size_t)nch * 8) != hipSuccess) {
             set_error(QH_ERR_HIP, "allocation failed"); return fail();
         }
     }
-    if (mode == Q_FM) {
+    if (is_fm(mode)) {
         std::vector<double4> init((size_t)nch, make_double4(10.0, 0.0, 0.0, 0.0));          // fm_1 = 10, quisk.c:1893
         if (hipMalloc((void **)&q.fm_state, (size_t)nch * sizeof(double4)) != hipSuccess ||
             hipMemcpy(q.fm_state, init.data(), (size_t)nch * sizeof(double4), hipMemcpyHostToDevice) != hipSuccess) {
@@ -241,6 +319,16 @@ qh_qrx *qh_qrx_create(int device, int nch, int sample_rate, int mode, const doub
     return h;
 }
 
+qh_qrx *qh_qrx_create(int device, int nch, int sample_rate, int mode, const double *f48dec24, const double *f144d3,
+                      const double *f240d5, const double *audio24p4, const double *audio24p6, const double *lp48,
+                      const double *fmhp, void *stream)
+{
+    qh_qrx_tables t{};
+    t.f48dec24 = f48dec24; t.f144d3 = f144d3; t.f240d5 = f240d5; t.audio24p4 = audio24p4; t.audio24p6 = audio24p6;
+    t.lp48 = lp48; t.fmhp = fmhp;
+    return qh_qrx_create_ex(device, nch, sample_rate, mode, 2700, &t, stream);
+}
+
 void qh_qrx_destroy(qh_qrx *h) { delete h; }
 int qh_qrx_filter_rate(const qh_qrx *h) { return h ? h->q.filter_srate : 0; }
 
@@ -251,7 +339,7 @@ int qh_qrx_set_tune(qh_qrx *h, int ch, int rx_tune_freq)
     Qrx &q = h->q;
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
     for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? q.nch : ch + 1); c++)
-        if (int rc = q.dec[0]->set_nco(c, -(double)rx_tune_freq, (double)q.sample_rate)) return rc;
+        if (int rc = q.steps[0].st->set_nco(c, -(double)rx_tune_freq, (double)q.sample_rate)) return rc;
     return QH_OK;
 }
 
@@ -265,22 +353,17 @@ int qh_qrx_set_filters(qh_qrx *h, int ch, const double *filtI, const double *fil
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
     if (size < 0 || size > 2048 || (size > 0 && (!filtI || !filtQ)))
         return set_error(QH_ERR_UNSUPPORTED, "Rx filter size must be 0..2048 (got %d)", size);
-    cd id(1.0, 0.0);
-    if (q.mode == Q_CWU || q.mode == Q_USB) id = cd(1.0, 1.0);
-    if (q.mode == Q_CWL || q.mode == Q_LSB) id = cd(1.0, -1.0);
-    std::vector<cd> g((size_t)(size > 0 ? size : 1), id);
+    const bool bypass = is_iq(q.mode) && q.bandwidth >= 19000;        // "No filtering for wide bandwidth", quisk.c:2143
+    if (bypass) size = 0;
+    std::vector<cd> g((size_t)(size > 0 ? size : 1), q.rx_identity());
     for (int d = 0; d < size; d++) {
         const int k = d == 0 ? 0 : size - d;
         const double gi = filtI[k], gq = filtQ[k];
-        switch (q.mode) {
-        case Q_CWU: case Q_USB: g[(size_t)d] = cd(gi, gq); break;      // re - im
-        case Q_CWL: case Q_LSB: g[(size_t)d] = cd(gi, -gq); break;     // re + im
-        default: g[(size_t)d] = cd(gi, 0.0); break;                    // dRxFilterOut
-        }
+        if (!sideband(q.mode)) g[(size_t)d] = cd(gi, 0.0);              // dRxFilterOut
+        else g[(size_t)d] = lower(q.mode) ? cd(gi, -gq) : cd(gi, gq);   // re + im : re - im
     }
     for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? q.nch : ch + 1); c++) {
         if (int rc = q.rxf->set_taps(c, g)) return rc;
-        q.rx_size[(size_t)c] = size;
     }
     return QH_OK;
 }
@@ -288,12 +371,15 @@ int qh_qrx_set_filters(qh_qrx *h, int ch, const double *filtI, const double *fil
 int qh_qrx_out_count(const qh_qrx *h, int n_in)
 {
     if (!h) return 0;
-    const Qrx &q = h->q;
     int n = n_in;
-    for (const Stage *s : q.dec) n = s->out_count(n);
-    if (q.post) n = q.post->out_count(n);
-    return q.up->out_count(n);
+    for (const Step &s : h->q.steps) {
+        if (s.kind == Step::FIR) n = s.st->out_count(n);
+        else if (s.kind == Step::RAT) n = qh_rat_out_count(s.rat, n);
+    }
+    return n;
 }
+
+int qh_qrx_decim_rate(const qh_qrx *h) { return h ? h->q.decim_srate : 0; }
 
 int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in, double *d_out, long long out_stride, int *n_out)
 {
@@ -305,8 +391,8 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     QH_HIP(hipSetDevice(q.device));
     const int total = qh_qrx_out_count(h, n_in);
     if (out_stride < total) return set_error(QH_ERR_INVALID, "output stride %lld shorter than %d samples", out_stride, total);
-    // intermediate buffers: no stage after the first produces more than max(n_in, total) samples
-    const long long need = (long long)(n_in > total ? n_in : total) + 8;
+    // intermediate buffers: the 6/5 stage is the only one that grows the count before the last step
+    const long long need = (long long)(n_in > total ? n_in : total) * 5 / 4 + 64;
     if (need > q.buf_cap) {
         QH_HIP(hipStreamSynchronize(q.stream));
         for (int i = 0; i < 2; i++) { (void)hipFree(q.buf[i]); q.buf[i] = nullptr; }
@@ -316,29 +402,36 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     const void *cur = d_in;
     long long cur_stride = in_stride;
     int n = n_in, w = 0;
-    for (Stage *s : q.dec) {
+    size_t last = 0;
+    for (size_t i = 0; i < q.steps.size(); i++)
+        if (q.steps[i].kind == Step::FIR || q.steps[i].kind == Step::RAT) last = i;
+    for (size_t i = 0; i < q.steps.size(); i++) {
+        const Step &s = q.steps[i];
+        void *dst = i == last ? (void *)d_out : (void *)q.buf[w];
+        const long long dst_stride = i == last ? out_stride : q.buf_cap;
         int m = 0;
-        if (int rc = s->process(cur, cur_stride, n, q.buf[w], q.buf_cap, &m)) return rc;
-        cur = q.buf[w]; cur_stride = q.buf_cap; n = m; w ^= 1;
+        switch (s.kind) {
+        case Step::FIR:
+            if (int rc = s.st->process(cur, cur_stride, n, dst, dst_stride, &m)) return rc;
+            break;
+        case Step::RAT:
+            if (int rc = qh_rat_process(s.rat, cur, cur_stride, n, dst, dst_stride, &m)) return rc;
+            break;
+        case Step::AM_ENV:
+            if (n > 0)
+                hipLaunchKernelGGL(q_am_env_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
+                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.dc_state);
+            continue;
+        case Step::FM_DISC:
+            if (n > 0)
+                hipLaunchKernelGGL(q_fm_disc_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
+                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);
+            continue;
+        }
+        cur = dst; cur_stride = dst_stride; n = m;
+        if (i != last) w ^= 1;
     }
-    {
-        int m = 0;
-        if (int rc = q.rxf->process(cur, cur_stride, n, q.buf[w], q.buf_cap, &m)) return rc;
-        cur = q.buf[w]; n = m; w ^= 1;
-    }
-    if (q.mode == Q_AM && n > 0)
-        hipLaunchKernelGGL(q_am_env_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream, const_cast<double2 *>(static_cast<const double2 *>(cur)),
-                           q.buf_cap, n, q.dc_state);
-    if (q.mode == Q_FM && n > 0) {
-        hipLaunchKernelGGL(q_fm_disc_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream, const_cast<double2 *>(static_cast<const double2 *>(cur)),
-                           q.buf_cap, n, q.fm_state, q.fm_prm);
-        int m = 0;
-        if (int rc = q.post->process(cur, q.buf_cap, n, q.buf[w], q.buf_cap, &m)) return rc;
-        cur = q.buf[w]; n = m; w ^= 1;
-    }
-    int m = 0;
-    if (int rc = q.up->process(cur, q.buf_cap, n, d_out, out_stride, &m)) return rc;
-    if (n_out) *n_out = m;
+    if (n_out) *n_out = n;
     QH_HIP(hipGetLastError());
     return QH_OK;
 }

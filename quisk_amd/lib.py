@@ -104,6 +104,9 @@ def load():
     L.qh_pan_graph.argtypes = [vp, d, d, vp, vp, C.POINTER(i)]
     L.qh_qrx_create.restype = vp
     L.qh_qrx_create.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.qh_qrx_create_ex.restype = vp
+    L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]
+    L.qh_qrx_decim_rate.argtypes = [vp]
     L.qh_qrx_destroy.argtypes = [vp]
     L.qh_qrx_destroy.restype = None
     L.qh_qrx_filter_rate.argtypes = [vp]

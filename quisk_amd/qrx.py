@@ -12,17 +12,32 @@ from . import rxfilter
 from .lib import load, check, QuiskHipError
 
 
+_TABLE_KEYS = ("quiskFilt48dec24Coefs", "quiskFilt144D3Coefs", "quiskFilt240D5CoefsSharp", "quiskAudio24p4Coefs",
+               "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs", "quiskFilt300D5Coefs",
+               "quiskFilt53D1Coefs", "quiskFilt111D2Coefs", "quiskFilt133D2Coefs", "quiskFilt167D3Coefs",
+               "quiskFilt185D3Coefs")
+
+
+class _Tables(C.Structure):         # include/quiskhip.h: qh_qrx_tables
+    _fields_ = [(k, C.c_void_p) for k in _TABLE_KEYS]
+
+
 class QuiskRxBank:
-    def __init__(self, nch, sample_rate, mode, device=0, stream=None):
+    """`bandwidth` is what the GUI passes as set_filters' third argument (quisk.c:4581); it decides the filter
+    rate of the DGT / FDV modes and whether DGT-IQ is filtered at all."""
+
+    def __init__(self, nch, sample_rate, mode, bandwidth=2700, device=0, stream=None):
         self._L = load()
         t = rxfilter.coefficient_tables()
-        self._tabs = [np.ascontiguousarray(t[k], dtype=np.float64) for k in (
-            "quiskFilt48dec24Coefs", "quiskFilt144D3Coefs", "quiskFilt240D5CoefsSharp", "quiskAudio24p4Coefs",
-            "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs")]
-        self._h = self._L.qh_qrx_create(device, nch, sample_rate, mode, *[a.ctypes.data for a in self._tabs], stream)
+        self._tabs = [np.ascontiguousarray(t[k], dtype=np.float64) for k in _TABLE_KEYS]
+        self._tstruct = _Tables(*[a.ctypes.data for a in self._tabs])
+        self._h = self._L.qh_qrx_create_ex(device, nch, sample_rate, mode, bandwidth, C.byref(self._tstruct), stream)
         if not self._h:
             raise QuiskHipError("qh_qrx_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
-        self.nch, self.sample_rate, self.mode = nch, sample_rate, mode
+        self.nch, self.sample_rate, self.mode, self.bandwidth = nch, sample_rate, mode, bandwidth
+
+    def get_decim_rate(self):
+        return self._L.qh_qrx_decim_rate(self._h)
 
     def get_filter_rate(self):
         return self._L.qh_qrx_filter_rate(self._h)

@@ -88,6 +88,74 @@ def test_unset_filter_passes_through_like_reference(qh, oracle):
     assert rel_rms(bank.process_host(x[None, :])[0], r.process(x)) < 1e-9
 
 
-def test_unsupported_rate_is_refused(qh):
+def run_pair(qh, oracle, fs, mode, bw, tune, n, cuts, filt, seed=0, sigmode=3):
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(1, fs, mode, bandwidth=bw)
+    r = oracle.OracleQuiskRx(fs, tabs)
+    r.set_mode(mode); r.set_bandwidth(bw); r.set_tune(tune)
+    bank.set_tune(0, tune)
+    if filt is not None:
+        fI, fQ = filt(bank.get_filter_rate())
+        bank.set_filters(0, fI, fQ); r.set_filters(fI, fQ)
+    x = signal(sigmode, seed, n, fs, float(tune))
+    y = np.concatenate([bank.process_host(x[None, a:b]) for a, b in zip(cuts, cuts[1:])], axis=1)[0]
+    want = np.concatenate([r.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert bank.get_filter_rate() == r.filter_srate() and bank.get_decim_rate() == r.decim_srate()
+    return y, want
+
+
+@pytest.mark.parametrize("fs", [250000, 50000, 300000])
+def test_rational_stage_rates(qh, oracle, fs):
+    """Rates that land on 50 / 60 ksps and take quisk_cInterpDecim 6/5 then 4/5 (quisk.c:1834-1838)."""
+    n = fs // 5
+    cuts = [0, 999, 1000, n // 2 + 3, n]
+    filt = lambda rate: rxfilter.make_filter_coef(rate, None, 2700, rxfilter.get_filter_center("USB", 2700))
+    y, want = run_pair(qh, oracle, fs, 3, 2700, 15000, n, cuts, filt)
+    assert y.size == want.size and np.abs(want).max() > 2.0 ** 10
+    assert rel_rms(y, want) < 1e-9
+
+
+@pytest.mark.parametrize("fs", [55555, 111111, 133333, 185185, 370370, 740740, 1333333])
+def test_sdriq_rates(qh, oracle, fs):
+    """The SDR-IQ table of quisk_process_decimate (quisk.c:1732-1768); audio stays at decim_rate != 48000."""
+    n = fs // 4
+    cuts = [0, 777, n // 2, n]
+    filt = lambda rate: rxfilter.make_filter_coef(rate, None, 2700, rxfilter.get_filter_center("USB", 2700))
+    y, want = run_pair(qh, oracle, fs, 3, 2700, 5000, n, cuts, filt)
+    assert y.size == want.size and np.abs(want).max() > 2.0 ** 10
+    assert rel_rms(y, want) < 1e-9
+
+
+@pytest.mark.parametrize("mode,bw", [(7, 500), (7, 3000), (8, 2800), (8, 6000), (11, 2000), (12, 3200), (10, 2700)])
+def test_digital_sideband_modes(qh, oracle, mode, bw):
+    """DGT-U/L, FDV-U/L (filter at 6 ksps below DGT_NARROW_FREQ, else at 48 ksps, quisk.c:2087-2140) and IMD."""
+    fs, n = 96000, 30000
+    name = {7: "DGT-U", 8: "DGT-L", 11: "FDV-U", 12: "FDV-L", 10: "USB"}[mode]
+    filt = lambda rate: rxfilter.make_filter_coef(rate, None, bw, rxfilter.get_filter_center(name, bw))
+    y, want = run_pair(qh, oracle, fs, mode, bw, 12000, n, [0, 501, 10000, n], filt, sigmode=2 if mode in (8, 12) else 3)
+    assert y.size == want.size and np.abs(want).max() > 2.0 ** 10
+    assert np.array_equal(y.real, y.imag)
+    assert rel_rms(y, want) < 1e-9
+
+
+@pytest.mark.parametrize("bw", [6000, 19000])
+def test_dgt_iq(qh, oracle, bw):
+    """DGT-IQ keeps the IQ stream: filtered by filtI below 19 kHz, untouched above (quisk.c:2141-2153,2534)."""
+    fs, n = 96000, 20000
+    filt = lambda rate: rxfilter.make_filter_coef(rate, None, bw, 0)
+    y, want = run_pair(qh, oracle, fs, 9, bw, -7000, n, [0, 333, n], filt)
+    assert y.size == want.size and not np.array_equal(y.real, y.imag)
+    assert rel_rms(y, want) < 1e-9
+
+
+def test_dgt_fm_is_fm(qh, oracle):
+    fs, n = 48000, 24000
+    filt = lambda rate: rxfilter.make_filter_coef(rate, None, 12000, 0)
+    y, want = run_pair(qh, oracle, fs, 13, 12000, 3000, n, [0, 1001, n], filt, sigmode=5)
+    assert y.size == want.size
+    assert rel_rms(y[2000:], want[2000:]) < 1e-9
+
+
+def test_ext_mode_is_refused(qh):
     with pytest.raises(qh.QuiskHipError):
-        qh.QuiskRxBank(1, 250000, 3)
+        qh.QuiskRxBank(1, 48000, 6)

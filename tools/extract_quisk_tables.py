@@ -16,6 +16,9 @@ TABLES = {  # name: length (filter.h:57-86)
     "quiskFilt300D5Coefs": 125, "quiskAudio24p4Coefs": 50, "quiskAudio24p6Coefs": 36, "quiskAudio24p3Coefs": 100,
     "quiskLpFilt48Coefs": 186, "quiskAudioFmHpCoefs": 309, "quiskFilt16dec8Coefs": 62, "quiskAudio48p6Coefs": 71,
     "quiskAudio96Coefs": 11,
+    # SDR-IQ rates (quisk.c:1706-1710,1732-1768)
+    "quiskFilt53D1Coefs": 55, "quiskFilt111D2Coefs": 114, "quiskFilt133D2Coefs": 136, "quiskFilt167D3Coefs": 174,
+    "quiskFilt185D3Coefs": 189,
 }
 
 
