@@ -278,6 +278,37 @@ int qh_qrx_process(qh_qrx *r, const double *d_in, long long in_stride, int n_in,
 int qh_qrx_process_host(qh_qrx *r, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out);
 int qh_qrx_synchronize(qh_qrx *r);
 
+/* ------------------------------------------------------------------ 7. wire-format sample ingest */
+/* Quisk's sample sources left-justify 1-4 byte integer IQ in an int32 (full scale +-2^31) and, for UDP sources,
+ * scale by rx_udp_gain_correct: quisk_read_rx_udp (quisk.c:3378-3392), add_rx_samples (quisk.c:2923-2952), the
+ * Hermes / HPSDR frames of read_rx_udp10 (quisk.c:3745-3760).  This describes such a byte stream so that the GPU
+ * reads it as it arrived: sample g of channel c starts at
+ *   c*chan_stride + first_offset + (g / records_per_frame)*frame_stride + (g % records_per_frame)*record_stride
+ * (records_per_frame 0 = one endless frame) and is two parts of sample_bytes bytes each.  Results are bit-exact
+ * with the reference's conversion (integer -> double -> one multiply). */
+typedef struct qh_iq_format {
+    int sample_bytes;               /* 1..4 bytes per part */
+    int big_endian;                 /* byte order of a part */
+    int q_first;                    /* 1: the first part is the imaginary one (Hermes, quisk.c:3748-3750) */
+    int records_per_frame;
+    long long first_offset, record_stride, frame_stride;
+    double gain;                    /* applied to the left-justified int32 (rx_udp_gain_correct; 1/2^31 for WDSP scale) */
+} qh_iq_format;
+void qh_iq_format_le24(qh_iq_format *f, double gain);               /* quisk_read_rx_udp, quisk.c:3378-3392 */
+void qh_iq_format_hermes(qh_iq_format *f, int nrx, double gain);    /* read_rx_udp10 frames, quisk.c:3745-3760; channel r: chan_stride 6 */
+/* d_src: packed bytes on the device; d_dst [nch][dst_stride] complex of `dtype`. */
+int qh_unpack_iq(int device, void *stream, const void *d_src, long long src_bytes, const qh_iq_format *fmt, int nch,
+                 long long chan_stride, int n, void *d_dst, long long dst_stride, int dtype);
+/* qh_rxa_process with the decode fused into the first kernel's load: 6 bytes per sample cross HBM instead of 16
+ * and no complex-double copy of the input exists.  nblk blocks of dsp_insize samples per channel. */
+int qh_rxa_process_packed(qh_rxa *e, const void *d_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
+                          double *d_out, long long out_stride, int nblk);
+/* The same two from host memory (upload, run, download, synchronize). */
+int qh_unpack_iq_host(int device, const void *h_src, long long src_bytes, const qh_iq_format *fmt, int nch, long long chan_stride,
+                      int n, void *h_dst, long long dst_stride, int dtype);
+int qh_rxa_process_packed_host(qh_rxa *e, const void *h_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
+                               double *h_out, long long out_stride, int nblk);
+
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library
  * instead of filter.o.  `double *` stands for `complex double *` (same ABI: interleaved re, im).  Each call

@@ -123,6 +123,8 @@ struct Engine {
     int refresh_demod();
     int run_front(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_in, long long n_mid);
+    const unsigned char *pk_src = nullptr;      // set for the duration of a qh_rxa_process_packed call
+    PackedFmt pk{};
     void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
                   const int *list, int nlist);
@@ -524,12 +526,12 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX>
+template <int D, bool MIX, bool PACKED = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles, (unsigned)nch), block(NT);
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX>), grid, block, lds_elems<kNfft>() * sizeof(double2), s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED>), grid, block, lds_elems<kNfft>() * sizeof(double2), s, a);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------
@@ -549,19 +551,35 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
         a.epi = ep;
         a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L;
         const int ntiles = (int)((n_mid + front_L - 1) / front_L);
-        switch (D) {
-        case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
-        case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
-        case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
-        default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
+        a.pk_src = pk_src; a.pk = pk;
+        if (pk_src) {
+            switch (D) {
+            case 2: launch_osfir<2, true, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, true, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, true, true>(a, ntiles, nch, stream); break;
+            default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
+            }
+        } else {
+            switch (D) {
+            case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
+            default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
+            }
         }
         tick(2);
         dim3 g((kHistFront + NT - 1) / NT, (unsigned)nch);
-        hipLaunchKernelGGL((hist_update_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
-                           hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase,
-                           (const int *)nullptr);
+        if (pk_src)
+            hipLaunchKernelGGL((hist_update_kernel<double, true, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
+                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase,
+                               (const int *)nullptr, pk_src, pk);
+        else
+            hipLaunchKernelGGL((hist_update_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
+                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase,
+                               (const int *)nullptr, (const unsigned char *)nullptr, PackedFmt{});
         cur_front ^= 1;
     } else {
+        if (pk_src) return set_error(QH_ERR_UNSUPPORTED, "packed input needs in_rate > dsp_rate (unpack with qh_unpack_iq first)");
         long long per = (n_in + NT - 1) / NT;
         dim3 g((unsigned)(per < 4096 ? per : 4096), (unsigned)nch);
         hipLaunchKernelGGL((pointwise_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, dst, dst_stride,
@@ -885,6 +903,23 @@ int qh_rxa_process(qh_rxa *h, const double *d_in, long long in_stride, double *d
     return h->e.process(d_in, in_stride, d_out, out_stride, nblk);
 }
 
+// The same chain fed with wire-format samples: the front kernel decodes them in its load.
+int qh_rxa_process_packed(qh_rxa *h, const void *d_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
+                          double *d_out, long long out_stride, int nblk)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    if (!d_src || !d_out || !fmt) return set_error(QH_ERR_INVALID, "null buffer");
+    if (out_stride < (long long)nblk * h->e.dsp_outsize) return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
+    PackedFmt pk;
+    if (int rc = qh::make_packed_fmt(fmt, chan_stride, src_bytes, (long long)nblk * h->e.dsp_insize, h->e.nch, &pk)) return rc;
+    h->e.pk_src = static_cast<const unsigned char *>(d_src);
+    h->e.pk = pk;
+    // process() wants an input pointer; the packed kernels never touch it
+    const int rc = h->e.process(reinterpret_cast<const double *>(d_src), (long long)nblk * h->e.dsp_insize, d_out, out_stride, nblk);
+    h->e.pk_src = nullptr;
+    return rc;
+}
+
 // flush_rxa (wdsp/RXA.c:527-559): NCO phase, resampler ring and fircore delay lines back to zero
 int qh_rxa_flush(qh_rxa *h)
 {
@@ -982,6 +1017,34 @@ int qh_rxa_process_host(qh_rxa *h, const double *h_in, long long in_stride, doub
     }
     hipError_t err2 = hipStreamSynchronize(e.stream);
     (void)hipFree(din); (void)hipFree(dout);
+    if (rc != QH_OK) return rc;
+    if (err != hipSuccess) return set_error(QH_ERR_HIP, "copy failed: %s", hipGetErrorString(err));
+    if (err2 != hipSuccess) return set_error(QH_ERR_HIP, "synchronize failed: %s", hipGetErrorString(err2));
+    return QH_OK;
+}
+
+int qh_rxa_process_packed_host(qh_rxa *h, const void *h_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
+                               double *h_out, long long out_stride, int nblk)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    if (!h_src || !h_out || src_bytes <= 0) return set_error(QH_ERR_INVALID, "null buffer");
+    Engine &e = h->e;
+    QH_HIP(hipSetDevice(e.device));
+    const long long n_out = (long long)nblk * e.dsp_outsize;
+    unsigned char *dsrc = nullptr;
+    double2 *dout = nullptr;
+    QH_HIP(dev_alloc(&dsrc, (size_t)src_bytes));
+    if (dev_alloc(&dout, (size_t)e.nch * (size_t)n_out) != hipSuccess) { (void)hipFree(dsrc); return set_error(QH_ERR_HIP, "hipMalloc failed"); }
+    int rc = QH_OK;
+    hipError_t err = hipMemcpyAsync(dsrc, h_src, (size_t)src_bytes, hipMemcpyHostToDevice, e.stream);
+    if (err == hipSuccess) {
+        rc = qh_rxa_process_packed(h, dsrc, src_bytes, fmt, chan_stride, reinterpret_cast<double *>(dout), n_out, nblk);
+        if (rc == QH_OK)
+            err = hipMemcpy2DAsync(h_out, (size_t)out_stride * sizeof(double2), dout, (size_t)n_out * sizeof(double2),
+                                   (size_t)n_out * sizeof(double2), (size_t)e.nch, hipMemcpyDeviceToHost, e.stream);
+    }
+    hipError_t err2 = hipStreamSynchronize(e.stream);
+    (void)hipFree(dsrc); (void)hipFree(dout);
     if (rc != QH_OK) return rc;
     if (err != hipSuccess) return set_error(QH_ERR_HIP, "copy failed: %s", hipGetErrorString(err));
     if (err2 != hipSuccess) return set_error(QH_ERR_HIP, "synchronize failed: %s", hipGetErrorString(err2));

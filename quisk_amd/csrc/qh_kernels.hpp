@@ -9,12 +9,13 @@ namespace qh {
 //   new_hist[j] <- sample at stream index  n_in - H + j   (j = 0..H-1; index -1 is the newest old sample)
 // taken from `in` (mixed with the NCO when MIX, so that history is stored already rotated) or, for
 // negative indices, from old_hist.  Ping-pong buffers, so reads never race the writes.
-template <typename T, bool MIX>
+template <typename T, bool MIX, bool PACKED = false>
 __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long long in_stride, int n_in,
                                                          const cplx<T> *old_hist, cplx<T> *new_hist, int H,
                                                          const unsigned long long *nco_phase,
                                                          const unsigned long long *nco_dphase,
-                                                         const int *chan_list = nullptr)
+                                                         const int *chan_list = nullptr,
+                                                         const unsigned char *pk_src = nullptr, PackedFmt pk = PackedFmt{})
 {
     using C = cplx<T>;
     const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
@@ -23,7 +24,8 @@ __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long
     const long long g = (long long)n_in - H + j;
     C v;
     if (g >= 0) {
-        v = in[(long long)ch * in_stride + g];
+        if constexpr (PACKED) v = decode_packed<T>(pk_src, pk, ch, g);
+        else v = in[(long long)ch * in_stride + g];
         if constexpr (MIX) {
             unsigned long long ph = nco_phase[ch] + nco_dphase[ch] * (unsigned long long)g;
             C rot;

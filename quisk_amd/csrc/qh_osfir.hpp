@@ -22,6 +22,7 @@
 // masks and twiddles are L2 resident.
 #pragma once
 #include "qh_fft.hpp"
+#include "qh_ingest.hpp"
 
 namespace qh {
 
@@ -56,6 +57,8 @@ template <typename T> struct OsfirArgs {
     int Lout;                     // outputs per tile, <= (NFFT - P) / D
     int ntiles;                   // ceil(n_out / Lout)
     int pick;                     // 0/1: every folded sample is an output; k > 1: every k-th (n_out counts final outputs)
+    const unsigned char *pk_src;  // PACKED kernels: the wire-format input (qh_ingest.hpp) instead of `in`
+    PackedFmt pk;
 };
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
@@ -101,7 +104,7 @@ __device__ __forceinline__ unsigned load_tile(cplx<T> (&x)[E], const cplx<T> *__
 // One workgroup = one tile (blockIdx.x) of one channel (blockIdx.y).  Straight-line code: a persistent
 // tile loop with register prefetch was tried and costs more in registers (spills at 2 workgroups/CU) than
 // it gains (tools/ab_bench.py, profiles/r01_notes.md); latency is hidden by the two workgroups per CU.
-template <typename T, int NFFT, int D, bool MIX>
+template <typename T, int NFFT, int D, bool MIX, bool PACKED = false>
 __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -127,7 +130,21 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     // one or two of a channel) take plain loads; edge tiles take the clamped, history-aware path.
     C x[E];
     const bool interior = (g0 >= 0) && (g0 + NFFT <= a.n_in);       // workgroup-uniform
-    if (interior) {
+    if constexpr (PACKED) {
+        // wire-format input: new samples are decoded from the packed bytes, the pre-roll comes from the (complex,
+        // already mixed) history like in the plain path
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < E; r++) x[r] = decode_packed<T>(a.pk_src, a.pk, ch, (long long)(g0 + t + r * NT));
+        } else {
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const int g = g0 + t + r * NT;
+                if (g >= 0) x[r] = g < a.n_in ? decode_packed<T>(a.pk_src, a.pk, ch, (long long)g) : mk<T>(0, 0);
+                else x[r] = (hist && g + a.hist_len >= 0) ? hist[g + a.hist_len] : mk<T>(0, 0);
+            }
+        }
+    } else if (interior) {
         const C *p = in + g0 + t;
 #pragma unroll
         for (int r = 0; r < E; r++) x[r] = p[r * NT];

@@ -104,6 +104,14 @@ def load():
     L.qh_pan_graph.argtypes = [vp, d, d, vp, vp, C.POINTER(i)]
     L.qh_qrx_create.restype = vp
     L.qh_qrx_create.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.qh_iq_format_le24.argtypes = [vp, C.c_double]
+    L.qh_iq_format_le24.restype = None
+    L.qh_iq_format_hermes.argtypes = [vp, i, C.c_double]
+    L.qh_iq_format_hermes.restype = None
+    L.qh_unpack_iq.argtypes = [i, vp, vp, ll, vp, i, ll, i, vp, ll, i]
+    L.qh_unpack_iq_host.argtypes = [i, vp, ll, vp, i, ll, i, vp, ll, i]
+    L.qh_rxa_process_packed.argtypes = [vp, vp, ll, vp, ll, vp, ll, i]
+    L.qh_rxa_process_packed_host.argtypes = [vp, vp, ll, vp, ll, vp, ll, i]
     L.qh_qrx_create_ex.restype = vp
     L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]
     L.qh_qrx_decim_rate.argtypes = [vp]

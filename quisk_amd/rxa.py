@@ -52,6 +52,17 @@ class RxaEngine:
         check(self._L.qh_rxa_process_host(self._h, x.ctypes.data, x.shape[1], out.ctypes.data, out.shape[1], nblk))
         return out
 
+    def process_packed_ptr(self, d_src, src_bytes, fmt, chan_stride, d_out, out_stride, nblk):
+        """Wire-format input (quisk_amd.ingest.IqFormat) decoded inside the first kernel's load."""
+        check(self._L.qh_rxa_process_packed(self._h, d_src, src_bytes, C.byref(fmt), chan_stride, d_out, out_stride, nblk))
+
+    def process_packed_host(self, buf, fmt, chan_stride, nblk):
+        raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+        out = np.empty((self.nch, nblk * self.dsp_outsize), dtype=np.complex128)
+        check(self._L.qh_rxa_process_packed_host(self._h, raw.ctypes.data, raw.size, C.byref(fmt), chan_stride, out.ctypes.data,
+                                                 out.shape[1], nblk))
+        return out
+
     def enable_meters(self, on=True):
         check(self._L.qh_rxa_enable_meters(self._h, 1 if on else 0))
 
