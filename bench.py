@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=1,
                     help="split a step into this many consecutive time chunks (engine calls); the intermediate "
                          "buffer of a chunk then stays in the 256 MiB Infinity Cache")
+    ap.add_argument("--ingest", choices=["f64", "le24"], default="f64",
+                    help="f64: complex double input resident in HBM (the BASELINE workload); le24: the same signal as "
+                         "24-bit little-endian IQ bytes (quisk_read_rx_udp wire format), decoded in the front kernel's load")
     args = ap.parse_args()
 
     import torch
@@ -118,9 +121,22 @@ def main():
         raise SystemExit("--chunks must divide %d" % nblk)
     cb = nblk // nchunk
 
-    def step():
-        for k in range(nchunk):
-            eng.process_ptr(x.data_ptr() + 16 * k * cb * (n_in // nblk), n_in, y.data_ptr() + 16 * k * cb * (n_out // nblk), n_out, cb)
+    if args.ingest == "le24":
+        from quisk_amd import IqFormat
+        if nchunk != 1:
+            raise SystemExit("--ingest le24 runs unchunked")
+        codes = torch.view_as_real(x).mul(2.0 ** 23).round_().to(torch.int32)       # [nch, n, 2] 24-bit ADC codes
+        packed = codes.view(torch.uint8).reshape(nch, n_in, 2, 4)[..., :3].contiguous()     # 6 bytes per sample
+        del codes
+        fmt = IqFormat.le24(2.0 ** -31)                     # left-justified int32 (code * 2^8) back to +-1.0 full scale
+        torch.cuda.synchronize(dev)
+
+        def step():
+            eng.process_packed_ptr(packed.data_ptr(), packed.numel(), fmt, 6 * n_in, y.data_ptr(), n_out, nblk)
+    else:
+        def step():
+            for k in range(nchunk):
+                eng.process_ptr(x.data_ptr() + 16 * k * cb * (n_in // nblk), n_in, y.data_ptr() + 16 * k * cb * (n_out // nblk), n_out, cb)
 
     for _ in range(args.warmup):
         step()
@@ -161,7 +177,7 @@ def main():
         #   front  (shift + resample /4): reads 16 B, writes 16/4 B per input sample        = 20 B / input sample
         #   band   (NBP overlap-save)   : reads 16 B, writes 16 B per DSP-rate sample (x1/4) =  8 B / input sample
         names = ["osfir_kernel<f64,4096,D=4,mix> (shift+resample)", "osfir_kernel<f64,4096,D=1> (nbp fircore)"]
-        algo = [20.0, 8.0]
+        algo = [20.0 if args.ingest == "f64" else 10.0, 8.0]      # 24-bit ingest: 6 B in + 16/4 B out
         k = 0 if kt[0] >= kt[1] else 1
         achieved = algo[k] * samples_per_step / (kt[k] * 1e-3) / 1e9
         line = {
@@ -179,7 +195,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d channels/GPU x 192 kHz IQ -> 48 kHz SSB RXA chain (shift + 561-tap resample/4 + NBP nc 2048 + "
                                    "fixed AGC + panel), 2^%d input samples per channel per step" % (nch, args.log2_samples),
-                       "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
+                       "ingest": args.ingest, "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
                        "parallelism": "channel-sharded x%d, no collective" % world},
             "chain_algorithmic_GBps": 20.0 * total / dt / 1e9,
             "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},

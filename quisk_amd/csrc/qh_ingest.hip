@@ -37,6 +37,9 @@ int qh::make_packed_fmt(const qh_iq_format *f, long long chan_stride, long long 
     out->records_per_frame = f->records_per_frame;
     out->inv_rpf = f->records_per_frame > 0 ? 1.0 / f->records_per_frame : 0.0;
     out->gain = f->gain;
+    const int p_re = f->q_first ? f->sample_bytes : 0, p_im = f->q_first ? 0 : f->sample_bytes;
+    out->sel_re = perm_selector(p_re, f->sample_bytes, f->big_endian != 0);
+    out->sel_im = perm_selector(p_im, f->sample_bytes, f->big_endian != 0);
     return QH_OK;
 }
 

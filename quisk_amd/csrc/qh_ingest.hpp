@@ -28,7 +28,34 @@ struct PackedFmt {
     int records_per_frame;      // 0: one endless frame
     double inv_rpf;             // 1 / records_per_frame
     double gain;
+    unsigned sel_re, sel_im;    // v_perm_b32 selectors: the 8 loaded bytes -> left-justified int32 of each part
 };
+
+// Byte selector that lifts the part starting `p` bytes into the loaded window into a left-justified int32:
+// little-endian wire bytes keep their order under the zero low bytes (memcpy to ptxr + 4 - sample_bytes,
+// quisk.c:3380), big-endian ones are reversed (xi = b0 << 24 | b1 << 16 | b2 << 8, quisk.c:3748).  0x0c selects 0x00.
+inline unsigned perm_selector(int p, int sample_bytes, bool big_endian)
+{
+    unsigned sel = 0;
+    for (int j = 0; j < 4; j++) {
+        unsigned b = 0x0c;
+        if (big_endian) { if (3 - j < sample_bytes) b = (unsigned)(p + 3 - j); }
+        else if (j >= 4 - sample_bytes) b = (unsigned)(p + j - (4 - sample_bytes));
+        sel |= b << (8 * j);
+    }
+    return sel;
+}
+
+// Fast form for windows that lie wholly inside the buffer: one unaligned 64-bit load, one byte permute per part.
+template <typename T>
+__device__ __forceinline__ cplx<T> decode_packed_at(const unsigned char *__restrict__ p, unsigned sel_re, unsigned sel_im, double gain)
+{
+    unsigned long long w;
+    __builtin_memcpy(&w, p, 8);
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+    const int ir = (int)__builtin_amdgcn_perm(hi, lo, sel_re), ii = (int)__builtin_amdgcn_perm(hi, lo, sel_im);
+    return mk<T>((T)((double)ir * gain), (T)((double)ii * gain));
+}
 
 // Sample g of channel ch.  One unaligned 64-bit load covers both parts (2 x 4 bytes at most); near the end of the
 // buffer the address is pulled back and the word shifted instead, so nothing past total_bytes is read.

@@ -133,7 +133,16 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     if constexpr (PACKED) {
         // wire-format input: new samples are decoded from the packed bytes, the pre-roll comes from the (complex,
         // already mixed) history like in the plain path
-        if (interior) {
+        // contiguous records whose 8-byte load windows all end inside the buffer: pointer + constant stride
+        const long long base = a.pk.first_offset + (long long)ch * a.pk.chan_stride + (long long)g0 * a.pk.record_stride;
+        const bool fast = interior && a.pk.records_per_frame == 0 &&
+                          base + (long long)(NFFT - 1) * a.pk.record_stride + 8 <= a.pk.total_bytes;    // workgroup-uniform
+        if (fast) {
+            const unsigned char *p = a.pk_src + base + (long long)t * a.pk.record_stride;
+            const long long step = (long long)NT * a.pk.record_stride;
+#pragma unroll
+            for (int r = 0; r < E; r++) x[r] = decode_packed_at<T>(p + r * step, a.pk.sel_re, a.pk.sel_im, a.pk.gain);
+        } else if (interior) {
 #pragma unroll
             for (int r = 0; r < E; r++) x[r] = decode_packed<T>(a.pk_src, a.pk, ch, (long long)(g0 + t + r * NT));
         } else {
