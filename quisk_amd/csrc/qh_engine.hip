@@ -209,13 +209,12 @@ int Engine::init()
     QH_HIP(hipMemsetAsync(nco_phase, 0, (size_t)nch * sizeof(unsigned long long), stream));
     dev_bytes += (size_t)nch * (16 + 16 + sizeof(EpiParam));
 
-    // allow the 64 KiB dynamic LDS of the overlap-save kernels
-    const int lds = lds_elems<kNfft>() * (int)sizeof(double2);
-#define QH_SET_LDS(K) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
-    QH_SET_LDS((osfir_kernel<double, 4096, 1, false>));
-    QH_SET_LDS((osfir_kernel<double, 4096, 2, true>));
-    QH_SET_LDS((osfir_kernel<double, 4096, 4, true>));
-    QH_SET_LDS((osfir_kernel<double, 4096, 8, true>));
+    // dynamic LDS of the overlap-save kernels
+#define QH_SET_LDS(D, ...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, 4096, D, __VA_ARGS__>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D>())))
+    QH_SET_LDS(1, false);
+    QH_SET_LDS(2, true); QH_SET_LDS(4, true); QH_SET_LDS(8, true);
+    QH_SET_LDS(2, true, true); QH_SET_LDS(4, true, true); QH_SET_LDS(8, true, true);
 #undef QH_SET_LDS
     QH_HIP(hipStreamSynchronize(stream));
     return QH_OK;
@@ -531,7 +530,8 @@ static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles, (unsigned)nch), block(NT);
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED>), grid, block, lds_elems<kNfft>() * sizeof(double2), s, a);
+    constexpr int lds = osfir_lds_bytes<double, kNfft, D>();
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED>), grid, block, lds, s, a);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------

@@ -259,6 +259,64 @@ template <bool INV, typename C> struct FftRR<4096, INV, C> {
     }
 };
 
+// The same 4096-point transform with the real and the imaginary parts exchanged through LDS one after the other:
+// the LDS image holds 4096 scalars (34.8 KB in fp64 instead of 69.6 KB), so four workgroups fit a CU where two did,
+// at the price of barriers (7 per transform instead of 2).  Registers -> registers; the caller guarantees that
+// nobody still reads the LDS image when run() starts.
+template <bool INV, typename C> struct FftSplit4096 {
+    using T = decltype(C{}.x);
+    using Tw = typename FftRR<4096, INV, C>::Tw;
+    static constexpr int kLdsBytes = lds_elems<4096>() * (int)sizeof(T);
+
+    template <int WS, int RS>
+    static __device__ __forceinline__ void exchange(C (&x)[16], T *lds, int wbase, int rbase)
+    {
+        T *wp = lds + wbase;
+        const T *rp = lds + rbase;
+#pragma unroll
+        for (int r = 0; r < 16; r++) wp[r * WS] = x[r].x;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r].x = rp[r * RS];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) wp[r * WS] = x[r].y;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r].y = rp[r * RS];
+    }
+
+    static __device__ __forceinline__ void run(C (&x)[16], void *lds_raw, const Tw &t)
+    {
+        T *lds = reinterpret_cast<T *>(lds_raw);
+        const int j = threadIdx.x;
+        Dft<16, INV, C>::run(x);                                    // pass 1: x[r] = in[j + 256 r]
+        // element j*16 + r  ->  j + 256 r'   (phys(i) = i + (i >> 4): 17 j + r, and phys(j) + 272 r')
+        exchange<1, 272>(x, lds, 17 * j, lds_phys(j));
+        const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);      // pass 2: outputs at base + 16 r
+        __syncthreads();
+        exchange<17, 272>(x, lds, lds_phys(base), lds_phys(j));
+        stockham_butterfly<4096, 16, 256, INV>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
+    }
+};
+
+// What the overlap-save kernels call: registers (strided layout) -> registers, LDS image of lds_bytes.
+template <int N, bool INV, typename C> struct TileFft {
+    static constexpr bool kSplit = N == 4096 && sizeof(C) == 16;
+    static constexpr int kLdsBytes = kSplit ? lds_elems<4096>() * 8 : lds_elems<N>() * (int)sizeof(C);
+    using Tw = typename FftRR<N, INV, C>::Tw;
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw) { return FftRR<N, INV, C>::load(tw); }
+    static __device__ __forceinline__ void run(C (&x)[N / NT], void *lds, const Tw &t)
+    {
+        if constexpr (kSplit) {
+            FftSplit4096<INV, C>::run(x, lds, t);
+        } else {
+            FftRR<N, INV, C>::first(x, reinterpret_cast<C *>(lds));
+            FftRR<N, INV, C>::rest(reinterpret_cast<C *>(lds), x, t);
+        }
+    }
+};
+
 template <bool INV, typename C> struct FftRR<2048, INV, C> {
     struct Tw { C a[2], b[1], c; };
     static __device__ __forceinline__ Tw load(const C *__restrict__ tw)

@@ -101,11 +101,35 @@ __device__ __forceinline__ unsigned load_tile(cplx<T> (&x)[E], const cplx<T> *__
     return okbits;
 }
 
+// dynamic LDS of the two kernels below
+template <typename T, int NFFT, int D> constexpr int osfir_lds_bytes()
+{
+    constexpr int a = TileFft<NFFT, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT / D, true, cplx<T>>::kLdsBytes;
+    return a > b ? a : b;
+}
+template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
+{
+    constexpr int a = TileFft<NFFT / U, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT, true, cplx<T>>::kLdsBytes;
+    return a > b ? a : b;
+}
+
 // One workgroup = one tile (blockIdx.x) of one channel (blockIdx.y).  Straight-line code: a persistent
 // tile loop with register prefetch was tried and costs more in registers (spills at 2 workgroups/CU) than
 // it gains (tools/ab_bench.py, profiles/r01_notes.md); latency is hidden by the two workgroups per CU.
+// Waves per SIMD the register allocator must leave room for: with the split LDS exchange three (or four) fp64
+// workgroups fit a CU, provided each stays within 168 (128) VGPRs.
+// Measured (tools/ab_bench.py, C2): the D = 1 kernel gains from four waves despite 2 spilled registers
+// (3.41 -> 2.77 ms), the decimating ones are best at three (128 VGPRs cost them 14 spills).
+#ifndef QH_OSFIR_WAVES_F64_D1
+#define QH_OSFIR_WAVES_F64_D1 4
+#endif
+#ifndef QH_OSFIR_WAVES_F64
+#define QH_OSFIR_WAVES_F64 3
+#endif
+template <typename T, int D> constexpr int osfir_min_waves() { return sizeof(T) == 8 ? (D == 1 ? QH_OSFIR_WAVES_F64_D1 : QH_OSFIR_WAVES_F64) : 4; }
+
 template <typename T, int NFFT, int D, bool MIX, bool PACKED = false>
-__global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
+__global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
     constexpr int E = NFFT / NT;            // elements per thread, forward
@@ -114,10 +138,10 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     static_assert(E % D == 0 && EO >= 1, "decimation must divide NFFT/256");
     static_assert(NOUT >= 2 * NT, "NFFT/D must be >= 512");
     static_assert(E <= 32, "validity bits are kept in one word");
-    using Fwd = FftRR<NFFT, false, C>;
-    using Inv = FftRR<NOUT, true, C>;
+    using Fwd = TileFft<NFFT, false, C>;
+    using Inv = TileFft<NOUT, true, C>;
     extern __shared__ __align__(16) unsigned char smem[];
-    C *lds = reinterpret_cast<C *>(smem);
+    void *lds = smem;
 
     const int t = threadIdx.x;
     const int tile = blockIdx.x;
@@ -181,8 +205,7 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
     }
 
     // ---- forward FFT, registers -> registers
-    Fwd::first(x, lds);
-    Fwd::rest(lds, x, Fwd::load(a.tw_fwd));
+    Fwd::run(x, lds, Fwd::load(a.tw_fwd));
 
     // ---- mask multiply + D-fold: lane holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
     const C *mask = a.mask + (long long)ch * a.mask_stride;
@@ -197,8 +220,7 @@ __global__ __launch_bounds__(NT) void osfir_kernel(OsfirArgs<T> a)
 
     // ---- inverse FFT at NOUT points
     __syncthreads();                        // every lane has finished reading LDS in the last forward pass
-    Inv::first(z, lds);
-    Inv::rest(lds, z, Inv::load(a.tw_inv));
+    Inv::run(z, lds, Inv::load(a.tw_inv));
 
     // ---- epilogue + store of the Lout valid outputs
     C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
@@ -248,10 +270,10 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
     constexpr int NF = NFFT / U;            // forward size
     constexpr int EF = NF / NT, E = NFFT / NT;
     static_assert(NF >= 2 * NT && U > 1, "NFFT/U must be >= 512");
-    using Fwd = FftRR<NF, false, C>;
-    using Inv = FftRR<NFFT, true, C>;
+    using Fwd = TileFft<NF, false, C>;
+    using Inv = TileFft<NFFT, true, C>;
     extern __shared__ __align__(16) unsigned char smem[];
-    C *lds = reinterpret_cast<C *>(smem);
+    void *lds = smem;
 
     const int t = threadIdx.x;
     const int tile = blockIdx.x;
@@ -266,8 +288,7 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
     for (int r = 0; r < EF; r++)
         if (!((ok >> r) & 1u)) x[r] = mk<T>(0, 0);
 
-    Fwd::first(x, lds);
-    Fwd::rest(lds, x, Fwd::load(a.tw_fwd));
+    Fwd::run(x, lds, Fwd::load(a.tw_fwd));
 
     const C *mask = a.mask + (long long)ch * a.mask_stride;
     C z[E];
@@ -275,8 +296,7 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
     for (int i = 0; i < E; i++) z[i] = cmul(x[i % EF], mask[t + NT * i]);
 
     __syncthreads();
-    Inv::first(z, lds);
-    Inv::rest(lds, z, Inv::load(a.tw_inv));
+    Inv::run(z, lds, Inv::load(a.tw_inv));
 
     C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
     EpiParam ep;

@@ -170,13 +170,13 @@ struct Stage {
     template <typename T, int FOLD, bool MIX> int attr_one()
     {
         QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<T, kStageNfft, FOLD, MIX>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_elems<kStageNfft>() * (int)sizeof(cplx<T>)));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<T, kStageNfft, FOLD>())));
         return QH_OK;
     }
     template <typename T, int U> int attr_up()
     {
         QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_interp_kernel<T, kStageNfft, U>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_elems<kStageNfft>() * (int)sizeof(cplx<T>)));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_interp_lds_bytes<T, kStageNfft, U>())));
         return QH_OK;
     }
     template <typename T> int set_attr_t()
@@ -190,12 +190,14 @@ struct Stage {
     template <typename T, int FOLD, bool MIX> void launch_dec(const OsfirArgs<T> &a)
     {
         dim3 grid((unsigned)a.ntiles, (unsigned)nch), block(NT);
-        hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX>), grid, block, lds_elems<kStageNfft>() * sizeof(cplx<T>), stream, a);
+        constexpr int lds = osfir_lds_bytes<T, kStageNfft, FOLD>();
+        hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX>), grid, block, lds, stream, a);
     }
     template <typename T, int U> void launch_up(const OsfirArgs<T> &a)
     {
         dim3 grid((unsigned)a.ntiles, (unsigned)nch), block(NT);
-        hipLaunchKernelGGL((osfir_interp_kernel<T, kStageNfft, U>), grid, block, lds_elems<kStageNfft>() * sizeof(cplx<T>), stream, a);
+        constexpr int lds = osfir_interp_lds_bytes<T, kStageNfft, U>();
+        hipLaunchKernelGGL((osfir_interp_kernel<T, kStageNfft, U>), grid, block, lds, stream, a);
     }
 
     template <typename T> int process_t(const void *in, long long in_stride, int n_in, void *out, long long out_stride, int *n_out)
