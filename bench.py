@@ -180,6 +180,15 @@ def main():
         algo = [20.0 if args.ingest == "f64" else 10.0, 8.0]      # 24-bit ingest: 6 B in + 16/4 B out
         k = 0 if kt[0] >= kt[1] else 1
         achieved = algo[k] * samples_per_step / (kt[k] * 1e-3) / 1e9
+        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c2_traffic.json),
+        # scaled by the number of samples: counters cannot be read inside this process
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c2_traffic.json")))
+            if args.ingest == "f64":
+                traffic = tj["kernels"]["front" if k == 0 else "band"]["bytes_per_input_sample"] * samples_per_step
+        except Exception:
+            traffic = None
         line = {
             "metric": "Mcomplex-samples/s through RXA chain",
             "value": value,
@@ -200,7 +209,8 @@ def main():
             "chain_algorithmic_GBps": 20.0 * total / dt / 1e9,
             "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "algorithmic_bytes_per_launch": algo[k] * samples_per_step},
             "check_inband_gain": gain,
         }
         if not args.no_cpu_baseline:

@@ -263,10 +263,18 @@ template <bool INV, typename C> struct FftRR<4096, INV, C> {
 // the LDS image holds 4096 scalars (34.8 KB in fp64 instead of 69.6 KB), so four workgroups fit a CU where two did,
 // at the price of barriers (7 per transform instead of 2).  Registers -> registers; the caller guarantees that
 // nobody still reads the LDS image when run() starts.
+#ifndef QH_SPLIT_PAD
+#define QH_SPLIT_PAD 2
+#endif
 template <bool INV, typename C> struct FftSplit4096 {
     using T = decltype(C{}.x);
     using Tw = typename FftRR<4096, INV, C>::Tw;
-    static constexpr int kLdsBytes = lds_elems<4096>() * (int)sizeof(T);
+    // scalar image, row pitch 18: the compiler pairs the 16 contiguous scalars a lane writes in the first exchange
+    // into 128-bit stores, which are served 8 lanes at a time -- a lane stride of 18 scalars = 4 banks (mod 32)
+    // keeps those 8 lanes on distinct banks (pitch 17 gave 2-way conflicts on a third of the LDS cycles)
+    static constexpr int kPad = QH_SPLIT_PAD;
+    static constexpr int kLdsBytes = (4096 + kPad * 256) * (int)sizeof(T);
+    static __device__ __forceinline__ int sphys(int i) { return i + (i >> 4) * kPad; }
 
     template <int WS, int RS>
     static __device__ __forceinline__ void exchange(C (&x)[16], T *lds, int wbase, int rbase)
@@ -291,11 +299,11 @@ template <bool INV, typename C> struct FftSplit4096 {
         T *lds = reinterpret_cast<T *>(lds_raw);
         const int j = threadIdx.x;
         Dft<16, INV, C>::run(x);                                    // pass 1: x[r] = in[j + 256 r]
-        // element j*16 + r  ->  j + 256 r'   (phys(i) = i + (i >> 4): 17 j + r, and phys(j) + 272 r')
-        exchange<1, 272>(x, lds, 17 * j, lds_phys(j));
+        // element j*16 + r  ->  j + 256 r'   (sphys: 18 j + r, and sphys(j) + 288 r')
+        exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
         const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);      // pass 2: outputs at base + 16 r
         __syncthreads();
-        exchange<17, 272>(x, lds, lds_phys(base), lds_phys(j));
+        exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
         stockham_butterfly<4096, 16, 256, INV>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
     }
 };
@@ -303,7 +311,7 @@ template <bool INV, typename C> struct FftSplit4096 {
 // What the overlap-save kernels call: registers (strided layout) -> registers, LDS image of lds_bytes.
 template <int N, bool INV, typename C> struct TileFft {
     static constexpr bool kSplit = N == 4096 && sizeof(C) == 16;
-    static constexpr int kLdsBytes = kSplit ? lds_elems<4096>() * 8 : lds_elems<N>() * (int)sizeof(C);
+    static constexpr int kLdsBytes = kSplit ? (4096 + QH_SPLIT_PAD * 256) * 8 : lds_elems<N>() * (int)sizeof(C);
     using Tw = typename FftRR<N, INV, C>::Tw;
     static __device__ __forceinline__ Tw load(const C *__restrict__ tw) { return FftRR<N, INV, C>::load(tw); }
     static __device__ __forceinline__ void run(C (&x)[N / NT], void *lds, const Tw &t)
