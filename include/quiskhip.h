@@ -309,6 +309,22 @@ int qh_unpack_iq_host(int device, const void *h_src, long long src_bytes, const 
 int qh_rxa_process_packed_host(qh_rxa *e, const void *h_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
                                double *h_out, long long out_stride, int nblk);
 
+/* ------------------------------------------------------------------ 8. Quisk's audio AGC */
+/* process_agc (quisk.c:2162-2287) for `nch` streams of complex double at `sample_rate` (the playback rate):
+ * 15 ms look-ahead FIFO, gain ramp on overload, exponential release towards min(release gain, headroom).
+ * max_out 0.7 and release_time 1.0 s are Quisk's values (quisk.c:2321,192); is_cpx selects |z| (EXT, DGT-IQ) or
+ * |Re z| (every other mode, quisk.c:2686-2702).  As in the reference, the FIRST call only sets the state up and
+ * leaves its samples untouched (quisk.c:2173-2190).  In place. */
+typedef struct qh_qagc qh_qagc;
+qh_qagc *qh_qagc_create(int device, int nch, int sample_rate, double max_out, double release_time, int is_cpx, void *stream);
+void qh_qagc_destroy(qh_qagc *a);
+int qh_qagc_set_gain(qh_qagc *a, int ch, double release_gain);          /* set_agc(d), quisk.c:4543; default 80 */
+int qh_qagc_reset(qh_qagc *a);
+int qh_qagc_process(qh_qagc *a, void *d_buf, long long stride, int n);
+int qh_qagc_process_host(qh_qagc *a, void *h_buf, long long stride, int n);
+/* The receiver bank with process_agc on its output, as quisk_process_samples has it; off by default. */
+int qh_qrx_set_agc(qh_qrx *r, int on, double release_gain);
+
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library
  * instead of filter.o.  `double *` stands for `complex double *` (same ABI: interleaved re, im).  Each call

@@ -420,6 +420,11 @@ class OracleQuiskRx:
     def set_tune(self, f): self.L.qo_rx_set_tune(self.h, int(f))
     def set_mode(self, m): self.L.qo_rx_set_mode(self.h, int(m))
     def set_bandwidth(self, bw): self.L.qo_rx_set_bandwidth(self.h, int(bw))
+
+    def set_agc(self, on, release_gain=80.0):
+        self.L.qo_rx_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        self.L.qo_rx_set_agc(self.h, int(on), float(release_gain))
+
     def decim_srate(self): return self.L.qo_rx_decim_srate(self.h)
     def filter_srate(self): return self.L.qo_rx_filter_srate(self.h)
 
@@ -438,4 +443,27 @@ class OracleQuiskRx:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.qo_rx_free(self.h)
+            self.h = None
+
+
+class OracleQuiskAgc:
+    """process_agc (quisk.c:2162-2287) for one stream; process(x) returns the AGC'd block (the first call only initialises)."""
+
+    def __init__(self, sample_rate=48000, max_out=0.7, release_time=1.0):
+        L = lib()
+        L.qo_agc_create.restype = C.c_void_p
+        L.qo_agc_create.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.qo_agc_free.argtypes = [C.c_void_p]
+        L.qo_agc_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
+        self.L = L
+        self.h = L.qo_agc_create(sample_rate, max_out, release_time)
+
+    def process(self, x, is_cpx, release_gain):
+        buf = np.ascontiguousarray(x, dtype=np.complex128).copy()
+        self.L.qo_agc_process(self.h, buf.ctypes.data, buf.size, int(is_cpx), float(release_gain))
+        return buf
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_agc_free(self.h)
             self.h = None

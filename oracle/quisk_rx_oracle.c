@@ -8,6 +8,80 @@
 #define MAX_FILTER_SIZE 10001       /* quisk.h */
 #define FM_FILTER_DEMPH 300.0       /* quisk.c:40 */
 
+#define AGC_DELAY 15                /* quisk.c:47 */
+#define CLIP32 2147483647.0         /* quisk.h:13 */
+
+struct qo_agc {                     /* struct AgcState, quisk.c:68-84 */
+    double max_out;
+    int sample_rate, buf_size, index_read, index_start, is_clipping;
+    double themax, gain, delta, target_gain, time_release, release_time;
+    double *c_samp;
+};
+
+qo_agc *qo_agc_create(int sample_rate, double max_out, double release_time)
+{
+    qo_agc *a = (qo_agc *)calloc(1, sizeof(*a));
+    a->max_out = max_out; a->sample_rate = sample_rate; a->release_time = release_time;
+    return a;
+}
+
+void qo_agc_free(qo_agc *a) { if (a) { free(a->c_samp); free(a); } }
+
+void qo_agc_process(qo_agc *d, double *cs, int count, int is_cpx, double agcReleaseGain)      /* quisk.c:2162-2287 */
+{
+    int i;
+    double out_magn, buf_magn, dtmp, clip_gain, sre, sim;
+    if (!d->buf_size) {             /* the first call only initialises (quisk.c:2173-2190) */
+        d->buf_size = d->sample_rate * AGC_DELAY / 1000;
+        d->index_read = 0; d->index_start = 0; d->is_clipping = 0;
+        d->themax = 1.0; d->gain = 100; d->delta = 0; d->target_gain = 100;
+        d->time_release = 1.0 - exp(-1.0 / d->sample_rate / d->release_time);
+        d->c_samp = (double *)calloc((size_t)d->buf_size * 2, sizeof(double));
+        return;
+    }
+    for (i = 0; i < count; i++) {
+        sre = cs[2 * i]; sim = cs[2 * i + 1];
+        cs[2 * i] = d->c_samp[2 * d->index_read] * d->gain;                 /* FIFO output */
+        cs[2 * i + 1] = d->c_samp[2 * d->index_read + 1] * d->gain;
+        out_magn = is_cpx ? hypot(cs[2 * i], cs[2 * i + 1]) : fabs(cs[2 * i]);
+        if (out_magn > CLIP32) { cs[2 * i] /= out_magn; cs[2 * i + 1] /= out_magn; }
+        d->c_samp[2 * d->index_read] = sre; d->c_samp[2 * d->index_read + 1] = sim;
+        buf_magn = is_cpx ? hypot(sre, sim) : fabs(sre);
+        if (d->is_clipping == 0) {
+            if (buf_magn * d->gain > d->max_out * CLIP32) {
+                d->target_gain = d->max_out * CLIP32 / buf_magn;
+                d->delta = (d->gain - d->target_gain) / d->buf_size;
+                d->is_clipping = 1;
+                d->themax = buf_magn;
+                d->gain -= d->delta;
+            } else if (d->index_read == d->index_start) {
+                clip_gain = d->max_out * CLIP32 / d->themax;
+                d->target_gain = agcReleaseGain > clip_gain ? clip_gain : agcReleaseGain;
+                d->themax = buf_magn;
+                d->gain = d->gain * (1.0 - d->time_release) + d->target_gain * d->time_release;
+            } else {
+                if (d->themax < buf_magn) d->themax = buf_magn;
+                d->gain = d->gain * (1.0 - d->time_release) + d->target_gain * d->time_release;
+            }
+        } else {
+            if (buf_magn > d->themax) {
+                d->themax = buf_magn;
+                d->target_gain = d->max_out * CLIP32 / buf_magn;
+                dtmp = (d->gain - d->target_gain) / d->buf_size;
+                if (dtmp > d->delta) d->delta = dtmp;
+            }
+            d->gain -= d->delta;
+            if (d->gain <= d->target_gain) {
+                d->is_clipping = 0;
+                d->gain = d->target_gain;
+                d->themax = buf_magn;
+                d->index_start = d->index_read;
+            }
+        }
+        if (++d->index_read >= d->buf_size) d->index_read = 0;
+    }
+}
+
 struct qo_rx {
     int sample_rate, decim2, decim3, decim5, decim_srate, filter_srate, mode, tune, bandwidth;
     qo_rx_tables t;
@@ -24,6 +98,9 @@ struct qo_rx {
     double *filtI, *filtQ, *bufI, *bufQ, *bufC;
     double *dsamples;
     int dcap;
+    qo_agc *agc;                    /* Agc1 = {0.7, 0, 0}, quisk.c:2321 */
+    int agc_on;
+    double agc_gain;
 };
 
 int qo_rx_decim_srate(const qo_rx *r) { return r->decim_srate; }
@@ -94,6 +171,7 @@ void qo_rx_free(qo_rx *r)
     qo_fir_free(&r->sdriq133); qo_fir_free(&r->sdriq167); qo_fir_free(&r->sdriq185);
     qo_fir_free(&r->d48to24); qo_fir_free(&r->dm48to24); qo_fir_free(&r->audio24p4); qo_fir_free(&r->audio12p2);
     qo_fir_free(&r->audio24p6); qo_fir_free(&r->audio48p3); qo_fir_free(&r->fmhp);
+    qo_agc_free(r->agc);
     free(r->filtI); free(r->filtQ); free(r->bufI); free(r->bufQ); free(r->bufC); free(r->dsamples);
     free(r);
 }
@@ -101,6 +179,7 @@ void qo_rx_free(qo_rx *r)
 void qo_rx_set_tune(qo_rx *r, int f) { r->tune = f; }
 void qo_rx_set_mode(qo_rx *r, int mode) { r->mode = mode; }
 void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
+void qo_rx_set_agc(qo_rx *r, int on, double release_gain) { r->agc_on = on; r->agc_gain = release_gain; }
 
 void qo_rx_set_filters(qo_rx *r, const double *fI, const double *fQ, int size)
 {
@@ -318,5 +397,9 @@ int qo_rx_process(qo_rx *r, double *x, int n)
     n = process_demodulate(r, x, r->dsamples, n);
     if (r->mode != QO_DGT_IQ)                                   /* "This mode is already stereo", quisk.c:2534 */
         for (i = 0; i < n; i++) { x[2 * i] = r->dsamples[i]; x[2 * i + 1] = r->dsamples[i]; }     /* quisk.c:2622-2627 */
+    if (r->agc_on) {                                            /* quisk.c:2686-2702; playback rate = decim_srate here */
+        if (!r->agc) r->agc = qo_agc_create(r->decim_srate, 0.7, 1.0);
+        qo_agc_process(r->agc, x, n, r->mode == QO_DGT_IQ, r->agc_gain);
+    }
     return n;
 }

@@ -5,7 +5,7 @@
  *   branch and its 6/5 x 4/5 rational stage) -> quisk_process_demodulate (quisk.c:1848-2160: CWL/CWU/LSB/USB/AM/FM/
  *   DGT-U/DGT-L/DGT-IQ/DGT-FM; IMD, FDV-U/L up to the audio, i.e. without the codec) with cRxFilterOut / dRxFilterOut
  *   (quisk.c:1182-1256) -> mono to both channels (quisk.c:2622-2627).
- * Stops before process_agc; squelch, auto-notch, noise blanker, test tone and key-down
+ * process_agc is restated too and can be switched on; squelch, auto-notch, noise blanker, test tone and key-down
  * handling are off, as they are by default.  The stages call the filter.c restatement (quisk_oracle.c), which is
  * pinned bit-exactly to the reference build; the control flow above them is PARITY UNPINNED (quisk.c needs
  * <fftw3.h>, quisk.c:6, and cannot be built here).
@@ -45,6 +45,15 @@ void qo_rx_set_filters(qo_rx *r, const double *filtI, const double *filtQ, int s
 /* in place on n interleaved complex samples; returns the number of 48 ksps output samples (may exceed n: the
  * buffer must hold max(n, returned)).  */
 int qo_rx_process(qo_rx *r, double *cSamples, int n);
+/* process_agc (quisk.c:2162-2287) as quisk_process_samples applies it to the playback stream (quisk.c:2686-2702):
+ * off by default here so that the stages can be checked without it; release_gain is set_agc's argument
+ * (agcReleaseGain, quisk.c:191,4543). */
+void qo_rx_set_agc(qo_rx *r, int on, double release_gain);
+/* The AGC alone: state for one stream. */
+typedef struct qo_agc qo_agc;
+qo_agc *qo_agc_create(int sample_rate, double max_out, double release_time);
+void qo_agc_free(qo_agc *a);
+void qo_agc_process(qo_agc *a, double *csamples, int count, int is_cpx, double release_gain);
 int qo_rx_decim_srate(const qo_rx *r);
 int qo_rx_filter_srate(const qo_rx *r);
 

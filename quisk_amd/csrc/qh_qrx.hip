@@ -93,9 +93,12 @@ struct Qrx {
     QFmParam fm_prm{};
     double2 *buf[2] = { nullptr, nullptr };
     long long buf_cap = 0;
+    qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = off
+    double agc_gain = 80.0;
 
     ~Qrx()
     {
+        if (agc) qh_qagc_destroy(agc);
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Step &s : steps) {
@@ -431,9 +434,26 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
         cur = dst; cur_stride = dst_stride; n = m;
         if (i != last) w ^= 1;
     }
+    if (q.agc && n > 0)
+        if (int rc = qh_qagc_process(q.agc, d_out, out_stride, n)) return rc;
     if (n_out) *n_out = n;
     QH_HIP(hipGetLastError());
     return QH_OK;
+}
+
+// process_agc as quisk_process_samples runs it on the playback stream: Agc1 = {0.7, ...} (quisk.c:2321), release
+// time 1.0 s (quisk.c:192), |z| for DGT-IQ and |Re z| otherwise (quisk.c:2686-2702), playback rate = decim rate
+int qh_qrx_set_agc(qh_qrx *h, int on, double release_gain)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    Qrx &q = h->q;
+    if (!on) { if (q.agc) { qh_qagc_destroy(q.agc); q.agc = nullptr; } return QH_OK; }
+    if (!q.agc) {
+        q.agc = qh_qagc_create(q.device, q.nch, q.decim_srate, 0.7, 1.0, is_iq(q.mode) ? 1 : 0, q.stream);
+        if (!q.agc) return QH_ERR_HIP;
+    }
+    q.agc_gain = release_gain;
+    return qh_qagc_set_gain(q.agc, -1, release_gain);
 }
 
 int qh_qrx_process_host(qh_qrx *h, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out)

@@ -112,6 +112,15 @@ def load():
     L.qh_unpack_iq_host.argtypes = [i, vp, ll, vp, i, ll, i, vp, ll, i]
     L.qh_rxa_process_packed.argtypes = [vp, vp, ll, vp, ll, vp, ll, i]
     L.qh_rxa_process_packed_host.argtypes = [vp, vp, ll, vp, ll, vp, ll, i]
+    L.qh_qagc_create.restype = vp
+    L.qh_qagc_create.argtypes = [i, i, i, C.c_double, C.c_double, i, vp]
+    L.qh_qagc_destroy.argtypes = [vp]
+    L.qh_qagc_destroy.restype = None
+    L.qh_qagc_set_gain.argtypes = [vp, i, C.c_double]
+    L.qh_qagc_reset.argtypes = [vp]
+    L.qh_qagc_process.argtypes = [vp, vp, ll, i]
+    L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
+    L.qh_qrx_set_agc.argtypes = [vp, i, C.c_double]
     L.qh_qrx_create_ex.restype = vp
     L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]
     L.qh_qrx_decim_rate.argtypes = [vp]

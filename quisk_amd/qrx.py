@@ -52,6 +52,10 @@ class QuiskRxBank:
             raise ValueError("The size of filters I and Q must be equal")
         check(self._L.qh_qrx_set_filters(self._h, ch, fI.ctypes.data, fQ.ctypes.data, fI.size))
 
+    def set_agc(self, on, release_gain=80.0):
+        """process_agc on the output like quisk_process_samples; release_gain is QS.set_agc's argument (quisk.c:4543)."""
+        check(self._L.qh_qrx_set_agc(self._h, 1 if on else 0, float(release_gain)))
+
     def out_count(self, n_in):
         return self._L.qh_qrx_out_count(self._h, n_in)
 
@@ -73,6 +77,41 @@ class QuiskRxBank:
     def close(self):
         if getattr(self, "_h", None):
             self._L.qh_qrx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QuiskAgc:
+    """process_agc (quisk.c:2162-2287) for `nch` streams; the first process call only initialises, as in the reference."""
+
+    def __init__(self, nch, sample_rate=48000, max_out=0.7, release_time=1.0, is_cpx=False, device=0, stream=None):
+        self._L = load()
+        self._h = self._L.qh_qagc_create(device, nch, sample_rate, max_out, release_time, 1 if is_cpx else 0, stream)
+        if not self._h:
+            raise QuiskHipError("qh_qagc_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch = nch
+
+    def set_agc(self, ch, release_gain):
+        check(self._L.qh_qagc_set_gain(self._h, ch, float(release_gain)))
+
+    def process_ptr(self, d_buf, stride, n):
+        check(self._L.qh_qagc_process(self._h, d_buf, stride, n))
+
+    def process_host(self, x):
+        buf = np.ascontiguousarray(x, dtype=np.complex128).copy()
+        if buf.ndim != 2 or buf.shape[0] != self.nch:
+            raise ValueError("expected [nch, n] complex128")
+        check(self._L.qh_qagc_process_host(self._h, buf.ctypes.data, buf.shape[1], buf.shape[1]))
+        return buf
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_qagc_destroy(self._h)
             self._h = None
 
     def __del__(self):
