@@ -15,6 +15,7 @@
 namespace qh {
 
 static constexpr double kTwoPiRef = 6.2831853071795864;     // wdsp/comm.h:147
+static constexpr double kPiRef = 3.1415926535897932;        // wdsp/comm.h:146
 
 struct AmParam {            // per engine (depends on the DSP rate only), init_amd wdsp/amd.c:86-89
     double mtauR, onem_mtauR, mtauI, onem_mtauI;
@@ -110,19 +111,21 @@ static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long lo
     PllState *sp = state + ch;
     double phs = sp->phs, fil_out = sp->fil_out, omega = sp->omega, fmdc = sp->fmdc;
     const double gain = again[ch];
+    // The reference forms det = atan2(c1, c0) of the sample rotated back by the VCO phase (fmd.c:151-158); that
+    // is arg(z) - phs wrapped to (-pi, pi].  arg(z) does not depend on the loop, so the 64 lanes take the atan2
+    // of their samples at once and the sequential part keeps ~7 dependent adds / FMAs per sample instead of a
+    // sincos and an atan2 (a PLL in lock is a contraction: the few-ulp difference in det does not accumulate).
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
         double2 z = make_double2(0, 0);
         if (lane < cnt) z = p[base + lane];
+        const double theta = atan2(z.y, z.x);
+        const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);     // "if both are zero, corr[0] = 1" -> det = 0
         double mine = 0.0;
         for (int i = 0; i < cnt; i++) {
-            const double I = __shfl(z.x, i, 64), Q = __shfl(z.y, i, 64);
-            double sn, cs;
-            sincos(phs, &sn, &cs);
-            double c0 = I * cs + Q * sn;
-            const double c1 = -I * sn + Q * cs;
-            if (c0 == 0.0 && c1 == 0.0) c0 = 1.0;
-            const double det = atan2(c1, c0);
+            double det = __shfl(theta, i, 64) - phs;        // theta in (-pi, pi], phs in [0, 2 pi)
+            if (det <= -kPiRef) det += kTwoPiRef;
+            if ((zero >> i) & 1ull) det = 0.0;
             const double del_out = fil_out;
             omega += q.g2 * det;
             if (omega < q.omega_min) omega = q.omega_min;
@@ -163,44 +166,23 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     double dsI = sp->dsI, dsQ = sp->dsQ;
     if (lane < 24) { fa[lane] = sp->a[lane]; fb[lane] = sp->b[lane]; fc[lane] = sp->c[lane]; fd[lane] = sp->d[lane]; }
     __syncthreads();
+    // Same split as in fm_pll_kernel: det = atan2(corr1, corr0) (amd.c:222-223) is arg(z) - phs, so the sequential
+    // part only carries the loop filter; each lane then forms the VCO products of ITS sample from the phase the
+    // loop had at that sample.  The fade leveler (two one-pole averages, amd.c:211-216) is solved by scans; only
+    // the sideband separator's all-pass chains (sbmode 1, 2) remain a per-sample loop.
+    const double pwR = lane_pow(q.mtauR, lane + 1), pwI = lane_pow(q.mtauI, lane + 1);
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
         double2 z = make_double2(0, 0);
         if (lane < cnt) z = p[base + lane];
-        double mine = 0.0;
+        const double theta = atan2(z.y, z.x);
+        const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);
+        double myphs = 0.0;
         for (int i = 0; i < cnt; i++) {
-            const double I = __shfl(z.x, i, 64), Q = __shfl(z.y, i, 64);
-            double sn, cs;
-            sincos(phs, &sn, &cs);
-            const double ai = I * cs, bi = I * sn, aq = Q * cs, bq = Q * sn;
-            double ai_ps = 0, bi_ps = 0, aq_ps = 0, bq_ps = 0;
-            if (sbmode != 0) {
-                fa[0] = dsI; fb[0] = bi; fc[0] = dsQ; fd[0] = aq;
-                dsI = ai; dsQ = bq;
-                for (int j = 0; j < STAGES; j++) {
-                    const int k = 3 * j;
-                    fa[k + 3] = c0[j] * (fa[k] - fa[k + 5]) + fa[k + 2];
-                    fb[k + 3] = c1[j] * (fb[k] - fb[k + 5]) + fb[k + 2];
-                    fc[k + 3] = c0[j] * (fc[k] - fc[k + 5]) + fc[k + 2];
-                    fd[k + 3] = c1[j] * (fd[k] - fd[k + 5]) + fd[k + 2];
-                }
-                ai_ps = fa[OUT_IDX]; bi_ps = fb[OUT_IDX]; bq_ps = fc[OUT_IDX]; aq_ps = fd[OUT_IDX];
-                for (int j = OUT_IDX + 2; j > 0; j--) { fa[j] = fa[j - 1]; fb[j] = fb[j - 1]; fc[j] = fc[j - 1]; fd[j] = fd[j - 1]; }
-            }
-            double corr0 = ai + bq;
-            const double corr1 = -bi + aq;
-            double audio;
-            if (sbmode == 1) audio = (ai_ps - bi_ps) + (aq_ps + bq_ps);
-            else if (sbmode == 2) audio = (ai_ps + bi_ps) - (aq_ps - bq_ps);
-            else audio = corr0;
-            if (levelfade) {
-                dc = q.mtauR * dc + q.onem_mtauR * audio;
-                dc_insert = q.mtauI * dc_insert + q.onem_mtauI * corr0;
-                audio += dc_insert - dc;
-            }
-            if (lane == i) mine = audio;
-            if (corr0 == 0.0 && corr1 == 0.0) corr0 = 1.0;
-            const double det = atan2(corr1, corr0);
+            if (lane == i) myphs = phs;
+            double det = __shfl(theta, i, 64) - phs;
+            if (det <= -kPiRef) det += kTwoPiRef;
+            if ((zero >> i) & 1ull) det = 0.0;
             const double del_out = fil_out;
             omega += q.g2 * det;
             if (omega < q.omega_min) omega = q.omega_min;
@@ -210,7 +192,41 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
             while (phs >= kTwoPiRef) phs -= kTwoPiRef;
             while (phs < 0.0) phs += kTwoPiRef;
         }
-        if (lane < cnt) p[base + lane] = make_double2(mine, mine);
+        double sn, cs;
+        sincos(myphs, &sn, &cs);
+        const double ai = z.x * cs, bi = z.x * sn, aq = z.y * cs, bq = z.y * sn;
+        const double corr0 = ai + bq;
+        double audio = corr0;
+        if (sbmode != 0) {
+            double mine = 0.0;
+            for (int i = 0; i < cnt; i++) {
+                const double ai_i = __shfl(ai, i, 64), bi_i = __shfl(bi, i, 64), aq_i = __shfl(aq, i, 64), bq_i = __shfl(bq, i, 64);
+                fa[0] = dsI; fb[0] = bi_i; fc[0] = dsQ; fd[0] = aq_i;
+                dsI = ai_i; dsQ = bq_i;
+                for (int j = 0; j < STAGES; j++) {
+                    const int k = 3 * j;
+                    fa[k + 3] = c0[j] * (fa[k] - fa[k + 5]) + fa[k + 2];
+                    fb[k + 3] = c1[j] * (fb[k] - fb[k + 5]) + fb[k + 2];
+                    fc[k + 3] = c0[j] * (fc[k] - fc[k + 5]) + fc[k + 2];
+                    fd[k + 3] = c1[j] * (fd[k] - fd[k + 5]) + fd[k + 2];
+                }
+                const double ai_ps = fa[OUT_IDX], bi_ps = fb[OUT_IDX], bq_ps = fc[OUT_IDX], aq_ps = fd[OUT_IDX];
+                for (int j = OUT_IDX + 2; j > 0; j--) { fa[j] = fa[j - 1]; fb[j] = fb[j - 1]; fc[j] = fc[j - 1]; fd[j] = fd[j - 1]; }
+                const double v = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
+                if (lane == i) mine = v;
+            }
+            audio = mine;
+        }
+        if (levelfade) {
+            // dc_i = mtauR dc_{i-1} + onem_mtauR audio_i ; dc_insert_i likewise on corr0 ; audio += dc_insert - dc
+            const bool live = lane < cnt;
+            const double dcs = scan_pole(live ? q.onem_mtauR * audio : 0.0, q.mtauR, lane) + pwR * dc;
+            const double dis = scan_pole(live ? q.onem_mtauI * corr0 : 0.0, q.mtauI, lane) + pwI * dc_insert;
+            audio += dis - dcs;
+            dc = __shfl(dcs, cnt - 1, 64);
+            dc_insert = __shfl(dis, cnt - 1, 64);
+        }
+        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
     }
     __syncthreads();
     if (lane == 0) {
