@@ -43,6 +43,15 @@ __device__ __forceinline__ double lane_pow(double x, int e)
 }
 
 // inclusive scan of v_i = m*v_{i-1} + u_i over the 64 lanes with zero carry-in: returns sum_j m^(i-j) u_j
+// Value of lane i for every lane, i wave-uniform: two v_readlane_b32 instead of the LDS-crossbar ds_bpermute that
+// __shfl compiles to (its ~100 cycles would sit in the critical path of every step of the sequential kernels).
+__device__ __forceinline__ double lane_bcast(double v, int i)
+{
+    const int u = __builtin_amdgcn_readfirstlane(i);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), u), hi = __builtin_amdgcn_readlane(__double2hiint(v), u);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double scan_pole(double u, double m, int lane)
 {
     double md = m;
@@ -76,8 +85,8 @@ static __global__ __launch_bounds__(64) void am_detect_kernel(double2 *buf, long
             double dc = scan_pole(prm.onem_mtauR * audio, prm.mtauR, lane) + pR * st.dc;
             double di = scan_pole(prm.onem_mtauI * audio, prm.mtauI, lane) + pI * st.dc_insert;
             audio += di - dc;
-            st.dc = __shfl(dc, cnt - 1, 64);
-            st.dc_insert = __shfl(di, cnt - 1, 64);
+            st.dc = lane_bcast(dc, cnt - 1);
+            st.dc_insert = lane_bcast(di, cnt - 1);
         }
         if (lane < cnt) p[i] = make_double2(audio, audio);
     }
@@ -101,6 +110,33 @@ struct PllState {
 
 struct SamChanParam { int sbmode, levelfade; };
 
+// The second-order loop of both PLL detectors (fmd.c:151-172, amd.c:222-232), 64 samples per call.
+// The reference forms det = atan2(c1, c0) of the sample rotated back by the VCO phase; that is arg(z) - phs wrapped
+// to (-pi, pi], and arg(z) does not depend on the loop: the lanes take the atan2 of their samples at once
+// (theta_t, in turns) and the sequential part carries the loop filter alone -- 9 dependent VALU operations per
+// sample with the phase kept in turns (wrap = x - rint(x), v_fract for the VCO) where the literal form needs a
+// sincos and an atan2.  A PLL in lock is a contraction, so the few-ulp difference in det does not accumulate
+// (tests compare after lock, like for every FFT-noise-driven acquisition).  Lane i receives the VCO phase that
+// sample i saw (turns) and the loop-filter output after sample i.
+struct PllLoop { double pt, fil_out, omega; };
+__device__ __forceinline__ void pll_run64(PllLoop &s, double theta_t, unsigned long long zero, int cnt, const PllParam &q,
+                                          int lane, double &my_pt, double &my_fil)
+{
+    const double g1t = q.g1 * kTwoPiRef, g2t = q.g2 * kTwoPiRef, inv = 1.0 / kTwoPiRef;
+    my_pt = 0.0; my_fil = 0.0;
+    for (int i = 0; i < cnt; i++) {
+        if (lane == i) my_pt = s.pt;
+        double d = lane_bcast(theta_t, i) - s.pt;           // (-1.5, 0.5] turns
+        d -= rint(d);
+        if ((zero >> i) & 1ull) d = 0.0;                    // "if both are zero, corr[0] = 1.0": det = 0
+        const double del_out = s.fil_out;
+        s.omega = fmin(fmax(__builtin_fma(g2t, d, s.omega), q.omega_min), q.omega_max);
+        s.fil_out = __builtin_fma(g1t, d, s.omega);
+        s.pt = __builtin_amdgcn_fract(__builtin_fma(del_out, inv, s.pt));
+        if (lane == i) my_fil = s.fil_out;
+    }
+}
+
 // FM discriminator: in place, z -> (audio, audio).  One wave per listed channel.
 static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                     PllState *state, const double *again, PllParam q)
@@ -109,37 +145,28 @@ static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long lo
     const int lane = threadIdx.x;
     double2 *p = buf + (long long)ch * stride;
     PllState *sp = state + ch;
-    double phs = sp->phs, fil_out = sp->fil_out, omega = sp->omega, fmdc = sp->fmdc;
+    PllLoop L{ sp->phs * (1.0 / kTwoPiRef), sp->fil_out, sp->omega };
+    double fmdc = sp->fmdc;
     const double gain = again[ch];
-    // The reference forms det = atan2(c1, c0) of the sample rotated back by the VCO phase (fmd.c:151-158); that
-    // is arg(z) - phs wrapped to (-pi, pi].  arg(z) does not depend on the loop, so the 64 lanes take the atan2
-    // of their samples at once and the sequential part keeps ~7 dependent adds / FMAs per sample instead of a
-    // sincos and an atan2 (a PLL in lock is a contraction: the few-ulp difference in det does not accumulate).
+    const double pw = lane_pow(q.mtau, lane + 1);
+    double2 znext = make_double2(0, 0);
+    if (lane < n) znext = p[lane];
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[base + lane];
-        const double theta = atan2(z.y, z.x);
-        const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);     // "if both are zero, corr[0] = 1" -> det = 0
-        double mine = 0.0;
-        for (int i = 0; i < cnt; i++) {
-            double det = __shfl(theta, i, 64) - phs;        // theta in (-pi, pi], phs in [0, 2 pi)
-            if (det <= -kPiRef) det += kTwoPiRef;
-            if ((zero >> i) & 1ull) det = 0.0;
-            const double del_out = fil_out;
-            omega += q.g2 * det;
-            if (omega < q.omega_min) omega = q.omega_min;
-            if (omega > q.omega_max) omega = q.omega_max;
-            fil_out = q.g1 * det + omega;
-            phs += del_out;
-            while (phs >= kTwoPiRef) phs -= kTwoPiRef;
-            while (phs < 0.0) phs += kTwoPiRef;
-            fmdc = q.mtau * fmdc + q.onem_mtau * fil_out;
-            const double audio = gain * (fil_out - fmdc);
-            if (lane == i) mine = audio;
-        }
-        if (lane < cnt) p[base + lane] = make_double2(mine, mine);
+        const double2 z = znext;                            // the next 64 samples travel while the loop below runs
+        znext = make_double2(0, 0);
+        if (base + 64 + lane < n) znext = p[base + 64 + lane];
+        const double theta_t = atan2(z.y, z.x) * (1.0 / kTwoPiRef);
+        const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);
+        double my_pt, fil;
+        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, fil);
+        // fmdc_i = mtau fmdc_{i-1} + onem_mtau fil_i (fmd.c:169), audio = again (fil - fmdc) (fmd.c:171): a scan
+        const double dcs = scan_pole(lane < cnt ? q.onem_mtau * fil : 0.0, q.mtau, lane) + pw * fmdc;
+        fmdc = lane_bcast(dcs, cnt - 1);
+        const double audio = gain * (fil - dcs);
+        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
     }
+    const double phs = L.pt * kTwoPiRef, fil_out = L.fil_out, omega = L.omega;
     if (lane == 0) { sp->phs = phs; sp->fil_out = fil_out; sp->omega = omega; sp->fmdc = fmdc; }
 }
 
@@ -162,7 +189,8 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     double2 *p = buf + (long long)ch * stride;
     PllState *sp = state + ch;
     const int sbmode = cprm[ch].sbmode, levelfade = cprm[ch].levelfade;
-    double phs = sp->phs, fil_out = sp->fil_out, omega = sp->omega, dc = sp->dc, dc_insert = sp->dc_insert;
+    PllLoop L{ sp->phs * (1.0 / kTwoPiRef), sp->fil_out, sp->omega };
+    double dc = sp->dc, dc_insert = sp->dc_insert;
     double dsI = sp->dsI, dsQ = sp->dsQ;
     if (lane < 24) { fa[lane] = sp->a[lane]; fb[lane] = sp->b[lane]; fc[lane] = sp->c[lane]; fd[lane] = sp->d[lane]; }
     __syncthreads();
@@ -171,27 +199,18 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     // loop had at that sample.  The fade leveler (two one-pole averages, amd.c:211-216) is solved by scans; only
     // the sideband separator's all-pass chains (sbmode 1, 2) remain a per-sample loop.
     const double pwR = lane_pow(q.mtauR, lane + 1), pwI = lane_pow(q.mtauI, lane + 1);
+    double2 znext = make_double2(0, 0);
+    if (lane < n) znext = p[lane];
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[base + lane];
-        const double theta = atan2(z.y, z.x);
+        const double2 z = znext;
+        znext = make_double2(0, 0);
+        if (base + 64 + lane < n) znext = p[base + 64 + lane];
+        const double theta_t = atan2(z.y, z.x) * (1.0 / kTwoPiRef);
         const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);
-        double myphs = 0.0;
-        for (int i = 0; i < cnt; i++) {
-            if (lane == i) myphs = phs;
-            double det = __shfl(theta, i, 64) - phs;
-            if (det <= -kPiRef) det += kTwoPiRef;
-            if ((zero >> i) & 1ull) det = 0.0;
-            const double del_out = fil_out;
-            omega += q.g2 * det;
-            if (omega < q.omega_min) omega = q.omega_min;
-            if (omega > q.omega_max) omega = q.omega_max;
-            fil_out = q.g1 * det + omega;
-            phs += del_out;
-            while (phs >= kTwoPiRef) phs -= kTwoPiRef;
-            while (phs < 0.0) phs += kTwoPiRef;
-        }
+        double my_pt, my_fil;
+        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, my_fil);
+        const double myphs = my_pt * kTwoPiRef;
         double sn, cs;
         sincos(myphs, &sn, &cs);
         const double ai = z.x * cs, bi = z.x * sn, aq = z.y * cs, bq = z.y * sn;
@@ -200,7 +219,7 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
         if (sbmode != 0) {
             double mine = 0.0;
             for (int i = 0; i < cnt; i++) {
-                const double ai_i = __shfl(ai, i, 64), bi_i = __shfl(bi, i, 64), aq_i = __shfl(aq, i, 64), bq_i = __shfl(bq, i, 64);
+                const double ai_i = lane_bcast(ai, i), bi_i = lane_bcast(bi, i), aq_i = lane_bcast(aq, i), bq_i = lane_bcast(bq, i);
                 fa[0] = dsI; fb[0] = bi_i; fc[0] = dsQ; fd[0] = aq_i;
                 dsI = ai_i; dsQ = bq_i;
                 for (int j = 0; j < STAGES; j++) {
@@ -223,14 +242,14 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
             const double dcs = scan_pole(live ? q.onem_mtauR * audio : 0.0, q.mtauR, lane) + pwR * dc;
             const double dis = scan_pole(live ? q.onem_mtauI * corr0 : 0.0, q.mtauI, lane) + pwI * dc_insert;
             audio += dis - dcs;
-            dc = __shfl(dcs, cnt - 1, 64);
-            dc_insert = __shfl(dis, cnt - 1, 64);
+            dc = lane_bcast(dcs, cnt - 1);
+            dc_insert = lane_bcast(dis, cnt - 1);
         }
         if (lane < cnt) p[base + lane] = make_double2(audio, audio);
     }
     __syncthreads();
     if (lane == 0) {
-        sp->phs = phs; sp->fil_out = fil_out; sp->omega = omega; sp->dc = dc; sp->dc_insert = dc_insert;
+        sp->phs = L.pt * kTwoPiRef; sp->fil_out = L.fil_out; sp->omega = L.omega; sp->dc = dc; sp->dc_insert = dc_insert;
         sp->dsI = dsI; sp->dsQ = dsQ;
     }
     if (lane < 24) { sp->a[lane] = fa[lane]; sp->b[lane] = fb[lane]; sp->c[lane] = fc[lane]; sp->d[lane] = fd[lane]; }
@@ -299,10 +318,10 @@ static __global__ __launch_bounds__(64) void snotch_kernel(double2 *buf, long lo
         const double ym1 = __shfl_up(y, 1, 64);
         // carry: the last valid sample's (x, y) pairs
         const int last = cnt - 1;
-        const double ny1 = __shfl(y, last, 64);
-        const double ny2 = last >= 1 ? __shfl(ym1, last, 64) : st.y1;
-        const double nx1 = __shfl(x0, last, 64);
-        const double nx2 = last >= 1 ? __shfl(xm1, last, 64) : st.x1;
+        const double ny1 = lane_bcast(y, last);
+        const double ny2 = last >= 1 ? lane_bcast(ym1, last) : st.y1;
+        const double nx1 = lane_bcast(x0, last);
+        const double nx2 = last >= 1 ? lane_bcast(xm1, last) : st.x1;
         st.x1 = nx1; st.x2 = nx2; st.y1 = ny1; st.y2 = ny2;
     }
     if (lane == 0) state[ch] = st;
@@ -339,7 +358,7 @@ static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, lo
             double smag = 0.0;
             if (lane < cnt) { const double2 z = p[(long long)b * size + base + lane]; smag = z.x * z.x + z.y * z.y; }
             const double a = scan_pole((1.0 - q.mult_average) * smag, q.mult_average, lane) + pw * st.avg;
-            st.avg = __shfl(a, cnt - 1, 64);
+            st.avg = lane_bcast(a, cnt - 1);
             np = fmax(np, wave_max_d(smag));
         }
         st.peak *= pk_blk;
@@ -392,7 +411,7 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
         if (lane < cnt) z = p[base + lane];
         double2 mine = make_double2(0, 0);
         for (int i = 0; i < cnt; i++) {
-            const double I = __shfl(z.x, i, 64), Q = __shfl(z.y, i, 64);
+            const double I = lane_bcast(z.x, i), Q = lane_bcast(z.y, i);
             out_index = (out_index + 1) & (kAgcRing - 1);
             const int in_index = (out_index + A) & (kAgcRing - 1);
             const double2 o = ring[out_index];
@@ -472,7 +491,7 @@ static __global__ __launch_bounds__(64) void q_am_env_kernel(double2 *buf, long 
         if (lane == 0) prev = carry;
         const double out = dc - prev;
         if (lane < cnt) p[base + lane] = make_double2(out, out);
-        carry = __shfl(dc, cnt - 1, 64);
+        carry = lane_bcast(dc, cnt - 1);
     }
     if (lane == 0) dc_state[ch] = carry;
 }
@@ -502,8 +521,8 @@ static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long
         const double y = scan_pole(u, pole, lane) + pw * st.w;
         if (lane < cnt) p[base + lane] = make_double2(y, 0.0);
         const int last = cnt - 1;
-        st.x = __shfl(z.x, last, 64); st.y = __shfl(z.y, last, 64);
-        st.z = __shfl(di, last, 64); st.w = __shfl(y, last, 64);
+        st.x = lane_bcast(z.x, last); st.y = lane_bcast(z.y, last);
+        st.z = lane_bcast(di, last); st.w = lane_bcast(y, last);
     }
     if (lane == 0) state[ch] = st;
 }

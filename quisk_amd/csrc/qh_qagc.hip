@@ -16,6 +16,14 @@ namespace {
 
 constexpr double kClip32 = 2147483647.0;      // CLIP32, quisk.h:13
 
+// value of lane i (wave-uniform) for every lane: v_readlane, not the LDS crossbar of __shfl
+__device__ __forceinline__ double lane_bcast(double v, int i)
+{
+    const int u = __builtin_amdgcn_readfirstlane(i);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), u), hi = __builtin_amdgcn_readlane(__double2hiint(v), u);
+    return __hiloint2double(hi, lo);
+}
+
 struct QAgcParam { double limit /* max_out * CLIP32 */, time_release; int buf_size, is_cpx; };
 struct QAgcState { int index_read, index_start, is_clipping, pad; double themax, gain, delta, target_gain; };
 
@@ -45,7 +53,7 @@ __global__ __launch_bounds__(64) void q_agc_kernel(double2 *buf, long long strid
         const double bm = q.is_cpx ? hypot(z.x, z.y) : fabs(z.x);
         double mygain = 0.0;
         for (int i = 0; i < cnt; i++) {              // uniform: every lane steps the same state
-            const double b = __shfl(bm, i, 64);
+            const double b = lane_bcast(bm, i);
             if (lane == i) mygain = st.gain;
             int ir = st.index_read + i;
             if (ir >= B) ir -= B;
