@@ -3,13 +3,16 @@
 // for `nch` receivers at once and for EVERY completed block (the reference drops blocks when its 4-deep ring
 // is full).
 //
-// fft_size N = R * M with M in {1024, 2048, 4096} (an LDS-resident FFT, qh_fft.hpp) and R in {1, 2, 4}:
-//   pan_fft_kernel    one workgroup per (block, channel): for r = 0..R-1 the decimated sequence x[R*m + r]
-//                     times the Hanning window (quisk.c:6008) goes through FFT-M; Y_r is parked in a scratch
-//                     buffer (L2 resident).  The R strided passes re-read the block from L2, not from HBM.
-//   pan_accum_kernel  one thread per (channel, bin k < M): X[k + M*q] = sum_r W_R^(r*q) * (W_N^(r*k) * Y_r[k]),
-//                     then fft_avg[(bin + N/2) mod N] += |X| and the RMS S-meter sum over the passband bins
-//                     (quisk.c:5218-5244), looping over the blocks so that no atomics touch fft_avg.
+// fft_size N = R * M with M in {1024, 2048, 4096} (an LDS-resident FFT, qh_fft.hpp) and R in {1, 2, 4}, split by
+// decimation in FREQUENCY so that every load is contiguous:
+//     X[R k + r] = FFT_M{ W_N^(m r) * sum_q W_R^(q r) x[m + M q] w[m + M q] }[k]
+//   pan_spectrum_kernel  one workgroup per (r, block range, channel): per block the R strips x[m + M q] times the
+//                     Hanning window (quisk.c:6008) are combined for this r, twiddled, put through FFT-M, and
+//                     |X| is added to per-lane accumulators kept in registers over the workgroup's blocks; so is
+//                     the RMS S-meter sum over the passband bins (quisk.c:5218-5244).  Each block is read by the R
+//                     workgroups of its r values; the re-reads come from L2 / Infinity Cache.
+//   pan_reduce_kernel the partial sums of the block ranges are added into fft_avg[(bin + N/2) mod N] in a fixed
+//                     order (no atomics: results do not depend on scheduling).
 //   pan_graph_kernel  the refresh branch (quisk.c:5279-5327): n-bin box sums per pixel done IN PLACE on fft_avg
 //                     in pixel order like the reference (a later pixel can see an earlier pixel's sum when
 //                     zoomed in), dB scale, clamp to [-200, 0], S-meter in dB.  Tiny: one thread per channel.
@@ -21,92 +24,144 @@
 
 namespace qh {
 
-template <int M>
-__global__ __launch_bounds__(NT) void pan_fft_kernel(const double2 *in, long long in_stride, long long blk_stride, int R,
-                                                     const double *window, const double2 *tw, double2 *scratch,
-                                                     long long scr_chan_stride)
+struct PanBand { int first, nwhole; double frac; int valid, pad; };     // S-meter passband in bins, quisk.c:5223-5244
+
+template <int M, int R>
+__global__ __launch_bounds__(NT, 2) void pan_spectrum_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
+                                                          const double *window, const double2 *tw, double *partial,
+                                                          double *partial_m2, const PanBand *band, int nch)
 {
     using C = double2;
+    using F = TileFft<M, false, C>;
     constexpr int E = M / NT;
     extern __shared__ __align__(16) unsigned char smem[];
-    C *lds = reinterpret_cast<C *>(smem);
-    const int t = threadIdx.x, blk = blockIdx.x, ch = blockIdx.y;
-    const C *x = in + (long long)ch * in_stride + (long long)blk * blk_stride;
-    C *y = scratch + (long long)ch * scr_chan_stride + (long long)blk * R * M;
-    const typename FftRR<M, false, C>::Tw twf = FftRR<M, false, C>::load(tw);
-    for (int r = 0; r < R; r++) {
-        C v[E];
+    __shared__ double wsum[NT / 64];
+    // Workgroup ids go round the 8 XCDs (each with its own L2): the R workgroups that read the same blocks are
+    // given ids 8 apart, so they land on ONE XCD at about the same time and share its L2 (id = 8 R g + 8 r + x,
+    // unit = 8 g + x; units beyond nsplit * nch are padding).
+    const int t = threadIdx.x;
+    const int id = blockIdx.x, grp = id / (8 * R), r = (id / 8) % R, unit = grp * 8 + id % 8;
+    if (unit >= nsplit * nch) return;
+    const int split = unit % nsplit, ch = unit / nsplit;
+    const int N = M * R;
+    const int per = (nblk + nsplit - 1) / nsplit;
+    const int b0 = split * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    const typename F::Tw twf = F::load(tw);
+    // W_N^(r m), m = t + NT i:  w0 * step^i
+    C w0, step;
+    sincospi(-2.0 * (double)r * (double)t / (double)N, &w0.y, &w0.x);
+    sincospi(-2.0 * (double)r * (double)NT / (double)N, &step.y, &step.x);
+    C e0, estep;                                                // exp(-2 pi i m / N) for the window
+    sincospi(-2.0 * (double)t / (double)N, &e0.y, &e0.x);
+    sincospi(-2.0 * (double)NT / (double)N, &estep.y, &estep.x);
+    const double sgn = (r & 1) ? -1.0 : 1.0;
+    const C tau = r == 0 ? mk<double>(1, 0) : r == 1 ? mk<double>(0, -1) : r == 2 ? mk<double>(-1, 0) : mk<double>(0, 1);
+    // weight of this lane's bins in the S-meter sum
+    const PanBand pb = band[ch];
+    // the |X| accumulators of this lane's E bins live in LDS behind the FFT image (32 more registers would spill)
+    double *acc = reinterpret_cast<double *>(smem + F::kLdsBytes) + t;
+    double m2 = 0.0;
+    unsigned whole = 0, part = 0;           // bit i: bin i of this lane counts fully / with weight frac
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int bin = R * (t + NT * i) + r;
+        const int sb = bin >= N / 2 ? bin - N : bin;            // signed bin
+        if (pb.valid) {
+            if (sb >= pb.first && sb < pb.first + pb.nwhole) whole |= 1u << i;
+            else if (sb == pb.first + pb.nwhole) part |= 1u << i;
+        }
+        acc[NT * i] = 0.0;
+    }
+    for (int blk = b0; blk < b1; blk++) {
+        const C *x = in + (long long)ch * in_stride + (long long)blk * N;
+        asm volatile("" : "+s"(x));         // keeps the R E per-lane load addresses from being precomputed and spilled
+        C u[E];
+        C w = w0, e = e0;
+        // ... and the window / twiddle recurrences from being hoisted out of the block loop as 5 E live values
+        asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(w.x), "+v"(w.y));
 #pragma unroll
         for (int i = 0; i < E; i++) {
-            const int n = R * (t + NT * i) + r;
-            const double w = window[n];
-            C s = x[n];
-            v[i].x = s.x * w; v[i].y = s.y * w;
-        }
-        FftRR<M, false, C>::first(v, lds);
-        FftRR<M, false, C>::rest(lds, v, twf);
+            // Hanning window 0.5 - 0.5 cos(2 pi n / N) (quisk.c:6008) at n = m + M q from e = exp(-2 pi i m / N):
+            // cos(a + pi q / 2) and cos(a + pi q) are +-cos a, +-sin a -- no table loads
+            double g[4];
+            if constexpr (R == 4) {
+                g[0] = __builtin_fma(-0.5, e.x, 0.5); g[2] = __builtin_fma(0.5, e.x, 0.5);
+                g[1] = __builtin_fma(-0.5, e.y, 0.5); g[3] = __builtin_fma(0.5, e.y, 0.5);
+            } else {
+                g[0] = __builtin_fma(-0.5, e.x, 0.5); g[1] = __builtin_fma(0.5, e.x, 0.5); g[2] = g[3] = 0.0;
+            }
+            C v[4];
 #pragma unroll
-        for (int i = 0; i < E; i++) y[(long long)r * M + t + NT * i] = v[i];
-        __syncthreads();
+            for (int q = 0; q < 4; q++) {
+                if (q < R) {
+                    const C sx = (x + (NT * i + M * q))[t];         // wave-uniform base + the lane index
+                    v[q] = mk<double>(sx.x * g[q], sx.y * g[q]);
+                } else {
+                    v[q] = mk<double>(0, 0);
+                }
+            }
+            // sum_q W_R^(q r) v_q with wave-uniform factors instead of branches on r:
+            //   R = 4:  (v0 + s v2) + tau (v1 + s v3),  s = (-1)^r,  tau = (-i)^r;   R = 2:  v0 + s v1
+            C o;
+            if constexpr (R == 1) {
+                o = v[0];
+            } else if constexpr (R == 2) {
+                o = mk<double>(__builtin_fma(sgn, v[1].x, v[0].x), __builtin_fma(sgn, v[1].y, v[0].y));
+            } else {
+                const C a = mk<double>(__builtin_fma(sgn, v[2].x, v[0].x), __builtin_fma(sgn, v[2].y, v[0].y));
+                const C c = mk<double>(__builtin_fma(sgn, v[3].x, v[1].x), __builtin_fma(sgn, v[3].y, v[1].y));
+                o = mk<double>(a.x + (c.x * tau.x - c.y * tau.y), a.y + (c.x * tau.y + c.y * tau.x));
+            }
+            u[i] = cmul(o, w);
+            w = cmul(w, step);
+            e = cmul(e, estep);
+            // four elements' worth of loads (16 + 16) in flight at a time: hoisting all 128 costs 400 registers
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        F::run(u, smem, twf);
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
+            acc[NT * i] += sqrt(pw2);       // cabs(): no overflow / underflow concern at +-2^31 * N full scale
+            m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
+        }
+        __syncthreads();                    // the LDS image is free for the next block
+    }
+    // partial[split][ch][(bin + N/2) mod N]
+    double *pp = partial + ((long long)split * nch + ch) * N;
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int bin = R * (t + NT * i) + r;
+        pp[(bin + N / 2) % N] = acc[NT * i];
+    }
+    // S-meter partial: lanes -> wave -> workgroup, fixed order
+    for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = m2;
+    __syncthreads();
+    if (t == 0) {
+        double sm = 0.0;
+        for (int k = 0; k < NT / 64; k++) sm += wsum[k];
+        partial_m2[((long long)split * nch + ch) * R + r] = sm;
     }
 }
 
-struct PanBand { int first, nwhole; double frac; int valid, pad; };     // S-meter passband in bins, quisk.c:5223-5244
-
-__global__ __launch_bounds__(NT) void pan_accum_kernel(const double2 *scratch, long long scr_chan_stride, int nblk, int M,
-                                                       int R, double *avg, double *meter, const PanBand *band)
+// fft_avg += sum over the block ranges; meter += sum over ranges and r.  One thread per (channel, index).
+__global__ __launch_bounds__(NT) void pan_reduce_kernel(const double *partial, const double *partial_m2, int nsplit, int N, int R,
+                                                        double *avg, double *meter)
 {
-    const int ch = blockIdx.y;
-    const int k = blockIdx.x * NT + threadIdx.x;
-    if (k >= M) return;
-    const int N = M * R;
-    const double2 *y = scratch + (long long)ch * scr_chan_stride;
-    const PanBand pb = band[ch];
-    // W_N^(r*k), r = 1..R-1
-    double2 w[4];
-    w[0] = make_double2(1.0, 0.0);
-    for (int r = 1; r < R; r++) {
-        double s, c;
-        sincospi(-2.0 * (double)r * (double)k / (double)N, &s, &c);
-        w[r] = make_double2(c, s);
+    const int ch = blockIdx.y, nch = gridDim.y;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx < N) {
+        double sacc = 0.0;
+        for (int sp = 0; sp < nsplit; sp++) sacc += partial[((long long)sp * nch + ch) * N + idx];
+        avg[(long long)ch * N + idx] += sacc;
     }
-    double acc[4] = { 0, 0, 0, 0 }, m2 = 0.0;
-    // weight of bin b in the S-meter sum
-    double wt[4];
-    for (int q = 0; q < R; q++) {
-        const int b = k + M * q;
-        const int sb = b >= N / 2 ? b - N : b;              // signed bin
-        double v = 0.0;
-        if (pb.valid) {
-            if (sb >= pb.first && sb < pb.first + pb.nwhole) v = 1.0;
-            else if (sb == pb.first + pb.nwhole) v = pb.frac;
-        }
-        wt[q] = v;
+    if (idx == 0) {
+        double sm = 0.0;
+        for (int sp = 0; sp < nsplit; sp++)
+            for (int r = 0; r < R; r++) sm += partial_m2[((long long)sp * nch + ch) * R + r];
+        meter[ch] += sm;
     }
-    for (int blk = 0; blk < nblk; blk++) {
-        const double2 *yb = y + (long long)blk * N;
-        double2 z[4];
-        for (int r = 0; r < R; r++) z[r] = cmul(yb[(long long)r * M + k], w[r]);
-        double2 X[4];
-        if (R == 1) {
-            X[0] = z[0];
-        } else if (R == 2) {
-            X[0] = cadd(z[0], z[1]); X[1] = csub(z[0], z[1]);
-        } else {
-            const double2 a = cadd(z[0], z[2]), b = csub(z[0], z[2]), c = cadd(z[1], z[3]);
-            const double2 d = mul_mi<false>(csub(z[1], z[3]));      // * (-i)
-            X[0] = cadd(a, c); X[2] = csub(a, c); X[1] = cadd(b, d); X[3] = csub(b, d);
-        }
-        for (int q = 0; q < R; q++) {
-            acc[q] += hypot(X[q].x, X[q].y);
-            m2 += wt[q] * (X[q].x * X[q].x + X[q].y * X[q].y);
-        }
-    }
-    for (int q = 0; q < R; q++) {
-        const int b = k + M * q;
-        avg[(long long)ch * N + ((b + N / 2) % N)] += acc[q];
-    }
-    if (m2 != 0.0) atomicAdd(meter + ch, m2);
 }
 
 __global__ void pan_graph_kernel(double *avg, double *meter, int nch, int N, int data_width, double rate, double zoom,
@@ -154,36 +209,50 @@ struct Pan {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double *window = nullptr, *avg = nullptr, *meter = nullptr, *pixels = nullptr, *smeter = nullptr;
-    double2 *tw = nullptr, *carry = nullptr, *scratch = nullptr;
+    double2 *tw = nullptr, *carry = nullptr;
+    double *partial = nullptr, *partial_m2 = nullptr;
     PanBand *band = nullptr;
     std::vector<PanBand> hband;
-    int fill = 0, count = 0, chunk_blocks = 0;
+    int fill = 0, count = 0, max_split = 1;
 
     ~Pan()
     {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         (void)hipFree(window); (void)hipFree(avg); (void)hipFree(meter); (void)hipFree(pixels); (void)hipFree(smeter);
-        (void)hipFree(tw); (void)hipFree(carry); (void)hipFree(scratch); (void)hipFree(band);
+        (void)hipFree(tw); (void)hipFree(carry); (void)hipFree(partial); (void)hipFree(partial_m2); (void)hipFree(band);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+
+    template <int MM, int RR> void launch2(const double2 *p, long long src_stride, int nblk, int nsplit)
+    {
+        constexpr int lds = TileFft<MM, false, double2>::kLdsBytes + MM * 8;
+        const int units = nsplit * nch, groups = (units + 7) / 8;
+        hipLaunchKernelGGL((pan_spectrum_kernel<MM, RR>), dim3((unsigned)(groups * 8 * RR)), dim3(NT), lds, stream, p, src_stride, nblk,
+                           nsplit, window, tw, partial, partial_m2, band, nch);
+    }
+    template <int MM> void launch(const double2 *p, long long src_stride, int nblk, int nsplit)
+    {
+        if (R == 1) launch2<MM, 1>(p, src_stride, nblk, nsplit);
+        else if (R == 2) launch2<MM, 2>(p, src_stride, nblk, nsplit);
+        else launch2<MM, 4>(p, src_stride, nblk, nsplit);
     }
 
     int run_blocks(const double2 *src, long long src_stride, long long off, int nblk)
     {
-        const int lds = (M + M / 16) * (int)sizeof(double2);
-        for (int done = 0; done < nblk; done += chunk_blocks) {
-            const int nb = nblk - done < chunk_blocks ? nblk - done : chunk_blocks;
-            const double2 *p = src + off + (long long)done * N;
-            dim3 g((unsigned)nb, (unsigned)nch);
-            const long long scs = (long long)chunk_blocks * N;
-            switch (M) {
-            case 1024: hipLaunchKernelGGL(pan_fft_kernel<1024>, g, dim3(NT), lds, stream, p, src_stride, (long long)N, R, window, tw, scratch, scs); break;
-            case 2048: hipLaunchKernelGGL(pan_fft_kernel<2048>, g, dim3(NT), lds, stream, p, src_stride, (long long)N, R, window, tw, scratch, scs); break;
-            default:   hipLaunchKernelGGL(pan_fft_kernel<4096>, g, dim3(NT), lds, stream, p, src_stride, (long long)N, R, window, tw, scratch, scs); break;
-            }
-            hipLaunchKernelGGL(pan_accum_kernel, dim3((unsigned)((M + NT - 1) / NT), (unsigned)nch), dim3(NT), 0, stream, scratch,
-                               scs, nb, M, R, avg, meter, band);
+        // enough workgroups to fill the chip (>= 1024) but no more block ranges than blocks
+        int nsplit = (1024 + R * nch - 1) / (R * nch);
+        if (nsplit > nblk) nsplit = nblk;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+        const double2 *p = src + off;
+        switch (M) {
+        case 1024: launch<1024>(p, src_stride, nblk, nsplit); break;
+        case 2048: launch<2048>(p, src_stride, nblk, nsplit); break;
+        default:   launch<4096>(p, src_stride, nblk, nsplit); break;
         }
+        hipLaunchKernelGGL(pan_reduce_kernel, dim3((unsigned)((N + NT - 1) / NT), (unsigned)nch), dim3(NT), 0, stream, partial, partial_m2,
+                           nsplit, N, R, avg, meter);
         count += nblk;
         QH_HIP(hipGetLastError());
         return QH_OK;
@@ -219,10 +288,9 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
     auto fail = [&](const char *what) -> qh_pan * { set_error(QH_ERR_HIP, "qh_pan_create: %s failed", what); delete h; return nullptr; };
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice");
     if (!p.stream) { if (hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess) return fail("stream"); p.own_stream = true; }
-    // scratch for at most ~256 MiB of sub-FFT results per pass
-    p.chunk_blocks = (int)((256ll << 20) / ((long long)nch * fft_size * 16));
-    if (p.chunk_blocks < 1) p.chunk_blocks = 1;
-    if (p.chunk_blocks > 64) p.chunk_blocks = 64;
+    // partial sums: one fft_avg image per block range of a call
+    p.max_split = (1024 + R * nch - 1) / (R * nch);
+    if (p.max_split < 1) p.max_split = 1;
     std::vector<double> win((size_t)fft_size);
     for (int i = 0, j = -fft_size / 2; i < fft_size; i++, j++)      // Hanning, quisk.c:6008
         win[(size_t)i] = 0.5 + 0.5 * std::cos(2. * M_PI * j / fft_size);
@@ -232,7 +300,8 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
         hipMalloc((void **)&p.avg, (size_t)nch * fft_size * 8) != hipSuccess || hipMalloc((void **)&p.meter, (size_t)nch * 8) != hipSuccess ||
         hipMalloc((void **)&p.pixels, (size_t)nch * data_width * 8) != hipSuccess || hipMalloc((void **)&p.smeter, (size_t)nch * 8) != hipSuccess ||
         hipMalloc((void **)&p.carry, (size_t)nch * fft_size * 16) != hipSuccess ||
-        hipMalloc((void **)&p.scratch, (size_t)nch * p.chunk_blocks * fft_size * 16) != hipSuccess ||
+        hipMalloc((void **)&p.partial, (size_t)p.max_split * nch * fft_size * 8) != hipSuccess ||
+        hipMalloc((void **)&p.partial_m2, (size_t)p.max_split * nch * R * 8) != hipSuccess ||
         hipMalloc((void **)&p.band, (size_t)nch * sizeof(PanBand)) != hipSuccess)
         return fail("hipMalloc");
     if (hipMemcpy(p.window, win.data(), win.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
@@ -240,13 +309,13 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
         hipMemcpy(p.band, p.hband.data(), (size_t)nch * sizeof(PanBand), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(p.avg, 0, (size_t)nch * fft_size * 8) != hipSuccess || hipMemset(p.meter, 0, (size_t)nch * 8) != hipSuccess)
         return fail("initial copies");
-    const int lds = (M + M / 16) * (int)sizeof(double2);
     hipError_t e = hipSuccess;
-    switch (M) {
-    case 1024: e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pan_fft_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-    case 2048: e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pan_fft_kernel<2048>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-    default:   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pan_fft_kernel<4096>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-    }
+#define QH_PAN_ATTR(MM, RR) if (M == MM && R == RR) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pan_spectrum_kernel<MM, RR>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (TileFft<MM, false, double2>::kLdsBytes + MM * 8))
+    QH_PAN_ATTR(1024, 1); QH_PAN_ATTR(1024, 2); QH_PAN_ATTR(1024, 4);
+    QH_PAN_ATTR(2048, 1); QH_PAN_ATTR(2048, 2); QH_PAN_ATTR(2048, 4);
+    QH_PAN_ATTR(4096, 1); QH_PAN_ATTR(4096, 2); QH_PAN_ATTR(4096, 4);
+#undef QH_PAN_ATTR
     if (e != hipSuccess) return fail("hipFuncSetAttribute");
     return h;
 }
