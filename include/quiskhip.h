@@ -77,6 +77,7 @@ int qh_rxa_SetRXAPanelGain2(qh_rxa *e, int ch, double gainI, double gainQ);
 int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
 int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
 int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
+int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
 int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *e, int ch, int levelfade);
 int qh_rxa_SetRXAFMDeviation(qh_rxa *e, int ch, double deviation);
 int qh_rxa_SetRXACTCSSFreq(qh_rxa *e, int ch, double freq);
@@ -123,6 +124,7 @@ void OpenChannel(int channel, int in_size, int dsp_size, int input_samplerate, i
 void CloseChannel(int channel);                                                  /* wdsp/channel.c:122-128 */
 int SetChannelState(int channel, int state, int dmode);                          /* wdsp/channel.c:260-298 */
 void fexchange0(int channel, double *in, double *out, int *error);               /* wdsp/iobuffs.c:464-516 */
+void fexchange2(int channel, float *Iin, float *Qin, float *Iout, float *Qout, int *error);     /* wdsp/iobuffs.c:518-582 */
 void SetRXAMode(int channel, int mode);                                          /* wdsp/RXA.c:748-787 */
 void RXASetPassband(int channel, double f_low, double f_high);                   /* wdsp/RXA.c:926-932 */
 void RXASetNC(int channel, int nc);                                              /* wdsp/RXA.c:934-946 */
@@ -147,6 +149,7 @@ void SetRXAPanelGain2(int channel, double gainI, double gainQ);                 
 void SetRXAPanelSelect(int channel, int select);                                 /* wdsp/patchpanel.c:131-137 */
 void SetRXAPanelCopy(int channel, int copy);                                     /* wdsp/patchpanel.c:175-181 */
 void SetRXAAMDSBMode(int channel, int sbmode);                                   /* wdsp/amd.c:277-283 */
+void SetRXAAMDRun(int channel, int run);                                         /* wdsp/amd.c:264-277 */
 void SetRXAAMDFadeLevel(int channel, int levelfade);                             /* wdsp/amd.c:285-291 */
 void SetRXAFMDeviation(int channel, double deviation);                           /* wdsp/fmd.c:236-246 */
 void SetRXACTCSSFreq(int channel, double freq);                                  /* wdsp/fmd.c:248-258 */
@@ -160,6 +163,7 @@ void qh_wdsp_set_parameter(int channel, int in_size, int in_use);
 /* accepted and ignored: these blocks are run = 0 on the hot path */
 void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c */
 void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */
+void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */
 void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c */
 
 /* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */

@@ -1130,6 +1130,15 @@ void wo_SetRXAPanelGain2(wo_channel *c, double gainI, double gainQ) { c->panel.g
 void wo_SetRXAPanelSelect(wo_channel *c, int select) { c->panel.inselect = select; }
 void wo_SetRXAPanelCopy(wo_channel *c, int copy) { c->panel.copy = copy; }
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode) { c->amd.sbmode = sbmode; }
+
+void wo_SetRXAAMDRun(wo_channel *c, int run)        /* amd.c:264-277 */
+{
+    if (c->amd.run != run) {
+        bp1_check(c, run);
+        c->amd.run = run;
+        bp1_set(c);
+    }
+}
 void wo_SetRXAAMDFadeLevel(wo_channel *c, int levelfade) { c->amd.levelfade = levelfade; }
 
 void wo_SetRXAFMDeviation(wo_channel *c, double deviation)

@@ -73,6 +73,7 @@ void wo_SetRXAPanelGain2(wo_channel *c, double gainI, double gainQ);
 void wo_SetRXAPanelSelect(wo_channel *c, int select);
 void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
+void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
 void wo_SetRXAAMDFadeLevel(wo_channel *c, int levelfade);       /* amd.c:267-273 */
 void wo_SetRXAFMDeviation(wo_channel *c, double deviation);     /* fmd.c:236-246 */
 void wo_SetRXACTCSSFreq(wo_channel *c, double freq);            /* fmd.c:248-258 */

@@ -821,6 +821,21 @@ int qh_rxa_SetRXAMode(qh_rxa *h, int ch, int mode)
     });
 }
 
+// SetRXAAMDRun (wdsp/amd.c:264-277): the AM demodulator's run flag on its own (SetRXAMode sets it from the mode)
+int qh_rxa_SetRXAAMDRun(qh_rxa *h, int ch, int run)
+{
+    FOR_CH(h, ch, {
+        run = run ? 1 : 0;
+        if (c.amd_run != run) {
+            bp1_check_set(c, run);
+            c.amd_run = run;
+            bp1_set(c);
+            c.epi_dirty = true;
+            h->e.lists_dirty = true;
+        }
+    });
+}
+
 int qh_rxa_SetRXABandpassFreqs(qh_rxa *h, int ch, double f_low, double f_high)
 {
     FOR_CH(h, ch, {

@@ -382,6 +382,7 @@ void SetRXAPanelGain2(int channel, double gainI, double gainQ) { WDSP_SETTER(qh_
 void SetRXAPanelSelect(int channel, int select) { WDSP_SETTER(qh_rxa_SetRXAPanelSelect(L.c->eng, 0, select)); }
 void SetRXAPanelCopy(int channel, int copy) { WDSP_SETTER(qh_rxa_SetRXAPanelCopy(L.c->eng, 0, copy)); }
 void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMode(L.c->eng, 0, sbmode)); }
+void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
 void SetRXAAMDFadeLevel(int channel, int levelfade) { WDSP_SETTER(qh_rxa_SetRXAAMDFadeLevel(L.c->eng, 0, levelfade)); }
 void SetRXAFMDeviation(int channel, double deviation) { WDSP_SETTER(qh_rxa_SetRXAFMDeviation(L.c->eng, 0, deviation)); }
 void SetRXACTCSSFreq(int channel, double freq) { WDSP_SETTER(qh_rxa_SetRXACTCSSFreq(L.c->eng, 0, freq)); }
@@ -456,6 +457,28 @@ void RXASetMP(int channel, int mp)
         if (!valid(channel)) return;                                                               \
         if (run) g_status = qh::set_error(QH_ERR_UNSUPPORTED, #name "(%d, 1): block is outside the GPU hot path", channel); \
     }
+// SetRXAEMNRgainMethod (wdsp/emnr.c:1112): a parameter of the noise-reduction block, which never runs here
+void SetRXAEMNRgainMethod(int channel, int method) { (void)method; g_status = QH_OK; (void)valid(channel); }
+
+// fexchange2 (wdsp/iobuffs.c:518-582): the same exchange with separate float I and Q buffers (INREAL / OUTREAL are
+// float, wdsp/comm.h:119-120); upslew2 / downslew2 are the slews of fexchange0 on that layout
+void fexchange2(int channel, float *Iin, float *Qin, float *Iout, float *Qout, int *error)
+{
+    g_status = QH_OK;
+    *error = 0;
+    int in_size = 0, out_size = 0;
+    {
+        Locked L(channel);
+        if (!L.c) { *error = -1; return; }
+        if (!L.c->exchange) return;                 // outputs are left untouched, like fexchange0
+        in_size = L.c->in_size; out_size = L.c->out_size;
+    }
+    std::vector<double> in((size_t)in_size * 2), out((size_t)out_size * 2);
+    for (int i = 0; i < in_size; i++) { in[2 * (size_t)i] = (double)Iin[i]; in[2 * (size_t)i + 1] = (double)Qin[i]; }
+    fexchange0(channel, in.data(), out.data(), error);
+    for (int i = 0; i < out_size; i++) { Iout[i] = (float)out[2 * (size_t)i]; Qout[i] = (float)out[2 * (size_t)i + 1]; }
+}
+
 WDSP_OFF_ONLY(SetRXAAMSQRun)
 WDSP_OFF_ONLY(SetRXAEMNRRun)
 WDSP_OFF_ONLY(SetRXASNBARun)

@@ -145,3 +145,42 @@ def test_meters_and_quisk_shim(qh, oracle):
     want = [o.GetRXAMeter(mt) for mt in range(7)]
     for mt in (0, 1, 2, 3, 5, 6):
         assert abs(meters[mt] - want[mt]) < 1e-3, (mt, meters[mt], want[mt])
+
+
+def test_fexchange2_float_split_buffers(qh, oracle):
+    """fexchange2 (wdsp/iobuffs.c:518-582): separate float I / Q buffers; same exchange as fexchange0 on the
+    float-rounded input, output rounded to float."""
+    lib = qh.load()
+    ch, in_size, out_size, nb = 6, 1024, 256, 24
+    _open(lib, ch, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    lib.SetRXAEMNRgainMethod(ch, 2)                    # accepted (quisk.py:6017), the block never runs
+    assert lib.qh_wdsp_status() == 0
+    x = synth.make_input_numpy(1, nb * in_size)[0]
+    xi, xq = x.real.astype(np.float32), x.imag.astype(np.float32)
+    oi, oq = np.zeros(nb * out_size, np.float32), np.zeros(nb * out_size, np.float32)
+    err = C.c_int(0)
+    for b in range(nb):
+        lib.fexchange2(ch, xi[b * in_size:].ctypes.data_as(C.c_void_p), xq[b * in_size:].ctypes.data_as(C.c_void_p),
+                       oi[b * out_size:].ctypes.data_as(C.c_void_p), oq[b * out_size:].ctypes.data_as(C.c_void_p), C.byref(err))
+        assert err.value == 0
+    lib.CloseChannel(ch)
+    ref, errs = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0)).fexchange0(xi.astype(np.float64) + 1j * xq.astype(np.float64))
+    assert errs == 0
+    assert rel_rms(oi + 1j * oq, ref) < 2e-7            # float32 rounding of the output
+
+
+def test_setrxaamdrun_switches_the_am_detector(qh, oracle):
+    """SetRXAAMDRun (wdsp/amd.c:264-277) on its own: USB mode with the AM detector forced on == the oracle's."""
+    lib = qh.load()
+    ch, in_size, out_size, nb = 7, 1024, 256, 40
+    _open(lib, ch, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    lib.SetRXAAMDRun(ch, 1)
+    assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
+    x = synth.make_input_numpy(1, nb * in_size)[0]
+    y = _run(lib, ch, x, in_size, out_size)
+    lib.CloseChannel(ch)
+    o = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    o.SetRXAAMDRun(1)
+    ref, errs = o.fexchange0(x)
+    assert errs == 0 and np.abs(ref).max() > 1e-3
+    assert rel_rms(y, ref) < 1e-9
