@@ -78,6 +78,7 @@ int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
 int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
 int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
 int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
+int qh_rxa_RXASetMP(qh_rxa *e, int ch, int mp);                  /* wdsp/RXA.c:948-958: minimum-phase filters (mp_imp, fir.c:319) */
 int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *e, int ch, int levelfade);
 int qh_rxa_SetRXAFMDeviation(qh_rxa *e, int ch, double deviation);
 int qh_rxa_SetRXACTCSSFreq(qh_rxa *e, int ch, double freq);

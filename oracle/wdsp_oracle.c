@@ -208,10 +208,11 @@ static double *wo_fc_impulse(int nc, double f0, double f1, double g0, double g1,
 }
 
 /* ------------------------------------------------------------------ fircore */
-/* wdsp/firmin.h:138-161, firmin.c:290-430 (mp = 0 only; min-phase is out of scope) */
+/* wdsp/firmin.h:138-161, firmin.c:290-430 */
 struct wo_fircore {
-    int size, nc, nfor, buffidx, idxmask;
-    double *imp;      /* nc complex */
+    int size, nc, nfor, buffidx, idxmask, mp;
+    double *impulse;  /* nc complex: what the caller gave (a->impulse) */
+    double *imp;      /* nc complex: what the masks are made of (a->imp) */
     double *fftin;    /* 2*size complex */
     double **fftout;  /* nfor x 2*size complex */
     double **fmask;   /* nfor x 2*size complex (single mask set: setters here run between blocks) */
@@ -243,9 +244,49 @@ static void fircore_deplan(wo_fircore *a)      /* deplan_fircore, firmin.c:364-3
     free(a->fftout); free(a->fmask); free(a->fftin); free(a->maskgen); free(a->accum);
 }
 
+/* analytic, wdsp/fir.c:292-317 (in place) */
+static void wo_analytic(int N, double *x)
+{
+    int i;
+    double inv_N = 1.0 / (double)N, two_inv_N = 2.0 * inv_N;
+    fo_fft(x, N, -1);
+    x[0] *= inv_N; x[1] *= inv_N;
+    for (i = 1; i < N / 2; i++) { x[2 * i] *= two_inv_N; x[2 * i + 1] *= two_inv_N; }
+    x[N] *= inv_N; x[N + 1] *= inv_N;
+    memset(&x[N + 2], 0, (size_t)(N - 2) * sizeof(double));
+    fo_fft(x, N, +1);
+}
+
+/* mp_imp, wdsp/fir.c:319-368 */
+void wo_mp_imp(int N, const double *fir, double *mpfir, int pfactor, int polarity)
+{
+    int i, size = N * pfactor;
+    double inv_PN = 1.0 / (double)size;
+    double *firfreq = (double *)zalloc((size_t)size * 2 * sizeof(double));
+    double *mag = (double *)zalloc((size_t)size * sizeof(double));
+    double *ana = (double *)zalloc((size_t)size * 2 * sizeof(double));
+    double *newfreq = (double *)zalloc((size_t)size * 2 * sizeof(double));
+    memcpy(firfreq, fir, (size_t)N * 2 * sizeof(double));
+    fo_fft(firfreq, size, -1);
+    for (i = 0; i < size; i++) {
+        mag[i] = sqrt(firfreq[2 * i] * firfreq[2 * i] + firfreq[2 * i + 1] * firfreq[2 * i + 1]) * inv_PN;
+        ana[2 * i] = mag[i] > 0.0 ? log(mag[i]) : log(1.0e-300);
+    }
+    wo_analytic(size, ana);
+    for (i = 0; i < size; i++) {
+        newfreq[2 * i] = mag[i] * cos(ana[2 * i + 1]);
+        newfreq[2 * i + 1] = (polarity ? 1.0 : -1.0) * mag[i] * sin(ana[2 * i + 1]);
+    }
+    fo_fft(newfreq, size, +1);
+    memcpy(mpfir, polarity ? &newfreq[2 * (pfactor - 1) * N] : newfreq, (size_t)N * 2 * sizeof(double));
+    free(firfreq); free(mag); free(ana); free(newfreq);
+}
+
 static void fircore_calc(wo_fircore *a)        /* calc_fircore, firmin.c:322-346 */
 {
     int i;
+    if (a->mp) wo_mp_imp(a->nc, a->impulse, a->imp, 16, 0);
+    else memcpy(a->imp, a->impulse, (size_t)a->nc * 2 * sizeof(double));
     for (i = 0; i < a->nfor; i++) {
         /* impulse partition right-justified in the 2*size buffer (firmin.c:335) */
         memset(a->maskgen, 0, (size_t)2 * a->size * 2 * sizeof(double));
@@ -261,7 +302,8 @@ wo_fircore *wo_fircore_create(int size, int nc, const double *impulse)  /* creat
     a->nc = nc;
     fircore_plan(a);
     a->imp = (double *)zalloc((size_t)nc * 2 * sizeof(double));
-    memcpy(a->imp, impulse, (size_t)nc * 2 * sizeof(double));
+    a->impulse = (double *)zalloc((size_t)nc * 2 * sizeof(double));
+    memcpy(a->impulse, impulse, (size_t)nc * 2 * sizeof(double));
     fircore_calc(a);
     return a;
 }
@@ -270,7 +312,7 @@ void wo_fircore_destroy(wo_fircore *a)
 {
     if (!a) return;
     fircore_deplan(a);
-    free(a->imp);
+    free(a->imp); free(a->impulse);
     free(a);
 }
 
@@ -284,18 +326,25 @@ static void fircore_flush(wo_fircore *a)        /* flush_fircore, firmin.c:399-4
 
 static void fircore_set_impulse(wo_fircore *a, const double *impulse)  /* setImpulse_fircore, firmin.c:448-452 */
 {
-    memcpy(a->imp, impulse, (size_t)a->nc * 2 * sizeof(double));
+    memcpy(a->impulse, impulse, (size_t)a->nc * 2 * sizeof(double));
+    fircore_calc(a);
+}
+
+static void fircore_set_mp(wo_fircore *a, int mp)      /* setMp_fircore, firmin.c:469-473 */
+{
+    a->mp = mp;
     fircore_calc(a);
 }
 
 static void fircore_set_nc(wo_fircore *a, int nc, const double *impulse) /* setNc_fircore, firmin.c:454-466 */
 {
     fircore_deplan(a);
-    free(a->imp);
+    free(a->imp); free(a->impulse);
     a->nc = nc;
     fircore_plan(a);
     a->imp = (double *)zalloc((size_t)nc * 2 * sizeof(double));
-    memcpy(a->imp, impulse, (size_t)nc * 2 * sizeof(double));
+    a->impulse = (double *)zalloc((size_t)nc * 2 * sizeof(double));
+    memcpy(a->impulse, impulse, (size_t)nc * 2 * sizeof(double));
     fircore_calc(a);
 }
 
@@ -1074,6 +1123,14 @@ void wo_RXASetPassband(wo_channel *c, double f_low, double f_high)
     wo_SetRXABandpassFreqs(c, f_low, f_high);
     /* SetRXASNBAOutputBandwidth: snba run = 0, no effect on the data */
     wo_RXANBPSetFreqs(c, f_low, f_high);
+}
+
+void wo_RXASetMP(wo_channel *c, int mp)         /* RXA.c:948-958: nbp0, bp1, FM de-emphasis and audio filter */
+{
+    if (c->nbp0.p->mp != mp) fircore_set_mp(c->nbp0.p, mp);       /* RXANBPSetMP, nbp.c:580-590 */
+    if (c->bp1.p->mp != mp) fircore_set_mp(c->bp1.p, mp);         /* SetRXABandpassMP, bandpass.c:448-457 */
+    if (c->fmd.pde->mp != mp) fircore_set_mp(c->fmd.pde, mp);     /* SetRXAFMMPde, fmd.c:296-305 */
+    if (c->fmd.paud->mp != mp) fircore_set_mp(c->fmd.paud, mp);   /* SetRXAFMMPaud, fmd.c:325-334 */
 }
 
 void wo_RXASetNC(wo_channel *c, int nc)         /* RXA.c:934-946 */

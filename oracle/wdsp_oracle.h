@@ -74,6 +74,8 @@ void wo_SetRXAPanelSelect(wo_channel *c, int select);
 void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
+void wo_RXASetMP(wo_channel *c, int mp);                        /* RXA.c:948-958 */
+void wo_mp_imp(int N, const double *fir, double *mpfir, int pfactor, int polarity);     /* fir.c:319-368 */
 void wo_SetRXAAMDFadeLevel(wo_channel *c, int levelfade);       /* amd.c:267-273 */
 void wo_SetRXAFMDeviation(wo_channel *c, double deviation);     /* fmd.c:236-246 */
 void wo_SetRXACTCSSFreq(wo_channel *c, double freq);            /* fmd.c:248-258 */

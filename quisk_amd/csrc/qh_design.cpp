@@ -156,6 +156,41 @@ void host_fft(std::vector<cd> &x, int sign)
     }
 }
 
+// mp_imp (wdsp/fir.c:319-368) with analytic() (fir.c:292-317): the minimum-phase impulse response with the
+// magnitude response of `fir`, by the cepstral method on a grid of pfactor * N points (N * pfactor a power of two).
+std::vector<cd> mp_imp(const std::vector<cd> &fir, int pfactor, int polarity)
+{
+    const int N = (int)fir.size(), size = N * pfactor;
+    const double inv_PN = 1.0 / (double)size;
+    std::vector<cd> freq((size_t)size, cd(0.0, 0.0));
+    for (int i = 0; i < N; i++) freq[(size_t)i] = fir[(size_t)i];
+    host_fft(freq, -1);
+    std::vector<double> mag((size_t)size);
+    std::vector<cd> ana((size_t)size);
+    for (int i = 0; i < size; i++) {
+        mag[(size_t)i] = std::sqrt(freq[(size_t)i].real() * freq[(size_t)i].real() + freq[(size_t)i].imag() * freq[(size_t)i].imag()) * inv_PN;
+        ana[(size_t)i] = cd(mag[(size_t)i] > 0.0 ? std::log(mag[(size_t)i]) : std::log(1.0e-300), 0.0);
+    }
+    // analytic(): forward FFT, keep DC and Nyquist once, double the positive bins, zero the negative ones, inverse
+    host_fft(ana, -1);
+    const double inv_N = 1.0 / (double)size, two_inv_N = 2.0 * inv_N;
+    ana[0] *= inv_N;
+    for (int i = 1; i < size / 2; i++) ana[(size_t)i] *= two_inv_N;
+    ana[(size_t)size / 2] *= inv_N;
+    for (int i = size / 2 + 1; i < size; i++) ana[(size_t)i] = cd(0.0, 0.0);
+    host_fft(ana, +1);
+    std::vector<cd> nf((size_t)size);
+    for (int i = 0; i < size; i++) {
+        const double ph = ana[(size_t)i].imag();
+        nf[(size_t)i] = cd(mag[(size_t)i] * std::cos(ph), (polarity ? 1.0 : -1.0) * mag[(size_t)i] * std::sin(ph));
+    }
+    host_fft(nf, +1);
+    std::vector<cd> out((size_t)N);
+    const size_t off = polarity ? (size_t)(pfactor - 1) * (size_t)N : 0;
+    for (int i = 0; i < N; i++) out[(size_t)i] = nf[off + (size_t)i];
+    return out;
+}
+
 std::vector<cd> make_mask(const std::vector<cd> &h, int nfft)
 {
     if ((int)h.size() > nfft) throw std::runtime_error("make_mask: impulse longer than the FFT");

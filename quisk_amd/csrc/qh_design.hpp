@@ -28,6 +28,7 @@ std::vector<cd> fc_impulse(int nc, double f0, double f1, double g0, double g1, i
 void host_fft(std::vector<cd> &x, int sign);
 
 // Frequency-domain mask for qh::osfir_kernel: FFT_NFFT(h zero padded) / NFFT.
+std::vector<cd> mp_imp(const std::vector<cd> &fir, int pfactor, int polarity);     // wdsp/fir.c:319-368
 std::vector<cd> make_mask(const std::vector<cd> &h, int nfft);
 
 // Concatenated per-pass twiddle tables for qh::FftRR<N> (see the Plan table in qh_fft.hpp).

@@ -50,6 +50,7 @@ struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33
     int shift_run = 1; double shift_freq = 0.0;                 // RXA.c:39-45
     int nbp_run = 1, nbp_nc = 2048, nbp_wintype = 0;            // RXA.c:90-106
+    int mp = 0;                                                 // RXASetMP, RXA.c:948
     double nbp_flow = -4150.0, nbp_fhigh = -150.0, nbp_gain = 1.0;
     int amd_run = 0, amd_mode = 0, fmd_run = 0;                 // RXA.c:175-212
     int agc_run = 1, agc_mode = 3; double agc_fixed = 1000.0;   // RXA.c:335-358
@@ -108,7 +109,7 @@ struct Engine {
     SnotchParam *sn_prm = nullptr;
     SnotchState *sn_state = nullptr;
     double2 *mask_de = nullptr, *mask_aud = nullptr, *hist_de[2] = { nullptr, nullptr }, *hist_aud[2] = { nullptr, nullptr };
-    int cur_de = 0, cur_aud = 0, fm_nc_built = 0;
+    int cur_de = 0, cur_aud = 0, fm_nc_built = 0, fm_mp = 0, fm_mp_built = 0;
     AgcParam *agc_prm = nullptr;
     AgcState *agc_state = nullptr;
     bool meters_on = false;
@@ -269,7 +270,7 @@ int Engine::refresh_params()
             // calc_nbp_impulse without notches, wdsp/nbp.c:234-238; identity when the filter is off
             bool same = last_nbp_cfg && last_nbp_cfg->nbp_run == c.nbp_run && last_nbp_cfg->nbp_nc == c.nbp_nc &&
                         last_nbp_cfg->nbp_wintype == c.nbp_wintype && last_nbp_cfg->nbp_flow == c.nbp_flow &&
-                        last_nbp_cfg->nbp_fhigh == c.nbp_fhigh && last_nbp_cfg->nbp_gain == c.nbp_gain;
+                        last_nbp_cfg->nbp_fhigh == c.nbp_fhigh && last_nbp_cfg->nbp_gain == c.nbp_gain && last_nbp_cfg->mp == c.mp;
             if (!same) {
                 std::vector<cd> h;
                 if (c.nbp_run)
@@ -277,6 +278,7 @@ int Engine::refresh_params()
                                      c.nbp_gain / (double)(2 * dsp_size));
                 else
                     h.assign(1, cd(1.0, 0.0));
+                if (c.nbp_run && c.mp) h = mp_imp(h, 16, 0);            // calc_fircore, wdsp/firmin.c:327-328
                 // the reference's unnormalised inverse FFT of 2*size points restores the 1/(2*size)
                 if (c.nbp_run) for (auto &v : h) v *= (double)(2 * dsp_size);
                 last_nbp = make_mask(h, kNfft);
@@ -289,12 +291,13 @@ int Engine::refresh_params()
         if (c.bp1_dirty) {
             bool same = last_bp1_cfg && last_bp1_cfg->bp1_run == c.bp1_run && last_bp1_cfg->bp1_nc == c.bp1_nc &&
                         last_bp1_cfg->bp1_wintype == c.bp1_wintype && last_bp1_cfg->bp1_flow == c.bp1_flow &&
-                        last_bp1_cfg->bp1_fhigh == c.bp1_fhigh && last_bp1_cfg->bp1_gain == c.bp1_gain;
+                        last_bp1_cfg->bp1_fhigh == c.bp1_fhigh && last_bp1_cfg->bp1_gain == c.bp1_gain && last_bp1_cfg->mp == c.mp;
             if (!same) {
                 std::vector<cd> h;
                 if (c.bp1_run) {
                     h = fir_bandpass(c.bp1_nc, c.bp1_flow, c.bp1_fhigh, (double)dsp_rate, c.bp1_wintype, 1,
                                      c.bp1_gain / (double)(2 * dsp_size));     // wdsp/bandpass.c:302
+                    if (c.mp) h = mp_imp(h, 16, 0);
                     for (auto &v : h) v *= (double)(2 * dsp_size);
                 } else {
                     h.assign(1, cd(1.0, 0.0));
@@ -475,17 +478,19 @@ int Engine::refresh_demod()
         QH_HIP(hipStreamSynchronize(stream));
         c.demod_dirty = false;
     }
-    if (want_nc && want_nc != fm_nc_built) {
+    if (want_nc && (want_nc != fm_nc_built || fm_mp != fm_mp_built)) {
         // create_fmd, wdsp/fmd.c:108-116: de-emphasis by frequency sampling, audio band-pass 0.8*f_low .. 1.1*f_high
         const double f_low = 300.0, f_high = 3000.0, afgain = 0.5;
         std::vector<cd> de = fc_impulse(want_nc, f_low, f_high, +20.0 * std::log10(f_high / f_low), 0.0, 1, rate,
                                         1.0 / (2.0 * dsp_size), 0, 0);
         std::vector<cd> au = fir_bandpass(want_nc, 0.8 * f_low, 1.1 * f_high, rate, 0, 1, afgain / (2.0 * dsp_size));
+        if (fm_mp) { de = mp_imp(de, 16, 0); au = mp_imp(au, 16, 0); }     // SetRXAFMMPde / MPaud, wdsp/RXA.c:956-957
+        fm_mp_built = fm_mp;
         for (auto &v : de) v *= (double)(2 * dsp_size);
         for (auto &v : au) v *= (double)(2 * dsp_size);
         if (int rc = upload(mask_de, make_mask(de, kNfft), stream)) return rc;
         if (int rc = upload(mask_aud, make_mask(au, kNfft), stream)) return rc;
-        if (fm_nc_built) {      // setNc_fircore zeroes the delay lines, wdsp/firmin.c:454-466
+        if (fm_nc_built && fm_nc_built != want_nc) {      // setNc_fircore zeroes the delay lines, wdsp/firmin.c:454-466
             for (int i = 0; i < 2; i++) {
                 QH_HIP(hipMemsetAsync(hist_de[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
                 QH_HIP(hipMemsetAsync(hist_aud[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
@@ -865,6 +870,18 @@ int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
         if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; }
         if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; }
         c.fm_nc = nc;                           // SetRXAFMNCde / SetRXAFMNCaud, wdsp/RXA.c:942-943
+    });
+}
+
+// RXASetMP (wdsp/RXA.c:948-958): minimum-phase impulse responses in every fircore of the chain.  nbp0 and bp1 have
+// per-channel masks; the FM de-emphasis / audio masks are shared by the channels of an engine and follow the
+// most recent call.
+int qh_rxa_RXASetMP(qh_rxa *h, int ch, int mp)
+{
+    mp = mp ? 1 : 0;
+    if (h) h->e.fm_mp = mp;
+    FOR_CH(h, ch, {
+        if (c.mp != mp) { c.mp = mp; c.nbp_dirty = true; c.bp1_dirty = true; c.demod_dirty = true; }
     });
 }
 

@@ -442,13 +442,7 @@ int wdspFexchange0(int channel, double *cSamples, int nSamples)
 
 // xpanel never looks at its run flag (wdsp/patchpanel.c:55-101): accepted, no effect on the data.
 void SetRXAPanelRun(int channel, int run) { (void)run; g_status = QH_OK; (void)valid(channel); }
-// minimum-phase impulse responses (mp_imp, wdsp/fir.c:319-368) are not provided: only mp = 0.
-void RXASetMP(int channel, int mp)
-{
-    g_status = QH_OK;
-    if (!valid(channel)) return;
-    if (mp) g_status = qh::set_error(QH_ERR_UNSUPPORTED, "RXASetMP(%d, %d): minimum-phase filters are not provided", channel, mp);
-}
+void RXASetMP(int channel, int mp) { WDSP_SETTER(qh_rxa_RXASetMP(L.c->eng, 0, mp)); }     // wdsp/RXA.c:948-958
 // blocks that are run = 0 on the hot path: run = 0 is accepted, run = 1 is reported as unsupported
 #define WDSP_OFF_ONLY(name)                                                                        \
     void name(int channel, int run)                                                                \

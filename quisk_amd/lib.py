@@ -37,7 +37,8 @@ def load():
     L.qh_rxa_device_bytes.restype = ll
     for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
-              "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold"):
+              "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
+              "RXASetMP", "SetRXAAMDRun"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
         f.restype = i

@@ -14,7 +14,8 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1",
             "RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2", "SetRXAAMDSBMode",
             "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun", "SetRXAAGCAttack",
-            "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold")
+            "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold", "RXASetMP",
+            "SetRXAAMDRun")
 
 
 class RxaEngine:

@@ -181,3 +181,32 @@ def test_agc_parameter_setters(qh, oracle):
         call("SetRXAAGCHangThreshold", 40)
     y = e.process_host(x[None, :])[0]
     assert rel_rms(y, o.xrxa(x)) < 1e-7
+
+
+@pytest.mark.parametrize("mode", [1, 5])
+def test_minimum_phase_filters(qh, oracle, mode):
+    """RXASetMP(1) (wdsp/RXA.c:948-958): every fircore impulse goes through mp_imp (wdsp/fir.c:319-368); switched
+    on after a few blocks like a GUI would, off again later."""
+    nch, nblk = 2, 60 if mode == 1 else 200
+    x = np.stack([synth.make_mode_input_numpy("fm" if mode == 5 else "usb", c, nblk * 1024) for c in range(nch)])
+    e = _engine(qh, nch)
+    e.SetRXAMode(-1, mode)
+    chans = []
+    for c in range(nch):
+        ch = _oracle_channel(oracle, c)
+        ch.SetRXAMode(mode)
+        chans.append(ch)
+    outs, refs = [], [[] for _ in range(nch)]
+    for (a, b), mp in zip(((0, 4), (4, 2 * nblk // 3), (2 * nblk // 3, nblk)), (0, 1, 0)):
+        e.RXASetMP(-1, mp)
+        outs.append(e.process_host(x[:, a * 1024:b * 1024]))
+        for c in range(nch):
+            chans[c].RXASetMP(mp)
+            refs[c].append(chans[c].xrxa(x[c, a * 1024:b * 1024]))
+    y = np.concatenate(outs, axis=1)
+    for c in range(nch):
+        ref = np.concatenate(refs[c])
+        if mode == 5:       # PLL acquisition rings in the CTCSS notch (pole radius 0.9994): compare after it died (DESIGN.md)
+            assert rel_rms(y[c][100 * 256:], ref[100 * 256:]) < 1e-6, (c, rel_rms(y[c][100 * 256:], ref[100 * 256:]))
+        else:
+            assert rel_rms(y[c], ref) < 1e-9, (c, rel_rms(y[c], ref))
