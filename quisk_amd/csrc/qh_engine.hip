@@ -131,6 +131,10 @@ struct Engine {
                   const int *list, int nlist);
     int ensure_buffers(long long n_mid);
     int process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
+    int process_chain(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
+    qh_rat *rsmpout = nullptr;          // xresample out (wdsp/RXA.c:596), only when out_rate != dsp_rate
+    double2 *obuf = nullptr;
+    long long obuf_cap = 0;
     void tick(int cat);
 };
 
@@ -138,6 +142,8 @@ Engine::~Engine()
 {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (rsmpout) qh_rat_destroy(rsmpout);
+    (void)hipFree(obuf);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
@@ -162,7 +168,16 @@ int Engine::init()
     if (!stream) { QH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     // pre_main_build, wdsp/channel.c:39-47
     dsp_insize = dsp_size * D;
-    dsp_outsize = dsp_size;
+    dsp_outsize = out_rate >= dsp_rate ? dsp_size * (out_rate / dsp_rate) : dsp_size / (dsp_rate / out_rate);    // channel.c:47-50
+    if (out_rate != dsp_rate) {
+        // create_resample(..., dsp_rate, out_rate, 0.0, 0, 1.0), wdsp/RXA.c:474-484; the polyphase loop of xresample
+        // (resample.c:120-157) is quisk_cInterpDecim's with the gain already in the taps
+        const ResamplerDesign rd = design_resampler(dsp_rate, out_rate, 0.0, 0, 1.0);
+        std::vector<double> taps(rd.h);
+        for (double &v : taps) v /= (double)rd.L;
+        rsmpout = qh_rat_create(device, nch, taps.data(), rd.ncoef, rd.L, rd.M, QH_F64, stream);
+        if (!rsmpout) return QH_ERR_HIP;
+    }
     cfg.assign((size_t)nch, ChanCfg());
 
     std::vector<cd> tw = fft_twiddle_table(kNfft);
@@ -622,7 +637,28 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     hc ^= 1;
 }
 
+// xrxa's last step (wdsp/RXA.c:596): rsmpout runs when out_rate != dsp_rate (RXAResCheck, RXA.c:789-798)
 int Engine::process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
+{
+    if (!rsmpout) return process_chain(d_in, in_stride, d_out, out_stride, nblk);
+    if (nblk <= 0) return QH_OK;
+    QH_HIP(hipSetDevice(device));
+    const long long n_mid = (long long)nblk * dsp_size;
+    if (n_mid > obuf_cap) {
+        QH_HIP(hipStreamSynchronize(stream));
+        if (obuf) { QH_HIP(hipFree(obuf)); dev_bytes -= obuf_cap * nch * (long long)sizeof(double2); obuf = nullptr; }
+        QH_HIP(dev_alloc(&obuf, (size_t)nch * (size_t)n_mid));
+        obuf_cap = n_mid;
+        dev_bytes += n_mid * nch * (long long)sizeof(double2);
+    }
+    if (int rc = process_chain(d_in, in_stride, reinterpret_cast<double *>(obuf), obuf_cap, nblk)) return rc;
+    int got = 0;
+    if (int rc = qh_rat_process(rsmpout, obuf, obuf_cap, (int)n_mid, d_out, out_stride, &got)) return rc;
+    if (got != nblk * dsp_outsize) return set_error(QH_ERR_HIP, "output resampler produced %d samples, expected %d", got, nblk * dsp_outsize);
+    return QH_OK;
+}
+
+int Engine::process_chain(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
 {
     if (nblk <= 0) return QH_OK;
     QH_HIP(hipSetDevice(device));
@@ -763,7 +799,10 @@ qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_ra
         set_error(QH_ERR_INVALID, "qh_rxa_create: bad arguments");
         return nullptr;
     }
-    if (out_rate != dsp_rate) { set_error(QH_ERR_UNSUPPORTED, "out_rate must equal dsp_rate"); return nullptr; }
+    if (out_rate <= 0 || (out_rate % dsp_rate && dsp_rate % out_rate) || (out_rate < dsp_rate && dsp_size % (dsp_rate / out_rate))) {
+        set_error(QH_ERR_UNSUPPORTED, "out_rate must be an integer multiple or fraction of dsp_rate (wdsp/channel.c:47-52)");
+        return nullptr;
+    }
     if (in_rate % dsp_rate) { set_error(QH_ERR_UNSUPPORTED, "in_rate must be a multiple of dsp_rate"); return nullptr; }
     const int D = in_rate / dsp_rate;
     if (D != 1 && D != 2 && D != 4 && D != 8) { set_error(QH_ERR_UNSUPPORTED, "in_rate/dsp_rate must be 1, 2, 4 or 8"); return nullptr; }
@@ -959,6 +998,7 @@ int qh_rxa_flush(qh_rxa *h)
     Engine &e = h->e;
     QH_HIP(hipSetDevice(e.device));
     QH_HIP(hipMemsetAsync(e.nco_phase, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
+    if (e.rsmpout) if (int rc = qh_rat_reset(e.rsmpout)) return rc;        // flush_resample, wdsp/resample.c:159-165
     for (int i = 0; i < 2; i++) {
         if (e.hist_front[i]) QH_HIP(hipMemsetAsync(e.hist_front[i], 0, (size_t)e.nch * kHistFront * sizeof(double2), e.stream));
         QH_HIP(hipMemsetAsync(e.hist_nbp[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));

@@ -210,3 +210,24 @@ def test_minimum_phase_filters(qh, oracle, mode):
             assert rel_rms(y[c][100 * 256:], ref[100 * 256:]) < 1e-6, (c, rel_rms(y[c][100 * 256:], ref[100 * 256:]))
         else:
             assert rel_rms(y[c], ref) < 1e-9, (c, rel_rms(y[c], ref))
+
+
+@pytest.mark.parametrize("out_rate", [96000, 24000, 12000])
+def test_output_resampler(qh, oracle, out_rate):
+    """out_rate != dsp_rate: xresample on the way out (wdsp/RXA.c:596, RXAResCheck :789-798)."""
+    nch, nblk = 2, 24
+    x = synth.make_input_numpy(nch, nblk * 1024)
+    e = qh.RxaEngine(nch, dsp_size=256, in_rate=192000, dsp_rate=48000, out_rate=out_rate)
+    e.SetRXAShiftRun(-1, 1); e.RXANBPSetRun(-1, 1); e.SetRXAMode(-1, 1); e.RXASetPassband(-1, 300.0, 3000.0)
+    e.SetRXAAGCMode(-1, 0); e.SetRXAAGCFixed(-1, 0.0)
+    assert e.dsp_outsize == 256 * out_rate // 48000
+    for c in range(nch):
+        e.SetRXAShiftFreq(c, synth.shift_freq(c))
+    y = np.concatenate([e.process_host(x[:, :5 * 1024]), e.process_host(x[:, 5 * 1024:])], axis=1)
+    for c in range(nch):
+        ch = oracle.WdspChannel(1024, 256, 192000, 48000, out_rate)
+        ch.SetRXAShiftRun(1); ch.SetRXAShiftFreq(synth.shift_freq(c)); ch.RXANBPSetRun(1); ch.SetRXAMode(1)
+        ch.RXASetPassband(300.0, 3000.0); ch.SetRXAAGCMode(0); ch.SetRXAAGCFixed(0.0)
+        ref = ch.xrxa(x[c])
+        assert y.shape[1] == ref.size
+        assert rel_rms(y[c], ref) < TOL, (c, rel_rms(y[c], ref))

@@ -184,3 +184,24 @@ def test_setrxaamdrun_switches_the_am_detector(qh, oracle):
     ref, errs = o.fexchange0(x)
     assert errs == 0 and np.abs(ref).max() > 1e-3
     assert rel_rms(y, ref) < 1e-9
+
+
+@pytest.mark.parametrize("out_rate", [96000, 24000])
+def test_fexchange0_with_output_resampler(qh, oracle, out_rate):
+    """OpenChannel with out_rate != dsp_rate: out_size = in_size * out_rate / in_rate, latency and slew at the output rate."""
+    lib = qh.load()
+    ch, in_size, nb = 9, 1024, 24
+    out_size = in_size * out_rate // 192000
+    lib.OpenChannel(ch, in_size, 256, 192000, 48000, out_rate, 0, 1, D(0.010), D(0.025), D(0.0), D(0.010), 1)
+    assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
+    lib.SetRXAShiftRun(ch, 1); lib.SetRXAShiftFreq(ch, D(synth.shift_freq(0))); lib.RXANBPSetRun(ch, 1)
+    lib.SetRXAMode(ch, 1); lib.RXASetPassband(ch, D(300.0), D(3000.0)); lib.SetRXAAGCMode(ch, 0); lib.SetRXAAGCFixed(ch, D(0.0))
+    x = synth.make_input_numpy(1, nb * in_size)[0]
+    y = _run(lib, ch, x, in_size, out_size)
+    lib.CloseChannel(ch)
+    o = oracle.WdspChannel(in_size, 256, 192000, 48000, out_rate)
+    o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(0)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+    o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0)
+    ref, errs = o.fexchange0(x)
+    assert errs == 0 and ref.size == y.size and np.abs(ref).max() > 1e-3
+    assert rel_rms(y, ref) < 1e-9
