@@ -4,18 +4,17 @@
 //   am_detect_kernel   xamd mode 0 (wdsp/amd.c:131-146): |z| and two one-pole averages.  The averages are
 //                      linear recurrences, solved inside the wavefront by a Kogge-Stone scan with constant
 //                      coefficients (v_i += m^d * v_{i-d}), the carry passing from one 64-sample group to the next.
-//   pll_kernel         xamd mode 1 (amd.c:148-232) and the discriminator of xfmd (fmd.c:151-172).  A PLL is a
-//                      non-linear recurrence: strictly sequential per channel (SURVEY.md hard part 3).  Every
-//                      lane runs the same recurrence; lane i keeps the i-th result, so loads and stores stay
-//                      coalesced and no lane diverges.  Parallelism = channels.
+//   fm_pll_kernel,     the discriminator of xfmd (fmd.c:151-172) and xamd mode 1 (amd.c:148-232).  A PLL is a
+//   sam_pll_kernel     non-linear recurrence: sequential per channel (SURVEY.md hard part 3).  Its phase detector
+//                      atan2(corr1, corr0) equals arg(z) - phs, so arg(z) is taken by all lanes at once and only
+//                      the loop filter is stepped sample by sample (pll_run64); every lane steps the same state,
+//                      lane i keeps the i-th result, loads and stores stay coalesced.  Parallelism = channels.
 //   snotch_kernel      xsnotch (wdsp/iir.c:76-95): bi-quad on the I component only; 2x2 constant-matrix scan.
 #pragma once
 #include "qh_fft.hpp"
+#include "qh_wave.hpp"
 
 namespace qh {
-
-static constexpr double kTwoPiRef = 6.2831853071795864;     // wdsp/comm.h:147
-static constexpr double kPiRef = 3.1415926535897932;        // wdsp/comm.h:146
 
 struct AmParam {            // per engine (depends on the DSP rate only), init_amd wdsp/amd.c:86-89
     double mtauR, onem_mtauR, mtauI, onem_mtauI;
@@ -23,48 +22,6 @@ struct AmParam {            // per engine (depends on the DSP rate only), init_a
 
 struct AmState { double dc, dc_insert; };
 
-__device__ __forceinline__ double wave_max_d(double v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
-    return v;
-}
-
-// x^(lane+1) for lane = 0..63 (wave-wide), by repeated squaring per lane
-__device__ __forceinline__ double lane_pow(double x, int e)
-{
-    double r = 1.0, b = x;
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        if (e & (1 << k)) r *= b;
-        b *= b;
-    }
-    return r;
-}
-
-// inclusive scan of v_i = m*v_{i-1} + u_i over the 64 lanes with zero carry-in: returns sum_j m^(i-j) u_j
-// Value of lane i for every lane, i wave-uniform: two v_readlane_b32 instead of the LDS-crossbar ds_bpermute that
-// __shfl compiles to (its ~100 cycles would sit in the critical path of every step of the sequential kernels).
-__device__ __forceinline__ double lane_bcast(double v, int i)
-{
-    const int u = __builtin_amdgcn_readfirstlane(i);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), u), hi = __builtin_amdgcn_readlane(__double2hiint(v), u);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double scan_pole(double u, double m, int lane)
-{
-    double md = m;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double up = __shfl_up(u, d, 64);
-        if (lane >= d) u = __builtin_fma(md, up, u);
-        md *= md;
-    }
-    return u;
-}
-
-// buf: [nch][stride] complex, n samples per channel, in place.  One wave per listed channel.
 static __global__ __launch_bounds__(64) void am_detect_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                        const int *levelfade, AmState *state, AmParam prm)
 {
@@ -470,61 +427,6 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
         sp->hang_backaverage = hba; sp->gain = gain; sp->out_index = out_index; sp->hang_counter = hang_counter;
         sp->decay_type = decay_type; sp->state = st;
     }
-}
-
-// ------------------------------------------------------------------------------------------------ Quisk detectors
-// Quisk's AM detector (quisk.c:2005-2012): di = |z|; d = di + 0.99*dc; out = d - dc; dc = d.  The DC remover is the
-// linear recurrence dc_n = di_n + 0.99*dc_{n-1}: wave scan.  In place, (out, out).  One wave per channel.
-static __global__ __launch_bounds__(64) void q_am_env_kernel(double2 *buf, long long stride, int n, double *dc_state)
-{
-    const int ch = blockIdx.x, lane = threadIdx.x;
-    double2 *p = buf + (long long)ch * stride;
-    double carry = dc_state[ch];
-    const double pw = lane_pow(0.99, lane + 1);
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = n - base < 64 ? n - base : 64;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[base + lane];
-        const double di = hypot(z.x, z.y);
-        const double dc = scan_pole(di, 0.99, lane) + pw * carry;
-        double prev = __shfl_up(dc, 1, 64);
-        if (lane == 0) prev = carry;
-        const double out = dc - prev;
-        if (lane < cnt) p[base + lane] = make_double2(out, out);
-        carry = lane_bcast(dc, cnt - 1);
-    }
-    if (lane == 0) dc_state[ch] = carry;
-}
-
-// Quisk's FM detector (quisk.c:2032-2064): di = arg(z * conj(z_prev)) * 20e5, then the one-pole de-emphasis
-// y = di*a0 + x1*a1 - y1*b1.  state: {z_prev.re, z_prev.im, x1, y1}.  In place, (y, 0).
-struct QFmParam { double a0, a1, b1; };
-static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long long stride, int n, double4 *state, QFmParam q)
-{
-    const int ch = blockIdx.x, lane = threadIdx.x;
-    double2 *p = buf + (long long)ch * stride;
-    double4 st = state[ch];
-    const double pole = -q.b1;
-    const double pw = lane_pow(pole, lane + 1);
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = n - base < 64 ? n - base : 64;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[base + lane];
-        double pr = __shfl_up(z.x, 1, 64), pi = __shfl_up(z.y, 1, 64);
-        if (lane == 0) { pr = st.x; pi = st.y; }
-        // cx * conj(fm_1)
-        const double re = z.x * pr + z.y * pi, im = z.y * pr - z.x * pi;
-        const double di = atan2(im, re) * 20e5;
-        double dm1 = __shfl_up(di, 1, 64);
-        if (lane == 0) dm1 = st.z;
-        const double u = di * q.a0 + dm1 * q.a1;
-        const double y = scan_pole(u, pole, lane) + pw * st.w;
-        if (lane < cnt) p[base + lane] = make_double2(y, 0.0);
-        const int last = cnt - 1;
-        st.x = lane_bcast(z.x, last); st.y = lane_bcast(z.y, last);
-        st.z = lane_bcast(di, last); st.w = lane_bcast(y, last);
-    }
-    if (lane == 0) state[ch] = st;
 }
 
 }  // namespace qh

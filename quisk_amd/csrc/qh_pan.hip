@@ -28,8 +28,8 @@ struct PanBand { int first, nwhole; double frac; int valid, pad; };     // S-met
 
 template <int M, int R>
 __global__ __launch_bounds__(NT, 2) void pan_spectrum_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
-                                                          const double *window, const double2 *tw, double *partial,
-                                                          double *partial_m2, const PanBand *band, int nch)
+                                                          const double2 *tw, double *partial, double *partial_m2,
+                                                          const PanBand *band, int nch)
 {
     using C = double2;
     using F = TileFft<M, false, C>;
@@ -208,7 +208,7 @@ struct Pan {
     double rate = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    double *window = nullptr, *avg = nullptr, *meter = nullptr, *pixels = nullptr, *smeter = nullptr;
+    double *avg = nullptr, *meter = nullptr, *pixels = nullptr, *smeter = nullptr;
     double2 *tw = nullptr, *carry = nullptr;
     double *partial = nullptr, *partial_m2 = nullptr;
     PanBand *band = nullptr;
@@ -219,7 +219,7 @@ struct Pan {
     {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        (void)hipFree(window); (void)hipFree(avg); (void)hipFree(meter); (void)hipFree(pixels); (void)hipFree(smeter);
+        (void)hipFree(avg); (void)hipFree(meter); (void)hipFree(pixels); (void)hipFree(smeter);
         (void)hipFree(tw); (void)hipFree(carry); (void)hipFree(partial); (void)hipFree(partial_m2); (void)hipFree(band);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -229,7 +229,7 @@ struct Pan {
         constexpr int lds = TileFft<MM, false, double2>::kLdsBytes + MM * 8;
         const int units = nsplit * nch, groups = (units + 7) / 8;
         hipLaunchKernelGGL((pan_spectrum_kernel<MM, RR>), dim3((unsigned)(groups * 8 * RR)), dim3(NT), lds, stream, p, src_stride, nblk,
-                           nsplit, window, tw, partial, partial_m2, band, nch);
+                           nsplit, tw, partial, partial_m2, band, nch);
     }
     template <int MM> void launch(const double2 *p, long long src_stride, int nblk, int nsplit)
     {
@@ -291,12 +291,9 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
     // partial sums: one fft_avg image per block range of a call
     p.max_split = (1024 + R * nch - 1) / (R * nch);
     if (p.max_split < 1) p.max_split = 1;
-    std::vector<double> win((size_t)fft_size);
-    for (int i = 0, j = -fft_size / 2; i < fft_size; i++, j++)      // Hanning, quisk.c:6008
-        win[(size_t)i] = 0.5 + 0.5 * std::cos(2. * M_PI * j / fft_size);
     std::vector<cd> tw = fft_twiddle_table(M);
     p.hband.assign((size_t)nch, PanBand{ 0, 0, 0.0, 0, 0 });
-    if (hipMalloc((void **)&p.window, win.size() * 8) != hipSuccess || hipMalloc((void **)&p.tw, tw.size() * 16) != hipSuccess ||
+    if (hipMalloc((void **)&p.tw, tw.size() * 16) != hipSuccess ||
         hipMalloc((void **)&p.avg, (size_t)nch * fft_size * 8) != hipSuccess || hipMalloc((void **)&p.meter, (size_t)nch * 8) != hipSuccess ||
         hipMalloc((void **)&p.pixels, (size_t)nch * data_width * 8) != hipSuccess || hipMalloc((void **)&p.smeter, (size_t)nch * 8) != hipSuccess ||
         hipMalloc((void **)&p.carry, (size_t)nch * fft_size * 16) != hipSuccess ||
@@ -304,8 +301,7 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
         hipMalloc((void **)&p.partial_m2, (size_t)p.max_split * nch * R * 8) != hipSuccess ||
         hipMalloc((void **)&p.band, (size_t)nch * sizeof(PanBand)) != hipSuccess)
         return fail("hipMalloc");
-    if (hipMemcpy(p.window, win.data(), win.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(p.tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(p.tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(p.band, p.hband.data(), (size_t)nch * sizeof(PanBand), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(p.avg, 0, (size_t)nch * fft_size * 8) != hipSuccess || hipMemset(p.meter, 0, (size_t)nch * 8) != hipSuccess)
         return fail("initial copies");

@@ -9,20 +9,13 @@
 #include <cmath>
 #include <vector>
 #include "qh_internal.hpp"
+#include "qh_wave.hpp"
 
 using namespace qh;
 
 namespace {
 
 constexpr double kClip32 = 2147483647.0;      // CLIP32, quisk.h:13
-
-// value of lane i (wave-uniform) for every lane: v_readlane, not the LDS crossbar of __shfl
-__device__ __forceinline__ double lane_bcast(double v, int i)
-{
-    const int u = __builtin_amdgcn_readfirstlane(i);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), u), hi = __builtin_amdgcn_readlane(__double2hiint(v), u);
-    return __hiloint2double(hi, lo);
-}
 
 struct QAgcParam { double limit /* max_out * CLIP32 */, time_release; int buf_size, is_cpx; };
 struct QAgcState { int index_read, index_start, is_clipping, pad; double themax, gain, delta, target_gain; };

@@ -13,7 +13,7 @@
 #include <cmath>
 #include <vector>
 #include "qh_stage.hpp"
-#include "qh_demod.hpp"
+#include "qh_qdemod.hpp"
 
 namespace qh {
 
