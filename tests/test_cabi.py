@@ -44,3 +44,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.replace("the CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_links_from_c(qh, tmp_path):
+    """include/quiskhip.h is C99 (no C++ or torch types in any signature) and a C program links against the library."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    lib = qh.load()._name
+    src = tmp_path / "t.c"
+    src.write_text('#include "quiskhip.h"\n'
+                   'int main(void) { qh_iq_format f; double t[43]; qh_iq_format_le24(&f, 1.0); qh_hb45_taps(t);\n'
+                   '  return (GetWDSPVersion() == 125 && f.sample_bytes == 3 && t[21] == 0.5) ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                    "-L", os.path.dirname(lib), "-lquiskhip", "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
