@@ -78,6 +78,19 @@ int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
 int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
 int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
 int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
+/* The notch database and nbp0's notched band-pass (wdsp/nbp.c:358-525, make_nbp :97-179, fir_mbandpass :64-80).
+ * *rval receives the reference's return value (0, or -1 for an index out of range). */
+int qh_rxa_RXANBPAddNotch(qh_rxa *e, int ch, int notch, double fcenter, double fwidth, int active, int *rval);
+int qh_rxa_RXANBPDeleteNotch(qh_rxa *e, int ch, int notch, int *rval);
+int qh_rxa_RXANBPEditNotch(qh_rxa *e, int ch, int notch, double fcenter, double fwidth, int active, int *rval);
+int qh_rxa_RXANBPGetNotch(qh_rxa *e, int ch, int notch, double *fcenter, double *fwidth, int *active, int *rval);
+int qh_rxa_RXANBPGetNumNotches(qh_rxa *e, int ch, int *nnotches);
+int qh_rxa_RXANBPGetMinNotchWidth(qh_rxa *e, int ch, double *minwidth);
+int qh_rxa_RXANBPSetTuneFrequency(qh_rxa *e, int ch, double tunefreq);
+int qh_rxa_RXANBPSetShiftFrequency(qh_rxa *e, int ch, double shift);
+int qh_rxa_RXANBPSetNotchesRun(qh_rxa *e, int ch, int run);
+int qh_rxa_RXANBPSetWindow(qh_rxa *e, int ch, int wintype);
+int qh_rxa_RXANBPSetAutoIncrease(qh_rxa *e, int ch, int autoincr);
 int qh_rxa_RXASetMP(qh_rxa *e, int ch, int mp);                  /* wdsp/RXA.c:948-958: minimum-phase filters (mp_imp, fir.c:319) */
 int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *e, int ch, int levelfade);
 int qh_rxa_SetRXAFMDeviation(qh_rxa *e, int ch, double deviation);
@@ -151,6 +164,17 @@ void SetRXAPanelSelect(int channel, int select);                                
 void SetRXAPanelCopy(int channel, int copy);                                     /* wdsp/patchpanel.c:175-181 */
 void SetRXAAMDSBMode(int channel, int sbmode);                                   /* wdsp/amd.c:277-283 */
 void SetRXAAMDRun(int channel, int run);                                         /* wdsp/amd.c:264-277 */
+int RXANBPAddNotch(int channel, int notch, double fcenter, double fwidth, int active);          /* wdsp/nbp.c:358-388 */
+int RXANBPGetNotch(int channel, int notch, double *fcenter, double *fwidth, int *active);       /* wdsp/nbp.c:390-412 */
+int RXANBPDeleteNotch(int channel, int notch);                                   /* wdsp/nbp.c:414-438 */
+int RXANBPEditNotch(int channel, int notch, double fcenter, double fwidth, int active);         /* wdsp/nbp.c:440-459 */
+void RXANBPGetNumNotches(int channel, int *nnotches);                            /* wdsp/nbp.c:461-469 */
+void RXANBPSetTuneFrequency(int channel, double tunefreq);                       /* wdsp/nbp.c:471-481 */
+void RXANBPSetShiftFrequency(int channel, double shift);                         /* wdsp/nbp.c:483-493 */
+void RXANBPSetNotchesRun(int channel, int run);                                  /* wdsp/nbp.c:495-514 */
+void RXANBPSetWindow(int channel, int wintype);                                  /* wdsp/nbp.c:542-560 */
+void RXANBPSetAutoIncrease(int channel, int autoincr);                           /* wdsp/nbp.c:600-619 */
+void RXANBPGetMinNotchWidth(int channel, double *minwidth);                      /* wdsp/nbp.c:588-597 */
 void SetRXAAMDFadeLevel(int channel, int levelfade);                             /* wdsp/amd.c:285-291 */
 void SetRXAFMDeviation(int channel, double deviation);                           /* wdsp/fmd.c:236-246 */
 void SetRXACTCSSFreq(int channel, double freq);                                  /* wdsp/fmd.c:248-258 */

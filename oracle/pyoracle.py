@@ -59,6 +59,13 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p, C.c_double, C.c_double]
             getattr(L, n).restype = None
         L.wo_GetRXAMeter.argtypes = [C.c_void_p, C.c_int]
+        for n in ("wo_RXANBPAddNotch", "wo_RXANBPEditNotch"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.wo_RXANBPDeleteNotch.argtypes = [C.c_void_p, C.c_int]
+        for n in ("wo_RXANBPSetTuneFrequency", "wo_RXANBPSetShiftFrequency"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_double]
+        for n in ("wo_RXANBPSetNotchesRun", "wo_RXANBPSetWindow", "wo_RXANBPSetAutoIncrease"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
         L.wo_GetRXAMeter.restype = C.c_double
         L.wo_fir_bandpass.restype = C.c_void_p
         L.wo_fir_bandpass.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]

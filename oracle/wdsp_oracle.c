@@ -520,7 +520,10 @@ struct wo_channel {
     wo_resample *rsmpin, *rsmpout;
     wo_meter adcmeter, smeter, agcmeter;
     /* nbp0 (notches never run on this path: ndb master_run = 0, RXA.c:84-87) */
-    struct { int run, nc, wintype; double flow, fhigh, gain, rate; wo_fircore *p; } nbp0;
+    struct { int run, nc, wintype; double flow, fhigh, gain, rate; wo_fircore *p;
+             int fnfrun, autoincr; } nbp0;                         /* create_nbp, nbp.c:241-268 */
+    struct { int master_run, nn; double tunefreq, shift;           /* notchdb, nbp.h */
+             double fcenter[1024], fwidth[1024], nlow[1024], nhigh[1024]; int active[1024]; } ndb;
     /* amd, wdsp/amd.h */
     struct {
         int run, mode, levelfade, sbmode;
@@ -588,10 +591,80 @@ static void xshift(wo_channel *c, double *buf, int size)
 }
 
 /* ---- nbp0 impulse without notches (calc_nbp_impulse else-branch, wdsp/nbp.c:234-238) */
-static double *nbp0_impulse(wo_channel *c)
+/* make_nbp, wdsp/nbp.c:97-179: the passband [flow, fhigh] with the active notches cut out, as a list of bands */
+int wo_make_nbp(int nn, const int *active, const double *center, const double *width, const double *nlow, const double *nhigh,
+                double minwidth, int autoincr, double flow, double fhigh, double *bplow, double *bphigh, int *havnotch)
 {
-    return wo_fir_bandpass(c->nbp0.nc, c->nbp0.flow, c->nbp0.fhigh, c->nbp0.rate, c->nbp0.wintype, 1,
-                           c->nbp0.gain / (double)(2 * c->dsp_size));
+    int nbp, nnbp, adds, i, j, k;
+    double nl, nh;
+    int *del = (int *)zalloc(1024 * sizeof(int));
+    if (fhigh > flow) { bplow[0] = flow; bphigh[0] = fhigh; nbp = 1; }
+    else { free(del); return 0; }
+    *havnotch = 0;
+    for (k = 0; k < nn; k++) {
+        if (autoincr && width[k] < minwidth) { nl = center[k] - 0.5 * minwidth; nh = center[k] + 0.5 * minwidth; }
+        else { nl = nlow[k]; nh = nhigh[k]; }
+        if (active[k] && (nh > flow && nl < fhigh)) {
+            *havnotch = 1;
+            adds = 0;
+            for (i = 0; i < nbp; i++) {
+                if (nh > bplow[i] && nl < bphigh[i]) {
+                    if (nl <= bplow[i] && nh >= bphigh[i]) del[i] = 1;
+                    else if (nl > bplow[i] && nh < bphigh[i]) {
+                        bplow[nbp + adds] = nh; bphigh[nbp + adds] = bphigh[i]; bphigh[i] = nl; adds++;
+                    }
+                    else if (nl <= bplow[i] && nh > bplow[i]) bplow[i] = nh;
+                    else if (nl < bphigh[i] && nh >= bphigh[i]) bphigh[i] = nl;
+                }
+            }
+            nbp += adds;
+            nnbp = nbp;
+            for (i = 0; i < nbp; i++) {
+                if (del[i] == 1) {
+                    nnbp--;
+                    for (j = i; j < nnbp; j++) { bplow[j] = bplow[j + 1]; bphigh[j] = bphigh[j + 1]; }
+                    del[i] = 0;
+                }
+            }
+            nbp = nnbp;
+        }
+    }
+    free(del);
+    return nbp;
+}
+
+static double nbp0_min_notch_width(wo_channel *c)      /* min_notch_width, nbp.c:82-95 */
+{
+    return (c->nbp0.wintype == 1 ? 2200.0 : 1600.0) / (c->nbp0.nc / 256) * (c->nbp0.rate / 48000);
+}
+
+static double *nbp0_impulse(wo_channel *c)             /* calc_nbp_impulse, nbp.c:214-239 */
+{
+    double scale = c->nbp0.gain / (double)(2 * c->dsp_size);
+    if (c->nbp0.fnfrun) {
+        double *bplow = (double *)zalloc(1025 * sizeof(double)), *bphigh = (double *)zalloc(1025 * sizeof(double));
+        double offset = c->ndb.tunefreq + c->ndb.shift;
+        int havnotch = 0, i, k, numpb;
+        double *impulse = (double *)zalloc((size_t)c->nbp0.nc * 2 * sizeof(double));
+        numpb = wo_make_nbp(c->ndb.nn, c->ndb.active, c->ndb.fcenter, c->ndb.fwidth, c->ndb.nlow, c->ndb.nhigh,
+                            nbp0_min_notch_width(c), c->nbp0.autoincr, c->nbp0.flow + offset, c->nbp0.fhigh + offset,
+                            bplow, bphigh, &havnotch);
+        for (k = 0; k < numpb; k++) {                   /* fir_mbandpass, nbp.c:64-80 */
+            double *imp = wo_fir_bandpass(c->nbp0.nc, bplow[k] - offset, bphigh[k] - offset, c->nbp0.rate, c->nbp0.wintype, 1, scale);
+            for (i = 0; i < 2 * c->nbp0.nc; i++) impulse[i] += imp[i];
+            free(imp);
+        }
+        free(bplow); free(bphigh);
+        return impulse;
+    }
+    return wo_fir_bandpass(c->nbp0.nc, c->nbp0.flow, c->nbp0.fhigh, c->nbp0.rate, c->nbp0.wintype, 1, scale);
+}
+
+static void nbp0_update(wo_channel *c)                 /* UpdateNBPFilters, nbp.c:342-356 (nbp0 part) */
+{
+    double *imp = nbp0_impulse(c);
+    fircore_set_impulse(c->nbp0.p, imp);
+    free(imp);
 }
 
 static double *bp1_impulse(wo_channel *c)      /* bandpass.c:302 */
@@ -1033,6 +1106,7 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     meter_init(&c->agcmeter, dsp_rate, 0.100, 0.100, WO_AGC_AV, WO_AGC_PK, WO_AGC_GAIN, c->meter);
     nc = imax(2048, dsp_size);
     c->nbp0.run = 1; c->nbp0.nc = nc; c->nbp0.wintype = 0; c->nbp0.gain = 1.0;
+    c->nbp0.fnfrun = 0; c->nbp0.autoincr = 1;                   /* RXA.c:92,104 */
     c->nbp0.flow = -4150.0; c->nbp0.fhigh = -150.0; c->nbp0.rate = (double)dsp_rate;
     imp = nbp0_impulse(c);
     c->nbp0.p = wo_fircore_create(dsp_size, nc, imp);
@@ -1117,6 +1191,61 @@ void wo_RXANBPSetFreqs(wo_channel *c, double flow, double fhigh)
         free(imp);
     }
 }
+
+/* the notch database, wdsp/nbp.c:358-525 */
+int wo_RXANBPAddNotch(wo_channel *c, int notch, double fcenter, double fwidth, int active)
+{
+    int i, j;
+    if (notch >= 0 && notch <= c->ndb.nn && c->ndb.nn < 1024) {
+        c->ndb.nn++;
+        for (i = c->ndb.nn - 2, j = c->ndb.nn - 1; i >= notch; i--, j--) {
+            c->ndb.fcenter[j] = c->ndb.fcenter[i]; c->ndb.fwidth[j] = c->ndb.fwidth[i];
+            c->ndb.nlow[j] = c->ndb.nlow[i]; c->ndb.nhigh[j] = c->ndb.nhigh[i]; c->ndb.active[j] = c->ndb.active[i];
+        }
+        c->ndb.fcenter[notch] = fcenter; c->ndb.fwidth[notch] = fwidth;
+        c->ndb.nlow[notch] = fcenter - 0.5 * fwidth; c->ndb.nhigh[notch] = fcenter + 0.5 * fwidth;
+        c->ndb.active[notch] = active;
+        if (c->nbp0.fnfrun) nbp0_update(c);
+        return 0;
+    }
+    return -1;
+}
+
+int wo_RXANBPDeleteNotch(wo_channel *c, int notch)
+{
+    int i, j;
+    if (notch >= 0 && notch < c->ndb.nn) {
+        c->ndb.nn--;
+        for (i = notch, j = notch + 1; i < c->ndb.nn; i++, j++) {
+            c->ndb.fcenter[i] = c->ndb.fcenter[j]; c->ndb.fwidth[i] = c->ndb.fwidth[j];
+            c->ndb.nlow[i] = c->ndb.nlow[j]; c->ndb.nhigh[i] = c->ndb.nhigh[j]; c->ndb.active[i] = c->ndb.active[j];
+        }
+        if (c->nbp0.fnfrun) nbp0_update(c);
+        return 0;
+    }
+    return -1;
+}
+
+int wo_RXANBPEditNotch(wo_channel *c, int notch, double fcenter, double fwidth, int active)
+{
+    if (notch >= 0 && notch < c->ndb.nn) {
+        c->ndb.fcenter[notch] = fcenter; c->ndb.fwidth[notch] = fwidth;
+        c->ndb.nlow[notch] = fcenter - 0.5 * fwidth; c->ndb.nhigh[notch] = fcenter + 0.5 * fwidth;
+        c->ndb.active[notch] = active;
+        if (c->nbp0.fnfrun) nbp0_update(c);
+        return 0;
+    }
+    return -1;
+}
+
+void wo_RXANBPSetTuneFrequency(wo_channel *c, double f) { if (f != c->ndb.tunefreq) { c->ndb.tunefreq = f; if (c->nbp0.fnfrun) nbp0_update(c); } }
+void wo_RXANBPSetShiftFrequency(wo_channel *c, double f) { if (f != c->ndb.shift) { c->ndb.shift = f; if (c->nbp0.fnfrun) nbp0_update(c); } }
+void wo_RXANBPSetNotchesRun(wo_channel *c, int run)
+{
+    if (run != c->ndb.master_run) { c->ndb.master_run = run; c->nbp0.fnfrun = run; nbp0_update(c); }
+}
+void wo_RXANBPSetWindow(wo_channel *c, int wintype) { if (c->nbp0.wintype != wintype) { c->nbp0.wintype = wintype; nbp0_update(c); } }
+void wo_RXANBPSetAutoIncrease(wo_channel *c, int autoincr) { if (c->nbp0.autoincr != autoincr) { c->nbp0.autoincr = autoincr; nbp0_update(c); } }
 
 void wo_RXASetPassband(wo_channel *c, double f_low, double f_high)
 {

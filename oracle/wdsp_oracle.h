@@ -75,6 +75,17 @@ void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
 void wo_RXASetMP(wo_channel *c, int mp);                        /* RXA.c:948-958 */
+/* notch database, nbp.c:358-525; make_nbp nbp.c:97-179 */
+int wo_RXANBPAddNotch(wo_channel *c, int notch, double fcenter, double fwidth, int active);
+int wo_RXANBPDeleteNotch(wo_channel *c, int notch);
+int wo_RXANBPEditNotch(wo_channel *c, int notch, double fcenter, double fwidth, int active);
+void wo_RXANBPSetTuneFrequency(wo_channel *c, double tunefreq);
+void wo_RXANBPSetShiftFrequency(wo_channel *c, double shift);
+void wo_RXANBPSetNotchesRun(wo_channel *c, int run);
+void wo_RXANBPSetWindow(wo_channel *c, int wintype);
+void wo_RXANBPSetAutoIncrease(wo_channel *c, int autoincr);
+int wo_make_nbp(int nn, const int *active, const double *center, const double *width, const double *nlow, const double *nhigh,
+                double minwidth, int autoincr, double flow, double fhigh, double *bplow, double *bphigh, int *havnotch);
 void wo_mp_imp(int N, const double *fir, double *mpfir, int pfactor, int polarity);     /* fir.c:319-368 */
 void wo_SetRXAAMDFadeLevel(wo_channel *c, int levelfade);       /* amd.c:267-273 */
 void wo_SetRXAFMDeviation(wo_channel *c, double deviation);     /* fmd.c:236-246 */

@@ -156,6 +156,57 @@ void host_fft(std::vector<cd> &x, int sign)
     }
 }
 
+// make_nbp (wdsp/nbp.c:97-179): the passband [flow, fhigh] minus the active notches, as a list of sub-bands.
+// A notch narrower than minwidth is widened about its centre when autoincr is set.  Sub-bands are produced in the
+// reference's order (a split appends the upper part at the end), which fixes the summation order of fir_mbandpass.
+std::vector<std::pair<double, double>> make_nbp(const std::vector<Notch> &notches, double minwidth, int autoincr, double flow,
+                                                double fhigh, bool *havnotch)
+{
+    std::vector<std::pair<double, double>> bp;
+    if (havnotch) *havnotch = false;
+    if (!(fhigh > flow)) return bp;
+    bp.emplace_back(flow, fhigh);
+    for (const Notch &n : notches) {
+        double nl = n.fcenter - 0.5 * n.fwidth, nh = n.fcenter + 0.5 * n.fwidth;       // nlow / nhigh, nbp.c:374-375
+        if (autoincr && n.fwidth < minwidth) { nl = n.fcenter - 0.5 * minwidth; nh = n.fcenter + 0.5 * minwidth; }
+        if (!(n.active && nh > flow && nl < fhigh)) continue;
+        if (havnotch) *havnotch = true;
+        const size_t nbp = bp.size();
+        std::vector<char> del(nbp, 0);
+        for (size_t i = 0; i < nbp; i++) {
+            if (!(nh > bp[i].first && nl < bp[i].second)) continue;
+            if (nl <= bp[i].first && nh >= bp[i].second) del[i] = 1;
+            else if (nl > bp[i].first && nh < bp[i].second) { bp.emplace_back(nh, bp[i].second); bp[i].second = nl; }
+            else if (nl <= bp[i].first && nh > bp[i].first) bp[i].first = nh;
+            else if (nl < bp[i].second && nh >= bp[i].second) bp[i].second = nl;
+        }
+        // the reference compacts in place while it scans (nbp.c:161-172): an entry that slides into a slot already
+        // visited is not looked at again, and del[] belongs to positions, not entries -- restated as is
+        del.resize(bp.size(), 0);
+        size_t total = bp.size(), nnbp = total;
+        for (size_t i = 0; i < total; i++) {
+            if (del[i] == 1) {
+                nnbp--;
+                for (size_t j = i; j < nnbp; j++) bp[j] = bp[j + 1];
+                del[i] = 0;
+            }
+        }
+        bp.resize(nnbp);
+    }
+    return bp;
+}
+
+// fir_mbandpass (wdsp/nbp.c:64-80): sum of the band-pass impulse responses of the sub-bands
+std::vector<cd> fir_mbandpass(int N, const std::vector<std::pair<double, double>> &bands, double rate, double scale, int wintype)
+{
+    std::vector<cd> h((size_t)N, cd(0.0, 0.0));
+    for (const auto &b : bands) {
+        const std::vector<cd> imp = fir_bandpass(N, b.first, b.second, rate, wintype, 1, scale);
+        for (int i = 0; i < N; i++) h[(size_t)i] += imp[(size_t)i];
+    }
+    return h;
+}
+
 // mp_imp (wdsp/fir.c:319-368) with analytic() (fir.c:292-317): the minimum-phase impulse response with the
 // magnitude response of `fir`, by the cepstral method on a grid of pfactor * N points (N * pfactor a power of two).
 std::vector<cd> mp_imp(const std::vector<cd> &fir, int pfactor, int polarity)

@@ -3,6 +3,7 @@
 // calc_resample / fir_bandpass / calc_fircore on the setter's thread).
 #pragma once
 #include <complex>
+#include <utility>
 #include <vector>
 
 namespace qh {
@@ -28,6 +29,11 @@ std::vector<cd> fc_impulse(int nc, double f0, double f1, double g0, double g1, i
 void host_fft(std::vector<cd> &x, int sign);
 
 // Frequency-domain mask for qh::osfir_kernel: FFT_NFFT(h zero padded) / NFFT.
+// WDSP notch database entry and the notched band-pass design, wdsp/nbp.c:64-179
+struct Notch { double fcenter, fwidth; int active; };
+std::vector<std::pair<double, double>> make_nbp(const std::vector<Notch> &notches, double minwidth, int autoincr, double flow,
+                                                double fhigh, bool *havnotch);
+std::vector<cd> fir_mbandpass(int N, const std::vector<std::pair<double, double>> &bands, double rate, double scale, int wintype);
 std::vector<cd> mp_imp(const std::vector<cd> &fir, int pfactor, int polarity);     // wdsp/fir.c:319-368
 std::vector<cd> make_mask(const std::vector<cd> &h, int nfft);
 

@@ -51,6 +51,10 @@ struct ChanCfg {
     int shift_run = 1; double shift_freq = 0.0;                 // RXA.c:39-45
     int nbp_run = 1, nbp_nc = 2048, nbp_wintype = 0;            // RXA.c:90-106
     int mp = 0;                                                 // RXASetMP, RXA.c:948
+    // notch database (create_notchdb RXA.c:85-87) and nbp0's use of it (fnfrun 0, autoincr 1: RXA.c:92,104)
+    std::vector<Notch> notches;
+    double ndb_tunefreq = 0.0, ndb_shift = 0.0;
+    int fnfrun = 0, autoincr = 1;
     double nbp_flow = -4150.0, nbp_fhigh = -150.0, nbp_gain = 1.0;
     int amd_run = 0, amd_mode = 0, fmd_run = 0;                 // RXA.c:175-212
     int agc_run = 1, agc_mode = 3; double agc_fixed = 1000.0;   // RXA.c:335-358
@@ -283,12 +287,20 @@ int Engine::refresh_params()
         }
         if (c.nbp_dirty) {
             // calc_nbp_impulse without notches, wdsp/nbp.c:234-238; identity when the filter is off
-            bool same = last_nbp_cfg && last_nbp_cfg->nbp_run == c.nbp_run && last_nbp_cfg->nbp_nc == c.nbp_nc &&
+            bool same = !c.fnfrun && last_nbp_cfg && !last_nbp_cfg->fnfrun && last_nbp_cfg->nbp_run == c.nbp_run && last_nbp_cfg->nbp_nc == c.nbp_nc &&
                         last_nbp_cfg->nbp_wintype == c.nbp_wintype && last_nbp_cfg->nbp_flow == c.nbp_flow &&
                         last_nbp_cfg->nbp_fhigh == c.nbp_fhigh && last_nbp_cfg->nbp_gain == c.nbp_gain && last_nbp_cfg->mp == c.mp;
             if (!same) {
                 std::vector<cd> h;
-                if (c.nbp_run)
+                if (c.nbp_run && c.fnfrun) {
+                    // calc_nbp_impulse with the notches, wdsp/nbp.c:221-232: bands in absolute frequency, filter in baseband
+                    const double offset = c.ndb_tunefreq + c.ndb_shift;
+                    const double minwidth = (c.nbp_wintype == 1 ? 2200.0 : 1600.0) / (c.nbp_nc / 256) * ((double)dsp_rate / 48000);
+                    std::vector<std::pair<double, double>> bands =
+                        make_nbp(c.notches, minwidth, c.autoincr, c.nbp_flow + offset, c.nbp_fhigh + offset, nullptr);
+                    for (auto &b : bands) { b.first -= offset; b.second -= offset; }
+                    h = fir_mbandpass(c.nbp_nc, bands, (double)dsp_rate, c.nbp_gain / (double)(2 * dsp_size), c.nbp_wintype);
+                } else if (c.nbp_run)
                     h = fir_bandpass(c.nbp_nc, c.nbp_flow, c.nbp_fhigh, (double)dsp_rate, c.nbp_wintype, 1,
                                      c.nbp_gain / (double)(2 * dsp_size));
                 else
@@ -911,6 +923,86 @@ int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
         c.fm_nc = nc;                           // SetRXAFMNCde / SetRXAFMNCaud, wdsp/RXA.c:942-943
     });
 }
+
+static Notch mk_notch(double fcenter, double fwidth, int active)
+{
+    Notch n;
+    n.fcenter = fcenter; n.fwidth = fwidth; n.active = active;
+    return n;
+}
+
+// ---- the notch database (wdsp/nbp.c:358-525).  Return values of Add / Delete / Edit / Get follow the reference:
+// 0, or -1 for an index out of range (reported through *rval; the function result stays the library's status).
+int qh_rxa_RXANBPAddNotch(qh_rxa *h, int ch, int notch, double fcenter, double fwidth, int active, int *rval)
+{
+    if (rval) *rval = -1;
+    FOR_CH(h, ch, {
+        if (notch >= 0 && notch <= (int)c.notches.size() && c.notches.size() < 1024) {
+            c.notches.insert(c.notches.begin() + notch, mk_notch(fcenter, fwidth, active));
+            if (c.fnfrun) c.nbp_dirty = true;
+            if (rval) *rval = 0;
+        } else if (rval) *rval = -1;
+    });
+}
+
+int qh_rxa_RXANBPDeleteNotch(qh_rxa *h, int ch, int notch, int *rval)
+{
+    if (rval) *rval = -1;
+    FOR_CH(h, ch, {
+        if (notch >= 0 && notch < (int)c.notches.size()) {
+            c.notches.erase(c.notches.begin() + notch);
+            if (c.fnfrun) c.nbp_dirty = true;
+            if (rval) *rval = 0;
+        } else if (rval) *rval = -1;
+    });
+}
+
+int qh_rxa_RXANBPEditNotch(qh_rxa *h, int ch, int notch, double fcenter, double fwidth, int active, int *rval)
+{
+    if (rval) *rval = -1;
+    FOR_CH(h, ch, {
+        if (notch >= 0 && notch < (int)c.notches.size()) {
+            c.notches[(size_t)notch] = mk_notch(fcenter, fwidth, active);
+            if (c.fnfrun) c.nbp_dirty = true;
+            if (rval) *rval = 0;
+        } else if (rval) *rval = -1;
+    });
+}
+
+int qh_rxa_RXANBPGetNotch(qh_rxa *h, int ch, int notch, double *fcenter, double *fwidth, int *active, int *rval)
+{
+    if (!h || ch < 0 || ch >= h->e.nch || !fcenter || !fwidth || !active) return set_error(QH_ERR_INVALID, "RXANBPGetNotch: bad arguments");
+    const ChanCfg &c = h->e.cfg[(size_t)ch];
+    if (notch >= 0 && notch < (int)c.notches.size()) {
+        *fcenter = c.notches[(size_t)notch].fcenter; *fwidth = c.notches[(size_t)notch].fwidth; *active = c.notches[(size_t)notch].active;
+        if (rval) *rval = 0;
+    } else {
+        *fcenter = -1.0; *fwidth = 0.0; *active = -1;
+        if (rval) *rval = -1;
+    }
+    return QH_OK;
+}
+
+int qh_rxa_RXANBPGetNumNotches(qh_rxa *h, int ch, int *nnotches)
+{
+    if (!h || ch < 0 || ch >= h->e.nch || !nnotches) return set_error(QH_ERR_INVALID, "RXANBPGetNumNotches: bad arguments");
+    *nnotches = (int)h->e.cfg[(size_t)ch].notches.size();
+    return QH_OK;
+}
+
+int qh_rxa_RXANBPGetMinNotchWidth(qh_rxa *h, int ch, double *minwidth)
+{
+    if (!h || ch < 0 || ch >= h->e.nch || !minwidth) return set_error(QH_ERR_INVALID, "RXANBPGetMinNotchWidth: bad arguments");
+    const ChanCfg &c = h->e.cfg[(size_t)ch];
+    *minwidth = (c.nbp_wintype == 1 ? 2200.0 : 1600.0) / (c.nbp_nc / 256) * ((double)h->e.dsp_rate / 48000);      // nbp.c:82-95
+    return QH_OK;
+}
+
+int qh_rxa_RXANBPSetTuneFrequency(qh_rxa *h, int ch, double f) { FOR_CH(h, ch, { if (f != c.ndb_tunefreq) { c.ndb_tunefreq = f; if (c.fnfrun) c.nbp_dirty = true; } }); }
+int qh_rxa_RXANBPSetShiftFrequency(qh_rxa *h, int ch, double f) { FOR_CH(h, ch, { if (f != c.ndb_shift) { c.ndb_shift = f; if (c.fnfrun) c.nbp_dirty = true; } }); }
+int qh_rxa_RXANBPSetNotchesRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { run = run ? 1 : 0; if (run != c.fnfrun) { c.fnfrun = run; c.nbp_dirty = true; } }); }
+int qh_rxa_RXANBPSetWindow(qh_rxa *h, int ch, int wintype) { FOR_CH(h, ch, { if (c.nbp_wintype != wintype) { c.nbp_wintype = wintype; c.nbp_dirty = true; } }); }
+int qh_rxa_RXANBPSetAutoIncrease(qh_rxa *h, int ch, int autoincr) { FOR_CH(h, ch, { if (c.autoincr != autoincr) { c.autoincr = autoincr; if (c.fnfrun) c.nbp_dirty = true; } }); }
 
 // RXASetMP (wdsp/RXA.c:948-958): minimum-phase impulse responses in every fircore of the chain.  nbp0 and bp1 have
 // per-channel masks; the FM de-emphasis / audio masks are shared by the channels of an engine and follow the

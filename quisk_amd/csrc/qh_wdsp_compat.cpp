@@ -383,6 +383,55 @@ void SetRXAPanelSelect(int channel, int select) { WDSP_SETTER(qh_rxa_SetRXAPanel
 void SetRXAPanelCopy(int channel, int copy) { WDSP_SETTER(qh_rxa_SetRXAPanelCopy(L.c->eng, 0, copy)); }
 void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMode(L.c->eng, 0, sbmode)); }
 void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
+
+// the notch database, wdsp/nbp.c:358-525: int results are the reference's (0 / -1)
+int RXANBPAddNotch(int channel, int notch, double fcenter, double fwidth, int active)
+{
+    int rval = -1;
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return -1;
+    const int rc = qh_rxa_RXANBPAddNotch(L.c->eng, 0, notch, fcenter, fwidth, active, &rval);
+    if (rc) g_status = rc;
+    return rval;
+}
+int RXANBPGetNotch(int channel, int notch, double *fcenter, double *fwidth, int *active)
+{
+    int rval = -1;
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return -1;
+    const int rc = qh_rxa_RXANBPGetNotch(L.c->eng, 0, notch, fcenter, fwidth, active, &rval);
+    if (rc) g_status = rc;
+    return rval;
+}
+int RXANBPDeleteNotch(int channel, int notch)
+{
+    int rval = -1;
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return -1;
+    const int rc = qh_rxa_RXANBPDeleteNotch(L.c->eng, 0, notch, &rval);
+    if (rc) g_status = rc;
+    return rval;
+}
+int RXANBPEditNotch(int channel, int notch, double fcenter, double fwidth, int active)
+{
+    int rval = -1;
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return -1;
+    const int rc = qh_rxa_RXANBPEditNotch(L.c->eng, 0, notch, fcenter, fwidth, active, &rval);
+    if (rc) g_status = rc;
+    return rval;
+}
+void RXANBPGetNumNotches(int channel, int *nnotches) { WDSP_SETTER(qh_rxa_RXANBPGetNumNotches(L.c->eng, 0, nnotches)); }
+void RXANBPGetMinNotchWidth(int channel, double *minwidth) { WDSP_SETTER(qh_rxa_RXANBPGetMinNotchWidth(L.c->eng, 0, minwidth)); }
+void RXANBPSetTuneFrequency(int channel, double tunefreq) { WDSP_SETTER(qh_rxa_RXANBPSetTuneFrequency(L.c->eng, 0, tunefreq)); }
+void RXANBPSetShiftFrequency(int channel, double shift) { WDSP_SETTER(qh_rxa_RXANBPSetShiftFrequency(L.c->eng, 0, shift)); }
+void RXANBPSetNotchesRun(int channel, int run) { WDSP_SETTER(qh_rxa_RXANBPSetNotchesRun(L.c->eng, 0, run)); }
+void RXANBPSetWindow(int channel, int wintype) { WDSP_SETTER(qh_rxa_RXANBPSetWindow(L.c->eng, 0, wintype)); }
+void RXANBPSetAutoIncrease(int channel, int autoincr) { WDSP_SETTER(qh_rxa_RXANBPSetAutoIncrease(L.c->eng, 0, autoincr)); }
 void SetRXAAMDFadeLevel(int channel, int levelfade) { WDSP_SETTER(qh_rxa_SetRXAAMDFadeLevel(L.c->eng, 0, levelfade)); }
 void SetRXAFMDeviation(int channel, double deviation) { WDSP_SETTER(qh_rxa_SetRXAFMDeviation(L.c->eng, 0, deviation)); }
 void SetRXACTCSSFreq(int channel, double freq) { WDSP_SETTER(qh_rxa_SetRXACTCSSFreq(L.c->eng, 0, freq)); }

@@ -38,11 +38,18 @@ def load():
     for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
-              "RXASetMP", "SetRXAAMDRun"):
+              "RXASetMP", "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
         f.restype = i
-    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop"):
+    L.qh_rxa_RXANBPAddNotch.argtypes = [vp, i, i, d, d, i, C.POINTER(i)]
+    L.qh_rxa_RXANBPEditNotch.argtypes = [vp, i, i, d, d, i, C.POINTER(i)]
+    L.qh_rxa_RXANBPDeleteNotch.argtypes = [vp, i, i, C.POINTER(i)]
+    L.qh_rxa_RXANBPGetNotch.argtypes = [vp, i, i, C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(i)]
+    L.qh_rxa_RXANBPGetNumNotches.argtypes = [vp, i, C.POINTER(i)]
+    L.qh_rxa_RXANBPGetMinNotchWidth.argtypes = [vp, i, C.POINTER(d)]
+    for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop",
+              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]
         f.restype = i

@@ -15,7 +15,8 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "RXASetPassband", "RXANBPSetFreqs", "SetRXABandpassFreqs", "SetRXAPanelGain2", "SetRXAAMDSBMode",
             "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun", "SetRXAAGCAttack",
             "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold", "RXASetMP",
-            "SetRXAAMDRun")
+            "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease", "RXANBPSetTuneFrequency",
+            "RXANBPSetShiftFrequency")
 
 
 class RxaEngine:
@@ -38,6 +39,37 @@ class RxaEngine:
                 check(f(self._h, ch, *args))
             return call
         raise AttributeError(name)
+
+    # the notch database (wdsp/nbp.c:358-469): results are the reference's return values (0 / -1)
+    def RXANBPAddNotch(self, ch, notch, fcenter, fwidth, active):
+        r = C.c_int(-1)
+        check(self._L.qh_rxa_RXANBPAddNotch(self._h, ch, notch, fcenter, fwidth, active, C.byref(r)))
+        return r.value
+
+    def RXANBPEditNotch(self, ch, notch, fcenter, fwidth, active):
+        r = C.c_int(-1)
+        check(self._L.qh_rxa_RXANBPEditNotch(self._h, ch, notch, fcenter, fwidth, active, C.byref(r)))
+        return r.value
+
+    def RXANBPDeleteNotch(self, ch, notch):
+        r = C.c_int(-1)
+        check(self._L.qh_rxa_RXANBPDeleteNotch(self._h, ch, notch, C.byref(r)))
+        return r.value
+
+    def RXANBPGetNotch(self, ch, notch):
+        f, w, a, r = C.c_double(0), C.c_double(0), C.c_int(0), C.c_int(-1)
+        check(self._L.qh_rxa_RXANBPGetNotch(self._h, ch, notch, C.byref(f), C.byref(w), C.byref(a), C.byref(r)))
+        return r.value, f.value, w.value, a.value
+
+    def RXANBPGetNumNotches(self, ch):
+        n = C.c_int(0)
+        check(self._L.qh_rxa_RXANBPGetNumNotches(self._h, ch, C.byref(n)))
+        return n.value
+
+    def RXANBPGetMinNotchWidth(self, ch):
+        w = C.c_double(0)
+        check(self._L.qh_rxa_RXANBPGetMinNotchWidth(self._h, ch, C.byref(w)))
+        return w.value
 
     def process_ptr(self, d_in, in_stride, d_out, out_stride, nblk):
         """Device pointers (ints), strides in complex samples.  Asynchronous on the engine's stream."""

@@ -231,3 +231,48 @@ def test_output_resampler(qh, oracle, out_rate):
         ref = ch.xrxa(x[c])
         assert y.shape[1] == ref.size
         assert rel_rms(y[c], ref) < TOL, (c, rel_rms(y[c], ref))
+
+
+def test_notch_database(qh, oracle):
+    """The notched band-pass (wdsp/nbp.c:64-239, 358-525): notches added, edited, deleted, the VFO moved under them."""
+    nch, nblk = 2, 40
+    x = synth.make_input_numpy(nch, nblk * 1024)
+    e = _engine(qh, nch)
+    chans = [_oracle_channel(oracle, c) for c in range(nch)]
+
+    def both(name, *args):
+        r = getattr(e, name)(-1, *args)
+        rs = [getattr(ch, name)(*args) for ch in chans]
+        return r, rs
+
+    steps = [
+        lambda: both("RXANBPSetTuneFrequency", 7100000.0),
+        lambda: both("RXANBPAddNotch", 0, 7101000.0, 300.0, 1),          # 1000 +- 150 Hz in baseband
+        lambda: both("RXANBPAddNotch", 1, 7102500.0, 50.0, 1),           # narrow: widened to the minimum width
+        lambda: both("RXANBPSetNotchesRun", 1),
+        lambda: both("RXANBPSetTuneFrequency", 7100400.0),                # notches slide by 400 Hz
+        lambda: both("RXANBPEditNotch", 0, 7101900.0, 800.0, 1),
+        lambda: both("RXANBPSetAutoIncrease", 0),
+        lambda: both("RXANBPAddNotch", 0, 7100500.0, 900.0, 1),          # overlaps the lower passband edge
+        lambda: both("RXANBPDeleteNotch", 1),
+        lambda: both("RXANBPSetWindow", 1),
+        lambda: both("RXANBPSetNotchesRun", 0),
+    ]
+    outs, refs = [], [[] for _ in range(nch)]
+    per = 3
+    for k, st in enumerate(steps):
+        r, rs = st()
+        if r is not None:
+            assert all(r == v for v in rs)                                # Add / Edit / Delete return 0 like the reference
+        a, b = k * per * 1024, (k + 1) * per * 1024
+        outs.append(e.process_host(x[:, a:b]))
+        for c in range(nch):
+            refs[c].append(chans[c].xrxa(x[c, a:b]))
+    assert e.RXANBPAddNotch(0, 99, 1.0, 1.0, 1) == -1 and e.RXANBPDeleteNotch(0, 99) == -1
+    assert e.RXANBPGetNumNotches(0) == 2 and e.RXANBPGetNotch(0, 0)[0] == 0 and e.RXANBPGetNotch(0, 5)[0] == -1
+    assert e.RXANBPGetMinNotchWidth(0) == 2200.0 / 8
+    y = np.concatenate(outs, axis=1)
+    for c in range(nch):
+        ref = np.concatenate(refs[c])
+        assert np.abs(ref).max() > 1e-3
+        assert rel_rms(y[c], ref) < TOL, (c, rel_rms(y[c], ref))

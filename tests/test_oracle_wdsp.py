@@ -140,3 +140,28 @@ def test_agc_known_answers(oracle):
     slope = (out_target * (1.0 - 1.0 / var_gain)) / np.log10(out_target / (1.0 * var_gain * max_gain))
     want = out_target - slope * min(0.0, np.log10(0.05))
     assert abs(np.abs(y[-2000:]).mean() - want) < 1e-6 * want
+
+
+def test_make_nbp_known_answers(oracle):
+    """make_nbp (wdsp/nbp.c:97-179), worked by hand: a notch inside the passband splits it, one over an edge trims it,
+    an inactive or outside one does nothing, one covering everything leaves no band, narrow ones are widened."""
+    import ctypes as C
+    L = oracle.lib()
+    L.wo_make_nbp.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 3
+
+    def run(notches, flow, fhigh, minwidth=0.0, autoincr=0):
+        act = (C.c_int * 1024)(*[n[2] for n in notches])
+        cen = (C.c_double * 1024)(*[n[0] for n in notches])
+        wid = (C.c_double * 1024)(*[n[1] for n in notches])
+        nlo = (C.c_double * 1024)(*[n[0] - n[1] / 2 for n in notches])
+        nhi = (C.c_double * 1024)(*[n[0] + n[1] / 2 for n in notches])
+        bl, bh, hv = (C.c_double * 1025)(), (C.c_double * 1025)(), C.c_int(0)
+        n = L.wo_make_nbp(len(notches), act, cen, wid, nlo, nhi, minwidth, autoincr, flow, fhigh, bl, bh, C.byref(hv))
+        return [(bl[i], bh[i]) for i in range(n)], hv.value
+
+    assert run([(1000, 200, 1)], 300, 3000) == ([(300.0, 900.0), (1100.0, 3000.0)], 1)
+    assert run([(1000, 200, 1), (2900, 400, 1), (100, 600, 1), (5000, 100, 1), (1500, 50, 0)], 300, 3000) == (
+        [(400.0, 900.0), (1100.0, 2700.0)], 1)
+    assert run([(1000, 10000, 1)], 300, 3000) == ([], 1)
+    assert run([(1000, 20, 1)], 300, 3000, minwidth=200, autoincr=1) == ([(300.0, 900.0), (1100.0, 3000.0)], 1)
+    assert run([(1000, 20, 1)], 3000, 300) == ([], 0)
