@@ -1,0 +1,80 @@
+"""Empty, one-sample and ragged inputs and bad arguments through every batched entry point: nothing crashes, state is
+untouched by empty calls, errors are reported (edge cases the reference's callers hit).  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from quisk_amd import rxfilter
+
+pytestmark = pytest.mark.gpu
+
+
+def cx(seed, shape):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+def test_empty_calls_change_nothing(qh):
+    x = cx(1, (2, 4096))
+    for make in (lambda: qh.FirBank(2, np.hanning(33), 3), lambda: qh.RationalFir(2, np.hanning(36), 3, 2),
+                 lambda: qh.HalfBandCascade(2, 3), lambda: qh.QuiskRxBank(2, 96000, 3)):
+        a, b = make(), make()
+        ya = np.concatenate([a.process_host(x[:, :1024]), a.process_host(x[:, 1024:1024]), a.process_host(x[:, 1024:])], axis=1)
+        yb = b.process_host(x)
+        assert a.process_host(x[:, :0]).shape[1] == 0
+        assert ya.shape == yb.shape and rel_rms(ya, yb) < 1e-12
+
+
+def test_one_sample_at_a_time_equals_one_block(qh):
+    x = cx(2, (1, 300))
+    for make in (lambda: qh.FirBank(1, np.hanning(21), 2), lambda: qh.RationalFir(1, np.hanning(24), 4, 3)):
+        a, b = make(), make()
+        ya = np.concatenate([a.process_host(x[:, k:k + 1]) for k in range(300)], axis=1)
+        yb = b.process_host(x)
+        assert ya.shape == yb.shape and rel_rms(ya, yb) < 1e-12
+
+
+def test_rxa_zero_blocks_and_bad_shapes(qh):
+    e = qh.RxaEngine(2)
+    assert e.process_host(np.zeros((2, 0), dtype=complex)).shape == (2, 0)
+    with pytest.raises(ValueError):
+        e.process_host(np.zeros((2, 1000), dtype=complex))          # not a multiple of dsp_insize
+    with pytest.raises(ValueError):
+        e.process_host(np.zeros((3, 1024), dtype=complex))          # wrong channel count
+    with pytest.raises(qh.QuiskHipError):
+        e.SetRXAShiftFreq(5, 1.0)                                   # channel out of range
+    with pytest.raises(qh.QuiskHipError):
+        e.RXASetNC(-1, 3000)                                        # not a power of two
+
+
+def test_constructor_argument_errors(qh):
+    for bad in (lambda: qh.FirBank(0, [1.0], 1), lambda: qh.FirBank(1, [1.0], 0), lambda: qh.RationalFir(1, [1.0], 0, 1),
+                lambda: qh.HalfBandCascade(1, 9), lambda: qh.QuiskRxBank(1, 48000, 14), lambda: qh.Panadapter(1, 1000, 100, 48000.0),
+                lambda: qh.RxaEngine(1, in_rate=100000), lambda: qh.QuiskAgc(1, sample_rate=100)):
+        with pytest.raises(qh.QuiskHipError):
+            bad()
+
+
+def test_zeros_in_zeros_out_and_no_nans(qh):
+    z = np.zeros((1, 8192), dtype=complex)
+    assert not np.any(qh.FirBank(1, np.hanning(45), 2).process_host(z))
+    assert not np.any(qh.HalfBandCascade(1, 5).process_host(z))
+    for mode in (3, 4, 5, 9):
+        y = qh.QuiskRxBank(1, 192000, mode).process_host(z)
+        assert np.all(np.isfinite(y)) and not np.any(y)
+    e = qh.RxaEngine(1)
+    for m in (1, 6, 10, 5):                                          # USB, AM, SAM, FM on silence
+        e.SetRXAMode(-1, m)
+        y = e.process_host(z)
+        assert np.all(np.isfinite(y))
+
+
+def test_full_scale_input_stays_finite(qh):
+    n = 1 << 15
+    x = 2.0 ** 31 * np.exp(2j * np.pi * 0.01 * np.arange(n))[None, :]
+    b = qh.QuiskRxBank(1, 192000, 3)
+    b.set_filters(0, *rxfilter.make_filter_coef(b.get_filter_rate(), None, 2700, 1650))
+    b.set_agc(True)
+    y = np.concatenate([b.process_host(x[:, k:k + 4096]) for k in range(0, n, 4096)], axis=1)
+    # the first call only initialises process_agc (quisk.c:2173-2190): its 1024 output samples are not limited
+    assert np.all(np.isfinite(y)) and np.abs(y.real[:, 1024:]).max() <= 0.7 * 2.0 ** 31 * 1.0001
