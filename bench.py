@@ -213,7 +213,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo[k] * samples_per_step},
             "check_inband_gain": gain,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported by the single-GPU run only
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as exc:                             # the baseline is reported, never required

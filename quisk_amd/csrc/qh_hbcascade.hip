@@ -16,6 +16,7 @@ struct qh_hbc {
     size_t esize = 16;
     void *hist[2] = { nullptr, nullptr };
     int cur = 0;
+    bool attr_set = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     ~qh_hbc()
@@ -40,7 +41,10 @@ int launch(qh_hbc *h, const void *in, long long in_stride, int n_in, void *out, 
     const int nseg = (int)((n_in + seg - 1) / seg);
     const size_t lds = (size_t)G::ring_pairs() * sizeof(HbPair<T>);
     auto k = hb45_cascade_kernel<T, NS>;
-    QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!h->attr_set) {                         // once per handle: the dynamic LDS limit of this instantiation
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->attr_set = true;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)h->nch), dim3(NT), lds, h->stream, (const cplx<T> *)in, in_stride,
                        (const cplx<T> *)h->hist[h->cur], n_in, (cplx<T> *)out, out_stride, (int)seg);
     QH_HIP(hipGetLastError());
