@@ -117,18 +117,27 @@ template <int N> constexpr int lds_elems() { return N + N / 16; }
 // depth <= log2(R) so the rounding error stays at a few ulp.
 template <int R, typename C> __device__ __forceinline__ void apply_twiddle_powers(C (&x)[R], C w1)
 {
-    C w[R];
+    // w^r = w^hi * w^lo (hi = top set bit of r, w^hi by squaring).  Powers below R/2 are kept because the upper
+    // half needs them as w^lo; those of the upper half are used once and dropped, so R/2 + 1 powers are live at
+    // most, not R - 1 (the difference is what lets the decimating fp64 kernels fit 128 registers).
+    constexpr int H = R / 2 > 1 ? R / 2 : 1;
+    C w[H + 1];
     w[1] = w1;
+    x[1] = cmul(x[1], w1);
 #pragma unroll
     for (int r = 2; r < R; r++) {
-        // r = hi + lo with hi the top set bit: w^r = w^hi * w^lo; w^hi by squaring
         int hi = 1;
         while (hi * 2 <= r) hi *= 2;
-        int lo = r - hi;
-        w[r] = (lo == 0) ? cmul(w[hi / 2], w[hi / 2]) : cmul(w[hi], w[lo]);
+        const int lo = r - hi;
+        C wr;
+        if (hi < H || (hi == H && lo == 0)) {
+            wr = (lo == 0) ? cmul(w[hi / 2], w[hi / 2]) : cmul(w[hi], w[lo]);
+            w[r < H + 1 ? r : H] = wr;
+        } else {
+            wr = cmul(w[H], w[lo]);         // hi == H, lo > 0: upper half
+        }
+        x[r] = cmul(x[r], wr);
     }
-#pragma unroll
-    for (int r = 1; r < R; r++) x[r] = cmul(x[r], w[r]);
 }
 
 // One Stockham pass of radix R over N points for butterfly j, data in registers x[r] = in[j + r*N/R].
