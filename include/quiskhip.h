@@ -354,6 +354,22 @@ int qh_qagc_process_host(qh_qagc *a, void *h_buf, long long stride, int n);
 /* The receiver bank with process_agc on its output, as quisk_process_samples has it; off by default. */
 int qh_qrx_set_agc(qh_qrx *r, int on, double release_gain);
 
+/* ------------------------------------------------------------------ 9. Quisk native block API, one receiver */
+/* The shape of quisk.c's own receive API: a process-wide receiver, parameters through setters, samples through
+ * `int quisk_process_samples(complex double *cSamples, int nSamples)` (quisk.h:375, quisk.c:2289) -- in place, returns
+ * the output count at the playback rate, nSamples <= 0 returned unchanged.  process_agc is on as in the reference
+ * (default release gain 80, quisk.c:191).  qh_quisk_open takes quisk_sound_state.sample_rate, the filters.h tables and
+ * record_app's fft_size / data_width (0, 0 = no panadapter). */
+int qh_quisk_open(int sample_rate, const qh_qrx_tables *tables, int fft_size, int data_width);
+void qh_quisk_close(void);
+void qh_quisk_set_tune(int rx_tune_freq);                   /* set_tune, quisk.c:4702 */
+void qh_quisk_set_rx_mode(int mode);                        /* set_rx_mode, quisk.c:4621 */
+int qh_quisk_set_filters(const double *filtI, const double *filtQ, int size, int bandwidth);       /* set_filters, quisk.c:4551 */
+void qh_quisk_set_agc(double level);                        /* set_agc, quisk.c:4543 */
+int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
+int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
+int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */
+
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library
  * instead of filter.o.  `double *` stands for `complex double *` (same ABI: interleaved re, im).  Each call

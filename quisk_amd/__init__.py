@@ -10,6 +10,7 @@ from .fir import FirBank, HalfBandCascade, RationalFir, hb45_taps           # no
 from .pan import Panadapter                   # noqa: F401
 from .qrx import QuiskRxBank, QuiskAgc                  # noqa: F401
 from . import ingest                          # noqa: F401
+from . import quiskapi                        # noqa: F401
 from .ingest import IqFormat                  # noqa: F401
 
-__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "QuiskRxBank", "QuiskAgc", "ingest", "IqFormat"]
+__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "QuiskRxBank", "QuiskAgc", "ingest", "IqFormat", "quiskapi"]

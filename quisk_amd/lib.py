@@ -129,6 +129,17 @@ def load():
     L.qh_qagc_process.argtypes = [vp, vp, ll, i]
     L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
     L.qh_qrx_set_agc.argtypes = [vp, i, C.c_double]
+    L.qh_quisk_open.argtypes = [i, vp, i, i]
+    L.qh_quisk_close.restype = None
+    L.qh_quisk_set_tune.argtypes = [i]
+    L.qh_quisk_set_tune.restype = None
+    L.qh_quisk_set_rx_mode.argtypes = [i]
+    L.qh_quisk_set_rx_mode.restype = None
+    L.qh_quisk_set_filters.argtypes = [vp, vp, i, i]
+    L.qh_quisk_set_agc.argtypes = [C.c_double]
+    L.qh_quisk_set_agc.restype = None
+    L.qh_quisk_process_samples.argtypes = [vp, i]
+    L.qh_quisk_get_graph.argtypes = [C.c_double, C.c_double, vp, vp]
     L.qh_qrx_create_ex.restype = vp
     L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]
     L.qh_qrx_decim_rate.argtypes = [vp]

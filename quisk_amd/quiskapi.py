@@ -1,0 +1,62 @@
+"""The Quisk native block API for one receiver (include/quiskhip.h group 9), named like the `_quisk` calls the GUI
+makes (QS.set_tune, QS.set_rx_mode, QS.set_filters, QS.set_agc, QS.get_filter_rate, QS.get_graph) around
+quisk_process_samples (quisk.c:2289)."""
+import ctypes as C
+
+import numpy as np
+
+from . import rxfilter
+from .lib import load, check
+from .qrx import _TABLE_KEYS, _Tables
+
+_keep = {}
+
+
+def open(sample_rate, fft_size=0, data_width=0):
+    L = load()
+    t = rxfilter.coefficient_tables()
+    tabs = [np.ascontiguousarray(t[k], dtype=np.float64) for k in _TABLE_KEYS]
+    st = _Tables(*[a.ctypes.data for a in tabs])
+    _keep["tabs"] = (tabs, st)
+    _keep["data_width"] = data_width
+    check(L.qh_quisk_open(sample_rate, C.byref(st), fft_size, data_width))
+
+
+def close():
+    load().qh_quisk_close()
+
+
+def set_tune(rx_tune_freq):
+    load().qh_quisk_set_tune(int(rx_tune_freq))
+
+
+def set_rx_mode(mode):
+    load().qh_quisk_set_rx_mode(int(mode))
+
+
+def set_filters(filtI, filtQ, bandwidth):
+    fI = np.ascontiguousarray(filtI, dtype=np.float64)
+    fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
+    if fI.size != fQ.size:
+        raise ValueError("The size of filters I and Q must be equal")
+    check(load().qh_quisk_set_filters(fI.ctypes.data, fQ.ctypes.data, fI.size, int(bandwidth)))
+
+
+def set_agc(level):
+    load().qh_quisk_set_agc(C.c_double(level))
+
+
+def get_filter_rate():
+    return load().qh_quisk_get_filter_rate()
+
+
+def process_samples(buf, n):
+    """In place on a complex128 buffer with room for the output; returns the output count."""
+    return load().qh_quisk_process_samples(buf.ctypes.data, int(n))
+
+
+def get_graph(zoom=1.0, deltaf=0.0):
+    pix = np.empty(_keep["data_width"], dtype=np.float64)
+    sm = C.c_double(0)
+    cnt = load().qh_quisk_get_graph(C.c_double(zoom), C.c_double(deltaf), pix.ctypes.data, C.byref(sm))
+    return None if cnt == 0 else (pix, sm.value, cnt)
