@@ -120,6 +120,9 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 // workgroups fit a CU, provided each stays within 168 (128) VGPRs.
 // Measured (tools/ab_bench.py, C2): the D = 1 kernel gains from four waves despite 2 spilled registers
 // (3.41 -> 2.77 ms), the decimating ones are best at three (128 VGPRs cost them 14 spills).
+#ifndef QH_MASK_BATCH
+#define QH_MASK_BATCH 8
+#endif
 #ifndef QH_OSFIR_WAVES_F64_D1
 #define QH_OSFIR_WAVES_F64_D1 4
 #endif
@@ -216,6 +219,8 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
 #pragma unroll
         for (int q = 1; q < D; q++) acc = cadd(acc, cmul(x[i + EO * q], mask[t + NT * (i + EO * q)]));
         z[i] = acc;
+        // at most QH_MASK_BATCH mask values in flight: all 16 at once cost the D = 1 kernel its spills (A/B: +0.8 %)
+        if (((i + 1) * D) % QH_MASK_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- inverse FFT at NOUT points
