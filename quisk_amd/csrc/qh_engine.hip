@@ -561,7 +561,7 @@ template <int D, bool MIX, bool PACKED = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
-    dim3 grid((unsigned)ntiles, (unsigned)nch), block(NT);
+    dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, kNfft, D>();
     hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED>), grid, block, lds, s, a);
 }

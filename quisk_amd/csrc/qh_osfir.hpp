@@ -101,6 +101,29 @@ __device__ __forceinline__ unsigned load_tile(cplx<T> (&x)[E], const cplx<T> *__
     return okbits;
 }
 
+// XCD-aware workgroup -> (channel, tile) map.  Workgroup ids go round the 8 XCDs of the chip, each with its own
+// L2, and consecutive tiles of a channel share NFFT - D*Lout input samples (half of a tile for the nc = 2048
+// band-pass).  With the plain (tile, channel) grid neighbouring tiles land on different XCDs and both fetch the
+// shared half across the fabric (PMC: 2.1x the input size for the D = 1 kernel).  Here the launch is one-dimensional
+// over G = tiles * channels workgroups; XCD c (= id % 8) walks ITS contiguous eighth of the channel-major tile list
+// in dispatch order, so a tile's neighbour runs on the same XCD right after it and finds the overlap in L2.
+#ifndef QH_XCD_SWIZZLE
+#define QH_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ void xcd_tile_map(int ntiles, int &chan_slot, int &tile)
+{
+    const unsigned G = gridDim.x, lin = blockIdx.x;
+#if QH_XCD_SWIZZLE
+    const unsigned c = lin & 7u, k = lin >> 3, q = G >> 3, rem = G & 7u;
+    const unsigned gt = c * q + (c < rem ? c : rem) + k;
+#else
+    const unsigned gt = lin;
+    (void)G;
+#endif
+    chan_slot = (int)(gt / (unsigned)ntiles);
+    tile = (int)(gt - (unsigned)chan_slot * (unsigned)ntiles);
+}
+
 // dynamic LDS of the two kernels below
 template <typename T, int NFFT, int D> constexpr int osfir_lds_bytes()
 {
@@ -131,6 +154,13 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 #endif
 template <typename T, int D> constexpr int osfir_min_waves() { return sizeof(T) == 8 ? (D == 1 ? QH_OSFIR_WAVES_F64_D1 : QH_OSFIR_WAVES_F64) : 4; }
 
+#ifdef QH_OSFIR_PROBE      // tools/ubench/osfir_phase.hip only: shader-clock stamps of one workgroup per phase
+__device__ long long g_osfir_probe[16];
+#define QH_OPROBE(slot) do { if (blockIdx.x == 7 * 8 && threadIdx.x == 0) g_osfir_probe[slot] = clock64(); } while (0)
+#else
+#define QH_OPROBE(slot) do { } while (0)
+#endif
+
 template <typename T, int NFFT, int D, bool MIX, bool PACKED = false>
 __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(OsfirArgs<T> a)
 {
@@ -147,14 +177,16 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
     void *lds = smem;
 
     const int t = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int ch = a.chan_list ? a.chan_list[blockIdx.y] : (int)blockIdx.y;
+    int tile, slot;
+    xcd_tile_map(a.ntiles, slot, tile);
+    const int ch = a.chan_list ? a.chan_list[slot] : slot;
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
     const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile (Lout counts folded samples)
 
     // Interior tiles (all NFFT inputs inside this call's buffer: every tile but the first and the last
     // one or two of a channel) take plain loads; edge tiles take the clamped, history-aware path.
+    QH_OPROBE(0);
     C x[E];
     const bool interior = (g0 >= 0) && (g0 + NFFT <= a.n_in);       // workgroup-uniform
     if constexpr (PACKED) {
@@ -208,7 +240,9 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
     }
 
     // ---- forward FFT, registers -> registers
+    QH_OPROBE(1);
     Fwd::run(x, lds, Fwd::load(a.tw_fwd));
+    QH_OPROBE(2);
 
     // ---- mask multiply + D-fold: lane holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
     const C *mask = a.mask + (long long)ch * a.mask_stride;
@@ -224,8 +258,10 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
     }
 
     // ---- inverse FFT at NOUT points
+    QH_OPROBE(3);
     __syncthreads();                        // every lane has finished reading LDS in the last forward pass
     Inv::run(z, lds, Inv::load(a.tw_inv));
+    QH_OPROBE(4);
 
     // ---- epilogue + store of the Lout valid outputs
     C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
@@ -260,6 +296,7 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
             }
         }
     }
+    QH_OPROBE(5);
 }
 
 // Interpolating overlap-save FIR:  y[n] = sum_m h[m] * u[n - m],  u[U*i] = x[i], zero elsewhere  -- the audio-rate
@@ -281,8 +318,9 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
     void *lds = smem;
 
     const int t = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int ch = a.chan_list ? a.chan_list[blockIdx.y] : (int)blockIdx.y;
+    int tile, slot;
+    xcd_tile_map(a.ntiles, slot, tile);
+    const int ch = a.chan_list ? a.chan_list[slot] : slot;
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
     const int g0 = tile * (a.Lout / U) - a.P / U;           // low-rate index of tile element 0

@@ -189,13 +189,13 @@ struct Stage {
 
     template <typename T, int FOLD, bool MIX> void launch_dec(const OsfirArgs<T> &a)
     {
-        dim3 grid((unsigned)a.ntiles, (unsigned)nch), block(NT);
+        dim3 grid((unsigned)a.ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile)
         constexpr int lds = osfir_lds_bytes<T, kStageNfft, FOLD>();
         hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX>), grid, block, lds, stream, a);
     }
     template <typename T, int U> void launch_up(const OsfirArgs<T> &a)
     {
-        dim3 grid((unsigned)a.ntiles, (unsigned)nch), block(NT);
+        dim3 grid((unsigned)a.ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile)
         constexpr int lds = osfir_interp_lds_bytes<T, kStageNfft, U>();
         hipLaunchKernelGGL((osfir_interp_kernel<T, kStageNfft, U>), grid, block, lds, stream, a);
     }
