@@ -26,8 +26,11 @@ namespace qh {
 
 struct PanBand { int first, nwhole; double frac; int valid, pad; };     // S-meter passband in bins, quisk.c:5223-5244
 
+#ifndef QH_PAN_WAVES
+#define QH_PAN_WAVES 2
+#endif
 template <int M, int R>
-__global__ __launch_bounds__(NT, 2) void pan_spectrum_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
+__global__ __launch_bounds__(NT, QH_PAN_WAVES) void pan_spectrum_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
                                                           const double2 *tw, double *partial, double *partial_m2,
                                                           const PanBand *band, int nch)
 {
