@@ -353,6 +353,9 @@ int qh_qagc_process(qh_qagc *a, void *d_buf, long long stride, int n);
 int qh_qagc_process_host(qh_qagc *a, void *h_buf, long long stride, int n);
 /* The receiver bank with process_agc on its output, as quisk_process_samples has it; off by default. */
 int qh_qrx_set_agc(qh_qrx *r, int on, double release_gain);
+/* FM / DGT-FM banks: set_squelch(d) (quisk.c:4721); the block is zeroed while the mean |cx| (dB re full scale, over >= 2400
+ * samples, evaluated per call: quisk.c:2076-2085) is below `level`.  Default -999: never. */
+int qh_qrx_set_squelch(qh_qrx *r, int ch, double level);
 
 /* ------------------------------------------------------------------ 9. Quisk native block API, one receiver */
 /* The shape of quisk.c's own receive API: a process-wide receiver, parameters through setters, samples through

@@ -428,6 +428,10 @@ class OracleQuiskRx:
     def set_mode(self, m): self.L.qo_rx_set_mode(self.h, int(m))
     def set_bandwidth(self, bw): self.L.qo_rx_set_bandwidth(self.h, int(bw))
 
+    def set_squelch(self, level):
+        self.L.qo_rx_set_squelch.argtypes = [C.c_void_p, C.c_double]
+        self.L.qo_rx_set_squelch(self.h, float(level))
+
     def set_agc(self, on, release_gain=80.0):
         self.L.qo_rx_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_double]
         self.L.qo_rx_set_agc(self.h, int(on), float(release_gain))

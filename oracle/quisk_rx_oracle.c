@@ -98,6 +98,8 @@ struct qo_rx {
     double *filtI, *filtQ, *bufI, *bufQ, *bufC;
     double *dsamples;
     int dcap;
+    double rf_sum, squelch, squelch_level;      /* MeasureSquelch[0], quisk.c:255-263; squelch_level quisk.c:193 */
+    int rf_count, squelch_active;
     qo_agc *agc;                    /* Agc1 = {0.7, 0, 0}, quisk.c:2321 */
     int agc_on;
     double agc_gain;
@@ -143,6 +145,7 @@ qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t)
     qo_fir_init(&r->sdriq133, t->sdriq133, 136, 1); qo_fir_init(&r->sdriq167, t->sdriq167, 174, 1);
     qo_fir_init(&r->sdriq185, t->sdriq185, 189, 1);
     r->bandwidth = 2700;
+    r->squelch_level = -999.0;
     qo_hb45_init(&r->dHB4); qo_hb45_init(&r->dHB5); qo_hb45_init(&r->dHB6); qo_hb45_init(&r->dHB7);
     qo_fir_init(&r->dm48to24, t->f48dec24, 98, 1);
     qo_fir_init(&r->audio24p4, t->audio24p4, 50, 0);
@@ -179,6 +182,7 @@ void qo_rx_free(qo_rx *r)
 void qo_rx_set_tune(qo_rx *r, int f) { r->tune = f; }
 void qo_rx_set_mode(qo_rx *r, int mode) { r->mode = mode; }
 void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
+void qo_rx_set_squelch(qo_rx *r, double level) { r->squelch_level = level; }     /* set_squelch, quisk.c:4721-4727 */
 void qo_rx_set_agc(qo_rx *r, int on, double release_gain) { r->agc_on = on; r->agc_gain = release_gain; }
 
 void qo_rx_set_filters(qo_rx *r, const double *fI, const double *fQ, int size)
@@ -287,6 +291,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
 {
     int i;
     double re, im, d, di;
+    r->squelch_active = 0;                                      /* quisk.c:1908 */
     switch (r->mode) {
     case QO_CWL: case QO_CWU:
         r->filter_srate = r->decim_srate / 8;
@@ -331,6 +336,8 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
         for (i = 0; i < n; i++) {
             double pr, pi;
             dRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
+            r->rf_sum += hypot(re, im);                         /* MeasureSquelch[bank].rf_sum += cabs(cx), quisk.c:2032 */
+            r->rf_count += 1;
             pr = re * r->fm1_re + im * r->fm1_im;               /* cx * conj(fm_1) */
             pi = im * r->fm1_re - re * r->fm1_im;
             di = atan2(pi, pr);                                 /* carg */
@@ -347,6 +354,12 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
         n = qo_dFilter(ds, n, &r->fmhp);
         n = qo_dInterp2HB45(ds, n, &r->dHB6);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        if (r->rf_count >= 2400) {                              /* quisk.c:2076-2084 */
+            r->squelch = r->rf_sum / r->rf_count / CLIP32;
+            r->squelch = r->squelch > 1.E-10 ? 20 * log10(r->squelch) : -200.0;
+            r->rf_sum = 0; r->rf_count = 0;
+        }
+        r->squelch_active = r->squelch < r->squelch_level;      /* quisk.c:2085 */
         break;
     case QO_DGT_U: case QO_FDV_U: case QO_DGT_L: case QO_FDV_L:         /* quisk.c:2087-2140 */
         if (r->bandwidth < 3000) {                                       /* DGT_NARROW_FREQ, quisk.c:52 */
@@ -401,5 +414,7 @@ int qo_rx_process(qo_rx *r, double *x, int n)
         if (!r->agc) r->agc = qo_agc_create(r->decim_srate, 0.7, 1.0);
         qo_agc_process(r->agc, x, n, r->mode == QO_DGT_IQ, r->agc_gain);
     }
+    if (r->squelch_active)                                      /* squelch_real && squelch_imag, quisk.c:2623,2716-2719 */
+        for (i = 0; i < n; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; }
     return n;
 }

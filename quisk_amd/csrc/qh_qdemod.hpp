@@ -59,4 +59,38 @@ static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long
     if (lane == 0) state[ch] = st;
 }
 
+
+// FM squelch (quisk.c:2032-2033,2076-2085): the mean |cx| of the Rx-filtered samples over at least 2400 of them
+// (evaluated once per call, like the reference) in dB re full scale; active while it is below squelch_level.
+// One wave per channel; `buf` is the Rx filter's output of this call.
+struct QSquelchState { double rf_sum, squelch; int rf_count, active; };
+static __global__ __launch_bounds__(64) void q_fm_squelch_kernel(const double2 *buf, long long stride, int n, QSquelchState *state,
+                                                             const double *level)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    const double2 *p = buf + (long long)ch * stride;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s += hypot(p[i].x, p[i].y);
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (lane == 0) {
+        QSquelchState st = state[ch];
+        st.rf_sum += s; st.rf_count += n;
+        if (st.rf_count >= 2400) {
+            double v = st.rf_sum / st.rf_count / 2147483647.0;
+            st.squelch = v > 1.E-10 ? 20 * log10(v) : -200.0;
+            st.rf_sum = 0; st.rf_count = 0;
+        }
+        st.active = st.squelch < level[ch];
+        state[ch] = st;
+    }
+}
+
+// squelch_real && squelch_imag: the block goes out as zeros (quisk.c:2716-2719)
+static __global__ __launch_bounds__(256) void q_mute_kernel(double2 *out, long long stride, int n, const QSquelchState *state)
+{
+    const int ch = blockIdx.y;
+    if (!state[ch].active) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[(long long)ch * stride + i] = make_double2(0.0, 0.0);
+}
+
 }  // namespace qh

@@ -93,6 +93,10 @@ struct Qrx {
     QFmParam fm_prm{};
     double2 *buf[2] = { nullptr, nullptr };
     long long buf_cap = 0;
+    QSquelchState *sq_state = nullptr;  // FM squelch (quisk.c:2076-2085)
+    double *sq_level = nullptr;
+    std::vector<double> h_sq_level;
+    bool sq_dirty = false;
     qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = off
     double agc_gain = 80.0;
 
@@ -106,6 +110,7 @@ struct Qrx {
             if (s.rat) qh_rat_destroy(s.rat);
         }
         (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
+        (void)hipFree(sq_state); (void)hipFree(sq_level);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -315,6 +320,13 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
             hipMemcpy(q.fm_state, init.data(), (size_t)nch * sizeof(double4), hipMemcpyHostToDevice) != hipSuccess) {
             set_error(QH_ERR_HIP, "allocation failed"); return fail();
         }
+        q.h_sq_level.assign((size_t)nch, -999.0);                                           // squelch_level, quisk.c:193
+        if (hipMalloc((void **)&q.sq_state, (size_t)nch * sizeof(QSquelchState)) != hipSuccess ||
+            hipMemset(q.sq_state, 0, (size_t)nch * sizeof(QSquelchState)) != hipSuccess ||
+            hipMalloc((void **)&q.sq_level, (size_t)nch * 8) != hipSuccess ||
+            hipMemcpy(q.sq_level, q.h_sq_level.data(), (size_t)nch * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error(QH_ERR_HIP, "allocation failed"); return fail();
+        }
         const double www = std::tan(M_PI * 300.0 / 48000);                                  // quisk.c:1894-1898
         const double nnn = 1.0 / (1.0 + www);
         q.fm_prm.a0 = www * nnn; q.fm_prm.a1 = q.fm_prm.a0; q.fm_prm.b1 = nnn * (www - 1.0);
@@ -426,6 +438,15 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.dc_state);
             continue;
         case Step::FM_DISC:
+            if (n > 0) {
+                if (q.sq_dirty) {
+                    QH_HIP(hipMemcpyAsync(q.sq_level, q.h_sq_level.data(), (size_t)q.nch * 8, hipMemcpyHostToDevice, q.stream));
+                    QH_HIP(hipStreamSynchronize(q.stream));
+                    q.sq_dirty = false;
+                }
+                hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream, static_cast<const double2 *>(cur),
+                                   cur_stride, n, q.sq_state, q.sq_level);
+            }
             if (n > 0)
                 hipLaunchKernelGGL(q_fm_disc_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);
@@ -436,8 +457,26 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     }
     if (q.agc && n > 0)
         if (int rc = qh_qagc_process(q.agc, d_out, out_stride, n)) return rc;
+    if (q.sq_state && n > 0) {
+        int gx = (n + 255) / 256;
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(q_mute_kernel, dim3((unsigned)gx, (unsigned)q.nch), dim3(256), 0, q.stream, reinterpret_cast<double2 *>(d_out),
+                           out_stride, n, q.sq_state);
+    }
     if (n_out) *n_out = n;
     QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+// set_squelch (quisk.c:4721-4727): the FM squelch threshold in dB re full scale; -999 (the default) never mutes
+int qh_qrx_set_squelch(qh_qrx *h, int ch, double level)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    Qrx &q = h->q;
+    if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
+    if (!q.sq_state) return set_error(QH_ERR_UNSUPPORTED, "the FM squelch belongs to modes FM and DGT-FM (quisk.c:2026-2085)");
+    for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? q.nch : ch + 1); c++) q.h_sq_level[(size_t)c] = level;
+    q.sq_dirty = true;
     return QH_OK;
 }
 

@@ -159,3 +159,37 @@ def test_dgt_fm_is_fm(qh, oracle):
 def test_ext_mode_is_refused(qh):
     with pytest.raises(qh.QuiskHipError):
         qh.QuiskRxBank(1, 48000, 6)
+
+
+def test_fm_squelch_mutes_blocks_like_the_reference(qh, oracle):
+    """FM squelch (quisk.c:2032,2076-2085,2716): carrier present -> audio, carrier gone -> zero blocks, per call."""
+    fs, blk = 48000, 1200
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(2, fs, 5)
+    r = [oracle.OracleQuiskRx(fs, tabs) for _ in range(2)]
+    fI, fQ = rxfilter.make_filter_coef(48000, None, 12000, 0)
+    levels = (-60.0, -999.0)
+    for c in range(2):
+        bank.set_filters(c, fI, fQ); bank.set_squelch(c, levels[c])
+        r[c].set_mode(5); r[c].set_filters(fI, fQ); r[c].set_squelch(levels[c])
+    n = 48000
+    t = np.arange(n)
+    amp = np.where((t > 12000) & (t < 30000), 2.0 ** 28, 2.0 ** 8)               # carrier on for a while, then noise floor
+    x = amp * np.exp(3j * np.sin(2 * np.pi * 1000.0 / fs * t)) + 2.0 ** 6 * (np.random.default_rng(3).standard_normal(n) + 0j)
+    x = np.stack([x, x])
+    ys = [bank.process_host(x[:, k:k + blk]) for k in range(0, n, blk)]
+    y = np.concatenate(ys, axis=1)
+    for c in range(2):
+        want = np.concatenate([r[c].process(x[c, k:k + blk]) for k in range(0, n, blk)])
+        muted = ~np.any(want.reshape(-1, blk), axis=1)
+        if c == 0:
+            assert muted.any() and not muted.all()                  # both states occur
+        else:
+            assert not muted.any()
+        got_muted = ~np.any(y[c].reshape(-1, blk), axis=1)
+        assert np.array_equal(muted, got_muted)
+        live = np.repeat(~muted, blk)
+        live[:4000] = False                                          # detector fill-in (see test_modes_and_rates)
+        assert rel_rms(y[c][live], want[live]) < 1e-6
+    with pytest.raises(qh.QuiskHipError):
+        qh.QuiskRxBank(1, fs, 3).set_squelch(0, -50.0)
