@@ -46,7 +46,7 @@ template <typename T> struct OsfirArgs {
     const unsigned long long *nco_dphase;  // [nch]
     const double2 *nco_step;               // [nch]
     const EpiParam *epi;          // [nch] or null
-    const int *chan_list;         // null: channel = blockIdx.y; else channel = chan_list[blockIdx.y] (sub-set launches)
+    const int *chan_list;         // null: channel = slot; else channel = chan_list[slot] (sub-set launches), slot from xcd_tile_map
     long long in_stride, hist_stride, out_stride, mask_stride;
     long long out_offset;
     int hist_len;
@@ -136,9 +136,9 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
     return a > b ? a : b;
 }
 
-// One workgroup = one tile (blockIdx.x) of one channel (blockIdx.y).  Straight-line code: a persistent
-// tile loop with register prefetch was tried and costs more in registers (spills at 2 workgroups/CU) than
-// it gains (tools/ab_bench.py, profiles/r01_notes.md); latency is hidden by the two workgroups per CU.
+// One workgroup = one tile of one channel (xcd_tile_map above).  Straight-line code: a persistent tile loop with
+// register prefetch was tried and costs more in registers than it gains (tools/ab_bench.py, profiles/r01_notes.md);
+// latency is hidden by the three or four workgroups a CU holds.
 // Waves per SIMD the register allocator must leave room for: with the split LDS exchange three (or four) fp64
 // workgroups fit a CU, provided each stays within 168 (128) VGPRs.
 // Measured (tools/ab_bench.py, C2): the D = 1 kernel gains from four waves despite 2 spilled registers
