@@ -356,6 +356,9 @@ int qh_qrx_set_agc(qh_qrx *r, int on, double release_gain);
 /* FM / DGT-FM banks: set_squelch(d) (quisk.c:4721); the block is zeroed while the mean |cx| (dB re full scale, over >= 2400
  * samples, evaluated per call: quisk.c:2076-2085) is below `level`.  Default -999: never. */
 int qh_qrx_set_squelch(qh_qrx *r, int ch, double level);
+/* CW / SSB / AM banks: set_ssb_squelch(enabled, level) (quisk.c:4729): spectral-flatness squelch on 512-sample blocks of the
+ * audio at the filter rate (ssb_squelch, quisk.c:1086-1180) plus the 512-sample audio delay that goes with it (d_delay). */
+int qh_qrx_set_ssb_squelch(qh_qrx *r, int enabled, int level);
 
 /* ------------------------------------------------------------------ 9. Quisk native block API, one receiver */
 /* The shape of quisk.c's own receive API: a process-wide receiver, parameters through setters, samples through

@@ -428,6 +428,10 @@ class OracleQuiskRx:
     def set_mode(self, m): self.L.qo_rx_set_mode(self.h, int(m))
     def set_bandwidth(self, bw): self.L.qo_rx_set_bandwidth(self.h, int(bw))
 
+    def set_ssb_squelch(self, enabled, level):
+        self.L.qo_rx_set_ssb_squelch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.L.qo_rx_set_ssb_squelch(self.h, int(enabled), int(level))
+
     def set_squelch(self, level):
         self.L.qo_rx_set_squelch.argtypes = [C.c_void_p, C.c_double]
         self.L.qo_rx_set_squelch(self.h, float(level))

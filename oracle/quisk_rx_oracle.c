@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include "fft_oracle.h"
 #include "quisk_oracle.h"
 #include "quisk_rx_oracle.h"
 
@@ -100,6 +101,10 @@ struct qo_rx {
     int dcap;
     double rf_sum, squelch, squelch_level;      /* MeasureSquelch[0], quisk.c:255-263; squelch_level quisk.c:193 */
     int rf_count, squelch_active;
+    int ssb_squelch_enabled, ssb_squelch_level; /* set_ssb_squelch, quisk.c:4729 */
+    int sq_inited, sq_index, sq_open;           /* ssb_squelch's static plan flag and MS->index, MS->sq_open */
+    double sq_in[512], sq_delay[512];           /* MS->in_fft; d_delay's buffer (quisk.c:1057-1084) */
+    int sq_delay_index;
     qo_agc *agc;                    /* Agc1 = {0.7, 0, 0}, quisk.c:2321 */
     int agc_on;
     double agc_gain;
@@ -183,6 +188,7 @@ void qo_rx_set_tune(qo_rx *r, int f) { r->tune = f; }
 void qo_rx_set_mode(qo_rx *r, int mode) { r->mode = mode; }
 void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
 void qo_rx_set_squelch(qo_rx *r, double level) { r->squelch_level = level; }     /* set_squelch, quisk.c:4721-4727 */
+void qo_rx_set_ssb_squelch(qo_rx *r, int enabled, int level) { r->ssb_squelch_enabled = enabled; r->ssb_squelch_level = level; }
 void qo_rx_set_agc(qo_rx *r, int on, double release_gain) { r->agc_on = on; r->agc_gain = release_gain; }
 
 void qo_rx_set_filters(qo_rx *r, const double *fI, const double *fQ, int size)
@@ -226,6 +232,64 @@ static void dRxFilterOut(qo_rx *r, double re, double im, double *ore, double *oi
     }
     r->indexD++;
     *ore = ar; *oim = ai;
+}
+
+#define SQUELCH_FFT_SIZE 512        /* quisk.c:53 */
+#define CLIP16 32767.0              /* quisk.h:14 */
+
+static void ssb_squelch(qo_rx *r, const double *ds, int n, int samp_rate)      /* quisk.c:1086-1180 */
+{
+    int i, bw, bw1, bw2, inp;
+    double d, arith_avg, geom_avg, ratio;
+    static double fft_window[SQUELCH_FFT_SIZE];
+    double buf[2 * SQUELCH_FFT_SIZE];
+    if (!r->sq_inited) {            /* "if (!plan) { ...; return; }": the first call only sets up */
+        r->sq_inited = 1;
+        return;
+    }
+    for (i = 0; i < SQUELCH_FFT_SIZE; i++) fft_window[i] = 0.50 - 0.50 * cos(2. * M_PI * i / SQUELCH_FFT_SIZE);
+    for (inp = 0; inp < n; inp++) {
+        r->sq_in[r->sq_index++] = ds[inp];
+        if (r->sq_index >= SQUELCH_FFT_SIZE) {
+            r->sq_index = 0;
+            for (i = 0; i < SQUELCH_FFT_SIZE; i++) { buf[2 * i] = r->sq_in[i] * fft_window[i]; buf[2 * i + 1] = 0.0; }
+            fo_fft(buf, SQUELCH_FFT_SIZE, -1);                  /* fftw_execute_dft_r2c: bins 0 .. N/2 */
+            bw = r->bandwidth;
+            if (bw > 3000) bw = 3000;
+            bw1 = 300 * SQUELCH_FFT_SIZE / samp_rate;
+            bw2 = (bw + 300) * SQUELCH_FFT_SIZE / samp_rate;
+            if (bw2 > SQUELCH_FFT_SIZE / 2 + 1) bw2 = SQUELCH_FFT_SIZE / 2 + 1;        /* out_fft holds N/2 + 1 bins */
+            arith_avg = 0.0; geom_avg = 0.0;
+            for (i = bw1; i < bw2; i++) {
+                double cr = buf[2 * i] / CLIP16, ci = buf[2 * i + 1] / CLIP16;
+                d = cr * cr + ci * ci;
+                if (d > 1E-4) { arith_avg += d; geom_avg += log(d); }
+            }
+            if (arith_avg > 1E-4) {
+                bw = bw2 - bw1;
+                arith_avg = log(arith_avg / bw);
+                geom_avg /= bw;
+                ratio = arith_avg - geom_avg;
+            } else {
+                ratio = 1.0;
+            }
+            if (ratio > r->ssb_squelch_level * 0.005) r->sq_open = samp_rate;       /* one second timer */
+        }
+    }
+    r->sq_open -= n;
+    if (r->sq_open < 0) r->sq_open = 0;
+    r->squelch_active = r->sq_open == 0;
+}
+
+static void d_delay(qo_rx *r, double *ds, int n)                /* quisk.c:1057-1084, samp_delay = SQUELCH_FFT_SIZE */
+{
+    int i;
+    for (i = 0; i < n; i++) {
+        double sample = r->sq_delay[r->sq_delay_index];
+        r->sq_delay[r->sq_delay_index] = ds[i];
+        ds[i] = sample;
+        if (++r->sq_delay_index >= SQUELCH_FFT_SIZE) r->sq_delay_index = 0;
+    }
 }
 
 static int process_decimate(qo_rx *r, double *x, int n)        /* quisk.c:1729-1843 */
@@ -302,6 +366,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
             ds[i] = r->mode == QO_CWL ? re + im : re - im;
         }
+        if (r->ssb_squelch_enabled) { ssb_squelch(r, ds, n, r->filter_srate); d_delay(r, ds, n); }     /* quisk.c:1925-1928 */
         n = qo_dInterpolate(ds, n, &r->audio12p2, 2);
         n = qo_dInterp2HB45(ds, n, &r->dHB6);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
@@ -314,6 +379,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
             ds[i] = r->mode == QO_LSB ? re + im : re - im;
         }
+        if (r->ssb_squelch_enabled) { ssb_squelch(r, ds, n, r->filter_srate); d_delay(r, ds, n); }     /* quisk.c:1970-1973 */
         n = qo_dInterpolate(ds, n, &r->audio24p4, 2);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
         break;
@@ -329,6 +395,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             ds[i] = di;
         }
         n = qo_dFilter(ds, n, &r->audio24p6);
+        if (r->ssb_squelch_enabled) { ssb_squelch(r, ds, n, r->filter_srate); d_delay(r, ds, n); }     /* quisk.c:2020-2023 */
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
         break;
     case QO_FM: case QO_DGT_FM:

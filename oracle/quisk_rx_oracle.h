@@ -37,6 +37,7 @@ typedef struct {                /* the filters.h tables the path uses */
 
 typedef struct qo_rx qo_rx;
 qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t);
+void qo_rx_set_ssb_squelch(qo_rx *r, int enabled, int level);   /* set_ssb_squelch, quisk.c:4729; CW / SSB / AM */
 void qo_rx_set_squelch(qo_rx *r, double level);                 /* set_squelch (FM), quisk.c:4721; default -999 = never */
 void qo_rx_set_bandwidth(qo_rx *r, int bw);                     /* filter_bandwidth[0], third argument of set_filters */
 void qo_rx_free(qo_rx *r);

@@ -93,4 +93,78 @@ static __global__ __launch_bounds__(256) void q_mute_kernel(double2 *out, long l
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[(long long)ch * stride + i] = make_double2(0.0, 0.0);
 }
 
+
+// SSB squelch (ssb_squelch, quisk.c:1086-1180): the real audio at the filter rate is cut into 512-sample blocks
+// (Hanning window, quisk.c:1110); per block the spectral flatness of the passband bins -- log of the arithmetic mean
+// minus the mean of the logs of |X / CLIP16|^2, bins below 1e-4 skipped -- is compared with level * 0.005; a
+// block above it opens the squelch for one second.  Per call: sq_open -= n, active = (sq_open == 0).  One
+// workgroup per channel; a lane owns one passband bin and evaluates it by a rotation-recurrence DFT (only the
+// passband bins are needed, at most 257).
+struct QSsbSqState { int index, sq_open; };
+struct QSsbSqParam { int samp_rate, bw1, bw2; double thresh; };
+static __global__ __launch_bounds__(256) void q_ssb_squelch_kernel(const double2 *buf, long long stride, int n, QSsbSqState *state,
+                                                               double *ring, QSquelchState *flag, QSsbSqParam q)
+{
+    __shared__ double blk[512];
+    __shared__ double red[8];
+    const int ch = blockIdx.x, t = threadIdx.x;
+    const double2 *p = buf + (long long)ch * stride;
+    double *rg = ring + (long long)ch * 512;
+    QSsbSqState st = state[ch];
+    int pos = 0, idx = st.index;
+    const int nb = q.bw2 - q.bw1;
+    while (idx + (n - pos) >= 512) {
+        const int need = 512 - idx;
+        for (int j = t; j < 512; j += 256) {
+            const double v = j < idx ? rg[j] : p[pos + j - idx].x;
+            blk[j] = v * (0.50 - 0.50 * cospi(2.0 * j / 512.0));
+        }
+        __syncthreads();
+        double arith = 0.0, geom = 0.0;
+        for (int i = q.bw1 + t; i < q.bw2; i += 256) {
+            double wr, wi, cr = 1.0, ci = 0.0, xr = 0.0, xi = 0.0;
+            sincospi(-2.0 * i / 512.0, &wi, &wr);
+            for (int j = 0; j < 512; j++) {
+                xr = __builtin_fma(blk[j], cr, xr); xi = __builtin_fma(blk[j], ci, xi);
+                const double nr = cr * wr - ci * wi;
+                ci = cr * wi + ci * wr; cr = nr;
+            }
+            xr /= 32767.0; xi /= 32767.0;           // CLIP16, quisk.h:14
+            const double d = xr * xr + xi * xi;
+            if (d > 1E-4) { arith += d; geom += log(d); }
+        }
+        for (int d2 = 32; d2 > 0; d2 >>= 1) { arith += __shfl_down(arith, d2, 64); geom += __shfl_down(geom, d2, 64); }
+        if ((t & 63) == 0) { red[t >> 6] = arith; red[4 + (t >> 6)] = geom; }
+        __syncthreads();
+        const double a_sum = red[0] + red[1] + red[2] + red[3], g_sum = red[4] + red[5] + red[6] + red[7];
+        const double ratio = a_sum > 1E-4 ? log(a_sum / nb) - g_sum / nb : 1.0;
+        if (ratio > q.thresh) st.sq_open = q.samp_rate;         // one second timer
+        pos += need; idx = 0;
+        __syncthreads();
+    }
+    for (int k = t; k < n - pos; k += 256) rg[idx + k] = p[pos + k].x;
+    if (t == 0) {
+        st.index = idx + (n - pos);
+        st.sq_open -= n;
+        if (st.sq_open < 0) st.sq_open = 0;
+        state[ch] = st;
+        flag[ch].active = st.sq_open == 0;
+    }
+}
+
+// d_delay (quisk.c:1057-1084) by 512 samples: dst = the stream delayed, dl_new = the 512 samples still inside the line
+static __global__ __launch_bounds__(256) void q_delay_kernel(const double2 *src, long long src_stride, double2 *dst, long long dst_stride,
+                                                         int n, const double2 *dl_old, double2 *dl_new)
+{
+    const int ch = blockIdx.y;
+    const double2 *x = src + (long long)ch * src_stride, *o = dl_old + (long long)ch * 512;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n + 512; i += gridDim.x * 256) {
+        if (i < n) dst[(long long)ch * dst_stride + i] = i < 512 ? o[i] : x[i - 512];
+        else {
+            const int k = i;                        // element n + j of [dl_old, src], j = i - n
+            dl_new[(long long)ch * 512 + (i - n)] = k < 512 ? o[k] : x[k - 512];
+        }
+    }
+}
+
 }  // namespace qh

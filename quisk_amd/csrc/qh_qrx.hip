@@ -77,7 +77,7 @@ static bool lower(int m) { return m == Q_CWL || m == Q_LSB || m == Q_DGT_L || m 
 static bool sideband(int m) { return is_cw(m) || is_ssb(m) || is_dgt(m); }                          // cRxFilterOut, re -+ im
 
 struct Step {
-    enum Kind { FIR, RAT, AM_ENV, FM_DISC } kind;
+    enum Kind { FIR, RAT, AM_ENV, FM_DISC, SSB_SQ, DELAY } kind;
     Stage *st = nullptr;
     qh_rat *rat = nullptr;
 };
@@ -93,7 +93,14 @@ struct Qrx {
     QFmParam fm_prm{};
     double2 *buf[2] = { nullptr, nullptr };
     long long buf_cap = 0;
-    QSquelchState *sq_state = nullptr;  // FM squelch (quisk.c:2076-2085)
+    // SSB squelch (quisk.c:1086-1180) + its 512-sample audio delay (quisk.c:1057-1084)
+    bool has_ssb_sq = false, ssb_sq_on = false, ssb_sq_inited = false;
+    int ssb_sq_level = 0;
+    QSsbSqState *ssq_state = nullptr;
+    double *ssq_ring = nullptr;
+    double2 *ssq_delay[2] = { nullptr, nullptr };
+    int ssq_cur = 0;
+    QSquelchState *sq_state = nullptr;  // squelch flag (FM squelch state, quisk.c:2076-2085)
     double *sq_level = nullptr;
     std::vector<double> h_sq_level;
     bool sq_dirty = false;
@@ -111,6 +118,7 @@ struct Qrx {
         }
         (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
         (void)hipFree(sq_state); (void)hipFree(sq_level);
+        (void)hipFree(ssq_state); (void)hipFree(ssq_ring); (void)hipFree(ssq_delay[0]); (void)hipFree(ssq_delay[1]);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -287,7 +295,11 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         ueq = conv(upsample(dinterp_taps(t->audio24p4, 50, 2), 2), g45); U = 4;
     } else if (is_am(mode)) {                       // dFilter(Audio24p6), HB45 (quisk.c:2017,2024)
         Step det; det.kind = Step::AM_ENV; q.steps.push_back(det);
-        ueq = conv(upsample(std::vector<double>(t->audio24p6, t->audio24p6 + 36), 2), g45); U = 2;
+        // dFilter(Audio24p6) is its own stage: ssb_squelch and d_delay sit between it and the interpolator (quisk.c:2017-2024)
+        std::vector<FirStageSpec> a6;
+        a6.push_back({ std::vector<double>(t->audio24p6, t->audio24p6 + 36), 1 });
+        if (q.add_groups(a6, false, false)) return fail();
+        ueq = g45; U = 2;
     } else if (is_fm(mode)) {                       // HB45, HB45 after the /4 (quisk.c:2067-2068)
         Step det; det.kind = Step::FM_DISC; q.steps.push_back(det);
         ueq = conv(upsample(g45, 2), g45); U = 4;
@@ -296,6 +308,12 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         post.push_back({ std::vector<double>(t->lp48, t->lp48 + 186), 4 });
         post.push_back({ std::vector<double>(t->fmhp, t->fmhp + 309), 1 });
         if (q.add_groups(post, false, false)) return fail();
+    }
+    if ((is_cw(mode) || is_ssb(mode) || is_am(mode)) && !dgt_narrow) {
+        // ssb_squelch + d_delay (quisk.c:1925-1928,1970-1973,2020-2023): present in the step list, idle until enabled
+        Step a; a.kind = Step::SSB_SQ; q.steps.push_back(a);
+        Step d; d.kind = Step::DELAY; q.steps.push_back(d);
+        q.has_ssb_sq = true;
     }
     if (U > 1) {
         Step step;
@@ -419,7 +437,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     int n = n_in, w = 0;
     size_t last = 0;
     for (size_t i = 0; i < q.steps.size(); i++)
-        if (q.steps[i].kind == Step::FIR || q.steps[i].kind == Step::RAT) last = i;
+        if (q.steps[i].kind == Step::FIR || q.steps[i].kind == Step::RAT) last = i;     // (a DELAY is always followed by the interpolator)
     for (size_t i = 0; i < q.steps.size(); i++) {
         const Step &s = q.steps[i];
         void *dst = i == last ? (void *)d_out : (void *)q.buf[w];
@@ -437,6 +455,32 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                 hipLaunchKernelGGL(q_am_env_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.dc_state);
             continue;
+        case Step::SSB_SQ:
+            if (q.ssb_sq_on && n > 0) {
+                if (!q.ssb_sq_inited) { q.ssb_sq_inited = true; continue; }      // "if (!plan) { ...; return; }", quisk.c:1104-1112
+                int bw = q.bandwidth > 3000 ? 3000 : q.bandwidth;
+                QSsbSqParam sp;
+                sp.samp_rate = q.filter_srate;
+                sp.bw1 = 300 * 512 / q.filter_srate;
+                sp.bw2 = (bw + 300) * 512 / q.filter_srate;
+                if (sp.bw2 > 257) sp.bw2 = 257;                                     // out_fft holds N/2 + 1 bins
+                sp.thresh = q.ssb_sq_level * 0.005;
+                hipLaunchKernelGGL(q_ssb_squelch_kernel, dim3((unsigned)q.nch), dim3(256), 0, q.stream, static_cast<const double2 *>(cur),
+                                   cur_stride, n, q.ssq_state, q.ssq_ring, q.sq_state, sp);
+            }
+            continue;
+        case Step::DELAY:
+            if (!q.ssb_sq_on || n <= 0) continue;
+            {
+                int gx = (n + 512 + 255) / 256;
+                if (gx > 256) gx = 256;
+                hipLaunchKernelGGL(q_delay_kernel, dim3((unsigned)gx, (unsigned)q.nch), dim3(256), 0, q.stream,
+                                   static_cast<const double2 *>(cur), cur_stride, static_cast<double2 *>(dst), dst_stride, n,
+                                   q.ssq_delay[q.ssq_cur], q.ssq_delay[q.ssq_cur ^ 1]);
+                q.ssq_cur ^= 1;
+                m = n;
+            }
+            break;
         case Step::FM_DISC:
             if (n > 0) {
                 if (q.sq_dirty) {
@@ -468,13 +512,41 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     return QH_OK;
 }
 
+// set_ssb_squelch(enabled, level) (quisk.c:4729): CW / SSB / AM banks.  Enabling also puts d_delay's 512 samples of
+// audio delay in the path, as in the reference.
+int qh_qrx_set_ssb_squelch(qh_qrx *h, int enabled, int level)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    Qrx &q = h->q;
+    if (!q.has_ssb_sq) return set_error(QH_ERR_UNSUPPORTED, "ssb_squelch belongs to the CW, SSB and AM modes (quisk.c:1925,1970,2020)");
+    QH_HIP(hipSetDevice(q.device));
+    if (enabled && !q.ssq_state) {
+        QH_HIP(hipMalloc((void **)&q.ssq_state, (size_t)q.nch * sizeof(QSsbSqState)));
+        QH_HIP(hipMalloc((void **)&q.ssq_ring, (size_t)q.nch * 512 * sizeof(double)));
+        for (int i = 0; i < 2; i++) QH_HIP(hipMalloc((void **)&q.ssq_delay[i], (size_t)q.nch * 512 * sizeof(double2)));
+        QH_HIP(hipMemsetAsync(q.ssq_state, 0, (size_t)q.nch * sizeof(QSsbSqState), q.stream));
+        QH_HIP(hipMemsetAsync(q.ssq_ring, 0, (size_t)q.nch * 512 * sizeof(double), q.stream));
+        for (int i = 0; i < 2; i++) QH_HIP(hipMemsetAsync(q.ssq_delay[i], 0, (size_t)q.nch * 512 * sizeof(double2), q.stream));
+        if (!q.sq_state) {
+            QH_HIP(hipMalloc((void **)&q.sq_state, (size_t)q.nch * sizeof(QSquelchState)));
+            QH_HIP(hipMemsetAsync(q.sq_state, 0, (size_t)q.nch * sizeof(QSquelchState), q.stream));
+        }
+        QH_HIP(hipStreamSynchronize(q.stream));
+    }
+    if (!enabled && q.ssb_sq_on && q.sq_state)          // MeasureSquelch[bank].squelch_active = 0 at the top of every call, quisk.c:1908
+        QH_HIP(hipMemsetAsync(q.sq_state, 0, (size_t)q.nch * sizeof(QSquelchState), q.stream));
+    q.ssb_sq_on = enabled != 0;
+    q.ssb_sq_level = level;
+    return QH_OK;
+}
+
 // set_squelch (quisk.c:4721-4727): the FM squelch threshold in dB re full scale; -999 (the default) never mutes
 int qh_qrx_set_squelch(qh_qrx *h, int ch, double level)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
-    if (!q.sq_state) return set_error(QH_ERR_UNSUPPORTED, "the FM squelch belongs to modes FM and DGT-FM (quisk.c:2026-2085)");
+    if (!is_fm(q.mode)) return set_error(QH_ERR_UNSUPPORTED, "the FM squelch belongs to modes FM and DGT-FM (quisk.c:2026-2085)");
     for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? q.nch : ch + 1); c++) q.h_sq_level[(size_t)c] = level;
     q.sq_dirty = true;
     return QH_OK;

@@ -130,6 +130,7 @@ def load():
     L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
     L.qh_qrx_set_agc.argtypes = [vp, i, C.c_double]
     L.qh_qrx_set_squelch.argtypes = [vp, i, C.c_double]
+    L.qh_qrx_set_ssb_squelch.argtypes = [vp, i, i]
     L.qh_quisk_open.argtypes = [i, vp, i, i]
     L.qh_quisk_close.restype = None
     L.qh_quisk_set_tune.argtypes = [i]

@@ -56,6 +56,10 @@ class QuiskRxBank:
         """process_agc on the output like quisk_process_samples; release_gain is QS.set_agc's argument (quisk.c:4543)."""
         check(self._L.qh_qrx_set_agc(self._h, 1 if on else 0, float(release_gain)))
 
+    def set_ssb_squelch(self, enabled, level):
+        """QS.set_ssb_squelch (quisk.c:4729): CW / SSB / AM."""
+        check(self._L.qh_qrx_set_ssb_squelch(self._h, 1 if enabled else 0, int(level)))
+
     def set_squelch(self, ch, level):
         """FM squelch threshold, QS.set_squelch (quisk.c:4721)."""
         check(self._L.qh_qrx_set_squelch(self._h, ch, float(level)))

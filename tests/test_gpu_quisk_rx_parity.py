@@ -193,3 +193,41 @@ def test_fm_squelch_mutes_blocks_like_the_reference(qh, oracle):
         assert rel_rms(y[c][live], want[live]) < 1e-6
     with pytest.raises(qh.QuiskHipError):
         qh.QuiskRxBank(1, fs, 3).set_squelch(0, -50.0)
+
+
+@pytest.mark.parametrize("mode,name,bw", [(3, "USB", 2700), (1, "CWU", 500), (4, "AM", 6000)])
+def test_ssb_squelch_and_its_audio_delay(qh, oracle, mode, name, bw):
+    """set_ssb_squelch (quisk.c:1086-1180,4729): noise alone closes the squelch, a carrier opens it for a second; the
+    512-sample d_delay is in the audio path whenever it is enabled."""
+    fs, blk = 48000, 4800
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(1, fs, mode, bandwidth=bw)
+    r = oracle.OracleQuiskRx(fs, tabs)
+    frate = bank.get_filter_rate()
+    fI, fQ = rxfilter.make_filter_coef(frate, None, bw, rxfilter.get_filter_center(name, bw))
+    bank.set_filters(0, fI, fQ); bank.set_ssb_squelch(True, 300)
+    r.set_mode(mode); r.set_bandwidth(bw); r.set_filters(fI, fQ); r.set_ssb_squelch(1, 300)
+    n = fs * 4
+    t = np.arange(n)
+    rng = np.random.default_rng(11)
+    noise = 2.0 ** 20 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    on = (t > fs) & (t < 2 * fs)
+    if mode == 4:
+        sig = np.where(on, 2.0 ** 26, 0) * (1 + 0.5 * np.cos(2 * np.pi * 1000.0 / fs * t))
+    else:
+        sig = np.where(on, 2.0 ** 26, 0) * np.exp(2j * np.pi * (700.0 if mode == 1 else 1000.0) / fs * t)
+    x = (noise + sig)[None, :]
+    y = np.concatenate([bank.process_host(x[:, k:k + blk]) for k in range(0, n, blk)], axis=1)[0]
+    want = np.concatenate([r.process(x[0, k:k + blk]) for k in range(0, n, blk)])
+    assert y.size == want.size
+    wb = want.reshape(-1, blk)
+    muted = ~np.any(wb, axis=1)
+    assert muted[5:].any() and not muted[5:].all()                    # closed on noise, open around the carrier
+    assert np.array_equal(muted, ~np.any(y.reshape(-1, blk), axis=1))
+    live = np.repeat(~muted, blk)
+    assert rel_rms(y[live], want[live]) < 1e-9
+    # switched off again: no delay line, no muting
+    bank.set_ssb_squelch(False, 300); r.set_ssb_squelch(0, 300)
+    y2 = bank.process_host(x[:, :blk])[0]
+    w2 = r.process(x[0, :blk])
+    assert np.any(w2) and rel_rms(y2, w2) < 1e-9
