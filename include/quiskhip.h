@@ -78,6 +78,8 @@ int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
 int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
 int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
 int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
+int qh_rxa_SetRXAFMLimRun(qh_rxa *e, int ch, int run);           /* wdsp/fmd.c:336-347: the FM detector's limiter */
+int qh_rxa_SetRXAFMLimGain(qh_rxa *e, int ch, double gaindB);    /* wdsp/fmd.c:349-362 */
 /* The notch database and nbp0's notched band-pass (wdsp/nbp.c:358-525, make_nbp :97-179, fir_mbandpass :64-80).
  * *rval receives the reference's return value (0, or -1 for an index out of range). */
 int qh_rxa_RXANBPAddNotch(qh_rxa *e, int ch, int notch, double fcenter, double fwidth, int active, int *rval);
@@ -164,6 +166,8 @@ void SetRXAPanelSelect(int channel, int select);                                
 void SetRXAPanelCopy(int channel, int copy);                                     /* wdsp/patchpanel.c:175-181 */
 void SetRXAAMDSBMode(int channel, int sbmode);                                   /* wdsp/amd.c:277-283 */
 void SetRXAAMDRun(int channel, int run);                                         /* wdsp/amd.c:264-277 */
+void SetRXAFMLimRun(int channel, int run);                                       /* wdsp/fmd.c:336-347 */
+void SetRXAFMLimGain(int channel, double gaindB);                                /* wdsp/fmd.c:349-362 */
 int RXANBPAddNotch(int channel, int notch, double fcenter, double fwidth, int active);          /* wdsp/nbp.c:358-388 */
 int RXANBPGetNotch(int channel, int notch, double *fcenter, double *fwidth, int *active);       /* wdsp/nbp.c:390-412 */
 int RXANBPDeleteNotch(int channel, int notch);                                   /* wdsp/nbp.c:414-438 */

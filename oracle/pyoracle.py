@@ -48,7 +48,7 @@ def lib():
         L.wo_SetRXAAGCTop.restype = None
         for n in ("wo_SetRXAMode", "wo_RXASetNC", "wo_SetRXAShiftRun", "wo_RXANBPSetRun", "wo_SetRXABandpassRun",
                   "wo_SetRXAAGCMode", "wo_SetRXAPanelRun", "wo_SetRXAPanelSelect", "wo_SetRXAPanelCopy",
-                  "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun", "wo_SetRXAAMDRun", "wo_RXASetMP"):
+                  "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun", "wo_SetRXAAMDRun", "wo_RXASetMP", "wo_SetRXAFMLimRun"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None
         for n in ("wo_SetRXAShiftFreq", "wo_SetRXAAGCFixed", "wo_SetRXAPanelGain1", "wo_SetRXAFMDeviation",
@@ -59,6 +59,7 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p, C.c_double, C.c_double]
             getattr(L, n).restype = None
         L.wo_GetRXAMeter.argtypes = [C.c_void_p, C.c_int]
+        L.wo_SetRXAFMLimGain.argtypes = [C.c_void_p, C.c_double]
         for n in ("wo_RXANBPAddNotch", "wo_RXANBPEditNotch"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
         L.wo_RXANBPDeleteNotch.argtypes = [C.c_void_p, C.c_int]

@@ -539,6 +539,7 @@ struct wo_channel {
         double omega_min, omega_max, g1, g2, phs, fil_out, omega, mtau, onem_mtau, fmdc, again;
         double *audio;
         wo_fircore *pde, *paud;
+        int lim_run; double lim_pre_gain, lim_gain; wo_agc plim;      /* detector limiter, fmd.c:48-72,106-108 */
         /* snotch, wdsp/iir.c:35-95 */
         double a0, a1, a2, b1, b2, x1, x2, y1, y2;
     } fmd;
@@ -813,7 +814,13 @@ static double *fmd_aud_impulse(wo_channel *c)   /* fmd.c:114 */
                            c->fmd.afgain / (2.0 * c->dsp_size));
 }
 
-static void xfmd(wo_channel *c, double *buf, int size)   /* fmd.c:144-188 (lim_run = 0) */
+static void fmd_make_limiter(wo_channel *c)          /* calc_fmd, fmd.c:48-72 */
+{
+    wo_agc_init(&c->fmd.plim, 1, 5, 1, (int)c->fmd.rate, 0.001, 0.008, 4, c->fmd.lim_gain, 1.0, 1.0, 1.0, 0.9,
+                0.250, 0.004, 4.0, 0, 0.500, 0.500, 2.000, 0.100);
+}
+
+static void xfmd(wo_channel *c, double *buf, int size)   /* fmd.c:144-188 */
 {
     int i;
     double det, del_out, vco[2], corr[2], x0;
@@ -849,6 +856,10 @@ static void xfmd(wo_channel *c, double *buf, int size)   /* fmd.c:144-188 (lim_r
             c->fmd.x2 = c->fmd.x1;
             c->fmd.x1 = x0;
         }
+    }
+    if (c->fmd.lim_run) {                             /* fmd.c:179-184 */
+        for (i = 0; i < 2 * size; i++) buf[i] *= c->fmd.lim_pre_gain;
+        wo_agc_exec(&c->fmd.plim, buf, size);
     }
 }
 
@@ -1118,6 +1129,8 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     c->fmd.zeta = 1.0; c->fmd.omegaN = 20000.0; c->fmd.tau = 0.02; c->fmd.afgain = 0.5;
     c->fmd.sntch_run = 1; c->fmd.ctcss_freq = 254.1; c->fmd.nc_de = nc; c->fmd.nc_aud = nc;
     calc_fmd(c);
+    c->fmd.lim_run = 0; c->fmd.lim_pre_gain = 0.4; c->fmd.lim_gain = 2.5;     /* fmd.c:106-108 */
+    fmd_make_limiter(c);
     c->fmd.audio = (double *)zalloc((size_t)dsp_size * 2 * sizeof(double));
     imp = fmd_de_impulse(c);
     c->fmd.pde = wo_fircore_create(dsp_size, nc, imp);
@@ -1335,4 +1348,14 @@ void wo_SetRXAFMDeviation(wo_channel *c, double deviation)
 
 void wo_SetRXACTCSSFreq(wo_channel *c, double freq) { c->fmd.ctcss_freq = freq; calc_snotch(c); }
 void wo_SetRXACTCSSRun(wo_channel *c, int run) { c->fmd.sntch_run = run; }
+void wo_SetRXAFMLimRun(wo_channel *c, int run) { c->fmd.lim_run = run; }                       /* fmd.c:336-347 */
+void wo_SetRXAFMLimGain(wo_channel *c, double gaindB)                                           /* fmd.c:349-362 */
+{
+    double gain = pow(10.0, gaindB / 20.0);
+    if (c->fmd.lim_gain != gain) {          /* decalc_fmd + calc_fmd: a new limiter with cleared state */
+        wo_agc_free(&c->fmd.plim);
+        c->fmd.lim_gain = gain;
+        fmd_make_limiter(c);
+    }
+}
 double wo_GetRXAMeter(wo_channel *c, int mt) { return c->meter[mt]; }

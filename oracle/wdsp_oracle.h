@@ -75,6 +75,8 @@ void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
 void wo_RXASetMP(wo_channel *c, int mp);                        /* RXA.c:948-958 */
+void wo_SetRXAFMLimRun(wo_channel *c, int run);                 /* fmd.c:336-347 */
+void wo_SetRXAFMLimGain(wo_channel *c, double gaindB);          /* fmd.c:349-362 */
 /* notch database, nbp.c:358-525; make_nbp nbp.c:97-179 */
 int wo_RXANBPAddNotch(wo_channel *c, int notch, double fcenter, double fwidth, int active);
 int wo_RXANBPDeleteNotch(wo_channel *c, int notch);

@@ -345,7 +345,7 @@ struct AgcState {
 };
 
 static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                           const AgcParam *prm, AgcState *state)
+                                                           const AgcParam *prm, AgcState *state, double pre_gain = 1.0)
 {
     __shared__ double2 ring[kAgcRing];
     __shared__ double abs_ring[kAgcRing];
@@ -366,6 +366,7 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
         const int cnt = n - base < 64 ? n - base : 64;
         double2 z = make_double2(0, 0);
         if (lane < cnt) z = p[base + lane];
+        z.x *= pre_gain; z.y *= pre_gain;           // the FM limiter's lim_pre_gain (fmd.c:181-182); 1 for the AGC proper
         double2 mine = make_double2(0, 0);
         for (int i = 0; i < cnt; i++) {
             const double I = lane_bcast(z.x, i), Q = lane_bcast(z.y, i);

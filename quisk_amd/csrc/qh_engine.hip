@@ -68,6 +68,7 @@ struct ChanCfg {
     int levelfade = 1, sbmode = 0;                              // RXA.c:180-181
     double fm_dev = 5000.0, ctcss_freq = 254.1;                 // RXA.c:198,208
     int ctcss_run = 1, fm_nc = 2048;                            // RXA.c:207,209-212
+    int lim_run = 0; double lim_gain = 2.5; bool lim_dirty = true;   // FM detector limiter, fmd.c:106-108
     bool demod_dirty = true, ctcss_flush = false;
     bool nbp_dirty = true, bp1_dirty = true, nco_dirty = true, epi_dirty = true;
     bool nbp_flush = false, bp1_flush = false;
@@ -116,6 +117,9 @@ struct Engine {
     int cur_de = 0, cur_aud = 0, fm_nc_built = 0, fm_mp = 0, fm_mp_built = 0;
     AgcParam *agc_prm = nullptr;
     AgcState *agc_state = nullptr;
+    AgcParam *lim_prm = nullptr;        // FM detector limiter: a wcpAGC of its own (fmd.c:48-72)
+    AgcState *lim_state = nullptr;
+    int *list_lim = nullptr, n_lim = 0;
     bool meters_on = false;
     MeterState *m_adc = nullptr, *m_s = nullptr, *m_agc = nullptr;
     MeterParam m_prm{};
@@ -152,7 +156,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
-    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
+    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -424,9 +428,10 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
+            if (c.fmd_run && c.lim_run) ll.push_back(ch);
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
             if (c.amd_run && c.amd_mode == 1) ls.push_back(ch);
             if (c.fmd_run) lf.push_back(ch);
@@ -435,6 +440,17 @@ int Engine::refresh_demod()
         }
         n_am = (int)la.size(); n_sam = (int)ls.size(); n_fm = (int)lf.size(); n_bp1 = (int)lb.size(); n_plain = (int)lp.size();
         n_agc_cur = (int)lgc.size(); n_agc_other = (int)lgo.size();
+        n_lim = (int)ll.size();
+        if (n_lim) {
+            if (!list_lim) {
+                QH_HIP(dev_alloc(&list_lim, (size_t)nch));
+                QH_HIP(dev_alloc(&lim_prm, (size_t)nch));
+                QH_HIP(dev_alloc(&lim_state, (size_t)nch));
+                dev_bytes += (long long)nch * (sizeof(AgcParam) + sizeof(AgcState) + sizeof(int));
+                for (ChanCfg &c : cfg) c.lim_dirty = true;
+            }
+            QH_HIP(hipMemcpyAsync(list_lim, ll.data(), ll.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        }
         auto put = [&](int *dst, const std::vector<int> &v) -> hipError_t {
             return v.empty() ? hipSuccess : hipMemcpyAsync(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream);
         };
@@ -483,6 +499,42 @@ int Engine::refresh_demod()
             QH_HIP(hipMemcpyAsync(agc_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.agc_dirty = false;
+        }
+        if (c.lim_dirty && lim_prm) {
+            // calc_fmd's create_wcpagc(1, 5, 1, ..., 0.001, 0.008, 4, lim_gain, 1.0, 1.0, 1.0, 0.9, 0.250, 0.004, 4.0, 0,
+            // 0.500, 0.500, 2.000, 0.100) (fmd.c:48-72) through loadWcpAGC (wcpAGC.c:115-146); a new limiter starts cleared
+            const double tau_attack = 0.001, tau_decay = 0.008, n_tau = 4.0, max_gain = c.lim_gain, var_gain = 1.0, max_input = 1.0,
+                         out_targ = 0.9, tau_fast_back = 0.250, tau_fast_decay = 0.004, tau_hang_backmult = 0.500, hangtime = 0.500,
+                         hang_thresh = 2.000, tau_hang_decay = 0.100;
+            AgcParam q{};
+            q.attack_buffsize = (int)std::ceil(rate * n_tau * tau_attack);
+            q.attack_mult = 1.0 - std::exp(-1.0 / (rate * tau_attack));
+            q.decay_mult = 1.0 - std::exp(-1.0 / (rate * tau_decay));
+            q.fast_decay_mult = 1.0 - std::exp(-1.0 / (rate * tau_fast_decay));
+            q.fast_backmult = 1.0 - std::exp(-1.0 / (rate * tau_fast_back));
+            q.onemfast_backmult = 1.0 - q.fast_backmult;
+            q.out_target = out_targ * (1.0 - std::exp(-n_tau)) * 0.9999;
+            q.min_volts = q.out_target / (var_gain * max_gain);
+            q.inv_out_target = 1.0 / q.out_target;
+            double tmp = std::log10(q.out_target / (max_input * var_gain * max_gain));
+            if (tmp == 0.0) tmp = 1e-16;
+            q.slope_constant = (q.out_target * (1.0 - 1.0 / var_gain)) / tmp;
+            q.inv_max_input = 1.0 / max_input;
+            tmp = std::pow(10.0, (hang_thresh - 1.0) / 0.125);
+            q.hang_level = (max_input * tmp + (q.out_target / (var_gain * max_gain)) * (1.0 - tmp)) * 0.637;
+            q.hang_backmult = 1.0 - std::exp(-1.0 / (rate * tau_hang_backmult));
+            q.onemhang_backmult = 1.0 - q.hang_backmult;
+            q.hang_decay_mult = 1.0 - std::exp(-1.0 / (rate * tau_hang_decay));
+            q.pop_ratio = 4.0;
+            q.hang_count_init = (int)(hangtime * rate);
+            q.hang_enable = 0;
+            q.pmode = 1;
+            QH_HIP(hipMemcpyAsync(lim_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemsetAsync(lim_state + ch, 0, sizeof(AgcState), stream));
+            const int oi = kAgcRing - 1;                            // out_index = -1 (calc_wcpagc, wcpAGC.c:34)
+            QH_HIP(hipMemcpyAsync(&lim_state[ch].out_index, &oi, sizeof(int), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.lim_dirty = false;
         }
         if (!c.demod_dirty) continue;
         const int lf = c.levelfade;
@@ -756,6 +808,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         tick(1);
         hipLaunchKernelGGL(snotch_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
                            sn_prm, sn_state);
+        if (n_lim)      // detector limiter: lim_pre_gain 0.4, then its own wcpAGC (fmd.c:179-184)
+            hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
+                               lim_state, 0.4);
     }
     if (n_bp1) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, cur_bp1, P, list_bp1, n_bp1);
     // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below
@@ -1025,6 +1080,13 @@ int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *h, int ch, int levelfade) { FOR_CH(h, ch, 
 int qh_rxa_SetRXAFMDeviation(qh_rxa *h, int ch, double deviation) { FOR_CH(h, ch, { c.fm_dev = deviation; c.demod_dirty = true; }); }
 int qh_rxa_SetRXACTCSSFreq(qh_rxa *h, int ch, double freq) { FOR_CH(h, ch, { c.ctcss_freq = freq; c.demod_dirty = true; c.ctcss_flush = true; }); }
 int qh_rxa_SetRXACTCSSRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.ctcss_run = run; c.demod_dirty = true; }); }
+// SetRXAFMLimRun / SetRXAFMLimGain (wdsp/fmd.c:336-362): the FM detector's limiter
+int qh_rxa_SetRXAFMLimRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { run = run ? 1 : 0; if (c.lim_run != run) { c.lim_run = run; h->e.lists_dirty = true; } }); }
+int qh_rxa_SetRXAFMLimGain(qh_rxa *h, int ch, double gaindB)
+{
+    const double gain = std::pow(10.0, gaindB / 20.0);
+    FOR_CH(h, ch, { if (c.lim_gain != gain) { c.lim_gain = gain; c.lim_dirty = true; } });
+}
 
 int qh_rxa_SetRXAAGCMode(qh_rxa *h, int ch, int mode)
 {

@@ -383,6 +383,8 @@ void SetRXAPanelSelect(int channel, int select) { WDSP_SETTER(qh_rxa_SetRXAPanel
 void SetRXAPanelCopy(int channel, int copy) { WDSP_SETTER(qh_rxa_SetRXAPanelCopy(L.c->eng, 0, copy)); }
 void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMode(L.c->eng, 0, sbmode)); }
 void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
+void SetRXAFMLimRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAFMLimRun(L.c->eng, 0, run)); }
+void SetRXAFMLimGain(int channel, double gaindB) { WDSP_SETTER(qh_rxa_SetRXAFMLimGain(L.c->eng, 0, gaindB)); }
 
 // the notch database, wdsp/nbp.c:358-525: int results are the reference's (0 / -1)
 int RXANBPAddNotch(int channel, int notch, double fcenter, double fwidth, int active)

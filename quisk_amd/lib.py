@@ -38,7 +38,7 @@ def load():
     for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
-              "RXASetMP", "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease"):
+              "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
         f.restype = i
@@ -49,7 +49,7 @@ def load():
     L.qh_rxa_RXANBPGetNumNotches.argtypes = [vp, i, C.POINTER(i)]
     L.qh_rxa_RXANBPGetMinNotchWidth.argtypes = [vp, i, C.POINTER(d)]
     for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop",
-              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency"):
+              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]
         f.restype = i

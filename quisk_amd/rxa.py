@@ -16,7 +16,7 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun", "SetRXAAGCAttack",
             "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold", "RXASetMP",
             "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease", "RXANBPSetTuneFrequency",
-            "RXANBPSetShiftFrequency")
+            "RXANBPSetShiftFrequency", "SetRXAFMLimRun", "SetRXAFMLimGain")
 
 
 class RxaEngine:

@@ -109,3 +109,27 @@ def test_mode_switch_mid_stream(qh, oracle):
         seg = x[k * 10240:(k + 1) * 10240]
         ys.append(e.process_host(seg[None, :])[0]); rs.append(o.xrxa(seg))
     assert rel_rms(np.concatenate(ys), np.concatenate(rs)) < TOL
+
+
+def test_fm_detector_limiter(qh, oracle):
+    """SetRXAFMLimRun / SetRXAFMLimGain (wdsp/fmd.c:179-184,336-362): pre-gain 0.4 and a wcpAGC of its own on the FM audio."""
+    from quisk_amd import synth
+    nch, nblk = 2, 200
+    x = np.stack([synth.make_mode_input_numpy("fm", c, nblk * 1024) for c in range(nch)])
+    e = qh.RxaEngine(nch, dsp_size=256, in_rate=192000, dsp_rate=48000, out_rate=48000)
+    e.SetRXAShiftRun(-1, 1); e.RXANBPSetRun(-1, 1); e.SetRXAMode(-1, 5); e.RXASetPassband(-1, -8000.0, 8000.0)
+    e.SetRXAFMLimRun(0, 1); e.SetRXAFMLimGain(0, 6.0)                   # channel 0 only; channel 1 stays unlimited
+    refs = []
+    for c in range(nch):
+        e.SetRXAShiftFreq(c, synth.shift_freq(c))
+        ch = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        ch.SetRXAShiftRun(1); ch.SetRXAShiftFreq(synth.shift_freq(c)); ch.RXANBPSetRun(1); ch.SetRXAMode(5)
+        ch.RXASetPassband(-8000.0, 8000.0)
+        if c == 0:
+            ch.SetRXAFMLimRun(1); ch.SetRXAFMLimGain(6.0)
+        refs.append(ch.xrxa(x[c]))
+    y = np.concatenate([e.process_host(x[:, :70 * 1024]), e.process_host(x[:, 70 * 1024:])], axis=1)
+    lo = 150 * 256                                                      # after PLL / notch settling (DESIGN.md parity caveat)
+    for c in range(nch):
+        assert rel_rms(y[c][lo:], refs[c][lo:]) < 1e-6, (c, rel_rms(y[c][lo:], refs[c][lo:]))
+    assert rel_rms(refs[0][lo:], refs[1][lo:] ) > 1e-2                 # the limiter does something
