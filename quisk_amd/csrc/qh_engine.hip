@@ -44,7 +44,7 @@ int set_error(int code, const char *fmt, ...)
 
 static constexpr int kNfft = 4096;          // FFT size of every overlap-save stage in this engine
 static constexpr int kHistBand = 2047;      // fircore history capacity: nc up to 2048
-static constexpr int kHistFront = 1120;     // resampler history capacity: 140 * D taps, D <= 8
+static constexpr int kHistFront = 2240;     // resampler history capacity: 140 * D taps, D <= 16
 
 struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33
@@ -76,7 +76,7 @@ struct ChanCfg {
 
 struct Engine {
     int device = 0, nch = 0, dsp_size = 0, in_rate = 0, dsp_rate = 0, out_rate = 0;
-    int D = 1, dsp_insize = 0, dsp_outsize = 0;
+    int D = 1, dsp_insize = 0, dsp_outsize = 0, front_fold = 1, front_pick = 1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<ChanCfg> cfg;
@@ -198,15 +198,18 @@ int Engine::init()
         ResamplerDesign rd = design_resampler(in_rate, dsp_rate, 0.0, 0, 1.0);
         if (rd.L != 1 || rd.M != D) return set_error(QH_ERR_UNSUPPORTED, "resampler L/M = %d/%d not supported", rd.L, rd.M);
         front_ntaps = rd.ncoef;
-        front_P = ((front_ntaps - 1 + D - 1) / D) * D;
-        front_L = (kNfft - front_P) / D;
+        // spectral fold by min(D, 8); the rest of the decimation (D = 16) keeps every second folded sample
+        front_fold = D > 8 ? 8 : D;
+        front_pick = D / front_fold;
+        front_P = ((front_ntaps - 1 + front_fold - 1) / front_fold) * front_fold;
+        front_L = (((kNfft - front_P) / front_fold) / front_pick) * front_pick;
         if (front_P > kHistFront) return set_error(QH_ERR_UNSUPPORTED, "resampler history %d too long", front_P);
         std::vector<cd> h((size_t)front_ntaps);
         for (int i = 0; i < front_ntaps; i++) h[i] = cd(rd.h[i], 0.0);
         std::vector<cd> m = make_mask(h, kNfft);
         QH_HIP(dev_alloc(&mask_front, m.size()));
         if (int rc = upload(mask_front, m, stream)) return rc;
-        std::vector<cd> twi = fft_twiddle_table(kNfft / D);
+        std::vector<cd> twi = fft_twiddle_table(kNfft / front_fold);
         QH_HIP(dev_alloc(&tw_inv_front, twi.size()));
         if (int rc = upload(tw_inv_front, twi, stream)) return rc;
         dev_bytes += (m.size() + twi.size()) * sizeof(cd);
@@ -633,18 +636,19 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
         a.tw_fwd = tw4096; a.tw_inv = tw_inv_front;
         a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
         a.epi = ep;
-        a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L;
-        const int ntiles = (int)((n_mid + front_L - 1) / front_L);
+        a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L; a.pick = front_pick;
+        const int per_tile = front_L / front_pick;
+        const int ntiles = (int)((n_mid + per_tile - 1) / per_tile);
         a.pk_src = pk_src; a.pk = pk;
         if (pk_src) {
-            switch (D) {
+            switch (front_fold) {
             case 2: launch_osfir<2, true, true>(a, ntiles, nch, stream); break;
             case 4: launch_osfir<4, true, true>(a, ntiles, nch, stream); break;
             case 8: launch_osfir<8, true, true>(a, ntiles, nch, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         } else {
-            switch (D) {
+            switch (front_fold) {
             case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
             case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
             case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
@@ -872,7 +876,7 @@ qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_ra
     }
     if (in_rate % dsp_rate) { set_error(QH_ERR_UNSUPPORTED, "in_rate must be a multiple of dsp_rate"); return nullptr; }
     const int D = in_rate / dsp_rate;
-    if (D != 1 && D != 2 && D != 4 && D != 8) { set_error(QH_ERR_UNSUPPORTED, "in_rate/dsp_rate must be 1, 2, 4 or 8"); return nullptr; }
+    if (D != 1 && D != 2 && D != 4 && D != 8 && D != 16) { set_error(QH_ERR_UNSUPPORTED, "in_rate/dsp_rate must be 1, 2, 4, 8 or 16"); return nullptr; }
     if (qh_device_count() <= device || device < 0) {
         set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
         return nullptr;

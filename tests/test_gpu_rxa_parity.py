@@ -276,3 +276,27 @@ def test_notch_database(qh, oracle):
         ref = np.concatenate(refs[c])
         assert np.abs(ref).max() > 1e-3
         assert rel_rms(y[c], ref) < TOL, (c, rel_rms(y[c], ref))
+
+
+def test_input_rate_768k(qh, oracle):
+    """in_rate / dsp_rate = 16: 2241-tap resampler, spectral fold by 8 then every second sample."""
+    nch, nblk, fs = 2, 12, 768000
+    rng = np.random.default_rng(4)
+    n = nblk * 256 * 16
+    t = np.arange(n)
+    x = np.stack([0.2 * np.exp(2j * np.pi * ((-(20000.0 + 500 * c) - 1000.0) / fs * t % 1.0)) +
+                  0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) for c in range(nch)])
+    e = qh.RxaEngine(nch, dsp_size=256, in_rate=fs, dsp_rate=48000, out_rate=48000)
+    assert e.dsp_insize == 4096
+    e.SetRXAShiftRun(-1, 1); e.RXANBPSetRun(-1, 1); e.SetRXAMode(-1, 1); e.RXASetPassband(-1, 300.0, 3000.0)
+    e.SetRXAAGCMode(-1, 0); e.SetRXAAGCFixed(-1, 0.0)
+    for c in range(nch):
+        e.SetRXAShiftFreq(c, 20000.0 + 500 * c)
+    y = np.concatenate([e.process_host(x[:, :5 * 4096]), e.process_host(x[:, 5 * 4096:])], axis=1)
+    for c in range(nch):
+        ch = oracle.WdspChannel(4096, 256, fs, 48000, 48000)
+        ch.SetRXAShiftRun(1); ch.SetRXAShiftFreq(20000.0 + 500 * c); ch.RXANBPSetRun(1); ch.SetRXAMode(1)
+        ch.RXASetPassband(300.0, 3000.0); ch.SetRXAAGCMode(0); ch.SetRXAAGCFixed(0.0)
+        ref = ch.xrxa(x[c])
+        assert np.abs(ref).max() > 0.1
+        assert rel_rms(y[c], ref) < TOL, (c, rel_rms(y[c], ref))
