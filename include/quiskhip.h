@@ -51,6 +51,13 @@ void qh_rxa_destroy(qh_rxa *e);
 int qh_rxa_nch(const qh_rxa *e);
 int qh_rxa_dsp_insize(const qh_rxa *e);     /* complex input samples per DSP block  (wdsp/channel.c:39-42) */
 int qh_rxa_dsp_outsize(const qh_rxa *e);    /* complex output samples per DSP block (wdsp/channel.c:44-47) */
+void *qh_rxa_stream(const qh_rxa *e);                            /* the hipStream_t the engine launches on */
+/* Launch-sequence replay for block-at-a-time callers (the WDSP drop-in switches it on).  While the arguments of
+ * qh_rxa_process and every parameter stand still, the launches of a call are captured into hipGraphs -- one per
+ * state of the engine's ping-pong history buffers -- and replayed; a setter, a flush or different arguments drop
+ * them.  Results are those of the plain path.  Off by default: a caller that passes large batches gains nothing. */
+int qh_rxa_set_graph_replay(qh_rxa *e, int on);
+long long qh_rxa_graph_launches(const qh_rxa *e);                /* calls served by a replayed graph so far */
 
 /* Per-channel setters; `ch` indexes the batch, or -1 for every channel.  Same meaning as the WDSP
  * export of the same name (cited in section 2).  They take effect at the next qh_rxa_process call,
@@ -197,6 +204,7 @@ void SetRXASNBARun(int channel, int run);                                       
 
 /* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */
 int qh_wdsp_status(void);
+long long qh_wdsp_graph_launches(void);     /* DSP blocks replayed from a captured hipGraph (steady state of fexchange0) */
 
 /* ------------------------------------------------------------------ 3. batched FIR decimator bank */
 /* GPU form of quisk_cDecimate / quisk_cCDecimate / quisk_cFilter (filter.c:203-257,372-375; filter.h:47-55)

@@ -77,6 +77,21 @@ struct ChanCfg {
 struct Engine {
     int device = 0, nch = 0, dsp_size = 0, in_rate = 0, dsp_rate = 0, out_rate = 0;
     int D = 1, dsp_insize = 0, dsp_outsize = 0, front_fold = 1, front_pick = 1;
+    unsigned long long epoch = 0;       // bumped by every setter / flush: a captured launch sequence is stale when it moves
+    // Launch-sequence replay (qh_rxa_set_graph_replay): a process() call whose arguments and parameters repeat is
+    // captured into a hipGraph, one per state of the ping-pong history flags, and replayed.  Everything the host
+    // side of process() changes from call to call is those flags, so a slot also records the flags it leaves behind.
+    struct GraphKey {
+        const void *in = nullptr; void *out = nullptr; long long in_stride = 0, out_stride = 0; int nblk = 0;
+        unsigned long long epoch = ~0ull;
+        bool operator==(const GraphKey &o) const
+        { return in == o.in && out == o.out && in_stride == o.in_stride && out_stride == o.out_stride && nblk == o.nblk && epoch == o.epoch; }
+    };
+    struct GraphSlot { hipGraphExec_t exec = nullptr; unsigned after = 0; };
+    bool graph_on = false, graph_seen = false;
+    GraphKey graph_key;
+    GraphSlot graph_slot[32];
+    long long graph_launches = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<ChanCfg> cfg;
@@ -115,6 +130,10 @@ struct Engine {
     SnotchState *sn_state = nullptr;
     double2 *mask_de = nullptr, *mask_aud = nullptr, *hist_de[2] = { nullptr, nullptr }, *hist_aud[2] = { nullptr, nullptr };
     int cur_de = 0, cur_aud = 0, fm_nc_built = 0, fm_mp = 0, fm_mp_built = 0;
+    unsigned flags() const { return (unsigned)(cur_front | cur_nbp << 1 | cur_bp1 << 2 | cur_de << 3 | cur_aud << 4); }
+    void set_flags(unsigned f) { cur_front = f & 1; cur_nbp = f >> 1 & 1; cur_bp1 = f >> 2 & 1; cur_de = f >> 3 & 1; cur_aud = f >> 4 & 1; }
+    void drop_graphs() { for (auto &g : graph_slot) if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; } }
+    int process_replayed(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     AgcParam *agc_prm = nullptr;
     AgcState *agc_state = nullptr;
     AgcParam *lim_prm = nullptr;        // FM detector limiter: a wcpAGC of its own (fmd.c:48-72)
@@ -150,6 +169,7 @@ Engine::~Engine()
 {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    drop_graphs();
     if (rsmpout) qh_rat_destroy(rsmpout);
     (void)hipFree(obuf);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
@@ -893,6 +913,7 @@ void qh_rxa_destroy(qh_rxa *h) { delete h; }
 int qh_rxa_nch(const qh_rxa *h) { return h->e.nch; }
 int qh_rxa_dsp_insize(const qh_rxa *h) { return h->e.dsp_insize; }
 int qh_rxa_dsp_outsize(const qh_rxa *h) { return h->e.dsp_outsize; }
+void *qh_rxa_stream(const qh_rxa *h) { return h ? (void *)h->e.stream : nullptr; }
 long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
 
 #define FOR_CH(h, ch, body)                                                                       \
@@ -900,6 +921,7 @@ long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
         if (!(h)) return set_error(QH_ERR_INVALID, "null engine");                                \
         if ((ch) < -1 || (ch) >= (h)->e.nch) return set_error(QH_ERR_INVALID, "channel %d out of range", (ch)); \
         int _lo = (ch) < 0 ? 0 : (ch), _hi = (ch) < 0 ? (h)->e.nch : (ch) + 1;                    \
+        (h)->e.epoch++;                                                                           \
         for (int _i = _lo; _i < _hi; _i++) { ChanCfg &c = (h)->e.cfg[(size_t)_i]; body }         \
         return QH_OK;                                                                             \
     } while (0)
@@ -1129,7 +1151,63 @@ int qh_rxa_process(qh_rxa *h, const double *d_in, long long in_stride, double *d
     if (!d_in || !d_out) return set_error(QH_ERR_INVALID, "null buffer");
     if (in_stride < (long long)nblk * h->e.dsp_insize || out_stride < (long long)nblk * h->e.dsp_outsize)
         return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
+    if (h->e.graph_on) return h->e.process_replayed(d_in, in_stride, d_out, out_stride, nblk);
     return h->e.process(d_in, in_stride, d_out, out_stride, nblk);
+}
+
+int qh_rxa_set_graph_replay(qh_rxa *h, int on)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    h->e.graph_on = on != 0;
+    if (!on) { h->e.drop_graphs(); h->e.graph_key = Engine::GraphKey{}; }
+    return QH_OK;
+}
+long long qh_rxa_graph_launches(const qh_rxa *h) { return h ? h->e.graph_launches : 0; }
+
+int Engine::process_replayed(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
+{
+    // the output resampler keeps a host-side phase and event timing records per call: both stay on the plain path
+    if (rsmpout || timing || nblk <= 0) return process(d_in, in_stride, d_out, out_stride, nblk);
+    const GraphKey key{d_in, d_out, in_stride, out_stride, nblk, epoch};
+    if (!(key == graph_key)) { drop_graphs(); graph_key = key; graph_seen = false; }
+    const unsigned before = flags();
+    GraphSlot &slot = graph_slot[before];
+    if (slot.exec) {
+        QH_HIP(hipSetDevice(device));
+        QH_HIP(hipGraphLaunch(slot.exec, stream));
+        set_flags(slot.after);
+        graph_launches++;
+        return QH_OK;
+    }
+    if (!graph_seen) {
+        // the first call under a new key uploads dirty parameters and grows buffers (synchronising): not capturable
+        const int rc = process(d_in, in_stride, d_out, out_stride, nblk);
+        graph_seen = rc == QH_OK;
+        return rc;
+    }
+    QH_HIP(hipSetDevice(device));
+    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        graph_on = false;
+        return process(d_in, in_stride, d_out, out_stride, nblk);
+    }
+    const int rc = process(d_in, in_stride, d_out, out_stride, nblk);
+    hipGraph_t g = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(stream, &g);
+    bool ok = rc == QH_OK && e_end == hipSuccess && g && hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0) == hipSuccess;
+    if (g) (void)hipGraphDestroy(g);
+    if (ok) {
+        slot.after = flags();
+        QH_HIP(hipGraphLaunch(slot.exec, stream));
+        graph_launches++;
+        return QH_OK;
+    }
+    // nothing ran: put the flags back, stop capturing for this engine and run the block the plain way
+    (void)hipGetLastError();
+    slot.exec = nullptr;
+    set_flags(before);
+    graph_on = false;
+    return process(d_in, in_stride, d_out, out_stride, nblk);
 }
 
 // The same chain fed with wire-format samples: the front kernel decodes them in its load.
@@ -1154,6 +1232,7 @@ int qh_rxa_flush(qh_rxa *h)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
     Engine &e = h->e;
+    e.epoch++;
     QH_HIP(hipSetDevice(e.device));
     QH_HIP(hipMemsetAsync(e.nco_phase, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
     if (e.rsmpout) if (int rc = qh_rat_reset(e.rsmpout)) return rc;        // flush_resample, wdsp/resample.c:159-165

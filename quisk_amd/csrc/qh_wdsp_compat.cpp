@@ -44,6 +44,7 @@ struct Chan {
     std::vector<double> cup, cdown;
     // staging: pinned host + device block buffers
     double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    // the DSP iteration replayed from captured hipGraphs: one per parity of the engine's ping-pong state buffers
 };
 
 Chan g_ch[kMaxChannels];
@@ -165,6 +166,8 @@ void downslew0(Chan &c, double *pout)       // wdsp/iobuffs.c:226-300
     }
 }
 
+long long g_graph_launches = 0;      // blocks replayed by engines that have since been closed
+
 // one DSP-thread iteration: dexchange (wdsp/iobuffs.c:583-604) then xrxa on the GPU
 int dsp_iteration(Chan &c)
 {
@@ -178,15 +181,25 @@ int dsp_iteration(Chan &c)
     }
     std::memcpy(c.h_in, c.r1.data() + 2 * c.r1_outidx, (size_t)c.r1_outsize * 2 * sizeof(double));
     if ((c.r1_outidx += c.r1_outsize) == c.r1_active) c.r1_outidx = 0;
-    // xrxa: one block through the engine
-    if (hipMemcpy(c.d_in, c.h_in, (size_t)c.dsp_insize * 2 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-        return qh::set_error(QH_ERR_HIP, "fexchange0: host to device copy failed");
-    int rc = qh_rxa_process(c.eng, c.d_in, c.dsp_insize, c.d_out, c.dsp_outsize, 1);
+    // xrxa: one block through the engine.  The kernels read the input block from and write the output block to the
+    // pinned staging buffers directly (a few KB over PCIe: no copy-engine hop); QH_WDSP_IO=copy stages both through
+    // device buffers with two async copies instead.  The launch sequence itself is replayed from hipGraphs by the
+    // engine once the parameters stand still (qh_rxa_set_graph_replay, switched on in OpenChannel).
+    static const bool staged = [] { const char *e = std::getenv("QH_WDSP_IO"); return e && std::strcmp(e, "copy") == 0; }();
+    int rc = QH_OK;
+    if (staged) {
+        hipStream_t s = (hipStream_t)qh_rxa_stream(c.eng);
+        if (hipMemcpyAsync(c.d_in, c.h_in, (size_t)c.dsp_insize * 2 * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess)
+            return qh::set_error(QH_ERR_HIP, "fexchange0: host to device copy failed");
+        rc = qh_rxa_process(c.eng, c.d_in, c.dsp_insize, c.d_out, c.dsp_outsize, 1);
+        if (rc == QH_OK && hipMemcpyAsync(c.h_out, c.d_out, (size_t)c.dsp_outsize * 2 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
+            return qh::set_error(QH_ERR_HIP, "fexchange0: device to host copy failed");
+    } else {
+        rc = qh_rxa_process(c.eng, c.h_in, c.dsp_insize, c.h_out, c.dsp_outsize, 1);
+    }
     if (rc) return rc;
     rc = qh_rxa_synchronize(c.eng);
     if (rc) return rc;
-    if (hipMemcpy(c.h_out, c.d_out, (size_t)c.dsp_outsize * 2 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        return qh::set_error(QH_ERR_HIP, "fexchange0: device to host copy failed");
     std::memcpy(c.outbuff.data(), c.h_out, (size_t)c.dsp_outsize * 2 * sizeof(double));
     return QH_OK;
 }
@@ -220,6 +233,15 @@ struct Locked {
 extern "C" {
 
 int qh_wdsp_status(void) { return g_status; }
+long long qh_wdsp_graph_launches(void)       // DSP blocks replayed from a captured hipGraph so far, over all channels
+{
+    long long n = g_graph_launches;
+    for (int ch = 0; ch < kMaxChannels; ch++) {
+        std::unique_lock<std::recursive_mutex> lk(g_mtx[ch]);
+        if (g_ch[ch].open) n += qh_rxa_graph_launches(g_ch[ch].eng);
+    }
+    return n;
+}
 
 int GetWDSPVersion(void) { return 125; }    // the WDSP release Quisk 4.2.52 bundles
 
@@ -267,6 +289,8 @@ void OpenChannel(int channel, int in_size, int dsp_size, int input_samplerate, i
     c.open = true;
     if (state) { c.upflag = 1; c.exchange = 1; }    // wdsp/channel.c:92-98
     (void)qh_rxa_enable_meters(c.eng, 1);           // WDSP's meters always run (RXA.c:69-82)
+    // the per-block sequence is launch-bound: replay it from hipGraphs (QH_WDSP_NO_GRAPHS=1 keeps plain launches)
+    if (!std::getenv("QH_WDSP_NO_GRAPHS")) (void)qh_rxa_set_graph_replay(c.eng, 1);
 }
 
 void CloseChannel(int channel)
@@ -276,6 +300,7 @@ void CloseChannel(int channel)
     if (!L.c) return;
     Chan &c = *L.c;
     free_staging(c);
+    g_graph_launches += qh_rxa_graph_launches(c.eng);
     qh_rxa_destroy(c.eng);
     c.eng = nullptr;
     c.open = false;

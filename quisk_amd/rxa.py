@@ -107,6 +107,13 @@ class RxaEngine:
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))
 
+    def set_graph_replay(self, on=True):
+        """Block-at-a-time callers: replay the launch sequence of process_ptr from hipGraphs while nothing changes."""
+        check(self._L.qh_rxa_set_graph_replay(self._h, 1 if on else 0))
+
+    def graph_launches(self):
+        return self._L.qh_rxa_graph_launches(self._h)
+
     def enable_timing(self, on=True):
         check(self._L.qh_rxa_enable_timing(self._h, 1 if on else 0))
 

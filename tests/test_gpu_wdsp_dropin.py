@@ -205,3 +205,27 @@ def test_fexchange0_with_output_resampler(qh, oracle, out_rate):
     ref, errs = o.fexchange0(x)
     assert errs == 0 and ref.size == y.size and np.abs(ref).max() > 1e-3
     assert rel_rms(y, ref) < 1e-9
+
+
+def test_steady_state_blocks_are_replayed_from_hipgraphs_and_setters_invalidate_them(qh, oracle):
+    """fexchange0's per-block launch sequence is captured once the parameters stand still; a setter in mid-stream
+    drops the graphs and the output still follows the oracle."""
+    lib = qh.load()
+    lib.qh_wdsp_graph_launches.restype = C.c_longlong
+    ch, in_size, out_size, nb = 11, 1024, 256, 40
+    _open(lib, ch, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    o = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    x = synth.make_input_numpy(1, nb * in_size)[0]
+    before = lib.qh_wdsp_graph_launches()
+    y1 = _run(lib, ch, x[:20 * in_size], in_size, out_size)
+    r1, errs1 = o.fexchange0(x[:20 * in_size])
+    mid = lib.qh_wdsp_graph_launches()
+    assert mid - before >= 15                                   # all but the first few blocks
+    lib.RXASetPassband(ch, D(200.0), D(2500.0)); o.RXASetPassband(200.0, 2500.0)
+    lib.SetRXAShiftFreq(ch, D(9000.0)); o.SetRXAShiftFreq(9000.0)
+    y2 = _run(lib, ch, x[20 * in_size:], in_size, out_size)
+    assert lib.qh_wdsp_graph_launches() - mid >= 15
+    lib.CloseChannel(ch)
+    r2, errs2 = o.fexchange0(x[20 * in_size:])
+    assert errs1 == 0 and errs2 == 0
+    assert rel_rms(np.concatenate([y1, y2]), np.concatenate([r1, r2])) < 1e-9

@@ -29,4 +29,6 @@ for in_size, in_rate in ((256, 48000), (1024, 192000), (4096, 192000)):
         lib.fexchange0(ch, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.byref(err))
     dt = (time.perf_counter() - t0) / n
     print("in_size %5d @ %6d Hz: %7.1f us per fexchange0 call = %5.2f %% of real time" % (in_size, in_rate, dt * 1e6, 100 * dt / (in_size / in_rate)))
+    lib.qh_wdsp_graph_launches.restype = C.c_longlong
+    print("   blocks replayed from hipGraphs so far:", lib.qh_wdsp_graph_launches())
     lib.CloseChannel(ch)
