@@ -372,6 +372,25 @@ int qh_qrx_set_squelch(qh_qrx *r, int ch, double level);
  * audio at the filter rate (ssb_squelch, quisk.c:1086-1180) plus the 512-sample audio delay that goes with it (d_delay). */
 int qh_qrx_set_ssb_squelch(qh_qrx *r, int enabled, int level);
 
+/* ------------------------------------------------------------------ 10. Quisk's noise blanker */
+/* NoiseBlanker (quisk.c:680-784) for `nch` fp64 complex streams at the receiver's INPUT rate,
+ * where quisk_process_samples runs it (quisk.c:2448-2449: before the panadapter ring and the tune).  While on, the
+ * output lags the input by qh_nb_delay() = 3 * (int)(sample_rate * 500e-6 + 0.5) samples (the reference's delay
+ * line); level 0 passes samples through undelayed and freezes the delay line, as the reference does.  Levels 1..3 =
+ * threshold 6.0 / 4.0 / 2.5 times the mean magnitude (set_noise_blanker, quisk.c:4605).  d_in and d_out must be
+ * different buffers.  Sample rates up to about 3.5 MHz (the 500 us window has to fit one LDS tile). */
+typedef struct qh_nb qh_nb;
+qh_nb *qh_nb_create(int device, int nch, int sample_rate, void *stream);
+void qh_nb_destroy(qh_nb *b);
+int qh_nb_delay(const qh_nb *b);
+int qh_nb_set_level(qh_nb *b, int level);
+int qh_nb_reset(qh_nb *b);
+int qh_nb_process(qh_nb *b, const void *d_in, long long in_stride, void *d_out, long long out_stride, int n);
+int qh_nb_process_host(qh_nb *b, const void *h_in, long long in_stride, void *h_out, long long out_stride, int n);
+int qh_nb_synchronize(qh_nb *b);
+/* The receiver bank with the blanker in front of its tune, as quisk_process_samples has it; 0 = off (default). */
+int qh_qrx_set_noise_blanker(qh_qrx *r, int level);
+
 /* ------------------------------------------------------------------ 9. Quisk native block API, one receiver */
 /* The shape of quisk.c's own receive API: a process-wide receiver, parameters through setters, samples through
  * `int quisk_process_samples(complex double *cSamples, int nSamples)` (quisk.h:375, quisk.c:2289) -- in place, returns
@@ -384,6 +403,7 @@ void qh_quisk_set_tune(int rx_tune_freq);                   /* set_tune, quisk.c
 void qh_quisk_set_rx_mode(int mode);                        /* set_rx_mode, quisk.c:4621 */
 int qh_quisk_set_filters(const double *filtI, const double *filtQ, int size, int bandwidth);       /* set_filters, quisk.c:4551 */
 void qh_quisk_set_agc(double level);                        /* set_agc, quisk.c:4543 */
+void qh_quisk_set_noise_blanker(int level);                 /* set_noise_blanker, quisk.c:4605 */
 int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
 int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
 int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */

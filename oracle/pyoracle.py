@@ -437,6 +437,10 @@ class OracleQuiskRx:
         self.L.qo_rx_set_squelch.argtypes = [C.c_void_p, C.c_double]
         self.L.qo_rx_set_squelch(self.h, float(level))
 
+    def set_noise_blanker(self, level):
+        self.L.qo_rx_set_noise_blanker.argtypes = [C.c_void_p, C.c_int]
+        self.L.qo_rx_set_noise_blanker(self.h, int(level))
+
     def set_agc(self, on, release_gain=80.0):
         self.L.qo_rx_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_double]
         self.L.qo_rx_set_agc(self.h, int(on), float(release_gain))
@@ -482,4 +486,34 @@ class OracleQuiskAgc:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.qo_agc_free(self.h)
+            self.h = None
+
+
+class OracleNoiseBlanker:
+    """NoiseBlanker (quisk.c:680-784) for one stream: process(x) returns the blanked block, delayed by `delay` samples."""
+
+    def __init__(self, sample_rate, level=1):
+        L = lib()
+        L.qo_nb_create.restype = C.c_void_p
+        L.qo_nb_create.argtypes = [C.c_int]
+        L.qo_nb_free.argtypes = [C.c_void_p]
+        L.qo_nb_set_level.argtypes = [C.c_void_p, C.c_int]
+        L.qo_nb_delay.argtypes = [C.c_void_p]
+        L.qo_nb_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L = L
+        self.h = L.qo_nb_create(sample_rate)
+        self.delay = L.qo_nb_delay(self.h)
+        L.qo_nb_set_level(self.h, level)
+
+    def set_level(self, level):
+        self.L.qo_nb_set_level(self.h, level)
+
+    def process(self, x):
+        buf = np.ascontiguousarray(x, dtype=np.complex128).copy()
+        self.L.qo_nb_process(self.h, buf.ctypes.data, buf.size)
+        return buf
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_nb_free(self.h)
             self.h = None

@@ -105,10 +105,72 @@ struct qo_rx {
     int sq_inited, sq_index, sq_open;           /* ssb_squelch's static plan flag and MS->index, MS->sq_open */
     double sq_in[512], sq_delay[512];           /* MS->in_fft; d_delay's buffer (quisk.c:1057-1084) */
     int sq_delay_index;
+    qo_nb *nb;                      /* NoiseBlanker's statics, quisk.c:682-687 */
     qo_agc *agc;                    /* Agc1 = {0.7, 0, 0}, quisk.c:2321 */
     int agc_on;
     double agc_gain;
 };
+
+/* ---- NoiseBlanker, quisk.c:680-784 --------------------------------------------------
+ * A delay line of 3 * hwindow samples (hwindow = 500 us) with a running sum of the magnitudes in it.  A sample
+ * larger than `limit` times the mean is a pulse: the hwindow samples before it are tapered to zero, samples are
+ * zeroed until the pulses stop, then the gain ramps back up over hwindow samples. */
+struct qo_nb {
+    int level, sample_rate, save_size, hwindow_size, state, index, win_index;
+    double save_sum, *cSaved, *dSaved;
+};
+
+qo_nb *qo_nb_create(int sample_rate)
+{
+    qo_nb *b = (qo_nb *)calloc(1, sizeof(*b));
+    b->sample_rate = sample_rate;
+    b->hwindow_size = (int)(sample_rate * 500.E-6 + 0.5);       /* QUISK_NB_HWINDOW_SECS, quisk.c:679,702 */
+    b->save_size = b->hwindow_size * 3;
+    b->dSaved = (double *)calloc((size_t)b->save_size, sizeof(double));
+    b->cSaved = (double *)calloc((size_t)b->save_size * 2, sizeof(double));
+    return b;
+}
+
+void qo_nb_free(qo_nb *b) { if (b) { free(b->cSaved); free(b->dSaved); free(b); } }
+void qo_nb_set_level(qo_nb *b, int level) { b->level = level; }     /* set_noise_blanker, quisk.c:4605 */
+int qo_nb_delay(const qo_nb *b) { return b->save_size; }
+
+void qo_nb_process(qo_nb *b, double *cs, int n)
+{
+    int i, j, k, is_pulse;
+    double mag, limit, sre, sim, f;
+    if (b->level <= 0) return;                                   /* quisk.c:695 */
+    limit = b->level == 2 ? 4.0 : b->level == 3 ? 2.5 : 6.0;     /* quisk.c:716-728 */
+    for (i = 0; i < n; i++) {
+        sre = cs[2 * i]; sim = cs[2 * i + 1];                    /* newest sample in, oldest out */
+        cs[2 * i] = b->cSaved[2 * b->index]; cs[2 * i + 1] = b->cSaved[2 * b->index + 1];
+        b->cSaved[2 * b->index] = sre; b->cSaved[2 * b->index + 1] = sim;
+        mag = hypot(sre, sim);                                   /* cabs */
+        b->save_sum -= b->dSaved[b->index];
+        b->dSaved[b->index] = mag;
+        b->save_sum += mag;
+        is_pulse = mag <= b->save_sum / b->save_size * limit ? 0 : 1;
+        if (b->state == 0) {
+            if (is_pulse) {                                      /* taper the samples before the pulse */
+                b->state = 1;
+                k = b->index;
+                for (j = 0; j < b->hwindow_size; j++) {
+                    f = (double)j / b->hwindow_size;
+                    b->cSaved[2 * k] *= f; b->cSaved[2 * k + 1] *= f;
+                    if (--k < 0) k = b->save_size - 1;
+                }
+            } else if (b->win_index) {                           /* pulses have stopped: ramp up to 1.0 */
+                f = (double)b->win_index / b->hwindow_size;
+                b->cSaved[2 * b->index] *= f; b->cSaved[2 * b->index + 1] *= f;
+                if (++b->win_index >= b->hwindow_size) b->win_index = 0;
+            }
+        } else {                                                 /* in a pulse: zero until it stops */
+            b->cSaved[2 * b->index] = 0; b->cSaved[2 * b->index + 1] = 0;
+            if (!is_pulse) { b->state = 0; b->win_index = 1; }
+        }
+        if (++b->index >= b->save_size) b->index = 0;
+    }
+}
 
 int qo_rx_decim_srate(const qo_rx *r) { return r->decim_srate; }
 int qo_rx_filter_srate(const qo_rx *r) { return r->filter_srate; }
@@ -180,6 +242,7 @@ void qo_rx_free(qo_rx *r)
     qo_fir_free(&r->d48to24); qo_fir_free(&r->dm48to24); qo_fir_free(&r->audio24p4); qo_fir_free(&r->audio12p2);
     qo_fir_free(&r->audio24p6); qo_fir_free(&r->audio48p3); qo_fir_free(&r->fmhp);
     qo_agc_free(r->agc);
+    qo_nb_free(r->nb);
     free(r->filtI); free(r->filtQ); free(r->bufI); free(r->bufQ); free(r->bufC); free(r->dsamples);
     free(r);
 }
@@ -190,6 +253,12 @@ void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
 void qo_rx_set_squelch(qo_rx *r, double level) { r->squelch_level = level; }     /* set_squelch, quisk.c:4721-4727 */
 void qo_rx_set_ssb_squelch(qo_rx *r, int enabled, int level) { r->ssb_squelch_enabled = enabled; r->ssb_squelch_level = level; }
 void qo_rx_set_agc(qo_rx *r, int on, double release_gain) { r->agc_on = on; r->agc_gain = release_gain; }
+
+void qo_rx_set_noise_blanker(qo_rx *r, int level)
+{
+    if (!r->nb) r->nb = qo_nb_create(r->sample_rate);
+    qo_nb_set_level(r->nb, level);
+}
 
 void qo_rx_set_filters(qo_rx *r, const double *fI, const double *fQ, int size)
 {
@@ -461,6 +530,7 @@ int qo_rx_process(qo_rx *r, double *x, int n)
     int i;
     if (n <= 0) return n;
     if (n * 2 > r->dcap) { r->dcap = n * 2 + 64; free(r->dsamples); r->dsamples = (double *)malloc((size_t)r->dcap * sizeof(double)); }
+    if (r->nb) qo_nb_process(r->nb, x, n);                      /* quisk.c:2448-2449 */
     if (r->tune != 0) {                                         /* quisk.c:2477-2488 */
         double a = -2.0 * M_PI * r->tune / r->sample_rate;      /* cexp((I * -2.0 * M_PI * tune) / sample_rate) */
         double pr = cos(a), pi = sin(a), t;

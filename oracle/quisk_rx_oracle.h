@@ -5,8 +5,9 @@
  *   branch and its 6/5 x 4/5 rational stage) -> quisk_process_demodulate (quisk.c:1848-2160: CWL/CWU/LSB/USB/AM/FM/
  *   DGT-U/DGT-L/DGT-IQ/DGT-FM; IMD, FDV-U/L up to the audio, i.e. without the codec) with cRxFilterOut / dRxFilterOut
  *   (quisk.c:1182-1256) -> mono to both channels (quisk.c:2622-2627).
- * process_agc is restated too and can be switched on; squelch, auto-notch, noise blanker, test tone and key-down
- * handling are off, as they are by default.  The stages call the filter.c restatement (quisk_oracle.c), which is
+ * process_agc and the squelches and the noise blanker (rank 3) are restated too and off
+ * until switched on; auto-notch, test tone and key-down handling are not restated (off by default in the
+ * reference).  The stages call the filter.c restatement (quisk_oracle.c), which is
  * pinned bit-exactly to the reference build; the control flow above them is PARITY UNPINNED (quisk.c needs
  * <fftw3.h>, quisk.c:6, and cannot be built here).
  */
@@ -56,6 +57,15 @@ typedef struct qo_agc qo_agc;
 qo_agc *qo_agc_create(int sample_rate, double max_out, double release_time);
 void qo_agc_free(qo_agc *a);
 void qo_agc_process(qo_agc *a, double *csamples, int count, int is_cpx, double release_gain);
+/* NoiseBlanker (quisk.c:680-784) alone, one stream; level 0 = off, 1..3 = limit 6.0 / 4.0 / 2.5; in place.  The
+ * output lags the input by qo_nb_delay() = 3 * (int)(sample_rate * 500e-6 + 0.5) samples. */
+typedef struct qo_nb qo_nb;
+qo_nb *qo_nb_create(int sample_rate);
+void qo_nb_free(qo_nb *b);
+void qo_nb_set_level(qo_nb *b, int level);
+int qo_nb_delay(const qo_nb *b);
+void qo_nb_process(qo_nb *b, double *csamples, int count);
+void qo_rx_set_noise_blanker(qo_rx *r, int level);              /* set_noise_blanker, quisk.c:4605; runs before the tune */
 int qo_rx_decim_srate(const qo_rx *r);
 int qo_rx_filter_srate(const qo_rx *r);
 

@@ -8,9 +8,9 @@ from .lib import load, QuiskHipError          # noqa: F401
 from .rxa import RxaEngine                    # noqa: F401
 from .fir import FirBank, HalfBandCascade, RationalFir, hb45_taps           # noqa: F401
 from .pan import Panadapter                   # noqa: F401
-from .qrx import QuiskRxBank, QuiskAgc                  # noqa: F401
+from .qrx import QuiskRxBank, QuiskAgc, NoiseBlanker                  # noqa: F401
 from . import ingest                          # noqa: F401
 from . import quiskapi                        # noqa: F401
 from .ingest import IqFormat                  # noqa: F401
 
-__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "QuiskRxBank", "QuiskAgc", "ingest", "IqFormat", "quiskapi"]
+__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "QuiskRxBank", "QuiskAgc", "NoiseBlanker", "ingest", "IqFormat", "quiskapi"]

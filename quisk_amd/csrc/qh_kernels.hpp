@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long
 }
 
 // phase[ch] += dphase[ch] * n   (wdsp/shift.c:77-79 accumulates the same quantity in radians)
-static __global__ void nco_advance_kernel(unsigned long long *phase, const unsigned long long *dphase, int nch, long long n)
+[[maybe_unused]] static __global__ void nco_advance_kernel(unsigned long long *phase, const unsigned long long *dphase, int nch, long long n)
 {
     int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < nch) phase[ch] += dphase[ch] * (unsigned long long)n;

@@ -106,10 +106,15 @@ struct Qrx {
     bool sq_dirty = false;
     qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = off
     double agc_gain = 80.0;
+    qh_nb *nb = nullptr;            // NoiseBlanker ahead of the tune (quisk.c:2448-2449); created by the first non-zero level
+    int nb_level = 0;
+    double2 *nb_buf = nullptr;
+    long long nb_cap = 0;
 
     ~Qrx()
     {
         if (agc) qh_qagc_destroy(agc);
+        if (nb) qh_nb_destroy(nb);
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Step &s : steps) {
@@ -117,7 +122,7 @@ struct Qrx {
             if (s.rat) qh_rat_destroy(s.rat);
         }
         (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
-        (void)hipFree(sq_state); (void)hipFree(sq_level);
+        (void)hipFree(sq_state); (void)hipFree(sq_level); (void)hipFree(nb_buf);
         (void)hipFree(ssq_state); (void)hipFree(ssq_ring); (void)hipFree(ssq_delay[0]); (void)hipFree(ssq_delay[1]);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -434,6 +439,17 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     }
     const void *cur = d_in;
     long long cur_stride = in_stride;
+    if (q.nb && q.nb_level > 0) {
+        // NoiseBlanker(cSamples, nSamples) on the raw samples, quisk.c:2448-2449
+        if (n_in > q.nb_cap) {
+            QH_HIP(hipStreamSynchronize(q.stream));
+            (void)hipFree(q.nb_buf); q.nb_buf = nullptr;
+            QH_HIP(hipMalloc((void **)&q.nb_buf, (size_t)q.nch * (size_t)n_in * 16));
+            q.nb_cap = n_in;
+        }
+        if (int rc = qh_nb_process(q.nb, d_in, in_stride, q.nb_buf, q.nb_cap, n_in)) return rc;
+        cur = q.nb_buf; cur_stride = q.nb_cap;
+    }
     int n = n_in, w = 0;
     size_t last = 0;
     for (size_t i = 0; i < q.steps.size(); i++)
@@ -565,6 +581,20 @@ int qh_qrx_set_agc(qh_qrx *h, int on, double release_gain)
     }
     q.agc_gain = release_gain;
     return qh_qagc_set_gain(q.agc, -1, release_gain);
+}
+
+// set_noise_blanker (quisk.c:4605): the blanker runs on the raw samples, ahead of the tune
+int qh_qrx_set_noise_blanker(qh_qrx *h, int level)
+{
+    if (!h || level < 0) return set_error(QH_ERR_INVALID, "qh_qrx_set_noise_blanker: bad arguments");
+    Qrx &q = h->q;
+    if (!q.nb) {
+        if (level == 0) return QH_OK;
+        q.nb = qh_nb_create(q.device, q.nch, q.sample_rate, q.stream);
+        if (!q.nb) return QH_ERR_HIP;
+    }
+    q.nb_level = level;
+    return qh_nb_set_level(q.nb, level);
 }
 
 int qh_qrx_process_host(qh_qrx *h, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out)

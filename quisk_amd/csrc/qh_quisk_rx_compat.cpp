@@ -31,6 +31,10 @@ struct QuiskRx {
     qh_pan *pan = nullptr;
     int fft_size = 0, data_width = 0;
     std::vector<double> out;
+    // NoiseBlanker's statics (quisk.c:682-687): outlive mode changes, so they are not the bank's
+    qh_nb *nb = nullptr;
+    int nb_level = 0;
+    std::vector<double> nb_out;
 };
 
 QuiskRx g;
@@ -88,6 +92,7 @@ int qh_quisk_open(int sample_rate, const qh_qrx_tables *tables, int fft_size, in
     g.sample_rate = sample_rate;
     if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
     if (g.pan) { qh_pan_destroy(g.pan); g.pan = nullptr; }
+    if (g.nb) { qh_nb_destroy(g.nb); g.nb = nullptr; }      // "sample_rate != sample_rate: Initialization", quisk.c:697
     g.fft_size = fft_size; g.data_width = data_width;
     if (fft_size > 0 && data_width > 0) {
         g.pan = qh_pan_create(0, 1, fft_size, data_width, (double)sample_rate, nullptr);
@@ -101,6 +106,7 @@ void qh_quisk_close(void)
     std::lock_guard<std::mutex> lk(g.mtx);
     if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
     if (g.pan) { qh_pan_destroy(g.pan); g.pan = nullptr; }
+    if (g.nb) { qh_nb_destroy(g.nb); g.nb = nullptr; }
     g.sample_rate = 0;
 }
 
@@ -133,6 +139,12 @@ void qh_quisk_set_agc(double level)                 // set_agc, quisk.c:4543
     g.agc_gain = level; g.params_dirty = true;
 }
 
+void qh_quisk_set_noise_blanker(int level)          // set_noise_blanker, quisk.c:4605
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.nb_level = level < 0 ? 0 : level;
+}
+
 int qh_quisk_get_filter_rate(void)                  // get_filter_rate(-1, 0): the rate the current Rx filter runs at
 {
     std::lock_guard<std::mutex> lk(g.mtx);
@@ -148,6 +160,13 @@ int qh_quisk_process_samples(double *cSamples, int nSamples)
     if (!cSamples) { qh::set_error(QH_ERR_INVALID, "null sample buffer"); return 0; }
     std::lock_guard<std::mutex> lk(g.mtx);
     if (ensure_bank()) return 0;
+    if (g.nb_level > 0 || g.nb) {                                        // NoiseBlanker(cSamples, nSamples), quisk.c:2448-2449
+        if (!g.nb && !(g.nb = qh_nb_create(0, 1, g.sample_rate, nullptr))) return 0;
+        if (qh_nb_set_level(g.nb, g.nb_level)) return 0;
+        g.nb_out.resize((size_t)nSamples * 2);
+        if (qh_nb_process_host(g.nb, cSamples, nSamples, g.nb_out.data(), nSamples, nSamples)) return 0;
+        std::memcpy(cSamples, g.nb_out.data(), (size_t)nSamples * 2 * sizeof(double));
+    }
     if (g.pan && qh_pan_feed_host(g.pan, cSamples, nSamples, nSamples)) return 0;       // the FFT ring producer, quisk.c:2454-2475
     const int cap = qh_qrx_out_count(g.bank, nSamples);
     g.out.resize((size_t)(cap > 0 ? cap : 1) * 2);

@@ -132,6 +132,19 @@ def load():
     L.qh_qagc_reset.argtypes = [vp]
     L.qh_qagc_process.argtypes = [vp, vp, ll, i]
     L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
+    L.qh_nb_create.restype = vp
+    L.qh_nb_create.argtypes = [i, i, i, vp]
+    L.qh_nb_destroy.argtypes = [vp]
+    L.qh_nb_destroy.restype = None
+    L.qh_nb_delay.argtypes = [vp]
+    L.qh_nb_set_level.argtypes = [vp, i]
+    L.qh_nb_reset.argtypes = [vp]
+    L.qh_nb_process.argtypes = [vp, vp, ll, vp, ll, i]
+    L.qh_nb_process_host.argtypes = [vp, vp, ll, vp, ll, i]
+    L.qh_nb_synchronize.argtypes = [vp]
+    L.qh_qrx_set_noise_blanker.argtypes = [vp, i]
+    L.qh_quisk_set_noise_blanker.argtypes = [i]
+    L.qh_quisk_set_noise_blanker.restype = None
     L.qh_qrx_set_agc.argtypes = [vp, i, C.c_double]
     L.qh_qrx_set_squelch.argtypes = [vp, i, C.c_double]
     L.qh_qrx_set_ssb_squelch.argtypes = [vp, i, i]

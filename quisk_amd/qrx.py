@@ -56,6 +56,10 @@ class QuiskRxBank:
         """process_agc on the output like quisk_process_samples; release_gain is QS.set_agc's argument (quisk.c:4543)."""
         check(self._L.qh_qrx_set_agc(self._h, 1 if on else 0, float(release_gain)))
 
+    def set_noise_blanker(self, level):
+        """QS.set_noise_blanker (quisk.c:4605): NoiseBlanker on the raw samples ahead of the tune; 0 = off."""
+        check(self._L.qh_qrx_set_noise_blanker(self._h, int(level)))
+
     def set_ssb_squelch(self, enabled, level):
         """QS.set_ssb_squelch (quisk.c:4729): CW / SSB / AM."""
         check(self._L.qh_qrx_set_ssb_squelch(self._h, 1 if enabled else 0, int(level)))
@@ -120,6 +124,51 @@ class QuiskAgc:
     def close(self):
         if getattr(self, "_h", None):
             self._L.qh_qagc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NoiseBlanker:
+    """NoiseBlanker (quisk.c:680-784) for `nch` streams at the receiver's input rate; level 0..3 as set_noise_blanker."""
+
+    def __init__(self, nch, sample_rate, level=1, device=0, stream=None):
+        self._L = load()
+        self._h = self._L.qh_nb_create(device, nch, sample_rate, stream)
+        if not self._h:
+            raise QuiskHipError("qh_nb_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch = nch
+        self.delay = self._L.qh_nb_delay(self._h)
+        self.set_level(level)
+
+    def set_level(self, level):
+        check(self._L.qh_nb_set_level(self._h, int(level)))
+
+    def reset(self):
+        check(self._L.qh_nb_reset(self._h))
+
+    def process_ptr(self, d_in, in_stride, d_out, out_stride, n):
+        """Device pointers, strides in complex samples; d_in != d_out.  Asynchronous on the blanker's stream."""
+        check(self._L.qh_nb_process(self._h, d_in, in_stride, d_out, out_stride, n))
+
+    def process_host(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        if x.ndim != 2 or x.shape[0] != self.nch:
+            raise ValueError("expected [nch, n] complex128")
+        out = np.empty_like(x)
+        check(self._L.qh_nb_process_host(self._h, x.ctypes.data, x.shape[1], out.ctypes.data, x.shape[1], x.shape[1]))
+        return out
+
+    def synchronize(self):
+        check(self._L.qh_nb_synchronize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_nb_destroy(self._h)
             self._h = None
 
     def __del__(self):

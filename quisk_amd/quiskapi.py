@@ -46,6 +46,10 @@ def set_agc(level):
     load().qh_quisk_set_agc(C.c_double(level))
 
 
+def set_noise_blanker(level):
+    load().qh_quisk_set_noise_blanker(int(level))
+
+
 def get_filter_rate():
     return load().qh_quisk_get_filter_rate()
 

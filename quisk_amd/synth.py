@@ -72,3 +72,19 @@ def make_mode_input_numpy(mode, c, n, fs=192000.0, sigma=0.01):
     if mode == "fm":
         return 0.1 * car * np.exp(1j * (3000.0 / 1000.0) * np.sin(2 * np.pi * 1000.0 / fs * t)) + noise
     raise ValueError(mode)
+
+
+def impulsive_input(nch, n, seed=7, scale=1e6):
+    """Gaussian noise at `scale` with spikes, short bursts and pairs of bursts 20-40 dB above it (noise-blanker input)."""
+    out = np.empty((nch, n), dtype=np.complex128)
+    for c in range(nch):
+        rng = np.random.default_rng(seed + c)
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * scale
+        for p in rng.integers(0, n, size=max(4, n // 3000)):
+            m = min(int(rng.integers(1, 6)), n - int(p))
+            x[p:p + m] += (rng.standard_normal(m) + 1j * rng.standard_normal(m)) * 50.0 * scale
+            q = int(p) + int(rng.integers(3, 40))              # often a second run inside the first one's recovery ramp
+            if rng.random() < 0.5 and q < n:
+                x[q] += 80.0 * scale
+        out[c] = x
+    return out
