@@ -388,6 +388,11 @@ int qh_nb_reset(qh_nb *b);
 int qh_nb_process(qh_nb *b, const void *d_in, long long in_stride, void *d_out, long long out_stride, int n);
 int qh_nb_process_host(qh_nb *b, const void *h_in, long long in_stride, void *h_out, long long out_stride, int n);
 int qh_nb_synchronize(qh_nb *b);
+/* dAutoNotch (quisk.c:786-963; 8(f) rank 3) inside the receiver bank, where the mode calls it (on the real audio after
+ * the Rx filter; after the interpolators for FM; DGT-IQ has none): set_auto_notch(i) (quisk.c:4596) -- stores the flag
+ * and starts the notch over -- with rit_freq as set_sidetone passes it (quisk.c:4712): the CW modes keep the notch off
+ * the sidetone.  Off by default. */
+int qh_qrx_set_auto_notch(qh_qrx *r, int on, int rit_freq);
 /* The receiver bank with the blanker in front of its tune, as quisk_process_samples has it; 0 = off (default). */
 int qh_qrx_set_noise_blanker(qh_qrx *r, int level);
 
@@ -404,6 +409,7 @@ void qh_quisk_set_rx_mode(int mode);                        /* set_rx_mode, quis
 int qh_quisk_set_filters(const double *filtI, const double *filtQ, int size, int bandwidth);       /* set_filters, quisk.c:4551 */
 void qh_quisk_set_agc(double level);                        /* set_agc, quisk.c:4543 */
 void qh_quisk_set_noise_blanker(int level);                 /* set_noise_blanker, quisk.c:4605 */
+void qh_quisk_set_auto_notch(int on, int rit_freq);         /* set_auto_notch, quisk.c:4596; rit_freq of set_sidetone, quisk.c:4712 */
 int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
 int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
 int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */

@@ -437,6 +437,10 @@ class OracleQuiskRx:
         self.L.qo_rx_set_squelch.argtypes = [C.c_void_p, C.c_double]
         self.L.qo_rx_set_squelch(self.h, float(level))
 
+    def set_auto_notch(self, on, rit_freq=0):
+        self.L.qo_rx_set_auto_notch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.L.qo_rx_set_auto_notch(self.h, int(on), int(rit_freq))
+
     def set_noise_blanker(self, level):
         self.L.qo_rx_set_noise_blanker.argtypes = [C.c_void_p, C.c_int]
         self.L.qo_rx_set_noise_blanker(self.h, int(level))
@@ -516,4 +520,31 @@ class OracleNoiseBlanker:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.qo_nb_free(self.h)
+            self.h = None
+
+
+class OracleAutoNotch:
+    """dAutoNotch (quisk.c:786-963) for one real audio stream; process(x, sidetone, rate) returns the filtered block."""
+
+    def __init__(self, on=True):
+        L = lib()
+        L.qo_notch_create.restype = C.c_void_p
+        L.qo_notch_free.argtypes = [C.c_void_p]
+        L.qo_notch_set.argtypes = [C.c_void_p, C.c_int]
+        L.qo_notch_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self.L = L
+        self.h = L.qo_notch_create()
+        L.qo_notch_set(self.h, int(on))
+
+    def set(self, on):
+        self.L.qo_notch_set(self.h, int(on))
+
+    def process(self, x, sidetone, rate):
+        buf = np.ascontiguousarray(x, dtype=np.float64).copy()
+        self.L.qo_notch_process(self.h, buf.ctypes.data, buf.size, int(sidetone), int(rate))
+        return buf
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_notch_free(self.h)
             self.h = None

@@ -106,6 +106,8 @@ struct qo_rx {
     double sq_in[512], sq_delay[512];           /* MS->in_fft; d_delay's buffer (quisk.c:1057-1084) */
     int sq_delay_index;
     qo_nb *nb;                      /* NoiseBlanker's statics, quisk.c:682-687 */
+    qo_notch *notch;                /* dAutoNotch's statics, quisk.c:798-813 */
+    int rit_freq;                   /* quisk.c:202 */
     qo_agc *agc;                    /* Agc1 = {0.7, 0, 0}, quisk.c:2321 */
     int agc_on;
     double agc_gain;
@@ -170,6 +172,155 @@ void qo_nb_process(qo_nb *b, double *cs, int n)
         }
         if (++b->index >= b->save_size) b->index = 0;
     }
+}
+
+/* ---- dAutoNotch, quisk.c:786-963 -----------------------------------------------------
+ * Overlap-save on 2048-sample blocks of the real audio (510 old + 1538 new samples): r2c FFT, half/half averaged
+ * magnitude spectrum, the two strongest bins (not near the CW sidetone, not near each other) with a hysteresis
+ * count each; when the pair changes, a 511-tap notch filter is designed by frequency sampling (c2r of a 0/1
+ * spectrum, centred, Hanning window, r2c), the block's spectrum is multiplied by it and transformed back.  The
+ * macros are the reference's (note NOTCH_DATA_SIZE / 20 = 102 and the un-parenthesised DESIGN_SIZE). */
+#define NOTCH_DATA_SIZE 2048
+#define NOTCH_FILTER_DESIGN_SIZE 512            /* NOTCH_DATA_SIZE / 4 */
+#define NOTCH_FILTER_SIZE 511                   /* (NOTCH_FILTER_DESIGN_SIZE - 1) */
+#define NOTCH_FILTER_FFT_SIZE 256               /* (NOTCH_FILTER_SIZE / 2 + 1) */
+#define NOTCH_DATA_START_SIZE 510               /* (NOTCH_FILTER_SIZE - 1) */
+#define NOTCH_DATA_OUTPUT_SIZE 1538             /* (NOTCH_DATA_SIZE - NOTCH_DATA_START_SIZE) */
+#define NOTCH_FFT_SIZE 1025                     /* (NOTCH_DATA_SIZE / 2 + 1) */
+struct qo_notch {
+    int on, old1, count1, old2, count2, index, fltrSig;
+    double data_in[NOTCH_DATA_SIZE], data_out[NOTCH_DATA_SIZE];
+    double notch_fft[2 * NOTCH_FFT_SIZE], fltr_fft[2 * NOTCH_FFT_SIZE];     /* complex double */
+    double fft_window[NOTCH_DATA_SIZE], fltr_in[NOTCH_DATA_SIZE], fltr_out[NOTCH_FILTER_DESIGN_SIZE];
+    double average_fft[NOTCH_FFT_SIZE];
+};
+
+/* fftw_plan_dft_r2c_1d: bins 0 .. n/2 of the forward transform of n real samples */
+static void notch_r2c(const double *in, double *out, int n)
+{
+    double *buf = (double *)malloc((size_t)n * 2 * sizeof(double));
+    int i;
+    for (i = 0; i < n; i++) { buf[2 * i] = in[i]; buf[2 * i + 1] = 0.0; }
+    fo_fft(buf, n, -1);
+    memcpy(out, buf, (size_t)(n / 2 + 1) * 2 * sizeof(double));
+    free(buf);
+}
+
+/* fftw_plan_dft_c2r_1d: unnormalised inverse of the Hermitian extension of bins 0 .. n/2 (imaginary parts of bins 0
+ * and n/2 do not enter) */
+static void notch_c2r(const double *in, double *out, int n)
+{
+    double *buf = (double *)malloc((size_t)n * 2 * sizeof(double));
+    int i;
+    buf[0] = in[0]; buf[1] = 0.0;
+    buf[n] = in[n]; buf[n + 1] = 0.0;
+    for (i = 1; i < n / 2; i++) {
+        buf[2 * i] = in[2 * i]; buf[2 * i + 1] = in[2 * i + 1];
+        buf[2 * (n - i)] = in[2 * i]; buf[2 * (n - i) + 1] = -in[2 * i + 1];
+    }
+    fo_fft(buf, n, +1);
+    for (i = 0; i < n; i++) out[i] = buf[2 * i];
+    free(buf);
+}
+
+void qo_notch_init(qo_notch *a)                                  /* dAutoNotch(NULL, 0, 0, 0), quisk.c:826-834 */
+{
+    a->index = NOTCH_DATA_START_SIZE;
+    a->fltrSig = -1;
+    a->old1 = a->old2 = 0;
+    a->count1 = a->count2 = -4;
+    memset(a->data_out, 0, sizeof(a->data_out));
+    memset(a->data_in, 0, sizeof(a->data_in));
+    memset(a->average_fft, 0, sizeof(a->average_fft));
+}
+
+qo_notch *qo_notch_create(void)
+{
+    int i;
+    qo_notch *a = (qo_notch *)calloc(1, sizeof(*a));
+    for (i = 0; i < NOTCH_FILTER_SIZE; i++)                      /* Hanning, quisk.c:822-823; the rest stays 0 */
+        a->fft_window[i] = 0.50 - 0.50 * cos(2. * M_PI * i / (NOTCH_FILTER_SIZE));
+    qo_notch_init(a);
+    return a;
+}
+
+void qo_notch_free(qo_notch *a) { free(a); }
+void qo_notch_set(qo_notch *a, int on) { a->on = on; qo_notch_init(a); }        /* set_auto_notch, quisk.c:4596-4603 */
+
+void qo_notch_process(qo_notch *a, double *dsamples, int nSamples, int sidetone, int rate)
+{
+    int i, j, k, i1, i2, inp, signal, delta_sig, delta_i1, half_width;
+    double d, d1, d2, avg;
+    if (!a->on) return;                                          /* quisk.c:835-836 */
+    for (inp = 0; inp < nSamples; inp++) {
+        a->data_in[a->index] = dsamples[inp];
+        dsamples[inp] = a->data_out[a->index];
+        if (++a->index >= NOTCH_DATA_SIZE) {
+            a->index = NOTCH_DATA_START_SIZE;
+            notch_r2c(a->data_in, a->notch_fft, NOTCH_DATA_SIZE);
+            delta_sig = (300 * 2 * NOTCH_FFT_SIZE + rate / 2) / rate;
+            delta_i1 = (400 * 2 * NOTCH_FFT_SIZE + rate / 2) / rate;
+            signal = sidetone != 0 ? (abs(sidetone) * 2 * NOTCH_FFT_SIZE + rate / 2) / rate : -999;
+            avg = 1;
+            d1 = 0; i1 = 0;
+            for (i = 0; i < NOTCH_FFT_SIZE; i++) {
+                d = hypot(a->notch_fft[2 * i], a->notch_fft[2 * i + 1]);
+                avg += d;
+                a->average_fft[i] = 0.5 * a->average_fft[i] + 0.5 * d;
+                if (abs(i - signal) > delta_sig && a->average_fft[i] > d1) { d1 = a->average_fft[i]; i1 = i; }
+            }
+            if (abs(i1 - a->old1) < 3) a->count1++; else a->count1--;
+            if (a->count1 > 4) a->count1 = 4; else if (a->count1 < -1) a->count1 = -1;
+            if (a->count1 < 0) a->old1 = i1;
+            avg /= NOTCH_FFT_SIZE;
+            d2 = 0; i2 = 0;
+            for (i = 0; i < NOTCH_FFT_SIZE; i++)
+                if (abs(i - signal) > delta_sig && abs(i - i1) > delta_i1 && a->average_fft[i] > d2) { d2 = a->average_fft[i]; i2 = i; }
+            if (abs(i2 - a->old2) < 3) a->count2++; else a->count2--;
+            if (a->count2 > 4) a->count2 = 4; else if (a->count2 < -2) a->count2 = -2;
+            if (a->count2 < 0) a->old2 = i2;
+            if (a->count1 > 0 && a->count2 > 0) k = i1 + 10000 * i2;
+            else if (a->count1 > 0) k = i1;
+            else k = 0;
+            if (a->fltrSig != k) {                               /* make the filter if it is different */
+                a->fltrSig = k;
+                half_width = (100 * 2 * NOTCH_FILTER_FFT_SIZE + rate / 2) / rate;
+                if (half_width < 3) half_width = 3;
+                for (i = 0; i < NOTCH_FILTER_FFT_SIZE; i++) { a->fltr_fft[2 * i] = 1.0; a->fltr_fft[2 * i + 1] = 0.0; }
+                k = (i1 + 2) / 4;
+                if (a->count1 > 0)
+                    for (i = -half_width; i <= half_width; i++) {
+                        j = k + i;
+                        if (j >= 0 && j < NOTCH_FILTER_FFT_SIZE) { a->fltr_fft[2 * j] = 0.0; a->fltr_fft[2 * j + 1] = 0.0; }
+                    }
+                k = (i2 + 2) / 4;
+                if (a->count1 > 0 && a->count2 > 0)
+                    for (i = -half_width; i <= half_width; i++) {
+                        j = k + i;
+                        if (j >= 0 && j < NOTCH_FILTER_FFT_SIZE) { a->fltr_fft[2 * j] = 0.0; a->fltr_fft[2 * j + 1] = 0.0; }
+                    }
+                /* fltrRev reads bins 0 .. 256; bin 256 still holds what the previous fltrFwd left there */
+                notch_c2r(a->fltr_fft, a->fltr_out, NOTCH_FILTER_DESIGN_SIZE);
+                memmove(a->fltr_out + NOTCH_FILTER_DESIGN_SIZE / 2 - 1, a->fltr_out, sizeof(double) * (NOTCH_FILTER_SIZE / 2 - 1));
+                for (i = NOTCH_FILTER_DESIGN_SIZE / 2 - 2, j = NOTCH_FILTER_DESIGN_SIZE / 2; i >= 0; i--, j++)
+                    a->fltr_out[i] = a->fltr_out[j];
+                for (i = 0; i < NOTCH_FILTER_SIZE; i++)
+                    a->fltr_in[i] = a->fltr_out[i] * a->fft_window[i] / NOTCH_DATA_SIZE / 4;   /* "/ NOTCH_FILTER_DESIGN_SIZE" as the macro expands */
+                for (i = NOTCH_FILTER_SIZE; i < NOTCH_DATA_SIZE; i++) a->fltr_in[i] = 0.0;
+                notch_r2c(a->fltr_in, a->fltr_fft, NOTCH_DATA_SIZE);
+            }
+            for (i = 0; i < NOTCH_FFT_SIZE; i++) {              /* apply the filter */
+                double xr = a->notch_fft[2 * i], xi = a->notch_fft[2 * i + 1], fr = a->fltr_fft[2 * i], fi = a->fltr_fft[2 * i + 1];
+                a->notch_fft[2 * i] = xr * fr - xi * fi;
+                a->notch_fft[2 * i + 1] = xr * fi + xi * fr;
+            }
+            notch_c2r(a->notch_fft, a->data_out, NOTCH_DATA_SIZE);
+            memmove(a->data_in, a->data_in + NOTCH_DATA_OUTPUT_SIZE, NOTCH_DATA_START_SIZE * sizeof(double));
+            for (i = NOTCH_DATA_START_SIZE; i < NOTCH_DATA_SIZE; i++)
+                a->data_out[i] /= NOTCH_DATA_SIZE / 20;          /* "Empirical": integer 102 */
+        }
+    }
+    (void)avg;
 }
 
 int qo_rx_decim_srate(const qo_rx *r) { return r->decim_srate; }
@@ -243,6 +394,7 @@ void qo_rx_free(qo_rx *r)
     qo_fir_free(&r->audio24p6); qo_fir_free(&r->audio48p3); qo_fir_free(&r->fmhp);
     qo_agc_free(r->agc);
     qo_nb_free(r->nb);
+    qo_notch_free(r->notch);
     free(r->filtI); free(r->filtQ); free(r->bufI); free(r->bufQ); free(r->bufC); free(r->dsamples);
     free(r);
 }
@@ -253,6 +405,13 @@ void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
 void qo_rx_set_squelch(qo_rx *r, double level) { r->squelch_level = level; }     /* set_squelch, quisk.c:4721-4727 */
 void qo_rx_set_ssb_squelch(qo_rx *r, int enabled, int level) { r->ssb_squelch_enabled = enabled; r->ssb_squelch_level = level; }
 void qo_rx_set_agc(qo_rx *r, int on, double release_gain) { r->agc_on = on; r->agc_gain = release_gain; }
+
+void qo_rx_set_auto_notch(qo_rx *r, int on, int rit_freq)
+{
+    if (!r->notch) r->notch = qo_notch_create();
+    r->rit_freq = rit_freq;
+    qo_notch_set(r->notch, on);
+}
 
 void qo_rx_set_noise_blanker(qo_rx *r, int level)
 {
@@ -435,6 +594,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
             ds[i] = r->mode == QO_CWL ? re + im : re - im;
         }
+        if (r->notch) qo_notch_process(r->notch, ds, n, r->rit_freq, r->filter_srate);                 /* quisk.c:1923-1924 */
         if (r->ssb_squelch_enabled) { ssb_squelch(r, ds, n, r->filter_srate); d_delay(r, ds, n); }     /* quisk.c:1925-1928 */
         n = qo_dInterpolate(ds, n, &r->audio12p2, 2);
         n = qo_dInterp2HB45(ds, n, &r->dHB6);
@@ -448,6 +608,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
             ds[i] = r->mode == QO_LSB ? re + im : re - im;
         }
+        if (r->notch) qo_notch_process(r->notch, ds, n, 0, r->filter_srate);                           /* quisk.c:1968-1969 */
         if (r->ssb_squelch_enabled) { ssb_squelch(r, ds, n, r->filter_srate); d_delay(r, ds, n); }     /* quisk.c:1970-1973 */
         n = qo_dInterpolate(ds, n, &r->audio24p4, 2);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
@@ -464,6 +625,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             ds[i] = di;
         }
         n = qo_dFilter(ds, n, &r->audio24p6);
+        if (r->notch) qo_notch_process(r->notch, ds, n, 0, r->filter_srate);                           /* quisk.c:2018-2019 */
         if (r->ssb_squelch_enabled) { ssb_squelch(r, ds, n, r->filter_srate); d_delay(r, ds, n); }     /* quisk.c:2020-2023 */
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
         break;
@@ -490,6 +652,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
         n = qo_dFilter(ds, n, &r->fmhp);
         n = qo_dInterp2HB45(ds, n, &r->dHB6);
         n = qo_dInterp2HB45(ds, n, &r->dHB7);
+        if (r->notch) qo_notch_process(r->notch, ds, n, 0, r->filter_srate);                           /* quisk.c:2069-2070 */
         if (r->rf_count >= 2400) {                              /* quisk.c:2076-2084 */
             r->squelch = r->rf_sum / r->rf_count / CLIP32;
             r->squelch = r->squelch > 1.E-10 ? 20 * log10(r->squelch) : -200.0;
@@ -510,6 +673,7 @@ static int process_demodulate(qo_rx *r, double *x, double *ds, int n)   /* quisk
             cRxFilterOut(r, x[2 * i], x[2 * i + 1], &re, &im);
             ds[i] = (r->mode == QO_DGT_L || r->mode == QO_FDV_L) ? re + im : re - im;
         }
+        if (r->notch) qo_notch_process(r->notch, ds, n, 0, r->filter_srate);                           /* quisk.c:2106-2107,2133-2134 */
         if (r->bandwidth < 3000) {
             n = qo_dInterpolate(ds, n, &r->audio12p2, 2);
             n = qo_dInterp2HB45(ds, n, &r->dHB6);

@@ -65,6 +65,15 @@ void qo_nb_free(qo_nb *b);
 void qo_nb_set_level(qo_nb *b, int level);
 int qo_nb_delay(const qo_nb *b);
 void qo_nb_process(qo_nb *b, double *csamples, int count);
+/* dAutoNotch (quisk.c:786-963) alone, one real audio stream, in place; `sidetone` = rit_freq in the CW modes else 0,
+ * `rate` = quisk_filter_srate.  qo_notch_set is set_auto_notch (quisk.c:4596): stores the flag and re-initialises. */
+typedef struct qo_notch qo_notch;
+qo_notch *qo_notch_create(void);
+void qo_notch_free(qo_notch *a);
+void qo_notch_set(qo_notch *a, int on);
+void qo_notch_init(qo_notch *a);
+void qo_notch_process(qo_notch *a, double *dsamples, int count, int sidetone, int rate);
+void qo_rx_set_auto_notch(qo_rx *r, int on, int rit_freq);      /* set_auto_notch + set_sidetone's rit_freq */
 void qo_rx_set_noise_blanker(qo_rx *r, int level);              /* set_noise_blanker, quisk.c:4605; runs before the tune */
 int qo_rx_decim_srate(const qo_rx *r);
 int qo_rx_filter_srate(const qo_rx *r);

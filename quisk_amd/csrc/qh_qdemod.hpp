@@ -167,4 +167,186 @@ static __global__ __launch_bounds__(256) void q_delay_kernel(const double2 *src,
     }
 }
 
+// dAutoNotch (quisk.c:786-963): overlap-save on 2048-sample blocks of the real audio (510 old + 1538 new), the two
+// strongest averaged bins tracked with a hysteresis count each, a 511-tap notch designed by frequency sampling when
+// the pair changes.  One workgroup per stream; the 2048-point transforms are TileFft<2048> on (x, 0) pairs -- the
+// audio runs at 6..48 ksps, one block per 32..256 ms of signal, so real-input tricks would buy nothing.  The
+// per-block decisions (argmax with the reference's first-wins tie rule, counts, filter signature) are taken by
+// lane 0 from block-wide reductions.  State lives in global memory in the reference's layout (data_in / data_out
+// rings with the write index, average_fft, fltr_fft), so a call may end anywhere inside a block.
+struct QNotchState {
+    int index, fltrSig, old1, count1, old2, count2, pad0, pad1;
+    double data_in[2048], data_out[2048], average_fft[1025];
+    double2 fltr_fft[2048];         // bins 0..1024 are the reference's array; the upper half is its Hermitian mirror
+};
+
+__device__ __forceinline__ void notch_argmax_reduce(double &v, int &i, double *sv, int *si)
+{
+    // larger value wins, the lower index on equal values (the reference scans upwards with a strict >)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ov = __shfl_xor(v, d, 64);
+        const int oi = __shfl_xor(i, d, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    const int t = threadIdx.x;
+    __syncthreads();
+    if ((t & 63) == 0) { sv[t >> 6] = v; si[t >> 6] = i; }
+    __syncthreads();
+    v = sv[0]; i = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++)
+        if (sv[w] > v || (sv[w] == v && si[w] < i)) { v = sv[w]; i = si[w]; }
+}
+
+// dAutoNotch(NULL, 0, 0, 0), quisk.c:826-834: everything but the filter spectrum starts over
+static __global__ __launch_bounds__(256) void q_autonotch_init_kernel(QNotchState *state)
+{
+    QNotchState &st = state[blockIdx.x];
+    for (int j = threadIdx.x; j < 2048; j += 256) { st.data_in[j] = 0.0; st.data_out[j] = 0.0; if (j < 1025) st.average_fft[j] = 0.0; }
+    if (threadIdx.x == 0) { st.average_fft[1024] = 0.0; st.index = 510; st.fltrSig = -1; st.old1 = st.old2 = 0; st.count1 = st.count2 = -4; }
+}
+
+static __global__ __launch_bounds__(256) void q_autonotch_kernel(double2 *buf, long long stride, int n, QNotchState *state,
+                                                                 const double2 *tw2048, int sidetone, int rate, int dup)
+{
+    using Fwd = TileFft<2048, false, double2>;
+    using Inv = TileFft<2048, true, double2>;
+    extern __shared__ __align__(16) unsigned char notch_smem[];
+    __shared__ double s_avg[1025], s_cos[512], s_c2r[512], s_v[4];
+    __shared__ int s_i[4], s_dec[4];
+    const int ch = blockIdx.x, t = threadIdx.x;
+    double2 *p = buf + (long long)ch * stride;
+    QNotchState &st = state[ch];
+    int pos = 0, idx = st.index;
+    for (int j = t; j < 512; j += 256) s_cos[j] = cospi(2.0 * j / 512.0);
+    while (pos < n) {
+        int take = 2048 - idx;
+        if (take > n - pos) take = n - pos;
+        for (int j = t; j < take; j += 256) {                   // newest sample in, filtered sample out (quisk.c:840-841)
+            const double v = p[pos + j].x, o = st.data_out[idx + j];
+            st.data_in[idx + j] = v;
+            p[pos + j].x = o;
+            if (dup) p[pos + j].y = o;
+        }
+        idx += take; pos += take;
+        if (idx < 2048) break;
+        idx = 510;                                              // NOTCH_DATA_START_SIZE
+        __syncthreads();                                        // data_in of this block is complete (same workgroup wrote it)
+        // ---- forward transform of the block
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[r] = make_double2(st.data_in[t + 256 * r], 0.0);
+        __syncthreads();
+        Fwd::run(x, notch_smem, Fwd::load(tw2048));
+        // ---- averaged magnitudes of bins 0..1024 (lane t holds bins t + 256 r)
+        const int delta_sig = (300 * 2 * 1025 + rate / 2) / rate, delta_i1 = (400 * 2 * 1025 + rate / 2) / rate;
+        const int signal = sidetone != 0 ? ((sidetone < 0 ? -sidetone : sidetone) * 2 * 1025 + rate / 2) / rate : -999;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int i = t + 256 * r;
+            if (i <= 1024) {
+                const double a = 0.5 * st.average_fft[i] + 0.5 * hypot(x[r].x, x[r].y);
+                st.average_fft[i] = a;
+                s_avg[i] = a;
+            }
+        }
+        __syncthreads();
+        double v1 = 0.0; int i1 = 0;                            // first maximum (quisk.c:857-869): d1 = 0, i1 = 0 to start
+        for (int i = t; i <= 1024; i += 256) {
+            const int ds = i - signal < 0 ? signal - i : i - signal;
+            if (ds > delta_sig && (s_avg[i] > v1)) { v1 = s_avg[i]; i1 = i; }
+        }
+        if (!(v1 > 0.0)) i1 = 0;
+        notch_argmax_reduce(v1, i1, s_v, s_i);
+        double v2 = 0.0; int i2 = 0;                            // next maximum not near the first (quisk.c:881-888)
+        for (int i = t; i <= 1024; i += 256) {
+            const int ds = i - signal < 0 ? signal - i : i - signal, d1 = i - i1 < 0 ? i1 - i : i - i1;
+            if (ds > delta_sig && d1 > delta_i1 && s_avg[i] > v2) { v2 = s_avg[i]; i2 = i; }
+        }
+        if (!(v2 > 0.0)) i2 = 0;
+        notch_argmax_reduce(v2, i2, s_v, s_i);
+        if (t == 0) {
+            int c1 = st.count1, c2 = st.count2;
+            const int a1 = i1 - st.old1 < 0 ? st.old1 - i1 : i1 - st.old1, a2 = i2 - st.old2 < 0 ? st.old2 - i2 : i2 - st.old2;
+            c1 += a1 < 3 ? 1 : -1;
+            if (c1 > 4) c1 = 4; else if (c1 < -1) c1 = -1;
+            if (c1 < 0) st.old1 = i1;
+            c2 += a2 < 3 ? 1 : -1;
+            if (c2 > 4) c2 = 4; else if (c2 < -2) c2 = -2;
+            if (c2 < 0) st.old2 = i2;
+            st.count1 = c1; st.count2 = c2;
+            const int sig = (c1 > 0 && c2 > 0) ? i1 + 10000 * i2 : c1 > 0 ? i1 : 0;
+            s_dec[0] = st.fltrSig != sig;
+            s_dec[1] = c1 > 0;
+            s_dec[2] = c1 > 0 && c2 > 0;
+            st.fltrSig = sig;
+        }
+        __syncthreads();
+        if (s_dec[0]) {
+            // ---- design (quisk.c:905-942): c2r of a 0/1 spectrum of 256 bins (+ bin 256 = whatever the last design
+            // left in fltr_fft[256]), centred with the reference's memmove / mirror, Hanning window, r2c at 2048
+            int half_width = (100 * 2 * 256 + rate / 2) / rate;
+            if (half_width < 3) half_width = 3;
+            const int k1 = (i1 + 2) / 4, k2 = (i2 + 2) / 4, on1 = s_dec[1], on2 = s_dec[2];
+            const double f256 = st.fltr_fft[256].x;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int m = t + 256 * h;
+                double acc = 0.0;
+                for (int k = 1; k < 256; k++) {
+                    const int da = k - k1 < 0 ? k1 - k : k - k1, db = k - k2 < 0 ? k2 - k : k - k2;
+                    const bool zero = (on1 && da <= half_width) || (on2 && db <= half_width);
+                    if (!zero) acc += s_cos[(k * m) & 511];
+                }
+                const bool zero0 = (on1 && k1 <= half_width) || (on2 && k2 <= half_width);      // bin 0 inside a notch
+                s_c2r[m] = (zero0 ? 0.0 : 1.0) + ((m & 1) ? -f256 : f256) + 2.0 * acc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int i = t + 256 * r;
+                double f = 0.0;
+                if (i < 511) {
+                    // fltr_out after "memmove(fltr_out + 255, fltr_out, 254 doubles)" and the mirror loop
+                    const double o = i >= 509 ? s_c2r[i] : i >= 255 ? s_c2r[i - 255] : i >= 2 ? s_c2r[255 - i] : s_c2r[510 - i];
+                    f = o * (0.50 - 0.50 * cospi(2.0 * i / 511.0)) / 2048.0 / 4.0;
+                }
+                x[r] = make_double2(f, 0.0);
+            }
+            __syncthreads();
+            Fwd::run(x, notch_smem, Fwd::load(tw2048));
+#pragma unroll
+            for (int r = 0; r < 8; r++) st.fltr_fft[t + 256 * r] = x[r];
+            __syncthreads();
+            // redo the block's transform (a design is rare; keeping 8 more complex registers live all the time is not)
+#pragma unroll
+            for (int r = 0; r < 8; r++) x[r] = make_double2(st.data_in[t + 256 * r], 0.0);
+            Fwd::run(x, notch_smem, Fwd::load(tw2048));
+        }
+        // ---- apply the filter and transform back (quisk.c:946-952)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const double2 f = st.fltr_fft[t + 256 * r];
+            x[r] = make_double2(x[r].x * f.x - x[r].y * f.y, x[r].x * f.y + x[r].y * f.x);
+        }
+        __syncthreads();
+        Inv::run(x, notch_smem, Inv::load(tw2048));
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int i = t + 256 * r;
+            if (i >= 510) st.data_out[i] = x[r].x / 102.0;      // NOTCH_DATA_SIZE / 20 in integers: "Empirical"
+        }
+        // memmove(data_in, data_in + NOTCH_DATA_OUTPUT_SIZE, NOTCH_DATA_START_SIZE doubles)
+        double mv0 = 0.0, mv1 = 0.0;
+        if (t < 510) mv0 = st.data_in[1538 + t];
+        if (t + 256 < 510) mv1 = st.data_in[1538 + t + 256];
+        __syncthreads();
+        if (t < 510) st.data_in[t] = mv0;
+        if (t + 256 < 510) st.data_in[t + 256] = mv1;
+        __syncthreads();
+    }
+    if (t == 0) st.index = idx;
+}
+
 }  // namespace qh

@@ -77,9 +77,10 @@ static bool lower(int m) { return m == Q_CWL || m == Q_LSB || m == Q_DGT_L || m 
 static bool sideband(int m) { return is_cw(m) || is_ssb(m) || is_dgt(m); }                          // cRxFilterOut, re -+ im
 
 struct Step {
-    enum Kind { FIR, RAT, AM_ENV, FM_DISC, SSB_SQ, DELAY } kind;
+    enum Kind { FIR, RAT, AM_ENV, FM_DISC, SSB_SQ, DELAY, NOTCH } kind;
     Stage *st = nullptr;
     qh_rat *rat = nullptr;
+    bool dup = false;               // NOTCH: the stream is already (d, d) here, keep both parts equal
 };
 
 struct Qrx {
@@ -106,6 +107,11 @@ struct Qrx {
     bool sq_dirty = false;
     qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = off
     double agc_gain = 80.0;
+    // dAutoNotch (quisk.c:786-963): a NOTCH step sits where the mode calls it, idle until qh_qrx_set_auto_notch
+    QNotchState *notch_state = nullptr;
+    double2 *tw2048 = nullptr;
+    bool notch_on = false;
+    int rit_freq = 0;
     qh_nb *nb = nullptr;            // NoiseBlanker ahead of the tune (quisk.c:2448-2449); created by the first non-zero level
     int nb_level = 0;
     double2 *nb_buf = nullptr;
@@ -122,7 +128,7 @@ struct Qrx {
             if (s.rat) qh_rat_destroy(s.rat);
         }
         (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
-        (void)hipFree(sq_state); (void)hipFree(sq_level); (void)hipFree(nb_buf);
+        (void)hipFree(sq_state); (void)hipFree(sq_level); (void)hipFree(nb_buf); (void)hipFree(notch_state); (void)hipFree(tw2048);
         (void)hipFree(ssq_state); (void)hipFree(ssq_ring); (void)hipFree(ssq_delay[0]); (void)hipFree(ssq_delay[1]);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -277,6 +283,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         st.insert(st.end(), fe.begin(), fe.end());
         if (q.add_groups(st, true, true)) return fail();
     }
+    bool notch_after_rxf = false;
     // ---- Rx filter: per-channel taps, up to 2048; identity until set_filters is called (sizeFilter == 0)
     const bool direct_out = (is_dgt(mode) && !dgt_narrow) || is_iq(mode);       // nothing follows the Rx filter
     {
@@ -286,10 +293,12 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         q.steps.push_back(step);
         if (q.rxf->init(device, nch, 2048, 1, 1, QH_F64, false, true, sideband(mode), q.stream)) return fail();
         if (q.rxf->set_taps(-1, std::vector<cd>(1, q.rx_identity()))) return fail();
+        if (sideband(mode) && !is_iq(mode)) notch_after_rxf = true;     // quisk.c:1923,1946,1968,1992,2106,2133 (not DGT-IQ)
         if (sideband(mode))
             for (int c = 0; c < nch; c++)       // re -+ im collapses to the real part; (d, d) when it is the last stage (quisk.c:2625)
                 if (q.rxf->set_epi(c, direct_out ? EpiParam{ 1, 0, 1, 0 } : EpiParam{ 1, 0, 0, 0 })) return fail();
     }
+    if (notch_after_rxf) { Step nt; nt.kind = Step::NOTCH; nt.dup = direct_out; q.steps.push_back(nt); }
     // ---- detector and the way back to decim_srate
     const std::vector<double> g45 = hb45_interp_taps();
     std::vector<double> ueq;
@@ -304,6 +313,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         std::vector<FirStageSpec> a6;
         a6.push_back({ std::vector<double>(t->audio24p6, t->audio24p6 + 36), 1 });
         if (q.add_groups(a6, false, false)) return fail();
+        { Step nt; nt.kind = Step::NOTCH; q.steps.push_back(nt); }                          // quisk.c:2018-2019
         ueq = g45; U = 2;
     } else if (is_fm(mode)) {                       // HB45, HB45 after the /4 (quisk.c:2067-2068)
         Step det; det.kind = Step::FM_DISC; q.steps.push_back(det);
@@ -332,6 +342,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         for (int c = 0; c < nch; c++)
             if (step.st->set_epi(c, EpiParam{ 1, 0, 1, 0 })) return fail();                 // d + I*d, quisk.c:2625
     }
+    if (is_fm(mode)) { Step nt; nt.kind = Step::NOTCH; nt.dup = true; q.steps.push_back(nt); }     // after the interpolators, quisk.c:2069-2070
     if (is_am(mode)) {
         if (hipMalloc((void **)&q.dc_state, (size_t)nch * 8) != hipSuccess || hipMemset(q.dc_state, 0, (size_t)nch * 8) != hipSuccess) {
             set_error(QH_ERR_HIP, "allocation failed"); return fail();
@@ -485,6 +496,13 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                                    cur_stride, n, q.ssq_state, q.ssq_ring, q.sq_state, sp);
             }
             continue;
+        case Step::NOTCH:
+            if (q.notch_on && n > 0) {
+                constexpr size_t lds = TileFft<2048, false, double2>::kLdsBytes;
+                hipLaunchKernelGGL(q_autonotch_kernel, dim3((unsigned)q.nch), dim3(256), lds, q.stream, const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.notch_state,
+                                   q.tw2048, is_cw(q.mode) ? q.rit_freq : 0, q.filter_srate, s.dup ? 1 : 0);
+            }
+            continue;
         case Step::DELAY:
             if (!q.ssb_sq_on || n <= 0) continue;
             {
@@ -581,6 +599,32 @@ int qh_qrx_set_agc(qh_qrx *h, int on, double release_gain)
     }
     q.agc_gain = release_gain;
     return qh_qagc_set_gain(q.agc, -1, release_gain);
+}
+
+// set_auto_notch (quisk.c:4596-4603) with set_sidetone's rit_freq (quisk.c:4712; the CW modes keep the notch off the
+// sidetone): stores the flag and starts the notch state over, like dAutoNotch(NULL, 0, 0, 0)
+int qh_qrx_set_auto_notch(qh_qrx *h, int on, int rit_freq)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    Qrx &q = h->q;
+    bool has = false;
+    for (const Step &s : q.steps) has = has || s.kind == Step::NOTCH;
+    if (!has) { q.notch_on = false; return on ? set_error(QH_ERR_UNSUPPORTED, "this mode has no auto-notch (DGT-IQ)") : QH_OK; }
+    QH_HIP(hipSetDevice(q.device));
+    if (!q.notch_state) {
+        if (!on) return QH_OK;
+        QH_HIP(hipMalloc((void **)&q.notch_state, (size_t)q.nch * sizeof(QNotchState)));
+        QH_HIP(hipMemsetAsync(q.notch_state, 0, (size_t)q.nch * sizeof(QNotchState), q.stream));
+        const std::vector<cd> tw = fft_twiddle_table(2048);
+        QH_HIP(hipMalloc((void **)&q.tw2048, tw.size() * sizeof(cd)));
+        QH_HIP(hipMemcpyAsync(q.tw2048, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice, q.stream));
+        QH_HIP(hipStreamSynchronize(q.stream));
+    }
+    hipLaunchKernelGGL(q_autonotch_init_kernel, dim3((unsigned)q.nch), dim3(256), 0, q.stream, q.notch_state);
+    QH_HIP(hipGetLastError());
+    q.notch_on = on != 0;
+    q.rit_freq = rit_freq;
+    return QH_OK;
 }
 
 // set_noise_blanker (quisk.c:4605): the blanker runs on the raw samples, ahead of the tune

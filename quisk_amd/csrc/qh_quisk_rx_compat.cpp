@@ -34,6 +34,7 @@ struct QuiskRx {
     // NoiseBlanker's statics (quisk.c:682-687): outlive mode changes, so they are not the bank's
     qh_nb *nb = nullptr;
     int nb_level = 0;
+    int auto_notch = 0, rit_freq = 0, notch_applied = -1;
     std::vector<double> nb_out;
 };
 
@@ -56,12 +57,17 @@ int ensure_bank()
         if (!g.bank) return QH_ERR_HIP;
         g.bank_mode = g.mode; g.bank_bw_class = cls; g.bank_rate = g.sample_rate;
         g.params_dirty = true;
+        g.notch_applied = -1;
     }
     if (g.params_dirty) {
         if (int rc = qh_qrx_set_tune(g.bank, 0, g.tune)) return rc;
         if (int rc = qh_qrx_set_filters(g.bank, 0, g.filtI.data(), g.filtQ.data(), (int)g.filtI.size())) return rc;
         if (int rc = qh_qrx_set_agc(g.bank, g.agc_on ? 1 : 0, g.agc_gain)) return rc;
         g.params_dirty = false;
+    }
+    if (g.notch_applied != g.auto_notch) {          // a set_auto_notch call (or a fresh bank) starts the notch over
+        if (g.mode != 9 /* DGT-IQ has no notch */) if (int rc = qh_qrx_set_auto_notch(g.bank, g.auto_notch, g.rit_freq)) return rc;
+        g.notch_applied = g.auto_notch;
     }
     return QH_OK;
 }
@@ -137,6 +143,12 @@ void qh_quisk_set_agc(double level)                 // set_agc, quisk.c:4543
 {
     std::lock_guard<std::mutex> lk(g.mtx);
     g.agc_gain = level; g.params_dirty = true;
+}
+
+void qh_quisk_set_auto_notch(int on, int rit_freq)   // set_auto_notch, quisk.c:4596: the flag, and dAutoNotch(NULL, ...)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.auto_notch = on ? 1 : 0; g.rit_freq = rit_freq; g.notch_applied = -1;
 }
 
 void qh_quisk_set_noise_blanker(int level)          // set_noise_blanker, quisk.c:4605

@@ -143,6 +143,9 @@ def load():
     L.qh_nb_process_host.argtypes = [vp, vp, ll, vp, ll, i]
     L.qh_nb_synchronize.argtypes = [vp]
     L.qh_qrx_set_noise_blanker.argtypes = [vp, i]
+    L.qh_qrx_set_auto_notch.argtypes = [vp, i, i]
+    L.qh_quisk_set_auto_notch.argtypes = [i, i]
+    L.qh_quisk_set_auto_notch.restype = None
     L.qh_quisk_set_noise_blanker.argtypes = [i]
     L.qh_quisk_set_noise_blanker.restype = None
     L.qh_qrx_set_agc.argtypes = [vp, i, C.c_double]

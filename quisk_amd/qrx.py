@@ -56,6 +56,10 @@ class QuiskRxBank:
         """process_agc on the output like quisk_process_samples; release_gain is QS.set_agc's argument (quisk.c:4543)."""
         check(self._L.qh_qrx_set_agc(self._h, 1 if on else 0, float(release_gain)))
 
+    def set_auto_notch(self, on, rit_freq=0):
+        """QS.set_auto_notch (quisk.c:4596): dAutoNotch on the demodulated audio; rit_freq keeps CW's sidetone."""
+        check(self._L.qh_qrx_set_auto_notch(self._h, 1 if on else 0, int(rit_freq)))
+
     def set_noise_blanker(self, level):
         """QS.set_noise_blanker (quisk.c:4605): NoiseBlanker on the raw samples ahead of the tune; 0 = off."""
         check(self._L.qh_qrx_set_noise_blanker(self._h, int(level)))

@@ -46,6 +46,10 @@ def set_agc(level):
     load().qh_quisk_set_agc(C.c_double(level))
 
 
+def set_auto_notch(on, rit_freq=0):
+    load().qh_quisk_set_auto_notch(int(on), int(rit_freq))
+
+
 def set_noise_blanker(level):
     load().qh_quisk_set_noise_blanker(int(level))
 
