@@ -282,6 +282,30 @@ int qh_pan_count(const qh_pan *p);          /* FFTs averaged since the last qh_p
 /* The refresh branch of get_graph: h_pixels [nch][data_width] dB, h_smeter [nch] dB (either may be NULL),
  * *count = FFTs that were averaged (0: nothing was written, like get_graph returning None). */
 int qh_pan_graph(qh_pan *p, double zoom, double deltaf, double *h_pixels, double *h_smeter, int *count);
+/* The waterfall row of the same refresh: get_graph followed by watfall_OnGraphData
+ * (quisk.c:5372-5421) -- colour index (int)((dB - gain + 40 + 0.69 y_zero) * (y_scale + 10) * 0.10 + 128) clamped to
+ * 0..255 through the 256-entry red / green / blue tables of watfall_RgbData (quisk.c:5334); h_rgb [nch][width][3]
+ * bytes, pixels past data_width black.  Resets the average like qh_pan_graph. */
+int qh_pan_waterfall(qh_pan *p, double zoom, double deltaf, const unsigned char *red, const unsigned char *green,
+                     const unsigned char *blue, int y_zero, int y_scale, double gain, int width, unsigned char *h_rgb,
+                     double *h_smeter, int *count);
+/* watfall_OnGraphData alone for `nrows` dB rows on the host: h_db [nrows][ncols] -> h_rgb [nrows][width][3]. */
+int qh_watfall_rows_host(int device, const double *h_db, int nrows, int ncols, const unsigned char *red,
+                         const unsigned char *green, const unsigned char *blue, int y_zero, int y_scale, double gain,
+                         int width, unsigned char *h_rgb);
+
+/* The bandscope (get_bandscope, quisk.c:4957-5011; 8(f) rank 4) for `nch` ADC streams: blocks of bandscope_size REAL
+ * samples (already divided by bandscopeScale, quisk.c:3596) -> Hanning (init_bandscope, quisk.c:2887) -> r2c ->
+ * |X[0 .. size/2]| averaged over the blocks; qh_bscope_graph is the refresh branch: copy2pixels (quisk.c:4932-4955:
+ * fractional-bin box sums for the view (zoom, deltaf) of 0 .. clock / 2), scale, dB with floor -200, and
+ * hermes_adc_level = the largest |sample| since the last call.  bandscope_size 1024 .. 16384, a power of two. */
+typedef struct qh_bscope qh_bscope;
+qh_bscope *qh_bscope_create(int device, int nch, int bandscope_size, int graph_width, void *stream);
+void qh_bscope_destroy(qh_bscope *b);
+int qh_bscope_feed(qh_bscope *b, const double *d_in, long long in_stride, int n);         /* [nch][in_stride] doubles */
+int qh_bscope_feed_host(qh_bscope *b, const double *h_in, long long in_stride, int n);
+int qh_bscope_count(const qh_bscope *b);
+int qh_bscope_graph(qh_bscope *b, int clock, double zoom, double deltaf, double *h_pixels, double *h_adc_level, int *count);
 
 /* ------------------------------------------------------------------ 6. Quisk-native receiver bank */
 /* The receive path of quisk_process_samples (quisk.c:2289-2742) for `nch` receivers that share the sample rate

@@ -548,3 +548,46 @@ class OracleAutoNotch:
         if getattr(self, "h", None):
             self.L.qo_notch_free(self.h)
             self.h = None
+
+
+def watfall_row(db, red, green, blue, y_zero, y_scale, gain, width):
+    """watfall_OnGraphData (quisk.c:5372-5421): dB row -> uint8 [width, 3]."""
+    L = lib()
+    L.qo_watfall_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    L.qo_watfall_row.restype = None
+    db = np.ascontiguousarray(db, dtype=np.float64)
+    pal = [np.ascontiguousarray(a, dtype=np.uint8) for a in (red, green, blue)]
+    rgb = np.zeros((width, 3), dtype=np.uint8)
+    L.qo_watfall_row(db.ctypes.data, db.size, width, pal[0].ctypes.data, pal[1].ctypes.data, pal[2].ctypes.data, int(y_zero), int(y_scale),
+                     float(gain), rgb.ctypes.data)
+    return rgb
+
+
+class OracleBandscope:
+    """get_bandscope (quisk.c:4957-5011): block(x) per `size` real samples, get(clock, zoom, deltaf) -> (pixels, adc, count)."""
+
+    def __init__(self, size, graph_width):
+        L = lib()
+        L.qo_bscope_create.restype = C.c_void_p
+        L.qo_bscope_create.argtypes = [C.c_int, C.c_int]
+        L.qo_bscope_free.argtypes = [C.c_void_p]
+        L.qo_bscope_block.argtypes = [C.c_void_p, C.c_void_p]
+        L.qo_bscope_get.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
+        self.L, self.size, self.width = L, size, graph_width
+        self.h = L.qo_bscope_create(size, graph_width)
+
+    def block(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.size
+        self.L.qo_bscope_block(self.h, x.ctypes.data)
+
+    def get(self, clock, zoom=1.0, deltaf=0.0):
+        pix = np.empty(self.width, dtype=np.float64)
+        adc = C.c_double(0)
+        n = self.L.qo_bscope_get(self.h, int(clock), zoom, deltaf, pix.ctypes.data, C.byref(adc))
+        return None if n <= 0 else (pix, adc.value, n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_bscope_free(self.h)
+            self.h = None

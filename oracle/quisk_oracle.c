@@ -419,3 +419,93 @@ int qo_graph_get(qo_graph *g, double zoom, double deltaf, double *pixels, double
     g->count_fft = 0;
     return count;
 }
+
+void qo_watfall_row(const double *db, int size, int width, const unsigned char *red, const unsigned char *green,
+                    const unsigned char *blue, int y_zero, int y_scale, double gain, unsigned char *rgb)     /* quisk.c:5372-5421 */
+{
+    int i, l;
+    double yz = 40.0 + y_zero * 0.69;       /* -yz is the color center in dB */
+    if (size > width) size = width;
+    for (i = 0; i < size; i++) {
+        l = (int)((db[i] - gain + yz) * (y_scale + 10) * 0.10 + 128);
+        if (l < 0) l = 0; else if (l > 255) l = 255;
+        *rgb++ = red[l]; *rgb++ = green[l]; *rgb++ = blue[l];
+    }
+    for (; i < width; i++) { *rgb++ = 0; *rgb++ = 0; *rgb++ = 0; }
+}
+
+/* ---- bandscope: copy2pixels quisk.c:4932-4955, init_bandscope :2876-2893, get_bandscope :4957-5011 ---- */
+void qo_copy2pixels(double *pixels, int n_pixels, const double *fft, int fft_size, double zoom, double deltaf, double rate)
+{
+    int i, j, j1, j2;
+    double f1, d1, d2, sample;
+    f1 = deltaf + rate / 2.0 * (1.0 - zoom);        /* frequency at left of graph */
+    for (i = 0; i < n_pixels; i++) {
+        d1 = fft_size / rate * (f1 + (double)i / n_pixels * zoom * rate);
+        d2 = fft_size / rate * (f1 + (double)(i + 1) / n_pixels * zoom * rate);
+        j1 = (int)floor(d1);
+        j2 = (int)floor(d2);
+        if (j1 == j2) {
+            sample = (d2 - d1) * fft[j1];
+        } else {
+            sample = (j1 + 1 - d1) * fft[j1];
+            for (j = j1 + 1; j < j2; j++) sample += fft[j];
+            sample += (d2 - j2) * fft[j2];
+        }
+        pixels[i] = sample;
+    }
+}
+
+struct qo_bscope {
+    int size, graph_width, fft_count;
+    double the_max, *window, *average, *buf;
+};
+
+qo_bscope *qo_bscope_create(int size, int graph_width)
+{
+    int i, j;
+    qo_bscope *b = (qo_bscope *)calloc(1, sizeof(*b));
+    b->size = size; b->graph_width = graph_width;
+    b->window = (double *)malloc((size_t)size * sizeof(double));
+    b->average = (double *)calloc((size_t)size / 2 + 2, sizeof(double));
+    b->buf = (double *)malloc((size_t)size * 2 * sizeof(double));
+    for (i = 0, j = -size / 2; i < size; i++, j++) b->window[i] = 0.5 + 0.5 * cos(2. * M_PI * j / size);     /* Hanning */
+    return b;
+}
+
+void qo_bscope_free(qo_bscope *b) { if (b) { free(b->window); free(b->average); free(b->buf); free(b); } }
+
+void qo_bscope_block(qo_bscope *b, const double *samples)       /* bandscopeState == 99, quisk.c:4970-4983 */
+{
+    int i, L = b->size / 2 + 1;
+    for (i = 0; i < b->size; i++) {
+        double d1 = fabs(samples[i]);
+        if (d1 > b->the_max) b->the_max = d1;
+        b->buf[2 * i] = samples[i] * b->window[i];
+        b->buf[2 * i + 1] = 0.0;
+    }
+    fo_fft(b->buf, b->size, -1);                                 /* r2c: bins 0 .. size / 2 */
+    for (i = 0; i < L; i++) b->average[i] += hypot(b->buf[2 * i], b->buf[2 * i + 1]);
+    b->fft_count++;
+}
+
+int qo_bscope_get(qo_bscope *b, int clock, double zoom, double deltaf, double *pixels, double *adc_level)   /* quisk.c:4984-5006 */
+{
+    int i, L = b->size / 2 + 1, n = b->fft_count;
+    double frac, scale, rate, sample;
+    if (n <= 0) return 0;
+    b->average[L] = 0.0;                                         /* in case we run off the end */
+    frac = (double)L / b->graph_width;
+    scale = 1.0 / frac / b->fft_count / b->size;
+    rate = clock / 2.0;
+    qo_copy2pixels(pixels, b->graph_width, b->average, L, zoom, deltaf, rate);
+    for (i = 0; i < b->graph_width; i++) {
+        sample = pixels[i] * scale;
+        pixels[i] = sample <= 1E-10 ? -200.0 : 20.0 * log10(sample);
+    }
+    b->fft_count = 0;
+    if (adc_level) *adc_level = b->the_max;                      /* hermes_adc_level */
+    b->the_max = 0;
+    for (i = 0; i < L; i++) b->average[i] = 0;
+    return n;
+}

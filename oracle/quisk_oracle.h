@@ -86,6 +86,20 @@ int qo_graph_feed(qo_graph *g, const double *x, int n);
 /* the `1/graph_refresh has elapsed` branch: pixel row (data_width doubles, dB, clamped to [-200, 0]) and the
  * S-meter in dB; resets the average.  Returns the number of FFTs that were averaged (0: nothing to return). */
 int qo_graph_get(qo_graph *g, double zoom, double deltaf, double *pixels, double *smeter_db);
+/* get_bandscope (quisk.c:4957-5011) with init_bandscope's window (quisk.c:2876-2893) and copy2pixels (quisk.c:4932-4955):
+ * blocks of `size` real samples (already scaled by 1 / bandscopeScale) -> Hanning, r2c, |X| averaged over the blocks;
+ * qo_bscope_get is the `1 / graph_refresh has elapsed` branch: graph_width pixels in dB (floor -200) for the view
+ * (zoom, deltaf) of 0 .. clock / 2, and the largest |sample| since the last get (hermes_adc_level).  Returns the number
+ * of blocks averaged (0: nothing to return). */
+typedef struct qo_bscope qo_bscope;
+qo_bscope *qo_bscope_create(int size, int graph_width);
+void qo_bscope_free(qo_bscope *b);
+void qo_bscope_block(qo_bscope *b, const double *samples);
+int qo_bscope_get(qo_bscope *b, int clock, double zoom, double deltaf, double *pixels, double *adc_level);
+void qo_copy2pixels(double *pixels, int n_pixels, const double *fft, int fft_size, double zoom, double deltaf, double rate);
+/* watfall_OnGraphData (quisk.c:5372-5421): one waterfall row, `width` RGB pixels, from `size` dB values. */
+void qo_watfall_row(const double *db, int size, int width, const unsigned char *red, const unsigned char *green,
+                    const unsigned char *blue, int y_zero, int y_scale, double gain, unsigned char *rgb);
 #ifdef __cplusplus
 }
 #endif

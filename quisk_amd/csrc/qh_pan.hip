@@ -17,6 +17,7 @@
 //                     in pixel order like the reference (a later pixel can see an earlier pixel's sum when
 //                     zoomed in), dB scale, clamp to [-200, 0], S-meter in dB.  Tiny: one thread per channel.
 #include <cmath>
+#include <cstring>
 #include <vector>
 #include "qh_design.hpp"
 #include "qh_internal.hpp"
@@ -195,6 +196,82 @@ __global__ void pan_graph_kernel(double *avg, double *meter, int nch, int N, int
         p[i] = d2;
     }
     for (int i = 0; i < N; i++) a[i] = 0.0;
+}
+
+// watfall_OnGraphData (quisk.c:5372-5421): one waterfall row per channel from the dB row of get_graph -- colour index
+// l = (int)((dB - gain + yz) * (y_scale + 10) * 0.10 + 128) clamped to 0..255, yz = 40 + 0.69 y_zero, through the
+// 256-entry red / green / blue tables; pixels past the dB row are black.  palette = red[256] green[256] blue[256].
+__global__ __launch_bounds__(NT) void watfall_row_kernel(const double *db, long long db_stride, int size, int width,
+                                                         const unsigned char *palette, int y_zero, int y_scale, double gain,
+                                                         unsigned char *rgb)
+{
+    // the colour index is a truncation: a fused multiply-add would round the product differently right at an integer
+#pragma clang fp contract(off)
+    __shared__ unsigned char pal[768];
+    for (int j = threadIdx.x; j < 768; j += NT) pal[j] = palette[j];
+    __syncthreads();
+    const int row = blockIdx.y;
+    const double yz = 40.0 + y_zero * 0.69;
+    unsigned char *o = rgb + (long long)row * width * 3;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < width; i += gridDim.x * NT) {
+        unsigned char r = 0, g = 0, b = 0;
+        if (i < size) {
+            const double v = (db[(long long)row * db_stride + i] - gain + yz) * (y_scale + 10) * 0.10 + 128;
+            int l = v < 0.0 ? 0 : v > 255.0 ? 255 : (int)v;        // (int) then the clamp, for every value the clamp leaves alone
+            if (!(v == v)) l = 0;
+            r = pal[l]; g = pal[256 + l]; b = pal[512 + l];
+        }
+        o[3 * i] = r; o[3 * i + 1] = g; o[3 * i + 2] = b;
+    }
+}
+
+// ---- bandscope (get_bandscope, quisk.c:4957-5011): real ADC samples through the same windowed transform as (x, 0)
+// out[ch][i] = (in[ch][i], 0); maxbits[ch] = max |in| (non-negative doubles order like their bit patterns)
+__global__ __launch_bounds__(NT) void bscope_convert_kernel(const double *in, long long in_stride, int n, double2 *out,
+                                                            unsigned long long *maxbits)
+{
+    __shared__ double wmax[NT / 64];
+    const int ch = blockIdx.y;
+    double m = 0.0;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        const double v = in[(long long)ch * in_stride + i];
+        out[(long long)ch * n + i] = make_double2(v, 0.0);
+        m = fmax(m, fabs(v));
+    }
+    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < NT / 64; k++) m = fmax(m, wmax[k]);
+        atomicMax(maxbits + ch, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// copy2pixels (quisk.c:4932-4955) over bandscopeAverage[0 .. N/2] (+ the zero the reference appends "in case we run off
+// the end"), then scale and dB (quisk.c:4986-4999).  avg is the panadapter's image: bin k sits at (k + N/2) % N.
+__global__ __launch_bounds__(NT) void bscope_graph_kernel(const double *avg, int N, int width, double rate, double zoom, double deltaf,
+                                                          int count, double *pixels)
+{
+    const int ch = blockIdx.y, L = N / 2 + 1;
+    const double *a = avg + (long long)ch * N;
+    auto bin = [&](int k) -> double { return k >= 0 && k < L ? a[(k + N / 2) % N] : 0.0; };
+    const double frac = (double)L / width, scale = 1.0 / frac / count / N;
+    const double f1 = deltaf + rate / 2.0 * (1.0 - zoom);
+    for (int i = blockIdx.x * NT + threadIdx.x; i < width; i += gridDim.x * NT) {
+        const double d1 = L / rate * (f1 + (double)i / width * zoom * rate);
+        const double d2 = L / rate * (f1 + (double)(i + 1) / width * zoom * rate);
+        const int j1 = (int)floor(d1), j2 = (int)floor(d2);
+        double sample;
+        if (j1 == j2) {
+            sample = (d2 - d1) * bin(j1);
+        } else {
+            sample = (j1 + 1 - d1) * bin(j1);
+            for (int j = j1 + 1; j < j2; j++) sample += bin(j);
+            sample += (d2 - j2) * bin(j2);
+        }
+        sample *= scale;
+        pixels[(long long)ch * width + i] = sample <= 1E-10 ? -200.0 : 20.0 * log10(sample);
+    }
 }
 
 // dst[ch][dst_off + i] = src[ch][src_off + i], i < n
@@ -390,6 +467,68 @@ int qh_pan_graph(qh_pan *h, double zoom, double deltaf, double *h_pixels, double
     return QH_OK;
 }
 
+static int watfall_launch(int device, hipStream_t s, const double *d_db, long long db_stride, int nrows, int size, int width,
+                          const unsigned char *palette, int y_zero, int y_scale, double gain, unsigned char *h_rgb)
+{
+    unsigned char *d_pal = nullptr, *d_rgb = nullptr;
+    QH_HIP(hipSetDevice(device));
+    QH_HIP(hipMalloc((void **)&d_pal, 768));
+    if (hipMalloc((void **)&d_rgb, (size_t)nrows * width * 3) != hipSuccess) { (void)hipFree(d_pal); return set_error(QH_ERR_HIP, "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(d_pal, palette, 768, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        int gx = (width + NT - 1) / NT;
+        hipLaunchKernelGGL(watfall_row_kernel, dim3((unsigned)gx, (unsigned)nrows), dim3(NT), 0, s, d_db, db_stride, size < width ? size : width,
+                           width, d_pal, y_zero, y_scale, gain, d_rgb);
+        e = hipMemcpyAsync(h_rgb, d_rgb, (size_t)nrows * width * 3, hipMemcpyDeviceToHost, s);
+    }
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(d_pal); (void)hipFree(d_rgb);
+    if (e != hipSuccess || e2 != hipSuccess) return set_error(QH_ERR_HIP, "waterfall row failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return QH_OK;
+}
+
+// get_graph + watfall_OnGraphData in one call: the dB row never leaves the device
+int qh_pan_waterfall(qh_pan *h, double zoom, double deltaf, const unsigned char *red, const unsigned char *green,
+                     const unsigned char *blue, int y_zero, int y_scale, double gain, int width, unsigned char *h_rgb,
+                     double *h_smeter, int *count)
+{
+    if (!h || !red || !green || !blue || !h_rgb || width <= 0) return set_error(QH_ERR_INVALID, "qh_pan_waterfall: bad arguments");
+    Pan &p = h->p;
+    if (count) *count = p.count;
+    if (p.count <= 0) return QH_OK;
+    QH_HIP(hipSetDevice(p.device));
+    hipLaunchKernelGGL(pan_graph_kernel, dim3((unsigned)((p.nch + 63) / 64)), dim3(64), 0, p.stream, p.avg, p.meter, p.nch, p.N,
+                       p.data_width, p.rate, zoom, deltaf, p.count, p.pixels, p.smeter);
+    if (h_smeter) QH_HIP(hipMemcpyAsync(h_smeter, p.smeter, (size_t)p.nch * 8, hipMemcpyDeviceToHost, p.stream));
+    p.count = 0;
+    unsigned char pal[768];
+    std::memcpy(pal, red, 256); std::memcpy(pal + 256, green, 256); std::memcpy(pal + 512, blue, 256);
+    return watfall_launch(p.device, p.stream, p.pixels, p.data_width, p.nch, p.data_width, width, pal, y_zero, y_scale, gain, h_rgb);
+}
+
+// watfall_OnGraphData for `nrows` dB rows that are already on the host (h_db [nrows][ncols])
+int qh_watfall_rows_host(int device, const double *h_db, int nrows, int ncols, const unsigned char *red, const unsigned char *green,
+                         const unsigned char *blue, int y_zero, int y_scale, double gain, int width, unsigned char *h_rgb)
+{
+    if (!h_db || !red || !green || !blue || !h_rgb || nrows <= 0 || ncols < 0 || width <= 0)
+        return set_error(QH_ERR_INVALID, "qh_watfall_rows_host: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
+    QH_HIP(hipSetDevice(device));
+    double *d_db = nullptr;
+    QH_HIP(hipMalloc((void **)&d_db, (size_t)nrows * (ncols > 0 ? ncols : 1) * 8));
+    if (ncols > 0 && hipMemcpy(d_db, h_db, (size_t)nrows * ncols * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d_db);
+        return set_error(QH_ERR_HIP, "upload failed");
+    }
+    unsigned char pal[768];
+    std::memcpy(pal, red, 256); std::memcpy(pal + 256, green, 256); std::memcpy(pal + 512, blue, 256);
+    const int rc = watfall_launch(device, nullptr, d_db, ncols, nrows, ncols, width, pal, y_zero, y_scale, gain, h_rgb);
+    (void)hipFree(d_db);
+    return rc;
+}
+
 int qh_pan_feed_host(qh_pan *h, const double *h_in, long long in_stride, int n)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null panadapter");
@@ -404,6 +543,101 @@ int qh_pan_feed_host(qh_pan *h, const double *h_in, long long in_stride, int n)
     (void)hipFree(d);
     if (rc) return rc == QH_ERR_HIP ? set_error(QH_ERR_HIP, "qh_pan_feed_host: copy failed") : rc;
     if (e2 != hipSuccess) return set_error(QH_ERR_HIP, "qh_pan_feed_host: synchronize failed");
+    return QH_OK;
+}
+
+// ---- bandscope: qh_bscope_* -------------------------------------------------------------------------------
+struct qh_bscope {
+    qh_pan *pan = nullptr;
+    int nch = 0, N = 0, width = 0;
+    unsigned long long *maxbits = nullptr;
+    double2 *cbuf = nullptr;
+    long long ccap = 0;
+    ~qh_bscope()
+    {
+        if (pan) {
+            (void)hipSetDevice(pan->p.device);
+            (void)hipStreamSynchronize(pan->p.stream);
+            (void)hipFree(maxbits); (void)hipFree(cbuf);
+            qh_pan_destroy(pan);
+        }
+    }
+};
+
+qh_bscope *qh_bscope_create(int device, int nch, int bandscope_size, int graph_width, void *stream)
+{
+    qh_pan *pan = qh_pan_create(device, nch, bandscope_size, graph_width, 1.0, stream);
+    if (!pan) return nullptr;
+    qh_bscope *b = new qh_bscope();
+    b->pan = pan; b->nch = nch; b->N = bandscope_size; b->width = graph_width;
+    if (hipMalloc((void **)&b->maxbits, (size_t)nch * 8) != hipSuccess ||
+        hipMemsetAsync(b->maxbits, 0, (size_t)nch * 8, pan->p.stream) != hipSuccess) {
+        set_error(QH_ERR_HIP, "qh_bscope_create: allocation failed");
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void qh_bscope_destroy(qh_bscope *b) { delete b; }
+int qh_bscope_count(const qh_bscope *b) { return b ? b->pan->p.count : 0; }
+
+// n real samples per channel, device pointer [nch][in_stride] doubles, already divided by bandscopeScale (quisk.c:3596)
+int qh_bscope_feed(qh_bscope *b, const double *d_in, long long in_stride, int n)
+{
+    if (!b) return set_error(QH_ERR_INVALID, "null bandscope");
+    if (n <= 0) return QH_OK;
+    if (!d_in || in_stride < n) return set_error(QH_ERR_INVALID, "bad input");
+    Pan &p = b->pan->p;
+    QH_HIP(hipSetDevice(p.device));
+    if (n > b->ccap) {
+        QH_HIP(hipStreamSynchronize(p.stream));
+        (void)hipFree(b->cbuf); b->cbuf = nullptr;
+        QH_HIP(hipMalloc((void **)&b->cbuf, (size_t)b->nch * (size_t)n * 16));
+        b->ccap = n;
+    }
+    int gx = (n + NT - 1) / NT;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(bscope_convert_kernel, dim3((unsigned)gx, (unsigned)b->nch), dim3(NT), 0, p.stream, d_in, in_stride, n, b->cbuf, b->maxbits);
+    return qh_pan_feed(b->pan, reinterpret_cast<const double *>(b->cbuf), n, n);
+}
+
+int qh_bscope_feed_host(qh_bscope *b, const double *h_in, long long in_stride, int n)
+{
+    if (!b) return set_error(QH_ERR_INVALID, "null bandscope");
+    if (n <= 0) return QH_OK;
+    if (!h_in || in_stride < n) return set_error(QH_ERR_INVALID, "bad input");
+    Pan &p = b->pan->p;
+    QH_HIP(hipSetDevice(p.device));
+    double *d = nullptr;
+    QH_HIP(hipMalloc((void **)&d, (size_t)b->nch * (size_t)n * 8));
+    int rc = QH_OK;
+    if (hipMemcpy2DAsync(d, (size_t)n * 8, h_in, (size_t)in_stride * 8, (size_t)n * 8, (size_t)b->nch, hipMemcpyHostToDevice, p.stream) != hipSuccess)
+        rc = set_error(QH_ERR_HIP, "qh_bscope_feed_host: copy failed");
+    if (rc == QH_OK) rc = qh_bscope_feed(b, d, n, n);
+    if (hipStreamSynchronize(p.stream) != hipSuccess && rc == QH_OK) rc = set_error(QH_ERR_HIP, "qh_bscope_feed_host: synchronize failed");
+    (void)hipFree(d);
+    return rc;
+}
+
+// The refresh branch of get_bandscope(clock, zoom, deltaf): h_pixels [nch][graph_width] dB, h_adc_level [nch] = the largest
+// |sample| since the last call (hermes_adc_level); *count = blocks averaged (0: nothing written, like returning None)
+int qh_bscope_graph(qh_bscope *b, int clock, double zoom, double deltaf, double *h_pixels, double *h_adc_level, int *count)
+{
+    if (!b || clock <= 0) return set_error(QH_ERR_INVALID, "qh_bscope_graph: bad arguments");
+    Pan &p = b->pan->p;
+    if (count) *count = p.count;
+    if (p.count <= 0) return QH_OK;
+    QH_HIP(hipSetDevice(p.device));
+    hipLaunchKernelGGL(bscope_graph_kernel, dim3((unsigned)((b->width + NT - 1) / NT), (unsigned)b->nch), dim3(NT), 0, p.stream, p.avg, p.N,
+                       b->width, clock / 2.0, zoom, deltaf, p.count, p.pixels);
+    if (h_pixels) QH_HIP(hipMemcpyAsync(h_pixels, p.pixels, (size_t)b->nch * b->width * 8, hipMemcpyDeviceToHost, p.stream));
+    if (h_adc_level) QH_HIP(hipMemcpyAsync(h_adc_level, b->maxbits, (size_t)b->nch * 8, hipMemcpyDeviceToHost, p.stream));
+    QH_HIP(hipMemsetAsync(p.avg, 0, (size_t)b->nch * p.N * 8, p.stream));
+    QH_HIP(hipMemsetAsync(p.meter, 0, (size_t)b->nch * 8, p.stream));
+    QH_HIP(hipMemsetAsync(b->maxbits, 0, (size_t)b->nch * 8, p.stream));
+    QH_HIP(hipStreamSynchronize(p.stream));
+    p.count = 0;
     return QH_OK;
 }
 

@@ -114,6 +114,16 @@ def load():
     L.qh_pan_feed_host.argtypes = [vp, vp, ll, i]
     L.qh_pan_count.argtypes = [vp]
     L.qh_pan_graph.argtypes = [vp, d, d, vp, vp, C.POINTER(i)]
+    L.qh_pan_waterfall.argtypes = [vp, d, d, vp, vp, vp, i, i, d, i, vp, vp, C.POINTER(i)]
+    L.qh_watfall_rows_host.argtypes = [i, vp, i, i, vp, vp, vp, i, i, d, i, vp]
+    L.qh_bscope_create.restype = vp
+    L.qh_bscope_create.argtypes = [i, i, i, i, vp]
+    L.qh_bscope_destroy.argtypes = [vp]
+    L.qh_bscope_destroy.restype = None
+    L.qh_bscope_feed.argtypes = [vp, vp, ll, i]
+    L.qh_bscope_feed_host.argtypes = [vp, vp, ll, i]
+    L.qh_bscope_count.argtypes = [vp]
+    L.qh_bscope_graph.argtypes = [vp, i, d, d, vp, vp, C.POINTER(i)]
     L.qh_qrx_create.restype = vp
     L.qh_qrx_create.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
     L.qh_iq_format_le24.argtypes = [vp, C.c_double]
