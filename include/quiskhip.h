@@ -87,6 +87,22 @@ int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
 int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
 int qh_rxa_SetRXAFMLimRun(qh_rxa *e, int ch, int run);           /* wdsp/fmd.c:336-347: the FM detector's limiter */
 int qh_rxa_SetRXAFMLimGain(qh_rxa *e, int ch, double gaindB);    /* wdsp/fmd.c:349-362 */
+/* xanf / xanr (wdsp/anf.c:82-133, anr.c:82-133), setters wdsp/anf.c:175-239 and anr.c:175-238; which position (0 before
+ * bp1 and the AGC, 1 after the AGC) also moves bp1, as in the reference.  Taps and delay 1..64. */
+int qh_rxa_SetRXAANFRun(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANFTaps(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANFDelay(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANFPosition(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANFGain(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAANFLeakage(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAANFVals(qh_rxa *e, int ch, int taps, int delay, double gain, double leakage);
+int qh_rxa_SetRXAANRRun(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANRTaps(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANRDelay(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANRPosition(qh_rxa *e, int ch, int v);
+int qh_rxa_SetRXAANRGain(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAANRLeakage(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAANRVals(qh_rxa *e, int ch, int taps, int delay, double gain, double leakage);
 /* The notch database and nbp0's notched band-pass (wdsp/nbp.c:358-525, make_nbp :97-179, fir_mbandpass :64-80).
  * *rval receives the reference's return value (0, or -1 for an index out of range). */
 int qh_rxa_RXANBPAddNotch(qh_rxa *e, int ch, int notch, double fcenter, double fwidth, int active, int *rval);
@@ -197,6 +213,22 @@ double GetRXAMeter(int channel, int mt);                                        
 int wdspFexchange0(int channel, double *cSamples, int nSamples);
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use);
 /* accepted and ignored: these blocks are run = 0 on the hot path */
+/* anf / anr: the leaky-LMS automatic notch filter and noise reduction of the RXA chain (wdsp/anf.c:175-239, anr.c:175-238);
+ * up to 64 taps and a delay of up to 64 samples (defaults 64 / 16, RXA.c:285-286,305-306) */
+void SetRXAANFRun(int channel, int v);
+void SetRXAANFTaps(int channel, int v);
+void SetRXAANFDelay(int channel, int v);
+void SetRXAANFPosition(int channel, int v);
+void SetRXAANFGain(int channel, double v);
+void SetRXAANFLeakage(int channel, double v);
+void SetRXAANFVals(int channel, int taps, int delay, double gain, double leakage);
+void SetRXAANRRun(int channel, int v);
+void SetRXAANRTaps(int channel, int v);
+void SetRXAANRDelay(int channel, int v);
+void SetRXAANRPosition(int channel, int v);
+void SetRXAANRGain(int channel, double v);
+void SetRXAANRLeakage(int channel, double v);
+void SetRXAANRVals(int channel, int taps, int delay, double gain, double leakage);
 void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c */
 void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */
 void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */

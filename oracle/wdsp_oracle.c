@@ -544,7 +544,13 @@ struct wo_channel {
         double a0, a1, a2, b1, b2, x1, x2, y1, y2;
     } fmd;
     wo_agc agc;
-    struct { int run, nc, wintype; double f_low, f_high, gain; wo_fircore *p; } bp1;
+    struct { int run, nc, wintype, position; double f_low, f_high, gain; wo_fircore *p; } bp1;
+    /* anf / anr, wdsp/anf.h:32-61, anr.h:32-61 (the two structs are the same) */
+    struct wo_lms {
+        int run, position, n_taps, delay, in_idx, mask;
+        double two_mu, gamma, lidx, lidx_min, lidx_max, ngamma, den_mult, lincr, ldecr;
+        double d[2048], w[2048];                /* ANF_DLINE_SIZE, anf.h:30 */
+    } anf, anr;
     struct { int run, inselect, copy; double gain1, gain2I, gain2Q; } panel;
     /* iobuffs, wdsp/iobuffs.h */
     struct {
@@ -908,10 +914,51 @@ static void xpanel(wo_channel *c, double *buf, int size)
     }
 }
 
-/* ---- RXAbp1Check / RXAbp1Set (RXA.c:800-827) */
-static void bp1_check(wo_channel *c, int amd_run)
+/* ---- xanf (anf.c:82-133) and xanr (anr.c:82-133): the same leaky LMS line enhancer; the notch filter outputs the
+ * error, the noise reduction the prediction.  Real part only; the imaginary part comes out zero. */
+static void xlms(struct wo_lms *a, int is_anr, int position, double *buf, int size)
 {
-    double gain = amd_run ? 2.0 : 1.0;          /* snba/emnr/anf/anr never run on this path */
+    int i, j, idx;
+    double c0, c1, y, error, sigma, inv_sigp, nel, nev;
+    if (!(a->run && a->position == position)) return;
+    for (i = 0; i < size; i++) {
+        a->d[a->in_idx] = buf[2 * i + 0];
+        y = 0; sigma = 0;
+        for (j = 0; j < a->n_taps; j++) {
+            idx = (a->in_idx + j + a->delay) & a->mask;
+            y += a->w[j] * a->d[idx];
+            sigma += a->d[idx] * a->d[idx];
+        }
+        inv_sigp = 1.0 / (sigma + 1e-10);
+        error = a->d[a->in_idx] - y;
+        buf[2 * i + 0] = is_anr ? y : error;
+        buf[2 * i + 1] = 0.0;
+        if ((nel = error * (1.0 - a->two_mu * sigma * inv_sigp)) < 0.0) nel = -nel;
+        if ((nev = a->d[a->in_idx] - (1.0 - a->two_mu * a->ngamma) * y - a->two_mu * error * sigma * inv_sigp) < 0.0) nev = -nev;
+        if (nev < nel) { if ((a->lidx += a->lincr) > a->lidx_max) a->lidx = a->lidx_max; }
+        else { if ((a->lidx -= a->ldecr) < a->lidx_min) a->lidx = a->lidx_min; }
+        a->ngamma = a->gamma * (a->lidx * a->lidx) * (a->lidx * a->lidx) * a->den_mult;
+        c0 = 1.0 - a->two_mu * a->ngamma;
+        c1 = a->two_mu * error * inv_sigp;
+        for (j = 0; j < a->n_taps; j++) {
+            idx = (a->in_idx + j + a->delay) & a->mask;
+            a->w[j] = c0 * a->w[j] + c1 * a->d[idx];
+        }
+        a->in_idx = (a->in_idx + a->mask) & a->mask;
+    }
+}
+
+static void lms_flush(struct wo_lms *a)          /* flush_anf, anf.c:135-140 */
+{
+    memset(a->d, 0, sizeof(a->d));
+    memset(a->w, 0, sizeof(a->w));
+    a->in_idx = 0;
+}
+
+/* ---- RXAbp1Check / RXAbp1Set (RXA.c:800-827) */
+static void bp1_check(wo_channel *c, int amd_run, int anf_run, int anr_run)
+{
+    double gain = (amd_run || anf_run || anr_run) ? 2.0 : 1.0;      /* snba / emnr never run on this path */
     if (c->bp1.gain != gain) {
         double *imp;
         c->bp1.gain = gain;
@@ -924,7 +971,7 @@ static void bp1_check(wo_channel *c, int amd_run)
 static void bp1_set(wo_channel *c)
 {
     int old = c->bp1.run;
-    c->bp1.run = (c->amd.run == 1) ? 1 : 0;
+    c->bp1.run = (c->amd.run == 1 || c->anf.run == 1 || c->anr.run == 1) ? 1 : 0;
     if (!old && c->bp1.run) fircore_flush(c->bp1.p);
 }
 
@@ -940,8 +987,13 @@ static void xrxa(wo_channel *c)
     meter_exec(&c->smeter, c->midbuff, n, c->meter, NULL);
     xamd(c, c->midbuff, n);
     xfmd(c, c->midbuff, n);
-    if (c->bp1.run) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);     /* position 0 */
+    xlms(&c->anf, 0, 0, c->midbuff, n);
+    xlms(&c->anr, 1, 0, c->midbuff, n);
+    if (c->bp1.run && c->bp1.position == 0) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);
     xwcpagc(c, c->midbuff, n);
+    xlms(&c->anf, 0, 1, c->midbuff, n);
+    xlms(&c->anr, 1, 1, c->midbuff, n);
+    if (c->bp1.run && c->bp1.position == 1) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);
     meter_exec(&c->agcmeter, c->midbuff, n, c->meter, &c->agc.gain);
     xpanel(c, c->midbuff, n);
     if (c->rsmpout->run) wo_resample_exec(c->rsmpout, c->midbuff, n, c->outbuff);
@@ -1140,7 +1192,14 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     free(imp);
     /* create_wcpagc arguments of create_rxa, RXA.c:335-358 */
     wo_agc_init(&c->agc, 1, 3, 1, dsp_rate, 0.001, 0.250, 4, 10000.0, 1.5, 1000.0, 1.0, 1.0, 0.250, 0.005, 5.0, 1, 0.500, 0.250, 0.250, 0.100);
-    c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0;
+    c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0; c->bp1.position = 0;
+    {   /* create_anf / create_anr arguments of create_rxa, RXA.c:278-315 */
+        struct wo_lms *a = &c->anf;
+        a->mask = 2047; a->n_taps = 64; a->delay = 16; a->two_mu = 0.0001; a->gamma = 0.1;
+        a->lidx = 1.0; a->lidx_min = 0.0; a->lidx_max = 200.0; a->ngamma = 6.25e-12; a->den_mult = 6.25e-10; a->lincr = 1.0; a->ldecr = 3.0;
+        c->anr = c->anf;
+        c->anr.lidx = 120.0; c->anr.lidx_min = 120.0; c->anr.ngamma = 0.001;
+    }
     c->bp1.f_low = -4150.0; c->bp1.f_high = -150.0;
     imp = bp1_impulse(c);
     c->bp1.p = wo_fircore_create(dsp_size, nc, imp);
@@ -1168,7 +1227,7 @@ void wo_SetRXAMode(wo_channel *c, int mode)     /* RXA.c:748-787 */
 {
     if (c->mode != mode) {
         int amd_run = (mode == WO_AM) || (mode == WO_SAM);
-        bp1_check(c, amd_run);
+        bp1_check(c, amd_run, c->anf.run, c->anr.run);
         c->mode = mode;
         c->amd.run = 0;
         c->fmd.run = 0;
@@ -1333,11 +1392,37 @@ void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode) { c->amd.sbmode = sbmode; }
 void wo_SetRXAAMDRun(wo_channel *c, int run)        /* amd.c:264-277 */
 {
     if (c->amd.run != run) {
-        bp1_check(c, run);
+        bp1_check(c, run, c->anf.run, c->anr.run);
         c->amd.run = run;
         bp1_set(c);
     }
 }
+/* SetRXAANFRun ... SetRXAANFPosition (anf.c:175-239) and the ANR twins (anr.c:175-238) */
+void wo_SetRXAANFRun(wo_channel *c, int run)
+{
+    if (c->anf.run != run) {
+        bp1_check(c, c->amd.run, run, c->anr.run);
+        c->anf.run = run;
+        bp1_set(c);
+        lms_flush(&c->anf);
+    }
+}
+void wo_SetRXAANRRun(wo_channel *c, int run)
+{
+    if (c->anr.run != run) {
+        bp1_check(c, c->amd.run, c->anf.run, run);
+        c->anr.run = run;
+        bp1_set(c);
+        lms_flush(&c->anr);
+    }
+}
+void wo_SetRXAANFVals(wo_channel *c, int taps, int delay, double gain, double leakage)
+{ c->anf.n_taps = taps; c->anf.delay = delay; c->anf.two_mu = gain; c->anf.gamma = leakage; lms_flush(&c->anf); }
+void wo_SetRXAANRVals(wo_channel *c, int taps, int delay, double gain, double leakage)
+{ c->anr.n_taps = taps; c->anr.delay = delay; c->anr.two_mu = gain; c->anr.gamma = leakage; lms_flush(&c->anr); }
+void wo_SetRXAANFPosition(wo_channel *c, int position) { c->anf.position = position; c->bp1.position = position; lms_flush(&c->anf); }
+void wo_SetRXAANRPosition(wo_channel *c, int position) { c->anr.position = position; c->bp1.position = position; lms_flush(&c->anr); }
+
 void wo_SetRXAAMDFadeLevel(wo_channel *c, int levelfade) { c->amd.levelfade = levelfade; }
 
 void wo_SetRXAFMDeviation(wo_channel *c, double deviation)

@@ -74,6 +74,12 @@ void wo_SetRXAPanelSelect(wo_channel *c, int select);
 void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
+void wo_SetRXAANFRun(wo_channel *c, int run);                   /* anf.c:175-189 */
+void wo_SetRXAANFVals(wo_channel *c, int taps, int delay, double gain, double leakage);     /* anf.c:191-201 */
+void wo_SetRXAANFPosition(wo_channel *c, int position);         /* anf.c:231-239 */
+void wo_SetRXAANRRun(wo_channel *c, int run);                   /* anr.c:175-189 */
+void wo_SetRXAANRVals(wo_channel *c, int taps, int delay, double gain, double leakage);     /* anr.c:191-201 */
+void wo_SetRXAANRPosition(wo_channel *c, int position);         /* anr.c:231-238 */
 void wo_RXASetMP(wo_channel *c, int mp);                        /* RXA.c:948-958 */
 void wo_SetRXAFMLimRun(wo_channel *c, int run);                 /* fmd.c:336-347 */
 void wo_SetRXAFMLimGain(wo_channel *c, double gaindB);          /* fmd.c:349-362 */

@@ -430,4 +430,79 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
     }
 }
 
+// xanf (wdsp/anf.c:82-133) / xanr (wdsp/anr.c:82-133): leaky normalised-LMS line enhancer on the real part, up to 64 taps.
+// The recurrence is sequential in time (the weight update needs the error of the full dot product), so one wavefront
+// per channel with one tap per lane: lane j keeps w[j] and x[n - delay - j]; per sample the window moves one lane up
+// (DPP wave_shr:1, lane 0 takes x[n - delay]), w.x and x.x are reduced across the wave (wave_sum_d), the step-size
+// logic runs uniformly in every lane in the reference's operation order, and the weights update in place.  Lane i of
+// a 64-sample batch keeps output i for one coalesced store.  State: the weights, the last 128 inputs, lidx, ngamma.
+struct LmsParam { int taps, delay, is_anr, pad; double two_mu, gamma, lidx_min, lidx_max, den_mult, lincr, ldecr, pre_gain; };
+struct LmsState { double w[64]; double hist[128]; double lidx, ngamma; };
+
+static __global__ __launch_bounds__(64) void lms_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                        const LmsParam *prm, LmsState *state)
+{
+#pragma clang fp contract(off)
+    __shared__ double s[192];
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
+    const LmsParam q = prm[ch];
+    LmsState *sp = state + ch;
+    double2 *p = buf + (long long)ch * stride;
+    const bool tap = lane < q.taps;
+    double w = tap ? sp->w[lane] : 0.0;
+    double h0 = sp->hist[lane], h1 = sp->hist[64 + lane];            // the 128 samples before this call, oldest first
+    double lidx = sp->lidx, ngamma = sp->ngamma;
+    // window before the first sample: x[-1 - delay - lane]
+    s[lane] = h0; s[64 + lane] = h1;
+    __syncthreads();
+    double xw = s[127 - q.delay - lane >= 0 ? 127 - q.delay - lane : 0];
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        const double xin = lane < cnt ? p[base + lane].x * q.pre_gain : 0.0;      // pre_gain: a fixed AGC gain ahead of a position-1 filter
+        // x[base + lane - delay] from the previous 64 samples and this batch
+        s[lane] = h1; s[64 + lane] = xin;
+        __syncthreads();
+        const double xdel = s[64 + lane - q.delay];
+        __syncthreads();
+        double myout = 0.0;
+        // sigma = sum of the window's squares: summed afresh once per batch, then moved along with the window (one sample
+        // in, one out); what the running form drifts by in 64 steps is ~1e-16 of sigma, against the 1e-10 added to it
+        double sigma = wave_sum_d(tap ? xw * xw : 0.0);
+        for (int i = 0; i < cnt; i++) {
+            const double xn = lane_bcast(xin, i), xd = lane_bcast(xdel, i);
+            const double xold = lane_bcast(xw, q.taps - 1);
+            xw = wave_shr1(xw);
+            if (lane == 0) xw = xd;
+            sigma = (sigma - xold * xold) + xd * xd;
+            // 1 / (sigma + 1e-10): v_rcp_f64 and two Newton steps (the weights' dependency chain waits for nothing else)
+            const double den = sigma + 1e-10;
+            double inv_sigp = __builtin_amdgcn_rcp(den);
+            inv_sigp = __builtin_fma(__builtin_fma(-den, inv_sigp, 1.0), inv_sigp, inv_sigp);
+            inv_sigp = __builtin_fma(__builtin_fma(-den, inv_sigp, 1.0), inv_sigp, inv_sigp);
+            const double y = wave_sum_d(w * xw);
+            const double error = xn - y;
+            if (lane == i) myout = q.is_anr ? y : error;
+            double nel = error * (1.0 - q.two_mu * sigma * inv_sigp);
+            if (nel < 0.0) nel = -nel;
+            double nev = xn - (1.0 - q.two_mu * ngamma) * y - q.two_mu * error * sigma * inv_sigp;
+            if (nev < 0.0) nev = -nev;
+            if (nev < nel) { lidx += q.lincr; if (lidx > q.lidx_max) lidx = q.lidx_max; }
+            else { lidx -= q.ldecr; if (lidx < q.lidx_min) lidx = q.lidx_min; }
+            ngamma = q.gamma * (lidx * lidx) * (lidx * lidx) * q.den_mult;
+            const double c0 = 1.0 - q.two_mu * ngamma, c1 = q.two_mu * error * inv_sigp;
+            if (tap) w = c0 * w + c1 * xw;
+        }
+        if (lane < cnt) p[base + lane] = make_double2(myout, 0.0);
+        // history moves on by cnt samples
+        s[lane] = h0; s[64 + lane] = h1; s[128 + lane] = xin;
+        __syncthreads();
+        h0 = s[lane + cnt]; h1 = s[64 + lane + cnt];
+        __syncthreads();
+    }
+    if (tap) sp->w[lane] = w;
+    sp->hist[lane] = h0; sp->hist[64 + lane] = h1;
+    if (lane == 0) { sp->lidx = lidx; sp->ngamma = ngamma; }
+}
+
 }  // namespace qh

@@ -69,6 +69,9 @@ struct ChanCfg {
     double fm_dev = 5000.0, ctcss_freq = 254.1;                 // RXA.c:198,208
     int ctcss_run = 1, fm_nc = 2048;                            // RXA.c:207,209-212
     int lim_run = 0; double lim_gain = 2.5; bool lim_dirty = true;   // FM detector limiter, fmd.c:106-108
+    // anf / anr (create_anf / create_anr of create_rxa, RXA.c:278-315): [0] = anf, [1] = anr
+    struct Lms { int run = 0, position = 0, taps = 64, delay = 16; double two_mu = 0.0001, gamma = 0.1; bool dirty = true, flush = false; } lms[2];
+    int bp1_pos = 0;                                            // SetRXAANFPosition / SetRXAANRPosition set it too (anf.c:236)
     bool demod_dirty = true, ctcss_flush = false;
     bool nbp_dirty = true, bp1_dirty = true, nco_dirty = true, epi_dirty = true;
     bool nbp_flush = false, bp1_flush = false;
@@ -119,6 +122,11 @@ struct Engine {
     bool demod_alloc = false, lists_dirty = true;
     int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
     int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0;
+    // anf / anr: lists per (filter, position), parameters and state per filter; bp1 lists per position
+    int *list_lms[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } }, n_lms[2][2] = { { 0, 0 }, { 0, 0 } };
+    int *list_bp1p[2] = { nullptr, nullptr }, n_bp1p[2] = { 0, 0 };
+    LmsParam *lms_prm[2] = { nullptr, nullptr };
+    LmsState *lms_state[2] = { nullptr, nullptr };
     int *levelfade = nullptr;
     AmState *am_state = nullptr;
     AmParam am_prm{};
@@ -177,6 +185,7 @@ Engine::~Engine()
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
+    (void)hipFree(lms_prm[0]); (void)hipFree(lms_prm[1]); (void)hipFree(lms_state[0]); (void)hipFree(lms_state[1]);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -297,7 +306,10 @@ int Engine::refresh_params()
         }
         if (c.epi_dirty) {
             // xwcpagc mode 0 (wcpAGC.c:167-175) then xpanel (patchpanel.c:55-101) as one 2x2 real matrix
-            const double g = (c.agc_run && c.agc_mode == 0) ? c.agc_fixed : 1.0;
+            // (a position-1 anf / anr sits between the fixed gain and the panel and is not scale-free: there the gain is
+            // applied by the LMS kernel on its input instead)
+            const bool lms_after_agc = (c.lms[0].run && c.lms[0].position) || (c.lms[1].run && c.lms[1].position);
+            const double g = (c.agc_run && c.agc_mode == 0 && !lms_after_agc) ? c.agc_fixed : 1.0;
             const double gI = c.gain1 * c.gain2I, gQ = c.gain1 * c.gain2Q;
             const double sI = (double)(c.inselect >> 1), sQ = (double)(c.inselect & 1);
             EpiParam e;
@@ -382,7 +394,9 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 7));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 13));
+        for (int f = 0; f < 2; f++) for (int ps = 0; ps < 2; ps++) list_lms[f][ps] = list_buf + (7 + 2 * f + ps) * nch;
+        list_bp1p[0] = list_buf + 11 * nch; list_bp1p[1] = list_buf + 12 * nch;
         list_am = list_buf; list_sam = list_buf + nch; list_fm = list_buf + 2 * nch; list_bp1 = list_buf + 3 * nch;
         list_plain = list_buf + 4 * nch; list_agc_cur = list_buf + 5 * nch; list_agc_other = list_buf + 6 * nch;
         {   // create_meter x3 (RXA.c:69-82,142-155,361-374): tau 0.1 s for average and peak decay; flush_meter -> -400 dB
@@ -451,15 +465,35 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][2], lbp[2];
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
+            for (int f = 0; f < 2; f++) if (c.lms[f].run) lms_l[f][c.lms[f].position ? 1 : 0].push_back(ch);
+            if (c.bp1_run) lbp[c.bp1_pos ? 1 : 0].push_back(ch);
             if (c.fmd_run && c.lim_run) ll.push_back(ch);
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
             if (c.amd_run && c.amd_mode == 1) ls.push_back(ch);
             if (c.fmd_run) lf.push_back(ch);
             if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
-            if (c.agc_run && c.agc_mode != 0) (c.bp1_run ? lgo : lgc).push_back(ch);
+            // xwcpagc sits between the two bp1 positions (RXA.c:581-586): a position-1 channel is still in `cur` there
+            if (c.agc_run && c.agc_mode != 0) (c.bp1_run && !c.bp1_pos ? lgo : lgc).push_back(ch);
+        }
+        bool any_lms = false;
+        for (int f = 0; f < 2; f++) for (int ps = 0; ps < 2; ps++) { n_lms[f][ps] = (int)lms_l[f][ps].size(); any_lms = any_lms || n_lms[f][ps]; }
+        n_bp1p[0] = (int)lbp[0].size(); n_bp1p[1] = (int)lbp[1].size();
+        if (any_lms && !lms_prm[0]) {
+            for (int f = 0; f < 2; f++) {
+                QH_HIP(dev_alloc(&lms_prm[f], (size_t)nch));
+                QH_HIP(dev_alloc(&lms_state[f], (size_t)nch));
+                // create_anf: lidx 1.0, ngamma 6.25e-12; create_anr: lidx 120.0, ngamma 0.001 (RXA.c:289-292,309-312)
+                std::vector<LmsState> init((size_t)nch);
+                std::memset(init.data(), 0, init.size() * sizeof(LmsState));
+                for (LmsState &st : init) { st.lidx = f ? 120.0 : 1.0; st.ngamma = f ? 0.001 : 6.25e-12; }
+                QH_HIP(hipMemcpyAsync(lms_state[f], init.data(), init.size() * sizeof(LmsState), hipMemcpyHostToDevice, stream));
+                QH_HIP(hipStreamSynchronize(stream));
+                dev_bytes += (long long)nch * (sizeof(LmsParam) + sizeof(LmsState));
+            }
+            for (ChanCfg &c : cfg) { c.lms[0].dirty = c.lms[1].dirty = true; c.lms[0].flush = c.lms[1].flush = false; }
         }
         n_am = (int)la.size(); n_sam = (int)ls.size(); n_fm = (int)lf.size(); n_bp1 = (int)lb.size(); n_plain = (int)lp.size();
         n_agc_cur = (int)lgc.size(); n_agc_other = (int)lgo.size();
@@ -479,6 +513,8 @@ int Engine::refresh_demod()
         };
         QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
         QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo));
+        for (int f = 0; f < 2; f++) for (int ps = 0; ps < 2; ps++) QH_HIP(put(list_lms[f][ps], lms_l[f][ps]));
+        QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
         QH_HIP(hipStreamSynchronize(stream));
         lists_dirty = false;
     }
@@ -522,6 +558,24 @@ int Engine::refresh_demod()
             QH_HIP(hipMemcpyAsync(agc_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.agc_dirty = false;
+        }
+        for (int f = 0; f < 2 && lms_prm[0]; f++) {
+            ChanCfg::Lms &m = c.lms[f];
+            if (m.dirty) {
+                if (m.run && (m.taps < 1 || m.taps > 64 || m.delay < 1 || m.delay > 64))
+                    return set_error(QH_ERR_UNSUPPORTED, "%s: taps %d / delay %d (1..64 each: one tap per lane)", f ? "ANR" : "ANF", m.taps, m.delay);
+                // lidx_min, lidx_max, den_mult, lincr, ldecr of create_rxa (RXA.c:290-295,310-315)
+                const bool first_after_agc = m.position && !(f == 1 && c.lms[0].run && c.lms[0].position);
+                const double pre = (first_after_agc && c.agc_run && c.agc_mode == 0) ? c.agc_fixed : 1.0;
+                const LmsParam q{ m.taps, m.delay, f, 0, m.two_mu, m.gamma, f ? 120.0 : 0.0, 200.0, 6.25e-10, 1.0, 3.0, pre };
+                QH_HIP(hipMemcpyAsync(lms_prm[f] + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
+                QH_HIP(hipStreamSynchronize(stream));
+                m.dirty = false;
+            }
+            if (m.flush) {          // flush_anf (anf.c:135-140): delay line and weights; lidx / ngamma carry on
+                QH_HIP(hipMemsetAsync(lms_state[f] + ch, 0, offsetof(LmsState, lidx), stream));
+                m.flush = false;
+            }
         }
         if (c.lim_dirty && lim_prm) {
             // calc_fmd's create_wcpagc(1, 5, 1, ..., 0.001, 0.008, 4, lim_gain, 1.0, 1.0, 1.0, 0.9, 0.250, 0.004, 4.0, 0,
@@ -756,7 +810,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
-        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || meters_on) mixed = true;
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || meters_on) mixed = true;
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
@@ -836,13 +890,24 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
                                lim_state, 0.4);
     }
-    if (n_bp1) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, cur_bp1, P, list_bp1, n_bp1);
+    // xanf, xanr, xbandpass(bp1) at position 0, xwcpagc, then the same three at position 1 (RXA.c:579-586).  The two bp1
+    // launches work on disjoint channel rows of one ping-pong history pair, so the pair flips once for both.
+    auto lms_bp1 = [&](int ps) {
+        for (int f = 0; f < 2; f++)
+            if (n_lms[f][ps]) hipLaunchKernelGGL(lms_kernel, dim3((unsigned)n_lms[f][ps]), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+                                                 list_lms[f][ps], lms_prm[f], lms_state[f]);
+        int hc = cur_bp1;
+        if (n_bp1p[ps]) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
+    };
+    lms_bp1(0);
     // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below
     tick(1);
     if (n_agc_cur) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                       list_agc_cur, agc_prm, agc_state);
     if (n_agc_other) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
                                         list_agc_other, agc_prm, agc_state);
+    lms_bp1(1);
+    if (n_bp1) cur_bp1 ^= 1;
     if (meters_on) {    // agcmeter sits after xwcpagc (RXA.c:589); mode 0's gain multiply is applied below, so its
                         // level reading is taken on the fixed-gain input and corrected in qh_rxa_GetRXAMeter
         if (n_plain) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)n_plain), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size,
@@ -927,15 +992,15 @@ long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
     } while (0)
 
 // RXAbp1Check + RXAbp1Set, wdsp/RXA.c:800-827 (snba/emnr/anf/anr never run here)
-static void bp1_check_set(ChanCfg &c, int amd_run)
+static void bp1_check_set(ChanCfg &c, int amd_run, int anf_run, int anr_run)
 {
-    const double gain = amd_run ? 2.0 : 1.0;
+    const double gain = (amd_run || anf_run || anr_run) ? 2.0 : 1.0;
     if (c.bp1_gain != gain) { c.bp1_gain = gain; c.bp1_dirty = true; }
 }
 static void bp1_set(ChanCfg &c)
 {
     const int old = c.bp1_run;
-    c.bp1_run = c.amd_run ? 1 : 0;
+    c.bp1_run = (c.amd_run || c.lms[0].run || c.lms[1].run) ? 1 : 0;
     if (old != c.bp1_run) c.bp1_dirty = true;
     if (!old && c.bp1_run) c.bp1_flush = true;
 }
@@ -945,7 +1010,7 @@ int qh_rxa_SetRXAMode(qh_rxa *h, int ch, int mode)
     FOR_CH(h, ch, {
         if (c.mode != mode) {       // wdsp/RXA.c:748-787
             const int amd_run = (mode == QH_AM) || (mode == QH_SAM);
-            bp1_check_set(c, amd_run);
+            bp1_check_set(c, amd_run, c.lms[0].run, c.lms[1].run);
             c.mode = mode;
             c.amd_run = 0; c.fmd_run = 0; c.agc_run = 1;
             if (mode == QH_AM) { c.amd_run = 1; c.amd_mode = 0; }
@@ -964,7 +1029,7 @@ int qh_rxa_SetRXAAMDRun(qh_rxa *h, int ch, int run)
     FOR_CH(h, ch, {
         run = run ? 1 : 0;
         if (c.amd_run != run) {
-            bp1_check_set(c, run);
+            bp1_check_set(c, run, c.lms[0].run, c.lms[1].run);
             c.amd_run = run;
             bp1_set(c);
             c.epi_dirty = true;
@@ -1114,6 +1179,58 @@ int qh_rxa_SetRXAFMLimGain(qh_rxa *h, int ch, double gaindB)
     FOR_CH(h, ch, { if (c.lim_gain != gain) { c.lim_gain = gain; c.lim_dirty = true; } });
 }
 
+// SetRXAANFRun ... SetRXAANFPosition (wdsp/anf.c:175-239) and the ANR twins (wdsp/anr.c:175-238); which = 0 anf, 1 anr
+static int lms_run(qh_rxa *h, int ch, int which, int run)
+{
+    FOR_CH(h, ch, {
+        run = run ? 1 : 0;
+        ChanCfg::Lms &m = c.lms[which];
+        if (m.run != run) {
+            bp1_check_set(c, c.amd_run, which == 0 ? run : c.lms[0].run, which == 1 ? run : c.lms[1].run);
+            m.run = run;
+            bp1_set(c);
+            m.flush = true;
+            c.lms[0].dirty = c.lms[1].dirty = true; c.epi_dirty = true;
+            h->e.lists_dirty = true;
+        }
+    });
+}
+static int lms_vals(qh_rxa *h, int ch, int which, const int *taps, const int *delay, const double *gain, const double *leakage)
+{
+    FOR_CH(h, ch, {
+        ChanCfg::Lms &m = c.lms[which];
+        if (taps) m.taps = *taps;
+        if (delay) m.delay = *delay;
+        if (gain) m.two_mu = *gain;
+        if (leakage) m.gamma = *leakage;
+        m.flush = true; m.dirty = true;
+    });
+}
+static int lms_position(qh_rxa *h, int ch, int which, int position)
+{
+    FOR_CH(h, ch, {
+        c.lms[which].position = position ? 1 : 0;
+        c.bp1_pos = position ? 1 : 0;                 // "rxa[channel].bp1.p->position = position", anf.c:236
+        c.lms[which].flush = true;
+        c.lms[0].dirty = c.lms[1].dirty = true; c.epi_dirty = true;
+        h->e.lists_dirty = true;
+    });
+}
+int qh_rxa_SetRXAANFRun(qh_rxa *h, int ch, int run) { return lms_run(h, ch, 0, run); }
+int qh_rxa_SetRXAANRRun(qh_rxa *h, int ch, int run) { return lms_run(h, ch, 1, run); }
+int qh_rxa_SetRXAANFVals(qh_rxa *h, int ch, int taps, int delay, double gain, double leakage) { return lms_vals(h, ch, 0, &taps, &delay, &gain, &leakage); }
+int qh_rxa_SetRXAANRVals(qh_rxa *h, int ch, int taps, int delay, double gain, double leakage) { return lms_vals(h, ch, 1, &taps, &delay, &gain, &leakage); }
+int qh_rxa_SetRXAANFTaps(qh_rxa *h, int ch, int taps) { return lms_vals(h, ch, 0, &taps, nullptr, nullptr, nullptr); }
+int qh_rxa_SetRXAANRTaps(qh_rxa *h, int ch, int taps) { return lms_vals(h, ch, 1, &taps, nullptr, nullptr, nullptr); }
+int qh_rxa_SetRXAANFDelay(qh_rxa *h, int ch, int delay) { return lms_vals(h, ch, 0, nullptr, &delay, nullptr, nullptr); }
+int qh_rxa_SetRXAANRDelay(qh_rxa *h, int ch, int delay) { return lms_vals(h, ch, 1, nullptr, &delay, nullptr, nullptr); }
+int qh_rxa_SetRXAANFGain(qh_rxa *h, int ch, double gain) { return lms_vals(h, ch, 0, nullptr, nullptr, &gain, nullptr); }
+int qh_rxa_SetRXAANRGain(qh_rxa *h, int ch, double gain) { return lms_vals(h, ch, 1, nullptr, nullptr, &gain, nullptr); }
+int qh_rxa_SetRXAANFLeakage(qh_rxa *h, int ch, double leakage) { return lms_vals(h, ch, 0, nullptr, nullptr, nullptr, &leakage); }
+int qh_rxa_SetRXAANRLeakage(qh_rxa *h, int ch, double leakage) { return lms_vals(h, ch, 1, nullptr, nullptr, nullptr, &leakage); }
+int qh_rxa_SetRXAANFPosition(qh_rxa *h, int ch, int position) { return lms_position(h, ch, 0, position); }
+int qh_rxa_SetRXAANRPosition(qh_rxa *h, int ch, int position) { return lms_position(h, ch, 1, position); }
+
 int qh_rxa_SetRXAAGCMode(qh_rxa *h, int ch, int mode)
 {
     FOR_CH(h, ch, {                 // wdsp/wcpAGC.c:369-411
@@ -1125,7 +1242,7 @@ int qh_rxa_SetRXAAGCMode(qh_rxa *h, int ch, int mode)
         case 4: c.agc_mode = 4; c.agc_hang_thresh = 1.0; c.agc_hangtime = 0.000; c.agc_tau_decay = 0.050; break;
         default: c.agc_mode = 5; break;
         }
-        c.epi_dirty = true; c.agc_dirty = true; h->e.lists_dirty = true;
+        c.epi_dirty = true; c.agc_dirty = true; c.lms[0].dirty = c.lms[1].dirty = true; h->e.lists_dirty = true;
     });
 }
 int qh_rxa_SetRXAAGCAttack(qh_rxa *h, int ch, int attack_ms) { FOR_CH(h, ch, { c.agc_tau_attack = (double)attack_ms / 1000.0; c.agc_dirty = true; }); }
@@ -1137,7 +1254,7 @@ int qh_rxa_SetRXAAGCHangThreshold(qh_rxa *h, int ch, int t) { FOR_CH(h, ch, { c.
 
 int qh_rxa_SetRXAAGCFixed(qh_rxa *h, int ch, double db)
 {
-    FOR_CH(h, ch, { c.agc_fixed = std::pow(10.0, db / 20.0); c.epi_dirty = true; });
+    FOR_CH(h, ch, { c.agc_fixed = std::pow(10.0, db / 20.0); c.epi_dirty = true; c.lms[0].dirty = c.lms[1].dirty = true; });
 }
 
 int qh_rxa_SetRXAPanelGain1(qh_rxa *h, int ch, double g) { FOR_CH(h, ch, { c.gain1 = g; c.epi_dirty = true; }); }
@@ -1252,6 +1369,7 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
         }
     }
+    for (ChanCfg &c : e.cfg) c.lms[0].flush = c.lms[1].flush = true;        // flush_anf / flush_anr, RXA.c:541-542
     if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch
         QH_HIP(hipMemsetAsync(e.am_state, 0, (size_t)e.nch * sizeof(AmState), e.stream));
         QH_HIP(hipMemsetAsync(e.pll_state, 0, (size_t)e.nch * sizeof(PllState), e.stream));

@@ -36,6 +36,34 @@ __device__ __forceinline__ double lane_bcast(double v, int i)
     return __hiloint2double(hi, lo);
 }
 
+// Lane i takes lane i - 1's value (lane 0: 0): one DPP move per half, no LDS crossbar.
+__device__ __forceinline__ double wave_shr1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);       // wave_shr:1, bound_ctrl: lane 0 reads 0
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL> __device__ __forceinline__ double row_shr_add(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);        // bound_ctrl: lanes shifted in from outside the row read 0
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes, the same value in every lane: inclusive scan inside each row of 16 by DPP shifts, then the
+// four row totals by v_readlane.
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v = row_shr_add<0x111>(v);      // row_shr:1
+    v = row_shr_add<0x112>(v);      // row_shr:2
+    v = row_shr_add<0x114>(v);      // row_shr:4
+    v = row_shr_add<0x118>(v);      // row_shr:8
+    return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
+}
+
 __device__ __forceinline__ double scan_pole(double u, double m, int lane)
 {
     double md = m;

@@ -410,6 +410,21 @@ void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMo
 void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
 void SetRXAFMLimRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAFMLimRun(L.c->eng, 0, run)); }
 void SetRXAFMLimGain(int channel, double gaindB) { WDSP_SETTER(qh_rxa_SetRXAFMLimGain(L.c->eng, 0, gaindB)); }
+// the LMS auto-notch / noise reduction, wdsp/anf.c:175-239, anr.c:175-238
+void SetRXAANFRun(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANFRun(L.c->eng, 0, v)); }
+void SetRXAANFTaps(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANFTaps(L.c->eng, 0, v)); }
+void SetRXAANFDelay(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANFDelay(L.c->eng, 0, v)); }
+void SetRXAANFPosition(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANFPosition(L.c->eng, 0, v)); }
+void SetRXAANFGain(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAANFGain(L.c->eng, 0, v)); }
+void SetRXAANFLeakage(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAANFLeakage(L.c->eng, 0, v)); }
+void SetRXAANFVals(int channel, int taps, int delay, double gain, double leakage) { WDSP_SETTER(qh_rxa_SetRXAANFVals(L.c->eng, 0, taps, delay, gain, leakage)); }
+void SetRXAANRRun(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANRRun(L.c->eng, 0, v)); }
+void SetRXAANRTaps(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANRTaps(L.c->eng, 0, v)); }
+void SetRXAANRDelay(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANRDelay(L.c->eng, 0, v)); }
+void SetRXAANRPosition(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANRPosition(L.c->eng, 0, v)); }
+void SetRXAANRGain(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAANRGain(L.c->eng, 0, v)); }
+void SetRXAANRLeakage(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAANRLeakage(L.c->eng, 0, v)); }
+void SetRXAANRVals(int channel, int taps, int delay, double gain, double leakage) { WDSP_SETTER(qh_rxa_SetRXAANRVals(L.c->eng, 0, taps, delay, gain, leakage)); }
 
 // the notch database, wdsp/nbp.c:358-525: int results are the reference's (0 / -1)
 int RXANBPAddNotch(int channel, int notch, double fcenter, double fwidth, int active)

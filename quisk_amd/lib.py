@@ -38,7 +38,9 @@ def load():
     for n in ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXABandpassRun", "SetRXAAGCMode",
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
-              "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease"):
+              "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease",
+              "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay",
+              "SetRXAANRPosition"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
         f.restype = i
@@ -49,7 +51,8 @@ def load():
     L.qh_rxa_RXANBPGetNumNotches.argtypes = [vp, i, C.POINTER(i)]
     L.qh_rxa_RXANBPGetMinNotchWidth.argtypes = [vp, i, C.POINTER(d)]
     for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop",
-              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain"):
+              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAANFGain", "SetRXAANFLeakage",
+              "SetRXAANRGain", "SetRXAANRLeakage"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]
         f.restype = i
@@ -57,6 +60,8 @@ def load():
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d, d]
         f.restype = i
+    for n in ("SetRXAANFVals", "SetRXAANRVals"):
+        getattr(L, "qh_rxa_" + n).argtypes = [vp, i, i, i, d, d]
     L.qh_rxa_process.argtypes = [vp, vp, ll, vp, ll, i]
     L.qh_rxa_process.restype = i
     L.qh_rxa_process_host.argtypes = [vp, vp, ll, vp, ll, i]

@@ -16,7 +16,9 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "SetRXAAMDFadeLevel", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXACTCSSRun", "SetRXAAGCAttack",
             "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold", "RXASetMP",
             "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease", "RXANBPSetTuneFrequency",
-            "RXANBPSetShiftFrequency", "SetRXAFMLimRun", "SetRXAFMLimGain")
+            "RXANBPSetShiftFrequency", "SetRXAFMLimRun", "SetRXAFMLimGain",
+            "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANFGain", "SetRXAANFLeakage", "SetRXAANFVals",
+            "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay", "SetRXAANRPosition", "SetRXAANRGain", "SetRXAANRLeakage", "SetRXAANRVals")
 
 
 class RxaEngine:

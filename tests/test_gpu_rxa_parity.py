@@ -300,3 +300,46 @@ def test_input_rate_768k(qh, oracle):
         ref = ch.xrxa(x[c])
         assert np.abs(ref).max() > 0.1
         assert rel_rms(y[c], ref) < TOL, (c, rel_rms(y[c], ref))
+
+
+@pytest.mark.parametrize("which,position,mode", [("ANF", 0, 1), ("ANR", 0, 1), ("ANF", 1, 1), ("ANR", 1, 0), ("BOTH", 0, 6), ("BOTH", 1, 1)])
+def test_lms_notch_and_noise_reduction(qh, oracle, which, position, mode):
+    """xanf / xanr (wdsp/anf.c:82-133, anr.c:82-133) in both chain positions, with bp1 (gain 2) following them.  The LMS sums
+    its 64 taps in a different order than the reference's loop and its step-size logic compares nearly equal numbers,
+    so the gate is the fp64 tolerance 1e-6 of the chain, not bit-exactness."""
+    nch, nblk = 3, 60
+    x = synth.make_input_numpy(nch, nblk * 1024)
+    e = qh.RxaEngine(nch)
+    refs = []
+    for ch in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        for t in (e, o):
+            args = (ch,) if t is e else ()
+            t.SetRXAShiftRun(*args, 1); t.SetRXAShiftFreq(*args, synth.shift_freq(ch)); t.RXANBPSetRun(*args, 1)
+            t.SetRXAMode(*args, mode)
+            t.RXASetPassband(*args, *((-3000.0, -300.0) if mode == 0 else (300.0, 3000.0) if mode == 1 else (-4000.0, 4000.0)))
+            # channel 0: fixed gain (the position-1 filters must see it applied), channel 1: AGC fast, channel 2: AGC off-ish long
+            t.SetRXAAGCMode(*args, (0, 4, 1)[ch])
+            if ch == 0:
+                t.SetRXAAGCFixed(*args, 12.0)
+            if which in ("ANF", "BOTH"):
+                t.SetRXAANFPosition(*args, position); t.SetRXAANFRun(*args, 1)
+            if which in ("ANR", "BOTH"):
+                t.SetRXAANRPosition(*args, position); t.SetRXAANRVals(*args, 48, 20, 2e-4, 0.05); t.SetRXAANRRun(*args, 1)
+        refs.append(o)
+    y = e.process_host(x)
+    ref = np.stack([o.xrxa(x[ch]) for ch, o in enumerate(refs)])
+    assert np.abs(ref).max() > 1e-3
+    for ch in range(nch):
+        assert rel_rms(y[ch], ref[ch]) < 1e-6
+    # switching the filter off and on again flushes its delay line and weights but keeps the step-size state
+    for ch in range(nch):
+        for t, args in ((e, (ch,)), (refs[ch], ())):
+            if which in ("ANF", "BOTH"):
+                t.SetRXAANFRun(*args, 0); t.SetRXAANFRun(*args, 1)
+            else:
+                t.SetRXAANRRun(*args, 0); t.SetRXAANRRun(*args, 1)
+    y2 = e.process_host(x[:, :20 * 1024])
+    ref2 = np.stack([o.xrxa(x[ch, :20 * 1024]) for ch, o in enumerate(refs)])
+    for ch in range(nch):
+        assert rel_rms(y2[ch], ref2[ch]) < 1e-6

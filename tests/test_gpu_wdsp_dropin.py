@@ -229,3 +229,23 @@ def test_steady_state_blocks_are_replayed_from_hipgraphs_and_setters_invalidate_
     r2, errs2 = o.fexchange0(x[20 * in_size:])
     assert errs1 == 0 and errs2 == 0
     assert rel_rms(np.concatenate([y1, y2]), np.concatenate([r1, r2])) < 1e-9
+
+
+def test_anf_and_anr_through_the_wdsp_names(qh, oracle):
+    lib = qh.load()
+    for n in ("SetRXAANFRun", "SetRXAANRRun", "SetRXAANFPosition"):
+        getattr(lib, n).argtypes = [C.c_int, C.c_int]
+    lib.SetRXAANRVals.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    ch, in_size, out_size, nb = 12, 1024, 256, 50
+    _open(lib, ch, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    o = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    x = synth.make_input_numpy(1, nb * in_size)[0]
+    lib.SetRXAANFRun(ch, 1); o.SetRXAANFRun(1)
+    y1 = _run(lib, ch, x[:25 * in_size], in_size, out_size); r1, _ = o.fexchange0(x[:25 * in_size])
+    lib.SetRXAANFRun(ch, 0); o.SetRXAANFRun(0)
+    lib.SetRXAANRVals(ch, 32, 8, 1e-4, 0.1); o.SetRXAANRVals(32, 8, 1e-4, 0.1)
+    lib.SetRXAANRRun(ch, 1); o.SetRXAANRRun(1)
+    y2 = _run(lib, ch, x[25 * in_size:], in_size, out_size); r2, _ = o.fexchange0(x[25 * in_size:])
+    assert lib.qh_wdsp_status() == 0
+    lib.CloseChannel(ch)
+    assert rel_rms(np.concatenate([y1, y2]), np.concatenate([r1, r2])) < 1e-6
