@@ -136,7 +136,7 @@ static __constant__ double kSamC1[7] = { -0.0991227952747244, -0.565619728761389
 // Synchronous AM: in place.  The all-pass state lives in LDS (uniform addresses: every lane reads and writes
 // the same words, which is a broadcast / same-value store).
 static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                     PllState *state, const SamChanParam *cprm, PllParam q)
+                                                     PllState *state, const SamChanParam *cprm, PllParam q, AmState *fade)
 {
     constexpr int STAGES = 7, OUT_IDX = 3 * STAGES;
     const double *c0 = kSamC0, *c1 = kSamC1;
@@ -147,7 +147,8 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     PllState *sp = state + ch;
     const int sbmode = cprm[ch].sbmode, levelfade = cprm[ch].levelfade;
     PllLoop L{ sp->phs * (1.0 / kTwoPiRef), sp->fil_out, sp->omega };
-    double dc = sp->dc, dc_insert = sp->dc_insert;
+    // the fade leveller's two averages belong to the amd block, not to a mode (amd.h:58-59): AM and SAM share them
+    double dc = fade[ch].dc, dc_insert = fade[ch].dc_insert;
     double dsI = sp->dsI, dsQ = sp->dsQ;
     if (lane < 24) { fa[lane] = sp->a[lane]; fb[lane] = sp->b[lane]; fc[lane] = sp->c[lane]; fd[lane] = sp->d[lane]; }
     __syncthreads();
@@ -206,7 +207,7 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     }
     __syncthreads();
     if (lane == 0) {
-        sp->phs = L.pt * kTwoPiRef; sp->fil_out = L.fil_out; sp->omega = L.omega; sp->dc = dc; sp->dc_insert = dc_insert;
+        sp->phs = L.pt * kTwoPiRef; sp->fil_out = L.fil_out; sp->omega = L.omega; fade[ch].dc = dc; fade[ch].dc_insert = dc_insert;
         sp->dsI = dsI; sp->dsQ = dsQ;
     }
     if (lane < 24) { sp->a[lane] = fa[lane]; sp->b[lane] = fb[lane]; sp->c[lane] = fc[lane]; sp->d[lane] = fd[lane]; }
@@ -430,13 +431,22 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
     }
 }
 
+// xwcpagc mode 0 (wcpAGC.c:167-175) in place, for the channels whose fixed gain cannot wait for the output matrix
+static __global__ __launch_bounds__(NT) void scale_kernel(double2 *buf, long long stride, int n, const int *chan_list, const double *gain)
+{
+    const int ch = chan_list[blockIdx.y];
+    const double g = gain[ch];
+    double2 *p = buf + (long long)ch * stride;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) p[i] = make_double2(g * p[i].x, g * p[i].y);
+}
+
 // xanf (wdsp/anf.c:82-133) / xanr (wdsp/anr.c:82-133): leaky normalised-LMS line enhancer on the real part, up to 64 taps.
 // The recurrence is sequential in time (the weight update needs the error of the full dot product), so one wavefront
 // per channel with one tap per lane: lane j keeps w[j] and x[n - delay - j]; per sample the window moves one lane up
 // (DPP wave_shr:1, lane 0 takes x[n - delay]), w.x and x.x are reduced across the wave (wave_sum_d), the step-size
 // logic runs uniformly in every lane in the reference's operation order, and the weights update in place.  Lane i of
 // a 64-sample batch keeps output i for one coalesced store.  State: the weights, the last 128 inputs, lidx, ngamma.
-struct LmsParam { int taps, delay, is_anr, pad; double two_mu, gamma, lidx_min, lidx_max, den_mult, lincr, ldecr, pre_gain; };
+struct LmsParam { int taps, delay, is_anr, pad; double two_mu, gamma, lidx_min, lidx_max, den_mult, lincr, ldecr; };
 struct LmsState { double w[64]; double hist[128]; double lidx, ngamma; };
 
 static __global__ __launch_bounds__(64) void lms_kernel(double2 *buf, long long stride, int n, const int *chan_list,
@@ -459,7 +469,7 @@ static __global__ __launch_bounds__(64) void lms_kernel(double2 *buf, long long 
     __syncthreads();
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
-        const double xin = lane < cnt ? p[base + lane].x * q.pre_gain : 0.0;      // pre_gain: a fixed AGC gain ahead of a position-1 filter
+        const double xin = lane < cnt ? p[base + lane].x : 0.0;
         // x[base + lane - delay] from the previous 64 samples and this batch
         s[lane] = h1; s[64 + lane] = xin;
         __syncthreads();

@@ -49,6 +49,7 @@ static constexpr int kHistFront = 2240;     // resampler history capacity: 140 *
 struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33
     int shift_run = 1; double shift_freq = 0.0;                 // RXA.c:39-45
+    int shift_on_device = 1;                                    // whether the device phase is live or parked (nco_park_kernel)
     int nbp_run = 1, nbp_nc = 2048, nbp_wintype = 0;            // RXA.c:90-106
     int mp = 0;                                                 // RXASetMP, RXA.c:948
     // notch database (create_notchdb RXA.c:85-87) and nbp0's use of it (fnfrun 0, autoincr 1: RXA.c:92,104)
@@ -72,9 +73,14 @@ struct ChanCfg {
     // anf / anr (create_anf / create_anr of create_rxa, RXA.c:278-315): [0] = anf, [1] = anr
     struct Lms { int run = 0, position = 0, taps = 64, delay = 16; double two_mu = 0.0001, gamma = 0.1; bool dirty = true, flush = false; } lms[2];
     int bp1_pos = 0;                                            // SetRXAANFPosition / SetRXAANRPosition set it too (anf.c:236)
+    // xwcpagc mode 0 with a position-1 stage behind it: the gain is applied in place at the AGC's spot, not in the epilogue
     bool demod_dirty = true, ctcss_flush = false;
     bool nbp_dirty = true, bp1_dirty = true, nco_dirty = true, epi_dirty = true;
     bool nbp_flush = false, bp1_flush = false;
+    bool fix_before() const
+    {
+        return agc_run && agc_mode == 0 && ((bp1_run && bp1_pos) || (lms[0].run && lms[0].position) || (lms[1].run && lms[1].position));
+    }
 };
 
 struct Engine {
@@ -103,7 +109,7 @@ struct Engine {
     // device state
     double2 *mask_front = nullptr, *mask_nbp = nullptr, *mask_bp1 = nullptr;
     double2 *tw4096 = nullptr, *tw_inv_front = nullptr;
-    unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr;
+    unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr, *nco_parked = nullptr;
     double2 *nco_step = nullptr;
     EpiParam *epi = nullptr;
     double2 *hist_front[2] = { nullptr, nullptr }, *hist_nbp[2] = { nullptr, nullptr }, *hist_bp1[2] = { nullptr, nullptr };
@@ -123,8 +129,14 @@ struct Engine {
     int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
     int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0;
     // anf / anr: lists per (filter, position), parameters and state per filter; bp1 lists per position
-    int *list_lms[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } }, n_lms[2][2] = { { 0, 0 }, { 0, 0 } };
+    // [filter][0] = position 0 (always in `cur`); [filter][1 + b] = position 1 with the data in cur (b = 0: bp1 still to come
+    // or not running) or in other (b = 1: bp1 ran at position 0)
+    int *list_lms[2][3] = { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } }, n_lms[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
     int *list_bp1p[2] = { nullptr, nullptr }, n_bp1p[2] = { 0, 0 };
+    // xwcpagc mode 0 ahead of a position-1 anf / anr / bp1: the fixed gain does not commute with what follows when it
+    // changes, so it is applied where the reference applies it; [b] = which buffer holds the channel at that point
+    int *list_fix[2] = { nullptr, nullptr }, n_fix[2] = { 0, 0 };
+    double *fix_gain = nullptr;
     LmsParam *lms_prm[2] = { nullptr, nullptr };
     LmsState *lms_state[2] = { nullptr, nullptr };
     int *levelfade = nullptr;
@@ -181,11 +193,11 @@ Engine::~Engine()
     if (rsmpout) qh_rat_destroy(rsmpout);
     (void)hipFree(obuf);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
-    (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
+    (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
-    (void)hipFree(lms_prm[0]); (void)hipFree(lms_prm[1]); (void)hipFree(lms_state[0]); (void)hipFree(lms_state[1]);
+    (void)hipFree(fix_gain); (void)hipFree(lms_prm[0]); (void)hipFree(lms_prm[1]); (void)hipFree(lms_state[0]); (void)hipFree(lms_state[1]);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -260,6 +272,8 @@ int Engine::init()
     }
     QH_HIP(dev_alloc(&nco_phase, (size_t)nch));
     QH_HIP(dev_alloc(&nco_dphase, (size_t)nch));
+    QH_HIP(dev_alloc(&nco_parked, (size_t)nch));
+    QH_HIP(hipMemsetAsync(nco_parked, 0, (size_t)nch * sizeof(unsigned long long), stream));
     QH_HIP(dev_alloc(&nco_step, (size_t)nch));
     QH_HIP(dev_alloc(&epi, (size_t)nch));
     QH_HIP(hipMemsetAsync(nco_phase, 0, (size_t)nch * sizeof(unsigned long long), stream));
@@ -294,6 +308,10 @@ int Engine::refresh_params()
     for (int ch = 0; ch < nch; ch++) {
         ChanCfg &c = cfg[(size_t)ch];
         if (c.nco_dirty) {
+            if ((c.shift_run != 0) != (c.shift_on_device != 0)) {
+                hipLaunchKernelGGL(nco_park_kernel, dim3(1), dim3(1), 0, stream, nco_phase, nco_parked, ch, c.shift_run ? 1 : 0);
+                c.shift_on_device = c.shift_run ? 1 : 0;
+            }
             // calc_shift, wdsp/shift.c:29-34: delta = 2*pi*shift/rate per input sample
             unsigned long long d = c.shift_run ? turns_fx(c.shift_freq, (double)in_rate) : 0ull;
             long double ang = 2.0L * 3.14159265358979323846264338327950288L *
@@ -306,10 +324,9 @@ int Engine::refresh_params()
         }
         if (c.epi_dirty) {
             // xwcpagc mode 0 (wcpAGC.c:167-175) then xpanel (patchpanel.c:55-101) as one 2x2 real matrix
-            // (a position-1 anf / anr sits between the fixed gain and the panel and is not scale-free: there the gain is
-            // applied by the LMS kernel on its input instead)
-            const bool lms_after_agc = (c.lms[0].run && c.lms[0].position) || (c.lms[1].run && c.lms[1].position);
-            const double g = (c.agc_run && c.agc_mode == 0 && !lms_after_agc) ? c.agc_fixed : 1.0;
+            // (with a position-1 anf / anr / bp1 behind it the gain is applied at the AGC's own spot instead: fix_before)
+            const double g = (c.agc_run && c.agc_mode == 0 && !c.fix_before()) ? c.agc_fixed : 1.0;
+            if (fix_gain) QH_HIP(hipMemcpyAsync(fix_gain + ch, &c.agc_fixed, sizeof(double), hipMemcpyHostToDevice, stream));
             const double gI = c.gain1 * c.gain2I, gQ = c.gain1 * c.gain2Q;
             const double sI = (double)(c.inselect >> 1), sQ = (double)(c.inselect & 1);
             EpiParam e;
@@ -394,9 +411,11 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 13));
-        for (int f = 0; f < 2; f++) for (int ps = 0; ps < 2; ps++) list_lms[f][ps] = list_buf + (7 + 2 * f + ps) * nch;
-        list_bp1p[0] = list_buf + 11 * nch; list_bp1p[1] = list_buf + 12 * nch;
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 17));
+        for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
+        list_bp1p[0] = list_buf + 13 * nch; list_bp1p[1] = list_buf + 14 * nch;
+        list_fix[0] = list_buf + 15 * nch; list_fix[1] = list_buf + 16 * nch;
+        QH_HIP(dev_alloc(&fix_gain, (size_t)nch));
         list_am = list_buf; list_sam = list_buf + nch; list_fm = list_buf + 2 * nch; list_bp1 = list_buf + 3 * nch;
         list_plain = list_buf + 4 * nch; list_agc_cur = list_buf + 5 * nch; list_agc_other = list_buf + 6 * nch;
         {   // create_meter x3 (RXA.c:69-82,142-155,361-374): tau 0.1 s for average and peak decay; flush_meter -> -400 dB
@@ -465,11 +484,13 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][2], lbp[2];
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2];
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
-            for (int f = 0; f < 2; f++) if (c.lms[f].run) lms_l[f][c.lms[f].position ? 1 : 0].push_back(ch);
+            const int at_agc = (c.bp1_run && !c.bp1_pos) ? 1 : 0;       // the buffer the channel is in when xwcpagc runs
+            for (int f = 0; f < 2; f++) if (c.lms[f].run) lms_l[f][c.lms[f].position ? 1 + at_agc : 0].push_back(ch);
             if (c.bp1_run) lbp[c.bp1_pos ? 1 : 0].push_back(ch);
+            if (c.fix_before()) lfix[at_agc].push_back(ch);
             if (c.fmd_run && c.lim_run) ll.push_back(ch);
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
             if (c.amd_run && c.amd_mode == 1) ls.push_back(ch);
@@ -479,8 +500,9 @@ int Engine::refresh_demod()
             if (c.agc_run && c.agc_mode != 0) (c.bp1_run && !c.bp1_pos ? lgo : lgc).push_back(ch);
         }
         bool any_lms = false;
-        for (int f = 0; f < 2; f++) for (int ps = 0; ps < 2; ps++) { n_lms[f][ps] = (int)lms_l[f][ps].size(); any_lms = any_lms || n_lms[f][ps]; }
+        for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) { n_lms[f][k] = (int)lms_l[f][k].size(); any_lms = any_lms || n_lms[f][k]; }
         n_bp1p[0] = (int)lbp[0].size(); n_bp1p[1] = (int)lbp[1].size();
+        n_fix[0] = (int)lfix[0].size(); n_fix[1] = (int)lfix[1].size();
         if (any_lms && !lms_prm[0]) {
             for (int f = 0; f < 2; f++) {
                 QH_HIP(dev_alloc(&lms_prm[f], (size_t)nch));
@@ -513,8 +535,12 @@ int Engine::refresh_demod()
         };
         QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
         QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo));
-        for (int f = 0; f < 2; f++) for (int ps = 0; ps < 2; ps++) QH_HIP(put(list_lms[f][ps], lms_l[f][ps]));
+        for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) QH_HIP(put(list_lms[f][k], lms_l[f][k]));
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
+        QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1]));
+        std::vector<double> fg((size_t)nch);
+        for (int ch = 0; ch < nch; ch++) fg[(size_t)ch] = cfg[(size_t)ch].agc_fixed;
+        QH_HIP(hipMemcpyAsync(fix_gain, fg.data(), fg.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         QH_HIP(hipStreamSynchronize(stream));
         lists_dirty = false;
     }
@@ -565,9 +591,7 @@ int Engine::refresh_demod()
                 if (m.run && (m.taps < 1 || m.taps > 64 || m.delay < 1 || m.delay > 64))
                     return set_error(QH_ERR_UNSUPPORTED, "%s: taps %d / delay %d (1..64 each: one tap per lane)", f ? "ANR" : "ANF", m.taps, m.delay);
                 // lidx_min, lidx_max, den_mult, lincr, ldecr of create_rxa (RXA.c:290-295,310-315)
-                const bool first_after_agc = m.position && !(f == 1 && c.lms[0].run && c.lms[0].position);
-                const double pre = (first_after_agc && c.agc_run && c.agc_mode == 0) ? c.agc_fixed : 1.0;
-                const LmsParam q{ m.taps, m.delay, f, 0, m.two_mu, m.gamma, f ? 120.0 : 0.0, 200.0, 6.25e-10, 1.0, 3.0, pre };
+                const LmsParam q{ m.taps, m.delay, f, 0, m.two_mu, m.gamma, f ? 120.0 : 0.0, 200.0, 6.25e-10, 1.0, 3.0 };
                 QH_HIP(hipMemcpyAsync(lms_prm[f] + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
                 QH_HIP(hipStreamSynchronize(stream));
                 m.dirty = false;
@@ -877,7 +901,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (n_am) hipLaunchKernelGGL(am_detect_kernel, dim3((unsigned)n_am), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                  list_am, levelfade, am_state, am_prm);
     if (n_sam) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)n_sam), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
-                                  list_sam, pll_state, sam_prm, sam_pll_prm);
+                                  list_sam, pll_state, sam_prm, sam_pll_prm, am_state);
     if (n_fm) {
         hipLaunchKernelGGL(fm_pll_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
                            pll_state, fm_again, fm_pll_prm);
@@ -892,21 +916,33 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     }
     // xanf, xanr, xbandpass(bp1) at position 0, xwcpagc, then the same three at position 1 (RXA.c:579-586).  The two bp1
     // launches work on disjoint channel rows of one ping-pong history pair, so the pair flips once for both.
-    auto lms_bp1 = [&](int ps) {
+    auto lms_on = [&](int k, double2 *b) {
         for (int f = 0; f < 2; f++)
-            if (n_lms[f][ps]) hipLaunchKernelGGL(lms_kernel, dim3((unsigned)n_lms[f][ps]), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
-                                                 list_lms[f][ps], lms_prm[f], lms_state[f]);
+            if (n_lms[f][k]) hipLaunchKernelGGL(lms_kernel, dim3((unsigned)n_lms[f][k]), dim3(64), 0, stream, b, buf_cap, (int)n_mid,
+                                                list_lms[f][k], lms_prm[f], lms_state[f]);
+    };
+    auto bp1_at = [&](int ps) {
         int hc = cur_bp1;
         if (n_bp1p[ps]) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
     };
-    lms_bp1(0);
-    // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below
+    lms_on(0, cur);
+    bp1_at(0);
+    // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below unless a position-1 stage follows
     tick(1);
     if (n_agc_cur) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                       list_agc_cur, agc_prm, agc_state);
     if (n_agc_other) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
                                         list_agc_other, agc_prm, agc_state);
-    lms_bp1(1);
+    {
+        long long per = (n_mid + NT - 1) / NT;
+        const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
+        for (int b = 0; b < 2; b++)
+            if (n_fix[b]) hipLaunchKernelGGL(scale_kernel, dim3(gx, (unsigned)n_fix[b]), dim3(NT), 0, stream, b ? other : cur, buf_cap,
+                                             (int)n_mid, list_fix[b], fix_gain);
+    }
+    lms_on(1, cur);
+    lms_on(2, other);
+    bp1_at(1);
     if (n_bp1) cur_bp1 ^= 1;
     if (meters_on) {    // agcmeter sits after xwcpagc (RXA.c:589); mode 0's gain multiply is applied below, so its
                         // level reading is taken on the fixed-gain input and corrected in qh_rxa_GetRXAMeter
@@ -1352,6 +1388,7 @@ int qh_rxa_flush(qh_rxa *h)
     e.epoch++;
     QH_HIP(hipSetDevice(e.device));
     QH_HIP(hipMemsetAsync(e.nco_phase, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
+    QH_HIP(hipMemsetAsync(e.nco_parked, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
     if (e.rsmpout) if (int rc = qh_rat_reset(e.rsmpout)) return rc;        // flush_resample, wdsp/resample.c:159-165
     for (int i = 0; i < 2; i++) {
         if (e.hist_front[i]) QH_HIP(hipMemsetAsync(e.hist_front[i], 0, (size_t)e.nch * kHistFront * sizeof(double2), e.stream));
@@ -1409,7 +1446,7 @@ int qh_rxa_GetRXAMeter(qh_rxa *h, int ch, int mt, double *value)
         return QH_OK;
     }
     double r = (mt == 0 || mt == 2 || mt == 5) ? st.res_pk : st.res_av;
-    if (mt >= 5 && c.agc_run && c.agc_mode == 0 && r > -399.0)
+    if (mt >= 5 && c.agc_run && c.agc_mode == 0 && !c.fix_before() && r > -399.0)
         r += 20.0 * std::log10(c.agc_fixed);                // |g z|^2 = g^2 |z|^2; exact up to mlog10's 11-bit mantissa steps
     *value = r;
     return QH_OK;

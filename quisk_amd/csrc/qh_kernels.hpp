@@ -45,6 +45,14 @@ __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long
     if (ch < nch) phase[ch] += dphase[ch] * (unsigned long long)n;
 }
 
+// xshift with run = 0 passes the samples through and leaves the phase where it is (wdsp/shift.c:60-85): park the phase
+// of channel `ch` while the shift is off (phase 0, step 0 = no rotation) and bring it back when it is switched on.
+[[maybe_unused]] static __global__ void nco_park_kernel(unsigned long long *phase, unsigned long long *parked, int ch, int run)
+{
+    if (run) phase[ch] = parked[ch];
+    else { parked[ch] = phase[ch]; phase[ch] = 0; }
+}
+
 // Elementwise stage used when a chain has no FIR stage to fuse into:
 //   out = epi * (in * nco)      (xshift, wdsp/shift.c:60-85; xwcpagc mode 0 + xpanel)
 template <typename T, bool MIX>

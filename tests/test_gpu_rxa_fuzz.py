@@ -1,0 +1,102 @@
+"""Seeded random walks over the RXA engine's setters, applied identically to the GPU engine (per channel) and to one
+oracle channel per GPU channel, with a few DSP blocks between changes: state carried across parameter changes (filter
+histories, AGC, LMS weights, notch database, mask rebuilds) is where a batched re-implementation goes wrong first.
+Gate: relative RMS over the whole run <= 1e-6 per channel (fp64 chain tolerance).  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from quisk_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+NCH = 4
+
+
+def _apply(rng, targets):
+    """Draw one setter call and apply it to every (object, leading-args) pair."""
+    k = int(rng.integers(0, 14))
+
+    done = []
+
+    def call(name, *args):
+        done.append((name,) + args)
+        for t, lead in targets:
+            getattr(t, name)(*lead, *args)
+    if k == 0:
+        mode = int(rng.choice([0, 1, 3, 4, 6, 10, 7]))          # LSB USB CWL CWU AM SAM DIGU
+        call("SetRXAMode", mode)
+    elif k == 1:
+        lo = float(rng.uniform(-4000, 3000)); hi = lo + float(rng.uniform(200, 4000))
+        call("RXASetPassband", lo, hi)
+    elif k == 2:
+        call("SetRXAShiftFreq", float(rng.uniform(-20000, 20000)))
+    elif k == 3:
+        call("SetRXAAGCMode", int(rng.integers(0, 5)))
+    elif k == 4:
+        call("SetRXAAGCFixed", float(rng.uniform(-10, 30)))
+    elif k == 5:
+        call("RXASetNC", int(rng.choice([256, 512, 1024, 2048])))
+    elif k == 6:
+        call("SetRXAANFRun", int(rng.integers(0, 2)))
+    elif k == 7:
+        call("SetRXAANRRun", int(rng.integers(0, 2)))
+    elif k == 8:
+        pos = int(rng.integers(0, 2))
+        call("SetRXAANFPosition", pos); call("SetRXAANRPosition", pos)
+    elif k == 9:
+        call("SetRXAPanelGain1", float(rng.uniform(0.5, 6.0)))
+    elif k == 10:
+        call("SetRXAPanelSelect", int(rng.integers(0, 4))); call("SetRXAPanelCopy", int(rng.integers(0, 4)))
+    elif k == 11:
+        call("RXASetMP", int(rng.integers(0, 2)))
+    elif k == 12:
+        call("SetRXAShiftRun", int(rng.integers(0, 2)))
+    else:
+        call("SetRXAAMDFadeLevel", int(rng.integers(0, 2))); call("SetRXAAMDSBMode", int(rng.integers(0, 3)))
+    return done
+
+
+@pytest.mark.parametrize("seed", list(range(1, 25)))
+def test_random_setter_walk(qh, oracle, seed):
+    rng = np.random.default_rng(seed)
+    nseg = 45
+    seglen = [int(rng.integers(1, 6)) for _ in range(nseg)]
+    nblk = sum(seglen)
+    x = synth.make_input_numpy(NCH, nblk * 1024)
+    x[1] = synth.make_mode_input_numpy("am", 1, nblk * 1024)
+    e = qh.RxaEngine(NCH)
+    os_ = [oracle.WdspChannel(1024, 256, 192000, 48000, 48000) for _ in range(NCH)]
+    for c in range(NCH):
+        for t, lead in ((e, (c,)), (os_[c], ())):
+            t.SetRXAShiftRun(*lead, 1); t.SetRXAShiftFreq(*lead, synth.shift_freq(c)); t.RXANBPSetRun(*lead, 1)
+            t.SetRXAMode(*lead, (1, 6, 0, 1)[c]); t.RXASetPassband(*lead, *((300.0, 3000.0), (-4000.0, 4000.0), (-3000.0, -300.0), (300.0, 3000.0))[c])
+            t.SetRXAAGCMode(*lead, (0, 3, 4, 2)[c])
+    ys, rs = [], [[] for _ in range(NCH)]
+    pos = 0
+    log = []
+    for s, n in enumerate(seglen):
+        if s:
+            for _ in range(int(rng.integers(1, 3))):
+                c = int(rng.integers(0, NCH))
+                log.append((s, c, _apply(rng, [(e, (c,)), (os_[c], ())])))
+        seg = x[:, pos * 1024:(pos + n) * 1024]
+        ys.append(e.process_host(seg))
+        for c in range(NCH):
+            rs[c].append(os_[c].xrxa(seg[c]))
+        pos += n
+    y = np.concatenate(ys, axis=1)
+    for c in range(NCH):
+        ref = np.concatenate(rs[c])
+        assert np.all(np.isfinite(ref)) and np.abs(ref).max() > 1e-4
+        err = rel_rms(y[c], ref)
+        if err >= 1e-6:
+            # first segment that is off, for the failure message
+            p0 = 0
+            for s, n in enumerate(seglen):
+                a, b = p0 * 256, (p0 + n) * 256
+                if np.abs(y[c, a:b] - ref[a:b]).max() > 1e-6 * np.abs(ref).max():
+                    raise AssertionError("seed %d channel %d: rel rms %.3e, first bad segment %d; setters so far %r" %
+                                         (seed, c, err, s, [l for l in log if l[0] <= s and l[1] == c]))
+                p0 += n
+        assert err < 1e-6
