@@ -105,6 +105,12 @@ struct Qrx {
     double *sq_level = nullptr;
     std::vector<double> h_sq_level;
     bool sq_dirty = false;
+    // c/dRxFilterOut keep their samples in a ring of sizeFilter entries with a running write index (quisk.c:1225-1253);
+    // a set_filters call with another size re-reads the same storage as a ring of the new size.  The linear history of
+    // the overlap-save stage is rebuilt to hold exactly what the reference's taps will then see: rx_size / rx_index are
+    // the reference's sizeFilter / indexFilter per channel, rx_ring what its buffer holds outside the live ring.
+    std::vector<int> rx_size, rx_index;
+    std::vector<std::vector<cd>> rx_ring;
     qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = off
     double agc_gain = 80.0;
     // dAutoNotch (quisk.c:786-963): a NOTCH step sits where the mode calls it, idle until qh_qrx_set_auto_notch
@@ -171,6 +177,49 @@ struct Qrx {
         if (!step.rat) return QH_ERR_HIP;
         steps.push_back(step);
         return QH_OK;
+    }
+
+    // The reference's ring of N = rx_size entries (position p was written when indexFilter was p; the tap loop reads
+    // (index + k) mod N) becomes a ring of M entries over the same storage.
+    int rx_resize(int c, int M)
+    {
+        const int N = rx_size[(size_t)c], H = rxf->hist_len;
+        QH_HIP(hipSetDevice(device));
+        std::vector<cd> row((size_t)H);
+        char *base = static_cast<char *>(rxf->hist[rxf->cur]) + (size_t)c * H * sizeof(cd);
+        std::vector<cd> &ring = rx_ring[(size_t)c];
+        if ((int)ring.size() < (N > M ? N : M)) ring.resize((size_t)(N > M ? N : M), cd(0.0, 0.0));
+        if (N > 0) {
+            QH_HIP(hipStreamSynchronize(stream));
+            QH_HIP(hipMemcpy(row.data(), base, row.size() * sizeof(cd), hipMemcpyDeviceToHost));
+            // what the live ring holds: the sample written `age` calls ago sits at (last - age) mod N, last = index - 1
+            const int last = rx_index[(size_t)c] - 1;
+            if (last >= 0)
+                for (int age = 0; age < N; age++) {
+                    const int p = ((last - age) % N + N) % N;
+                    ring[(size_t)p] = age < H ? row[(size_t)(H - 1 - age)] : cd(0.0, 0.0);      // (a 2048-entry ring's oldest sample is not kept)
+                }
+        }
+        if (M > 0) {
+            // the next sample is written at w; tap k >= 1 reads (w + k) mod M = the history sample of age M - k
+            const int i = rx_index[(size_t)c], w = i >= M ? 0 : i;
+            std::fill(row.begin(), row.end(), cd(0.0, 0.0));
+            for (int d = 1; d < M && d <= H; d++) row[(size_t)(H - d)] = ring[(size_t)(((w - d) % M + M) % M)];
+            QH_HIP(hipStreamSynchronize(stream));
+            QH_HIP(hipMemcpy(base, row.data(), row.size() * sizeof(cd), hipMemcpyHostToDevice));
+        }
+        rx_size[(size_t)c] = M;
+        return QH_OK;
+    }
+    // indexFilter after m more samples: "if (index >= size) index = 0; ...; index++" per sample
+    void rx_advance(int m)
+    {
+        for (size_t c = 0; c < rx_size.size(); c++) {
+            const int N = rx_size[c];
+            if (N <= 0 || m <= 0) continue;
+            const int i0 = rx_index[c] >= N ? 0 : rx_index[c];
+            rx_index[c] = (int)(((long long)i0 + m - 1) % N) + 1;
+        }
     }
 
     cd rx_identity() const      // sizeFilter == 0: c/dRxFilterOut return the sample itself (quisk.c:1201,1239)
@@ -411,8 +460,10 @@ int qh_qrx_set_filters(qh_qrx *h, int ch, const double *filtI, const double *fil
         if (!sideband(q.mode)) g[(size_t)d] = cd(gi, 0.0);              // dRxFilterOut
         else g[(size_t)d] = lower(q.mode) ? cd(gi, -gq) : cd(gi, gq);   // re + im : re - im
     }
+    if (q.rx_size.empty()) { q.rx_size.assign((size_t)q.nch, 0); q.rx_index.assign((size_t)q.nch, 0); q.rx_ring.resize((size_t)q.nch); }
     for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? q.nch : ch + 1); c++) {
         if (int rc = q.rxf->set_taps(c, g)) return rc;
+        if (size != q.rx_size[(size_t)c]) if (int rc = q.rx_resize(c, size)) return rc;
     }
     return QH_OK;
 }
@@ -473,6 +524,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
         switch (s.kind) {
         case Step::FIR:
             if (int rc = s.st->process(cur, cur_stride, n, dst, dst_stride, &m)) return rc;
+            if (s.st == q.rxf) q.rx_advance(n);
             break;
         case Step::RAT:
             if (int rc = qh_rat_process(s.rat, cur, cur_stride, n, dst, dst_stride, &m)) return rc;
