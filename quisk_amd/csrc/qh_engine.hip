@@ -1420,6 +1420,7 @@ int qh_rxa_enable_meters(qh_rxa *h, int enable)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
     h->e.meters_on = enable != 0;
+    h->e.epoch++;                   // the meter launches join / leave the sequence
     return QH_OK;
 }
 

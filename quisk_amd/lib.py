@@ -1,4 +1,7 @@
-"""ctypes loader for libquiskhip.so.  Fails loudly when the library is missing."""
+"""ctypes loader for libquiskhip.so.  Fails loudly when the library is missing.
+
+A process that also uses PyTorch must `import torch` BEFORE the first quisk_amd call: PyTorch ships its own HIP runtime
+under the same soname, and whichever copy is loaded first serves both (torch finds no GPU behind /opt/rocm's copy)."""
 import ctypes as C
 import os
 

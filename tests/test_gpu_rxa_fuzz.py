@@ -7,6 +7,7 @@ its weights wander along the null space on rounding noise, and two correct imple
 different order agree to a few 1e-6 there, not to 1e-13 (seen: 1.0e-6 .. 3.6e-6 on 3 of 24 walks).  -m gpu."""
 import numpy as np
 import pytest
+import torch          # before libquiskhip: one HIP runtime per process (torch's), as in bench.py
 
 from conftest import rel_rms
 from quisk_amd import synth
@@ -74,6 +75,17 @@ def _apply(rng, targets):
 
 @pytest.mark.parametrize("seed", list(range(1, 41)))
 def test_random_setter_walk(qh, oracle, seed):
+    _walk(qh, oracle, seed, replay=False)
+
+
+@pytest.mark.parametrize("seed", list(range(101, 113)))
+def test_random_setter_walk_block_at_a_time_with_graph_replay(qh, oracle, seed):
+    """The same walks fed one DSP block per call from fixed device buffers with qh_rxa_set_graph_replay on: every setter
+    must invalidate the captured launch sequences, and replayed blocks must leave the ping-pong state where plain ones do."""
+    _walk(qh, oracle, seed, replay=True)
+
+
+def _walk(qh, oracle, seed, replay):
     rng = np.random.default_rng(seed)
     nseg = 45
     seglen = [int(rng.integers(1, 6)) for _ in range(nseg)]
@@ -81,6 +93,12 @@ def test_random_setter_walk(qh, oracle, seed):
     x = synth.make_input_numpy(NCH, nblk * 1024)
     x[1] = synth.make_mode_input_numpy("am", 1, nblk * 1024)
     e = qh.RxaEngine(NCH)
+    if replay:
+        e.set_graph_replay(True)
+        e.enable_meters(True)
+        dev = torch.device("cuda:0")
+        d_in = torch.zeros((NCH, 1024), dtype=torch.complex128, device=dev)
+        d_out = torch.zeros((NCH, 256), dtype=torch.complex128, device=dev)
     os_ = [oracle.WdspChannel(1024, 256, 192000, 48000, 48000) for _ in range(NCH)]
     for c in range(NCH):
         for t, lead in ((e, (c,)), (os_[c], ())):
@@ -98,11 +116,23 @@ def test_random_setter_walk(qh, oracle, seed):
                 log.append((s, c, _apply(rng, [(e, (c,)), (os_[c], ())])))
                 lms_used[c] = lms_used[c] or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in log[-1][2])
         seg = x[:, pos * 1024:(pos + n) * 1024]
-        ys.append(e.process_host(seg))
+        if replay:
+            yb = np.empty((NCH, n * 256), dtype=np.complex128)
+            for b in range(n):
+                d_in.copy_(torch.from_numpy(seg[:, b * 1024:(b + 1) * 1024]))
+                torch.cuda.synchronize()
+                e.process_ptr(d_in.data_ptr(), 1024, d_out.data_ptr(), 256, 1)
+                e.synchronize()
+                yb[:, b * 256:(b + 1) * 256] = d_out.cpu().numpy()
+            ys.append(yb)
+        else:
+            ys.append(e.process_host(seg))
         for c in range(NCH):
             rs[c].append(os_[c].xrxa(seg[c]))
         pos += n
     y = np.concatenate(ys, axis=1)
+    if replay:
+        assert e.graph_launches() > nblk // 3
     for c in range(NCH):
         ref = np.concatenate(rs[c])
         assert np.all(np.isfinite(ref)) and np.abs(ref).max() > 1e-4
