@@ -300,7 +300,9 @@ int qh_rat_synchronize(qh_rat *h);
  * (quisk.c:5142-5331: window, complex FFT, RMS S-meter over the passband bins, fftshift, |X| average,
  * box sum per pixel, 20*log10 - 20*(log10 count + log10 N + 31 log10 2), clamp [-200, 0]).
  * Every completed block of fft_size samples is transformed (the reference drops blocks when the GUI is
- * slow).  fft_size: 1024 .. 16384, power of two. */
+ * slow).  fft_size: any even size 16 .. 16384 ("FFT size must be an even number", quisk.py:186).  Powers of two from 1024 run
+ * the fused kernel; the sizes Quisk itself picks (data_width * fft_mult with data_width = 2^a * y * z, quisk.py:186-194,4179:
+ * 4000, 9600 ...) run Bluestein's algorithm on the power-of-two transforms, about three times the work. */
 typedef struct qh_pan qh_pan;
 qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double sample_rate, void *stream);
 void qh_pan_destroy(qh_pan *p);

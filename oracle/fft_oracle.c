@@ -25,10 +25,35 @@ static const double *fo_twiddles(int logn)
     return fo_tw[logn];
 }
 
+/* Sizes that are not a power of two (Quisk's panadapter: fft_size = data_width * fft_mult, quisk.py:186-194,4179): the
+ * definition itself, X[k] = sum_n x[n] exp(sign 2 pi i n k / N), with the phase index n k mod N kept exact. */
+static void fo_dft_direct(double *x, int n, int sign)
+{
+    double *c = (double *)malloc(sizeof(double) * 2 * (size_t)n), *y = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    int k, m;
+    for (m = 0; m < n; m++) {
+        long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+        c[2 * m] = (double)cosl(a); c[2 * m + 1] = (double)(sign < 0 ? -sinl(a) : sinl(a));
+    }
+    for (k = 0; k < n; k++) {
+        long double sr = 0.0L, si = 0.0L;
+        long long idx = 0;
+        for (m = 0; m < n; m++) {
+            sr += (long double)x[2 * m] * c[2 * idx] - (long double)x[2 * m + 1] * c[2 * idx + 1];
+            si += (long double)x[2 * m] * c[2 * idx + 1] + (long double)x[2 * m + 1] * c[2 * idx];
+            idx += k; if (idx >= n) idx -= n;
+        }
+        y[2 * k] = (double)sr; y[2 * k + 1] = (double)si;
+    }
+    memcpy(x, y, sizeof(double) * 2 * (size_t)n);
+    free(c); free(y);
+}
+
 void fo_fft(double *x, int n, int sign)
 {
     int logn = 0, i, j, len;
     const double *tw;
+    if (n > 1 && (n & (n - 1))) { fo_dft_direct(x, n, sign); return; }
     while ((1 << logn) < n) logn++;
     if (n <= 1) return;
     tw = fo_twiddles(logn);

@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-/* In-place complex DFT of n points (n a power of two), interleaved re/im doubles.
+/* In-place complex DFT of n points (radix-2 for powers of two, the O(n^2) definition otherwise), interleaved re/im doubles.
  * sign = -1: forward (FFTW_FORWARD), sign = +1: backward (FFTW_BACKWARD), unnormalised. */
 void fo_fft(double *x, int n, int sign);
 

@@ -274,6 +274,88 @@ __global__ __launch_bounds__(NT) void bscope_graph_kernel(const double *avg, int
     }
 }
 
+// ---- panadapter sizes that are not a power of two (Quisk's fft_size = data_width * fft_mult with data_width = 2^a * y * z,
+// y, z odd <= 15, quisk.py:186-194,4179): Bluestein's chirp-z on the power-of-two transforms.  With w_n = exp(i pi n^2 / N):
+//   X[k] = conj(w_k) * sum_n (x[n] conj(w_n)) w_(k-n)   -- a circular convolution of length BM >= 2 N - 1,
+// and |X[k]| = |conv[k]| (the last chirp has unit modulus), which is all get_graph keeps.
+// gfft_kernel: one forward transform of BM = R * M points per (f, r) workgroup pair, decimation in frequency like
+// pan_spectrum_kernel (bins R k + r from an M-point LDS transform of the r-th combination), global -> global.
+//   LOAD 0: src = the sample stream; element n of transform f = x[ch][blk N + n] * pre[n] for n < N, else 0
+//   LOAD 1: src = transforms; element n = conj(src[f][n] * mul[n])   (inverse transform by conjugation)
+//   STORE 0: dst[f][bin] = value;   STORE 1: mag[f][(bin + N/2) % N] = |value| * scale for bin < N
+template <int M, int R, int LOAD, int STORE>
+__global__ __launch_bounds__(NT) void gfft_kernel(const double2 *src, long long src_stride, int nblk_c, long long blk0, int N,
+                                                  const double2 *aux, const double2 *tw, double2 *dst, double *mag, double scale)
+{
+    using C = double2;
+    using F = TileFft<M, false, C>;
+    constexpr int E = M / NT, BM = M * R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int t = threadIdx.x, f = blockIdx.x / R, r = blockIdx.x % R;
+    const typename F::Tw twf = F::load(tw);
+    C u[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int m = t + NT * i;
+        C sum = mk<double>(0, 0);
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int n = m + M * q;
+            C v;
+            if constexpr (LOAD == 0) {
+                const int ch = f / nblk_c, b = f % nblk_c;
+                v = mk<double>(0, 0);
+                if (n < N) v = cmul(src[(long long)ch * src_stride + (blk0 + b) * N + n], aux[n]);
+            } else {
+                const C a = cmul(src[(long long)f * BM + n], aux[n]);
+                v = mk<double>(a.x, -a.y);
+            }
+            if constexpr (R > 1) {
+                C wq;                                           // W_R^(q r)
+                sincospi(-2.0 * (double)((q * r) % R) / (double)R, &wq.y, &wq.x);
+                v = cmul(v, wq);
+            }
+            sum = cadd(sum, v);
+        }
+        C wm;                                                   // W_BM^(m r)
+        sincospi(-2.0 * (double)(((long long)m * r) % BM) / (double)BM, &wm.y, &wm.x);
+        u[i] = R > 1 ? cmul(sum, wm) : sum;
+    }
+    F::run(u, smem, twf);
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int bin = R * (t + NT * i) + r;
+        if constexpr (STORE == 0) dst[(long long)f * BM + bin] = u[i];
+        else if (bin < N) mag[(long long)f * N + (bin + N / 2) % N] = sqrt(u[i].x * u[i].x + u[i].y * u[i].y) * scale;
+    }
+}
+
+// fft_avg += the blocks' magnitudes (fixed order), S-meter += the passband's |X|^2 (quisk.c:5223-5244, 5271-5276)
+__global__ __launch_bounds__(NT) void gfft_reduce_kernel(const double *mag, int nblk_c, int N, const PanBand *band, double *avg, double *meter)
+{
+    __shared__ double wsum[NT / 64];
+    const int ch = blockIdx.y;
+    const PanBand pb = band[ch];
+    double m2 = 0.0;
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < N; idx += gridDim.x * NT) {
+        double sacc = 0.0, p2 = 0.0;
+        for (int b = 0; b < nblk_c; b++) { const double v = mag[((long long)ch * nblk_c + b) * N + idx]; sacc += v; p2 += v * v; }
+        avg[(long long)ch * N + idx] += sacc;
+        const int sb = idx - N / 2;                             // signed bin of this fftshifted index (N even)
+        if (pb.valid) {
+            if (sb >= pb.first && sb < pb.first + pb.nwhole) m2 += p2;
+            else if (sb == pb.first + pb.nwhole) m2 += pb.frac * p2;
+        }
+    }
+    // one workgroup per channel does the meter so that the sum has a fixed order
+    if (gridDim.x == 1) {
+        for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = m2;
+        __syncthreads();
+        if (threadIdx.x == 0) { double sm = 0.0; for (int k = 0; k < NT / 64; k++) sm += wsum[k]; meter[ch] += sm; }
+    }
+}
+
 // dst[ch][dst_off + i] = src[ch][src_off + i], i < n
 __global__ void pan_copy_kernel(const double2 *src, long long src_stride, long long src_off, double2 *dst, long long dst_stride,
                                 long long dst_off, int n)
@@ -294,6 +376,12 @@ struct Pan {
     PanBand *band = nullptr;
     std::vector<PanBand> hband;
     int fill = 0, count = 0, max_split = 1;
+    // Bluestein mode (fft_size not a power of two): transforms of BM = BR * M points
+    bool blue = false;
+    int BM = 0, BR = 1;
+    double2 *b_pre = nullptr, *b_filt = nullptr, *wa = nullptr, *wb = nullptr;
+    double *mag = nullptr;
+    int chunk_blk = 0;          // blocks per channel the work buffers hold
 
     ~Pan()
     {
@@ -301,6 +389,7 @@ struct Pan {
         if (stream) (void)hipStreamSynchronize(stream);
         (void)hipFree(avg); (void)hipFree(meter); (void)hipFree(pixels); (void)hipFree(smeter);
         (void)hipFree(tw); (void)hipFree(carry); (void)hipFree(partial); (void)hipFree(partial_m2); (void)hipFree(band);
+        (void)hipFree(b_pre); (void)hipFree(b_filt); (void)hipFree(wa); (void)hipFree(wb); (void)hipFree(mag);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -318,8 +407,39 @@ struct Pan {
         else launch2<MM, 4>(p, src_stride, nblk, nsplit);
     }
 
+    template <int MM, int RR> void blue_launch(const double2 *src, long long src_stride, int nb, long long blk0)
+    {
+        constexpr size_t lds = TileFft<MM, false, double2>::kLdsBytes;
+        const unsigned g = (unsigned)(nb * nch * RR);
+        hipLaunchKernelGGL((gfft_kernel<MM, RR, 0, 0>), dim3(g), dim3(NT), lds, stream, src, src_stride, nb, blk0, N, b_pre, tw, wa,
+                           (double *)nullptr, 1.0);
+        hipLaunchKernelGGL((gfft_kernel<MM, RR, 1, 1>), dim3(g), dim3(NT), lds, stream, wa, 0, nb, 0, N, b_filt, tw, (double2 *)nullptr,
+                           mag, 1.0 / (double)BM);
+    }
+    // fft_size that is not a power of two: Bluestein over chunks of blocks that fit the work buffers
+    int run_blocks_blue(const double2 *src, long long src_stride, long long off, int nblk)
+    {
+        for (int done = 0; done < nblk; done += chunk_blk) {
+            const int nb = nblk - done < chunk_blk ? nblk - done : chunk_blk;
+            const double2 *p0 = src + off;
+            switch (BR * 10000 + M) {
+            case 10000 + 1024: blue_launch<1024, 1>(p0, src_stride, nb, done); break;
+            case 10000 + 2048: blue_launch<2048, 1>(p0, src_stride, nb, done); break;
+            case 10000 + 4096: blue_launch<4096, 1>(p0, src_stride, nb, done); break;
+            case 20000 + 4096: blue_launch<4096, 2>(p0, src_stride, nb, done); break;
+            case 40000 + 4096: blue_launch<4096, 4>(p0, src_stride, nb, done); break;
+            default:           blue_launch<4096, 8>(p0, src_stride, nb, done); break;
+            }
+            hipLaunchKernelGGL(gfft_reduce_kernel, dim3(1, (unsigned)nch), dim3(NT), 0, stream, mag, nb, N, band, avg, meter);
+        }
+        count += nblk;
+        QH_HIP(hipGetLastError());
+        return QH_OK;
+    }
+
     int run_blocks(const double2 *src, long long src_stride, long long off, int nblk)
     {
+        if (blue) return run_blocks_blue(src, src_stride, off, nblk);
         // enough workgroups to fill the chip (>= 1024) but no more block ranges than blocks
         int nsplit = (1024 + R * nch - 1) / (R * nch);
         if (nsplit > nblk) nsplit = nblk;
@@ -348,12 +468,19 @@ extern "C" {
 
 qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double sample_rate, void *stream)
 {
-    int M = 0, R = 0;
+    int M = 0, R = 0, BM = 0;
     for (int r : { 1, 2, 4 })
         for (int m : { 4096, 2048, 1024 })
             if (!M && r * m == fft_size) { M = m; R = r; }
+    if (!M && fft_size >= 16 && fft_size <= 16384 && fft_size % 2 == 0) {
+        // any even size (FFT size must be an even number, quisk.py:186): Bluestein on BM = 2^k >= 2 N - 1 points
+        BM = 1024;
+        while (BM < 2 * fft_size - 1) BM *= 2;
+        M = BM > 4096 ? 4096 : BM;
+        R = BM / M;
+    }
     if (nch <= 0 || data_width <= 0 || sample_rate <= 0 || !M) {
-        set_error(M ? QH_ERR_INVALID : QH_ERR_UNSUPPORTED, "qh_pan_create: fft_size must be 1024 .. 16384, a power of two (got %d)", fft_size);
+        set_error(M ? QH_ERR_INVALID : QH_ERR_UNSUPPORTED, "qh_pan_create: fft_size must be even, 16 .. 16384 (got %d)", fft_size);
         return nullptr;
     }
     int ndev = 0;
@@ -364,6 +491,7 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
     qh_pan *h = new qh_pan();
     Pan &p = h->p;
     p.device = device; p.nch = nch; p.N = fft_size; p.M = M; p.R = R; p.data_width = data_width; p.rate = sample_rate;
+    if (BM) { p.blue = true; p.BM = BM; p.BR = R; p.R = 1; }
     p.stream = (hipStream_t)stream;
     auto fail = [&](const char *what) -> qh_pan * { set_error(QH_ERR_HIP, "qh_pan_create: %s failed", what); delete h; return nullptr; };
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice");
@@ -385,6 +513,31 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
         hipMemcpy(p.band, p.hband.data(), (size_t)nch * sizeof(PanBand), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(p.avg, 0, (size_t)nch * fft_size * 8) != hipSuccess || hipMemset(p.meter, 0, (size_t)nch * 8) != hipSuccess)
         return fail("initial copies");
+    if (p.blue) {
+        const int N = fft_size;
+        // w_n = exp(i pi n^2 / N), the phase reduced exactly: n^2 mod 2N in integers
+        std::vector<cd> chirp((size_t)N), pre((size_t)N), filt((size_t)BM, cd(0.0, 0.0));
+        for (int n = 0; n < N; n++) {
+            const long long q = ((long long)n * n) % (2ll * N);
+            const long double a = 3.14159265358979323846264338327950288L * (long double)q / (long double)N;
+            chirp[(size_t)n] = cd((double)cosl(a), (double)sinl(a));
+            // Hanning window of record_app (quisk.c:6008): 0.5 - 0.5 cos(2 pi n / N)
+            const double win = 0.5 - 0.5 * (double)cosl(2.0L * 3.14159265358979323846264338327950288L * (long double)n / (long double)N);
+            pre[(size_t)n] = std::conj(chirp[(size_t)n]) * win;
+        }
+        filt[0] = chirp[0];
+        for (int n = 1; n < N; n++) { filt[(size_t)n] = chirp[(size_t)n]; filt[(size_t)(BM - n)] = chirp[(size_t)n]; }
+        host_fft(filt, -1);
+        long long per = 256ll * 1024 * 1024 / ((long long)nch * BM * 16);
+        p.chunk_blk = (int)(per < 1 ? 1 : per > 64 ? 64 : per);
+        if (hipMalloc((void **)&p.b_pre, (size_t)N * 16) != hipSuccess || hipMalloc((void **)&p.b_filt, (size_t)BM * 16) != hipSuccess ||
+            hipMalloc((void **)&p.wa, (size_t)p.chunk_blk * nch * BM * 16) != hipSuccess ||
+            hipMalloc((void **)&p.mag, (size_t)p.chunk_blk * nch * N * 8) != hipSuccess)
+            return fail("hipMalloc");
+        if (hipMemcpy(p.b_pre, pre.data(), (size_t)N * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p.b_filt, filt.data(), (size_t)BM * 16, hipMemcpyHostToDevice) != hipSuccess)
+            return fail("initial copies");
+    }
     hipError_t e = hipSuccess;
 #define QH_PAN_ATTR(MM, RR) if (M == MM && R == RR) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pan_spectrum_kernel<MM, RR>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (TileFft<MM, false, double2>::kLdsBytes + MM * 8))

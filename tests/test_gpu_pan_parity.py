@@ -74,3 +74,31 @@ def test_config3_shape_pan_plus_fir(qh, oracle):
         assert np.abs(pix[c] - r.get()[0]).max() < 1e-8
         want = oracle.OracleFir(taps).cDecimate(x[c], 32)
         assert np.sqrt(np.sum(np.abs(y[c] - want) ** 2) / np.sum(np.abs(want) ** 2)) < 1e-12
+
+
+@pytest.mark.parametrize("fft_size,data_width,fs", [(4000, 1000, 192000.0), (2400, 1200, 48000.0), (9000, 1000, 960000.0), (672, 336, 48000.0),
+                                                    (15360, 960, 192000.0), (1008 * 6, 1008, 96000.0)])
+def test_quisk_sizes_that_are_not_powers_of_two(qh, oracle, fft_size, data_width, fs):
+    """fft_size = data_width * fft_mult with data_width = 2^a y z (quisk.py:186-194, 4179): Bluestein on the power-of-two
+    transforms; the oracle evaluates the DFT by its definition."""
+    nch = 2
+    n = fft_size * 3 + 321
+    x = make(nch, n, fs, fft_size)
+    p = qh.Panadapter(nch, fft_size, data_width, fs)
+    refs = [oracle.OracleGraph(fft_size, data_width, fs) for _ in range(nch)]
+    for c in range(nch):
+        p.set_smeter_band(c, 9000.0 + 1000.0 * c, 2700.0)
+        refs[c].set_smeter_band(9000.0 + 1000.0 * c, 2700.0)
+    for a, b in ((0, 77), (77, fft_size + 5), (fft_size + 5, n)):
+        p.feed_host(x[:, a:b])
+        for c in range(nch):
+            refs[c].feed(x[c, a:b])
+    pix, sm, cnt = p.get_graph(1.0, 0.0)
+    assert cnt == 3
+    for c in range(nch):
+        rp, rs, rc = refs[c].get(1.0, 0.0)
+        assert rc == 3
+        assert np.abs(pix[c] - rp).max() < 1e-8 and abs(sm[c] - rs) < 1e-8
+    assert p.get_graph() is None
+    with pytest.raises(qh.QuiskHipError):
+        qh.Panadapter(1, 4001, 1000, fs)                    # "FFT size must be an even number", quisk.py:186
