@@ -418,6 +418,7 @@ typedef struct qh_qagc qh_qagc;
 qh_qagc *qh_qagc_create(int device, int nch, int sample_rate, double max_out, double release_time, int is_cpx, void *stream);
 void qh_qagc_destroy(qh_qagc *a);
 int qh_qagc_set_gain(qh_qagc *a, int ch, double release_gain);          /* set_agc(d), quisk.c:4543; default 80 */
+int qh_qagc_set_cpx(qh_qagc *a, int is_cpx);                            /* process_agc's is_cpx argument for the calls to come */
 int qh_qagc_reset(qh_qagc *a);
 int qh_qagc_process(qh_qagc *a, void *d_buf, long long stride, int n);
 int qh_qagc_process_host(qh_qagc *a, void *h_buf, long long stride, int n);

@@ -173,6 +173,14 @@ int qh_qagc_set_gain(qh_qagc *h, int ch, double release_gain)
     return QH_OK;
 }
 
+// process_agc takes is_cpx per call (quisk.c:2162: |z| for the DGT-IQ stream, |Re z| otherwise); the state carries over
+int qh_qagc_set_cpx(qh_qagc *h, int is_cpx)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "qh_qagc_set_cpx: null handle");
+    h->prm.is_cpx = is_cpx ? 1 : 0;
+    return QH_OK;
+}
+
 int qh_qagc_reset(qh_qagc *h)
 {
     if (!h) return set_error(QH_ERR_INVALID, "qh_qagc_reset: null handle");

@@ -32,6 +32,10 @@ struct QuiskRx {
     int fft_size = 0, data_width = 0;
     std::vector<double> out;
     // NoiseBlanker's statics (quisk.c:682-687): outlive mode changes, so they are not the bank's
+    // Agc1 (quisk.c:2321) is one static AGC for the playback stream whatever the mode: it belongs here, not to a bank
+    qh_qagc *agc = nullptr;
+    int agc_rate = 0;
+    double agc_gain_set = -1.0;
     qh_nb *nb = nullptr;
     int nb_level = 0;
     int auto_notch = 0, rit_freq = 0, notch_applied = -1;
@@ -62,7 +66,6 @@ int ensure_bank()
     if (g.params_dirty) {
         if (int rc = qh_qrx_set_tune(g.bank, 0, g.tune)) return rc;
         if (int rc = qh_qrx_set_filters(g.bank, 0, g.filtI.data(), g.filtQ.data(), (int)g.filtI.size())) return rc;
-        if (int rc = qh_qrx_set_agc(g.bank, g.agc_on ? 1 : 0, g.agc_gain)) return rc;
         g.params_dirty = false;
     }
     if (g.notch_applied != g.auto_notch) {          // a set_auto_notch call (or a fresh bank) starts the notch over
@@ -99,6 +102,7 @@ int qh_quisk_open(int sample_rate, const qh_qrx_tables *tables, int fft_size, in
     if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
     if (g.pan) { qh_pan_destroy(g.pan); g.pan = nullptr; }
     if (g.nb) { qh_nb_destroy(g.nb); g.nb = nullptr; }      // "sample_rate != sample_rate: Initialization", quisk.c:697
+    if (g.agc) { qh_qagc_destroy(g.agc); g.agc = nullptr; }
     g.fft_size = fft_size; g.data_width = data_width;
     if (fft_size > 0 && data_width > 0) {
         g.pan = qh_pan_create(0, 1, fft_size, data_width, (double)sample_rate, nullptr);
@@ -113,6 +117,7 @@ void qh_quisk_close(void)
     if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
     if (g.pan) { qh_pan_destroy(g.pan); g.pan = nullptr; }
     if (g.nb) { qh_nb_destroy(g.nb); g.nb = nullptr; }
+    if (g.agc) { qh_qagc_destroy(g.agc); g.agc = nullptr; }
     g.sample_rate = 0;
 }
 
@@ -184,6 +189,19 @@ int qh_quisk_process_samples(double *cSamples, int nSamples)
     g.out.resize((size_t)(cap > 0 ? cap : 1) * 2);
     int got = 0;
     if (qh_qrx_process_host(g.bank, cSamples, nSamples, nSamples, g.out.data(), cap > 0 ? cap : 1, &got)) return 0;
+    if (g.agc_on && got > 0) {                                           // process_agc(&Agc1, ...), quisk.c:2686-2702
+        const int rate = qh_qrx_decim_rate(g.bank);
+        if (g.agc && g.agc_rate != rate) { qh_qagc_destroy(g.agc); g.agc = nullptr; }
+        if (!g.agc) {
+            g.agc = qh_qagc_create(0, 1, rate, 0.7, 1.0, 0, nullptr);
+            if (!g.agc) return 0;
+            g.agc_rate = rate;
+            g.agc_gain_set = -1.0;
+        }
+        if (qh_qagc_set_cpx(g.agc, g.mode == 9 /* DGT-IQ */)) return 0;
+        if (g.agc_gain_set != g.agc_gain) { if (qh_qagc_set_gain(g.agc, -1, g.agc_gain)) return 0; g.agc_gain_set = g.agc_gain; }
+        if (qh_qagc_process_host(g.agc, g.out.data(), got, got)) return 0;
+    }
     std::memcpy(cSamples, g.out.data(), (size_t)got * 2 * sizeof(double));
     return got;
 }

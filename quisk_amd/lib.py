@@ -148,6 +148,7 @@ def load():
     L.qh_qagc_destroy.restype = None
     L.qh_qagc_set_gain.argtypes = [vp, i, C.c_double]
     L.qh_qagc_reset.argtypes = [vp]
+    L.qh_qagc_set_cpx.argtypes = [vp, i]
     L.qh_qagc_process.argtypes = [vp, vp, ll, i]
     L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
     L.qh_nb_create.restype = vp

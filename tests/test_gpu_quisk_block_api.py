@@ -16,7 +16,7 @@ def test_process_samples_in_place_with_mode_and_tune_changes(qh, oracle):
     api.open(fs, fft_size=2048, data_width=512)
     tabs = rxfilter.coefficient_tables()
     r = oracle.OracleQuiskRx(fs, tabs)
-    r.set_agc(True, 80.0)
+    agc = oracle.OracleQuiskAgc(48000, 0.7, 1.0)            # Agc1 is static: one AGC for every mode (quisk.c:2321)
     g = oracle.OracleGraph(2048, 512, float(fs))
     t = np.arange(fs)
     x = 2.0 ** 22 * np.exp(2j * np.pi * ((10900.0 / fs) * t % 1.0)) + 2.0 ** 14 * (np.random.default_rng(0).standard_normal(fs) + 0j)
@@ -31,14 +31,14 @@ def test_process_samples_in_place_with_mode_and_tune_changes(qh, oracle):
                 fI, fQ = rxfilter.make_filter_coef(frate, None, bw, rxfilter.get_filter_center(name, bw))
                 api.set_filters(fI, fQ, bw)
                 assert api.get_filter_rate() == frate
-                # the reference keeps one static AGC and filter set; here a mode change starts a fresh receiver
+                # the reference keeps its static filter histories; here a mode change starts fresh filters (the AGC carries on)
                 r = oracle.OracleQuiskRx(fs, tabs)
-                r.set_mode(mode); r.set_tune(tune); r.set_filters(fI, fQ); r.set_bandwidth(bw); r.set_agc(True, 80.0)
+                r.set_mode(mode); r.set_tune(tune); r.set_filters(fI, fQ); r.set_bandwidth(bw)
         buf = np.zeros(blk, dtype=np.complex128)
         buf[:] = x[k:k + blk]
         n = api.process_samples(buf, blk)
         outs.append(buf[:n].copy())
-        refs.append(r.process(x[k:k + blk]))
+        refs.append(agc.process(r.process(x[k:k + blk]), False, 80.0))
         g.feed(x[k:k + blk])
     y, want = np.concatenate(outs), np.concatenate(refs)
     assert y.size == want.size == (fs // blk) * blk // 4
