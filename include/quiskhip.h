@@ -87,6 +87,10 @@ int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
 int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
 int qh_rxa_SetRXAFMLimRun(qh_rxa *e, int ch, int run);           /* wdsp/fmd.c:336-347: the FM detector's limiter */
 int qh_rxa_SetRXAFMLimGain(qh_rxa *e, int ch, double gaindB);    /* wdsp/fmd.c:349-362 */
+/* xamsqcap / xamsq, the AM squelch (wdsp/amsq.c:119-192; create_amsq arguments RXA.c:158-172) */
+int qh_rxa_SetRXAAMSQRun(qh_rxa *e, int ch, int run);
+int qh_rxa_SetRXAAMSQThreshold(qh_rxa *e, int ch, double threshold_db);
+int qh_rxa_SetRXAAMSQMaxTail(qh_rxa *e, int ch, double tail_seconds);
 /* xanf / xanr (wdsp/anf.c:82-133, anr.c:82-133), setters wdsp/anf.c:175-239 and anr.c:175-238; which position (0 before
  * bp1 and the AGC, 1 after the AGC) also moves bp1, as in the reference.  Taps and delay 1..64. */
 int qh_rxa_SetRXAANFRun(qh_rxa *e, int ch, int v);
@@ -229,7 +233,9 @@ void SetRXAANRPosition(int channel, int v);
 void SetRXAANRGain(int channel, double v);
 void SetRXAANRLeakage(int channel, double v);
 void SetRXAANRVals(int channel, int taps, int delay, double gain, double leakage);
-void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c */
+void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c:216-222 */
+void SetRXAAMSQThreshold(int channel, double threshold);                         /* wdsp/amsq.c:224-232, dB */
+void SetRXAAMSQMaxTail(int channel, double tail);                                /* wdsp/amsq.c:234-243, seconds */
 void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */
 void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */
 void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c */

@@ -44,6 +44,9 @@ def lib():
         for n in ("wo_SetRXAAGCAttack", "wo_SetRXAAGCDecay", "wo_SetRXAAGCHang", "wo_SetRXAAGCSlope", "wo_SetRXAAGCHangThreshold"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None
+        for n in ("wo_SetRXAAMSQThreshold", "wo_SetRXAAMSQMaxTail"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_double]
+            getattr(L, n).restype = None
         for n in ("wo_SetRXAANFVals", "wo_SetRXAANRVals"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             getattr(L, n).restype = None
@@ -52,7 +55,7 @@ def lib():
         for n in ("wo_SetRXAMode", "wo_RXASetNC", "wo_SetRXAShiftRun", "wo_RXANBPSetRun", "wo_SetRXABandpassRun",
                   "wo_SetRXAAGCMode", "wo_SetRXAPanelRun", "wo_SetRXAPanelSelect", "wo_SetRXAPanelCopy",
                   "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun", "wo_SetRXAAMDRun", "wo_RXASetMP", "wo_SetRXAFMLimRun",
-                  "wo_SetRXAANFRun", "wo_SetRXAANRRun", "wo_SetRXAANFPosition", "wo_SetRXAANRPosition"):
+                  "wo_SetRXAAMSQRun", "wo_SetRXAANFRun", "wo_SetRXAANRRun", "wo_SetRXAANFPosition", "wo_SetRXAANRPosition"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None
         for n in ("wo_SetRXAShiftFreq", "wo_SetRXAAGCFixed", "wo_SetRXAPanelGain1", "wo_SetRXAFMDeviation",

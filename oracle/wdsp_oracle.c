@@ -545,6 +545,12 @@ struct wo_channel {
     } fmd;
     wo_agc agc;
     struct { int run, nc, wintype, position; double f_low, f_high, gain; wo_fircore *p; } bp1;
+    /* amsq, wdsp/amsq.h */
+    struct {
+        int run, state, count, ntup, ntdown;
+        double avm, onem_avm, avsig, tail_thresh, unmute_thresh, min_tail, max_tail, muted_gain, rate;
+        double *cup, *cdown, *trigsig;
+    } amsq;
     /* anf / anr, wdsp/anf.h:32-61, anr.h:32-61 (the two structs are the same) */
     struct wo_lms {
         int run, position, n_taps, delay, in_idx, mask;
@@ -914,6 +920,64 @@ static void xpanel(wo_channel *c, double *buf, int size)
     }
 }
 
+/* ---- AM squelch: calc_amsq / compute_slews (amsq.c:28-64), xamsqcap (:189-192), xamsq (:119-187) */
+static void amsq_calc(wo_channel *c)
+{
+    int i;
+    double delta, theta;
+    c->amsq.rate = (double)c->dsp_rate;
+    c->amsq.trigsig = (double *)zalloc((size_t)c->dsp_size * 2 * sizeof(double));
+    c->amsq.avm = exp(-1.0 / (c->amsq.rate * 0.010));
+    c->amsq.onem_avm = 1.0 - c->amsq.avm;
+    c->amsq.ntup = (int)(0.070 * c->amsq.rate);
+    c->amsq.ntdown = (int)(0.070 * c->amsq.rate);
+    c->amsq.cup = (double *)zalloc((size_t)(c->amsq.ntup + 1) * sizeof(double));
+    c->amsq.cdown = (double *)zalloc((size_t)(c->amsq.ntdown + 1) * sizeof(double));
+    delta = WO_PI / (double)c->amsq.ntup; theta = 0.0;
+    for (i = 0; i <= c->amsq.ntup; i++) { c->amsq.cup[i] = c->amsq.muted_gain + (1.0 - c->amsq.muted_gain) * 0.5 * (1.0 - cos(theta)); theta += delta; }
+    delta = WO_PI / (double)c->amsq.ntdown; theta = 0.0;
+    for (i = 0; i <= c->amsq.ntdown; i++) { c->amsq.cdown[i] = c->amsq.muted_gain + (1.0 - c->amsq.muted_gain) * 0.5 * (1.0 + cos(theta)); theta += delta; }
+}
+
+static void xamsq(wo_channel *c, double *buf, int size)
+{
+    enum { MUTED, INCREASE, UNMUTED, TAIL, DECREASE };
+    int i;
+    double sig, siglimit, g;
+    if (!c->amsq.run) return;
+    for (i = 0; i < size; i++) {
+        sig = sqrt(c->amsq.trigsig[2 * i] * c->amsq.trigsig[2 * i] + c->amsq.trigsig[2 * i + 1] * c->amsq.trigsig[2 * i + 1]);
+        c->amsq.avsig = c->amsq.avm * c->amsq.avsig + c->amsq.onem_avm * sig;
+        g = 1.0;
+        switch (c->amsq.state) {
+        case MUTED:
+            if (c->amsq.avsig > c->amsq.unmute_thresh) { c->amsq.state = INCREASE; c->amsq.count = c->amsq.ntup; }
+            g = c->amsq.muted_gain;
+            break;
+        case INCREASE:
+            g = c->amsq.cup[c->amsq.ntup - c->amsq.count];
+            if (c->amsq.count-- == 0) c->amsq.state = UNMUTED;
+            break;
+        case UNMUTED:
+            if (c->amsq.avsig < c->amsq.tail_thresh) {
+                c->amsq.state = TAIL;
+                if ((siglimit = c->amsq.avsig) > 1.0) siglimit = 1.0;
+                c->amsq.count = (int)((c->amsq.min_tail + (c->amsq.max_tail - c->amsq.min_tail) * (1.0 - siglimit)) * c->amsq.rate);
+            }
+            break;
+        case TAIL:
+            if (c->amsq.avsig > c->amsq.unmute_thresh) c->amsq.state = UNMUTED;
+            else if (c->amsq.count-- == 0) { c->amsq.state = DECREASE; c->amsq.count = c->amsq.ntdown; }
+            break;
+        case DECREASE:
+            g = c->amsq.cdown[c->amsq.ntdown - c->amsq.count];
+            if (c->amsq.count-- == 0) c->amsq.state = MUTED;
+            break;
+        }
+        if (g != 1.0) { buf[2 * i] = g * buf[2 * i]; buf[2 * i + 1] = g * buf[2 * i + 1]; }      /* out = in elsewhere */
+    }
+}
+
 /* ---- xanf (anf.c:82-133) and xanr (anr.c:82-133): the same leaky LMS line enhancer; the notch filter outputs the
  * error, the noise reduction the prediction.  Real part only; the imaginary part comes out zero. */
 static void xlms(struct wo_lms *a, int is_anr, int position, double *buf, int size)
@@ -985,6 +1049,7 @@ static void xrxa(wo_channel *c)
     meter_exec(&c->adcmeter, c->midbuff, n, c->meter, NULL);
     if (c->nbp0.run) wo_fircore_exec(c->nbp0.p, c->midbuff, c->midbuff);
     meter_exec(&c->smeter, c->midbuff, n, c->meter, NULL);
+    memcpy(c->amsq.trigsig, c->midbuff, (size_t)n * 2 * sizeof(double));            /* xamsqcap, RXA.c:571 */
     xamd(c, c->midbuff, n);
     xfmd(c, c->midbuff, n);
     xlms(&c->anf, 0, 0, c->midbuff, n);
@@ -996,6 +1061,7 @@ static void xrxa(wo_channel *c)
     if (c->bp1.run && c->bp1.position == 1) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);
     meter_exec(&c->agcmeter, c->midbuff, n, c->meter, &c->agc.gain);
     xpanel(c, c->midbuff, n);
+    xamsq(c, c->midbuff, n);                                                        /* RXA.c:596 */
     if (c->rsmpout->run) wo_resample_exec(c->rsmpout, c->midbuff, n, c->outbuff);
     else memcpy(c->outbuff, c->midbuff, (size_t)n * 2 * sizeof(double));
 }
@@ -1193,6 +1259,10 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     /* create_wcpagc arguments of create_rxa, RXA.c:335-358 */
     wo_agc_init(&c->agc, 1, 3, 1, dsp_rate, 0.001, 0.250, 4, 10000.0, 1.5, 1000.0, 1.0, 1.0, 0.250, 0.005, 5.0, 1, 0.500, 0.250, 0.250, 0.100);
     c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0; c->bp1.position = 0;
+    /* create_amsq arguments of create_rxa, RXA.c:158-172 */
+    c->amsq.run = 0; c->amsq.tail_thresh = 0.009; c->amsq.unmute_thresh = 0.010; c->amsq.min_tail = 0.0; c->amsq.max_tail = 1.5;
+    c->amsq.muted_gain = 0.0;
+    amsq_calc(c);
     {   /* create_anf / create_anr arguments of create_rxa, RXA.c:278-315 */
         struct wo_lms *a = &c->anf;
         a->mask = 2047; a->n_taps = 64; a->delay = 16; a->two_mu = 0.0001; a->gamma = 0.1;
@@ -1217,6 +1287,7 @@ void wo_close(wo_channel *c)
     wo_fircore_destroy(c->fmd.pde); wo_fircore_destroy(c->fmd.paud);
     free(c->fmd.audio);
     free(c->inbuff); free(c->midbuff); free(c->outbuff);
+    free(c->amsq.cup); free(c->amsq.cdown); free(c->amsq.trigsig);
     free(c->iob.r1); free(c->iob.r2); free(c->iob.cup);
     wo_agc_free(&c->agc);
     free(c);
@@ -1397,6 +1468,19 @@ void wo_SetRXAAMDRun(wo_channel *c, int run)        /* amd.c:264-277 */
         bp1_set(c);
     }
 }
+void wo_SetRXAAMSQRun(wo_channel *c, int run) { c->amsq.run = run; }                 /* amsq.c:216-222 */
+void wo_SetRXAAMSQThreshold(wo_channel *c, double threshold)                         /* amsq.c:224-232 */
+{
+    double thresh = pow(10.0, threshold / 20.0);
+    c->amsq.tail_thresh = 0.9 * thresh;
+    c->amsq.unmute_thresh = thresh;
+}
+void wo_SetRXAAMSQMaxTail(wo_channel *c, double tail)                                /* amsq.c:234-243 */
+{
+    if (tail < c->amsq.min_tail) tail = c->amsq.min_tail;
+    c->amsq.max_tail = tail;
+}
+
 /* SetRXAANFRun ... SetRXAANFPosition (anf.c:175-239) and the ANR twins (anr.c:175-238) */
 void wo_SetRXAANFRun(wo_channel *c, int run)
 {

@@ -74,6 +74,9 @@ void wo_SetRXAPanelSelect(wo_channel *c, int select);
 void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
+void wo_SetRXAAMSQRun(wo_channel *c, int run);                  /* amsq.c:216-222 */
+void wo_SetRXAAMSQThreshold(wo_channel *c, double threshold);   /* amsq.c:224-232 */
+void wo_SetRXAAMSQMaxTail(wo_channel *c, double tail);          /* amsq.c:234-243 */
 void wo_SetRXAANFRun(wo_channel *c, int run);                   /* anf.c:175-189 */
 void wo_SetRXAANFVals(wo_channel *c, int taps, int delay, double gain, double leakage);     /* anf.c:191-201 */
 void wo_SetRXAANFPosition(wo_channel *c, int position);         /* anf.c:231-239 */

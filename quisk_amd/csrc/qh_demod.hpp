@@ -515,4 +515,72 @@ static __global__ __launch_bounds__(64) void lms_kernel(double2 *buf, long long 
     if (lane == 0) { sp->lidx = lidx; sp->ngamma = ngamma; }
 }
 
+// AM squelch, wdsp/amsq.c: xamsqcap (:189-192) keeps the signal behind nbp0, xamsq (:119-187) at the end of the chain runs a
+// five-state machine (muted / raised-cosine up / unmuted / tail / raised-cosine down) on the 10 ms average of its magnitude.
+// The average is a linear recurrence (wave scan); the state machine is sequential: one wavefront per channel, uniform state,
+// lane i keeps the gain of sample i.  cup / cdown are the reference's slew tables (compute_slews, amsq.c:28-46).
+struct AmsqParam { double avm, onem_avm, tail_thresh, unmute_thresh, min_tail, max_tail, muted_gain, rate; int ntup, ntdown; };
+struct AmsqState { double avsig; int state, count; };
+
+static __global__ __launch_bounds__(NT) void amsq_cap_kernel(const double2 *buf, long long stride, int n, const int *chan_list, double *mag,
+                                                             long long mag_stride)
+{
+    const int ch = chan_list[blockIdx.y];
+    const double2 *p = buf + (long long)ch * stride;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT)
+        mag[(long long)ch * mag_stride + i] = sqrt(p[i].x * p[i].x + p[i].y * p[i].y);
+}
+
+static __global__ __launch_bounds__(64) void amsq_apply_kernel(double2 *out, long long out_stride, int n, const int *chan_list, const double *mag,
+                                                               long long mag_stride, const AmsqParam *prm, AmsqState *state,
+                                                               const double *cup, const double *cdown)
+{
+    enum { MUTED, INCREASE, UNMUTED, TAIL, DECREASE };
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
+    const AmsqParam q = prm[ch];
+    AmsqState st = state[ch];
+    double2 *p = out + (long long)ch * out_stride;
+    const double *m = mag + (long long)ch * mag_stride;
+    const double pw = lane_pow(q.avm, lane + 1);
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        const double sig = lane < cnt ? m[base + lane] : 0.0;
+        const double av = scan_pole(q.onem_avm * sig, q.avm, lane) + pw * st.avsig;       // avsig = avm avsig + onem_avm sig
+        double myg = 1.0;
+        for (int i = 0; i < cnt; i++) {
+            const double a = lane_bcast(av, i);
+            double g = 1.0;
+            switch (st.state) {
+            case MUTED:
+                if (a > q.unmute_thresh) { st.state = INCREASE; st.count = q.ntup; }
+                g = q.muted_gain;
+                break;
+            case INCREASE:
+                g = cup[q.ntup - st.count];
+                if (st.count-- == 0) st.state = UNMUTED;
+                break;
+            case UNMUTED:
+                if (a < q.tail_thresh) {
+                    st.state = TAIL;
+                    const double siglimit = a > 1.0 ? 1.0 : a;
+                    st.count = (int)((q.min_tail + (q.max_tail - q.min_tail) * (1.0 - siglimit)) * q.rate);
+                }
+                break;
+            case TAIL:
+                if (a > q.unmute_thresh) st.state = UNMUTED;
+                else if (st.count-- == 0) { st.state = DECREASE; st.count = q.ntdown; }
+                break;
+            default:
+                g = cdown[q.ntdown - st.count];
+                if (st.count-- == 0) st.state = MUTED;
+                break;
+            }
+            if (lane == i) myg = g;
+        }
+        st.avsig = lane_bcast(av, cnt - 1);
+        if (lane < cnt && myg != 1.0) { const double2 v = p[base + lane]; p[base + lane] = make_double2(myg * v.x, myg * v.y); }
+    }
+    if (lane == 0) state[ch] = st;
+}
+
 }  // namespace qh

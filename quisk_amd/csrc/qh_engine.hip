@@ -72,6 +72,8 @@ struct ChanCfg {
     int lim_run = 0; double lim_gain = 2.5; bool lim_dirty = true;   // FM detector limiter, fmd.c:106-108
     // anf / anr (create_anf / create_anr of create_rxa, RXA.c:278-315): [0] = anf, [1] = anr
     struct Lms { int run = 0, position = 0, taps = 64, delay = 16; double two_mu = 0.0001, gamma = 0.1; bool dirty = true, flush = false; } lms[2];
+    // amsq (create_amsq of create_rxa, RXA.c:158-172)
+    int amsq_run = 0; double amsq_tail_thresh = 0.009, amsq_unmute_thresh = 0.010, amsq_max_tail = 1.5; bool amsq_dirty = true;
     int bp1_pos = 0;                                            // SetRXAANFPosition / SetRXAANRPosition set it too (anf.c:236)
     // xwcpagc mode 0 with a position-1 stage behind it: the gain is applied in place at the AGC's spot, not in the epilogue
     bool demod_dirty = true, ctcss_flush = false;
@@ -137,6 +139,12 @@ struct Engine {
     // changes, so it is applied where the reference applies it; [b] = which buffer holds the channel at that point
     int *list_fix[2] = { nullptr, nullptr }, n_fix[2] = { 0, 0 };
     double *fix_gain = nullptr;
+    int *list_amsq = nullptr, n_amsq = 0;
+    AmsqParam *amsq_prm = nullptr;
+    AmsqState *amsq_state = nullptr;
+    double *amsq_cup = nullptr, *amsq_cdown = nullptr, *amsq_mag = nullptr;
+    long long amsq_mag_cap = 0;
+    int amsq_ntup = 0, amsq_ntdown = 0;
     LmsParam *lms_prm[2] = { nullptr, nullptr };
     LmsState *lms_state[2] = { nullptr, nullptr };
     int *levelfade = nullptr;
@@ -197,6 +205,7 @@ Engine::~Engine()
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
+    (void)hipFree(amsq_prm); (void)hipFree(amsq_state); (void)hipFree(amsq_cup); (void)hipFree(amsq_cdown); (void)hipFree(amsq_mag);
     (void)hipFree(fix_gain); (void)hipFree(lms_prm[0]); (void)hipFree(lms_prm[1]); (void)hipFree(lms_state[0]); (void)hipFree(lms_state[1]);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
@@ -411,7 +420,8 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 17));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 18));
+        list_amsq = list_buf + 17 * nch;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
         list_bp1p[0] = list_buf + 13 * nch; list_bp1p[1] = list_buf + 14 * nch;
         list_fix[0] = list_buf + 15 * nch; list_fix[1] = list_buf + 16 * nch;
@@ -484,9 +494,10 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2];
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
+            if (c.amsq_run) lsq.push_back(ch);
             const int at_agc = (c.bp1_run && !c.bp1_pos) ? 1 : 0;       // the buffer the channel is in when xwcpagc runs
             for (int f = 0; f < 2; f++) if (c.lms[f].run) lms_l[f][c.lms[f].position ? 1 + at_agc : 0].push_back(ch);
             if (c.bp1_run) lbp[c.bp1_pos ? 1 : 0].push_back(ch);
@@ -503,6 +514,26 @@ int Engine::refresh_demod()
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) { n_lms[f][k] = (int)lms_l[f][k].size(); any_lms = any_lms || n_lms[f][k]; }
         n_bp1p[0] = (int)lbp[0].size(); n_bp1p[1] = (int)lbp[1].size();
         n_fix[0] = (int)lfix[0].size(); n_fix[1] = (int)lfix[1].size();
+        n_amsq = (int)lsq.size();
+        if (n_amsq && !amsq_prm) {
+            QH_HIP(dev_alloc(&amsq_prm, (size_t)nch));
+            QH_HIP(dev_alloc(&amsq_state, (size_t)nch));
+            QH_HIP(hipMemsetAsync(amsq_state, 0, (size_t)nch * sizeof(AmsqState), stream));
+            // compute_slews, amsq.c:28-46, with muted_gain 0 and 70 ms up / down (RXA.c:166-167,172): theta accumulates as there
+            amsq_ntup = (int)(0.070 * rate); amsq_ntdown = (int)(0.070 * rate);
+            std::vector<double> up((size_t)amsq_ntup + 1), down((size_t)amsq_ntdown + 1);
+            double delta = kPiRef / (double)amsq_ntup, theta = 0.0;
+            for (int i = 0; i <= amsq_ntup; i++) { up[(size_t)i] = 0.0 + (1.0 - 0.0) * 0.5 * (1.0 - std::cos(theta)); theta += delta; }
+            delta = kPiRef / (double)amsq_ntdown; theta = 0.0;
+            for (int i = 0; i <= amsq_ntdown; i++) { down[(size_t)i] = 0.0 + (1.0 - 0.0) * 0.5 * (1.0 + std::cos(theta)); theta += delta; }
+            QH_HIP(dev_alloc(&amsq_cup, up.size()));
+            QH_HIP(dev_alloc(&amsq_cdown, down.size()));
+            QH_HIP(hipMemcpyAsync(amsq_cup, up.data(), up.size() * 8, hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemcpyAsync(amsq_cdown, down.data(), down.size() * 8, hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            dev_bytes += (long long)nch * (sizeof(AmsqParam) + sizeof(AmsqState)) + (long long)(up.size() + down.size()) * 8;
+            for (ChanCfg &c : cfg) c.amsq_dirty = true;
+        }
         if (any_lms && !lms_prm[0]) {
             for (int f = 0; f < 2; f++) {
                 QH_HIP(dev_alloc(&lms_prm[f], (size_t)nch));
@@ -537,7 +568,7 @@ int Engine::refresh_demod()
         QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo));
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) QH_HIP(put(list_lms[f][k], lms_l[f][k]));
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
-        QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1]));
+        QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1])); QH_HIP(put(list_amsq, lsq));
         std::vector<double> fg((size_t)nch);
         for (int ch = 0; ch < nch; ch++) fg[(size_t)ch] = cfg[(size_t)ch].agc_fixed;
         QH_HIP(hipMemcpyAsync(fix_gain, fg.data(), fg.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -584,6 +615,16 @@ int Engine::refresh_demod()
             QH_HIP(hipMemcpyAsync(agc_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.agc_dirty = false;
+        }
+        if (amsq_prm && c.amsq_dirty) {
+            // calc_amsq, amsq.c:48-64: 10 ms average (RXA.c:165)
+            AmsqParam q{};
+            q.avm = std::exp(-1.0 / (rate * 0.010)); q.onem_avm = 1.0 - q.avm;
+            q.tail_thresh = c.amsq_tail_thresh; q.unmute_thresh = c.amsq_unmute_thresh; q.min_tail = 0.0; q.max_tail = c.amsq_max_tail;
+            q.muted_gain = 0.0; q.rate = rate; q.ntup = amsq_ntup; q.ntdown = amsq_ntdown;
+            QH_HIP(hipMemcpyAsync(amsq_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.amsq_dirty = false;
         }
         for (int f = 0; f < 2 && lms_prm[0]; f++) {
             ChanCfg::Lms &m = c.lms[f];
@@ -834,7 +875,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
-        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || meters_on) mixed = true;
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || meters_on) mixed = true;
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
@@ -897,6 +938,17 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     }
     if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_s,
                                       m_prm, (const int *)nullptr);
+    if (n_amsq) {           // xamsqcap (RXA.c:571): the magnitudes of the signal behind nbp0, for xamsq at the end of the chain
+        if (buf_cap > amsq_mag_cap) {
+            QH_HIP(hipStreamSynchronize(stream));
+            (void)hipFree(amsq_mag); amsq_mag = nullptr;
+            QH_HIP(dev_alloc(&amsq_mag, (size_t)nch * (size_t)buf_cap));
+            amsq_mag_cap = buf_cap;
+        }
+        long long per = (n_mid + NT - 1) / NT;
+        hipLaunchKernelGGL(amsq_cap_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_amsq), dim3(NT), 0, stream, cur, buf_cap,
+                           (int)n_mid, list_amsq, amsq_mag, amsq_mag_cap);
+    }
     tick(1);
     if (n_am) hipLaunchKernelGGL(am_detect_kernel, dim3((unsigned)n_am), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                  list_am, levelfade, am_state, am_prm);
@@ -961,6 +1013,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (n_bp1) hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3(gx, (unsigned)n_bp1), dim3(NT), 0, stream, other,
                                   buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
                                   (const unsigned long long *)nullptr, epi, list_bp1);
+    if (n_amsq) hipLaunchKernelGGL(amsq_apply_kernel, dim3((unsigned)n_amsq), dim3(64), 0, stream, out, out_stride, (int)n_mid, list_amsq,
+                                   amsq_mag, amsq_mag_cap, amsq_prm, amsq_state, amsq_cup, amsq_cdown);       // xamsq, RXA.c:596
     tick(3);
     QH_HIP(hipGetLastError());
     return QH_OK;
@@ -1252,6 +1306,13 @@ static int lms_position(qh_rxa *h, int ch, int which, int position)
         h->e.lists_dirty = true;
     });
 }
+// SetRXAAMSQRun / Threshold / MaxTail, wdsp/amsq.c:216-243
+int qh_rxa_SetRXAAMSQRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.amsq_run = run ? 1 : 0; h->e.lists_dirty = true; }); }
+int qh_rxa_SetRXAAMSQThreshold(qh_rxa *h, int ch, double threshold)
+{
+    FOR_CH(h, ch, { const double t = std::pow(10.0, threshold / 20.0); c.amsq_tail_thresh = 0.9 * t; c.amsq_unmute_thresh = t; c.amsq_dirty = true; });
+}
+int qh_rxa_SetRXAAMSQMaxTail(qh_rxa *h, int ch, double tail) { FOR_CH(h, ch, { c.amsq_max_tail = tail < 0.0 ? 0.0 : tail; c.amsq_dirty = true; }); }
 int qh_rxa_SetRXAANFRun(qh_rxa *h, int ch, int run) { return lms_run(h, ch, 0, run); }
 int qh_rxa_SetRXAANRRun(qh_rxa *h, int ch, int run) { return lms_run(h, ch, 1, run); }
 int qh_rxa_SetRXAANFVals(qh_rxa *h, int ch, int taps, int delay, double gain, double leakage) { return lms_vals(h, ch, 0, &taps, &delay, &gain, &leakage); }
@@ -1407,6 +1468,7 @@ int qh_rxa_flush(qh_rxa *h)
         }
     }
     for (ChanCfg &c : e.cfg) c.lms[0].flush = c.lms[1].flush = true;        // flush_anf / flush_anr, RXA.c:541-542
+    if (e.amsq_state) QH_HIP(hipMemsetAsync(e.amsq_state, 0, (size_t)e.nch * sizeof(AmsqState), e.stream));     // flush_amsq
     if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch
         QH_HIP(hipMemsetAsync(e.am_state, 0, (size_t)e.nch * sizeof(AmState), e.stream));
         QH_HIP(hipMemsetAsync(e.pll_state, 0, (size_t)e.nch * sizeof(PllState), e.stream));

@@ -410,6 +410,10 @@ void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMo
 void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
 void SetRXAFMLimRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAFMLimRun(L.c->eng, 0, run)); }
 void SetRXAFMLimGain(int channel, double gaindB) { WDSP_SETTER(qh_rxa_SetRXAFMLimGain(L.c->eng, 0, gaindB)); }
+// the AM squelch, wdsp/amsq.c:216-243
+void SetRXAAMSQRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMSQRun(L.c->eng, 0, run)); }
+void SetRXAAMSQThreshold(int channel, double threshold) { WDSP_SETTER(qh_rxa_SetRXAAMSQThreshold(L.c->eng, 0, threshold)); }
+void SetRXAAMSQMaxTail(int channel, double tail) { WDSP_SETTER(qh_rxa_SetRXAAMSQMaxTail(L.c->eng, 0, tail)); }
 // the LMS auto-notch / noise reduction, wdsp/anf.c:175-239, anr.c:175-238
 void SetRXAANFRun(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANFRun(L.c->eng, 0, v)); }
 void SetRXAANFTaps(int channel, int v) { WDSP_SETTER(qh_rxa_SetRXAANFTaps(L.c->eng, 0, v)); }
@@ -564,7 +568,6 @@ void fexchange2(int channel, float *Iin, float *Qin, float *Iout, float *Qout, i
     for (int i = 0; i < out_size; i++) { Iout[i] = (float)out[2 * (size_t)i]; Qout[i] = (float)out[2 * (size_t)i + 1]; }
 }
 
-WDSP_OFF_ONLY(SetRXAAMSQRun)
 WDSP_OFF_ONLY(SetRXAEMNRRun)
 WDSP_OFF_ONLY(SetRXASNBARun)
 

@@ -42,7 +42,7 @@ def load():
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
               "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease",
-              "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay",
+              "SetRXAAMSQRun", "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay",
               "SetRXAANRPosition"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, i]
@@ -54,7 +54,7 @@ def load():
     L.qh_rxa_RXANBPGetNumNotches.argtypes = [vp, i, C.POINTER(i)]
     L.qh_rxa_RXANBPGetMinNotchWidth.argtypes = [vp, i, C.POINTER(d)]
     for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop",
-              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAANFGain", "SetRXAANFLeakage",
+              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAANFGain", "SetRXAANFLeakage",
               "SetRXAANRGain", "SetRXAANRLeakage"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]

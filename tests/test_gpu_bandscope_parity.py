@@ -6,7 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,W,zoom,deltaf", [(16384, 1000, 1.0, 0.0), (4096, 777, 0.25, 3.0e6), (1024, 300, 0.5, -7.0e6), (8192, 1200, 1.0, 0.0)])
+@pytest.mark.parametrize("N,W,zoom,deltaf", [(16384, 1000, 1.0, 0.0), (4096, 777, 0.25, 3.0e6), (1024, 300, 0.5, -7.0e6), (8192, 1200, 1.0, 0.0),
+                                             (24 * 512, 1000, 1.0, 0.0), (3000, 500, 0.5, 1.0e6)])
 def test_bandscope_matches_oracle(qh, oracle, N, W, zoom, deltaf):
     clock, nch, nblk = 122880000, 3, 5
     rng = np.random.default_rng(N)
@@ -43,4 +44,4 @@ def test_silence_hits_the_floor_and_bad_sizes_fail(qh):
     pix, adc, cnt = b.get_bandscope(122880000)
     assert cnt == 1 and adc[0] == 0.0 and np.all(pix == -200.0)
     with pytest.raises(qh.QuiskHipError):
-        qh.Bandscope(1, 3000, 100)
+        qh.Bandscope(1, 3001, 100)                          # odd sizes have no Nyquist bin to put at N / 2

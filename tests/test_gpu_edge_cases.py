@@ -49,7 +49,7 @@ def test_rxa_zero_blocks_and_bad_shapes(qh):
 
 def test_constructor_argument_errors(qh):
     for bad in (lambda: qh.FirBank(0, [1.0], 1), lambda: qh.FirBank(1, [1.0], 0), lambda: qh.RationalFir(1, [1.0], 0, 1),
-                lambda: qh.HalfBandCascade(1, 9), lambda: qh.QuiskRxBank(1, 48000, 14), lambda: qh.Panadapter(1, 1000, 100, 48000.0),
+                lambda: qh.HalfBandCascade(1, 9), lambda: qh.QuiskRxBank(1, 48000, 14), lambda: qh.Panadapter(1, 1001, 100, 48000.0),
                 lambda: qh.RxaEngine(1, in_rate=100000), lambda: qh.QuiskAgc(1, sample_rate=100)):
         with pytest.raises(qh.QuiskHipError):
             bad()

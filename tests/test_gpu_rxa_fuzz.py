@@ -19,7 +19,7 @@ NCH = 4
 
 def _apply(rng, targets):
     """Draw one setter call and apply it to every (object, leading-args) pair."""
-    k = int(rng.integers(0, 20))
+    k = int(rng.integers(0, 22))
 
     done = []
 
@@ -68,8 +68,12 @@ def _apply(rng, targets):
         call("SetRXAAMDRun", int(rng.integers(0, 2)))
     elif k == 18:
         call("SetRXABandpassFreqs", float(rng.uniform(-4000, 0)), float(rng.uniform(100, 4000)))
-    else:
+    elif k == 19:
         call("SetRXAAGCTop", float(rng.uniform(40, 100))); call("SetRXAAGCSlope", int(rng.integers(0, 20)))
+    elif k == 20:
+        call("SetRXAAMSQRun", int(rng.integers(0, 2)))
+    else:
+        call("SetRXAAMSQThreshold", float(rng.uniform(-60, -10))); call("SetRXAAMSQMaxTail", float(rng.uniform(0.0, 0.3)))
     return done
 
 

@@ -343,3 +343,38 @@ def test_lms_notch_and_noise_reduction(qh, oracle, which, position, mode):
     ref2 = np.stack([o.xrxa(x[ch, :20 * 1024]) for ch, o in enumerate(refs)])
     for ch in range(nch):
         assert rel_rms(y2[ch], ref2[ch]) < 1e-6
+
+
+@pytest.mark.parametrize("mode,thresh,tail", [(1, -30.0, 0.2), (6, -35.0, 0.05), (1, -20.0, 1.5)])
+def test_am_squelch(qh, oracle, mode, thresh, tail):
+    """xamsqcap / xamsq (wdsp/amsq.c:119-192): the squelch opens and closes on the 10 ms average of the signal behind nbp0,
+    with raised-cosine slews and a tail whose length depends on the level; the input fades in and out twice."""
+    nch, nblk = 2, 260
+    n = nblk * 1024
+    x = synth.make_input_numpy(nch, n)
+    env = np.ones(n)
+    env[40 * 1024:110 * 1024] = 1e-3
+    env[170 * 1024:200 * 1024] = 3e-2
+    x = x * env
+    e = qh.RxaEngine(nch)
+    refs = []
+    for ch in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        for t, a in ((e, (ch,)), (o, ())):
+            t.SetRXAShiftRun(*a, 1); t.SetRXAShiftFreq(*a, synth.shift_freq(ch)); t.RXANBPSetRun(*a, 1)
+            t.SetRXAMode(*a, mode); t.RXASetPassband(*a, *((300.0, 3000.0) if mode == 1 else (-4000.0, 4000.0)))
+            t.SetRXAAGCMode(*a, 0 if ch == 0 else 3)
+            t.SetRXAAMSQThreshold(*a, thresh); t.SetRXAAMSQMaxTail(*a, tail); t.SetRXAAMSQRun(*a, 1)
+        refs.append(o)
+    ys, rs = [], [[] for _ in range(nch)]
+    for a, b in ((0, 50), (50, 51), (51, 180), (180, nblk)):
+        ys.append(e.process_host(x[:, a * 1024:b * 1024]))
+        for ch in range(nch):
+            rs[ch].append(refs[ch].xrxa(x[ch, a * 1024:b * 1024]))
+    y = np.concatenate(ys, axis=1)
+    for ch in range(nch):
+        ref = np.concatenate(rs[ch])
+        muted = np.count_nonzero(ref == 0)
+        assert 1000 < muted < (nblk - 20) * 256                 # it did close (start-up at least), and it did open
+        assert np.array_equal(y[ch] == 0, ref == 0)             # same samples muted
+        assert rel_rms(y[ch], ref) < 1e-9
