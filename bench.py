@@ -207,6 +207,10 @@ def main():
                        "ingest": args.ingest, "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
                        "parallelism": "channel-sharded x%d, no collective" % world},
             "chain_algorithmic_GBps": 20.0 * total / dt / 1e9,
+            # ~650 flop per input sample if the chain is evaluated in direct form like the reference; the
+            # overlap-save kernels execute about a quarter of that, which is how `value` can sit above the fp64-vector bound
+            # the survey derives from this count (78.6e12 / 650 = 121 Gsamp/s)
+            "chain_direct_form_equivalent_TFLOPs": 650.0 * total / dt / 1e12,
             "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
