@@ -87,6 +87,18 @@ int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
 int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
 int qh_rxa_SetRXAFMLimRun(qh_rxa *e, int ch, int run);           /* wdsp/fmd.c:336-347: the FM detector's limiter */
 int qh_rxa_SetRXAFMLimGain(qh_rxa *e, int ch, double gaindB);    /* wdsp/fmd.c:349-362 */
+/* xemnr, WDSP's spectral noise reduction "NR2" (wdsp/emnr.c; setters :1096-1143): overlap-add STFT 4096 / 1024, noise estimate by
+ * minimum statistics (npe 0) or speech presence (npe 1), gain methods 0 Gaussian-amplitude, 1 log-MMSE, 2 gamma tables, 3 trained
+ * zeta tables, post-filter aepf; position 0 (before bp1 and the AGC) or 1.  The tables are the data WDSP loads at create time from
+ * its files `calculus` (GG, GGS: 241 x 241 doubles each) and `zetaHat.bin` (60 x 60 doubles, 60 x 60 int validity flags, ranges in
+ * dB): hand them over once per engine before switching EMNR on.  dsp_size up to 1024. */
+int qh_rxa_SetEMNRTables(qh_rxa *e, const double *GG, const double *GGS, const double *zeta_hat, const int *zeta_valid, double gamma_min,
+                         double gamma_max, double xi_min, double xi_max);
+int qh_rxa_SetRXAEMNRRun(qh_rxa *e, int ch, int run);
+int qh_rxa_SetRXAEMNRgainMethod(qh_rxa *e, int ch, int method);
+int qh_rxa_SetRXAEMNRnpeMethod(qh_rxa *e, int ch, int method);
+int qh_rxa_SetRXAEMNRaeRun(qh_rxa *e, int ch, int run);
+int qh_rxa_SetRXAEMNRPosition(qh_rxa *e, int ch, int position);
 /* xamsqcap / xamsq, the AM squelch (wdsp/amsq.c:119-192; create_amsq arguments RXA.c:158-172) */
 int qh_rxa_SetRXAAMSQRun(qh_rxa *e, int ch, int run);
 int qh_rxa_SetRXAAMSQThreshold(qh_rxa *e, int ch, double threshold_db);
@@ -236,7 +248,11 @@ void SetRXAANRVals(int channel, int taps, int delay, double gain, double leakage
 void SetRXAAMSQRun(int channel, int run);                                        /* wdsp/amsq.c:216-222 */
 void SetRXAAMSQThreshold(int channel, double threshold);                         /* wdsp/amsq.c:224-232, dB */
 void SetRXAAMSQMaxTail(int channel, double tail);                                /* wdsp/amsq.c:234-243, seconds */
-void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c */
+void SetRXAEMNRRun(int channel, int run);                                        /* wdsp/emnr.c:1096-1110; needs the files `calculus` and
+                                                                                    `zetaHat.bin` in the working directory or in $QH_WDSP_DATA, as WDSP reads them (emnr.c:212,317) */
+void SetRXAEMNRnpeMethod(int channel, int method);                               /* wdsp/emnr.c:1120 */
+void SetRXAEMNRaeRun(int channel, int run);                                      /* wdsp/emnr.c:1128 */
+void SetRXAEMNRPosition(int channel, int position);                              /* wdsp/emnr.c:1136 */
 void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */
 void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c */
 

@@ -55,6 +55,7 @@ def lib():
         for n in ("wo_SetRXAMode", "wo_RXASetNC", "wo_SetRXAShiftRun", "wo_RXANBPSetRun", "wo_SetRXABandpassRun",
                   "wo_SetRXAAGCMode", "wo_SetRXAPanelRun", "wo_SetRXAPanelSelect", "wo_SetRXAPanelCopy",
                   "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun", "wo_SetRXAAMDRun", "wo_RXASetMP", "wo_SetRXAFMLimRun",
+                  "wo_SetRXAEMNRRun", "wo_SetRXAEMNRgainMethod", "wo_SetRXAEMNRnpeMethod", "wo_SetRXAEMNRaeRun", "wo_SetRXAEMNRPosition",
                   "wo_SetRXAAMSQRun", "wo_SetRXAANFRun", "wo_SetRXAANRRun", "wo_SetRXAANFPosition", "wo_SetRXAANRPosition"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None
@@ -157,6 +158,24 @@ class Resample:
             self.h = None
 
 
+_EMNR = None
+
+
+def emnr_tables():
+    """GG / GGS / zetaHat (quisk_amd/data/wdsp_emnr_tables.npz, made by tools/extract_wdsp_emnr_tables.py) or None."""
+    global _EMNR
+    if _EMNR is None:
+        path = os.path.join(os.path.dirname(_HERE), "quisk_amd", "data", "wdsp_emnr_tables.npz")
+        if not os.path.exists(path):
+            return None
+        z = np.load(path)
+        _EMNR = {"GG": np.ascontiguousarray(z["GG"], dtype=np.float64), "GGS": np.ascontiguousarray(z["GGS"], dtype=np.float64),
+                 "zeta_hat": np.ascontiguousarray(z["zeta_hat"], dtype=np.float64),
+                 "zeta_valid": np.ascontiguousarray(z["zeta_valid"], dtype=np.int32), "zeta_range": z["zeta_range"],
+                 "zeta_dims": z["zeta_dims"]}
+    return _EMNR
+
+
 class WdspChannel:
     """One oracle RXA channel; method names follow the WDSP exports (minus the channel argument)."""
 
@@ -168,6 +187,12 @@ class WdspChannel:
         self.out_size = self.L.wo_out_size(self.h)
         self.dsp_insize = self.L.wo_dsp_insize(self.h)
         self.dsp_outsize = self.L.wo_dsp_outsize(self.h)
+        t = emnr_tables()
+        if t is not None:       # WDSP reads these from the files `calculus` / `zetaHat.bin` when a channel is created (emnr.c:317-334)
+            self._emnr_tables = t
+            self.L.wo_SetEMNRTables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_double] * 4
+            self.L.wo_SetEMNRTables(self.h, t["GG"].ctypes.data, t["GGS"].ctypes.data, t["zeta_hat"].ctypes.data, t["zeta_valid"].ctypes.data,
+                                    *[float(v) for v in t["zeta_range"]])
 
     def __getattr__(self, name):
         f = getattr(lib(), "wo_" + name)

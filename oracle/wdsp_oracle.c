@@ -9,6 +9,7 @@
 #include <string.h>
 #include "fft_oracle.h"
 #include "wdsp_oracle.h"
+#include "emnr_oracle.h"
 #include "wcpagc_oracle.h"
 
 #define WO_PI    3.1415926535897932   /* wdsp/comm.h:146 */
@@ -545,6 +546,8 @@ struct wo_channel {
     } fmd;
     wo_agc agc;
     struct { int run, nc, wintype, position; double f_low, f_high, gain; wo_fircore *p; } bp1;
+    wo_emnr *emnr;                              /* wdsp/emnr.c, restated in emnr_oracle.c */
+    int emnr_pending_run;                       /* the emnr_run argument of RXAbp1Check (RXA.c:800) */
     /* amsq, wdsp/amsq.h */
     struct {
         int run, state, count, ntup, ntdown;
@@ -1022,7 +1025,7 @@ static void lms_flush(struct wo_lms *a)          /* flush_anf, anf.c:135-140 */
 /* ---- RXAbp1Check / RXAbp1Set (RXA.c:800-827) */
 static void bp1_check(wo_channel *c, int amd_run, int anf_run, int anr_run)
 {
-    double gain = (amd_run || anf_run || anr_run) ? 2.0 : 1.0;      /* snba / emnr never run on this path */
+    double gain = (amd_run || anf_run || anr_run || c->emnr_pending_run) ? 2.0 : 1.0;      /* snba never runs on this path */
     if (c->bp1.gain != gain) {
         double *imp;
         c->bp1.gain = gain;
@@ -1035,7 +1038,7 @@ static void bp1_check(wo_channel *c, int amd_run, int anf_run, int anr_run)
 static void bp1_set(wo_channel *c)
 {
     int old = c->bp1.run;
-    c->bp1.run = (c->amd.run == 1 || c->anf.run == 1 || c->anr.run == 1) ? 1 : 0;
+    c->bp1.run = (c->amd.run == 1 || c->anf.run == 1 || c->anr.run == 1 || *wo_emnr_run(c->emnr) == 1) ? 1 : 0;
     if (!old && c->bp1.run) fircore_flush(c->bp1.p);
 }
 
@@ -1054,10 +1057,12 @@ static void xrxa(wo_channel *c)
     xfmd(c, c->midbuff, n);
     xlms(&c->anf, 0, 0, c->midbuff, n);
     xlms(&c->anr, 1, 0, c->midbuff, n);
+    wo_emnr_exec(c->emnr, 0, c->midbuff);
     if (c->bp1.run && c->bp1.position == 0) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);
     xwcpagc(c, c->midbuff, n);
     xlms(&c->anf, 0, 1, c->midbuff, n);
     xlms(&c->anr, 1, 1, c->midbuff, n);
+    wo_emnr_exec(c->emnr, 1, c->midbuff);
     if (c->bp1.run && c->bp1.position == 1) wo_fircore_exec(c->bp1.p, c->midbuff, c->midbuff);
     meter_exec(&c->agcmeter, c->midbuff, n, c->meter, &c->agc.gain);
     xpanel(c, c->midbuff, n);
@@ -1259,6 +1264,7 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     /* create_wcpagc arguments of create_rxa, RXA.c:335-358 */
     wo_agc_init(&c->agc, 1, 3, 1, dsp_rate, 0.001, 0.250, 4, 10000.0, 1.5, 1000.0, 1.0, 1.0, 0.250, 0.005, 5.0, 1, 0.500, 0.250, 0.250, 0.100);
     c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0; c->bp1.position = 0;
+    c->emnr = wo_emnr_create(dsp_size, dsp_rate);
     /* create_amsq arguments of create_rxa, RXA.c:158-172 */
     c->amsq.run = 0; c->amsq.tail_thresh = 0.009; c->amsq.unmute_thresh = 0.010; c->amsq.min_tail = 0.0; c->amsq.max_tail = 1.5;
     c->amsq.muted_gain = 0.0;
@@ -1288,6 +1294,7 @@ void wo_close(wo_channel *c)
     free(c->fmd.audio);
     free(c->inbuff); free(c->midbuff); free(c->outbuff);
     free(c->amsq.cup); free(c->amsq.cdown); free(c->amsq.trigsig);
+    wo_emnr_free(c->emnr);
     free(c->iob.r1); free(c->iob.r2); free(c->iob.cup);
     wo_agc_free(&c->agc);
     free(c);
@@ -1468,6 +1475,24 @@ void wo_SetRXAAMDRun(wo_channel *c, int run)        /* amd.c:264-277 */
         bp1_set(c);
     }
 }
+/* SetRXAEMNRRun ... SetRXAEMNRPosition, emnr.c:1096-1142 */
+void wo_SetRXAEMNRRun(wo_channel *c, int run)
+{
+    if (*wo_emnr_run(c->emnr) != run) {
+        c->emnr_pending_run = run;
+        bp1_check(c, c->amd.run, c->anf.run, c->anr.run);
+        *wo_emnr_run(c->emnr) = run;
+        bp1_set(c);
+    }
+}
+void wo_SetRXAEMNRgainMethod(wo_channel *c, int method) { wo_emnr_set_gain_method(c->emnr, method); }
+void wo_SetRXAEMNRnpeMethod(wo_channel *c, int method) { wo_emnr_set_npe_method(c->emnr, method); }
+void wo_SetRXAEMNRaeRun(wo_channel *c, int run) { wo_emnr_set_ae_run(c->emnr, run); }
+void wo_SetRXAEMNRPosition(wo_channel *c, int position) { *wo_emnr_position(c->emnr) = position; c->bp1.position = position; }
+void wo_SetEMNRTables(wo_channel *c, const double *GG, const double *GGS, const double *zeta_hat, const int *zeta_true, double gmin, double gmax,
+                      double ximin, double ximax)
+{ wo_emnr_set_tables(c->emnr, GG, GGS, zeta_hat, zeta_true, gmin, gmax, ximin, ximax); }
+
 void wo_SetRXAAMSQRun(wo_channel *c, int run) { c->amsq.run = run; }                 /* amsq.c:216-222 */
 void wo_SetRXAAMSQThreshold(wo_channel *c, double threshold)                         /* amsq.c:224-232 */
 {

@@ -25,6 +25,7 @@
 #include "qh_design.hpp"
 #include "qh_kernels.hpp"
 #include "qh_demod.hpp"
+#include "qh_emnr.hpp"
 #include "qh_internal.hpp"
 
 namespace qh {
@@ -72,6 +73,8 @@ struct ChanCfg {
     int lim_run = 0; double lim_gain = 2.5; bool lim_dirty = true;   // FM detector limiter, fmd.c:106-108
     // anf / anr (create_anf / create_anr of create_rxa, RXA.c:278-315): [0] = anf, [1] = anr
     struct Lms { int run = 0, position = 0, taps = 64, delay = 16; double two_mu = 0.0001, gamma = 0.1; bool dirty = true, flush = false; } lms[2];
+    // emnr (create_emnr of create_rxa, RXA.c:319-332)
+    int emnr_run = 0, emnr_pos = 0, emnr_gain_method = 2, emnr_npe = 0, emnr_ae = 1; bool emnr_dirty = true, emnr_flush = false;
     // amsq (create_amsq of create_rxa, RXA.c:158-172)
     int amsq_run = 0; double amsq_tail_thresh = 0.009, amsq_unmute_thresh = 0.010, amsq_max_tail = 1.5; bool amsq_dirty = true;
     int bp1_pos = 0;                                            // SetRXAANFPosition / SetRXAANRPosition set it too (anf.c:236)
@@ -81,7 +84,8 @@ struct ChanCfg {
     bool nbp_flush = false, bp1_flush = false;
     bool fix_before() const
     {
-        return agc_run && agc_mode == 0 && ((bp1_run && bp1_pos) || (lms[0].run && lms[0].position) || (lms[1].run && lms[1].position));
+        return agc_run && agc_mode == 0 && ((bp1_run && bp1_pos) || (lms[0].run && lms[0].position) || (lms[1].run && lms[1].position) ||
+                                            (emnr_run && emnr_pos));
     }
 };
 
@@ -139,6 +143,15 @@ struct Engine {
     // changes, so it is applied where the reference applies it; [b] = which buffer holds the channel at that point
     int *list_fix[2] = { nullptr, nullptr }, n_fix[2] = { 0, 0 };
     double *fix_gain = nullptr;
+    // emnr: lists like the LMS filters' ([0] position 0; [1 + b] position 1 with the data in cur / other)
+    int *list_emnr[3] = { nullptr, nullptr, nullptr }, n_emnr[3] = { 0, 0, 0 };
+    EmnrParam emnr_prm{};
+    EmnrChan *emnr_chan = nullptr;
+    EmnrScalars *emnr_scal = nullptr;
+    double *emnr_state = nullptr, *emnr_window = nullptr, *emnr_GG = nullptr, *emnr_GGS = nullptr, *emnr_zeta = nullptr;
+    int *emnr_zeta_true = nullptr;
+    bool emnr_tables = false;
+    std::vector<double> h_GG, h_GGS, h_zeta; std::vector<int> h_zeta_true; double h_zrange[4] = { 0, 0, 0, 0 };
     int *list_amsq = nullptr, n_amsq = 0;
     AmsqParam *amsq_prm = nullptr;
     AmsqState *amsq_state = nullptr;
@@ -185,6 +198,7 @@ struct Engine {
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
                   const int *list, int nlist);
     int ensure_buffers(long long n_mid);
+    int emnr_alloc();
     int process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     int process_chain(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     qh_rat *rsmpout = nullptr;          // xresample out (wdsp/RXA.c:596), only when out_rate != dsp_rate
@@ -205,6 +219,8 @@ Engine::~Engine()
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
+    (void)hipFree(emnr_chan); (void)hipFree(emnr_scal); (void)hipFree(emnr_state); (void)hipFree(emnr_window); (void)hipFree(emnr_GG);
+    (void)hipFree(emnr_GGS); (void)hipFree(emnr_zeta); (void)hipFree(emnr_zeta_true);
     (void)hipFree(amsq_prm); (void)hipFree(amsq_state); (void)hipFree(amsq_cup); (void)hipFree(amsq_cdown); (void)hipFree(amsq_mag);
     (void)hipFree(fix_gain); (void)hipFree(lms_prm[0]); (void)hipFree(lms_prm[1]); (void)hipFree(lms_state[0]); (void)hipFree(lms_state[1]);
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
@@ -420,8 +436,9 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 18));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 21));
         list_amsq = list_buf + 17 * nch;
+        for (int k = 0; k < 3; k++) list_emnr[k] = list_buf + (18 + k) * nch;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
         list_bp1p[0] = list_buf + 13 * nch; list_bp1p[1] = list_buf + 14 * nch;
         list_fix[0] = list_buf + 15 * nch; list_fix[1] = list_buf + 16 * nch;
@@ -494,10 +511,11 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3];
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
             if (c.amsq_run) lsq.push_back(ch);
+            if (c.emnr_run) lem[c.emnr_pos ? 1 + ((c.bp1_run && !c.bp1_pos) ? 1 : 0) : 0].push_back(ch);
             const int at_agc = (c.bp1_run && !c.bp1_pos) ? 1 : 0;       // the buffer the channel is in when xwcpagc runs
             for (int f = 0; f < 2; f++) if (c.lms[f].run) lms_l[f][c.lms[f].position ? 1 + at_agc : 0].push_back(ch);
             if (c.bp1_run) lbp[c.bp1_pos ? 1 : 0].push_back(ch);
@@ -515,6 +533,8 @@ int Engine::refresh_demod()
         n_bp1p[0] = (int)lbp[0].size(); n_bp1p[1] = (int)lbp[1].size();
         n_fix[0] = (int)lfix[0].size(); n_fix[1] = (int)lfix[1].size();
         n_amsq = (int)lsq.size();
+        for (int k = 0; k < 3; k++) n_emnr[k] = (int)lem[k].size();
+        if ((n_emnr[0] || n_emnr[1] || n_emnr[2]) && !emnr_state) if (int rc = emnr_alloc()) return rc;
         if (n_amsq && !amsq_prm) {
             QH_HIP(dev_alloc(&amsq_prm, (size_t)nch));
             QH_HIP(dev_alloc(&amsq_state, (size_t)nch));
@@ -569,6 +589,7 @@ int Engine::refresh_demod()
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) QH_HIP(put(list_lms[f][k], lms_l[f][k]));
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
         QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1])); QH_HIP(put(list_amsq, lsq));
+        for (int k = 0; k < 3; k++) QH_HIP(put(list_emnr[k], lem[k]));
         std::vector<double> fg((size_t)nch);
         for (int ch = 0; ch < nch; ch++) fg[(size_t)ch] = cfg[(size_t)ch].agc_fixed;
         QH_HIP(hipMemcpyAsync(fix_gain, fg.data(), fg.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -615,6 +636,24 @@ int Engine::refresh_demod()
             QH_HIP(hipMemcpyAsync(agc_prm + ch, &q, sizeof(q), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.agc_dirty = false;
+        }
+        if (emnr_chan && c.emnr_dirty) {
+            if (c.emnr_run && (c.emnr_npe < 0 || c.emnr_npe > 1 || c.emnr_gain_method < 0 || c.emnr_gain_method > 3))
+                return set_error(QH_ERR_UNSUPPORTED, "EMNR: gain methods 0..3 and noise estimators 0 (minimum statistics), 1 (speech presence)");
+            const EmnrChan ec{ c.emnr_gain_method, c.emnr_npe, c.emnr_ae, 0 };
+            QH_HIP(hipMemcpyAsync(emnr_chan + ch, &ec, sizeof(ec), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.emnr_dirty = false;
+        }
+        if (emnr_state && c.emnr_flush) {           // flush_emnr, emnr.c:583-596: the accumulators and their indices, not the estimators
+            EmnrScalars sc;
+            QH_HIP(hipMemcpyAsync(&sc, emnr_scal + ch, sizeof(sc), hipMemcpyDeviceToHost, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            sc.iainidx = sc.iaoutidx = sc.oaoutidx = sc.nsamps = sc.saveidx = 0; sc.oainidx = emnr_prm.init_oainidx;
+            QH_HIP(hipMemcpyAsync(emnr_scal + ch, &sc, sizeof(sc), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemsetAsync(emnr_state + (size_t)ch * kEmnrStateDoubles, 0, (size_t)EO_PREVG * sizeof(double), stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.emnr_flush = false;
         }
         if (amsq_prm && c.amsq_dirty) {
             // calc_amsq, amsq.c:48-64: 10 ms average (RXA.c:165)
@@ -719,6 +758,103 @@ int Engine::refresh_demod()
         }
         fm_nc_built = want_nc;
     }
+    return QH_OK;
+}
+
+// calc_emnr (wdsp/emnr.c:240-497) with create_rxa's arguments (RXA.c:319-332): parameters, window, start values of every array
+int Engine::emnr_alloc()
+{
+    if (dsp_size > kEmnrIncr) return set_error(QH_ERR_UNSUPPORTED, "EMNR: dsp_size up to %d", kEmnrIncr);
+    const double rate = (double)dsp_rate, incr = (double)kEmnrIncr;
+    EmnrParam &q = emnr_prm;
+    auto tc = [&](double base) { const double tau = -128.0 / 8000.0 / std::log(base); return std::exp(-incr / rate / tau); };
+    q.gain = 1.0 / kEmnrF / 4.0;
+    q.gf1p5 = std::sqrt(kPiRef) / 2.0;
+    q.alpha = tc(0.985);
+    q.eps_floor = 1.0e-300; q.gamma_max = 40.0; q.xi_min = std::pow(10.0, -40.0 / 10.0); q.q = 0.2; q.gmax = 10000.0;
+    q.dim_zeta = 60; q.zeta_thresh = -2.0;
+    q.z_gamma_min = h_zrange[0]; q.z_gamma_max = h_zrange[1]; q.z_xihat_min = h_zrange[2]; q.z_xihat_max = h_zrange[3];
+    q.alphaCsmooth = tc(0.7); q.alphaMax = tc(0.96); q.alphaCmin = tc(0.7); q.alphaMin_max_value = tc(0.3);
+    q.snrq = -incr / (0.064 * rate);
+    q.betamax = tc(0.8);
+    q.invQeqMax = 0.5; q.av = 2.12;
+    const double Dtime = 8.0 * 12.0 * 128.0 / 8000.0;
+    q.U = 8;
+    q.V = (int)(0.5 + (Dtime * rate / (q.U * incr)));
+    if (q.V < 4) q.V = 4;
+    if ((q.U = (int)(0.5 + (Dtime * rate / (q.V * incr)))) < 1) q.U = 1;
+    if (q.U > kEmnrU) return set_error(QH_ERR_UNSUPPORTED, "EMNR: %d minimum sub-windows at this rate (up to %d)", q.U, kEmnrU);
+    q.D = q.U * q.V;
+    {
+        static const double Dvals[18] = { 1.0, 2.0, 5.0, 8.0, 10.0, 15.0, 20.0, 30.0, 40.0, 60.0, 80.0, 120.0, 140.0, 160.0, 180.0, 220.0, 260.0, 300.0 };
+        static const double Mvals[18] = { 0.000, 0.260, 0.480, 0.580, 0.610, 0.668, 0.705, 0.762, 0.800, 0.841, 0.865, 0.890, 0.900, 0.910,
+                                          0.920, 0.930, 0.935, 0.940 };
+        auto interpM = [&](double x) {              // emnr.c:185-202
+            if (x <= Dvals[0]) return Mvals[0];
+            if (x >= Dvals[17]) return Mvals[17];
+            int idx = 0;
+            while (x >= Dvals[idx]) idx++;
+            const double xllow = std::log10(Dvals[idx - 1]), xlhigh = std::log10(Dvals[idx]);
+            const double frac = (std::log10(x) - xllow) / (xlhigh - xllow);
+            return Mvals[idx - 1] + frac * (Mvals[idx] - Mvals[idx - 1]);
+        };
+        q.MofD = interpM((double)q.D); q.MofV = interpM((double)q.V);
+    }
+    q.invQbar_points[0] = 0.03; q.invQbar_points[1] = 0.05; q.invQbar_points[2] = 0.06; q.invQbar_points[3] = 1.0e300;
+    {
+        const double f[4] = { 8.0, 4.0, 2.0, 1.2 };
+        for (int i = 0; i < 4; i++) {
+            const double db = 10.0 * std::log10(f[i]) / (12.0 * 128 / 8000);
+            q.nsmax[i] = std::pow(10.0, db / 10.0 * q.V * incr / rate);
+        }
+    }
+    q.alpha_pow = tc(0.8); q.alpha_Pbar = tc(0.9);
+    q.epsH1 = std::pow(10.0, 15.0 / 10.0); q.epsH1r = q.epsH1 / (1.0 + q.epsH1);
+    q.zetaThresh = 0.75; q.psi = 20.0; q.t2 = 0.20;
+    q.bsize = dsp_size;
+    q.oasize = dsp_size > kEmnrIncr ? dsp_size : kEmnrIncr;
+    q.init_oainidx = (kEmnrF - dsp_size - kEmnrIncr) % q.oasize;
+    // window (calc_window, wintype 0, emnr.c:160-183)
+    std::vector<double> win(kEmnrF);
+    {
+        const double arg = 2.0 * kPiRef / (double)kEmnrF;
+        double sum = 0.0;
+        for (int i = 0; i < kEmnrF; i++) { win[(size_t)i] = std::sqrt(0.54 - 0.46 * std::cos((double)i * arg)); sum += win[(size_t)i]; }
+        const double inv_coherent_gain = (double)kEmnrF / sum;
+        for (double &w : win) w *= inv_coherent_gain;
+    }
+    // start values (emnr.c:309-313,409-426,452-456)
+    std::vector<double> st((size_t)kEmnrStateDoubles, 0.0);
+    for (int k = 0; k < kEmnrM; k++) {
+        st[(size_t)(EO_PREVG + k)] = 1.0; st[(size_t)(EO_PREVM + k)] = 1.0;
+        st[(size_t)(EO_P + k)] = 0.5; st[(size_t)(EO_SIG + k)] = 0.5; st[(size_t)(EO_PBAR + k)] = 0.5; st[(size_t)(EO_PMINU + k)] = 0.5;
+        st[(size_t)(EO_P2BAR + k)] = 0.25;
+        st[(size_t)(EO_ACTMIN + k)] = 1.0e300; st[(size_t)(EO_ACTSUB + k)] = 1.0e300;
+        for (int ku = 0; ku < kEmnrU; ku++) st[(size_t)(EO_AMB + ku * kEmnrPad + k)] = 1.0e300;
+        st[(size_t)(EO_SSIG + k)] = 0.5; st[(size_t)(EO_SPBAR + k)] = 0.5;
+    }
+    QH_HIP(dev_alloc(&emnr_state, (size_t)nch * kEmnrStateDoubles));
+    QH_HIP(dev_alloc(&emnr_scal, (size_t)nch));
+    QH_HIP(dev_alloc(&emnr_chan, (size_t)nch));
+    QH_HIP(dev_alloc(&emnr_window, (size_t)kEmnrF));
+    QH_HIP(dev_alloc(&emnr_GG, (size_t)241 * 241));
+    QH_HIP(dev_alloc(&emnr_GGS, (size_t)241 * 241));
+    QH_HIP(dev_alloc(&emnr_zeta, (size_t)3600));
+    QH_HIP(dev_alloc(&emnr_zeta_true, (size_t)3600));
+    const EmnrScalars sc0{ 0, 0, q.init_oainidx, 0, 0, 0, q.V, 0, 1.0 };
+    for (int ch = 0; ch < nch; ch++) {
+        QH_HIP(hipMemcpyAsync(emnr_state + (size_t)ch * kEmnrStateDoubles, st.data(), st.size() * 8, hipMemcpyHostToDevice, stream));
+        QH_HIP(hipMemcpyAsync(emnr_scal + ch, &sc0, sizeof(sc0), hipMemcpyHostToDevice, stream));
+    }
+    QH_HIP(hipMemcpyAsync(emnr_window, win.data(), win.size() * 8, hipMemcpyHostToDevice, stream));
+    QH_HIP(hipMemcpyAsync(emnr_GG, h_GG.data(), h_GG.size() * 8, hipMemcpyHostToDevice, stream));
+    QH_HIP(hipMemcpyAsync(emnr_GGS, h_GGS.data(), h_GGS.size() * 8, hipMemcpyHostToDevice, stream));
+    QH_HIP(hipMemcpyAsync(emnr_zeta, h_zeta.data(), h_zeta.size() * 8, hipMemcpyHostToDevice, stream));
+    QH_HIP(hipMemcpyAsync(emnr_zeta_true, h_zeta_true.data(), h_zeta_true.size() * 4, hipMemcpyHostToDevice, stream));
+    QH_HIP(hipStreamSynchronize(stream));
+    QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&emnr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, emnr_lds_bytes()));
+    dev_bytes += (long long)nch * (kEmnrStateDoubles * 8 + sizeof(EmnrScalars) + sizeof(EmnrChan)) + 2 * 241 * 241 * 8;
+    for (ChanCfg &c : cfg) { c.emnr_dirty = true; c.emnr_flush = false; }
     return QH_OK;
 }
 
@@ -875,7 +1011,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
-        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || meters_on) mixed = true;
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || meters_on) mixed = true;
+        if (c.emnr_run && !emnr_tables) return set_error(QH_ERR_INVALID, "EMNR needs its gain tables first (qh_rxa_SetEMNRTables: WDSP's `calculus` and `zetaHat.bin` data)");
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
@@ -972,6 +1109,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         for (int f = 0; f < 2; f++)
             if (n_lms[f][k]) hipLaunchKernelGGL(lms_kernel, dim3((unsigned)n_lms[f][k]), dim3(64), 0, stream, b, buf_cap, (int)n_mid,
                                                 list_lms[f][k], lms_prm[f], lms_state[f]);
+        if (n_emnr[k])          // xemnr follows xanf and xanr at either position (RXA.c:581,585)
+            hipLaunchKernelGGL(emnr_kernel, dim3((unsigned)n_emnr[k]), dim3(NT), (size_t)emnr_lds_bytes(), stream, b, buf_cap, nblk, list_emnr[k],
+                               emnr_prm, emnr_chan, emnr_scal, emnr_state, emnr_window, tw4096, emnr_GG, emnr_GGS, emnr_zeta, emnr_zeta_true);
     };
     auto bp1_at = [&](int ps) {
         int hc = cur_bp1;
@@ -1082,15 +1222,16 @@ long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
     } while (0)
 
 // RXAbp1Check + RXAbp1Set, wdsp/RXA.c:800-827 (snba/emnr/anf/anr never run here)
-static void bp1_check_set(ChanCfg &c, int amd_run, int anf_run, int anr_run)
+static void bp1_check_set(ChanCfg &c, int amd_run, int anf_run, int anr_run, int emnr_run = -1)
 {
-    const double gain = (amd_run || anf_run || anr_run) ? 2.0 : 1.0;
+    if (emnr_run < 0) emnr_run = c.emnr_run;
+    const double gain = (amd_run || anf_run || anr_run || emnr_run) ? 2.0 : 1.0;
     if (c.bp1_gain != gain) { c.bp1_gain = gain; c.bp1_dirty = true; }
 }
 static void bp1_set(ChanCfg &c)
 {
     const int old = c.bp1_run;
-    c.bp1_run = (c.amd_run || c.lms[0].run || c.lms[1].run) ? 1 : 0;
+    c.bp1_run = (c.amd_run || c.lms[0].run || c.lms[1].run || c.emnr_run) ? 1 : 0;
     if (old != c.bp1_run) c.bp1_dirty = true;
     if (!old && c.bp1_run) c.bp1_flush = true;
 }
@@ -1267,6 +1408,54 @@ int qh_rxa_SetRXAFMLimGain(qh_rxa *h, int ch, double gaindB)
 {
     const double gain = std::pow(10.0, gaindB / 20.0);
     FOR_CH(h, ch, { if (c.lim_gain != gain) { c.lim_gain = gain; c.lim_dirty = true; } });
+}
+
+// SetRXAEMNRRun ... SetRXAEMNRPosition, wdsp/emnr.c:1096-1143
+int qh_rxa_SetRXAEMNRRun(qh_rxa *h, int ch, int run)
+{
+    if (h && run && !h->e.emnr_tables)
+        return set_error(QH_ERR_INVALID, "EMNR needs its gain tables first (qh_rxa_SetEMNRTables: WDSP's `calculus` and `zetaHat.bin` data)");
+    if (h && run && h->e.dsp_size > kEmnrIncr) return set_error(QH_ERR_UNSUPPORTED, "EMNR: dsp_size up to %d", kEmnrIncr);
+    FOR_CH(h, ch, {
+        run = run ? 1 : 0;
+        if (c.emnr_run != run) {
+            bp1_check_set(c, c.amd_run, c.lms[0].run, c.lms[1].run, run);
+            c.emnr_run = run;
+            bp1_set(c);
+            c.epi_dirty = true;
+            h->e.lists_dirty = true;
+        }
+    });
+}
+int qh_rxa_SetRXAEMNRgainMethod(qh_rxa *h, int ch, int method) { FOR_CH(h, ch, { c.emnr_gain_method = method; c.emnr_dirty = true; }); }
+int qh_rxa_SetRXAEMNRnpeMethod(qh_rxa *h, int ch, int method) { FOR_CH(h, ch, { c.emnr_npe = method; c.emnr_dirty = true; }); }
+int qh_rxa_SetRXAEMNRaeRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.emnr_ae = run ? 1 : 0; c.emnr_dirty = true; }); }
+int qh_rxa_SetRXAEMNRPosition(qh_rxa *h, int ch, int position)
+{
+    FOR_CH(h, ch, { c.emnr_pos = position ? 1 : 0; c.bp1_pos = position ? 1 : 0; c.epi_dirty = true; h->e.lists_dirty = true; });
+}
+// The data WDSP reads at create time from the files `calculus` (GG, GGS: 241 x 241 each) and `zetaHat.bin` (60 x 60 values, validity
+// flags and their gamma / xi ranges in dB), emnr.c:206-238,317-334
+int qh_rxa_SetEMNRTables(qh_rxa *h, const double *GG, const double *GGS, const double *zeta_hat, const int *zeta_true, double gamma_min,
+                         double gamma_max, double xi_min, double xi_max)
+{
+    if (!h || !GG || !GGS || !zeta_hat || !zeta_true) return set_error(QH_ERR_INVALID, "qh_rxa_SetEMNRTables: null table");
+    Engine &e = h->e;
+    e.epoch++;
+    e.h_GG.assign(GG, GG + 241 * 241); e.h_GGS.assign(GGS, GGS + 241 * 241);
+    e.h_zeta.assign(zeta_hat, zeta_hat + 3600); e.h_zeta_true.assign(zeta_true, zeta_true + 3600);
+    e.h_zrange[0] = gamma_min; e.h_zrange[1] = gamma_max; e.h_zrange[2] = xi_min; e.h_zrange[3] = xi_max;
+    e.emnr_tables = true;
+    if (e.emnr_GG) {            // already on the device: refresh
+        QH_HIP(hipSetDevice(e.device));
+        QH_HIP(hipMemcpyAsync(e.emnr_GG, GG, 241 * 241 * 8, hipMemcpyHostToDevice, e.stream));
+        QH_HIP(hipMemcpyAsync(e.emnr_GGS, GGS, 241 * 241 * 8, hipMemcpyHostToDevice, e.stream));
+        QH_HIP(hipMemcpyAsync(e.emnr_zeta, zeta_hat, 3600 * 8, hipMemcpyHostToDevice, e.stream));
+        QH_HIP(hipMemcpyAsync(e.emnr_zeta_true, zeta_true, 3600 * 4, hipMemcpyHostToDevice, e.stream));
+        QH_HIP(hipStreamSynchronize(e.stream));
+        e.emnr_prm.z_gamma_min = gamma_min; e.emnr_prm.z_gamma_max = gamma_max; e.emnr_prm.z_xihat_min = xi_min; e.emnr_prm.z_xihat_max = xi_max;
+    }
+    return QH_OK;
 }
 
 // SetRXAANFRun ... SetRXAANFPosition (wdsp/anf.c:175-239) and the ANR twins (wdsp/anr.c:175-238); which = 0 anf, 1 anr
@@ -1467,7 +1656,7 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
         }
     }
-    for (ChanCfg &c : e.cfg) c.lms[0].flush = c.lms[1].flush = true;        // flush_anf / flush_anr, RXA.c:541-542
+    for (ChanCfg &c : e.cfg) { c.lms[0].flush = c.lms[1].flush = true; c.emnr_flush = true; }    // flush_anf / flush_anr / flush_emnr, RXA.c:541-543
     if (e.amsq_state) QH_HIP(hipMemsetAsync(e.amsq_state, 0, (size_t)e.nch * sizeof(AmsqState), e.stream));     // flush_amsq
     if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch
         QH_HIP(hipMemsetAsync(e.am_state, 0, (size_t)e.nch * sizeof(AmState), e.stream));

@@ -10,7 +10,9 @@
 // deterministic: output lags input by (DSP_MULT-1)*r2_size + dsp_outsize samples.  The same
 // sequence is executed here synchronously on the calling thread.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -27,7 +29,7 @@ constexpr double kPi = 3.1415926535897932;
 enum { SL_BEGIN = 0, SL_DELAYUP, SL_UPSLEW, SL_ON, SL_DELAYDOWN, SL_DOWNSLEW, SL_ZERO, SL_OFF };  // iobuffs.c:36-46
 
 struct Chan {
-    bool open = false;
+    bool open = false, emnr_tables = false;
     qh_rxa *eng = nullptr;
     int in_size = 0, dsp_size = 0, in_rate = 0, dsp_rate = 0, out_rate = 0;
     int dsp_insize = 0, dsp_outsize = 0, out_size = 0;
@@ -304,6 +306,7 @@ void CloseChannel(int channel)
     qh_rxa_destroy(c.eng);
     c.eng = nullptr;
     c.open = false;
+    c.emnr_tables = false;
 }
 
 int SetChannelState(int channel, int state, int dmode)
@@ -410,6 +413,43 @@ void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMo
 void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
 void SetRXAFMLimRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAFMLimRun(L.c->eng, 0, run)); }
 void SetRXAFMLimGain(int channel, double gaindB) { WDSP_SETTER(qh_rxa_SetRXAFMLimGain(L.c->eng, 0, gaindB)); }
+// EMNR, wdsp/emnr.c:1096-1143.  Its tables come from the files WDSP itself reads at create time (emnr.c:212,317): `calculus` and
+// `zetaHat.bin`, looked for in $QH_WDSP_DATA and in the working directory; without them EMNR cannot be switched on.
+static bool load_emnr_tables(Chan &c)
+{
+    std::vector<double> gg(2 * 241 * 241), zeta(3600);
+    std::vector<int> valid(3600);
+    double range[4];
+    int dims[2];
+    const char *dir = std::getenv("QH_WDSP_DATA");
+    for (int pass = 0; pass < 2; pass++) {
+        const std::string base = pass == 0 ? (dir ? std::string(dir) + "/" : std::string()) : std::string();
+        if (pass == 0 && !dir) continue;
+        FILE *f1 = std::fopen((base + "calculus").c_str(), "rb"), *f2 = std::fopen((base + "zetaHat.bin").c_str(), "rb");
+        bool ok = f1 && f2 && std::fread(gg.data(), 8, gg.size(), f1) == gg.size() && std::fread(dims, 4, 2, f2) == 2 &&
+                  dims[0] == 60 && dims[1] == 60 && std::fread(range, 8, 4, f2) == 4 && std::fread(zeta.data(), 8, 3600, f2) == 3600 &&
+                  std::fread(valid.data(), 4, 3600, f2) == 3600;
+        if (f1) std::fclose(f1);
+        if (f2) std::fclose(f2);
+        if (ok) return qh_rxa_SetEMNRTables(c.eng, gg.data(), gg.data() + 241 * 241, zeta.data(), valid.data(), range[0], range[1], range[2], range[3]) == QH_OK;
+    }
+    return false;
+}
+void SetRXAEMNRRun(int channel, int run)
+{
+    g_status = QH_OK;
+    Locked L(channel);
+    if (!L.c) return;
+    if (run && !L.c->emnr_tables) {
+        L.c->emnr_tables = load_emnr_tables(*L.c);
+        if (!L.c->emnr_tables) { g_status = qh::set_error(QH_ERR_INVALID, "SetRXAEMNRRun: WDSP's data files `calculus` and `zetaHat.bin` were not found (working directory or $QH_WDSP_DATA)"); return; }
+    }
+    const int rc = qh_rxa_SetRXAEMNRRun(L.c->eng, 0, run);
+    if (rc) g_status = rc;
+}
+void SetRXAEMNRnpeMethod(int channel, int method) { WDSP_SETTER(qh_rxa_SetRXAEMNRnpeMethod(L.c->eng, 0, method)); }
+void SetRXAEMNRaeRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAEMNRaeRun(L.c->eng, 0, run)); }
+void SetRXAEMNRPosition(int channel, int position) { WDSP_SETTER(qh_rxa_SetRXAEMNRPosition(L.c->eng, 0, position)); }
 // the AM squelch, wdsp/amsq.c:216-243
 void SetRXAAMSQRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMSQRun(L.c->eng, 0, run)); }
 void SetRXAAMSQThreshold(int channel, double threshold) { WDSP_SETTER(qh_rxa_SetRXAAMSQThreshold(L.c->eng, 0, threshold)); }
@@ -546,8 +586,7 @@ void RXASetMP(int channel, int mp) { WDSP_SETTER(qh_rxa_RXASetMP(L.c->eng, 0, mp
         if (!valid(channel)) return;                                                               \
         if (run) g_status = qh::set_error(QH_ERR_UNSUPPORTED, #name "(%d, 1): block is outside the GPU hot path", channel); \
     }
-// SetRXAEMNRgainMethod (wdsp/emnr.c:1112): a parameter of the noise-reduction block, which never runs here
-void SetRXAEMNRgainMethod(int channel, int method) { (void)method; g_status = QH_OK; (void)valid(channel); }
+void SetRXAEMNRgainMethod(int channel, int method) { WDSP_SETTER(qh_rxa_SetRXAEMNRgainMethod(L.c->eng, 0, method)); }      // emnr.c:1112
 
 // fexchange2 (wdsp/iobuffs.c:518-582): the same exchange with separate float I and Q buffers (INREAL / OUTREAL are
 // float, wdsp/comm.h:119-120); upslew2 / downslew2 are the slews of fexchange0 on that layout
@@ -568,7 +607,6 @@ void fexchange2(int channel, float *Iin, float *Qin, float *Iout, float *Qout, i
     for (int i = 0; i < out_size; i++) { Iout[i] = (float)out[2 * (size_t)i]; Qout[i] = (float)out[2 * (size_t)i + 1]; }
 }
 
-WDSP_OFF_ONLY(SetRXAEMNRRun)
 WDSP_OFF_ONLY(SetRXASNBARun)
 
 }  // extern "C"

@@ -42,6 +42,7 @@ def load():
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
               "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease",
+              "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition",
               "SetRXAAMSQRun", "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay",
               "SetRXAANRPosition"):
         f = getattr(L, "qh_rxa_" + n)
@@ -65,6 +66,7 @@ def load():
         f.restype = i
     for n in ("SetRXAANFVals", "SetRXAANRVals"):
         getattr(L, "qh_rxa_" + n).argtypes = [vp, i, i, i, d, d]
+    L.qh_rxa_SetEMNRTables.argtypes = [vp, vp, vp, vp, vp, d, d, d, d]
     L.qh_rxa_process.argtypes = [vp, vp, ll, vp, ll, i]
     L.qh_rxa_process.restype = i
     L.qh_rxa_process_host.argtypes = [vp, vp, ll, vp, ll, i]

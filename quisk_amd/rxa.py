@@ -17,6 +17,7 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold", "RXASetMP",
             "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease", "RXANBPSetTuneFrequency",
             "RXANBPSetShiftFrequency", "SetRXAFMLimRun", "SetRXAFMLimGain",
+            "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition",
             "SetRXAAMSQRun", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANFGain", "SetRXAANFLeakage", "SetRXAANFVals",
             "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay", "SetRXAANRPosition", "SetRXAANRGain", "SetRXAANRLeakage", "SetRXAANRVals")
 
@@ -32,6 +33,18 @@ class RxaEngine:
         self.nch = nch
         self.dsp_insize = self._L.qh_rxa_dsp_insize(self._h)
         self.dsp_outsize = self._L.qh_rxa_dsp_outsize(self._h)
+        self._emnr = None
+
+    def load_emnr_tables(self, path=None):
+        """EMNR's gain tables (WDSP's `calculus` / `zetaHat.bin` data, extracted by tools/extract_wdsp_emnr_tables.py)."""
+        import os
+        path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "wdsp_emnr_tables.npz")
+        z = np.load(path)
+        t = [np.ascontiguousarray(z["GG"], dtype=np.float64), np.ascontiguousarray(z["GGS"], dtype=np.float64),
+             np.ascontiguousarray(z["zeta_hat"], dtype=np.float64), np.ascontiguousarray(z["zeta_valid"], dtype=np.int32)]
+        r = [float(v) for v in z["zeta_range"]]
+        check(self._L.qh_rxa_SetEMNRTables(self._h, t[0].ctypes.data, t[1].ctypes.data, t[2].ctypes.data, t[3].ctypes.data, *r))
+        self._emnr = t
 
     def __getattr__(self, name):
         if name in _SETTERS:
