@@ -88,7 +88,7 @@ int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:2
 int qh_rxa_SetRXAFMLimRun(qh_rxa *e, int ch, int run);           /* wdsp/fmd.c:336-347: the FM detector's limiter */
 int qh_rxa_SetRXAFMLimGain(qh_rxa *e, int ch, double gaindB);    /* wdsp/fmd.c:349-362 */
 /* xemnr, WDSP's spectral noise reduction "NR2" (wdsp/emnr.c; setters :1096-1143): overlap-add STFT 4096 / 1024, noise estimate by
- * minimum statistics (npe 0) or speech presence (npe 1), gain methods 0 Gaussian-amplitude, 1 log-MMSE, 2 gamma tables, 3 trained
+ * minimum statistics (npe 0), speech presence (npe 1) or LambdaDl (npe 2), gain methods 0 Gaussian-amplitude, 1 log-MMSE, 2 gamma tables, 3 trained
  * zeta tables, post-filter aepf; position 0 (before bp1 and the AGC) or 1.  The tables are the data WDSP loads at create time from
  * its files `calculus` (GG, GGS: 241 x 241 doubles each) and `zetaHat.bin` (60 x 60 doubles, 60 x 60 int validity flags, ranges in
  * dB): hand them over once per engine before switching EMNR on.  dsp_size up to 1024. */
@@ -99,6 +99,10 @@ int qh_rxa_SetRXAEMNRgainMethod(qh_rxa *e, int ch, int method);
 int qh_rxa_SetRXAEMNRnpeMethod(qh_rxa *e, int ch, int method);
 int qh_rxa_SetRXAEMNRaeRun(qh_rxa *e, int ch, int run);
 int qh_rxa_SetRXAEMNRPosition(qh_rxa *e, int ch, int position);
+int qh_rxa_SetRXAEMNRaeZetaThresh(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAEMNRaePsi(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAEMNRtrainZetaThresh(qh_rxa *e, int ch, double v);
+int qh_rxa_SetRXAEMNRtrainT2(qh_rxa *e, int ch, double v);
 /* xamsqcap / xamsq, the AM squelch (wdsp/amsq.c:119-192; create_amsq arguments RXA.c:158-172) */
 int qh_rxa_SetRXAAMSQRun(qh_rxa *e, int ch, int run);
 int qh_rxa_SetRXAAMSQThreshold(qh_rxa *e, int ch, double threshold_db);
@@ -253,6 +257,11 @@ void SetRXAEMNRRun(int channel, int run);                                       
 void SetRXAEMNRnpeMethod(int channel, int method);                               /* wdsp/emnr.c:1120 */
 void SetRXAEMNRaeRun(int channel, int run);                                      /* wdsp/emnr.c:1128 */
 void SetRXAEMNRPosition(int channel, int position);                              /* wdsp/emnr.c:1136 */
+void SetRXAEMNRaeZetaThresh(int channel, double v);
+void SetRXAEMNRaePsi(int channel, double v);
+void SetRXAEMNRtrainZetaThresh(int channel, double v);
+void SetRXAEMNRtrainT2(int channel, double v);
+
 void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */
 void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c */
 

@@ -31,6 +31,8 @@ struct wo_emnr {
     int *k_mod, *lmin_flag;
     /* nps */
     double alpha_pow, alpha_Pbar, epsH1, epsH1r, *s_sigma2N, *PH1y, *Pbar, *EN2y;
+    /* npl */
+    double l_eta, l_gamma, l_beta, l_alpha_d, l_alpha_p, delta_LF, delta_MF, delta_0, delta_1, delta_2, *lP, *lPmin, *lp, *lD;
     /* ae */
     double zetaThresh, psi, t2, *nmask;
 };
@@ -189,6 +191,15 @@ wo_emnr *wo_emnr_create(int bsize, int rate)    /* create_emnr with create_rxa's
     a->epsH1 = pow(10.0, 15.0 / 10.0); a->epsH1r = a->epsH1 / (1.0 + a->epsH1);
     a->s_sigma2N = dz(a->msize); a->PH1y = dz(a->msize); a->Pbar = dz(a->msize); a->EN2y = dz(a->msize);
     for (i = 0; i < a->msize; i++) { a->s_sigma2N[i] = 0.5; a->Pbar[i] = 0.5; }
+    /* npl (emnr.c:458-489) */
+    a->lP = dz(a->msize); a->lPmin = dz(a->msize); a->lp = dz(a->msize); a->lD = dz(a->msize);
+    tau = -256.0 / (20100.0 * log(0.7));   a->l_eta = exp(-a->incr / (a->rate * tau));
+    tau = -256.0 / (20100.0 * log(0.998)); a->l_gamma = exp(-a->incr / (a->rate * tau));
+    tau = -256.0 / (20100.0 * log(0.8));   a->l_beta = exp(-a->incr / (a->rate * tau));
+    tau = -256.0 / (20100.0 * log(0.85));  a->l_alpha_d = exp(-a->incr / (a->rate * tau));
+    tau = -256.0 / (20100.0 * log(0.2));   a->l_alpha_p = exp(-a->incr / (a->rate * tau));
+    a->delta_LF = 1000.0 / (a->rate / 2) * a->msize; a->delta_MF = 3000.0 / (a->rate / 2) * a->msize;
+    a->delta_0 = 2.0; a->delta_1 = 2.0; a->delta_2 = 5.0;
     /* ae */
     a->zetaThresh = 0.75; a->psi = 20.0; a->t2 = 0.20; a->nmask = dz(a->msize);
     return a;
@@ -204,7 +215,7 @@ void wo_emnr_free(wo_emnr *a)
     free(a->p); free(a->alphaOptHat); free(a->alphaHat); free(a->sigma2N); free(a->pbar); free(a->p2bar); free(a->Qeq); free(a->bmin);
     free(a->bmin_sub); free(a->k_mod); free(a->actmin); free(a->actmin_sub); free(a->lmin_flag); free(a->pmin_u);
     for (i = 0; i < 16; i++) free(a->actminbuff[i]);
-    free(a->s_sigma2N); free(a->PH1y); free(a->Pbar); free(a->EN2y); free(a->nmask);
+    free(a->s_sigma2N); free(a->PH1y); free(a->Pbar); free(a->EN2y); free(a->nmask); free(a->lP); free(a->lPmin); free(a->lp); free(a->lD);
     free(a);
 }
 
@@ -229,6 +240,13 @@ int *wo_emnr_position(wo_emnr *a) { return &a->position; }
 void wo_emnr_set_gain_method(wo_emnr *a, int m) { a->gain_method = m; }
 void wo_emnr_set_npe_method(wo_emnr *a, int m) { a->npe_method = m; }
 void wo_emnr_set_ae_run(wo_emnr *a, int run) { a->ae_run = run; }
+void wo_emnr_set_scalars(wo_emnr *a, double zetaThresh, double psi, double zeta_thresh, double t2)   /* emnr.c:1145-1174: < 0 keeps a value */
+{
+    if (zetaThresh >= 0) a->zetaThresh = zetaThresh;
+    if (psi >= 0) a->psi = psi;
+    if (zeta_thresh > -1e300) a->zeta_thresh = zeta_thresh;
+    if (t2 >= 0) a->t2 = t2;
+}
 
 static void LambdaD(wo_emnr *a)                 /* emnr.c:604-739 */
 {
@@ -319,6 +337,28 @@ static void LambdaDs(wo_emnr *a)                /* emnr.c:741-754 */
     memcpy(a->lambda_d, a->s_sigma2N, (size_t)a->msize * sizeof(double));
 }
 
+static void LambdaDl(wo_emnr *a)                /* emnr.c:756-775 */
+{
+    double P_old, c, Sr, delta, I, alpha_s;
+    int k;
+    c = (1.0 - a->l_gamma) / (1.0 - a->l_beta);
+    for (k = 0; k < a->msize; k++) {
+        P_old = a->lP[k];
+        a->lP[k] = a->l_eta * P_old + (1.0 - a->l_eta) * a->lambda_y[k];
+        if (a->lPmin[k] < a->lP[k]) a->lPmin[k] = a->l_gamma * a->lPmin[k] + c * (a->lP[k] - a->l_beta * P_old);
+        else a->lPmin[k] = a->lP[k];
+        Sr = a->lP[k] / a->lPmin[k];
+        if (k <= a->delta_LF) delta = a->delta_0;
+        else if (k <= a->delta_MF) delta = a->delta_1;
+        else delta = a->delta_2;
+        I = Sr > delta ? 1.0 : 0.0;
+        a->lp[k] = a->l_alpha_p * a->lp[k] + (1.0 - a->l_alpha_p) * I;
+        alpha_s = a->l_alpha_d + (1.0 - a->l_alpha_d) * a->lp[k];
+        a->lD[k] = alpha_s * a->lD[k] + (1.0 - alpha_s) * a->lambda_y[k];
+    }
+    memcpy(a->lambda_d, a->lD, (size_t)a->msize * sizeof(double));
+}
+
 static void aepf(wo_emnr *a)                    /* emnr.c:777-816 */
 {
     int k, m, N, n;
@@ -402,7 +442,7 @@ static void calc_gain(wo_emnr *a)               /* emnr.c:885-1013 */
     double gamma, eps_hat, eps_p, v, ehr, v2, eta, eps, witchHat, xi_ts, v_ts, zeta_hat;
     for (k = 0; k < a->msize; k++)
         a->lambda_y[k] = a->forfftout[2 * k] * a->forfftout[2 * k] + a->forfftout[2 * k + 1] * a->forfftout[2 * k + 1];
-    if (a->npe_method == 0) LambdaD(a); else if (a->npe_method == 1) LambdaDs(a);
+    if (a->npe_method == 0) LambdaD(a); else if (a->npe_method == 1) LambdaDs(a); else if (a->npe_method == 2) LambdaDl(a);
     for (k = 0; k < a->msize; k++) {
         gamma = dmin(a->lambda_y[k] / a->lambda_d[k], a->gamma_max);
         eps_hat = a->alpha * a->prev_mask[k] * a->prev_mask[k] * a->prev_gamma[k] + (1.0 - a->alpha) * dmax(gamma - 1.0, a->eps_floor);

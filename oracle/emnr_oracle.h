@@ -15,7 +15,8 @@ void wo_emnr_flush(wo_emnr *a);
 int *wo_emnr_run(wo_emnr *a);
 int *wo_emnr_position(wo_emnr *a);
 void wo_emnr_set_gain_method(wo_emnr *a, int m);                /* SetRXAEMNRgainMethod, emnr.c:1112 */
-void wo_emnr_set_npe_method(wo_emnr *a, int m);                 /* SetRXAEMNRnpeMethod, emnr.c:1120; 0 and 1 */
+void wo_emnr_set_npe_method(wo_emnr *a, int m);                 /* SetRXAEMNRnpeMethod, emnr.c:1120; 0, 1, 2 */
+void wo_emnr_set_scalars(wo_emnr *a, double ae_zeta_thresh, double ae_psi, double train_zeta_thresh, double train_t2);
 void wo_emnr_set_ae_run(wo_emnr *a, int run);                   /* SetRXAEMNRaeRun, emnr.c:1128 */
 void wo_emnr_exec(wo_emnr *a, int pos, double *buf);            /* xemnr on one block of bsize complex samples, in place */
 #ifdef __cplusplus

@@ -44,7 +44,8 @@ def lib():
         for n in ("wo_SetRXAAGCAttack", "wo_SetRXAAGCDecay", "wo_SetRXAAGCHang", "wo_SetRXAAGCSlope", "wo_SetRXAAGCHangThreshold"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None
-        for n in ("wo_SetRXAAMSQThreshold", "wo_SetRXAAMSQMaxTail"):
+        for n in ("wo_SetRXAAMSQThreshold", "wo_SetRXAAMSQMaxTail", "wo_SetRXAEMNRaeZetaThresh", "wo_SetRXAEMNRaePsi",
+                  "wo_SetRXAEMNRtrainZetaThresh", "wo_SetRXAEMNRtrainT2"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_double]
             getattr(L, n).restype = None
         for n in ("wo_SetRXAANFVals", "wo_SetRXAANRVals"):

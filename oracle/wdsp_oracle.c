@@ -1488,6 +1488,10 @@ void wo_SetRXAEMNRRun(wo_channel *c, int run)
 void wo_SetRXAEMNRgainMethod(wo_channel *c, int method) { wo_emnr_set_gain_method(c->emnr, method); }
 void wo_SetRXAEMNRnpeMethod(wo_channel *c, int method) { wo_emnr_set_npe_method(c->emnr, method); }
 void wo_SetRXAEMNRaeRun(wo_channel *c, int run) { wo_emnr_set_ae_run(c->emnr, run); }
+void wo_SetRXAEMNRaeZetaThresh(wo_channel *c, double v) { wo_emnr_set_scalars(c->emnr, v, -1, -1e301, -1); }       /* emnr.c:1145 */
+void wo_SetRXAEMNRaePsi(wo_channel *c, double v) { wo_emnr_set_scalars(c->emnr, -1, v, -1e301, -1); }              /* emnr.c:1153 */
+void wo_SetRXAEMNRtrainZetaThresh(wo_channel *c, double v) { wo_emnr_set_scalars(c->emnr, -1, -1, v, -1); }        /* emnr.c:1161 */
+void wo_SetRXAEMNRtrainT2(wo_channel *c, double v) { wo_emnr_set_scalars(c->emnr, -1, -1, -1e301, v); }            /* emnr.c:1169 */
 void wo_SetRXAEMNRPosition(wo_channel *c, int position) { *wo_emnr_position(c->emnr) = position; c->bp1.position = position; }
 void wo_SetEMNRTables(wo_channel *c, const double *GG, const double *GGS, const double *zeta_hat, const int *zeta_true, double gmin, double gmax,
                       double ximin, double ximax)

@@ -76,8 +76,12 @@ void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
 void wo_SetRXAEMNRRun(wo_channel *c, int run);                  /* emnr.c:1096-1110 */
 void wo_SetRXAEMNRgainMethod(wo_channel *c, int method);        /* emnr.c:1112-1118 */
-void wo_SetRXAEMNRnpeMethod(wo_channel *c, int method);         /* emnr.c:1120-1126; 0 and 1 restated */
+void wo_SetRXAEMNRnpeMethod(wo_channel *c, int method);         /* emnr.c:1120-1126 */
 void wo_SetRXAEMNRaeRun(wo_channel *c, int run);                /* emnr.c:1128-1134 */
+void wo_SetRXAEMNRaeZetaThresh(wo_channel *c, double v);       /* emnr.c:1145-1174 */
+void wo_SetRXAEMNRaePsi(wo_channel *c, double v);
+void wo_SetRXAEMNRtrainZetaThresh(wo_channel *c, double v);
+void wo_SetRXAEMNRtrainT2(wo_channel *c, double v);
 void wo_SetRXAEMNRPosition(wo_channel *c, int position);        /* emnr.c:1136-1143 */
 void wo_SetEMNRTables(wo_channel *c, const double *GG, const double *GGS, const double *zeta_hat, const int *zeta_true, double gmin, double gmax,
                       double ximin, double ximax);              /* the run-time data of emnr.c:317-334 */

@@ -17,12 +17,13 @@ namespace qh {
 constexpr int kEmnrF = 4096, kEmnrM = 2049, kEmnrIncr = 1024, kEmnrU = 8;
 
 struct EmnrParam {      // calc_emnr (emnr.c:240-497) for one sample rate; the same for every channel of an engine
-    double gain, gf1p5, alpha, eps_floor, gamma_max, xi_min, q, gmax, zeta_thresh, z_gamma_min, z_gamma_max, z_xihat_min, z_xihat_max;
+    double gain, gf1p5, alpha, eps_floor, gamma_max, xi_min, q, gmax, z_gamma_min, z_gamma_max, z_xihat_min, z_xihat_max;
     double alphaCsmooth, alphaMax, alphaCmin, alphaMin_max_value, snrq, betamax, invQeqMax, av, MofD, MofV, invQbar_points[4], nsmax[4];
-    double alpha_pow, alpha_Pbar, epsH1, epsH1r, zetaThresh, psi, t2;
+    double alpha_pow, alpha_Pbar, epsH1, epsH1r;
+    double l_eta, l_gamma, l_beta, l_alpha_d, l_alpha_p, delta_LF, delta_MF;        // npl, emnr.c:458-489
     int U, V, D, dim_zeta, bsize, oasize, init_oainidx, pad;
 };
-struct EmnrChan { int gain_method, npe_method, ae_run, pad; };
+struct EmnrChan { int gain_method, npe_method, ae_run, pad; double zetaThresh, psi, zeta_thresh, t2; };      // per channel (emnr.c:1112-1174)
 struct EmnrScalars { int iainidx, iaoutidx, oainidx, oaoutidx, nsamps, saveidx, subwc, amb_idx; double alphaC; };
 
 // per-channel arrays, all doubles, in one block of kEmnrStateDoubles
@@ -31,7 +32,8 @@ enum EmnrOff {
     EO_INACC = 0, EO_OUTACC = EO_INACC + kEmnrF, EO_SAVE = EO_OUTACC + kEmnrIncr, EO_PREVG = EO_SAVE + 4 * kEmnrF, EO_PREVM = EO_PREVG + kEmnrPad,
     EO_P = EO_PREVM + kEmnrPad, EO_SIG = EO_P + kEmnrPad, EO_PBAR = EO_SIG + kEmnrPad, EO_P2BAR = EO_PBAR + kEmnrPad, EO_ACTMIN = EO_P2BAR + kEmnrPad,
     EO_ACTSUB = EO_ACTMIN + kEmnrPad, EO_PMINU = EO_ACTSUB + kEmnrPad, EO_LMIN = EO_PMINU + kEmnrPad, EO_AMB = EO_LMIN + kEmnrPad,
-    EO_SSIG = EO_AMB + kEmnrU * kEmnrPad, EO_SPBAR = EO_SSIG + kEmnrPad, EO_END = EO_SPBAR + kEmnrPad
+    EO_SSIG = EO_AMB + kEmnrU * kEmnrPad, EO_SPBAR = EO_SSIG + kEmnrPad, EO_LP = EO_SPBAR + kEmnrPad, EO_LPMIN = EO_LP + kEmnrPad,
+    EO_LPP = EO_LPMIN + kEmnrPad, EO_LD = EO_LPP + kEmnrPad, EO_END = EO_LD + kEmnrPad
 };
 constexpr int kEmnrStateDoubles = EO_END;
 
@@ -223,6 +225,23 @@ static __global__ __launch_bounds__(NT) void emnr_kernel(double2 *buf, long long
                 }
                 if (sc.subwc == q.V) { if (++sc.amb_idx == q.U) sc.amb_idx = 0; sc.subwc = 1; }
                 else ++sc.subwc;
+            } else if (cc.npe_method == 2) {
+                // ---- LambdaDl, emnr.c:756-775
+                const double c = (1.0 - q.l_gamma) / (1.0 - q.l_beta);
+                for (int k = t; k < M; k += NT) {
+                    const double P_old = S[EO_LP + k];
+                    const double P = q.l_eta * P_old + (1.0 - q.l_eta) * ly[k];
+                    double Pmin = S[EO_LPMIN + k];
+                    if (Pmin < P) Pmin = q.l_gamma * Pmin + c * (P - q.l_beta * P_old); else Pmin = P;
+                    const double Sr = P / Pmin;
+                    const double delta = (double)k <= q.delta_LF ? 2.0 : (double)k <= q.delta_MF ? 2.0 : 5.0;
+                    const double I = Sr > delta ? 1.0 : 0.0;
+                    const double pp = q.l_alpha_p * S[EO_LPP + k] + (1.0 - q.l_alpha_p) * I;
+                    const double alpha_s = q.l_alpha_d + (1.0 - q.l_alpha_d) * pp;
+                    const double Dk = alpha_s * S[EO_LD + k] + (1.0 - alpha_s) * ly[k];
+                    S[EO_LP + k] = P; S[EO_LPMIN + k] = Pmin; S[EO_LPP + k] = pp; S[EO_LD + k] = Dk;
+                    ld[k] = Dk;
+                }
             } else {
                 // ---- LambdaDs, emnr.c:741-754
                 for (int k = t; k < M; k += NT) {
@@ -282,7 +301,7 @@ static __global__ __launch_bounds__(NT) void emnr_kernel(double2 *buf, long long
                         const int i_gamma = (int)floor((gamma_dB - q.z_gamma_min) / gpc), i_xi = (int)floor((xi_dB - q.z_xihat_min) / xpc);
                         if (!(i_gamma < 0 || i_gamma >= q.dim_zeta || i_xi < 0 || xi_dB >= q.dim_zeta)) {
                             const int index = i_gamma * q.dim_zeta + i_xi;
-                            if (zeta_true[index] > 0) m = zeta_hat[index] > q.zeta_thresh ? 1.0 : 0.0;
+                            if (zeta_true[index] > 0) m = zeta_hat[index] > cc.zeta_thresh ? 1.0 : 0.0;
                         }
                     }
                 }
@@ -294,10 +313,10 @@ static __global__ __launch_bounds__(NT) void emnr_kernel(double2 *buf, long long
                 // ---- aepf, emnr.c:777-816
                 const double sumPre = emnr_block_sum(s_pre, red), sumPost = emnr_block_sum(s_post, red);
                 const double zeta = sumPost / sumPre;
-                const double zetaT = zeta >= q.zetaThresh ? 1.0 : zeta;
-                const int N = zetaT == 1.0 ? 1 : 1 + 2 * (int)(0.5 + q.psi * (1.0 - zetaT / q.zetaThresh));
+                const double zetaT = zeta >= cc.zetaThresh ? 1.0 : zeta;
+                const int N = zetaT == 1.0 ? 1 : 1 + 2 * (int)(0.5 + cc.psi * (1.0 - zetaT / cc.zetaThresh));
                 const int n = N / 2;
-                const double tail = (cc.gain_method == 3 && zetaT < q.t2) ? 0.05 : 1.0;
+                const double tail = (cc.gain_method == 3 && zetaT < cc.t2) ? 0.05 : 1.0;
                 for (int k = t; k < M; k += NT) {
                     double acc = 0.0, div;
                     if (k < n) { for (int m2 = 0; m2 <= 2 * k; m2++) acc += mk_[m2]; div = (double)(2 * k + 1); }

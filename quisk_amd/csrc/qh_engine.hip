@@ -75,6 +75,7 @@ struct ChanCfg {
     struct Lms { int run = 0, position = 0, taps = 64, delay = 16; double two_mu = 0.0001, gamma = 0.1; bool dirty = true, flush = false; } lms[2];
     // emnr (create_emnr of create_rxa, RXA.c:319-332)
     int emnr_run = 0, emnr_pos = 0, emnr_gain_method = 2, emnr_npe = 0, emnr_ae = 1; bool emnr_dirty = true, emnr_flush = false;
+    double emnr_ae_zeta = 0.75, emnr_ae_psi = 20.0, emnr_train_zeta = -2.0, emnr_train_t2 = 0.20;       // emnr.c:332,491-493
     // amsq (create_amsq of create_rxa, RXA.c:158-172)
     int amsq_run = 0; double amsq_tail_thresh = 0.009, amsq_unmute_thresh = 0.010, amsq_max_tail = 1.5; bool amsq_dirty = true;
     int bp1_pos = 0;                                            // SetRXAANFPosition / SetRXAANRPosition set it too (anf.c:236)
@@ -638,9 +639,9 @@ int Engine::refresh_demod()
             c.agc_dirty = false;
         }
         if (emnr_chan && c.emnr_dirty) {
-            if (c.emnr_run && (c.emnr_npe < 0 || c.emnr_npe > 1 || c.emnr_gain_method < 0 || c.emnr_gain_method > 3))
-                return set_error(QH_ERR_UNSUPPORTED, "EMNR: gain methods 0..3 and noise estimators 0 (minimum statistics), 1 (speech presence)");
-            const EmnrChan ec{ c.emnr_gain_method, c.emnr_npe, c.emnr_ae, 0 };
+            if (c.emnr_run && (c.emnr_npe < 0 || c.emnr_npe > 2 || c.emnr_gain_method < 0 || c.emnr_gain_method > 3))
+                return set_error(QH_ERR_UNSUPPORTED, "EMNR: gain methods 0..3 and noise estimators 0..2");
+            const EmnrChan ec{ c.emnr_gain_method, c.emnr_npe, c.emnr_ae, 0, c.emnr_ae_zeta, c.emnr_ae_psi, c.emnr_train_zeta, c.emnr_train_t2 };
             QH_HIP(hipMemcpyAsync(emnr_chan + ch, &ec, sizeof(ec), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.emnr_dirty = false;
@@ -772,7 +773,7 @@ int Engine::emnr_alloc()
     q.gf1p5 = std::sqrt(kPiRef) / 2.0;
     q.alpha = tc(0.985);
     q.eps_floor = 1.0e-300; q.gamma_max = 40.0; q.xi_min = std::pow(10.0, -40.0 / 10.0); q.q = 0.2; q.gmax = 10000.0;
-    q.dim_zeta = 60; q.zeta_thresh = -2.0;
+    q.dim_zeta = 60;
     q.z_gamma_min = h_zrange[0]; q.z_gamma_max = h_zrange[1]; q.z_xihat_min = h_zrange[2]; q.z_xihat_max = h_zrange[3];
     q.alphaCsmooth = tc(0.7); q.alphaMax = tc(0.96); q.alphaCmin = tc(0.7); q.alphaMin_max_value = tc(0.3);
     q.snrq = -incr / (0.064 * rate);
@@ -810,7 +811,11 @@ int Engine::emnr_alloc()
     }
     q.alpha_pow = tc(0.8); q.alpha_Pbar = tc(0.9);
     q.epsH1 = std::pow(10.0, 15.0 / 10.0); q.epsH1r = q.epsH1 / (1.0 + q.epsH1);
-    q.zetaThresh = 0.75; q.psi = 20.0; q.t2 = 0.20;
+    {   // npl, emnr.c:458-489
+        auto tl = [&](double base) { const double tau = -256.0 / (20100.0 * std::log(base)); return std::exp(-incr / (rate * tau)); };
+        q.l_eta = tl(0.7); q.l_gamma = tl(0.998); q.l_beta = tl(0.8); q.l_alpha_d = tl(0.85); q.l_alpha_p = tl(0.2);
+        q.delta_LF = 1000.0 / (rate / 2) * kEmnrM; q.delta_MF = 3000.0 / (rate / 2) * kEmnrM;
+    }
     q.bsize = dsp_size;
     q.oasize = dsp_size > kEmnrIncr ? dsp_size : kEmnrIncr;
     q.init_oainidx = (kEmnrF - dsp_size - kEmnrIncr) % q.oasize;
@@ -1430,6 +1435,10 @@ int qh_rxa_SetRXAEMNRRun(qh_rxa *h, int ch, int run)
 int qh_rxa_SetRXAEMNRgainMethod(qh_rxa *h, int ch, int method) { FOR_CH(h, ch, { c.emnr_gain_method = method; c.emnr_dirty = true; }); }
 int qh_rxa_SetRXAEMNRnpeMethod(qh_rxa *h, int ch, int method) { FOR_CH(h, ch, { c.emnr_npe = method; c.emnr_dirty = true; }); }
 int qh_rxa_SetRXAEMNRaeRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.emnr_ae = run ? 1 : 0; c.emnr_dirty = true; }); }
+int qh_rxa_SetRXAEMNRaeZetaThresh(qh_rxa *h, int ch, double v) { FOR_CH(h, ch, { c.emnr_ae_zeta = v; c.emnr_dirty = true; }); }       // emnr.c:1145
+int qh_rxa_SetRXAEMNRaePsi(qh_rxa *h, int ch, double v) { FOR_CH(h, ch, { c.emnr_ae_psi = v; c.emnr_dirty = true; }); }               // emnr.c:1153
+int qh_rxa_SetRXAEMNRtrainZetaThresh(qh_rxa *h, int ch, double v) { FOR_CH(h, ch, { c.emnr_train_zeta = v; c.emnr_dirty = true; }); }  // emnr.c:1161
+int qh_rxa_SetRXAEMNRtrainT2(qh_rxa *h, int ch, double v) { FOR_CH(h, ch, { c.emnr_train_t2 = v; c.emnr_dirty = true; }); }            // emnr.c:1169
 int qh_rxa_SetRXAEMNRPosition(qh_rxa *h, int ch, int position)
 {
     FOR_CH(h, ch, { c.emnr_pos = position ? 1 : 0; c.bp1_pos = position ? 1 : 0; c.epi_dirty = true; h->e.lists_dirty = true; });

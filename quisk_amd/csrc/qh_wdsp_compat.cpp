@@ -450,6 +450,10 @@ void SetRXAEMNRRun(int channel, int run)
 void SetRXAEMNRnpeMethod(int channel, int method) { WDSP_SETTER(qh_rxa_SetRXAEMNRnpeMethod(L.c->eng, 0, method)); }
 void SetRXAEMNRaeRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAEMNRaeRun(L.c->eng, 0, run)); }
 void SetRXAEMNRPosition(int channel, int position) { WDSP_SETTER(qh_rxa_SetRXAEMNRPosition(L.c->eng, 0, position)); }
+void SetRXAEMNRaeZetaThresh(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAEMNRaeZetaThresh(L.c->eng, 0, v)); }
+void SetRXAEMNRaePsi(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAEMNRaePsi(L.c->eng, 0, v)); }
+void SetRXAEMNRtrainZetaThresh(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAEMNRtrainZetaThresh(L.c->eng, 0, v)); }
+void SetRXAEMNRtrainT2(int channel, double v) { WDSP_SETTER(qh_rxa_SetRXAEMNRtrainT2(L.c->eng, 0, v)); }
 // the AM squelch, wdsp/amsq.c:216-243
 void SetRXAAMSQRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMSQRun(L.c->eng, 0, run)); }
 void SetRXAAMSQThreshold(int channel, double threshold) { WDSP_SETTER(qh_rxa_SetRXAAMSQThreshold(L.c->eng, 0, threshold)); }

@@ -55,7 +55,8 @@ def load():
     L.qh_rxa_RXANBPGetNumNotches.argtypes = [vp, i, C.POINTER(i)]
     L.qh_rxa_RXANBPGetMinNotchWidth.argtypes = [vp, i, C.POINTER(d)]
     for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop",
-              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAANFGain", "SetRXAANFLeakage",
+              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAEMNRaeZetaThresh", "SetRXAEMNRaePsi", "SetRXAEMNRtrainZetaThresh",
+              "SetRXAEMNRtrainT2", "SetRXAANFGain", "SetRXAANFLeakage",
               "SetRXAANRGain", "SetRXAANRLeakage"):
         f = getattr(L, "qh_rxa_" + n)
         f.argtypes = [vp, i, d]

@@ -20,7 +20,8 @@ def speechy(c, n, fs=192000.0):
     return x * env + 0.004 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
 
 
-@pytest.mark.parametrize("gain_method,npe,ae,position", [(2, 0, 1, 0), (3, 0, 1, 0), (0, 0, 0, 0), (1, 1, 1, 0), (2, 0, 1, 1), (3, 1, 0, 1)])
+@pytest.mark.parametrize("gain_method,npe,ae,position", [(2, 0, 1, 0), (3, 0, 1, 0), (0, 0, 0, 0), (1, 1, 1, 0), (2, 0, 1, 1), (3, 1, 0, 1),
+                                                         (2, 2, 1, 0), (3, 2, 1, 1)])
 def test_emnr_matches_oracle(qh, oracle, gain_method, npe, ae, position):
     nch, nblk = 2, 700                       # 3.7 s at 192 k
     x = np.stack([speechy(c, nblk * 1024) for c in range(nch)])
@@ -35,6 +36,8 @@ def test_emnr_matches_oracle(qh, oracle, gain_method, npe, ae, position):
             t.SetRXAAGCMode(*a, 0 if ch == 0 else 3); t.SetRXAAGCFixed(*a, 6.0)
             t.SetRXAEMNRgainMethod(*a, gain_method); t.SetRXAEMNRnpeMethod(*a, npe); t.SetRXAEMNRaeRun(*a, ae)
             t.SetRXAEMNRPosition(*a, position); t.SetRXAEMNRRun(*a, 1)
+            if ch == 1:     # the four scalar knobs of emnr.c:1145-1174
+                t.SetRXAEMNRaeZetaThresh(*a, 0.6); t.SetRXAEMNRaePsi(*a, 12.0); t.SetRXAEMNRtrainZetaThresh(*a, -1.0); t.SetRXAEMNRtrainT2(*a, 0.3)
         refs.append(o)
     ys, rs = [], [[] for _ in range(nch)]
     for a, b in ((0, 3), (3, 4), (4, 301), (301, nblk)):        # ragged calls: frames straddle them

@@ -80,7 +80,7 @@ def _apply(rng, targets):
         call("SetRXAEMNRgainMethod", int(rng.integers(0, 4))); call("SetRXAEMNRaeRun", int(rng.integers(0, 2)))
     else:
         pos = int(rng.integers(0, 2))
-        call("SetRXAEMNRPosition", pos); call("SetRXAEMNRnpeMethod", int(rng.integers(0, 2)))
+        call("SetRXAEMNRPosition", pos); call("SetRXAEMNRnpeMethod", int(rng.integers(0, 3)))
     return done
 
 
