@@ -76,28 +76,43 @@ struct SamChanParam { int sbmode, levelfade; };
 // (tests compare after lock, like for every FFT-noise-driven acquisition).  Lane i receives the VCO phase that
 // sample i saw (turns) and the loop-filter output after sample i.
 struct PllLoop { double pt, fil_out, omega; };
-__device__ __forceinline__ void pll_run64(PllLoop &s, double theta_t, unsigned long long zero, int cnt, const PllParam &q,
-                                          int lane, double &my_pt, double &my_fil)
+// `out` is 128 doubles of LDS: the loop's uniform state after / before each sample is written there (the same value from every
+// lane) and picked up per lane afterwards -- two LDS stores per sample instead of four predicated register moves.
+template <bool ZEROS>
+__device__ __forceinline__ void pll_steps(PllLoop &s, double theta_t, unsigned long long zero, int cnt, const PllParam &q, double *out)
 {
     const double g1t = q.g1 * kTwoPiRef, g2t = q.g2 * kTwoPiRef, inv = 1.0 / kTwoPiRef;
-    my_pt = 0.0; my_fil = 0.0;
+    const double lo = q.omega_min, hi = q.omega_max;
     for (int i = 0; i < cnt; i++) {
-        if (lane == i) my_pt = s.pt;
+        out[i] = s.pt;
         double d = lane_bcast(theta_t, i) - s.pt;           // (-1.5, 0.5] turns
         d -= rint(d);
-        if ((zero >> i) & 1ull) d = 0.0;                    // "if both are zero, corr[0] = 1.0": det = 0
+        if constexpr (ZEROS) if ((zero >> i) & 1ull) d = 0.0;   // "if both are zero, corr[0] = 1.0": det = 0
         const double del_out = s.fil_out;
-        s.omega = fmin(fmax(__builtin_fma(g2t, d, s.omega), q.omega_min), q.omega_max);
+        s.omega = fmin(fmax(__builtin_fma(g2t, d, s.omega), lo), hi);
         s.fil_out = __builtin_fma(g1t, d, s.omega);
         s.pt = __builtin_amdgcn_fract(__builtin_fma(del_out, inv, s.pt));
-        if (lane == i) my_fil = s.fil_out;
+        out[64 + i] = s.fil_out;
     }
+}
+__device__ __forceinline__ void pll_run64(PllLoop &s, double theta_t, unsigned long long zero, int cnt, const PllParam &q,
+                                          int lane, double &my_pt, double &my_fil, double *out)
+{
+    if (zero == 0ull) pll_steps<false>(s, theta_t, zero, cnt, q, out);      // wave-uniform: no all-zero sample in the batch
+    else pll_steps<true>(s, theta_t, zero, cnt, q, out);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    my_pt = lane < cnt ? out[lane] : 0.0;
+    my_fil = lane < cnt ? out[64 + lane] : 0.0;
+    __builtin_amdgcn_wave_barrier();
 }
 
 // FM discriminator: in place, z -> (audio, audio).  One wave per listed channel.
 static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                     PllState *state, const double *again, PllParam q)
 {
+    __shared__ double pll_out[128];
     const int ch = chan_list[blockIdx.x];
     const int lane = threadIdx.x;
     double2 *p = buf + (long long)ch * stride;
@@ -116,7 +131,7 @@ static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long lo
         const double theta_t = atan2(z.y, z.x) * (1.0 / kTwoPiRef);
         const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);
         double my_pt, fil;
-        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, fil);
+        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, fil, pll_out);
         // fmdc_i = mtau fmdc_{i-1} + onem_mtau fil_i (fmd.c:169), audio = again (fil - fmdc) (fmd.c:171): a scan
         const double dcs = scan_pole(lane < cnt ? q.onem_mtau * fil : 0.0, q.mtau, lane) + pw * fmdc;
         fmdc = lane_bcast(dcs, cnt - 1);
@@ -140,7 +155,7 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
 {
     constexpr int STAGES = 7, OUT_IDX = 3 * STAGES;
     const double *c0 = kSamC0, *c1 = kSamC1;
-    __shared__ double fa[24], fb[24], fc[24], fd[24];
+    __shared__ double fa[24], fb[24], fc[24], fd[24], pll_out[128];
     const int ch = chan_list[blockIdx.x];
     const int lane = threadIdx.x;
     double2 *p = buf + (long long)ch * stride;
@@ -167,7 +182,7 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
         const double theta_t = atan2(z.y, z.x) * (1.0 / kTwoPiRef);
         const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);
         double my_pt, my_fil;
-        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, my_fil);
+        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, my_fil, pll_out);
         const double myphs = my_pt * kTwoPiRef;
         double sn, cs;
         sincos(myphs, &sn, &cs);
