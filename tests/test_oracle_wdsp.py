@@ -165,3 +165,45 @@ def test_make_nbp_known_answers(oracle):
     assert run([(1000, 10000, 1)], 300, 3000) == ([], 1)
     assert run([(1000, 20, 1)], 300, 3000, minwidth=200, autoincr=1) == ([(300.0, 900.0), (1100.0, 3000.0)], 1)
     assert run([(1000, 20, 1)], 3000, 300) == ([], 0)
+
+
+def _ssb_channel(oracle):
+    from quisk_amd import synth
+    ch = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+    ch.SetRXAShiftRun(1); ch.SetRXAShiftFreq(synth.shift_freq(0)); ch.RXANBPSetRun(1); ch.SetRXAMode(1); ch.RXASetPassband(300.0, 3000.0)
+    ch.SetRXAAGCMode(0); ch.SetRXAAGCFixed(0.0)
+    return ch
+
+
+def test_anf_takes_a_carrier_out_and_anr_keeps_it(oracle):
+    """xanf outputs the LMS prediction error (the steady tone goes), xanr the prediction (the tone stays, noise drops); both
+    force bp1 on with gain 2 (RXAbp1Check, RXA.c:800-813), which makes up for dropping the imaginary part."""
+    from quisk_amd import synth
+    x = synth.make_input_numpy(1, 600 * 1024)[0]
+
+    def tone_and_floor(y):
+        S = np.abs(np.fft.fft(y[-16384:] * np.hanning(16384))) ** 2
+        k = int(np.argmax(S))
+        return 10 * np.log10(S[k - 3:k + 4].sum()), 10 * np.log10((S.sum() - S[k - 3:k + 4].sum()) / 16384)
+
+    plain = tone_and_floor(_ssb_channel(oracle).xrxa(x))
+    a = _ssb_channel(oracle); a.SetRXAANFRun(1)
+    anf = tone_and_floor(a.xrxa(x))
+    r = _ssb_channel(oracle); r.SetRXAANRRun(1)
+    anr = tone_and_floor(r.xrxa(x))
+    assert anf[0] < plain[0] - 10.0                         # the carrier is notched
+    assert abs(anr[0] - plain[0]) < 3.0                     # the carrier stays (real part only: half the amplitude, then bp1's gain of 2)
+    assert anr[1] < plain[1] - 3.0                          # and the noise floor is at least 3 dB down
+
+
+def test_am_squelch_opens_on_signal_and_closes_after_its_tail(oracle):
+    from quisk_amd import synth
+    n = 300 * 1024
+    x = synth.make_input_numpy(1, n)[0]
+    env = np.ones(n); env[100 * 1024:] = 1e-4
+    ch = _ssb_channel(oracle)
+    ch.SetRXAAMSQThreshold(-30.0); ch.SetRXAAMSQMaxTail(0.1); ch.SetRXAAMSQRun(1)
+    y = ch.xrxa(x * env)
+    lvl = [np.abs(y[k * 256:(k + 1) * 256]).max() for k in range(300)]
+    assert lvl[0] == 0.0 and max(lvl[60:95]) > 0.1          # muted at the start, open (after the 70 ms slew) while the signal is there
+    assert max(lvl[160:]) == 0.0                            # closed again: tail <= 0.1 s + 70 ms slew after the fade at block 100
