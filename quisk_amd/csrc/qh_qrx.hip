@@ -111,7 +111,8 @@ struct Qrx {
     // the reference's sizeFilter / indexFilter per channel, rx_ring what its buffer holds outside the live ring.
     std::vector<int> rx_size, rx_index;
     std::vector<std::vector<cd>> rx_ring;
-    qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = off
+    qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = never switched on
+    bool agc_on = false;
     double agc_gain = 80.0;
     // dAutoNotch (quisk.c:786-963): a NOTCH step sits where the mode calls it, idle until qh_qrx_set_auto_notch
     QNotchState *notch_state = nullptr;
@@ -585,7 +586,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
         cur = dst; cur_stride = dst_stride; n = m;
         if (i != last) w ^= 1;
     }
-    if (q.agc && n > 0)
+    if (q.agc && q.agc_on && n > 0)
         if (int rc = qh_qagc_process(q.agc, d_out, out_stride, n)) return rc;
     if (q.sq_state && n > 0) {
         int gx = (n + 255) / 256;
@@ -644,7 +645,8 @@ int qh_qrx_set_agc(qh_qrx *h, int on, double release_gain)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
-    if (!on) { if (q.agc) { qh_qagc_destroy(q.agc); q.agc = nullptr; } return QH_OK; }
+    q.agc_on = on != 0;
+    if (!on) return QH_OK;          // the AGC's state stays as it is (Agc1 is static in the reference) and carries on when switched back on
     if (!q.agc) {
         q.agc = qh_qagc_create(q.device, q.nch, q.decim_srate, 0.7, 1.0, is_iq(q.mode) ? 1 : 0, q.stream);
         if (!q.agc) return QH_ERR_HIP;
