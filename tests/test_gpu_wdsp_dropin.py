@@ -249,3 +249,43 @@ def test_anf_and_anr_through_the_wdsp_names(qh, oracle):
     assert lib.qh_wdsp_status() == 0
     lib.CloseChannel(ch)
     assert rel_rms(np.concatenate([y1, y2]), np.concatenate([r1, r2])) < 1e-6
+
+
+def test_set_channel_state_slews_down_flushes_and_restarts_like_a_fresh_channel(qh, oracle):
+    """SetChannelState(ch, 0, 0) (wdsp/channel.c:261-296): the following fexchange0 calls run the down-slew state machine on the
+    output (iobuffs.c:226-300: the first sample as it is, then tdelaydown, then a raised cosine over tslewdown, then zeros up to the
+    end of a block), after which the channel is flushed and stops exchanging; SetChannelState(ch, 1, 0) starts it again with the
+    up-slew, and from there on it must behave exactly like a freshly opened channel."""
+    lib = qh.load()
+    lib.SetChannelState.argtypes = [C.c_int, C.c_int, C.c_int]
+    ch, in_size, out_size = 13, 1024, 256
+    _open(lib, ch, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    x = synth.make_input_numpy(1, 120 * in_size)[0]
+    y1 = _run(lib, ch, x[:40 * in_size], in_size, out_size)
+    assert lib.SetChannelState(ch, 0, 0) == 1                   # prior state
+    # the blocks of the down-slew: compare with the same channel left running
+    o = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    ref, _ = o.fexchange0(x[:44 * in_size])
+    assert rel_rms(y1, ref[:40 * out_size]) < 1e-9
+    err = C.c_int(0)
+    tail = np.full(4 * out_size, 7.0 + 7.0j)
+    for b in range(4):
+        blk = np.ascontiguousarray(x[(40 + b) * in_size:(41 + b) * in_size])
+        lib.fexchange0(ch, blk.ctypes.data_as(C.c_void_p), tail[b * out_size:].ctypes.data_as(C.c_void_p), C.byref(err))
+    ntdown = int(0.010 * 48000)
+    ramp = 0.5 * (1.0 + np.cos(np.pi * np.arange(ntdown + 1) / ntdown))
+    want = ref[40 * out_size:41 * out_size].copy()
+    # sample 0 passes (BEGIN), tdelaydown = 0 -> DOWNSLEW: samples 1 .. 256 take cdown[0 .. 255] ...
+    want[1:] *= ramp[:out_size - 1]
+    assert np.abs(tail[:out_size] - want).max() < 1e-9 * np.abs(ref).max()
+    # ... the second block continues the ramp to zero, then zeros to the block's end; after that the channel does not exchange
+    want2 = ref[41 * out_size:42 * out_size].copy()
+    k = np.arange(out_size) + out_size - 1
+    want2 = np.where(k <= ntdown, want2 * ramp[np.minimum(k, ntdown)], 0.0)
+    assert np.abs(tail[out_size:2 * out_size] - want2).max() < 1e-9 * np.abs(ref).max()
+    assert lib.SetChannelState(ch, 1, 0) == 0
+    y2 = _run(lib, ch, x[60 * in_size:], in_size, out_size)
+    fresh = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    ref2, _ = fresh.fexchange0(x[60 * in_size:])
+    lib.CloseChannel(ch)
+    assert rel_rms(y2, ref2) < 1e-9
