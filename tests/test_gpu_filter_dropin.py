@@ -195,3 +195,25 @@ def test_interp2hb45_struct_state(qh, oracle):
     st3 = oracle.RefDHB45()
     mixed = alternate([lib.quisk_dInterp2HB45, ref.quisk_dInterp2HB45], lambda fn, a, b, s: call_real(fn, xr[a:b], s, grow=2), st3)
     assert mixed.size == wantr.size and rel_rms(mixed, wantr) < 1e-12
+
+
+def test_differ_init_builds_the_reference_differentiator(qh, oracle):
+    """quisk_filt_differInit (filter.c:35-56): taps (-1)^k / k around a zero centre; then quisk_dFilter with it, against the
+    reference's own (its printf goes to stdout)."""
+    lib, ref = qh.load(), oracle.ref_filter_lib()
+    taps = 31
+    st = oracle.RefCFilter()
+    lib.quisk_filt_differInit(C.byref(st), C.c_int(taps))
+    k = np.arange(taps) - (taps - 1) // 2
+    want = np.where(k == 0, 0.0, (-1.0) ** np.abs(k) / np.where(k == 0, 1, k))
+    got = np.array([st.dCoefs[i] for i in range(taps)])
+    assert st.nTaps == taps and np.array_equal(got, want)
+    x = np.random.default_rng(3).standard_normal(2000)
+    ours = np.concatenate([call_real(lib.quisk_dFilter, x[a:b], st) for a, b in ((0, 700), (700, 701), (701, 2000))])
+    assert rel_rms(ours, oracle.OracleFir(want, is_complex=False).dFilter(x)) < 1e-12
+    if ref is not None:
+        st2 = oracle.RefCFilter()
+        ref.quisk_filt_differInit(C.byref(st2), C.c_int(taps))
+        assert np.array_equal(np.array([st2.dCoefs[i] for i in range(taps)]), got)
+        theirs = call_real(ref.quisk_dFilter, x, st2)
+        assert rel_rms(ours, theirs) < 1e-12
