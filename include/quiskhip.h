@@ -105,6 +105,10 @@ int qh_rxa_SetRXAEMNRtrainZetaThresh(qh_rxa *e, int ch, double v);
 int qh_rxa_SetRXAEMNRtrainT2(qh_rxa *e, int ch, double v);
 /* xamsqcap / xamsq, the AM squelch (wdsp/amsq.c:119-192; create_amsq arguments RXA.c:158-172) */
 int qh_rxa_SetRXAAMSQRun(qh_rxa *e, int ch, int run);
+/* SNBA, wdsp/snb.c:579-593 (run; also switches bpsnba and bp1 as RXA.c:800-917) and :660-694 (pass band of its output resampler;
+ * RXASetPassband calls it).  dsp_rate 12000 / 24000 / 48000, dsp_size <= 1024. */
+int qh_rxa_SetRXASNBARun(qh_rxa *e, int ch, int run);
+int qh_rxa_SetRXASNBAOutputBandwidth(qh_rxa *e, int ch, double flow, double fhigh);
 int qh_rxa_SetRXAAMSQThreshold(qh_rxa *e, int ch, double threshold_db);
 int qh_rxa_SetRXAAMSQMaxTail(qh_rxa *e, int ch, double tail_seconds);
 /* xanf / xanr (wdsp/anf.c:82-133, anr.c:82-133), setters wdsp/anf.c:175-239 and anr.c:175-238; which position (0 before
@@ -263,7 +267,8 @@ void SetRXAEMNRtrainZetaThresh(int channel, double v);
 void SetRXAEMNRtrainT2(int channel, double v);
 
 void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */
-void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c */
+void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c:579-593 */
+void SetRXASNBAOutputBandwidth(int channel, double flow, double fhigh);          /* wdsp/snb.c:660-694 */
 
 /* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */
 int qh_wdsp_status(void);

@@ -56,7 +56,7 @@ def lib():
         for n in ("wo_SetRXAMode", "wo_RXASetNC", "wo_SetRXAShiftRun", "wo_RXANBPSetRun", "wo_SetRXABandpassRun",
                   "wo_SetRXAAGCMode", "wo_SetRXAPanelRun", "wo_SetRXAPanelSelect", "wo_SetRXAPanelCopy",
                   "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun", "wo_SetRXAAMDRun", "wo_RXASetMP", "wo_SetRXAFMLimRun",
-                  "wo_SetRXAEMNRRun", "wo_SetRXAEMNRgainMethod", "wo_SetRXAEMNRnpeMethod", "wo_SetRXAEMNRaeRun", "wo_SetRXAEMNRPosition",
+                  "wo_SetRXAEMNRRun", "wo_SetRXASNBARun", "wo_SetRXAEMNRgainMethod", "wo_SetRXAEMNRnpeMethod", "wo_SetRXAEMNRaeRun", "wo_SetRXAEMNRPosition",
                   "wo_SetRXAAMSQRun", "wo_SetRXAANFRun", "wo_SetRXAANRRun", "wo_SetRXAANFPosition", "wo_SetRXAANRPosition"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None

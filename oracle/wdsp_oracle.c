@@ -10,6 +10,7 @@
 #include "fft_oracle.h"
 #include "wdsp_oracle.h"
 #include "emnr_oracle.h"
+#include "snba_oracle.h"
 #include "wcpagc_oracle.h"
 
 #define WO_PI    3.1415926535897932   /* wdsp/comm.h:146 */
@@ -548,6 +549,10 @@ struct wo_channel {
     struct { int run, nc, wintype, position; double f_low, f_high, gain; wo_fircore *p; } bp1;
     wo_emnr *emnr;                              /* wdsp/emnr.c, restated in emnr_oracle.c */
     int emnr_pending_run;                       /* the emnr_run argument of RXAbp1Check (RXA.c:800) */
+    wo_snba *snba;                              /* wdsp/snb.c, restated in snba_oracle.c */
+    int snba_pending_run;                       /* the snba_run argument of RXAbp1Check */
+    /* bpsnba, snb.c:696-855: a notched bandpass fed ahead of nbp0 (position 0) or behind the detectors (position 1) */
+    struct { int run, run_notches, position, nc, wintype, autoincr; double abs_low, abs_high, f_low, f_high; double *buff; wo_fircore *p; } bpsnba;
     /* amsq, wdsp/amsq.h */
     struct {
         int run, state, count, ntup, ntdown;
@@ -654,6 +659,29 @@ static double nbp0_min_notch_width(wo_channel *c)      /* min_notch_width, nbp.c
     return (c->nbp0.wintype == 1 ? 2200.0 : 1600.0) / (c->nbp0.nc / 256) * (c->nbp0.rate / 48000);
 }
 
+static double *bpsnba_impulse(wo_channel *c)           /* calc_nbp_impulse for the nbp inside bpsnba (wintype 0, gain 1, autoincr 1: RXA.c:109-127) */
+{
+    double scale = 1.0 / (double)(2 * c->dsp_size);
+    double rate = (double)c->dsp_rate;
+    if (c->bpsnba.run_notches) {
+        double *bplow = (double *)zalloc(1025 * sizeof(double)), *bphigh = (double *)zalloc(1025 * sizeof(double));
+        double offset = c->ndb.tunefreq + c->ndb.shift;
+        int havnotch = 0, i, k, numpb;
+        double *impulse = (double *)zalloc((size_t)c->bpsnba.nc * 2 * sizeof(double));
+        numpb = wo_make_nbp(c->ndb.nn, c->ndb.active, c->ndb.fcenter, c->ndb.fwidth, c->ndb.nlow, c->ndb.nhigh,
+                            (c->bpsnba.wintype == 1 ? 2200.0 : 1600.0) / (c->bpsnba.nc / 256) * (rate / 48000), c->bpsnba.autoincr, c->bpsnba.f_low + offset, c->bpsnba.f_high + offset,
+                            bplow, bphigh, &havnotch);
+        for (k = 0; k < numpb; k++) {
+            double *imp = wo_fir_bandpass(c->bpsnba.nc, bplow[k] - offset, bphigh[k] - offset, rate, c->bpsnba.wintype, 1, scale);
+            for (i = 0; i < 2 * c->bpsnba.nc; i++) impulse[i] += imp[i];
+            free(imp);
+        }
+        free(bplow); free(bphigh);
+        return impulse;
+    }
+    return wo_fir_bandpass(c->bpsnba.nc, c->bpsnba.f_low, c->bpsnba.f_high, rate, c->bpsnba.wintype, 1, scale);
+}
+
 static double *nbp0_impulse(wo_channel *c)             /* calc_nbp_impulse, nbp.c:214-239 */
 {
     double scale = c->nbp0.gain / (double)(2 * c->dsp_size);
@@ -681,6 +709,19 @@ static void nbp0_update(wo_channel *c)                 /* UpdateNBPFilters, nbp.
     double *imp = nbp0_impulse(c);
     fircore_set_impulse(c->nbp0.p, imp);
     free(imp);
+}
+
+static void bpsnba_update(wo_channel *c)               /* recalc_bpsnba_filter, snb.c:807-822 */
+{
+    double *imp = bpsnba_impulse(c);
+    fircore_set_impulse(c->bpsnba.p, imp);
+    free(imp);
+}
+
+static void ndb_update(wo_channel *c)                  /* UpdateNBPFilters, nbp.c:342-356 */
+{
+    if (c->nbp0.fnfrun) nbp0_update(c);
+    if (c->bpsnba.run_notches) bpsnba_update(c);
 }
 
 static double *bp1_impulse(wo_channel *c)      /* bandpass.c:302 */
@@ -1023,9 +1064,36 @@ static void lms_flush(struct wo_lms *a)          /* flush_anf, anf.c:135-140 */
 }
 
 /* ---- RXAbp1Check / RXAbp1Set (RXA.c:800-827) */
+static void bpsnba_check(wo_channel *c, int mode, int notch_run)     /* RXAbpsnbaCheck, RXA.c:829-881 */
+{
+    double f_low = 0.0, f_high = 0.0;
+    int run_notches = 0;
+    switch (mode) {
+    case WO_LSB: case WO_CWL: case WO_DIGL: f_low = -c->bpsnba.abs_high; f_high = -c->bpsnba.abs_low; run_notches = notch_run; break;
+    case WO_USB: case WO_CWU: case WO_DIGU: f_low = +c->bpsnba.abs_low; f_high = +c->bpsnba.abs_high; run_notches = notch_run; break;
+    case WO_AM: case WO_SAM: case WO_DSB: case WO_FM: f_low = +c->bpsnba.abs_low; f_high = +c->bpsnba.abs_high; break;
+    default: break;
+    }
+    if (c->bpsnba.f_low != f_low || c->bpsnba.f_high != f_high || c->bpsnba.run_notches != run_notches) {
+        c->bpsnba.f_low = f_low; c->bpsnba.f_high = f_high; c->bpsnba.run_notches = run_notches;
+        bpsnba_update(c);
+    }
+}
+
+static void bpsnba_set(wo_channel *c)           /* RXAbpsnbaSet, RXA.c:883-917 */
+{
+    switch (c->mode) {
+    case WO_LSB: case WO_CWL: case WO_DIGL: case WO_USB: case WO_CWU: case WO_DIGU:
+        c->bpsnba.run = *wo_snba_run(c->snba); c->bpsnba.position = 0; break;
+    case WO_AM: case WO_SAM: case WO_DSB: case WO_FM:
+        c->bpsnba.run = *wo_snba_run(c->snba); c->bpsnba.position = 1; break;
+    default: c->bpsnba.run = 0; break;
+    }
+}
+
 static void bp1_check(wo_channel *c, int amd_run, int anf_run, int anr_run)
 {
-    double gain = (amd_run || anf_run || anr_run || c->emnr_pending_run) ? 2.0 : 1.0;      /* snba never runs on this path */
+    double gain = (amd_run || anf_run || anr_run || c->emnr_pending_run || c->snba_pending_run) ? 2.0 : 1.0;
     if (c->bp1.gain != gain) {
         double *imp;
         c->bp1.gain = gain;
@@ -1038,7 +1106,7 @@ static void bp1_check(wo_channel *c, int amd_run, int anf_run, int anr_run)
 static void bp1_set(wo_channel *c)
 {
     int old = c->bp1.run;
-    c->bp1.run = (c->amd.run == 1 || c->anf.run == 1 || c->anr.run == 1 || *wo_emnr_run(c->emnr) == 1) ? 1 : 0;
+    c->bp1.run = (c->amd.run == 1 || c->anf.run == 1 || c->anr.run == 1 || *wo_emnr_run(c->emnr) == 1 || *wo_snba_run(c->snba) == 1) ? 1 : 0;
     if (!old && c->bp1.run) fircore_flush(c->bp1.p);
 }
 
@@ -1050,11 +1118,15 @@ static void xrxa(wo_channel *c)
     if (c->rsmpin->run) wo_resample_exec(c->rsmpin, c->inbuff, c->dsp_insize, c->midbuff);
     else memcpy(c->midbuff, c->inbuff, (size_t)c->dsp_insize * 2 * sizeof(double));
     meter_exec(&c->adcmeter, c->midbuff, n, c->meter, NULL);
+    if (c->bpsnba.run && c->bpsnba.position == 0) memcpy(c->bpsnba.buff, c->midbuff, (size_t)n * 2 * sizeof(double));  /* xbpsnbain, RXA.c:567 */
     if (c->nbp0.run) wo_fircore_exec(c->nbp0.p, c->midbuff, c->midbuff);
     meter_exec(&c->smeter, c->midbuff, n, c->meter, NULL);
     memcpy(c->amsq.trigsig, c->midbuff, (size_t)n * 2 * sizeof(double));            /* xamsqcap, RXA.c:571 */
+    if (c->bpsnba.run && c->bpsnba.position == 0) wo_fircore_exec(c->bpsnba.p, c->bpsnba.buff, c->midbuff);           /* xbpsnbaout, RXA.c:572 */
     xamd(c, c->midbuff, n);
     xfmd(c, c->midbuff, n);
+    if (c->bpsnba.run && c->bpsnba.position == 1) wo_fircore_exec(c->bpsnba.p, c->midbuff, c->midbuff);              /* RXA.c:576-577 */
+    wo_snba_exec(c->snba, c->midbuff);                                                                                 /* xsnba, RXA.c:578 */
     xlms(&c->anf, 0, 0, c->midbuff, n);
     xlms(&c->anr, 1, 0, c->midbuff, n);
     wo_emnr_exec(c->emnr, 0, c->midbuff);
@@ -1265,6 +1337,13 @@ wo_channel *wo_open(int in_size, int dsp_size, int in_rate, int dsp_rate, int ou
     wo_agc_init(&c->agc, 1, 3, 1, dsp_rate, 0.001, 0.250, 4, 10000.0, 1.5, 1000.0, 1.0, 1.0, 0.250, 0.005, 5.0, 1, 0.500, 0.250, 0.250, 0.100);
     c->bp1.run = 1; c->bp1.nc = nc; c->bp1.wintype = 1; c->bp1.gain = 1.0; c->bp1.position = 0;
     c->emnr = wo_emnr_create(dsp_size, dsp_rate);
+    c->snba = wo_snba_create(dsp_rate, dsp_size);
+    c->bpsnba.run = 0; c->bpsnba.run_notches = 0; c->bpsnba.position = 0; c->bpsnba.nc = nc; c->bpsnba.wintype = 0; c->bpsnba.autoincr = 1;
+    c->bpsnba.abs_low = 250.0; c->bpsnba.abs_high = 5700.0; c->bpsnba.f_low = -5700.0; c->bpsnba.f_high = -250.0;      /* RXA.c:109-127 */
+    c->bpsnba.buff = (double *)zalloc((size_t)dsp_size * 2 * sizeof(double));
+    imp = bpsnba_impulse(c);
+    c->bpsnba.p = wo_fircore_create(dsp_size, nc, imp);
+    free(imp);
     /* create_amsq arguments of create_rxa, RXA.c:158-172 */
     c->amsq.run = 0; c->amsq.tail_thresh = 0.009; c->amsq.unmute_thresh = 0.010; c->amsq.min_tail = 0.0; c->amsq.max_tail = 1.5;
     c->amsq.muted_gain = 0.0;
@@ -1295,6 +1374,7 @@ void wo_close(wo_channel *c)
     free(c->inbuff); free(c->midbuff); free(c->outbuff);
     free(c->amsq.cup); free(c->amsq.cdown); free(c->amsq.trigsig);
     wo_emnr_free(c->emnr);
+    wo_snba_free(c->snba); wo_fircore_destroy(c->bpsnba.p); free(c->bpsnba.buff);
     free(c->iob.r1); free(c->iob.r2); free(c->iob.cup);
     wo_agc_free(&c->agc);
     free(c);
@@ -1305,6 +1385,7 @@ void wo_SetRXAMode(wo_channel *c, int mode)     /* RXA.c:748-787 */
 {
     if (c->mode != mode) {
         int amd_run = (mode == WO_AM) || (mode == WO_SAM);
+        bpsnba_check(c, mode, c->ndb.master_run);
         bp1_check(c, amd_run, c->anf.run, c->anr.run);
         c->mode = mode;
         c->amd.run = 0;
@@ -1317,6 +1398,7 @@ void wo_SetRXAMode(wo_channel *c, int mode)     /* RXA.c:748-787 */
         default: break;
         }
         bp1_set(c);
+        bpsnba_set(c);
     }
 }
 
@@ -1355,7 +1437,7 @@ int wo_RXANBPAddNotch(wo_channel *c, int notch, double fcenter, double fwidth, i
         c->ndb.fcenter[notch] = fcenter; c->ndb.fwidth[notch] = fwidth;
         c->ndb.nlow[notch] = fcenter - 0.5 * fwidth; c->ndb.nhigh[notch] = fcenter + 0.5 * fwidth;
         c->ndb.active[notch] = active;
-        if (c->nbp0.fnfrun) nbp0_update(c);
+        ndb_update(c);
         return 0;
     }
     return -1;
@@ -1370,7 +1452,7 @@ int wo_RXANBPDeleteNotch(wo_channel *c, int notch)
             c->ndb.fcenter[i] = c->ndb.fcenter[j]; c->ndb.fwidth[i] = c->ndb.fwidth[j];
             c->ndb.nlow[i] = c->ndb.nlow[j]; c->ndb.nhigh[i] = c->ndb.nhigh[j]; c->ndb.active[i] = c->ndb.active[j];
         }
-        if (c->nbp0.fnfrun) nbp0_update(c);
+        ndb_update(c);
         return 0;
     }
     return -1;
@@ -1382,31 +1464,40 @@ int wo_RXANBPEditNotch(wo_channel *c, int notch, double fcenter, double fwidth, 
         c->ndb.fcenter[notch] = fcenter; c->ndb.fwidth[notch] = fwidth;
         c->ndb.nlow[notch] = fcenter - 0.5 * fwidth; c->ndb.nhigh[notch] = fcenter + 0.5 * fwidth;
         c->ndb.active[notch] = active;
-        if (c->nbp0.fnfrun) nbp0_update(c);
+        ndb_update(c);
         return 0;
     }
     return -1;
 }
 
-void wo_RXANBPSetTuneFrequency(wo_channel *c, double f) { if (f != c->ndb.tunefreq) { c->ndb.tunefreq = f; if (c->nbp0.fnfrun) nbp0_update(c); } }
-void wo_RXANBPSetShiftFrequency(wo_channel *c, double f) { if (f != c->ndb.shift) { c->ndb.shift = f; if (c->nbp0.fnfrun) nbp0_update(c); } }
+void wo_RXANBPSetTuneFrequency(wo_channel *c, double f) { if (f != c->ndb.tunefreq) { c->ndb.tunefreq = f; ndb_update(c); } }
+void wo_RXANBPSetShiftFrequency(wo_channel *c, double f) { if (f != c->ndb.shift) { c->ndb.shift = f; ndb_update(c); } }
 void wo_RXANBPSetNotchesRun(wo_channel *c, int run)
 {
-    if (run != c->ndb.master_run) { c->ndb.master_run = run; c->nbp0.fnfrun = run; nbp0_update(c); }
+    if (run != c->ndb.master_run) { c->ndb.master_run = run; c->nbp0.fnfrun = run; bpsnba_check(c, c->mode, run); nbp0_update(c); bpsnba_set(c); }
 }
-void wo_RXANBPSetWindow(wo_channel *c, int wintype) { if (c->nbp0.wintype != wintype) { c->nbp0.wintype = wintype; nbp0_update(c); } }
-void wo_RXANBPSetAutoIncrease(wo_channel *c, int autoincr) { if (c->nbp0.autoincr != autoincr) { c->nbp0.autoincr = autoincr; nbp0_update(c); } }
+void wo_RXANBPSetWindow(wo_channel *c, int wintype)     /* nbp.c:543-561 */
+{
+    if (c->nbp0.wintype != wintype) { c->nbp0.wintype = wintype; nbp0_update(c); }
+    if (c->bpsnba.wintype != wintype) { c->bpsnba.wintype = wintype; bpsnba_update(c); }
+}
+void wo_RXANBPSetAutoIncrease(wo_channel *c, int autoincr)      /* nbp.c:601-619 */
+{
+    if (c->nbp0.autoincr != autoincr) { c->nbp0.autoincr = autoincr; nbp0_update(c); }
+    if (c->bpsnba.autoincr != autoincr) { c->bpsnba.autoincr = autoincr; bpsnba_update(c); }
+}
 
 void wo_RXASetPassband(wo_channel *c, double f_low, double f_high)
 {
     wo_SetRXABandpassFreqs(c, f_low, f_high);
-    /* SetRXASNBAOutputBandwidth: snba run = 0, no effect on the data */
+    wo_snba_set_output_bandwidth(c->snba, f_low, f_high);       /* SetRXASNBAOutputBandwidth, snb.c:660 */
     wo_RXANBPSetFreqs(c, f_low, f_high);
 }
 
 void wo_RXASetMP(wo_channel *c, int mp)         /* RXA.c:948-958: nbp0, bp1, FM de-emphasis and audio filter */
 {
     if (c->nbp0.p->mp != mp) fircore_set_mp(c->nbp0.p, mp);       /* RXANBPSetMP, nbp.c:580-590 */
+    if (c->bpsnba.p->mp != mp) fircore_set_mp(c->bpsnba.p, mp);   /* RXABPSNBASetMP, snb.c:845-855 */
     if (c->bp1.p->mp != mp) fircore_set_mp(c->bp1.p, mp);         /* SetRXABandpassMP, bandpass.c:448-457 */
     if (c->fmd.pde->mp != mp) fircore_set_mp(c->fmd.pde, mp);     /* SetRXAFMMPde, fmd.c:296-305 */
     if (c->fmd.paud->mp != mp) fircore_set_mp(c->fmd.paud, mp);   /* SetRXAFMMPaud, fmd.c:325-334 */
@@ -1419,6 +1510,12 @@ void wo_RXASetNC(wo_channel *c, int nc)         /* RXA.c:934-946 */
         c->nbp0.nc = nc;
         imp = nbp0_impulse(c);
         fircore_set_nc(c->nbp0.p, nc, imp);
+        free(imp);
+    }
+    if (c->bpsnba.nc != nc) {                   /* RXABPSNBASetNC, snb.c:830-843 */
+        c->bpsnba.nc = nc;
+        imp = bpsnba_impulse(c);
+        fircore_set_nc(c->bpsnba.p, nc, imp);
         free(imp);
     }
     if (c->bp1.nc != nc) {                      /* SetRXABandpassNC, bandpass.c:428-444 */
@@ -1483,6 +1580,17 @@ void wo_SetRXAEMNRRun(wo_channel *c, int run)
         bp1_check(c, c->amd.run, c->anf.run, c->anr.run);
         *wo_emnr_run(c->emnr) = run;
         bp1_set(c);
+    }
+}
+void wo_SetRXASNBARun(wo_channel *c, int run)          /* snb.c:579-593 */
+{
+    if (*wo_snba_run(c->snba) != run) {
+        bpsnba_check(c, c->mode, c->ndb.master_run);
+        c->snba_pending_run = run;
+        bp1_check(c, c->amd.run, c->anf.run, c->anr.run);
+        *wo_snba_run(c->snba) = run;
+        bp1_set(c);
+        bpsnba_set(c);
     }
 }
 void wo_SetRXAEMNRgainMethod(wo_channel *c, int method) { wo_emnr_set_gain_method(c->emnr, method); }

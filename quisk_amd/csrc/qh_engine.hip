@@ -26,6 +26,7 @@
 #include "qh_kernels.hpp"
 #include "qh_demod.hpp"
 #include "qh_emnr.hpp"
+#include "qh_snba.hpp"
 #include "qh_internal.hpp"
 
 namespace qh {
@@ -74,6 +75,18 @@ struct ChanCfg {
     // anf / anr (create_anf / create_anr of create_rxa, RXA.c:278-315): [0] = anf, [1] = anr
     struct Lms { int run = 0, position = 0, taps = 64, delay = 16; double two_mu = 0.0001, gamma = 0.1; bool dirty = true, flush = false; } lms[2];
     // emnr (create_emnr of create_rxa, RXA.c:319-332)
+    // snba (wdsp/snb.c) and its bandpass bpsnba (snb.c:696-855; run / position follow the mode, RXA.c:883-917)
+    int snba_run = 0, snb_hist_at = 0;
+    bool snba_flush = false, snba_taps_dirty = true, snba_rout_flush = false, snb_dirty = true, snb_flush = false;
+    double snba_f_low = 200.0, snba_f_high = 0.0;               // outresamp fc_low / fcin (snb.c:45-46, resample.c:195-204)
+    int snb_pos() const {
+        if (!snba_run) return -1;
+        switch (mode) {
+        case QH_LSB: case QH_CWL: case QH_DIGL: case QH_USB: case QH_CWU: case QH_DIGU: return 0;
+        case QH_AM: case QH_SAM: case QH_DSB: case QH_FM: return 1;
+        default: return -1;
+        }
+    }
     int emnr_run = 0, emnr_pos = 0, emnr_gain_method = 2, emnr_npe = 0, emnr_ae = 1; bool emnr_dirty = true, emnr_flush = false;
     double emnr_ae_zeta = 0.75, emnr_ae_psi = 20.0, emnr_train_zeta = -2.0, emnr_train_t2 = 0.20;       // emnr.c:332,491-493
     // amsq (create_amsq of create_rxa, RXA.c:158-172)
@@ -106,7 +119,7 @@ struct Engine {
     struct GraphSlot { hipGraphExec_t exec = nullptr; unsigned after = 0; };
     bool graph_on = false, graph_seen = false;
     GraphKey graph_key;
-    GraphSlot graph_slot[32];
+    GraphSlot graph_slot[64];
     long long graph_launches = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -120,7 +133,8 @@ struct Engine {
     double2 *nco_step = nullptr;
     EpiParam *epi = nullptr;
     double2 *hist_front[2] = { nullptr, nullptr }, *hist_nbp[2] = { nullptr, nullptr }, *hist_bp1[2] = { nullptr, nullptr };
-    int cur_front = 0, cur_nbp = 0, cur_bp1 = 0;
+    int cur_front = 0, cur_nbp = 0, cur_bp1 = 0, cur_snb = 0;
+    double2 *mask_snb = nullptr, *hist_snb[2] = { nullptr, nullptr };
     double2 *buf[2] = { nullptr, nullptr };
     long long buf_cap = 0;                  // complex samples per channel
     long long dev_bytes = 0;
@@ -146,6 +160,13 @@ struct Engine {
     double *fix_gain = nullptr;
     // emnr: lists like the LMS filters' ([0] position 0; [1 + b] position 1 with the data in cur / other)
     int *list_emnr[3] = { nullptr, nullptr, nullptr }, n_emnr[3] = { 0, 0, 0 };
+    // snba: bpsnba lists per position, the blanker's list, its parameters, taps, state and the Toeplitz-inverse scratch
+    int *list_snb[2] = { nullptr, nullptr }, n_snb[2] = { 0, 0 }, *list_snba = nullptr, n_snba = 0;
+    SnbaParam snba_prm{};
+    double *snba_state = nullptr, *snba_hin = nullptr, *snba_hout = nullptr, *snba_scratch = nullptr;
+    SnbaIdx *snba_idx = nullptr;
+    std::vector<char> snb_listed;
+    int snba_alloc();
     EmnrParam emnr_prm{};
     EmnrChan *emnr_chan = nullptr;
     EmnrScalars *emnr_scal = nullptr;
@@ -172,8 +193,8 @@ struct Engine {
     SnotchState *sn_state = nullptr;
     double2 *mask_de = nullptr, *mask_aud = nullptr, *hist_de[2] = { nullptr, nullptr }, *hist_aud[2] = { nullptr, nullptr };
     int cur_de = 0, cur_aud = 0, fm_nc_built = 0, fm_mp = 0, fm_mp_built = 0;
-    unsigned flags() const { return (unsigned)(cur_front | cur_nbp << 1 | cur_bp1 << 2 | cur_de << 3 | cur_aud << 4); }
-    void set_flags(unsigned f) { cur_front = f & 1; cur_nbp = f >> 1 & 1; cur_bp1 = f >> 2 & 1; cur_de = f >> 3 & 1; cur_aud = f >> 4 & 1; }
+    unsigned flags() const { return (unsigned)(cur_front | cur_nbp << 1 | cur_bp1 << 2 | cur_de << 3 | cur_aud << 4 | cur_snb << 5); }
+    void set_flags(unsigned f) { cur_front = f & 1; cur_nbp = f >> 1 & 1; cur_bp1 = f >> 2 & 1; cur_de = f >> 3 & 1; cur_aud = f >> 4 & 1; cur_snb = f >> 5 & 1; }
     void drop_graphs() { for (auto &g : graph_slot) if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; } }
     int process_replayed(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     AgcParam *agc_prm = nullptr;
@@ -220,6 +241,8 @@ Engine::~Engine()
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
+    (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
+    (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx);
     (void)hipFree(emnr_chan); (void)hipFree(emnr_scal); (void)hipFree(emnr_state); (void)hipFree(emnr_window); (void)hipFree(emnr_GG);
     (void)hipFree(emnr_GGS); (void)hipFree(emnr_zeta); (void)hipFree(emnr_zeta_true);
     (void)hipFree(amsq_prm); (void)hipFree(amsq_state); (void)hipFree(amsq_cup); (void)hipFree(amsq_cdown); (void)hipFree(amsq_mag);
@@ -367,6 +390,39 @@ int Engine::refresh_params()
             QH_HIP(hipStreamSynchronize(stream));
             c.epi_dirty = false;
         }
+        if (c.nbp_dirty) c.snb_dirty = true;        // bpsnba's nbp shares nc, window, auto-increase, mp and the notch database with nbp0
+        if (c.snb_dirty && c.snba_run && mask_snb) {
+            // recalc_bpsnba_filter (snb.c:807-822) with RXAbpsnbaCheck's frequencies (RXA.c:829-881): 250..5700 Hz on the mode's side
+            double f_low = 0.0, f_high = 0.0;
+            int run_notches = 0;
+            switch (c.mode) {
+            case QH_LSB: case QH_CWL: case QH_DIGL: f_low = -5700.0; f_high = -250.0; run_notches = c.fnfrun; break;
+            case QH_USB: case QH_CWU: case QH_DIGU: f_low = 250.0; f_high = 5700.0; run_notches = c.fnfrun; break;
+            case QH_AM: case QH_SAM: case QH_DSB: case QH_FM: f_low = 250.0; f_high = 5700.0; break;
+            default: break;
+            }
+            std::vector<cd> h;
+            const double scale = 1.0 / (double)(2 * dsp_size);
+            if (run_notches) {
+                const double offset = c.ndb_tunefreq + c.ndb_shift;
+                const double minwidth = (c.nbp_wintype == 1 ? 2200.0 : 1600.0) / (c.nbp_nc / 256) * ((double)dsp_rate / 48000);
+                std::vector<std::pair<double, double>> bands = make_nbp(c.notches, minwidth, c.autoincr, f_low + offset, f_high + offset, nullptr);
+                for (auto &b : bands) { b.first -= offset; b.second -= offset; }
+                h = fir_mbandpass(c.nbp_nc, bands, (double)dsp_rate, scale, c.nbp_wintype);
+            } else
+                h = fir_bandpass(c.nbp_nc, f_low, f_high, (double)dsp_rate, c.nbp_wintype, 1, scale);
+            if (c.mp) h = mp_imp(h, 16, 0);
+            for (auto &v : h) v *= (double)(2 * dsp_size);
+            const std::vector<cd> m = make_mask(h, kNfft);
+            QH_HIP(hipMemcpyAsync(mask_snb + (size_t)ch * kNfft, m.data(), kNfft * sizeof(cd), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            c.snb_dirty = false;
+        }
+        if (c.snb_flush && hist_snb[0]) {           // setNc_fircore zeroes the delay line
+            for (int i = 0; i < 2; i++)
+                QH_HIP(hipMemsetAsync(hist_snb[i] + (size_t)ch * kHistBand, 0, kHistBand * sizeof(double2), stream));
+        }
+        c.snb_flush = false;
         if (c.nbp_dirty) {
             // calc_nbp_impulse without notches, wdsp/nbp.c:234-238; identity when the filter is off
             bool same = !c.fnfrun && last_nbp_cfg && !last_nbp_cfg->fnfrun && last_nbp_cfg->nbp_run == c.nbp_run && last_nbp_cfg->nbp_nc == c.nbp_nc &&
@@ -437,10 +493,11 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 21));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 24));
         list_amsq = list_buf + 17 * nch;
         for (int k = 0; k < 3; k++) list_emnr[k] = list_buf + (18 + k) * nch;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
+        list_snb[0] = list_buf + 21 * nch; list_snb[1] = list_buf + 22 * nch; list_snba = list_buf + 23 * nch;
         list_bp1p[0] = list_buf + 13 * nch; list_bp1p[1] = list_buf + 14 * nch;
         list_fix[0] = list_buf + 15 * nch; list_fix[1] = list_buf + 16 * nch;
         QH_HIP(dev_alloc(&fix_gain, (size_t)nch));
@@ -512,10 +569,12 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3];
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
             if (c.amsq_run) lsq.push_back(ch);
+            if (c.snba_run) lsnba.push_back(ch);
+            if (c.snb_pos() >= 0) lsn[c.snb_pos()].push_back(ch);
             if (c.emnr_run) lem[c.emnr_pos ? 1 + ((c.bp1_run && !c.bp1_pos) ? 1 : 0) : 0].push_back(ch);
             const int at_agc = (c.bp1_run && !c.bp1_pos) ? 1 : 0;       // the buffer the channel is in when xwcpagc runs
             for (int f = 0; f < 2; f++) if (c.lms[f].run) lms_l[f][c.lms[f].position ? 1 + at_agc : 0].push_back(ch);
@@ -536,6 +595,23 @@ int Engine::refresh_demod()
         n_amsq = (int)lsq.size();
         for (int k = 0; k < 3; k++) n_emnr[k] = (int)lem[k].size();
         if ((n_emnr[0] || n_emnr[1] || n_emnr[2]) && !emnr_state) if (int rc = emnr_alloc()) return rc;
+        n_snb[0] = (int)lsn[0].size(); n_snb[1] = (int)lsn[1].size(); n_snba = (int)lsnba.size();
+        if (n_snba && !snba_state) if (int rc = snba_alloc()) return rc;
+        if (snba_state) {
+            // bpsnba's fircore keeps its delay line while it does not run: a channel that (re)joins the list finds its rows in
+            // the ping-pong half that was current when it left
+            for (int ch = 0; ch < nch; ch++) if (snb_listed[(size_t)ch]) cfg[(size_t)ch].snb_hist_at = cur_snb;
+            std::fill(snb_listed.begin(), snb_listed.end(), 0);
+            for (int ps = 0; ps < 2; ps++)
+                for (int ch : lsn[ps]) {
+                    ChanCfg &c = cfg[(size_t)ch];
+                    if (c.snb_hist_at != cur_snb)
+                        QH_HIP(hipMemcpyAsync(hist_snb[cur_snb] + (size_t)ch * kHistBand, hist_snb[c.snb_hist_at] + (size_t)ch * kHistBand,
+                                              kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                    c.snb_hist_at = cur_snb;
+                    snb_listed[(size_t)ch] = 1;
+                }
+        }
         if (n_amsq && !amsq_prm) {
             QH_HIP(dev_alloc(&amsq_prm, (size_t)nch));
             QH_HIP(dev_alloc(&amsq_state, (size_t)nch));
@@ -591,6 +667,7 @@ int Engine::refresh_demod()
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
         QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1])); QH_HIP(put(list_amsq, lsq));
         for (int k = 0; k < 3; k++) QH_HIP(put(list_emnr[k], lem[k]));
+        QH_HIP(put(list_snb[0], lsn[0])); QH_HIP(put(list_snb[1], lsn[1])); QH_HIP(put(list_snba, lsnba));
         std::vector<double> fg((size_t)nch);
         for (int ch = 0; ch < nch; ch++) fg[(size_t)ch] = cfg[(size_t)ch].agc_fixed;
         QH_HIP(hipMemcpyAsync(fix_gain, fg.data(), fg.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -656,6 +733,35 @@ int Engine::refresh_demod()
             QH_HIP(hipStreamSynchronize(stream));
             c.emnr_flush = false;
         }
+        if (snba_state && c.snba_taps_dirty) {
+            // calc_resample for outresamp (12 kHz -> dsp_rate, gain 2, resample.c:35-79) with the channel's output bandwidth
+            const SnbaParam &q = snba_prm;
+            if (q.ratio > 1) {
+                const int L = q.ratio, ncoef = q.cpp_out * L;
+                const double full = (double)(12000 * L), fc = c.snba_f_high == 0.0 ? 0.45 * 12000.0 : c.snba_f_high;
+                const double lo = c.snba_f_low < 0.0 ? -fc / full : c.snba_f_low / full;
+                const std::vector<cd> imp = fir_bandpass(ncoef, lo, fc / full, 1.0, 1, 0, 2.0 * (double)L);
+                std::vector<double> hp((size_t)ncoef);
+                size_t i = 0;
+                for (int j = 0; j < L; j++) for (int k = 0; k < ncoef; k += L) hp[i++] = imp[(size_t)(j + k)].real();
+                QH_HIP(hipMemcpyAsync(snba_hout + (size_t)ch * ncoef, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+                QH_HIP(hipStreamSynchronize(stream));
+            }
+            c.snba_taps_dirty = false;
+        }
+        if (snba_state && (c.snba_flush || c.snba_rout_flush)) {
+            const SnbaParam &q = snba_prm;
+            double *st = snba_state + (size_t)ch * q.state_doubles;
+            if (q.cpp_out > 1) QH_HIP(hipMemsetAsync(st + q.off_rout, 0, (size_t)(q.cpp_out - 1) * sizeof(double), stream));
+            if (c.snba_flush) {         // flush_snba, snb.c:161-185: the frame half of xbase, the accumulators, both resamplers
+                QH_HIP(hipMemsetAsync(st + kSnbX, 0, (size_t)kSnbX * sizeof(double), stream));
+                QH_HIP(hipMemsetAsync(st + q.off_inacc, 0, (size_t)(q.state_doubles - q.off_inacc) * sizeof(double), stream));
+                const SnbaIdx ix{ 0, 0, 0, 0, q.init_oaoutidx, { 0, 0, 0 } };
+                QH_HIP(hipMemcpyAsync(snba_idx + ch, &ix, sizeof(ix), hipMemcpyHostToDevice, stream));
+                QH_HIP(hipStreamSynchronize(stream));
+            }
+        }
+        c.snba_flush = c.snba_rout_flush = false;
         if (amsq_prm && c.amsq_dirty) {
             // calc_amsq, amsq.c:48-64: 10 ms average (RXA.c:165)
             AmsqParam q{};
@@ -763,6 +869,51 @@ int Engine::refresh_demod()
 }
 
 // calc_emnr (wdsp/emnr.c:240-497) with create_rxa's arguments (RXA.c:319-332): parameters, window, start values of every array
+int Engine::snba_alloc()
+{
+    // calc_snba, snb.c:31-66, with create_rxa's arguments (RXA.c:237-255)
+    SnbaParam &q = snba_prm;
+    if (dsp_rate % 12000 || (dsp_rate / 12000 != 1 && dsp_rate / 12000 != 2 && dsp_rate / 12000 != 4) || dsp_size > kSnbMaxDsp ||
+        dsp_size % (dsp_rate / 12000))
+        return set_error(QH_ERR_UNSUPPORTED, "SNBA: dsp_rate 12000, 24000 or 48000 and dsp_size up to %d", kSnbMaxDsp);
+    q.ratio = dsp_rate / 12000;
+    q.isize = dsp_size / q.ratio;
+    q.incr = kSnbX / 4;
+    q.iasize = q.incr > q.isize ? q.incr : q.isize;
+    q.oasize = q.iasize;
+    q.init_oaoutidx = q.incr > q.isize ? q.isize : 0;
+    q.cpp_in = q.ratio > 1 ? 140 * q.ratio + 1 : 1;
+    q.cpp_out = q.ratio > 1 ? 141 : 1;
+    q.asize = 64; q.npasses = 2; q.b = 10; q.pre = 2; q.post = 2; q.k1 = 8.0; q.k2 = 20.0; q.pmultmin = 0.5;
+    q.off_inacc = 2 * kSnbX; q.off_outacc = q.off_inacc + q.iasize; q.off_rin = q.off_outacc + q.oasize;
+    q.off_rout = q.off_rin + (q.cpp_in - 1); q.state_doubles = q.off_rout + (q.cpp_out - 1);
+    QH_HIP(dev_alloc(&snba_state, (size_t)nch * q.state_doubles));
+    QH_HIP(hipMemsetAsync(snba_state, 0, (size_t)nch * q.state_doubles * sizeof(double), stream));
+    QH_HIP(dev_alloc(&snba_idx, (size_t)nch));
+    std::vector<SnbaIdx> ix((size_t)nch, SnbaIdx{ 0, 0, 0, 0, q.init_oaoutidx, { 0, 0, 0 } });
+    QH_HIP(hipMemcpyAsync(snba_idx, ix.data(), ix.size() * sizeof(SnbaIdx), hipMemcpyHostToDevice, stream));
+    QH_HIP(dev_alloc(&snba_scratch, (size_t)nch * kSnbX * kSnbX));
+    QH_HIP(dev_alloc(&snba_hin, (size_t)q.cpp_in));
+    QH_HIP(dev_alloc(&snba_hout, (size_t)nch * q.cpp_out * q.ratio));
+    std::vector<double> hin((size_t)q.cpp_in, 1.0);
+    if (q.ratio > 1) {      // inresamp: dsp_rate -> 12 kHz, 250 .. 5400 Hz, gain 2 (snb.c:43-44)
+        const double full = (double)dsp_rate;
+        const std::vector<cd> imp = fir_bandpass(q.cpp_in, 250.0 / full, 0.45 * 12000.0 / full, 1.0, 1, 0, 2.0);
+        for (int i = 0; i < q.cpp_in; i++) hin[(size_t)i] = imp[(size_t)i].real();
+    }
+    QH_HIP(hipMemcpyAsync(snba_hin, hin.data(), hin.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    QH_HIP(dev_alloc(&mask_snb, (size_t)nch * kNfft));
+    for (int i = 0; i < 2; i++) {
+        QH_HIP(dev_alloc(&hist_snb[i], (size_t)nch * kHistBand));
+        QH_HIP(hipMemsetAsync(hist_snb[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
+    }
+    QH_HIP(hipStreamSynchronize(stream));
+    dev_bytes += (long long)nch * ((long long)q.state_doubles * 8 + (long long)kSnbX * kSnbX * 8 + (long long)kNfft * 16 + 2LL * kHistBand * 16);
+    snb_listed.assign((size_t)nch, 0);
+    for (ChanCfg &c : cfg) { c.snba_taps_dirty = true; c.snb_dirty = true; c.snba_flush = c.snba_rout_flush = false; c.snb_flush = false; c.snb_hist_at = cur_snb; }
+    return QH_OK;
+}
+
 int Engine::emnr_alloc()
 {
     if (dsp_size > kEmnrIncr) return set_error(QH_ERR_UNSUPPORTED, "EMNR: dsp_size up to %d", kEmnrIncr);
@@ -1016,7 +1167,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
-        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || meters_on) mixed = true;
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || c.snba_run || meters_on) mixed = true;
         if (c.emnr_run && !emnr_tables) return set_error(QH_ERR_INVALID, "EMNR needs its gain tables first (qh_rxa_SetEMNRTables: WDSP's `calculus` and `zetaHat.bin` data)");
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
@@ -1025,6 +1176,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
     if (int rc = refresh_params()) return rc;
     if (mixed) if (int rc = refresh_demod()) return rc;
+    if (n_snba) if (int rc = refresh_params()) return rc;       // bpsnba's mask needs the buffers the line above may just have made
 
     const long long n_in = (long long)nblk * dsp_insize;
     const long long n_mid = (long long)nblk * dsp_size;
@@ -1091,6 +1243,18 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         hipLaunchKernelGGL(amsq_cap_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_amsq), dim3(NT), 0, stream, cur, buf_cap,
                            (int)n_mid, list_amsq, amsq_mag, amsq_mag_cap);
     }
+    // xbpsnbaout at position 0 (RXA.c:572): the 250..5700 Hz filter of the signal ahead of nbp0 replaces nbp0's output
+    auto snb_inplace = [&](const int *list, int n) {
+        int hc = cur_snb;
+        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_snb, kNfft, hist_snb, hc, P, list, n);
+        long long per = (n_mid + NT - 1) / NT;
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n), dim3(NT), 0, stream, other, cur, buf_cap,
+                           (int)n_mid, list);
+    };
+    if (n_snb[0]) {
+        if (any_nbp) { int hc = cur_snb; run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_snb, kNfft, hist_snb, hc, P, list_snb[0], n_snb[0]); }
+        else snb_inplace(list_snb[0], n_snb[0]);
+    }
     tick(1);
     if (n_am) hipLaunchKernelGGL(am_detect_kernel, dim3((unsigned)n_am), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                  list_am, levelfade, am_state, am_prm);
@@ -1108,6 +1272,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
                                lim_state, 0.4);
     }
+    if (n_snb[1]) snb_inplace(list_snb[1], n_snb[1]);       // xbpsnbain / xbpsnbaout at position 1 (RXA.c:576-577)
+    if (n_snb[0] || n_snb[1]) cur_snb ^= 1;
+    if (n_snba)                                             // xsnba, RXA.c:578
+        hipLaunchKernelGGL(snba_kernel, dim3((unsigned)n_snba), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, list_snba, snba_prm,
+                           snba_hin, snba_hout, snba_state, snba_idx, snba_scratch);
     // xanf, xanr, xbandpass(bp1) at position 0, xwcpagc, then the same three at position 1 (RXA.c:579-586).  The two bp1
     // launches work on disjoint channel rows of one ping-pong history pair, so the pair flips once for both.
     auto lms_on = [&](int k, double2 *b) {
@@ -1227,16 +1396,17 @@ long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
     } while (0)
 
 // RXAbp1Check + RXAbp1Set, wdsp/RXA.c:800-827 (snba/emnr/anf/anr never run here)
-static void bp1_check_set(ChanCfg &c, int amd_run, int anf_run, int anr_run, int emnr_run = -1)
+static void bp1_check_set(ChanCfg &c, int amd_run, int anf_run, int anr_run, int emnr_run = -1, int snba_run = -1)
 {
     if (emnr_run < 0) emnr_run = c.emnr_run;
-    const double gain = (amd_run || anf_run || anr_run || emnr_run) ? 2.0 : 1.0;
+    if (snba_run < 0) snba_run = c.snba_run;
+    const double gain = (amd_run || anf_run || anr_run || emnr_run || snba_run) ? 2.0 : 1.0;
     if (c.bp1_gain != gain) { c.bp1_gain = gain; c.bp1_dirty = true; }
 }
 static void bp1_set(ChanCfg &c)
 {
     const int old = c.bp1_run;
-    c.bp1_run = (c.amd_run || c.lms[0].run || c.lms[1].run || c.emnr_run) ? 1 : 0;
+    c.bp1_run = (c.amd_run || c.lms[0].run || c.lms[1].run || c.emnr_run || c.snba_run) ? 1 : 0;
     if (old != c.bp1_run) c.bp1_dirty = true;
     if (!old && c.bp1_run) c.bp1_flush = true;
 }
@@ -1253,6 +1423,7 @@ int qh_rxa_SetRXAMode(qh_rxa *h, int ch, int mode)
             else if (mode == QH_SAM) { c.amd_run = 1; c.amd_mode = 1; }
             else if (mode == QH_FM) { c.fmd_run = 1; c.agc_run = 0; }
             bp1_set(c);
+            c.snb_dirty = true;
             c.epi_dirty = true;
             h->e.lists_dirty = true;
         }
@@ -1288,10 +1459,61 @@ int qh_rxa_RXANBPSetFreqs(qh_rxa *h, int ch, double flow, double fhigh)
     });
 }
 
+// SetRXASNBAOutputBandwidth, wdsp/snb.c:660-694: the pass band of the blanker's 12 kHz -> dsp_rate resampler
+int qh_rxa_SetRXASNBAOutputBandwidth(qh_rxa *h, int ch, double flow, double fhigh)
+{
+    FOR_CH(h, ch, {
+        const double lc = 200.0;        // out_low_cut / out_high_cut, RXA.c:254-255
+        const double hc = 5400.0;
+        double lo = flow;
+        double hi = fhigh;
+        double f_low = c.snba_f_low;
+        double f_high = c.snba_f_high;
+        if (lo >= 0 && hi >= 0) {
+            if (hi < lc) hi = lc;
+            if (lo > hc) lo = hc;
+            f_low = lc > lo ? lc : lo;
+            f_high = hc < hi ? hc : hi;
+        } else if (lo <= 0 && hi <= 0) {
+            if (lo > -lc) lo = -lc;
+            if (hi < -hc) hi = -hc;
+            f_low = lc > -hi ? lc : -hi;
+            f_high = hc < -lo ? hc : -lo;
+        } else if (lo < 0 && hi > 0) {
+            double absmax = -lo > hi ? -lo : hi;
+            if (absmax < lc) absmax = lc;
+            f_low = lc;
+            f_high = hc < absmax ? hc : absmax;
+        }
+        if (f_low != c.snba_f_low || f_high != c.snba_f_high) {     // setBandwidth_resample rebuilds the filter and clears its ring
+            c.snba_f_low = f_low; c.snba_f_high = f_high;
+            c.snba_taps_dirty = true; c.snba_rout_flush = true;
+            c.epi_dirty = true;
+        }
+    });
+}
+
+// SetRXASNBARun, wdsp/snb.c:579-593
+int qh_rxa_SetRXASNBARun(qh_rxa *h, int ch, int run)
+{
+    FOR_CH(h, ch, {
+        run = run ? 1 : 0;
+        if (c.snba_run != run) {
+            bp1_check_set(c, c.amd_run, c.lms[0].run, c.lms[1].run, -1, run);
+            c.snba_run = run;
+            bp1_set(c);
+            c.snb_dirty = true;
+            c.epi_dirty = true;
+            h->e.lists_dirty = true;
+        }
+    });
+}
+
 int qh_rxa_RXASetPassband(qh_rxa *h, int ch, double f_low, double f_high)
 {
     int rc = qh_rxa_SetRXABandpassFreqs(h, ch, f_low, f_high);
     if (rc) return rc;
+    if ((rc = qh_rxa_SetRXASNBAOutputBandwidth(h, ch, f_low, f_high))) return rc;
     return qh_rxa_RXANBPSetFreqs(h, ch, f_low, f_high);
 }
 
@@ -1300,7 +1522,7 @@ int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
     if (nc < 1 || (nc & (nc - 1)) || nc > kHistBand + 1 || (h && nc < h->e.dsp_size))
         return set_error(QH_ERR_UNSUPPORTED, "nc must be a power of two in [dsp_size, %d]", kHistBand + 1);
     FOR_CH(h, ch, {
-        if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; }
+        if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; c.snb_flush = true; }
         if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; }
         c.fm_nc = nc;                           // SetRXAFMNCde / SetRXAFMNCaud, wdsp/RXA.c:942-943
     });
@@ -1665,7 +1887,7 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
         }
     }
-    for (ChanCfg &c : e.cfg) { c.lms[0].flush = c.lms[1].flush = true; c.emnr_flush = true; }    // flush_anf / flush_anr / flush_emnr, RXA.c:541-543
+    for (ChanCfg &c : e.cfg) { c.lms[0].flush = c.lms[1].flush = true; c.emnr_flush = true; c.snba_flush = true; c.snb_flush = true; }    // flush_anf / flush_anr / flush_emnr, RXA.c:541-543
     if (e.amsq_state) QH_HIP(hipMemsetAsync(e.amsq_state, 0, (size_t)e.nch * sizeof(AmsqState), e.stream));     // flush_amsq
     if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch
         QH_HIP(hipMemsetAsync(e.am_state, 0, (size_t)e.nch * sizeof(AmState), e.stream));

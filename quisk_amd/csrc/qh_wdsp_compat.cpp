@@ -582,14 +582,6 @@ int wdspFexchange0(int channel, double *cSamples, int nSamples)
 // xpanel never looks at its run flag (wdsp/patchpanel.c:55-101): accepted, no effect on the data.
 void SetRXAPanelRun(int channel, int run) { (void)run; g_status = QH_OK; (void)valid(channel); }
 void RXASetMP(int channel, int mp) { WDSP_SETTER(qh_rxa_RXASetMP(L.c->eng, 0, mp)); }     // wdsp/RXA.c:948-958
-// blocks that are run = 0 on the hot path: run = 0 is accepted, run = 1 is reported as unsupported
-#define WDSP_OFF_ONLY(name)                                                                        \
-    void name(int channel, int run)                                                                \
-    {                                                                                              \
-        g_status = QH_OK;                                                                          \
-        if (!valid(channel)) return;                                                               \
-        if (run) g_status = qh::set_error(QH_ERR_UNSUPPORTED, #name "(%d, 1): block is outside the GPU hot path", channel); \
-    }
 void SetRXAEMNRgainMethod(int channel, int method) { WDSP_SETTER(qh_rxa_SetRXAEMNRgainMethod(L.c->eng, 0, method)); }      // emnr.c:1112
 
 // fexchange2 (wdsp/iobuffs.c:518-582): the same exchange with separate float I and Q buffers (INREAL / OUTREAL are
@@ -611,6 +603,7 @@ void fexchange2(int channel, float *Iin, float *Qin, float *Iout, float *Qout, i
     for (int i = 0; i < out_size; i++) { Iout[i] = (float)out[2 * (size_t)i]; Qout[i] = (float)out[2 * (size_t)i + 1]; }
 }
 
-WDSP_OFF_ONLY(SetRXASNBARun)
+void SetRXASNBARun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXASNBARun(L.c->eng, 0, run)); }          // wdsp/snb.c:579-593
+void SetRXASNBAOutputBandwidth(int channel, double flow, double fhigh) { WDSP_SETTER(qh_rxa_SetRXASNBAOutputBandwidth(L.c->eng, 0, flow, fhigh)); }  // snb.c:660-694
 
 }  // extern "C"

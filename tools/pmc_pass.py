@@ -44,8 +44,8 @@ def main():
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if "qh::" in row["Kernel_Name"]:
-                    k = row["Kernel_Name"].replace("void ", "").split("(")[0]
+                if "qh::" in row["Kernel_Name"] or "anonymous namespace" in row["Kernel_Name"]:
+                    k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
                     acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         if not acc:
             res["_errors"]["group%d" % gi] = (r.stderr or r.stdout)[-400:]
