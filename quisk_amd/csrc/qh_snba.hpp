@@ -11,6 +11,7 @@
 // the predictor `a` while P1 = A1'A2 is formed; the Toeplitz inverse (up to xsize x xsize) lives in a per-channel scratch.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "qh_wave.hpp"
 
 namespace qh {
 
@@ -44,17 +45,25 @@ struct SnbaLds {
 static __device__ void snba_asolve(SnbaLds &s, int xsize, int asize, const double *x, int lane)
 {
 #pragma clang fp contract(off)
-    for (int i = lane; i <= asize; i += 64) {
-        double acc = 0.0;
-        for (int j = 0; j < xsize; j++) acc += x[j] * x[j - i];
-        s.r[i] = acc;
-        s.z[i] = i == 0 ? 1.0 : 0.0;
+    {   // lags lane and lane + 64 side by side (asize <= 64: the second one is lag 64 in lane 0); each sum in the order j = 0 .. xsize - 1
+        double acc = 0.0, acc2 = 0.0;
+        const double *xa = x - lane, *xb2 = x - lane - 64;
+#pragma unroll 8
+        for (int j = 0; j < xsize; j++) {
+            const double xj = x[j];
+            acc += xj * xa[j];
+            acc2 += xj * xb2[j];
+        }
+        if (lane <= asize) { s.r[lane] = acc; s.z[lane] = lane == 0 ? 1.0 : 0.0; }
+        if (lane + 64 <= asize) { s.r[lane + 64] = acc2; s.z[lane + 64] = 0.0; }
     }
     __syncthreads();
     double beta = s.r[0];
     for (int k = 0; k < asize; k++) {
+        // the products in parallel, their sum in the reference's order j = 0 .. k (one readlane + one subtract per term)
+        const double prod = lane <= k ? s.z[lane] * s.r[k + 1 - lane] : 0.0;
         double alpha = 0.0;
-        for (int j = 0; j <= k; j++) alpha -= s.z[j] * s.r[k + 1 - j];
+        for (int j = 0; j <= k; j++) alpha -= lane_bcast(prod, j);
         alpha /= beta;
         const int half = (k + 1) / 2;
         double zi = 0.0, zo = 0.0;
@@ -114,10 +123,13 @@ static __device__ void snba_det(SnbaLds &s, const SnbaParam &q, int asize, int l
     __syncthreads();
     const double t1 = q.k1 * s.scal[0];
     double t2 = 0.0;
-    for (int i = asize; i < xs; i++) {
-        const double p = s.vpwr[i];
-        if (p <= t1) t2 += p;
-        else if (p <= 2.0 * t1) t2 += 2.0 * t1 - p;
+    for (int base = asize; base < xs; base += 64) {        // contributions in parallel (0.0 where the reference adds nothing), summed in order
+        const int i = base + lane;
+        const double p = i < xs ? s.vpwr[i] : 0.0;
+        double c = 0.0;
+        if (i < xs) { if (p <= t1) c = p; else if (p <= 2.0 * t1) c = 2.0 * t1 - p; }
+        const int cnt = xs - base < 64 ? xs - base : 64;
+        for (int j = 0; j < cnt; j++) t2 += lane_bcast(c, j);
     }
     t2 *= q.k2 / (double)n;
     for (int i = lane; i < xs; i += 64) s.det[i] = (i >= asize && s.vpwr[i] > t2) ? 1 : 0;

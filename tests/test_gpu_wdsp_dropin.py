@@ -251,6 +251,25 @@ def test_anf_and_anr_through_the_wdsp_names(qh, oracle):
     assert rel_rms(np.concatenate([y1, y2]), np.concatenate([r1, r2])) < 1e-6
 
 
+def test_snba_through_the_wdsp_names_as_quisk_switches_it(qh, oracle):
+    """quisk.py:6041-6047: SetRXASNBARun(ch, 1) on a running channel, off again later; block-at-a-time fexchange0 (graph replay)."""
+    lib = qh.load()
+    lib.SetRXASNBARun.argtypes = [C.c_int, C.c_int]
+    ch, in_size, out_size, nb = 14, 1024, 256, 90
+    _open(lib, ch, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    o = _oracle(oracle, in_size, 256, 192000, True, shift_freq=synth.shift_freq(0))
+    x = synth.impulsive_input(1, nb * in_size, seed=4, scale=0.01)[0] + synth.make_input_numpy(1, nb * in_size)[0]
+    ys, rs = [], []
+    for (a, b), run in (((0, 20), 0), ((20, 70), 1), ((70, 90), 0)):
+        lib.SetRXASNBARun(ch, run); o.SetRXASNBARun(run)
+        assert lib.qh_wdsp_status() == 0
+        ys.append(_run(lib, ch, x[a * in_size:b * in_size], in_size, out_size)); rs.append(o.fexchange0(x[a * in_size:b * in_size])[0])
+    lib.CloseChannel(ch)
+    y, r = np.concatenate(ys), np.concatenate(rs)
+    assert rel_rms(y, r) < 1e-6, rel_rms(y, r)
+    assert rel_rms(r[40 * out_size:70 * out_size], r[40 * out_size:70 * out_size].real) > 1e-3     # bp1 made it analytic again
+
+
 def test_set_channel_state_slews_down_flushes_and_restarts_like_a_fresh_channel(qh, oracle):
     """SetChannelState(ch, 0, 0) (wdsp/channel.c:261-296): the following fexchange0 calls run the down-slew state machine on the
     output (iobuffs.c:226-300: the first sample as it is, then tdelaydown, then a raised cosine over tslewdown, then zeros up to the
