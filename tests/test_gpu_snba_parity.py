@@ -128,3 +128,48 @@ def test_snba_with_the_notch_database_and_graph_replay(qh, oracle):
     for ch in range(nch):
         ref = refs[ch].xrxa(x[ch])
         assert rel_rms(y[ch], ref) < 1e-6, (ch, rel_rms(y[ch], ref))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_snba_seeded_setter_walks(qh, oracle, seed):
+    """Random walks over what moves bpsnba / snba / bp1 around: the blanker on and off, modes that put bpsnba at position 0 or 1,
+    pass bands (the output resampler is rebuilt and its ring cleared), the notch database, filter lengths.  State carry is what is
+    tested: bpsnba's delay line survives while it is off, the ping-pong histories flip only on calls where some channel runs it."""
+    rng = np.random.default_rng(7000 + seed)
+    nch, nseg = 2, 14
+    e = qh.RxaEngine(nch)
+    refs = [oracle.WdspChannel(1024, 256, 192000, 48000, 48000) for _ in range(nch)]
+    mode = [USB, LSB]
+    for ch in range(nch):
+        for t, a in ((e, (ch,)), (refs[ch], ())):
+            setup(t, a, ch, mode[ch])
+            t.RXANBPAddNotch(*a, 0, 900.0 if mode[ch] == USB else -900.0, 150.0, 1)
+    e.SetRXASNBARun(1, 1); refs[1].SetRXASNBARun(1)          # channel 1 keeps it on throughout: the histories flip on every call
+    segs = [int(v) for v in rng.integers(1, 24, nseg)]
+    x = np.stack([crackle(c, sum(segs) * 1024, USB, rate=15.0) for c in range(nch)])
+    pos, ys, rs, log = 0, [], [[] for _ in range(nch)], []
+    for n in segs:
+        kind = int(rng.integers(0, 6))
+        both = lambda f: [f(e, (0,)), f(refs[0], ())]
+        if kind == 0:
+            run = int(rng.integers(0, 2)); both(lambda t, a: t.SetRXASNBARun(*a, run)); log.append(("run", run))
+        elif kind == 1:
+            m = int(rng.choice([USB, LSB, AM, 4])); both(lambda t, a: t.SetRXAMode(*a, m)); log.append(("mode", m))
+        elif kind == 2:
+            lo = float(rng.choice([150.0, 300.0, 500.0])); hi = float(rng.choice([2400.0, 3000.0, 6000.0]))
+            both(lambda t, a: t.RXASetPassband(*a, lo, hi)); log.append(("pass", lo, hi))
+        elif kind == 3:
+            nr = int(rng.integers(0, 2)); both(lambda t, a: t.RXANBPSetNotchesRun(*a, nr)); log.append(("notches", nr))
+        elif kind == 4:
+            nc = int(rng.choice([512, 1024, 2048])); both(lambda t, a: t.RXASetNC(*a, nc)); log.append(("nc", nc))
+        else:
+            run = 1; both(lambda t, a: t.SetRXASNBARun(*a, run)); log.append(("run", 1))
+        ys.append(e.process_host(x[:, pos * 1024:(pos + n) * 1024]))
+        for ch in range(nch):
+            rs[ch].append(refs[ch].xrxa(x[ch, pos * 1024:(pos + n) * 1024]))
+        pos += n
+    y = np.concatenate(ys, axis=1)
+    for ch in range(nch):
+        ref = np.concatenate(rs[ch])
+        assert np.all(np.isfinite(ref))
+        assert rel_rms(y[ch], ref) < 1e-5, (seed, ch, rel_rms(y[ch], ref), log)
