@@ -34,7 +34,7 @@ def cpu_baseline(log2_samples=23):
     from quisk_amd import synth
     po.build(ref=False)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
+    cores = max(1, cores)               # every core this process may run on (what `nproc` prints)
     n = 1 << log2_samples
     po.fft(np.zeros(512, dtype=np.complex128))                  # warm the oracle's twiddle cache before threading
     x = synth.make_input_numpy(1, n)[0]
@@ -53,7 +53,7 @@ def cpu_baseline(log2_samples=23):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(lambda ch: ch.xrxa(x), chans))              # ctypes releases the GIL inside the C call
     dt = time.perf_counter() - t0
-    return {"value": cores * n / dt / 1e6, "unit": "Mcomplex-samples/s", "cores": cores, "kind": "port",
+    return {"value": cores * n / dt / 1e6, "unit": "Mcomplex-samples/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
             "sample": "%d channels (one per core) x 2^%d input samples, oracle/wdsp_oracle.c -O3, own radix-2 FFT (not FFTW)"
                       % (cores, log2_samples)}
 
@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--channels", type=int, default=NCH, help="channels per GPU")
     ap.add_argument("--log2-samples", type=int, default=LOG2_SAMPLES, help="input samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--meters", choices=["on", "off"], default="on",
+                    help="on (default): xrxa's three meters run as in the reference (adc, S, agc: wdsp/RXA.c:566,569,589), "
+                         "fused into the nbp0 launch; the line also carries the rate of a second, untimed-for-`value` run with them off")
     ap.add_argument("--chunks", type=int, default=1,
                     help="split a step into this many consecutive time chunks (engine calls); the intermediate "
                          "buffer of a chunk then stays in the 256 MiB Infinity Cache")
@@ -111,6 +114,7 @@ def main():
     eng.RXASetPassband(-1, 300.0, 3000.0)
     eng.SetRXAAGCMode(-1, 0)
     eng.SetRXAAGCFixed(-1, 0.0)
+    eng.enable_meters(args.meters == "on")
 
     x = synth.make_input_torch(nch, n_in, dev, fs=float(IN_RATE), first_channel=first)
     y = torch.empty((nch, n_out), dtype=torch.complex128, device=dev)
@@ -138,21 +142,29 @@ def main():
             for k in range(nchunk):
                 eng.process_ptr(x.data_ptr() + 16 * k * cb * (n_in // nblk), n_in, y.data_ptr() + 16 * k * cb * (n_out // nblk), n_out, cb)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dev)
+    def timed_run():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        return shard.max_over_ranks(time.perf_counter() - t0, dev)
+
+    dt = timed_run()                    # the measurement `value` reports
+    meter_db = [eng.GetRXAMeter(0, mt) for mt in (1, 3, 6)] if args.meters == "on" else None
+    dt_off = None
+    if args.meters == "on":             # the same steps once more with the meters off, reported beside it
+        eng.enable_meters(False)
+        dt_off = timed_run()
+        eng.enable_meters(True)
 
     # per-kernel durations with HIP events on the engine's stream (separate short run, not in the timed region)
     eng.enable_timing(True)
@@ -202,9 +214,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d channels/GPU x 192 kHz IQ -> 48 kHz SSB RXA chain (shift + 561-tap resample/4 + NBP nc 2048 + "
-                                   "fixed AGC + panel), 2^%d input samples per channel per step" % (nch, args.log2_samples),
-                       "ingest": args.ingest, "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
+            "config": {"workload": "%d channels/GPU x 192 kHz IQ -> 48 kHz SSB RXA chain (shift + 561-tap resample/4 + adc meter + NBP nc 2048 "
+                                   "+ S meter + fixed AGC + agc meter + panel), 2^%d input samples per channel per step" % (nch, args.log2_samples),
+                       "meters": args.meters, "ingest": args.ingest, "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
                        "parallelism": "channel-sharded x%d, no collective" % world},
             "chain_algorithmic_GBps": 20.0 * total / dt / 1e9,
             # ~650 flop per input sample if the chain is evaluated in direct form like the reference; the
@@ -217,6 +229,10 @@ def main():
                          "algorithmic_bytes_per_launch": algo[k] * samples_per_step},
             "check_inband_gain": gain,
         }
+        if dt_off is not None:
+            line["value_meters_off"] = shard.job_throughput(samples_per_step, world, args.steps, dt_off) / 1e6
+            line["ms_per_step_meters_off"] = dt_off / args.steps * 1e3
+            line["check_meters_dB"] = {"S_AV": meter_db[0], "ADC_AV": meter_db[1], "AGC_AV": meter_db[2]}
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported by the single-GPU run only
             try:
                 line["cpu_baseline"] = cpu_baseline()

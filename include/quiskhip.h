@@ -266,7 +266,7 @@ void SetRXAEMNRaePsi(int channel, double v);
 void SetRXAEMNRtrainZetaThresh(int channel, double v);
 void SetRXAEMNRtrainT2(int channel, double v);
 
-void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112; accepted, the block never runs */
+void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112: gain methods 0..3 */
 void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c:579-593 */
 void SetRXASNBAOutputBandwidth(int channel, double flow, double fhigh);          /* wdsp/snb.c:660-694 */
 

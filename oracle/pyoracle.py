@@ -236,6 +236,61 @@ class WdspChannel:
             pass
 
 
+class OracleWdspShim:
+    """The restated quisk_wdsp.c shim (wo_shim_*) in front of a callable fexchange0(in_ptr, out_ptr) -> error."""
+
+    def __init__(self, fexchange0):
+        self.L = lib()
+        self.L.wo_shim_create.restype = C.c_void_p
+        self.L.wo_shim_destroy.argtypes = [C.c_void_p]
+        self.L.wo_shim_set_parameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._fn_t = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int))
+        self.L.wo_shim_fexchange0.argtypes = [C.c_void_p, self._fn_t, C.c_void_p, C.c_void_p, C.c_int]
+        self.L.wo_shim_fexchange0.restype = C.c_int
+        self.h = self.L.wo_shim_create()
+
+        def tramp(ctx, pin, pout, perr):
+            perr[0] = int(fexchange0(pin, pout))
+        self._cb = self._fn_t(tramp)
+
+    def set_parameter(self, in_size=-1, in_use=-1):
+        self.L.wo_shim_set_parameter(self.h, in_size, in_use)
+
+    def fexchange0(self, buf, n):
+        """buf: complex128 work array, first n entries are input; returns the count written back."""
+        return self.L.wo_shim_fexchange0(self.h, self._cb, None, buf.ctypes.data, n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.wo_shim_destroy(self.h)
+            self.h = None
+
+
+_REF_WDSP = None
+
+
+def ref_wdsp_shim_lib():
+    """The reference's own quisk_wdsp.c compiled into oracle/_ref/ (None when it was not built).  Loaded with PyDLL:
+    quisk_wdsp_set_parameter is a CPython function (PyArg_ParseTupleAndKeywords) and must run with the GIL held."""
+    global _REF_WDSP
+    if _REF_WDSP is None:
+        path = os.path.join(_HERE, "_ref", "libquisk_wdsp_ref.so")
+        if not os.path.exists(path):
+            return None
+        L = C.PyDLL(path)
+        L.quisk_wdsp_set_parameter.restype = C.py_object
+        L.quisk_wdsp_set_parameter.argtypes = [C.py_object, C.py_object, C.py_object]
+        L.wdspFexchange0.restype = C.c_int
+        L.wdspFexchange0.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        _REF_WDSP = L
+    return _REF_WDSP
+
+
+def ref_wdsp_set_parameter(channel, **kw):
+    """QS.wdsp_set_parameter(channel, in_size=, fexchange0=<address>, in_use=) of the reference build."""
+    return ref_wdsp_shim_lib().quisk_wdsp_set_parameter(None, (int(channel),), dict(kw))
+
+
 def ref_filter_lib():
     """The reference's own filter.c compiled into oracle/_ref/ (None when it was not built)."""
     global _REF

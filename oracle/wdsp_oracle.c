@@ -1665,3 +1665,50 @@ void wo_SetRXAFMLimGain(wo_channel *c, double gaindB)                           
     }
 }
 double wo_GetRXAMeter(wo_channel *c, int mt) { return c->meter[mt]; }
+
+
+/* ---- quisk_wdsp.c:12-69: wdspFexchange0, Quisk's re-blocking shim in front of fexchange0 ----------------------------
+ * An arbitrary count of samples scaled to CLIP32 goes into a ring; every full in_size block is handed to fexchange0
+ * (scaled to +-1.0) and the output is written back over cSamples, in_size samples per block, scaled to CLIP32 again.
+ * Pinned bit for bit against the reference's own quisk_wdsp.c compiled into oracle/_ref (tests/test_oracle_wdsp_shim.py). */
+#define WO_CLIP32 2147483647
+
+wo_shim *wo_shim_create(void) { return (wo_shim *)zalloc(sizeof(wo_shim)); }
+void wo_shim_destroy(wo_shim *s) { if (s) { free(s->cBuf); free(s); } }
+
+void wo_shim_set_parameter(wo_shim *s, int in_size, int in_use)      /* quisk_wdsp.c:71-91 (channel and fexchange0 are the caller's) */
+{
+    if (in_size > 0) s->in_size = in_size;
+    if (in_use >= 0) s->in_use = in_use;
+}
+
+int wo_shim_fexchange0(wo_shim *s, wo_fexchange0_fn fn, void *ctx, double *cSamples, int nSamples)   /* quisk_wdsp.c:24-69 */
+{
+    int i, error, in_size;
+    if (!s->in_use) { s->Windex = 0; s->Rindex = 0; s->nBuf = 0; return nSamples; }
+    if (!fn) return nSamples;
+    if (nSamples <= 0) return nSamples;
+    in_size = s->in_size;
+    i = nSamples / in_size + 3;
+    if (i * in_size > s->sizeBuf) {
+        i *= in_size;
+        s->sizeBuf = i;
+        s->cBuf = (double *)realloc(s->cBuf, (size_t)i * 2 * sizeof(double));
+    }
+    for (i = 0; i < nSamples; i++) {
+        s->cBuf[2 * s->Windex] = cSamples[2 * i] / WO_CLIP32;            /* complex / int: both parts divided */
+        s->cBuf[2 * s->Windex + 1] = cSamples[2 * i + 1] / WO_CLIP32;
+        if (++s->Windex >= s->sizeBuf) s->Windex = 0;
+    }
+    s->nBuf += nSamples;
+    nSamples = 0;
+    while (s->nBuf >= in_size) {
+        fn(ctx, s->cBuf + 2 * s->Rindex, cSamples + 2 * nSamples, &error);
+        s->Rindex += in_size;
+        if (s->Rindex >= s->sizeBuf) s->Rindex = 0;
+        nSamples += in_size;
+        s->nBuf -= in_size;
+    }
+    for (i = 0; i < nSamples; i++) { cSamples[2 * i] *= WO_CLIP32; cSamples[2 * i + 1] *= WO_CLIP32; }
+    return nSamples;
+}

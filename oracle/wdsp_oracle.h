@@ -131,6 +131,18 @@ wo_resample *wo_resample_create(int in_rate, int out_rate, double fc, int ncoef,
 void wo_resample_destroy(wo_resample *a);
 int wo_resample_exec(wo_resample *a, const double *in, int size, double *out);
 
+/* Quisk's re-blocking shim in front of fexchange0 (quisk_wdsp.c:12-91); fn(ctx, in, out, &error) stands for the
+ * (*wdsp_fexchange0)(channel, in, out, &error) pointer Quisk is handed through QS.wdsp_set_parameter */
+typedef struct wo_shim {
+    double *cBuf;       /* circular sample buffer, interleaved complex */
+    int sizeBuf, nBuf, in_size, in_use, Windex, Rindex;
+} wo_shim;
+typedef void (*wo_fexchange0_fn)(void *ctx, double *in, double *out, int *error);
+wo_shim *wo_shim_create(void);
+void wo_shim_destroy(wo_shim *s);
+void wo_shim_set_parameter(wo_shim *s, int in_size, int in_use);
+int wo_shim_fexchange0(wo_shim *s, wo_fexchange0_fn fn, void *ctx, double *cSamples, int nSamples);
+
 #ifdef __cplusplus
 }
 #endif

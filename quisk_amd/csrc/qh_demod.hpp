@@ -317,11 +317,14 @@ __device__ __forceinline__ double mlog10_dev(double val)
 }
 
 static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, long long stride, int nblk, int size,
-                                                          MeterState *state, MeterParam q, const int *chan_list)
+                                                          MeterState *state, MeterParam q, const int *chan_list,
+                                                          const double *gain2 = nullptr)
 {
     const int ch = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const double2 *p = buf + (long long)ch * stride;
     MeterState st = state[ch];
+    // the buffer holds the signal ahead of a fixed AGC gain g that the output stage applies: |g z|^2 = g^2 |z|^2
+    const double g2 = gain2 ? gain2[ch] : 1.0;
     const double pw = lane_pow(q.mult_average, lane + 1);
     const double pk_blk = pow(q.mult_peak, (double)size);
     for (int b = 0; b < nblk; b++) {
@@ -329,7 +332,7 @@ static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, lo
         for (int base = 0; base < size; base += 64) {
             const int cnt = size - base < 64 ? size - base : 64;
             double smag = 0.0;
-            if (lane < cnt) { const double2 z = p[(long long)b * size + base + lane]; smag = z.x * z.x + z.y * z.y; }
+            if (lane < cnt) { const double2 z = p[(long long)b * size + base + lane]; smag = (z.x * z.x + z.y * z.y) * g2; }
             const double a = scan_pole((1.0 - q.mult_average) * smag, q.mult_average, lane) + pw * st.avg;
             st.avg = lane_bcast(a, cnt - 1);
             np = fmax(np, wave_max_d(smag));
@@ -340,6 +343,66 @@ static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, lo
         st.res_pk = 10.0 * mlog10_dev(st.peak + 1.0e-40);
     }
     if (lane == 0) state[ch] = st;
+}
+
+// The same meters from the per-chunk partials the METER overlap-save kernel leaves behind (qh_osfir.hpp: x = sum over
+// the chunk's 64 samples of (1 - m) m^(63 - i) |z_i|^2, y = max |z_i|^2): the one-pole average advances a chunk at a time,
+// avg <- m^64 avg + x, and the peak a DSP block (cpb chunks) at a time, peak <- max(peak * mp^(64 cpb), block max).  Both
+// recurrences are linear (the second over (max, *)), so their value at the end of the call is a weighted sum / maximum of
+// independent pieces: every thread of the workgroup walks its own short run of consecutive chunks from a zero state,
+// weights the result by the decay from the end of its run to the end of the call, and one reduction joins them with the
+// carried state.  One workgroup per channel and meter; blockIdx.y: 0 = adc meter (partials of the stage input), 1 = S
+// meter, 2 = agc meter (both on the stage output, the agc meter behind the fixed gain g: gain2 = g^2).
+// wdsp/RXA.c:566,569,589.  Storage: tile-major, inside a tile [wave][register] (cpt chunks per tile).
+static constexpr int kMeterFinishThreads = 1024;
+static __global__ __launch_bounds__(kMeterFinishThreads) void meter_finish_kernel(const double2 *part_in, const double2 *part_out,
+                                                                 long long stride, int nchunks, int cpb, int cpt, MeterState *m_adc,
+                                                                 MeterState *m_s, MeterState *m_agc, MeterParam q, const double *gain2)
+{
+    __shared__ double s_avg[kMeterFinishThreads / 64], s_pk[kMeterFinishThreads / 64];
+    const int ch = blockIdx.x, which = blockIdx.y, T = threadIdx.x, lane = T & 63, wave = T >> 6;
+    const double2 *p = (which == 0 ? part_in : part_out) + (long long)ch * stride;
+    MeterState *state = which == 0 ? m_adc : which == 1 ? m_s : m_agc;
+    const double g2 = (which == 2 && gain2) ? gain2[ch] : 1.0;
+    double m64 = q.mult_average;
+#pragma unroll
+    for (int k = 0; k < 6; k++) m64 *= m64;
+    const double pk_blk = pow(q.mult_peak, (double)(cpb * 64));
+    const int nseg = cpt >> 2;
+    // runs of whole DSP blocks: per = chunks per thread
+    const int per = ((nchunks + kMeterFinishThreads * cpb - 1) / (kMeterFinishThreads * cpb)) * cpb;
+    const int c0 = T * per < nchunks ? T * per : nchunks, c1 = (T + 1) * per < nchunks ? (T + 1) * per : nchunks;
+    double avg = 0.0, peak = 0.0;
+    if (c1 > c0) {
+        int tile = c0 / cpt, k = c0 - tile * cpt;           // chunk k of the tile: register k >> 2, wave k & 3
+        for (int c = c0; c < c1; c += cpb) {
+            double np = 0.0;
+            for (int j = 0; j < cpb; j++) {
+                const double2 v = p[(long long)tile * cpt + (k & 3) * nseg + (k >> 2)];
+                avg = __builtin_fma(avg, m64, v.x);
+                np = fmax(np, v.y);
+                if (++k == cpt) { k = 0; tile++; }
+            }
+            peak = fmax(peak * pk_blk, np);
+        }
+        const double left = (double)(nchunks - c1);         // chunks between the end of this run and the end of the call
+        avg *= pow(m64, left);
+        peak *= pow(q.mult_peak, 64.0 * left);
+    }
+    avg = wave_sum_d(avg);
+    peak = wave_max_d(peak);
+    if (lane == 0) { s_avg[wave] = avg; s_pk[wave] = peak; }
+    __syncthreads();
+    if (T == 0) {
+        MeterState st = state[ch];
+        double a = 0.0, pk = 0.0;
+        for (int w = 0; w < kMeterFinishThreads / 64; w++) { a += s_avg[w]; pk = fmax(pk, s_pk[w]); }
+        st.avg = st.avg * pow(m64, (double)nchunks) + g2 * a;
+        st.peak = fmax(st.peak * pow(q.mult_peak, 64.0 * (double)nchunks), g2 * pk);
+        st.res_av = 10.0 * mlog10_dev(st.avg + 1.0e-40);
+        st.res_pk = 10.0 * mlog10_dev(st.peak + 1.0e-40);
+        state[ch] = st;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ WDSP AGC

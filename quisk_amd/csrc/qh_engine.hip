@@ -205,6 +205,12 @@ struct Engine {
     bool meters_on = false;
     MeterState *m_adc = nullptr, *m_s = nullptr, *m_agc = nullptr;
     MeterParam m_prm{};
+    // meters fused into the nbp0 launch of the linear fast path (qh_osfir.hpp METER): chunk partials of the stage's input and
+    // output, the chunk weights, and g^2 of a fixed AGC gain that the output matrix applies behind the agc meter's tap
+    double2 *m_part[2] = { nullptr, nullptr };
+    long long m_part_cap = 0;               // chunks per channel
+    double *m_w = nullptr, *m_g2 = nullptr;
+    int meters_alloc();
     int *list_agc_cur = nullptr, *list_agc_other = nullptr;
     int n_agc_cur = 0, n_agc_other = 0;
 
@@ -218,8 +224,9 @@ struct Engine {
     PackedFmt pk{};
     void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                  const int *list, int nlist);
+                  const int *list, int nlist, bool meter = false);
     int ensure_buffers(long long n_mid);
+    int ensure_meter_partials(long long n_mid, int lout);
     int emnr_alloc();
     int process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     int process_chain(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
@@ -240,7 +247,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
-    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc);
+    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
     (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx);
     (void)hipFree(emnr_chan); (void)hipFree(emnr_scal); (void)hipFree(emnr_state); (void)hipFree(emnr_window); (void)hipFree(emnr_GG);
@@ -331,7 +338,7 @@ int Engine::init()
     // dynamic LDS of the overlap-save kernels
 #define QH_SET_LDS(D, ...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, 4096, D, __VA_ARGS__>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D>())))
-    QH_SET_LDS(1, false);
+    QH_SET_LDS(1, false); QH_SET_LDS(1, false, false, true);
     QH_SET_LDS(2, true); QH_SET_LDS(4, true); QH_SET_LDS(8, true);
     QH_SET_LDS(2, true, true); QH_SET_LDS(4, true, true); QH_SET_LDS(8, true, true);
 #undef QH_SET_LDS
@@ -375,6 +382,8 @@ int Engine::refresh_params()
             // xwcpagc mode 0 (wcpAGC.c:167-175) then xpanel (patchpanel.c:55-101) as one 2x2 real matrix
             // (with a position-1 anf / anr / bp1 behind it the gain is applied at the AGC's own spot instead: fix_before)
             const double g = (c.agc_run && c.agc_mode == 0 && !c.fix_before()) ? c.agc_fixed : 1.0;
+            const double g2 = g * g;            // the agc meter reads |g z|^2 off the signal ahead of the output matrix
+            if (m_g2) QH_HIP(hipMemcpyAsync(m_g2 + ch, &g2, sizeof(double), hipMemcpyHostToDevice, stream));
             if (fix_gain) QH_HIP(hipMemcpyAsync(fix_gain + ch, &c.agc_fixed, sizeof(double), hipMemcpyHostToDevice, stream));
             const double gI = c.gain1 * c.gain2I, gQ = c.gain1 * c.gain2Q;
             const double sI = (double)(c.inselect >> 1), sQ = (double)(c.inselect & 1);
@@ -488,6 +497,33 @@ int Engine::refresh_params()
     return QH_OK;
 }
 
+// create_meter x3 (RXA.c:69-82,142-155,361-374): tau 0.1 s for average and peak decay; flush_meter -> -400 dB
+int Engine::meters_alloc()
+{
+    if (m_adc) return QH_OK;
+    const double rate = (double)dsp_rate;
+    std::vector<MeterState> init((size_t)nch, MeterState{ 0.0, 0.0, -400.0, -400.0 });
+    for (MeterState **pm : { &m_adc, &m_s, &m_agc }) {
+        QH_HIP(dev_alloc(pm, (size_t)nch));
+        QH_HIP(hipMemcpyAsync(*pm, init.data(), (size_t)nch * sizeof(MeterState), hipMemcpyHostToDevice, stream));
+    }
+    m_prm.mult_average = std::exp(-1.0 / (rate * 0.100));
+    m_prm.mult_peak = std::exp(-1.0 / (rate * 0.100));
+    std::vector<double> w(64), g2((size_t)nch);
+    for (int i = 0; i < 64; i++) w[(size_t)i] = (1.0 - m_prm.mult_average) * std::pow(m_prm.mult_average, (double)(63 - i));
+    for (int ch = 0; ch < nch; ch++) {
+        const ChanCfg &c = cfg[(size_t)ch];
+        g2[(size_t)ch] = (c.agc_run && c.agc_mode == 0 && !c.fix_before()) ? c.agc_fixed * c.agc_fixed : 1.0;
+    }
+    QH_HIP(dev_alloc(&m_w, (size_t)64));
+    QH_HIP(dev_alloc(&m_g2, (size_t)nch));
+    QH_HIP(hipMemcpyAsync(m_w, w.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
+    QH_HIP(hipMemcpyAsync(m_g2, g2.data(), g2.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    QH_HIP(hipStreamSynchronize(stream));
+    dev_bytes += (long long)nch * (3 * sizeof(MeterState) + 8) + 512;
+    return QH_OK;
+}
+
 // Demodulator state, channel lists and FM filters (only engines that run AM/SAM/FM channels get here).
 int Engine::refresh_demod()
 {
@@ -503,16 +539,7 @@ int Engine::refresh_demod()
         QH_HIP(dev_alloc(&fix_gain, (size_t)nch));
         list_am = list_buf; list_sam = list_buf + nch; list_fm = list_buf + 2 * nch; list_bp1 = list_buf + 3 * nch;
         list_plain = list_buf + 4 * nch; list_agc_cur = list_buf + 5 * nch; list_agc_other = list_buf + 6 * nch;
-        {   // create_meter x3 (RXA.c:69-82,142-155,361-374): tau 0.1 s for average and peak decay; flush_meter -> -400 dB
-            std::vector<MeterState> init((size_t)nch, MeterState{ 0.0, 0.0, -400.0, -400.0 });
-            for (MeterState **pm : { &m_adc, &m_s, &m_agc }) {
-                QH_HIP(dev_alloc(pm, (size_t)nch));
-                QH_HIP(hipMemcpyAsync(*pm, init.data(), (size_t)nch * sizeof(MeterState), hipMemcpyHostToDevice, stream));
-            }
-            QH_HIP(hipStreamSynchronize(stream));
-            m_prm.mult_average = std::exp(-1.0 / (rate * 0.100));
-            m_prm.mult_peak = std::exp(-1.0 / (rate * 0.100));
-        }
+        if (int rc = meters_alloc()) return rc;
         QH_HIP(dev_alloc(&agc_prm, (size_t)nch));
         QH_HIP(dev_alloc(&agc_state, (size_t)nch));
         QH_HIP(hipMemsetAsync(agc_state, 0, (size_t)nch * sizeof(AgcState), stream));
@@ -1018,6 +1045,8 @@ int Engine::ensure_buffers(long long n_mid)
 {
     if (n_mid <= buf_cap) return QH_OK;
     QH_HIP(hipStreamSynchronize(stream));
+    // captured launch sequences hold the old buffer addresses: whatever entry point grows the buffers, they are stale now
+    drop_graphs(); epoch++;
     for (int i = 0; i < 2; i++) {
         if (buf[i]) { QH_HIP(hipFree(buf[i])); dev_bytes -= buf_cap * nch * (long long)sizeof(double2); buf[i] = nullptr; }
     }
@@ -1026,6 +1055,22 @@ int Engine::ensure_buffers(long long n_mid)
         dev_bytes += n_mid * nch * (long long)sizeof(double2);
     }
     buf_cap = n_mid;
+    return QH_OK;
+}
+
+// chunk partials of the fused meters: whole tiles per channel (a tile's store is not bounds-checked)
+int Engine::ensure_meter_partials(long long n_mid, int lout)
+{
+    const long long need = ((n_mid + lout - 1) / lout) * (lout / 64);
+    if (need <= m_part_cap) return QH_OK;
+    QH_HIP(hipStreamSynchronize(stream));
+    drop_graphs(); epoch++;
+    for (int i = 0; i < 2; i++) {
+        if (m_part[i]) { QH_HIP(hipFree(m_part[i])); dev_bytes -= m_part_cap * nch * (long long)sizeof(double2); m_part[i] = nullptr; }
+        QH_HIP(dev_alloc(&m_part[i], (size_t)nch * (size_t)need));
+        dev_bytes += need * nch * (long long)sizeof(double2);
+    }
+    m_part_cap = need;
     return QH_OK;
 }
 
@@ -1043,13 +1088,13 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX, bool PACKED = false>
+template <int D, bool MIX, bool PACKED = false, bool METER = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, kNfft, D>();
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED, METER>), grid, block, lds, s, a);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------
@@ -1112,7 +1157,7 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
 // one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
 void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                      const int *list, int nlist)
+                      const int *list, int nlist, bool meter)
 {
     const int Lout = kNfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
@@ -1126,7 +1171,11 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     a.chan_list = list;
     a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
     tick(1);
-    launch_osfir<1, false>(a, ntiles, list ? nlist : nch, stream);
+    if (meter) {
+        a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w;
+        launch_osfir<1, false, false, true>(a, ntiles, list ? nlist : nch, stream);
+    } else
+        launch_osfir<1, false>(a, ntiles, list ? nlist : nch, stream);
     tick(2);
     dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
     hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
@@ -1145,6 +1194,7 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
     const long long n_mid = (long long)nblk * dsp_size;
     if (n_mid > obuf_cap) {
         QH_HIP(hipStreamSynchronize(stream));
+        drop_graphs(); epoch++;
         if (obuf) { QH_HIP(hipFree(obuf)); dev_bytes -= obuf_cap * nch * (long long)sizeof(double2); obuf = nullptr; }
         QH_HIP(dev_alloc(&obuf, (size_t)nch * (size_t)n_mid));
         obuf_cap = n_mid;
@@ -1167,13 +1217,19 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
-        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || c.snba_run || meters_on) mixed = true;
+        if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || c.snba_run) mixed = true;
         if (c.emnr_run && !emnr_tables) return set_error(QH_ERR_INVALID, "EMNR needs its gain tables first (qh_rxa_SetEMNRTables: WDSP's `calculus` and `zetaHat.bin` data)");
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
     }
     if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
+    // The three meters of xrxa (adc, S, agc: RXA.c:566,569,589) ride on the nbp0 launch when the chain is linear (nbp0 runs,
+    // bp1 does not, fixed AGC gain): the band tile then starts on a multiple of 256 samples so that a register holds one
+    // 64-sample chunk per wavefront.  Any other chain takes the per-mode path with the stand-alone meter kernel.
+    const bool meters_fused = meters_on && !mixed && any_nbp && !any_bp1 && dsp_size >= 64 && dsp_size <= 2048;
+    if (meters_on && !meters_fused) mixed = true;
+    if (meters_on) if (int rc = meters_alloc()) return rc;
     if (int rc = refresh_params()) return rc;
     if (mixed) if (int rc = refresh_demod()) return rc;
     if (n_snba) if (int rc = refresh_params()) return rc;       // bpsnba's mask needs the buffers the line above may just have made
@@ -1186,7 +1242,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
 
     const double2 *in = reinterpret_cast<const double2 *>(d_in);
     double2 *out = reinterpret_cast<double2 *>(d_out);
-    const int P = nc_max - 1;
+    const int P = meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
 
     if (!mixed) {
         // ---- every channel is a linear chain: the epilogue rides on the last stage, no extra pass
@@ -1211,11 +1267,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             if (f == 0 ? !any_nbp : !any_bp1) continue;
             long long dst_stride;
             double2 *dst = dst_of(stage, dst_stride);
+            if (meters_fused) if (int rc = ensure_meter_partials(n_mid, kNfft - P)) return rc;
             run_band(cur, cur_stride, dst, dst_stride, stage == nstage - 1 ? epi : nullptr, n_mid,
                      f == 0 ? mask_nbp : mask_bp1, kNfft, f == 0 ? hist_nbp : hist_bp1, f == 0 ? cur_nbp : cur_bp1, P,
-                     nullptr, 0);
+                     nullptr, 0, meters_fused);
             cur = dst; cur_stride = dst_stride; stage++;
         }
+        if (meters_fused)
+            hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch, 3), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
+                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (kNfft - P) / 64, m_adc, m_s, m_agc, m_prm, (const double *)m_g2);
         tick(3);
         QH_HIP(hipGetLastError());
         return QH_OK;
@@ -1235,6 +1295,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (n_amsq) {           // xamsqcap (RXA.c:571): the magnitudes of the signal behind nbp0, for xamsq at the end of the chain
         if (buf_cap > amsq_mag_cap) {
             QH_HIP(hipStreamSynchronize(stream));
+            drop_graphs(); epoch++;
             (void)hipFree(amsq_mag); amsq_mag = nullptr;
             QH_HIP(dev_alloc(&amsq_mag, (size_t)nch * (size_t)buf_cap));
             amsq_mag_cap = buf_cap;
@@ -1311,11 +1372,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     bp1_at(1);
     if (n_bp1) cur_bp1 ^= 1;
     if (meters_on) {    // agcmeter sits after xwcpagc (RXA.c:589); mode 0's gain multiply is applied below, so its
-                        // level reading is taken on the fixed-gain input and corrected in qh_rxa_GetRXAMeter
+                        // level reading is taken on the fixed-gain input times g^2 (m_g2)
         if (n_plain) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)n_plain), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size,
-                                        m_agc, m_prm, list_plain);
+                                        m_agc, m_prm, list_plain, (const double *)m_g2);
         if (n_bp1) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)n_bp1), dim3(64), 0, stream, other, buf_cap, nblk, dsp_size,
-                                      m_agc, m_prm, list_bp1);
+                                      m_agc, m_prm, list_bp1, (const double *)m_g2);
     }
     tick(2);
     // xwcpagc mode 0 + xpanel
@@ -1912,26 +1973,23 @@ int qh_rxa_GetRXAMeter(qh_rxa *h, int ch, int mt, double *value)
     if (!h || !value) return set_error(QH_ERR_INVALID, "null argument");
     Engine &e = h->e;
     if (ch < 0 || ch >= e.nch || mt < 0 || mt > 6) return set_error(QH_ERR_INVALID, "channel or meter index out of range");
-    if (!e.meters_on || !e.demod_alloc) { *value = -400.0; return QH_OK; }      // flush_meter's initial reading
+    if (!e.meters_on || !e.m_adc) { *value = -400.0; return QH_OK; }             // flush_meter's initial reading
     QH_HIP(hipSetDevice(e.device));
     QH_HIP(hipStreamSynchronize(e.stream));
-    const ChanCfg &c = e.cfg[(size_t)ch];
     MeterState st;
     const MeterState *src = mt <= 1 ? e.m_s : mt <= 3 ? e.m_adc : e.m_agc;
     QH_HIP(hipMemcpy(&st, src + ch, sizeof(st), hipMemcpyDeviceToHost));
     if (mt == 4) {
         double g = 0.0;
-        QH_HIP(hipMemcpy(&g, &e.agc_state[ch].gain, sizeof(double), hipMemcpyDeviceToHost));
+        // RXA_AGC_GAIN: xwcpagc's `gain` (wcpAGC.c:334), which only the modes 1-5 write; 0 from create_wcpagc's calloc until then
+        if (e.agc_state) QH_HIP(hipMemcpy(&g, &e.agc_state[ch].gain, sizeof(double), hipMemcpyDeviceToHost));
         const double v = g + 1.0e-40;
         unsigned long long N; std::memcpy(&N, &v, 8);
         const int ex = (int)((N >> 52) & 2047) - 1023, m = (int)((N >> 41) & 2047);
         *value = 20.0 * 0.301029995663981 * ((double)ex + std::log2(1.0 + (double)m / 2048.0));
         return QH_OK;
     }
-    double r = (mt == 0 || mt == 2 || mt == 5) ? st.res_pk : st.res_av;
-    if (mt >= 5 && c.agc_run && c.agc_mode == 0 && !c.fix_before() && r > -399.0)
-        r += 20.0 * std::log10(c.agc_fixed);                // |g z|^2 = g^2 |z|^2; exact up to mlog10's 11-bit mantissa steps
-    *value = r;
+    *value = (mt == 0 || mt == 2 || mt == 5) ? st.res_pk : st.res_av;
     return QH_OK;
 }
 

@@ -87,3 +87,30 @@ def test_changed_arguments_drop_the_graphs(qh):
         e.synchronize(); p.synchronize()
         assert torch.equal(d_out[b % 2], d_out[2])
     assert e.graph_launches() == 0
+
+
+def test_buffers_grown_through_another_entry_point_drop_the_graphs(qh):
+    # captured graphs hold the addresses of the engine's intermediate buffers; process_host (which does not go through the
+    # replay key) with a larger block count re-allocates them: the next replayed block must not run the stale graph
+    e, p = _engine(qh, True), _engine(qh, False)
+    dev = torch.device("cuda:0")
+    nb = 10
+    x = synth.make_input_numpy(len(MODES), (nb + 16) * 1024)
+    d_in = torch.zeros((len(MODES), 1024), dtype=torch.complex128, device=dev)
+    d_out = torch.zeros((len(MODES), 256), dtype=torch.complex128, device=dev)
+    d_ref = torch.zeros((len(MODES), 256), dtype=torch.complex128, device=dev)
+    pos = 0
+    for b in range(nb):
+        if b == 5:      # 16 blocks in one host call on both engines
+            big = np.ascontiguousarray(x[:, pos:pos + 16 * 1024])
+            ya, yb = e.process_host(big), p.process_host(big)
+            assert np.array_equal(ya, yb)
+            pos += 16 * 1024
+        d_in.copy_(torch.from_numpy(x[:, pos:pos + 1024]))
+        pos += 1024
+        torch.cuda.synchronize()
+        e.process_ptr(d_in.data_ptr(), 1024, d_out.data_ptr(), 256, 1)
+        p.process_ptr(d_in.data_ptr(), 1024, d_ref.data_ptr(), 256, 1)
+        e.synchronize(); p.synchronize()
+        assert torch.equal(d_out, d_ref), "block %d" % b
+    assert e.graph_launches() > 0

@@ -308,3 +308,36 @@ def test_set_channel_state_slews_down_flushes_and_restarts_like_a_fresh_channel(
     ref2, _ = fresh.fexchange0(x[60 * in_size:])
     lib.CloseChannel(ch)
     assert rel_rms(y2, ref2) < 1e-9
+
+
+def test_reference_quisk_wdsp_c_drives_our_fexchange0(qh, oracle):
+    """Row b1 with the reference's own code in the loop: quisk_wdsp.c compiled from /root/reference (oracle/_ref, built in
+    the build container, shipped as a binary) is handed the ADDRESS of libquiskhip's fexchange0 exactly as Quisk hands it
+    libwdsp's (quisk_wdsp.py:57-67 -> QS.wdsp_set_parameter(0, fexchange0=fpt)), and re-blocks ragged sample counts into it.
+    libquiskhip's own wdspFexchange0 on a second, identically configured channel must return the same bits."""
+    ref = oracle.ref_wdsp_shim_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref/libquisk_wdsp_ref.so not shipped")
+    lib = qh.load()
+    cha, chb, in_size = 11, 12, 1024
+    for ch in (cha, chb):
+        _open(lib, ch, in_size, 256, 192000, nbp=True, shift_freq=10000.0)
+    try:
+        fpt = C.cast(lib.fexchange0, C.c_void_p).value
+        oracle.ref_wdsp_set_parameter(cha, in_size=in_size, fexchange0=fpt, in_use=1)
+        lib.qh_wdsp_set_parameter(chb, in_size, 1)
+        x = synth.make_input_numpy(1, 1024 * 40)[0] * 2147483647.0
+        pos = 0
+        for k in (100, 1024, 3000, 5, 0, 2048 * 4 + 17, 1, 1023, 2, 7000, 11111):
+            a = np.zeros(k + 4 * in_size, dtype=np.complex128); a[:k] = x[pos:pos + k]
+            b = a.copy()
+            na = ref.wdspFexchange0(cha, a.ctypes.data, k)
+            nb = lib.wdspFexchange0(chb, b.ctypes.data_as(C.c_void_p), k)
+            pos += k
+            assert na == nb, (k, na, nb)
+            assert np.array_equal(a.view(np.float64), b.view(np.float64)), k
+        assert np.abs(a[:na]).max() > 1e6               # real audio came back (CLIP32 scale), not zeros
+    finally:
+        oracle.ref_wdsp_set_parameter(cha, in_use=0)
+        lib.qh_wdsp_set_parameter(chb, 0, 0)
+        lib.CloseChannel(cha); lib.CloseChannel(chb)

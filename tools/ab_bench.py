@@ -33,9 +33,9 @@ def main():
             name = os.path.basename(lib)[len("libquiskhip_"):-3]
             try:
                 j = json.loads(r.stdout.strip().splitlines()[-1])
-                print("%-28s %9.1f Msamp/s  step %.3f ms  front %.3f  band %.3f  gain %.4f" % (
+                print("%-28s %9.1f Msamp/s  step %.3f ms  front %.3f  band %.3f  rest %.3f  gain %.4f  meters off: %s" % (
                     name, j["value"], j["ms_per_step"], j["kernel_ms"]["front_shift_resample"], j["kernel_ms"]["band_nbp"],
-                    j["check_inband_gain"]), flush=True)
+                    j["kernel_ms"]["state_bookkeeping"], j["check_inband_gain"], j.get("value_meters_off")), flush=True)
             except Exception:
                 print(name, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
 
