@@ -10,7 +10,9 @@
 //   epilogue: xwcpagc mode 0 + xpanel     -> fused into the last launch (2x2 real matrix per channel)
 //
 // State carried between calls (all device resident, right-aligned rows of the most recent samples):
-//   hist_front [2][nch][HF]  mixed input samples (the reference's resampler ring)
+//   hist_front [2][nch][HF]  raw input samples (the reference's resampler ring holds them behind xshift; here the
+//                            oscillator sits behind the filter, qh_osfir.hpp OUTMIX, and nco_retune_hist_kernel
+//                            rewrites the row when a channel's shift changes)
 //   hist_nbp   [2][nch][HB]  nbp0 input samples  (the reference's fircore delay line)
 //   hist_bp1   [2][nch][HB]
 //   nco_phase  [nch]         64-bit fixed-point turns
@@ -131,6 +133,13 @@ struct Engine {
     double2 *tw4096 = nullptr, *tw_inv_front = nullptr;
     unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr, *nco_parked = nullptr;
     double2 *nco_step = nullptr;
+    // output-side oscillator of the front stage (D > 1): per-channel lane table, per-launch tile table, the resampler taps,
+    // and the scratch lists of refresh_params (channel list, new phase law)
+    double2 *lane_rot = nullptr, *tile_rot = nullptr;
+    long long tile_rot_cap = 0;             // tiles per channel
+    double *front_taps = nullptr;
+    int *retune_list = nullptr;
+    unsigned long long *retune_law = nullptr;
     EpiParam *epi = nullptr;
     double2 *hist_front[2] = { nullptr, nullptr }, *hist_nbp[2] = { nullptr, nullptr }, *hist_bp1[2] = { nullptr, nullptr };
     int cur_front = 0, cur_nbp = 0, cur_bp1 = 0, cur_snb = 0;
@@ -245,6 +254,7 @@ Engine::~Engine()
     (void)hipFree(obuf);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
+    (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
@@ -301,15 +311,20 @@ int Engine::init()
         front_P = ((front_ntaps - 1 + front_fold - 1) / front_fold) * front_fold;
         front_L = (((kNfft - front_P) / front_fold) / front_pick) * front_pick;
         if (front_P > kHistFront) return set_error(QH_ERR_UNSUPPORTED, "resampler history %d too long", front_P);
-        std::vector<cd> h((size_t)front_ntaps);
-        for (int i = 0; i < front_ntaps; i++) h[i] = cd(rd.h[i], 0.0);
-        std::vector<cd> m = make_mask(h, kNfft);
-        QH_HIP(dev_alloc(&mask_front, m.size()));
-        if (int rc = upload(mask_front, m, stream)) return rc;
+        // the masks are per channel (taps modulated by the channel's shift): front_mask_kernel builds them in refresh_params
+        QH_HIP(dev_alloc(&mask_front, (size_t)nch * kNfft));
+        QH_HIP(dev_alloc(&lane_rot, (size_t)nch * NT));
+        QH_HIP(dev_alloc(&front_taps, (size_t)front_ntaps));
+        QH_HIP(dev_alloc(&retune_list, (size_t)nch));
+        QH_HIP(dev_alloc(&retune_law, (size_t)nch * 2));
+        QH_HIP(hipMemcpyAsync(front_taps, rd.h.data(), (size_t)front_ntaps * sizeof(double), hipMemcpyHostToDevice, stream));
+        QH_HIP(hipStreamSynchronize(stream));
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_mask_kernel<kNfft>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (TileFft<kNfft, false, double2>::kLdsBytes)));
         std::vector<cd> twi = fft_twiddle_table(kNfft / front_fold);
         QH_HIP(dev_alloc(&tw_inv_front, twi.size()));
         if (int rc = upload(tw_inv_front, twi, stream)) return rc;
-        dev_bytes += (m.size() + twi.size()) * sizeof(cd);
+        dev_bytes += twi.size() * sizeof(cd) + (size_t)nch * (kNfft + NT) * sizeof(double2) + (size_t)front_ntaps * 8 + (size_t)nch * 20;
         for (int i = 0; i < 2; i++) {
             QH_HIP(dev_alloc(&hist_front[i], (size_t)nch * kHistFront));
             QH_HIP(hipMemsetAsync(hist_front[i], 0, (size_t)nch * kHistFront * sizeof(double2), stream));
@@ -330,6 +345,7 @@ int Engine::init()
     QH_HIP(dev_alloc(&nco_dphase, (size_t)nch));
     QH_HIP(dev_alloc(&nco_parked, (size_t)nch));
     QH_HIP(hipMemsetAsync(nco_parked, 0, (size_t)nch * sizeof(unsigned long long), stream));
+    QH_HIP(hipMemsetAsync(nco_dphase, 0, (size_t)nch * sizeof(unsigned long long), stream));
     QH_HIP(dev_alloc(&nco_step, (size_t)nch));
     QH_HIP(dev_alloc(&epi, (size_t)nch));
     QH_HIP(hipMemsetAsync(nco_phase, 0, (size_t)nch * sizeof(unsigned long long), stream));
@@ -339,8 +355,8 @@ int Engine::init()
 #define QH_SET_LDS(D, ...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, 4096, D, __VA_ARGS__>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D>())))
     QH_SET_LDS(1, false); QH_SET_LDS(1, false, false, true);
-    QH_SET_LDS(2, true); QH_SET_LDS(4, true); QH_SET_LDS(8, true);
-    QH_SET_LDS(2, true, true); QH_SET_LDS(4, true, true); QH_SET_LDS(8, true, true);
+    QH_SET_LDS(2, false, false, false, true); QH_SET_LDS(4, false, false, false, true); QH_SET_LDS(8, false, false, false, true);
+    QH_SET_LDS(2, false, true, false, true); QH_SET_LDS(4, false, true, false, true); QH_SET_LDS(8, false, true, false, true);
 #undef QH_SET_LDS
     QH_HIP(hipStreamSynchronize(stream));
     return QH_OK;
@@ -361,6 +377,30 @@ int Engine::refresh_params()
     // one pass over the channels; upload only what changed
     std::vector<cd> last_nbp, last_bp1;
     const ChanCfg *last_nbp_cfg = nullptr, *last_bp1_cfg = nullptr;
+    // Oscillator changes (SetRXAShiftFreq / SetRXAShiftRun).  With a front FIR stage (D > 1) the oscillator sits behind
+    // the filter: first the stored raw history of every changed channel is re-expressed for its new phase law (the kernel
+    // reads the old law from the device arrays, so it goes first), then the arrays are updated, then the channel's
+    // modulated mask and phasor tables are rebuilt.
+    std::vector<int> nco_list;
+    if (D > 1) {
+        std::vector<unsigned long long> law;
+        for (int ch = 0; ch < nch; ch++) {
+            const ChanCfg &c = cfg[(size_t)ch];
+            if (!c.nco_dirty) continue;
+            nco_list.push_back(ch);
+            const bool flip = (c.shift_run != 0) != (c.shift_on_device != 0);
+            law.push_back(flip ? (c.shift_run ? 2ull : 1ull) : 0ull);
+            law.push_back(c.shift_run ? turns_fx(c.shift_freq, (double)in_rate) : 0ull);
+        }
+        if (!nco_list.empty()) {
+            QH_HIP(hipMemcpyAsync(retune_list, nco_list.data(), nco_list.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemcpyAsync(retune_law, law.data(), law.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(nco_retune_hist_kernel, dim3((kHistFront + NT - 1) / NT, (unsigned)nco_list.size()), dim3(NT), 0, stream,
+                               hist_front[cur_front], kHistFront, nco_phase, nco_dphase, nco_parked, (const int *)retune_list,
+                               (const unsigned long long *)retune_law);
+            QH_HIP(hipStreamSynchronize(stream));           // the host vectors die with this scope
+        }
+    }
     for (int ch = 0; ch < nch; ch++) {
         ChanCfg &c = cfg[(size_t)ch];
         if (c.nco_dirty) {
@@ -370,11 +410,7 @@ int Engine::refresh_params()
             }
             // calc_shift, wdsp/shift.c:29-34: delta = 2*pi*shift/rate per input sample
             unsigned long long d = c.shift_run ? turns_fx(c.shift_freq, (double)in_rate) : 0ull;
-            long double ang = 2.0L * 3.14159265358979323846264338327950288L *
-                              ((long double)(d * (unsigned long long)NT) / 18446744073709551616.0L);
-            double2 st; st.x = (double)cosl(ang); st.y = (double)sinl(ang);
             QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, sizeof(d), hipMemcpyHostToDevice, stream));
-            QH_HIP(hipMemcpyAsync(nco_step + ch, &st, sizeof(st), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.nco_dirty = false;
         }
@@ -494,6 +530,10 @@ int Engine::refresh_params()
             c.bp1_flush = false;
         }
     }
+    if (!nco_list.empty())      // retune_list still holds the channels; the new dphase values are in place
+        hipLaunchKernelGGL((front_mask_kernel<kNfft>), dim3((unsigned)nco_list.size()), dim3(NT), (size_t)(TileFft<kNfft, false, double2>::kLdsBytes),
+                           stream, (const double *)front_taps, front_ntaps, (const unsigned long long *)nco_dphase, (const int *)retune_list, front_fold,
+                           (const double2 *)tw4096, mask_front, lane_rot, nco_step);
     return QH_OK;
 }
 
@@ -1088,13 +1128,13 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX, bool PACKED = false, bool METER = false>
+template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, kNfft, D>();
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED, METER>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED, METER, OUTMIX>), grid, block, lds, s, a);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------
@@ -1108,39 +1148,52 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
         a.in = src; a.in_stride = src_stride;
         a.hist = hist_front[cur_front]; a.hist_stride = kHistFront; a.hist_len = kHistFront;
         a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
-        a.mask = mask_front; a.mask_stride = 0;
+        a.mask = mask_front; a.mask_stride = kNfft;
         a.tw_fwd = tw4096; a.tw_inv = tw_inv_front;
-        a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
+        a.nco_step = nco_step; a.lane_rot = lane_rot;
         a.epi = ep;
         a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L; a.pick = front_pick;
         const int per_tile = front_L / front_pick;
         const int ntiles = (int)((n_mid + per_tile - 1) / per_tile);
+        if (ntiles > tile_rot_cap) {
+            QH_HIP(hipStreamSynchronize(stream));
+            drop_graphs(); epoch++;
+            if (tile_rot) { QH_HIP(hipFree(tile_rot)); dev_bytes -= tile_rot_cap * nch * (long long)sizeof(double2); tile_rot = nullptr; }
+            QH_HIP(dev_alloc(&tile_rot, (size_t)nch * (size_t)ntiles));
+            tile_rot_cap = ntiles;
+            dev_bytes += (long long)ntiles * nch * (long long)sizeof(double2);
+        }
+        // oscillator phasor at the first input index of every tile: g0 = off - P + tile * fold * Lout (qh_osfir.hpp)
+        hipLaunchKernelGGL(nco_tile_kernel, dim3((unsigned)((ntiles + 255) / 256), (unsigned)nch), dim3(256), 0, stream,
+                           (const unsigned long long *)nco_phase, (const unsigned long long *)nco_dphase, tile_rot, ntiles,
+                           (long long)(a.off - a.P), (long long)front_fold * front_L);
+        a.tile_rot = tile_rot;
         a.pk_src = pk_src; a.pk = pk;
         if (pk_src) {
             switch (front_fold) {
-            case 2: launch_osfir<2, true, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, true, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, true, true>(a, ntiles, nch, stream); break;
+            case 2: launch_osfir<2, false, true, false, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, false, true, false, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, false, true, false, true>(a, ntiles, nch, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         } else {
             switch (front_fold) {
-            case 2: launch_osfir<2, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, true>(a, ntiles, nch, stream); break;
+            case 2: launch_osfir<2, false, false, false, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, false, false, false, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, false, false, false, true>(a, ntiles, nch, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         }
         tick(2);
         dim3 g((kHistFront + NT - 1) / NT, (unsigned)nch);
         if (pk_src)
-            hipLaunchKernelGGL((hist_update_kernel<double, true, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
-                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase,
-                               (const int *)nullptr, pk_src, pk);
+            hipLaunchKernelGGL((hist_update_kernel<double, false, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
+                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, (const unsigned long long *)nullptr,
+                               (const unsigned long long *)nullptr, (const int *)nullptr, pk_src, pk);
         else
-            hipLaunchKernelGGL((hist_update_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
-                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, nco_phase, nco_dphase,
-                               (const int *)nullptr, (const unsigned char *)nullptr, PackedFmt{});
+            hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
+                               hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, (const unsigned long long *)nullptr,
+                               (const unsigned long long *)nullptr, (const int *)nullptr, (const unsigned char *)nullptr, PackedFmt{});
         cur_front ^= 1;
     } else {
         if (pk_src) return set_error(QH_ERR_UNSUPPORTED, "packed input needs in_rate > dsp_rate (unpack with qh_unpack_iq first)");
@@ -1878,6 +1931,7 @@ int Engine::process_replayed(const double *d_in, long long in_stride, double *d_
         // the first call under a new key uploads dirty parameters and grows buffers (synchronising): not capturable
         const int rc = process(d_in, in_stride, d_out, out_stride, nblk);
         graph_seen = rc == QH_OK;
+        graph_key.epoch = epoch;        // buffers that this call grew are in place now
         return rc;
     }
     QH_HIP(hipSetDevice(device));

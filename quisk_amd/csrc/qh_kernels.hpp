@@ -53,6 +53,80 @@ __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long
     else { parked[ch] = phase[ch]; phase[ch] = 0; }
 }
 
+// ---- output-side NCO (osfir_kernel OUTMIX) ---------------------------------------------------------------------------
+// Phasor of the oscillator at the first input index of every tile of the coming launch: g0(tile) = g00 + tile * gstep.
+[[maybe_unused]] static __global__ void nco_tile_kernel(const unsigned long long *phase, const unsigned long long *dphase, double2 *tile_rot,
+                                                        int ntiles, long long g00, long long gstep)
+{
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (tile >= ntiles) return;
+    const long long g0 = g00 + (long long)tile * gstep;
+    double2 r;
+    sincos_turns<double>(phase[ch] + dphase[ch] * (unsigned long long)g0, r.x, r.y);
+    tile_rot[(long long)ch * ntiles + tile] = r;
+}
+
+// A channel's oscillator changes (frequency, run / parked phase) between two calls: the stored raw history x[n'], n' < 0,
+// was going to be seen through the old phase law phi_old(n') = p_old + d_old n'; the kernel will apply the new one.
+// x[n'] <- x[n'] exp(j (phi_old(n') - phi_new(n'))) keeps every product h[k] x[n'] exp(j phi(n')) what the reference's
+// sample-by-sample xshift (wdsp/shift.c:60-85) made it.  Reads the old law from the device arrays (the update follows in
+// stream order); list[] = channel, new_law[] = (action, d_new) per listed channel.
+[[maybe_unused]] static __global__ void nco_retune_hist_kernel(double2 *hist, int H, const unsigned long long *phase,
+                                                               const unsigned long long *dphase, const unsigned long long *parked,
+                                                               const int *list, const unsigned long long *new_law)
+{
+    const int ch = list[blockIdx.y], j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    const long long np = (long long)j - H;                  // n' of history entry j
+    // new_law: (action, d_new) -- action 0: the phase carries on, 1: the shift is switched off (phase parked, no rotation
+    // from now on), 2: switched on again (the parked phase comes back)
+    const unsigned long long act = new_law[2 * blockIdx.y], d_new = new_law[2 * blockIdx.y + 1];
+    const unsigned long long p_new = act == 0 ? phase[ch] : act == 1 ? 0ull : parked[ch];
+    const unsigned long long dphi = (phase[ch] - p_new) + (dphase[ch] - d_new) * (unsigned long long)np;
+    double2 r;
+    sincos_turns<double>(dphi, r.x, r.y);
+    double2 *p = hist + (long long)ch * H + j;
+    *p = cmul(*p, r);
+}
+
+// The front stage's per-channel tables for the output-side oscillator: mask = FFT_NFFT(h[k] exp(-j k delta)) / NFFT (the
+// resampler's real taps of wdsp/resample.c:35-78 modulated down by the channel's shift), lane_rot[t] = exp(j D delta t),
+// step = exp(j D NT delta).  One workgroup per listed channel; delta = dphase[ch] in 2^-64 turns, every angle exact in
+// 64-bit wrap-around arithmetic before it is converted.
+template <int NFFT>
+__global__ __launch_bounds__(NT) void front_mask_kernel(const double *taps, int ntaps, const unsigned long long *dphase, const int *list,
+                                                        int D, const double2 *tw, double2 *mask, double2 *lane_rot, double2 *step)
+{
+    constexpr int E = NFFT / NT;
+    using Fwd = TileFft<NFFT, false, double2>;
+    extern __shared__ __align__(16) unsigned char smem_mask[];
+    const int ch = list[blockIdx.x], t = threadIdx.x;
+    const unsigned long long d = dphase[ch];
+    double2 x[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int k = t + NT * r;
+        x[r] = make_double2(0.0, 0.0);
+        if (k < ntaps) {
+            double c, s;
+            sincos_turns<double>(0ull - d * (unsigned long long)k, c, s);
+            const double h = taps[k];
+            x[r] = make_double2(h * c, h * s);
+        }
+    }
+    Fwd::run(x, smem_mask, Fwd::load(tw));
+#pragma unroll
+    for (int r = 0; r < E; r++) mask[(long long)ch * NFFT + t + NT * r] = make_double2(x[r].x * (1.0 / NFFT), x[r].y * (1.0 / NFFT));
+    double2 lr;
+    sincos_turns<double>(d * (unsigned long long)((long long)D * t), lr.x, lr.y);
+    lane_rot[(long long)ch * NT + t] = lr;
+    if (t == 0) {
+        double2 st;
+        sincos_turns<double>(d * (unsigned long long)((long long)D * NT), st.x, st.y);
+        step[ch] = st;
+    }
+}
+
 // Elementwise stage used when a chain has no FIR stage to fuse into:
 //   out = epi * (in * nco)      (xshift, wdsp/shift.c:60-85; xwcpagc mode 0 + xpanel)
 template <typename T, bool MIX>

@@ -4,6 +4,15 @@
 //
 //     y[m] = sum_k h[k] * x'[D*m + off - k],      x'[n] = x[n] * exp(j*(phase0 + n*delta))   (MIX)
 //
+// or, for OUTMIX, the same thing with the oscillator moved behind the filter:
+//
+//     y[m] = exp(j*(phase0 + (D*m + off)*delta)) * sum_k (h[k] exp(-j*k*delta)) * x[D*m + off - k]
+//
+// (an identity while delta is constant over the taps' span; the engine rewrites the short history when it changes):
+// the mask is the spectrum of the modulated taps, one per channel, and the rotation costs one multiply per OUTPUT
+// sample -- a D-th of the input-side form -- with the phasor taken from two tables, exp(j*Phi_tile) * exp(j*D*delta*t)
+// (tile_rot, lane_rot), instead of a sincospi per lane and tile.
+//
 // which is, with D = 1: WDSP's partitioned overlap-save "fircore" (wdsp/firmin.c:409-430: the
 // partitions sum to one causal linear convolution with the nc-tap complex impulse), and with
 // real taps and D > 1: WDSP's polyphase resampler for L = 1 (wdsp/resample.c:120-157, preceded
@@ -62,6 +71,9 @@ template <typename T> struct OsfirArgs {
     // METER kernels (D = 1, P and Lout multiples of 256): per 64-sample chunk of the stage's input (meter_in) and of its
     // output ahead of the epilogue (meter_out), x = sum_i w[i] |z_i|^2 and y = max_i |z_i|^2 -- what xmeter's one-pole
     // average and block peak (wdsp/meter.c:75-108) need from the chunk; meter_finish_kernel walks them in time order
+    // OUTMIX kernels: phasor of the NCO at input index g0 of every tile, at D*t for lane t, at D*256 (nco_step)
+    const double2 *tile_rot;            // [nch][ntiles]
+    const double2 *lane_rot;            // [nch][NT]
     double2 *meter_in, *meter_out;      // [nch][meter_stride] chunk partials, chunk c = samples 64c .. 64c + 63 of this call
     long long meter_stride;
     const double *meter_w;              // [64]  (1 - m) m^(63 - i)
@@ -158,7 +170,13 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 #ifndef QH_OSFIR_WAVES_F64
 #define QH_OSFIR_WAVES_F64 3
 #endif
-template <typename T, int D> constexpr int osfir_min_waves() { return sizeof(T) == 8 ? (D == 1 ? QH_OSFIR_WAVES_F64_D1 : QH_OSFIR_WAVES_F64) : 4; }
+#ifndef QH_OSFIR_WAVES_F64_OUTMIX
+#define QH_OSFIR_WAVES_F64_OUTMIX 3
+#endif
+template <typename T, int D, bool OUTMIX = false> constexpr int osfir_min_waves()
+{
+    return sizeof(T) == 8 ? (D == 1 ? QH_OSFIR_WAVES_F64_D1 : OUTMIX ? QH_OSFIR_WAVES_F64_OUTMIX : QH_OSFIR_WAVES_F64) : 4;
+}
 
 #ifdef QH_OSFIR_PROBE      // tools/ubench/osfir_phase.hip only: shader-clock stamps of one workgroup per phase
 __device__ long long g_osfir_probe[16];
@@ -183,18 +201,7 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v)
     return __hiloint2double(hi, lo);
 }
 constexpr int kMeterLdsDoublesPerWave = 2 * 64 * 9;
-#if defined(QH_METER_EXP) && QH_METER_EXP == 3
-__device__ __forceinline__ double wave_sum_exp(double v)
-{
-    v += dpp_mov_d<0xB1>(v); v += dpp_mov_d<0x4E>(v); v += dpp_mov_d<0x141>(v); v += dpp_mov_d<0x140>(v);
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    double a = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-    double c = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-    double d = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-    return (a + b) + (c + d);
-}
-#endif     // (sum set, max set) x 64 segments x pitch 9
+     // (sum set, max set) x 64 segments x pitch 9
 
 // max of two numbers that are not NaN (squared magnitudes): fmax() would first re-quiet operands the compiler cannot
 // prove canonical (everything that comes back from LDS or a DPP move) with a v_max_f64 x, x each
@@ -207,12 +214,6 @@ __device__ __forceinline__ double max_nn(double a, double b)
 
 // x[r0 + k], k = 0 .. nseg - 1 (nseg = E - r0), are the registers to meter.  The wave's nseg partials go out as one
 // contiguous run: dst[wave * nseg + k] (meter_finish_kernel knows that chunk 4 k + wave of the tile sits there).
-#ifndef QH_METER_SKIP
-#define QH_METER_SKIP 0         // experiments: 1 = no input tap, 2 = no output tap (timing only, results wrong)
-#endif
-#ifndef QH_METER_EXP
-#define QH_METER_EXP 0          // timing experiments (results wrong): 1 no extra barriers, 2 no partial stores, 3 Horner sums
-#endif
 template <typename C, int E>
 __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane, double *lds_wave, double2 *dst, int wave, int lane)
 {
@@ -221,49 +222,31 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
 #pragma unroll
     for (int g = 0; g < E / 8; g++) {
         if (8 * (g + 1) <= r0) continue;                // workgroup-uniform
-#if QH_METER_EXP == 3
-        double hs = 0.0;
-#endif
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const C v = x[8 * g + k];
             double m2 = (double)v.x * (double)v.x;
             m2 = __builtin_fma((double)v.y, (double)v.y, m2);       // wdsp/meter.c:90 (contracted)
-#if QH_METER_EXP == 3
-            hs = __builtin_fma(hs, 0.94807, m2);
-#else
             lds_wave[k * 72 + wr] = m2 * wlane;
-#endif
             lds_wave[64 * 9 + k * 72 + wr] = m2;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if QH_METER_EXP == 3
-        double sum = wave_sum_exp(hs * wlane), mx = rd[64 * 9];
-#pragma unroll
-        for (int k = 1; k < 8; k++) mx = max_nn(mx, rd[64 * 9 + k]);
-        mx = max_nn(mx, dpp_mov_d<0xB1>(mx)); mx = max_nn(mx, dpp_mov_d<0x4E>(mx)); mx = max_nn(mx, dpp_mov_d<0x141>(mx));
-#else
         double sum = rd[0], mx = rd[64 * 9];
 #pragma unroll
         for (int k = 1; k < 8; k++) { sum += rd[k]; mx = max_nn(mx, rd[64 * 9 + k]); }
         sum += dpp_mov_d<0xB1>(sum); mx = max_nn(mx, dpp_mov_d<0xB1>(mx));        // quad_perm [1,0,3,2]
         sum += dpp_mov_d<0x4E>(sum); mx = max_nn(mx, dpp_mov_d<0x4E>(mx));        // quad_perm [2,3,0,1]
         sum += dpp_mov_d<0x141>(sum); mx = max_nn(mx, dpp_mov_d<0x141>(mx));      // row_half_mirror
-#endif
         const int r = 8 * g + (lane >> 3);
-#if QH_METER_EXP == 2
-        if ((lane & 7) == 0 && r >= r0 && sum == 1.2345) dst[wave * (E - r0) + (r - r0)] = make_double2(sum, mx);
-#else
         if ((lane & 7) == 0 && r >= r0) dst[wave * (E - r0) + (r - r0)] = make_double2(sum, mx);
-#endif
         __builtin_amdgcn_wave_barrier();                // the next group overwrites the block
     }
 }
 
-template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false>
-__global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(OsfirArgs<T> a)
+template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false>
+__global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
     constexpr int E = NFFT / NT;            // elements per thread, forward
@@ -344,12 +327,9 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
         static_assert(D == 1 && !MIX && !PACKED, "meters ride on a plain D = 1 stage");
         static_assert(NT / 64 * kMeterLdsDoublesPerWave * 8 <= osfir_lds_bytes<T, NFFT, D>(), "meter blocks overlay the exchange image");
         // the tile's new samples [tile * Lout, (tile + 1) * Lout) are chunks tile * Lout / 64 ...; register P / 256 holds the first
-        if (QH_METER_SKIP != 1)
         meter_tap<C, E>(x, a.P >> 8, a.meter_w[t & 63], reinterpret_cast<double *>(lds) + (t >> 6) * kMeterLdsDoublesPerWave,
                         a.meter_in + (long long)ch * a.meter_stride + (long long)tile * (a.Lout >> 6), t >> 6, t & 63);
-#if QH_METER_EXP != 1
         __syncthreads();                    // the transform's exchange image overlays the waves' meter blocks
-#endif
     }
 
     // ---- forward FFT, registers -> registers
@@ -376,12 +356,23 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D>())) void osfir_kernel(Os
     Inv::run(z, lds, Inv::load(a.tw_inv));
     QH_OPROBE(4);
     if constexpr (METER) {
-#if QH_METER_EXP != 1
         __syncthreads();                    // other waves may still be reading the exchange image
-#endif
-        if (QH_METER_SKIP != 2)
         meter_tap<C, EO>(z, a.P >> 8, a.meter_w[t & 63], reinterpret_cast<double *>(lds) + (t >> 6) * kMeterLdsDoublesPerWave,
                          a.meter_out + (long long)ch * a.meter_stride + (long long)tile * (a.Lout >> 6), t >> 6, t & 63);
+    }
+
+    if constexpr (OUTMIX) {
+        static_assert(!MIX, "one oscillator");
+        const double2 tr = a.tile_rot[(long long)slot * a.ntiles + tile];       // workgroup-uniform: a scalar load
+        const double2 lr = a.lane_rot[(long long)ch * NT + t];
+        const double2 st = a.nco_step[ch];
+        C rot = cmul(mk<T>((T)tr.x, (T)tr.y), mk<T>((T)lr.x, (T)lr.y));
+        const C step = mk<T>((T)st.x, (T)st.y);
+#pragma unroll
+        for (int i = 0; i < EO; i++) {
+            z[i] = cmul(z[i], rot);
+            if (i + 1 < EO) rot = cmul(rot, step);
+        }
     }
 
     // ---- epilogue + store of the Lout valid outputs

@@ -66,6 +66,7 @@ def test_bench_call_shape_against_oracle_and_chunking(qh, oracle):
     y = torch.empty((nch, n_out), dtype=torch.complex128, device=dev)
     e = _engine(qh, nch)
     e.enable_meters(True)
+    torch.cuda.synchronize()            # the engine runs on its own stream
     e.process_ptr(x.data_ptr(), n_in, y.data_ptr(), n_out, nblk)
     e.synchronize()
     step_db = 10.0 * np.log10(2.0) / 2048.0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kstats.sh <out.csv> <program> [args...]   -- rocprofv3 kernel-trace stats of one command, top kernels
 # (run on the GPU box; the program goes straight after `--`, never through env/bash -c)
-out=$1; shift
+out=$(realpath -m "$1"); shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kst && mkdir -p /tmp/kst
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- "$@" > /tmp/kst/run.log 2>&1
