@@ -156,6 +156,10 @@ int qh_rxa_process(qh_rxa *e, const double *d_in, long long in_stride, double *d
 /* Same with host buffers (synchronous; pageable memory; includes the PCIe copies). */
 int qh_rxa_process_host(qh_rxa *e, const double *h_in, long long in_stride, double *h_out, long long out_stride, int nblk);
 
+/* Tiles of the time-tiled FM loop that had to be re-run sequentially so far (diagnostics; 0 on carriers, a fraction of a
+ * percent of the 256-sample tiles on noise alone). */
+long long qh_rxa_pll_repairs(qh_rxa *h);
+int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max);   /* diagnostics, see qh_engine.hip */
 int qh_rxa_synchronize(qh_rxa *e);
 
 /* Meters (wdsp/meter.c:75-142).  They cost an extra pass, so they are off until enabled.  mt as wdsp/RXA.h:47-57:

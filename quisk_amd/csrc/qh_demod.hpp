@@ -22,34 +22,6 @@ struct AmParam {            // per engine (depends on the DSP rate only), init_a
 
 struct AmState { double dc, dc_insert; };
 
-static __global__ __launch_bounds__(64) void am_detect_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                       const int *levelfade, AmState *state, AmParam prm)
-{
-    const int ch = chan_list[blockIdx.x];
-    const int lane = threadIdx.x;
-    double2 *p = buf + (long long)ch * stride;
-    AmState st = state[ch];
-    const bool lf = levelfade[ch] != 0;
-    const double pR = lane_pow(prm.mtauR, lane + 1), pI = lane_pow(prm.mtauI, lane + 1);
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = n - base < 64 ? n - base : 64;
-        const int i = base + lane;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[i];
-        double audio = sqrt(z.x * z.x + z.y * z.y);
-        if (lf) {
-            // dc = mtauR*dc + onem_mtauR*audio ; dc_insert = mtauI*dc_insert + onem_mtauI*audio
-            double dc = scan_pole(prm.onem_mtauR * audio, prm.mtauR, lane) + pR * st.dc;
-            double di = scan_pole(prm.onem_mtauI * audio, prm.mtauI, lane) + pI * st.dc_insert;
-            audio += di - dc;
-            st.dc = lane_bcast(dc, cnt - 1);
-            st.dc_insert = lane_bcast(di, cnt - 1);
-        }
-        if (lane < cnt) p[i] = make_double2(audio, audio);
-    }
-    if (lane == 0) state[ch] = st;
-}
-
 // ------------------------------------------------------------------------------------------------ PLLs
 struct PllParam {           // calc_fmd wdsp/fmd.c:29-44 ; init_amd wdsp/amd.c:72-89
     double omega_min, omega_max, g1, g2;
@@ -106,40 +78,6 @@ __device__ __forceinline__ void pll_run64(PllLoop &s, double theta_t, unsigned l
     my_pt = lane < cnt ? out[lane] : 0.0;
     my_fil = lane < cnt ? out[64 + lane] : 0.0;
     __builtin_amdgcn_wave_barrier();
-}
-
-// FM discriminator: in place, z -> (audio, audio).  One wave per listed channel.
-static __global__ __launch_bounds__(64) void fm_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                    PllState *state, const double *again, PllParam q)
-{
-    __shared__ double pll_out[128];
-    const int ch = chan_list[blockIdx.x];
-    const int lane = threadIdx.x;
-    double2 *p = buf + (long long)ch * stride;
-    PllState *sp = state + ch;
-    PllLoop L{ sp->phs * (1.0 / kTwoPiRef), sp->fil_out, sp->omega };
-    double fmdc = sp->fmdc;
-    const double gain = again[ch];
-    const double pw = lane_pow(q.mtau, lane + 1);
-    double2 znext = make_double2(0, 0);
-    if (lane < n) znext = p[lane];
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = n - base < 64 ? n - base : 64;
-        const double2 z = znext;                            // the next 64 samples travel while the loop below runs
-        znext = make_double2(0, 0);
-        if (base + 64 + lane < n) znext = p[base + 64 + lane];
-        const double theta_t = atan2(z.y, z.x) * (1.0 / kTwoPiRef);
-        const unsigned long long zero = __ballot(z.x == 0.0 && z.y == 0.0);
-        double my_pt, fil;
-        pll_run64(L, theta_t, zero, cnt, q, lane, my_pt, fil, pll_out);
-        // fmdc_i = mtau fmdc_{i-1} + onem_mtau fil_i (fmd.c:169), audio = again (fil - fmdc) (fmd.c:171): a scan
-        const double dcs = scan_pole(lane < cnt ? q.onem_mtau * fil : 0.0, q.mtau, lane) + pw * fmdc;
-        fmdc = lane_bcast(dcs, cnt - 1);
-        const double audio = gain * (fil - dcs);
-        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
-    }
-    const double phs = L.pt * kTwoPiRef, fil_out = L.fil_out, omega = L.omega;
-    if (lane == 0) { sp->phs = phs; sp->fil_out = fil_out; sp->omega = omega; sp->fmdc = fmdc; }
 }
 
 // all-pass coefficients of the SAM sideband separator, wdsp/amd.c:91-106
@@ -239,65 +177,6 @@ __device__ __forceinline__ M2 mmul(M2 x, M2 y)
     r.a = x.a * y.a + x.b * y.c; r.b = x.a * y.b + x.b * y.d;
     r.c = x.c * y.a + x.d * y.c; r.d = x.c * y.b + x.d * y.d;
     return r;
-}
-
-// y_i = b1*y_{i-1} + b2*y_{i-2} + f_i,  f_i = a0*x_i + a1*x_{i-1} + a2*x_{i-2};  only .x is filtered.
-static __global__ __launch_bounds__(64) void snotch_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                    const SnotchParam *prm, SnotchState *state)
-{
-    const int ch = chan_list[blockIdx.x];
-    const SnotchParam q = prm[ch];
-    if (!q.run) return;
-    const int lane = threadIdx.x;
-    double2 *p = buf + (long long)ch * stride;
-    SnotchState st = state[ch];
-    // A^(2^k), k = 0..5, and A^(lane+1)
-    M2 A; A.a = q.b1; A.b = q.b2; A.c = 1.0; A.d = 0.0;
-    M2 Apow[6];
-    Apow[0] = A;
-#pragma unroll
-    for (int k = 1; k < 6; k++) Apow[k] = mmul(Apow[k - 1], Apow[k - 1]);
-    M2 Al; Al.a = 1; Al.b = 0; Al.c = 0; Al.d = 1;
-    {
-        M2 b = A;
-        const int e = lane + 1;
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            if (e & (1 << k)) Al = mmul(b, Al);
-            b = mmul(b, b);
-        }
-    }
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = n - base < 64 ? n - base : 64;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[base + lane];
-        const double x0 = z.x;
-        double xm1 = __shfl_up(x0, 1, 64), xm2 = __shfl_up(x0, 2, 64);
-        if (lane == 0) { xm1 = st.x1; xm2 = st.x2; }
-        if (lane == 1) xm2 = st.x1;
-        // state vector u = [y_i, y_{i-1}] driven by [f_i, 0]
-        double u0 = q.a0 * x0 + q.a1 * xm1 + q.a2 * xm2, u1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int d = 1 << k;
-            const double v0 = __shfl_up(u0, d, 64), v1 = __shfl_up(u1, d, 64);
-            if (lane >= d) {
-                u0 += Apow[k].a * v0 + Apow[k].b * v1;
-                u1 += Apow[k].c * v0 + Apow[k].d * v1;
-            }
-        }
-        const double y = u0 + Al.a * st.y1 + Al.b * st.y2;
-        if (lane < cnt) p[base + lane] = make_double2(y, z.y);
-        const double ym1 = __shfl_up(y, 1, 64);
-        // carry: the last valid sample's (x, y) pairs
-        const int last = cnt - 1;
-        const double ny1 = lane_bcast(y, last);
-        const double ny2 = last >= 1 ? lane_bcast(ym1, last) : st.y1;
-        const double nx1 = lane_bcast(x0, last);
-        const double nx2 = last >= 1 ? lane_bcast(xm1, last) : st.x1;
-        st.x1 = nx1; st.x2 = nx2; st.y1 = ny1; st.y2 = ny2;
-    }
-    if (lane == 0) state[ch] = st;
 }
 
 // ------------------------------------------------------------------------------------------------ WDSP meters

@@ -27,6 +27,7 @@
 #include "qh_design.hpp"
 #include "qh_kernels.hpp"
 #include "qh_demod.hpp"
+#include "qh_tiled.hpp"
 #include "qh_emnr.hpp"
 #include "qh_snba.hpp"
 #include "qh_internal.hpp"
@@ -49,6 +50,11 @@ int set_error(int code, const char *fmt, ...)
 static constexpr int kNfft = 4096;          // FFT size of every overlap-save stage in this engine
 static constexpr int kHistBand = 2047;      // fircore history capacity: nc up to 2048
 static constexpr int kHistFront = 2240;     // resampler history capacity: 140 * D taps, D <= 16
+// FM PLL time tiles (qh_tiled.hpp).  On a carrier the loop (double pole at 0.66 per sample) forgets its start state in ~100
+// samples; on noise alone two runs meet after ~135 samples on average with an exponential tail, so a 768-sample warm-up
+// leaves a fraction of a percent of the tiles to the verify kernel's sequential re-run.
+static constexpr int kFmTile = 256;
+static constexpr int kFmWarm = 768;
 
 struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33
@@ -196,6 +202,12 @@ struct Engine {
     AmParam am_prm{};
     PllState *pll_state = nullptr;
     double *fm_again = nullptr;
+    // time-tiled FM loop (qh_tiled.hpp): per tile the loop state where its warm-up and where the tile ends, and the count of
+    // tiles fm_pll_verify_kernel had to re-run
+    double *pll_ends = nullptr;
+    long long pll_ends_cap = 0;             // tiles per channel
+    int *pll_nfixed = nullptr;
+    int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
     SamChanParam *sam_prm = nullptr;
     PllParam sam_pll_prm{}, fm_pll_prm{};
     SnotchParam *sn_prm = nullptr;
@@ -256,7 +268,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
-    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again);
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
     (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx);
@@ -594,6 +606,8 @@ int Engine::refresh_demod()
         QH_HIP(dev_alloc(&am_state, (size_t)nch));
         QH_HIP(dev_alloc(&pll_state, (size_t)nch));
         QH_HIP(dev_alloc(&fm_again, (size_t)nch));
+        QH_HIP(dev_alloc(&pll_nfixed, (size_t)1));
+        QH_HIP(hipMemsetAsync(pll_nfixed, 0, sizeof(int), stream));
         QH_HIP(dev_alloc(&sam_prm, (size_t)nch));
         QH_HIP(dev_alloc(&sn_prm, (size_t)nch));
         QH_HIP(dev_alloc(&sn_state, (size_t)nch));
@@ -1370,17 +1384,40 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         else snb_inplace(list_snb[0], n_snb[0]);
     }
     tick(1);
-    if (n_am) hipLaunchKernelGGL(am_detect_kernel, dim3((unsigned)n_am), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+    if (n_am) hipLaunchKernelGGL(am_detect_tiled_kernel, dim3((unsigned)n_am), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
                                  list_am, levelfade, am_state, am_prm);
     if (n_sam) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)n_sam), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
                                   list_sam, pll_state, sam_prm, sam_pll_prm, am_state);
     if (n_fm) {
-        hipLaunchKernelGGL(fm_pll_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
-                           pll_state, fm_again, fm_pll_prm);
+        // xfmd's loop (fmd.c:151-172), time-tiled (qh_tiled.hpp): angles, then one loop per lane and tile, then dc removal + gain.
+        // The FM channels' rows of `other` are free here: first half = angles, second half = loop filter output.
+        {
+            double *theta = reinterpret_cast<double *>(other), *fil = theta + buf_cap;
+            const long long per = (n_mid + NT - 1) / NT;
+            hipLaunchKernelGGL(pll_theta_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_fm), dim3(NT), 0, stream, cur, buf_cap,
+                               (int)n_mid, list_fm, theta, 2 * buf_cap);
+            const long long ntl = (n_mid + kFmTile - 1) / kFmTile;
+            const int ngroups = (int)((ntl + 63) / 64);
+            if ((long long)ngroups * 64 > pll_ends_cap) {
+                QH_HIP(hipStreamSynchronize(stream));
+                drop_graphs(); epoch++;
+                (void)hipFree(pll_ends); pll_ends = nullptr;
+                QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * 6));
+                pll_ends_cap = (long long)ngroups * 64;
+            }
+            hipLaunchKernelGGL(fm_pll_lanes_kernel, dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
+                               2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, pll_ends, pll_ends_cap * 6,
+                               fm_pll_prm, kFmTile, kFmWarm);
+            hipLaunchKernelGGL(fm_pll_verify_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
+                               2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * 6, fm_pll_prm, kFmTile, kFmWarm,
+                               pll_nfixed, pll_check_only);
+            hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, (const double *)fil, 2 * buf_cap, cur,
+                               buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm);
+        }
         run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm);      // de-emphasis
         run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_aud, 0, hist_aud, cur_aud, P, list_fm, n_fm);   // audio filter
         tick(1);
-        hipLaunchKernelGGL(snotch_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
+        hipLaunchKernelGGL(snotch_tiled_kernel, dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
                            sn_prm, sn_state);
         if (n_lim)      // detector limiter: lim_pre_gain 0.4, then its own wcpAGC (fmd.c:179-184)
             hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
@@ -2045,6 +2082,32 @@ int qh_rxa_GetRXAMeter(qh_rxa *h, int ch, int mt, double *value)
     }
     *value = (mt == 0 || mt == 2 || mt == 5) ? st.res_pk : st.res_av;
     return QH_OK;
+}
+
+// Diagnostics of the time-tiled FM loop: tiles whose speculative warm-up had not converged and were re-run in order.
+long long qh_rxa_pll_repairs(qh_rxa *h)
+{
+    if (!h || !h->e.pll_nfixed) return 0;
+    int v = 0;
+    if (hipSetDevice(h->e.device) != hipSuccess || hipStreamSynchronize(h->e.stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, h->e.pll_nfixed, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
+
+// Diagnostics: check_only >= 0 sets the verify pass to count-only (1) or repair (0); then copies up to `max` doubles of
+// channel ch's per-tile loop states of the last call ([tile][6]: pt, fil_out, omega where the warm-up ended / the tile ended).
+int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    Engine &e = h->e;
+    if (check_only >= 0) e.pll_check_only = check_only;
+    if (!out || max <= 0 || !e.pll_ends) return 0;
+    QH_HIP(hipSetDevice(e.device));
+    QH_HIP(hipStreamSynchronize(e.stream));
+    long long n = e.pll_ends_cap * 6;
+    if (n > max) n = max;
+    QH_HIP(hipMemcpy(out, e.pll_ends + (long long)ch * e.pll_ends_cap * 6, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 int qh_rxa_synchronize(qh_rxa *h)

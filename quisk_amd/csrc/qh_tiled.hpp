@@ -1,0 +1,495 @@
+// qh_tiled.hpp -- the per-channel recurrences of the WDSP detectors, parallel in TIME as well as over channels.
+//
+// The reference steps every one of them sample by sample (xamd wdsp/amd.c:131-146, xfmd wdsp/fmd.c:151-172, xsnotch
+// wdsp/iir.c:76-95).  On the GPU a channel's 2^16 ... 2^20 samples per call would leave one wavefront per channel busy for
+// milliseconds while a thousand SIMDs idle (round 1: 85 FM channels = 85 wavefronts, 5.5 ms).  Two facts remove the
+// serialisation:
+//
+//  * LINEAR recurrences (the AM fade leveller's two one-pole averages, the FM detector's DC removal, the CTCSS bi-quad)
+//    have a state that is an affine function of the state at any earlier time: a workgroup of 16 wavefronts cuts the call
+//    into 16 time segments, every wavefront first runs its segment from a ZERO state and keeps the end value, the end
+//    values are chained (C <- T^len C + e, 15 steps), and a second pass over the segment starts from the true carry.  Exact:
+//    the same additions in a different association.  Inside a wavefront the scan over 64 consecutive samples uses DPP row
+//    shifts / row broadcasts (18 instructions) instead of six LDS-crossbar shuffles.
+//
+//  * The PLL of the FM detector is not linear (phase wrap, frequency clamp) but it is a CONTRACTION: WDSP's loop
+//    (zeta 1, omega_N 20 000 rad/s at 48 kHz, RXA.c:199-204) has a double pole at 0.66 per sample, so two runs that start
+//    from different states agree to 1e-16 after ~100 samples (a 2 pi slip of one of them only restarts that clock).  The call
+//    is cut into tiles of L samples; EVERY LANE of a wavefront owns one tile and steps its own loop state through the tile's
+//    samples, beginning H samples early from a zero state (the first tile begins at the carried state and is exact).  The
+//    detector angle arg z is taken for all samples up front (pll_theta_kernel); a wavefront stages the angles of its 64 tiles
+//    through LDS 64 steps at a time (rows loaded coalesced, read back transposed, pitch 65: conflict free).
+#pragma once
+#include "qh_demod.hpp"
+
+namespace qh {
+
+static constexpr int kSegWaves = 16;                // wavefronts (time segments) per channel in the two-pass kernels
+static constexpr int kSegThreads = 64 * kSegWaves;
+
+// ---- DPP scans ------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_fetch_d(double v)
+{
+    // lanes the control leaves without a source (shifted in from outside the row, rows outside ROWMASK) read 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// v_i = m v_{i-1} + u_i over the 64 lanes, zero carry-in: Kogge-Stone inside each row of 16 (row_shr 1, 2, 4, 8), then
+// lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31).
+struct PoleScan { double m1, m2, m4, m8, pa, pb, pw; };     // pa = m^((lane & 15) + 1), pb = m^((lane & 31) + 1), pw = m^(lane + 1)
+__device__ __forceinline__ PoleScan make_pole_scan(double m, int lane)
+{
+    PoleScan p;
+    p.m1 = m; p.m2 = m * m; p.m4 = p.m2 * p.m2; p.m8 = p.m4 * p.m4;
+    p.pa = lane_pow(m, (lane & 15) + 1); p.pb = lane_pow(m, (lane & 31) + 1); p.pw = lane_pow(m, lane + 1);
+    return p;
+}
+__device__ __forceinline__ double scan_pole_dpp(double u, const PoleScan &p)
+{
+    u = __builtin_fma(p.m1, dpp_fetch_d<0x111, 0xf>(u), u);
+    u = __builtin_fma(p.m2, dpp_fetch_d<0x112, 0xf>(u), u);
+    u = __builtin_fma(p.m4, dpp_fetch_d<0x114, 0xf>(u), u);
+    u = __builtin_fma(p.m8, dpp_fetch_d<0x118, 0xf>(u), u);
+    u = __builtin_fma(p.pa, dpp_fetch_d<0x142, 0xa>(u), u);
+    u = __builtin_fma(p.pb, dpp_fetch_d<0x143, 0xc>(u), u);
+    return u;
+}
+
+// the segment of wavefront `wave`: batches of 64 samples [b0, b1) of the ceil(n / 64) in the call
+__device__ __forceinline__ void seg_range(int n, int wave, int &b0, int &b1)
+{
+    const int nb = (n + 63) >> 6;
+    b0 = (int)((long long)wave * nb / kSegWaves);
+    b1 = (int)((long long)(wave + 1) * nb / kSegWaves);
+}
+__device__ __forceinline__ int seg_samples(int n, int b0, int b1)
+{
+    const int lo = b0 * 64 < n ? b0 * 64 : n, hi = b1 * 64 < n ? b1 * 64 : n;
+    return hi - lo;
+}
+
+// ---- AM envelope detector + fade leveller (xamd mode 0, wdsp/amd.c:131-146), in place, z -> (audio, audio) ------------
+static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                                             const int *levelfade, AmState *state, AmParam prm)
+{
+    __shared__ double s_e[kSegWaves][2];
+    __shared__ int s_n[kSegWaves];
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2 *p = buf + (long long)ch * stride;
+    const bool lf = levelfade[ch] != 0;
+    int b0, b1;
+    seg_range(n, wave, b0, b1);
+    const PoleScan sR = make_pole_scan(prm.mtauR, lane), sI = make_pole_scan(prm.mtauI, lane);
+    // pass 1: the magnitudes (the output already when the leveller is off) and the segment's response to its own samples
+    double eR = 0.0, eI = 0.0;
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
+        double a = 0.0;
+        if (lane < cnt) {
+            const double2 z = p[base + lane];
+            a = sqrt(z.x * z.x + z.y * z.y);
+            p[base + lane] = make_double2(a, a);
+        }
+        if (lf) {
+            const double vR = scan_pole_dpp(prm.onem_mtauR * a, sR) + sR.pw * eR;
+            const double vI = scan_pole_dpp(prm.onem_mtauI * a, sI) + sI.pw * eI;
+            eR = lane_bcast(vR, cnt - 1); eI = lane_bcast(vI, cnt - 1);
+        }
+    }
+    if (!lf) return;                                    // block-uniform
+    if (lane == 0) { s_e[wave][0] = eR; s_e[wave][1] = eI; s_n[wave] = seg_samples(n, b0, b1); }
+    __syncthreads();
+    // the true state at the start of this segment: dc <- mtau^len dc + e over the segments before it
+    double cR = state[ch].dc, cI = state[ch].dc_insert;
+    for (int w = 0; w < wave; w++) {
+        const double len = (double)s_n[w];
+        cR = __builtin_fma(cR, pow(prm.mtauR, len), s_e[w][0]);
+        cI = __builtin_fma(cI, pow(prm.mtauI, len), s_e[w][1]);
+    }
+    // pass 2
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
+        const double a = lane < cnt ? p[base + lane].x : 0.0;
+        const double dc = scan_pole_dpp(prm.onem_mtauR * a, sR) + sR.pw * cR;       // amd.c:136-137
+        const double di = scan_pole_dpp(prm.onem_mtauI * a, sI) + sI.pw * cI;
+        const double audio = a + (di - dc);                                          // amd.c:138
+        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
+        cR = lane_bcast(dc, cnt - 1); cI = lane_bcast(di, cnt - 1);
+    }
+    int last = kSegWaves - 1;                           // the wavefront that holds the last sample of the call
+    while (last > 0 && s_n[last] == 0) last--;
+    if (wave == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+}
+
+// ---- CTCSS notch (xsnotch, wdsp/iir.c:76-95): bi-quad on the I component, in place ------------------------------------
+// state vector (y_i, y_{i-1}) driven by (f_i, 0), f_i = a0 x_i + a1 x_{i-1} + a2 x_{i-2}; transition A = [[b1, b2], [1, 0]]
+__device__ __forceinline__ M2 m2_pow(M2 a, int e)
+{
+    M2 r; r.a = 1; r.b = 0; r.c = 0; r.d = 1;
+    while (e > 0) {
+        if (e & 1) r = mmul(a, r);
+        a = mmul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+struct BiquadScan { M2 a1, a2, a4, a8, pa, pb, pw; };
+__device__ __forceinline__ BiquadScan make_biquad_scan(M2 A, int lane)
+{
+    BiquadScan s;
+    s.a1 = A; s.a2 = mmul(A, A); s.a4 = mmul(s.a2, s.a2); s.a8 = mmul(s.a4, s.a4);
+    s.pa = m2_pow(A, (lane & 15) + 1); s.pb = m2_pow(A, (lane & 31) + 1); s.pw = m2_pow(A, lane + 1);
+    return s;
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void biquad_step(double &u0, double &u1, const M2 &m)
+{
+    const double v0 = dpp_fetch_d<CTRL, ROWMASK>(u0), v1 = dpp_fetch_d<CTRL, ROWMASK>(u1);
+    u0 += m.a * v0 + m.b * v1;
+    u1 += m.c * v0 + m.d * v1;
+}
+__device__ __forceinline__ void scan_biquad_dpp(double &u0, double &u1, const BiquadScan &s)
+{
+    biquad_step<0x111, 0xf>(u0, u1, s.a1);
+    biquad_step<0x112, 0xf>(u0, u1, s.a2);
+    biquad_step<0x114, 0xf>(u0, u1, s.a4);
+    biquad_step<0x118, 0xf>(u0, u1, s.a8);
+    biquad_step<0x142, 0xa>(u0, u1, s.pa);
+    biquad_step<0x143, 0xc>(u0, u1, s.pb);
+}
+
+static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                                          const SnotchParam *prm, SnotchState *state)
+{
+    __shared__ double s_e[kSegWaves][2], s_x[kSegWaves][2];
+    __shared__ int s_n[kSegWaves];
+    const int ch = chan_list[blockIdx.x];
+    const SnotchParam q = prm[ch];
+    if (!q.run) return;                                 // block-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2 *p = buf + (long long)ch * stride;
+    const SnotchState st0 = state[ch];
+    int b0, b1;
+    seg_range(n, wave, b0, b1);
+    M2 A; A.a = q.b1; A.b = q.b2; A.c = 1.0; A.d = 0.0;
+    const BiquadScan sc = make_biquad_scan(A, lane);
+    // the forcing term needs x two samples back: from the buffer (pass 1 leaves it untouched), from the carried state at
+    // the very beginning; pass 2 overwrites x with y, so every segment's last two inputs are put aside for its successor
+    auto x_at = [&](int i) -> double { return i >= 0 ? p[i].x : (i == -1 ? st0.x1 : st0.x2); };
+    // pass 1: response of the zero state to the segment's forcing
+    double e0 = 0.0, e1 = 0.0;
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64, i = base + lane;
+        double u0 = 0.0, u1 = 0.0;
+        if (lane < cnt) u0 = q.a0 * x_at(i) + q.a1 * x_at(i - 1) + q.a2 * x_at(i - 2);
+        scan_biquad_dpp(u0, u1, sc);
+        const double y0 = u0 + sc.pw.a * e0 + sc.pw.b * e1, y1 = u1 + sc.pw.c * e0 + sc.pw.d * e1;
+        e0 = lane_bcast(y0, cnt - 1); e1 = lane_bcast(y1, cnt - 1);
+    }
+    const int ns = seg_samples(n, b0, b1);
+    if (lane == 0) {
+        const int end = b0 * 64 + ns;                   // one past the segment's last sample
+        s_e[wave][0] = e0; s_e[wave][1] = e1; s_n[wave] = ns;
+        s_x[wave][0] = ns > 0 ? x_at(end - 1) : 0.0; s_x[wave][1] = ns > 0 ? x_at(end - 2) : 0.0;
+    }
+    __syncthreads();
+    // true (y_{-1}, y_{-2}) and (x_{-1}, x_{-2}) at the start of this segment
+    double c0 = st0.y1, c1 = st0.y2, xm1 = st0.x1, xm2 = st0.x2;
+    for (int w = 0; w < wave; w++) {
+        if (s_n[w] == 0) continue;
+        const M2 T = m2_pow(A, s_n[w]);
+        const double n0 = T.a * c0 + T.b * c1 + s_e[w][0], n1 = T.c * c0 + T.d * c1 + s_e[w][1];
+        c0 = n0; c1 = n1;
+        xm1 = s_x[w][0]; xm2 = s_x[w][1];
+    }
+    // pass 2 (every segment's boundary inputs were put aside before the barrier above: in-place writes are safe now)
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[base + lane];
+        const double x0 = z.x;
+        double x1 = dpp_fetch_d<0x138, 0xf>(x0), x2 = dpp_fetch_d<0x138, 0xf>(x1);    // wave_shr:1, twice
+        if (lane == 0) { x1 = xm1; x2 = xm2; }
+        if (lane == 1) x2 = xm1;
+        double u0 = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0, u1 = 0.0;
+        scan_biquad_dpp(u0, u1, sc);
+        const double y0 = u0 + sc.pw.a * c0 + sc.pw.b * c1, y1 = u1 + sc.pw.c * c0 + sc.pw.d * c1;
+        if (lane < cnt) p[base + lane] = make_double2(y0, z.y);
+        c0 = lane_bcast(y0, cnt - 1); c1 = lane_bcast(y1, cnt - 1);
+        const double prev1 = xm1;
+        xm1 = lane_bcast(x0, cnt - 1);
+        xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
+    }
+    int last = kSegWaves - 1;
+    while (last > 0 && s_n[last] == 0) last--;
+    if (wave == last && lane == 0 && n > 0) { SnotchState st; st.x1 = xm1; st.x2 = xm2; st.y1 = c0; st.y2 = c1; state[ch] = st; }
+}
+
+// ---- FM discriminator (xfmd's loop, wdsp/fmd.c:151-172) ---------------------------------------------------------------
+// arg z in turns, (-0.5, 0.5], for every sample of the listed channels; an all-zero sample ("corr[0] = 1.0": det = 0) is
+// marked by the value kThetaZero, which the loop turns into zero loop gains for that step
+static constexpr double kThetaZero = 8.0;
+static __global__ __launch_bounds__(NT) void pll_theta_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
+                                                              double *theta, long long tstride)
+{
+    const int ch = chan_list[blockIdx.y];
+    const double2 *p = buf + (long long)ch * stride;
+    double *th = theta + (long long)ch * tstride;
+    for (long long g = (long long)blockIdx.x * NT + threadIdx.x; g < n; g += (long long)gridDim.x * NT) {
+        const double2 z = p[g];
+        double t = atan2(z.y, z.x) * (1.0 / kTwoPiRef);
+        if (z.x == 0.0 && z.y == 0.0) t = kThetaZero;
+        th[g] = t;
+    }
+}
+
+__device__ __forceinline__ double min_nn(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_nn_d(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// One wavefront = 64 consecutive tiles of one channel, one tile per lane.  theta: [ch][tstride] angles (turns) of the call's
+// n samples; fil: [ch][fstride] the loop filter output per sample (what xfmd's dc removal and gain work on).  L = tile length
+// (multiple of 64), H = warm-up (multiple of 64).  Lane l of group g owns outputs [q L, (q + 1) L), q = 64 g + l, and starts
+// at sample max(0, q L - H): from the carried state when that is sample 0 -- exact -- else from the zero state.
+// 64 steps at a time: the 64 x 64 angles of the next batch travel from HBM into registers (row j = tile j, coalesced) while
+// the current batch is stepped (lane l takes row l out of LDS into registers first; pitch 65 doubles: conflict free both
+// ways); the loop filter outputs go back through LDS and leave row by row, coalesced again.
+// Speculation is checked, not trusted: every tile records its loop state where the warm-up ends (`ends` [ch][tile][0..2]) and
+// where the tile ends ([3..5]); fm_pll_verify_kernel compares neighbours and re-runs, in order, the tiles whose warm-up had
+// not met the true trajectory yet (a loop that sits on noise, without a carrier, can take several hundred samples).
+static constexpr int kPllPitch = 65;
+struct PllLane { double pt, fil_out, omega; };
+
+template <bool CHECKED>
+__device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[64], long long gb, int n, double g1t, double g2t, double inv,
+                                               double lo, double hi)
+{
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const double th = t[k];
+        double d = th - s.pt;                                   // (-1.5, 0.5] turns
+        d -= rint(d);
+        d = th < 4.0 ? d : 0.0;                                 // all-zero sample: det = 0 (fmd.c:156-157)
+        const double del_out = s.fil_out;
+        const double om = min_nn(max_nn_d(__builtin_fma(g2t, d, s.omega), lo), hi);     // fmd.c:159-161
+        const double fo = __builtin_fma(g1t, d, om);
+        const double np = __builtin_amdgcn_fract(__builtin_fma(del_out, inv, s.pt));
+        if (CHECKED) {
+            const long long g = gb + k;
+            if (g >= 0 && g < n) { s.omega = om; s.fil_out = fo; s.pt = np; }        // outside the call the state stands still
+        } else {
+            s.omega = om; s.fil_out = fo; s.pt = np;
+        }
+        t[k] = s.fil_out;
+    }
+}
+
+static __global__ __launch_bounds__(64) void fm_pll_lanes_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
+                                                                 const int *chan_list, const PllState *state, double *ends, long long estride,
+                                                                 PllParam q, int L, int H)
+{
+    __shared__ double lds[64 * kPllPitch];
+    const int ch = chan_list[blockIdx.y], lane = threadIdx.x, group = blockIdx.x;
+    const long long tile0 = (long long)group * 64 * L;                  // first output sample of lane 0's tile
+    if (tile0 >= n) return;                                             // no tile of this wavefront starts inside the call
+    const double *th = theta + (long long)ch * tstride;
+    double *fo = fil + (long long)ch * fstride;
+    const long long s0 = tile0 + (long long)lane * L;                   // first output sample of this lane's tile
+    const long long g_first = s0 - H;                                   // sample of step 0 (may be negative: those steps idle)
+    const bool live = s0 < n;
+    // loop state: carried for a lane whose run begins at (or before) sample 0, zero otherwise
+    const PllState *sp = state + ch;
+    const bool from_carry = g_first <= 0;
+    PllLane s{ from_carry ? sp->phs * (1.0 / kTwoPiRef) : 0.0, from_carry ? sp->fil_out : 0.0, from_carry ? sp->omega : 0.0 };
+    const double g1t = q.g1 * kTwoPiRef, g2t = q.g2 * kTwoPiRef, inv = 1.0 / kTwoPiRef, lo = q.omega_min, hi = q.omega_max;
+    if (!from_carry && live) {
+        // a warm-up has to end on the trajectory the loop is really on, and a loop with a wrapping detector can hold several
+        // (false locks): start where a loop that has been tracking would be -- on the signal's own phase and phase step
+        const double t0 = th[g_first], t1 = th[g_first + 1];
+        if (t0 < 4.0 && t1 < 4.0) {
+            double dt = t1 - t0;
+            dt -= rint(dt);
+            s.pt = t0 - floor(t0);
+            s.omega = min_nn(max_nn_d(dt * kTwoPiRef, lo), hi);
+            s.fil_out = s.omega;
+        }
+    }
+    const int nsteps = H + L;
+    double *e = ends + (long long)ch * estride + ((long long)group * 64 + lane) * 6;
+    double tn[64];                                                      // the next batch's angles, row j in tn[j]
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const long long g = tile0 + (long long)j * L - H + i0 + lane;
+            tn[j] = (g >= 0 && g < n) ? th[g] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int i0 = 0; i0 < nsteps; i0 += 64) {
+#pragma unroll
+        for (int j = 0; j < 64; j++) lds[j * kPllPitch + lane] = tn[j];
+        if (i0 + 64 < nsteps) fetch(i0 + 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double *row = lds + lane * kPllPitch;
+        double t[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) t[k] = row[k];
+        const long long gb = g_first + i0;
+        if (live) {
+            if (gb >= 0 && gb + 64 <= n) pll_lane_steps<false>(s, t, gb, n, g1t, g2t, inv, lo, hi);
+            else if (gb + 63 >= 0) pll_lane_steps<true>(s, t, gb, n, g1t, g2t, inv, lo, hi);
+        }
+        if (i0 + 64 == H && live) { e[0] = s.pt; e[1] = s.fil_out; e[2] = s.omega; }      // state where the warm-up ends
+#pragma unroll
+        for (int k = 0; k < 64; k++) row[k] = t[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // write the output steps out, row by row (warm-up steps i < H are dropped)
+        if (i0 >= H) {
+#pragma unroll 16
+            for (int j = 0; j < 64; j++) {
+                const long long g = tile0 + (long long)j * L - H + i0 + lane;
+                if (g < n) fo[g] = lds[j * kPllPitch + lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (live) { e[3] = s.pt; e[4] = s.fil_out; e[5] = s.omega; }          // state at the end of the tile (or of the call)
+}
+
+// Checks the speculation of fm_pll_lanes_kernel and repairs it.  Tile t is right when the state its warm-up reached equals
+// the state tile t - 1 ended in and tile t - 1 is right (the loop is deterministic: equal states stay equal; tiles 0 .. H/L ran
+// from the carried state and are right by construction).  One wavefront per channel walks the tiles in order; a tile that
+// fails is re-run from its predecessor's end state the sequential way (64 samples per batch, the angles in the lanes, the
+// loop stepped uniformly: pll_run64), which also gives the end state its successor is checked against.  A carrier the loop
+// tracks costs nothing here; a loop that history has left in one of its false locks (the wrapping detector and the +-8 kHz
+// clamp allow alias locks with the frequency pinned at the clamp, e.g. on an unmodulated carrier 1 kHz off tune after a
+// noisy start) fails every check and the whole call is stepped sequentially, as the reference does.
+// Then the loop state after the call's last sample goes into `state`.
+__device__ __forceinline__ bool pll_state_differs(double pa, double fa, double oa, double pb, double fb, double ob)
+{
+    double dp = pa - pb;
+    dp -= rint(dp);
+    const double tol = 1e-12;
+    return !(fabs(dp) < tol && fabs(fa - fb) < tol && fabs(oa - ob) < tol);
+}
+
+static __global__ __launch_bounds__(64) void fm_pll_verify_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
+                                                                  const int *chan_list, PllState *state, double *ends, long long estride,
+                                                                  PllParam q, int L, int H, int *nfixed, int check_only)
+{
+    __shared__ double pll_out[128];
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
+    const double *th = theta + (long long)ch * tstride;
+    double *fo = fil + (long long)ch * fstride;
+    double *e = ends + (long long)ch * estride;
+    const int ntiles = (n + L - 1) / L;
+    const int first = H / L + 1;                                        // tiles 0 .. H/L began at sample 0 from the carried state
+    int fixed = 0;
+    // the tile re-run last and its end state (uniform): whoever needs that state takes it from here, not from memory
+    double rp = 0, rf = 0, ro = 0;
+    int rt = -1;
+    for (int base = first; base < ntiles; base += 64) {
+        const int t = base + lane;
+        bool bad = false;
+        double wp = 0, wf = 0, wo = 0;
+        if (t < ntiles) {
+            const double *a = e + (long long)t * 6, *b = e + (long long)(t - 1) * 6 + 3;
+            wp = a[0]; wf = a[1]; wo = a[2];
+            double bp = b[0], bf = b[1], bo = b[2];
+            if (t - 1 == rt) { bp = rp; bf = rf; bo = ro; }             // the last tile of the batch before was re-run
+            bad = pll_state_differs(wp, wf, wo, bp, bf, bo);
+        }
+        unsigned long long mask = __ballot(bad);
+        if (check_only) { fixed += __popcll(mask); mask = 0; }         // diagnostics: count, leave the speculative result
+        while (mask) {
+            const int l0 = __ffsll((long long)mask) - 1, tq = base + l0;
+            mask &= ~(1ull << l0);
+            // re-run tile tq from the end state of tile tq - 1 (uniform values: read by every lane)
+            const double *bq = e + (long long)(tq - 1) * 6 + 3;
+            PllLoop Ls{ bq[0], bq[1], bq[2] };
+            if (tq - 1 == rt) { Ls.pt = rp; Ls.fil_out = rf; Ls.omega = ro; }
+            const long long s0 = (long long)tq * L;
+            const int len = (int)((long long)n - s0 < L ? (long long)n - s0 : L);
+            for (int off = 0; off < len; off += 64) {
+                const int cnt = len - off < 64 ? len - off : 64;
+                double tt = 0.0;
+                if (lane < cnt) tt = th[s0 + off + lane];
+                const unsigned long long zero = __ballot(tt >= 4.0);
+                double my_pt, my_fil;
+                pll_run64(Ls, tt, zero, cnt, q, lane, my_pt, my_fil, pll_out);
+                if (lane < cnt) fo[s0 + off + lane] = my_fil;
+            }
+            if (lane == 0) { double *w = e + (long long)tq * 6 + 3; w[0] = Ls.pt; w[1] = Ls.fil_out; w[2] = Ls.omega; }
+            rt = tq; rp = Ls.pt; rf = Ls.fil_out; ro = Ls.omega;
+            fixed++;
+            // the successor is judged against the repaired end state
+            const double np_ = lane_bcast(wp, l0 + 1 < 64 ? l0 + 1 : 63), nf_ = lane_bcast(wf, l0 + 1 < 64 ? l0 + 1 : 63),
+                         no_ = lane_bcast(wo, l0 + 1 < 64 ? l0 + 1 : 63);
+            if (l0 + 1 < 64 && tq + 1 < ntiles) {
+                if (pll_state_differs(np_, nf_, no_, Ls.pt, Ls.fil_out, Ls.omega)) mask |= 1ull << (l0 + 1);
+                else mask &= ~(1ull << (l0 + 1));
+            }
+        }
+    }
+    if (lane == 0 && n > 0) {
+        const double *b = e + (long long)(ntiles - 1) * 6 + 3;
+        double b0 = b[0], b1 = b[1], b2 = b[2];
+        if (rt == ntiles - 1) { b0 = rp; b1 = rf; b2 = ro; }
+        state[ch].phs = b0 * kTwoPiRef; state[ch].fil_out = b1; state[ch].omega = b2;
+        if (fixed && nfixed) atomicAdd(nfixed, fixed);
+    }
+}
+
+// dc removal and gain of xfmd (fmd.c:169-171): fmdc <- mtau fmdc + onem_mtau fil ; audio = again (fil - fmdc), written as
+// (audio, audio).  Same two-pass segment scheme as the AM leveller; fil is a real array, out the channel's complex row.
+static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const double *fil, long long fstride, double2 *out, long long stride,
+                                                                         int n, const int *chan_list, PllState *state, const double *again,
+                                                                         PllParam q)
+{
+    __shared__ double s_e[kSegWaves];
+    __shared__ int s_n[kSegWaves];
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *f = fil + (long long)ch * fstride;
+    double2 *p = out + (long long)ch * stride;
+    int b0, b1;
+    seg_range(n, wave, b0, b1);
+    const PoleScan sc = make_pole_scan(q.mtau, lane);
+    double e = 0.0;
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
+        const double v = scan_pole_dpp(lane < cnt ? q.onem_mtau * f[base + lane] : 0.0, sc) + sc.pw * e;
+        e = lane_bcast(v, cnt - 1);
+    }
+    if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); }
+    __syncthreads();
+    double c = state[ch].fmdc;
+    for (int w = 0; w < wave; w++) c = __builtin_fma(c, pow(q.mtau, (double)s_n[w]), s_e[w]);
+    const double gain = again[ch];
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
+        const double fv = lane < cnt ? f[base + lane] : 0.0;
+        const double dcs = scan_pole_dpp(q.onem_mtau * fv, sc) + sc.pw * c;
+        const double audio = gain * (fv - dcs);
+        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
+        c = lane_bcast(dcs, cnt - 1);
+    }
+    int last = kSegWaves - 1;
+    while (last > 0 && s_n[last] == 0) last--;
+    if (wave == last && lane == 0 && n > 0) state[ch].fmdc = c;
+}
+
+}  // namespace qh

@@ -78,6 +78,8 @@ def load():
     L.qh_rxa_set_graph_replay.argtypes = [vp, i]
     L.qh_rxa_graph_launches.argtypes = [vp]
     L.qh_rxa_graph_launches.restype = ll
+    L.qh_rxa_pll_repairs.argtypes = [vp]
+    L.qh_rxa_pll_repairs.restype = ll
     L.qh_wdsp_graph_launches.restype = ll
     L.qh_rxa_GetRXAMeter.argtypes = [vp, i, i, C.POINTER(d)]
     L.qh_rxa_flush.argtypes = [vp]

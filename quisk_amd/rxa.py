@@ -119,6 +119,9 @@ class RxaEngine:
         check(self._L.qh_rxa_GetRXAMeter(self._h, ch, mt, C.byref(v)))
         return v.value
 
+    def pll_repairs(self):
+        return self._L.qh_rxa_pll_repairs(self._h)
+
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))
 

@@ -57,14 +57,18 @@ def config4(torch, qh, dev):
         if m == 1: eng.RXASetPassband(c, 300.0, 3000.0)
         elif m == 6: eng.RXASetPassband(c, -4000.0, 4000.0)
         else: eng.RXASetPassband(c, -8000.0, 8000.0)
-    x = synth.make_input_torch(nch, n_in, dev)
+    # USB channels get the two-tone input of C2, AM channels a carrier with m = 0.5 / 1 kHz, FM channels a
+    # carrier with a 1 kHz tone at +-3 kHz deviation, all + noise (synth.make_mode_input_numpy)
+    kinds = {1: "usb", 6: "am", 5: "fm"}
+    x = torch.from_numpy(np.stack([synth.make_mode_input_numpy(kinds[modes[c % 3]], c, n_in) for c in range(nch)])).to(dev)
     y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
     sync = lambda: torch.cuda.synchronize(dev)
     t = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=5, warmup=1)
     tot = nch * n_in
     return {"config": "4 (one GPU's share): 256 ch x 192 k, mode by c mod 3 = USB / AM / FM, fp64", "samples_per_step": tot,
             "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6,
-            "note": "FM (85 channels) runs a PLL that is sequential per channel: it bounds the step"}
+            "pll_tiles_rerun": eng.pll_repairs(),
+            "note": "AM / FM / notch recurrences time-tiled (qh_tiled.hpp); pll_tiles_rerun = FM tiles the verify pass re-ran sequentially over all steps"}
 
 
 def config5(torch, qh, dev):
