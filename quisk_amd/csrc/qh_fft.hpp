@@ -251,11 +251,13 @@ template <int N, bool INV, typename C> struct FftRR;
 
 template <bool INV, typename C> struct FftRR<4096, INV, C> {
     struct Tw { C a[1], b; };
-    static __device__ __forceinline__ Tw load(const C *__restrict__ tw)
+    static __device__ __forceinline__ Tw load(const C *__restrict__ tw) { return load_at(tw, threadIdx.x); }
+    // j = index of the thread inside its 256-thread transform group (workgroups that run several transforms side by side)
+    static __device__ __forceinline__ Tw load_at(const C *__restrict__ tw, int j)
     {
         Tw t;
-        t.a[0] = pass_twiddle<16, INV>(tw, threadIdx.x);
-        t.b = pass_twiddle<256, INV>(tw + 16, threadIdx.x);
+        t.a[0] = pass_twiddle<16, INV>(tw, j);
+        t.b = pass_twiddle<256, INV>(tw + 16, j);
         return t;
     }
     static __device__ __forceinline__ void first(C (&x)[16], C *lds) { pass_regs_to_lds<4096, 16, INV>(x, lds); }
@@ -303,10 +305,12 @@ template <bool INV, typename C> struct FftSplit4096 {
         for (int r = 0; r < 16; r++) x[r].y = rp[r * RS];
     }
 
-    static __device__ __forceinline__ void run(C (&x)[16], void *lds_raw, const Tw &t)
+    static __device__ __forceinline__ void run(C (&x)[16], void *lds_raw, const Tw &t) { run_at(x, lds_raw, t, threadIdx.x); }
+    // the same for thread j of a 256-thread group inside a larger workgroup (the barriers are the workgroup's: every group of
+    // the workgroup must run its transform at the same time)
+    static __device__ __forceinline__ void run_at(C (&x)[16], void *lds_raw, const Tw &t, int j)
     {
         T *lds = reinterpret_cast<T *>(lds_raw);
-        const int j = threadIdx.x;
         Dft<16, INV, C>::run(x);                                    // pass 1: x[r] = in[j + 256 r]
         // element j*16 + r  ->  j + 256 r'   (sphys: 18 j + r, and sphys(j) + 288 r')
         exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));

@@ -27,6 +27,18 @@ namespace qh {
 
 struct PanBand { int first, nwhole; double frac; int valid, pad; };     // S-meter passband in bins, quisk.c:5223-5244
 
+// sqrt of a power |X|^2 (an ordinary magnitude or exactly 0; never denormal, infinite or NaN): the hardware's 26-bit
+// reciprocal square root and one Newton step in fused arithmetic -- s = x y, s += (y / 2) (x - s s) -- leave an error of a
+// few 1e-16 relative; the library sqrt spends three times the instructions on scaling and special cases that cannot occur
+__device__ __forceinline__ double sqrt_pow(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    const double r = __builtin_fma(-s, s, x);
+    s = __builtin_fma(0.5 * y, r, s);
+    return x == 0.0 ? 0.0 : s;
+}
+
 #ifndef QH_PAN_WAVES
 #define QH_PAN_WAVES 2
 #endif
@@ -146,6 +158,140 @@ __global__ __launch_bounds__(NT, QH_PAN_WAVES) void pan_spectrum_kernel(const do
         double sm = 0.0;
         for (int k = 0; k < NT / 64; k++) sm += wsum[k];
         partial_m2[((long long)split * nch + ch) * R + r] = sm;
+    }
+}
+
+// fft_size 16384 (BASELINE config 3), second form: a workgroup of G 256-thread groups (G = 2 or 4) computes G of the four
+// r-transforms of the decimation in frequency side by side, and reads the block once for all of them: thread (s, t) loads
+// the four strips x[m + 4096 q] for its 16 / G values m = t + 256 (16 s / G + j), windows them, forms the radix-4 combination
+// (a 4-point DFT over q) for the workgroup's r values, applies W_N^(m r) -- W_N^m is the phasor the window already uses --
+// and the sixteen results change hands inside {(0, t) .. (G - 1, t)} through LDS (real parts, then imaginary parts, laid
+// over the G transform images).  Then every group runs the split-exchange FFT-4096 of qh_fft.hpp on its own image, the
+// barriers being the workgroup's.  |X| accumulates over the range's blocks in the workgroup's own slice of `partial`
+// (read and written once per block: it stays in L2 / Infinity Cache; registers are what these workgroups are short of).
+// G = 2 (72 KB of LDS, two workgroups per CU that cover each other's load phases, the block read twice, the second time
+// from L2: the two workgroups of a block sit 8 ids apart = on one XCD) or G = 4 (one workgroup per CU, one read).
+// Against pan_spectrum_kernel<4096, 4>: a half / a quarter of the load instructions, 16 wavefronts per CU instead of 8,
+// same partial-sum layout and summation order.
+#ifndef QH_PAN16K_GROUPS
+#define QH_PAN16K_GROUPS 4
+#endif
+template <int G> constexpr int pan16k_lds() { return G * FftSplit4096<false, double2>::kLdsBytes; }
+template <int G>
+__global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
+                                                         const double2 *tw, double *partial, double *partial_m2,
+                                                         const PanBand *band, int nch)
+{
+    using C = double2;
+    using S = FftSplit4096<false, C>;
+    constexpr int M = 4096, N = 16384, E = 16, RP = 4 / G, MJ = 16 / G;      // RP workgroups per block, MJ values of m per thread
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double wsum[4 * G];
+    const int T = threadIdx.x, s = T >> 8, t = T & 255;
+    const int id = blockIdx.x, grp = id / (8 * RP), rp = (id / 8) % RP, unit = grp * 8 + id % 8;
+    if (unit >= nsplit * nch) return;
+    const int rbase = rp * G, r = rbase + s;
+    const int split = unit % nsplit, ch = unit / nsplit;
+    const int per = (nblk + nsplit - 1) / nsplit;
+    const int b0 = split * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    const typename S::Tw twf = FftRR<M, false, C>::load_at(tw, t);
+    double *xch = reinterpret_cast<double *>(smem);                     // exchange area [group][i][t] scalars
+    void *image = smem + (size_t)s * S::kLdsBytes;                      // this group's transform image
+    // e_j = exp(-2 pi i m_j / N), m_j = t + 256 (MJ s + j): e_0 and a step of 256
+    C e0, estep;
+    sincospi(-2.0 * (double)(t + 256 * MJ * s) / (double)N, &e0.y, &e0.x);
+    sincospi(-2.0 * 256.0 / (double)N, &estep.y, &estep.x);
+    const PanBand pb = band[ch];
+    double m2 = 0.0;
+    unsigned whole = 0, part = 0;           // bit i: bin i of this lane counts fully / with weight frac
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int bin = 4 * (t + NT * i) + r;
+        const int sb = bin >= N / 2 ? bin - N : bin;
+        if (pb.valid) {
+            if (sb >= pb.first && sb < pb.first + pb.nwhole) whole |= 1u << i;
+            else if (sb == pb.first + pb.nwhole) part |= 1u << i;
+        }
+    }
+    // the S-meter passband is a few bins wide: almost every wavefront holds none of them and skips that sum
+    const bool in_band = __ballot((whole | part) != 0) != 0ull;
+    // partial[split][ch][(bin + N/2) mod N]; bin = 4 (t + 256 i) + r: slot 4 t + r + 1024 ((i + 8) mod 16)
+    double *pp = partial + ((long long)split * nch + ch) * N + 4 * t + r;
+    for (int blk = b0; blk < b1; blk++) {
+        const C *x = in + (long long)ch * in_stride + (long long)blk * N + (t + 256 * MJ * s);
+        double oim[16];                     // imaginary parts of this thread's sixteen results, [j][group]: they travel second
+        double *xw = xch + (MJ * s) * 256 + t;                              // + (group * 16 + j) * 256
+        const double *xr = xch + (s * 16) * 256 + t;                        // + i * 256
+        C e = e0;
+        asm volatile("" : "+v"(e.x), "+v"(e.y));
+        __syncthreads();                    // the images are free: the previous block's transform has been read out
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            const C x0 = x[256 * j], x1 = x[256 * j + M], x2 = x[256 * j + 2 * M], x3 = x[256 * j + 3 * M];
+            // Hanning window 0.5 - 0.5 cos(2 pi n / N) at n = m + M q (quisk.c:6008): cos(a + pi q / 2) = cos a, -sin a, -cos a, sin a
+            // with e = (cos a, -sin a)
+            const double g0 = __builtin_fma(-0.5, e.x, 0.5), g2 = __builtin_fma(0.5, e.x, 0.5);
+            const double g1 = __builtin_fma(-0.5, e.y, 0.5), g3 = __builtin_fma(0.5, e.y, 0.5);
+            const C v0 = mk<double>(x0.x * g0, x0.y * g0), v1 = mk<double>(x1.x * g1, x1.y * g1);
+            const C v2 = mk<double>(x2.x * g2, x2.y * g2), v3 = mk<double>(x3.x * g3, x3.y * g3);
+            // sum_q W_4^(q r) v_q, r = 0 .. 3 (W_4 = -i), then W_N^(m r) = e^r
+            const C a0 = cadd(v0, v2), a1 = csub(v0, v2), c0 = cadd(v1, v3), c1 = csub(v1, v3);
+            const C e2 = cmul(e, e);
+            C o[G];
+            if (G == 4 || rbase == 0) {     // workgroup-uniform
+                o[0] = cadd(a0, c0);
+                o[1] = cmul(mk<double>(a1.x + c1.y, a1.y - c1.x), e);           // a1 - i c1
+            }
+            if (G == 4 || rbase == 2) {
+                o[G - 2] = cmul(csub(a0, c0), e2);
+                o[G - 1] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));        // a1 + i c1
+            }
+            // group g takes element i = MJ s + j of its transform from this thread: real parts now
+#pragma unroll
+            for (int g = 0; g < G; g++) { xw[(g * 16 + j) * 256] = o[g].x; oim[G * j + g] = o[g].y; }
+            e = cmul(e, estep);
+            // one j at a time -- four loads in flight, sixteen values kept: all 16 loads at once (latency paid once) cost
+            // 30 more spilled registers and measured slower (0.67 against 0.65 ms on config 3)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        C u[E];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) u[i].x = xr[i * 256];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MJ; j++)
+#pragma unroll
+            for (int g = 0; g < G; g++) xw[(g * 16 + j) * 256] = oim[G * j + g];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) u[i].y = xr[i * 256];
+        __syncthreads();                    // everybody has taken its elements: the images may be written
+        // (the pass twiddles' powers are loop invariant: left alone, the compiler computes all 28 of them once, ahead of the
+        // block loop, and spills them)
+        typename S::Tw twb = twf;
+        asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
+        S::run_at(u, image, twb, t);
+        double *ppb = pp;
+        asm volatile("" : "+v"(ppb));       // (likewise the sixteen slot addresses)
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
+            double *slot = ppb + 1024 * ((i + 8) & 15);
+            const double prev = blk == b0 ? 0.0 : *slot;
+            *slot = prev + sqrt_pow(pw2);   // cabs(): no overflow / underflow concern at +-2^31 * N full scale
+            if (in_band) m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // S-meter partial: lanes -> wave -> group of four waves (one r), fixed order, in the layout of pan_spectrum_kernel
+    for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
+    if ((T & 63) == 0) wsum[T >> 6] = m2;
+    __syncthreads();
+    if (t == 0) {
+        double sm = 0.0;
+        for (int k = 0; k < 4; k++) sm += wsum[4 * s + k];
+        partial_m2[((long long)split * nch + ch) * 4 + r] = sm;
     }
 }
 
@@ -402,6 +548,13 @@ struct Pan {
     }
     template <int MM> void launch(const double2 *p, long long src_stride, int nblk, int nsplit)
     {
+        if (MM == 4096 && R == 4) {     // fft_size 16384: the one-read form
+            constexpr int G = QH_PAN16K_GROUPS;
+            const int units = nsplit * nch, groups = (units + 7) / 8;
+            hipLaunchKernelGGL((pan16k_kernel<G>), dim3((unsigned)(groups * 8 * (4 / G))), dim3(256 * G), (size_t)pan16k_lds<G>(), stream, p,
+                               src_stride, nblk, nsplit, tw, partial, partial_m2, band, nch);
+            return;
+        }
         if (R == 1) launch2<MM, 1>(p, src_stride, nblk, nsplit);
         else if (R == 2) launch2<MM, 2>(p, src_stride, nblk, nsplit);
         else launch2<MM, 4>(p, src_stride, nblk, nsplit);
@@ -545,6 +698,9 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
     QH_PAN_ATTR(2048, 1); QH_PAN_ATTR(2048, 2); QH_PAN_ATTR(2048, 4);
     QH_PAN_ATTR(4096, 1); QH_PAN_ATTR(4096, 2); QH_PAN_ATTR(4096, 4);
 #undef QH_PAN_ATTR
+    if (e == hipSuccess && M == 4096 && R == 4)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pan16k_kernel<QH_PAN16K_GROUPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                pan16k_lds<QH_PAN16K_GROUPS>());
     if (e != hipSuccess) return fail("hipFuncSetAttribute");
     return h;
 }
