@@ -24,9 +24,37 @@ namespace {
 
 constexpr int kMaxChannels = 32;    // wdsp/comm.h:117
 constexpr int kDspMult = 2;         // wdsp/comm.h:118
-constexpr double kPi = 3.1415926535897932;
 
-enum { SL_BEGIN = 0, SL_DELAYUP, SL_UPSLEW, SL_ON, SL_DELAYDOWN, SL_DOWNSLEW, SL_ZERO, SL_OFF };  // iobuffs.c:36-46
+// The up / down slews of wdsp/iobuffs.c:47-160,226-300 are gain ENVELOPES over a sample count here, not the reference's
+// per-sample state machines: g(p) with p = 0 at the trigger (up: the first non-zero input sample after the channel is
+// switched on, which itself is muted; down: the first output sample after SetChannelState(ch, 0, 0), which still passes).
+//   up:   0 for p <= lead,  0.5 (1 - cos(pi k / ramp)) for k = p - lead - 1 = 0 .. ramp,  1 beyond
+//   down: 1 for p <= lead,  0.5 (1 + cos(pi k / ramp)) for k = 0 .. ramp,                 0 beyond
+// lead = delay + 1 when there is a delay (the reference's counters run down to zero inclusive), else 0.  The host keeps
+// the positions; the multiplication is a small kernel on the block that is on its way to / from the GPU anyway.
+struct Slew {
+    int delay = 0, ramp = 0;        // samples
+    bool armed = false;             // upflag / downflag
+    long long p = -1;               // up: envelope position of stream sample `origin`; down: position of the next output sample
+    long long origin = 0;
+    int lead() const { return delay > 0 ? delay + 1 : 0; }
+    long long level_from() const { return (long long)lead() + (ramp > 0 ? ramp + 1 : 0) + 1; }     // first position at the end level
+    void reset() { armed = false; p = -1; origin = 0; }
+};
+
+__global__ void slew_kernel(double2 *buf, int n, long long p0, int lead, int ramp, int rising)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long p = p0 + i;
+    double g;
+    if (p <= lead) g = rising ? 0.0 : 1.0;
+    else if (ramp > 0 && p - lead - 1 <= ramp) {
+        const double c = cospi((double)(p - lead - 1) / (double)ramp);
+        g = rising ? 0.5 * (1.0 - c) : 0.5 * (1.0 + c);
+    } else g = rising ? 1.0 : 0.0;
+    buf[i].x *= g; buf[i].y *= g;
+}
 
 struct Chan {
     bool open = false, emnr_tables = false;
@@ -40,10 +68,8 @@ struct Chan {
     std::vector<double> r1, r2, outbuff;
     int r1_inidx = 0, r1_outidx = 0, r1_unqueued = 0, r2_inidx = 0, r2_outidx = 0, r2_havesamps = 0, r2_unqueued = 0;
     int sem_buffready = 0, sem_outready = 0;
-    // slews
-    int ustate = SL_BEGIN, dstate = SL_BEGIN, ucount = 0, dcount = 0, ndelup = 0, ndeldown = 0, ntup = 0, ntdown = 0;
-    int upflag = 0, downflag = 0;
-    std::vector<double> cup, cdown;
+    Slew up, down;
+    long long in_count = 0, dsp_count = 0;          // input samples written to r1 / taken out of it since the rings were reset
     // staging: pinned host + device block buffers
     double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
     // the DSP iteration replayed from captured hipGraphs: one per parity of the engine's ping-pong state buffers
@@ -62,26 +88,14 @@ bool valid(int channel)
     return true;
 }
 
-void create_slews(Chan &c)          // wdsp/iobuffs.c:47-82
+void create_slews(Chan &c)          // the sample counts of wdsp/iobuffs.c:47-68: up-slew at the input rate, down-slew at the output rate
 {
-    c.ustate = SL_BEGIN; c.dstate = SL_BEGIN; c.ucount = 0; c.dcount = 0;
-    c.ndelup = (int)(c.tdelayup * c.in_rate);
-    c.ndeldown = (int)(c.tdelaydown * c.out_rate);
-    c.ntup = (int)(c.tslewup * c.in_rate);
-    c.ntdown = (int)(c.tslewdown * c.out_rate);
-    c.cup.assign((size_t)c.ntup + 1, 0.0);
-    c.cdown.assign((size_t)c.ntdown + 1, 0.0);
-    double delta = kPi / (double)c.ntup, theta = 0.0;
-    for (int i = 0; i <= c.ntup; i++) { c.cup[(size_t)i] = 0.5 * (1.0 - std::cos(theta)); theta += delta; }
-    delta = kPi / (double)c.ntdown; theta = 0.0;
-    for (int i = 0; i <= c.ntdown; i++) { c.cdown[(size_t)i] = 0.5 * (1.0 + std::cos(theta)); theta += delta; }
-    c.upflag = 0; c.downflag = 0;
+    c.up = Slew(); c.down = Slew();
+    c.up.delay = (int)(c.tdelayup * c.in_rate); c.up.ramp = (int)(c.tslewup * c.in_rate);
+    c.down.delay = (int)(c.tdelaydown * c.out_rate); c.down.ramp = (int)(c.tslewdown * c.out_rate);
 }
 
-void flush_slews(Chan &c)           // wdsp/iobuffs.c:90-98
-{
-    c.ustate = SL_BEGIN; c.dstate = SL_BEGIN; c.ucount = 0; c.dcount = 0; c.upflag = 0; c.downflag = 0;
-}
+void flush_slews(Chan &c) { c.up.reset(); c.down.reset(); }
 
 void init_rings(Chan &c)            // create_iobuffs / flush_iobuffs, wdsp/iobuffs.c:384-455
 {
@@ -96,76 +110,16 @@ void init_rings(Chan &c)            // create_iobuffs / flush_iobuffs, wdsp/iobu
     c.r2_unqueued = c.r2_havesamps - n * c.out_size;
     c.sem_buffready = 0;
     c.sem_outready = n;
+    c.in_count = 0; c.dsp_count = 0;
 }
 
-void upslew0(Chan &c, const double *pin)    // wdsp/iobuffs.c:98-160
+// Multiplies the n samples at `buf` (device-visible) by the envelope, the first one at position p0; on the engine's stream.
+int apply_slew(Chan &c, const Slew &sl, double *buf, int n, long long p0, int rising)
 {
-    double *pout = c.r1.data() + 2 * c.r1_inidx;
-    for (int i = 0; i < c.in_size; i++) {
-        const double I = pin[2 * i], Q = pin[2 * i + 1];
-        switch (c.ustate) {
-        case SL_BEGIN:
-            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
-            if (I != 0.0 || Q != 0.0) {
-                if (c.ndelup > 0) { c.ustate = SL_DELAYUP; c.ucount = c.ndelup; }
-                else if (c.ntup > 0) { c.ustate = SL_UPSLEW; c.ucount = c.ntup; }
-                else c.ustate = SL_ON;
-            }
-            break;
-        case SL_DELAYUP:
-            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
-            if (c.ucount-- == 0) {
-                if (c.ntup > 0) { c.ustate = SL_UPSLEW; c.ucount = c.ntup; }
-                else c.ustate = SL_ON;
-            }
-            break;
-        case SL_UPSLEW:
-            pout[2 * i] = I * c.cup[(size_t)(c.ntup - c.ucount)];
-            pout[2 * i + 1] = Q * c.cup[(size_t)(c.ntup - c.ucount)];
-            if (c.ucount-- == 0) c.ustate = SL_ON;
-            break;
-        case SL_ON:
-            pout[2 * i] = I; pout[2 * i + 1] = Q;
-            if (i == c.in_size - 1) { c.ustate = SL_BEGIN; c.upflag = 0; }
-            break;
-        }
-    }
-}
-
-void downslew0(Chan &c, double *pout)       // wdsp/iobuffs.c:226-300
-{
-    const double *pin = c.r2.data() + 2 * c.r2_outidx;
-    for (int i = 0; i < c.out_size; i++) {
-        const double I = pin[2 * i], Q = pin[2 * i + 1];
-        switch (c.dstate) {
-        case SL_BEGIN:
-            pout[2 * i] = I; pout[2 * i + 1] = Q;
-            if (c.ndeldown > 0) { c.dstate = SL_DELAYDOWN; c.dcount = c.ndeldown; }
-            else if (c.ntdown > 0) { c.dstate = SL_DOWNSLEW; c.dcount = c.ntdown; }
-            else { c.dstate = SL_ZERO; c.dcount = c.out_size; }
-            break;
-        case SL_DELAYDOWN:
-            pout[2 * i] = I; pout[2 * i + 1] = Q;
-            if (c.dcount-- == 0) {
-                if (c.ntdown > 0) { c.dstate = SL_DOWNSLEW; c.dcount = c.ntdown; }
-                else { c.dstate = SL_ZERO; c.dcount = c.out_size; }
-            }
-            break;
-        case SL_DOWNSLEW:
-            pout[2 * i] = I * c.cdown[(size_t)(c.ntdown - c.dcount)];
-            pout[2 * i + 1] = Q * c.cdown[(size_t)(c.ntdown - c.dcount)];
-            if (c.dcount-- == 0) { c.dstate = SL_ZERO; c.dcount = c.out_size; }
-            break;
-        case SL_ZERO:
-            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
-            if (c.dcount-- == 0) c.dstate = SL_OFF;
-            break;
-        case SL_OFF:
-            pout[2 * i] = 0.0; pout[2 * i + 1] = 0.0;
-            if (i == c.out_size - 1) { c.dstate = SL_BEGIN; c.downflag = 0; }
-            break;
-        }
-    }
+    hipStream_t st = (hipStream_t)qh_rxa_stream(c.eng);
+    hipLaunchKernelGGL(slew_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<double2 *>(buf), n, p0, sl.lead(),
+                       sl.ramp, rising);
+    return hipGetLastError() == hipSuccess ? QH_OK : qh::set_error(QH_ERR_HIP, "slew kernel launch failed");
 }
 
 long long g_graph_launches = 0;      // blocks replayed by engines that have since been closed
@@ -183,6 +137,11 @@ int dsp_iteration(Chan &c)
     }
     std::memcpy(c.h_in, c.r1.data() + 2 * c.r1_outidx, (size_t)c.r1_outsize * 2 * sizeof(double));
     if ((c.r1_outidx += c.r1_outsize) == c.r1_active) c.r1_outidx = 0;
+    // the up-slew: this block holds stream samples dsp_count ...; while any of them sits below the envelope's end level the
+    // block takes the envelope on its way in (before the trigger the stream is zeros: nothing to do)
+    const long long blk0 = c.dsp_count;
+    c.dsp_count += c.r1_outsize;
+    const bool slew_in = c.up.p >= 0 && blk0 - c.up.origin + c.up.p < c.up.level_from();
     // xrxa: one block through the engine.  The kernels read the input block from and write the output block to the
     // pinned staging buffers directly (a few KB over PCIe: no copy-engine hop); QH_WDSP_IO=copy stages both through
     // device buffers with two async copies instead.  The launch sequence itself is replayed from hipGraphs by the
@@ -193,10 +152,12 @@ int dsp_iteration(Chan &c)
         hipStream_t s = (hipStream_t)qh_rxa_stream(c.eng);
         if (hipMemcpyAsync(c.d_in, c.h_in, (size_t)c.dsp_insize * 2 * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess)
             return qh::set_error(QH_ERR_HIP, "fexchange0: host to device copy failed");
+        if (slew_in) if (int e = apply_slew(c, c.up, c.d_in, c.dsp_insize, blk0 - c.up.origin + c.up.p, 1)) return e;
         rc = qh_rxa_process(c.eng, c.d_in, c.dsp_insize, c.d_out, c.dsp_outsize, 1);
         if (rc == QH_OK && hipMemcpyAsync(c.h_out, c.d_out, (size_t)c.dsp_outsize * 2 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
             return qh::set_error(QH_ERR_HIP, "fexchange0: device to host copy failed");
     } else {
+        if (slew_in) if (int e = apply_slew(c, c.up, c.h_in, c.dsp_insize, blk0 - c.up.origin + c.up.p, 1)) return e;
         rc = qh_rxa_process(c.eng, c.h_in, c.dsp_insize, c.h_out, c.dsp_outsize, 1);
     }
     if (rc) return rc;
@@ -289,7 +250,7 @@ void OpenChannel(int channel, int in_size, int dsp_size, int input_samplerate, i
     }
     c.exchange = 0;
     c.open = true;
-    if (state) { c.upflag = 1; c.exchange = 1; }    // wdsp/channel.c:92-98
+    if (state) { c.up.armed = true; c.exchange = 1; }      // wdsp/channel.c:92-98
     (void)qh_rxa_enable_meters(c.eng, 1);           // WDSP's meters always run (RXA.c:69-82)
     // the per-block sequence is launch-bound: replay it from hipGraphs (QH_WDSP_NO_GRAPHS=1 keeps plain launches)
     if (!std::getenv("QH_WDSP_NO_GRAPHS")) (void)qh_rxa_set_graph_replay(c.eng, 1);
@@ -323,10 +284,10 @@ int SetChannelState(int channel, int state, int dmode)
             // fexchange0 calls to finish the down-slew; when none arrive (the single-threaded use Quisk
             // makes of it, quisk_wdsp.py:117-139) it times out: exchange off, no flush.  That outcome is
             // produced here at once.
-            if (dmode) { c.exchange = 0; c.downflag = 0; }
-            else c.downflag = 1;
+            if (dmode) { c.exchange = 0; c.down.reset(); }
+            else { c.down.armed = true; c.down.p = 0; }
         } else {
-            c.upflag = 1;
+            c.up.armed = true; c.up.p = -1;
             c.exchange = 1;
         }
     }
@@ -341,8 +302,17 @@ void fexchange0(int channel, double *in, double *out, int *error)
     if (!L.c) { *error = -1; return; }
     Chan &c = *L.c;
     if (!c.exchange) return;                        // wdsp/iobuffs.c:471: `out` is left untouched
-    if (c.upflag) upslew0(c, in);
-    else std::memcpy(c.r1.data() + 2 * c.r1_inidx, in, (size_t)c.in_size * 2 * sizeof(double));
+    std::memcpy(c.r1.data() + 2 * c.r1_inidx, in, (size_t)c.in_size * 2 * sizeof(double));
+    if (c.up.armed) {
+        // iobuffs.c:98-160 as bookkeeping: the envelope is triggered by the first non-zero sample; the flag drops at the end of
+        // the first call whose last sample has reached the end level
+        if (c.up.p < 0) {
+            for (int i = 0; i < c.in_size; i++)
+                if (in[2 * i] != 0.0 || in[2 * i + 1] != 0.0) { c.up.origin = c.in_count + i; c.up.p = 0; break; }
+        }
+        if (c.up.p >= 0 && c.in_count + c.in_size - 1 - c.up.origin + c.up.p >= c.up.level_from()) c.up.armed = false;
+    }
+    c.in_count += c.in_size;
     if ((c.r1_unqueued += c.in_size) >= c.r1_outsize) {
         const int n = c.r1_unqueued / c.r1_outsize;
         c.sem_buffready += n;
@@ -360,17 +330,30 @@ void fexchange0(int channel, double *in, double *out, int *error)
     if (c.bfo) { if (c.sem_outready > 0) { c.sem_outready--; ready = 1; } }
     else ready = doit;
     if (ready) {
-        if (c.downflag) {
-            downslew0(c, out);
-            if (!c.downflag) {                      // slew finished: stop and flush, wdsp/iobuffs.c:499-503
+        std::memcpy(out, c.r2.data() + 2 * c.r2_outidx, (size_t)c.out_size * 2 * sizeof(double));
+        if (c.down.armed) {
+            // iobuffs.c:226-300: this call's samples sit at envelope positions p ... p + out_size - 1; behind the ramp come
+            // out_size + 1 zeros, and the call that ends beyond those stops the channel and flushes it (iobuffs.c:499-503)
+            if (c.down.p < c.down.level_from()) {
+                for (int o = 0; o < c.out_size; o += c.dsp_outsize) {       // through the pinned block buffer, a DSP block at a time
+                    const int m = c.out_size - o < c.dsp_outsize ? c.out_size - o : c.dsp_outsize;
+                    std::memcpy(c.h_out, out + 2 * (size_t)o, (size_t)m * 2 * sizeof(double));
+                    int rc = apply_slew(c, c.down, c.h_out, m, c.down.p + o, 0);
+                    if (!rc) rc = qh_rxa_synchronize(c.eng);
+                    if (rc) { g_status = rc; *error = -1; return; }
+                    std::memcpy(out + 2 * (size_t)o, c.h_out, (size_t)m * 2 * sizeof(double));
+                }
+            } else {
+                std::memset(out, 0, (size_t)c.out_size * 2 * sizeof(double));
+            }
+            c.down.p += c.out_size;
+            if (c.down.p - 1 >= c.down.level_from() + c.out_size + 1) {
                 c.exchange = 0;
                 init_rings(c);
                 flush_slews(c);
                 (void)qh_rxa_flush(c.eng);
                 return;
             }
-        } else {
-            std::memcpy(out, c.r2.data() + 2 * c.r2_outidx, (size_t)c.out_size * 2 * sizeof(double));
         }
     } else {
         std::memset(out, 0, (size_t)c.out_size * 2 * sizeof(double));
