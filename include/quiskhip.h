@@ -448,6 +448,29 @@ int qh_unpack_iq_host(int device, const void *h_src, long long src_bytes, const 
 int qh_rxa_process_packed_host(qh_rxa *e, const void *h_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
                                double *h_out, long long out_stride, int nblk);
 
+/* ------------------------------------------------------------------ 7b. audio egress */
+/* The narrowing Quisk's sound back ends apply to the complex doubles a receive chain returns, done in the store of the
+ * chain's last kernel so that 4 (Int16 stereo) instead of 16 bytes per output sample cross HBM:
+ *   QH_AUDIO_I16   (short)(int)(volume * x / 65536)            sound_alsa.c:344-348, sound_pulseaudio.c:694-695
+ *   QH_AUDIO_I24   three low bytes (LE) of (int)(volume * x / 256)                       sound_alsa.c:360-375
+ *   QH_AUDIO_I32   (int)(volume * x)                           sound_alsa.c:386-390
+ *   QH_AUDIO_F32   (float)(volume * x / CLIP32)                sound_pulseaudio.c:684-685, sound_portaudio.c:120-123
+ * x = real / imaginary part at Quisk's +-2^31 scale.  prescale multiplies first (0 or 1: none): WDSP-scale chains (+-1.0)
+ * pass 2147483647.0, the factor of quisk_wdsp.c:67.  A frame has num_channels slots; the real part goes to slot channel_I,
+ * the imaginary part to slot channel_Q (struct sound_dev, quisk.h).  (int) truncates toward zero; it saturates where C
+ * leaves the conversion undefined.  Bit-exact with the reference's expression for every in-range value. */
+enum { QH_AUDIO_I16 = 1, QH_AUDIO_I24 = 2, QH_AUDIO_I32 = 3, QH_AUDIO_F32 = 4 };
+typedef struct qh_audio_format {
+    int kind, num_channels, channel_I, channel_Q;
+    double volume, prescale;
+} qh_audio_format;
+/* qh_rxa_process with audio frames as output: d_out [nch][out_stride_bytes], nblk * dsp_outsize frames per channel. */
+int qh_rxa_process_audio(qh_rxa *e, const double *d_in, long long in_stride, void *d_out, long long out_stride_bytes, int nblk,
+                         const qh_audio_format *fmt);
+/* Stand-alone: d_src [nch][src_stride] complex double on the device -> frames. */
+int qh_audio_pack(int device, void *stream, const double *d_src, long long src_stride, int nch, int n, const qh_audio_format *fmt,
+                  void *d_dst, long long dst_stride_bytes);
+
 /* ------------------------------------------------------------------ 8. Quisk's audio AGC */
 /* process_agc (quisk.c:2162-2287) for `nch` streams of complex double at `sample_rate` (the playback rate):
  * 15 ms look-ahead FIFO, gain ramp on overload, exponential release towards min(release gain, headroom).

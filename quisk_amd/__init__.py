@@ -5,7 +5,7 @@ this package is the thin Python host side that mirrors the reference's own Pytho
 (quisk_wdsp.py) on top of it.  There is no CPU fallback: every compute call needs a HIP device.
 """
 from .lib import load, QuiskHipError          # noqa: F401
-from .rxa import RxaEngine                    # noqa: F401
+from .rxa import RxaEngine, AudioFormat       # noqa: F401
 from .fir import FirBank, HalfBandCascade, RationalFir, hb45_taps           # noqa: F401
 from .pan import Panadapter, Bandscope, waterfall_rows                   # noqa: F401
 from .qrx import QuiskRxBank, QuiskAgc, NoiseBlanker                  # noqa: F401
@@ -13,4 +13,4 @@ from . import ingest                          # noqa: F401
 from . import quiskapi                        # noqa: F401
 from .ingest import IqFormat                  # noqa: F401
 
-__all__ = ["load", "QuiskHipError", "RxaEngine", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "Bandscope", "waterfall_rows", "QuiskRxBank", "QuiskAgc", "NoiseBlanker", "ingest", "IqFormat", "quiskapi"]
+__all__ = ["load", "QuiskHipError", "RxaEngine", "AudioFormat", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "Bandscope", "waterfall_rows", "QuiskRxBank", "QuiskAgc", "NoiseBlanker", "ingest", "IqFormat", "quiskapi"]

@@ -243,9 +243,14 @@ struct Engine {
                   long long n_in, long long n_mid);
     const unsigned char *pk_src = nullptr;      // set for the duration of a qh_rxa_process_packed call
     PackedFmt pk{};
+    EgressFmt eg{};                             // set (kind != 0) for the duration of a qh_rxa_process_audio call
+    double2 *abuf = nullptr;                    // complex-double staging of an audio call whose last stage cannot narrow in its store
+    long long abuf_cap = 0;
+    int ensure_abuf(long long n);
+    void pack_audio(const double2 *src, long long src_stride, long long n);
     void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                  const int *list, int nlist, bool meter = false);
+                  const int *list, int nlist, bool meter = false, bool egress = false);
     int ensure_buffers(long long n_mid);
     int ensure_meter_partials(long long n_mid, int lout);
     int emnr_alloc();
@@ -263,7 +268,7 @@ Engine::~Engine()
     if (stream) (void)hipStreamSynchronize(stream);
     drop_graphs();
     if (rsmpout) qh_rat_destroy(rsmpout);
-    (void)hipFree(obuf);
+    (void)hipFree(obuf); (void)hipFree(abuf);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
@@ -367,6 +372,7 @@ int Engine::init()
 #define QH_SET_LDS(D, ...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, 4096, D, __VA_ARGS__>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D>())))
     QH_SET_LDS(1, false); QH_SET_LDS(1, false, false, true);
+    QH_SET_LDS(1, false, false, false, false, true); QH_SET_LDS(1, false, false, true, false, true);
     QH_SET_LDS(2, false, false, false, true); QH_SET_LDS(4, false, false, false, true); QH_SET_LDS(8, false, false, false, true);
     QH_SET_LDS(2, false, true, false, true); QH_SET_LDS(4, false, true, false, true); QH_SET_LDS(8, false, true, false, true);
 #undef QH_SET_LDS
@@ -1128,6 +1134,25 @@ int Engine::ensure_meter_partials(long long n_mid, int lout)
     return QH_OK;
 }
 
+int Engine::ensure_abuf(long long n)
+{
+    if (n <= abuf_cap) return QH_OK;
+    QH_HIP(hipStreamSynchronize(stream));
+    drop_graphs(); epoch++;
+    if (abuf) { QH_HIP(hipFree(abuf)); dev_bytes -= abuf_cap * nch * (long long)sizeof(double2); abuf = nullptr; }
+    QH_HIP(dev_alloc(&abuf, (size_t)nch * (size_t)n));
+    abuf_cap = n;
+    dev_bytes += n * nch * (long long)sizeof(double2);
+    return QH_OK;
+}
+
+void Engine::pack_audio(const double2 *src, long long src_stride, long long n)
+{
+    const long long per = (n + 255) / 256;
+    hipLaunchKernelGGL(egress_pack_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)nch), dim3(256), 0, stream, src, src_stride,
+                       (int)n, eg);
+}
+
 void Engine::tick(int cat)
 {
     if (!timing) return;
@@ -1142,13 +1167,13 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false>
+template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, kNfft, D>();
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED, METER, OUTMIX>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED, METER, OUTMIX, EGRESS>), grid, block, lds, s, a);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------
@@ -1224,7 +1249,7 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
 // one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
 void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                      const int *list, int nlist, bool meter)
+                      const int *list, int nlist, bool meter, bool egress)
 {
     const int Lout = kNfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
@@ -1238,11 +1263,13 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     a.chan_list = list;
     a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
     tick(1);
-    if (meter) {
-        a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w;
-        launch_osfir<1, false, false, true>(a, ntiles, list ? nlist : nch, stream);
-    } else
-        launch_osfir<1, false>(a, ntiles, list ? nlist : nch, stream);
+    if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
+    if (egress) a.eg = eg;
+    const int nl = list ? nlist : nch;
+    if (meter && egress) launch_osfir<1, false, false, true, false, true>(a, ntiles, nl, stream);
+    else if (meter) launch_osfir<1, false, false, true>(a, ntiles, nl, stream);
+    else if (egress) launch_osfir<1, false, false, false, false, true>(a, ntiles, nl, stream);
+    else launch_osfir<1, false>(a, ntiles, nl, stream);
     tick(2);
     dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
     hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
@@ -1258,6 +1285,18 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
     if (!rsmpout) return process_chain(d_in, in_stride, d_out, out_stride, nblk);
     if (nblk <= 0) return QH_OK;
     QH_HIP(hipSetDevice(device));
+    if (eg.kind) {      // audio frames behind the output resampler: resample into the staging rows, then narrow
+        const long long n_out = (long long)nblk * dsp_outsize;
+        if (int rc = ensure_abuf(n_out)) return rc;
+        const EgressFmt keep = eg;
+        eg = EgressFmt{};
+        const int rc = process(d_in, in_stride, reinterpret_cast<double *>(abuf), abuf_cap, nblk);
+        eg = keep;
+        if (rc) return rc;
+        pack_audio(abuf, abuf_cap, n_out);
+        QH_HIP(hipGetLastError());
+        return QH_OK;
+    }
     const long long n_mid = (long long)nblk * dsp_size;
     if (n_mid > obuf_cap) {
         QH_HIP(hipStreamSynchronize(stream));
@@ -1311,6 +1350,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     double2 *out = reinterpret_cast<double2 *>(d_out);
     const int P = meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
 
+    // audio egress (qh_rxa_process_audio): the narrowing rides in the store of the last kernel when that is an overlap-save
+    // band stage or the per-mode path's output pass; other endings write complex doubles to the staging rows and narrow after
+    const bool eg_fused = eg.kind && (mixed ? n_amsq == 0 : (any_nbp || any_bp1));
+    if (eg.kind && !eg_fused) {
+        if (int rc = ensure_abuf(n_mid)) return rc;
+        out = abuf; out_stride = abuf_cap;
+    }
     if (!mixed) {
         // ---- every channel is a linear chain: the epilogue rides on the last stage, no extra pass
         const int nstage = 1 + (any_nbp ? 1 : 0) + (any_bp1 ? 1 : 0);
@@ -1337,12 +1383,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             if (meters_fused) if (int rc = ensure_meter_partials(n_mid, kNfft - P)) return rc;
             run_band(cur, cur_stride, dst, dst_stride, stage == nstage - 1 ? epi : nullptr, n_mid,
                      f == 0 ? mask_nbp : mask_bp1, kNfft, f == 0 ? hist_nbp : hist_bp1, f == 0 ? cur_nbp : cur_bp1, P,
-                     nullptr, 0, meters_fused);
+                     nullptr, 0, meters_fused, eg_fused && stage == nstage - 1);
             cur = dst; cur_stride = dst_stride; stage++;
         }
         if (meters_fused)
             hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch, 3), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
                                m_part_cap, (int)(n_mid / 64), dsp_size / 64, (kNfft - P) / 64, m_adc, m_s, m_agc, m_prm, (const double *)m_g2);
+        if (eg.kind && !eg_fused) pack_audio(out, out_stride, n_mid);
         tick(3);
         QH_HIP(hipGetLastError());
         return QH_OK;
@@ -1472,14 +1519,24 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // xwcpagc mode 0 + xpanel
     long long per = (n_mid + NT - 1) / NT;
     const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
+    if (eg_fused) {
+        if (n_plain) hipLaunchKernelGGL((pointwise_kernel<double, false, true>), dim3(gx, (unsigned)n_plain), dim3(NT), 0, stream, cur,
+                                        buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
+                                        (const unsigned long long *)nullptr, epi, list_plain, eg);
+        if (n_bp1) hipLaunchKernelGGL((pointwise_kernel<double, false, true>), dim3(gx, (unsigned)n_bp1), dim3(NT), 0, stream, other,
+                                      buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
+                                      (const unsigned long long *)nullptr, epi, list_bp1, eg);
+    } else {
     if (n_plain) hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3(gx, (unsigned)n_plain), dim3(NT), 0, stream, cur,
                                     buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
                                     (const unsigned long long *)nullptr, epi, list_plain);
     if (n_bp1) hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3(gx, (unsigned)n_bp1), dim3(NT), 0, stream, other,
                                   buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
                                   (const unsigned long long *)nullptr, epi, list_bp1);
+    }
     if (n_amsq) hipLaunchKernelGGL(amsq_apply_kernel, dim3((unsigned)n_amsq), dim3(64), 0, stream, out, out_stride, (int)n_mid, list_amsq,
                                    amsq_mag, amsq_mag_cap, amsq_prm, amsq_state, amsq_cup, amsq_cdown);       // xamsq, RXA.c:596
+    if (eg.kind && !eg_fused) pack_audio(out, out_stride, n_mid);
     tick(3);
     QH_HIP(hipGetLastError());
     return QH_OK;
@@ -1938,6 +1995,53 @@ int qh_rxa_process(qh_rxa *h, const double *d_in, long long in_stride, double *d
         return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
     if (h->e.graph_on) return h->e.process_replayed(d_in, in_stride, d_out, out_stride, nblk);
     return h->e.process(d_in, in_stride, d_out, out_stride, nblk);
+}
+
+// ---- audio egress ---------------------------------------------------------------------------------------------------
+static int make_egress(const qh_audio_format *fmt, void *d_out, long long out_stride_bytes, long long frames, EgressFmt *f)
+{
+    if (!fmt || !d_out) return set_error(QH_ERR_INVALID, "null audio format or buffer");
+    if (fmt->kind < QH_AUDIO_I16 || fmt->kind > QH_AUDIO_F32) return set_error(QH_ERR_INVALID, "audio kind %d", fmt->kind);
+    if (fmt->num_channels < 1 || fmt->channel_I < 0 || fmt->channel_Q < 0 || fmt->channel_I >= fmt->num_channels ||
+        fmt->channel_Q >= fmt->num_channels)
+        return set_error(QH_ERR_INVALID, "audio channel slots outside the frame");
+    const int bytes = fmt->kind == QH_AUDIO_I16 ? 2 : fmt->kind == QH_AUDIO_I24 ? 3 : 4;
+    if (out_stride_bytes < frames * fmt->num_channels * bytes) return set_error(QH_ERR_INVALID, "audio row stride shorter than the frames");
+    if (fmt->kind != QH_AUDIO_I24 && out_stride_bytes % bytes) return set_error(QH_ERR_INVALID, "audio row stride not a multiple of the sample size");
+    f->kind = fmt->kind; f->nchan = fmt->num_channels; f->ch_i = fmt->channel_I; f->ch_q = fmt->channel_Q;
+    f->volume = fmt->volume; f->prescale = fmt->prescale == 0.0 ? 1.0 : fmt->prescale;
+    f->out = static_cast<unsigned char *>(d_out); f->stride = out_stride_bytes;
+    return QH_OK;
+}
+
+int qh_rxa_process_audio(qh_rxa *h, const double *d_in, long long in_stride, void *d_out, long long out_stride_bytes, int nblk,
+                         const qh_audio_format *fmt)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    if (!d_in) return set_error(QH_ERR_INVALID, "null buffer");
+    if (in_stride < (long long)nblk * h->e.dsp_insize) return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
+    EgressFmt f{};
+    if (int rc = make_egress(fmt, d_out, out_stride_bytes, (long long)nblk * h->e.dsp_outsize, &f)) return rc;
+    h->e.eg = f;
+    const int rc = h->e.process(d_in, in_stride, nullptr, 0, nblk);
+    h->e.eg = EgressFmt{};
+    return rc;
+}
+
+int qh_audio_pack(int device, void *stream, const double *d_src, long long src_stride, int nch, int n, const qh_audio_format *fmt,
+                  void *d_dst, long long dst_stride_bytes)
+{
+    if (!d_src || nch <= 0 || n < 0) return set_error(QH_ERR_INVALID, "qh_audio_pack: bad arguments");
+    if (qh_device_count() <= device || device < 0) return set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
+    EgressFmt f{};
+    if (int rc = make_egress(fmt, d_dst, dst_stride_bytes, n, &f)) return rc;
+    if (n == 0) return QH_OK;
+    QH_HIP(hipSetDevice(device));
+    const long long per = ((long long)n + 255) / 256;
+    hipLaunchKernelGGL(egress_pack_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)nch), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const double2 *>(d_src), src_stride, n, f);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
 }
 
 int qh_rxa_set_graph_replay(qh_rxa *h, int on)

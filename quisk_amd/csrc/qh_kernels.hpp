@@ -129,12 +129,12 @@ __global__ __launch_bounds__(NT) void front_mask_kernel(const double *taps, int 
 
 // Elementwise stage used when a chain has no FIR stage to fuse into:
 //   out = epi * (in * nco)      (xshift, wdsp/shift.c:60-85; xwcpagc mode 0 + xpanel)
-template <typename T, bool MIX>
+template <typename T, bool MIX, bool EGRESS = false>
 __global__ __launch_bounds__(NT) void pointwise_kernel(const cplx<T> *in, long long in_stride, cplx<T> *out,
                                                        long long out_stride, int n,
                                                        const unsigned long long *nco_phase,
                                                        const unsigned long long *nco_dphase,
-                                                       const EpiParam *epi, const int *chan_list = nullptr)
+                                                       const EpiParam *epi, const int *chan_list = nullptr, EgressFmt eg = EgressFmt{})
 {
     using C = cplx<T>;
     const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(NT) void pointwise_kernel(const cplx<T> *in, long l
         C o;
         o.x = (T)ep.a * v.x + (T)ep.b * v.y;
         o.y = (T)ep.c * v.x + (T)ep.d * v.y;
-        out[(long long)ch * out_stride + g] = o;
+        if constexpr (EGRESS) egress_store(eg, ch, g, (double)o.x, (double)o.y);
+        else out[(long long)ch * out_stride + g] = o;
     }
 }
 

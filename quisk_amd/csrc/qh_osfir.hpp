@@ -32,6 +32,7 @@
 #pragma once
 #include "qh_fft.hpp"
 #include "qh_ingest.hpp"
+#include "qh_egress.hpp"
 
 namespace qh {
 
@@ -74,6 +75,7 @@ template <typename T> struct OsfirArgs {
     // OUTMIX kernels: phasor of the NCO at input index g0 of every tile, at D*t for lane t, at D*256 (nco_step)
     const double2 *tile_rot;            // [nch][ntiles]
     const double2 *lane_rot;            // [nch][NT]
+    EgressFmt eg;                       // EGRESS kernels: the outputs leave as audio frames (qh_egress.hpp) instead of through `out`
     double2 *meter_in, *meter_out;      // [nch][meter_stride] chunk partials, chunk c = samples 64c .. 64c + 63 of this call
     long long meter_stride;
     const double *meter_w;              // [64]  (1 - m) m^(63 - i)
@@ -245,7 +247,7 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
     }
 }
 
-template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false>
+template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false>
 __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX>())) void osfir_k
                 C v;
                 v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
                 v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
-                out[m] = v;
+                if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, (double)v.x, (double)v.y);
+                else out[m] = v;
             }
         }
     } else {
@@ -404,7 +407,8 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX>())) void osfir_k
                 C v;
                 v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
                 v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
-                out[m] = v;
+                if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, (double)v.x, (double)v.y);
+                else out[m] = v;
             }
         }
     }

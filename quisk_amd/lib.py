@@ -80,6 +80,10 @@ def load():
     L.qh_rxa_graph_launches.restype = ll
     L.qh_rxa_pll_repairs.argtypes = [vp]
     L.qh_rxa_pll_repairs.restype = ll
+    L.qh_rxa_process_audio.argtypes = [vp, vp, ll, vp, ll, i, vp]
+    L.qh_rxa_process_audio.restype = i
+    L.qh_audio_pack.argtypes = [i, vp, vp, ll, i, i, vp, vp, ll]
+    L.qh_audio_pack.restype = i
     L.qh_wdsp_graph_launches.restype = ll
     L.qh_rxa_GetRXAMeter.argtypes = [vp, i, i, C.POINTER(d)]
     L.qh_rxa_flush.argtypes = [vp]

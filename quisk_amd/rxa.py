@@ -22,6 +22,22 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay", "SetRXAANRPosition", "SetRXAANRGain", "SetRXAANRLeakage", "SetRXAANRVals")
 
 
+class AudioFormat(C.Structure):
+    """qh_audio_format (include/quiskhip.h 7b): the narrowing of Quisk's sound back ends (sound_alsa.c:344-390,
+    sound_pulseaudio.c:684-695).  kind: "i16", "i24", "i32", "f32"."""
+    _fields_ = [("kind", C.c_int), ("num_channels", C.c_int), ("channel_I", C.c_int), ("channel_Q", C.c_int),
+                ("volume", C.c_double), ("prescale", C.c_double)]
+    KINDS = {"i16": 1, "i24": 2, "i32": 3, "f32": 4}
+    NP = {1: np.int16, 2: np.uint8, 3: np.int32, 4: np.float32}
+
+    def __init__(self, kind="i16", volume=1.0, prescale=1.0, num_channels=2, channel_I=0, channel_Q=1):
+        super().__init__(self.KINDS[kind], num_channels, channel_I, channel_Q, volume, prescale)
+
+    @property
+    def frame_bytes(self):
+        return self.num_channels * (2 if self.kind == 1 else 3 if self.kind == 2 else 4)
+
+
 class RxaEngine:
     """nch independent WDSP-RXA receiver channels on one MI355X."""
 
@@ -99,6 +115,10 @@ class RxaEngine:
         out = np.empty((self.nch, nblk * self.dsp_outsize), dtype=np.complex128)
         check(self._L.qh_rxa_process_host(self._h, x.ctypes.data, x.shape[1], out.ctypes.data, out.shape[1], nblk))
         return out
+
+    def process_audio_ptr(self, d_in, in_stride, d_out, out_stride_bytes, nblk, fmt):
+        """Like process_ptr, the output as audio frames (AudioFormat) narrowed in the last kernel's store."""
+        check(self._L.qh_rxa_process_audio(self._h, d_in, in_stride, d_out, out_stride_bytes, nblk, C.byref(fmt)))
 
     def process_packed_ptr(self, d_src, src_bytes, fmt, chan_stride, d_out, out_stride, nblk):
         """Wire-format input (quisk_amd.ingest.IqFormat) decoded inside the first kernel's load."""
