@@ -6,6 +6,7 @@ shift -> 561-tap resampler /4 -> NBP fircore (nc 2048, 300..3000 Hz) -> fixed-ga
 one pass ("step") = 2^22 input samples per channel, inputs resident in HBM.
 With --gpus N every rank runs its own 256 channels (independent receivers shard by channel, no
 collective on the data path): weak scaling, value = all ranks' input samples / max-over-ranks time.
+--total-channels C instead splits C channels over the ranks (strong scaling; north_star's shape is 256 over 8).
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +24,52 @@ LOG2_SAMPLES = 22
 IN_RATE, DSP_RATE = 192000, 48000
 DSP_SIZE = 256
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "c2_traffic.json")
+
+
+def kernel_source_sha16():
+    """Fingerprint of the kernel sources: tools/pmc_pass.py stamps the counter-derived HBM traffic with it, and a stamp that
+    does not match the sources this run was built from is not reported (counters cannot be read from inside the run)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "quisk_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class DryEngine:
+    """--dry-run only (tests/test_bench_plumbing.py): stands where RxaEngine stands so that the argument / rank / channel
+    split / barrier / max-over-ranks / JSON plumbing of this file can run in CPU processes.  It does no DSP; a line made
+    with it says "dry_run": true and is not a measurement."""
+
+    def __init__(self, nch, **kw):
+        self.nch, self.calls, self.rank = nch, [], int(os.environ.get("RANK", "0"))
+        self.setters = 0
+
+    def __getattr__(self, name):
+        if name.startswith(("Set", "RXA")):
+            def setter(*a):
+                self.setters += 1
+            return setter
+        raise AttributeError(name)
+
+    def enable_meters(self, on):
+        self.meters = on
+
+    def process_ptr(self, *a):
+        time.sleep(0.001 * (self.rank + 1))
+
+    def enable_timing(self, on):
+        pass
+
+    def timing_ms(self):
+        return [1.0, 0.5, 0.1]
+
+    def GetRXAMeter(self, ch, mt):
+        return -20.0
 
 
 def cpu_baseline(log2_samples=23):
@@ -63,7 +110,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=NCH, help="channels per GPU")
+    ap.add_argument("--channels", type=int, default=NCH, help="channels per GPU (weak scaling)")
+    ap.add_argument("--total-channels", type=int, default=0,
+                    help="strong scaling: this many channels in all, split over the ranks in contiguous ranges (SURVEY.md 8(e))")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the barrier / max-over-ranks (nccl = RCCL)")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing test only: no GPU, no DSP (DryEngine); the line is not a measurement")
     ap.add_argument("--log2-samples", type=int, default=LOG2_SAMPLES, help="input samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--meters", choices=["on", "off"], default="on",
@@ -79,33 +130,58 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from quisk_amd import RxaEngine, synth, shard, build as qbuild
+    from quisk_amd import synth, shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the RXA chain has no CPU path")
-    if rank == 0:
-        qbuild.build()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        from quisk_amd import build as qbuild
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the RXA chain has no CPU path")
+        if rank == 0:
+            qbuild.build()
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = lambda: torch.cuda.synchronize(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if (dry and args.backend == "nccl") else args.backend
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         dist.barrier()
 
-    nch = args.channels
     n_in = 1 << args.log2_samples
     nblk = n_in // (DSP_SIZE * (IN_RATE // DSP_RATE))
     n_out = nblk * DSP_SIZE
-    first = shard.channel_range(rank, world, nch)[0]           # rank r owns channels [r*nch, (r+1)*nch)
+    if args.total_channels > 0:
+        # strong scaling: the job's channels in contiguous ranges (256 over 8 GPUs = 32 each)
+        mine = shard.split_channels(args.total_channels, world)[rank]
+        first, nch, scaling = mine.start, len(mine), "strong"
+        total_channels = args.total_channels
+        if nch == 0:
+            raise SystemExit("bench.py: rank %d has no channel (--total-channels %d over %d ranks)" % (rank, args.total_channels, world))
+    else:
+        nch = args.channels
+        first = shard.channel_range(rank, world, nch)[0]       # rank r owns channels [r*nch, (r+1)*nch)
+        scaling, total_channels = "weak", nch * world
 
-    stream = torch.cuda.current_stream(dev)
-    eng = RxaEngine(nch, dsp_size=DSP_SIZE, in_rate=IN_RATE, dsp_rate=DSP_RATE, out_rate=DSP_RATE,
-                    device=local_rank, stream=stream.cuda_stream)
+    if dry:
+        eng = DryEngine(nch)
+        stream = None
+    else:
+        from quisk_amd import RxaEngine
+        stream = torch.cuda.current_stream(dev)
+        eng = RxaEngine(nch, dsp_size=DSP_SIZE, in_rate=IN_RATE, dsp_rate=DSP_RATE, out_rate=DSP_RATE,
+                        device=local_rank, stream=stream.cuda_stream)
     eng.SetRXAShiftRun(-1, 1)
     for c in range(nch):
         eng.SetRXAShiftFreq(c, synth.shift_freq(first + c))
@@ -116,9 +192,13 @@ def main():
     eng.SetRXAAGCFixed(-1, 0.0)
     eng.enable_meters(args.meters == "on")
 
-    x = synth.make_input_torch(nch, n_in, dev, fs=float(IN_RATE), first_channel=first)
-    y = torch.empty((nch, n_out), dtype=torch.complex128, device=dev)
-    torch.cuda.synchronize(dev)
+    if dry:
+        x = torch.zeros((nch, 8), dtype=torch.complex128)
+        y = torch.zeros((nch, 8), dtype=torch.complex128)
+    else:
+        x = synth.make_input_torch(nch, n_in, dev, fs=float(IN_RATE), first_channel=first)
+        y = torch.empty((nch, n_out), dtype=torch.complex128, device=dev)
+    sync()
 
     nchunk = max(1, args.chunks)
     if nblk % nchunk:
@@ -133,7 +213,7 @@ def main():
         packed = codes.view(torch.uint8).reshape(nch, n_in, 2, 4)[..., :3].contiguous()     # 6 bytes per sample
         del codes
         fmt = IqFormat.le24(2.0 ** -31)                     # left-justified int32 (code * 2^8) back to +-1.0 full scale
-        torch.cuda.synchronize(dev)
+        sync()
 
         def step():
             eng.process_packed_ptr(packed.data_ptr(), packed.numel(), fmt, 6 * n_in, y.data_ptr(), n_out, nblk)
@@ -145,18 +225,18 @@ def main():
     def timed_run():
         for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
-        return shard.max_over_ranks(time.perf_counter() - t0, dev)
+        sync()
+        return shard.max_over_ranks(time.perf_counter() - t0, dev if not dry else None)
 
     dt = timed_run()                    # the measurement `value` reports
     meter_db = [eng.GetRXAMeter(0, mt) for mt in (1, 3, 6)] if args.meters == "on" else None
@@ -182,9 +262,10 @@ def main():
     gain = float(tail.abs().mean().item()) / 0.1
 
     if rank == 0:
-        samples_per_step = float(nch) * n_in
-        total = samples_per_step * world * args.steps
-        value = shard.job_throughput(samples_per_step, world, args.steps, dt) / 1e6
+        samples_per_step = float(nch) * n_in                     # this rank's launch (kernel-level figures below)
+        job_samples_per_step = float(total_channels) * n_in      # all ranks
+        total = job_samples_per_step * args.steps
+        value = total / dt / 1e6
         # dominant kernel and its algorithmic bytes per launch:
         #   front  (shift + resample /4): reads 16 B, writes 16/4 B per input sample        = 20 B / input sample
         #   band   (NBP overlap-save)   : reads 16 B, writes 16 B per DSP-rate sample (x1/4) =  8 B / input sample
@@ -194,13 +275,17 @@ def main():
         achieved = algo[k] * samples_per_step / (kt[k] * 1e-3) / 1e9
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c2_traffic.json),
         # scaled by the number of samples: counters cannot be read inside this process
-        traffic = None
+        traffic, traffic_note = None, None
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c2_traffic.json")))
-            if args.ingest == "f64":
+            tj = json.load(open(TRAFFIC_JSON))
+            if tj.get("source_sha16") != kernel_source_sha16():
+                traffic_note = "profiles/c2_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("source_sha16")
+            elif args.ingest == "f64" and tj.get("meters") == args.meters:
                 traffic = tj["kernels"]["front" if k == 0 else "band"]["bytes_per_input_sample"] * samples_per_step
-        except Exception:
-            traffic = None
+            else:
+                traffic_note = "profiles/c2_traffic.json holds another variant (ingest / meters)"
+        except Exception as exc:
+            traffic_note = "no counter-derived traffic: %r" % (exc,)
         line = {
             "metric": "Mcomplex-samples/s through RXA chain",
             "value": value,
@@ -210,14 +295,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%d channels/GPU x 192 kHz IQ -> 48 kHz SSB RXA chain (shift + 561-tap resample/4 + adc meter + NBP nc 2048 "
                                    "+ S meter + fixed AGC + agc meter + panel), 2^%d input samples per channel per step" % (nch, args.log2_samples),
-                       "meters": args.meters, "ingest": args.ingest, "channels_per_gpu": nch, "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
-                       "parallelism": "channel-sharded x%d, no collective" % world},
+                       "meters": args.meters, "ingest": args.ingest, "channels_per_gpu": nch, "total_channels": total_channels,
+                       "in_rate": IN_RATE, "dsp_rate": DSP_RATE, "dsp_size": DSP_SIZE,
+                       "parallelism": "channel-sharded x%d (%s), no collective" % (world, scaling)},
             "chain_algorithmic_GBps": 20.0 * total / dt / 1e9,
             # ~650 flop per input sample if the chain is evaluated in direct form like the reference; the
             # overlap-save kernels execute about a quarter of that, which is how `value` can sit above the fp64-vector bound
@@ -225,15 +311,18 @@ def main():
             "chain_direct_form_equivalent_TFLOPs": 650.0 * total / dt / 1e12,
             "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo[k] * samples_per_step},
             "check_inband_gain": gain,
         }
+        if dry:
+            line["dry_run"] = True
+            line["dry"] = {"rank0_channels": [first, first + nch], "setters": eng.setters}
         if dt_off is not None:
-            line["value_meters_off"] = shard.job_throughput(samples_per_step, world, args.steps, dt_off) / 1e6
+            line["value_meters_off"] = total / dt_off / 1e6
             line["ms_per_step_meters_off"] = dt_off / args.steps * 1e3
             line["check_meters_dB"] = {"S_AV": meter_db[0], "ADC_AV": meter_db[1], "AGC_AV": meter_db[2]}
-        if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported by the single-GPU run only
+        if not args.no_cpu_baseline and world == 1 and not dry:       # the CPU baseline is reported by the single-GPU run only
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as exc:                             # the baseline is reported, never required

@@ -1,0 +1,66 @@
+"""bench.py's multi-process plumbing without a GPU: argument parsing, RANK / WORLD_SIZE handling, the weak and the strong
+channel split, the barrier-bracketed timing, the max over ranks and the one JSON line of rank 0 -- run in two fresh child
+processes over gloo with `--dry-run`, which puts bench.DryEngine where RxaEngine stands (no DSP: the printed line says
+"dry_run": true and is not a measurement).  The real launch differs in the backend (nccl = RCCL) and the engine only."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, extra):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run", "--backend", "gloo",
+                                       "--steps", "4", "--warmup", "1", "--log2-samples", "12"] + extra,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    js = [[l for l in so.splitlines() if l.startswith("{")] for so, _ in outs]
+    assert len(js[0]) == 1 and all(not j for j in js[1:])       # rank 0 prints the one JSON line, nobody else
+    return json.loads(js[0][0])
+
+
+def test_strong_split_two_ranks():
+    j = _launch(2, ["--total-channels", "256"])
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 1
+    assert j["scaling"] == "strong"
+    assert j["config"]["total_channels"] == 256 and j["config"]["channels_per_gpu"] == 128
+    assert j["dry"]["rank0_channels"] == [0, 128]
+    # rank 1's fake step takes 2 ms: the job time is the max over ranks, and value is the whole job's samples over it
+    assert j["ms_per_step"] >= 2.0
+    want = 256 * 4096 * 4 / (j["ms_per_step"] * 4e-3) / 1e6
+    assert abs(j["value"] - want) < 1e-6 * want
+    assert j["config"]["meters"] == "on" and "value_meters_off" in j
+
+
+def test_weak_split_two_ranks_and_uneven_strong_split():
+    j = _launch(2, ["--channels", "8"])
+    assert j["scaling"] == "weak" and j["config"]["total_channels"] == 16 and j["config"]["channels_per_gpu"] == 8
+    want = 16 * 4096 * 4 / (j["ms_per_step"] * 4e-3) / 1e6
+    assert abs(j["value"] - want) < 1e-6 * want
+    j = _launch(2, ["--total-channels", "5"])          # 3 + 2
+    assert j["config"]["channels_per_gpu"] == 3 and j["config"]["total_channels"] == 5
+
+
+def test_single_process_dry_run():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0", "--log2-samples", "12"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["dry_run"] is True and j["scaling"] == "weak"

@@ -25,6 +25,37 @@ GROUPS = [
 ]
 
 
+def write_c2_traffic(res, bench_args, path):
+    """HBM bytes per input sample of the two kernels of BASELINE config 2 from the FETCH_SIZE / WRITE_SIZE passes (rocprofv3
+    reports KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md: on gfx950 it tallies 128-byte requests at 64 bytes), stamped
+    with the fingerprint of the kernel sources: bench.py reports `roofline.traffic` only from a stamp that matches its own."""
+    sys.path.insert(0, ROOT)
+    import bench
+    log2 = 22
+    meters = "on"
+    for i, a in enumerate(bench_args):
+        if a == "--log2-samples":
+            log2 = int(bench_args[i + 1])
+        if a == "--meters":
+            meters = bench_args[i + 1]
+    samples = 256.0 * (1 << log2)
+    kern = {}
+    for name, v in res.items():
+        if "osfir_kernel<double, 4096, 4" in name:
+            key = "front"
+        elif "osfir_kernel<double, 4096, 1" in name and (("true, false" in name.split("4096, 1,")[1][:30]) == (meters == "on")):
+            key = "band"        # the METER instantiation when the meters run (template flags: MIX, PACKED, METER, ...)
+        else:
+            continue
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            kern[key] = {"kernel": name, "fetch_bytes_x2": 2048.0 * v["FETCH_SIZE"], "write_bytes": 1024.0 * v["WRITE_SIZE"],
+                         "bytes_per_input_sample": (2048.0 * v["FETCH_SIZE"] + 1024.0 * v["WRITE_SIZE"]) / samples}
+    j = {"source_sha16": bench.kernel_source_sha16(), "meters": meters, "log2_samples": log2, "channels": 256, "kernels": kern,
+         "source": "tools/pmc_pass.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over bench.py " + " ".join(bench_args)}
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(j, open(path, "w"), indent=1, sort_keys=True)
+
+
 def main():
     out = sys.argv[1]
     script = os.path.join(ROOT, "bench.py")
@@ -54,6 +85,8 @@ def main():
                 res[k][n] = sum(v) / len(v)
                 res[k]["_launches"] = len(v)
     res["_bench_args"] = bench_args
+    if os.path.basename(script) == "bench.py":
+        write_c2_traffic(res, bench_args, os.path.join(os.path.dirname(os.path.abspath(out)), "c2_traffic.json"))
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
