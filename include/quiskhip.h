@@ -535,6 +535,24 @@ void qh_quisk_set_auto_notch(int on, int rit_freq);         /* set_auto_notch, q
 int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
 int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
 int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */
+/* The rest of quisk_process_samples' orchestration (quisk.c:2289-2742): a second receiver bank whose audio shares the
+ * stereo output with the first -- split Rx/Tx (the same samples at tx_tune + rit, split modes 1..4 of quisk.c:2548-2590) or
+ * the played sub-receiver (its own samples, frequency, mode and nFilter-1 filter; play methods 0..2 of quisk.c:2601-2620) --
+ * with one AGC per output channel (Agc1 / Agc2, quisk.c:2690-2698); the key-down replacement of the block by sidetone or
+ * silence, the TxRxSilenceMsec of silence after it and the 5 ms key-up ramp (quisk.c:2368-2433,2729-2738); kill_audio;
+ * invert_spectrum. */
+void qh_quisk_set_tx_tune(int tx_tune_freq);                               /* set_tune's second argument, quisk.c:4702 */
+void qh_quisk_set_split_rxtx(int split);                                   /* set_split_rxtx, quisk.c:4694 */
+void qh_quisk_set_multirx_play_channel(int ch);                            /* quisk.c:4856 */
+void qh_quisk_set_multirx_play_method(int method);                         /* quisk.c:4846 */
+void qh_quisk_set_multirx_freq(int index, int freq);                       /* quisk.c:4826 */
+void qh_quisk_set_multirx_mode(int index, int mode);                       /* quisk.c:4836 */
+int qh_quisk_multirx_samples(int index, const double *cSamples, int nSamples);     /* multirx_cSamples[index] for the next block */
+int qh_quisk_set_filters2(const double *filtI, const double *filtQ, int size, int bandwidth);      /* set_filters(..., nFilter 1) */
+void qh_quisk_set_key_state(int key_down, int cw_key_down, int active_sidetone, int is_fdx);
+void qh_quisk_set_sidetone(double volume, int rit_freq, int playback_rate, int txrx_silence_msec);     /* set_sidetone, quisk.c:4710 */
+void qh_quisk_set_kill_audio(int kill);
+void qh_quisk_invert_spectrum(int invert);                                 /* quisk.c:4535 */
 
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library

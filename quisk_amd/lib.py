@@ -189,6 +189,14 @@ def load():
     L.qh_quisk_set_agc.argtypes = [C.c_double]
     L.qh_quisk_set_agc.restype = None
     L.qh_quisk_process_samples.argtypes = [vp, i]
+    for n, at in (("set_tx_tune", [i]), ("set_split_rxtx", [i]), ("set_multirx_play_channel", [i]), ("set_multirx_play_method", [i]),
+                  ("set_multirx_freq", [i, i]), ("set_multirx_mode", [i, i]), ("set_key_state", [i, i, i, i]),
+                  ("set_sidetone", [C.c_double, i, i, i]), ("set_kill_audio", [i]), ("invert_spectrum", [i])):
+        f = getattr(L, "qh_quisk_" + n)
+        f.argtypes = at
+        f.restype = None
+    L.qh_quisk_multirx_samples.argtypes = [i, vp, i]
+    L.qh_quisk_set_filters2.argtypes = [vp, vp, i, i]
     L.qh_quisk_get_graph.argtypes = [C.c_double, C.c_double, vp, vp]
     L.qh_qrx_create_ex.restype = vp
     L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]

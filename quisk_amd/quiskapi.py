@@ -42,6 +42,61 @@ def set_filters(filtI, filtQ, bandwidth):
     check(load().qh_quisk_set_filters(fI.ctypes.data, fQ.ctypes.data, fI.size, int(bandwidth)))
 
 
+def set_tune2(rx_tune_freq, tx_tune_freq):
+    """QS.set_tune(rx, tx), quisk.c:4702."""
+    load().qh_quisk_set_tune(int(rx_tune_freq))
+    load().qh_quisk_set_tx_tune(int(tx_tune_freq))
+
+
+def set_split_rxtx(split):
+    load().qh_quisk_set_split_rxtx(int(split))
+
+
+def set_multirx_play_channel(ch):
+    load().qh_quisk_set_multirx_play_channel(int(ch))
+
+
+def set_multirx_play_method(method):
+    load().qh_quisk_set_multirx_play_method(int(method))
+
+
+def set_multirx_freq(index, freq):
+    load().qh_quisk_set_multirx_freq(int(index), int(freq))
+
+
+def set_multirx_mode(index, mode):
+    load().qh_quisk_set_multirx_mode(int(index), int(mode))
+
+
+def multirx_samples(index, x):
+    """The played sub-receiver's block (multirx_cSamples[index]) for the next process_samples call."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    check(load().qh_quisk_multirx_samples(int(index), x.ctypes.data, x.size))
+
+
+def set_filters2(filtI, filtQ, bandwidth):
+    """QS.set_filters(I, Q, bandwidth, offset, 1): the filter of the played sub-receiver."""
+    fI = np.ascontiguousarray(filtI, dtype=np.float64)
+    fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
+    check(load().qh_quisk_set_filters2(fI.ctypes.data, fQ.ctypes.data, fI.size, int(bandwidth)))
+
+
+def set_key_state(key_down, cw_key_down=0, active_sidetone=0, is_fdx=0):
+    load().qh_quisk_set_key_state(int(key_down), int(cw_key_down), int(active_sidetone), int(is_fdx))
+
+
+def set_sidetone(volume, rit_freq, playback_rate=48000, txrx_silence_msec=50):
+    load().qh_quisk_set_sidetone(C.c_double(volume), int(rit_freq), int(playback_rate), int(txrx_silence_msec))
+
+
+def set_kill_audio(kill):
+    load().qh_quisk_set_kill_audio(int(kill))
+
+
+def invert_spectrum(invert):
+    load().qh_quisk_invert_spectrum(int(invert))
+
+
 def set_agc(level):
     load().qh_quisk_set_agc(C.c_double(level))
 
