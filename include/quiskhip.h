@@ -44,7 +44,9 @@ typedef struct qh_rxa qh_rxa;
  * OpenChannel(ch, *, dsp_size, in_rate, dsp_rate, out_rate, type 0, ...) followed by create_rxa()
  * (wdsp/channel.c:75-103, wdsp/RXA.c:31-490): shift run=1 at 0 Hz, nbp0 -4150..-150 Hz nc 2048,
  * AGC mode 3, panel gain 4.  `stream` is a hipStream_t (NULL = the engine creates its own).
- * in_rate must be an integer multiple (1, 2, 4, 8) of dsp_rate and out_rate == dsp_rate. */
+ * in_rate / dsp_rate = 1, 2, 4, 8 or 16 runs the fused overlap-save front stage; any other whole ratio up or down (3, 5,
+ * 6 ...; 1/2, 1/4 ...: what pre_main_build's integer divisions size consistently, wdsp/channel.c:39-42) runs xshift and the
+ * polyphase resampler of wdsp/resample.c:35-157 as two passes.  out_rate: an integer multiple or fraction of dsp_rate. */
 qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_rate, int out_rate, void *stream);
 void qh_rxa_destroy(qh_rxa *e);
 

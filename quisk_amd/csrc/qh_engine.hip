@@ -257,6 +257,9 @@ struct Engine {
     int process(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     int process_chain(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     qh_rat *rsmpout = nullptr;          // xresample out (wdsp/RXA.c:596), only when out_rate != dsp_rate
+    qh_rat *rsmpin = nullptr;           // xresample in for the rate ratios the overlap-save front stage does not cover (D == 0)
+    double2 *fbuf = nullptr;            // its input: the shifted samples at in_rate
+    long long fbuf_cap = 0;
     double2 *obuf = nullptr;
     long long obuf_cap = 0;
     void tick(int cat);
@@ -268,6 +271,8 @@ Engine::~Engine()
     if (stream) (void)hipStreamSynchronize(stream);
     drop_graphs();
     if (rsmpout) qh_rat_destroy(rsmpout);
+    if (rsmpin) qh_rat_destroy(rsmpin);
+    (void)hipFree(fbuf);
     (void)hipFree(obuf); (void)hipFree(abuf);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
@@ -299,7 +304,15 @@ int Engine::init()
     QH_HIP(hipSetDevice(device));
     if (!stream) { QH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     // pre_main_build, wdsp/channel.c:39-47
-    dsp_insize = dsp_size * D;
+    dsp_insize = D > 0 ? dsp_size * D : (int)((long long)dsp_size * in_rate / dsp_rate);
+    if (D == 0) {
+        // create_resample(..., in_rate, dsp_rate, 0.0, 0, 1.0), wdsp/RXA.c:48-57
+        const ResamplerDesign rd = design_resampler(in_rate, dsp_rate, 0.0, 0, 1.0);
+        std::vector<double> taps(rd.h);
+        for (double &v : taps) v /= (double)rd.L;           // qh_rat applies the gain `interp` itself (quisk_cInterpDecim's convention)
+        rsmpin = qh_rat_create(device, nch, taps.data(), rd.ncoef, rd.L, rd.M, QH_F64, stream);
+        if (!rsmpin) return QH_ERR_HIP;
+    }
     dsp_outsize = out_rate >= dsp_rate ? dsp_size * (out_rate / dsp_rate) : dsp_size / (dsp_rate / out_rate);    // channel.c:47-50
     if (out_rate != dsp_rate) {
         // create_resample(..., dsp_rate, out_rate, 0.0, 0, 1.0), wdsp/RXA.c:474-484; the polyphase loop of xresample
@@ -1234,6 +1247,31 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
                                hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, (const unsigned long long *)nullptr,
                                (const unsigned long long *)nullptr, (const int *)nullptr, (const unsigned char *)nullptr, PackedFmt{});
         cur_front ^= 1;
+    } else if (D == 0) {
+        // any other ratio: xshift into the staging rows, then the polyphase resampler (its ring and phase live in qh_rat)
+        if (pk_src) return set_error(QH_ERR_UNSUPPORTED, "packed input needs in_rate / dsp_rate in 2, 4, 8, 16");
+        if (n_in > fbuf_cap) {
+            QH_HIP(hipStreamSynchronize(stream));
+            drop_graphs(); epoch++;
+            if (fbuf) { QH_HIP(hipFree(fbuf)); dev_bytes -= fbuf_cap * nch * (long long)sizeof(double2); fbuf = nullptr; }
+            QH_HIP(dev_alloc(&fbuf, (size_t)nch * (size_t)n_in));
+            fbuf_cap = n_in;
+            dev_bytes += n_in * nch * (long long)sizeof(double2);
+        }
+        long long per = (n_in + NT - 1) / NT;
+        dim3 g((unsigned)(per < 4096 ? per : 4096), (unsigned)nch);
+        hipLaunchKernelGGL((pointwise_kernel<double, true>), g, dim3(NT), 0, stream, src, src_stride, fbuf, fbuf_cap,
+                           (int)n_in, nco_phase, nco_dphase, (const EpiParam *)nullptr, (const int *)nullptr);
+        int got = 0;
+        if (int rc = qh_rat_process(rsmpin, fbuf, fbuf_cap, (int)n_in, dst, dst_stride, &got)) return rc;
+        if (got != (int)n_mid) return set_error(QH_ERR_HIP, "input resampler produced %d samples, expected %lld", got, n_mid);
+        if (ep) {       // the front stage is the chain's last: fixed AGC gain and panel, in place
+            long long pm = (n_mid + NT - 1) / NT;
+            hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3((unsigned)(pm < 1024 ? pm : 1024), (unsigned)nch), dim3(NT), 0, stream,
+                               (const double2 *)dst, dst_stride, dst, dst_stride, (int)n_mid, (const unsigned long long *)nullptr,
+                               (const unsigned long long *)nullptr, ep, (const int *)nullptr);
+        }
+        tick(2);
     } else {
         if (pk_src) return set_error(QH_ERR_UNSUPPORTED, "packed input needs in_rate > dsp_rate (unpack with qh_unpack_iq first)");
         long long per = (n_in + NT - 1) / NT;
@@ -1571,9 +1609,17 @@ qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_ra
         set_error(QH_ERR_UNSUPPORTED, "out_rate must be an integer multiple or fraction of dsp_rate (wdsp/channel.c:47-52)");
         return nullptr;
     }
-    if (in_rate % dsp_rate) { set_error(QH_ERR_UNSUPPORTED, "in_rate must be a multiple of dsp_rate"); return nullptr; }
-    const int D = in_rate / dsp_rate;
-    if (D != 1 && D != 2 && D != 4 && D != 8 && D != 16) { set_error(QH_ERR_UNSUPPORTED, "in_rate/dsp_rate must be 1, 2, 4, 8 or 16"); return nullptr; }
+    // in_rate / dsp_rate 1, 2, 4, 8, 16: the overlap-save front stage.  Any other whole ratio, up or down (3, 5, 6 ...; 1/2,
+    // 1/4 ...): xshift as a pointwise pass + the polyphase form of xresample (wdsp/resample.c:35-157) -- D = 0 marks it.  The
+    // reference sizes its blocks with integer divisions of the two rates (pre_main_build, wdsp/channel.c:39-42): a ratio that is
+    // not whole one way or the other does not give it consistent block sizes, and is refused here.
+    int D = (in_rate % dsp_rate) ? 0 : in_rate / dsp_rate;
+    if (D != 1 && D != 2 && D != 4 && D != 8 && D != 16) D = 0;
+    if (D == 0 && !((in_rate > dsp_rate && in_rate % dsp_rate == 0) ||
+                    (in_rate < dsp_rate && dsp_rate % in_rate == 0 && dsp_size % (dsp_rate / in_rate) == 0))) {
+        set_error(QH_ERR_UNSUPPORTED, "in_rate / dsp_rate must be a whole number or the reciprocal of one (wdsp/channel.c:39-42)");
+        return nullptr;
+    }
     if (qh_device_count() <= device || device < 0) {
         set_error(QH_ERR_NO_DEVICE, "no HIP device %d (libquiskhip has no CPU fallback)", device);
         return nullptr;
@@ -2127,6 +2173,7 @@ int qh_rxa_flush(qh_rxa *h)
     QH_HIP(hipMemsetAsync(e.nco_phase, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
     QH_HIP(hipMemsetAsync(e.nco_parked, 0, (size_t)e.nch * sizeof(unsigned long long), e.stream));
     if (e.rsmpout) if (int rc = qh_rat_reset(e.rsmpout)) return rc;        // flush_resample, wdsp/resample.c:159-165
+    if (e.rsmpin) if (int rc = qh_rat_reset(e.rsmpin)) return rc;
     for (int i = 0; i < 2; i++) {
         if (e.hist_front[i]) QH_HIP(hipMemsetAsync(e.hist_front[i], 0, (size_t)e.nch * kHistFront * sizeof(double2), e.stream));
         QH_HIP(hipMemsetAsync(e.hist_nbp[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));

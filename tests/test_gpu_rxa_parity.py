@@ -378,3 +378,32 @@ def test_am_squelch(qh, oracle, mode, thresh, tail):
         assert 1000 < muted < (nblk - 20) * 256                 # it did close (start-up at least), and it did open
         assert np.array_equal(y[ch] == 0, ref == 0)             # same samples muted
         assert rel_rms(y[ch], ref) < 1e-9
+
+
+@pytest.mark.parametrize("in_rate,nblk", [(144000, 24), (240000, 16), (288000, 12), (24000, 60), (12000, 60)])
+def test_general_input_rate_ratios(qh, oracle, in_rate, nblk):
+    """in_rate / dsp_rate = 3, 5, 6, 1/2, 1/4: calc_resample's L / M (wdsp/resample.c:35-78) through the polyphase resampler
+    instead of the fused overlap-save front stage; two ragged calls.  (Ratios that are not whole either way are refused: the
+    reference's block sizes come from integer divisions of the rates, wdsp/channel.c:39-42.)"""
+    nch, dsp_size = 2, 256
+    insize = dsp_size * in_rate // 48000
+    x = synth.make_input_numpy(nch, nblk * insize, fs=float(in_rate))
+    e = qh.RxaEngine(nch, dsp_size=dsp_size, in_rate=in_rate)
+    assert e.dsp_insize == insize
+    refs = []
+    for c in range(nch):
+        f = 5000.0 + 37.0 * c
+        e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, f); e.RXANBPSetRun(c, 1); e.SetRXAMode(c, 1)
+        e.RXASetPassband(c, 300.0, 3000.0); e.SetRXAAGCMode(c, 0); e.SetRXAAGCFixed(c, 0.0)
+        o = oracle.WdspChannel(insize, dsp_size, in_rate, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(f); o.RXANBPSetRun(1); o.SetRXAMode(1)
+        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0)
+        refs.append(o.xrxa(x[c]))
+    k = 7 * insize
+    y = np.concatenate([e.process_host(np.ascontiguousarray(x[:, :k])), e.process_host(np.ascontiguousarray(x[:, k:]))], axis=1)
+    for c in range(nch):
+        assert rel_rms(y[c], refs[c]) < 1e-9, (in_rate, c)
+    assert np.abs(y).max() > 1e-3
+    if in_rate == 144000:
+        with pytest.raises(qh.QuiskHipError):
+            qh.RxaEngine(1, in_rate=72000)
