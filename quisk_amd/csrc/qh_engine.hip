@@ -47,8 +47,9 @@ int set_error(int code, const char *fmt, ...)
     return code;
 }
 
-static constexpr int kNfft = 4096;          // FFT size of every overlap-save stage in this engine
-static constexpr int kHistBand = 2047;      // fircore history capacity: nc up to 2048
+static constexpr int kNfft = 4096;          // FFT size of the front stage and, for nc <= 2048, of the fircore stages
+static constexpr int kBandNfftMax = 8192;   // fircore stages with 2048 < nc <= 4096 run 8192-point tiles (Engine::bnfft)
+static constexpr int kHistBand = 4095;      // fircore history capacity: nc up to 4096
 static constexpr int kHistFront = 2240;     // resampler history capacity: 140 * D taps, D <= 16
 // FM PLL time tiles (qh_tiled.hpp).  On a carrier the loop (double pole at 0.66 per sample) forgets its start state in ~100
 // samples; on noise alone two runs meet after ~135 samples on average with an exponential tail, so a 768-sample warm-up
@@ -136,7 +137,8 @@ struct Engine {
     int front_ntaps = 0, front_P = 0, front_L = 0;
     // device state
     double2 *mask_front = nullptr, *mask_nbp = nullptr, *mask_bp1 = nullptr;
-    double2 *tw4096 = nullptr, *tw_inv_front = nullptr;
+    double2 *tw4096 = nullptr, *tw_inv_front = nullptr, *tw8192 = nullptr;
+    int bnfft = kNfft;                      // tile size of the fircore stages: what their masks are built for (4096 or 8192)
     unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr, *nco_parked = nullptr;
     double2 *nco_step = nullptr;
     // output-side oscillator of the front stage (D > 1): per-channel lane table, per-launch tile table, the resampler taps,
@@ -213,7 +215,7 @@ struct Engine {
     SnotchParam *sn_prm = nullptr;
     SnotchState *sn_state = nullptr;
     double2 *mask_de = nullptr, *mask_aud = nullptr, *hist_de[2] = { nullptr, nullptr }, *hist_aud[2] = { nullptr, nullptr };
-    int cur_de = 0, cur_aud = 0, fm_nc_built = 0, fm_mp = 0, fm_mp_built = 0;
+    int cur_de = 0, cur_aud = 0, fm_nc_built = 0, fm_mp = 0, fm_mp_built = 0, fm_nfft_built = 0;
     unsigned flags() const { return (unsigned)(cur_front | cur_nbp << 1 | cur_bp1 << 2 | cur_de << 3 | cur_aud << 4 | cur_snb << 5); }
     void set_flags(unsigned f) { cur_front = f & 1; cur_nbp = f >> 1 & 1; cur_bp1 = f >> 2 & 1; cur_de = f >> 3 & 1; cur_aud = f >> 4 & 1; cur_snb = f >> 5 & 1; }
     void drop_graphs() { for (auto &g : graph_slot) if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; } }
@@ -274,7 +276,7 @@ Engine::~Engine()
     if (rsmpin) qh_rat_destroy(rsmpin);
     (void)hipFree(fbuf);
     (void)hipFree(obuf); (void)hipFree(abuf);
-    (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front);
+    (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front); (void)hipFree(tw8192);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
@@ -329,6 +331,10 @@ int Engine::init()
     QH_HIP(dev_alloc(&tw4096, tw.size()));
     if (int rc = upload(tw4096, tw, stream)) return rc;
     dev_bytes += tw.size() * sizeof(cd);
+    tw = fft_twiddle_table(kBandNfftMax);
+    QH_HIP(dev_alloc(&tw8192, tw.size()));
+    if (int rc = upload(tw8192, tw, stream)) return rc;
+    dev_bytes += tw.size() * sizeof(cd);
 
     if (D > 1) {
         // calc_resample, wdsp/resample.c:35-72 (L = 1): y[m] = sum_j h[j] x[D*m - j]
@@ -361,9 +367,9 @@ int Engine::init()
             dev_bytes += (size_t)nch * kHistFront * sizeof(double2);
         }
     }
-    QH_HIP(dev_alloc(&mask_nbp, (size_t)nch * kNfft));
-    QH_HIP(dev_alloc(&mask_bp1, (size_t)nch * kNfft));
-    dev_bytes += 2ll * nch * kNfft * sizeof(double2);
+    QH_HIP(dev_alloc(&mask_nbp, (size_t)nch * kBandNfftMax));
+    QH_HIP(dev_alloc(&mask_bp1, (size_t)nch * kBandNfftMax));
+    dev_bytes += 2ll * nch * kBandNfftMax * sizeof(double2);
     for (int i = 0; i < 2; i++) {
         QH_HIP(dev_alloc(&hist_nbp[i], (size_t)nch * kHistBand));
         QH_HIP(dev_alloc(&hist_bp1[i], (size_t)nch * kHistBand));
@@ -386,6 +392,10 @@ int Engine::init()
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D>())))
     QH_SET_LDS(1, false); QH_SET_LDS(1, false, false, true);
     QH_SET_LDS(1, false, false, false, false, true); QH_SET_LDS(1, false, false, true, false, true);
+#define QH_SET_LDS8(...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, kBandNfftMax, 1, false, false, __VA_ARGS__>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, kBandNfftMax, 1>())))
+    QH_SET_LDS8(false, false, false); QH_SET_LDS8(true, false, false); QH_SET_LDS8(false, false, true); QH_SET_LDS8(true, false, true);
+#undef QH_SET_LDS8
     QH_SET_LDS(2, false, false, false, true); QH_SET_LDS(4, false, false, false, true); QH_SET_LDS(8, false, false, false, true);
     QH_SET_LDS(2, false, true, false, true); QH_SET_LDS(4, false, true, false, true); QH_SET_LDS(8, false, true, false, true);
 #undef QH_SET_LDS
@@ -489,8 +499,8 @@ int Engine::refresh_params()
                 h = fir_bandpass(c.nbp_nc, f_low, f_high, (double)dsp_rate, c.nbp_wintype, 1, scale);
             if (c.mp) h = mp_imp(h, 16, 0);
             for (auto &v : h) v *= (double)(2 * dsp_size);
-            const std::vector<cd> m = make_mask(h, kNfft);
-            QH_HIP(hipMemcpyAsync(mask_snb + (size_t)ch * kNfft, m.data(), kNfft * sizeof(cd), hipMemcpyHostToDevice, stream));
+            const std::vector<cd> m = make_mask(h, bnfft);
+            QH_HIP(hipMemcpyAsync(mask_snb + (size_t)ch * kBandNfftMax, m.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.snb_dirty = false;
         }
@@ -522,10 +532,10 @@ int Engine::refresh_params()
                 if (c.nbp_run && c.mp) h = mp_imp(h, 16, 0);            // calc_fircore, wdsp/firmin.c:327-328
                 // the reference's unnormalised inverse FFT of 2*size points restores the 1/(2*size)
                 if (c.nbp_run) for (auto &v : h) v *= (double)(2 * dsp_size);
-                last_nbp = make_mask(h, kNfft);
+                last_nbp = make_mask(h, bnfft);
                 last_nbp_cfg = &c;
             }
-            QH_HIP(hipMemcpyAsync(mask_nbp + (size_t)ch * kNfft, last_nbp.data(), kNfft * sizeof(cd), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemcpyAsync(mask_nbp + (size_t)ch * kBandNfftMax, last_nbp.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.nbp_dirty = false;
         }
@@ -543,10 +553,10 @@ int Engine::refresh_params()
                 } else {
                     h.assign(1, cd(1.0, 0.0));
                 }
-                last_bp1 = make_mask(h, kNfft);
+                last_bp1 = make_mask(h, bnfft);
                 last_bp1_cfg = &c;
             }
-            QH_HIP(hipMemcpyAsync(mask_bp1 + (size_t)ch * kNfft, last_bp1.data(), kNfft * sizeof(cd), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemcpyAsync(mask_bp1 + (size_t)ch * kBandNfftMax, last_bp1.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.bp1_dirty = false;
         }
@@ -633,8 +643,8 @@ int Engine::refresh_demod()
         QH_HIP(hipMemsetAsync(am_state, 0, (size_t)nch * sizeof(AmState), stream));
         QH_HIP(hipMemsetAsync(pll_state, 0, (size_t)nch * sizeof(PllState), stream));
         QH_HIP(hipMemsetAsync(sn_state, 0, (size_t)nch * sizeof(SnotchState), stream));
-        QH_HIP(dev_alloc(&mask_de, (size_t)kNfft));
-        QH_HIP(dev_alloc(&mask_aud, (size_t)kNfft));
+        QH_HIP(dev_alloc(&mask_de, (size_t)kBandNfftMax));
+        QH_HIP(dev_alloc(&mask_aud, (size_t)kBandNfftMax));
         for (int i = 0; i < 2; i++) {
             QH_HIP(dev_alloc(&hist_de[i], (size_t)nch * kHistBand));
             QH_HIP(dev_alloc(&hist_aud[i], (size_t)nch * kHistBand));
@@ -643,7 +653,7 @@ int Engine::refresh_demod()
         }
         dev_bytes += (long long)nch * (5 * 4 + 4 + sizeof(AmState) + sizeof(PllState) + 8 + sizeof(SamChanParam) +
                                       sizeof(SnotchParam) + sizeof(SnotchState) + 4 * kHistBand * sizeof(double2)) +
-                     2ll * kNfft * sizeof(double2);
+                     2ll * kBandNfftMax * sizeof(double2);
         // init_amd (wdsp/amd.c:72-89) with create_rxa's constants (RXA.c:183-189)
         {
             const double zeta = 1.0, omegaN = 250.0, tauR = 0.02, tauI = 1.4;
@@ -945,7 +955,7 @@ int Engine::refresh_demod()
         QH_HIP(hipStreamSynchronize(stream));
         c.demod_dirty = false;
     }
-    if (want_nc && (want_nc != fm_nc_built || fm_mp != fm_mp_built)) {
+    if (want_nc && (want_nc != fm_nc_built || fm_mp != fm_mp_built || fm_nfft_built != bnfft)) {
         // create_fmd, wdsp/fmd.c:108-116: de-emphasis by frequency sampling, audio band-pass 0.8*f_low .. 1.1*f_high
         const double f_low = 300.0, f_high = 3000.0, afgain = 0.5;
         std::vector<cd> de = fc_impulse(want_nc, f_low, f_high, +20.0 * std::log10(f_high / f_low), 0.0, 1, rate,
@@ -955,8 +965,9 @@ int Engine::refresh_demod()
         fm_mp_built = fm_mp;
         for (auto &v : de) v *= (double)(2 * dsp_size);
         for (auto &v : au) v *= (double)(2 * dsp_size);
-        if (int rc = upload(mask_de, make_mask(de, kNfft), stream)) return rc;
-        if (int rc = upload(mask_aud, make_mask(au, kNfft), stream)) return rc;
+        if (int rc = upload(mask_de, make_mask(de, bnfft), stream)) return rc;
+        if (int rc = upload(mask_aud, make_mask(au, bnfft), stream)) return rc;
+        fm_nfft_built = bnfft;
         if (fm_nc_built && fm_nc_built != want_nc) {      // setNc_fircore zeroes the delay lines, wdsp/firmin.c:454-466
             for (int i = 0; i < 2; i++) {
                 QH_HIP(hipMemsetAsync(hist_de[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
@@ -1002,13 +1013,13 @@ int Engine::snba_alloc()
         for (int i = 0; i < q.cpp_in; i++) hin[(size_t)i] = imp[(size_t)i].real();
     }
     QH_HIP(hipMemcpyAsync(snba_hin, hin.data(), hin.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    QH_HIP(dev_alloc(&mask_snb, (size_t)nch * kNfft));
+    QH_HIP(dev_alloc(&mask_snb, (size_t)nch * kBandNfftMax));
     for (int i = 0; i < 2; i++) {
         QH_HIP(dev_alloc(&hist_snb[i], (size_t)nch * kHistBand));
         QH_HIP(hipMemsetAsync(hist_snb[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
     }
     QH_HIP(hipStreamSynchronize(stream));
-    dev_bytes += (long long)nch * ((long long)q.state_doubles * 8 + (long long)kSnbX * kSnbX * 8 + (long long)kNfft * 16 + 2LL * kHistBand * 16);
+    dev_bytes += (long long)nch * ((long long)q.state_doubles * 8 + (long long)kSnbX * kSnbX * 8 + (long long)kBandNfftMax * 16 + 2LL * kHistBand * 16);
     snb_listed.assign((size_t)nch, 0);
     for (ChanCfg &c : cfg) { c.snba_taps_dirty = true; c.snb_dirty = true; c.snba_flush = c.snba_rout_flush = false; c.snb_flush = false; c.snb_hist_at = cur_snb; }
     return QH_OK;
@@ -1180,13 +1191,21 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false>
+template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
-    constexpr int lds = osfir_lds_bytes<double, kNfft, D>();
-    hipLaunchKernelGGL((osfir_kernel<double, kNfft, D, MIX, PACKED, METER, OUTMIX, EGRESS>), grid, block, lds, s, a);
+    constexpr int lds = osfir_lds_bytes<double, NFFT, D>();
+    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS>), grid, block, lds, s, a);
+}
+template <int NFFT>
+static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
+{
+    if (meter && egress) launch_osfir<1, false, false, true, false, true, NFFT>(a, ntiles, nch, s);
+    else if (meter) launch_osfir<1, false, false, true, false, false, NFFT>(a, ntiles, nch, s);
+    else if (egress) launch_osfir<1, false, false, false, false, true, NFFT>(a, ntiles, nch, s);
+    else launch_osfir<1, false, false, false, false, false, NFFT>(a, ntiles, nch, s);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------
@@ -1289,14 +1308,14 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
                       const int *list, int nlist, bool meter, bool egress)
 {
-    const int Lout = kNfft - P;
+    const int Lout = bnfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
     OsfirArgs<double> a{};
     a.in = src; a.in_stride = src_stride;
     a.hist = hist[hc]; a.hist_stride = kHistBand; a.hist_len = kHistBand;
     a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
     a.mask = mask; a.mask_stride = mask_stride;
-    a.tw_fwd = tw4096; a.tw_inv = tw4096;
+    a.tw_fwd = a.tw_inv = bnfft == kNfft ? tw4096 : tw8192;
     a.epi = ep;
     a.chan_list = list;
     a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
@@ -1304,10 +1323,8 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
-    if (meter && egress) launch_osfir<1, false, false, true, false, true>(a, ntiles, nl, stream);
-    else if (meter) launch_osfir<1, false, false, true>(a, ntiles, nl, stream);
-    else if (egress) launch_osfir<1, false, false, false, false, true>(a, ntiles, nl, stream);
-    else launch_osfir<1, false>(a, ntiles, nl, stream);
+    if (bnfft == kNfft) launch_band<kNfft>(a, ntiles, nl, stream, meter, egress);
+    else launch_band<kBandNfftMax>(a, ntiles, nl, stream, meter, egress);
     tick(2);
     dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
     hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
@@ -1368,6 +1385,14 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
     }
     if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
+    {   // impulse responses longer than 2048 taps need 8192-point tiles; the masks are spectra of the tile size, so a change
+        // of it rebuilds every fircore mask (the delay lines, kept 4095 samples deep, carry over)
+        const int want = nc_max > 2048 ? kBandNfftMax : kNfft;
+        if (want != bnfft) {
+            bnfft = want;
+            for (ChanCfg &c : cfg) { c.nbp_dirty = c.bp1_dirty = true; c.snb_dirty = true; }
+        }
+    }
     // The three meters of xrxa (adc, S, agc: RXA.c:566,569,589) ride on the nbp0 launch when the chain is linear (nbp0 runs,
     // bp1 does not, fixed AGC gain): the band tile then starts on a multiple of 256 samples so that a register holds one
     // 64-sample chunk per wavefront.  Any other chain takes the per-mode path with the stand-alone meter kernel.
@@ -1418,15 +1443,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             if (f == 0 ? !any_nbp : !any_bp1) continue;
             long long dst_stride;
             double2 *dst = dst_of(stage, dst_stride);
-            if (meters_fused) if (int rc = ensure_meter_partials(n_mid, kNfft - P)) return rc;
+            if (meters_fused) if (int rc = ensure_meter_partials(n_mid, bnfft - P)) return rc;
             run_band(cur, cur_stride, dst, dst_stride, stage == nstage - 1 ? epi : nullptr, n_mid,
-                     f == 0 ? mask_nbp : mask_bp1, kNfft, f == 0 ? hist_nbp : hist_bp1, f == 0 ? cur_nbp : cur_bp1, P,
+                     f == 0 ? mask_nbp : mask_bp1, kBandNfftMax, f == 0 ? hist_nbp : hist_bp1, f == 0 ? cur_nbp : cur_bp1, P,
                      nullptr, 0, meters_fused, eg_fused && stage == nstage - 1);
             cur = dst; cur_stride = dst_stride; stage++;
         }
         if (meters_fused)
             hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch, 3), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
-                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (kNfft - P) / 64, m_adc, m_s, m_agc, m_prm, (const double *)m_g2);
+                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, m_adc, m_s, m_agc, m_prm, (const double *)m_g2);
         if (eg.kind && !eg_fused) pack_audio(out, out_stride, n_mid);
         tick(3);
         QH_HIP(hipGetLastError());
@@ -1439,7 +1464,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_adc,
                                       m_prm, (const int *)nullptr);
     if (any_nbp) {
-        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kNfft, hist_nbp, cur_nbp, P, nullptr, 0);
+        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, cur_nbp, P, nullptr, 0);
         std::swap(cur, other);
     }
     if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_s,
@@ -1459,13 +1484,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // xbpsnbaout at position 0 (RXA.c:572): the 250..5700 Hz filter of the signal ahead of nbp0 replaces nbp0's output
     auto snb_inplace = [&](const int *list, int n) {
         int hc = cur_snb;
-        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_snb, kNfft, hist_snb, hc, P, list, n);
+        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_snb, kBandNfftMax, hist_snb, hc, P, list, n);
         long long per = (n_mid + NT - 1) / NT;
         hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n), dim3(NT), 0, stream, other, cur, buf_cap,
                            (int)n_mid, list);
     };
     if (n_snb[0]) {
-        if (any_nbp) { int hc = cur_snb; run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_snb, kNfft, hist_snb, hc, P, list_snb[0], n_snb[0]); }
+        if (any_nbp) { int hc = cur_snb; run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_snb, kBandNfftMax, hist_snb, hc, P, list_snb[0], n_snb[0]); }
         else snb_inplace(list_snb[0], n_snb[0]);
     }
     tick(1);
@@ -1525,7 +1550,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     };
     auto bp1_at = [&](int ps) {
         int hc = cur_bp1;
-        if (n_bp1p[ps]) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kNfft, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
+        if (n_bp1p[ps]) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
     };
     lms_on(0, cur);
     bp1_at(0);

@@ -168,10 +168,16 @@ __device__ __forceinline__ void pass_regs_to_lds(C (&x)[R], C *lds)
     static_assert(R == N / NT, "first pass radix must equal N/NT");
     const int j = threadIdx.x;
     Dft<R, INV, C>::run(x);
-    static_assert(16 % R == 0, "first pass radix must divide 16");
-    C *p = lds + lds_phys(j * R);           // (j*R + r) >> 4 == (j*R) >> 4 for r < R when R divides 16
+    if constexpr (16 % R == 0) {
+        C *p = lds + lds_phys(j * R);       // (j*R + r) >> 4 == (j*R) >> 4 for r < R when R divides 16
 #pragma unroll
-    for (int r = 0; r < R; r++) p[r] = x[r];
+        for (int r = 0; r < R; r++) p[r] = x[r];
+    } else {
+        static_assert(R % 16 == 0, "first pass radix: a divisor or a multiple of 16");
+        C *p = lds + lds_phys(j * R);       // rows of 16 elements, one pad element between them
+#pragma unroll
+        for (int r = 0; r < R; r++) p[r + r / 16] = x[r];
+    }
 }
 
 template <int N, int R> struct PassGeom {

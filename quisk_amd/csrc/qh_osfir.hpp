@@ -175,8 +175,9 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 #ifndef QH_OSFIR_WAVES_F64_OUTMIX
 #define QH_OSFIR_WAVES_F64_OUTMIX 3
 #endif
-template <typename T, int D, bool OUTMIX = false> constexpr int osfir_min_waves()
+template <typename T, int D, bool OUTMIX = false, int NFFT = 4096> constexpr int osfir_min_waves()
 {
+    if (NFFT >= 8192) return sizeof(T) == 8 ? 1 : 2;        // 32 elements per lane: one 139 KB (fp64) image per CU anyway
     return sizeof(T) == 8 ? (D == 1 ? QH_OSFIR_WAVES_F64_D1 : OUTMIX ? QH_OSFIR_WAVES_F64_OUTMIX : QH_OSFIR_WAVES_F64) : 4;
 }
 
@@ -248,7 +249,7 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
 }
 
 template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false>
-__global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX>())) void osfir_kernel(OsfirArgs<T> a)
+__global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
     constexpr int E = NFFT / NT;            // elements per thread, forward

@@ -130,9 +130,9 @@ def test_unsupported_requests_fail_loudly(qh):
     with pytest.raises(qh.QuiskHipError):
         e.process_host(x)
     with pytest.raises(qh.QuiskHipError):
-        e.RXASetNC(0, 4096)                     # nc > 2048 is not provided
+        e.RXASetNC(0, 8192)                     # nc > 4096 is not provided (8192-point tiles at most)
     with pytest.raises(qh.QuiskHipError):
-        qh.RxaEngine(1, in_rate=44100)          # in_rate must be 1/2/4/8 x dsp_rate
+        qh.RxaEngine(1, in_rate=44100)          # in_rate / dsp_rate must be whole one way or the other (wdsp/channel.c:39-42)
 
 
 def _agc_signal(n, fs=192000.0):
@@ -407,3 +407,32 @@ def test_general_input_rate_ratios(qh, oracle, in_rate, nblk):
     if in_rate == 144000:
         with pytest.raises(qh.QuiskHipError):
             qh.RxaEngine(1, in_rate=72000)
+
+
+@pytest.mark.parametrize("mode,settle", [(1, 0), (6, 0), (5, 150)])
+def test_long_filters_nc_4096_and_back(qh, oracle, mode, settle):
+    """RXASetNC(4096) (wdsp/RXA.c:934-946): impulse responses longer than 2048 taps run 8192-point overlap-save tiles; the
+    change of nc zeroes the delay lines like setNc_fircore does, and going back to 2048 returns to 4096-point tiles."""
+    nblk = 210 if mode == 5 else 60
+    sig = {1: "usb", 6: "am", 5: "fm"}[mode]
+    x = synth.make_mode_input_numpy(sig, 0, nblk * 1024)
+    pb = {1: (300.0, 3000.0), 6: (-4000.0, 4000.0), 5: (-8000.0, 8000.0)}[mode]
+    e = qh.RxaEngine(1)
+    o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+    for obj, pre in ((e, (0,)), (o, ())):
+        obj.SetRXAShiftRun(*pre, 1); obj.SetRXAShiftFreq(*pre, synth.shift_freq(0)); obj.RXANBPSetRun(*pre, 1)
+        obj.SetRXAMode(*pre, mode); obj.RXASetPassband(*pre, *pb); obj.SetRXAAGCMode(*pre, 0); obj.SetRXAAGCFixed(*pre, 0.0)
+    e.enable_meters(True)
+    ys, rs = [], []
+    cuts = [0, nblk // 3, 2 * nblk // 3 + 1, nblk]
+    for k, nc in enumerate((None, 4096, 2048)):
+        if nc:
+            e.RXASetNC(0, nc); o.RXASetNC(nc)
+        seg = x[cuts[k] * 1024:cuts[k + 1] * 1024]
+        ys.append(e.process_host(seg[None, :])[0]); rs.append(o.xrxa(seg))
+    y, ref = np.concatenate(ys), np.concatenate(rs)
+    lo = settle * 256
+    assert rel_rms(y[lo:], ref[lo:]) < (1e-9 if settle == 0 else 1e-6)
+    if mode == 1:
+        for mt in (0, 1, 2, 3, 5, 6):
+            assert abs(e.GetRXAMeter(0, mt) - o.GetRXAMeter(mt)) < 0.002, mt
