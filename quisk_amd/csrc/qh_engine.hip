@@ -20,7 +20,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/quiskhip.h"
@@ -86,6 +88,7 @@ struct ChanCfg {
     // emnr (create_emnr of create_rxa, RXA.c:319-332)
     // snba (wdsp/snb.c) and its bandpass bpsnba (snb.c:696-855; run / position follow the mode, RXA.c:883-917)
     int snba_run = 0, snb_hist_at = 0;
+    int fm_hist_at = 0;                                         // ping-pong half that holds this channel's FM fircore delay lines
     bool snba_flush = false, snba_taps_dirty = true, snba_rout_flush = false, snb_dirty = true, snb_flush = false;
     double snba_f_low = 200.0, snba_f_high = 0.0;               // outresamp fc_low / fcin (snb.c:45-46, resample.c:195-204)
     int snb_pos() const {
@@ -182,7 +185,7 @@ struct Engine {
     SnbaParam snba_prm{};
     double *snba_state = nullptr, *snba_hin = nullptr, *snba_hout = nullptr, *snba_scratch = nullptr;
     SnbaIdx *snba_idx = nullptr;
-    std::vector<char> snb_listed;
+    std::vector<char> snb_listed, fm_listed;
     int snba_alloc();
     EmnrParam emnr_prm{};
     EmnrChan *emnr_chan = nullptr;
@@ -721,6 +724,25 @@ int Engine::refresh_demod()
                     c.snb_hist_at = cur_snb;
                     snb_listed[(size_t)ch] = 1;
                 }
+        }
+        {
+            // the FM de-emphasis / audio fircores keep their delay lines while the channel is in another mode (SetRXAMode only
+            // clears fmd's run flag, RXA.c:758-776): the ping-pong pair flips for the listed channels only, so a channel that
+            // comes back finds its rows in the half that was current when it left
+            if (fm_listed.size() != (size_t)nch) fm_listed.assign((size_t)nch, 0);
+            for (int ch = 0; ch < nch; ch++) if (fm_listed[(size_t)ch]) cfg[(size_t)ch].fm_hist_at = cur_de;
+            std::fill(fm_listed.begin(), fm_listed.end(), 0);
+            for (int ch : lf) {
+                ChanCfg &c = cfg[(size_t)ch];
+                if (c.fm_hist_at != cur_de) {
+                    QH_HIP(hipMemcpyAsync(hist_de[cur_de] + (size_t)ch * kHistBand, hist_de[c.fm_hist_at] + (size_t)ch * kHistBand,
+                                          kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                    QH_HIP(hipMemcpyAsync(hist_aud[cur_aud] + (size_t)ch * kHistBand, hist_aud[c.fm_hist_at] + (size_t)ch * kHistBand,
+                                          kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                }
+                c.fm_hist_at = cur_de;
+                fm_listed[(size_t)ch] = 1;
+            }
         }
         if (n_amsq && !amsq_prm) {
             QH_HIP(dev_alloc(&amsq_prm, (size_t)nch));
@@ -1387,7 +1409,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
     {   // impulse responses longer than 2048 taps need 8192-point tiles; the masks are spectra of the tile size, so a change
         // of it rebuilds every fircore mask (the delay lines, kept 4095 samples deep, carry over)
-        const int want = nc_max > 2048 ? kBandNfftMax : kNfft;
+        static const bool force8k = [] { const char *e = std::getenv("QH_BAND_NFFT"); return e && std::atoi(e) == 8192; }();  // tuning experiments
+        const int want = (nc_max > 2048 || force8k) ? kBandNfftMax : kNfft;
         if (want != bnfft) {
             bnfft = want;
             for (ChanCfg &c : cfg) { c.nbp_dirty = c.bp1_dirty = true; c.snb_dirty = true; }
@@ -1610,7 +1633,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
 // ------------------------------------------------------------------------------------------ C ABI
 using namespace qh;
 
-struct qh_rxa { Engine e; };
+// One lock per engine: setters may come from another thread than the one that runs the blocks (Quisk's GUI thread against its
+// sound thread; WDSP's setters take csDSP).  A setter only edits the host-side configuration and marks it dirty; the next
+// process call uploads what changed before it enqueues the block, so parameters swap on a block boundary.
+struct qh_rxa { Engine e; std::recursive_mutex mtx; };
+#define QH_RXA_LOCK(h) std::lock_guard<std::recursive_mutex> _lk((h)->mtx)
 
 extern "C" {
 
@@ -1667,6 +1694,7 @@ long long qh_rxa_device_bytes(const qh_rxa *h) { return h->e.dev_bytes; }
 #define FOR_CH(h, ch, body)                                                                       \
     do {                                                                                          \
         if (!(h)) return set_error(QH_ERR_INVALID, "null engine");                                \
+        QH_RXA_LOCK(h);                                                                           \
         if ((ch) < -1 || (ch) >= (h)->e.nch) return set_error(QH_ERR_INVALID, "channel %d out of range", (ch)); \
         int _lo = (ch) < 0 ? 0 : (ch), _hi = (ch) < 0 ? (h)->e.nch : (ch) + 1;                    \
         (h)->e.epoch++;                                                                           \
@@ -1950,6 +1978,7 @@ int qh_rxa_SetEMNRTables(qh_rxa *h, const double *GG, const double *GGS, const d
                          double gamma_max, double xi_min, double xi_max)
 {
     if (!h || !GG || !GGS || !zeta_hat || !zeta_true) return set_error(QH_ERR_INVALID, "qh_rxa_SetEMNRTables: null table");
+    QH_RXA_LOCK(h);
     Engine &e = h->e;
     e.epoch++;
     e.h_GG.assign(GG, GG + 241 * 241); e.h_GGS.assign(GGS, GGS + 241 * 241);
@@ -2061,6 +2090,7 @@ int qh_rxa_SetRXAPanelCopy(qh_rxa *h, int ch, int cp) { FOR_CH(h, ch, { c.copy =
 int qh_rxa_process(qh_rxa *h, const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     if (!d_in || !d_out) return set_error(QH_ERR_INVALID, "null buffer");
     if (in_stride < (long long)nblk * h->e.dsp_insize || out_stride < (long long)nblk * h->e.dsp_outsize)
         return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
@@ -2089,6 +2119,7 @@ int qh_rxa_process_audio(qh_rxa *h, const double *d_in, long long in_stride, voi
                          const qh_audio_format *fmt)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     if (!d_in) return set_error(QH_ERR_INVALID, "null buffer");
     if (in_stride < (long long)nblk * h->e.dsp_insize) return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
     EgressFmt f{};
@@ -2118,6 +2149,7 @@ int qh_audio_pack(int device, void *stream, const double *d_src, long long src_s
 int qh_rxa_set_graph_replay(qh_rxa *h, int on)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     h->e.graph_on = on != 0;
     if (!on) { h->e.drop_graphs(); h->e.graph_key = Engine::GraphKey{}; }
     return QH_OK;
@@ -2176,6 +2208,7 @@ int qh_rxa_process_packed(qh_rxa *h, const void *d_src, long long src_bytes, con
                           double *d_out, long long out_stride, int nblk)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     if (!d_src || !d_out || !fmt) return set_error(QH_ERR_INVALID, "null buffer");
     if (out_stride < (long long)nblk * h->e.dsp_outsize) return set_error(QH_ERR_INVALID, "stride shorter than nblk blocks");
     PackedFmt pk;
@@ -2192,6 +2225,7 @@ int qh_rxa_process_packed(qh_rxa *h, const void *d_src, long long src_bytes, con
 int qh_rxa_flush(qh_rxa *h)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     Engine &e = h->e;
     e.epoch++;
     QH_HIP(hipSetDevice(e.device));
@@ -2229,6 +2263,7 @@ int qh_rxa_flush(qh_rxa *h)
 int qh_rxa_enable_meters(qh_rxa *h, int enable)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     h->e.meters_on = enable != 0;
     h->e.epoch++;                   // the meter launches join / leave the sequence
     return QH_OK;
@@ -2238,6 +2273,7 @@ int qh_rxa_enable_meters(qh_rxa *h, int enable)
 int qh_rxa_GetRXAMeter(qh_rxa *h, int ch, int mt, double *value)
 {
     if (!h || !value) return set_error(QH_ERR_INVALID, "null argument");
+    QH_RXA_LOCK(h);
     Engine &e = h->e;
     if (ch < 0 || ch >= e.nch || mt < 0 || mt > 6) return set_error(QH_ERR_INVALID, "channel or meter index out of range");
     if (!e.meters_on || !e.m_adc) { *value = -400.0; return QH_OK; }             // flush_meter's initial reading
@@ -2275,6 +2311,7 @@ long long qh_rxa_pll_repairs(qh_rxa *h)
 int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     Engine &e = h->e;
     if (check_only >= 0) e.pll_check_only = check_only;
     if (!out || max <= 0 || !e.pll_ends) return 0;
@@ -2289,6 +2326,7 @@ int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
 int qh_rxa_synchronize(qh_rxa *h)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     QH_HIP(hipSetDevice(h->e.device));
     QH_HIP(hipStreamSynchronize(h->e.stream));
     return QH_OK;
@@ -2297,6 +2335,7 @@ int qh_rxa_synchronize(qh_rxa *h)
 int qh_rxa_process_host(qh_rxa *h, const double *h_in, long long in_stride, double *h_out, long long out_stride, int nblk)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     if (!h_in || !h_out) return set_error(QH_ERR_INVALID, "null buffer");
     Engine &e = h->e;
     QH_HIP(hipSetDevice(e.device));
@@ -2325,6 +2364,7 @@ int qh_rxa_process_packed_host(qh_rxa *h, const void *h_src, long long src_bytes
                                double *h_out, long long out_stride, int nblk)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     if (!h_src || !h_out || src_bytes <= 0) return set_error(QH_ERR_INVALID, "null buffer");
     Engine &e = h->e;
     QH_HIP(hipSetDevice(e.device));
@@ -2352,6 +2392,7 @@ int qh_rxa_process_packed_host(qh_rxa *h, const void *h_src, long long src_bytes
 int qh_rxa_enable_timing(qh_rxa *h, int enable)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     h->e.timing = enable != 0;
     return QH_OK;
 }
@@ -2359,6 +2400,7 @@ int qh_rxa_enable_timing(qh_rxa *h, int enable)
 int qh_rxa_timing(qh_rxa *h, double *ms, int n)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
     Engine &e = h->e;
     QH_HIP(hipSetDevice(e.device));
     QH_HIP(hipStreamSynchronize(e.stream));

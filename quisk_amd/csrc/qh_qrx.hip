@@ -11,6 +11,7 @@
 // plus a detector kernel for AM (envelope, DC remover) and FM (phase difference, de-emphasis).  Results equal the
 // staged computation to rounding.  Stops before process_agc.
 #include <cmath>
+#include <mutex>
 #include <vector>
 #include "qh_stage.hpp"
 #include "qh_qdemod.hpp"
@@ -233,7 +234,9 @@ struct Qrx {
 }  // namespace qh
 
 using namespace qh;
-struct qh_qrx { Qrx q; };
+// one lock per bank: setters (GUI thread) against the thread that runs the blocks
+struct qh_qrx { Qrx q; std::recursive_mutex mtx; };
+#define QH_QRX_LOCK(h) std::unique_lock<std::recursive_mutex> _lk; if (h) _lk = std::unique_lock<std::recursive_mutex>((h)->mtx)
 
 extern "C" {
 
@@ -434,6 +437,7 @@ int qh_qrx_filter_rate(const qh_qrx *h) { return h ? h->q.filter_srate : 0; }
 // set_tune (quisk.c:4702): the stream is multiplied by exp(-j 2 pi tune n / sample_rate)
 int qh_qrx_set_tune(qh_qrx *h, int ch, int rx_tune_freq)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
@@ -447,6 +451,7 @@ int qh_qrx_set_tune(qh_qrx *h, int ch, int rx_tune_freq)
 // g[0] = h[0], g[d] = h[N-d].  SSB/CW keep re -+ im = Re{(gI +- j gQ) * x}; AM/FM use filtI on both parts.
 int qh_qrx_set_filters(qh_qrx *h, int ch, const double *filtI, const double *filtQ, int size)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
@@ -484,6 +489,7 @@ int qh_qrx_decim_rate(const qh_qrx *h) { return h ? h->q.decim_srate : 0; }
 
 int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in, double *d_out, long long out_stride, int *n_out)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     if (n_out) *n_out = 0;
     if (n_in <= 0) return QH_OK;
@@ -603,6 +609,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
 // audio delay in the path, as in the reference.
 int qh_qrx_set_ssb_squelch(qh_qrx *h, int enabled, int level)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     if (!q.has_ssb_sq) return set_error(QH_ERR_UNSUPPORTED, "ssb_squelch belongs to the CW, SSB and AM modes (quisk.c:1925,1970,2020)");
@@ -630,6 +637,7 @@ int qh_qrx_set_ssb_squelch(qh_qrx *h, int enabled, int level)
 // set_squelch (quisk.c:4721-4727): the FM squelch threshold in dB re full scale; -999 (the default) never mutes
 int qh_qrx_set_squelch(qh_qrx *h, int ch, double level)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
@@ -643,6 +651,7 @@ int qh_qrx_set_squelch(qh_qrx *h, int ch, double level)
 // time 1.0 s (quisk.c:192), |z| for DGT-IQ and |Re z| otherwise (quisk.c:2686-2702), playback rate = decim rate
 int qh_qrx_set_agc(qh_qrx *h, int on, double release_gain)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     q.agc_on = on != 0;
@@ -659,6 +668,7 @@ int qh_qrx_set_agc(qh_qrx *h, int on, double release_gain)
 // sidetone): stores the flag and starts the notch state over, like dAutoNotch(NULL, 0, 0, 0)
 int qh_qrx_set_auto_notch(qh_qrx *h, int on, int rit_freq)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     bool has = false;
@@ -684,6 +694,7 @@ int qh_qrx_set_auto_notch(qh_qrx *h, int on, int rit_freq)
 // set_noise_blanker (quisk.c:4605): the blanker runs on the raw samples, ahead of the tune
 int qh_qrx_set_noise_blanker(qh_qrx *h, int level)
 {
+    QH_QRX_LOCK(h);
     if (!h || level < 0) return set_error(QH_ERR_INVALID, "qh_qrx_set_noise_blanker: bad arguments");
     Qrx &q = h->q;
     if (!q.nb) {
@@ -697,6 +708,7 @@ int qh_qrx_set_noise_blanker(qh_qrx *h, int level)
 
 int qh_qrx_process_host(qh_qrx *h, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     if (n_out) *n_out = 0;
     if (n_in <= 0) return QH_OK;
@@ -721,6 +733,7 @@ int qh_qrx_process_host(qh_qrx *h, const double *h_in, long long in_stride, int 
 
 int qh_qrx_synchronize(qh_qrx *h)
 {
+    QH_QRX_LOCK(h);
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     QH_HIP(hipSetDevice(h->q.device));
     QH_HIP(hipStreamSynchronize(h->q.stream));

@@ -27,7 +27,12 @@ struct Key {
 };
 
 std::mutex g_mtx;
-std::map<Key, qh_fir *> g_banks;            // one single-channel bank per distinct (taps, decimation)
+// one single-channel bank per distinct (taps, decimation), at most kCacheCap of them: quisk_filt_tune rewrites cpxCoefs in place,
+// so every retune is a new checksum; the entry used longest ago makes room
+constexpr size_t kCacheCap = 32;
+unsigned long long g_tick = 0;
+struct FirEntry { qh_fir *bank; unsigned long long used; };
+std::map<Key, FirEntry> g_banks;
 
 unsigned long long checksum(const double *p, size_t n)
 {
@@ -44,7 +49,13 @@ qh_fir *bank_for(const double *re_or_interleaved, int ntaps, int decim, bool cpl
 {
     Key k{ re_or_interleaved, ntaps, decim, cplx ? 1 : 0, checksum(re_or_interleaved, (size_t)ntaps * (cplx ? 2 : 1)) };
     auto it = g_banks.find(k);
-    if (it != g_banks.end()) return it->second;
+    if (it != g_banks.end()) { it->second.used = ++g_tick; return it->second.bank; }
+    if (g_banks.size() >= kCacheCap) {
+        auto old = g_banks.begin();
+        for (auto e = g_banks.begin(); e != g_banks.end(); ++e) if (e->second.used < old->second.used) old = e;
+        qh_fir_destroy(old->second.bank);
+        g_banks.erase(old);
+    }
     qh_fir *b;
     if (cplx) {
         std::vector<double> re((size_t)ntaps), im((size_t)ntaps);
@@ -53,7 +64,7 @@ qh_fir *bank_for(const double *re_or_interleaved, int ntaps, int decim, bool cpl
     } else {
         b = qh_fir_create(0, 1, re_or_interleaved, nullptr, ntaps, decim, QH_F64, nullptr);
     }
-    if (b) g_banks[k] = b;
+    if (b) g_banks[k] = FirEntry{ b, ++g_tick };
     return b;
 }
 
@@ -118,15 +129,22 @@ struct RatKey {
         return sum < o.sum;
     }
 };
-std::map<RatKey, qh_rat *> g_rats;
+struct RatEntry { qh_rat *rat; unsigned long long used; };
+std::map<RatKey, RatEntry> g_rats;
 
 qh_rat *rat_for(const double *taps, int ntaps, int interp, int decim)
 {
     RatKey k{ taps, ntaps, interp, decim, checksum(taps, (size_t)ntaps) };
     auto it = g_rats.find(k);
-    if (it != g_rats.end()) return it->second;
+    if (it != g_rats.end()) { it->second.used = ++g_tick; return it->second.rat; }
+    if (g_rats.size() >= kCacheCap) {
+        auto old = g_rats.begin();
+        for (auto e = g_rats.begin(); e != g_rats.end(); ++e) if (e->second.used < old->second.used) old = e;
+        qh_rat_destroy(old->second.rat);
+        g_rats.erase(old);
+    }
     qh_rat *b = qh_rat_create(0, 1, taps, ntaps, interp, decim, QH_F64, nullptr);
-    if (b) g_rats[k] = b;
+    if (b) g_rats[k] = RatEntry{ b, ++g_tick };
     return b;
 }
 

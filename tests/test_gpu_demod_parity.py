@@ -133,3 +133,31 @@ def test_fm_detector_limiter(qh, oracle):
     for c in range(nch):
         assert rel_rms(y[c][lo:], refs[c][lo:]) < 1e-6, (c, rel_rms(y[c][lo:], refs[c][lo:]))
     assert rel_rms(refs[0][lo:], refs[1][lo:] ) > 1e-2                 # the limiter does something
+
+
+def test_fm_channel_leaves_and_returns_keeps_its_delay_lines(qh, oracle):
+    """SetRXAMode only clears fmd's run flag (RXA.c:758-776): the de-emphasis and audio fircores keep their delay lines while
+    the channel is in another mode.  Channel 0 goes FM -> USB for an ODD number of calls -> FM while channel 1 stays in FM (so
+    the engine's ping-pong history pair keeps flipping): the first blocks after the return still hold the old samples."""
+    nblk = 60
+    x = np.stack([synth.make_mode_input_numpy("fm", c, 5 * nblk * 1024) for c in range(2)])
+    e = qh.RxaEngine(2)
+    os_ = []
+    for c in range(2):
+        _cfg_engine(e, c, FM)
+        os_.append(_cfg_oracle(oracle, c, FM))
+    plan = [(FM, 2 * nblk), (USB, 7), (USB, 5), (USB, 9), (FM, nblk)]          # 3 calls away
+    pos, got, ref = 0, None, None
+    for mode, nb in plan:
+        e.SetRXAMode(0, mode); os_[0].SetRXAMode(mode)
+        if mode == USB:
+            e.RXASetPassband(0, 300.0, 3000.0); os_[0].RXASetPassband(300.0, 3000.0)
+        else:
+            e.RXASetPassband(0, -8000.0, 8000.0); os_[0].RXASetPassband(-8000.0, 8000.0)
+        seg = np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024])
+        pos += nb
+        got = e.process_host(seg)
+        ref = [os_[c].xrxa(seg[c]) for c in range(2)]
+    # the last segment: channel 0 is back in FM; compare from its first sample on
+    assert rel_rms(got[0], ref[0]) < 1e-6
+    assert rel_rms(got[1][20 * 256:], ref[1][20 * 256:]) < 1e-6
