@@ -228,56 +228,51 @@ static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, lo
 // the chunk's 64 samples of (1 - m) m^(63 - i) |z_i|^2, y = max |z_i|^2): the one-pole average advances a chunk at a time,
 // avg <- m^64 avg + x, and the peak a DSP block (cpb chunks) at a time, peak <- max(peak * mp^(64 cpb), block max).  Both
 // recurrences are linear (the second over (max, *)), so their value at the end of the call is a weighted sum / maximum of
-// independent pieces: every thread of the workgroup walks its own short run of consecutive chunks from a zero state,
-// weights the result by the decay from the end of its run to the end of the call, and one reduction joins them with the
-// carried state.  One workgroup per channel and meter; blockIdx.y: 0 = adc meter (partials of the stage input), 1 = S
-// meter, 2 = agc meter (both on the stage output, the agc meter behind the fixed gain g: gain2 = g^2).
+// independent pieces: every chunk's partial carries its own decay to the end of the call, and one reduction joins them
+// with the carried state.  One workgroup per channel serves the three meters: adc meter (partials of the stage input), S meter and agc
+// meter (both on the stage output, the agc meter behind the fixed gain g: gain2 = g^2).
 // wdsp/RXA.c:566,569,589.  Storage: tile-major, inside a tile [wave][register] (cpt chunks per tile).
 static constexpr int kMeterFinishThreads = 1024;
+// m^k for the meters' decay factors m = exp(-1 / (rate tau)): exp(k ln m) with ln m exact by construction
+__device__ __forceinline__ double meter_decay(double ln_m, double k) { return exp(k * ln_m); }
+
 static __global__ __launch_bounds__(kMeterFinishThreads) void meter_finish_kernel(const double2 *part_in, const double2 *part_out,
                                                                  long long stride, int nchunks, int cpb, int cpt, MeterState *m_adc,
-                                                                 MeterState *m_s, MeterState *m_agc, MeterParam q, const double *gain2)
+                                                                 MeterState *m_s, MeterState *m_agc, double ln_avg, double ln_pk,
+                                                                 const double *gain2)
 {
-    __shared__ double s_avg[kMeterFinishThreads / 64], s_pk[kMeterFinishThreads / 64];
-    const int ch = blockIdx.x, which = blockIdx.y, T = threadIdx.x, lane = T & 63, wave = T >> 6;
-    const double2 *p = (which == 0 ? part_in : part_out) + (long long)ch * stride;
-    MeterState *state = which == 0 ? m_adc : which == 1 ? m_s : m_agc;
-    const double g2 = (which == 2 && gain2) ? gain2[ch] : 1.0;
-    double m64 = q.mult_average;
-#pragma unroll
-    for (int k = 0; k < 6; k++) m64 *= m64;
-    const double pk_blk = pow(q.mult_peak, (double)(cpb * 64));
-    const int nseg = cpt >> 2;
-    // runs of whole DSP blocks: per = chunks per thread
-    const int per = ((nchunks + kMeterFinishThreads * cpb - 1) / (kMeterFinishThreads * cpb)) * cpb;
-    const int c0 = T * per < nchunks ? T * per : nchunks, c1 = (T + 1) * per < nchunks ? (T + 1) * per : nchunks;
-    double avg = 0.0, peak = 0.0;
-    if (c1 > c0) {
-        int tile = c0 / cpt, k = c0 - tile * cpt;           // chunk k of the tile: register k >> 2, wave k & 3
-        for (int c = c0; c < c1; c += cpb) {
-            double np = 0.0;
-            for (int j = 0; j < cpb; j++) {
-                const double2 v = p[(long long)tile * cpt + (k & 3) * nseg + (k >> 2)];
-                avg = __builtin_fma(avg, m64, v.x);
-                np = fmax(np, v.y);
-                if (++k == cpt) { k = 0; tile++; }
-            }
-            peak = fmax(peak * pk_blk, np);
-        }
-        const double left = (double)(nchunks - c1);         // chunks between the end of this run and the end of the call
-        avg *= pow(m64, left);
-        peak *= pow(q.mult_peak, 64.0 * left);
+    __shared__ double s_red[kMeterFinishThreads / 64][4];
+    const int ch = blockIdx.x, T = threadIdx.x, lane = T & 63, wave = T >> 6;
+    const double2 *pi = part_in + (long long)ch * stride, *po = part_out + (long long)ch * stride;
+    const int nseg = cpt >> 2, nblocks = nchunks / cpb;
+    // Both recurrences unrolled: chunk c of the call weighs m^(64 (nchunks - 1 - c)) in the average, and the peak of DSP
+    // block b weighs mp^(size (nblocks - 1 - b)) in the peak.  Lanes read consecutive partials (storage order) and weigh
+    // each by its own place in time.
+    double avg_i = 0.0, peak_i = 0.0, avg_o = 0.0, peak_o = 0.0;        // adc meter (stage input), S meter (stage output)
+    const int nslots = (nchunks + cpt - 1) / cpt * cpt;                 // the last tile may hold fewer chunks than slots
+    for (int s0 = T; s0 < nslots; s0 += kMeterFinishThreads) {
+        const int tile = s0 / cpt, in = s0 - tile * cpt;
+        const int c = tile * cpt + 4 * (in % nseg) + in / nseg;         // [wave][register] -> chunk 4 register + wave
+        if (c >= nchunks) continue;
+        const double2 vi = pi[s0], vo = po[s0];
+        const double wa = meter_decay(ln_avg, 64.0 * (double)(nchunks - 1 - c));
+        const double wp = meter_decay(ln_pk, 64.0 * (double)cpb * (double)(nblocks - 1 - c / cpb));
+        avg_i = __builtin_fma(vi.x, wa, avg_i); peak_i = fmax(peak_i, vi.y * wp);
+        avg_o = __builtin_fma(vo.x, wa, avg_o); peak_o = fmax(peak_o, vo.y * wp);
     }
-    avg = wave_sum_d(avg);
-    peak = wave_max_d(peak);
-    if (lane == 0) { s_avg[wave] = avg; s_pk[wave] = peak; }
+    avg_i = wave_sum_d(avg_i); avg_o = wave_sum_d(avg_o);
+    peak_i = wave_max_d(peak_i); peak_o = wave_max_d(peak_o);
+    if (lane == 0) { s_red[wave][0] = avg_i; s_red[wave][1] = peak_i; s_red[wave][2] = avg_o; s_red[wave][3] = peak_o; }
     __syncthreads();
-    if (T == 0) {
-        MeterState st = state[ch];
+    if (T < 3) {            // thread 0: adc meter, 1: S meter, 2: agc meter (the S meter's sums behind the fixed gain g: g^2)
         double a = 0.0, pk = 0.0;
-        for (int w = 0; w < kMeterFinishThreads / 64; w++) { a += s_avg[w]; pk = fmax(pk, s_pk[w]); }
-        st.avg = st.avg * pow(m64, (double)nchunks) + g2 * a;
-        st.peak = fmax(st.peak * pow(q.mult_peak, 64.0 * (double)nchunks), g2 * pk);
+        const int col = T == 0 ? 0 : 2;
+        for (int w = 0; w < kMeterFinishThreads / 64; w++) { a += s_red[w][col]; pk = fmax(pk, s_red[w][col + 1]); }
+        MeterState *state = T == 0 ? m_adc : T == 1 ? m_s : m_agc;
+        const double g2 = (T == 2 && gain2) ? gain2[ch] : 1.0;
+        MeterState st = state[ch];
+        st.avg = st.avg * meter_decay(ln_avg, 64.0 * (double)nchunks) + g2 * a;
+        st.peak = fmax(st.peak * meter_decay(ln_pk, 64.0 * (double)nchunks), g2 * pk);
         st.res_av = 10.0 * mlog10_dev(st.avg + 1.0e-40);
         st.res_pk = 10.0 * mlog10_dev(st.peak + 1.0e-40);
         state[ch] = st;

@@ -1473,8 +1473,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             cur = dst; cur_stride = dst_stride; stage++;
         }
         if (meters_fused)
-            hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch, 3), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
-                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, m_adc, m_s, m_agc, m_prm, (const double *)m_g2);
+            hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
+                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, m_adc, m_s, m_agc,
+                               -1.0 / ((double)dsp_rate * 0.100), -1.0 / ((double)dsp_rate * 0.100), (const double *)m_g2);
         if (eg.kind && !eg_fused) pack_audio(out, out_stride, n_mid);
         tick(3);
         QH_HIP(hipGetLastError());

@@ -360,8 +360,10 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
     QH_OPROBE(4);
     if constexpr (METER) {
         __syncthreads();                    // other waves may still be reading the exchange image
-        meter_tap<C, EO>(z, a.P >> 8, a.meter_w[t & 63], reinterpret_cast<double *>(lds) + (t >> 6) * kMeterLdsDoublesPerWave,
-                         a.meter_out + (long long)ch * a.meter_stride + (long long)tile * (a.Lout >> 6), t >> 6, t & 63);
+        int t2 = t;
+        asm volatile("" : "+v"(t2));        // the lane's weight and block address are derived again, not carried through both transforms
+        meter_tap<C, EO>(z, a.P >> 8, a.meter_w[t2 & 63], reinterpret_cast<double *>(lds) + (t2 >> 6) * kMeterLdsDoublesPerWave,
+                         a.meter_out + (long long)ch * a.meter_stride + (long long)tile * (a.Lout >> 6), t2 >> 6, t2 & 63);
     }
 
     if constexpr (OUTMIX) {
