@@ -70,6 +70,30 @@ __device__ __forceinline__ int seg_samples(int n, int b0, int b1)
     return hi - lo;
 }
 
+// Batches in flight per wavefront: a segment is walked in groups of kSegGroup batches, the next group's loads issued ahead
+// of the work on the current one (the recurrences chain the batches, the loads do not).
+static constexpr int kSegGroup = 8;
+template <typename V>
+__device__ __forceinline__ void seg_load(V (&z)[kSegGroup], int b, int b1, int n, int lane, const V *p)
+{
+#pragma unroll
+    for (int k = 0; k < kSegGroup; k++) {
+        const int i = (b + k) * 64 + lane;
+        z[k] = V{};
+        if (b + k < b1 && i < n) z[k] = p[i];
+    }
+}
+
+__device__ __forceinline__ void seg_load_re(double (&z)[kSegGroup], int b, int b1, int n, int lane, const double2 *p)
+{
+#pragma unroll
+    for (int k = 0; k < kSegGroup; k++) {
+        const int i = (b + k) * 64 + lane;
+        z[k] = 0.0;
+        if (b + k < b1 && i < n) z[k] = p[i].x;
+    }
+}
+
 // ---- AM envelope detector + fade leveller (xamd mode 0, wdsp/amd.c:131-146), in place, z -> (audio, audio) ------------
 static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                                              const int *levelfade, AmState *state, AmParam prm)
@@ -82,23 +106,31 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
     int b0, b1;
     seg_range(n, wave, b0, b1);
     const PoleScan sR = make_pole_scan(prm.mtauR, lane), sI = make_pole_scan(prm.mtauI, lane);
-    // pass 1: the magnitudes (the output already when the leveller is off) and the segment's response to its own samples
-    double eR = 0.0, eI = 0.0;
-    for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
-        double a = 0.0;
-        if (lane < cnt) {
-            const double2 z = p[base + lane];
-            a = sqrt(z.x * z.x + z.y * z.y);
-            p[base + lane] = make_double2(a, a);
-        }
-        if (lf) {
-            const double vR = scan_pole_dpp(prm.onem_mtauR * a, sR) + sR.pw * eR;
-            const double vI = scan_pole_dpp(prm.onem_mtauI * a, sI) + sI.pw * eI;
-            eR = lane_bcast(vR, cnt - 1); eI = lane_bcast(vI, cnt - 1);
+    // pass 1: the magnitudes (the output already when the leveller is off) and the segment's response to its own samples.
+    // Only the END value is wanted here, so no scan: lane l keeps sum_b u[64 b + l] (m^64)^(B - 1 - b), one FMA per batch,
+    // and one weighted wave sum closes the segment.  (The batch that is cut short by the end of the call belongs to the
+    // last segment with samples, whose end value nobody reads.)
+    const double m64R = lane_pow(prm.mtauR, 64), m64I = lane_pow(prm.mtauI, 64);
+    double accR = 0.0, accI = 0.0;
+    double2 zn[kSegGroup];
+    seg_load(zn, b0, b1, n, lane, p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double2 z[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) z[k] = zn[k];
+        seg_load(zn, b + kSegGroup, b1, n, lane, p);        // the next group is on its way while this one is worked on
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;                         // wave-uniform
+            const int i = (b + k) * 64 + lane;
+            const double a = sqrt(z[k].x * z[k].x + z[k].y * z[k].y);
+            if (i < n) p[i] = make_double2(a, a);
+            accR = __builtin_fma(accR, m64R, prm.onem_mtauR * a);
+            accI = __builtin_fma(accI, m64I, prm.onem_mtauI * a);
         }
     }
     if (!lf) return;                                    // block-uniform
+    const double eR = wave_sum_d(accR * lane_pow(prm.mtauR, 63 - lane)), eI = wave_sum_d(accI * lane_pow(prm.mtauI, 63 - lane));
     if (lane == 0) { s_e[wave][0] = eR; s_e[wave][1] = eI; s_n[wave] = seg_samples(n, b0, b1); }
     __syncthreads();
     // the true state at the start of this segment: dc <- mtau^len dc + e over the segments before it
@@ -109,14 +141,24 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
         cI = __builtin_fma(cI, pow(prm.mtauI, len), s_e[w][1]);
     }
     // pass 2
-    for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
-        const double a = lane < cnt ? p[base + lane].x : 0.0;
-        const double dc = scan_pole_dpp(prm.onem_mtauR * a, sR) + sR.pw * cR;       // amd.c:136-137
-        const double di = scan_pole_dpp(prm.onem_mtauI * a, sI) + sI.pw * cI;
-        const double audio = a + (di - dc);                                          // amd.c:138
-        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
-        cR = lane_bcast(dc, cnt - 1); cI = lane_bcast(di, cnt - 1);
+    double an[kSegGroup];
+    seg_load_re(an, b0, b1, n, lane, p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double av[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) av[k] = an[k];
+        seg_load_re(an, b + kSegGroup, b1, n, lane, p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double a = av[k];
+            const double dc = scan_pole_dpp(prm.onem_mtauR * a, sR) + sR.pw * cR;       // amd.c:136-137
+            const double di = scan_pole_dpp(prm.onem_mtauI * a, sI) + sI.pw * cI;
+            const double audio = a + (di - dc);                                          // amd.c:138
+            if (lane < cnt) p[base + lane] = make_double2(audio, audio);
+            cR = lane_bcast(dc, cnt - 1); cI = lane_bcast(di, cnt - 1);
+        }
     }
     int last = kSegWaves - 1;                           // the wavefront that holds the last sample of the call
     while (last > 0 && s_n[last] == 0) last--;
@@ -177,16 +219,36 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
     // the forcing term needs x two samples back: from the buffer (pass 1 leaves it untouched), from the carried state at
     // the very beginning; pass 2 overwrites x with y, so every segment's last two inputs are put aside for its successor
     auto x_at = [&](int i) -> double { return i >= 0 ? p[i].x : (i == -1 ? st0.x1 : st0.x2); };
-    // pass 1: response of the zero state to the segment's forcing
-    double e0 = 0.0, e1 = 0.0;
-    for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64, i = base + lane;
-        double u0 = 0.0, u1 = 0.0;
-        if (lane < cnt) u0 = q.a0 * x_at(i) + q.a1 * x_at(i - 1) + q.a2 * x_at(i - 2);
-        scan_biquad_dpp(u0, u1, sc);
-        const double y0 = u0 + sc.pw.a * e0 + sc.pw.b * e1, y1 = u1 + sc.pw.c * e0 + sc.pw.d * e1;
-        e0 = lane_bcast(y0, cnt - 1); e1 = lane_bcast(y1, cnt - 1);
+    // pass 1: response of the zero state to the segment's forcing.  End value only: lane l keeps
+    // sum_b (A^64)^(B - 1 - b) (u[64 b + l], 0), and sum_l A^(63 - l) acc_l closes the segment.
+    const M2 A64 = m2_pow(A, 64);
+    double acc0 = 0.0, acc1 = 0.0;
+    double xm1 = x_at(b0 * 64 - 1), xm2 = x_at(b0 * 64 - 2);
+    double xn[kSegGroup];
+    seg_load_re(xn, b0, b1, n, lane, p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double xv[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) xv[k] = xn[k];
+        seg_load_re(xn, b + kSegGroup, b1, n, lane, p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double x0 = xv[k];
+            double x1 = dpp_fetch_d<0x138, 0xf>(x0), x2 = dpp_fetch_d<0x138, 0xf>(x1);    // wave_shr:1, twice
+            if (lane == 0) { x1 = xm1; x2 = xm2; }
+            if (lane == 1) x2 = xm1;
+            const double u = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0;
+            const double t0 = A64.a * acc0 + A64.b * acc1 + u, t1 = A64.c * acc0 + A64.d * acc1;
+            acc0 = t0; acc1 = t1;
+            const double prev1 = xm1;
+            xm1 = lane_bcast(x0, cnt - 1);
+            xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
+        }
     }
+    const M2 W = m2_pow(A, 63 - lane);
+    const double e0 = wave_sum_d(W.a * acc0 + W.b * acc1), e1 = wave_sum_d(W.c * acc0 + W.d * acc1);
     const int ns = seg_samples(n, b0, b1);
     if (lane == 0) {
         const int end = b0 * 64 + ns;                   // one past the segment's last sample
@@ -195,7 +257,8 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
     }
     __syncthreads();
     // true (y_{-1}, y_{-2}) and (x_{-1}, x_{-2}) at the start of this segment
-    double c0 = st0.y1, c1 = st0.y2, xm1 = st0.x1, xm2 = st0.x2;
+    double c0 = st0.y1, c1 = st0.y2;
+    xm1 = st0.x1; xm2 = st0.x2;
     for (int w = 0; w < wave; w++) {
         if (s_n[w] == 0) continue;
         const M2 T = m2_pow(A, s_n[w]);
@@ -204,22 +267,29 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
         xm1 = s_x[w][0]; xm2 = s_x[w][1];
     }
     // pass 2 (every segment's boundary inputs were put aside before the barrier above: in-place writes are safe now)
-    for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
-        double2 z = make_double2(0, 0);
-        if (lane < cnt) z = p[base + lane];
-        const double x0 = z.x;
-        double x1 = dpp_fetch_d<0x138, 0xf>(x0), x2 = dpp_fetch_d<0x138, 0xf>(x1);    // wave_shr:1, twice
-        if (lane == 0) { x1 = xm1; x2 = xm2; }
-        if (lane == 1) x2 = xm1;
-        double u0 = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0, u1 = 0.0;
-        scan_biquad_dpp(u0, u1, sc);
-        const double y0 = u0 + sc.pw.a * c0 + sc.pw.b * c1, y1 = u1 + sc.pw.c * c0 + sc.pw.d * c1;
-        if (lane < cnt) p[base + lane] = make_double2(y0, z.y);
-        c0 = lane_bcast(y0, cnt - 1); c1 = lane_bcast(y1, cnt - 1);
-        const double prev1 = xm1;
-        xm1 = lane_bcast(x0, cnt - 1);
-        xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
+    seg_load_re(xn, b0, b1, n, lane, p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double xv[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) xv[k] = xn[k];
+        seg_load_re(xn, b + kSegGroup, b1, n, lane, p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double x0 = xv[k];
+            double x1 = dpp_fetch_d<0x138, 0xf>(x0), x2 = dpp_fetch_d<0x138, 0xf>(x1);    // wave_shr:1, twice
+            if (lane == 0) { x1 = xm1; x2 = xm2; }
+            if (lane == 1) x2 = xm1;
+            double u0 = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0, u1 = 0.0;
+            scan_biquad_dpp(u0, u1, sc);
+            const double y0 = u0 + sc.pw.a * c0 + sc.pw.b * c1, y1 = u1 + sc.pw.c * c0 + sc.pw.d * c1;
+            if (lane < cnt) p[base + lane].x = y0;                  // the Q component passes (iir.c:76-95 filters I only)
+            c0 = lane_bcast(y0, cnt - 1); c1 = lane_bcast(y1, cnt - 1);
+            const double prev1 = xm1;
+            xm1 = lane_bcast(x0, cnt - 1);
+            xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
+        }
     }
     int last = kSegWaves - 1;
     while (last > 0 && s_n[last] == 0) last--;
@@ -468,24 +538,43 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
     int b0, b1;
     seg_range(n, wave, b0, b1);
     const PoleScan sc = make_pole_scan(q.mtau, lane);
-    double e = 0.0;
-    for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
-        const double v = scan_pole_dpp(lane < cnt ? q.onem_mtau * f[base + lane] : 0.0, sc) + sc.pw * e;
-        e = lane_bcast(v, cnt - 1);
+    // pass 1: end value only (see the AM leveller)
+    const double m64 = lane_pow(q.mtau, 64);
+    double acc = 0.0;
+    double fn[kSegGroup];
+    seg_load(fn, b0, b1, n, lane, f);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double fv[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) fv[k] = fn[k];
+        seg_load(fn, b + kSegGroup, b1, n, lane, f);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            acc = __builtin_fma(acc, m64, q.onem_mtau * fv[k]);
+        }
     }
+    const double e = wave_sum_d(acc * lane_pow(q.mtau, 63 - lane));
     if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); }
     __syncthreads();
     double c = state[ch].fmdc;
     for (int w = 0; w < wave; w++) c = __builtin_fma(c, pow(q.mtau, (double)s_n[w]), s_e[w]);
     const double gain = again[ch];
-    for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64;
-        const double fv = lane < cnt ? f[base + lane] : 0.0;
-        const double dcs = scan_pole_dpp(q.onem_mtau * fv, sc) + sc.pw * c;
-        const double audio = gain * (fv - dcs);
-        if (lane < cnt) p[base + lane] = make_double2(audio, audio);
-        c = lane_bcast(dcs, cnt - 1);
+    seg_load(fn, b0, b1, n, lane, f);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double fv[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) fv[k] = fn[k];
+        seg_load(fn, b + kSegGroup, b1, n, lane, f);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double dcs = scan_pole_dpp(q.onem_mtau * fv[k], sc) + sc.pw * c;
+            const double audio = gain * (fv[k] - dcs);
+            if (lane < cnt) p[base + lane] = make_double2(audio, audio);
+            c = lane_bcast(dcs, cnt - 1);
+        }
     }
     int last = kSegWaves - 1;
     while (last > 0 && s_n[last] == 0) last--;
