@@ -520,6 +520,63 @@ int qh_qrx_set_auto_notch(qh_qrx *r, int on, int rit_freq);
 /* The receiver bank with the blanker in front of its tune, as quisk_process_samples has it; 0 = off (default). */
 int qh_qrx_set_noise_blanker(qh_qrx *r, int level);
 
+/* ------------------------------------------------------------------ 11. WDSP display engine (analyzer) */
+/* wdsp/analyzer.c for a bank of `ndisp` displays that share one configuration: Spectrum0's sample
+ * rings, the windowed transform every size - overlap samples, clip / flip / stitch (Celiminate, eliminate, stitch,
+ * analyzer.c:179-279,555-600), the five detectors or the bin interpolation (detector, :282-461), the five averaging modes
+ * (avenger, :463-553), the calibration spline (SetCalibration / build_interpolants / interpolate, :747-882,1380-1410) and
+ * GetPixels (:1315).  The reference's dispatcher and worker threads become: every frame that is complete when a feed call
+ * returns has been computed, in order.  fft sizes: powers of two from 512 to 8192 * 64; one LO per sub-span (dMAX_NUM_FFT = 1,
+ * comm.h:125); SnapSpectrum is not built.  Samples are (I, Q) doubles; they are kept as floats like the reference's dINREAL
+ * rings (comm.h:128-132).  Setters take the reference's arguments (analyzer.c:999-1017,1582-1676). */
+typedef struct qh_ana qh_ana;
+qh_ana *qh_ana_create(int device, int ndisp, int max_size, int max_stitch, void *stream);
+void qh_ana_destroy(qh_ana *a);
+int qh_ana_set_analyzer(qh_ana *a, int n_pixout, int n_fft, int typ, const int *flp, int sz, int bf_sz, int win_type, double pi, int ovrlp, int clp,
+                        double fscLin, double fscHin, int n_pix, int n_stch, int calset, double fmin, double fmax, int max_w);
+int qh_ana_set_calibration(qh_ana *a, int set_num, int n_points, const double *cal /* n_points rows of (frequency, value) */);
+int qh_ana_set_detector_mode(qh_ana *a, int pixout, int mode);
+int qh_ana_set_average_mode(qh_ana *a, int pixout, int mode);
+int qh_ana_set_num_average(qh_ana *a, int pixout, int num);
+int qh_ana_set_av_backmult(qh_ana *a, int pixout, double mult);
+int qh_ana_set_sample_rate(qh_ana *a, int rate);
+int qh_ana_set_norm_onehz(qh_ana *a, int pixout, int norm);
+double qh_ana_get_enb(qh_ana *a);
+int qh_ana_reset_pixel_buffers(qh_ana *a);
+/* n = k * buff_size samples for sub-span ss of every display: d_iq[ndisp][disp_stride] on the device (qh_ana_feed) or in host
+ * memory (qh_ana_feed_host; swap_iq = 1 reads Spectrum0's (Q, I) pair order).  *frames = pixel rows published by this call. */
+int qh_ana_feed(qh_ana *a, int ss, const void *d_iq, long long disp_stride, int n, int *frames);
+int qh_ana_feed_host(qh_ana *a, int ss, const double *h_iq, long long disp_stride, int n, int swap_iq, int *frames);
+/* GetPixels for one display of the bank: *flag = 1 and num_pixels floats (dB) if a row has been published since the last read */
+int qh_ana_get_pixels(qh_ana *a, int disp, int pixout, float *pix, int *flag);
+/* every row of the last feed call, [ndisp][frames][num_pixels] floats: device pointer / host copy */
+int qh_ana_rows(qh_ana *a, int pixout, const float **d_rows, int *frames, int *num_pixels);
+int qh_ana_rows_host(qh_ana *a, int pixout, float *out, int max_frames, int *frames);
+void *qh_ana_stream(qh_ana *a);
+long long qh_ana_frames(qh_ana *a);
+int qh_ana_buff_size(qh_ana *a);
+int qh_ana_num_pixels(qh_ana *a);
+/* WDSP's own names and signatures (wdsp/analyzer.h:100-193, wdsp.h), one display per id 0..63, host pointers */
+void XCreateAnalyzer(int disp, int *success, int m_size, int m_LO, int m_stitch, char *app_data_path);
+void DestroyAnalyzer(int disp);
+void SetAnalyzer(int disp, int n_pixout, int n_fft, int typ, int *flp, int sz, int bf_sz, int win_type, double pi, int ovrlp, int clp, double fscLin,
+                 double fscHin, int n_pix, int n_stch, int calset, double fmin, double fmax, int max_w);
+void SetCalibration(int disp, int set_num, int n_points, double (*cal)[2]);
+void Spectrum0(int run, int disp, int ss, int LO, double *pbuff);
+void Spectrum2(int run, int disp, int ss, int LO, float *pbuff);
+void Spectrum(int disp, int ss, int LO, float *pI, float *pQ);
+void OpenBuffer(int disp, int ss, int LO, void **Ipointer, void **Qpointer);
+void CloseBuffer(int disp, int ss, int LO);
+void GetPixels(int disp, int pixout, float *pix, int *flag);
+void ResetPixelBuffers(int disp);
+void SetDisplayDetectorMode(int disp, int pixout, int mode);
+void SetDisplayAverageMode(int disp, int pixout, int mode);
+void SetDisplayNumAverage(int disp, int pixout, int num);
+void SetDisplayAvBackmult(int disp, int pixout, double mult);
+void SetDisplaySampleRate(int disp, int rate);
+void SetDisplayNormOneHz(int disp, int pixout, int norm);
+double GetDisplayENB(int disp);
+
 /* ------------------------------------------------------------------ 9. Quisk native block API, one receiver */
 /* The shape of quisk.c's own receive API: a process-wide receiver, parameters through setters, samples through
  * `int quisk_process_samples(complex double *cSamples, int nSamples)` (quisk.h:375, quisk.c:2289) -- in place, returns

@@ -679,3 +679,89 @@ class OracleBandscope:
         if getattr(self, "h", None):
             self.L.qo_bscope_free(self.h)
             self.h = None
+
+
+class OracleAnalyzer:
+    """oracle/analyzer_oracle.c: one WDSP display (wdsp/analyzer.c), synchronous."""
+
+    def __init__(self, max_size, max_stitch=1):
+        L = lib()
+        L.ao_create.restype = C.c_void_p
+        L.ao_create.argtypes = [C.c_int, C.c_int]
+        L.ao_destroy.argtypes = [C.c_void_p]
+        L.ao_set_analyzer.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_double] + [C.c_int] * 2 + [C.c_double] * 2 + [C.c_int] * 3 + [C.c_double] * 2 + [C.c_int]
+        L.ao_set_calibration.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ao_spectrum0.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ao_spectrum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ao_get_pixels.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for n in ("ao_set_detector_mode", "ao_set_average_mode", "ao_set_num_average", "ao_set_norm_onehz"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_int]
+            getattr(L, n).restype = None
+        L.ao_set_av_backmult.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.ao_set_av_backmult.restype = None
+        L.ao_set_sample_rate.argtypes = [C.c_void_p, C.c_int]
+        L.ao_set_sample_rate.restype = None
+        L.ao_get_enb.argtypes = [C.c_void_p]
+        L.ao_get_enb.restype = C.c_double
+        L.ao_frames.argtypes = [C.c_void_p]
+        L.ao_frames.restype = C.c_long
+        L.ao_window_ptr.argtypes = [C.c_void_p]
+        L.ao_window_ptr.restype = C.POINTER(C.c_double)
+        L.ao_cd_ptr.argtypes = [C.c_void_p]
+        L.ao_cd_ptr.restype = C.POINTER(C.c_double)
+        self.L = L
+        self.h = L.ao_create(max_size, max_stitch)
+        self.num_pixels = 0
+        self.buff_size = 0
+        self.size = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ao_destroy(self.h)
+            self.h = None
+
+    def SetAnalyzer(self, n_pixout, n_fft, typ, flp, sz, bf_sz, win_type, pi, ovrlp, clp, fscLin, fscHin, n_pix, n_stch, calset, fmin, fmax,
+                    max_w):
+        assert n_fft == 1
+        self.L.ao_set_analyzer(self.h, n_pixout, typ, int(flp[0]), sz, bf_sz, win_type, pi, ovrlp, clp, fscLin, fscHin, n_pix, n_stch, calset,
+                               fmin, fmax, max_w)
+        self.num_pixels, self.buff_size, self.size = n_pix, bf_sz, sz
+
+    def SetCalibration(self, set_num, table):
+        t = np.ascontiguousarray(table, dtype=np.float64).copy()
+        self.L.ao_set_calibration(self.h, set_num, t.shape[0], t.ctypes.data)
+
+    def Spectrum0(self, run, ss, LO, pbuff):
+        b = np.ascontiguousarray(pbuff, dtype=np.float64)
+        assert b.size == 2 * self.buff_size
+        self.L.ao_spectrum0(self.h, run, ss, b.ctypes.data)
+
+    def Spectrum(self, ss, LO, pI, pQ):
+        i = np.ascontiguousarray(pI, dtype=np.float32)
+        q = np.ascontiguousarray(pQ, dtype=np.float32)
+        self.L.ao_spectrum(self.h, ss, i.ctypes.data, q.ctypes.data)
+
+    def GetPixels(self, pixout):
+        pix = np.zeros(self.num_pixels, dtype=np.float32)
+        flag = self.L.ao_get_pixels(self.h, pixout, pix.ctypes.data)
+        return pix, flag
+
+    def SetDisplayDetectorMode(self, pixout, mode): self.L.ao_set_detector_mode(self.h, pixout, mode)
+    def SetDisplayAverageMode(self, pixout, mode): self.L.ao_set_average_mode(self.h, pixout, mode)
+    def SetDisplayNumAverage(self, pixout, num): self.L.ao_set_num_average(self.h, pixout, num)
+    def SetDisplayAvBackmult(self, pixout, mult): self.L.ao_set_av_backmult(self.h, pixout, mult)
+    def SetDisplaySampleRate(self, rate): self.L.ao_set_sample_rate(self.h, rate)
+    def SetDisplayNormOneHz(self, pixout, norm): self.L.ao_set_norm_onehz(self.h, pixout, norm)
+    def GetDisplayENB(self): return self.L.ao_get_enb(self.h)
+    def frames(self): return self.L.ao_frames(self.h)
+    def window(self): return np.ctypeslib.as_array(self.L.ao_window_ptr(self.h), shape=(self.size,)).copy()
+    def cd(self): return np.ctypeslib.as_array(self.L.ao_cd_ptr(self.h), shape=(self.num_pixels,)).copy()
+
+
+def analyzer_detector(det_type, bins, num_pixels, pix_per_bin, bin_per_pix, inv_enb, fsclipL, fsclipH, det_offset, pixels=None):
+    L = lib()
+    L.ao_detector.argtypes = [C.c_int] * 3 + [C.c_double] * 2 + [C.c_void_p] * 2 + [C.c_double] * 4
+    b = np.ascontiguousarray(bins, dtype=np.float64)
+    out = np.zeros(num_pixels) if pixels is None else np.ascontiguousarray(pixels, dtype=np.float64).copy()
+    L.ao_detector(det_type, b.size, num_pixels, pix_per_bin, bin_per_pix, b.ctypes.data, out.ctypes.data, inv_enb, fsclipL, fsclipH, det_offset)
+    return out

@@ -475,6 +475,8 @@ static double wo_mlog10(double val)
     return 0.301029995663981 * (e + log2(1.0 + m / 2048.0));
 }
 
+double wo_mlog10_value(double v) { return wo_mlog10(v); }      /* for analyzer_oracle.c */
+
 static void meter_init(wo_meter *m, int rate, double tau_av, double tau_decay, int eav, int epk, int egain, double *result)
 {
     m->rate = (double)rate;

@@ -187,14 +187,6 @@ __device__ __forceinline__ M2 mmul(M2 x, M2 y)
 struct MeterParam { double mult_average, mult_peak; };
 struct MeterState { double avg, peak, res_av, res_pk; };
 
-__device__ __forceinline__ double mlog10_dev(double val)
-{
-    const unsigned long long N = (unsigned long long)__double_as_longlong(val);
-    const int e = (int)((N >> 52) & 2047) - 1023;
-    const int m = (int)((N >> (52 - 11)) & 2047);
-    return 0.301029995663981 * ((double)e + log2(1.0 + (double)m / 2048.0));
-}
-
 static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, long long stride, int nblk, int size,
                                                           MeterState *state, MeterParam q, const int *chan_list,
                                                           const double *gain2 = nullptr)

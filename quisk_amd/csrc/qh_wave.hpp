@@ -76,5 +76,13 @@ __device__ __forceinline__ double scan_pole(double u, double m, int lane)
     return u;
 }
 
-// buf: [nch][stride] complex, n samples per channel, in place.  One wave per listed channel.
+// WDSP's mlog10 (wdsp/meterlog10.c:29-32,547-554): log10(2) * (exponent + log2 of the mantissa truncated to 11 bits)
+__device__ __forceinline__ double mlog10_dev(double val)
+{
+    const unsigned long long N = (unsigned long long)__double_as_longlong(val);
+    const int e = (int)((N >> 52) & 2047) - 1023;
+    const int m = (int)((N >> (52 - 11)) & 2047);
+    return 0.301029995663981 * ((double)e + log2(1.0 + (double)m / 2048.0));
+}
+
 }  // namespace qh

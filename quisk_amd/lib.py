@@ -160,6 +160,59 @@ def load():
     L.qh_qagc_set_cpx.argtypes = [vp, i]
     L.qh_qagc_process.argtypes = [vp, vp, ll, i]
     L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
+    L.qh_ana_create.restype = vp
+    L.qh_ana_create.argtypes = [i, i, i, i, vp]
+    L.qh_ana_destroy.argtypes = [vp]
+    L.qh_ana_destroy.restype = None
+    L.qh_ana_set_analyzer.argtypes = [vp, i, i, i, C.POINTER(i), i, i, i, d, i, i, d, d, i, i, i, d, d, i]
+    L.qh_ana_set_calibration.argtypes = [vp, i, i, vp]
+    for n in ("detector_mode", "average_mode", "num_average", "norm_onehz"):
+        getattr(L, "qh_ana_set_" + n).argtypes = [vp, i, i]
+    L.qh_ana_set_av_backmult.argtypes = [vp, i, d]
+    L.qh_ana_set_sample_rate.argtypes = [vp, i]
+    L.qh_ana_get_enb.argtypes = [vp]
+    L.qh_ana_get_enb.restype = d
+    L.qh_ana_reset_pixel_buffers.argtypes = [vp]
+    L.qh_ana_feed.argtypes = [vp, i, vp, ll, i, C.POINTER(i)]
+    L.qh_ana_feed_host.argtypes = [vp, i, vp, ll, i, i, C.POINTER(i)]
+    L.qh_ana_get_pixels.argtypes = [vp, i, i, vp, C.POINTER(i)]
+    L.qh_ana_rows.argtypes = [vp, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i)]
+    L.qh_ana_rows_host.argtypes = [vp, i, vp, i, C.POINTER(i)]
+    L.qh_ana_stream.argtypes = [vp]
+    L.qh_ana_stream.restype = vp
+    L.qh_ana_frames.argtypes = [vp]
+    L.qh_ana_frames.restype = ll
+    L.XCreateAnalyzer.argtypes = [i, C.POINTER(i), i, i, i, C.c_char_p]
+    L.XCreateAnalyzer.restype = None
+    L.DestroyAnalyzer.argtypes = [i]
+    L.DestroyAnalyzer.restype = None
+    L.SetAnalyzer.argtypes = [i, i, i, i, C.POINTER(i), i, i, i, d, i, i, d, d, i, i, i, d, d, i]
+    L.SetAnalyzer.restype = None
+    L.Spectrum0.argtypes = [i, i, i, i, vp]
+    L.Spectrum0.restype = None
+    L.Spectrum2.argtypes = [i, i, i, i, vp]
+    L.Spectrum2.restype = None
+    L.Spectrum.argtypes = [i, i, i, vp, vp]
+    L.Spectrum.restype = None
+    L.OpenBuffer.argtypes = [i, i, i, C.POINTER(vp), C.POINTER(vp)]
+    L.OpenBuffer.restype = None
+    L.CloseBuffer.argtypes = [i, i, i]
+    L.CloseBuffer.restype = None
+    L.GetPixels.argtypes = [i, i, vp, C.POINTER(i)]
+    L.GetPixels.restype = None
+    L.SetCalibration.argtypes = [i, i, i, vp]
+    L.SetCalibration.restype = None
+    L.ResetPixelBuffers.argtypes = [i]
+    L.ResetPixelBuffers.restype = None
+    for n in ("SetDisplayDetectorMode", "SetDisplayAverageMode", "SetDisplayNumAverage", "SetDisplayNormOneHz"):
+        getattr(L, n).argtypes = [i, i, i]
+        getattr(L, n).restype = None
+    L.SetDisplayAvBackmult.argtypes = [i, i, d]
+    L.SetDisplayAvBackmult.restype = None
+    L.SetDisplaySampleRate.argtypes = [i, i]
+    L.SetDisplaySampleRate.restype = None
+    L.GetDisplayENB.argtypes = [i]
+    L.GetDisplayENB.restype = d
     L.qh_nb_create.restype = vp
     L.qh_nb_create.argtypes = [i, i, i, vp]
     L.qh_nb_destroy.argtypes = [vp]

@@ -1,0 +1,202 @@
+"""WDSP's display engine on the GPU (quisk_amd/csrc/qh_analyzer.hip) against the CPU restatement of wdsp/analyzer.c.
+
+Pixels are float dB from mlog10, a table of the top 11 mantissa bits: its steps are 10 log10(1 + 1/2048) = 0.0021 dB, and a
+last-bit difference of the transform can move a value across a step.  The gates: every pixel within one step, at most 2 % of
+the pixels more than 1e-4 dB apart.  -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RATE = 192000
+STEP = 0.0022
+
+
+def _signal(n, seed, tones=((0.0371, 0.3), (-0.211, 0.05), (0.4031, 0.01))):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.003
+    t = np.arange(n)
+    for f, a in tones:
+        x += a * np.exp(2j * np.pi * f * t)
+    return x
+
+
+def _compare(got, want, what):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, what
+    d = np.abs(got - want)
+    assert d.max() < STEP, (what, d.max(), int(d.argmax()))
+    assert np.mean(d > 1e-4) < 0.02, (what, np.mean(d > 1e-4))
+
+
+def _oracle_rows(oracle, cfg, xs, setup=None):
+    """xs: [nss][n] complex.  Every row GetPixels hands out while the streams are fed buffer by buffer, ss in turn."""
+    a = oracle.OracleAnalyzer(cfg["max_size"], cfg["stitch"])
+    a.SetDisplaySampleRate(RATE)
+    if setup:
+        setup(a)
+    a.SetAnalyzer(*cfg["args"])
+    bf = cfg["bf"]
+    rows = [[] for _ in range(cfg["pixout"])]
+    for b in range(xs.shape[1] // bf):
+        for ss in range(cfg["stitch"]):
+            blk = xs[ss, b * bf:(b + 1) * bf]
+            buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+            a.Spectrum0(1, ss, 0, buf)
+        for o in range(cfg["pixout"]):
+            pix, flag = a.GetPixels(o)
+            if flag:
+                rows[o].append(pix)
+    return [np.array(r) for r in rows]
+
+
+def _cfg(size, bf, overlap, npix, typ=1, win=2, clip=0, fL=0.0, fH=0.0, flip=0, stitch=1, pixout=1, pi=0.0, calset=0, fmin=0.0, fmax=0.0):
+    return {"max_size": size, "stitch": stitch, "bf": bf, "pixout": pixout,
+            "args": (pixout, 1, typ, [flip], size, bf, win, pi, overlap, clip, fL, fH, npix, stitch, calset, fmin, fmax, 2 * size)}
+
+
+@pytest.mark.parametrize("size", [512, 1024, 2048, 4096, 8192, 16384, 65536])
+def test_every_transform_size_peak_detector(qh, oracle, size):
+    bf = size // 4
+    cfg = _cfg(size, bf, size // 2, 1000)
+    x = _signal(4 * size, size)[None, :]
+    want = _oracle_rows(oracle, cfg, x)[0]
+    g = qh.AnalyzerBank(1, size)
+    g.SetDisplaySampleRate(RATE)
+    g.SetAnalyzer(*cfg["args"])
+    frames = g.feed_host(0, x)
+    assert frames == want.shape[0] == 7
+    _compare(g.rows_host(0)[0], want, size)
+
+
+@pytest.mark.parametrize("det", range(5))
+@pytest.mark.parametrize("geom", [dict(), dict(clip=100, fL=37.5, fH=12.25), dict(clip=100, fL=37.5, fH=12.25, flip=1), dict(typ=0, clip=20, fL=3.0)])
+def test_detectors_clip_flip_and_real_input(qh, oracle, det, geom):
+    size, bf, npix = 4096, 1024, 777
+    cfg = _cfg(size, bf, 1024, npix, **geom)
+    x = _signal(5 * size, 11 + det)[None, :]
+    want = _oracle_rows(oracle, cfg, x, setup=lambda a: a.SetDisplayDetectorMode(0, det))[0]
+    g = qh.AnalyzerBank(1, size)
+    g.SetDisplaySampleRate(RATE)
+    g.SetDisplayDetectorMode(0, det)
+    g.SetAnalyzer(*cfg["args"])
+    got = []
+    for k in range(0, x.shape[1], 2 * bf):              # two buffers per call
+        if g.feed_host(0, x[:, k:k + 2 * bf]):
+            got.append(g.rows_host(0)[0])
+    _compare(np.concatenate(got), want, (det, geom))
+
+
+@pytest.mark.parametrize("det", [0, 2, 3])
+def test_more_pixels_than_bins(qh, oracle, det):
+    size, bf, npix = 1024, 512, 3000
+    cfg = _cfg(size, bf, 0, npix, clip=30, fL=10.75, fH=2.5)
+    x = _signal(3 * size, 5)[None, :]
+    want = _oracle_rows(oracle, cfg, x, setup=lambda a: a.SetDisplayDetectorMode(0, det))[0]
+    g = qh.AnalyzerBank(1, size)
+    g.SetDisplaySampleRate(RATE)
+    g.SetDisplayDetectorMode(0, det)
+    g.SetAnalyzer(*cfg["args"])
+    assert g.feed_host(0, x) == 3
+    _compare(g.rows_host(0)[0], want, det)
+
+
+@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3])
+def test_averaging_modes_across_calls_and_four_outputs(qh, oracle, mode):
+    size, bf, npix = 2048, 512, 640
+    cfg = _cfg(size, bf, 1536, npix, pixout=4, win=6)
+    x = _signal(40 * bf, 21)[None, :]
+
+    def setup(a):
+        for o, (det, norm) in enumerate(((0, 0), (2, 1), (0, 1), (4, 0))):
+            a.SetDisplayDetectorMode(o, det)
+            a.SetDisplayAverageMode(o, mode)
+            a.SetDisplayAvBackmult(o, 0.7 + 0.05 * o)
+            a.SetDisplayNumAverage(o, 3 + 2 * o)
+            a.SetDisplayNormOneHz(o, norm)
+    want = _oracle_rows(oracle, cfg, x, setup=setup)
+    g = qh.AnalyzerBank(1, size)
+    g.SetDisplaySampleRate(RATE)
+    setup(g)
+    g.SetAnalyzer(*cfg["args"])
+    got = [[] for _ in range(4)]
+    pos = 0
+    for nb in (1, 3, 7, 2, 11, 16):                     # buffers per call: 0, 1, several rows per call
+        if g.feed_host(0, x[:, pos * bf:(pos + nb) * bf]):
+            for o in range(4):
+                got[o].append(g.rows_host(o)[0])
+        pos += nb
+    assert pos == 40
+    for o in range(4):
+        _compare(np.concatenate(got[o]), want[o], (mode, o))
+
+
+def test_stitched_sub_spans_in_a_bank_of_displays(qh, oracle):
+    size, bf, npix, ndisp = 1024, 256, 500, 3
+    cfg = _cfg(size, bf, 512, npix, clip=64, fL=100.5, fH=7.0, stitch=2, win=1)
+    xs = np.stack([np.stack([_signal(6 * size, 100 + 10 * d + ss) for ss in range(2)]) for d in range(ndisp)])    # [disp][ss][n]
+    g = qh.AnalyzerBank(ndisp, size, max_stitch=2)
+    g.SetDisplaySampleRate(RATE)
+    g.SetAnalyzer(*cfg["args"])
+    got = []
+    for k in range(0, xs.shape[2], 3 * bf):
+        assert g.feed_host(0, xs[:, 0, k:k + 3 * bf]) == 0              # nothing is published before the second sub-span has its share
+        if g.feed_host(1, xs[:, 1, k:k + 3 * bf]):
+            got.append(g.rows_host(0))
+    got = np.concatenate(got, axis=1)
+    for d in range(ndisp):
+        _compare(got[d], _oracle_rows(oracle, cfg, xs[d])[0], d)
+    pix, flag = g.GetPixels(1, 0)
+    assert flag == 1 and np.array_equal(pix, got[1][-1])
+    assert g.GetPixels(1, 0)[1] == 0 and g.GetPixels(2, 0)[1] == 1      # read once per display
+
+
+def test_calibration_and_kaiser_window(qh, oracle):
+    size, bf, npix = 4096, 1024, 800
+    table = np.array([[0.0, 1.0], [30000.0, 1.6], [10000.0, 1.25], [20000.0, 0.8], [48000.0, 1.1], [60000.0, 0.7], [96000.0, 1.0]])
+    cfg = _cfg(size, bf, 0, npix, win=5, pi=11.5, calset=1, fmin=0.0, fmax=96000.0)
+    x = _signal(2 * size, 8)[None, :]
+    want = _oracle_rows(oracle, cfg, x, setup=lambda a: a.SetCalibration(1, table))[0]
+    g = qh.AnalyzerBank(1, size)
+    g.SetDisplaySampleRate(RATE)
+    g.SetCalibration(1, table)
+    g.SetAnalyzer(*cfg["args"])
+    assert g.feed_host(0, x) == 2
+    _compare(g.rows_host(0)[0], want, "cal")
+    o = oracle.OracleAnalyzer(size); o.SetDisplaySampleRate(RATE); o.SetAnalyzer(*cfg["args"])
+    assert abs(g.GetDisplayENB() - o.GetDisplayENB()) < 1e-12 * o.GetDisplayENB()
+
+
+def test_wdsp_named_exports_buffer_by_buffer(qh, oracle):
+    """XCreateAnalyzer / SetAnalyzer / Spectrum0 / Spectrum / Spectrum2 / OpenBuffer+CloseBuffer / GetPixels: same flags, same rows"""
+    size, bf, npix = 2048, 512, 400
+    cfg = _cfg(size, bf, 1024, npix)
+    x = _signal(12 * bf, 77)
+    a = oracle.OracleAnalyzer(size)
+    a.SetDisplaySampleRate(RATE)
+    a.SetDisplayAverageMode(0, 1); a.SetDisplayAvBackmult(0, 0.5)
+    a.SetAnalyzer(*cfg["args"])
+    g = qh.WdspDisplay(7, size)
+    try:
+        g.SetDisplaySampleRate(RATE)
+        g.SetDisplayAverageMode(0, 1); g.SetDisplayAvBackmult(0, 0.5)
+        g.SetAnalyzer(*cfg["args"])
+        nrows = 0
+        for b in range(12):
+            blk = x[b * bf:(b + 1) * bf]
+            buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+            a.Spectrum0(1, 0, 0, buf)
+            i32, q32 = blk.real.astype(np.float32), blk.imag.astype(np.float32)
+            if b % 4 == 0: g.Spectrum0(1, 0, 0, buf)
+            elif b % 4 == 1: g.Spectrum(0, 0, i32, q32)
+            elif b % 4 == 2: g.Spectrum2(1, 0, 0, buf.astype(np.float32))
+            else: g.OpenCloseBuffer(0, 0, i32, q32)
+            want, wflag = a.GetPixels(0)
+            got, gflag = g.GetPixels(0)
+            assert gflag == wflag, b
+            if wflag:
+                _compare(got, want, b)
+                nrows += 1
+        assert nrows == 5
+    finally:
+        g.close()
