@@ -60,6 +60,13 @@ void *qh_rxa_stream(const qh_rxa *e);                            /* the hipStrea
  * them.  Results are those of the plain path.  Off by default: a caller that passes large batches gains nothing. */
 int qh_rxa_set_graph_replay(qh_rxa *e, int on);
 long long qh_rxa_graph_launches(const qh_rxa *e);                /* calls served by a replayed graph so far */
+/* Tile of the fircore (nbp0 / bp1 / bpsnba / FM audio) stages for nc <= 2048: 4096 points (0 = default), or 8192 points
+ * shared by two lane groups: three times the useful outputs per pair of transforms and 22 % fewer instructions per sample, yet
+ * slower on MI355X because its barriers hold eight wavefronts; kept selectable for that comparison.
+ * nc = 4096 always runs 8192-point tiles.  Results agree to rounding; a change rebuilds the filter masks on the next call.
+ * qh_rxa_band_tile: the size in use. */
+int qh_rxa_set_band_tile(qh_rxa *e, int nfft);
+int qh_rxa_band_tile(const qh_rxa *e);
 
 /* Per-channel setters; `ch` indexes the batch, or -1 for every channel.  Same meaning as the WDSP
  * export of the same name (cited in section 2).  They take effect at the next qh_rxa_process call,

@@ -223,13 +223,14 @@ static __global__ __launch_bounds__(64) void meter_kernel(const double2 *buf, lo
 // independent pieces: every chunk's partial carries its own decay to the end of the call, and one reduction joins them
 // with the carried state.  One workgroup per channel serves the three meters: adc meter (partials of the stage input), S meter and agc
 // meter (both on the stage output, the agc meter behind the fixed gain g: gain2 = g^2).
-// wdsp/RXA.c:566,569,589.  Storage: tile-major, inside a tile [wave][register] (cpt chunks per tile).
+// wdsp/RXA.c:566,569,589.  Storage: tile-major, inside a tile [wave][register] (cpt chunks per tile; layout 1: the
+// two-group tile's [A: wave][8], [B: wave][16]).
 static constexpr int kMeterFinishThreads = 1024;
 // m^k for the meters' decay factors m = exp(-1 / (rate tau)): exp(k ln m) with ln m exact by construction
 __device__ __forceinline__ double meter_decay(double ln_m, double k) { return exp(k * ln_m); }
 
 static __global__ __launch_bounds__(kMeterFinishThreads) void meter_finish_kernel(const double2 *part_in, const double2 *part_out,
-                                                                 long long stride, int nchunks, int cpb, int cpt, MeterState *m_adc,
+                                                                 long long stride, int nchunks, int cpb, int cpt, int layout, MeterState *m_adc,
                                                                  MeterState *m_s, MeterState *m_agc, double ln_avg, double ln_pk,
                                                                  const double *gain2)
 {
@@ -244,7 +245,13 @@ static __global__ __launch_bounds__(kMeterFinishThreads) void meter_finish_kerne
     const int nslots = (nchunks + cpt - 1) / cpt * cpt;                 // the last tile may hold fewer chunks than slots
     for (int s0 = T; s0 < nslots; s0 += kMeterFinishThreads) {
         const int tile = s0 / cpt, in = s0 - tile * cpt;
-        const int c = tile * cpt + 4 * (in % nseg) + in / nseg;         // [wave][register] -> chunk 4 register + wave
+        int c;
+        if (layout == 0) c = tile * cpt + 4 * (in % nseg) + in / nseg;  // [wave][register] -> chunk 4 register + wave
+        else if (in < 32) c = tile * cpt + 32 + 4 * (in & 7) + (in >> 3);      // two-group tile (osfir8k_kernel): group A, registers 8 .. 15
+        else {                                                                  // group B: [wave][16 registers], the upper eight 4096 samples on
+            const int w = (in - 32) >> 4, k = (in - 32) & 15;
+            c = tile * cpt + (k < 8 ? 4 * k + w : 64 + 4 * (k - 8) + w);
+        }
         if (c >= nchunks) continue;
         const double2 vi = pi[s0], vo = po[s0];
         const double wa = meter_decay(ln_avg, 64.0 * (double)(nchunks - 1 - c));

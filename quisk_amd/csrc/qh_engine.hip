@@ -142,6 +142,9 @@ struct Engine {
     double2 *mask_front = nullptr, *mask_nbp = nullptr, *mask_bp1 = nullptr;
     double2 *tw4096 = nullptr, *tw_inv_front = nullptr, *tw8192 = nullptr;
     int bnfft = kNfft;                      // tile size of the fircore stages: what their masks are built for (4096 or 8192)
+    bool band2g = false;                    // 8192-point tiles shared by two lane groups (osfir8k_kernel): masks stored [even | odd]
+    int band_tile_pref = 0;                 // qh_rxa_set_band_tile: 0 / 4096: 4096-point tiles, 8192: the two-group tiles
+    std::vector<cd> band_mask(const std::vector<cd> &h) const;
     unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr, *nco_parked = nullptr;
     double2 *nco_step = nullptr;
     // output-side oscillator of the front stage (D > 1): per-channel lane table, per-launch tile table, the resampler taps,
@@ -399,6 +402,10 @@ int Engine::init()
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, kBandNfftMax, 1>())))
     QH_SET_LDS8(false, false, false); QH_SET_LDS8(true, false, false); QH_SET_LDS8(false, false, true); QH_SET_LDS8(true, false, true);
 #undef QH_SET_LDS8
+#define QH_SET_LDS2G(...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8k_kernel<__VA_ARGS__>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, osfir8k_lds_bytes()))
+    QH_SET_LDS2G(false, false); QH_SET_LDS2G(true, false); QH_SET_LDS2G(false, true); QH_SET_LDS2G(true, true);
+#undef QH_SET_LDS2G
     QH_SET_LDS(2, false, false, false, true); QH_SET_LDS(4, false, false, false, true); QH_SET_LDS(8, false, false, false, true);
     QH_SET_LDS(2, false, true, false, true); QH_SET_LDS(4, false, true, false, true); QH_SET_LDS(8, false, true, false, true);
 #undef QH_SET_LDS
@@ -502,7 +509,7 @@ int Engine::refresh_params()
                 h = fir_bandpass(c.nbp_nc, f_low, f_high, (double)dsp_rate, c.nbp_wintype, 1, scale);
             if (c.mp) h = mp_imp(h, 16, 0);
             for (auto &v : h) v *= (double)(2 * dsp_size);
-            const std::vector<cd> m = make_mask(h, bnfft);
+            const std::vector<cd> m = band_mask(h);
             QH_HIP(hipMemcpyAsync(mask_snb + (size_t)ch * kBandNfftMax, m.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.snb_dirty = false;
@@ -535,7 +542,7 @@ int Engine::refresh_params()
                 if (c.nbp_run && c.mp) h = mp_imp(h, 16, 0);            // calc_fircore, wdsp/firmin.c:327-328
                 // the reference's unnormalised inverse FFT of 2*size points restores the 1/(2*size)
                 if (c.nbp_run) for (auto &v : h) v *= (double)(2 * dsp_size);
-                last_nbp = make_mask(h, bnfft);
+                last_nbp = band_mask(h);
                 last_nbp_cfg = &c;
             }
             QH_HIP(hipMemcpyAsync(mask_nbp + (size_t)ch * kBandNfftMax, last_nbp.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
@@ -556,7 +563,7 @@ int Engine::refresh_params()
                 } else {
                     h.assign(1, cd(1.0, 0.0));
                 }
-                last_bp1 = make_mask(h, bnfft);
+                last_bp1 = band_mask(h);
                 last_bp1_cfg = &c;
             }
             QH_HIP(hipMemcpyAsync(mask_bp1 + (size_t)ch * kBandNfftMax, last_bp1.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
@@ -977,7 +984,7 @@ int Engine::refresh_demod()
         QH_HIP(hipStreamSynchronize(stream));
         c.demod_dirty = false;
     }
-    if (want_nc && (want_nc != fm_nc_built || fm_mp != fm_mp_built || fm_nfft_built != bnfft)) {
+    if (want_nc && (want_nc != fm_nc_built || fm_mp != fm_mp_built || fm_nfft_built != 2 * bnfft + (band2g ? 1 : 0))) {
         // create_fmd, wdsp/fmd.c:108-116: de-emphasis by frequency sampling, audio band-pass 0.8*f_low .. 1.1*f_high
         const double f_low = 300.0, f_high = 3000.0, afgain = 0.5;
         std::vector<cd> de = fc_impulse(want_nc, f_low, f_high, +20.0 * std::log10(f_high / f_low), 0.0, 1, rate,
@@ -987,9 +994,9 @@ int Engine::refresh_demod()
         fm_mp_built = fm_mp;
         for (auto &v : de) v *= (double)(2 * dsp_size);
         for (auto &v : au) v *= (double)(2 * dsp_size);
-        if (int rc = upload(mask_de, make_mask(de, bnfft), stream)) return rc;
-        if (int rc = upload(mask_aud, make_mask(au, bnfft), stream)) return rc;
-        fm_nfft_built = bnfft;
+        if (int rc = upload(mask_de, band_mask(de), stream)) return rc;
+        if (int rc = upload(mask_aud, band_mask(au), stream)) return rc;
+        fm_nfft_built = 2 * bnfft + (band2g ? 1 : 0);
         if (fm_nc_built && fm_nc_built != want_nc) {      // setNc_fircore zeroes the delay lines, wdsp/firmin.c:454-466
             for (int i = 0; i < 2; i++) {
                 QH_HIP(hipMemsetAsync(hist_de[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
@@ -1165,6 +1172,17 @@ int Engine::ensure_buffers(long long n_mid)
 }
 
 // chunk partials of the fused meters: whole tiles per channel (a tile's store is not bounds-checked)
+// the mask of a fircore stage for the tile in use; the two-group tile reads even bins in group A, odd bins in group B
+std::vector<cd> Engine::band_mask(const std::vector<cd> &h) const
+{
+    std::vector<cd> m = make_mask(h, bnfft);
+    if (!band2g) return m;
+    std::vector<cd> p(m.size());
+    const size_t half = m.size() / 2;
+    for (size_t k = 0; k < half; k++) { p[k] = m[2 * k]; p[half + k] = m[2 * k + 1]; }
+    return p;
+}
+
 int Engine::ensure_meter_partials(long long n_mid, int lout)
 {
     const long long need = ((n_mid + lout - 1) / lout) * (lout / 64);
@@ -1228,6 +1246,17 @@ static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s,
     else if (meter) launch_osfir<1, false, false, true, false, false, NFFT>(a, ntiles, nch, s);
     else if (egress) launch_osfir<1, false, false, false, false, true, NFFT>(a, ntiles, nch, s);
     else launch_osfir<1, false, false, false, false, false, NFFT>(a, ntiles, nch, s);
+}
+
+static void launch_band2g(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
+{
+    a.ntiles = ntiles;
+    dim3 grid((unsigned)ntiles * (unsigned)nch), block(kOsfir8kThreads);
+    constexpr int lds = osfir8k_lds_bytes();
+    if (meter && egress) hipLaunchKernelGGL((osfir8k_kernel<true, true>), grid, block, lds, s, a);
+    else if (meter) hipLaunchKernelGGL((osfir8k_kernel<true, false>), grid, block, lds, s, a);
+    else if (egress) hipLaunchKernelGGL((osfir8k_kernel<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((osfir8k_kernel<false, false>), grid, block, lds, s, a);
 }
 
 // ---- stage helpers ---------------------------------------------------------------------------
@@ -1337,7 +1366,8 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     a.hist = hist[hc]; a.hist_stride = kHistBand; a.hist_len = kHistBand;
     a.out = dst; a.out_stride = dst_stride; a.out_offset = 0;
     a.mask = mask; a.mask_stride = mask_stride;
-    a.tw_fwd = a.tw_inv = bnfft == kNfft ? tw4096 : tw8192;
+    a.tw_fwd = a.tw_inv = (bnfft == kNfft || band2g) ? tw4096 : tw8192;
+    a.tw_r2 = tw8192 + 32;                  // second pass table of the 8192-point plan: exp(-2 pi i k / 8192), k < 256 (qh_design.cpp)
     a.epi = ep;
     a.chan_list = list;
     a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
@@ -1345,7 +1375,8 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
-    if (bnfft == kNfft) launch_band<kNfft>(a, ntiles, nl, stream, meter, egress);
+    if (band2g) launch_band2g(a, ntiles, nl, stream, meter, egress);
+    else if (bnfft == kNfft) launch_band<kNfft>(a, ntiles, nl, stream, meter, egress);
     else launch_band<kBandNfftMax>(a, ntiles, nl, stream, meter, egress);
     tick(2);
     dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
@@ -1407,12 +1438,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
     }
     if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
-    {   // impulse responses longer than 2048 taps need 8192-point tiles; the masks are spectra of the tile size, so a change
-        // of it rebuilds every fircore mask (the delay lines, kept 4095 samples deep, carry over)
+    {   // The fircore tile.  Impulse responses longer than 2048 taps need 8192 points (osfir_kernel<8192>, one wave per SIMD).
+        // Shorter ones run 4096-point tiles; the two-group 8192-point tile (osfir8k_kernel, 6144 instead of 2049 outputs per
+        // pair of transforms) is there on request (qh_rxa_set_band_tile) -- it measured slower, see qh_osfir.hpp.  The masks are
+        // spectra of the tile size, so a change rebuilds every one of them (the delay lines, kept 4095 samples deep, carry over).
         static const bool force8k = [] { const char *e = std::getenv("QH_BAND_NFFT"); return e && std::atoi(e) == 8192; }();  // tuning experiments
-        const int want = (nc_max > 2048 || force8k) ? kBandNfftMax : kNfft;
-        if (want != bnfft) {
-            bnfft = want;
+        const bool two_group = nc_max <= 2048 && band_tile_pref == 8192 && !force8k;
+        const int want = (nc_max > 2048 || force8k || two_group) ? kBandNfftMax : kNfft;
+        if (want != bnfft || two_group != band2g) {
+            bnfft = want; band2g = two_group;
             for (ChanCfg &c : cfg) { c.nbp_dirty = c.bp1_dirty = true; c.snb_dirty = true; }
         }
     }
@@ -1434,7 +1468,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
 
     const double2 *in = reinterpret_cast<const double2 *>(d_in);
     double2 *out = reinterpret_cast<double2 *>(d_out);
-    const int P = meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
+    const int P = band2g ? kOsfir8kP : meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
 
     // audio egress (qh_rxa_process_audio): the narrowing rides in the store of the last kernel when that is an overlap-save
     // band stage or the per-mode path's output pass; other endings write complex doubles to the staging rows and narrow after
@@ -1474,7 +1508,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         }
         if (meters_fused)
             hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
-                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, m_adc, m_s, m_agc,
+                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, band2g ? 1 : 0, m_adc, m_s, m_agc,
                                -1.0 / ((double)dsp_rate * 0.100), -1.0 / ((double)dsp_rate * 0.100), (const double *)m_g2);
         if (eg.kind && !eg_fused) pack_audio(out, out_stride, n_mid);
         tick(3);
@@ -2156,6 +2190,15 @@ int qh_rxa_set_graph_replay(qh_rxa *h, int on)
     return QH_OK;
 }
 long long qh_rxa_graph_launches(const qh_rxa *h) { return h ? h->e.graph_launches : 0; }
+
+int qh_rxa_set_band_tile(qh_rxa *h, int nfft)
+{
+    if (!h || (nfft != 0 && nfft != 4096 && nfft != 8192)) return set_error(QH_ERR_INVALID, "qh_rxa_set_band_tile: 0 (default), 4096 or 8192");
+    QH_RXA_LOCK(h);
+    h->e.band_tile_pref = nfft;
+    return QH_OK;
+}
+int qh_rxa_band_tile(const qh_rxa *h) { return h ? h->e.bnfft : 0; }
 
 int Engine::process_replayed(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
 {

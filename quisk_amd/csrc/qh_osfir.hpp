@@ -79,6 +79,7 @@ template <typename T> struct OsfirArgs {
     double2 *meter_in, *meter_out;      // [nch][meter_stride] chunk partials, chunk c = samples 64c .. 64c + 63 of this call
     long long meter_stride;
     const double *meter_w;              // [64]  (1 - m) m^(63 - i)
+    const double2 *tw_r2;               // osfir8k_kernel: exp(-2 pi i k / 8192), k < 256
 };
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
@@ -416,6 +417,168 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
         }
     }
     QH_OPROBE(5);
+}
+
+// ---- D = 1 stage on 8192-point tiles shared by two 256-lane groups ---------------------------------------------------
+// A filter of nc <= 2048 taps leaves a 4096-point tile 2049 useful outputs of 4096 (two transforms per 2049 samples); an
+// 8192-point tile leaves 6144 of 8192.  A lane cannot hold 32 fp64 complex elements at four waves per SIMD (the one-wave
+// osfir_kernel<8192> above is slower than the 4096-point tile), so the tile is shared by two groups of 256 lanes that hold 16
+// elements each -- the register budget of the 4096-point kernel -- and split the transform by one radix-2 step in registers:
+//   forward (decimation in frequency):  a[n] = x[n] + x[n + 4096],  b[n] = (x[n] - x[n + 4096]) W^n,  W = exp(-2 pi i / 8192)
+//                                       X[2k] = FFT4096(a)[k]  (group A),   X[2k + 1] = FFT4096(b)[k]  (group B)
+//   inverse (decimation in time):       y[n] = A'[n] + W^-n B'[n],  y[n + 4096] = A'[n] - W^-n B'[n],
+//                                       A' = IFFT4096(X[2k] H[2k]),  B' = IFFT4096(X[2k + 1] H[2k + 1])
+// Lane j of group g loads x[n] and x[n + 4096] for n = 2048 g + j + 256 s (s = 0 .. 7), so both operands of the forward
+// butterflies are its own; it keeps the half its group transforms and hands the other half to lane j of the other group (8
+// elements through LDS, conflict free), after which each group holds element j + 256 r of its sequence in register r: the
+// layout FftSplit4096 takes.  The inverse mirrors it.  The mask is stored [even bins | odd bins].  P is 2048: the 6144 outputs
+// are y[2048 .. 8191]; group A stores y[4096 + j + 256 s], group B y[2048 + j + 256 s] and y[6144 + j + 256 s].
+//
+// MEASURED (profiles/r02_notes.md): the VALU instruction count per output falls to 0.775 of the 4096-point kernel's as
+// planned, but the kernel is SLOWER (2.8 against 2.54 ms for 256 x 2^20 samples): a CU holds two 8-wavefront workgroups
+// instead of four 4-wavefront ones, the twenty barriers of a tile stop eight wavefronts at a time, and the VALU is busy 48 %
+// of the time instead of 79 %.  (A four-wavefront barrier through an LDS counter, to let the groups drift apart between the
+// hand-overs: 4.3 ms.)  The engine therefore runs 4096-point tiles unless qh_rxa_set_band_tile(e, 8192) asks for these.
+// The group index must be SCALAR (readfirstlane): as a vector condition it put the meter taps' wave barriers inside
+// exec-masked regions and the taps corrupted live registers of the lanes that do not store.
+// component-wise select: `c ? a : b` on two lvalues of struct type is an lvalue (a select of ADDRESSES), which pins the
+// register arrays to scratch memory
+__device__ __forceinline__ double2 sel2(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
+constexpr int kOsfir8kThreads = 512, kOsfir8kP = 2048, kOsfir8kLout = 6144;
+constexpr int osfir8k_lds_bytes() { return 2 * FftSplit4096<false, double2>::kLdsBytes; }
+
+template <bool METER, bool EGRESS>
+__global__ __launch_bounds__(kOsfir8kThreads, 4) void osfir8k_kernel(OsfirArgs<double> a)
+{
+    using C = double2;
+    using SF = FftSplit4096<false, C>;
+    using SI = FftSplit4096<true, C>;
+    constexpr int N = 8192, P = kOsfir8kP, L = kOsfir8kLout;
+    extern __shared__ __align__(16) unsigned char smem8k[];
+    const int T = threadIdx.x, j = T & 255;
+    const int g = __builtin_amdgcn_readfirstlane(T >> 8);      // the group is the same for a whole wavefront: scalar branches
+    unsigned char *image = smem8k + (size_t)g * SF::kLdsBytes;              // this group's exchange image
+    C *mine = reinterpret_cast<C *>(image), *theirs = reinterpret_cast<C *>(smem8k + (size_t)(g ^ 1) * SF::kLdsBytes);
+    int tile, slot;
+    xcd_tile_map(a.ntiles, slot, tile);
+    const int ch = a.chan_list ? a.chan_list[slot] : slot;
+    const C *in = a.in + (long long)ch * a.in_stride;
+    const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
+    const int g0 = a.off - P + tile * L;
+    const int n0 = 2048 * g + j;                        // the lane's first sample inside the tile
+
+    C x[16];                                            // x[s] = tile[n0 + 256 s], x[8 + s] = tile[n0 + 256 s + 4096]
+    if (g0 >= 0 && g0 + N <= a.n_in) {                  // workgroup-uniform
+        const C *p = in + g0 + n0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) { x[s] = p[256 * s]; x[8 + s] = p[256 * s + 4096]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int gi = g0 + n0 + 256 * (r & 7) + (r >> 3) * 4096;
+            C v = make_double2(0.0, 0.0);
+            if (gi >= 0) { if (gi < a.n_in) v = in[gi]; }
+            else if (hist && gi + a.hist_len >= 0) v = hist[gi + a.hist_len];
+            x[r] = v;
+        }
+    }
+    if constexpr (METER) {
+        // new samples: tile[2048 ..]: group A registers 8 .. 15 (chunks 32 ..), group B all sixteen (chunks 0 .. 31, 64 .. 95);
+        // a tile's 96 partials are stored [A: wave][8] then [B: wave][16] (meter_finish_kernel, layout 1)
+        double *blk = reinterpret_cast<double *>(image) + (j >> 6) * kMeterLdsDoublesPerWave;
+        double2 *dst = a.meter_in + (long long)ch * a.meter_stride + (long long)tile * (L >> 6) + (g ? 32 : 0);
+        meter_tap<C, 16>(x, g ? 0 : 8, a.meter_w[j & 63], blk, dst, j >> 6, j & 63);
+        __syncthreads();
+    }
+
+    // ---- forward radix-2 step and the hand-over
+    {
+        C w = a.tw_r2[j];                               // W^n0 = W^j (-i)^g
+        if (g) w = make_double2(w.y, -w.x);
+        const C wstep = make_double2(0.98078528040323044913, -0.19509032201612826785);      // exp(-i pi / 16) = W^256
+        C give[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const C sum = cadd(x[s], x[8 + s]);
+            const C dif = cmul(make_double2(x[s].x - x[8 + s].x, x[s].y - x[8 + s].y), w);
+            if (s < 7) w = cmul(w, wstep);
+            x[s] = sel2(g != 0, dif, sum);              // kept: a[n] in group A, b[n] in group B
+            give[s] = sel2(g != 0, sum, dif);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) theirs[256 * s + j] = give[s];
+        __syncthreads();
+        // group A: a[j + 256 r] = own (r < 8), B's sums (r >= 8);  group B: b[j + 256 r] = A's differences (r < 8), own (r >= 8)
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const C got = mine[256 * s + j], own = x[s];
+            x[8 + s] = sel2(g != 0, own, got);
+            x[s] = sel2(g != 0, got, own);
+        }
+        __syncthreads();
+    }
+    SF::run_at(x, image, FftRR<4096, false, C>::load_at(a.tw_fwd, j), j);
+
+    // ---- mask: group A holds bins 2 (j + 256 r), group B the odd ones; the mask rows are [even | odd]
+    const C *mask = a.mask + (long long)ch * a.mask_stride + 4096 * g;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        x[r] = cmul(x[r], mask[j + 256 * r]);
+        if ((r + 1) % QH_MASK_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    SI::run_at(x, image, FftRR<4096, true, C>::load_at(a.tw_inv, j), j);
+
+    // ---- inverse radix-2 step: B turns its half by W^-n, the halves change hands, sums and differences leave
+    {
+        if (g) {
+            C w = a.tw_r2[j];
+            w.y = -w.y;                                 // W^-j
+            const C wstep = make_double2(0.98078528040323044913, 0.19509032201612826785);
+#pragma unroll
+            for (int r = 0; r < 16; r++) { x[r] = cmul(x[r], w); if (r < 15) w = cmul(w, wstep); }
+        }
+        __syncthreads();                                // the inverse transform's last LDS reads are done
+#pragma unroll
+        for (int s = 0; s < 8; s++) theirs[256 * s + j] = sel2(g != 0, x[s], x[8 + s]);    // B: W^-n B'[j + 256 s];  A: A'[2048 + j + 256 s]
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const C got = mine[256 * s + j];
+            // B, n = 2048 + j + 256 s: y[n] = A'[n] + W^-n B'[n] and y[n + 4096] = A'[n] - W^-n B'[n], A' received
+            // A, n = j + 256 s: only y[n + 4096] = A'[n] - (received) lies behind the pre-roll
+            const C wb = x[8 + s], lo = x[s];
+            const C minuend = sel2(g != 0, got, lo), subtrahend = sel2(g != 0, wb, got);
+            x[s] = cadd(got, wb);                       // used by group B only
+            x[8 + s] = make_double2(minuend.x - subtrahend.x, minuend.y - subtrahend.y);
+        }
+    }
+    if constexpr (METER) {
+        __syncthreads();
+        int j2 = j;
+        asm volatile("" : "+v"(j2));
+        double *blk = reinterpret_cast<double *>(image) + (j2 >> 6) * kMeterLdsDoublesPerWave;
+        double2 *dst = a.meter_out + (long long)ch * a.meter_stride + (long long)tile * (L >> 6) + (g ? 32 : 0);
+        meter_tap<C, 16>(x, g ? 0 : 8, a.meter_w[j2 & 63], blk, dst, j2 >> 6, j2 & 63);
+    }
+
+    // ---- epilogue + store: register r of group g is output (r < 8 ? 2048 g : 4096 + 2048 g) + j + 256 (r & 7) - P of the tile
+    C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
+    EpiParam ep;
+    if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (r < 8 && g == 0) continue;                  // wave-uniform
+        const int rel = (r < 8 ? 0 : 4096) + n0 + 256 * (r & 7) - P;
+        const long long m = (long long)tile * L + rel;
+        if (m < a.n_out) {
+            C v;
+            v.x = ep.a * x[r].x + ep.b * x[r].y;
+            v.y = ep.c * x[r].x + ep.d * x[r].y;
+            if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, v.x, v.y);
+            else out[m] = v;
+        }
+    }
 }
 
 // Interpolating overlap-save FIR:  y[n] = sum_m h[m] * u[n - m],  u[U*i] = x[i], zero elsewhere  -- the audio-rate

@@ -76,6 +76,8 @@ def load():
     L.qh_rxa_synchronize.restype = i
     L.qh_rxa_enable_meters.argtypes = [vp, i]
     L.qh_rxa_set_graph_replay.argtypes = [vp, i]
+    L.qh_rxa_set_band_tile.argtypes = [vp, i]
+    L.qh_rxa_band_tile.argtypes = [vp]
     L.qh_rxa_graph_launches.argtypes = [vp]
     L.qh_rxa_graph_launches.restype = ll
     L.qh_rxa_pll_repairs.argtypes = [vp]

@@ -149,6 +149,13 @@ class RxaEngine:
         """Block-at-a-time callers: replay the launch sequence of process_ptr from hipGraphs while nothing changes."""
         check(self._L.qh_rxa_set_graph_replay(self._h, 1 if on else 0))
 
+    def set_band_tile(self, nfft=0):
+        """Tile of the band-pass stages: 4096 (0 = default) or 8192 (two lane groups per tile; measured slower)."""
+        check(self._L.qh_rxa_set_band_tile(self._h, int(nfft)))
+
+    def band_tile(self):
+        return self._L.qh_rxa_band_tile(self._h)
+
     def graph_launches(self):
         return self._L.qh_rxa_graph_launches(self._h)
 

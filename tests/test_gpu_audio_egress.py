@@ -26,8 +26,9 @@ def c_rule(kind, x, volume, prescale):
     return (t / CLIP32).astype(np.float32)
 
 
-def _engine(qh, nch, mode, agc_mode=0, meters=False, out_rate=48000):
+def _engine(qh, nch, mode, agc_mode=0, meters=False, out_rate=48000, tile=0):
     e = qh.RxaEngine(nch, out_rate=out_rate)
+    e.set_band_tile(tile)
     for c in range(nch):
         e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, synth.shift_freq(c)); e.RXANBPSetRun(c, 1)
         e.SetRXAMode(c, mode); e.SetRXAAGCMode(c, agc_mode); e.SetRXAAGCFixed(c, 0.0)
@@ -45,13 +46,14 @@ def _frames(fmt, raw, nch, n):
 
 
 @pytest.mark.parametrize("kind", ["i16", "i24", "i32", "f32"])
-@pytest.mark.parametrize("path", ["fast", "fast_meters", "modes", "resampled"])
+@pytest.mark.parametrize("path", ["fast", "fast_meters", "modes", "resampled", "fast_tile8k", "fast_meters_tile8k"])
 def test_egress_is_the_reference_expression_bit_for_bit(qh, kind, path):
     nch, nblk = 3, 23
     dev = torch.device("cuda:0")
     x = torch.from_numpy(synth.make_input_numpy(nch, nblk * 1024)).to(dev)
     kw = {"fast": dict(mode=1), "fast_meters": dict(mode=1, meters=True), "modes": dict(mode=6, agc_mode=3),
-          "resampled": dict(mode=1, out_rate=96000)}[path]
+          "resampled": dict(mode=1, out_rate=96000), "fast_tile8k": dict(mode=1, tile=8192),
+          "fast_meters_tile8k": dict(mode=1, meters=True, tile=8192)}[path]
     ea, eb = _engine(qh, nch, **kw), _engine(qh, nch, **kw)
     n_out = nblk * ea.dsp_outsize
     y = torch.zeros((nch, n_out), dtype=torch.complex128, device=dev)
