@@ -118,6 +118,15 @@ int qh_rxa_SetRXAAMSQRun(qh_rxa *e, int ch, int run);
  * RXASetPassband calls it).  dsp_rate 12000 / 24000 / 48000, dsp_size <= 1024. */
 int qh_rxa_SetRXASNBARun(qh_rxa *e, int ch, int run);
 int qh_rxa_SetRXASNBAOutputBandwidth(qh_rxa *e, int ch, double flow, double fhigh);
+/* the blanker's tuning, wdsp/snb.c:604-658 (defaults: create_rxa's 64, 2, 8.0, 20.0, 10, 2, 2, 0.5; SetRXASNBAovrlp is not provided) */
+int qh_rxa_SetRXASNBAasize(qh_rxa *e, int ch, int size);
+int qh_rxa_SetRXASNBAnpasses(qh_rxa *e, int ch, int npasses);
+int qh_rxa_SetRXASNBAk1(qh_rxa *e, int ch, double k1);
+int qh_rxa_SetRXASNBAk2(qh_rxa *e, int ch, double k2);
+int qh_rxa_SetRXASNBAbridge(qh_rxa *e, int ch, int bridge);
+int qh_rxa_SetRXASNBApresamps(qh_rxa *e, int ch, int presamps);
+int qh_rxa_SetRXASNBApostsamps(qh_rxa *e, int ch, int postsamps);
+int qh_rxa_SetRXASNBApmultmin(qh_rxa *e, int ch, double pmultmin);
 int qh_rxa_SetRXAAMSQThreshold(qh_rxa *e, int ch, double threshold_db);
 int qh_rxa_SetRXAAMSQMaxTail(qh_rxa *e, int ch, double tail_seconds);
 /* xanf / xanr (wdsp/anf.c:82-133, anr.c:82-133), setters wdsp/anf.c:175-239 and anr.c:175-238; which position (0 before
@@ -282,6 +291,14 @@ void SetRXAEMNRtrainT2(int channel, double v);
 void SetRXAEMNRgainMethod(int channel, int method);                              /* wdsp/emnr.c:1112: gain methods 0..3 */
 void SetRXASNBARun(int channel, int run);                                        /* wdsp/snb.c:579-593 */
 void SetRXASNBAOutputBandwidth(int channel, double flow, double fhigh);          /* wdsp/snb.c:660-694 */
+void SetRXASNBAasize(int channel, int size);                                     /* wdsp/snb.c:604-658 */
+void SetRXASNBAnpasses(int channel, int npasses);
+void SetRXASNBAk1(int channel, double k1);
+void SetRXASNBAk2(int channel, double k2);
+void SetRXASNBAbridge(int channel, int bridge);
+void SetRXASNBApresamps(int channel, int presamps);
+void SetRXASNBApostsamps(int channel, int postsamps);
+void SetRXASNBApmultmin(int channel, double pmultmin);
 
 /* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */
 int qh_wdsp_status(void);

@@ -67,6 +67,8 @@ def lib():
         for n in ("wo_RXASetPassband", "wo_RXANBPSetFreqs", "wo_SetRXABandpassFreqs", "wo_SetRXAPanelGain2"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_double, C.c_double]
             getattr(L, n).restype = None
+        L.wo_SetRXASNBATuning.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.wo_SetRXASNBATuning.restype = None
         L.wo_GetRXAMeter.argtypes = [C.c_void_p, C.c_int]
         L.wo_SetRXAFMLimGain.argtypes = [C.c_void_p, C.c_double]
         for n in ("wo_RXANBPAddNotch", "wo_RXANBPEditNotch"):

@@ -497,3 +497,17 @@ void wo_snba_exec(wo_snba *d, double *buf)      /* xsnba, snb.c:539-571 (in == o
     sn_resample_exec(&d->rout, d->outbuf, 1, d->isize, buf, 2);
     for (i = 0; i < d->bsize; i++) buf[2 * i + 1] = 0.0;       /* the imaginary part of outbuff is zero, snb.c:565 */
 }
+
+void wo_snba_set_tuning(wo_snba *d, int which, double v)        /* snb.c:604-658 */
+{
+    switch (which) {
+    case 0: d->asize = (int)v; break;
+    case 1: d->npasses = (int)v; break;
+    case 2: d->k1 = v; break;
+    case 3: d->k2 = v; break;
+    case 4: d->b = (int)v; break;
+    case 5: d->pre = (int)v; break;
+    case 6: d->post = (int)v; break;
+    default: d->pmultmin = v; break;
+    }
+}

@@ -188,6 +188,9 @@ struct Engine {
     SnbaParam snba_prm{};
     double *snba_state = nullptr, *snba_hin = nullptr, *snba_hout = nullptr, *snba_scratch = nullptr;
     SnbaIdx *snba_idx = nullptr;
+    SnbaTune *snba_tune = nullptr;          // [nch]; host copy below, uploaded when a tuning setter has run
+    std::vector<SnbaTune> snba_tune_h;
+    bool snba_tune_dirty = true;
     std::vector<char> snb_listed, fm_listed;
     int snba_alloc();
     EmnrParam emnr_prm{};
@@ -289,7 +292,7 @@ Engine::~Engine()
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed);
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
-    (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx);
+    (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx); (void)hipFree(snba_tune);
     (void)hipFree(emnr_chan); (void)hipFree(emnr_scal); (void)hipFree(emnr_state); (void)hipFree(emnr_window); (void)hipFree(emnr_GG);
     (void)hipFree(emnr_GGS); (void)hipFree(emnr_zeta); (void)hipFree(emnr_zeta_true);
     (void)hipFree(amsq_prm); (void)hipFree(amsq_state); (void)hipFree(amsq_cup); (void)hipFree(amsq_cdown); (void)hipFree(amsq_mag);
@@ -332,6 +335,7 @@ int Engine::init()
         if (!rsmpout) return QH_ERR_HIP;
     }
     cfg.assign((size_t)nch, ChanCfg());
+    snba_tune_h.assign((size_t)nch, SnbaTune{ 64, 2, 10, 2, 2, 0, 8.0, 20.0, 0.5 });         // create_snba's arguments, RXA.c:183-202
 
     std::vector<cd> tw = fft_twiddle_table(kNfft);
     QH_HIP(dev_alloc(&tw4096, tw.size()));
@@ -1033,6 +1037,8 @@ int Engine::snba_alloc()
     std::vector<SnbaIdx> ix((size_t)nch, SnbaIdx{ 0, 0, 0, 0, q.init_oaoutidx, { 0, 0, 0 } });
     QH_HIP(hipMemcpyAsync(snba_idx, ix.data(), ix.size() * sizeof(SnbaIdx), hipMemcpyHostToDevice, stream));
     QH_HIP(dev_alloc(&snba_scratch, (size_t)nch * kSnbX * kSnbX));
+    QH_HIP(dev_alloc(&snba_tune, (size_t)nch));
+    snba_tune_dirty = true;
     QH_HIP(dev_alloc(&snba_hin, (size_t)q.cpp_in));
     QH_HIP(dev_alloc(&snba_hout, (size_t)nch * q.cpp_out * q.ratio));
     std::vector<double> hin((size_t)q.cpp_in, 1.0);
@@ -1593,9 +1599,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     }
     if (n_snb[1]) snb_inplace(list_snb[1], n_snb[1]);       // xbpsnbain / xbpsnbaout at position 1 (RXA.c:576-577)
     if (n_snb[0] || n_snb[1]) cur_snb ^= 1;
-    if (n_snba)                                             // xsnba, RXA.c:578
+    if (n_snba) {                                           // xsnba, RXA.c:578
+        if (snba_tune_dirty) {
+            QH_HIP(hipMemcpyAsync(snba_tune, snba_tune_h.data(), snba_tune_h.size() * sizeof(SnbaTune), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            snba_tune_dirty = false;
+        }
         hipLaunchKernelGGL(snba_kernel, dim3((unsigned)n_snba), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, list_snba, snba_prm,
-                           snba_hin, snba_hout, snba_state, snba_idx, snba_scratch);
+                           snba_hin, snba_hout, snba_state, snba_idx, snba_scratch, (const SnbaTune *)snba_tune);
+    }
     // xanf, xanr, xbandpass(bp1) at position 0, xwcpagc, then the same three at position 1 (RXA.c:579-586).  The two bp1
     // launches work on disjoint channel rows of one ping-pong history pair, so the pair flips once for both.
     auto lms_on = [&](int k, double2 *b) {
@@ -1834,6 +1846,36 @@ int qh_rxa_SetRXASNBAOutputBandwidth(qh_rxa *h, int ch, double flow, double fhig
         }
     });
 }
+
+// The blanker's tuning setters, wdsp/snb.c:604-658.  They act on the next block, as under csDSP.  (SetRXASNBAovrlp, snb.c:595,
+// re-plans the frame advance and both accumulators: not provided.)
+static int snba_tune_set(qh_rxa *h, int ch, const char *who, bool ok, void (*apply)(SnbaTune &, double), double v)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    if (!ok) return set_error(QH_ERR_INVALID, "%s: value out of range", who);
+    QH_RXA_LOCK(h);
+    if (ch < -1 || ch >= h->e.nch) return set_error(QH_ERR_INVALID, "channel out of range");
+    for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? h->e.nch : ch + 1); c++) apply(h->e.snba_tune_h[(size_t)c], v);
+    h->e.snba_tune_dirty = true;
+    h->e.drop_graphs(); h->e.epoch++;
+    return QH_OK;
+}
+int qh_rxa_SetRXASNBAasize(qh_rxa *h, int ch, int size)
+{ return snba_tune_set(h, ch, "SetRXASNBAasize (1 .. 64)", size >= 1 && size <= 64, [](SnbaTune &t, double v) { t.asize = (int)v; }, size); }
+int qh_rxa_SetRXASNBAnpasses(qh_rxa *h, int ch, int npasses)
+{ return snba_tune_set(h, ch, "SetRXASNBAnpasses (0 .. 8)", npasses >= 0 && npasses <= 8, [](SnbaTune &t, double v) { t.npasses = (int)v; }, npasses); }
+int qh_rxa_SetRXASNBAk1(qh_rxa *h, int ch, double k1)
+{ return snba_tune_set(h, ch, "SetRXASNBAk1", k1 > 0.0, [](SnbaTune &t, double v) { t.k1 = v; }, k1); }
+int qh_rxa_SetRXASNBAk2(qh_rxa *h, int ch, double k2)
+{ return snba_tune_set(h, ch, "SetRXASNBAk2", k2 > 0.0, [](SnbaTune &t, double v) { t.k2 = v; }, k2); }
+int qh_rxa_SetRXASNBAbridge(qh_rxa *h, int ch, int bridge)
+{ return snba_tune_set(h, ch, "SetRXASNBAbridge (0 .. 64)", bridge >= 0 && bridge <= 64, [](SnbaTune &t, double v) { t.b = (int)v; }, bridge); }
+int qh_rxa_SetRXASNBApresamps(qh_rxa *h, int ch, int presamps)
+{ return snba_tune_set(h, ch, "SetRXASNBApresamps (0 .. 64)", presamps >= 0 && presamps <= 64, [](SnbaTune &t, double v) { t.pre = (int)v; }, presamps); }
+int qh_rxa_SetRXASNBApostsamps(qh_rxa *h, int ch, int postsamps)
+{ return snba_tune_set(h, ch, "SetRXASNBApostsamps (0 .. 64)", postsamps >= 0 && postsamps <= 64, [](SnbaTune &t, double v) { t.post = (int)v; }, postsamps); }
+int qh_rxa_SetRXASNBApmultmin(qh_rxa *h, int ch, double pmultmin)
+{ return snba_tune_set(h, ch, "SetRXASNBApmultmin", pmultmin >= 0.0, [](SnbaTune &t, double v) { t.pmultmin = v; }, pmultmin); }
 
 // SetRXASNBARun, wdsp/snb.c:579-593
 int qh_rxa_SetRXASNBARun(qh_rxa *h, int ch, int run)

@@ -28,6 +28,9 @@ struct SnbaParam {
     int off_inacc, off_outacc, off_rin, off_rout, state_doubles, pad2;
 };
 struct SnbaIdx { int iainidx, iaoutidx, nsamps, oainidx, oaoutidx, pad[3]; };
+// what the tuning setters change, per channel (SetRXASNBAasize / npasses / k1 / k2 / bridge / presamps / postsamps / pmultmin,
+// snb.c:604-658); the defaults are create_rxa's (RXA.c:183-202)
+struct SnbaTune { int asize, npasses, b, pre, post, pad; double k1, k2, pmultmin; };
 
 struct SnbaLds {
     double xb[2 * kSnbX];           // xbase | xaux
@@ -345,11 +348,15 @@ static __global__ __launch_bounds__(NT) void copy_rows_kernel(const double2 *src
 // xsnba (snb.c:539-571) over nblk blocks of dsp_size samples, in place on the channel's row of buf
 static __global__ __launch_bounds__(64) void snba_kernel(double2 *buf, long long stride, int nblk, int dsp_size, const int *chan_list,
                                                          SnbaParam q, const double *h_in, const double *h_out, double *state,
-                                                         SnbaIdx *idx, double *scratch)
+                                                         SnbaIdx *idx, double *scratch, const SnbaTune *tune)
 {
 #pragma clang fp contract(off)
     __shared__ SnbaLds s;
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
+    {
+        const SnbaTune t = tune[ch];
+        q.asize = t.asize; q.npasses = t.npasses; q.b = t.b; q.pre = t.pre; q.post = t.post; q.k1 = t.k1; q.k2 = t.k2; q.pmultmin = t.pmultmin;
+    }
     double2 *row = buf + (long long)ch * stride;
     double *st = state + (size_t)ch * q.state_doubles;
     double *B = scratch + (size_t)ch * kSnbX * kSnbX;

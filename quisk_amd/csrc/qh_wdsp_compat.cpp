@@ -588,5 +588,13 @@ void fexchange2(int channel, float *Iin, float *Qin, float *Iout, float *Qout, i
 
 void SetRXASNBARun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXASNBARun(L.c->eng, 0, run)); }          // wdsp/snb.c:579-593
 void SetRXASNBAOutputBandwidth(int channel, double flow, double fhigh) { WDSP_SETTER(qh_rxa_SetRXASNBAOutputBandwidth(L.c->eng, 0, flow, fhigh)); }  // snb.c:660-694
+void SetRXASNBAasize(int channel, int size) { WDSP_SETTER(qh_rxa_SetRXASNBAasize(L.c->eng, 0, size)); }                  // snb.c:604
+void SetRXASNBAnpasses(int channel, int npasses) { WDSP_SETTER(qh_rxa_SetRXASNBAnpasses(L.c->eng, 0, npasses)); }        // snb.c:611
+void SetRXASNBAk1(int channel, double k1) { WDSP_SETTER(qh_rxa_SetRXASNBAk1(L.c->eng, 0, k1)); }                          // snb.c:618
+void SetRXASNBAk2(int channel, double k2) { WDSP_SETTER(qh_rxa_SetRXASNBAk2(L.c->eng, 0, k2)); }                          // snb.c:625
+void SetRXASNBAbridge(int channel, int bridge) { WDSP_SETTER(qh_rxa_SetRXASNBAbridge(L.c->eng, 0, bridge)); }             // snb.c:632
+void SetRXASNBApresamps(int channel, int presamps) { WDSP_SETTER(qh_rxa_SetRXASNBApresamps(L.c->eng, 0, presamps)); }     // snb.c:639
+void SetRXASNBApostsamps(int channel, int postsamps) { WDSP_SETTER(qh_rxa_SetRXASNBApostsamps(L.c->eng, 0, postsamps)); } // snb.c:646
+void SetRXASNBApmultmin(int channel, double pmultmin) { WDSP_SETTER(qh_rxa_SetRXASNBApmultmin(L.c->eng, 0, pmultmin)); }  // snb.c:653
 
 }  // extern "C"

@@ -42,7 +42,7 @@ def load():
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
               "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease",
-              "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition", "SetRXASNBARun",
+              "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition", "SetRXASNBARun", "SetRXASNBAasize", "SetRXASNBAnpasses", "SetRXASNBAbridge", "SetRXASNBApresamps", "SetRXASNBApostsamps",
               "SetRXAAMSQRun", "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay",
               "SetRXAANRPosition"):
         f = getattr(L, "qh_rxa_" + n)
@@ -55,7 +55,7 @@ def load():
     L.qh_rxa_RXANBPGetNumNotches.argtypes = [vp, i, C.POINTER(i)]
     L.qh_rxa_RXANBPGetMinNotchWidth.argtypes = [vp, i, C.POINTER(d)]
     for n in ("SetRXAShiftFreq", "SetRXAAGCFixed", "SetRXAPanelGain1", "SetRXAFMDeviation", "SetRXACTCSSFreq", "SetRXAAGCTop",
-              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAEMNRaeZetaThresh", "SetRXAEMNRaePsi", "SetRXAEMNRtrainZetaThresh",
+              "RXANBPSetTuneFrequency", "RXANBPSetShiftFrequency", "SetRXAFMLimGain", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAEMNRaeZetaThresh", "SetRXAEMNRaePsi", "SetRXAEMNRtrainZetaThresh", "SetRXASNBAk1", "SetRXASNBAk2", "SetRXASNBApmultmin",
               "SetRXAEMNRtrainT2", "SetRXAANFGain", "SetRXAANFLeakage",
               "SetRXAANRGain", "SetRXAANRLeakage"):
         f = getattr(L, "qh_rxa_" + n)

@@ -173,3 +173,53 @@ def test_snba_seeded_setter_walks(qh, oracle, seed):
         ref = np.concatenate(rs[ch])
         assert np.all(np.isfinite(ref))
         assert rel_rms(y[ch], ref) < 1e-5, (seed, ch, rel_rms(y[ch], ref), log)
+
+
+TUNINGS = (("SetRXASNBAasize", 0), ("SetRXASNBAnpasses", 1), ("SetRXASNBAk1", 2), ("SetRXASNBAk2", 3), ("SetRXASNBAbridge", 4),
+           ("SetRXASNBApresamps", 5), ("SetRXASNBApostsamps", 6), ("SetRXASNBApmultmin", 7))
+
+
+def test_snba_tuning_setters_per_channel_and_mid_stream(qh, oracle):
+    """SetRXASNBAasize / npasses / k1 / k2 / bridge / presamps / postsamps / pmultmin (wdsp/snb.c:604-658): different values per
+    channel, changed between calls, through the WDSP-named argument lists."""
+    sets = [dict(SetRXASNBAasize=32, SetRXASNBAk1=5.0, SetRXASNBAk2=12.0, SetRXASNBAbridge=4),
+            dict(SetRXASNBAnpasses=1, SetRXASNBApresamps=5, SetRXASNBApostsamps=0, SetRXASNBApmultmin=0.9),
+            dict(SetRXASNBAasize=48, SetRXASNBAnpasses=3, SetRXASNBAk1=12.0, SetRXASNBAbridge=20, SetRXASNBApostsamps=6)]
+    later = [dict(SetRXASNBAnpasses=1, SetRXASNBAasize=40), dict(SetRXASNBAnpasses=2), dict(SetRXASNBAk2=30.0, SetRXASNBApmultmin=0.2)]
+    # (Settings under which the blanker is well conditioned.  With low thresholds AND the full predictor order -- k1 5, k2 12,
+    # asize 64 -- the restatement itself turns a 1e-15 relative change of its input into a different set of repaired samples
+    # within twenty blocks: nothing to compare there.)
+    which = dict(TUNINGS)
+    nch, nblk = 3, 120
+    x = np.stack([crackle(c, nblk * 1024, USB, rate=30.0) for c in range(nch)])
+    e = qh.RxaEngine(nch)
+    refs = []
+    for ch in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        for t, a in ((e, (ch,)), (o, ())):
+            setup(t, a, ch, USB)
+            t.SetRXASNBARun(*a, 1)
+        for name, v in sets[ch].items():
+            getattr(e, name)(ch, v)
+            o.SetRXASNBATuning(which[name], float(v))
+        refs.append(o)
+    ys, rs = [], [[] for _ in range(nch)]
+    for k, (a, b) in enumerate(((0, 50), (50, 51), (51, nblk))):
+        if k == 1:
+            for ch in range(nch):
+                for name, v in later[ch].items():
+                    getattr(e, name)(ch, v)
+                    refs[ch].SetRXASNBATuning(which[name], float(v))
+        ys.append(e.process_host(x[:, a * 1024:b * 1024]))
+        for ch in range(nch):
+            rs[ch].append(refs[ch].xrxa(x[ch, a * 1024:b * 1024]))
+    y = np.concatenate(ys, axis=1)
+    plain = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+    setup(plain, (), 0, USB); plain.SetRXASNBARun(1)
+    default0 = plain.xrxa(x[0])
+    for ch in range(nch):
+        ref = np.concatenate(rs[ch])
+        assert rel_rms(y[ch], ref) < 1e-6, (ch, rel_rms(y[ch], ref))
+    assert rel_rms(np.concatenate(rs[0]), default0) > 1e-3             # the settings do change what the blanker repairs
+    with pytest.raises(qh.QuiskHipError):
+        e.SetRXASNBAasize(0, 65)
