@@ -719,10 +719,11 @@ int qh_ana_set_analyzer(qh_ana *h, int n_pixout, int n_fft, int typ, const int *
     if (n_pixout < 1 || n_pixout > kMaxPixouts || (typ != 0 && typ != 1) || n_stch < 1 || n_stch > a.max_stitch || n_pix < 2 || n_pix > kMaxPixels ||
         win_type < 0 || win_type > 6 || ovrlp < 0 || ovrlp >= sz || clp < 0 || bf_sz < 1 || calset < 0 || calset >= kMaxCalSets || !flp)
         return set_error(QH_ERR_INVALID, "SetAnalyzer: argument out of range");
-    // the transform: sz = R * M, M a power of two in 512 .. 8192, R a power of two up to 64
+    // the transform: sz = R * M, M a power of two in 512 .. 4096 (8192 for the largest sizes), R a power of two up to 64
     if (sz < 512 || sz > a.max_size || (sz & (sz - 1))) return set_error(QH_ERR_UNSUPPORTED, "SetAnalyzer: fft size %d (powers of two from 512 to max_size)", sz);
     int M = sz, R = 1;
-    while (M > 8192) { M >>= 1; R <<= 1; }
+    while (M > 4096) { M >>= 1; R <<= 1; }              // 4096-point tiles: four workgroups per CU (the 8192-point transform holds one)
+    if (R > kMaxR) { M <<= 1; R >>= 1; }
     if (R > kMaxR) return set_error(QH_ERR_UNSUPPORTED, "SetAnalyzer: fft size %d above %d", sz, 8192 * kMaxR);
     if ((a.max_size * 2) % bf_sz) return set_error(QH_ERR_INVALID, "SetAnalyzer: buff_size must divide the sample buffer (2 * max_size)");
     QH_HIP(hipSetDevice(a.device));
