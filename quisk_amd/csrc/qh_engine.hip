@@ -135,6 +135,9 @@ struct Engine {
     long long graph_launches = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // the AM / SAM detectors of a call run beside the FM detector chain: other channels' rows, other state (process_chain)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<ChanCfg> cfg;
     // front (resampler) design
     int front_ntaps = 0, front_P = 0, front_L = 0;
@@ -300,6 +303,9 @@ Engine::~Engine()
     (void)hipFree(sam_prm); (void)hipFree(sn_prm); (void)hipFree(sn_state); (void)hipFree(mask_de); (void)hipFree(mask_aud);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_de[i]); (void)hipFree(hist_aud[i]); }
     for (auto e : ev) (void)hipEventDestroy(e);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -1558,10 +1564,26 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         else snb_inplace(list_snb[0], n_snb[0]);
     }
     tick(1);
-    if (n_am) hipLaunchKernelGGL(am_detect_tiled_kernel, dim3((unsigned)n_am), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
+    // The AM / SAM detectors and the FM detector chain touch disjoint channel rows and disjoint state, and neither fills the
+    // chip (one workgroup or wavefront per channel): with both kinds of channel in the call the AM side runs on a second
+    // stream, forked and joined by events (which a launch-sequence capture records as graph edges).
+    const bool side = (n_am || n_sam) && n_fm;
+    hipStream_t am_stream = stream;
+    if (side) {
+        if (!side_stream) {
+            QH_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            QH_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            QH_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        QH_HIP(hipEventRecord(ev_fork, stream));
+        QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        am_stream = side_stream;
+    }
+    if (n_am) hipLaunchKernelGGL(am_detect_tiled_kernel, dim3((unsigned)n_am), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
                                  list_am, levelfade, am_state, am_prm);
-    if (n_sam) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)n_sam), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+    if (n_sam) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)n_sam), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,
                                   list_sam, pll_state, sam_prm, sam_pll_prm, am_state);
+    if (side) QH_HIP(hipEventRecord(ev_join, side_stream));
     if (n_fm) {
         // xfmd's loop (fmd.c:151-172), time-tiled (qh_tiled.hpp): angles, then one loop per lane and tile, then dc removal + gain.
         // The FM channels' rows of `other` are free here: first half = angles, second half = loop filter output.
@@ -1597,6 +1619,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
                                lim_state, 0.4);
     }
+    if (side) QH_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     if (n_snb[1]) snb_inplace(list_snb[1], n_snb[1]);       // xbpsnbain / xbpsnbaout at position 1 (RXA.c:576-577)
     if (n_snb[0] || n_snb[1]) cur_snb ^= 1;
     if (n_snba) {                                           // xsnba, RXA.c:578

@@ -64,9 +64,13 @@ def config4(torch, qh, dev):
     y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
     sync = lambda: torch.cuda.synchronize(dev)
     t = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=5, warmup=1)
+    # the same call with the launch sequence replayed from hipGraphs (qh_rxa_set_graph_replay): ~25 launches per call
+    eng.set_graph_replay(True)
+    tg = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=8, warmup=4)
     tot = nch * n_in
     return {"config": "4 (one GPU's share): 256 ch x 192 k, mode by c mod 3 = USB / AM / FM, fp64", "samples_per_step": tot,
-            "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6,
+            "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "ms_graph_replay": tg * 1e3, "Msamp_per_s_graph_replay": tot / tg / 1e6,
+            "graph_launches": eng.graph_launches(),
             "pll_tiles_rerun": eng.pll_repairs(),
             "note": "AM / FM / notch recurrences time-tiled (qh_tiled.hpp); pll_tiles_rerun = FM tiles the verify pass re-ran sequentially over all steps"}
 
