@@ -269,11 +269,11 @@ def main():
         # dominant kernel and its algorithmic bytes per launch:
         #   front  (shift + resample /4): reads 16 B, writes 16/4 B per input sample        = 20 B / input sample
         #   band   (NBP overlap-save)   : reads 16 B, writes 16 B per DSP-rate sample (x1/4) =  8 B / input sample
-        names = ["osfir_kernel<f64,4096,D=4,mix> (shift+resample)", "osfir_kernel<f64,4096,D=1> (nbp fircore)"]
+        names = ["osfir_kernel<f64,4096,D=4,OUTMIX> (561-tap resample /4 + shift)", "osfir_kernel<f64,4096,D=1> (nbp fircore)"]
         algo = [20.0 if args.ingest == "f64" else 10.0, 8.0]      # 24-bit ingest: 6 B in + 16/4 B out
         k = 0 if kt[0] >= kt[1] else 1
         achieved = algo[k] * samples_per_step / (kt[k] * 1e-3) / 1e9
-        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c2_traffic.json),
+        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/c2_traffic.json, stamped with the kernel sources' hash),
         # scaled by the number of samples: counters cannot be read inside this process
         traffic, traffic_note = None, None
         try:
