@@ -58,6 +58,10 @@ static constexpr int kHistFront = 2240;     // resampler history capacity: 140 *
 // leaves a fraction of a percent of the tiles to the verify kernel's sequential re-run.
 static constexpr int kFmTile = 256;
 static constexpr int kFmWarm = 768;
+// SAM's loop (omega_N 250 rad/s, zeta 1, RXA.c:185-186) forgets a state in exp(-250 t): 1e-16 after 0.147 s = 7068 samples at 48 kHz
+static constexpr int kSamTile = 4096;
+static constexpr int kSamWarm = 8192;
+static constexpr long long kSamTiledMin = 4 * 8192;     // shorter calls take the sequential kernel
 
 struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33
@@ -175,6 +179,7 @@ struct Engine {
     bool demod_alloc = false, lists_dirty = true;
     int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
     int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0;
+    int n_sam0 = 0;                         // the first n_sam0 entries of list_sam have sbmode 0 (no all-pass chains): time-tiled in long calls
     // anf / anr: lists per (filter, position), parameters and state per filter; bp1 lists per position
     // [filter][0] = position 0 (always in `cur`); [filter][1 + b] = position 1 with the data in cur (b = 0: bp1 still to come
     // or not running) or in other (b = 1: bp1 ran at position 0)
@@ -217,7 +222,7 @@ struct Engine {
     PllState *pll_state = nullptr;
     double *fm_again = nullptr;
     // time-tiled FM loop (qh_tiled.hpp): per tile the loop state where its warm-up and where the tile ends, and the count of
-    // tiles fm_pll_verify_kernel had to re-run
+    // tiles pll_verify_kernel had to re-run
     double *pll_ends = nullptr;
     long long pll_ends_cap = 0;             // tiles per channel
     int *pll_nfixed = nullptr;
@@ -700,6 +705,7 @@ int Engine::refresh_demod()
     }
     if (lists_dirty) {
         std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba;
+        int n_sam0_new = 0;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
             if (c.amsq_run) lsq.push_back(ch);
@@ -712,7 +718,7 @@ int Engine::refresh_demod()
             if (c.fix_before()) lfix[at_agc].push_back(ch);
             if (c.fmd_run && c.lim_run) ll.push_back(ch);
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
-            if (c.amd_run && c.amd_mode == 1) ls.push_back(ch);
+            if (c.amd_run && c.amd_mode == 1) { if (c.sbmode == 0) ls.insert(ls.begin() + n_sam0_new++, ch); else ls.push_back(ch); }
             if (c.fmd_run) lf.push_back(ch);
             if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
             // xwcpagc sits between the two bp1 positions (RXA.c:581-586): a position-1 channel is still in `cur` there
@@ -794,6 +800,7 @@ int Engine::refresh_demod()
             }
             for (ChanCfg &c : cfg) { c.lms[0].dirty = c.lms[1].dirty = true; c.lms[0].flush = c.lms[1].flush = false; }
         }
+        n_sam0 = n_sam0_new;
         n_am = (int)la.size(); n_sam = (int)ls.size(); n_fm = (int)lf.size(); n_bp1 = (int)lb.size(); n_plain = (int)lp.size();
         n_agc_cur = (int)lgc.size(); n_agc_other = (int)lgo.size();
         n_lim = (int)ll.size();
@@ -1579,10 +1586,41 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
         am_stream = side_stream;
     }
-    if (n_am) hipLaunchKernelGGL(am_detect_tiled_kernel, dim3((unsigned)n_am), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
-                                 list_am, levelfade, am_state, am_prm);
-    if (n_sam) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)n_sam), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,
-                                  list_sam, pll_state, sam_prm, sam_pll_prm, am_state);
+    if (n_am) hipLaunchKernelGGL((am_detect_tiled_kernel<false>), dim3((unsigned)n_am), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                                 list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL);
+    {
+        // SAM without sideband separation in a long call: angles, the loop one tile per lane with a warm-up, verify / repair,
+        // then the mix with the phase each sample saw and the fade leveller over time segments (qh_tiled.hpp).  The channels'
+        // rows of `other` are free here: first half = angles, second half = phases.  Short calls and the all-pass modes
+        // (SAM-L / SAM-U) take the sequential kernel.
+        const int nt = n_mid >= kSamTiledMin ? n_sam0 : 0;
+        if (nt) {
+            double *theta = reinterpret_cast<double *>(other), *pts = theta + buf_cap;
+            const long long per = (n_mid + NT - 1) / NT;
+            hipLaunchKernelGGL(pll_theta_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)nt), dim3(NT), 0, am_stream, cur, buf_cap,
+                               (int)n_mid, list_sam, theta, 2 * buf_cap);
+            const long long ntl = (n_mid + kSamTile - 1) / kSamTile;
+            const int ngroups = (int)((ntl + 63) / 64);
+            if ((long long)ngroups * 64 > pll_ends_cap) {
+                QH_HIP(hipStreamSynchronize(stream));
+                if (side) QH_HIP(hipStreamSynchronize(side_stream));
+                drop_graphs(); epoch++;
+                (void)hipFree(pll_ends); pll_ends = nullptr;
+                QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * 6));
+                pll_ends_cap = (long long)ngroups * 64;
+            }
+            hipLaunchKernelGGL((pll_lanes_kernel<true>), dim3((unsigned)ngroups, (unsigned)nt), dim3(64), 0, am_stream, (const double *)theta,
+                               2 * buf_cap, pts, 2 * buf_cap, (int)n_mid, list_sam, (const PllState *)pll_state, pll_ends, pll_ends_cap * 6,
+                               sam_pll_prm, kSamTile, kSamWarm);
+            hipLaunchKernelGGL((pll_verify_kernel<true>), dim3((unsigned)nt), dim3(64), 0, am_stream, (const double *)theta, 2 * buf_cap, pts,
+                               2 * buf_cap, (int)n_mid, list_sam, pll_state, pll_ends, pll_ends_cap * 6, sam_pll_prm, kSamTile, kSamWarm,
+                               pll_nfixed, pll_check_only);
+            hipLaunchKernelGGL((am_detect_tiled_kernel<true>), dim3((unsigned)nt), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                               list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap);
+        }
+        if (n_sam - nt) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)(n_sam - nt)), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,
+                                           list_sam + nt, pll_state, sam_prm, sam_pll_prm, am_state);
+    }
     if (side) QH_HIP(hipEventRecord(ev_join, side_stream));
     if (n_fm) {
         // xfmd's loop (fmd.c:151-172), time-tiled (qh_tiled.hpp): angles, then one loop per lane and tile, then dc removal + gain.
@@ -1601,10 +1639,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * 6));
                 pll_ends_cap = (long long)ngroups * 64;
             }
-            hipLaunchKernelGGL(fm_pll_lanes_kernel, dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
+            hipLaunchKernelGGL((pll_lanes_kernel<false>), dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
                                2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, pll_ends, pll_ends_cap * 6,
                                fm_pll_prm, kFmTile, kFmWarm);
-            hipLaunchKernelGGL(fm_pll_verify_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
+            hipLaunchKernelGGL((pll_verify_kernel<false>), dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
                                2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * 6, fm_pll_prm, kFmTile, kFmWarm,
                                pll_nfixed, pll_check_only);
             hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, (const double *)fil, 2 * buf_cap, cur,

@@ -95,13 +95,19 @@ __device__ __forceinline__ void seg_load_re(double (&z)[kSegGroup], int b, int b
 }
 
 // ---- AM envelope detector + fade leveller (xamd mode 0, wdsp/amd.c:131-146), in place, z -> (audio, audio) ------------
+// SAM (xamd mode 1 without sideband separation, amd.c:148-232): the detected value is the sample mixed with the VCO phase it
+// saw, corr0 = I cos(phs) + Q sin(phs) (amd.c:150-158,169), phs per sample from the time-tiled loop (pll_lanes_kernel<true>);
+// the fade leveller behind it is the AM one.
+template <bool SAM>
 static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                                             const int *levelfade, AmState *state, AmParam prm)
+                                                                             const int *levelfade, AmState *state, AmParam prm,
+                                                                             const double *pt = nullptr, long long ptstride = 0)
 {
     __shared__ double s_e[kSegWaves][2];
     __shared__ int s_n[kSegWaves];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double2 *p = buf + (long long)ch * stride;
+    const double *ph = SAM ? pt + (long long)ch * ptstride : nullptr;
     const bool lf = levelfade[ch] != 0;
     int b0, b1;
     seg_range(n, wave, b0, b1);
@@ -123,7 +129,12 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
         for (int k = 0; k < kSegGroup; k++) {
             if (b + k >= b1) break;                         // wave-uniform
             const int i = (b + k) * 64 + lane;
-            const double a = sqrt(z[k].x * z[k].x + z[k].y * z[k].y);
+            double a;
+            if constexpr (SAM) {
+                double sn, cs;
+                sincos((i < n ? ph[i] : 0.0) * kTwoPiRef, &sn, &cs);
+                a = z[k].x * cs + z[k].y * sn;
+            } else a = sqrt(z[k].x * z[k].x + z[k].y * z[k].y);
             if (i < n) p[i] = make_double2(a, a);
             accR = __builtin_fma(accR, m64R, prm.onem_mtauR * a);
             accI = __builtin_fma(accI, m64I, prm.onem_mtauI * a);
@@ -335,18 +346,21 @@ __device__ __forceinline__ double max_nn_d(double a, double b)
 // the current batch is stepped (lane l takes row l out of LDS into registers first; pitch 65 doubles: conflict free both
 // ways); the loop filter outputs go back through LDS and leave row by row, coalesced again.
 // Speculation is checked, not trusted: every tile records its loop state where the warm-up ends (`ends` [ch][tile][0..2]) and
-// where the tile ends ([3..5]); fm_pll_verify_kernel compares neighbours and re-runs, in order, the tiles whose warm-up had
+// where the tile ends ([3..5]); pll_verify_kernel compares neighbours and re-runs, in order, the tiles whose warm-up had
 // not met the true trajectory yet (a loop that sits on noise, without a carrier, can take several hundred samples).
 static constexpr int kPllPitch = 65;
 struct PllLane { double pt, fil_out, omega; };
 
-template <bool CHECKED>
+// EMIT_PT: the step's output is the VCO phase the sample SAW (turns; what the SAM detector mixes with, amd.c:150-158) instead
+// of the loop filter's output after it (the FM discriminator's audio, fmd.c:165)
+template <bool CHECKED, bool EMIT_PT>
 __device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[64], long long gb, int n, double g1t, double g2t, double inv,
                                                double lo, double hi)
 {
 #pragma unroll
     for (int k = 0; k < 64; k++) {
         const double th = t[k];
+        const double seen = s.pt;
         double d = th - s.pt;                                   // (-1.5, 0.5] turns
         d -= rint(d);
         d = th < 4.0 ? d : 0.0;                                 // all-zero sample: det = 0 (fmd.c:156-157)
@@ -360,11 +374,12 @@ __device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[64], long
         } else {
             s.omega = om; s.fil_out = fo; s.pt = np;
         }
-        t[k] = s.fil_out;
+        t[k] = EMIT_PT ? seen : s.fil_out;
     }
 }
 
-static __global__ __launch_bounds__(64) void fm_pll_lanes_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
+template <bool EMIT_PT>
+static __global__ __launch_bounds__(64) void pll_lanes_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
                                                                  const int *chan_list, const PllState *state, double *ends, long long estride,
                                                                  PllParam q, int L, int H)
 {
@@ -384,13 +399,21 @@ static __global__ __launch_bounds__(64) void fm_pll_lanes_kernel(const double *t
     const double g1t = q.g1 * kTwoPiRef, g2t = q.g2 * kTwoPiRef, inv = 1.0 / kTwoPiRef, lo = q.omega_min, hi = q.omega_max;
     if (!from_carry && live) {
         // a warm-up has to end on the trajectory the loop is really on, and a loop with a wrapping detector can hold several
-        // (false locks): start where a loop that has been tracking would be -- on the signal's own phase and phase step
+        // (false locks): start where a loop that has been tracking would be -- on the signal's own phase ...
         const double t0 = th[g_first], t1 = th[g_first + 1];
         if (t0 < 4.0 && t1 < 4.0) {
-            double dt = t1 - t0;
-            dt -= rint(dt);
             s.pt = t0 - floor(t0);
-            s.omega = min_nn(max_nn_d(dt * kTwoPiRef, lo), hi);
+            if constexpr (EMIT_PT) {
+                // ... and, for SAM's narrow loop (40 Hz: it cannot pull a frequency guess in within a warm-up), at the frequency
+                // the loop held when the call began: a carrier it has locked to stays put over a call.  While it is still
+                // acquiring, the tiles fail the check and the verify pass steps the call in order, like the reference.
+                s.omega = sp->omega;
+            } else {
+                // ... and phase step (the FM loop follows a single step's estimate within a few samples)
+                double dt = t1 - t0;
+                dt -= rint(dt);
+                s.omega = min_nn(max_nn_d(dt * kTwoPiRef, lo), hi);
+            }
             s.fil_out = s.omega;
         }
     }
@@ -418,8 +441,8 @@ static __global__ __launch_bounds__(64) void fm_pll_lanes_kernel(const double *t
         for (int k = 0; k < 64; k++) t[k] = row[k];
         const long long gb = g_first + i0;
         if (live) {
-            if (gb >= 0 && gb + 64 <= n) pll_lane_steps<false>(s, t, gb, n, g1t, g2t, inv, lo, hi);
-            else if (gb + 63 >= 0) pll_lane_steps<true>(s, t, gb, n, g1t, g2t, inv, lo, hi);
+            if (gb >= 0 && gb + 64 <= n) pll_lane_steps<false, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
+            else if (gb + 63 >= 0) pll_lane_steps<true, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
         }
         if (i0 + 64 == H && live) { e[0] = s.pt; e[1] = s.fil_out; e[2] = s.omega; }      // state where the warm-up ends
 #pragma unroll
@@ -440,7 +463,7 @@ static __global__ __launch_bounds__(64) void fm_pll_lanes_kernel(const double *t
     if (live) { e[3] = s.pt; e[4] = s.fil_out; e[5] = s.omega; }          // state at the end of the tile (or of the call)
 }
 
-// Checks the speculation of fm_pll_lanes_kernel and repairs it.  Tile t is right when the state its warm-up reached equals
+// Checks the speculation of pll_lanes_kernel and repairs it.  Tile t is right when the state its warm-up reached equals
 // the state tile t - 1 ended in and tile t - 1 is right (the loop is deterministic: equal states stay equal; tiles 0 .. H/L ran
 // from the carried state and are right by construction).  One wavefront per channel walks the tiles in order; a tile that
 // fails is re-run from its predecessor's end state the sequential way (64 samples per batch, the angles in the lanes, the
@@ -457,7 +480,8 @@ __device__ __forceinline__ bool pll_state_differs(double pa, double fa, double o
     return !(fabs(dp) < tol && fabs(fa - fb) < tol && fabs(oa - ob) < tol);
 }
 
-static __global__ __launch_bounds__(64) void fm_pll_verify_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
+template <bool EMIT_PT>
+static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
                                                                   const int *chan_list, PllState *state, double *ends, long long estride,
                                                                   PllParam q, int L, int H, int *nfixed, int check_only)
 {
@@ -501,7 +525,7 @@ static __global__ __launch_bounds__(64) void fm_pll_verify_kernel(const double *
                 const unsigned long long zero = __ballot(tt >= 4.0);
                 double my_pt, my_fil;
                 pll_run64(Ls, tt, zero, cnt, q, lane, my_pt, my_fil, pll_out);
-                if (lane < cnt) fo[s0 + off + lane] = my_fil;
+                if (lane < cnt) fo[s0 + off + lane] = EMIT_PT ? my_pt : my_fil;
             }
             if (lane == 0) { double *w = e + (long long)tq * 6 + 3; w[0] = Ls.pt; w[1] = Ls.fil_out; w[2] = Ls.omega; }
             rt = tq; rp = Ls.pt; rf = Ls.fil_out; ro = Ls.omega;

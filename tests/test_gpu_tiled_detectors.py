@@ -25,7 +25,7 @@ def _engine(qh, nch, mode, **kw):
         e.SetRXAMode(c, mode)
         e.SetRXAAGCMode(c, 0)
         e.SetRXAAGCFixed(c, 0.0)
-        e.RXASetPassband(c, *((-4000.0, 4000.0) if mode == AM else (-8000.0, 8000.0)))
+        e.RXASetPassband(c, *((-8000.0, 8000.0) if mode == FM else (-4000.0, 4000.0)))
         if "ctcss_run" in kw:
             e.SetRXACTCSSRun(c, kw["ctcss_run"])
     return e
@@ -35,7 +35,7 @@ def _oracle(po, c, mode):
     o = po.WdspChannel(1024, 256, 192000, 48000, 48000)
     o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(mode)
     o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0)
-    o.RXASetPassband(*((-4000.0, 4000.0) if mode == AM else (-8000.0, 8000.0)))
+    o.RXASetPassband(*((-8000.0, 8000.0) if mode == FM else (-4000.0, 4000.0)))
     return o
 
 
@@ -107,3 +107,49 @@ def test_linear_scans_are_exact_across_segments(qh, oracle, mode, sig):
     for c in range(3):
         ref = _oracle(oracle, c, mode).xrxa(x[c])
         assert rel_rms(y[c][settle:], ref[settle:]) < (1e-8 if mode == AM else 1e-6), c
+
+
+SAM = 10
+
+
+def _sam_input(c, n, df, seed):
+    """AM carrier df Hz off the channel's centre, two audio tones, noise 30 dB under the carrier in the full bandwidth"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 192000.0
+    env = 1.0 + 0.5 * np.cos(2 * np.pi * 700.0 * t) + 0.3 * np.cos(2 * np.pi * 1900.0 * t)
+    x = 0.2 * env * np.exp(2j * np.pi * (df - synth.shift_freq(c)) * t)
+    return x + 0.006 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+
+
+def test_sam_long_calls_are_time_tiled_and_equal_block_calls_and_the_oracle(qh, oracle):
+    """SAM without sideband separation: calls of 32768 DSP-rate samples and more run the loop one 4096-sample tile per lane behind
+    an 8192-sample warm-up (qh_tiled.hpp), shorter ones the sequential kernel.  Acquisition amplifies last-bit differences and
+    the fade leveller (1.4 s) remembers them for seconds, so the two engines that are compared acquire the same way -- block by
+    block -- and part only afterwards: what is left is what tiling adds."""
+    nacq, nlong = 160, 160
+    offs = (12.0, -35.0, 30.0)
+    x = np.stack([_sam_input(c, (nacq + 2 * nlong) * 1024, offs[c], 40 + c) for c in range(3)])
+    ea, eb = _engine(qh, 3, SAM), _engine(qh, 3, SAM)
+    for b in range(nacq):
+        blk = np.ascontiguousarray(x[:, b * 1024:(b + 1) * 1024])
+        assert np.array_equal(ea.process_host(blk), eb.process_host(blk))
+    long = np.concatenate([ea.process_host(np.ascontiguousarray(x[:, (nacq + k * nlong) * 1024:(nacq + (k + 1) * nlong) * 1024])) for k in range(2)], axis=1)
+    print("tiles re-run by the verify pass: %d of %d" % (ea.pll_repairs(), 3 * 2 * 10))
+    assert ea.pll_repairs() == 0                            # locked: the speculation holds
+    short = np.concatenate([eb.process_host(np.ascontiguousarray(x[:, b * 1024:(b + 1) * 1024])) for b in range(nacq, nacq + 2 * nlong)], axis=1)
+    assert eb.pll_repairs() == 0                            # block calls never tile
+    assert rel_rms(long, short) < 1e-11
+    # long calls from a cold start (tiles fail their check while the loop acquires and are stepped in order), against the
+    # oracle, the leveller off so that the comparison can begin once the loop has locked
+    ec = _engine(qh, 3, SAM)
+    for c in range(3):
+        ec.SetRXAAMDFadeLevel(c, 0)
+    y = np.concatenate([ec.process_host(np.ascontiguousarray(x[:, k * nlong * 1024:(k + 1) * nlong * 1024])) for k in range(3)], axis=1)
+    for c in range(3):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(SAM)
+        o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0); o.RXASetPassband(-4000.0, 4000.0); o.SetRXAAMDFadeLevel(0)
+        ref = o.xrxa(x[c])
+        settle = 160 * 256
+        assert rel_rms(y[c][settle:], ref[settle:]) < 1e-6, c
+        assert np.abs(ref[-4096:]).max() > 1e-2
