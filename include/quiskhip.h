@@ -474,6 +474,20 @@ int qh_unpack_iq_host(int device, const void *h_src, long long src_bytes, const 
 int qh_rxa_process_packed_host(qh_rxa *e, const void *h_src, long long src_bytes, const qh_iq_format *fmt, long long chan_stride,
                                double *h_out, long long out_stride, int nblk);
 
+/* read_rx_udp17 (quisk.c:3821-3999), the two-stream UDP source: packets of 2 header bytes (sequence number; status, bit 1 =
+ * ADC overrange) + 6-byte records, 24-bit little-endian I then Q left-justified in an int32 and scaled by rx_udp_gain_correct.
+ * The LSB of I sorts every sample into the receiver's stream (clear: d_ch0, what the function returns in cSamples0) or the
+ * panadapter's (set: d_ch1, conjugated when the spectrum is inverted, the DC estimate (dc_re, dc_im) removed); on the
+ * panadapter stream a clear LSB of Q marks the first sample of a scan's first block (d_marks: slots of d_ch1).  The flag bits
+ * stay in the sample values, as in the reference.  d_counts[4] = samples on channel 0, on channel 1, marks, packets with
+ * the overrange bit; d_dc_sum[2] = sum of the channel-1 samples ahead of the DC removal: the caller keeps the estimate (the
+ * reference renews it from that sum once a second of wall time, quisk.c:3947-3952).  Buffers: npackets * (packet_bytes - 2) / 6
+ * entries each.  Bit-exact with the reference's loop. */
+int qh_unpack_udp17(int device, void *stream, const void *d_src, int npackets, int packet_bytes, double gain, int invert_spectrum,
+                    double dc_re, double dc_im, void *d_ch0, void *d_ch1, int *d_marks, long long *d_counts, double *d_dc_sum);
+int qh_unpack_udp17_host(int device, const void *h_src, int npackets, int packet_bytes, double gain, int invert_spectrum, double dc_re,
+                         double dc_im, void *h_ch0, void *h_ch1, int *h_marks, long long *h_counts, double *h_dc_sum);
+
 /* ------------------------------------------------------------------ 7b. audio egress */
 /* The narrowing Quisk's sound back ends apply to the complex doubles a receive chain returns, done in the store of the
  * chain's last kernel so that 4 (Int16 stereo) instead of 16 bytes per output sample cross HBM:

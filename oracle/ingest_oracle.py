@@ -59,3 +59,32 @@ def hermes_frames(buf, nrx=1):
                 xr = xr - (1 << 32) if xr >= (1 << 31) else xr
                 out[j, f * per + r] = float(xr) + 1j * float(xi)
     return out
+
+
+def read_rx_udp17(buf, packet_bytes=1442, gain=1.0, invert_spectrum=False, dc=0j):
+    """read_rx_udp17's sample loop, quisk.c:3917-3996, little-endian host branch, packet after packet: 2 header bytes, then
+    records of I, Q (3 bytes each, memcpy to bytes 1..3 of a zeroed int).  `xr & 0x100` (the LSB of I) selects channel 1, where
+    the sample is conjugated when the spectrum is inverted, added to dc_sum and has dc_average removed; `!(xi & 0x100)` there marks
+    the start of the first block.  Returns (channel 0, channel 1, mark slots, overrange packets, dc_sum)."""
+    b = np.frombuffer(bytes(buf), dtype=np.uint8)
+    ch0, ch1, marks = [], [], []
+    over, dc_sum = 0, 0j
+    for p in range(b.size // packet_bytes):
+        pk = b[p * packet_bytes:(p + 1) * packet_bytes]
+        if pk[1] & 0x02:
+            over += 1
+        index = 2
+        while index < packet_bytes:
+            xr = int(_left_justified_le(pk[index:index + 3][None, :], 3)[0]); index += 3
+            xi = int(_left_justified_le(pk[index:index + 3][None, :], 3)[0]); index += 3
+            sample = complex(float(xr), float(xi)) * gain
+            if xr & 0x100:
+                if invert_spectrum:
+                    sample = sample.conjugate()
+                dc_sum += sample
+                if not (xi & 0x100):
+                    marks.append(len(ch1))
+                ch1.append(sample - dc)
+            else:
+                ch0.append(sample)
+    return np.array(ch0, dtype=np.complex128), np.array(ch1, dtype=np.complex128), np.array(marks, dtype=np.int32), over, dc_sum

@@ -44,3 +44,20 @@ def unpack_host(buf, fmt, nch, chan_stride, n, dtype=F64, device=0):
     check(load().qh_unpack_iq_host(device, raw.ctypes.data, raw.size, C.byref(fmt), nch, chan_stride, n, out.ctypes.data,
                                    out.shape[1], dtype))
     return out[:, :n]
+
+
+def unpack_udp17_host(buf, packet_bytes=1442, gain=1.0, invert_spectrum=False, dc=0j, device=0):
+    """read_rx_udp17's sample loop (quisk.c:3917-3996) on whole packets: returns (channel 0 samples, channel 1 samples with `dc`
+    removed, slots of channel 1 where a scan's first block starts, packets with the overrange bit, sum of the raw channel 1
+    samples)."""
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+    npk = raw.size // packet_bytes
+    nrec = npk * ((packet_bytes - 2) // 6)
+    ch0 = np.empty(max(nrec, 1), dtype=np.complex128)
+    ch1 = np.empty(max(nrec, 1), dtype=np.complex128)
+    marks = np.empty(max(nrec, 1), dtype=np.int32)
+    counts = np.zeros(4, dtype=np.int64)
+    dcs = np.zeros(2, dtype=np.float64)
+    check(load().qh_unpack_udp17_host(device, raw.ctypes.data, npk, packet_bytes, float(gain), 1 if invert_spectrum else 0, float(dc.real),
+                                      float(dc.imag), ch0.ctypes.data, ch1.ctypes.data, marks.ctypes.data, counts.ctypes.data, dcs.ctypes.data))
+    return ch0[:counts[0]].copy(), ch1[:counts[1]].copy(), marks[:counts[2]].copy(), int(counts[3]), complex(dcs[0], dcs[1])

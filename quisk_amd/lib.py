@@ -149,6 +149,8 @@ def load():
     L.qh_iq_format_le24.restype = None
     L.qh_iq_format_hermes.argtypes = [vp, i, C.c_double]
     L.qh_iq_format_hermes.restype = None
+    L.qh_unpack_udp17.argtypes = [i, vp, vp, i, i, d, i, d, d, vp, vp, vp, vp, vp]
+    L.qh_unpack_udp17_host.argtypes = [i, vp, i, i, d, i, d, d, vp, vp, vp, vp, vp]
     L.qh_unpack_iq.argtypes = [i, vp, vp, ll, vp, i, ll, i, vp, ll, i]
     L.qh_unpack_iq_host.argtypes = [i, vp, ll, vp, i, ll, i, vp, ll, i]
     L.qh_rxa_process_packed.argtypes = [vp, vp, ll, vp, ll, vp, ll, i]

@@ -88,3 +88,23 @@ def test_rxa_chain_fed_with_24bit_samples(qh, oracle):
         ch.SetRXAMode(1); ch.RXASetPassband(300.0, 3000.0); ch.SetRXAAGCMode(0); ch.SetRXAAGCFixed(0.0)
         want = ch.xrxa(xs[c])
         assert rel_rms(y[c], want) < 1e-9
+
+
+@pytest.mark.parametrize("npk,invert", [(1, False), (5, True), (40, False)])
+def test_udp17_two_stream_demultiplexer_bit_exact(qh, npk, invert):
+    """read_rx_udp17 (quisk.c:3821-3999): random packets, so the two streams and the block marks interleave at random; 40 packets
+    = 9600 records = several 1024-record tiles with carried offsets."""
+    buf = bytearray(rand_bytes(170 + npk, 1442 * npk))
+    want = io.read_rx_udp17(bytes(buf), 1442, 1.053497942, invert, 1234.5 - 987.25j)
+    got = qh.ingest.unpack_udp17_host(bytes(buf), 1442, 1.053497942, invert, 1234.5 - 987.25j)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert got[3] == want[3]
+    assert len(got[0]) + len(got[1]) == 240 * npk and len(got[2]) > 0
+    # the sum is added in another order on the GPU (lanes, wavefronts): last-bit agreement, not identity
+    assert abs(got[4] - want[4]) <= 1e-12 * abs(want[4]) + 1e-3
+    # one stream only: every I with the LSB clear
+    b = np.frombuffer(bytes(buf), dtype=np.uint8).copy().reshape(npk, 1442)
+    b[:, 2::6] &= 0xfe
+    ch0, ch1, marks, over, dcs = qh.ingest.unpack_udp17_host(b.tobytes(), 1442, 1.0)
+    assert len(ch0) == 240 * npk and len(ch1) == 0 and len(marks) == 0 and dcs == 0
+    assert np.array_equal(ch0, io.read_rx_udp17(b.tobytes(), 1442, 1.0)[0])
