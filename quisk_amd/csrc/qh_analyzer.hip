@@ -175,12 +175,12 @@ __global__ void ana_detect_kernel(AnaDetArgs a)
 struct AnaAvgArgs {
     const double *tframes;      // [ndisp][nframes][npix] of this output's detector
     const unsigned char *valid; // [npix]
-    double *t_persist;          // [ndisp][npix]
-    double *av_sum;             // [ndisp][npix]
-    double *av_buff;            // [ndisp][kMaxAverage][npix] (mode 2)
+    double *t_persist;          // [ndisp][kMaxPixels]
+    double *av_sum;             // [ndisp][kMaxPixels]
+    double *av_buff;            // [ndisp][kMaxAverage][kMaxPixels] (mode 2)
     const double *cd;           // [npix]
     float *rows;                // [ndisp][nframes][npix]
-    float *latest;              // [ndisp][npix]
+    float *latest;              // [ndisp][kMaxPixels]
     double scale, back, norm_oneHz;
     int mode, npix, nframes, avail, num_average, in_idx, out_idx, normalize;
 };
@@ -190,7 +190,7 @@ __global__ void ana_average_kernel(AnaAvgArgs a)      // avenger, analyzer.c:463
 #pragma clang fp contract(off)
     const int d = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.npix) return;
-    const long long di = (long long)d * a.npix + i;
+    const long long di = (long long)d * kMaxPixels + i;     // the per-pixel state keeps its place when num_pixels changes (dMAX_PIXELS arrays, analyzer.c:1196-1203)
     double t = a.t_persist[di], sum = a.av_sum[di];
     const double cd = a.cd[i], onem = 1.0 - a.back;
     const bool valid = a.valid[i] != 0;
@@ -208,17 +208,17 @@ __global__ void ana_average_kernel(AnaAvgArgs a)      // avenger, analyzer.c:463
             px = (float)(10.0 * mlog10_dev(a.scale * cd * sum + 1.0e-60));
             break;
         case 2: {
-            double *ring = a.av_buff + (long long)d * kMaxAverage * a.npix + i;
+            double *ring = a.av_buff + (long long)d * kMaxAverage * kMaxPixels + i;
             double factor;
             if (avail < a.num_average) {
                 factor = a.scale / (double)++avail;
                 sum += t;
             } else {
                 factor = a.scale / (double)avail;
-                sum += t - ring[(long long)out_idx * a.npix];
+                sum += t - ring[(long long)out_idx * kMaxPixels];
                 if (++out_idx == kMaxAverage) out_idx = 0;
             }
-            ring[(long long)in_idx * a.npix] = t;
+            ring[(long long)in_idx * kMaxPixels] = t;
             if (++in_idx == kMaxAverage) in_idx = 0;
             px = (float)(10.0 * mlog10_dev(cd * sum * factor + 1.0e-60));
             break; }
@@ -953,7 +953,7 @@ int qh_ana_get_pixels(qh_ana *h, int disp, int pixout, float *pix, int *flag)
     *flag = 0;
     if (a.fresh[pixout].size() != (size_t)a.ndisp || !a.fresh[pixout][(size_t)disp]) return QH_OK;
     QH_HIP(hipSetDevice(a.device));
-    QH_HIP(hipMemcpyAsync(pix, a.latest[pixout].p + (size_t)disp * a.num_pixels, (size_t)a.num_pixels * sizeof(float), hipMemcpyDeviceToHost, a.stream));
+    QH_HIP(hipMemcpyAsync(pix, a.latest[pixout].p + (size_t)disp * kMaxPixels, (size_t)a.num_pixels * sizeof(float), hipMemcpyDeviceToHost, a.stream));
     QH_HIP(hipStreamSynchronize(a.stream));
     a.fresh[pixout][(size_t)disp] = 0;
     *flag = 1;
