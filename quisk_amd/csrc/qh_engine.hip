@@ -421,8 +421,8 @@ int Engine::init()
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, osfir8k_lds_bytes()))
     QH_SET_LDS2G(false, false); QH_SET_LDS2G(true, false); QH_SET_LDS2G(false, true); QH_SET_LDS2G(true, true);
 #undef QH_SET_LDS2G
-    QH_SET_LDS(2, false, false, false, true); QH_SET_LDS(4, false, false, false, true); QH_SET_LDS(8, false, false, false, true);
-    QH_SET_LDS(2, false, true, false, true); QH_SET_LDS(4, false, true, false, true); QH_SET_LDS(8, false, true, false, true);
+    QH_SET_LDS(2, false, false, false, true, false, true); QH_SET_LDS(4, false, false, false, true, false, true); QH_SET_LDS(8, false, false, false, true, false, true);
+    QH_SET_LDS(2, false, true, false, true, false, true); QH_SET_LDS(4, false, true, false, true, false, true); QH_SET_LDS(8, false, true, false, true, false, true);
 #undef QH_SET_LDS
     QH_HIP(hipStreamSynchronize(stream));
     return QH_OK;
@@ -599,7 +599,7 @@ int Engine::refresh_params()
     if (!nco_list.empty())      // retune_list still holds the channels; the new dphase values are in place
         hipLaunchKernelGGL((front_mask_kernel<kNfft>), dim3((unsigned)nco_list.size()), dim3(NT), (size_t)(TileFft<kNfft, false, double2>::kLdsBytes),
                            stream, (const double *)front_taps, front_ntaps, (const unsigned long long *)nco_dphase, (const int *)retune_list, front_fold,
-                           (const double2 *)tw4096, mask_front, lane_rot, nco_step);
+                           (const double2 *)tw4096, mask_front, lane_rot, nco_step, 1);
     return QH_OK;
 }
 
@@ -1250,13 +1250,13 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft>
+template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft, bool POLY = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, NFFT, D>();
-    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY>), grid, block, lds, s, a);
 }
 template <int NFFT>
 static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
@@ -1312,16 +1312,16 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
         a.pk_src = pk_src; a.pk = pk;
         if (pk_src) {
             switch (front_fold) {
-            case 2: launch_osfir<2, false, true, false, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, false, true, false, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, false, true, false, true>(a, ntiles, nch, stream); break;
+            case 2: launch_osfir<2, false, true, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, false, true, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, false, true, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         } else {
             switch (front_fold) {
-            case 2: launch_osfir<2, false, false, false, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, false, false, false, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, false, false, false, true>(a, ntiles, nch, stream); break;
+            case 2: launch_osfir<2, false, false, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
+            case 4: launch_osfir<4, false, false, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
+            case 8: launch_osfir<8, false, false, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         }

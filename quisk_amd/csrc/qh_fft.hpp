@@ -325,6 +325,46 @@ template <bool INV, typename C> struct FftSplit4096 {
         exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
         stockham_butterfly<4096, 16, 256, INV>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
     }
+
+    // The transform WITHOUT the stage that would combine the D decimated sequences x[D m + a] (plan 16 x 16 x 16/D x [D], the last
+    // radix-D pass left out): register i + (16/D) a ends up with bin j + 256 i of the (4096/D)-point transform of phase a.  A
+    // decimating overlap-save stage wants exactly that: its D-fold aliasing sum over X[k + (4096/D) q] M[k + (4096/D) q] equals
+    // sum_a X_a[k] G_a[k] with G_a[k] = W_4096^(a k) sum_q W_D^(a q) M[k + (4096/D) q] -- the same number of mask products,
+    // one butterfly stage less (polyphase form of the decimator; the masks are turned into G when they are built).
+    template <int D>
+    static __device__ __forceinline__ void run_poly(C (&x)[16], void *lds_raw, const Tw &t)
+    {
+        static_assert(!INV && (D == 2 || D == 4 || D == 8), "forward transform of a decimating stage");
+        constexpr int R3 = 16 / D;
+        const int j = threadIdx.x;
+        T *lds = reinterpret_cast<T *>(lds_raw);
+        Dft<16, INV, C>::run(x);
+        exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
+        const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);
+        __syncthreads();
+        exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
+        // pass 3 of the shorter plan: R3-point butterflies with twiddle exp(-2 pi i j r / (256 R3)) = (t.b^D)^r; butterfly a takes
+        // the elements j + 256 (a + D r), i.e. registers a + D r
+        C w[R3];
+        w[1] = t.b;
+#pragma unroll
+        for (int s = 1; s < D; s <<= 1) w[1] = cmul(w[1], w[1]);
+#pragma unroll
+        for (int r = 2; r < R3; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
+        C y[16];
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            C b[R3];
+            b[0] = x[a];
+#pragma unroll
+            for (int r = 1; r < R3; r++) b[r] = cmul(x[a + D * r], w[r]);
+            Dft<R3, INV, C>::run(b);
+#pragma unroll
+            for (int r = 0; r < R3; r++) y[r + R3 * a] = b[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = y[r];
+    }
 };
 
 // What the overlap-save kernels call: registers (strided layout) -> registers, LDS image of lds_bytes.
@@ -341,6 +381,11 @@ template <int N, bool INV, typename C> struct TileFft {
             FftRR<N, INV, C>::first(x, reinterpret_cast<C *>(lds));
             FftRR<N, INV, C>::rest(reinterpret_cast<C *>(lds), x, t);
         }
+    }
+    template <int D> static __device__ __forceinline__ void run_poly(C (&x)[N / NT], void *lds, const Tw &t)
+    {
+        static_assert(kSplit, "polyphase plan: the fp64 4096-point transform");
+        FftSplit4096<INV, C>::template run_poly<D>(x, lds, t);
     }
 };
 

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NT) void hist_update_kernel(const cplx<T> *in, long
 // 64-bit wrap-around arithmetic before it is converted.
 template <int NFFT>
 __global__ __launch_bounds__(NT) void front_mask_kernel(const double *taps, int ntaps, const unsigned long long *dphase, const int *list,
-                                                        int D, const double2 *tw, double2 *mask, double2 *lane_rot, double2 *step)
+                                                        int D, const double2 *tw, double2 *mask, double2 *lane_rot, double2 *step, int poly)
 {
     constexpr int E = NFFT / NT;
     using Fwd = TileFft<NFFT, false, double2>;
@@ -115,8 +115,28 @@ __global__ __launch_bounds__(NT) void front_mask_kernel(const double *taps, int 
         }
     }
     Fwd::run(x, smem_mask, Fwd::load(tw));
+    if (poly) {
+        // polyphase form for the stage's shortened transform (FftSplit4096::run_poly): G_a[k] = W_NFFT^(a k) sum_q W_D^(a q) M[k + (NFFT/D) q],
+        // k = t + NT i < NFFT / D; the lane holds M[t + NT (i + EO q)] in x[i + EO q]; G_a is stored where the fold reads its q = a
+        const int EO = E / D;
+        for (int i = 0; i < EO; i++)
+            for (int a = 0; a < D; a++) {
+                double2 acc = make_double2(0.0, 0.0);
+                for (int q = 0; q < D; q++) {
+                    double c, s;
+                    sincospi(-2.0 * (double)((a * q) % D) / (double)D, &s, &c);
+                    const double2 m = x[i + EO * q];
+                    acc.x += m.x * c - m.y * s; acc.y += m.x * s + m.y * c;
+                }
+                double c, s;
+                sincospi(-2.0 * (double)(((long long)a * (t + NT * i)) % NFFT) / (double)NFFT, &s, &c);
+                mask[(long long)ch * NFFT + t + NT * (i + EO * a)] =
+                    make_double2((acc.x * c - acc.y * s) * (1.0 / NFFT), (acc.x * s + acc.y * c) * (1.0 / NFFT));
+            }
+    } else {
 #pragma unroll
-    for (int r = 0; r < E; r++) mask[(long long)ch * NFFT + t + NT * r] = make_double2(x[r].x * (1.0 / NFFT), x[r].y * (1.0 / NFFT));
+        for (int r = 0; r < E; r++) mask[(long long)ch * NFFT + t + NT * r] = make_double2(x[r].x * (1.0 / NFFT), x[r].y * (1.0 / NFFT));
+    }
     double2 lr;
     sincos_turns<double>(d * (unsigned long long)((long long)D * t), lr.x, lr.y);
     lane_rot[(long long)ch * NT + t] = lr;

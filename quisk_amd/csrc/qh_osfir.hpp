@@ -249,7 +249,9 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
     }
 }
 
-template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false>
+// POLY: the forward transform stops ahead of the stage that combines the D decimated sequences and the mask holds the
+// polyphase spectra G (FftSplit4096::run_poly, front_mask_kernel): same fold below, one butterfly stage less.
+template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, bool POLY = false>
 __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
 
     // ---- forward FFT, registers -> registers
     QH_OPROBE(1);
-    Fwd::run(x, lds, Fwd::load(a.tw_fwd));
+    if constexpr (POLY) Fwd::template run_poly<D>(x, lds, Fwd::load(a.tw_fwd));
+    else Fwd::run(x, lds, Fwd::load(a.tw_fwd));
     QH_OPROBE(2);
 
     // ---- mask multiply + D-fold: lane holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'

@@ -22,6 +22,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def qh():
     """The product library; built in-tree if missing.  GPU tests fail loudly without it."""
+    try:
+        import torch  # noqa: F401  -- before libquiskhip: one HIP runtime per process (torch's own copy), see quisk_amd/lib.py
+    except ImportError:
+        pass
     from quisk_amd import build as qbuild
     qbuild.build()
     import quisk_amd

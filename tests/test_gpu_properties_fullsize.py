@@ -1,5 +1,6 @@
 """Size-independent properties of the HIP chain at sizes the CPU oracle could not finish in seconds.  -m gpu."""
 import numpy as np
+import torch          # before libquiskhip: one HIP runtime per process (torch's), as in bench.py
 import pytest
 
 from conftest import rel_rms
@@ -58,7 +59,6 @@ def test_bench_call_shape_against_oracle_and_chunking(qh, oracle):
     """The exact call bench.py times -- 256 channels x 2^22 input samples in ONE qh_rxa_process, meters on -- checked
     sample for sample against the oracle on three channels (whole output, from sample 0), against the same engine fed in
     uneven pieces on all 256 channels (device-side comparison), and the meter readings against the oracle's xmeter."""
-    import torch
     dev = torch.device("cuda:0")
     nch, n_in, nblk = 256, 1 << 22, 4096
     n_out = nblk * 256
