@@ -118,6 +118,25 @@ struct Stage {
         if ((int)taps.size() > ntaps) return set_error(QH_ERR_INVALID, "more taps than the stage was created for");
         QH_HIP(hipSetDevice(device));
         std::vector<cd> m = make_mask(taps, kStageNfft);
+        if (poly()) {
+            // the decimating fp64 kernel runs the polyphase form of its transform (FftSplit4096::run_poly): the fold then reads
+            // G_a[k] = W_N^(a k) sum_q W_D^(a q) M[k + (N / D) q] at index (N / D) a + k
+            const int N = kStageNfft, D = fold, S = N / D;
+            const long double pi = 3.14159265358979323846264338327950288L;
+            std::vector<cd> g((size_t)N);
+            for (int a = 0; a < D; a++)
+                for (int k = 0; k < S; k++) {
+                    std::complex<long double> acc(0, 0);
+                    for (int q = 0; q < D; q++) {
+                        const long double ang = -2.0L * pi * (long double)((a * q) % D) / (long double)D;
+                        acc += std::complex<long double>(m[(size_t)(k + S * q)]) * std::complex<long double>(cosl(ang), sinl(ang));
+                    }
+                    const long double ang = -2.0L * pi * (long double)(((long long)a * k) % N) / (long double)N;
+                    acc *= std::complex<long double>(cosl(ang), sinl(ang));
+                    g[(size_t)(S * a + k)] = cd((double)acc.real(), (double)acc.imag());
+                }
+            m.swap(g);
+        }
         char *dst = static_cast<char *>(mask);
         if (per_channel) {
             if (ch < 0) {
@@ -167,9 +186,12 @@ struct Stage {
 
     int out_count(int n_in) const { return interp > 1 ? n_in * interp : (phase + n_in) / decim; }
 
+    // fp64 decimating stages run the polyphase form of the forward transform (masks turned into G in set_taps)
+    bool poly() const { return dtype == QH_F64 && interp == 1 && fold > 1; }
+    template <typename T, int FOLD> static constexpr bool kPoly = sizeof(T) == 8 && FOLD > 1;
     template <typename T, int FOLD, bool MIX> int attr_one()
     {
-        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<T, kStageNfft, FOLD, MIX>),
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<T, kStageNfft, FOLD, MIX, false, false, false, false, kPoly<T, FOLD>>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<T, kStageNfft, FOLD>())));
         return QH_OK;
     }
@@ -191,7 +213,7 @@ struct Stage {
     {
         dim3 grid((unsigned)a.ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile)
         constexpr int lds = osfir_lds_bytes<T, kStageNfft, FOLD>();
-        hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX, false, false, false, false, kPoly<T, FOLD>>), grid, block, lds, stream, a);
     }
     template <typename T, int U> void launch_up(const OsfirArgs<T> &a)
     {
