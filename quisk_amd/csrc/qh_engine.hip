@@ -410,11 +410,11 @@ int Engine::init()
 
     // dynamic LDS of the overlap-save kernels
 #define QH_SET_LDS(D, ...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, 4096, D, __VA_ARGS__>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D>())))
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, 4096, D, true>())))
     QH_SET_LDS(1, false); QH_SET_LDS(1, false, false, true);
     QH_SET_LDS(1, false, false, false, false, true); QH_SET_LDS(1, false, false, true, false, true);
 #define QH_SET_LDS8(...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, kBandNfftMax, 1, false, false, __VA_ARGS__>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, kBandNfftMax, 1>())))
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, kBandNfftMax, 1, true>())))
     QH_SET_LDS8(false, false, false); QH_SET_LDS8(true, false, false); QH_SET_LDS8(false, false, true); QH_SET_LDS8(true, false, true);
 #undef QH_SET_LDS8
 #define QH_SET_LDS2G(...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8k_kernel<__VA_ARGS__>), \
@@ -1255,7 +1255,7 @@ static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
-    constexpr int lds = osfir_lds_bytes<double, NFFT, D>();
+    constexpr int lds = osfir_lds_bytes<double, NFFT, D, METER>();
     hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY>), grid, block, lds, s, a);
 }
 template <int NFFT>

@@ -283,14 +283,47 @@ template <bool INV, typename C> struct FftRR<4096, INV, C> {
 #ifndef QH_SPLIT_PAD
 #define QH_SPLIT_PAD 2
 #endif
+// QH_SPLIT_SWIZZLE: no padding at all -- the image is exactly 4096 scalars = 32 KB in fp64, so FIVE workgroups fit the 160 KB
+// of a CU -- and bank conflicts are avoided by an XOR swizzle instead: element i lives at (i & ~15) | ((i ^ (i >> 4)) & 15).
+// A lane's 16 contiguous scalars of the first exchange (row j, column r) land in column r ^ (j & 15): one store instruction
+// (fixed r) spreads 16 neighbouring lanes over the 16 bank pairs; the second exchange's stores (row 16 u + r, column k) land
+// in column k ^ r: again all 16; every load is element j + 256 r = row 16 r + (j >> 4), column (j & 15) ^ ((j >> 4) & 15):
+// lane base + compile-time offset, 32 consecutive lanes on every bank pair exactly twice (the floor for 64-bit accesses).
+// MEASURED (profiles/r02_notes.md): correct, conflict free -- and no faster.  The per-access XOR costs the front kernel 24
+// VGPRs (98 -> 122, so still four wavefronts per SIMD, not five; capped at 102 it spills 35 and takes 7.5 ms) and the band
+// kernel its last free registers (14 spilled: 3.01 -> 3.33 ms).  Off by default; the padded image below is what ships.
+#ifndef QH_SPLIT_SWIZZLE
+#define QH_SPLIT_SWIZZLE 0
+#endif
+constexpr int split4096_lds_bytes(int scalar_bytes) { return (QH_SPLIT_SWIZZLE ? 4096 : 4096 + QH_SPLIT_PAD * 256) * scalar_bytes; }
 template <bool INV, typename C> struct FftSplit4096 {
     using T = decltype(C{}.x);
     using Tw = typename FftRR<4096, INV, C>::Tw;
+    static constexpr bool kSwizzle = QH_SPLIT_SWIZZLE != 0;
+    // PHASE 1: the lane's elements are 16 j + r; PHASE 2: base + 16 r with base = 256 u + k (j = 16 u + k)
+    template <int PHASE>
+    static __device__ __forceinline__ void exchange_sw(C (&x)[16], T *lds, int j, int base)
+    {
+        const int m = j & 15;
+        T *wb = PHASE == 1 ? lds + 16 * j : lds + (base - m);              // row start of r = 0 (phase 2: base & 15 == m)
+        const T *rp = lds + 16 * (j >> 4) + (m ^ ((j >> 4) & 15));
+#pragma unroll
+        for (int r = 0; r < 16; r++) (PHASE == 1 ? wb : wb + 16 * r)[PHASE == 1 ? (r ^ m) : (m ^ r)] = x[r].x;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r].x = rp[256 * r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) (PHASE == 1 ? wb : wb + 16 * r)[PHASE == 1 ? (r ^ m) : (m ^ r)] = x[r].y;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r].y = rp[256 * r];
+    }
     // scalar image, row pitch 18: the compiler pairs the 16 contiguous scalars a lane writes in the first exchange
     // into 128-bit stores, which are served 8 lanes at a time -- a lane stride of 18 scalars = 4 banks (mod 32)
     // keeps those 8 lanes on distinct banks (pitch 17 gave 2-way conflicts on a third of the LDS cycles)
     static constexpr int kPad = QH_SPLIT_PAD;
-    static constexpr int kLdsBytes = (4096 + kPad * 256) * (int)sizeof(T);
+    static constexpr int kLdsBytes = split4096_lds_bytes((int)sizeof(T));
     static __device__ __forceinline__ int sphys(int i) { return i + (i >> 4) * kPad; }
 
     template <int WS, int RS>
@@ -319,10 +352,12 @@ template <bool INV, typename C> struct FftSplit4096 {
         T *lds = reinterpret_cast<T *>(lds_raw);
         Dft<16, INV, C>::run(x);                                    // pass 1: x[r] = in[j + 256 r]
         // element j*16 + r  ->  j + 256 r'   (sphys: 18 j + r, and sphys(j) + 288 r')
-        exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
+        if constexpr (kSwizzle) exchange_sw<1>(x, lds, j, 0);
+        else exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
         const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);      // pass 2: outputs at base + 16 r
         __syncthreads();
-        exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
+        if constexpr (kSwizzle) exchange_sw<2>(x, lds, j, base);
+        else exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
         stockham_butterfly<4096, 16, 256, INV>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
     }
 
@@ -339,10 +374,12 @@ template <bool INV, typename C> struct FftSplit4096 {
         const int j = threadIdx.x;
         T *lds = reinterpret_cast<T *>(lds_raw);
         Dft<16, INV, C>::run(x);
-        exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
+        if constexpr (kSwizzle) exchange_sw<1>(x, lds, j, 0);
+        else exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
         const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);
         __syncthreads();
-        exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
+        if constexpr (kSwizzle) exchange_sw<2>(x, lds, j, base);
+        else exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
         // pass 3 of the shorter plan: R3-point butterflies with twiddle exp(-2 pi i j r / (256 R3)) = (t.b^D)^r; butterfly a takes
         // the elements j + 256 (a + D r), i.e. registers a + D r
         C w[R3];
@@ -370,7 +407,7 @@ template <bool INV, typename C> struct FftSplit4096 {
 // What the overlap-save kernels call: registers (strided layout) -> registers, LDS image of lds_bytes.
 template <int N, bool INV, typename C> struct TileFft {
     static constexpr bool kSplit = N == 4096 && sizeof(C) == 16;
-    static constexpr int kLdsBytes = kSplit ? (4096 + QH_SPLIT_PAD * 256) * 8 : lds_elems<N>() * (int)sizeof(C);
+    static constexpr int kLdsBytes = kSplit ? split4096_lds_bytes(8) : lds_elems<N>() * (int)sizeof(C);
     using Tw = typename FftRR<N, INV, C>::Tw;
     static __device__ __forceinline__ Tw load(const C *__restrict__ tw) { return FftRR<N, INV, C>::load(tw); }
     static __device__ __forceinline__ void run(C (&x)[N / NT], void *lds, const Tw &t)

@@ -146,10 +146,11 @@ __device__ __forceinline__ void xcd_tile_map(int ntiles, int &chan_slot, int &ti
 }
 
 // dynamic LDS of the two kernels below
-template <typename T, int NFFT, int D> constexpr int osfir_lds_bytes()
+template <typename T, int NFFT, int D, bool METER = false> constexpr int osfir_lds_bytes()
 {
     constexpr int a = TileFft<NFFT, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT / D, true, cplx<T>>::kLdsBytes;
-    return a > b ? a : b;
+    constexpr int m = METER ? NT / 64 * 2 * 64 * 9 * 8 : 0;        // the meter taps' per-wave blocks overlay the image (kMeterLdsDoublesPerWave)
+    return (a > b ? a : b) > m ? (a > b ? a : b) : m;
 }
 template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
 
     if constexpr (METER) {
         static_assert(D == 1 && !MIX && !PACKED, "meters ride on a plain D = 1 stage");
-        static_assert(NT / 64 * kMeterLdsDoublesPerWave * 8 <= osfir_lds_bytes<T, NFFT, D>(), "meter blocks overlay the exchange image");
+        static_assert(NT / 64 * kMeterLdsDoublesPerWave * 8 <= osfir_lds_bytes<T, NFFT, D, true>(), "meter blocks overlay the exchange image");
         // the tile's new samples [tile * Lout, (tile + 1) * Lout) are chunks tile * Lout / 64 ...; register P / 256 holds the first
         meter_tap<C, E>(x, a.P >> 8, a.meter_w[t & 63], reinterpret_cast<double *>(lds) + (t >> 6) * kMeterLdsDoublesPerWave,
                         a.meter_in + (long long)ch * a.meter_stride + (long long)tile * (a.Lout >> 6), t >> 6, t & 63);
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
 // register arrays to scratch memory
 __device__ __forceinline__ double2 sel2(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 constexpr int kOsfir8kThreads = 512, kOsfir8kP = 2048, kOsfir8kLout = 6144;
-constexpr int osfir8k_lds_bytes() { return 2 * FftSplit4096<false, double2>::kLdsBytes; }
+constexpr int kOsfir8kImage = FftSplit4096<false, double2>::kLdsBytes > 4 * 2 * 64 * 9 * 8 ? FftSplit4096<false, double2>::kLdsBytes : 4 * 2 * 64 * 9 * 8;   // image or meter blocks
+constexpr int osfir8k_lds_bytes() { return 2 * kOsfir8kImage; }
 
 template <bool METER, bool EGRESS>
 __global__ __launch_bounds__(kOsfir8kThreads, 4) void osfir8k_kernel(OsfirArgs<double> a)
@@ -460,8 +462,8 @@ __global__ __launch_bounds__(kOsfir8kThreads, 4) void osfir8k_kernel(OsfirArgs<d
     extern __shared__ __align__(16) unsigned char smem8k[];
     const int T = threadIdx.x, j = T & 255;
     const int g = __builtin_amdgcn_readfirstlane(T >> 8);      // the group is the same for a whole wavefront: scalar branches
-    unsigned char *image = smem8k + (size_t)g * SF::kLdsBytes;              // this group's exchange image
-    C *mine = reinterpret_cast<C *>(image), *theirs = reinterpret_cast<C *>(smem8k + (size_t)(g ^ 1) * SF::kLdsBytes);
+    unsigned char *image = smem8k + (size_t)g * kOsfir8kImage;              // this group's exchange image
+    C *mine = reinterpret_cast<C *>(image), *theirs = reinterpret_cast<C *>(smem8k + (size_t)(g ^ 1) * kOsfir8kImage);
     int tile, slot;
     xcd_tile_map(a.ntiles, slot, tile);
     const int ch = a.chan_list ? a.chan_list[slot] : slot;
