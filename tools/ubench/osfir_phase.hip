@@ -14,8 +14,8 @@ template <int D, bool MIX, bool OUTMIX = false, bool POLY = false> int run(const
     const int nch = 256, ntiles = 128, P = (MIX || OUTMIX) ? 560 : 2047, Lout = (4096 - (P + D - 1) / D * D) / D;
     const long long n_in = (long long)ntiles * Lout * D + 8192, n_out = (long long)ntiles * Lout;
     double2 *in, *out, *mask, *twf, *twi; unsigned long long *ph, *dph; double2 *st;
-    CK(hipMalloc(&in, nch * n_in * 16)); CK(hipMalloc(&out, nch * n_out * 16)); CK(hipMalloc(&mask, 4096 * 16));
-    CK(hipMemset(in, 0, nch * n_in * 16)); CK(hipMemset(mask, 0, 4096 * 16));
+    CK(hipMalloc(&in, nch * n_in * 16)); CK(hipMalloc(&out, nch * n_out * 16)); CK(hipMalloc(&mask, (size_t)nch * 4096 * 16));
+    CK(hipMemset(in, 0, nch * n_in * 16)); CK(hipMemset(mask, 0, (size_t)nch * 4096 * 16));
     std::vector<cd> t1 = fft_twiddle_table(4096), t2 = fft_twiddle_table(4096 / D);
     CK(hipMalloc(&twf, t1.size() * 16)); CK(hipMalloc(&twi, t2.size() * 16));
     CK(hipMemcpy(twf, t1.data(), t1.size() * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(twi, t2.data(), t2.size() * 16, hipMemcpyHostToDevice));
@@ -25,7 +25,7 @@ template <int D, bool MIX, bool OUTMIX = false, bool POLY = false> int run(const
     CK(hipMalloc(&trot, (size_t)nch * ntiles * 16)); CK(hipMalloc(&lrot, (size_t)nch * 256 * 16));
     CK(hipMemset(trot, 0, (size_t)nch * ntiles * 16)); CK(hipMemset(lrot, 0, (size_t)nch * 256 * 16));
     OsfirArgs<double> a{};
-    a.in = in + 4096; a.in_stride = n_in; a.out = out; a.out_stride = n_out; a.mask = mask; a.tw_fwd = twf; a.tw_inv = twi;
+    a.in = in + 4096; a.in_stride = n_in; a.out = out; a.out_stride = n_out; a.mask = mask; a.mask_stride = 4096 /* per-channel masks, as in the engine */; a.tw_fwd = twf; a.tw_inv = twi;
     a.nco_phase = ph; a.nco_dphase = dph; a.nco_step = st; a.n_in = (int)(n_in - 8192); a.n_out = (int)n_out; a.P = (P + D - 1) / D * D;
     a.Lout = Lout; a.ntiles = ntiles; a.tile_rot = trot; a.lane_rot = lrot;
     constexpr int lds = osfir_lds_bytes<double, 4096, D>();
