@@ -207,3 +207,23 @@ def test_am_squelch_opens_on_signal_and_closes_after_its_tail(oracle):
     lvl = [np.abs(y[k * 256:(k + 1) * 256]).max() for k in range(300)]
     assert lvl[0] == 0.0 and max(lvl[60:95]) > 0.1          # muted at the start, open (after the 70 ms slew) while the signal is there
     assert max(lvl[160:]) == 0.0                            # closed again: tail <= 0.1 s + 70 ms slew after the fade at block 100
+
+
+def test_mlog10_is_pinned_to_the_reference_table(oracle):
+    """wdsp/meterlog10.c keeps mtable[2048]; the restatements use log2(1 + m / 2048).  tests/golden/mlog10_pin.json (made here by
+    tests/golden/make_mlog10_pin.py from the reference's own numbers) records that the two agree to one ulp, and the constants."""
+    import ctypes as C
+    import json
+    import os
+    pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlog10_pin.json")))
+    assert pin["entries"] == 2048 and pin["mbits"] == 11 and pin["mconv"] == 0.301029995663981
+    assert pin["max_abs_deviation_from_log2_1_plus_m_over_2048"] < 2.3e-16 and pin["first"] == 0.0
+    L = oracle.lib()
+    L.wo_mlog10_value.restype = C.c_double
+    L.wo_mlog10_value.argtypes = [C.c_double]
+    for v in (1.0, 1.0 + 1.0 / 2048.0, 0.75, 3.1e-7, 2.0 ** -40 * 1.9995):
+        bits = np.float64(v).view(np.uint64)
+        e = int((bits >> np.uint64(52)) & np.uint64(2047)) - 1023
+        m = int((bits >> np.uint64(41)) & np.uint64(2047))
+        assert L.wo_mlog10_value(v) == pin["mconv"] * (e + np.log2(1.0 + m / 2048.0))
+    assert abs(L.wo_mlog10_value(1.0 + 2047.0 / 2048.0) / pin["mconv"] - pin["last"]) < 3e-16
