@@ -513,6 +513,28 @@ int ao_get_pixels(ao_disp *a, int pixout, float *pix)
     return 1;
 }
 
+/* ResetPixelBuffers, analyzer.c:927-996.  (Mode 2 keeps av_sum: its case only has a comment, the sum is not cleared.) */
+void ao_reset_pixel_buffers(ao_disp *a)
+{
+    int i, j, k;
+    for (i = 0; i < AO_MAX_PIXOUTS; i++) {
+        for (j = 0; j < AO_MAX_PIXELS; j++) a->t_pixels[i][j] = 0.0;
+        for (j = 0; j < AO_MAX_AVERAGE; j++) for (k = 0; k < AO_MAX_PIXELS; k++) a->av_buff[i][j][k] = 0.0;
+        switch (a->av_mode[i]) {
+        case 1: for (j = 0; j < AO_MAX_PIXELS; j++) a->av_sum[i][j] = 1.0e-12; break;
+        case 2: break;
+        case 3: for (j = 0; j < AO_MAX_PIXELS; j++) a->av_sum[i][j] = -160.0; break;
+        default: memset(a->av_sum[i], 0, sizeof(double) * AO_MAX_PIXELS); break;
+        }
+        a->avail_frames[i] = a->av_in_idx[i] = a->av_out_idx[i] = 0;
+        a->w_pix[i] = a->r_pix[i] = a->last_pix[i] = 0;
+        for (j = 0; j < AO_NUM_PIXEL_BUFFS; j++) a->pb_ready[i][j] = 0;
+    }
+    memset(a->pre_av_out, 0, sizeof(double) * a->max_size * a->max_stitch);
+    a->stitch_flag = 0;
+    for (i = 0; i < AO_MAX_STITCH; i++) { a->busy[i] = a->ready[i] = a->have[i] = a->in_idx[i] = a->out_idx[i] = 0; }
+}
+
 void ao_set_detector_mode(ao_disp *a, int pixout, int mode) { a->det_type[pixout] = mode; }     /* analyzer.c:1582 */
 void ao_set_average_mode(ao_disp *a, int pixout, int mode)                                      /* analyzer.c:1594-1623 */
 {

@@ -26,6 +26,7 @@ void ao_set_calibration(ao_disp *a, int set, int n_points, double *cal);
 void ao_spectrum0(ao_disp *a, int run, int ss, const double *pbuff);
 void ao_spectrum(ao_disp *a, int ss, const float *pI, const float *pQ);
 int ao_get_pixels(ao_disp *a, int pixout, float *pix);
+void ao_reset_pixel_buffers(ao_disp *a);
 void ao_set_detector_mode(ao_disp *a, int pixout, int mode);
 void ao_set_average_mode(ao_disp *a, int pixout, int mode);
 void ao_set_num_average(ao_disp *a, int pixout, int num);

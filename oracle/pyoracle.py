@@ -748,6 +748,10 @@ class OracleAnalyzer:
         flag = self.L.ao_get_pixels(self.h, pixout, pix.ctypes.data)
         return pix, flag
 
+    def ResetPixelBuffers(self):
+        self.L.ao_reset_pixel_buffers.argtypes = [C.c_void_p]
+        self.L.ao_reset_pixel_buffers(self.h)
+
     def SetDisplayDetectorMode(self, pixout, mode): self.L.ao_set_detector_mode(self.h, pixout, mode)
     def SetDisplayAverageMode(self, pixout, mode): self.L.ao_set_average_mode(self.h, pixout, mode)
     def SetDisplayNumAverage(self, pixout, num): self.L.ao_set_num_average(self.h, pixout, num)

@@ -200,3 +200,60 @@ def test_wdsp_named_exports_buffer_by_buffer(qh, oracle):
         assert nrows == 5
     finally:
         g.close()
+
+
+def test_writeahead_skip_reset_and_reconfiguration(qh, oracle):
+    """The corners of the ring bookkeeping: a max_writeahead smaller than a frame (the reference then keeps skipping samples,
+    analyzer.c:1428-1434, and never fills one), ResetPixelBuffers in mid-stream, and further SetAnalyzer calls with another
+    size / pixel count / detector on the same display."""
+    size, bf, npix = 2048, 512, 300
+    starve = (1, 1, 1, [0], size, bf, 1, 0.0, 0, 0, 0.0, 0.0, npix, 1, 0, 0.0, 0.0, 1024)
+    normal = starve[:-1] + (4 * size,)
+    x = _signal(48 * bf, 31)
+
+    def fresh_oracle(args):
+        o = oracle.OracleAnalyzer(8192)
+        o.SetDisplaySampleRate(RATE)
+        o.SetDisplayAverageMode(0, 2); o.SetDisplayNumAverage(0, 3)
+        o.SetAnalyzer(*args)
+        return o
+    a = fresh_oracle(starve)
+    g = qh.WdspDisplay(9, 8192)
+    try:
+        g.SetDisplaySampleRate(RATE)
+        g.SetDisplayAverageMode(0, 2); g.SetDisplayNumAverage(0, 3)
+        g.SetAnalyzer(*starve)
+        rows = []
+
+        def push(b):
+            blk = x[b * bf:(b + 1) * bf]
+            buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+            a.Spectrum0(1, 0, 0, buf); g.Spectrum0(1, 0, 0, buf)
+            want, wflag = a.GetPixels(0)
+            got, gflag = g.GetPixels(0)
+            assert gflag == wflag, b
+            if wflag:
+                _compare(got, want, b)
+                rows.append(b)
+        for b in range(8):
+            push(b)
+        assert rows == []                               # 1024 samples of write-ahead never make a 2048-sample frame
+        a.SetAnalyzer(*normal); g.SetAnalyzer(*normal)
+        for b in range(8, 20):
+            push(b)
+        assert len(rows) == 3
+        a.ResetPixelBuffers(); g.ResetPixelBuffers()    # (window averaging keeps its running sum across the reset, as in the reference)
+        for b in range(20, 30):
+            push(b)
+        assert len(rows) == 5
+        # another transform size, pixel count and detector on the same display
+        args2 = (1, 1, 1, [0], 4096, bf, 4, 0.0, 2048, 16, 5.5, 0.0, 777, 1, 0, 0.0, 0.0, 8192)
+        a.SetDisplayDetectorMode(0, 2); g.SetDisplayDetectorMode(0, 2)
+        a.SetDisplayAverageMode(0, 1); g.SetDisplayAverageMode(0, 1)
+        a.SetDisplayAvBackmult(0, 0.6); g.SetDisplayAvBackmult(0, 0.6)
+        a.SetAnalyzer(*args2); g.SetAnalyzer(*args2)
+        for b in range(30, 48):
+            push(b)
+        assert len(rows) == 5 + 3
+    finally:
+        g.close()
