@@ -28,6 +28,61 @@ static __global__ __launch_bounds__(64) void q_am_env_kernel(double2 *buf, long 
     if (lane == 0) dc_state[ch] = carry;
 }
 
+// The same over kSegWaves time segments (long calls), as q_fm_disc_tiled_kernel below: pass 1 = each segment's response to its
+// own magnitudes from a zero state, chained; pass 2 = the scan from the true carry and the first difference.
+static __global__ __launch_bounds__(kSegThreads) void q_am_env_tiled_kernel(double2 *buf, long long stride, int n, double *dc_state)
+{
+    __shared__ double s_e[kSegWaves];
+    __shared__ int s_n[kSegWaves];
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2 *p = buf + (long long)ch * stride;
+    int b0, b1;
+    seg_range(n, wave, b0, b1);
+    const PoleScan sc = make_pole_scan(0.99, lane);
+    const double m64 = lane_pow(0.99, 64);
+    double acc = 0.0;
+    double2 zn[kSegGroup];
+    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double2 zz[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
+        seg_load(zn, b + kSegGroup, b1, n, lane, (const double2 *)p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            acc = __builtin_fma(acc, m64, hypot(zz[k].x, zz[k].y));        // lanes past the end of the call hold zeros
+        }
+    }
+    const double e = wave_sum_d(acc * lane_pow(0.99, 63 - lane));
+    if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); }
+    __syncthreads();
+    double c = dc_state[ch];
+    for (int w = 0; w < wave; w++) if (s_n[w]) c = __builtin_fma(c, pow(0.99, (double)s_n[w]), s_e[w]);
+    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double2 zz[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
+        seg_load(zn, b + kSegGroup, b1, n, lane, (const double2 *)p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double di = lane < cnt ? hypot(zz[k].x, zz[k].y) : 0.0;
+            const double dc = scan_pole_dpp(di, sc) + sc.pw * c;
+            double prev = wave_shr1(dc);
+            if (lane == 0) prev = c;
+            const double out = dc - prev;
+            if (lane < cnt) p[base + lane] = make_double2(out, out);
+            c = lane_bcast(dc, cnt - 1);
+        }
+    }
+    int last = kSegWaves - 1;
+    while (last > 0 && s_n[last] == 0) last--;
+    if (wave == last && lane == 0 && n > 0) dc_state[ch] = c;
+}
+
 // Quisk's FM detector (quisk.c:2032-2064): di = arg(z * conj(z_prev)) * 20e5, then the one-pole de-emphasis
 // y = di*a0 + x1*a1 - y1*b1.  state: {z_prev.re, z_prev.im, x1, y1}.  In place, (y, 0).
 struct QFmParam { double a0, a1, b1; };
@@ -60,19 +115,108 @@ static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long
 }
 
 
+// The same detector with the call cut into kSegWaves time segments, one wavefront each (long calls: the sequential form leaves one
+// wavefront per receiver busy for milliseconds).  The discriminator needs the sample before it -- from the neighbour lane, the
+// batch before, the segment before (read in place ahead of the barrier: the buffer is only overwritten in pass 2) or the carried
+// state; the de-emphasis is a one-pole recurrence: pass 1 takes each segment's response to its own samples from a zero state
+// (lane-local accumulation, one weighted wave sum), the sixteen are chained, pass 2 runs the scan from the true carry.
+static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(double2 *buf, long long stride, int n, double4 *state, QFmParam q)
+{
+    __shared__ double s_e[kSegWaves], s_z[kSegWaves][3];
+    __shared__ int s_n[kSegWaves];
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2 *p = buf + (long long)ch * stride;
+    const double4 st0 = state[ch];
+    const double pole = -q.b1;
+    int b0, b1;
+    seg_range(n, wave, b0, b1);
+    const PoleScan sc = make_pole_scan(pole, lane);
+    const double m64 = lane_pow(pole, 64);
+    auto z_at = [&](int i) -> double2 { return i >= 0 ? p[i] : make_double2(st0.x, st0.y); };
+    auto disc = [&](double2 z, double2 zp) -> double { return atan2(z.y * zp.x - z.x * zp.y, z.x * zp.x + z.y * zp.y) * 20e5; };
+    // the sample ahead of the segment and its discriminator value
+    const int i0 = b0 * 64;
+    double2 zc = z_at(i0 - 1);
+    double dc = i0 >= 1 ? disc(zc, z_at(i0 - 2)) : st0.z;
+    const double2 zc0 = zc;
+    const double dc0 = dc;
+    double acc = 0.0;
+    double2 zn[kSegGroup];
+    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double2 zz[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
+        seg_load(zn, b + kSegGroup, b1, n, lane, (const double2 *)p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double2 z = zz[k];
+            double2 zp = make_double2(wave_shr1(z.x), wave_shr1(z.y));
+            if (lane == 0) zp = zc;
+            const double di = disc(z, zp);
+            double dm1 = wave_shr1(di);
+            if (lane == 0) dm1 = dc;
+            acc = __builtin_fma(acc, m64, lane < cnt ? di * q.a0 + dm1 * q.a1 : 0.0);
+            zc = make_double2(lane_bcast(z.x, cnt - 1), lane_bcast(z.y, cnt - 1));
+            dc = lane_bcast(di, cnt - 1);
+        }
+    }
+    const double e = wave_sum_d(acc * lane_pow(pole, 63 - lane));
+    if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); s_z[wave][0] = zc.x; s_z[wave][1] = zc.y; s_z[wave][2] = dc; }
+    __syncthreads();
+    double c = st0.w;
+    for (int w = 0; w < wave; w++) if (s_n[w]) c = __builtin_fma(c, pow(pole, (double)s_n[w]), s_e[w]);
+    // pass 2 (zc0 / dc0 were read before anybody wrote)
+    zc = zc0; dc = dc0;
+    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double2 zz[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
+        seg_load(zn, b + kSegGroup, b1, n, lane, (const double2 *)p);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double2 z = zz[k];
+            double2 zp = make_double2(wave_shr1(z.x), wave_shr1(z.y));
+            if (lane == 0) zp = zc;
+            const double di = disc(z, zp);
+            double dm1 = wave_shr1(di);
+            if (lane == 0) dm1 = dc;
+            const double y = scan_pole_dpp(lane < cnt ? di * q.a0 + dm1 * q.a1 : 0.0, sc) + sc.pw * c;
+            if (lane < cnt) p[base + lane] = make_double2(y, 0.0);
+            c = lane_bcast(y, cnt - 1);
+            zc = make_double2(lane_bcast(z.x, cnt - 1), lane_bcast(z.y, cnt - 1));
+            dc = lane_bcast(di, cnt - 1);
+        }
+    }
+    int last = kSegWaves - 1;
+    while (last > 0 && s_n[last] == 0) last--;
+    if (wave == last && lane == 0 && n > 0) state[ch] = make_double4(zc.x, zc.y, dc, c);
+}
+
 // FM squelch (quisk.c:2032-2033,2076-2085): the mean |cx| of the Rx-filtered samples over at least 2400 of them
 // (evaluated once per call, like the reference) in dB re full scale; active while it is below squelch_level.
 // One wave per channel; `buf` is the Rx filter's output of this call.
 struct QSquelchState { double rf_sum, squelch; int rf_count, active; };
-static __global__ __launch_bounds__(64) void q_fm_squelch_kernel(const double2 *buf, long long stride, int n, QSquelchState *state,
+static __global__ __launch_bounds__(kSegThreads) void q_fm_squelch_kernel(const double2 *buf, long long stride, int n, QSquelchState *state,
                                                              const double *level)
 {
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    // blockDim.x = 64 (short calls) or kSegThreads: the lanes stride over the call, a fixed reduction order joins them
+    __shared__ double s_part[kSegWaves];
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const double2 *p = buf + (long long)ch * stride;
     double s = 0.0;
-    for (int i = lane; i < n; i += 64) s += hypot(p[i].x, p[i].y);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += hypot(p[i].x, p[i].y);
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if (lane == 0) {
+    if (lane == 0) s_part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = 0.0;
+        for (int w = 0; w < nw; w++) s += s_part[w];
         QSquelchState st = state[ch];
         st.rf_sum += s; st.rf_count += n;
         if (st.rf_count >= 2400) {

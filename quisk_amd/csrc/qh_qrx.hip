@@ -16,6 +16,8 @@
 #include "qh_stage.hpp"
 #include "qh_qdemod.hpp"
 
+static constexpr int kQTiledMin = 8192;     // samples per call from which the detectors run over time segments
+
 namespace qh {
 
 // rx_mode_type, quisk.h:55-70
@@ -537,7 +539,10 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
             if (int rc = qh_rat_process(s.rat, cur, cur_stride, n, dst, dst_stride, &m)) return rc;
             break;
         case Step::AM_ENV:
-            if (n > 0)
+            if (n >= kQTiledMin)
+                hipLaunchKernelGGL(q_am_env_tiled_kernel, dim3((unsigned)q.nch), dim3(kSegThreads), 0, q.stream,
+                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.dc_state);
+            else if (n > 0)
                 hipLaunchKernelGGL(q_am_env_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.dc_state);
             continue;
@@ -581,10 +586,13 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                     QH_HIP(hipStreamSynchronize(q.stream));
                     q.sq_dirty = false;
                 }
-                hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream, static_cast<const double2 *>(cur),
-                                   cur_stride, n, q.sq_state, q.sq_level);
+                hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(n >= kQTiledMin ? kSegThreads : 64), 0, q.stream,
+                                   static_cast<const double2 *>(cur), cur_stride, n, q.sq_state, q.sq_level);
             }
-            if (n > 0)
+            if (n >= kQTiledMin)         // long calls: the detector over time segments (qh_qdemod.hpp)
+                hipLaunchKernelGGL(q_fm_disc_tiled_kernel, dim3((unsigned)q.nch), dim3(kSegThreads), 0, q.stream,
+                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);
+            else if (n > 0)
                 hipLaunchKernelGGL(q_fm_disc_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);
             continue;

@@ -85,4 +85,75 @@ __device__ __forceinline__ double mlog10_dev(double val)
     return 0.301029995663981 * ((double)e + log2(1.0 + (double)m / 2048.0));
 }
 
+// ---- time segments of a call: the helpers of the two-pass segment kernels (qh_tiled.hpp, qh_qdemod.hpp) --------------------
+static constexpr int kSegWaves = 16;                // wavefronts (time segments) per channel in the two-pass kernels
+static constexpr int kSegThreads = 64 * kSegWaves;
+
+// ---- DPP scans ------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_fetch_d(double v)
+{
+    // lanes the control leaves without a source (shifted in from outside the row, rows outside ROWMASK) read 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// v_i = m v_{i-1} + u_i over the 64 lanes, zero carry-in: Kogge-Stone inside each row of 16 (row_shr 1, 2, 4, 8), then
+// lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31).
+struct PoleScan { double m1, m2, m4, m8, pa, pb, pw; };     // pa = m^((lane & 15) + 1), pb = m^((lane & 31) + 1), pw = m^(lane + 1)
+__device__ __forceinline__ PoleScan make_pole_scan(double m, int lane)
+{
+    PoleScan p;
+    p.m1 = m; p.m2 = m * m; p.m4 = p.m2 * p.m2; p.m8 = p.m4 * p.m4;
+    p.pa = lane_pow(m, (lane & 15) + 1); p.pb = lane_pow(m, (lane & 31) + 1); p.pw = lane_pow(m, lane + 1);
+    return p;
+}
+__device__ __forceinline__ double scan_pole_dpp(double u, const PoleScan &p)
+{
+    u = __builtin_fma(p.m1, dpp_fetch_d<0x111, 0xf>(u), u);
+    u = __builtin_fma(p.m2, dpp_fetch_d<0x112, 0xf>(u), u);
+    u = __builtin_fma(p.m4, dpp_fetch_d<0x114, 0xf>(u), u);
+    u = __builtin_fma(p.m8, dpp_fetch_d<0x118, 0xf>(u), u);
+    u = __builtin_fma(p.pa, dpp_fetch_d<0x142, 0xa>(u), u);
+    u = __builtin_fma(p.pb, dpp_fetch_d<0x143, 0xc>(u), u);
+    return u;
+}
+
+// the segment of wavefront `wave`: batches of 64 samples [b0, b1) of the ceil(n / 64) in the call
+__device__ __forceinline__ void seg_range(int n, int wave, int &b0, int &b1)
+{
+    const int nb = (n + 63) >> 6;
+    b0 = (int)((long long)wave * nb / kSegWaves);
+    b1 = (int)((long long)(wave + 1) * nb / kSegWaves);
+}
+__device__ __forceinline__ int seg_samples(int n, int b0, int b1)
+{
+    const int lo = b0 * 64 < n ? b0 * 64 : n, hi = b1 * 64 < n ? b1 * 64 : n;
+    return hi - lo;
+}
+
+// Batches in flight per wavefront: a segment is walked in groups of kSegGroup batches, the next group's loads issued ahead
+// of the work on the current one (the recurrences chain the batches, the loads do not).
+static constexpr int kSegGroup = 8;
+template <typename V>
+__device__ __forceinline__ void seg_load(V (&z)[kSegGroup], int b, int b1, int n, int lane, const V *p)
+{
+#pragma unroll
+    for (int k = 0; k < kSegGroup; k++) {
+        const int i = (b + k) * 64 + lane;
+        z[k] = V{};
+        if (b + k < b1 && i < n) z[k] = p[i];
+    }
+}
+
+__device__ __forceinline__ void seg_load_re(double (&z)[kSegGroup], int b, int b1, int n, int lane, const double2 *p)
+{
+#pragma unroll
+    for (int k = 0; k < kSegGroup; k++) {
+        const int i = (b + k) * 64 + lane;
+        z[k] = 0.0;
+        if (b + k < b1 && i < n) z[k] = p[i].x;
+    }
+}
+
 }  // namespace qh

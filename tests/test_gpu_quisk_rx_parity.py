@@ -231,3 +231,28 @@ def test_ssb_squelch_and_its_audio_delay(qh, oracle, mode, name, bw):
     y2 = bank.process_host(x[:, :blk])[0]
     w2 = r.process(x[0, :blk])
     assert np.any(w2) and rel_rms(y2, w2) < 1e-9
+
+
+@pytest.mark.parametrize("mode", [4, 5])
+def test_detectors_over_time_segments_equal_block_calls(qh, oracle, mode):
+    """AM envelope + DC remover and the FM discriminator + de-emphasis (quisk.c:2002-2068): calls of 8192 detector samples and more
+    run them over sixteen time segments per receiver (qh_qdemod.hpp); the same stream in small pieces takes the sequential
+    kernels.  Same audio (FM behind its start-up, see test_modes_and_rates), and against the restatement."""
+    fs, nch = 192000, 2
+    n = 400000                                  # 50 000 (AM) / 100 000 (FM) samples at the detector in the long call
+    tabs = rxfilter.coefficient_tables()
+    x = np.stack([signal(mode, c, n, fs, 9000.0 + 500 * c) for c in range(nch)])
+    outs = []
+    for pieces in ([0, n], list(range(0, n, 9600)) + [n]):
+        bank = qh.QuiskRxBank(nch, fs, mode)
+        fI, fQ = default_filter(mode, bank.get_filter_rate())
+        for c in range(nch):
+            bank.set_tune(c, 9000 + 500 * c)
+            bank.set_filters(c, fI, fQ)
+        outs.append(np.concatenate([bank.process_host(x[:, a:b]) for a, b in zip(pieces, pieces[1:])], axis=1))
+    skip = 2000 if mode == 5 else 0
+    assert rel_rms(outs[0][:, skip:], outs[1][:, skip:]) < 1e-11
+    r = oracle.OracleQuiskRx(fs, tabs)
+    r.set_mode(mode); r.set_tune(9000); r.set_filters(*default_filter(mode, rxfilter.get_filter_rate(fs, mode)))
+    want = np.concatenate([r.process(x[0, k:k + 9600]) for k in range(0, n, 9600)])
+    assert want.size == outs[0].shape[1] and rel_rms(outs[0][0][skip:], want[skip:]) < 1e-9

@@ -120,6 +120,32 @@ def config5(torch, qh, dev):
             "note": "unfused cascade of overlap-save banks; the first half-band alone moves 12 B/sample"}
 
 
+def quisk_native(torch, qh, dev):
+    """Path A: 256 receivers of Quisk's own chain (quisk_process_samples: tune, quisk_process_decimate, cRxFilterOut, the x4
+    interpolators), 192 ksps in, 48 ksps out, USB, AM and FM, 2^20 input samples per receiver per step.  The reference's own
+    figure for ONE receiver on a CPU core is 9.9 Msamp/s."""
+    from quisk_amd import rxfilter
+    nch, n, fs = 256, 1 << 20, 192000
+    out = []
+    for name, mode, bw in (("USB", rxfilter.USB, 2700), ("AM", rxfilter.AM, 6000), ("FM", rxfilter.FM, 12000)):
+        bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=torch.cuda.current_stream(dev).cuda_stream)
+        rate = bank.get_filter_rate()
+        fI, fQ = rxfilter.make_filter_coef(rate, None, bw, rxfilter.get_filter_center(name, bw))
+        for c in range(nch):
+            bank.set_tune(c, 1000 * (c % 40) - 20000)
+        bank.set_filters(-1, fI, fQ)
+        x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 22
+        m = bank.out_count(n)
+        y = torch.empty((nch, m + 64), dtype=torch.complex128, device=dev)
+        sync = lambda: torch.cuda.synchronize(dev)
+        t = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), m + 64), sync, steps=8, warmup=2)
+        out.append({"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": rate, "filter_taps": int(fI.size)})
+        del bank, x, y
+    return {"config": "Quisk-native chain (path A): 256 receivers x 192 ksps -> 48 ksps, 2^20 input samples per receiver per step",
+            "samples_per_step": nch * n, "modes": out,
+            "note": "the reference's quisk_process_samples handles one receiver per process: 9.9 Msamp/s on a CPU core (SURVEY.md 8 a10)"}
+
+
 def analyzer(torch, qh, dev):
     """WDSP display engine (wdsp/analyzer.c) for a bank of 64 displays fed 2^20 samples each per step: 16384-point frames with
     50 % overlap (127 frames per display and step), Blackman-Harris window, peak detector to 2048 pixels, recursive averaging."""
@@ -147,7 +173,7 @@ def main():
     torch.cuda.set_device(dev)
     which = sys.argv[1:] or ["3", "4", "5"]
     for w in which:
-        r = {"3": config3, "4": config4, "5": config5, "analyzer": analyzer}[w](torch, qh, dev)
+        r = {"3": config3, "4": config4, "5": config5, "analyzer": analyzer, "quisk": quisk_native}[w](torch, qh, dev)
         print(json.dumps(r), flush=True)
 
 
