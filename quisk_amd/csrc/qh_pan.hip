@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
     // e_j = exp(-2 pi i m_j / N), m_j = t + 256 (MJ s + j): e_0 and a step of 256
     C e0, estep;
     sincospi(-2.0 * (double)(t + 256 * MJ * s) / (double)N, &e0.y, &e0.x);
-    sincospi(-2.0 * 256.0 / (double)N, &estep.y, &estep.x);
+    estep.x = 0.99518472667219693; estep.y = -0.098017140329560604;            // exp(-2 pi i 256 / N) = exp(-i pi / 32): literals stay out of the vector registers
     const PanBand pb = band[ch];
     double m2 = 0.0;
     unsigned whole = 0, part = 0;           // bit i: bin i of this lane counts fully / with weight frac
@@ -215,8 +215,12 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
     }
     // the S-meter passband is a few bins wide: almost every wavefront holds none of them and skips that sum
     const bool in_band = __ballot((whole | part) != 0) != 0ull;
-    // partial[split][ch][(bin + N/2) mod N]; bin = 4 (t + 256 i) + r: slot 4 t + r + 1024 ((i + 8) mod 16)
-    double *pp = partial + ((long long)split * nch + ch) * N + 4 * t + r;
+    // |X| sums of the workgroup's block range: sixteen registers per lane (read-modify-write of `partial` once per block, even
+    // laid out so that a wavefront's accesses coalesce, was 0.19 of this kernel's 0.64 ms on config 3 -- the sums spill less than the
+    // sixteen slot addresses did)
+    double racc[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) racc[i] = 0.0;
     for (int blk = b0; blk < b1; blk++) {
         const C *x = in + (long long)ch * in_stride + (long long)blk * N + (t + 256 * MJ * s);
         double oim[16];                     // imaginary parts of this thread's sixteen results, [j][group]: they travel second
@@ -250,8 +254,9 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 #pragma unroll
             for (int g = 0; g < G; g++) { xw[(g * 16 + j) * 256] = o[g].x; oim[G * j + g] = o[g].y; }
             e = cmul(e, estep);
-            // one j at a time -- four loads in flight, sixteen values kept: all 16 loads at once (latency paid once) cost
-            // 30 more spilled registers and measured slower (0.67 against 0.65 ms on config 3)
+            // one j at a time -- four loads in flight, sixteen values kept.  Measured slower: all 16 loads at once (30 more spilled
+            // registers); the loads of j + 1 issued ahead of j's arithmetic; the next block's first four issued behind the transform,
+            // ahead of the |X| arithmetic (75 instead of 29 spilled registers)
             __builtin_amdgcn_sched_barrier(0);
         }
         C u[E];
@@ -272,18 +277,19 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
         typename S::Tw twb = twf;
         asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
         S::run_at(u, image, twb, t);
-        double *ppb = pp;
-        asm volatile("" : "+v"(ppb));       // (likewise the sixteen slot addresses)
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
-            double *slot = ppb + 1024 * ((i + 8) & 15);
-            const double prev = blk == b0 ? 0.0 : *slot;
-            *slot = prev + sqrt_pow(pw2);   // cabs(): no overflow / underflow concern at +-2^31 * N full scale
+            racc[i] += sqrt_pow(pw2);       // cabs(): no overflow / underflow concern at +-2^31 * N full scale
             if (in_band) m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // partial[split][ch][r][t + 256 i] for bin = 4 (t + 256 i) + r (pan_reduce_kernel undoes the order): coalesced stores; a block range
+    // that came out empty (nblk not a multiple of the ranges) stores its zeros
+    double *pp = partial + ((long long)split * nch + ch) * N + r * M + t;
+#pragma unroll
+    for (int i = 0; i < E; i++) pp[256 * i] = racc[i];
     // S-meter partial: lanes -> wave -> group of four waves (one r), fixed order, in the layout of pan_spectrum_kernel
     for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
     if ((T & 63) == 0) wsum[T >> 6] = m2;
@@ -296,14 +302,20 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 }
 
 // fft_avg += sum over the block ranges; meter += sum over ranges and r.  One thread per (channel, index).
+// by_residue: the partial sums lie as [r][bin / 4] (pan16k_kernel) instead of in fft_avg's order.
 __global__ __launch_bounds__(NT) void pan_reduce_kernel(const double *partial, const double *partial_m2, int nsplit, int N, int R,
-                                                        double *avg, double *meter)
+                                                        double *avg, double *meter, int by_residue)
 {
     const int ch = blockIdx.y, nch = gridDim.y;
     const int idx = blockIdx.x * NT + threadIdx.x;
     if (idx < N) {
         double sacc = 0.0;
-        for (int sp = 0; sp < nsplit; sp++) sacc += partial[((long long)sp * nch + ch) * N + idx];
+        int src = idx;
+        if (by_residue) {
+            const int bin = (idx + N / 2) % N;
+            src = (bin & 3) * (N / 4) + (bin >> 2);
+        }
+        for (int sp = 0; sp < nsplit; sp++) sacc += partial[((long long)sp * nch + ch) * N + src];
         avg[(long long)ch * N + idx] += sacc;
     }
     if (idx == 0) {
@@ -605,7 +617,7 @@ struct Pan {
         default:   launch<4096>(p, src_stride, nblk, nsplit); break;
         }
         hipLaunchKernelGGL(pan_reduce_kernel, dim3((unsigned)((N + NT - 1) / NT), (unsigned)nch), dim3(NT), 0, stream, partial, partial_m2,
-                           nsplit, N, R, avg, meter);
+                           nsplit, N, R, avg, meter, (M == 4096 && R == 4) ? 1 : 0);
         count += nblk;
         QH_HIP(hipGetLastError());
         return QH_OK;

@@ -102,3 +102,20 @@ def test_quisk_sizes_that_are_not_powers_of_two(qh, oracle, fft_size, data_width
     assert p.get_graph() is None
     with pytest.raises(qh.QuiskHipError):
         qh.Panadapter(1, 4001, 1000, fs)                    # "FFT size must be an even number", quisk.py:186
+
+
+def test_block_ranges_that_come_out_empty(qh, oracle):
+    """64 channels x 16384 points split a call's blocks into four ranges per channel; five blocks leave the fourth range empty
+    (2 + 2 + 1 + 0).  Its partial sums must count as zero, not as what an earlier, longer call left in the buffer."""
+    fs, nch, N = 1536000.0, 64, 16384
+    x = make(nch, N * 8, fs, 21)
+    p = qh.Panadapter(nch, N, 1024, fs)
+    p.feed_host(x)                                  # eight blocks: every range of every channel holds sums
+    assert p.get_graph()[2] == 8
+    p.feed_host(x[:, :5 * N])
+    pix, sm, cnt = p.get_graph()
+    assert cnt == 5
+    for c in (0, 17, 63):
+        r = oracle.OracleGraph(N, 1024, fs); r.feed(x[c, :5 * N])
+        rp, rs, _ = r.get()
+        assert np.abs(pix[c] - rp).max() < 1e-8 and abs(sm[c] - rs) < 1e-8
