@@ -26,13 +26,15 @@ def needs_build():
 
 
 def build(force=False, verbose=False, defines=(), out=None):
-    """defines/out: experiment builds (tools/ab_bench.py) with -D overrides into another file."""
+    """defines/out: experiment builds (tools/ab_bench.py) with -D overrides into another file; QH_HIPCC_FLAGS in the environment adds
+    compiler flags to such builds (scheduler strategies and the like)."""
     target = out or LIB
     if not force and not out and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(target), exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-x", "hip", "-o", target] + ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-x", "hip", "-o", target] + ["-D" + d for d in defines] + os.environ.get("QH_HIPCC_FLAGS", "").split() + \
+          [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
