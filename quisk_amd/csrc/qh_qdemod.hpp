@@ -28,6 +28,15 @@ static __global__ __launch_bounds__(64) void q_am_env_kernel(double2 *buf, long 
     if (lane == 0) dc_state[ch] = carry;
 }
 
+// Pass 1 of the two-pass kernels below needs a segment's response to its own samples only as far back as the pole remembers:
+// contributions older than kTail batches are below pole^(64 kTail) <= 1e-22 of full scale, far under the last bit of what they are
+// added to.  Batches of a segment ahead of that are skipped in pass 1 (a segment shorter than the tail is walked whole: exact).
+__device__ __forceinline__ int seg_tail_batches(double pole)
+{
+    const double t = -50.66 / (64.0 * log(fabs(pole)));        // ln 1e-22 = -50.66
+    return t < 1.0e6 ? (int)t + 1 : 1000000;
+}
+
 // The same over kSegWaves time segments (long calls), as q_fm_disc_tiled_kernel below: pass 1 = each segment's response to its
 // own magnitudes from a zero state, chained; pass 2 = the scan from the true carry and the first difference.
 static __global__ __launch_bounds__(kSegThreads) void q_am_env_tiled_kernel(double2 *buf, long long stride, int n, double *dc_state)
@@ -42,8 +51,9 @@ static __global__ __launch_bounds__(kSegThreads) void q_am_env_tiled_kernel(doub
     const double m64 = lane_pow(0.99, 64);
     double acc = 0.0;
     double2 zn[kSegGroup];
-    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
-    for (int b = b0; b < b1; b += kSegGroup) {
+    const int tail = seg_tail_batches(0.99), bs = b1 - b0 > tail ? b1 - tail : b0;
+    seg_load(zn, bs, b1, n, lane, (const double2 *)p);
+    for (int b = bs; b < b1; b += kSegGroup) {
         double2 zz[kSegGroup];
 #pragma unroll
         for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
@@ -142,8 +152,11 @@ static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(dou
     const double dc0 = dc;
     double acc = 0.0;
     double2 zn[kSegGroup];
-    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
-    for (int b = b0; b < b1; b += kSegGroup) {
+    // pass 1 over the tail of the segment that the de-emphasis still remembers at its end (seg_tail_batches)
+    const int tail = seg_tail_batches(pole), bs = b1 - b0 > tail ? b1 - tail : b0;
+    if (bs > b0) { zc = z_at(bs * 64 - 1); dc = disc(zc, z_at(bs * 64 - 2)); }
+    seg_load(zn, bs, b1, n, lane, (const double2 *)p);
+    for (int b = bs; b < b1; b += kSegGroup) {
         double2 zz[kSegGroup];
 #pragma unroll
         for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];

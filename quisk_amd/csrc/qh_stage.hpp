@@ -4,6 +4,13 @@
 //   decimating   y[m] = sum_k h[k] x'[decim*m + (decim-1-phase) - k]      (x' = x * NCO when mix)
 //   interpolating y[n] = sum_m h[m] u[n-m], u[interp*i] = x[i]
 // Taps: one set for all channels or one set per channel; optional per-channel 2x2 real output matrix.
+//
+// A mixing fp64 stage that decimates by an even factor with REAL taps keeps its oscillator BEHIND the filter (`outmix`, the
+// RXA front stage's form, qh_osfir.hpp OUTMIX): with theta(n) = phi + delta n,
+//      sum_k h[k] x[g - k] exp(j theta(g - k)) = exp(j theta(g)) sum_k (h[k] exp(-j delta k)) x[g - k],
+// so every channel gets its own mask (the taps modulated down by its delta, front_mask_kernel), the tile kernel rotates the
+// 4096 / fold folded outputs instead of the 4096 inputs, and the history rows hold raw samples -- rewritten for the new phase
+// law when a channel is retuned (nco_retune_hist_kernel), because the reference mixed them sample by sample with the old one.
 #pragma once
 #include <cmath>
 #include <vector>
@@ -18,6 +25,13 @@ static constexpr int kStageNfft = 4096;
 struct Stage {
     int device = 0, nch = 0, ntaps = 0, decim = 1, interp = 1, dtype = QH_F64;
     bool mix = false, per_channel = false;
+    bool outmix = false;                        // oscillator behind the filter (see above); decided by the first set_taps
+    bool taps_set = false;
+    double *taps_re = nullptr;                  // outmix: the real taps on the device, for front_mask_kernel
+    double2 *lane_rot = nullptr, *out_step = nullptr, *tile_rot = nullptr;
+    int tile_cap = 0;
+    int *d_list = nullptr;
+    unsigned long long *d_law = nullptr;
     int fold = 1, pick = 1, P = 0, Lf = 0;      // decimating: Lf folded outputs per tile; interpolating: Lf high-rate outputs per tile
     int hist_len = 0;                           // history rows (input-rate samples)
     int phase = 0;                              // decim_index
@@ -33,8 +47,10 @@ struct Stage {
     {
         (void)hipFree(mask); (void)hipFree(tw_fwd); (void)hipFree(tw_inv); (void)hipFree(hist[0]); (void)hipFree(hist[1]);
         (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
+        (void)hipFree(taps_re); (void)hipFree(lane_rot); (void)hipFree(out_step); (void)hipFree(tile_rot); (void)hipFree(d_list); (void)hipFree(d_law);
         mask = tw_fwd = tw_inv = hist[0] = hist[1] = nullptr;
         nco_phase = nco_dphase = nullptr; nco_step = nullptr; epi = nullptr;
+        taps_re = nullptr; lane_rot = out_step = tile_rot = nullptr; d_list = nullptr; d_law = nullptr; tile_cap = 0;
     }
 
     int upload_cplx(void *dst, const std::vector<cd> &v)
@@ -77,7 +93,9 @@ struct Stage {
         if (Lf <= 0) return set_error(QH_ERR_UNSUPPORTED, "%d taps with decimation %d / interpolation %d do not fit a %d-point tile",
                                       ntaps, decim, interp, kStageNfft);
         QH_HIP(hipSetDevice(device));
-        const size_t nmask = (size_t)(per_channel ? nch : 1) * kStageNfft;
+        outmix = mix && dtype == QH_F64 && interp == 1 && fold > 1;      // taken back by set_taps if the taps are not real
+        taps_set = false;
+        const size_t nmask = (size_t)(per_channel || outmix ? nch : 1) * kStageNfft;
         QH_HIP(hipMalloc(&mask, nmask * esize));
         QH_HIP(hipMemsetAsync(mask, 0, nmask * esize, stream));
         const int nfwd = interp > 1 ? kStageNfft / interp : kStageNfft;
@@ -101,6 +119,17 @@ struct Stage {
             QH_HIP(hipMemcpyAsync(nco_step, one.data(), (size_t)nch * 16, hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
         }
+        if (outmix) {
+            QH_HIP(dev_alloc(&taps_re, (size_t)ntaps));
+            QH_HIP(dev_alloc(&lane_rot, (size_t)nch * NT));
+            QH_HIP(dev_alloc(&out_step, (size_t)nch));
+            QH_HIP(dev_alloc(&d_list, (size_t)nch));
+            QH_HIP(dev_alloc(&d_law, (size_t)2));
+            std::vector<int> all((size_t)nch);
+            for (int c = 0; c < nch; c++) all[(size_t)c] = c;
+            QH_HIP(hipMemcpyAsync(d_list, all.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
         if (with_epi) {
             QH_HIP(dev_alloc(&epi, (size_t)nch));
             std::vector<EpiParam> id((size_t)nch, EpiParam{ 1, 0, 0, 1 });
@@ -117,6 +146,22 @@ struct Stage {
     {
         if ((int)taps.size() > ntaps) return set_error(QH_ERR_INVALID, "more taps than the stage was created for");
         QH_HIP(hipSetDevice(device));
+        if (outmix) {
+            bool real = true;
+            for (const cd &v : taps) if (v.imag() != 0.0) { real = false; break; }
+            if (!real) {
+                if (taps_set) return set_error(QH_ERR_UNSUPPORTED, "a mixing stage that ran with real taps cannot take complex ones");
+                outmix = false;                 // complex taps: the oscillator stays at the input (MIX)
+            }
+        }
+        taps_set = true;
+        if (outmix) {
+            std::vector<double> re((size_t)ntaps, 0.0);
+            for (size_t i = 0; i < taps.size(); i++) re[i] = taps[i].real();
+            QH_HIP(hipMemcpyAsync(taps_re, re.data(), (size_t)ntaps * 8, hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            return build_outmix_tables(0, nch);
+        }
         std::vector<cd> m = make_mask(taps, kStageNfft);
         if (poly()) {
             // the decimating fp64 kernel runs the polyphase form of its transform (FftSplit4096::run_poly): the fold then reads
@@ -149,6 +194,17 @@ struct Stage {
         return upload_cplx(dst, m);
     }
 
+    // outmix: masks (modulated taps, polyphase form), lane phasors and per-register steps of channels [c0, c0 + n)
+    int build_outmix_tables(int c0, int n)
+    {
+        hipLaunchKernelGGL((front_mask_kernel<kStageNfft>), dim3((unsigned)n), dim3(NT), (size_t)(TileFft<kStageNfft, false, double2>::kLdsBytes),
+                           stream, (const double *)taps_re, ntaps, (const unsigned long long *)nco_dphase, (const int *)(d_list + c0), fold,
+                           static_cast<const double2 *>(tw_fwd), static_cast<double2 *>(mask), lane_rot, out_step, 1);
+        QH_HIP(hipGetLastError());
+        QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+
     // NCO of channel ch: frequency ratio f/rate in turns per input sample (negative = tune down)
     int set_nco(int ch, double freq, double rate)
     {
@@ -158,6 +214,19 @@ struct Stage {
         t -= floorl(t);
         long double sc = t * 18446744073709551616.0L;
         unsigned long long d = sc >= 18446744073709551616.0L ? 0ull : (unsigned long long)sc;
+        if (outmix) {
+            // the raw history was going to be seen through the old phase law: re-express it for the new one (the kernel reads the
+            // old law from the device arrays, so it runs ahead of their update), then rebuild the channel's tables
+            const unsigned long long law[2] = { 0ull, d };
+            QH_HIP(hipMemcpyAsync(d_law, law, sizeof(law), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(nco_retune_hist_kernel, dim3((unsigned)((hist_len + NT - 1) / NT), 1u), dim3(NT), 0, stream,
+                               static_cast<double2 *>(hist[cur]), hist_len, (const unsigned long long *)nco_phase,
+                               (const unsigned long long *)nco_dphase, (const unsigned long long *)nullptr, (const int *)(d_list + ch),
+                               (const unsigned long long *)d_law);
+            QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, 8, hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            return taps_set ? build_outmix_tables(ch, 1) : QH_OK;
+        }
         long double ang = 2.0L * 3.14159265358979323846264338327950288L * ((long double)(d * (unsigned long long)NT) / 18446744073709551616.0L);
         double2 st = make_double2((double)cosl(ang), (double)sinl(ang));
         QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, 8, hipMemcpyHostToDevice, stream));
@@ -207,7 +276,25 @@ struct Stage {
         if (mix) return fold == 1 ? attr_one<T, 1, true>() : fold == 2 ? attr_one<T, 2, true>() : fold == 4 ? attr_one<T, 4, true>() : attr_one<T, 8, true>();
         return fold == 1 ? attr_one<T, 1, false>() : fold == 2 ? attr_one<T, 2, false>() : fold == 4 ? attr_one<T, 4, false>() : attr_one<T, 8, false>();
     }
-    int set_attr() { return dtype == QH_F64 ? set_attr_t<double>() : set_attr_t<float>(); }
+    template <int FOLD> int attr_outmix()
+    {
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<double, kStageNfft, FOLD, false, false, false, true, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, kStageNfft, FOLD>())));
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_mask_kernel<kStageNfft>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   TileFft<kStageNfft, false, double2>::kLdsBytes));
+        return QH_OK;
+    }
+    int set_attr()
+    {
+        if (outmix) if (int rc = fold == 2 ? attr_outmix<2>() : fold == 4 ? attr_outmix<4>() : attr_outmix<8>()) return rc;
+        return dtype == QH_F64 ? set_attr_t<double>() : set_attr_t<float>();
+    }
+    template <int FOLD> void launch_outmix(const OsfirArgs<double> &a)
+    {
+        dim3 grid((unsigned)a.ntiles * (unsigned)nch), block(NT);
+        constexpr int lds = osfir_lds_bytes<double, kStageNfft, FOLD>();
+        hipLaunchKernelGGL((osfir_kernel<double, kStageNfft, FOLD, false, false, false, true, false, true>), grid, block, lds, stream, a);
+    }
 
     template <typename T, int FOLD, bool MIX> void launch_dec(const OsfirArgs<T> &a)
     {
@@ -232,7 +319,7 @@ struct Stage {
         a.in = static_cast<const cplx<T> *>(in); a.in_stride = in_stride;
         a.hist = static_cast<const cplx<T> *>(hist[cur]); a.hist_stride = hist_len; a.hist_len = hist_len;
         a.out = static_cast<cplx<T> *>(out); a.out_stride = out_stride; a.out_offset = 0;
-        a.mask = static_cast<const cplx<T> *>(mask); a.mask_stride = per_channel ? kStageNfft : 0;
+        a.mask = static_cast<const cplx<T> *>(mask); a.mask_stride = per_channel || outmix ? kStageNfft : 0;
         a.tw_fwd = static_cast<const cplx<T> *>(tw_fwd); a.tw_inv = static_cast<const cplx<T> *>(tw_inv);
         a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
         a.epi = epi;
@@ -245,14 +332,35 @@ struct Stage {
                 a.off = decim - 1 - phase; a.pick = pick;
                 const int per_tile = Lf / pick;
                 a.ntiles = (nout + per_tile - 1) / per_tile;
-                if (mix) switch (fold) { case 1: launch_dec<T, 1, true>(a); break; case 2: launch_dec<T, 2, true>(a); break;
+                if constexpr (sizeof(T) == 8) if (outmix) {
+                    if (a.ntiles > tile_cap) {
+                        QH_HIP(hipStreamSynchronize(stream));
+                        (void)hipFree(tile_rot); tile_rot = nullptr; tile_cap = 0;
+                        QH_HIP(dev_alloc(&tile_rot, (size_t)nch * (size_t)a.ntiles));
+                        tile_cap = a.ntiles;
+                    }
+                    // oscillator phase at the first input index of every tile: g0 = off - P + tile * fold * Lf
+                    hipLaunchKernelGGL(nco_tile_kernel, dim3((unsigned)((a.ntiles + 255) / 256), (unsigned)nch), dim3(256), 0, stream,
+                                       (const unsigned long long *)nco_phase, (const unsigned long long *)nco_dphase, tile_rot, a.ntiles,
+                                       (long long)(a.off - a.P), (long long)fold * Lf);
+                    a.tile_rot = tile_rot; a.lane_rot = lane_rot; a.nco_step = out_step;
+                    switch (fold) { case 2: launch_outmix<2>(a); break; case 4: launch_outmix<4>(a); break; default: launch_outmix<8>(a); }
+                }
+                if (outmix) { }
+                else if (mix) switch (fold) { case 1: launch_dec<T, 1, true>(a); break; case 2: launch_dec<T, 2, true>(a); break;
                                          case 4: launch_dec<T, 4, true>(a); break; default: launch_dec<T, 8, true>(a); }
                 else switch (fold) { case 1: launch_dec<T, 1, false>(a); break; case 2: launch_dec<T, 2, false>(a); break;
                                      case 4: launch_dec<T, 4, false>(a); break; default: launch_dec<T, 8, false>(a); }
             }
         }
         dim3 g((unsigned)((hist_len + NT - 1) / NT), (unsigned)nch);
-        if (mix) {
+        if (outmix) {           // raw history; the phase advances all the same
+            hipLaunchKernelGGL((hist_update_kernel<T, false>), g, dim3(NT), 0, stream, a.in, in_stride, n_in, a.hist,
+                               static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, (const unsigned long long *)nullptr,
+                               (const unsigned long long *)nullptr, (const int *)nullptr);
+            hipLaunchKernelGGL(nco_advance_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, stream, nco_phase, nco_dphase,
+                               nch, (long long)n_in);
+        } else if (mix) {
             hipLaunchKernelGGL((hist_update_kernel<T, true>), g, dim3(NT), 0, stream, a.in, in_stride, n_in, a.hist,
                                static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, nco_phase, nco_dphase, (const int *)nullptr);
             hipLaunchKernelGGL(nco_advance_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, stream, nco_phase, nco_dphase,
