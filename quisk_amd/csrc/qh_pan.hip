@@ -167,12 +167,12 @@ __global__ __launch_bounds__(NT, QH_PAN_WAVES) void pan_spectrum_kernel(const do
 // (a 4-point DFT over q) for the workgroup's r values, applies W_N^(m r) -- W_N^m is the phasor the window already uses --
 // and the sixteen results change hands inside {(0, t) .. (G - 1, t)} through LDS (real parts, then imaginary parts, laid
 // over the G transform images).  Then every group runs the split-exchange FFT-4096 of qh_fft.hpp on its own image, the
-// barriers being the workgroup's.  |X| accumulates over the range's blocks in the workgroup's own slice of `partial`
-// (read and written once per block: it stays in L2 / Infinity Cache; registers are what these workgroups are short of).
+// barriers being the workgroup's.  |X| accumulates over the range's blocks in sixteen registers per lane and is stored once, in
+// the order [r][bin / 4] (pan_reduce_kernel undoes it).
 // G = 2 (72 KB of LDS, two workgroups per CU that cover each other's load phases, the block read twice, the second time
 // from L2: the two workgroups of a block sit 8 ids apart = on one XCD) or G = 4 (one workgroup per CU, one read).
 // Against pan_spectrum_kernel<4096, 4>: a half / a quarter of the load instructions, 16 wavefronts per CU instead of 8,
-// same partial-sum layout and summation order.
+// same summation order.
 #ifndef QH_PAN16K_GROUPS
 #define QH_PAN16K_GROUPS 4
 #endif
