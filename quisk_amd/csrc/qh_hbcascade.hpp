@@ -102,8 +102,12 @@ template <typename T, int NS, int S> struct HbStage {
                 const int ke = HE - 10 + r;
                 const C ctr = ce[ke / 2 - JE0].e[ke % 2];
                 acc[r].x = (T)0.5 * ctr.x; acc[r].y = (T)0.5 * ctr.y;
+            }
+            // taps outside, outputs inside: the R accumulation chains advance side by side (same order of additions per output)
 #pragma unroll
-                for (int i = 0; i < 11; i++) {
+            for (int i = 0; i < 11; i++) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
                     const int ka = HO + r - i, kb = K0 + r + i;
                     const C a = w[ka / 2 - J0].e[ka % 2], b = w[kb / 2 - J0].e[kb % 2];
                     acc[r].x += cc[i] * (a.x + b.x);
@@ -236,10 +240,13 @@ __global__ __launch_bounds__(NT, sizeof(T) == 4 ? 3 : 2) void hb45_cascade_kerne
         QH_PROBE(1);
         if (step + 1 < nsteps) fetch(base + STEP);
         HbStages<T, NS, 0>::run(lds, t, step >= 0, y, base >> NS, (long long)(n_in >> NS), probe_on, probe_row);
-        PR carry;
-        if (cdst >= 0) carry = lds[csrc];
+        // every lane reads (lanes without a carried pair read pair 0 and drop it): a value defined under a condition on both sides of
+        // the barrier went through scratch memory, and the scratch load's vmcnt(0) wait also waited for the prefetch above
+        // (and as two scalars-of-complex rather than one aggregate: the aggregate copy was given a stack slot)
+        const PR *cs = lds + (cdst >= 0 ? csrc : 0);
+        const C carry0 = cs->e[0], carry1 = cs->e[1];
         __syncthreads();
-        if (cdst >= 0) lds[cdst] = carry;
+        if (cdst >= 0) { lds[cdst].e[0] = carry0; lds[cdst].e[1] = carry1; }
         QH_PROBE(12);
         // no barrier here: the next step's ring-0 fill touches only the "new" columns, and is followed by one
     }
