@@ -28,15 +28,26 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "c2_traffic.json")
 
 
 def kernel_source_sha16():
-    """Fingerprint of the kernel sources: tools/pmc_pass.py stamps the counter-derived HBM traffic with it, and a stamp that
-    does not match the sources this run was built from is not reported (counters cannot be read from inside the run)."""
+    """Fingerprint of the sources the two measured kernels are compiled from -- qh_engine.hip and every file of quisk_amd/csrc it
+    includes, directly or not: tools/pmc_pass.py stamps the counter-derived HBM traffic with it, and a stamp that does not match the
+    sources this run was built from is not reported (counters cannot be read from inside the run).  Other translation units of the
+    library (panadapter, receiver bank, ...) do not enter."""
     import hashlib
-    h = hashlib.sha256()
+    import re
     d = os.path.join(ROOT, "quisk_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    seen, todo = [], ["qh_engine.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(os.path.join(d, f)):
+            continue
+        seen.append(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(os.path.join(d, f)).read(), re.M):
+            if "/" not in inc:
+                todo.append(inc)
+    h = hashlib.sha256()
+    for f in sorted(seen):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
