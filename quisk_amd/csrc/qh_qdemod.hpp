@@ -96,6 +96,7 @@ static __global__ __launch_bounds__(kSegThreads) void q_am_env_tiled_kernel(doub
 // Quisk's FM detector (quisk.c:2032-2064): di = arg(z * conj(z_prev)) * 20e5, then the one-pole de-emphasis
 // y = di*a0 + x1*a1 - y1*b1.  state: {z_prev.re, z_prev.im, x1, y1}.  In place, (y, 0).
 struct QFmParam { double a0, a1, b1; };
+struct QSquelchState { double rf_sum, squelch; int rf_count, active; };     // FM squelch, see q_fm_squelch_kernel
 static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long long stride, int n, double4 *state, QFmParam q)
 {
     const int ch = blockIdx.x, lane = threadIdx.x;
@@ -130,8 +131,26 @@ static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long
 // batch before, the segment before (read in place ahead of the barrier: the buffer is only overwritten in pass 2) or the carried
 // state; the de-emphasis is a one-pole recurrence: pass 1 takes each segment's response to its own samples from a zero state
 // (lane-local accumulation, one weighted wave sum), the sixteen are chained, pass 2 runs the scan from the true carry.
-static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(double2 *buf, long long stride, int n, double4 *state, QFmParam q)
+// the squelch's per-call update from the call's sum of |cx| (quisk.c:2076-2085)
+__device__ __forceinline__ void q_squelch_update(QSquelchState *state, const double *level, int ch, double s, int n)
 {
+    QSquelchState st = state[ch];
+    st.rf_sum += s; st.rf_count += n;
+    if (st.rf_count >= 2400) {
+        double v = st.rf_sum / st.rf_count / 2147483647.0;
+        st.squelch = v > 1.E-10 ? 20 * log10(v) : -200.0;
+        st.rf_sum = 0; st.rf_count = 0;
+    }
+    st.active = st.squelch < level[ch];
+    state[ch] = st;
+}
+
+// sq_state != nullptr: the FM squelch's sum of |cx| over the call rides on pass 2, which reads the same samples (a separate
+// q_fm_squelch_kernel launch read the call a second time: 0.25 of the FM mode's 3.5 ms at 256 receivers).
+static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(double2 *buf, long long stride, int n, double4 *state, QFmParam q,
+                                                                               QSquelchState *sq_state, const double *sq_level)
+{
+    __shared__ double s_sq[kSegWaves];
     __shared__ double s_e[kSegWaves], s_z[kSegWaves][3];
     __shared__ int s_n[kSegWaves];
     const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,6 +202,7 @@ static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(dou
     for (int w = 0; w < wave; w++) if (s_n[w]) c = __builtin_fma(c, pow(pole, (double)s_n[w]), s_e[w]);
     // pass 2 (zc0 / dc0 were read before anybody wrote)
     zc = zc0; dc = dc0;
+    double sq = 0.0;
     seg_load(zn, b0, b1, n, lane, (const double2 *)p);
     for (int b = b0; b < b1; b += kSegGroup) {
         double2 zz[kSegGroup];
@@ -200,6 +220,7 @@ static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(dou
             double dm1 = wave_shr1(di);
             if (lane == 0) dm1 = dc;
             const double y = scan_pole_dpp(lane < cnt ? di * q.a0 + dm1 * q.a1 : 0.0, sc) + sc.pw * c;
+            if (sq_state && lane < cnt) sq += hypot(z.x, z.y);
             if (lane < cnt) p[base + lane] = make_double2(y, 0.0);
             c = lane_bcast(y, cnt - 1);
             zc = make_double2(lane_bcast(z.x, cnt - 1), lane_bcast(z.y, cnt - 1));
@@ -209,12 +230,21 @@ static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(dou
     int last = kSegWaves - 1;
     while (last > 0 && s_n[last] == 0) last--;
     if (wave == last && lane == 0 && n > 0) state[ch] = make_double4(zc.x, zc.y, dc, c);
+    if (sq_state) {                         // lanes -> wavefront -> segments in order
+        sq = wave_sum_d(sq);
+        if (lane == 0) s_sq[wave] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kSegWaves; w++) s += s_sq[w];
+            q_squelch_update(sq_state, sq_level, ch, s, n);
+        }
+    }
 }
 
 // FM squelch (quisk.c:2032-2033,2076-2085): the mean |cx| of the Rx-filtered samples over at least 2400 of them
 // (evaluated once per call, like the reference) in dB re full scale; active while it is below squelch_level.
 // One wave per channel; `buf` is the Rx filter's output of this call.
-struct QSquelchState { double rf_sum, squelch; int rf_count, active; };
 static __global__ __launch_bounds__(kSegThreads) void q_fm_squelch_kernel(const double2 *buf, long long stride, int n, QSquelchState *state,
                                                              const double *level)
 {
@@ -230,15 +260,7 @@ static __global__ __launch_bounds__(kSegThreads) void q_fm_squelch_kernel(const 
     if (threadIdx.x == 0) {
         s = 0.0;
         for (int w = 0; w < nw; w++) s += s_part[w];
-        QSquelchState st = state[ch];
-        st.rf_sum += s; st.rf_count += n;
-        if (st.rf_count >= 2400) {
-            double v = st.rf_sum / st.rf_count / 2147483647.0;
-            st.squelch = v > 1.E-10 ? 20 * log10(v) : -200.0;
-            st.rf_sum = 0; st.rf_count = 0;
-        }
-        st.active = st.squelch < level[ch];
-        state[ch] = st;
+        q_squelch_update(state, level, ch, s, n);
     }
 }
 

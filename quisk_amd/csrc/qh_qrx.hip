@@ -586,12 +586,14 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                     QH_HIP(hipStreamSynchronize(q.stream));
                     q.sq_dirty = false;
                 }
-                hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(n >= kQTiledMin ? kSegThreads : 64), 0, q.stream,
-                                   static_cast<const double2 *>(cur), cur_stride, n, q.sq_state, q.sq_level);
+                if (n < kQTiledMin)      // long calls: the sum rides on the tiled detector below
+                    hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
+                                       static_cast<const double2 *>(cur), cur_stride, n, q.sq_state, q.sq_level);
             }
             if (n >= kQTiledMin)         // long calls: the detector over time segments (qh_qdemod.hpp)
                 hipLaunchKernelGGL(q_fm_disc_tiled_kernel, dim3((unsigned)q.nch), dim3(kSegThreads), 0, q.stream,
-                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);
+                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm, q.sq_state,
+                                   (const double *)q.sq_level);
             else if (n > 0)
                 hipLaunchKernelGGL(q_fm_disc_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);

@@ -256,3 +256,32 @@ def test_detectors_over_time_segments_equal_block_calls(qh, oracle, mode):
     r.set_mode(mode); r.set_tune(9000); r.set_filters(*default_filter(mode, rxfilter.get_filter_rate(fs, mode)))
     want = np.concatenate([r.process(x[0, k:k + 9600]) for k in range(0, n, 9600)])
     assert want.size == outs[0].shape[1] and rel_rms(outs[0][0][skip:], want[skip:]) < 1e-9
+
+
+def test_fm_squelch_in_long_calls(qh, oracle):
+    """Calls of 8192 detector samples and more sum |cx| for the squelch inside the time-segmented detector (qh_qdemod.hpp) instead
+    of in a kernel of its own: same decisions and audio as the reference, call by call (calls of 12000 samples at 48 ksps)."""
+    fs, blk = 48000, 12000
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(2, fs, 5)
+    r = [oracle.OracleQuiskRx(fs, tabs) for _ in range(2)]
+    fI, fQ = rxfilter.make_filter_coef(48000, None, 12000, 0)
+    levels = (-60.0, -999.0)
+    for c in range(2):
+        bank.set_filters(c, fI, fQ); bank.set_squelch(c, levels[c])
+        r[c].set_mode(5); r[c].set_filters(fI, fQ); r[c].set_squelch(levels[c])
+    n = 8 * blk
+    t = np.arange(n)
+    amp = np.where((t > 2 * blk) & (t < 5 * blk), 2.0 ** 28, 2.0 ** 8)
+    x = amp * np.exp(3j * np.sin(2 * np.pi * 1000.0 / fs * t)) + 2.0 ** 6 * (np.random.default_rng(4).standard_normal(n) + 0j)
+    x = np.stack([x, x])
+    y = np.concatenate([bank.process_host(x[:, k:k + blk]) for k in range(0, n, blk)], axis=1)
+    for c in range(2):
+        want = np.concatenate([r[c].process(x[c, k:k + blk]) for k in range(0, n, blk)])
+        assert want.size == y.shape[1]
+        muted = ~np.any(want.reshape(-1, blk), axis=1)
+        assert (muted.any() and not muted.all()) if c == 0 else not muted.any()
+        assert np.array_equal(muted, ~np.any(y[c].reshape(-1, blk), axis=1))
+        live = np.repeat(~muted, blk)
+        live[:4000] = False
+        assert rel_rms(y[c][live], want[live]) < 1e-6
