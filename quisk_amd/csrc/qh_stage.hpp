@@ -27,6 +27,7 @@ struct Stage {
     bool mix = false, per_channel = false;
     bool outmix = false;                        // oscillator behind the filter (see above); decided by the first set_taps
     bool taps_set = false;
+    std::vector<int> taps_len;                  // taps actually set, per channel (per_channel) or [0]: the tile plan follows their maximum
     double *taps_re = nullptr;                  // outmix: the real taps on the device, for front_mask_kernel
     double2 *lane_rot = nullptr, *out_step = nullptr, *tile_rot = nullptr;
     int tile_cap = 0;
@@ -95,6 +96,7 @@ struct Stage {
         QH_HIP(hipSetDevice(device));
         outmix = mix && dtype == QH_F64 && interp == 1 && fold > 1;      // taken back by set_taps if the taps are not real
         taps_set = false;
+        taps_len.assign((size_t)(per_channel ? nch : 1), 0);
         const size_t nmask = (size_t)(per_channel || outmix ? nch : 1) * kStageNfft;
         QH_HIP(hipMalloc(&mask, nmask * esize));
         QH_HIP(hipMemsetAsync(mask, 0, nmask * esize, stream));
@@ -146,6 +148,17 @@ struct Stage {
     {
         if ((int)taps.size() > ntaps) return set_error(QH_ERR_INVALID, "more taps than the stage was created for");
         QH_HIP(hipSetDevice(device));
+        if (interp == 1) {
+            // The stage was created for up to `ntaps` taps (the Rx filter: 2048) and keeps that much history, but a tile only has to
+            // overlap its neighbour by the longest filter actually set: 153 taps leave 3841 useful outputs of 4096, not 2049.
+            if (per_channel && ch >= 0) taps_len[(size_t)ch] = (int)taps.size();
+            else for (int &v : taps_len) v = (int)taps.size();
+            int need = 1;
+            for (int v : taps_len) need = v > need ? v : need;
+            P = ((need - 1 + fold - 1) / fold) * fold;
+            if (P < fold) P = fold;
+            Lf = (((kStageNfft - P) / fold) / pick) * pick;
+        }
         if (outmix) {
             bool real = true;
             for (const cd &v : taps) if (v.imag() != 0.0) { real = false; break; }

@@ -127,7 +127,10 @@ def quisk_native(torch, qh, dev):
     from quisk_amd import rxfilter
     nch, n, fs = 256, 1 << 20, 192000
     out = []
+    only = os.environ.get("QH_QUISK_MODES", "USB,AM,FM").split(",")          # e.g. QH_QUISK_MODES=FM for a kernel trace of one mode
     for name, mode, bw in (("USB", rxfilter.USB, 2700), ("AM", rxfilter.AM, 6000), ("FM", rxfilter.FM, 12000)):
+        if name not in only:
+            continue
         bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=torch.cuda.current_stream(dev).cuda_stream)
         rate = bank.get_filter_rate()
         fI, fQ = rxfilter.make_filter_coef(rate, None, bw, rxfilter.get_filter_center(name, bw))
