@@ -619,9 +619,11 @@ double GetDisplayENB(int disp);
 /* The shape of quisk.c's own receive API: a process-wide receiver, parameters through setters, samples through
  * `int quisk_process_samples(complex double *cSamples, int nSamples)` (quisk.h:375, quisk.c:2289) -- in place, returns
  * the output count at the playback rate, nSamples <= 0 returned unchanged.  process_agc is on as in the reference
- * (default release gain 80, quisk.c:191).  qh_quisk_open takes quisk_sound_state.sample_rate, the filters.h tables and
- * record_app's fft_size / data_width (0, 0 = no panadapter). */
-int qh_quisk_open(int sample_rate, const qh_qrx_tables *tables, int fft_size, int data_width);
+ * (default release gain 80, quisk.c:191).  qh_quisk_open takes quisk_sound_state.sample_rate and .playback_rate (open_sound,
+ * quisk.c:4106; 48000 x 1, 2, 4 or 8 -- the ratios quisk.c:2663-2682 interpolates), the filters.h tables and record_app's
+ * fft_size / data_width (0, 0 = no panadapter).  The whole of quisk_process_samples (quisk.c:2289-2742) runs behind
+ * qh_quisk_process_samples; the block is uploaded once and every step is a kernel on one stream (qh_quisk_rx_compat.cpp). */
+int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *tables, int fft_size, int data_width);
 void qh_quisk_close(void);
 void qh_quisk_set_tune(int rx_tune_freq);                   /* set_tune, quisk.c:4702 */
 void qh_quisk_set_rx_mode(int mode);                        /* set_rx_mode, quisk.c:4621 */
@@ -650,6 +652,34 @@ void qh_quisk_set_key_state(int key_down, int cw_key_down, int active_sidetone, 
 void qh_quisk_set_sidetone(double volume, int rit_freq, int playback_rate, int txrx_silence_msec);     /* set_sidetone, quisk.c:4710 */
 void qh_quisk_set_kill_audio(int kill);
 void qh_quisk_invert_spectrum(int invert);                                 /* quisk.c:4535 */
+/* The tail and the side paths of quisk_process_samples: set_filters for any nFilter (0 main / split, 1 played sub-receiver,
+ * 2 sub-receiver 1's digital output; one global sizeFilter as in quisk.c:4591); the squelches; add_tone (quisk.c:3203) and
+ * AddTestTone (quisk.c:1258-1303); measure_frequency (quisk.c:3181) and measure_freq (quisk.c:5579-5649); sub-receiver 1
+ * demodulated to a digital output device (quisk.c:2630-2651: quisk_multirx_count, the device's driver flag, the audio that
+ * play_sound_interface is handed).  cFracDecim (quisk.c:622-665), the wdspFexchange0 hand-off (channel 0, when
+ * qh_wdsp_set_parameter switched it on) and the HB45 interpolation to the playback rate need no setter. */
+int qh_quisk_set_filters_n(const double *filtI, const double *filtQ, int size, int bandwidth, int nFilter);   /* set_filters, quisk.c:4551 */
+void qh_quisk_set_squelch(double level);                                   /* set_squelch (FM), quisk.c:4721 */
+void qh_quisk_set_ssb_squelch(int enabled, int level);                     /* set_ssb_squelch, quisk.c:4729 */
+int qh_quisk_squelch_flags(void);                                          /* bit 0 squelch_real, bit 1 squelch_imag of the last block */
+void qh_quisk_add_tone(int freq);                                          /* add_tone, quisk.c:3203 */
+double qh_quisk_measure_frequency(int mode);                               /* measure_frequency, quisk.c:3181 */
+void qh_quisk_set_multirx_count(int n);                                    /* quisk_multirx_count */
+void qh_quisk_set_sub_rx1_output(int on);                                  /* quiskPlaybackDevices[QUISK_INDEX_SUB_RX1]->driver */
+int qh_quisk_sub_rx1_audio(double *cSamples, int cap);                     /* the block play_sound_interface got, quisk.c:2651 */
+/* Plumbing between the block API and the engines it chains (device-resident; used by qh_quisk_rx_compat.cpp): the bank
+ * leaves the squelch to its caller and says where the flag lives; ssb_squelch's one-for-all-banks `plan` static
+ * (quisk.c:1091,1104); the tuning oscillator's phase in 2^-64 turns (one vector per purpose in the reference,
+ * quisk.c:2308-2311); measure_freq's window and averaged spectrum on the panadapter engine; the shim's state. */
+int qh_qrx_set_mute_deferred(qh_qrx *r, int on);
+const int *qh_qrx_squelch_flag(qh_qrx *r, int ch);
+int qh_qrx_ssb_squelch_planned(qh_qrx *r, int set);
+int qh_qrx_get_nco_phase(qh_qrx *r, int ch, unsigned long long *phase);
+int qh_qrx_set_nco_phase(qh_qrx *r, int ch, unsigned long long phase);
+int qh_pan_set_window(qh_pan *p, const double *window);
+int qh_pan_read_avg(qh_pan *p, double *h_avg, int reset);
+int qh_pan_drop_partial(qh_pan *p);
+int qh_wdsp_shim_in_size(int channel);
 
 /* ------------------------------------------------------------------ 4. filter.h drop-in exports */
 /* The reference's own names and struct layouts (filter.h:1-55) so that quisk.c links against this library

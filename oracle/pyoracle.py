@@ -560,6 +560,108 @@ class OracleQuiskRx:
             self.h = None
 
 
+class OracleQuiskBlock:
+    """qo_ps wrapper: quisk_process_samples as a whole (quisk.c:2289-2742) with the reference's setter names.
+    process(x) returns the block at the playback rate."""
+
+    _TABLE_KEYS = ("quiskFilt48dec24Coefs", "quiskFilt144D3Coefs", "quiskFilt240D5CoefsSharp", "quiskAudio24p4Coefs",
+                   "quiskAudio24p6Coefs", "quiskLpFilt48Coefs", "quiskAudioFmHpCoefs", "quiskFilt300D5Coefs",
+                   "quiskFilt53D1Coefs", "quiskFilt111D2Coefs", "quiskFilt133D2Coefs", "quiskFilt167D3Coefs",
+                   "quiskFilt185D3Coefs")
+
+    def __init__(self, sample_rate, playback_rate, tables):
+        L = lib()
+        V, I, D = C.c_void_p, C.c_int, C.c_double
+        L.qo_ps_create.restype = V
+        L.qo_ps_create.argtypes = [I, I, V]
+        sig = {"qo_ps_free": [V], "qo_ps_set_tune": [V, I, I], "qo_ps_set_mode": [V, I], "qo_ps_set_filters": [V, V, V, I, I, I],
+               "qo_ps_set_agc": [V, D], "qo_ps_set_split_rxtx": [V, I], "qo_ps_set_multirx_play_channel": [V, I],
+               "qo_ps_set_multirx_play_method": [V, I], "qo_ps_set_multirx_freq": [V, I, I], "qo_ps_set_multirx_mode": [V, I, I],
+               "qo_ps_set_multirx_count": [V, I], "qo_ps_set_sub_rx1_output": [V, I], "qo_ps_multirx_samples": [V, I, V, I],
+               "qo_ps_set_key_state": [V, I, I, I, I], "qo_ps_set_sidetone": [V, D, I, I], "qo_ps_set_kill_audio": [V, I],
+               "qo_ps_invert_spectrum": [V, I], "qo_ps_set_noise_blanker": [V, I], "qo_ps_set_auto_notch": [V, I],
+               "qo_ps_set_squelch": [V, D], "qo_ps_set_ssb_squelch": [V, I, I], "qo_ps_add_tone": [V, I],
+               "qo_ps_measure_frequency": [V, I], "qo_ps_set_graph": [V, V], "qo_ps_set_wdsp": [V, V, V, V],
+               "qo_ps_sub_rx1_audio": [V, V, I], "qo_ps_squelch_flags": [V], "qo_ps_process": [V, V, I],
+               "qo_ps_restart_bank": [V, I]}
+        for name, args in sig.items():
+            getattr(L, name).argtypes = args
+        L.qo_ps_measure_frequency.restype = D
+        self.L = L
+        self._keep = [np.ascontiguousarray(tables[k], dtype=np.float64) for k in self._TABLE_KEYS]
+        self._t = QoRxTables(*[a.ctypes.data_as(c_double_p) for a in self._keep])
+        self.ratio = max(1, playback_rate // 48000)
+        self.h = L.qo_ps_create(sample_rate, playback_rate, C.byref(self._t))
+        self._hooks = []
+
+    def set_tune(self, rx, tx=0): self.L.qo_ps_set_tune(self.h, int(rx), int(tx))
+    def set_rx_mode(self, m): self.L.qo_ps_set_mode(self.h, int(m))
+
+    def set_filters(self, fI, fQ, bw, nFilter=0):
+        fI = np.ascontiguousarray(fI, dtype=np.float64)
+        fQ = np.ascontiguousarray(fQ, dtype=np.float64)
+        self.L.qo_ps_set_filters(self.h, fI.ctypes.data, fQ.ctypes.data, fI.size, int(bw), int(nFilter))
+
+    def set_agc(self, level): self.L.qo_ps_set_agc(self.h, float(level))
+    def set_split_rxtx(self, s): self.L.qo_ps_set_split_rxtx(self.h, int(s))
+    def set_multirx_play_channel(self, ch): self.L.qo_ps_set_multirx_play_channel(self.h, int(ch))
+    def set_multirx_play_method(self, m): self.L.qo_ps_set_multirx_play_method(self.h, int(m))
+    def set_multirx_freq(self, i, f): self.L.qo_ps_set_multirx_freq(self.h, int(i), int(f))
+    def set_multirx_mode(self, i, m): self.L.qo_ps_set_multirx_mode(self.h, int(i), int(m))
+    def set_multirx_count(self, n): self.L.qo_ps_set_multirx_count(self.h, int(n))
+    def set_sub_rx1_output(self, on): self.L.qo_ps_set_sub_rx1_output(self.h, int(on))
+
+    def multirx_samples(self, i, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        self.L.qo_ps_multirx_samples(self.h, int(i), x.ctypes.data, x.size)
+
+    def set_key_state(self, key_down, cw_key_down, active_sidetone, is_fdx):
+        self.L.qo_ps_set_key_state(self.h, int(key_down), int(cw_key_down), int(active_sidetone), int(is_fdx))
+
+    def set_sidetone(self, volume, rit_freq, txrx_silence_ms=-1):
+        self.L.qo_ps_set_sidetone(self.h, float(volume), int(rit_freq), int(txrx_silence_ms))
+
+    def set_kill_audio(self, k): self.L.qo_ps_set_kill_audio(self.h, int(k))
+    def invert_spectrum(self, inv): self.L.qo_ps_invert_spectrum(self.h, int(inv))
+    def set_noise_blanker(self, level): self.L.qo_ps_set_noise_blanker(self.h, int(level))
+    def set_auto_notch(self, on): self.L.qo_ps_set_auto_notch(self.h, int(on))
+    def set_squelch(self, level): self.L.qo_ps_set_squelch(self.h, float(level))
+    def set_ssb_squelch(self, enabled, level): self.L.qo_ps_set_ssb_squelch(self.h, int(enabled), int(level))
+    def add_tone(self, freq): self.L.qo_ps_add_tone(self.h, int(freq))
+    def measure_frequency(self, mode): return self.L.qo_ps_measure_frequency(self.h, int(mode))
+
+    def set_graph(self, graph):
+        self._hooks.append(graph)
+        self.L.qo_ps_set_graph(self.h, graph.h)
+
+    def set_wdsp(self, shim, channel):
+        """shim: OracleWdspShim (its own callback is not used); channel: WdspChannel whose wo_fexchange0 serves the hand-off."""
+        self._hooks += [shim, channel]
+        fn = C.cast(self.L.wo_fexchange0, C.c_void_p)
+        self.L.qo_ps_set_wdsp(self.h, shim.h, fn, channel.h)
+
+    def sub_rx1_audio(self):
+        n = self.L.qo_ps_sub_rx1_audio(self.h, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.complex128)
+        self.L.qo_ps_sub_rx1_audio(self.h, out.ctypes.data, n)
+        return out[:n]
+
+    def squelch_flags(self): return self.L.qo_ps_squelch_flags(self.h)
+    def restart_bank(self, bank): self.L.qo_ps_restart_bank(self.h, int(bank))
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        buf = np.zeros(max(x.size, 16) * (self.ratio + 1), dtype=np.complex128)
+        buf[:x.size] = x
+        n = self.L.qo_ps_process(self.h, buf.ctypes.data, x.size)
+        return buf[:n].copy() if n > 0 else buf[:0].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.qo_ps_free(self.h)
+            self.h = None
+
+
 class OracleQuiskAgc:
     """process_agc (quisk.c:2162-2287) for one stream; process(x) returns the AGC'd block (the first call only initialises)."""
 

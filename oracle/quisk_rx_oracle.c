@@ -719,3 +719,506 @@ int qo_rx_process(qo_rx *r, double *x, int n)
         for (i = 0; i < n; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; }
     return n;
 }
+
+/* ==== quisk_process_samples as a whole, quisk.c:2289-2742 ============================================================
+ * The orchestration around the banks: key-down replacement (sidetone / silence, quisk.c:2368-2433), AddTestTone
+ * (quisk.c:1258-1303), spectrum inversion, NoiseBlanker, the FFT ring, the tune, quisk_process_decimate /
+ * measure_freq (quisk.c:5579-5649) / quisk_process_demodulate on bank 0, the second channel (split Rx/Tx or the played
+ * sub-receiver) on bank 1 with Buffer2Chan (quisk.c:1577-1611), the digital output of sub-receiver 1 on bank 2, and the
+ * tail: cFracDecim (quisk.c:622-665) -> wdspFexchange0 -> HB45 interpolation to the playback rate (quisk.c:2654-2682)
+ * -> process_agc -> kill_audio / squelch -> key-up envelope.  The reference keeps all of this in function statics and
+ * globals; here it is one struct.  Bank storage (decimator and demodulator filters, c/dRxFilterOut rings) is per bank,
+ * the filter taps per nFilter and `sizeFilter` one global for all of them, as in the reference (quisk.c:127-129,4591).
+ * PARITY UNPINNED (quisk.c needs <fftw3.h>); every filter it calls is the pinned quisk_oracle.c. */
+#include "wdsp_oracle.h"
+
+#define QO_MAX_SUB 9                /* QUISK_MAX_SUB_RECEIVERS, quisk.h */
+#define BUF2CHAN_SIZE 12000         /* quisk.c:1576 */
+#define BIG_VOLUME 2.2e9            /* quisk.h:11 */
+#define MF_FFT_SIZE 12000           /* measure_freq's fft_size, quisk.c:5586 */
+
+struct qo_ps {
+    int sample_rate, playback_rate;
+    qo_rx *bank[3];
+    qo_rx_tables t;
+    /* globals set by the GUI thread */
+    int rx_mode, rx_tune, tx_tune, rit_freq, split_rxtx, play_channel, play_method, multirx_count;
+    int sub_freq[QO_MAX_SUB], sub_mode[QO_MAX_SUB];
+    double *sub_samples[QO_MAX_SUB];            /* multirx_cSamples[] for the coming call (NULL: none) */
+    int sub_cap[QO_MAX_SUB];
+    double *filtI[3], *filtQ[3];                /* cFilterI / cFilterQ [nFilter] */
+    int filter_bandwidth[3], sizeFilter;
+    int key_down, cw_key_down, active_sidetone, is_fdx, kill_audio, invert, nb_level, sub_rx1_driver;
+    int txrx_silence_ms;
+    double sidetone_volume, agc_release_gain;
+    double tt_phase_re, tt_phase_im;            /* testtonePhase (0 = off) */
+    int measure_freq_mode;
+    double measured_frequency;
+    /* statics of quisk_process_samples, quisk.c:2301-2321 */
+    int old_split, old_play;
+    double rxTV[2], txTV[2], aux1TV[2], aux2TV[2], sidetoneV[2], sidetonePhase[2];
+    double dOutCounter, sidetoneEnvelope, keyupEnvelope;
+    int sidetoneIsOn, playSilence;
+    qo_hb45 HalfBand7, HalfBand8, HalfBand9;
+    qo_agc *Agc1, *Agc2, *Agc3;
+    qo_nb *nb;
+    /* AddTestTone statics */
+    double ttV[2], audioV[2];
+    /* Buffer2Chan statics */
+    int nbuf1, nbuf2;
+    double buf1[BUF2CHAN_SIZE], buf2[BUF2CHAN_SIZE];
+    /* cFracDecim statics */
+    double fd_dindex, fd_c0[2], fd_c1[2], fd_c2[2];
+    /* measure_freq statics */
+    int mf_index, mf_count;
+    double *mf_samples, *mf_window, *mf_average;
+    qo_hb45 mfHB1, mfHB2, mfHB3;
+    /* hooks */
+    qo_graph *graph;
+    wo_shim *shim; wo_fexchange0_fn wdsp_fn; void *wdsp_ctx;
+    /* work */
+    double *dsamples, *dsamples2, *orig, *bufc, *sub1_out;
+    int cap, sub1_n;
+    int squelch_real, squelch_imag;             /* as left by the last call */
+};
+
+qo_ps *qo_ps_create(int sample_rate, int playback_rate, const qo_rx_tables *t)
+{
+    int i;
+    qo_ps *p = (qo_ps *)calloc(1, sizeof(*p));
+    p->sample_rate = sample_rate; p->playback_rate = playback_rate; p->t = *t;
+    for (i = 0; i < 3; i++) {
+        p->bank[i] = qo_rx_create(sample_rate, t);
+        p->filtI[i] = (double *)calloc(MAX_FILTER_SIZE, sizeof(double));
+        p->filtQ[i] = (double *)calloc(MAX_FILTER_SIZE, sizeof(double));
+        p->filter_bandwidth[i] = 0;
+    }
+    p->rx_mode = QO_USB; p->play_channel = -1; p->old_play = 0;     /* "static int old_multirx_play_channel = 0", quisk.c:2303 */
+    p->txrx_silence_ms = 50; p->agc_release_gain = 80.0;            /* agcReleaseGain, quisk.c:191 */
+    p->rxTV[0] = p->txTV[0] = p->aux1TV[0] = p->aux2TV[0] = 1.0;
+    p->sidetoneV[0] = BIG_VOLUME; p->sidetonePhase[0] = 1.0;
+    p->keyupEnvelope = 1.0;
+    qo_hb45_init(&p->HalfBand7); qo_hb45_init(&p->HalfBand8); qo_hb45_init(&p->HalfBand9);
+    p->Agc1 = qo_agc_create(playback_rate, 0.7, 1.0);               /* {0.7, 0, 0}: sample_rate 0 -> playback_rate, quisk.c:2174-2175 */
+    p->Agc2 = qo_agc_create(playback_rate, 0.7, 1.0);
+    p->Agc3 = qo_agc_create(playback_rate, 0.7, 1.0);
+    p->ttV[0] = 21474836.47; p->audioV[0] = 1.0;                    /* quisk.c:1263-1264 */
+    p->fd_dindex = 1;
+    qo_hb45_init(&p->mfHB1); qo_hb45_init(&p->mfHB2); qo_hb45_init(&p->mfHB3);
+    return p;
+}
+
+void qo_ps_free(qo_ps *p)
+{
+    int i;
+    if (!p) return;
+    for (i = 0; i < 3; i++) { qo_rx_free(p->bank[i]); free(p->filtI[i]); free(p->filtQ[i]); }
+    for (i = 0; i < QO_MAX_SUB; i++) free(p->sub_samples[i]);
+    qo_agc_free(p->Agc1); qo_agc_free(p->Agc2); qo_agc_free(p->Agc3);
+    qo_nb_free(p->nb);
+    free(p->mf_samples); free(p->mf_window); free(p->mf_average);
+    free(p->dsamples); free(p->dsamples2); free(p->orig); free(p->bufc); free(p->sub1_out);
+    free(p);
+}
+
+void qo_ps_set_tune(qo_ps *p, int rx, int tx) { p->rx_tune = rx; p->tx_tune = tx; }                /* set_tune, quisk.c:4702 */
+void qo_ps_set_mode(qo_ps *p, int mode) { p->rx_mode = mode; }                                      /* set_rx_mode, quisk.c:4621 */
+void qo_ps_set_filters(qo_ps *p, const double *fI, const double *fQ, int size, int bw, int nFilter) /* set_filters, quisk.c:4551 */
+{
+    p->filter_bandwidth[nFilter] = bw;
+    memcpy(p->filtI[nFilter], fI, (size_t)size * sizeof(double));
+    memcpy(p->filtQ[nFilter], fQ, (size_t)size * sizeof(double));
+    p->sizeFilter = size;
+}
+void qo_ps_set_agc(qo_ps *p, double level) { p->agc_release_gain = level; }                         /* set_agc, quisk.c:4543 */
+void qo_ps_set_split_rxtx(qo_ps *p, int s) { p->split_rxtx = s; }
+void qo_ps_set_multirx_play_channel(qo_ps *p, int ch) { p->play_channel = ch >= QO_MAX_SUB ? -1 : ch; }     /* quisk.c:4856 */
+void qo_ps_set_multirx_play_method(qo_ps *p, int m) { p->play_method = m; }
+void qo_ps_set_multirx_freq(qo_ps *p, int i, int f) { if (i >= 0 && i < QO_MAX_SUB) p->sub_freq[i] = f; }
+void qo_ps_set_multirx_mode(qo_ps *p, int i, int m) { if (i >= 0 && i < QO_MAX_SUB) p->sub_mode[i] = m; }
+void qo_ps_set_multirx_count(qo_ps *p, int n) { p->multirx_count = n; }                             /* quisk_multirx_count */
+void qo_ps_set_sub_rx1_output(qo_ps *p, int on) { p->sub_rx1_driver = on; }                         /* quiskPlaybackDevices[QUISK_INDEX_SUB_RX1]->driver */
+void qo_ps_multirx_samples(qo_ps *p, int i, const double *x, int n)                                 /* multirx_cSamples[i] of the coming call */
+{
+    if (i < 0 || i >= QO_MAX_SUB) return;
+    if (n > p->sub_cap[i]) { free(p->sub_samples[i]); p->sub_samples[i] = (double *)malloc((size_t)n * 2 * sizeof(double)); p->sub_cap[i] = n; }
+    memcpy(p->sub_samples[i], x, (size_t)n * 2 * sizeof(double));
+}
+void qo_ps_set_key_state(qo_ps *p, int key_down, int cw_key_down, int active_sidetone, int is_fdx)
+{
+    p->key_down = key_down; p->cw_key_down = cw_key_down; p->active_sidetone = active_sidetone; p->is_fdx = is_fdx;
+}
+void qo_ps_set_sidetone(qo_ps *p, double volume, int rit_freq, int txrx_silence_ms)                 /* set_sidetone, quisk.c:4710-4719 */
+{
+    double a = 2.0 * M_PI * abs(rit_freq) / p->playback_rate;
+    p->sidetone_volume = volume; p->rit_freq = rit_freq;
+    p->sidetonePhase[0] = cos(a); p->sidetonePhase[1] = sin(a);
+    if (txrx_silence_ms >= 0) p->txrx_silence_ms = txrx_silence_ms;
+    if (p->bank[0]->notch && (p->rx_mode == QO_CWL || p->rx_mode == QO_CWU)) qo_notch_init(p->bank[0]->notch);      /* quisk.c:4716-4717 */
+    p->bank[0]->rit_freq = rit_freq;
+}
+void qo_ps_set_kill_audio(qo_ps *p, int k) { p->kill_audio = k; }
+void qo_ps_invert_spectrum(qo_ps *p, int inv) { p->invert = inv; }
+void qo_ps_set_noise_blanker(qo_ps *p, int level) { p->nb_level = level; }
+void qo_ps_set_auto_notch(qo_ps *p, int on) { qo_rx_set_auto_notch(p->bank[0], on, p->rit_freq); }  /* set_auto_notch, quisk.c:4596 */
+void qo_ps_set_squelch(qo_ps *p, double level) { int i; for (i = 0; i < 3; i++) qo_rx_set_squelch(p->bank[i], level); }
+void qo_ps_set_ssb_squelch(qo_ps *p, int enabled, int level) { int i; for (i = 0; i < 3; i++) qo_rx_set_ssb_squelch(p->bank[i], enabled, level); }
+void qo_ps_add_tone(qo_ps *p, int freq)                                                             /* add_tone, quisk.c:3203-3216 */
+{
+    if (freq && p->sample_rate) { double a = 2.0 * M_PI * freq / p->sample_rate; p->tt_phase_re = cos(a); p->tt_phase_im = sin(a); }
+    else { p->tt_phase_re = 0; p->tt_phase_im = 0; }
+}
+double qo_ps_measure_frequency(qo_ps *p, int mode)                                                  /* measure_frequency, quisk.c:3181-3191 */
+{
+    if (mode >= 0) p->measure_freq_mode = mode;
+    return p->measured_frequency;
+}
+void qo_ps_set_graph(qo_ps *p, qo_graph *g) { p->graph = g; }
+void qo_ps_set_wdsp(qo_ps *p, wo_shim *s, wo_fexchange0_fn fn, void *ctx) { p->shim = s; p->wdsp_fn = fn; p->wdsp_ctx = ctx; }
+int qo_ps_sub_rx1_audio(qo_ps *p, double *out, int cap)            /* what play_sound_interface got for QUISK_INDEX_SUB_RX1 in the last call */
+{
+    int n = p->sub1_n < cap ? p->sub1_n : cap;
+    if (n > 0) memcpy(out, p->sub1_out, (size_t)n * 2 * sizeof(double));
+    return p->sub1_n;
+}
+/* TEST HOOK, not in the reference: forget bank `b`'s filter storage (decimators, demodulator, Rx filter rings), as the GPU
+ * library does when a mode change makes it rebuild the bank; the tune vectors, AGCs and everything else carry on. */
+void qo_ps_restart_bank(qo_ps *p, int b)
+{
+    int inited;
+    if (b < 0 || b > 2) return;
+    inited = p->bank[b]->sq_inited;
+    qo_rx_free(p->bank[b]);
+    p->bank[b] = qo_rx_create(p->sample_rate, &p->t);
+    p->bank[b]->sq_inited = inited;
+    p->bank[b]->rit_freq = p->rit_freq;
+}
+int qo_ps_squelch_flags(const qo_ps *p) { return p->squelch_real | (p->squelch_imag << 1); }
+
+static void cmul_inplace(double *a, const double *b)   /* a *= b */
+{
+    double t = a[0] * b[0] - a[1] * b[1];
+    a[1] = a[0] * b[1] + a[1] * b[0];
+    a[0] = t;
+}
+
+static void ps_tune(double *x, int n, double *vec, double freq, int rate)       /* quisk.c:2483-2488 and its three copies */
+{
+    double a = -2.0 * M_PI * freq / rate, ph[2];
+    int i;
+    ph[0] = cos(a); ph[1] = sin(a);
+    for (i = 0; i < n; i++) { cmul_inplace(x + 2 * i, vec); cmul_inplace(vec, ph); }
+}
+
+static void AddTestTone(qo_ps *p, double *x, int n)                             /* quisk.c:1258-1303 */
+{
+    int i;
+    double tp[2], ap[2], a, v[2], e[2];
+    tp[0] = p->tt_phase_re; tp[1] = p->tt_phase_im;
+    a = 2.0 * M_PI * 1000 / p->sample_rate; ap[0] = cos(a); ap[1] = sin(a);
+    switch (p->rx_mode) {
+    default:
+        for (i = 0; i < n; i++) { x[2 * i] += p->ttV[0]; x[2 * i + 1] += p->ttV[1]; cmul_inplace(p->ttV, tp); }
+        break;
+    case QO_AM:
+        for (i = 0; i < n; i++) {
+            double g = 1.0 + p->audioV[0];
+            x[2 * i] += p->ttV[0] * g; x[2 * i + 1] += p->ttV[1] * g;
+            cmul_inplace(p->ttV, tp); cmul_inplace(p->audioV, ap);
+        }
+        break;
+    case QO_FM: case QO_DGT_FM:
+        for (i = 0; i < n; i++) {
+            e[0] = cos(p->audioV[0]); e[1] = sin(p->audioV[0]);                  /* cexp(I * creal(audioVector)) */
+            v[0] = p->ttV[0]; v[1] = p->ttV[1];
+            cmul_inplace(v, e);
+            x[2 * i] += v[0]; x[2 * i + 1] += v[1];
+            cmul_inplace(p->ttV, tp); cmul_inplace(p->audioV, ap);
+        }
+        break;
+    }
+}
+
+static int Buffer2Chan(qo_ps *p, double *samp1, int count1, double *samp2, int count2)      /* quisk.c:1577-1611 */
+{
+    int nout;
+    if (samp1 == NULL) { p->nbuf1 = p->nbuf2 = 0; return 0; }
+    if (p->nbuf1 == 0 && p->nbuf2 == 0 && count1 == count2) return count1;
+    if (count1 + p->nbuf1 >= BUF2CHAN_SIZE || count2 + p->nbuf2 >= BUF2CHAN_SIZE) p->nbuf1 = p->nbuf2 = 0;
+    memcpy(p->buf1 + p->nbuf1, samp1, (size_t)count1 * sizeof(double)); p->nbuf1 += count1;
+    memcpy(p->buf2 + p->nbuf2, samp2, (size_t)count2 * sizeof(double)); p->nbuf2 += count2;
+    nout = p->nbuf1 <= p->nbuf2 ? p->nbuf1 : p->nbuf2;
+    memcpy(samp1, p->buf1, (size_t)nout * sizeof(double)); p->nbuf1 -= nout;
+    memmove(p->buf1, p->buf1 + nout, (size_t)p->nbuf1 * sizeof(double));
+    memcpy(samp2, p->buf2, (size_t)nout * sizeof(double)); p->nbuf2 -= nout;
+    memmove(p->buf2, p->buf2 + nout, (size_t)p->nbuf2 * sizeof(double));
+    return nout;
+}
+
+static int cFracDecim(qo_ps *p, double *x, int n, double fdecim)               /* quisk.c:622-665 */
+{
+    int i, nout = 0;
+    double xm0, xm1, xm2, xm3, c3[2];
+    for (i = 0; i < n; i++) {
+        c3[0] = x[2 * i]; c3[1] = x[2 * i + 1];
+        if (p->fd_dindex < 2) {
+            int k;
+            xm0 = p->fd_dindex - 0; xm1 = p->fd_dindex - 1; xm2 = p->fd_dindex - 2; xm3 = p->fd_dindex - 3;
+            for (k = 0; k < 2; k++)
+                x[2 * nout + k] = xm1 * xm2 * xm3 * p->fd_c0[k] / -6.0 + xm0 * xm2 * xm3 * p->fd_c1[k] / 2.0 +
+                                  xm0 * xm1 * xm3 * p->fd_c2[k] / -2.0 + xm0 * xm1 * xm2 * c3[k] / 6.0;
+            nout++;
+            p->fd_dindex += fdecim - 1;
+        } else {
+            p->fd_dindex -= 1;
+        }
+        p->fd_c0[0] = p->fd_c1[0]; p->fd_c0[1] = p->fd_c1[1];
+        p->fd_c1[0] = p->fd_c2[0]; p->fd_c1[1] = p->fd_c2[1];
+        p->fd_c2[0] = c3[0]; p->fd_c2[1] = c3[1];
+    }
+    return nout;
+}
+
+static void measure_freq(qo_ps *p, const double *x, int n, int srate)           /* quisk.c:5579-5649 */
+{
+    int i, k, center, ipeak;
+    double dmax, c3, freq, *buf, *avg;
+    const int N = MF_FFT_SIZE;
+    if (!p->mf_samples) {                                                        /* measure_freq(NULL, 0, 0) from record_app */
+        p->mf_samples = (double *)calloc((size_t)N * 2, sizeof(double));
+        p->mf_window = (double *)malloc((size_t)(N + 1) * sizeof(double));
+        p->mf_average = (double *)calloc((size_t)N, sizeof(double));
+        for (i = 0; i < N; i++) p->mf_window[i] = 0.50 - 0.50 * cos(2. * M_PI * i / (N - 1));
+    }
+    avg = p->mf_average;
+    buf = (double *)malloc((size_t)(n > 0 ? n : 1) * 2 * sizeof(double));
+    memcpy(buf, x, (size_t)n * 2 * sizeof(double));                             /* do not destroy cSamples */
+    n = qo_cDecim2HB45(buf, n, &p->mfHB1);
+    n = qo_cDecim2HB45(buf, n, &p->mfHB2);
+    n = qo_cDecim2HB45(buf, n, &p->mfHB3);
+    srate /= 8;
+    for (i = 0; i < n && p->mf_index < N; i++, p->mf_index++) {
+        p->mf_samples[2 * p->mf_index] = buf[2 * i]; p->mf_samples[2 * p->mf_index + 1] = buf[2 * i + 1];
+    }
+    free(buf);
+    if (p->mf_index < N) return;                                                /* wait for a full array (the rest of the block is dropped) */
+    for (i = 0; i < N; i++) { p->mf_samples[2 * i] *= p->mf_window[i]; p->mf_samples[2 * i + 1] *= p->mf_window[i]; }
+    fo_fft(p->mf_samples, N, -1);
+    p->mf_index = 0;
+    p->mf_count++;
+    k = 0;
+    for (i = N / 2; i < N; i++) avg[k++] += hypot(p->mf_samples[2 * i], p->mf_samples[2 * i + 1]);
+    for (i = 0; i < N / 2; i++) avg[k++] += hypot(p->mf_samples[2 * i], p->mf_samples[2 * i + 1]);
+    if (p->mf_count < p->measure_freq_mode / 2) return;
+    p->mf_count = 0;
+    dmax = 1.e-20; ipeak = 0;
+    center = N / 2 - p->rit_freq * N / srate;
+    k = 500;
+    k = k * N / srate;
+    for (i = center - k; i <= center + k; i++)
+        if (avg[i] > dmax) { dmax = avg[i]; ipeak = i; }
+    c3 = 1.36 * (avg[ipeak + 1] - avg[ipeak - 1]) / (avg[ipeak - 1] + avg[ipeak] + avg[ipeak + 1]);
+    freq = srate * (2 * (ipeak + c3) - N) / 2 / N;
+    freq += p->rx_tune;
+    p->measured_frequency = freq;
+    memset(avg, 0, sizeof(double) * N);
+}
+
+/* the bank's filter set for this call: cFilterI/Q[nFilter] with the one global sizeFilter; the rings stay the bank's.
+ * ssb_squelch's `plan` is ONE function static for all banks (quisk.c:1093,1104): the first call of any bank creates it. */
+static void ps_load_filter(qo_ps *p, int bank, int nFilter, int mode)
+{
+    qo_rx *r = p->bank[bank];
+    r->sq_inited = p->bank[0]->sq_inited | p->bank[1]->sq_inited | p->bank[2]->sq_inited;
+    memcpy(r->filtI, p->filtI[nFilter], (size_t)p->sizeFilter * sizeof(double));
+    memcpy(r->filtQ, p->filtQ[nFilter], (size_t)p->sizeFilter * sizeof(double));
+    r->sizeFilter = p->sizeFilter;
+    r->bandwidth = p->filter_bandwidth[nFilter];
+    r->mode = mode;
+}
+
+static int ps_take(qo_ps *p, int n)                                             /* quisk.c:2372-2375 */
+{
+    int nout;
+    p->dOutCounter += (double)n * p->playback_rate / p->sample_rate;
+    nout = (int)p->dOutCounter;
+    p->dOutCounter -= nout;
+    return nout;
+}
+
+int qo_ps_process(qo_ps *p, double *x, int n)
+{
+    int i, nout, orig_n, n2, decim_srate, stereo;
+    double d, di, env_step = 1. / (p->playback_rate * 5e-3);
+    double *ds, *ds2;
+    p->sub1_n = 0;
+    if (n <= 0) return n;                                                       /* quisk.c:2336-2337 */
+    if (n > p->cap) {
+        p->cap = n * 2;
+        free(p->dsamples); free(p->dsamples2); free(p->orig); free(p->bufc); free(p->sub1_out);
+        p->dsamples = (double *)malloc((size_t)p->cap * 8 * sizeof(double));    /* room for the interpolated count */
+        p->dsamples2 = (double *)malloc((size_t)p->cap * 8 * sizeof(double));
+        p->orig = (double *)malloc((size_t)p->cap * 16 * sizeof(double));
+        p->bufc = (double *)malloc((size_t)p->cap * 2 * sizeof(double));
+        p->sub1_out = (double *)malloc((size_t)p->cap * 2 * sizeof(double));
+    }
+    ds = p->dsamples; ds2 = p->dsamples2;
+    orig_n = n;
+    if (p->split_rxtx) {                                                        /* quisk.c:2361-2365 */
+        memcpy(p->orig, x, (size_t)n * 2 * sizeof(double));
+        if (!p->old_split) Buffer2Chan(p, NULL, 0, NULL, 0);
+    }
+    if (p->play_channel != p->old_play) Buffer2Chan(p, NULL, 0, NULL, 0);
+    p->old_split = p->split_rxtx;
+    p->old_play = p->play_channel;
+    if (p->key_down && !p->is_fdx) {                                            /* quisk.c:2371-2400 */
+        nout = ps_take(p, n);
+        p->playSilence = (int)(p->playback_rate * 1E-3 * p->txrx_silence_ms);
+        p->keyupEnvelope = 0;
+        if (p->active_sidetone == 2 && p->cw_key_down) {
+            if (!p->sidetoneIsOn) { p->sidetoneIsOn = 1; p->sidetoneEnvelope = 0; p->sidetoneV[0] = BIG_VOLUME; p->sidetoneV[1] = 0; }
+            for (i = 0; i < nout; i++) {
+                if (p->sidetoneEnvelope < 1.0) { p->sidetoneEnvelope += env_step; if (p->sidetoneEnvelope > 1.0) p->sidetoneEnvelope = 1.0; }
+                d = p->sidetoneV[0] * p->sidetone_volume * p->sidetoneEnvelope;
+                x[2 * i] = d; x[2 * i + 1] = d;
+                cmul_inplace(p->sidetoneV, p->sidetonePhase);
+            }
+        } else {
+            for (i = 0; i < nout; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; }
+        }
+        return nout;
+    }
+    if (p->sidetoneIsOn) {                                                      /* quisk.c:2402-2421 */
+        nout = ps_take(p, n);
+        for (i = 0; i < nout; i++) {
+            p->sidetoneEnvelope -= env_step;
+            if (p->sidetoneEnvelope < 0) { p->sidetoneIsOn = 0; p->sidetoneEnvelope = 0; break; }
+            d = p->sidetoneV[0] * p->sidetone_volume * p->sidetoneEnvelope;
+            x[2 * i] = d; x[2 * i + 1] = d;
+            cmul_inplace(p->sidetoneV, p->sidetonePhase);
+        }
+        for (; i < nout; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; p->playSilence--; }
+        return nout;
+    }
+    if (p->playSilence > 0) {                                                   /* quisk.c:2422-2433 */
+        nout = ps_take(p, n);
+        for (i = 0; i < nout; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; }
+        p->playSilence -= nout;
+        return nout;
+    }
+    if (p->tt_phase_re != 0 || p->tt_phase_im != 0) AddTestTone(p, x, n);      /* quisk.c:2438-2439 */
+    if (p->invert) for (i = 0; i < n; i++) x[2 * i + 1] = -x[2 * i + 1];        /* quisk.c:2441-2446 */
+    if (!p->key_down) {                                                         /* quisk.c:2448-2449 */
+        if (!p->nb) p->nb = qo_nb_create(p->sample_rate);
+        qo_nb_set_level(p->nb, p->nb_level);
+        qo_nb_process(p->nb, x, n);
+    }
+    if (p->graph) qo_graph_feed(p->graph, x, n);                                /* quisk.c:2454-2475 */
+    if (p->rx_tune != 0) ps_tune(x, n, p->rxTV, p->rx_tune, p->sample_rate);    /* quisk.c:2477-2488 */
+    ps_load_filter(p, 0, 0, p->rx_mode);
+    n = process_decimate(p->bank[0], x, n);                                     /* quisk.c:2518 */
+    decim_srate = p->bank[0]->decim_srate;
+    if (p->measure_freq_mode) measure_freq(p, x, n, decim_srate);               /* quisk.c:2527-2528 */
+    n = process_demodulate(p->bank[0], x, ds, n);                               /* quisk.c:2530 */
+    p->squelch_real = p->squelch_imag = 0;
+    stereo = p->rx_mode == QO_DGT_IQ;
+    if (stereo) {
+        ;                                                                       /* this mode is already stereo */
+    } else if (p->split_rxtx) {                                                 /* quisk.c:2537-2590 */
+        int s0 = p->bank[0]->squelch_active, s1, first_real;
+        ps_tune(p->orig, orig_n, p->txTV, p->tx_tune + p->rit_freq, p->sample_rate);
+        ps_load_filter(p, 1, 0, p->rx_mode);
+        n2 = process_decimate(p->bank[1], p->orig, orig_n);
+        n2 = process_demodulate(p->bank[1], p->orig, ds2, n2);
+        s1 = p->bank[1]->squelch_active;
+        n = Buffer2Chan(p, ds, n, ds2, n2);
+        switch (p->split_rxtx) {
+        default:
+        case 1: first_real = p->tx_tune < p->rx_tune; goto two;
+        case 2: first_real = p->tx_tune >= p->rx_tune;
+        two:
+            if (first_real) { p->squelch_real = s0; p->squelch_imag = s1; for (i = 0; i < n; i++) { x[2 * i] = ds[i]; x[2 * i + 1] = ds2[i]; } }
+            else { p->squelch_real = s1; p->squelch_imag = s0; for (i = 0; i < n; i++) { x[2 * i] = ds2[i]; x[2 * i + 1] = ds[i]; } }
+            break;
+        case 3: p->squelch_real = p->squelch_imag = s0; for (i = 0; i < n; i++) { x[2 * i] = ds[i]; x[2 * i + 1] = ds[i]; } break;
+        case 4: p->squelch_real = p->squelch_imag = s1; for (i = 0; i < n; i++) { x[2 * i] = ds2[i]; x[2 * i + 1] = ds2[i]; } break;
+        }
+    } else if (p->play_channel >= 0 && p->sub_samples[p->play_channel]) {       /* quisk.c:2591-2621 */
+        int pc = p->play_channel, s0 = p->bank[0]->squelch_active, s1;
+        memcpy(p->bufc, p->sub_samples[pc], (size_t)orig_n * 2 * sizeof(double));
+        ps_tune(p->bufc, orig_n, p->aux1TV, p->sub_freq[pc], p->sample_rate);
+        ps_load_filter(p, 1, 1, p->sub_mode[pc]);
+        n2 = process_decimate(p->bank[1], p->bufc, orig_n);
+        n2 = process_demodulate(p->bank[1], p->bufc, ds2, n2);
+        s1 = p->bank[1]->squelch_active;
+        n = Buffer2Chan(p, ds, n, ds2, n2);
+        switch (p->play_method) {
+        default:
+        case 0: p->squelch_real = p->squelch_imag = s1; for (i = 0; i < n; i++) { x[2 * i] = ds2[i]; x[2 * i + 1] = ds2[i]; } break;
+        case 1: p->squelch_real = s0; p->squelch_imag = s1; for (i = 0; i < n; i++) { x[2 * i] = ds[i]; x[2 * i + 1] = ds2[i]; } break;
+        case 2: p->squelch_real = s1; p->squelch_imag = s0; for (i = 0; i < n; i++) { x[2 * i] = ds2[i]; x[2 * i + 1] = ds[i]; } break;
+        }
+    } else {                                                                    /* quisk.c:2622-2628 */
+        p->squelch_real = p->squelch_imag = p->bank[0]->squelch_active;
+        for (i = 0; i < n; i++) { x[2 * i] = ds[i]; x[2 * i + 1] = ds[i]; }
+    }
+    {                                                                           /* sub-receiver 1 on a digital output device, quisk.c:2630-2651 */
+        int m = p->sub_mode[0];
+        if (p->multirx_count > 0 && (m == QO_DGT_U || m == QO_DGT_L || m == QO_DGT_IQ || m == QO_DGT_FM) && p->sub_rx1_driver &&
+            p->sub_samples[0]) {
+            double *s = p->sub_samples[0];
+            ps_tune(s, orig_n, p->aux2TV, p->sub_freq[0], p->sample_rate);
+            ps_load_filter(p, 2, 2, m);
+            n2 = process_decimate(p->bank[2], s, orig_n);
+            n2 = process_demodulate(p->bank[2], s, ds2, n2);
+            if (m == QO_DGT_IQ) {
+                qo_agc_process(p->Agc3, s, n2, 1, p->agc_release_gain);
+            } else {
+                for (i = 0; i < n2; i++) { s[2 * i] = ds2[i]; s[2 * i + 1] = ds2[i]; }
+                qo_agc_process(p->Agc3, s, n2, 0, p->agc_release_gain);
+            }
+            memcpy(p->sub1_out, s, (size_t)n2 * 2 * sizeof(double));            /* play_sound_interface(..., n, multirx_cSamples[0], ...) */
+            p->sub1_n = n2;
+        }
+    }
+    for (i = 0; i < QO_MAX_SUB; i++) if (p->sub_cap[i]) { free(p->sub_samples[i]); p->sub_samples[i] = NULL; p->sub_cap[i] = 0; }
+    if (decim_srate != 48000)                                                   /* quisk.c:2654-2659 */
+        n = cFracDecim(p, x, n, decim_srate / 48000.0);
+    if (p->shim && p->wdsp_fn) n = wo_shim_fexchange0(p->shim, p->wdsp_fn, p->wdsp_ctx, x, n);      /* quisk.c:2660-2661 */
+    switch (p->playback_rate / 48000) {                                         /* quisk.c:2663-2682 */
+    case 1: break;
+    case 2: n = qo_cInterp2HB45(x, n, &p->HalfBand7); break;
+    case 4: n = qo_cInterp2HB45(x, n, &p->HalfBand7); n = qo_cInterp2HB45(x, n, &p->HalfBand8); break;
+    case 8: n = qo_cInterp2HB45(x, n, &p->HalfBand7); n = qo_cInterp2HB45(x, n, &p->HalfBand8); n = qo_cInterp2HB45(x, n, &p->HalfBand9); break;
+    default: break;
+    }
+    if (stereo) {                                                               /* quisk.c:2686-2701 */
+        qo_agc_process(p->Agc1, x, n, 1, p->agc_release_gain);
+    } else if (p->split_rxtx || p->play_channel >= 0) {
+        for (i = 0; i < n; i++) { p->orig[2 * i] = x[2 * i + 1]; p->orig[2 * i + 1] = 0; x[2 * i + 1] = 0; }
+        qo_agc_process(p->Agc1, x, n, 0, p->agc_release_gain);
+        qo_agc_process(p->Agc2, p->orig, n, 0, p->agc_release_gain);
+        for (i = 0; i < n; i++) x[2 * i + 1] = p->orig[2 * i];
+    } else {
+        qo_agc_process(p->Agc1, x, n, 0, p->agc_release_gain);
+    }
+    if (p->kill_audio) {                                                        /* quisk.c:2712-2728 */
+        p->squelch_real = p->squelch_imag = 1;
+        for (i = 0; i < n; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; }
+    } else if (p->squelch_real && p->squelch_imag) {
+        for (i = 0; i < n; i++) { x[2 * i] = 0; x[2 * i + 1] = 0; }
+    } else if (p->squelch_imag) {
+        for (i = 0; i < n; i++) x[2 * i + 1] = 0;
+    } else if (p->squelch_real) {
+        for (i = 0; i < n; i++) x[2 * i] = 0;
+    }
+    if (p->keyupEnvelope < 1.0) {                                               /* quisk.c:2729-2738 */
+        di = env_step;
+        for (i = 0; i < n; i++) {
+            p->keyupEnvelope += di;
+            if (p->keyupEnvelope > 1.0) { p->keyupEnvelope = 1.0; break; }
+            x[2 * i] *= p->keyupEnvelope; x[2 * i + 1] *= p->keyupEnvelope;
+        }
+    }
+    return n;
+}

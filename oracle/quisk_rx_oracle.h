@@ -78,6 +78,45 @@ void qo_rx_set_noise_blanker(qo_rx *r, int level);              /* set_noise_bla
 int qo_rx_decim_srate(const qo_rx *r);
 int qo_rx_filter_srate(const qo_rx *r);
 
+/* ---- quisk_process_samples as a whole (quisk.c:2289-2742): key-down replacement, AddTestTone, inversion, NoiseBlanker,
+ * FFT ring, banks 0-2 (main receiver; split Rx/Tx or played sub-receiver with Buffer2Chan; sub-receiver 1's digital
+ * output), measure_freq, cFracDecim, the wdspFexchange0 hand-off, HB45 interpolation to the playback rate, the AGCs,
+ * kill_audio / squelch, the key-up envelope.  One struct instead of the reference's statics and globals. */
+struct qo_graph;
+struct wo_shim;
+typedef struct qo_ps qo_ps;
+qo_ps *qo_ps_create(int sample_rate, int playback_rate, const qo_rx_tables *t);
+void qo_ps_free(qo_ps *p);
+void qo_ps_set_tune(qo_ps *p, int rx_tune_freq, int tx_tune_freq);
+void qo_ps_set_mode(qo_ps *p, int mode);
+void qo_ps_set_filters(qo_ps *p, const double *fI, const double *fQ, int size, int bandwidth, int nFilter);
+void qo_ps_set_agc(qo_ps *p, double level);
+void qo_ps_set_split_rxtx(qo_ps *p, int split);
+void qo_ps_set_multirx_play_channel(qo_ps *p, int ch);
+void qo_ps_set_multirx_play_method(qo_ps *p, int method);
+void qo_ps_set_multirx_freq(qo_ps *p, int index, int freq);
+void qo_ps_set_multirx_mode(qo_ps *p, int index, int mode);
+void qo_ps_set_multirx_count(qo_ps *p, int n);
+void qo_ps_set_sub_rx1_output(qo_ps *p, int on);
+void qo_ps_multirx_samples(qo_ps *p, int index, const double *x, int n);
+void qo_ps_set_key_state(qo_ps *p, int key_down, int cw_key_down, int active_sidetone, int is_fdx);
+void qo_ps_set_sidetone(qo_ps *p, double volume, int rit_freq, int txrx_silence_ms);
+void qo_ps_set_kill_audio(qo_ps *p, int kill);
+void qo_ps_invert_spectrum(qo_ps *p, int invert);
+void qo_ps_set_noise_blanker(qo_ps *p, int level);
+void qo_ps_set_auto_notch(qo_ps *p, int on);
+void qo_ps_set_squelch(qo_ps *p, double level);
+void qo_ps_set_ssb_squelch(qo_ps *p, int enabled, int level);
+void qo_ps_add_tone(qo_ps *p, int freq);                       /* add_tone, quisk.c:3203 */
+double qo_ps_measure_frequency(qo_ps *p, int mode);            /* measure_frequency, quisk.c:3181 */
+void qo_ps_set_graph(qo_ps *p, struct qo_graph *g);
+void qo_ps_set_wdsp(qo_ps *p, struct wo_shim *s, void (*fn)(void *ctx, double *in, double *out, int *error), void *ctx);
+int qo_ps_sub_rx1_audio(qo_ps *p, double *out, int cap);
+void qo_ps_restart_bank(qo_ps *p, int bank);                   /* test hook: what a GPU bank rebuild forgets */
+int qo_ps_squelch_flags(const qo_ps *p);                       /* bit 0: squelch_real, bit 1: squelch_imag of the last call */
+/* in place; the buffer must hold max(n, output count) samples; returns the count at the playback rate */
+int qo_ps_process(qo_ps *p, double *cSamples, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,20 +25,84 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False, defines=(), out=None):
-    """defines/out: experiment builds (tools/ab_bench.py) with -D overrides into another file; QH_HIPCC_FLAGS in the environment adds
-    compiler flags to such builds (scheduler strategies and the like)."""
+def _deps(src):
+    """Headers a source includes (transitively, by name), so that a header edit rebuilds only the units that see it."""
+    seen, todo = set(), [os.path.join(CSRC, src)]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(f).read()
+        except OSError:
+            continue
+        for line in text.splitlines():
+            line = line.strip()
+            if line.startswith('#include "'):
+                h = os.path.normpath(os.path.join(os.path.dirname(f), line.split('"')[1]))
+                if h not in seen:
+                    seen.add(h)
+                    todo.append(h)
+    return seen
+
+
+def build(force=False, verbose=False, defines=(), out=None, jobs=None):
+    """One object per source under quisk_amd/lib/obj (rebuilt when the source or a header it includes is newer), then the
+    link.  defines/out: experiment builds (tools/ab_bench.py) with -D overrides into another file, compiled in one go;
+    QH_HIPCC_FLAGS in the environment adds compiler flags to such builds (scheduler strategies and the like)."""
     target = out or LIB
-    if not force and not out and not needs_build():
-        return LIB
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "hip"]
+    extra = ["-D" + d for d in defines] + os.environ.get("QH_HIPCC_FLAGS", "").split()
     os.makedirs(os.path.dirname(target), exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-x", "hip", "-o", target] + ["-D" + d for d in defines] + os.environ.get("QH_HIPCC_FLAGS", "").split() + \
-          [os.path.join(CSRC, f) for f in SOURCES]
+    if out or extra:
+        cmd = base + ["-shared", "-o", target] + extra + [os.path.join(CSRC, f) for f in SOURCES]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        return target
+    if not force and not needs_build():          # the library that travelled with the snapshot is current: nothing to do
+        return LIB
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    todo, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        stale = force or not os.path.exists(obj)
+        if not stale:
+            t = os.path.getmtime(obj)
+            stale = any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, src)] + [d for d in _deps(src) if os.path.exists(d)])
+        if stale:
+            todo.append((src, obj))
+    if not todo and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+        return LIB
+    jobs = jobs or min(4, os.cpu_count() or 1)
+    running = []
+
+    def reap(block):
+        for pr, src in list(running):
+            if block or pr.poll() is not None:
+                if pr.wait() != 0:
+                    for other, _ in running:
+                        if other is not pr:
+                            other.kill()
+                    raise subprocess.CalledProcessError(pr.returncode, src)
+                running.remove((pr, src))
+                if block:
+                    return
+
+    for src, obj in todo:
+        while len(running) >= jobs:
+            reap(True)
+        cmd = base + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        running.append((subprocess.Popen(cmd), src))
+    while running:
+        reap(True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return target
+    return LIB
 
 
 if __name__ == "__main__":

@@ -772,6 +772,51 @@ int qh_pan_feed(qh_pan *h, const double *d_in, long long in_stride, int n)
 
 int qh_pan_count(const qh_pan *h) { return h ? h->p.count : 0; }
 
+// Another window in place of record_app's Hanning (measure_freq multiplies by 0.5 - 0.5 cos(2 pi i / (N - 1)), quisk.c:5600-5601).
+// Sizes that run Bluestein's transform only: there the window is a table (folded into the pre-chirp); the power-of-two kernels
+// form record_app's window from their twiddles.
+int qh_pan_set_window(qh_pan *h, const double *window)
+{
+    if (!h || !window) return set_error(QH_ERR_INVALID, "qh_pan_set_window: bad arguments");
+    Pan &p = h->p;
+    if (!p.blue) return set_error(QH_ERR_UNSUPPORTED, "qh_pan_set_window: fft_size %d uses the fused power-of-two kernels (fixed Hanning window)", p.N);
+    QH_HIP(hipSetDevice(p.device));
+    const int N = p.N;
+    std::vector<cd> pre((size_t)N);
+    for (int n = 0; n < N; n++) {
+        const long long q = ((long long)n * n) % (2ll * N);
+        const long double a = 3.14159265358979323846264338327950288L * (long double)q / (long double)N;
+        pre[(size_t)n] = cd((double)cosl(a), -(double)sinl(a)) * window[n];
+    }
+    QH_HIP(hipStreamSynchronize(p.stream));
+    QH_HIP(hipMemcpy(p.b_pre, pre.data(), (size_t)N * 16, hipMemcpyHostToDevice));
+    return QH_OK;
+}
+
+// The running sums of |X| in fftshift order (fft_avg of get_graph, fft_average of measure_freq), [nch][fft_size]; reset != 0
+// starts the average over like a get_graph call does.
+int qh_pan_read_avg(qh_pan *h, double *h_avg, int reset)
+{
+    if (!h || !h_avg) return set_error(QH_ERR_INVALID, "qh_pan_read_avg: bad arguments");
+    Pan &p = h->p;
+    QH_HIP(hipSetDevice(p.device));
+    QH_HIP(hipMemcpyAsync(h_avg, p.avg, (size_t)p.nch * p.N * 8, hipMemcpyDeviceToHost, p.stream));
+    if (reset) {
+        QH_HIP(hipMemsetAsync(p.avg, 0, (size_t)p.nch * p.N * 8, p.stream));
+        QH_HIP(hipMemsetAsync(p.meter, 0, (size_t)p.nch * 8, p.stream));
+        p.count = 0;
+    }
+    QH_HIP(hipStreamSynchronize(p.stream));
+    return QH_OK;
+}
+// forgets a partly filled block (measure_freq drops the rest of the call that completes a transform, quisk.c:5607-5610)
+int qh_pan_drop_partial(qh_pan *h)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null panadapter");
+    h->p.fill = 0;
+    return QH_OK;
+}
+
 int qh_pan_graph(qh_pan *h, double zoom, double deltaf, double *h_pixels, double *h_smeter, int *count)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null panadapter");

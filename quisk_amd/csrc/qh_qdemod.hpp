@@ -66,8 +66,9 @@ static __global__ __launch_bounds__(kSegThreads) void q_am_env_tiled_kernel(doub
     }
     const double e = wave_sum_d(acc * lane_pow(0.99, 63 - lane));
     if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); }
+    const double c_in = dc_state[ch];                    // ahead of the barrier: the last wavefront stores the new carry at its end
     __syncthreads();
-    double c = dc_state[ch];
+    double c = c_in;
     for (int w = 0; w < wave; w++) if (s_n[w]) c = __builtin_fma(c, pow(0.99, (double)s_n[w]), s_e[w]);
     seg_load(zn, b0, b1, n, lane, (const double2 *)p);
     for (int b = b0; b < b1; b += kSegGroup) {

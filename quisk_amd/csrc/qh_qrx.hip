@@ -105,6 +105,7 @@ struct Qrx {
     double2 *ssq_delay[2] = { nullptr, nullptr };
     int ssq_cur = 0;
     QSquelchState *sq_state = nullptr;  // squelch flag (FM squelch state, quisk.c:2076-2085)
+    bool mute_deferred = false;         // the caller applies the squelch itself, behind its AGC (qh_quisk_process_samples)
     double *sq_level = nullptr;
     std::vector<double> h_sq_level;
     bool sq_dirty = false;
@@ -604,7 +605,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
     }
     if (q.agc && q.agc_on && n > 0)
         if (int rc = qh_qagc_process(q.agc, d_out, out_stride, n)) return rc;
-    if (q.sq_state && n > 0) {
+    if (q.sq_state && !q.mute_deferred && n > 0) {
         int gx = (n + 255) / 256;
         if (gx > 64) gx = 64;
         hipLaunchKernelGGL(q_mute_kernel, dim3((unsigned)gx, (unsigned)q.nch), dim3(256), 0, q.stream, reinterpret_cast<double2 *>(d_out),
@@ -714,6 +715,46 @@ int qh_qrx_set_noise_blanker(qh_qrx *h, int level)
     }
     q.nb_level = level;
     return qh_nb_set_level(q.nb, level);
+}
+
+// ---- hooks for quisk_process_samples' orchestration (qh_quisk_rx_compat.cpp) ------------------------------------------------
+// The reference applies the squelch flags of its banks at the very end of the block, behind the interpolation and the AGC
+// (quisk.c:2712-2728): the bank leaves its output alone and hands out where its flag lives.
+int qh_qrx_set_mute_deferred(qh_qrx *h, int on)
+{
+    QH_QRX_LOCK(h);
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    h->q.mute_deferred = on != 0;
+    return QH_OK;
+}
+// device address of MeasureSquelch[bank].squelch_active of channel ch (an int), or null while the bank has no squelch
+const int *qh_qrx_squelch_flag(qh_qrx *h, int ch)
+{
+    QH_QRX_LOCK(h);
+    if (!h || ch < 0 || ch >= h->q.nch || !h->q.sq_state) return nullptr;
+    return &h->q.sq_state[ch].active;
+}
+// ssb_squelch's FFT plan is ONE function static for all banks (quisk.c:1091,1104): the first call of any bank creates it and
+// returns without looking at its samples.  A caller that runs several banks as the reference's bank 0 / 1 / 2 passes the fact on.
+int qh_qrx_ssb_squelch_planned(qh_qrx *h, int set)
+{
+    QH_QRX_LOCK(h);
+    if (!h) return 0;
+    if (set > 0) h->q.ssb_sq_inited = true;
+    return h->q.ssb_sq_inited ? 1 : 0;
+}
+// the tuning oscillator's phase (2^-64 turns) at the next input sample: one vector per purpose in the reference (quisk.c:2308-2311)
+int qh_qrx_get_nco_phase(qh_qrx *h, int ch, unsigned long long *phase)
+{
+    QH_QRX_LOCK(h);
+    if (!h || !phase || ch < 0 || ch >= h->q.nch) return set_error(QH_ERR_INVALID, "qh_qrx_get_nco_phase: bad arguments");
+    return h->q.steps[0].st->get_nco_phase(ch, phase);
+}
+int qh_qrx_set_nco_phase(qh_qrx *h, int ch, unsigned long long phase)
+{
+    QH_QRX_LOCK(h);
+    if (!h || ch < 0 || ch >= h->q.nch) return set_error(QH_ERR_INVALID, "qh_qrx_set_nco_phase: bad arguments");
+    return h->q.steps[0].st->set_nco_phase(ch, phase);
 }
 
 int qh_qrx_process_host(qh_qrx *h, const double *h_in, long long in_stride, int n_in, double *h_out, long long out_stride, int *n_out)

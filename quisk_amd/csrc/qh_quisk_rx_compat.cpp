@@ -1,13 +1,30 @@
 // qh_quisk_rx_compat.cpp -- the Quisk native block API for ONE receiver (include/quiskhip.h group 9).
 //
 // quisk.c keeps its receive path behind `int quisk_process_samples(complex double *cSamples, int nSamples)`
-// (quisk.h:375, quisk.c:2289): in place, returns the output count, parameters arrive through globals that the
-// GUI thread sets with set_tune / set_rx_mode / set_filters / set_agc (quisk.c:4702,4621,4551,4543) and reads with
-// get_filter_rate / get_graph (quisk.c:2787,5142).  This layer offers exactly that shape -- one process-wide
-// receiver, the same call names with a qh_quisk_ prefix -- on top of the batched GPU bank (qh_qrx.hip), the AGC
-// (qh_qagc.hip) and the panadapter (qh_pan.hip).  A maintainer replaces the body of quisk_process_samples with a
-// call to qh_quisk_process_samples.  Mode, bandwidth class or rate changes rebuild
-// the bank (filter histories restart: a few ms of transient where the reference keeps its static histories).
+// (quisk.h:375, quisk.c:2289): in place, returns the output count at the playback rate, parameters arrive through
+// globals that the GUI thread sets with set_tune / set_rx_mode / set_filters / set_agc ... and reads with
+// get_filter_rate / get_graph.  This layer offers exactly that shape -- one process-wide receiver, the same call names
+// with a qh_quisk_ prefix -- and restates the WHOLE function (quisk.c:2289-2742) in its order:
+//
+//   key-down replacement (host: nothing is demodulated)             quisk.c:2368-2433
+//   AddTestTone, spectrum inversion                                  quisk.c:1258-1303,2438-2446
+//   NoiseBlanker (not while the key is down)                         quisk.c:2448-2449
+//   FFT ring producer                                                quisk.c:2454-2475
+//   tune + quisk_process_decimate + quisk_process_demodulate, bank 0 quisk.c:2477-2530
+//   measure_freq on the decimated samples                            quisk.c:2527-2528,5579-5649
+//   second channel on bank 1: split Rx/Tx or the played sub-receiver, Buffer2Chan   quisk.c:2537-2621,1577-1611
+//   sub-receiver 1 on a digital output device, bank 2, Agc3          quisk.c:2630-2651
+//   cFracDecim to 48 ksps                                            quisk.c:2654-2659,622-665
+//   wdspFexchange0                                                   quisk.c:2660-2661
+//   HB45 interpolation x2 / x4 / x8 to the playback rate             quisk.c:2663-2682
+//   process_agc (Agc1, Agc2), kill_audio / squelch, key-up envelope  quisk.c:2686-2738
+//
+// The block is uploaded ONCE and stays on the device until the playback samples come back: every step above is a kernel
+// (or one of the library's engines) on one HIP stream.  The only host round trip inside the chain is the optional WDSP
+// hand-off, whose entry point (fexchange0) takes host pointers by definition; it moves 48 ksps audio.
+// Mode, bandwidth class or rate changes rebuild a bank (filter histories restart: a few ms of transient where the
+// reference keeps its static histories); the tuning oscillators keep their phase (one per purpose, as the reference's
+// rxTuneVector / txTuneVector / aux1TuneVector / aux2TuneVector).
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -15,61 +32,253 @@
 #include <vector>
 #include "qh_internal.hpp"
 
+
 namespace {
+
+using u64 = unsigned long long;
+constexpr int kBuf2Chan = 12000;            // BUF2CHAN_SIZE, quisk.c:1576
+constexpr int kMfSize = 12000;              // measure_freq's fft_size, quisk.c:5586
+
+__device__ __forceinline__ double2 turns_phasor(u64 ph)
+{
+    double s, c;
+    sincospi(2.0 * ((double)(ph >> 11) * (1.0 / 9007199254740992.0)), &s, &c);
+    return make_double2(c, s);
+}
+
+// AddTestTone (quisk.c:1258-1303) and the spectrum inversion (quisk.c:2441-2446) in one pass, out of place: the split
+// receiver keeps the raw block (orig_cSamples is copied ahead of both, quisk.c:2361-2363).
+//   kind 0: x += A e^{j th}        1 (AM): x += A e^{j th} (1 + cos a)        2 (FM): x += A e^{j th} e^{j cos a}
+// th / a: phases of testtoneVector / audioVector in 2^-64 turns, advanced per sample by dth / da.
+__global__ void ps_prep_kernel(const double2 *in, double2 *out, int n, int kind, u64 th0, u64 dth, u64 a0, u64 da, int invert)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double2 x = in[i];
+    if (kind >= 0) {
+        const double A = 21474836.47;                   // -40 dB, quisk.c:1263
+        double2 t = turns_phasor(th0 + dth * (u64)i);
+        if (kind == 1) {
+            const double g = 1.0 + turns_phasor(a0 + da * (u64)i).x;
+            t.x *= g; t.y *= g;
+        } else if (kind == 2) {
+            double s, c;
+            sincos(turns_phasor(a0 + da * (u64)i).x, &s, &c);
+            t = make_double2(t.x * c - t.y * s, t.x * s + t.y * c);
+        }
+        x.x += A * t.x; x.y += A * t.y;
+    }
+    if (invert) x.y = -x.y;
+    out[i] = x;
+}
+
+// The stereo join of the two demodulated streams (quisk.c:2548-2620) behind Buffer2Chan (quisk.c:1577-1611).  Stream k is the
+// concatenation of what Buffer2Chan held back for it (buf_k, nbuf_k samples) and the real parts of this call's bank output.
+// sel_re / sel_im: which stream goes to the real / imaginary output (0 = bank 0, 1 = bank 1).
+__device__ __forceinline__ double b2c_at(const double *buf, int nbuf, const double2 *samp, int i)
+{
+    return i < nbuf ? buf[i] : samp[i - nbuf].x;
+}
+__global__ void ps_join_kernel(const double *buf1, int nbuf1, const double2 *s1, const double *buf2, int nbuf2, const double2 *s2,
+                               int nout, int sel_re, int sel_im, double2 *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout) return;
+    const double a = b2c_at(buf1, nbuf1, s1, i), b = b2c_at(buf2, nbuf2, s2, i);
+    out[i] = make_double2(sel_re ? b : a, sel_im ? b : a);
+}
+// what stays in Buffer2Chan's buffers: samples nout .. total_k - 1 of either stream
+__global__ void ps_b2c_keep_kernel(const double *buf1, int nbuf1, const double2 *s1, int keep1, double *new1, const double *buf2, int nbuf2,
+                                   const double2 *s2, int keep2, double *new2, int nout)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < keep1) new1[i] = b2c_at(buf1, nbuf1, s1, nout + i);
+    if (i < keep2) new2[i] = b2c_at(buf2, nbuf2, s2, nout + i);
+}
+
+// cFracDecim (quisk.c:622-665): a 4-point Lagrange interpolator stepped by fdecim input samples per output.  The reference
+// carries `dindex`: +(fdecim - 1) per output, -1 per skipped input.  Unrolled, output m of a call sits at
+//   w = d0 + m (fdecim - 1),  input index i_m = m + floor(w) - 1,  position within (c0..c3) = w - floor(w) + 1  in [1, 2)
+// with d0 the carried dindex: one lane per output.  hist = the last three inputs of the call before (c0, c1, c2).
+__global__ void ps_fracdecim_kernel(const double2 *in, const double2 *hist, int nout, double d0, double step, double2 *out)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nout) return;
+    const double w = fma(step, (double)m, d0), fl = floor(w);
+    const int i = m + (int)fl - 1;
+    const double d = w - fl + 1.0;
+    double2 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int j = i - 3 + k; c[k] = j >= 0 ? in[j] : hist[3 + j]; }
+    const double xm0 = d, xm1 = d - 1, xm2 = d - 2, xm3 = d - 3;
+    const double w0 = xm1 * xm2 * xm3 / -6.0, w1 = xm0 * xm2 * xm3 / 2.0, w2 = xm0 * xm1 * xm3 / -2.0, w3 = xm0 * xm1 * xm2 / 6.0;
+    out[m] = make_double2(w0 * c[0].x + w1 * c[1].x + w2 * c[2].x + w3 * c[3].x, w0 * c[0].y + w1 * c[1].y + w2 * c[2].y + w3 * c[3].y);
+}
+__global__ void ps_fd_hist_kernel(const double2 *in, int n, const double2 *hist_old, double2 *hist_new)
+{
+    const int k = threadIdx.x;                          // 3 lanes
+    if (k >= 3) return;
+    const int j = n - 3 + k;
+    hist_new[k] = j >= 0 ? in[j] : hist_old[3 + j];
+}
+
+// the two output channels as two real streams for Agc1 / Agc2 and back (quisk.c:2690-2698)
+__global__ void ps_split_kernel(const double2 *x, int n, double2 *a, double2 *b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double2 v = x[i];
+    a[i] = make_double2(v.x, 0.0); b[i] = make_double2(v.y, 0.0);
+}
+__global__ void ps_merge_kernel(const double2 *a, const double2 *b, int n, double2 *x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i] = make_double2(a[i].x, b[i].x);
+}
+// kill_audio / the squelch of either output channel (quisk.c:2712-2728), then the key-up envelope (quisk.c:2729-2738; the
+// host steps keyupEnvelope the way the reference does and hands over the factors of the first env_n samples).
+// flags_out[0..1] = squelch_real, squelch_imag as the reference leaves them.
+__global__ void ps_epilogue_kernel(double2 *x, int n, const int *flag_real, const int *flag_imag, int kill, const double *env, int env_n,
+                                   int *flags_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int sr = flag_real ? *flag_real : 0, si = flag_imag ? *flag_imag : 0;
+    if (kill) sr = si = 1;
+    if (i == 0) { flags_out[0] = sr; flags_out[1] = si; }
+    if (i >= n) return;
+    double2 v = x[i];
+    if (sr) v.x = 0.0;
+    if (si) v.y = 0.0;
+    if (i < env_n) { const double e = env[i]; v.x *= e; v.y *= e; }
+    x[i] = v;
+}
+
+inline unsigned grid_for(int n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
+
+// 2^-64 turns per sample for a tone of `freq` Hz at `rate` (any sign)
+u64 turns_step(double freq, double rate)
+{
+    long double t = (long double)freq / (long double)rate;
+    t -= floorl(t);
+    const long double sc = t * 18446744073709551616.0L;
+    return sc >= 18446744073709551616.0L ? 0ull : (u64)sc;
+}
+
+template <typename T> struct DevBuf {           // grows on demand; contents are not kept across a growth
+    T *p = nullptr;
+    size_t cap = 0;
+    int need(size_t n)
+    {
+        if (n <= cap) return QH_OK;
+        if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 4 + 64;
+        if (hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess) return qh::set_error(QH_ERR_HIP, "qh_quisk: hipMalloc of %zu bytes failed", want * sizeof(T));
+        cap = want;
+        return QH_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int need(size_t n)
+    {
+        if (n <= cap) return QH_OK;
+        if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 4 + 64;
+        if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) return qh::set_error(QH_ERR_HIP, "qh_quisk: pinned allocation failed");
+        cap = want;
+        return QH_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// one receiver bank of the reference (Storage[bank] of quisk_process_decimate / _demodulate and of c/dRxFilterOut)
+struct Bank {
+    qh_qrx *rx = nullptr;
+    int mode = -1, cls = -1, tune = 0x7fffffff;
+    int filt_n = -1;                    // which of cFilterI/Q[nFilter] its Rx filter stage holds ...
+    long long filt_epoch = -1;          // ... as of which set_filters call
+    int notch_applied = -1;
+    int purpose = -1;                   // whose tune vector its oscillator carries (index into QuiskRx::phase)
+    double sq_level = -1e300;           // squelch settings the bank has been given
+    int ssb_en = -1, ssb_lv = -1;
+};
 
 struct QuiskRx {
     std::mutex mtx;
-    int sample_rate = 0, mode = 3 /* USB */, tune = 0, bandwidth = 2700;
+    int sample_rate = 0, playback_rate = 48000, mode = 3 /* USB */, tune = 0;
     double agc_gain = 80.0;                     // agcReleaseGain, quisk.c:191
-    bool agc_on = true;
     std::vector<double> tables[13];
     qh_qrx_tables t{};
     bool have_tables = false;
-    std::vector<double> filtI, filtQ;
-    qh_qrx *bank = nullptr;
-    int bank_mode = -1, bank_bw_class = -1, bank_rate = 0;
-    bool params_dirty = true;
+    hipStream_t stream = nullptr;
+    // cFilterI / cFilterQ [nFilter], filter_bandwidth[nFilter] and the ONE sizeFilter of set_filters (quisk.c:127-129,4551-4594)
+    std::vector<double> filtI[3], filtQ[3];
+    int filt_bw[3] = { 2700, 2700, 2700 }, size_filter = 0;
+    long long filt_epoch = 0;
+    Bank bank[3];
+    // the tune vectors (quisk.c:2308-2311) as oscillator phases: 0 rx, 1 tx (split), 2 aux1 (played sub-receiver), 3 aux2;
+    // 4: the measurement receiver's own
+    u64 phase[5] = { 0, 0, 0, 0, 0 };
+    bool ssb_planned = false;                   // ssb_squelch's `plan` static: one for all banks (quisk.c:1091,1104)
     // panadapter (record_app's fft_size / data_width, quisk.c:5946)
     qh_pan *pan = nullptr;
     int fft_size = 0, data_width = 0;
-    std::vector<double> out;
-    // NoiseBlanker's statics (quisk.c:682-687): outlive mode changes, so they are not the bank's
-    // Agc1 (quisk.c:2321) is one static AGC for the playback stream whatever the mode: it belongs here, not to a bank
-    qh_qagc *agc = nullptr;
-    int agc_rate = 0;
-    double agc_gain_set = -1.0;
-    qh_nb *nb = nullptr;
+    qh_nb *nb = nullptr;                        // NoiseBlanker's statics (quisk.c:682-687) outlive mode changes
     int nb_level = 0;
-    int auto_notch = 0, rit_freq = 0, notch_applied = -1;
-    std::vector<double> nb_out;
-    // ---- the rest of quisk_process_samples' orchestration (quisk.c:2289-2742) ----
-    // A second receiver bank on another frequency: split Rx/Tx (the same samples at quisk_tx_tune_freq + rit_freq, the
-    // filters of nFilter 0) or the played sub-receiver (its own samples, frequency and mode, the filters of nFilter 1);
-    // the two audio streams go to the real and the imaginary output and get an AGC each (Agc1, Agc2).
-    int tx_tune = 0, split_rxtx = 0;                 // set_tune's second argument, set_split_rxtx (quisk.c:4702,4694)
-    int play_channel = -1, play_method = 0;          // set_multirx_play_channel / _method (quisk.c:4856,4846)
-    static constexpr int kMaxSub = 9;                // QUISK_MAX_SUB_RECEIVERS, quisk.h
-    int sub_freq[kMaxSub] = { 0 }, sub_mode[kMaxSub] = { 0 };      // set_multirx_freq / set_multirx_mode (quisk.c:4826,4836)
-    std::vector<double> sub_samples;                 // the played sub-receiver's block for the coming call (multirx_cSamples[])
-    int sub_have = 0;
-    std::vector<double> filt2I, filt2Q;              // set_filters(..., nFilter = 1)
-    int bandwidth2 = 2700;
-    qh_qrx *bank2 = nullptr;
-    int bank2_mode = -1, bank2_cls = -1, bank2_tune = 0x7fffffff;
-    bool filt2_dirty = true;
-    qh_qagc *agc2 = nullptr;
-    int agc2_rate = 0;
-    double agc2_gain_set = -1.0;
-    std::vector<double> out2, chan_a, chan_b;
-    int old_split = 0, old_play = -1;
-    // key handling (quisk.c:2368-2433): the block is replaced by the sidetone or by silence while the key is down and
-    // for TxRxSilenceMsec after it, then the volume comes back over 5 ms
+    int auto_notch = 0, rit_freq = 0;
+    bool notch_reset = false;
+    qh_qagc *agc[3] = { nullptr, nullptr, nullptr };        // Agc1, Agc2, Agc3 = {0.7, 0, 0} (quisk.c:2321): rate = playback rate
+    double agc_gain_set[3] = { -1.0, -1.0, -1.0 };
+    int tx_tune = 0, split_rxtx = 0;            // set_tune's second argument, set_split_rxtx (quisk.c:4702,4694)
+    int play_channel = -1, play_method = 0;     // set_multirx_play_channel / _method (quisk.c:4856,4846)
+    static constexpr int kMaxSub = 9;           // QUISK_MAX_SUB_RECEIVERS, quisk.h
+    int sub_freq[kMaxSub] = { 0 }, sub_mode[kMaxSub] = { 0 };
+    std::vector<double> sub_samples[kMaxSub];   // multirx_cSamples[] for the coming call
+    int sub_have[kMaxSub] = { 0 };
+    int multirx_count = 0, sub_rx1_driver = 0;
+    int old_split = 0, old_play = 0;            // "static int old_multirx_play_channel = 0", quisk.c:2303
+    // key handling (quisk.c:2368-2433)
     int key_down = 0, cw_key_down = 0, active_sidetone = 0, is_fdx = 0, kill_audio = 0, invert_spectrum = 0;
-    int playback_rate = 48000, txrx_silence_ms = 50;
+    int txrx_silence_ms = 50;
     double sidetone_volume = 0.0;
-    std::complex<double> sidetone_phase{ 1.0, 0.0 }, sidetone_vec{ 0.0, 0.0 };
+    std::complex<double> sidetone_phase{ 1.0, 0.0 }, sidetone_vec{ 2.2e9, 0.0 };
     double out_counter = 0.0, sidetone_env = 0.0, keyup_env = 1.0;
     int sidetone_on = 0, play_silence = 0;
+    // squelches of quisk_process_demodulate (set_squelch quisk.c:4721, set_ssb_squelch quisk.c:4729)
+    double squelch_level = -999.0;
+    int ssb_squelch_enabled = 0, ssb_squelch_level = 0;
+    // AddTestTone (quisk.c:1258-1303, add_tone quisk.c:3203)
+    bool tone_on = false;
+    u64 tone_phase = 0, tone_step = 0, audio_phase = 0;
+    // Buffer2Chan (quisk.c:1577-1611): device buffers, counts on the host
+    DevBuf<double> b2c[2][2];
+    int b2c_cur = 0, nbuf1 = 0, nbuf2 = 0;
+    // cFracDecim's statics (quisk.c:626-629)
+    double fd_dindex = 1.0;
+    double2 *fd_hist[2] = { nullptr, nullptr };
+    int fd_cur = 0;
+    // the interpolator to the playback rate (HalfBand7..9, quisk.c:2663-2682) as one polyphase filter
+    qh_rat *up = nullptr;
+    int up_ratio = 1;
+    // measure_freq (quisk.c:5579-5649)
+    int measure_mode = 0, mf_index = 0, mf_count = 0;
+    double measured_frequency = 0.0;
+    Bank mf_bank;
+    qh_fir *mf_dec = nullptr;
+    qh_pan *mf_fft = nullptr;
+    std::vector<double> mf_avg;
+    // work buffers
+    DevBuf<double2> d_raw, d_x, d_nb, d_o0, d_o1, d_mix, d_fd, d_up, d_a, d_b, d_sub, d_sub0, d_s1, d_mf, d_mf8;
+    DevBuf<double> d_env;
+    int *d_flags = nullptr;
+    PinBuf<double> h_in, h_out, h_sub1;
+    int *h_flags = nullptr;
+    std::vector<double> sub1_out;               // sub-receiver 1's audio of the last call (what play_sound_interface got)
+    int sub1_n = 0;
+    int squelch_real = 0, squelch_imag = 0;
 };
 
 QuiskRx g;
@@ -80,167 +289,99 @@ int bw_class(int mode, int bw)     // what of the bandwidth the bank's structure
     if (mode == 9) return bw < 19000 ? 0 : 1;
     return 0;
 }
+bool has_ssb_squelch(int mode) { return mode <= 4 || mode == 10; }       // CW, SSB, AM (IMD takes the SSB path)
+bool is_fm_mode(int mode) { return mode == 5 || mode == 13; }
 
-int ensure_bank()
+void destroy_bank(Bank &b, bool keep_phase)
 {
-    if (!g.sample_rate || !g.have_tables) return qh::set_error(QH_ERR_INVALID, "qh_quisk_open has not been called");
-    const int cls = bw_class(g.mode, g.bandwidth);
-    if (!g.bank || g.bank_mode != g.mode || g.bank_bw_class != cls || g.bank_rate != g.sample_rate) {
-        if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
-        g.bank = qh_qrx_create_ex(0, 1, g.sample_rate, g.mode, g.bandwidth, &g.t, nullptr);
-        if (!g.bank) return QH_ERR_HIP;
-        g.bank_mode = g.mode; g.bank_bw_class = cls; g.bank_rate = g.sample_rate;
-        g.params_dirty = true;
-        g.notch_applied = -1;
+    if (b.rx) {
+        if (keep_phase && b.purpose >= 0) (void)qh_qrx_get_nco_phase(b.rx, 0, &g.phase[b.purpose]);
+        qh_qrx_destroy(b.rx);
     }
-    if (g.params_dirty) {
-        if (int rc = qh_qrx_set_tune(g.bank, 0, g.tune)) return rc;
-        if (int rc = qh_qrx_set_filters(g.bank, 0, g.filtI.data(), g.filtQ.data(), (int)g.filtI.size())) return rc;
-        g.params_dirty = false;
+    b = Bank();
+}
+
+// Bank `b` ready for this call: the receiver structure of (mode, bandwidth class), the purpose's oscillator phase, the tune
+// frequency, cFilterI/Q[nFilter][0 .. sizeFilter) and the squelch settings.
+int ensure_bank(Bank &b, int mode, int nFilter, int tune, int purpose, int bw_force = -1)
+{
+    if (mode == 6) return qh::set_error(QH_ERR_UNSUPPORTED, "mode EXT calls the user's quisk_extern_demod (extdemod.c:13): not provided");
+    const int bw = bw_force >= 0 ? bw_force : g.filt_bw[nFilter];
+    const int cls = bw_class(mode, bw);
+    if (!b.rx || b.mode != mode || b.cls != cls) {
+        destroy_bank(b, true);
+        b.rx = qh_qrx_create_ex(0, 1, g.sample_rate, mode, bw, &g.t, g.stream);
+        if (!b.rx) return QH_ERR_HIP;
+        b.mode = mode; b.cls = cls;
+        if (int rc = qh_qrx_set_mute_deferred(b.rx, 1)) return rc;
     }
-    if (g.notch_applied != g.auto_notch) {          // a set_auto_notch call (or a fresh bank) starts the notch over
-        if (g.mode != 9 /* DGT-IQ has no notch */) if (int rc = qh_qrx_set_auto_notch(g.bank, g.auto_notch, g.rit_freq)) return rc;
-        g.notch_applied = g.auto_notch;
+    if (b.tune != tune) { if (int rc = qh_qrx_set_tune(b.rx, 0, tune)) return rc; b.tune = tune; }
+    if (b.purpose != purpose) {
+        if (b.purpose >= 0) if (int rc = qh_qrx_get_nco_phase(b.rx, 0, &g.phase[b.purpose])) return rc;
+        if (int rc = qh_qrx_set_nco_phase(b.rx, 0, g.phase[purpose])) return rc;
+        b.purpose = purpose;
+    }
+    if (b.filt_n != nFilter || b.filt_epoch != g.filt_epoch) {
+        std::vector<double> fI((size_t)g.size_filter, 0.0), fQ((size_t)g.size_filter, 0.0);
+        for (int i = 0; i < g.size_filter; i++) {
+            if ((size_t)i < g.filtI[nFilter].size()) { fI[(size_t)i] = g.filtI[nFilter][(size_t)i]; fQ[(size_t)i] = g.filtQ[nFilter][(size_t)i]; }
+        }
+        if (int rc = qh_qrx_set_filters(b.rx, 0, fI.data(), fQ.data(), g.size_filter)) return rc;
+        b.filt_n = nFilter; b.filt_epoch = g.filt_epoch;
+    }
+    if (is_fm_mode(mode)) {
+        if (b.sq_level != g.squelch_level) { if (int rc = qh_qrx_set_squelch(b.rx, 0, g.squelch_level)) return rc; b.sq_level = g.squelch_level; }
+    } else if (has_ssb_squelch(mode)) {
+        if (b.ssb_en != g.ssb_squelch_enabled || b.ssb_lv != g.ssb_squelch_level) {
+            if (int rc = qh_qrx_set_ssb_squelch(b.rx, g.ssb_squelch_enabled, g.ssb_squelch_level)) return rc;
+            b.ssb_en = g.ssb_squelch_enabled; b.ssb_lv = g.ssb_squelch_level;
+        }
+        if (g.ssb_planned) (void)qh_qrx_ssb_squelch_planned(b.rx, 1);
     }
     return QH_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-// quisk_sound_state.sample_rate + the filters.h tables (data, passed in like to qh_qrx_create_ex) + record_app's
-// fft_size and data_width (0, 0: no panadapter).
-int qh_quisk_open(int sample_rate, const qh_qrx_tables *tables, int fft_size, int data_width)
+int ensure_agc(int k)
 {
-    static const int len[13] = { 98, 147, 245, 50, 36, 186, 309, 125, 55, 114, 136, 174, 189 };
-    if (sample_rate <= 0 || !tables) return qh::set_error(QH_ERR_INVALID, "qh_quisk_open: bad arguments");
-    std::lock_guard<std::mutex> lk(g.mtx);
-    const double *src[13] = { tables->f48dec24, tables->f144d3, tables->f240d5, tables->audio24p4, tables->audio24p6, tables->lp48,
-                              tables->fmhp, tables->f300d5, tables->sdriq53, tables->sdriq111, tables->sdriq133, tables->sdriq167,
-                              tables->sdriq185 };
-    const double *dst[13];
-    for (int i = 0; i < 13; i++) {
-        if (src[i]) { g.tables[i].assign(src[i], src[i] + len[i]); dst[i] = g.tables[i].data(); }
-        else { g.tables[i].clear(); dst[i] = nullptr; }
+    if (!g.agc[k]) {
+        g.agc[k] = qh_qagc_create(0, 1, g.playback_rate, 0.7, 1.0, 0, g.stream);       // struct AgcState {0.7, 0, 0}, quisk.c:2321,2174
+        if (!g.agc[k]) return QH_ERR_HIP;
+        g.agc_gain_set[k] = -1.0;
     }
-    g.t.f48dec24 = dst[0]; g.t.f144d3 = dst[1]; g.t.f240d5 = dst[2]; g.t.audio24p4 = dst[3]; g.t.audio24p6 = dst[4];
-    g.t.lp48 = dst[5]; g.t.fmhp = dst[6]; g.t.f300d5 = dst[7]; g.t.sdriq53 = dst[8]; g.t.sdriq111 = dst[9];
-    g.t.sdriq133 = dst[10]; g.t.sdriq167 = dst[11]; g.t.sdriq185 = dst[12];
-    g.have_tables = true;
-    g.sample_rate = sample_rate;
-    if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
-    if (g.pan) { qh_pan_destroy(g.pan); g.pan = nullptr; }
-    if (g.nb) { qh_nb_destroy(g.nb); g.nb = nullptr; }      // "sample_rate != sample_rate: Initialization", quisk.c:697
-    if (g.agc) { qh_qagc_destroy(g.agc); g.agc = nullptr; }
-    if (g.bank2) { qh_qrx_destroy(g.bank2); g.bank2 = nullptr; }
-    if (g.agc2) { qh_qagc_destroy(g.agc2); g.agc2 = nullptr; }
-    g.fft_size = fft_size; g.data_width = data_width;
-    // the orchestration state starts like the reference's statics and globals at program start
-    g.tx_tune = 0; g.split_rxtx = 0; g.play_channel = -1; g.play_method = 0; g.sub_have = 0; g.old_split = 0; g.old_play = -1;
-    for (int i = 0; i < QuiskRx::kMaxSub; i++) { g.sub_freq[i] = 0; g.sub_mode[i] = 0; }
-    g.filt2I.clear(); g.filt2Q.clear(); g.filt2_dirty = true;
-    g.key_down = g.cw_key_down = g.active_sidetone = g.is_fdx = g.kill_audio = g.invert_spectrum = 0;
-    g.out_counter = 0.0; g.sidetone_env = 0.0; g.keyup_env = 1.0; g.sidetone_on = 0; g.play_silence = 0;
-    if (fft_size > 0 && data_width > 0) {
-        g.pan = qh_pan_create(0, 1, fft_size, data_width, (double)sample_rate, nullptr);
-        if (!g.pan) return QH_ERR_HIP;
-    }
-    return ensure_bank();
+    if (g.agc_gain_set[k] != g.agc_gain) { if (int rc = qh_qagc_set_gain(g.agc[k], -1, g.agc_gain)) return rc; g.agc_gain_set[k] = g.agc_gain; }
+    return QH_OK;
+}
+int run_agc(int k, int is_cpx, double2 *buf, int n)
+{
+    if (int rc = ensure_agc(k)) return rc;
+    if (int rc = qh_qagc_set_cpx(g.agc[k], is_cpx)) return rc;
+    return qh_qagc_process(g.agc[k], buf, n, n);
 }
 
-void qh_quisk_close(void)
+void free_all()
 {
-    std::lock_guard<std::mutex> lk(g.mtx);
-    if (g.bank) { qh_qrx_destroy(g.bank); g.bank = nullptr; }
+    for (Bank &b : g.bank) destroy_bank(b, false);
+    destroy_bank(g.mf_bank, false);
     if (g.pan) { qh_pan_destroy(g.pan); g.pan = nullptr; }
     if (g.nb) { qh_nb_destroy(g.nb); g.nb = nullptr; }
-    if (g.agc) { qh_qagc_destroy(g.agc); g.agc = nullptr; }
-    if (g.bank2) { qh_qrx_destroy(g.bank2); g.bank2 = nullptr; }
-    if (g.agc2) { qh_qagc_destroy(g.agc2); g.agc2 = nullptr; }
-    g.sample_rate = 0;
-}
-
-void qh_quisk_set_tune(int rx_tune_freq)            // set_tune, quisk.c:4702
-{
-    std::lock_guard<std::mutex> lk(g.mtx);
-    g.tune = rx_tune_freq; g.params_dirty = true;
-}
-
-void qh_quisk_set_rx_mode(int mode)                 // set_rx_mode, quisk.c:4621
-{
-    std::lock_guard<std::mutex> lk(g.mtx);
-    g.mode = mode;
-}
-
-// set_filters(filterI, filterQ, bandwidth, start_offset, nFilter = 0), quisk.c:4551
-int qh_quisk_set_filters(const double *filtI, const double *filtQ, int size, int bandwidth)
-{
-    if (size < 0 || size >= 10001 || (size > 0 && (!filtI || !filtQ)))
-        return qh::set_error(QH_ERR_INVALID, "Filter size must be less than 10001");    // MAX_FILTER_SIZE, quisk.c:4576
-    std::lock_guard<std::mutex> lk(g.mtx);
-    g.filtI.assign(filtI, filtI + size); g.filtQ.assign(filtQ, filtQ + size);
-    g.bandwidth = bandwidth; g.params_dirty = true; g.filt2_dirty = true;       // split Rx/Tx runs bank 1 with these too
-    return QH_OK;
-}
-
-void qh_quisk_set_agc(double level)                 // set_agc, quisk.c:4543
-{
-    std::lock_guard<std::mutex> lk(g.mtx);
-    g.agc_gain = level; g.params_dirty = true;
-}
-
-void qh_quisk_set_auto_notch(int on, int rit_freq)   // set_auto_notch, quisk.c:4596: the flag, and dAutoNotch(NULL, ...)
-{
-    std::lock_guard<std::mutex> lk(g.mtx);
-    g.auto_notch = on ? 1 : 0; g.rit_freq = rit_freq; g.notch_applied = -1;
-}
-
-void qh_quisk_set_noise_blanker(int level)          // set_noise_blanker, quisk.c:4605
-{
-    std::lock_guard<std::mutex> lk(g.mtx);
-    g.nb_level = level < 0 ? 0 : level;
-}
-
-int qh_quisk_get_filter_rate(void)                  // get_filter_rate(-1, 0): the rate the current Rx filter runs at
-{
-    std::lock_guard<std::mutex> lk(g.mtx);
-    if (ensure_bank()) return 0;
-    return qh_qrx_filter_rate(g.bank);
-}
-
-// ---- the second receiver bank (split Rx/Tx, played sub-receiver) -------------------------------------------------------
-static int ensure_bank2(int mode, int bandwidth, const std::vector<double> &fI, const std::vector<double> &fQ, int tune, bool filt_dirty)
-{
-    const int cls = bw_class(mode, bandwidth);
-    if (!g.bank2 || g.bank2_mode != mode || g.bank2_cls != cls) {
-        if (g.bank2) { qh_qrx_destroy(g.bank2); g.bank2 = nullptr; }
-        g.bank2 = qh_qrx_create_ex(0, 1, g.sample_rate, mode, bandwidth, &g.t, nullptr);
-        if (!g.bank2) return QH_ERR_HIP;
-        g.bank2_mode = mode; g.bank2_cls = cls; g.bank2_tune = 0x7fffffff;
-        filt_dirty = true;
-    }
-    if (g.bank2_tune != tune) { if (int rc = qh_qrx_set_tune(g.bank2, 0, tune)) return rc; g.bank2_tune = tune; }
-    if (filt_dirty) if (int rc = qh_qrx_set_filters(g.bank2, 0, fI.data(), fQ.data(), (int)fI.size())) return rc;
-    return QH_OK;
-}
-
-static int agc_run(qh_qagc *&agc, int &agc_rate, double &gain_set, int rate, int is_cpx, double *buf, int n)
-{
-    if (agc && agc_rate != rate) { qh_qagc_destroy(agc); agc = nullptr; }
-    if (!agc) {
-        agc = qh_qagc_create(0, 1, rate, 0.7, 1.0, 0, nullptr);       // struct AgcState {0.7, 0, 0}, quisk.c:2321
-        if (!agc) return QH_ERR_HIP;
-        agc_rate = rate; gain_set = -1.0;
-    }
-    if (int rc = qh_qagc_set_cpx(agc, is_cpx)) return rc;
-    if (gain_set != g.agc_gain) { if (int rc = qh_qagc_set_gain(agc, -1, g.agc_gain)) return rc; gain_set = g.agc_gain; }
-    return qh_qagc_process_host(agc, buf, n, n);
+    for (qh_qagc *&a : g.agc) if (a) { qh_qagc_destroy(a); a = nullptr; }
+    if (g.up) { qh_rat_destroy(g.up); g.up = nullptr; }
+    if (g.mf_dec) { qh_fir_destroy(g.mf_dec); g.mf_dec = nullptr; }
+    if (g.mf_fft) { qh_pan_destroy(g.mf_fft); g.mf_fft = nullptr; }
+    g.d_raw.release(); g.d_x.release(); g.d_nb.release(); g.d_o0.release(); g.d_o1.release(); g.d_mix.release(); g.d_fd.release();
+    g.d_up.release(); g.d_a.release(); g.d_b.release(); g.d_sub.release(); g.d_sub0.release(); g.d_s1.release(); g.d_mf.release();
+    g.d_mf8.release(); g.d_env.release();
+    for (auto &row : g.b2c) for (auto &bb : row) bb.release();
+    for (double2 *&h : g.fd_hist) { if (h) (void)hipFree(h); h = nullptr; }
+    if (g.d_flags) { (void)hipFree(g.d_flags); g.d_flags = nullptr; }
+    if (g.h_flags) { (void)hipHostFree(g.h_flags); g.h_flags = nullptr; }
+    g.h_in.release(); g.h_out.release(); g.h_sub1.release();
+    if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
 }
 
 // The key is down (or was a moment ago): the block is not demodulated; sidetone or silence at the playback rate take its
 // place (quisk.c:2368-2433).  Returns the number of samples written, or -1 when the block is radio sound.
-static int key_block(double *cSamples, int nSamples)
+int key_block(double *cSamples, int nSamples)
 {
     auto take = [&]() {         // the block's share of playback samples, the fraction carried over (quisk.c:2372-2375)
         g.out_counter += (double)nSamples * g.playback_rate / g.sample_rate;
@@ -288,6 +429,460 @@ static int key_block(double *cSamples, int nSamples)
     return -1;
 }
 
+// measure_freq (quisk.c:5579-5649) on the device: the decimated samples come from a receiver of their own (the main bank runs
+// its decimators and its demodulator's as ONE filter, so the 48 ksps stream between them does not exist there): wide DGT-IQ is
+// exactly tune + quisk_process_decimate.  Then HalfBand1..3 as one 293-tap /8 filter, 12000-sample blocks under the reference's
+// window through the chirp-z transform of the panadapter engine, |X| summed in fftshift order.  The peak search over +-500 Hz
+// and its three-point interpolation read the averaged spectrum back once every measure_freq_mode / 2 transforms.
+int measure_freq(const double2 *d_in, int n)
+{
+    if (int rc = ensure_bank(g.mf_bank, 9, 0, g.tune, 4, 20000)) return rc;     // wide DGT-IQ: no Rx filter (quisk.c:2143)
+    if (!g.mf_dec) {
+        double t[43];
+        qh_hb45_taps(t);
+        std::vector<double> c1(t, t + 43), c2(85, 0.0), c4(169, 0.0);
+        for (int i = 0; i < 43; i++) { c2[2 * (size_t)i] = t[i]; c4[4 * (size_t)i] = t[i]; }
+        auto conv = [](const std::vector<double> &a, const std::vector<double> &b) {
+            std::vector<double> r(a.size() + b.size() - 1, 0.0);
+            for (size_t i = 0; i < a.size(); i++) for (size_t j = 0; j < b.size(); j++) r[i + j] += a[i] * b[j];
+            return r;
+        };
+        const std::vector<double> h = conv(conv(c1, c2), c4);
+        g.mf_dec = qh_fir_create(0, 1, h.data(), nullptr, (int)h.size(), 8, QH_F64, g.stream);
+        if (!g.mf_dec) return QH_ERR_HIP;
+    }
+    if (!g.mf_fft) {
+        g.mf_fft = qh_pan_create(0, 1, kMfSize, 16, 6000.0, g.stream);
+        if (!g.mf_fft) return QH_ERR_HIP;
+        std::vector<double> w((size_t)kMfSize);
+        for (int i = 0; i < kMfSize; i++) w[(size_t)i] = 0.50 - 0.50 * std::cos(2. * M_PI * i / (kMfSize - 1));     // quisk.c:5600-5601
+        if (int rc = qh_pan_set_window(g.mf_fft, w.data())) return rc;
+        g.mf_avg.assign((size_t)kMfSize, 0.0);
+    }
+    const int cap = qh_qrx_out_count(g.mf_bank.rx, n);
+    if (int rc = g.d_mf.need((size_t)cap + 1)) return rc;
+    int nd = 0;
+    if (int rc = qh_qrx_process(g.mf_bank.rx, reinterpret_cast<const double *>(d_in), n, n, reinterpret_cast<double *>(g.d_mf.p), (long long)g.d_mf.cap, &nd)) return rc;
+    const int srate = qh_qrx_decim_rate(g.mf_bank.rx) / 8;
+    if (nd <= 0) return QH_OK;
+    const int n8cap = qh_fir_out_count(g.mf_dec, nd);
+    if (int rc = g.d_mf8.need((size_t)n8cap + 1)) return rc;
+    int n8 = 0;
+    if (int rc = qh_fir_process(g.mf_dec, g.d_mf.p, nd, nd, g.d_mf8.p, (long long)g.d_mf8.cap, &n8)) return rc;
+    // "for (i = 0; i < nSamples && index < fft_size; ...)": the transform runs when the array is full and the rest of the call is dropped
+    const int take = n8 < kMfSize - g.mf_index ? n8 : kMfSize - g.mf_index;
+    if (take > 0) if (int rc = qh_pan_feed(g.mf_fft, reinterpret_cast<const double *>(g.d_mf8.p), take, take)) return rc;
+    g.mf_index += take;
+    if (g.mf_index < kMfSize) return QH_OK;
+    g.mf_index = 0;
+    (void)qh_pan_drop_partial(g.mf_fft);
+    g.mf_count++;
+    if (g.mf_count < g.measure_mode / 2) return QH_OK;
+    g.mf_count = 0;
+    if (int rc = qh_pan_read_avg(g.mf_fft, g.mf_avg.data(), 1)) return rc;
+    const double *avg = g.mf_avg.data();
+    const int N = kMfSize;
+    double dmax = 1.e-20;
+    int ipeak = 0;
+    const int center = N / 2 - g.rit_freq * N / srate;
+    int k = 500;
+    k = k * N / srate;
+    for (int i = center - k; i <= center + k; i++)
+        if (i >= 0 && i < N && avg[i] > dmax) { dmax = avg[i]; ipeak = i; }
+    if (ipeak < 1 || ipeak > N - 2) return QH_OK;
+    const double c3 = 1.36 * (avg[ipeak + 1] - avg[ipeak - 1]) / (avg[ipeak - 1] + avg[ipeak] + avg[ipeak + 1]);
+    double freq = srate * (2 * (ipeak + c3) - N) / 2 / N;
+    freq += g.tune;
+    g.measured_frequency = freq;
+    return QH_OK;
+}
+
+// the body of quisk_process_samples behind the key handling; returns the output count or -1 (error set)
+int process_radio(double *cSamples, int nSamples)
+{
+    const int n = nSamples;
+    hipStream_t s = g.stream;
+    // ---- the block goes to the device once
+    if (g.h_in.need((size_t)n * 2) || g.d_raw.need((size_t)n)) return -1;
+    std::memcpy(g.h_in.p, cSamples, (size_t)n * 2 * sizeof(double));
+    if (hipMemcpyAsync(g.d_raw.p, g.h_in.p, (size_t)n * 16, hipMemcpyHostToDevice, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
+    const double2 *cur = g.d_raw.p;
+    // ---- AddTestTone and the inversion (quisk.c:2438-2446)
+    if (g.tone_on || g.invert_spectrum) {
+        if (g.d_x.need((size_t)n)) return -1;
+        const int kind = !g.tone_on ? -1 : g.mode == 4 ? 1 : is_fm_mode(g.mode) ? 2 : 0;
+        const u64 da = turns_step(1000.0, (double)g.sample_rate);
+        hipLaunchKernelGGL(ps_prep_kernel, dim3(grid_for(n)), dim3(256), 0, s, cur, g.d_x.p, n, kind, g.tone_phase, g.tone_step, g.audio_phase, da,
+                           g.invert_spectrum);
+        if (g.tone_on) {
+            g.tone_phase += g.tone_step * (u64)n;
+            if (kind >= 1) g.audio_phase += da * (u64)n;
+        }
+        cur = g.d_x.p;
+    }
+    // ---- NoiseBlanker, not while the key is down (full duplex reaches this point with the key down; quisk.c:2448-2449)
+    if (!g.key_down && (g.nb_level > 0 || g.nb)) {
+        if (!g.nb && !(g.nb = qh_nb_create(0, 1, g.sample_rate, s))) return -1;
+        if (qh_nb_set_level(g.nb, g.nb_level) || g.d_nb.need((size_t)n)) return -1;
+        if (qh_nb_process(g.nb, cur, n, g.d_nb.p, n, n)) return -1;
+        cur = g.d_nb.p;
+    }
+    // ---- the FFT ring producer (quisk.c:2454-2475)
+    if (g.pan && qh_pan_feed(g.pan, reinterpret_cast<const double *>(cur), n, n)) return -1;
+    // ---- bank 0: tune, decimate, demodulate
+    Bank &b0 = g.bank[0];
+    if (ensure_bank(b0, g.mode, 0, g.tune, 0)) return -1;
+    if (g.notch_reset || b0.notch_applied != g.auto_notch) {     // set_auto_notch (or a fresh bank) starts the notch over
+        if (g.mode != 9 /* DGT-IQ has no notch */) if (qh_qrx_set_auto_notch(b0.rx, g.auto_notch, g.rit_freq)) return -1;
+        b0.notch_applied = g.auto_notch; g.notch_reset = false;
+    }
+    const int cap0 = qh_qrx_out_count(b0.rx, n);
+    if (g.d_o0.need((size_t)cap0 + 1)) return -1;
+    int n0 = 0;
+    if (qh_qrx_process(b0.rx, reinterpret_cast<const double *>(cur), n, n, reinterpret_cast<double *>(g.d_o0.p), (long long)g.d_o0.cap, &n0)) return -1;
+    const int decim_srate = qh_qrx_decim_rate(b0.rx);
+    if (qh_qrx_ssb_squelch_planned(b0.rx, 0)) g.ssb_planned = true;
+    if (g.measure_mode) {                                        // quisk.c:2527-2528 (the same tuned and decimated samples)
+        if (measure_freq(cur, n)) return -1;
+    }
+    const bool stereo = g.mode == 9;                             // DGT-IQ is already stereo (quisk.c:2534)
+    const int *flag0 = qh_qrx_squelch_flag(b0.rx, 0), *flag1 = nullptr;
+    const int *flag_real = nullptr, *flag_imag = nullptr;
+    double2 *audio = g.d_o0.p;
+    int na = n0;
+    // ---- a second channel: the same receiver on the transmit frequency, or the played sub-receiver (quisk.c:2537-2621)
+    int second = 0;                                              // 1 split, 2 played sub-receiver
+    if (!stereo && g.split_rxtx) second = 1;
+    else if (!stereo && g.play_channel >= 0 && g.sub_have[g.play_channel] == n) second = 2;
+    if (second) {
+        Bank &b1 = g.bank[1];
+        const double2 *src2;
+        if (second == 1) {
+            if (ensure_bank(b1, g.mode, 0, g.tx_tune + g.rit_freq, 1)) return -1;
+            src2 = g.d_raw.p;                                    // orig_cSamples: copied ahead of the test tone, the inversion and the blanker
+        } else {
+            const int pc = g.play_channel;
+            if (ensure_bank(b1, g.sub_mode[pc], 1, g.sub_freq[pc], 2)) return -1;
+            if (g.d_sub.need((size_t)n)) return -1;
+            if (hipMemcpyAsync(g.d_sub.p, g.sub_samples[pc].data(), (size_t)n * 16, hipMemcpyHostToDevice, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
+            if (hipStreamSynchronize(s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }     // pageable source
+            src2 = g.d_sub.p;
+        }
+        if (g.ssb_planned) (void)qh_qrx_ssb_squelch_planned(b1.rx, 1);
+        const int cap1 = qh_qrx_out_count(b1.rx, n);
+        if (g.d_o1.need((size_t)cap1 + 1)) return -1;
+        int n1 = 0;
+        if (qh_qrx_process(b1.rx, reinterpret_cast<const double *>(src2), n, n, reinterpret_cast<double *>(g.d_o1.p), (long long)g.d_o1.cap, &n1)) return -1;
+        flag1 = qh_qrx_squelch_flag(b1.rx, 0);
+        if (qh_qrx_ssb_squelch_planned(b1.rx, 0)) g.ssb_planned = true;
+        // which stream is the real (left) output
+        int sel_re = 0, sel_im = 1;
+        if (second == 1) {
+            switch (g.split_rxtx) {
+            default:
+            case 1: if (!(g.tx_tune < g.tune)) { sel_re = 1; sel_im = 0; } break;       // higher frequency is real
+            case 2: if (!(g.tx_tune >= g.tune)) { sel_re = 1; sel_im = 0; } break;      // lower frequency is real
+            case 3: sel_re = sel_im = 0; break;
+            case 4: sel_re = sel_im = 1; break;
+            }
+        } else {
+            switch (g.play_method) {
+            default:
+            case 0: sel_re = sel_im = 1; break;
+            case 1: sel_re = 0; sel_im = 1; break;
+            case 2: sel_re = 1; sel_im = 0; break;
+            }
+        }
+        flag_real = sel_re ? flag1 : flag0;
+        flag_imag = sel_im ? flag1 : flag0;
+        // Buffer2Chan(dsamples, nSamples, dsamples2, n)
+        int nout;
+        if (g.nbuf1 == 0 && g.nbuf2 == 0 && n0 == n1) {
+            nout = n0;
+            if (g.d_mix.need((size_t)nout + 1)) return -1;
+            if (nout > 0)
+                hipLaunchKernelGGL(ps_join_kernel, dim3(grid_for(nout)), dim3(256), 0, s, (const double *)nullptr, 0, (const double2 *)g.d_o0.p,
+                                   (const double *)nullptr, 0, (const double2 *)g.d_o1.p, nout, sel_re, sel_im, g.d_mix.p);
+        } else {
+            if (n0 + g.nbuf1 >= kBuf2Chan || n1 + g.nbuf2 >= kBuf2Chan) g.nbuf1 = g.nbuf2 = 0;      // overflow: the reference starts over
+            const int t1 = g.nbuf1 + n0, t2 = g.nbuf2 + n1;
+            nout = t1 <= t2 ? t1 : t2;
+            const int keep1 = t1 - nout, keep2 = t2 - nout, nc = g.b2c_cur;
+            if (g.d_mix.need((size_t)nout + 1) || g.b2c[0][nc ^ 1].need((size_t)keep1 + 1) || g.b2c[1][nc ^ 1].need((size_t)keep2 + 1)) return -1;
+            if (nout > 0)
+                hipLaunchKernelGGL(ps_join_kernel, dim3(grid_for(nout)), dim3(256), 0, s, (const double *)g.b2c[0][nc].p, g.nbuf1,
+                                   (const double2 *)g.d_o0.p, (const double *)g.b2c[1][nc].p, g.nbuf2, (const double2 *)g.d_o1.p, nout, sel_re,
+                                   sel_im, g.d_mix.p);
+            const int kmax = keep1 > keep2 ? keep1 : keep2;
+            if (kmax > 0)
+                hipLaunchKernelGGL(ps_b2c_keep_kernel, dim3(grid_for(kmax)), dim3(256), 0, s, (const double *)g.b2c[0][nc].p, g.nbuf1,
+                                   (const double2 *)g.d_o0.p, keep1, g.b2c[0][nc ^ 1].p, (const double *)g.b2c[1][nc].p, g.nbuf2,
+                                   (const double2 *)g.d_o1.p, keep2, g.b2c[1][nc ^ 1].p, nout);
+            g.nbuf1 = keep1; g.nbuf2 = keep2; g.b2c_cur = nc ^ 1;
+        }
+        audio = g.d_mix.p; na = nout;
+    } else if (!stereo) {
+        flag_real = flag_imag = flag0;                           // monophonic sound on both channels: the bank wrote (d, d)
+    }
+    // ---- sub-receiver 1 on a digital output device (quisk.c:2630-2651)
+    g.sub1_n = 0;
+    {
+        const int m = g.sub_mode[0];
+        if (g.multirx_count > 0 && (m == 7 || m == 8 || m == 9 || m == 13) && g.sub_rx1_driver && g.sub_have[0] == n) {
+            Bank &b2 = g.bank[2];
+            if (ensure_bank(b2, m, 2, g.sub_freq[0], 3)) return -1;
+            if (g.d_sub0.need((size_t)n)) return -1;
+            if (hipMemcpyAsync(g.d_sub0.p, g.sub_samples[0].data(), (size_t)n * 16, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
+            const int cap2 = qh_qrx_out_count(b2.rx, n);
+            if (g.d_s1.need((size_t)cap2 + 1)) return -1;
+            int n2 = 0;
+            if (qh_qrx_process(b2.rx, reinterpret_cast<const double *>(g.d_sub0.p), n, n, reinterpret_cast<double *>(g.d_s1.p), (long long)g.d_s1.cap, &n2)) return -1;
+            if (n2 > 0) {
+                if (run_agc(2, m == 9 ? 1 : 0, g.d_s1.p, n2)) return -1;    // the bank wrote (d, d) for the mono modes; process_agc(.., 0) scales both parts alike
+                if (g.h_sub1.need((size_t)n2 * 2)) return -1;
+                if (hipMemcpyAsync(g.h_sub1.p, g.d_s1.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "download failed"); return -1; }
+            }
+            g.sub1_n = n2;
+        }
+    }
+    // ---- cFracDecim to 48 ksps (quisk.c:2654-2659)
+    if (decim_srate != 48000 && na > 0) {
+        const double fdecim = decim_srate / 48000.0, step = fdecim - 1;
+        // outputs m with input index m + floor(d0 + m step) - 1 <= na - 1
+        int M = (int)(((double)na + 1.0 - g.fd_dindex) / fdecim) + 2;
+        if (M < 0) M = 0;
+        auto idx = [&](int m) { return m + (int)std::floor(std::fma(step, (double)m, g.fd_dindex)) - 1; };
+        while (M > 0 && idx(M - 1) > na - 1) M--;
+        while (idx(M) <= na - 1) M++;
+        if (g.d_fd.need((size_t)M + 1)) return -1;
+        if (M > 0) hipLaunchKernelGGL(ps_fracdecim_kernel, dim3(grid_for(M)), dim3(256), 0, s, (const double2 *)audio, (const double2 *)g.fd_hist[g.fd_cur], M,
+                                      g.fd_dindex, step, g.d_fd.p);
+        hipLaunchKernelGGL(ps_fd_hist_kernel, dim3(1), dim3(64), 0, s, (const double2 *)audio, na, (const double2 *)g.fd_hist[g.fd_cur], g.fd_hist[g.fd_cur ^ 1]);
+        g.fd_cur ^= 1;
+        g.fd_dindex = std::fma(step, (double)M, g.fd_dindex) + (double)M - (double)na;        // dindex as the next call's first sample finds it
+        audio = g.d_fd.p; na = M;
+    }
+    // ---- the WDSP hand-off (quisk.c:2660-2661): fexchange0 takes host pointers, so this is the one round trip of the chain
+    if (qh_wdsp_shim_in_size(0) <= 0) (void)wdspFexchange0(0, nullptr, 0);      // not in use: the shim only rewinds its ring (quisk_wdsp.c:32-37)
+    if (const int in_size = qh_wdsp_shim_in_size(0); in_size > 0 && na > 0) {
+        if (g.h_out.need((size_t)(na + in_size) * 2)) return -1;
+        if (hipMemcpyAsync(g.h_out.p, audio, (size_t)na * 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            qh::set_error(QH_ERR_HIP, "download failed"); return -1;
+        }
+        const int nw = wdspFexchange0(0, g.h_out.p, na);
+        if (g.d_fd.need((size_t)nw + 1)) return -1;              // (d_fd may hold `audio`; it has been copied out)
+        if (nw > 0 && hipMemcpyAsync(g.d_fd.p, g.h_out.p, (size_t)nw * 16, hipMemcpyHostToDevice, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
+        if (hipStreamSynchronize(s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
+        audio = g.d_fd.p; na = nw;
+    }
+    // ---- interpolation to the playback rate (quisk.c:2663-2682)
+    if (g.up && na > 0) {
+        const int nu = qh_rat_out_count(g.up, na);
+        if (g.d_up.need((size_t)nu + 1)) return -1;
+        int got = 0;
+        if (qh_rat_process(g.up, audio, na, na, g.d_up.p, (long long)g.d_up.cap, &got)) return -1;
+        audio = g.d_up.p; na = got;
+    }
+    // ---- AGC (quisk.c:2686-2702)
+    if (na > 0) {
+        if (stereo) {
+            if (run_agc(0, 1, audio, na)) return -1;
+        } else if (g.split_rxtx || g.play_channel >= 0) {        // separate AGC for left and right
+            if (g.d_a.need((size_t)na) || g.d_b.need((size_t)na)) return -1;
+            hipLaunchKernelGGL(ps_split_kernel, dim3(grid_for(na)), dim3(256), 0, s, (const double2 *)audio, na, g.d_a.p, g.d_b.p);
+            if (run_agc(0, 0, g.d_a.p, na) || run_agc(1, 0, g.d_b.p, na)) return -1;
+            hipLaunchKernelGGL(ps_merge_kernel, dim3(grid_for(na)), dim3(256), 0, s, (const double2 *)g.d_a.p, (const double2 *)g.d_b.p, na, audio);
+        } else {
+            if (run_agc(0, 0, audio, na)) return -1;
+        }
+    }
+    // ---- kill_audio / squelch / key-up envelope (quisk.c:2712-2738)
+    int env_n = 0;
+    if (g.keyup_env < 1.0 && na > 0) {
+        const double di = 1. / (g.playback_rate * 5e-3);
+        std::vector<double> env;
+        for (int i = 0; i < na; i++) {
+            g.keyup_env += di;
+            if (g.keyup_env > 1.0) { g.keyup_env = 1.0; break; }
+            env.push_back(g.keyup_env);
+        }
+        env_n = (int)env.size();
+        if (env_n > 0) {
+            if (g.d_env.need((size_t)env_n)) return -1;
+            if (hipMemcpyAsync(g.d_env.p, env.data(), (size_t)env_n * 8, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                qh::set_error(QH_ERR_HIP, "upload failed"); return -1;
+            }
+        }
+    }
+    hipLaunchKernelGGL(ps_epilogue_kernel, dim3(grid_for(na)), dim3(256), 0, s, audio, na, flag_real, flag_imag, g.kill_audio, (const double *)g.d_env.p,
+                       env_n, g.d_flags);
+    if (g.h_out.need((size_t)(na > 0 ? na : 1) * 2)) return -1;
+    if (na > 0 && hipMemcpyAsync(g.h_out.p, audio, (size_t)na * 16, hipMemcpyDeviceToHost, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "download failed"); return -1; }
+    if (hipMemcpyAsync(g.h_flags, g.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "download failed"); return -1; }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "qh_quisk_process_samples: the device chain failed"); return -1; }
+    if (na > 0) std::memcpy(cSamples, g.h_out.p, (size_t)na * 2 * sizeof(double));
+    g.squelch_real = g.h_flags[0]; g.squelch_imag = g.h_flags[1];
+    if (g.sub1_n > 0) g.sub1_out.assign(g.h_sub1.p, g.h_sub1.p + 2 * (size_t)g.sub1_n);
+    return na;
+}
+
+}  // namespace
+
+extern "C" {
+
+// quisk_sound_state.sample_rate and .playback_rate (open_sound, quisk.c:4106) + the filters.h tables (data, passed in like to
+// qh_qrx_create_ex) + record_app's fft_size and data_width (0, 0: no panadapter).
+int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *tables, int fft_size, int data_width)
+{
+    static const int len[13] = { 98, 147, 245, 50, 36, 186, 309, 125, 55, 114, 136, 174, 189 };
+    if (sample_rate <= 0 || !tables) return qh::set_error(QH_ERR_INVALID, "qh_quisk_open: bad arguments");
+    const int ratio = playback_rate / 48000;
+    if (playback_rate <= 0 || playback_rate % 48000 || (ratio != 1 && ratio != 2 && ratio != 4 && ratio != 8))
+        return qh::set_error(QH_ERR_UNSUPPORTED, "Failure in quisk.c in integer interpolation: playback rate %d is not 48000 x 1, 2, 4 or 8 (quisk.c:2664-2681)",
+                             playback_rate);
+    std::lock_guard<std::mutex> lk(g.mtx);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return qh::set_error(QH_ERR_NO_DEVICE, "no HIP device (libquiskhip has no CPU fallback)");
+    QH_HIP(hipSetDevice(0));
+    free_all();
+    const double *src[13] = { tables->f48dec24, tables->f144d3, tables->f240d5, tables->audio24p4, tables->audio24p6, tables->lp48,
+                              tables->fmhp, tables->f300d5, tables->sdriq53, tables->sdriq111, tables->sdriq133, tables->sdriq167,
+                              tables->sdriq185 };
+    const double *dst[13];
+    for (int i = 0; i < 13; i++) {
+        if (src[i]) { g.tables[i].assign(src[i], src[i] + len[i]); dst[i] = g.tables[i].data(); }
+        else { g.tables[i].clear(); dst[i] = nullptr; }
+    }
+    g.t.f48dec24 = dst[0]; g.t.f144d3 = dst[1]; g.t.f240d5 = dst[2]; g.t.audio24p4 = dst[3]; g.t.audio24p6 = dst[4];
+    g.t.lp48 = dst[5]; g.t.fmhp = dst[6]; g.t.f300d5 = dst[7]; g.t.sdriq53 = dst[8]; g.t.sdriq111 = dst[9];
+    g.t.sdriq133 = dst[10]; g.t.sdriq167 = dst[11]; g.t.sdriq185 = dst[12];
+    g.have_tables = true;
+    g.sample_rate = sample_rate; g.playback_rate = playback_rate;
+    g.fft_size = fft_size; g.data_width = data_width;
+    QH_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    // the orchestration state starts like the reference's statics and globals at program start
+    g.tx_tune = 0; g.split_rxtx = 0; g.play_channel = -1; g.play_method = 0; g.old_split = 0; g.old_play = 0;
+    for (int i = 0; i < QuiskRx::kMaxSub; i++) { g.sub_freq[i] = 0; g.sub_mode[i] = 0; g.sub_have[i] = 0; }
+    g.multirx_count = 0; g.sub_rx1_driver = 0;
+    for (int i = 1; i < 3; i++) { g.filtI[i].clear(); g.filtQ[i].clear(); }
+    for (u64 &p : g.phase) p = 0;
+    g.key_down = g.cw_key_down = g.active_sidetone = g.is_fdx = g.kill_audio = g.invert_spectrum = 0;
+    g.out_counter = 0.0; g.sidetone_env = 0.0; g.keyup_env = 1.0; g.sidetone_on = 0; g.play_silence = 0;
+    g.sidetone_vec = 2.2e9;
+    g.tone_on = false; g.tone_phase = 0; g.audio_phase = 0;
+    g.nbuf1 = g.nbuf2 = 0; g.b2c_cur = 0;
+    g.fd_dindex = 1.0; g.fd_cur = 0;
+    g.measure_mode = 0; g.mf_index = 0; g.mf_count = 0; g.measured_frequency = 0.0;
+    g.sub1_n = 0; g.squelch_real = g.squelch_imag = 0;
+    g.squelch_level = -999.0; g.ssb_squelch_enabled = 0; g.ssb_squelch_level = 0; g.ssb_planned = false;
+    for (int i = 0; i < 2; i++) {
+        QH_HIP(hipMalloc((void **)&g.fd_hist[i], 3 * sizeof(double2)));
+        QH_HIP(hipMemset(g.fd_hist[i], 0, 3 * sizeof(double2)));
+    }
+    QH_HIP(hipMalloc((void **)&g.d_flags, 2 * sizeof(int)));
+    QH_HIP(hipMemset(g.d_flags, 0, 2 * sizeof(int)));
+    QH_HIP(hipHostMalloc((void **)&g.h_flags, 2 * sizeof(int), hipHostMallocDefault));
+    if (int rc = g.d_env.need(64)) return rc;
+    for (auto &row : g.b2c) for (auto &bb : row) if (int rc = bb.need(kBuf2Chan)) return rc;
+    if (fft_size > 0 && data_width > 0) {
+        g.pan = qh_pan_create(0, 1, fft_size, data_width, (double)sample_rate, g.stream);
+        if (!g.pan) return QH_ERR_HIP;
+    }
+    g.up_ratio = ratio;
+    if (ratio > 1) {
+        // HalfBand7 (.. 8, 9) chained (quisk.c:2666-2677) = one polyphase interpolator: g = h * up2(h) * up4(h), gain 2 per stage
+        double t[43];
+        qh_hb45_taps(t);                                        // t[2k] = coef[k]
+        std::vector<double> h45(45, 0.0);
+        for (int k = 0; k < 11; k++) { h45[(size_t)(2 * k + 1)] = t[2 * k]; h45[(size_t)(43 - 2 * k)] = t[2 * k]; }
+        h45[22] = 0.5;
+        auto up = [](const std::vector<double> &a, int f) {
+            std::vector<double> r((a.size() - 1) * (size_t)f + 1, 0.0);
+            for (size_t i = 0; i < a.size(); i++) r[i * (size_t)f] = a[i];
+            return r;
+        };
+        auto conv = [](const std::vector<double> &a, const std::vector<double> &b) {
+            std::vector<double> r(a.size() + b.size() - 1, 0.0);
+            for (size_t i = 0; i < a.size(); i++) for (size_t j = 0; j < b.size(); j++) r[i + j] += a[i] * b[j];
+            return r;
+        };
+        std::vector<double> taps = h45;                         // the stage that runs at the highest rate is applied last
+        if (ratio == 4) taps = conv(up(h45, 2), h45);
+        if (ratio == 8) taps = conv(conv(up(h45, 4), up(h45, 2)), h45);
+        g.up = qh_rat_create(0, 1, taps.data(), (int)taps.size(), ratio, 1, QH_F64, g.stream);
+        if (!g.up) return QH_ERR_HIP;
+    }
+    if (g.size_filter == 0 && !g.filtI[0].empty()) g.size_filter = (int)g.filtI[0].size();
+    g.filt_epoch++;
+    return ensure_bank(g.bank[0], g.mode, 0, g.tune, 0);
+}
+
+void qh_quisk_close(void)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    if (g.sample_rate) (void)hipSetDevice(0);
+    free_all();
+    g.sample_rate = 0;
+}
+
+void qh_quisk_set_tune(int rx_tune_freq)            // set_tune, quisk.c:4702
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.tune = rx_tune_freq;
+}
+
+void qh_quisk_set_rx_mode(int mode)                 // set_rx_mode, quisk.c:4621
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.mode = mode;
+}
+
+// set_filters(filterI, filterQ, bandwidth, start_offset, nFilter), quisk.c:4551: the taps of filter set nFilter, its bandwidth,
+// and the ONE global sizeFilter that every bank's filter then runs with
+int qh_quisk_set_filters_n(const double *filtI, const double *filtQ, int size, int bandwidth, int nFilter)
+{
+    if (size < 0 || size >= 10001 || (size > 0 && (!filtI || !filtQ)))
+        return qh::set_error(QH_ERR_INVALID, "Filter size must be less than 10001");    // MAX_FILTER_SIZE, quisk.c:4576
+    if (nFilter < 0 || nFilter > 2) return qh::set_error(QH_ERR_INVALID, "nFilter must be 0, 1 or 2 (MAX_RX_FILTERS, quisk.c:127)");
+    std::lock_guard<std::mutex> lk(g.mtx);
+    std::vector<double> &fI = g.filtI[nFilter], &fQ = g.filtQ[nFilter];
+    if (fI.size() < (size_t)size) { fI.resize((size_t)size, 0.0); fQ.resize((size_t)size, 0.0); }    // entries beyond `size` keep what earlier calls left
+    for (int i = 0; i < size; i++) { fI[(size_t)i] = filtI[i]; fQ[(size_t)i] = filtQ[i]; }
+    g.filt_bw[nFilter] = bandwidth;
+    g.size_filter = size;
+    g.filt_epoch++;
+    return QH_OK;
+}
+int qh_quisk_set_filters(const double *filtI, const double *filtQ, int size, int bandwidth) { return qh_quisk_set_filters_n(filtI, filtQ, size, bandwidth, 0); }
+int qh_quisk_set_filters2(const double *filtI, const double *filtQ, int size, int bandwidth) { return qh_quisk_set_filters_n(filtI, filtQ, size, bandwidth, 1); }
+
+void qh_quisk_set_agc(double level)                 // set_agc, quisk.c:4543
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.agc_gain = level;
+}
+
+void qh_quisk_set_auto_notch(int on, int rit_freq)   // set_auto_notch, quisk.c:4596: the flag, and dAutoNotch(NULL, ...)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.auto_notch = on ? 1 : 0; g.rit_freq = rit_freq; g.notch_reset = true;
+}
+
+void qh_quisk_set_noise_blanker(int level)          // set_noise_blanker, quisk.c:4605
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.nb_level = level < 0 ? 0 : level;
+}
+
+int qh_quisk_get_filter_rate(void)                  // get_filter_rate(-1, 0): the rate the current Rx filter runs at
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    if (!g.sample_rate || !g.have_tables) { qh::set_error(QH_ERR_INVALID, "qh_quisk_open has not been called"); return 0; }
+    if (ensure_bank(g.bank[0], g.mode, 0, g.tune, 0)) return 0;
+    return qh_qrx_filter_rate(g.bank[0].rx);
+}
+
 // quisk_process_samples (quisk.c:2289): in place; returns the number of output samples at the playback rate
 // (the buffer must have room for them: SAMP_BUFFER_SIZE in the reference); nSamples <= 0 is returned unchanged.
 int qh_quisk_process_samples(double *cSamples, int nSamples)
@@ -295,97 +890,19 @@ int qh_quisk_process_samples(double *cSamples, int nSamples)
     if (nSamples <= 0) return nSamples;                                  // quisk.c:2336-2337
     if (!cSamples) { qh::set_error(QH_ERR_INVALID, "null sample buffer"); return 0; }
     std::lock_guard<std::mutex> lk(g.mtx);
-    if (ensure_bank()) return 0;
-    {
-        const int kb = key_block(cSamples, nSamples);
-        if (kb >= 0) { g.sub_have = 0; return kb; }
-    }
-    if (g.invert_spectrum)                                               // quisk.c:2441-2446
-        for (int i = 0; i < nSamples; i++) cSamples[2 * i + 1] = -cSamples[2 * i + 1];
-    if (g.nb_level > 0 || g.nb) {                                        // NoiseBlanker(cSamples, nSamples), quisk.c:2448-2449
-        if (!g.nb && !(g.nb = qh_nb_create(0, 1, g.sample_rate, nullptr))) return 0;
-        if (qh_nb_set_level(g.nb, g.nb_level)) return 0;
-        g.nb_out.resize((size_t)nSamples * 2);
-        if (qh_nb_process_host(g.nb, cSamples, nSamples, g.nb_out.data(), nSamples, nSamples)) return 0;
-        std::memcpy(cSamples, g.nb_out.data(), (size_t)nSamples * 2 * sizeof(double));
-    }
-    if (g.pan && qh_pan_feed_host(g.pan, cSamples, nSamples, nSamples)) return 0;       // the FFT ring producer, quisk.c:2454-2475
-    const int cap = qh_qrx_out_count(g.bank, nSamples);
-    g.out.resize((size_t)(cap > 0 ? cap : 1) * 2);
-    int got = 0;
-    if (qh_qrx_process_host(g.bank, cSamples, nSamples, nSamples, g.out.data(), cap > 0 ? cap : 1, &got)) return 0;
-    const int rate = qh_qrx_decim_rate(g.bank);
-    const bool stereo_mode = g.mode == 9 || g.mode == 6;                 // DGT-IQ, EXT: already stereo (quisk.c:2536,2687)
-    // ---- a second channel: the same receiver on the transmit frequency, or the played sub-receiver (quisk.c:2539-2621)
-    bool two = false;
-    if (!stereo_mode && g.split_rxtx) {
-        if (ensure_bank2(g.mode, g.bandwidth, g.filtI, g.filtQ, g.tx_tune + g.rit_freq, g.filt2_dirty || !g.old_split)) return 0;
-        two = true;
-    } else if (!stereo_mode && g.play_channel >= 0 && g.sub_have == nSamples) {
-        const int pc = g.play_channel;
-        if (g.filt2I.empty()) { qh::set_error(QH_ERR_INVALID, "played sub-receiver without set_filters(..., nFilter = 1)"); return 0; }
-        if (ensure_bank2(g.sub_mode[pc], g.bandwidth2, g.filt2I, g.filt2Q, g.sub_freq[pc], g.filt2_dirty || g.old_play != pc)) return 0;
-        two = true;
-    }
-    g.filt2_dirty = false;
+    if (!g.sample_rate || !g.have_tables) { qh::set_error(QH_ERR_INVALID, "qh_quisk_open has not been called"); return 0; }
+    if (hipSetDevice(0) != hipSuccess) { qh::set_error(QH_ERR_NO_DEVICE, "no HIP device (libquiskhip has no CPU fallback)"); return 0; }
+    // quisk.c:2360-2367: a new split or another play channel starts Buffer2Chan over -- ahead of the key handling
+    if (g.split_rxtx && !g.old_split) g.nbuf1 = g.nbuf2 = 0;
+    if (g.play_channel != g.old_play) g.nbuf1 = g.nbuf2 = 0;
     g.old_split = g.split_rxtx; g.old_play = g.play_channel;
-    if (two) {
-        const double *src2 = g.split_rxtx ? cSamples : g.sub_samples.data();
-        g.out2.resize((size_t)(cap > 0 ? cap : 1) * 2);
-        int got2 = 0;
-        if (qh_qrx_process_host(g.bank2, src2, nSamples, nSamples, g.out2.data(), cap > 0 ? cap : 1, &got2)) return 0;
-        if (got2 < got) got = got2;             // (Buffer2Chan, quisk.c:1577-1611: the banks here return equal counts)
-        // which stream is the real (left) output
-        int first_is_real = 1, both = 0;        // both: 1 = bank 0 on both channels, 2 = bank 1 on both
-        if (g.split_rxtx) {
-            switch (g.split_rxtx) {
-            default:
-            case 1: first_is_real = g.tx_tune < g.tune; break;                 // higher frequency is real
-            case 2: first_is_real = g.tx_tune >= g.tune; break;                // lower frequency is real
-            case 3: both = 1; break;
-            case 4: both = 2; break;
-            }
-        } else {
-            switch (g.play_method) {
-            default:
-            case 0: both = 2; break;
-            case 1: first_is_real = 1; break;
-            case 2: first_is_real = 0; break;
-            }
-        }
-        for (int i = 0; i < got; i++) {
-            const double d = g.out[2 * (size_t)i], d2 = g.out2[2 * (size_t)i];
-            const double re = both == 1 ? d : both == 2 ? d2 : first_is_real ? d : d2;
-            const double im = both == 1 ? d : both == 2 ? d2 : first_is_real ? d2 : d;
-            g.out[2 * (size_t)i] = re; g.out[2 * (size_t)i + 1] = im;
-        }
+    int out = key_block(cSamples, nSamples);
+    if (out < 0) {
+        out = process_radio(cSamples, nSamples);
+        if (out < 0) out = 0;
     }
-    g.sub_have = 0;
-    // ---- AGC (quisk.c:2686-2702)
-    if (g.agc_on && got > 0) {
-        if (stereo_mode) {
-            if (agc_run(g.agc, g.agc_rate, g.agc_gain_set, rate, 1, g.out.data(), got)) return 0;
-        } else if (g.split_rxtx || g.play_channel >= 0) {        // separate AGC for left and right
-            g.chan_a.assign((size_t)got * 2, 0.0); g.chan_b.assign((size_t)got * 2, 0.0);
-            for (int i = 0; i < got; i++) { g.chan_a[2 * (size_t)i] = g.out[2 * (size_t)i]; g.chan_b[2 * (size_t)i] = g.out[2 * (size_t)i + 1]; }
-            if (agc_run(g.agc, g.agc_rate, g.agc_gain_set, rate, 0, g.chan_a.data(), got)) return 0;
-            if (agc_run(g.agc2, g.agc2_rate, g.agc2_gain_set, rate, 0, g.chan_b.data(), got)) return 0;
-            for (int i = 0; i < got; i++) { g.out[2 * (size_t)i] = g.chan_a[2 * (size_t)i]; g.out[2 * (size_t)i + 1] = g.chan_b[2 * (size_t)i]; }
-        } else {
-            if (agc_run(g.agc, g.agc_rate, g.agc_gain_set, rate, 0, g.out.data(), got)) return 0;
-        }
-    }
-    if (g.kill_audio) std::memset(g.out.data(), 0, (size_t)got * 2 * sizeof(double));       // quisk.c:2712-2716
-    if (g.keyup_env < 1.0) {                                             // raise the volume slowly after the key goes up, quisk.c:2729-2738
-        const double di = 1.0 / (g.playback_rate * 5e-3);
-        for (int i = 0; i < got; i++) {
-            g.keyup_env += di;
-            if (g.keyup_env > 1.0) { g.keyup_env = 1.0; break; }
-            g.out[2 * (size_t)i] *= g.keyup_env; g.out[2 * (size_t)i + 1] *= g.keyup_env;
-        }
-    }
-    std::memcpy(cSamples, g.out.data(), (size_t)got * 2 * sizeof(double));
-    return got;
+    for (int &h : g.sub_have) h = 0;
+    return out;
 }
 
 // ---- the setters of the orchestration state (names after the QS calls they mirror)
@@ -395,28 +912,31 @@ void qh_quisk_set_multirx_play_channel(int ch) { std::lock_guard<std::mutex> lk(
 void qh_quisk_set_multirx_play_method(int m) { std::lock_guard<std::mutex> lk(g.mtx); g.play_method = m; }                 // quisk.c:4846
 void qh_quisk_set_multirx_freq(int index, int freq) { std::lock_guard<std::mutex> lk(g.mtx); if (index >= 0 && index < QuiskRx::kMaxSub) g.sub_freq[index] = freq; }   // quisk.c:4826
 void qh_quisk_set_multirx_mode(int index, int mode) { std::lock_guard<std::mutex> lk(g.mtx); if (index >= 0 && index < QuiskRx::kMaxSub) g.sub_mode[index] = mode; }   // quisk.c:4836
-// the played sub-receiver's samples for the coming qh_quisk_process_samples call (the reference's sample source fills
-// multirx_cSamples[index] with as many samples as the main receiver gets)
+void qh_quisk_set_multirx_count(int n) { std::lock_guard<std::mutex> lk(g.mtx); g.multirx_count = n; }                     // quisk_multirx_count
+void qh_quisk_set_sub_rx1_output(int on) { std::lock_guard<std::mutex> lk(g.mtx); g.sub_rx1_driver = on; }                 // quiskPlaybackDevices[QUISK_INDEX_SUB_RX1]->driver
+// a sub-receiver's samples for the coming qh_quisk_process_samples call (the reference's sample source fills
+// multirx_cSamples[index] with as many samples as the main receiver gets); kept for the played one and for sub-receiver 1
 int qh_quisk_multirx_samples(int index, const double *cSamples, int nSamples)
 {
     if (!cSamples || nSamples <= 0) return qh::set_error(QH_ERR_INVALID, "qh_quisk_multirx_samples: no samples");
     std::lock_guard<std::mutex> lk(g.mtx);
-    if (index != g.play_channel) return QH_OK;      // only the played sub-receiver is demodulated on this path
-    g.sub_samples.assign(cSamples, cSamples + 2 * (size_t)nSamples);
-    g.sub_have = nSamples;
+    if (index < 0 || index >= QuiskRx::kMaxSub) return QH_OK;
+    if (index != g.play_channel && index != 0) return QH_OK;    // only these two are demodulated on this path
+    g.sub_samples[index].assign(cSamples, cSamples + 2 * (size_t)nSamples);
+    g.sub_have[index] = nSamples;
     return QH_OK;
 }
-// set_filters(filterI, filterQ, bandwidth, start_offset, nFilter = 1): the played sub-receiver's filter (quisk.c:4551)
-int qh_quisk_set_filters2(const double *filtI, const double *filtQ, int size, int bandwidth)
+// what play_sound_interface(quiskPlaybackDevices[QUISK_INDEX_SUB_RX1], ...) was handed in the last call (quisk.c:2651);
+// returns its length (copies at most `cap` samples)
+int qh_quisk_sub_rx1_audio(double *cSamples, int cap)
 {
-    if (size <= 0 || size >= 10001 || !filtI || !filtQ) return qh::set_error(QH_ERR_INVALID, "Filter size must be less than 10001");
     std::lock_guard<std::mutex> lk(g.mtx);
-    g.filt2I.assign(filtI, filtI + size); g.filt2Q.assign(filtQ, filtQ + size);
-    g.bandwidth2 = bandwidth; g.filt2_dirty = true;
-    return QH_OK;
+    const int n = g.sub1_n < cap ? g.sub1_n : cap;
+    if (n > 0 && cSamples) std::memcpy(cSamples, g.sub1_out.data(), (size_t)n * 2 * sizeof(double));
+    return g.sub1_n;
 }
 // quisk_is_key_down() / QUISK_CWKEY_DOWN / quisk_active_sidetone / quisk_isFDX as the caller sees them now; the sidetone
-// of set_sidetone (quisk.c:4710: volume, |rit_freq| as its pitch) at the playback rate of open_sound
+// of set_sidetone (quisk.c:4710: volume, |rit_freq| as its pitch) at the playback rate of qh_quisk_open
 void qh_quisk_set_key_state(int key_down, int cw_key_down, int active_sidetone, int is_fdx)
 {
     std::lock_guard<std::mutex> lk(g.mtx);
@@ -425,13 +945,36 @@ void qh_quisk_set_key_state(int key_down, int cw_key_down, int active_sidetone, 
 void qh_quisk_set_sidetone(double volume, int rit_freq, int playback_rate, int txrx_silence_msec)
 {
     std::lock_guard<std::mutex> lk(g.mtx);
-    g.sidetone_volume = volume; g.rit_freq = rit_freq; g.notch_applied = -1;
-    if (playback_rate > 0) g.playback_rate = playback_rate;
+    (void)playback_rate;                                // the playback rate is qh_quisk_open's (open_sound sets it, quisk.c:4106)
+    g.sidetone_volume = volume; g.rit_freq = rit_freq;
+    if (g.mode == 0 || g.mode == 1) g.notch_reset = true;       // for CW, changing the RIT affects autonotch (quisk.c:4716-4717)
     if (txrx_silence_msec >= 0) g.txrx_silence_ms = txrx_silence_msec;
-    g.sidetone_phase = std::exp(std::complex<double>(0.0, 2.0 * 3.14159265358979323846 * std::abs(rit_freq) / g.playback_rate));
+    g.sidetone_phase = std::exp(std::complex<double>(0.0, 2.0 * M_PI * std::abs(rit_freq) / g.playback_rate));
 }
 void qh_quisk_set_kill_audio(int kill) { std::lock_guard<std::mutex> lk(g.mtx); g.kill_audio = kill; }
 void qh_quisk_invert_spectrum(int invert) { std::lock_guard<std::mutex> lk(g.mtx); g.invert_spectrum = invert; }           // quisk.c:4535
+void qh_quisk_set_squelch(double level) { std::lock_guard<std::mutex> lk(g.mtx); g.squelch_level = level; }               // set_squelch, quisk.c:4721
+void qh_quisk_set_ssb_squelch(int enabled, int level)                                                                     // set_ssb_squelch, quisk.c:4729
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.ssb_squelch_enabled = enabled; g.ssb_squelch_level = level;
+}
+int qh_quisk_squelch_flags(void) { std::lock_guard<std::mutex> lk(g.mtx); return g.squelch_real | (g.squelch_imag << 1); }
+// add_tone(freq) (quisk.c:3203-3216): a -40 dB test tone added to the samples; 0 switches it off
+void qh_quisk_add_tone(int freq)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.tone_on = freq != 0 && g.sample_rate != 0;
+    if (g.tone_on) g.tone_step = turns_step((double)freq, (double)g.sample_rate);
+}
+// measure_frequency(mode) (quisk.c:3181-3191): mode >= 0 sets measure_freq_mode (0 = off; a result every mode / 2 transforms of
+// 12000 samples at decim_srate / 8); returns the last measured frequency
+double qh_quisk_measure_frequency(int mode)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    if (mode >= 0) g.measure_mode = mode;
+    return g.measured_frequency;
+}
 
 // get_graph(1, zoom, deltaf) (quisk.c:5142): data_width pixels in dB and the S-meter; returns the number of FFTs
 // averaged (0: nothing new, pixels untouched -- the reference returns None).

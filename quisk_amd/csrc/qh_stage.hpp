@@ -32,7 +32,7 @@ struct Stage {
     double2 *lane_rot = nullptr, *out_step = nullptr, *tile_rot = nullptr;
     int tile_cap = 0;
     int *d_list = nullptr;
-    unsigned long long *d_law = nullptr;
+    unsigned long long *d_law = nullptr, *d_park = nullptr;
     int fold = 1, pick = 1, P = 0, Lf = 0;      // decimating: Lf folded outputs per tile; interpolating: Lf high-rate outputs per tile
     int hist_len = 0;                           // history rows (input-rate samples)
     int phase = 0;                              // decim_index
@@ -48,10 +48,10 @@ struct Stage {
     {
         (void)hipFree(mask); (void)hipFree(tw_fwd); (void)hipFree(tw_inv); (void)hipFree(hist[0]); (void)hipFree(hist[1]);
         (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
-        (void)hipFree(taps_re); (void)hipFree(lane_rot); (void)hipFree(out_step); (void)hipFree(tile_rot); (void)hipFree(d_list); (void)hipFree(d_law);
+        (void)hipFree(taps_re); (void)hipFree(lane_rot); (void)hipFree(out_step); (void)hipFree(tile_rot); (void)hipFree(d_list); (void)hipFree(d_law); (void)hipFree(d_park);
         mask = tw_fwd = tw_inv = hist[0] = hist[1] = nullptr;
         nco_phase = nco_dphase = nullptr; nco_step = nullptr; epi = nullptr;
-        taps_re = nullptr; lane_rot = out_step = tile_rot = nullptr; d_list = nullptr; d_law = nullptr; tile_cap = 0;
+        taps_re = nullptr; lane_rot = out_step = tile_rot = nullptr; d_list = nullptr; d_law = nullptr; d_park = nullptr; tile_cap = 0;
     }
 
     int upload_cplx(void *dst, const std::vector<cd> &v)
@@ -148,6 +148,14 @@ struct Stage {
     {
         if ((int)taps.size() > ntaps) return set_error(QH_ERR_INVALID, "more taps than the stage was created for");
         QH_HIP(hipSetDevice(device));
+        if (outmix) {                           // decided before anything is touched: a refused call leaves the stage as it was
+            bool real = true;
+            for (const cd &v : taps) if (v.imag() != 0.0) { real = false; break; }
+            if (!real) {
+                if (taps_set) return set_error(QH_ERR_UNSUPPORTED, "a mixing stage that ran with real taps cannot take complex ones");
+                outmix = false;                 // complex taps: the oscillator stays at the input (MIX); nco_step is kept current by set_nco
+            }
+        }
         if (interp == 1) {
             // The stage was created for up to `ntaps` taps (the Rx filter: 2048) and keeps that much history, but a tile only has to
             // overlap its neighbour by the longest filter actually set: 153 taps leave 3841 useful outputs of 4096, not 2049.
@@ -158,14 +166,6 @@ struct Stage {
             P = ((need - 1 + fold - 1) / fold) * fold;
             if (P < fold) P = fold;
             Lf = (((kStageNfft - P) / fold) / pick) * pick;
-        }
-        if (outmix) {
-            bool real = true;
-            for (const cd &v : taps) if (v.imag() != 0.0) { real = false; break; }
-            if (!real) {
-                if (taps_set) return set_error(QH_ERR_UNSUPPORTED, "a mixing stage that ran with real taps cannot take complex ones");
-                outmix = false;                 // complex taps: the oscillator stays at the input (MIX)
-            }
         }
         taps_set = true;
         if (outmix) {
@@ -227,6 +227,12 @@ struct Stage {
         t -= floorl(t);
         long double sc = t * 18446744073709551616.0L;
         unsigned long long d = sc >= 18446744073709551616.0L ? 0ull : (unsigned long long)sc;
+        {       // the input-side oscillator's per-register step: kept current in both forms (outmix may still be withdrawn by set_taps)
+            long double ang = 2.0L * 3.14159265358979323846264338327950288L * ((long double)(d * (unsigned long long)NT) / 18446744073709551616.0L);
+            double2 st = make_double2((double)cosl(ang), (double)sinl(ang));
+            QH_HIP(hipMemcpyAsync(nco_step + ch, &st, 16, hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
         if (outmix) {
             // the raw history was going to be seen through the old phase law: re-express it for the new one (the kernel reads the
             // old law from the device arrays, so it runs ahead of their update), then rebuild the channel's tables
@@ -240,10 +246,42 @@ struct Stage {
             QH_HIP(hipStreamSynchronize(stream));
             return taps_set ? build_outmix_tables(ch, 1) : QH_OK;
         }
-        long double ang = 2.0L * 3.14159265358979323846264338327950288L * ((long double)(d * (unsigned long long)NT) / 18446744073709551616.0L);
-        double2 st = make_double2((double)cosl(ang), (double)sinl(ang));
         QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, 8, hipMemcpyHostToDevice, stream));
-        QH_HIP(hipMemcpyAsync(nco_step + ch, &st, 16, hipMemcpyHostToDevice, stream));
+        QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+
+    // The oscillator's phase (2^-64 turns) at the next input sample of channel ch.  quisk_process_samples keeps one tune vector
+    // per PURPOSE (rxTuneVector, txTuneVector, aux1TuneVector, aux2TuneVector; quisk.c:2308-2311) while the banks' filter storage is
+    // per bank: a bank that changes purpose takes the other vector's phase and keeps its filter history.
+    int get_nco_phase(int ch, unsigned long long *p)
+    {
+        if (!mix) return set_error(QH_ERR_INVALID, "stage has no NCO");
+        QH_HIP(hipSetDevice(device));
+        QH_HIP(hipMemcpyAsync(p, nco_phase + ch, 8, hipMemcpyDeviceToHost, stream));
+        QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+    int set_nco_phase(int ch, unsigned long long p)
+    {
+        if (!mix) return set_error(QH_ERR_INVALID, "stage has no NCO");
+        QH_HIP(hipSetDevice(device));
+        if (outmix) {
+            // the raw history was going to be seen through the old phase; re-express it for the new one (same frequency)
+            if (!d_park) QH_HIP(dev_alloc(&d_park, (size_t)nch));
+            unsigned long long d = 0;
+            QH_HIP(hipMemcpyAsync(&d, nco_dphase + ch, 8, hipMemcpyDeviceToHost, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+            const unsigned long long law[2] = { 2ull, d };
+            QH_HIP(hipMemcpyAsync(d_law, law, sizeof(law), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemcpyAsync(d_park + ch, &p, 8, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(nco_retune_hist_kernel, dim3((unsigned)((hist_len + NT - 1) / NT), 1u), dim3(NT), 0, stream,
+                               static_cast<double2 *>(hist[cur]), hist_len, (const unsigned long long *)nco_phase,
+                               (const unsigned long long *)nco_dphase, (const unsigned long long *)d_park, (const int *)(d_list + ch),
+                               (const unsigned long long *)d_law);
+            QH_HIP(hipGetLastError());
+        }
+        QH_HIP(hipMemcpyAsync(nco_phase + ch, &p, 8, hipMemcpyHostToDevice, stream));
         QH_HIP(hipStreamSynchronize(stream));
         return QH_OK;
     }

@@ -76,9 +76,10 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
     if (!lf) return;                                    // block-uniform
     const double eR = wave_sum_d(accR * lane_pow(prm.mtauR, 63 - lane)), eI = wave_sum_d(accI * lane_pow(prm.mtauI, 63 - lane));
     if (lane == 0) { s_e[wave][0] = eR; s_e[wave][1] = eI; s_n[wave] = seg_samples(n, b0, b1); }
+    const double st_dc = state[ch].dc, st_dci = state[ch].dc_insert;     // read ahead of the barrier: the last wavefront stores the new carry at its end
     __syncthreads();
     // the true state at the start of this segment: dc <- mtau^len dc + e over the segments before it
-    double cR = state[ch].dc, cI = state[ch].dc_insert;
+    double cR = st_dc, cI = st_dci;
     for (int w = 0; w < wave; w++) {
         const double len = (double)s_n[w];
         cR = __builtin_fma(cR, pow(prm.mtauR, len), s_e[w][0]);
@@ -513,8 +514,9 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
     }
     const double e = wave_sum_d(acc * lane_pow(q.mtau, 63 - lane));
     if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); }
+    const double c_in = state[ch].fmdc;                  // ahead of the barrier: the last wavefront stores the new carry at its end
     __syncthreads();
-    double c = state[ch].fmdc;
+    double c = c_in;
     for (int w = 0; w < wave; w++) c = __builtin_fma(c, pow(q.mtau, (double)s_n[w]), s_e[w]);
     const double gain = again[ch];
     seg_load(fn, b0, b1, n, lane, f);

@@ -534,6 +534,13 @@ void qh_wdsp_set_parameter(int channel, int in_size, int in_use)
     if (in_use >= 0) g_shim[channel].in_use = in_use;
 }
 
+// for qh_quisk_process_samples: the block size of the channel while quisk_wdsp.c's hand-off is in use, else 0
+int qh_wdsp_shim_in_size(int channel)
+{
+    if (channel < 0 || channel >= kMaxChannels) return 0;
+    return g_shim[channel].in_use && g_shim[channel].in_size > 0 ? g_shim[channel].in_size : 0;
+}
+
 int wdspFexchange0(int channel, double *cSamples, int nSamples)
 {
     const double CLIP32 = 2147483647.0;

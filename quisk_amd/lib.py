@@ -236,7 +236,7 @@ def load():
     L.qh_qrx_set_agc.argtypes = [vp, i, C.c_double]
     L.qh_qrx_set_squelch.argtypes = [vp, i, C.c_double]
     L.qh_qrx_set_ssb_squelch.argtypes = [vp, i, i]
-    L.qh_quisk_open.argtypes = [i, vp, i, i]
+    L.qh_quisk_open.argtypes = [i, i, vp, i, i]
     L.qh_quisk_close.restype = None
     L.qh_quisk_set_tune.argtypes = [i]
     L.qh_quisk_set_tune.restype = None
@@ -248,12 +248,19 @@ def load():
     L.qh_quisk_process_samples.argtypes = [vp, i]
     for n, at in (("set_tx_tune", [i]), ("set_split_rxtx", [i]), ("set_multirx_play_channel", [i]), ("set_multirx_play_method", [i]),
                   ("set_multirx_freq", [i, i]), ("set_multirx_mode", [i, i]), ("set_key_state", [i, i, i, i]),
-                  ("set_sidetone", [C.c_double, i, i, i]), ("set_kill_audio", [i]), ("invert_spectrum", [i])):
+                  ("set_sidetone", [C.c_double, i, i, i]), ("set_kill_audio", [i]), ("invert_spectrum", [i]),
+                  ("set_squelch", [C.c_double]), ("set_ssb_squelch", [i, i]), ("add_tone", [i]), ("set_multirx_count", [i]),
+                  ("set_sub_rx1_output", [i])):
         f = getattr(L, "qh_quisk_" + n)
         f.argtypes = at
         f.restype = None
     L.qh_quisk_multirx_samples.argtypes = [i, vp, i]
     L.qh_quisk_set_filters2.argtypes = [vp, vp, i, i]
+    L.qh_quisk_set_filters_n.argtypes = [vp, vp, i, i, i]
+    L.qh_quisk_measure_frequency.argtypes = [i]
+    L.qh_quisk_measure_frequency.restype = C.c_double
+    L.qh_quisk_sub_rx1_audio.argtypes = [vp, i]
+    L.qh_quisk_squelch_flags.argtypes = []
     L.qh_quisk_get_graph.argtypes = [C.c_double, C.c_double, vp, vp]
     L.qh_qrx_create_ex.restype = vp
     L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]

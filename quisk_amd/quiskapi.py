@@ -12,14 +12,16 @@ from .qrx import _TABLE_KEYS, _Tables
 _keep = {}
 
 
-def open(sample_rate, fft_size=0, data_width=0):
+def open(sample_rate, fft_size=0, data_width=0, playback_rate=48000):
+    """record_app's fft_size / data_width and open_sound's sample and playback rates (quisk.c:5946,4106)."""
     L = load()
     t = rxfilter.coefficient_tables()
     tabs = [np.ascontiguousarray(t[k], dtype=np.float64) for k in _TABLE_KEYS]
     st = _Tables(*[a.ctypes.data for a in tabs])
     _keep["tabs"] = (tabs, st)
     _keep["data_width"] = data_width
-    check(L.qh_quisk_open(sample_rate, C.byref(st), fft_size, data_width))
+    _keep["ratio"] = max(1, playback_rate // 48000)
+    check(L.qh_quisk_open(sample_rate, playback_rate, C.byref(st), fft_size, data_width))
 
 
 def close():
@@ -34,12 +36,13 @@ def set_rx_mode(mode):
     load().qh_quisk_set_rx_mode(int(mode))
 
 
-def set_filters(filtI, filtQ, bandwidth):
+def set_filters(filtI, filtQ, bandwidth, nFilter=0):
+    """QS.set_filters(I, Q, bandwidth, start_offset, nFilter), quisk.c:4551."""
     fI = np.ascontiguousarray(filtI, dtype=np.float64)
     fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
     if fI.size != fQ.size:
         raise ValueError("The size of filters I and Q must be equal")
-    check(load().qh_quisk_set_filters(fI.ctypes.data, fQ.ctypes.data, fI.size, int(bandwidth)))
+    check(load().qh_quisk_set_filters_n(fI.ctypes.data, fQ.ctypes.data, fI.size, int(bandwidth), int(nFilter)))
 
 
 def set_tune2(rx_tune_freq, tx_tune_freq):
@@ -123,3 +126,47 @@ def get_graph(zoom=1.0, deltaf=0.0):
     sm = C.c_double(0)
     cnt = load().qh_quisk_get_graph(C.c_double(zoom), C.c_double(deltaf), pix.ctypes.data, C.byref(sm))
     return None if cnt == 0 else (pix, sm.value, cnt)
+
+
+def set_squelch(level):
+    load().qh_quisk_set_squelch(C.c_double(level))
+
+
+def set_ssb_squelch(enabled, level):
+    load().qh_quisk_set_ssb_squelch(int(enabled), int(level))
+
+
+def squelch_flags():
+    return load().qh_quisk_squelch_flags()
+
+
+def add_tone(freq):
+    load().qh_quisk_add_tone(int(freq))
+
+
+def measure_frequency(mode):
+    return load().qh_quisk_measure_frequency(int(mode))
+
+
+def set_multirx_count(n):
+    load().qh_quisk_set_multirx_count(int(n))
+
+
+def set_sub_rx1_output(on):
+    load().qh_quisk_set_sub_rx1_output(int(on))
+
+
+def sub_rx1_audio():
+    n = load().qh_quisk_sub_rx1_audio(None, 0)
+    out = np.zeros(max(n, 1), dtype=np.complex128)
+    load().qh_quisk_sub_rx1_audio(out.ctypes.data, n)
+    return out[:n]
+
+
+def process(x):
+    """process_samples on a copy with room for the playback-rate output; returns the output block."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    buf = np.zeros(max(x.size, 16) * (_keep.get("ratio", 1) + 1), dtype=np.complex128)
+    buf[:x.size] = x
+    n = process_samples(buf, x.size)
+    return buf[:max(n, 0)].copy()

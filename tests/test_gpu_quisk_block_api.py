@@ -15,9 +15,9 @@ def test_process_samples_in_place_with_mode_and_tune_changes(qh, oracle):
     api = qh.quiskapi
     api.open(fs, fft_size=2048, data_width=512)
     tabs = rxfilter.coefficient_tables()
-    r = oracle.OracleQuiskRx(fs, tabs)
-    agc = oracle.OracleQuiskAgc(48000, 0.7, 1.0)            # Agc1 is static: one AGC for every mode (quisk.c:2321)
-    g = oracle.OracleGraph(2048, 512, float(fs))
+    ref = oracle.OracleQuiskBlock(fs, 48000, tabs)          # quisk_process_samples restated as a whole: tune vector, Agc1 and
+    g = oracle.OracleGraph(2048, 512, float(fs))            # the FFT ring carry on across mode changes
+    ref.set_graph(g)
     t = np.arange(fs)
     x = 2.0 ** 22 * np.exp(2j * np.pi * ((10900.0 / fs) * t % 1.0)) + 2.0 ** 14 * (np.random.default_rng(0).standard_normal(fs) + 0j)
     plan = [(0, 3, 10000, "USB", 2700), (60000, 2, 11800, "LSB", 2400), (120000, 4, 10900, "AM", 6000)]
@@ -31,15 +31,15 @@ def test_process_samples_in_place_with_mode_and_tune_changes(qh, oracle):
                 fI, fQ = rxfilter.make_filter_coef(frate, None, bw, rxfilter.get_filter_center(name, bw))
                 api.set_filters(fI, fQ, bw)
                 assert api.get_filter_rate() == frate
-                # the reference keeps its static filter histories; here a mode change starts fresh filters (the AGC carries on)
-                r = oracle.OracleQuiskRx(fs, tabs)
-                r.set_mode(mode); r.set_tune(tune); r.set_filters(fI, fQ); r.set_bandwidth(bw)
+                # the reference keeps its static filter histories; here a mode change starts fresh filters (everything else carries on)
+                ref.set_rx_mode(mode); ref.set_tune(tune); ref.set_filters(fI, fQ, bw)
+                if start:
+                    ref.restart_bank(0)
         buf = np.zeros(blk, dtype=np.complex128)
         buf[:] = x[k:k + blk]
         n = api.process_samples(buf, blk)
         outs.append(buf[:n].copy())
-        refs.append(agc.process(r.process(x[k:k + blk]), False, 80.0))
-        g.feed(x[k:k + blk])
+        refs.append(ref.process(x[k:k + blk]))
     y, want = np.concatenate(outs), np.concatenate(refs)
     assert y.size == want.size == (fs // blk) * blk // 4
     assert np.abs(want).max() > 2.0 ** 24
@@ -118,13 +118,14 @@ def test_played_sub_receiver(qh, oracle, method):
     x = _two_tone(fs, blk * nblk, 10900.0, 40000.0, 5)
     xs = _two_tone(fs, blk * nblk, -15600.0, 30000.0, 6)
     fI, fQ = _filters("USB", 3, 2700)
-    gI, gQ = _filters("LSB", 2, 2400)
+    gI, gQ = _filters("LSB", 2, 2700)                       # as long as fI: set_filters keeps ONE sizeFilter for every filter set (quisk.c:4591)
+    assert len(gI) == len(fI)
     api.open(fs)
     api.set_rx_mode(3); api.set_tune(10000); api.set_filters(fI, fQ, 2700)
-    api.set_multirx_mode(1, 2); api.set_multirx_freq(1, -15000); api.set_filters2(gI, gQ, 2400)
+    api.set_multirx_mode(1, 2); api.set_multirx_freq(1, -15000); api.set_filters2(gI, gQ, 2700)
     api.set_multirx_play_channel(1); api.set_multirx_play_method(method)
     r0 = oracle.OracleQuiskRx(fs, tabs); r0.set_mode(3); r0.set_tune(10000); r0.set_filters(fI, fQ); r0.set_bandwidth(2700)
-    r1 = oracle.OracleQuiskRx(fs, tabs); r1.set_mode(2); r1.set_tune(-15000); r1.set_filters(gI, gQ); r1.set_bandwidth(2400)
+    r1 = oracle.OracleQuiskRx(fs, tabs); r1.set_mode(2); r1.set_tune(-15000); r1.set_filters(gI, gQ); r1.set_bandwidth(2700)
     agc = [oracle.OracleQuiskAgc(48000, 0.7, 1.0), oracle.OracleQuiskAgc(48000, 0.7, 1.0)]
     outs, refs = [], []
     for k in range(nblk):
