@@ -761,11 +761,13 @@ int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *table
     g.sample_rate = sample_rate; g.playback_rate = playback_rate;
     g.fft_size = fft_size; g.data_width = data_width;
     QH_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    // the orchestration state starts like the reference's statics and globals at program start
+    // everything starts like the reference's statics and globals at program start
+    g.mode = 0; g.tune = 0; g.agc_gain = 80.0; g.nb_level = 0; g.auto_notch = 0; g.rit_freq = 0; g.notch_reset = false;
+    for (int i = 0; i < 3; i++) { g.filtI[i].clear(); g.filtQ[i].clear(); g.filt_bw[i] = 0; }
+    g.size_filter = 0; g.sidetone_volume = 0.0; g.sidetone_phase = 1.0; g.txrx_silence_ms = 50;
     g.tx_tune = 0; g.split_rxtx = 0; g.play_channel = -1; g.play_method = 0; g.old_split = 0; g.old_play = 0;
     for (int i = 0; i < QuiskRx::kMaxSub; i++) { g.sub_freq[i] = 0; g.sub_mode[i] = 0; g.sub_have[i] = 0; }
     g.multirx_count = 0; g.sub_rx1_driver = 0;
-    for (int i = 1; i < 3; i++) { g.filtI[i].clear(); g.filtQ[i].clear(); }
     for (u64 &p : g.phase) p = 0;
     g.key_down = g.cw_key_down = g.active_sidetone = g.is_fdx = g.kill_audio = g.invert_spectrum = 0;
     g.out_counter = 0.0; g.sidetone_env = 0.0; g.keyup_env = 1.0; g.sidetone_on = 0; g.play_silence = 0;
@@ -813,9 +815,8 @@ int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *table
         g.up = qh_rat_create(0, 1, taps.data(), (int)taps.size(), ratio, 1, QH_F64, g.stream);
         if (!g.up) return QH_ERR_HIP;
     }
-    if (g.size_filter == 0 && !g.filtI[0].empty()) g.size_filter = (int)g.filtI[0].size();
     g.filt_epoch++;
-    return ensure_bank(g.bank[0], g.mode, 0, g.tune, 0);
+    return QH_OK;
 }
 
 void qh_quisk_close(void)
