@@ -83,37 +83,44 @@ class DryEngine:
         return -20.0
 
 
-def cpu_baseline(log2_samples=23):
-    """The CPU oracle (a restatement of the reference's WDSP path, oracle/wdsp_oracle.c) timed on the
-    host cores of this box: one channel per core, each 2^log2_samples input samples."""
-    import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline(log2_single=24, log2_each=22):
+    """The CPU oracle (oracle/wdsp_oracle.c, a restatement of the reference's WDSP path; own radix-2 FFT, not FFTW) timed on the
+    host cores of this box, outside the timed region, the two ways BASELINE.md section 3 plans:
+      (i)  one channel on one core (a worker process pinned to the first core this process may use);
+      (ii) one channel per core: one worker PROCESS per core, each pinned, each with its own input and output buffers made on
+           its core (first touch), all started at one agreed wall-clock time; rate = all samples / (last end - first start).
+    The workers are fresh processes (tools/cpu_baseline_worker.py: numpy + ctypes, no torch, no GPU)."""
+    import subprocess
     from oracle import pyoracle as po
-    from quisk_amd import synth
     po.build(ref=False)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, cores)               # every core this process may run on (what `nproc` prints)
-    n = 1 << log2_samples
-    po.fft(np.zeros(512, dtype=np.complex128))                  # warm the oracle's twiddle cache before threading
-    x = synth.make_input_numpy(1, n)[0]
-    chans = []
-    for c in range(cores):
-        ch = po.WdspChannel(1024, DSP_SIZE, IN_RATE, DSP_RATE, DSP_RATE)
-        ch.SetRXAShiftRun(1)
-        ch.SetRXAShiftFreq(synth.shift_freq(c))
-        ch.RXANBPSetRun(1)
-        ch.SetRXAMode(1)
-        ch.RXASetPassband(300.0, 3000.0)
-        ch.SetRXAAGCMode(0)
-        ch.SetRXAAGCFixed(0.0)
-        chans.append(ch)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(lambda ch: ch.xrxa(x), chans))              # ctypes releases the GIL inside the C call
-    dt = time.perf_counter() - t0
-    return {"value": cores * n / dt / 1e6, "unit": "Mcomplex-samples/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
-            "sample": "%d channels (one per core) x 2^%d input samples, oracle/wdsp_oracle.c -O3, own radix-2 FFT (not FFTW)"
-                      % (cores, log2_samples)}
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    worker = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
+
+    def run(cores, log2n, lead):
+        t_start = time.time() + lead
+        procs = [subprocess.Popen([sys.executable, worker, str(c), str(i), str(log2n), repr(t_start)], stdout=subprocess.PIPE, text=True)
+                 for i, c in enumerate(cores)]
+        outs = []
+        for pr in procs:
+            o, _ = pr.communicate(timeout=600)
+            if pr.returncode != 0:
+                raise RuntimeError("cpu baseline worker failed")
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        span = max(o["t1"] for o in outs) - min(o["t0"] for o in outs)
+        late = max(o["t0"] for o in outs) - t_start            # > 0.5 s: a worker was not ready at the start time
+        return sum(o["samples"] for o in outs) / span / 1e6, span, late, outs
+
+    single, span1, _, _ = run(avail[:1], log2_single, 4.0)
+    # workers need a few seconds to import numpy and make 2^log2_each samples; give 256 of them room
+    lead = 6.0 + 0.05 * len(avail)
+    allc, span, late, outs = run(avail, log2_each, lead)
+    per = sorted((1 << log2_each) / o["seconds"] / 1e6 for o in outs)
+    return {"value": allc, "unit": "Mcomplex-samples/s", "cores": len(avail), "nproc": os.cpu_count(), "kind": "port",
+            "single_thread_value": single, "per_core_value": allc / len(avail),
+            "per_core_min_median_max": [per[0], per[len(per) // 2], per[-1]], "start_skew_s": late,
+            "sample": "(i) 1 channel x 2^%d input samples on one pinned core, %.1f s; (ii) %d channels, one pinned process per core, each 2^%d "
+                      "samples in buffers of its own, %.1f s; oracle/wdsp_oracle.c -O3 -march=native, own radix-2 FFT (not FFTW)"
+                      % (log2_single, span1, len(avail), log2_each, span)}
 
 
 def main():
