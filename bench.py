@@ -83,7 +83,7 @@ class DryEngine:
         return -20.0
 
 
-def cpu_baseline(log2_single=24, log2_each=22):
+def cpu_baseline(log2_single=25, log2_each=24):
     """The CPU oracle (oracle/wdsp_oracle.c, a restatement of the reference's WDSP path; own radix-2 FFT, not FFTW) timed on the
     host cores of this box, outside the timed region, the two ways BASELINE.md section 3 plans:
       (i)  one channel on one core (a worker process pinned to the first core this process may use);
@@ -94,6 +94,26 @@ def cpu_baseline(log2_single=24, log2_each=22):
     from oracle import pyoracle as po
     po.build(ref=False)
     avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    visible = len(avail)
+    # The container's CPU-time quota (cgroup cpu.max / cfs_quota_us): the GPU boxes of this pool show 256 hardware threads but
+    # grant 16 CPUs' worth of time, so 256 busy workers each get a sixteenth of a core (that was round 2's 0.41 Msamp/s "per
+    # core").  The baseline uses as many cores as the quota grants, spread over the visible ones, and says so.
+    quota = None
+    for f_quota, f_period in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if f_period is None:
+                q, per = open(f_quota).read().split()[:2]
+            else:
+                q, per = open(f_quota).read().strip(), open(f_period).read().strip()
+            if q not in ("max", "-1"):
+                quota = float(q) / float(per)
+            break
+        except (OSError, ValueError):
+            continue
+    if quota is not None and quota < visible:
+        ncores = max(1, int(quota))
+        stride = visible // ncores
+        avail = [avail[i * stride] for i in range(ncores)]
     worker = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
 
     def run(cores, log2n, lead):
@@ -115,12 +135,58 @@ def cpu_baseline(log2_single=24, log2_each=22):
     lead = 6.0 + 0.05 * len(avail)
     allc, span, late, outs = run(avail, log2_each, lead)
     per = sorted((1 << log2_each) / o["seconds"] / 1e6 for o in outs)
-    return {"value": allc, "unit": "Mcomplex-samples/s", "cores": len(avail), "nproc": os.cpu_count(), "kind": "port",
+    return {"value": allc, "unit": "Mcomplex-samples/s", "cores": len(avail), "nproc": os.cpu_count(), "cpu_quota": quota, "kind": "port",
             "single_thread_value": single, "per_core_value": allc / len(avail),
             "per_core_min_median_max": [per[0], per[len(per) // 2], per[-1]], "start_skew_s": late,
-            "sample": "(i) 1 channel x 2^%d input samples on one pinned core, %.1f s; (ii) %d channels, one pinned process per core, each 2^%d "
-                      "samples in buffers of its own, %.1f s; oracle/wdsp_oracle.c -O3 -march=native, own radix-2 FFT (not FFTW)"
+            "sample": "(i) 1 channel x 2^%d input samples on one pinned core, %.1f s; (ii) %d channels, one pinned process per core (as many cores as the container's CPU quota "
+                      "grants), each 2^%d samples in buffers of its own, %.1f s; oracle/wdsp_oracle.c -O3 -march=native, own radix-2 FFT (not FFTW)"
                       % (log2_single, span1, len(avail), log2_each, span)}
+
+
+def other_configs(torch, dev):
+    """BASELINE.json configs 3, 4, 5 (one GPU's share each) and the Quisk-native chain (path A), run after the timed region of the
+    headline workload with tools/bench_configs.py's legs: per configuration the algorithmic bytes per input sample,
+    the rate, GB/s against the 8 TB/s roofline, and the kernel that takes most of the step.  Reported as extra keys; `value` is
+    configuration 2's alone."""
+    import importlib.util
+    import quisk_amd as qh
+    spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    out = {}
+
+    def leg(key, fn, bytes_per_sample, ms_key, dominant):
+        try:
+            r = fn(torch, qh, dev)
+            ms = r[ms_key]
+            rate = r["samples_per_step"] / (ms * 1e-3)
+            gbps = bytes_per_sample * rate / 1e9
+            name, kms = dominant(r)
+            out[key] = {"workload": r["config"], "samples_per_step": r["samples_per_step"], "ms_per_step": ms, "Msamp_per_s": rate / 1e6,
+                        "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                        "dominant_kernel": name, "dominant_kernel_ms": kms, "detail": {k: v for k, v in r.items() if k not in ("config",)}}
+        except Exception as exc:                                 # reported, never required
+            out[key] = {"failed": repr(exc)}
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+
+    # config 3: 16 B in (read once by the FIR and once by the transform) + 16/32 B FIR output; the |X| sums stay on the chip and only
+    # the running average leaves it, so SURVEY.md 8(d)'s 16.5 B, not 24.5
+    leg("config3", bc.config3, 16.5, "both_ms",
+        lambda r: ("pan16k_kernel (16384-point panadapter, read-once)", r["pan_ms"]) if r["pan_ms"] >= r["fir_ms"]
+        else ("osfir_kernel<f64,4096,D=8,pick 4> (1023-tap /32)", r["fir_ms"]))
+    leg("config4", bc.config4, 20.0, "ms", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
+    leg("config5", bc.config5, 8.0, "fused_ms", lambda r: ("hb45_cascade_kernel<float,8>", r["fused_cascade_only_ms"]))
+    try:
+        r = bc.quisk_native(torch, qh, dev)
+        out["quisk_native"] = {"workload": r["config"], "samples_per_step": r["samples_per_step"], "algorithmic_bytes_per_sample": 20.0,
+                               "modes": [{"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
+                                          "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
+                                          "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS} for m in r["modes"]],
+                               "dominant_kernel": "osfir_kernel<f64,4096,D=8,OUTMIX> (tune + collapsed 1181-tap /16)"}
+    except Exception as exc:
+        out["quisk_native"] = {"failed": repr(exc)}
+    return out
 
 
 def main():
@@ -135,6 +201,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="plumbing test only: no GPU, no DSP (DryEngine); the line is not a measurement")
     ap.add_argument("--log2-samples", type=int, default=LOG2_SAMPLES, help="input samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra legs (BASELINE configs 3, 4, 5 and the Quisk-native chain)")
     ap.add_argument("--meters", choices=["on", "off"], default="on",
                     help="on (default): xrxa's three meters run as in the reference (adc, S, agc: wdsp/RXA.c:566,569,589), "
                          "fused into the nbp0 launch; the line also carries the rate of a second, untimed-for-`value` run with them off")
@@ -340,6 +407,10 @@ def main():
             line["value_meters_off"] = total / dt_off / 1e6
             line["ms_per_step_meters_off"] = dt_off / args.steps * 1e3
             line["check_meters_dB"] = {"S_AV": meter_db[0], "ADC_AV": meter_db[1], "AGC_AV": meter_db[2]}
+        if not args.no_other_configs and world == 1 and not dry and args.ingest == "f64":
+            del x, y, eng                                        # the headline workload's 21 GB go back before the other legs allocate
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(torch, dev)
         if not args.no_cpu_baseline and world == 1 and not dry:       # the CPU baseline is reported by the single-GPU run only
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -41,7 +41,8 @@ def config3(torch, qh, dev):
     return {"config": "3: 64 ch x 1.536 Msps fp64, 1023-tap FIR /32 + 16384-pt panadapter every block", "samples_per_step": tot,
             "fir_ms": t_fir * 1e3, "pan_ms": t_pan * 1e3, "both_ms": t_both * 1e3, "Msamp_per_s": tot / t_both / 1e6,
             "fir_Msamp_per_s": tot / t_fir / 1e6, "pan_Msamp_per_s": tot / t_pan / 1e6,
-            "algorithmic_GBps": 24.5 * tot / t_both / 1e9}
+            "algorithmic_GBps": 16.5 * tot / t_both / 1e9,
+            "note": "16 B in + 16/32 B FIR out per sample; only the running |X| average leaves the chip (SURVEY.md 8(d): 16.5 B)"}
 
 
 def config4(torch, qh, dev):
@@ -67,8 +68,14 @@ def config4(torch, qh, dev):
     # the same call with the launch sequence replayed from hipGraphs (qh_rxa_set_graph_replay): ~25 launches per call
     eng.set_graph_replay(True)
     tg = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=8, warmup=4)
+    eng.set_graph_replay(False)
+    eng.enable_timing(True)
+    eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk)
+    kt = eng.timing_ms()
+    eng.enable_timing(False)
     tot = nch * n_in
-    return {"config": "4 (one GPU's share): 256 ch x 192 k, mode by c mod 3 = USB / AM / FM, fp64", "samples_per_step": tot,
+    return {"front_ms": kt[0], "band_ms": kt[1], "rest_ms": kt[2],
+            "config": "4 (one GPU's share): 256 ch x 192 k, mode by c mod 3 = USB / AM / FM, fp64", "samples_per_step": tot,
             "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "ms_graph_replay": tg * 1e3, "Msamp_per_s_graph_replay": tot / tg / 1e6,
             "graph_launches": eng.graph_launches(),
             "pll_tiles_rerun": eng.pll_repairs(),
