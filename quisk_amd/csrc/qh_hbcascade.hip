@@ -19,11 +19,22 @@ struct qh_hbc {
     bool attr_set = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // Six and more stages run as TWO launches: the first three stages (7/8 of the arithmetic, every wavefront full, 4 barriers per
+    // 2048-sample step) write the /8 stream to `mid`, a second cascade of the remaining stages reads it.  In the one-launch form
+    // the stages behind the third occupy 32 .. 8 lanes of a wavefront and still cost every wavefront a barrier each per step, and
+    // a segment's warm-up is 6 steps instead of 1; the extra 2 x 1/8 of HBM traffic is small beside that
+    // (61.44 Msps fp32, 2^26 samples: 0.214 ms as one launch, 0.170 ms as 3 + 5; tools/dbg/hbc_split.py).
+    int head = 0;                   // stages of this handle's own launch (== nstage when there is no tail)
+    qh_hbc *tail = nullptr;
+    void *mid = nullptr;
+    long long mid_cap = 0;
     ~qh_hbc()
     {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
+        delete tail;
         for (auto &h : hist) if (h) (void)hipFree(h);
+        if (mid) (void)hipFree(mid);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -59,7 +70,7 @@ int launch(qh_hbc *h, const void *in, long long in_stride, int n_in, void *out, 
 template <typename T>
 int dispatch(qh_hbc *h, const void *in, long long is, int n, void *out, long long os)
 {
-    switch (h->nstage) {
+    switch (h->head) {
     case 1: return launch<T, 1>(h, in, is, n, out, os);
     case 2: return launch<T, 2>(h, in, is, n, out, os);
     case 3: return launch<T, 3>(h, in, is, n, out, os);
@@ -96,7 +107,8 @@ qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream)
     qh_hbc *h = new qh_hbc();
     h->device = device; h->nch = nch; h->nstage = nstage; h->dtype = dtype;
     h->esize = dtype == QH_F64 ? 16 : 8;
-    h->warm = warm_of(nstage);
+    h->head = nstage >= 6 ? 3 : nstage;
+    h->warm = warm_of(h->head);
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); delete h; return nullptr; }
     if (!s) {
@@ -104,6 +116,10 @@ qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream)
         h->own_stream = true;
     }
     h->stream = s;
+    if (h->head < nstage) {
+        h->tail = qh_hbc_create(device, nch, nstage - h->head, dtype, s);
+        if (!h->tail) { delete h; return nullptr; }
+    }
     const size_t bytes = (size_t)nch * (size_t)h->warm * h->esize;
     for (auto &p : h->hist) {
         if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
@@ -122,7 +138,7 @@ int qh_hbc_reset(qh_hbc *h)
     if (!h) return set_error(QH_ERR_INVALID, "qh_hbc_reset: null handle");
     QH_HIP(hipSetDevice(h->device));
     for (auto &p : h->hist) QH_HIP(hipMemsetAsync(p, 0, (size_t)h->nch * (size_t)h->warm * h->esize, h->stream));
-    return QH_OK;
+    return h->tail ? qh_hbc_reset(h->tail) : QH_OK;
 }
 
 int qh_hbc_process(qh_hbc *h, const void *d_in, long long in_stride, int n_in, void *d_out, long long out_stride)
@@ -132,6 +148,19 @@ int qh_hbc_process(qh_hbc *h, const void *d_in, long long in_stride, int n_in, v
     if (in_stride < n_in || out_stride < (n_in >> h->nstage)) return set_error(QH_ERR_INVALID, "qh_hbc_process: stride shorter than the data");
     if (n_in == 0) return QH_OK;
     QH_HIP(hipSetDevice(h->device));
+    if (h->tail) {
+        const long long n_mid = n_in >> h->head;
+        if (n_mid > h->mid_cap) {
+            QH_HIP(hipStreamSynchronize(h->stream));
+            if (h->mid) (void)hipFree(h->mid);
+            h->mid = nullptr; h->mid_cap = 0;
+            QH_HIP(hipMalloc(&h->mid, (size_t)h->nch * (size_t)n_mid * h->esize));
+            h->mid_cap = n_mid;
+        }
+        if (int rc = h->dtype == QH_F64 ? dispatch<double>(h, d_in, in_stride, n_in, h->mid, h->mid_cap)
+                                        : dispatch<float>(h, d_in, in_stride, n_in, h->mid, h->mid_cap)) return rc;
+        return qh_hbc_process(h->tail, h->mid, h->mid_cap, (int)n_mid, d_out, out_stride);
+    }
     return h->dtype == QH_F64 ? dispatch<double>(h, d_in, in_stride, n_in, d_out, out_stride)
                               : dispatch<float>(h, d_in, in_stride, n_in, d_out, out_stride);
 }
