@@ -175,7 +175,8 @@ def other_configs(torch, dev):
     leg("config3", bc.config3, 16.5, "both_ms",
         lambda r: ("pan16k_kernel (16384-point panadapter, read-once)", r["pan_ms"]) if r["pan_ms"] >= r["fir_ms"]
         else ("osfir_kernel<f64,4096,D=8,pick 4> (1023-tap /32)", r["fir_ms"]))
-    leg("config4", bc.config4, 20.0, "ms", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
+    # config 4: the call's launch sequence replayed from a hipGraph (qh_rxa_set_graph_replay), the engine's mode for repeated calls
+    leg("config4", bc.config4, 20.0, "ms_graph_replay", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
     leg("config5", bc.config5, 8.0, "fused_ms", lambda r: ("hb45_cascade_kernel<float,8>", r["fused_cascade_only_ms"]))
     try:
         r = bc.quisk_native(torch, qh, dev)

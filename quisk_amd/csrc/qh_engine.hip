@@ -178,7 +178,8 @@ struct Engine {
     // demodulators (allocated on first use)
     bool demod_alloc = false, lists_dirty = true;
     int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
-    int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0;
+    int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0, n_rest = 0;
+    int *list_rest = nullptr;                // the channels that are not FM (the mixed-mode path runs the two kinds on two streams)
     int n_sam0 = 0;                         // the first n_sam0 entries of list_sam have sbmode 0 (no all-pass chains): time-tiled in long calls
     // anf / anr: lists per (filter, position), parameters and state per filter; bp1 lists per position
     // [filter][0] = position 0 (always in `cur`); [filter][1 + b] = position 1 with the data in cur (b = 0: bp1 still to come
@@ -225,6 +226,7 @@ struct Engine {
     // tiles pll_verify_kernel had to re-run
     double *pll_ends = nullptr;
     long long pll_ends_cap = 0;             // tiles per channel
+    double *seg_sum[3] = { nullptr, nullptr, nullptr };     // segment summaries of the multi-workgroup scans: AM / SAM, FM dc, snotch
     int *pll_nfixed = nullptr;
     int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
     SamChanParam *sam_prm = nullptr;
@@ -259,7 +261,7 @@ struct Engine {
     int refresh_params();
     int refresh_demod();
     int run_front(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
-                  long long n_in, long long n_mid);
+                  long long n_in, long long n_mid, const int *list = nullptr, int nlist = 0, int part = 0);
     const unsigned char *pk_src = nullptr;      // set for the duration of a qh_rxa_process_packed call
     PackedFmt pk{};
     EgressFmt eg{};                             // set (kind != 0) for the duration of a qh_rxa_process_audio call
@@ -298,6 +300,7 @@ Engine::~Engine()
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed);
+    for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
     (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx); (void)hipFree(snba_tune);
@@ -635,7 +638,8 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 24));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 25));
+        list_rest = list_buf + 24 * nch;
         list_amsq = list_buf + 17 * nch;
         for (int k = 0; k < 3; k++) list_emnr[k] = list_buf + (18 + k) * nch;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
@@ -704,7 +708,7 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba, lrest;
         int n_sam0_new = 0;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
@@ -719,7 +723,7 @@ int Engine::refresh_demod()
             if (c.fmd_run && c.lim_run) ll.push_back(ch);
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
             if (c.amd_run && c.amd_mode == 1) { if (c.sbmode == 0) ls.insert(ls.begin() + n_sam0_new++, ch); else ls.push_back(ch); }
-            if (c.fmd_run) lf.push_back(ch);
+            if (c.fmd_run) lf.push_back(ch); else lrest.push_back(ch);
             if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
             // xwcpagc sits between the two bp1 positions (RXA.c:581-586): a position-1 channel is still in `cur` there
             if (c.agc_run && c.agc_mode != 0) (c.bp1_run && !c.bp1_pos ? lgo : lgc).push_back(ch);
@@ -818,7 +822,8 @@ int Engine::refresh_demod()
             return v.empty() ? hipSuccess : hipMemcpyAsync(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream);
         };
         QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
-        QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo));
+        QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo)); QH_HIP(put(list_rest, lrest));
+        n_rest = (int)lrest.size();
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) QH_HIP(put(list_lms[f][k], lms_l[f][k]));
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
         QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1])); QH_HIP(put(list_amsq, lsq));
@@ -1280,10 +1285,13 @@ static void launch_band2g(OsfirArgs<double> a, int ntiles, int nch, hipStream_t 
 
 // ---- stage helpers ---------------------------------------------------------------------------
 // front: xshift + xresample(in) over all channels
+// part 0: the whole stage.  The mixed-mode path runs the FM channels and the others on two streams: part 1 = the oscillator's tile
+// table for every channel, part 2 = the tile kernel for the listed channels (on whatever `stream` is at the moment), part 3 = the
+// history rows and the oscillator phases of every channel.  Parts 1 - 3 exist for the overlap-save form (D > 1) only.
 int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
-                      long long n_in, long long n_mid)
+                      long long n_in, long long n_mid, const int *list, int nlist, int part)
 {
-    tick(0);
+    if (part == 0) tick(0);
     if (D > 1) {
         OsfirArgs<double> a{};
         a.in = src; a.in_stride = src_stride;
@@ -1296,7 +1304,9 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
         a.n_in = (int)n_in; a.n_out = (int)n_mid; a.off = 0; a.P = front_P; a.Lout = front_L; a.pick = front_pick;
         const int per_tile = front_L / front_pick;
         const int ntiles = (int)((n_mid + per_tile - 1) / per_tile);
-        if (ntiles > tile_rot_cap) {
+        a.chan_list = list;
+        const int nl = list ? nlist : nch;
+        if (part <= 1 && ntiles > tile_rot_cap) {
             QH_HIP(hipStreamSynchronize(stream));
             drop_graphs(); epoch++;
             if (tile_rot) { QH_HIP(hipFree(tile_rot)); dev_bytes -= tile_rot_cap * nch * (long long)sizeof(double2); tile_rot = nullptr; }
@@ -1305,27 +1315,29 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
             dev_bytes += (long long)ntiles * nch * (long long)sizeof(double2);
         }
         // oscillator phasor at the first input index of every tile: g0 = off - P + tile * fold * Lout (qh_osfir.hpp)
-        hipLaunchKernelGGL(nco_tile_kernel, dim3((unsigned)((ntiles + 255) / 256), (unsigned)nch), dim3(256), 0, stream,
+        if (part <= 1) hipLaunchKernelGGL(nco_tile_kernel, dim3((unsigned)((ntiles + 255) / 256), (unsigned)nch), dim3(256), 0, stream,
                            (const unsigned long long *)nco_phase, (const unsigned long long *)nco_dphase, tile_rot, ntiles,
                            (long long)(a.off - a.P), (long long)front_fold * front_L);
         a.tile_rot = tile_rot;
         a.pk_src = pk_src; a.pk = pk;
-        if (pk_src) {
+        if (part == 1 || part == 3) { }
+        else if (pk_src) {
             switch (front_fold) {
-            case 2: launch_osfir<2, false, true, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, false, true, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, false, true, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
+            case 2: launch_osfir<2, false, true, false, true, false, kNfft, true>(a, ntiles, nl, stream); break;
+            case 4: launch_osfir<4, false, true, false, true, false, kNfft, true>(a, ntiles, nl, stream); break;
+            case 8: launch_osfir<8, false, true, false, true, false, kNfft, true>(a, ntiles, nl, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         } else {
             switch (front_fold) {
-            case 2: launch_osfir<2, false, false, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
-            case 4: launch_osfir<4, false, false, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
-            case 8: launch_osfir<8, false, false, false, true, false, kNfft, true>(a, ntiles, nch, stream); break;
+            case 2: launch_osfir<2, false, false, false, true, false, kNfft, true>(a, ntiles, nl, stream); break;
+            case 4: launch_osfir<4, false, false, false, true, false, kNfft, true>(a, ntiles, nl, stream); break;
+            case 8: launch_osfir<8, false, false, false, true, false, kNfft, true>(a, ntiles, nl, stream); break;
             default: return set_error(QH_ERR_UNSUPPORTED, "decimation %d not supported", D);
             }
         }
-        tick(2);
+        if (part == 0) tick(2);
+        if (part == 1 || part == 2) return QH_OK;
         dim3 g((kHistFront + NT - 1) / NT, (unsigned)nch);
         if (pk_src)
             hipLaunchKernelGGL((hist_update_kernel<double, false, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
@@ -1537,12 +1549,40 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
 
     // ---- mixed modes: per-mode stages run on channel lists; gains/panel in a final pointwise pass
     double2 *cur = buf[0], *other = buf[1];
+    // FM channels have a long detector chain of kernels that fill a fraction of the chip (one lane per 256-sample tile of the loop,
+    // a few workgroups per channel in the scans) while the other channels' work is dense filtering.  With both kinds in the call
+    // the FM channels' front and nbp0 stages are launched first and their detector chain follows on the main stream; the other
+    // channels' front, nbp0 and AM detectors run beside it on a second stream (fork / join by events, which a launch-sequence
+    // capture records as graph edges).  BASELINE config 4: 1.20 -> 0.8 ms per call.
+    const bool split = n_fm > 0 && n_rest > 0 && D > 1 && !meters_on && !n_amsq && !n_snb[0] && !timing;
+    if (split) {
+        if (!side_stream) {
+            QH_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            QH_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            QH_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, nullptr, 0, 1)) return rc;      // tile table, every channel
+        QH_HIP(hipEventRecord(ev_fork, stream));
+        QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_fm, n_fm, 2)) return rc;
+        int hc = cur_nbp;
+        if (any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_fm, n_fm);
+        std::swap(stream, side_stream);
+        int rc2 = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_rest, n_rest, 2);
+        hc = cur_nbp;
+        if (!rc2 && any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rest, n_rest);
+        std::swap(stream, side_stream);
+        if (rc2) return rc2;
+        if (any_nbp) { cur_nbp ^= 1; std::swap(cur, other); }
+        if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, nullptr, 0, 3)) return rc;          // histories, oscillator phases
+    } else {
     if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid)) return rc;
     if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_adc,
                                       m_prm, (const int *)nullptr);
     if (any_nbp) {
         run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, cur_nbp, P, nullptr, 0);
         std::swap(cur, other);
+    }
     }
     if (meters_on) hipLaunchKernelGGL(meter_kernel, dim3((unsigned)nch), dim3(64), 0, stream, cur, buf_cap, nblk, dsp_size, m_s,
                                       m_prm, (const int *)nullptr);
@@ -1574,9 +1614,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // The AM / SAM detectors and the FM detector chain touch disjoint channel rows and disjoint state, and neither fills the
     // chip (one workgroup or wavefront per channel): with both kinds of channel in the call the AM side runs on a second
     // stream, forked and joined by events (which a launch-sequence capture records as graph edges).
-    const bool side = (n_am || n_sam) && n_fm;
+    const bool side = split || ((n_am || n_sam) && n_fm);
     hipStream_t am_stream = stream;
-    if (side) {
+    if (split) am_stream = side_stream;         // forked already: the AM detectors follow the other channels' filters there
+    else if (side) {
         if (!side_stream) {
             QH_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
             QH_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -1586,8 +1627,26 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
         am_stream = side_stream;
     }
-    if (n_am) hipLaunchKernelGGL((am_detect_tiled_kernel<false>), dim3((unsigned)n_am), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
-                                 list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL);
+    // Segment scans: one 16-wavefront workgroup per channel fills one CU.  With fewer channels of a kind than the chip has CUs the
+    // call is cut into 16 G segments, G workgroups per channel, pass 1 and pass 2 as two launches (qh_wave.hpp, MODE 1 / 2).
+    auto seg_groups = [&](int count) {
+        int G = count > 0 ? 256 / count : 1;
+        while (G > 1 && n_mid / (64LL * kSegWaves * G) < 8) G--;        // at least 8 batches of 64 samples per segment
+        return G < 1 ? 1 : G > kSegMaxGroups ? kSegMaxGroups : G;
+    };
+    for (double *&q : seg_sum)
+        if (!q) QH_HIP(dev_alloc(&q, (size_t)nch * kSegWaves * kSegMaxGroups * kSegSumW));
+    if (n_am) {
+        const int G = seg_groups(n_am + (n_mid >= kSamTiledMin ? n_sam0 : 0));
+        if (G > 1) {
+            hipLaunchKernelGGL((am_detect_tiled_kernel<false, 1>), dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
+                               (int)n_mid, list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, seg_sum[0]);
+            hipLaunchKernelGGL((am_detect_tiled_kernel<false, 2>), dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
+                               (int)n_mid, list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, seg_sum[0]);
+        } else
+            hipLaunchKernelGGL((am_detect_tiled_kernel<false, 0>), dim3((unsigned)n_am), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                               list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, (double *)nullptr);
+    }
     {
         // SAM without sideband separation in a long call: angles, the loop one tile per lane with a warm-up, verify / repair,
         // then the mix with the phase each sample saw and the fade leveller over time segments (qh_tiled.hpp).  The channels'
@@ -1615,8 +1674,18 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             hipLaunchKernelGGL((pll_verify_kernel<true>), dim3((unsigned)nt), dim3(64), 0, am_stream, (const double *)theta, 2 * buf_cap, pts,
                                2 * buf_cap, (int)n_mid, list_sam, pll_state, pll_ends, pll_ends_cap * 6, sam_pll_prm, kSamTile, kSamWarm,
                                pll_nfixed, pll_check_only);
-            hipLaunchKernelGGL((am_detect_tiled_kernel<true>), dim3((unsigned)nt), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
-                               list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap);
+            {
+                const int G = seg_groups(n_am + nt);
+                double *gs = seg_sum[0] + (size_t)n_am * kSegWaves * kSegMaxGroups * kSegSumW;       // behind the AM channels' rows
+                if (G > 1) {
+                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 1>), dim3((unsigned)nt, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
+                                       buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs);
+                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 2>), dim3((unsigned)nt, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
+                                       buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs);
+                } else
+                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 0>), dim3((unsigned)nt), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
+                                       (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, (double *)nullptr);
+            }
         }
         if (n_sam - nt) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)(n_sam - nt)), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,
                                            list_sam + nt, pll_state, sam_prm, sam_pll_prm, am_state);
@@ -1645,14 +1714,32 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             hipLaunchKernelGGL((pll_verify_kernel<false>), dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
                                2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * 6, fm_pll_prm, kFmTile, kFmWarm,
                                pll_nfixed, pll_check_only);
-            hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, (const double *)fil, 2 * buf_cap, cur,
-                               buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm);
+            {
+                const int G = seg_groups(n_fm);
+                if (G > 1) {
+                    hipLaunchKernelGGL((fm_dc_tiled_kernel<1>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
+                                       2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, seg_sum[1]);
+                    hipLaunchKernelGGL((fm_dc_tiled_kernel<2>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
+                                       2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, seg_sum[1]);
+                } else
+                    hipLaunchKernelGGL((fm_dc_tiled_kernel<0>), dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, (const double *)fil, 2 * buf_cap,
+                                       cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, (double *)nullptr);
+            }
         }
         run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm);      // de-emphasis
         run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_aud, 0, hist_aud, cur_aud, P, list_fm, n_fm);   // audio filter
         tick(1);
-        hipLaunchKernelGGL(snotch_tiled_kernel, dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
-                           sn_prm, sn_state);
+        {
+            const int G = seg_groups(n_fm);
+            if (G > 1) {
+                hipLaunchKernelGGL((snotch_tiled_kernel<1>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
+                                   list_fm, sn_prm, sn_state, seg_sum[2]);
+                hipLaunchKernelGGL((snotch_tiled_kernel<2>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
+                                   list_fm, sn_prm, sn_state, seg_sum[2]);
+            } else
+                hipLaunchKernelGGL((snotch_tiled_kernel<0>), dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
+                                   sn_prm, sn_state, (double *)nullptr);
+        }
         if (n_lim)      // detector limiter: lim_pre_gain 0.4, then its own wcpAGC (fmd.c:179-184)
             hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
                                lim_state, 0.4);

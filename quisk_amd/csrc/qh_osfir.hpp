@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
 
     if constexpr (OUTMIX) {
         static_assert(!MIX, "one oscillator");
-        const double2 tr = a.tile_rot[(long long)slot * a.ntiles + tile];       // workgroup-uniform: a scalar load
+        const double2 tr = a.tile_rot[(long long)ch * a.ntiles + tile];         // workgroup-uniform: a scalar load (rows by channel, also under a channel list)
         const double2 lr = a.lane_rot[(long long)ch * NT + t];
         const double2 st = a.nco_step[ch];
         C rot = cmul(mk<T>((T)tr.x, (T)tr.y), mk<T>((T)lr.x, (T)lr.y));

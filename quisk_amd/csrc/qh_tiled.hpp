@@ -31,59 +31,71 @@ namespace qh {
 // SAM (xamd mode 1 without sideband separation, amd.c:148-232): the detected value is the sample mixed with the VCO phase it
 // saw, corr0 = I cos(phs) + Q sin(phs) (amd.c:150-158,169), phs per sample from the time-tiled loop (pll_lanes_kernel<true>);
 // the fade leveller behind it is the AM one.
-template <bool SAM>
+template <bool SAM, int MODE = 0>
 static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                                              const int *levelfade, AmState *state, AmParam prm,
-                                                                             const double *pt = nullptr, long long ptstride = 0)
+                                                                             const double *pt = nullptr, long long ptstride = 0,
+                                                                             double *gsum = nullptr)
 {
-    __shared__ double s_e[kSegWaves][2];
-    __shared__ int s_n[kSegWaves];
+    __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = MODE == 0 ? kSegWaves : kSegWaves * (int)gridDim.y, sidx = MODE == 0 ? wave : (int)blockIdx.y * kSegWaves + wave;
+    double *sum = MODE == 0 ? s_sum : gsum + (long long)blockIdx.x * S * kSegSumW;
     double2 *p = buf + (long long)ch * stride;
     const double *ph = SAM ? pt + (long long)ch * ptstride : nullptr;
     const bool lf = levelfade[ch] != 0;
     int b0, b1;
-    seg_range(n, wave, b0, b1);
+    seg_range(n, sidx, b0, b1, S);
     const PoleScan sR = make_pole_scan(prm.mtauR, lane), sI = make_pole_scan(prm.mtauI, lane);
     // pass 1: the magnitudes (the output already when the leveller is off) and the segment's response to its own samples.
     // Only the END value is wanted here, so no scan: lane l keeps sum_b u[64 b + l] (m^64)^(B - 1 - b), one FMA per batch,
     // and one weighted wave sum closes the segment.  (The batch that is cut short by the end of the call belongs to the
     // last segment with samples, whose end value nobody reads.)
     const double m64R = lane_pow(prm.mtauR, 64), m64I = lane_pow(prm.mtauI, 64);
-    double accR = 0.0, accI = 0.0;
-    double2 zn[kSegGroup];
-    seg_load(zn, b0, b1, n, lane, p);
-    for (int b = b0; b < b1; b += kSegGroup) {
-        double2 z[kSegGroup];
+    if constexpr (MODE != 2) {
+        double accR = 0.0, accI = 0.0;
+        double2 zn[kSegGroup];
+        seg_load(zn, b0, b1, n, lane, p);
+        for (int b = b0; b < b1; b += kSegGroup) {
+            double2 z[kSegGroup];
 #pragma unroll
-        for (int k = 0; k < kSegGroup; k++) z[k] = zn[k];
-        seg_load(zn, b + kSegGroup, b1, n, lane, p);        // the next group is on its way while this one is worked on
+            for (int k = 0; k < kSegGroup; k++) z[k] = zn[k];
+            seg_load(zn, b + kSegGroup, b1, n, lane, p);        // the next group is on its way while this one is worked on
 #pragma unroll
-        for (int k = 0; k < kSegGroup; k++) {
-            if (b + k >= b1) break;                         // wave-uniform
-            const int i = (b + k) * 64 + lane;
-            double a;
-            if constexpr (SAM) {
-                double sn, cs;
-                sincos((i < n ? ph[i] : 0.0) * kTwoPiRef, &sn, &cs);
-                a = z[k].x * cs + z[k].y * sn;
-            } else a = sqrt(z[k].x * z[k].x + z[k].y * z[k].y);
-            if (i < n) p[i] = make_double2(a, a);
-            accR = __builtin_fma(accR, m64R, prm.onem_mtauR * a);
-            accI = __builtin_fma(accI, m64I, prm.onem_mtauI * a);
+            for (int k = 0; k < kSegGroup; k++) {
+                if (b + k >= b1) break;                         // wave-uniform
+                const int i = (b + k) * 64 + lane;
+                double a;
+                if constexpr (SAM) {
+                    double sn, cs;
+                    sincos((i < n ? ph[i] : 0.0) * kTwoPiRef, &sn, &cs);
+                    a = z[k].x * cs + z[k].y * sn;
+                } else a = sqrt(z[k].x * z[k].x + z[k].y * z[k].y);
+                if (i < n) p[i] = make_double2(a, a);
+                accR = __builtin_fma(accR, m64R, prm.onem_mtauR * a);
+                accI = __builtin_fma(accI, m64I, prm.onem_mtauI * a);
+            }
         }
-    }
-    if (!lf) return;                                    // block-uniform
-    const double eR = wave_sum_d(accR * lane_pow(prm.mtauR, 63 - lane)), eI = wave_sum_d(accI * lane_pow(prm.mtauI, 63 - lane));
-    if (lane == 0) { s_e[wave][0] = eR; s_e[wave][1] = eI; s_n[wave] = seg_samples(n, b0, b1); }
+        if (!lf) return;                                    // block-uniform
+        const double eR = wave_sum_d(accR * lane_pow(prm.mtauR, 63 - lane)), eI = wave_sum_d(accI * lane_pow(prm.mtauI, 63 - lane));
+        if (lane == 0) { sum[sidx * kSegSumW] = eR; sum[sidx * kSegSumW + 1] = eI; }
+        if constexpr (MODE == 1) return;
+    } else if (!lf) return;
     const double st_dc = state[ch].dc, st_dci = state[ch].dc_insert;     // read ahead of the barrier: the last wavefront stores the new carry at its end
-    __syncthreads();
-    // the true state at the start of this segment: dc <- mtau^len dc + e over the segments before it
+    if constexpr (MODE == 0) __syncthreads();
+    // the true state at the start of this segment: dc <- mtau^len dc + e over the segments before it (whole batches each: the
+    // ragged batch at the end of the call belongs to the last segment with samples)
     double cR = st_dc, cI = st_dci;
-    for (int w = 0; w < wave; w++) {
-        const double len = (double)s_n[w];
-        cR = __builtin_fma(cR, pow(prm.mtauR, len), s_e[w][0]);
-        cI = __builtin_fma(cI, pow(prm.mtauI, len), s_e[w][1]);
+    {
+        const int q = ((n + 63) >> 6) / S;                  // a segment has q or q + 1 batches
+        const double tR0 = pow(m64R, (double)q), tI0 = pow(m64I, (double)q), tR1 = tR0 * m64R, tI1 = tI0 * m64I;
+        SegWalk walk(n, S);
+        for (int w = 0; w < sidx; w++) {
+            const int nbw = walk.next();
+            if (nbw == 0) continue;
+            cR = __builtin_fma(cR, nbw == q ? tR0 : tR1, sum[w * kSegSumW]);
+            cI = __builtin_fma(cI, nbw == q ? tI0 : tI1, sum[w * kSegSumW + 1]);
+        }
     }
     // pass 2
     double an[kSegGroup];
@@ -105,9 +117,9 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
             cR = lane_bcast(dc, cnt - 1); cI = lane_bcast(di, cnt - 1);
         }
     }
-    int last = kSegWaves - 1;                           // the wavefront that holds the last sample of the call
-    while (last > 0 && s_n[last] == 0) last--;
-    if (wave == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+    int last = S - 1;                                   // the segment that holds the last sample of the call
+    while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
+    if (sidx == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
 }
 
 // ---- CTCSS notch (xsnotch, wdsp/iir.c:76-95): bi-quad on the I component, in place ------------------------------------
@@ -146,70 +158,84 @@ __device__ __forceinline__ void scan_biquad_dpp(double &u0, double &u1, const Bi
     biquad_step<0x143, 0xc>(u0, u1, s.pb);
 }
 
+template <int MODE = 0>
 static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                                          const SnotchParam *prm, SnotchState *state)
+                                                                          const SnotchParam *prm, SnotchState *state, double *gsum = nullptr)
 {
-    __shared__ double s_e[kSegWaves][2], s_x[kSegWaves][2];
-    __shared__ int s_n[kSegWaves];
+    __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x];
     const SnotchParam q = prm[ch];
     if (!q.run) return;                                 // block-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = MODE == 0 ? kSegWaves : kSegWaves * (int)gridDim.y, sidx = MODE == 0 ? wave : (int)blockIdx.y * kSegWaves + wave;
+    double *sum = MODE == 0 ? s_sum : gsum + (long long)blockIdx.x * S * kSegSumW;     // row: e0, e1, x[end - 1], x[end - 2]
     double2 *p = buf + (long long)ch * stride;
     const SnotchState st0 = state[ch];
     int b0, b1;
-    seg_range(n, wave, b0, b1);
+    seg_range(n, sidx, b0, b1, S);
     M2 A; A.a = q.b1; A.b = q.b2; A.c = 1.0; A.d = 0.0;
     const BiquadScan sc = make_biquad_scan(A, lane);
     // the forcing term needs x two samples back: from the buffer (pass 1 leaves it untouched), from the carried state at
     // the very beginning; pass 2 overwrites x with y, so every segment's last two inputs are put aside for its successor
     auto x_at = [&](int i) -> double { return i >= 0 ? p[i].x : (i == -1 ? st0.x1 : st0.x2); };
-    // pass 1: response of the zero state to the segment's forcing.  End value only: lane l keeps
-    // sum_b (A^64)^(B - 1 - b) (u[64 b + l], 0), and sum_l A^(63 - l) acc_l closes the segment.
     const M2 A64 = m2_pow(A, 64);
-    double acc0 = 0.0, acc1 = 0.0;
-    double xm1 = x_at(b0 * 64 - 1), xm2 = x_at(b0 * 64 - 2);
+    double xm1, xm2;
     double xn[kSegGroup];
-    seg_load_re(xn, b0, b1, n, lane, p);
-    for (int b = b0; b < b1; b += kSegGroup) {
-        double xv[kSegGroup];
+    if constexpr (MODE != 2) {
+        // pass 1: response of the zero state to the segment's forcing.  End value only: lane l keeps
+        // sum_b (A^64)^(B - 1 - b) (u[64 b + l], 0), and sum_l A^(63 - l) acc_l closes the segment.
+        double acc0 = 0.0, acc1 = 0.0;
+        xm1 = x_at(b0 * 64 - 1); xm2 = x_at(b0 * 64 - 2);
+        seg_load_re(xn, b0, b1, n, lane, p);
+        for (int b = b0; b < b1; b += kSegGroup) {
+            double xv[kSegGroup];
 #pragma unroll
-        for (int k = 0; k < kSegGroup; k++) xv[k] = xn[k];
-        seg_load_re(xn, b + kSegGroup, b1, n, lane, p);
+            for (int k = 0; k < kSegGroup; k++) xv[k] = xn[k];
+            seg_load_re(xn, b + kSegGroup, b1, n, lane, p);
 #pragma unroll
-        for (int k = 0; k < kSegGroup; k++) {
-            if (b + k >= b1) break;
-            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
-            const double x0 = xv[k];
-            double x1 = dpp_fetch_d<0x138, 0xf>(x0), x2 = dpp_fetch_d<0x138, 0xf>(x1);    // wave_shr:1, twice
-            if (lane == 0) { x1 = xm1; x2 = xm2; }
-            if (lane == 1) x2 = xm1;
-            const double u = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0;
-            const double t0 = A64.a * acc0 + A64.b * acc1 + u, t1 = A64.c * acc0 + A64.d * acc1;
-            acc0 = t0; acc1 = t1;
-            const double prev1 = xm1;
-            xm1 = lane_bcast(x0, cnt - 1);
-            xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
+            for (int k = 0; k < kSegGroup; k++) {
+                if (b + k >= b1) break;
+                const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+                const double x0 = xv[k];
+                double x1 = dpp_fetch_d<0x138, 0xf>(x0), x2 = dpp_fetch_d<0x138, 0xf>(x1);    // wave_shr:1, twice
+                if (lane == 0) { x1 = xm1; x2 = xm2; }
+                if (lane == 1) x2 = xm1;
+                const double u = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0;
+                const double t0 = A64.a * acc0 + A64.b * acc1 + u, t1 = A64.c * acc0 + A64.d * acc1;
+                acc0 = t0; acc1 = t1;
+                const double prev1 = xm1;
+                xm1 = lane_bcast(x0, cnt - 1);
+                xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
+            }
         }
+        const M2 W = m2_pow(A, 63 - lane);
+        const double e0 = wave_sum_d(W.a * acc0 + W.b * acc1), e1 = wave_sum_d(W.c * acc0 + W.d * acc1);
+        const int ns = seg_samples(n, b0, b1);
+        if (lane == 0) {
+            const int end = b0 * 64 + ns;                   // one past the segment's last sample
+            double *row = sum + sidx * kSegSumW;
+            row[0] = e0; row[1] = e1;
+            row[2] = ns > 0 ? x_at(end - 1) : 0.0; row[3] = ns > 0 ? x_at(end - 2) : 0.0;
+        }
+        if constexpr (MODE == 1) return;
     }
-    const M2 W = m2_pow(A, 63 - lane);
-    const double e0 = wave_sum_d(W.a * acc0 + W.b * acc1), e1 = wave_sum_d(W.c * acc0 + W.d * acc1);
-    const int ns = seg_samples(n, b0, b1);
-    if (lane == 0) {
-        const int end = b0 * 64 + ns;                   // one past the segment's last sample
-        s_e[wave][0] = e0; s_e[wave][1] = e1; s_n[wave] = ns;
-        s_x[wave][0] = ns > 0 ? x_at(end - 1) : 0.0; s_x[wave][1] = ns > 0 ? x_at(end - 2) : 0.0;
-    }
-    __syncthreads();
+    if constexpr (MODE == 0) __syncthreads();
     // true (y_{-1}, y_{-2}) and (x_{-1}, x_{-2}) at the start of this segment
     double c0 = st0.y1, c1 = st0.y2;
     xm1 = st0.x1; xm2 = st0.x2;
-    for (int w = 0; w < wave; w++) {
-        if (s_n[w] == 0) continue;
-        const M2 T = m2_pow(A, s_n[w]);
-        const double n0 = T.a * c0 + T.b * c1 + s_e[w][0], n1 = T.c * c0 + T.d * c1 + s_e[w][1];
-        c0 = n0; c1 = n1;
-        xm1 = s_x[w][0]; xm2 = s_x[w][1];
+    {
+        const int qb = ((n + 63) >> 6) / S;
+        const M2 T0 = m2_pow(A64, qb), T1 = mmul(A64, T0);
+        SegWalk walk(n, S);
+        for (int w = 0; w < sidx; w++) {
+            const int nbw = walk.next();
+            if (nbw == 0) continue;
+            const M2 T = nbw == qb ? T0 : T1;
+            const double *row = sum + w * kSegSumW;
+            const double n0 = T.a * c0 + T.b * c1 + row[0], n1 = T.c * c0 + T.d * c1 + row[1];
+            c0 = n0; c1 = n1;
+            xm1 = row[2]; xm2 = row[3];
+        }
     }
     // pass 2 (every segment's boundary inputs were put aside before the barrier above: in-place writes are safe now)
     seg_load_re(xn, b0, b1, n, lane, p);
@@ -236,9 +262,9 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
             xm2 = cnt >= 2 ? lane_bcast(x0, cnt - 2) : prev1;
         }
     }
-    int last = kSegWaves - 1;
-    while (last > 0 && s_n[last] == 0) last--;
-    if (wave == last && lane == 0 && n > 0) { SnotchState st; st.x1 = xm1; st.x2 = xm2; st.y1 = c0; st.y2 = c1; state[ch] = st; }
+    int last = S - 1;
+    while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
+    if (sidx == last && lane == 0 && n > 0) { SnotchState st; st.x1 = xm1; st.x2 = xm2; st.y1 = c0; st.y2 = c1; state[ch] = st; }
 }
 
 // ---- FM discriminator (xfmd's loop, wdsp/fmd.c:151-172) ---------------------------------------------------------------
@@ -484,40 +510,54 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
 
 // dc removal and gain of xfmd (fmd.c:169-171): fmdc <- mtau fmdc + onem_mtau fil ; audio = again (fil - fmdc), written as
 // (audio, audio).  Same two-pass segment scheme as the AM leveller; fil is a real array, out the channel's complex row.
+template <int MODE = 0>
 static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const double *fil, long long fstride, double2 *out, long long stride,
                                                                          int n, const int *chan_list, PllState *state, const double *again,
-                                                                         PllParam q)
+                                                                         PllParam q, double *gsum = nullptr)
 {
-    __shared__ double s_e[kSegWaves];
-    __shared__ int s_n[kSegWaves];
+    __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = MODE == 0 ? kSegWaves : kSegWaves * (int)gridDim.y, sidx = MODE == 0 ? wave : (int)blockIdx.y * kSegWaves + wave;
+    double *sum = MODE == 0 ? s_sum : gsum + (long long)blockIdx.x * S * kSegSumW;
     const double *f = fil + (long long)ch * fstride;
     double2 *p = out + (long long)ch * stride;
     int b0, b1;
-    seg_range(n, wave, b0, b1);
+    seg_range(n, sidx, b0, b1, S);
     const PoleScan sc = make_pole_scan(q.mtau, lane);
-    // pass 1: end value only (see the AM leveller)
     const double m64 = lane_pow(q.mtau, 64);
-    double acc = 0.0;
     double fn[kSegGroup];
-    seg_load(fn, b0, b1, n, lane, f);
-    for (int b = b0; b < b1; b += kSegGroup) {
-        double fv[kSegGroup];
+    if constexpr (MODE != 2) {
+        // pass 1: end value only (see the AM leveller)
+        double acc = 0.0;
+        seg_load(fn, b0, b1, n, lane, f);
+        for (int b = b0; b < b1; b += kSegGroup) {
+            double fv[kSegGroup];
 #pragma unroll
-        for (int k = 0; k < kSegGroup; k++) fv[k] = fn[k];
-        seg_load(fn, b + kSegGroup, b1, n, lane, f);
+            for (int k = 0; k < kSegGroup; k++) fv[k] = fn[k];
+            seg_load(fn, b + kSegGroup, b1, n, lane, f);
 #pragma unroll
-        for (int k = 0; k < kSegGroup; k++) {
-            if (b + k >= b1) break;
-            acc = __builtin_fma(acc, m64, q.onem_mtau * fv[k]);
+            for (int k = 0; k < kSegGroup; k++) {
+                if (b + k >= b1) break;
+                acc = __builtin_fma(acc, m64, q.onem_mtau * fv[k]);
+            }
+        }
+        const double e = wave_sum_d(acc * lane_pow(q.mtau, 63 - lane));
+        if (lane == 0) sum[sidx * kSegSumW] = e;
+        if constexpr (MODE == 1) return;
+    }
+    const double c_in = state[ch].fmdc;                  // ahead of the barrier: the last wavefront stores the new carry at its end
+    if constexpr (MODE == 0) __syncthreads();
+    double c = c_in;
+    {
+        const int qb = ((n + 63) >> 6) / S;
+        const double t0 = pow(m64, (double)qb), t1 = t0 * m64;
+        SegWalk walk(n, S);
+        for (int w = 0; w < sidx; w++) {
+            const int nbw = walk.next();
+            if (nbw == 0) continue;
+            c = __builtin_fma(c, nbw == qb ? t0 : t1, sum[w * kSegSumW]);
         }
     }
-    const double e = wave_sum_d(acc * lane_pow(q.mtau, 63 - lane));
-    if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); }
-    const double c_in = state[ch].fmdc;                  // ahead of the barrier: the last wavefront stores the new carry at its end
-    __syncthreads();
-    double c = c_in;
-    for (int w = 0; w < wave; w++) c = __builtin_fma(c, pow(q.mtau, (double)s_n[w]), s_e[w]);
     const double gain = again[ch];
     seg_load(fn, b0, b1, n, lane, f);
     for (int b = b0; b < b1; b += kSegGroup) {
@@ -535,9 +575,9 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
             c = lane_bcast(dcs, cnt - 1);
         }
     }
-    int last = kSegWaves - 1;
-    while (last > 0 && s_n[last] == 0) last--;
-    if (wave == last && lane == 0 && n > 0) state[ch].fmdc = c;
+    int last = S - 1;
+    while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
+    if (sidx == last && lane == 0 && n > 0) state[ch].fmdc = c;
 }
 
 }  // namespace qh

@@ -120,16 +120,44 @@ __device__ __forceinline__ double scan_pole_dpp(double u, const PoleScan &p)
 }
 
 // the segment of wavefront `wave`: batches of 64 samples [b0, b1) of the ceil(n / 64) in the call
-__device__ __forceinline__ void seg_range(int n, int wave, int &b0, int &b1)
+__device__ __forceinline__ void seg_range(int n, int wave, int &b0, int &b1, int nseg = kSegWaves)
 {
     const int nb = (n + 63) >> 6;
-    b0 = (int)((long long)wave * nb / kSegWaves);
-    b1 = (int)((long long)(wave + 1) * nb / kSegWaves);
+    b0 = (int)((long long)wave * nb / nseg);
+    b1 = (int)((long long)(wave + 1) * nb / nseg);
 }
+// Segment kernels over SEVERAL workgroups per channel.  One workgroup = 16 wavefronts = 16 time segments fills one CU; a call
+// with fewer channels than the chip has CUs (BASELINE config 4: 85 FM channels) leaves two thirds of them idle.  With G
+// workgroups per channel (grid = channels x G, segment index 16 g + wave of S = 16 G) the two passes become two launches:
+//   MODE 1  pass 1 only: every segment's response to its own samples from a zero state -> summary row in global memory
+//   MODE 2  chains the summaries of the segments before its own (S - 1 at most, read from global memory) and runs pass 2
+//   MODE 0  the one-launch form (G = 1, summaries in LDS, a barrier between the passes)
+// kSegSumW doubles per summary; row (slot * S + sidx).
+static constexpr int kSegSumW = 6;
+static constexpr int kSegMaxGroups = 8;
+// Batches of segment w = floor((w + 1) nb / S) - floor(w nb / S), walked in order without a division per segment: q = nb / S each,
+// one more whenever the running remainder wraps (SegWalk w; ... w.next() for segments 0, 1, 2, ...).
+struct SegWalk {
+    int q, r, S, acc;
+    __device__ __forceinline__ SegWalk(int n, int nseg) : q(((n + 63) >> 6) / nseg), r(((n + 63) >> 6) % nseg), S(nseg), acc(0) {}
+    __device__ __forceinline__ int next()
+    {
+        acc += r;
+        const int extra = acc >= S ? 1 : 0;
+        acc -= extra ? S : 0;
+        return q + extra;
+    }
+};
 __device__ __forceinline__ int seg_samples(int n, int b0, int b1)
 {
     const int lo = b0 * 64 < n ? b0 * 64 : n, hi = b1 * 64 < n ? b1 * 64 : n;
     return hi - lo;
+}
+__device__ __forceinline__ int seg_samples_of(int n, int w, int nseg)
+{
+    int b0, b1;
+    seg_range(n, w, b0, b1, nseg);
+    return seg_samples(n, b0, b1);
 }
 
 // Batches in flight per wavefront: a segment is walked in groups of kSegGroup batches, the next group's loads issued ahead
