@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=1,
                     help="split a step into this many consecutive time chunks (engine calls); the intermediate "
                          "buffer of a chunk then stays in the 256 MiB Infinity Cache")
+    ap.add_argument("--band-tile", type=int, default=0, help="tile of the fircore (nbp0) stage: 0 = the engine's default, 4096, 6144 or 8192")
     ap.add_argument("--ingest", choices=["f64", "le24"], default="f64",
                     help="f64: complex double input resident in HBM (the BASELINE workload); le24: the same signal as "
                          "24-bit little-endian IQ bytes (quisk_read_rx_udp wire format), decoded in the front kernel's load")
@@ -277,6 +278,8 @@ def main():
     eng.SetRXAAGCMode(-1, 0)
     eng.SetRXAAGCFixed(-1, 0.0)
     eng.enable_meters(args.meters == "on")
+    if args.band_tile and not dry:
+        eng.set_band_tile(args.band_tile)
 
     if dry:
         x = torch.zeros((nch, 8), dtype=torch.complex128)

@@ -246,7 +246,10 @@ static __global__ __launch_bounds__(kMeterFinishThreads) void meter_finish_kerne
     for (int s0 = T; s0 < nslots; s0 += kMeterFinishThreads) {
         const int tile = s0 / cpt, in = s0 - tile * cpt;
         int c;
-        if (layout == 0) c = tile * cpt + 4 * (in % nseg) + in / nseg;  // [wave][register] -> chunk 4 register + wave
+        if (layout == 2) {                                              // 6144-point tile on six wavefronts (osfir6k_kernel): chunk 6 r + w - 32
+            const int w = in < 20 ? in / 10 : 2 + (in - 20) / 11, r = in < 20 ? 6 + in % 10 : 5 + (in - 20) % 11;
+            c = tile * cpt + 6 * r + w - 32;
+        } else if (layout == 0) c = tile * cpt + 4 * (in % nseg) + in / nseg;  // [wave][register] -> chunk 4 register + wave
         else if (in < 32) c = tile * cpt + 32 + 4 * (in & 7) + (in >> 3);      // two-group tile (osfir8k_kernel): group A, registers 8 .. 15
         else {                                                                  // group B: [wave][16 registers], the upper eight 4096 samples on
             const int w = (in - 32) >> 4, k = (in - 32) & 15;

@@ -242,12 +242,34 @@ std::vector<cd> mp_imp(const std::vector<cd> &fir, int pfactor, int polarity)
     return out;
 }
 
+// forward DFT of 3 * 2^k points: the three decimated sequences x[3 m + a] by host_fft, then X[k + M q] = sum_a W_N^(a (k + M q)) F_a[k]
+static void host_fft_3x(std::vector<cd> &x)
+{
+    const int N = (int)x.size(), M = N / 3;
+    std::vector<cd> f[3];
+    for (int a = 0; a < 3; a++) {
+        f[a].resize((size_t)M);
+        for (int m = 0; m < M; m++) f[a][(size_t)m] = x[(size_t)(3 * m + a)];
+        host_fft(f[a], -1);
+    }
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int k = 0; k < N; k++) {
+        std::complex<long double> acc(0, 0);
+        for (int a = 0; a < 3; a++) {
+            const long double ang = -2.0L * pi * (long double)(((long long)a * k) % N) / (long double)N;
+            acc += std::complex<long double>(f[a][(size_t)(k % M)]) * std::complex<long double>(cosl(ang), sinl(ang));
+        }
+        x[(size_t)k] = cd((double)acc.real(), (double)acc.imag());
+    }
+}
+
 std::vector<cd> make_mask(const std::vector<cd> &h, int nfft)
 {
     if ((int)h.size() > nfft) throw std::runtime_error("make_mask: impulse longer than the FFT");
     std::vector<cd> m((size_t)nfft, cd(0, 0));
     for (size_t i = 0; i < h.size(); i++) m[i] = h[i];
-    host_fft(m, -1);
+    if (nfft % 3 == 0) host_fft_3x(m);
+    else host_fft(m, -1);
     const double s = 1.0 / (double)nfft;
     for (auto &v : m) v *= s;
     return m;

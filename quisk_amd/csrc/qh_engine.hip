@@ -150,6 +150,7 @@ struct Engine {
     double2 *tw4096 = nullptr, *tw_inv_front = nullptr, *tw8192 = nullptr;
     int bnfft = kNfft;                      // tile size of the fircore stages: what their masks are built for (4096 or 8192)
     bool band2g = false;                    // 8192-point tiles shared by two lane groups (osfir8k_kernel): masks stored [even | odd]
+    bool band6k = false;                    // 6144-point tiles on 384 lanes (osfir6k_kernel)
     int band_tile_pref = 0;                 // qh_rxa_set_band_tile: 0 / 4096: 4096-point tiles, 8192: the two-group tiles
     std::vector<cd> band_mask(const std::vector<cd> &h) const;
     unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr, *nco_parked = nullptr;
@@ -420,6 +421,10 @@ int Engine::init()
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<double, kBandNfftMax, 1, true>())))
     QH_SET_LDS8(false, false, false); QH_SET_LDS8(true, false, false); QH_SET_LDS8(false, false, true); QH_SET_LDS8(true, false, true);
 #undef QH_SET_LDS8
+#define QH_SET_LDS6K(...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir6k_kernel<__VA_ARGS__>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, osfir6k_lds_bytes()))
+    QH_SET_LDS6K(false, false); QH_SET_LDS6K(true, false); QH_SET_LDS6K(false, true); QH_SET_LDS6K(true, true);
+#undef QH_SET_LDS6K
 #define QH_SET_LDS2G(...) QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8k_kernel<__VA_ARGS__>), \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, osfir8k_lds_bytes()))
     QH_SET_LDS2G(false, false); QH_SET_LDS2G(true, false); QH_SET_LDS2G(false, true); QH_SET_LDS2G(true, true);
@@ -1272,6 +1277,17 @@ static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s,
     else launch_osfir<1, false, false, false, false, false, NFFT>(a, ntiles, nch, s);
 }
 
+static void launch_band6k(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
+{
+    a.ntiles = ntiles;
+    dim3 grid((unsigned)ntiles * (unsigned)nch), block(kOsfir6kThreads);
+    constexpr int lds = osfir6k_lds_bytes();
+    if (meter && egress) hipLaunchKernelGGL((osfir6k_kernel<true, true>), grid, block, lds, s, a);
+    else if (meter) hipLaunchKernelGGL((osfir6k_kernel<true, false>), grid, block, lds, s, a);
+    else if (egress) hipLaunchKernelGGL((osfir6k_kernel<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((osfir6k_kernel<false, false>), grid, block, lds, s, a);
+}
+
 static void launch_band2g(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
 {
     a.ntiles = ntiles;
@@ -1406,7 +1422,8 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
-    if (band2g) launch_band2g(a, ntiles, nl, stream, meter, egress);
+    if (band6k) launch_band6k(a, ntiles, nl, stream, meter, egress);
+    else if (band2g) launch_band2g(a, ntiles, nl, stream, meter, egress);
     else if (bnfft == kNfft) launch_band<kNfft>(a, ntiles, nl, stream, meter, egress);
     else launch_band<kBandNfftMax>(a, ntiles, nl, stream, meter, egress);
     tick(2);
@@ -1475,9 +1492,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         // spectra of the tile size, so a change rebuilds every one of them (the delay lines, kept 4095 samples deep, carry over).
         static const bool force8k = [] { const char *e = std::getenv("QH_BAND_NFFT"); return e && std::atoi(e) == 8192; }();  // tuning experiments
         const bool two_group = nc_max <= 2048 && band_tile_pref == 8192 && !force8k;
-        const int want = (nc_max > 2048 || force8k || two_group) ? kBandNfftMax : kNfft;
-        if (want != bnfft || two_group != band2g) {
-            bnfft = want; band2g = two_group;
+        const bool six_k = nc_max <= 2048 && band_tile_pref == 6144 && !force8k;
+        const int want = six_k ? kOsfir6kN : (nc_max > 2048 || force8k || two_group) ? kBandNfftMax : kNfft;
+        if (want != bnfft || two_group != band2g || six_k != band6k) {
+            bnfft = want; band2g = two_group; band6k = six_k;
             for (ChanCfg &c : cfg) { c.nbp_dirty = c.bp1_dirty = true; c.snb_dirty = true; }
         }
     }
@@ -1499,7 +1517,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
 
     const double2 *in = reinterpret_cast<const double2 *>(d_in);
     double2 *out = reinterpret_cast<double2 *>(d_out);
-    const int P = band2g ? kOsfir8kP : meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
+    const int P = band6k ? kOsfir6kP : band2g ? kOsfir8kP : meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
 
     // audio egress (qh_rxa_process_audio): the narrowing rides in the store of the last kernel when that is an overlap-save
     // band stage or the per-mode path's output pass; other endings write complex doubles to the staging rows and narrow after
@@ -1539,7 +1557,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         }
         if (meters_fused)
             hipLaunchKernelGGL(meter_finish_kernel, dim3((unsigned)nch), dim3(kMeterFinishThreads), 0, stream, m_part[0], m_part[1],
-                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, band2g ? 1 : 0, m_adc, m_s, m_agc,
+                               m_part_cap, (int)(n_mid / 64), dsp_size / 64, (bnfft - P) / 64, band6k ? 2 : band2g ? 1 : 0, m_adc, m_s, m_agc,
                                -1.0 / ((double)dsp_rate * 0.100), -1.0 / ((double)dsp_rate * 0.100), (const double *)m_g2);
         if (eg.kind && !eg_fused) pack_audio(out, out_stride, n_mid);
         tick(3);
@@ -2383,7 +2401,7 @@ long long qh_rxa_graph_launches(const qh_rxa *h) { return h ? h->e.graph_launche
 
 int qh_rxa_set_band_tile(qh_rxa *h, int nfft)
 {
-    if (!h || (nfft != 0 && nfft != 4096 && nfft != 8192)) return set_error(QH_ERR_INVALID, "qh_rxa_set_band_tile: 0 (default), 4096 or 8192");
+    if (!h || (nfft != 0 && nfft != 4096 && nfft != 6144 && nfft != 8192)) return set_error(QH_ERR_INVALID, "qh_rxa_set_band_tile: 0 (default), 4096, 6144 or 8192");
     QH_RXA_LOCK(h);
     h->e.band_tile_pref = nfft;
     return QH_OK;

@@ -586,6 +586,91 @@ __global__ __launch_bounds__(kOsfir8kThreads, 4) void osfir8k_kernel(OsfirArgs<d
     }
 }
 
+// ---- D = 1 stage on 6144-point tiles, 384 lanes ---------------------------------------------------------------------------
+// The 16 x 24 x 16 plan of qh_fft.hpp (Fft6144): 16 elements per lane like the 4096-point kernel, 4096 outputs per pair of
+// transforms instead of 2049 (P = 2048: whole 64-sample chunks, so the fused meters keep one chunk per wavefront and register).
+// Lane t holds tile elements t + 384 r; the new samples begin at element 2048 = register 5 of wavefronts 2 .. 5, register 6 of
+// wavefronts 0 and 1 (the meter taps take a per-wavefront first register).  Mask: the 6144-point spectrum in natural order.
+constexpr int kOsfir6kThreads = kFft6kThreads, kOsfir6kP = 2048, kOsfir6kLout = 4096, kOsfir6kN = 6144;
+constexpr int osfir6k_lds_bytes()
+{
+    constexpr int m = kOsfir6kThreads / 64 * kMeterLdsDoublesPerWave * 8;
+    return kFft6kLdsBytes > m ? kFft6kLdsBytes : m;
+}
+
+template <bool METER, bool EGRESS>
+__global__ __launch_bounds__(kOsfir6kThreads, 3) void osfir6k_kernel(OsfirArgs<double> a)
+{
+    using C = double2;
+    constexpr int N = kOsfir6kN, P = kOsfir6kP, L = kOsfir6kLout, TH = kOsfir6kThreads;
+    extern __shared__ __align__(16) unsigned char smem6k[];
+    const int t = threadIdx.x;
+    int tile, slot;
+    xcd_tile_map(a.ntiles, slot, tile);
+    const int ch = a.chan_list ? a.chan_list[slot] : slot;
+    const C *in = a.in + (long long)ch * a.in_stride;
+    const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
+    const int g0 = a.off - P + tile * L;
+
+    C x[16];
+    if (g0 >= 0 && g0 + N <= a.n_in) {                  // workgroup-uniform
+        const C *p = in + g0 + t;
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = p[TH * r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int gi = g0 + t + TH * r;
+            C v = make_double2(0.0, 0.0);
+            if (gi >= 0) { if (gi < a.n_in) v = in[gi]; }
+            else if (hist && gi + a.hist_len >= 0) v = hist[gi + a.hist_len];
+            x[r] = v;
+        }
+    }
+    // meter taps: wavefront w's chunks are elements 64 w + 384 r; new from register 5 (w >= 2) or 6 (w < 2).  A tile's 64
+    // partials are stored [w = 0: 10][w = 1: 10][w = 2: 11] .. [w = 5: 11] (meter_finish_kernel, layout 2)
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r0 = wv < 2 ? 6 : 5, moff = wv < 2 ? 10 * wv : 20 + 11 * (wv - 2);
+    if constexpr (METER) {
+        double *blk = reinterpret_cast<double *>(smem6k) + wv * kMeterLdsDoublesPerWave;
+        meter_tap<C, 16>(x, r0, a.meter_w[t & 63], blk, a.meter_in + (long long)ch * a.meter_stride + (long long)tile * (L >> 6) + moff, 0, t & 63);
+        __syncthreads();
+    }
+    Fft6144<false>::run(x, smem6k, Fft6144<false>::load(t), t);
+
+    const C *mask = a.mask + (long long)ch * a.mask_stride;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        x[r] = cmul(x[r], mask[t + TH * r]);
+        if ((r + 1) % QH_MASK_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    Fft6144<true>::run(x, smem6k, Fft6144<true>::load(t), t);
+    if constexpr (METER) {
+        __syncthreads();
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+        double *blk = reinterpret_cast<double *>(smem6k) + wv * kMeterLdsDoublesPerWave;
+        meter_tap<C, 16>(x, r0, a.meter_w[t2 & 63], blk, a.meter_out + (long long)ch * a.meter_stride + (long long)tile * (L >> 6) + moff, 0, t2 & 63);
+    }
+
+    C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
+    EpiParam ep;
+    if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+#pragma unroll
+    for (int r = 5; r < 16; r++) {
+        const int rel = t + TH * r - P;
+        const long long m = (long long)tile * L + rel;
+        if (rel >= 0 && m < a.n_out) {
+            C v;
+            v.x = ep.a * x[r].x + ep.b * x[r].y;
+            v.y = ep.c * x[r].x + ep.d * x[r].y;
+            if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, v.x, v.y);
+            else out[m] = v;
+        }
+    }
+}
+
 // Interpolating overlap-save FIR:  y[n] = sum_m h[m] * u[n - m],  u[U*i] = x[i], zero elsewhere  -- the audio-rate
 // interpolators quisk_dInterpolate / quisk_cInterpolate / quisk_*Interp2HB45 (filter.c:131-201,420-488; the gain
 // factor `interp` is folded into the taps).  Zero stuffing replicates the spectrum, so the tile takes an FFT of

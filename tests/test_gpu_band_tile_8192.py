@@ -1,4 +1,5 @@
-"""The fircore stages on 8192-point tiles shared by two lane groups (osfir8k_kernel, quisk_amd/csrc/qh_osfir.hpp): one radix-2
+"""The fircore stages on the other tile shapes -- 6144 points on 384 lanes (osfir6k_kernel: 16 x 24 x 16 plan, 4096 outputs per tile) and
+8192-point tiles shared by two lane groups (osfir8k_kernel, quisk_amd/csrc/qh_osfir.hpp): one radix-2
 step in registers, a half-tile hand-over between the groups, two 4096-point transforms side by side; 6144 outputs per tile
 instead of 2049 (selectable, not the default: it measured slower).  Against the oracle, against the 4096-point tile, with
 the fused meters, across switches between calls, and in the
@@ -36,33 +37,35 @@ def _oracle(po, c, nc=None, agc_db=0.0, mode=1, passband=(300.0, 3000.0), dsp_si
     return o
 
 
+@pytest.mark.parametrize("big", [8192, 6144])
 @pytest.mark.parametrize("nc", [None, 256, 1024])
-def test_ssb_chain_ragged_calls_against_the_oracle_and_the_4096_tile(qh, oracle, nc):
+def test_ssb_chain_ragged_calls_against_the_oracle_and_the_4096_tile(qh, oracle, nc, big):
     nch = 4
     calls = [30, 1, 7, 50, 2, 24]                    # 7680 ... 256 DSP-rate samples: less than a tile, one, several
     x = synth.make_input_numpy(nch, sum(calls) * 1024)
     e8 = qh.RxaEngine(nch); e4 = qh.RxaEngine(nch)
     _setup(e8, nch, nc); _setup(e4, nch, nc)
-    e8.set_band_tile(8192); e4.set_band_tile(4096)
+    e8.set_band_tile(big); e4.set_band_tile(4096)
     outs8, outs4, pos = [], [], 0
     for nb in calls:
         seg = np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024])
         outs8.append(e8.process_host(seg)); outs4.append(e4.process_host(seg))
         pos += nb
-    assert e8.band_tile() == 8192 and e4.band_tile() == 4096
+    assert e8.band_tile() == big and e4.band_tile() == 4096
     y8, y4 = np.concatenate(outs8, axis=1), np.concatenate(outs4, axis=1)
     assert rel_rms(y8, y4) < 1e-12
     for c in range(nch):
         assert rel_rms(y8[c], _oracle(oracle, c, nc).xrxa(x[c])) < 1e-9, c
 
 
-def test_fused_meters_on_the_two_group_tile(qh, oracle):
+@pytest.mark.parametrize("big", [8192, 6144])
+def test_fused_meters_on_the_two_group_tile(qh, oracle, big):
     nch = 3
     calls = [8, 3, 21, 1, 40, 30]
     x = synth.make_input_numpy(nch, sum(calls) * 1024)
     e = qh.RxaEngine(nch)
     _setup(e, nch, agc_db=6.0)
-    e.set_band_tile(8192)
+    e.set_band_tile(big)
     e.enable_meters(True)
     refs = [_oracle(oracle, c, agc_db=6.0) for c in range(nch)]
     pos = 0
@@ -79,7 +82,7 @@ def test_fused_meters_on_the_two_group_tile(qh, oracle):
 
 def test_switching_tiles_between_calls_keeps_the_delay_lines(qh, oracle):
     nch = 2
-    calls = [(5, 0), (9, 8192), (40, 8192), (3, 4096), (30, 8192)]
+    calls = [(5, 0), (9, 8192), (40, 6144), (3, 4096), (30, 8192), (17, 6144)]
     x = synth.make_input_numpy(nch, sum(nb for nb, _ in calls) * 1024)
     e = qh.RxaEngine(nch)
     _setup(e, nch)
@@ -89,7 +92,7 @@ def test_switching_tiles_between_calls_keeps_the_delay_lines(qh, oracle):
         outs.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024])))
         tiles.append(e.band_tile())
         pos += nb
-    assert tiles == [4096, 8192, 8192, 4096, 8192]
+    assert tiles == [4096, 8192, 6144, 4096, 8192, 6144]
     y = np.concatenate(outs, axis=1)
     for c in range(nch):
         assert rel_rms(y[c], _oracle(oracle, c).xrxa(x[c])) < 1e-9
@@ -101,10 +104,10 @@ def test_per_mode_path_every_fircore_stage(qh, mode, sig, passband):
     nch, nblk = 3, 150
     x = np.stack([synth.make_mode_input_numpy(sig, c, nblk * 1024) for c in range(nch)])
     ys = []
-    for tile in (4096, 8192):
+    for tile in (4096, 8192, 6144):
         e = qh.RxaEngine(nch)
         _setup(e, nch, mode=mode, passband=passband)
         e.set_band_tile(tile)
         ys.append(np.concatenate([e.process_host(np.ascontiguousarray(x[:, k * 1024:(k + 50) * 1024])) for k in (0, 50, 100)], axis=1))
     settle = 120 * 256 if mode == 5 else 0           # FM: the loop's start-up depends on the transform's last bit
-    assert rel_rms(ys[0][:, settle:], ys[1][:, settle:]) < 1e-8
+    assert rel_rms(ys[0][:, settle:], ys[1][:, settle:]) < 1e-8 and rel_rms(ys[0][:, settle:], ys[2][:, settle:]) < 1e-8
