@@ -51,6 +51,15 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def _trace(what):
+    """--dry-run plumbing tests only: with QH_BENCH_TRACE=<file> every rank appends `rank what unix-time` lines (who built, when each
+    rank left its warm-up, entered and left the timed region), which tests/test_bench_plumbing.py reads back."""
+    f = os.environ.get("QH_BENCH_TRACE")
+    if f:
+        with open(f, "a") as fh:
+            fh.write("%s %s %.6f\n" % (os.environ.get("RANK", "0"), what, time.time()))
+
+
 class DryEngine:
     """--dry-run only (tests/test_bench_plumbing.py): stands where RxaEngine stands so that the argument / rank / channel
     split / barrier / max-over-ranks / JSON plumbing of this file can run in CPU processes.  It does no DSP; a line made
@@ -228,6 +237,8 @@ def main():
     if dry:
         dev = torch.device("cpu")
         sync = lambda: None
+        if rank == 0:
+            _trace("build")             # where the real run builds the library: rank 0 only, ahead of the first barrier
     else:
         from quisk_amd import build as qbuild
         if not torch.cuda.is_available():
@@ -315,16 +326,20 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
+        _trace("warm_done")
         if world > 1:
             dist.barrier()
         sync()
+        _trace("timed_start")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
+        _trace("steps_done")
         if world > 1:
             dist.barrier()
         sync()
+        _trace("timed_end")
         return shard.max_over_ranks(time.perf_counter() - t0, dev if not dry else None)
 
     dt = timed_run()                    # the measurement `value` reports

@@ -19,11 +19,13 @@ def _free_port():
     return p
 
 
-def _launch(world, extra):
+def _launch(world, extra, trace=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if trace:
+            env["QH_BENCH_TRACE"] = trace
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run", "--backend", "gloo",
                                        "--steps", "4", "--warmup", "1", "--log2-samples", "12"] + extra,
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -64,3 +66,35 @@ def test_single_process_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["dry_run"] is True and j["scaling"] == "weak"
+
+
+def _read_trace(path):
+    ev = {}
+    for line in open(path):
+        r, what, t = line.split()
+        ev.setdefault(what, {}).setdefault(int(r), []).append(float(t))
+    return ev
+
+
+def test_eight_ranks_strong_256_and_weak_2048(tmp_path):
+    """The driver's 8-GPU shapes on eight gloo ranks: north_star's 256 channels over 8 GPUs (32 each, strong) and BASELINE config 4's
+    2048 (256 each, weak).  Rank 0 alone is where the library gets built, ahead of the first barrier; no rank enters the timed region
+    before every rank has left its warm-up, and none leaves it before every rank has done its steps."""
+    for extra, per, total, scaling in ((["--total-channels", "256"], 32, 256, "strong"), (["--channels", "256"], 256, 2048, "weak")):
+        trace = str(tmp_path / ("trace_%s.txt" % scaling))
+        j = _launch(8, extra, trace=trace)
+        assert j["n_gpus"] == 8 and j["scaling"] == scaling
+        assert j["config"]["channels_per_gpu"] == per and j["config"]["total_channels"] == total
+        assert j["dry"]["rank0_channels"] == [0, per]
+        assert j["ms_per_step"] >= 8.0                    # rank 7's fake step takes 8 ms: max over ranks
+        want = total * 4096 * 4 / (j["ms_per_step"] * 4e-3) / 1e6
+        assert abs(j["value"] - want) < 1e-6 * want
+        ev = _read_trace(trace)
+        assert sorted(ev["build"]) == [0]                 # rank 0 builds, nobody else
+        for k in (0, 1):                                  # two timed runs per launch: meters on, meters off
+            warm = max(ev["warm_done"][r][k] for r in range(8))
+            start = min(ev["timed_start"][r][k] for r in range(8))
+            done = max(ev["steps_done"][r][k] for r in range(8))
+            end = min(ev["timed_end"][r][k] for r in range(8))
+            assert start >= warm - 1e-3 and end >= done - 1e-3
+        assert min(ev["warm_done"][r][0] for r in range(8)) >= ev["build"][0][0]
