@@ -20,9 +20,10 @@ def test_make_filter_coef_matches_reference_python():
         fI, fQ = rxfilter.make_filter_coef(rate, None, bw, center)
         assert fI.shape == g["case%d_I" % i].shape
         # the module designs the filter from its formula with numpy's vectorised sin / cos / exp, the reference with the C
-        # library's one tap at a time: the same numbers to the last bit or two
+        # library's one tap at a time: NOT bit-identical -- 10 of the 34 arrays differ in the last bit (measured 1.5e-16 of the
+        # largest tap).  The gate is pinned to that one unit in the last place (2.2e-16), not to a tolerance that would hide drift.
         for got, want in ((fI, g["case%d_I" % i]), (fQ, g["case%d_Q" % i])):
-            assert np.abs(got - want).max() <= 2e-15 * np.abs(want).max(), (i, np.abs(got - want).max() / np.abs(want).max())
+            assert np.abs(got - want).max() <= 2.3e-16 * np.abs(want).max(), (i, np.abs(got - want).max() / np.abs(want).max())
         if bw * 24000 // rate // 2 not in rxfilter.prototype_table():
             seen_window_branch = True
             if rate == 12000 and bw == 2700:
