@@ -181,7 +181,7 @@ def other_configs(torch, dev):
 
     # config 3: 16 B in (read once by the FIR and once by the transform) + 16/32 B FIR output; the |X| sums stay on the chip and only
     # the running average leaves it, so SURVEY.md 8(d)'s 16.5 B, not 24.5
-    leg("config3", bc.config3, 16.5, "both_ms",
+    leg("config3", bc.config3, 16.5, "best_ms",
         lambda r: ("pan16k_kernel (16384-point panadapter, read-once)", r["pan_ms"]) if r["pan_ms"] >= r["fir_ms"]
         else ("osfir_kernel<f64,4096,D=8,pick 4> (1023-tap /32)", r["fir_ms"]))
     # config 4: the call's launch sequence replayed from a hipGraph (qh_rxa_set_graph_replay), the engine's mode for repeated calls

@@ -379,6 +379,14 @@ int qh_pan_set_smeter_band(qh_pan *p, int ch, double f_start, double bandwidth);
 int qh_pan_feed(qh_pan *p, const double *d_in, long long in_stride, int n);
 int qh_pan_feed_host(qh_pan *p, const double *h_in, long long in_stride, int n);
 int qh_pan_count(const qh_pan *p);          /* FFTs averaged since the last qh_pan_graph */
+/* A decimating FIR on the panadapter's read: quisk_process_samples feeds the same cSamples to the FFT ring (quisk.c:2454-2475)
+ * and to quisk_cDecimate (filter.c:203-229); with fft_size 16384, decimation 32 and up to 1024 real taps (BASELINE config 3) the
+ * panadapter's own transform serves both (panfir16k_kernel, qh_pan.hip) and the stream is read once.  qh_pan_feed_decimate
+ * takes whole blocks (n a multiple of fft_size, the panadapter at a block boundary) and writes n / decim samples per channel
+ * exactly as quisk_cDecimate(cSamples, n, filter, decim) leaves them, state carried between calls; other shapes are refused
+ * (QH_ERR_UNSUPPORTED): qh_fir beside qh_pan_feed does those. */
+int qh_pan_attach_fir(qh_pan *p, const double *taps, int ntaps, int decim);
+int qh_pan_feed_decimate(qh_pan *p, const double *d_in, long long in_stride, int n, double *d_out, long long out_stride, int *n_out);
 /* The refresh branch of get_graph: h_pixels [nch][data_width] dB, h_smeter [nch] dB (either may be NULL),
  * *count = FFTs that were averaged (0: nothing was written, like get_graph returning None). */
 int qh_pan_graph(qh_pan *p, double zoom, double deltaf, double *h_pixels, double *h_smeter, int *count);

@@ -301,6 +301,217 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
     }
 }
 
+// ---- fft_size 16384 with a decimating FIR on the same read (BASELINE config 3: 1023-tap /32 beside the panadapter) -----------
+// quisk_process_samples copies the raw block into the FFT ring (quisk.c:2454-2475) and decimates the same samples
+// (quisk_cDecimate, filter.c:203-229): one stream, two consumers.  pan16k_kernel already holds the whole 16384-sample block of a
+// channel in one workgroup; this variant makes its transform serve both:
+//   * the transform is taken of the UNWINDOWED block; the Hanning window 0.5 - 0.5 cos(2 pi n / N) (quisk.c:6008) is applied in the
+//     frequency domain, X_w[k] = X[k] / 2 - (X[k - 1] + X[k + 1]) / 4 -- the neighbours of bin 4 m + r are bins of the residue
+//     groups r - 1 and r + 1 at the same m (one step along m at the two ends), fetched through the exchange area;
+//   * the FIR is the circular convolution of the block with the taps, decimated by D = 32: Z[k] = X[k] H'[k] with
+//     H'[k] = FFT_N(h)[k] exp(2 pi i (D - 1) k / N) / N (the output of index m is the sample of time D m + D - 1, filter.c:216),
+//     folded over the 32 images of every bin class k mod 512 -- all of a lane's sixteen bins and those of lane t +- 128 of its
+//     group are ONE class -- and handed to panfir_finish_kernel as 512 folded bins per block: a 512-point inverse transform, and
+//     the circular wrap of the first (ntaps - 1) / D outputs repaired by direct sums over the difference between the previous
+//     block's and this block's last ntaps - 1 samples.
+// The input is read once: 16 B + 16 / 32 B per sample (16.5), where FIR bank + panadapter read it twice.
+template <int DUMMY>
+__global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
+                                                            const double2 *tw, double *partial, double *partial_m2,
+                                                            const PanBand *band, int nch, const double2 *firH, double2 *yfold)
+{
+    using C = double2;
+    using S = FftSplit4096<false, C>;
+    constexpr int M = 4096, N = 16384, E = 16, G = 4, MJ = 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double wsum[4 * G];
+    const int T = threadIdx.x, t = T & 255;
+    const int s = __builtin_amdgcn_readfirstlane(T >> 8);               // residue group: the same for a whole wavefront
+    const int id = blockIdx.x, grp = id / 8, unit = grp * 8 + id % 8;
+    if (unit >= nsplit * nch) return;
+    const int r = s;
+    const int split = unit % nsplit, ch = unit / nsplit;
+    const int per = (nblk + nsplit - 1) / nsplit;
+    const int b0 = split * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    const typename S::Tw twf = FftRR<M, false, C>::load_at(tw, t);
+    double *xch = reinterpret_cast<double *>(smem);                     // exchange area [group][i][t] scalars: 128 KB
+    C *fold = reinterpret_cast<C *>(smem + 4 * 16 * 256 * 8);           // [group][t] complex: the last 16 KB of the four images
+    void *image = smem + (size_t)s * S::kLdsBytes;                      // this group's transform image
+    C e0, estep;
+    sincospi(-2.0 * (double)(t + 256 * MJ * s) / (double)N, &e0.y, &e0.x);
+    estep.x = 0.99518472667219693; estep.y = -0.098017140329560604;    // exp(-2 pi i 256 / N)
+    const PanBand pb = band[ch];
+    double m2 = 0.0;
+    unsigned whole = 0, part = 0;
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int bin = 4 * (t + NT * i) + r;
+        const int sb = bin >= N / 2 ? bin - N : bin;
+        if (pb.valid) {
+            if (sb >= pb.first && sb < pb.first + pb.nwhole) whole |= 1u << i;
+            else if (sb == pb.first + pb.nwhole) part |= 1u << i;
+        }
+    }
+    const bool in_band = __ballot((whole | part) != 0) != 0ull;
+    // neighbours in the exchange area: bin 4 m + r + 1 is residue r + 1 at m (r = 3: residue 0 at m + 1), bin 4 m + r - 1 residue r - 1
+    // at m (r = 0: residue 3 at m - 1); m = t + 256 i is linear in the [i][t] rows, so the two ends are one address step -- except
+    // for the two bins where the spectrum wraps round
+    const int up0 = s < 3 ? ((s + 1) * 16) * 256 + t : t + 1;
+    const int dn0 = s > 0 ? ((s - 1) * 16) * 256 + t : (48 * 256) + t - 1;
+    double racc[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) racc[i] = 0.0;
+    for (int blk = b0; blk < b1; blk++) {
+        const C *x = in + (long long)ch * in_stride + (long long)blk * N + (t + 256 * MJ * s);
+        double oim[16];
+        double *xw = xch + (MJ * s) * 256 + t;
+        const double *xr = xch + (s * 16) * 256 + t;
+        C e = e0;
+        asm volatile("" : "+v"(e.x), "+v"(e.y));
+        __syncthreads();                    // the images and the fold rows are free
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            const C v0 = x[256 * j], v1 = x[256 * j + M], v2 = x[256 * j + 2 * M], v3 = x[256 * j + 3 * M];
+            const C a0 = cadd(v0, v2), a1 = csub(v0, v2), c0 = cadd(v1, v3), c1 = csub(v1, v3);
+            const C e2 = cmul(e, e);
+            C o[G];
+            o[0] = cadd(a0, c0);
+            o[1] = cmul(mk<double>(a1.x + c1.y, a1.y - c1.x), e);
+            o[2] = cmul(csub(a0, c0), e2);
+            o[3] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));
+#pragma unroll
+            for (int g = 0; g < G; g++) { xw[(g * 16 + j) * 256] = o[g].x; oim[G * j + g] = o[g].y; }
+            e = cmul(e, estep);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        C u[E];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) u[i].x = xr[i * 256];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MJ; j++)
+#pragma unroll
+            for (int g = 0; g < G; g++) xw[(g * 16 + j) * 256] = oim[G * j + g];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) u[i].y = xr[i * 256];
+        __syncthreads();
+        typename S::Tw twb = twf;
+        asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
+        S::run_at(u, image, twb, t);        // u[i] = X[4 (t + 256 i) + r], unwindowed
+        // ---- the FIR's share: sum of the lane's sixteen products (one class k mod 512), lanes t and t + 128 joined below
+#ifndef QH_PANFIR_NOFIR        // (tools/ab_bench.py attribution builds: timing only)
+        {
+            const C *hh = firH + r * M + t;
+            C acc = cmul(u[0], hh[0]);
+#pragma unroll
+            for (int i = 1; i < E; i++) {
+                const C z = cmul(u[i], hh[256 * i]);
+                acc.x += z.x; acc.y += z.y;
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                // every group has read its transform out of its image
+            fold[s * 256 + t] = acc;
+        }
+#else
+        __syncthreads();
+#endif
+        // ---- the window in the frequency domain: real parts, then imaginary parts, through the exchange area
+#ifndef QH_PANFIR_NOHANN
+        double *own = xch + (s * 16) * 256 + t;
+#pragma unroll
+        for (int i = 0; i < E; i++) own[i * 256] = u[i].x;
+        __syncthreads();
+#ifndef QH_PANFIR_NOFIR
+        if (t < 128) {
+            const C a = fold[s * 256 + t], b = fold[s * 256 + t + 128];
+            yfold[((long long)ch * nblk + blk) * 512 + 4 * t + r] = mk<double>(a.x + b.x, a.y + b.y);
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            int ua = up0 + i * 256, da = dn0 + i * 256;
+            if (s == 3 && i == 15 && t == 255) ua = 0;                  // X[16384] = X[0]
+            if (s == 0 && i == 0 && t == 0) da = 63 * 256 + 255;        // X[-1] = X[16383]
+            u[i].x = __builtin_fma(0.5, u[i].x, -0.25 * (xch[ua] + xch[da]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) own[i * 256] = u[i].y;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            int ua = up0 + i * 256, da = dn0 + i * 256;
+            if (s == 3 && i == 15 && t == 255) ua = 0;
+            if (s == 0 && i == 0 && t == 0) da = 63 * 256 + 255;
+            u[i].y = __builtin_fma(0.5, u[i].y, -0.25 * (xch[ua] + xch[da]));
+        }
+#else
+        (void)up0; (void)dn0;
+#endif
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
+            racc[i] += sqrt_pow(pw2);
+            if (in_band) m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    double *pp = partial + ((long long)split * nch + ch) * N + r * M + t;
+#pragma unroll
+    for (int i = 0; i < E; i++) pp[256 * i] = racc[i];
+    for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
+    if ((T & 63) == 0) wsum[T >> 6] = m2;
+    __syncthreads();
+    if (t == 0) {
+        double sm = 0.0;
+        for (int k = 0; k < 4; k++) sm += wsum[4 * s + k];
+        partial_m2[((long long)split * nch + ch) * 4 + r] = sm;
+    }
+}
+
+// The FIR outputs of one 16384-sample block from its 512 folded bins: unnormalised inverse transform (the 1 / N sits in H'), then
+// the circular wrap of outputs m < ncorr repaired: y[m] += sum_{k > n} h[k] (xprev - xcur)[N + n - k], n = D m + D - 1 -- the circular
+// convolution took the block's own last samples where the previous block's belong (`hist`: the last `hl` samples of the call
+// before, for block 0).  Thread 8 m + p takes every eighth tap of output m.
+__global__ __launch_bounds__(NT) void panfir_finish_kernel(const double2 *yfold, int nblk, const double2 *tw512, const double *taps, int ntaps,
+                                                           int D, const double2 *in, long long in_stride, const double2 *hist, int hl,
+                                                           double2 *out, long long out_stride)
+{
+    using C = double2;
+    using F = TileFft<512, true, C>;
+    __shared__ __align__(16) unsigned char fimg[F::kLdsBytes];
+    __shared__ C corr[32];
+    __shared__ C diff[1024];                // diff[d] = (previous block - this block)[N - d], d = 1 .. hl
+    constexpr int N = 16384;
+    const int blk = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+    const C *yf = yfold + ((long long)ch * nblk + blk) * 512;
+    C z[2] = { yf[t], yf[t + 256] };
+    const C *cur = in + (long long)ch * in_stride + (long long)blk * N + N;         // cur[-d] = the d-th last sample of this block
+    const C *prv = blk > 0 ? cur - N : hist + (long long)ch * hl + hl;              // the same of the block before
+    for (int d = 1 + t; d <= hl; d += NT) {
+        const C a = prv[-d], b = cur[-d];
+        diff[d] = mk<double>(a.x - b.x, a.y - b.y);
+    }
+    F::run(z, fimg, F::load(tw512));        // (its barriers also publish diff[])
+    const int m = t >> 3, p = t & 7, n = D * m + D - 1;
+    C acc = mk<double>(0, 0);
+    for (int k = n + 1 + p; k < ntaps; k += 8) {
+        const C dv = diff[k - n];
+        const double h = taps[k];
+        acc.x = __builtin_fma(h, dv.x, acc.x);
+        acc.y = __builtin_fma(h, dv.y, acc.y);
+    }
+#pragma unroll
+    for (int sft = 1; sft < 8; sft <<= 1) { acc.x += __shfl_xor(acc.x, sft, 64); acc.y += __shfl_xor(acc.y, sft, 64); }
+    if (p == 0) corr[m] = acc;
+    __syncthreads();
+    if (t < 32) { z[0].x += corr[t].x; z[0].y += corr[t].y; }
+    C *o = out + (long long)ch * out_stride + (long long)blk * (N / D);
+    o[t] = z[0]; o[t + 256] = z[1];
+}
+
 // fft_avg += sum over the block ranges; meter += sum over ranges and r.  One thread per (channel, index).
 // by_residue: the partial sums lie as [r][bin / 4] (pan16k_kernel) instead of in fft_avg's order.
 __global__ __launch_bounds__(NT) void pan_reduce_kernel(const double *partial, const double *partial_m2, int nsplit, int N, int R,
@@ -540,6 +751,12 @@ struct Pan {
     double2 *b_pre = nullptr, *b_filt = nullptr, *wa = nullptr, *wb = nullptr;
     double *mag = nullptr;
     int chunk_blk = 0;          // blocks per channel the work buffers hold
+    // a decimating FIR on the panadapter's read (qh_pan_attach_fir / qh_pan_feed_decimate; fft_size 16384)
+    int fir_ntaps = 0, fir_decim = 0, fir_hl = 0;
+    double2 *fir_H = nullptr, *fir_hist[2] = { nullptr, nullptr }, *fir_yf = nullptr, *fir_tw512 = nullptr;
+    double *fir_taps = nullptr;
+    long long fir_yf_cap = 0;
+    int fir_cur = 0;
 
     ~Pan()
     {
@@ -548,6 +765,7 @@ struct Pan {
         (void)hipFree(avg); (void)hipFree(meter); (void)hipFree(pixels); (void)hipFree(smeter);
         (void)hipFree(tw); (void)hipFree(carry); (void)hipFree(partial); (void)hipFree(partial_m2); (void)hipFree(band);
         (void)hipFree(b_pre); (void)hipFree(b_filt); (void)hipFree(wa); (void)hipFree(wb); (void)hipFree(mag);
+        (void)hipFree(fir_H); (void)hipFree(fir_hist[0]); (void)hipFree(fir_hist[1]); (void)hipFree(fir_yf); (void)hipFree(fir_tw512); (void)hipFree(fir_taps);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -771,6 +989,96 @@ int qh_pan_feed(qh_pan *h, const double *d_in, long long in_stride, int n)
 }
 
 int qh_pan_count(const qh_pan *h) { return h ? h->p.count : 0; }
+
+// ---- the decimating FIR that shares the panadapter's read (panfir16k_kernel) ----------------------------------------------------
+// quisk_process_samples feeds the same cSamples to the FFT ring (quisk.c:2454-2475) and to quisk_cDecimate (filter.c:203-229).
+// Shapes: fft_size 16384, decimation 32, up to 1024 real taps (BASELINE config 3: 1023 taps, /32); anything else is refused --
+// qh_fir + qh_pan_feed do those.  State: the last ntaps - 1 samples of the call before.
+__global__ __launch_bounds__(NT) void panfir_hist_kernel(const double2 *in, long long in_stride, int n, double2 *hist, int hl)
+{
+    const int ch = blockIdx.y, j = blockIdx.x * NT + threadIdx.x;
+    if (j < hl) hist[(long long)ch * hl + j] = in[(long long)ch * in_stride + n - hl + j];
+}
+
+int qh_pan_attach_fir(qh_pan *h, const double *taps, int ntaps, int decim)
+{
+    if (!h || !taps) return set_error(QH_ERR_INVALID, "qh_pan_attach_fir: bad arguments");
+    Pan &p = h->p;
+    if (p.blue || p.M != 4096 || p.R != 4 || decim != 32 || ntaps < 2 || ntaps > 1024)
+        return set_error(QH_ERR_UNSUPPORTED, "qh_pan_attach_fir: fft_size 16384, decimation 32 and 2 .. 1024 taps (got %d, %d, %d): "
+                         "use qh_fir beside qh_pan_feed for other shapes", p.N, decim, ntaps);
+    QH_HIP(hipSetDevice(p.device));
+    QH_HIP(hipStreamSynchronize(p.stream));
+    const int N = p.N;
+    // H'[k] = FFT_N(h)[k] exp(2 pi i (D - 1) k / N) / N, stored [r][m] for k = 4 m + r
+    std::vector<cd> hp((size_t)N, cd(0, 0));
+    for (int i = 0; i < ntaps; i++) hp[(size_t)i] = cd(taps[i], 0.0);
+    host_fft(hp, -1);
+    std::vector<cd> hr((size_t)N);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int k = 0; k < N; k++) {
+        const long double a = 2.0L * pi * (long double)(((long long)(decim - 1) * k) % N) / (long double)N;
+        const cd v = hp[(size_t)k] * cd((double)cosl(a), (double)sinl(a)) / (double)N;
+        hr[(size_t)((k & 3) * (N / 4) + (k >> 2))] = v;
+    }
+    const int hl = ntaps - 1;
+    if (!p.fir_H) {
+        QH_HIP(hipMalloc((void **)&p.fir_H, (size_t)N * 16));
+        QH_HIP(hipMalloc((void **)&p.fir_taps, 1024 * 8));
+        for (auto &q : p.fir_hist) QH_HIP(hipMalloc((void **)&q, (size_t)p.nch * 1024 * 16));
+        const std::vector<cd> tw = fft_twiddle_table(512);
+        QH_HIP(hipMalloc((void **)&p.fir_tw512, tw.size() * 16));
+        QH_HIP(hipMemcpy(p.fir_tw512, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panfir16k_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pan16k_lds<4>()));
+    }
+    QH_HIP(hipMemcpy(p.fir_H, hr.data(), (size_t)N * 16, hipMemcpyHostToDevice));
+    QH_HIP(hipMemcpy(p.fir_taps, taps, (size_t)ntaps * 8, hipMemcpyHostToDevice));
+    for (auto &q : p.fir_hist) QH_HIP(hipMemset(q, 0, (size_t)p.nch * 1024 * 16));
+    p.fir_ntaps = ntaps; p.fir_decim = decim; p.fir_hl = hl; p.fir_cur = 0;
+    return QH_OK;
+}
+
+// n (a multiple of fft_size, the panadapter at a block boundary) samples per channel: every block goes through the panadapter like
+// qh_pan_feed AND comes out decimated, n / decim samples per channel, as quisk_cDecimate(..., decim) would leave them.
+int qh_pan_feed_decimate(qh_pan *h, const double *d_in, long long in_stride, int n, double *d_out, long long out_stride, int *n_out)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null panadapter");
+    if (n_out) *n_out = 0;
+    Pan &p = h->p;
+    if (!p.fir_H) return set_error(QH_ERR_INVALID, "qh_pan_feed_decimate: no filter attached (qh_pan_attach_fir)");
+    if (n <= 0) return QH_OK;
+    if (!d_in || !d_out || in_stride < n || p.fill != 0 || n % p.N) return set_error(QH_ERR_INVALID, "qh_pan_feed_decimate: whole blocks of %d samples at a block boundary", p.N);
+    const int nblk = n / p.N, nout = n / p.fir_decim;
+    if (out_stride < nout) return set_error(QH_ERR_INVALID, "qh_pan_feed_decimate: output stride shorter than %d samples", nout);
+    QH_HIP(hipSetDevice(p.device));
+    const long long need = (long long)p.nch * nblk * 512;
+    if (need > p.fir_yf_cap) {
+        QH_HIP(hipStreamSynchronize(p.stream));
+        (void)hipFree(p.fir_yf); p.fir_yf = nullptr; p.fir_yf_cap = 0;
+        QH_HIP(hipMalloc((void **)&p.fir_yf, (size_t)need * 16));
+        p.fir_yf_cap = need;
+    }
+    const double2 *in = reinterpret_cast<const double2 *>(d_in);
+    int nsplit = (1024 + p.R * p.nch - 1) / (p.R * p.nch);
+    if (nsplit > nblk) nsplit = nblk;
+    if (nsplit > p.max_split) nsplit = p.max_split;
+    if (nsplit < 1) nsplit = 1;
+    const int units = nsplit * p.nch, groups = (units + 7) / 8;
+    hipLaunchKernelGGL((panfir16k_kernel<0>), dim3((unsigned)(groups * 8)), dim3(1024), (size_t)pan16k_lds<4>(), p.stream, in, in_stride, nblk, nsplit,
+                       p.tw, p.partial, p.partial_m2, p.band, p.nch, (const double2 *)p.fir_H, p.fir_yf);
+    hipLaunchKernelGGL(pan_reduce_kernel, dim3((unsigned)((p.N + NT - 1) / NT), (unsigned)p.nch), dim3(NT), 0, p.stream, p.partial, p.partial_m2,
+                       nsplit, p.N, p.R, p.avg, p.meter, 1);
+    p.count += nblk;
+    hipLaunchKernelGGL(panfir_finish_kernel, dim3((unsigned)nblk, (unsigned)p.nch), dim3(NT), 0, p.stream, (const double2 *)p.fir_yf, nblk,
+                       (const double2 *)p.fir_tw512, (const double *)p.fir_taps, p.fir_ntaps, p.fir_decim, in, in_stride,
+                       (const double2 *)p.fir_hist[p.fir_cur], p.fir_hl, reinterpret_cast<double2 *>(d_out), out_stride);
+    hipLaunchKernelGGL(panfir_hist_kernel, dim3((unsigned)((p.fir_hl + NT - 1) / NT), (unsigned)p.nch), dim3(NT), 0, p.stream, in, in_stride, n,
+                       p.fir_hist[p.fir_cur ^ 1], p.fir_hl);
+    p.fir_cur ^= 1;
+    QH_HIP(hipGetLastError());
+    if (n_out) *n_out = nout;
+    return QH_OK;
+}
 
 // Another window in place of record_app's Hanning (measure_freq multiplies by 0.5 - 0.5 cos(2 pi i / (N - 1)), quisk.c:5600-5601).
 // Sizes that run Bluestein's transform only: there the window is a table (folded into the pre-chirp); the power-of-two kernels

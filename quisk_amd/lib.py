@@ -257,6 +257,8 @@ def load():
     L.qh_quisk_multirx_samples.argtypes = [i, vp, i]
     L.qh_quisk_set_filters2.argtypes = [vp, vp, i, i]
     L.qh_quisk_set_filters_n.argtypes = [vp, vp, i, i, i]
+    L.qh_pan_attach_fir.argtypes = [vp, vp, i, i]
+    L.qh_pan_feed_decimate.argtypes = [vp, vp, ll, i, vp, ll, vp]
     L.qh_quisk_measure_frequency.argtypes = [i]
     L.qh_quisk_measure_frequency.restype = C.c_double
     L.qh_quisk_sub_rx1_audio.argtypes = [vp, i]

@@ -20,6 +20,16 @@ class Panadapter:
     def feed_ptr(self, d_in, in_stride, n):
         check(self._L.qh_pan_feed(self._h, d_in, in_stride, n))
 
+    def attach_fir(self, taps, decim):
+        """A decimating FIR on the panadapter's own read (fft_size 16384, decimation 32, <= 1024 real taps)."""
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        check(self._L.qh_pan_attach_fir(self._h, taps.ctypes.data, taps.size, int(decim)))
+
+    def feed_decimate_ptr(self, d_in, in_stride, n, d_out, out_stride):
+        got = C.c_int(0)
+        check(self._L.qh_pan_feed_decimate(self._h, d_in, in_stride, n, d_out, out_stride, C.byref(got)))
+        return got.value
+
     def feed_host(self, x):
         x = np.ascontiguousarray(x, dtype=np.complex128)
         if x.ndim != 2 or x.shape[0] != self.nch:

@@ -7,4 +7,4 @@ rm -rf /tmp/kst && mkdir -p /tmp/kst
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- "$@" > /tmp/kst/run.log 2>&1
 tail -3 /tmp/kst/run.log
 f=$(find /tmp/kst -name "*kernel_stats.csv" | head -1)
-if [ -n "$f" ]; then head -40 "$f" | cut -c1-260 | tee "$out"; else echo "no kernel_stats.csv"; fi
+if [ -n "$f" ]; then head -40 "$f" | cut -c1-700 | tee "$out"; else echo "no kernel_stats.csv"; fi
