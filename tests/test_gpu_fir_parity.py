@@ -74,11 +74,11 @@ def test_complex_taps_against_oracle(qh, oracle, gold):
 
 
 def test_config3_decimator_many_channels(qh, oracle):
-    """BASELINE config 3's FIR: 1023-tap Blackman-windowed sinc (cutoff fs/64), decimate by 32, several
-    channels, two calls; reference = the oracle's quisk_cDecimate restatement."""
+    """BASELINE config 3's FIR: 1023-tap Blackman-windowed sinc (cutoff fs/64), decimate by 32, all 64 channels of the
+    configuration, two calls; reference = the oracle's quisk_cDecimate restatement on every channel."""
     n = np.arange(1023) - 511
     taps = np.sinc(n / 32.0) / 32.0 * np.blackman(1023)
-    nch = 6
+    nch = 64
     x = np.stack([stream(100 + c, 32 * 700 + 13) for c in range(nch)])
     bank = qh.FirBank(nch, taps, 32)
     y = np.concatenate([bank.process_host(x[:, :9001]), bank.process_host(x[:, 9001:])], axis=1)

@@ -57,7 +57,7 @@ def test_bench_shape_tone_gain_and_rejection(qh):
 
 def test_bench_call_shape_against_oracle_and_chunking(qh, oracle):
     """The exact call bench.py times -- 256 channels x 2^22 input samples in ONE qh_rxa_process, meters on -- checked
-    sample for sample against the oracle on three channels (whole output, from sample 0), against the same engine fed in
+    sample for sample against the oracle on 32 of the channels (every eighth; whole output, from sample 0), against the same engine fed in
     uneven pieces on all 256 channels (device-side comparison), and the meter readings against the oracle's xmeter."""
     dev = torch.device("cuda:0")
     nch, n_in, nblk = 256, 1 << 22, 4096
@@ -70,16 +70,30 @@ def test_bench_call_shape_against_oracle_and_chunking(qh, oracle):
     e.process_ptr(x.data_ptr(), n_in, y.data_ptr(), n_out, nblk)
     e.synchronize()
     step_db = 10.0 * np.log10(2.0) / 2048.0
-    for c in (0, 131, 255):
+    # every eighth channel (32 of the 256) against the oracle over the WHOLE call: the oracle channels run side by side on the host
+    # cores (ctypes releases the GIL inside the C call)
+    chans = list(range(0, 256, 8))
+    chans[-1] = 255
+
+    def check(c):
         o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
         o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
         o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0)
-        want = o.xrxa(x[c].cpu().numpy())
-        got = y[c].cpu().numpy()
-        assert rel_rms(got, want) < 1e-9
-        assert np.abs(got - want).max() < 1e-9                # no tile anywhere in the 2^20 outputs is off
-        for mt in (0, 1, 2, 3, 5, 6):
-            assert abs(e.GetRXAMeter(c, mt) - o.GetRXAMeter(mt)) < 1.01 * step_db, (c, mt)
+        want = o.xrxa(xs[c])
+        got = ys[c]
+        meters = [(mt, o.GetRXAMeter(mt)) for mt in (0, 1, 2, 3, 5, 6)]
+        return c, rel_rms(got, want), float(np.abs(got - want).max()), meters
+
+    xs = {c: x[c].cpu().numpy() for c in chans}
+    ys = {c: y[c].cpu().numpy() for c in chans}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        results = list(ex.map(check, chans))
+    for c, rr, mx, meters in results:
+        assert rr < 1e-9, (c, rr)
+        assert mx < 1e-9, (c, mx)                             # no tile anywhere in the 2^20 outputs is off
+        for mt, ref in meters:
+            assert abs(e.GetRXAMeter(c, mt) - ref) < 1.01 * step_db, (c, mt)
     # the same stream in pieces of 1000, 3000 and 96 DSP blocks (tile boundaries fall elsewhere), meters off
     e2 = _engine(qh, nch)
     y2 = torch.empty_like(y)
