@@ -179,7 +179,9 @@ struct Engine {
     // demodulators (allocated on first use)
     bool demod_alloc = false, lists_dirty = true;
     int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
-    int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0, n_rest = 0;
+    int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0, n_rest = 0, n_usb = 0, n_rb = 0;
+    int *list_usb = nullptr, *list_rb = nullptr;       // the non-FM channels without / with a bp1 stage
+    bool all_nbp = false;
     int *list_rest = nullptr;                // the channels that are not FM (the mixed-mode path runs the two kinds on two streams)
     int n_sam0 = 0;                         // the first n_sam0 entries of list_sam have sbmode 0 (no all-pass chains): time-tiled in long calls
     // anf / anr: lists per (filter, position), parameters and state per filter; bp1 lists per position
@@ -643,8 +645,8 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 25));
-        list_rest = list_buf + 24 * nch;
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 27));
+        list_rest = list_buf + 24 * nch; list_usb = list_buf + 25 * nch; list_rb = list_buf + 26 * nch;
         list_amsq = list_buf + 17 * nch;
         for (int k = 0; k < 3; k++) list_emnr[k] = list_buf + (18 + k) * nch;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
@@ -713,7 +715,7 @@ int Engine::refresh_demod()
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba, lrest;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba, lrest, lusb, lrb;
         int n_sam0_new = 0;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
@@ -728,7 +730,7 @@ int Engine::refresh_demod()
             if (c.fmd_run && c.lim_run) ll.push_back(ch);
             if (c.amd_run && c.amd_mode == 0) la.push_back(ch);
             if (c.amd_run && c.amd_mode == 1) { if (c.sbmode == 0) ls.insert(ls.begin() + n_sam0_new++, ch); else ls.push_back(ch); }
-            if (c.fmd_run) lf.push_back(ch); else lrest.push_back(ch);
+            if (c.fmd_run) lf.push_back(ch); else { lrest.push_back(ch); (c.bp1_run ? lrb : lusb).push_back(ch); }
             if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
             // xwcpagc sits between the two bp1 positions (RXA.c:581-586): a position-1 channel is still in `cur` there
             if (c.agc_run && c.agc_mode != 0) (c.bp1_run && !c.bp1_pos ? lgo : lgc).push_back(ch);
@@ -827,8 +829,8 @@ int Engine::refresh_demod()
             return v.empty() ? hipSuccess : hipMemcpyAsync(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream);
         };
         QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
-        QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo)); QH_HIP(put(list_rest, lrest));
-        n_rest = (int)lrest.size();
+        QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo)); QH_HIP(put(list_rest, lrest)); QH_HIP(put(list_usb, lusb)); QH_HIP(put(list_rb, lrb));
+        n_rest = (int)lrest.size(); n_usb = (int)lusb.size(); n_rb = (int)lrb.size();
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) QH_HIP(put(list_lms[f][k], lms_l[f][k]));
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
         QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1])); QH_HIP(put(list_amsq, lsq));
@@ -1474,14 +1476,14 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (nblk <= 0) return QH_OK;
     QH_HIP(hipSetDevice(device));
     // what the chain of every channel needs
-    bool any_nbp = false, any_bp1 = false, mixed = false;
+    bool any_nbp = false, any_bp1 = false, mixed = false, every_nbp = true;
     int nc_max = 1;
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
         if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || c.snba_run) mixed = true;
         if (c.emnr_run && !emnr_tables) return set_error(QH_ERR_INVALID, "EMNR needs its gain tables first (qh_rxa_SetEMNRTables: WDSP's `calculus` and `zetaHat.bin` data)");
-        if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; }
+        if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; } else every_nbp = false;
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
     }
@@ -1573,6 +1575,17 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // channels' front, nbp0 and AM detectors run beside it on a second stream (fork / join by events, which a launch-sequence
     // capture records as graph edges).  BASELINE config 4: 1.20 -> 0.8 ms per call.
     const bool split = n_fm > 0 && n_rest > 0 && D > 1 && !meters_on && !n_amsq && !n_snb[0] && !timing;
+    // ... and when nothing sits between a channel's last filter and the output matrix (no AGC state machine, LMS, EMNR, SNBA,
+    // limiter, squelch or position-1 stage anywhere), that last stage -- nbp0 for the plain channels, bp1 for AM / SAM, the CTCSS
+    // notch for FM -- applies the matrix in its store and writes the caller's buffer: the output pass (32 B per output sample) goes.
+    bool no_lms = true;
+    for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) no_lms = no_lms && !n_lms[f][k];
+    const bool direct = split && every_nbp && !eg.kind && !n_lim && !n_agc_cur && !n_agc_other && !n_snba && !n_snb[1] && no_lms &&
+                        !n_emnr[0] && !n_emnr[1] && !n_emnr[2] && !n_fix[0] && !n_fix[1] && !n_bp1p[1] && n_bp1p[0] == n_bp1 && n_rb == n_bp1 &&
+                        n_usb + n_fm == n_plain &&
+                        // the first stores to `out` come while other channels' input is still being read: not for a caller that works in place
+                        ((const char *)(out + (size_t)nch * (size_t)out_stride) <= (const char *)in ||
+                         (const char *)in + (size_t)nch * (size_t)in_stride * sizeof(double2) <= (const char *)out);
     if (split) {
         if (!side_stream) {
             QH_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -1588,7 +1601,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         std::swap(stream, side_stream);
         int rc2 = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_rest, n_rest, 2);
         hc = cur_nbp;
-        if (!rc2 && any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rest, n_rest);
+        if (!rc2 && any_nbp) {
+            if (direct) {       // the plain channels end here: output matrix in the store, straight to the caller's buffer
+                if (n_usb) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_usb, n_usb);
+                hc = cur_nbp;
+                if (n_rb) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rb, n_rb);
+            } else run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rest, n_rest);
+        }
         std::swap(stream, side_stream);
         if (rc2) return rc2;
         if (any_nbp) { cur_nbp ^= 1; std::swap(cur, other); }
@@ -1753,10 +1772,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL((snotch_tiled_kernel<1>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
                                    list_fm, sn_prm, sn_state, seg_sum[2]);
                 hipLaunchKernelGGL((snotch_tiled_kernel<2>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
-                                   list_fm, sn_prm, sn_state, seg_sum[2]);
+                                   list_fm, sn_prm, sn_state, seg_sum[2], direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi);
             } else
                 hipLaunchKernelGGL((snotch_tiled_kernel<0>), dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
-                                   sn_prm, sn_state, (double *)nullptr);
+                                   sn_prm, sn_state, (double *)nullptr, direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi);
         }
         if (n_lim)      // detector limiter: lim_pre_gain 0.4, then its own wcpAGC (fmd.c:179-184)
             hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
@@ -1786,7 +1805,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     };
     auto bp1_at = [&](int ps) {
         int hc = cur_bp1;
-        if (n_bp1p[ps]) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
+        if (n_bp1p[ps]) {
+            if (direct) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
+            else run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
+        }
     };
     lms_on(0, cur);
     bp1_at(0);
@@ -1818,7 +1840,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // xwcpagc mode 0 + xpanel
     long long per = (n_mid + NT - 1) / NT;
     const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
-    if (eg_fused) {
+    if (direct) {
+        // every channel's last stage has written the caller's buffer
+    } else if (eg_fused) {
         if (n_plain) hipLaunchKernelGGL((pointwise_kernel<double, false, true>), dim3(gx, (unsigned)n_plain), dim3(NT), 0, stream, cur,
                                         buf_cap, out, out_stride, (int)n_mid, (const unsigned long long *)nullptr,
                                         (const unsigned long long *)nullptr, epi, list_plain, eg);

@@ -159,15 +159,33 @@ __device__ __forceinline__ void scan_biquad_dpp(double &u0, double &u1, const Bi
 }
 
 template <int MODE = 0>
+// dst != null: the stage is the channel's last -- pass 2 writes the output matrix applied to (y, Q) to dst instead of y in place (a
+// channel whose notch does not run is copied through the matrix)
 static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                                          const SnotchParam *prm, SnotchState *state, double *gsum = nullptr)
+                                                                          const SnotchParam *prm, SnotchState *state, double *gsum = nullptr,
+                                                                          double2 *dst = nullptr, long long dst_stride = 0,
+                                                                          const EpiParam *epi = nullptr)
 {
     __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x];
     const SnotchParam q = prm[ch];
-    if (!q.run) return;                                 // block-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = MODE == 0 ? kSegWaves : kSegWaves * (int)gridDim.y, sidx = MODE == 0 ? wave : (int)blockIdx.y * kSegWaves + wave;
+    EpiParam ep{ 1, 0, 0, 1 };
+    if (dst && epi) ep = epi[ch];
+    if (!q.run) {                                       // block-uniform
+        if (dst && MODE != 1) {
+            int c0, c1;
+            seg_range(n, sidx, c0, c1, S);
+            const double2 *src = buf + (long long)ch * stride;
+            double2 *o = dst + (long long)ch * dst_stride;
+            for (int i = c0 * 64 + lane; i < c1 * 64 && i < n; i += 64) {
+                const double2 v = src[i];
+                o[i] = make_double2(ep.a * v.x + ep.b * v.y, ep.c * v.x + ep.d * v.y);
+            }
+        }
+        return;
+    }
     double *sum = MODE == 0 ? s_sum : gsum + (long long)blockIdx.x * S * kSegSumW;     // row: e0, e1, x[end - 1], x[end - 2]
     double2 *p = buf + (long long)ch * stride;
     const SnotchState st0 = state[ch];
@@ -255,7 +273,12 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
             double u0 = lane < cnt ? q.a0 * x0 + q.a1 * x1 + q.a2 * x2 : 0.0, u1 = 0.0;
             scan_biquad_dpp(u0, u1, sc);
             const double y0 = u0 + sc.pw.a * c0 + sc.pw.b * c1, y1 = u1 + sc.pw.c * c0 + sc.pw.d * c1;
-            if (lane < cnt) p[base + lane].x = y0;                  // the Q component passes (iir.c:76-95 filters I only)
+            if (lane < cnt) {                                       // the Q component passes (iir.c:76-95 filters I only)
+                if (dst) {
+                    const double qv = p[base + lane].y;
+                    dst[(long long)ch * dst_stride + base + lane] = make_double2(ep.a * y0 + ep.b * qv, ep.c * y0 + ep.d * qv);
+                } else p[base + lane].x = y0;
+            }
             c0 = lane_bcast(y0, cnt - 1); c1 = lane_bcast(y1, cnt - 1);
             const double prev1 = xm1;
             xm1 = lane_bcast(x0, cnt - 1);

@@ -74,6 +74,42 @@ def make_mode_input_numpy(mode, c, n, fs=192000.0, sigma=0.01):
     raise ValueError(mode)
 
 
+def make_mode_input_torch(modes, n, device, fs=192000.0, sigma=0.01, first_channel=0):
+    """make_mode_input_numpy's signal model generated on the GPU: modes = one of 'usb' / 'am' / 'fm' per channel; complex128
+    [len(modes), n]; noise from a torch generator seeded 1000 + c (not the numpy stream: bench input, not a parity vector)."""
+    import torch
+    nch = len(modes)
+    x = torch.empty((nch, n), dtype=torch.complex128, device=device)
+    t = torch.arange(n, dtype=torch.float64, device=device)
+    two_pi = 2.0 * np.pi
+    for i, mode in enumerate(modes):
+        c = first_channel + i
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1000 + c)
+        if mode == "usb":
+            f1, f2 = channel_tones(c, fs)
+            ph1 = torch.remainder(t * (f1 / fs), 1.0) * two_pi
+            ph2 = torch.remainder(t * (f2 / fs), 1.0) * two_pi
+            re = 0.1 * torch.cos(ph1) + 0.05 * torch.cos(ph2)
+            im = 0.1 * torch.sin(ph1) + 0.05 * torch.sin(ph2)
+        else:
+            ph = torch.remainder(t * (-shift_freq(c) / fs), 1.0) * two_pi
+            aud = t * (two_pi * 1000.0 / fs)
+            if mode == "am":
+                amp = 0.1 * (1.0 + 0.5 * torch.cos(aud))
+            elif mode == "fm":
+                amp = 0.1
+                ph = ph + (3000.0 / 1000.0) * torch.sin(aud)
+            else:
+                raise ValueError(mode)
+            re = amp * torch.cos(ph)
+            im = amp * torch.sin(ph)
+        re = re + sigma * torch.randn(n, dtype=torch.float64, device=device, generator=gen)
+        im = im + sigma * torch.randn(n, dtype=torch.float64, device=device, generator=gen)
+        x[i] = torch.complex(re, im)
+    return x
+
+
 def impulsive_input(nch, n, seed=7, scale=1e6):
     """Gaussian noise at `scale` with spikes, short bursts and pairs of bursts 20-40 dB above it (noise-blanker input)."""
     out = np.empty((nch, n), dtype=np.complex128)

@@ -161,3 +161,40 @@ def test_fm_channel_leaves_and_returns_keeps_its_delay_lines(qh, oracle):
     # the last segment: channel 0 is back in FM; compare from its first sample on
     assert rel_rms(got[0], ref[0]) < 1e-6
     assert rel_rms(got[1][20 * 256:], ref[1][20 * 256:]) < 1e-6
+
+
+def test_last_stage_writes_the_output_directly_and_equals_the_separate_output_pass(qh, oracle):
+    """USB / AM / SAM / FM (one with its CTCSS notch off) in one call, fixed gain and panel gains that differ per channel: with no
+    stage between a channel's last filter and the output matrix that filter's store applies the matrix (qh_engine.hip, `direct`).
+    The same engine with meters on runs every channel through the separate output pass; a caller working in place does as well.
+    All three agree to the last bit, and with the oracle."""
+    import torch
+    nch, nblk = 10, 160
+    modes = [(USB, "usb"), (AM, "am"), (FM, "fm"), (SAM, "am"), (FM, "fm")]
+    kws = [{}, {}, {}, {"levelfade": 0}, {"ctcss_run": 0}]   # SAM without the fade leveller's 1.4 s memory of the pull-in
+    x = np.stack([synth.make_mode_input_numpy(modes[c % 5][1], c, nblk * 1024) for c in range(nch)])
+    def make(meters):
+        e = qh.RxaEngine(nch)
+        for c in range(nch):
+            _cfg_engine(e, c, modes[c % 5][0], **kws[c % 5])
+            e.SetRXAAGCFixed(c, 3.0 * c - 6.0)
+            e.SetRXAPanelGain1(c, 0.5 + 0.1 * c)
+            e.SetRXAPanelGain2(c, 1.0 - 0.05 * c, 0.6 + 0.03 * c)
+            e.SetRXAPanelCopy(c, c % 4)
+        e.enable_meters(meters)
+        return e
+    ya = make(False).process_host(x)
+    yb = make(True).process_host(x)
+    assert np.array_equal(ya, yb)
+    e = make(False)                                      # in place: output rows over the input rows
+    d = torch.from_numpy(x.view(np.float64).copy()).cuda()
+    e.process_ptr(d.data_ptr(), nblk * 1024, d.data_ptr(), nblk * 1024, nblk)
+    e.synchronize()
+    yc = d.cpu().numpy().view(np.complex128)[:, :nblk * 256]
+    assert np.array_equal(ya, yc)
+    for c in range(nch):
+        o = _cfg_oracle(oracle, c, modes[c % 5][0], **kws[c % 5])
+        o.SetRXAAGCFixed(3.0 * c - 6.0); o.SetRXAPanelGain1(0.5 + 0.1 * c); o.SetRXAPanelGain2(1.0 - 0.05 * c, 0.6 + 0.03 * c); o.SetRXAPanelCopy(c % 4)
+        ref = o.xrxa(x[c])
+        lo = 0 if modes[c % 5][0] in (USB, AM) else 120 * 256
+        assert rel_rms(ya[c][lo:], ref[lo:]) < (TOL if lo == 0 else 1e-6), c

@@ -52,7 +52,8 @@ def config3(torch, qh, dev):
 
 def config4(torch, qh, dev):
     from quisk_amd import synth
-    nch, nblk = 256, 256        # 2^18 input samples per channel per step
+    nch = 256
+    nblk = int(os.environ.get("QH_C4_NBLK", "1024"))       # DSP blocks per call: 2^20 input samples per channel per step by default
     n_in = nblk * 1024
     eng = qh.RxaEngine(nch, stream=torch.cuda.current_stream(dev).cuda_stream)
     modes = [1, 6, 5]
@@ -66,7 +67,7 @@ def config4(torch, qh, dev):
     # USB channels get the two-tone input of C2, AM channels a carrier with m = 0.5 / 1 kHz, FM channels a
     # carrier with a 1 kHz tone at +-3 kHz deviation, all + noise (synth.make_mode_input_numpy)
     kinds = {1: "usb", 6: "am", 5: "fm"}
-    x = torch.from_numpy(np.stack([synth.make_mode_input_numpy(kinds[modes[c % 3]], c, n_in) for c in range(nch)])).to(dev)
+    x = synth.make_mode_input_torch([kinds[modes[c % 3]] for c in range(nch)], n_in, dev)
     y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
     sync = lambda: torch.cuda.synchronize(dev)
     t = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=5, warmup=1)
