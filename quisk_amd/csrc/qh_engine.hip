@@ -1702,14 +1702,14 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 if (side) QH_HIP(hipStreamSynchronize(side_stream));
                 drop_graphs(); epoch++;
                 (void)hipFree(pll_ends); pll_ends = nullptr;
-                QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * 6));
+                QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * kPllEndsW));
                 pll_ends_cap = (long long)ngroups * 64;
             }
             hipLaunchKernelGGL((pll_lanes_kernel<true>), dim3((unsigned)ngroups, (unsigned)nt), dim3(64), 0, am_stream, (const double *)theta,
-                               2 * buf_cap, pts, 2 * buf_cap, (int)n_mid, list_sam, (const PllState *)pll_state, pll_ends, pll_ends_cap * 6,
+                               2 * buf_cap, pts, 2 * buf_cap, (int)n_mid, list_sam, (const PllState *)pll_state, pll_ends, pll_ends_cap * kPllEndsW,
                                sam_pll_prm, kSamTile, kSamWarm);
             hipLaunchKernelGGL((pll_verify_kernel<true>), dim3((unsigned)nt), dim3(64), 0, am_stream, (const double *)theta, 2 * buf_cap, pts,
-                               2 * buf_cap, (int)n_mid, list_sam, pll_state, pll_ends, pll_ends_cap * 6, sam_pll_prm, kSamTile, kSamWarm,
+                               2 * buf_cap, (int)n_mid, list_sam, pll_state, pll_ends, pll_ends_cap * kPllEndsW, sam_pll_prm, kSamTile, kSamWarm,
                                pll_nfixed, pll_check_only);
             {
                 const int G = seg_groups(n_am + nt);
@@ -1727,6 +1727,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         if (n_sam - nt) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)(n_sam - nt)), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,
                                            list_sam + nt, pll_state, sam_prm, sam_pll_prm, am_state);
     }
+    if (direct && n_bp1p[0]) {      // bp1 is the AM / SAM channels' last stage: it follows their detectors on the second stream
+        std::swap(stream, side_stream);
+        int hc = cur_bp1;
+        run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[0], n_bp1p[0]);
+        std::swap(stream, side_stream);
+    }
     if (side) QH_HIP(hipEventRecord(ev_join, side_stream));
     if (n_fm) {
         // xfmd's loop (fmd.c:151-172), time-tiled (qh_tiled.hpp): angles, then one loop per lane and tile, then dc removal + gain.
@@ -1742,25 +1748,21 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 QH_HIP(hipStreamSynchronize(stream));
                 drop_graphs(); epoch++;
                 (void)hipFree(pll_ends); pll_ends = nullptr;
-                QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * 6));
+                QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * kPllEndsW));
                 pll_ends_cap = (long long)ngroups * 64;
             }
             hipLaunchKernelGGL((pll_lanes_kernel<false>), dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
-                               2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, pll_ends, pll_ends_cap * 6,
+                               2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, pll_ends, pll_ends_cap * kPllEndsW,
                                fm_pll_prm, kFmTile, kFmWarm);
             hipLaunchKernelGGL((pll_verify_kernel<false>), dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
-                               2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * 6, fm_pll_prm, kFmTile, kFmWarm,
+                               2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * kPllEndsW, fm_pll_prm, kFmTile, kFmWarm,
                                pll_nfixed, pll_check_only);
             {
+                // dc removal + gain: the tiles' contributions are in `ends` already, one pass over `fil`
                 const int G = seg_groups(n_fm);
-                if (G > 1) {
-                    hipLaunchKernelGGL((fm_dc_tiled_kernel<1>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
-                                       2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, seg_sum[1]);
-                    hipLaunchKernelGGL((fm_dc_tiled_kernel<2>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
-                                       2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, seg_sum[1]);
-                } else
-                    hipLaunchKernelGGL((fm_dc_tiled_kernel<0>), dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, (const double *)fil, 2 * buf_cap,
-                                       cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, (double *)nullptr);
+                hipLaunchKernelGGL((fm_dc_tiled_kernel<3>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
+                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, (double *)nullptr,
+                                   (const double *)pll_ends, pll_ends_cap * kPllEndsW, kFmTile);
             }
         }
         run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm);      // de-emphasis
@@ -1805,10 +1807,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     };
     auto bp1_at = [&](int ps) {
         int hc = cur_bp1;
-        if (n_bp1p[ps]) {
-            if (direct) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
-            else run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
-        }
+        if (n_bp1p[ps] && !direct) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[ps], n_bp1p[ps]);
     };
     lms_on(0, cur);
     bp1_at(0);
@@ -2583,7 +2582,7 @@ long long qh_rxa_pll_repairs(qh_rxa *h)
 }
 
 // Diagnostics: check_only >= 0 sets the verify pass to count-only (1) or repair (0); then copies up to `max` doubles of
-// channel ch's per-tile loop states of the last call ([tile][6]: pt, fil_out, omega where the warm-up ended / the tile ended).
+// channel ch's per-tile loop states of the last call ([tile][kPllEndsW]: pt, fil_out, omega where the warm-up ended / the tile ended).
 int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
@@ -2593,9 +2592,9 @@ int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
     if (!out || max <= 0 || !e.pll_ends) return 0;
     QH_HIP(hipSetDevice(e.device));
     QH_HIP(hipStreamSynchronize(e.stream));
-    long long n = e.pll_ends_cap * 6;
+    long long n = e.pll_ends_cap * kPllEndsW;
     if (n > max) n = max;
-    QH_HIP(hipMemcpy(out, e.pll_ends + (long long)ch * e.pll_ends_cap * 6, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    QH_HIP(hipMemcpy(out, e.pll_ends + (long long)ch * e.pll_ends_cap * kPllEndsW, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return (int)n;
 }
 

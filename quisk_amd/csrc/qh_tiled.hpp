@@ -332,6 +332,10 @@ __device__ __forceinline__ double max_nn_d(double a, double b)
 // where the tile ends ([3..5]); pll_verify_kernel compares neighbours and re-runs, in order, the tiles whose warm-up had
 // not met the true trajectory yet (a loop that sits on noise, without a carrier, can take several hundred samples).
 static constexpr int kPllPitch = 65;
+// `ends` row of a tile: [0..2] loop state where the warm-up ended, [3..5] where the tile ended, [6] (FM) the tile's own
+// contribution to the dc-removal average at its end: onem_mtau sum_i mtau^(L-1-i) fil_i -- what fm_dc_tiled_kernel's first pass
+// would read `fil` again for.  The loop kernel has every fil_i in a register anyway.
+static constexpr int kPllEndsW = 8;
 struct PllLane { double pt, fil_out, omega; };
 
 // EMIT_PT: the step's output is the VCO phase the sample SAW (turns; what the SAM detector mixes with, amd.c:150-158) instead
@@ -401,7 +405,8 @@ static __global__ __launch_bounds__(64) void pll_lanes_kernel(const double *thet
         }
     }
     const int nsteps = H + L;
-    double *e = ends + (long long)ch * estride + ((long long)group * 64 + lane) * 6;
+    double *e = ends + (long long)ch * estride + ((long long)group * 64 + lane) * kPllEndsW;
+    double dcsum = 0.0;
     double tn[64];                                                      // the next batch's angles, row j in tn[j]
     auto fetch = [&](int i0) {
 #pragma unroll
@@ -428,6 +433,12 @@ static __global__ __launch_bounds__(64) void pll_lanes_kernel(const double *thet
             else if (gb + 63 >= 0) pll_lane_steps<true, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
         }
         if (i0 + 64 == H && live) { e[0] = s.pt; e[1] = s.fil_out; e[2] = s.omega; }      // state where the warm-up ends
+        if constexpr (!EMIT_PT) {
+            if (i0 >= H) {                              // output steps (a tile that crosses the call's end is nobody's predecessor)
+#pragma unroll
+                for (int k = 0; k < 64; k++) dcsum = __builtin_fma(dcsum, q.mtau, t[k]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 64; k++) row[k] = t[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -443,7 +454,10 @@ static __global__ __launch_bounds__(64) void pll_lanes_kernel(const double *thet
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (live) { e[3] = s.pt; e[4] = s.fil_out; e[5] = s.omega; }          // state at the end of the tile (or of the call)
+    if (live) {                                                           // state at the end of the tile (or of the call)
+        e[3] = s.pt; e[4] = s.fil_out; e[5] = s.omega;
+        if constexpr (!EMIT_PT) e[6] = q.onem_mtau * dcsum;
+    }
 }
 
 // Checks the speculation of pll_lanes_kernel and repairs it.  Tile t is right when the state its warm-up reached equals
@@ -484,7 +498,7 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
         bool bad = false;
         double wp = 0, wf = 0, wo = 0;
         if (t < ntiles) {
-            const double *a = e + (long long)t * 6, *b = e + (long long)(t - 1) * 6 + 3;
+            const double *a = e + (long long)t * kPllEndsW, *b = e + (long long)(t - 1) * kPllEndsW + 3;
             wp = a[0]; wf = a[1]; wo = a[2];
             double bp = b[0], bf = b[1], bo = b[2];
             if (t - 1 == rt) { bp = rp; bf = rf; bo = ro; }             // the last tile of the batch before was re-run
@@ -496,11 +510,12 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
             const int l0 = __ffsll((long long)mask) - 1, tq = base + l0;
             mask &= ~(1ull << l0);
             // re-run tile tq from the end state of tile tq - 1 (uniform values: read by every lane)
-            const double *bq = e + (long long)(tq - 1) * 6 + 3;
+            const double *bq = e + (long long)(tq - 1) * kPllEndsW + 3;
             PllLoop Ls{ bq[0], bq[1], bq[2] };
             if (tq - 1 == rt) { Ls.pt = rp; Ls.fil_out = rf; Ls.omega = ro; }
             const long long s0 = (long long)tq * L;
             const int len = (int)((long long)n - s0 < L ? (long long)n - s0 : L);
+            double dcsum = 0.0;
             for (int off = 0; off < len; off += 64) {
                 const int cnt = len - off < 64 ? len - off : 64;
                 double tt = 0.0;
@@ -509,8 +524,14 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
                 double my_pt, my_fil;
                 pll_run64(Ls, tt, zero, cnt, q, lane, my_pt, my_fil, pll_out);
                 if (lane < cnt) fo[s0 + off + lane] = EMIT_PT ? my_pt : my_fil;
+                if constexpr (!EMIT_PT)
+                    dcsum = __builtin_fma(dcsum, lane_pow(q.mtau, cnt), wave_sum_d(lane < cnt ? my_fil * lane_pow(q.mtau, cnt - 1 - lane) : 0.0));
             }
-            if (lane == 0) { double *w = e + (long long)tq * 6 + 3; w[0] = Ls.pt; w[1] = Ls.fil_out; w[2] = Ls.omega; }
+            if (lane == 0) {
+                double *w = e + (long long)tq * kPllEndsW + 3;
+                w[0] = Ls.pt; w[1] = Ls.fil_out; w[2] = Ls.omega;
+                if constexpr (!EMIT_PT) w[3] = q.onem_mtau * dcsum;
+            }
             rt = tq; rp = Ls.pt; rf = Ls.fil_out; ro = Ls.omega;
             fixed++;
             // the successor is judged against the repaired end state
@@ -523,7 +544,7 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
         }
     }
     if (lane == 0 && n > 0) {
-        const double *b = e + (long long)(ntiles - 1) * 6 + 3;
+        const double *b = e + (long long)(ntiles - 1) * kPllEndsW + 3;
         double b0 = b[0], b1 = b[1], b2 = b[2];
         if (rt == ntiles - 1) { b0 = rp; b1 = rf; b2 = ro; }
         state[ch].phs = b0 * kTwoPiRef; state[ch].fil_out = b1; state[ch].omega = b2;
@@ -533,10 +554,13 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
 
 // dc removal and gain of xfmd (fmd.c:169-171): fmdc <- mtau fmdc + onem_mtau fil ; audio = again (fil - fmdc), written as
 // (audio, audio).  Same two-pass segment scheme as the AM leveller; fil is a real array, out the channel's complex row.
+// MODE 3: no first pass at all.  The loop kernels left every tile's contribution in `ends` (kPllEndsW per tile, [6]); segments are
+// cut on tile boundaries (L samples) and a segment's carry-in is the chain over the tiles before it.
 template <int MODE = 0>
 static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const double *fil, long long fstride, double2 *out, long long stride,
                                                                          int n, const int *chan_list, PllState *state, const double *again,
-                                                                         PllParam q, double *gsum = nullptr)
+                                                                         PllParam q, double *gsum = nullptr, const double *ends = nullptr,
+                                                                         long long estride = 0, int L = 64)
 {
     __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -549,7 +573,17 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
     const PoleScan sc = make_pole_scan(q.mtau, lane);
     const double m64 = lane_pow(q.mtau, 64);
     double fn[kSegGroup];
-    if constexpr (MODE != 2) {
+    int t0 = 0;                                             // MODE 3: tiles ahead of this segment
+    bool is_last = false;
+    if constexpr (MODE == 3) {
+        const int nb = (n + 63) >> 6, lb = L >> 6, nt = (n + L - 1) / L;
+        t0 = (int)((long long)sidx * nt / S);
+        const int t1 = (int)((long long)(sidx + 1) * nt / S);
+        b0 = t0 * lb;
+        b1 = t1 * lb < nb ? t1 * lb : nb;
+        is_last = t1 == nt && t0 < t1;                      // the segment that holds the call's last sample
+    }
+    if constexpr (MODE == 0 || MODE == 1) {
         // pass 1: end value only (see the AM leveller)
         double acc = 0.0;
         seg_load(fn, b0, b1, n, lane, f);
@@ -571,7 +605,21 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
     const double c_in = state[ch].fmdc;                  // ahead of the barrier: the last wavefront stores the new carry at its end
     if constexpr (MODE == 0) __syncthreads();
     double c = c_in;
-    {
+    if constexpr (MODE == 3) {
+        // c = c_in mL^t0 + sum_{t < t0} mL^(t0 - 1 - t) s_t, 64 tiles per step; tiles whose weight is below 1e-40 are left out
+        const double mL = pow(q.mtau, (double)L), mL64 = lane_pow(mL, 64);
+        const double *e = ends + (long long)ch * estride;
+        int depth = 1;
+        for (double w = mL64; w > 1e-40 && depth < 4096; w *= mL64) depth++;
+        int first = t0 - 64 * depth;
+        if (first <= 0) first = 0; else c = 0.0;
+        for (int blk = first; blk < t0; blk += 64) {
+            const int cnt = t0 - blk < 64 ? t0 - blk : 64;
+            double v = 0.0;
+            if (lane < cnt) v = e[(long long)(blk + lane) * kPllEndsW + 6] * lane_pow(mL, cnt - 1 - lane);
+            c = __builtin_fma(c, lane_pow(mL, cnt), wave_sum_d(v));
+        }
+    } else {
         const int qb = ((n + 63) >> 6) / S;
         const double t0 = pow(m64, (double)qb), t1 = t0 * m64;
         SegWalk walk(n, S);
@@ -598,9 +646,13 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
             c = lane_bcast(dcs, cnt - 1);
         }
     }
-    int last = S - 1;
-    while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
-    if (sidx == last && lane == 0 && n > 0) state[ch].fmdc = c;
+    if constexpr (MODE == 3) {
+        if (is_last && lane == 0 && n > 0) state[ch].fmdc = c;
+    } else {
+        int last = S - 1;
+        while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
+        if (sidx == last && lane == 0 && n > 0) state[ch].fmdc = c;
+    }
 }
 
 }  // namespace qh
