@@ -274,7 +274,7 @@ struct Engine {
     void pack_audio(const double2 *src, long long src_stride, long long n);
     void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                  const int *list, int nlist, bool meter = false, bool egress = false);
+                  const int *list, int nlist, bool meter = false, bool egress = false, double *theta = nullptr, long long theta_stride = 0);
     int ensure_buffers(long long n_mid);
     int ensure_meter_partials(long long n_mid, int lout);
     int emnr_alloc();
@@ -1262,13 +1262,14 @@ void Engine::tick(int cat)
     ev_used++;
 }
 
-template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft, bool POLY = false>
+template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft, bool POLY = false,
+          bool THETA = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, NFFT, D, METER>();
-    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY, THETA>), grid, block, lds, s, a);
 }
 template <int NFFT>
 static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
@@ -1406,7 +1407,7 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
 // one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
 void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                      const int *list, int nlist, bool meter, bool egress)
+                      const int *list, int nlist, bool meter, bool egress, double *theta, long long theta_stride)
 {
     const int Lout = bnfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
@@ -1424,7 +1425,10 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
-    if (band6k) launch_band6k(a, ntiles, nl, stream, meter, egress);
+    if (theta) {            // the caller has checked: 4096-point tiles, no meters, no egress
+        a.theta = theta; a.theta_stride = theta_stride;
+        launch_osfir<1, false, false, false, false, false, kNfft, false, true>(a, ntiles, nl, stream);
+    } else if (band6k) launch_band6k(a, ntiles, nl, stream, meter, egress);
     else if (band2g) launch_band2g(a, ntiles, nl, stream, meter, egress);
     else if (bnfft == kNfft) launch_band<kNfft>(a, ntiles, nl, stream, meter, egress);
     else launch_band<kBandNfftMax>(a, ntiles, nl, stream, meter, egress);
@@ -1578,6 +1582,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // ... and when nothing sits between a channel's last filter and the output matrix (no AGC state machine, LMS, EMNR, SNBA,
     // limiter, squelch or position-1 stage anywhere), that last stage -- nbp0 for the plain channels, bp1 for AM / SAM, the CTCSS
     // notch for FM -- applies the matrix in its store and writes the caller's buffer: the output pass (32 B per output sample) goes.
+    const bool fm_theta_fused = split && any_nbp && !band6k && !band2g && bnfft == kNfft;
     bool no_lms = true;
     for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) no_lms = no_lms && !n_lms[f][k];
     const bool direct = split && every_nbp && !eg.kind && !n_lim && !n_agc_cur && !n_agc_other && !n_snba && !n_snb[1] && no_lms &&
@@ -1597,7 +1602,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
         if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_fm, n_fm, 2)) return rc;
         int hc = cur_nbp;
-        if (any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_fm, n_fm);
+        // the FM channels' nbp0 feeds the loop's phase detector and nothing else: its store takes the angles (first half of the rows)
+        if (any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_fm, n_fm, false, false,
+                              fm_theta_fused ? reinterpret_cast<double *>(other) : nullptr, 2 * buf_cap);
         std::swap(stream, side_stream);
         int rc2 = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_rest, n_rest, 2);
         hc = cur_nbp;
@@ -1738,10 +1745,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         // xfmd's loop (fmd.c:151-172), time-tiled (qh_tiled.hpp): angles, then one loop per lane and tile, then dc removal + gain.
         // The FM channels' rows of `other` are free here: first half = angles, second half = loop filter output.
         {
-            double *theta = reinterpret_cast<double *>(other), *fil = theta + buf_cap;
+            // fused: nbp0 left the angles in the channels' own rows (first half) and the loop output goes to the rows of `other`
+            double *theta = reinterpret_cast<double *>(fm_theta_fused ? cur : other), *fil = reinterpret_cast<double *>(other) + buf_cap;
             const long long per = (n_mid + NT - 1) / NT;
-            hipLaunchKernelGGL(pll_theta_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_fm), dim3(NT), 0, stream, cur, buf_cap,
-                               (int)n_mid, list_fm, theta, 2 * buf_cap);
+            if (!fm_theta_fused)
+                hipLaunchKernelGGL(pll_theta_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_fm), dim3(NT), 0, stream, cur, buf_cap,
+                                   (int)n_mid, list_fm, theta, 2 * buf_cap);
             const long long ntl = (n_mid + kFmTile - 1) / kFmTile;
             const int ngroups = (int)((ntl + 63) / 64);
             if ((long long)ngroups * 64 > pll_ends_cap) {

@@ -17,6 +17,10 @@
 
 namespace qh {
 
+// angle arrays (turns, (-0.5, 0.5]) mark an all-zero sample with this value (pll_theta_kernel, THETA stores of osfir_kernel)
+static constexpr double kThetaZeroMark = 8.0;
+
+
 constexpr int NT = 256;     // threads per workgroup for every kernel in this file
 
 template <typename T> struct cplx_of;

@@ -80,6 +80,8 @@ template <typename T> struct OsfirArgs {
     long long meter_stride;
     const double *meter_w;              // [64]  (1 - m) m^(63 - i)
     const double2 *tw_r2;               // osfir8k_kernel: exp(-2 pi i k / 8192), k < 256
+    double *theta;                      // THETA kernels: arg(output) in turns (qh_tiled.hpp, pll_theta_kernel) leaves instead of the output
+    long long theta_stride;             // [nch][theta_stride] doubles
 };
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
@@ -252,7 +254,10 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
 
 // POLY: the forward transform stops ahead of the stage that combines the D decimated sequences and the mask holds the
 // polyphase spectra G (FftSplit4096::run_poly, front_mask_kernel): same fold below, one butterfly stage less.
-template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, bool POLY = false>
+// THETA: the stage feeds a phase detector only (xfmd's loop behind nbp0): the store takes the angle of each output, 8 bytes instead of 16
+// and no pass of its own over the stage's output (kThetaZero marks an all-zero sample, as pll_theta_kernel does).
+template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, bool POLY = false,
+          bool THETA = false>
 __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -399,7 +404,11 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
                 C v;
                 v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
                 v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
-                if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, (double)v.x, (double)v.y);
+                if constexpr (THETA) {
+                    double th = atan2((double)v.y, (double)v.x) * (1.0 / 6.2831853071795864);
+                    if (v.x == (T)0 && v.y == (T)0) th = kThetaZeroMark;
+                    a.theta[(long long)ch * a.theta_stride + a.out_offset + m] = th;
+                } else if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, (double)v.x, (double)v.y);
                 else out[m] = v;
             }
         }

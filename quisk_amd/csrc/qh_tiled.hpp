@@ -293,7 +293,7 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
 // ---- FM discriminator (xfmd's loop, wdsp/fmd.c:151-172) ---------------------------------------------------------------
 // arg z in turns, (-0.5, 0.5], for every sample of the listed channels; an all-zero sample ("corr[0] = 1.0": det = 0) is
 // marked by the value kThetaZero, which the loop turns into zero loop gains for that step
-static constexpr double kThetaZero = 8.0;
+static constexpr double kThetaZero = kThetaZeroMark;     // qh_osfir.hpp: a THETA stage writes the same mark
 static __global__ __launch_bounds__(NT) void pll_theta_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
                                                               double *theta, long long tstride)
 {
