@@ -229,6 +229,8 @@ struct Engine {
     // tiles pll_verify_kernel had to re-run
     double *pll_ends = nullptr;
     long long pll_ends_cap = 0;             // tiles per channel
+    double *am_tsum = nullptr;              // [nch][am_tsum_cap][2]: the AM nbp0 tiles' contributions to the fade leveller (osfir_kernel DET 2)
+    long long am_tsum_cap = 0;
     double *seg_sum[3] = { nullptr, nullptr, nullptr };     // segment summaries of the multi-workgroup scans: AM / SAM, FM dc, snotch
     int *pll_nfixed = nullptr;
     int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
@@ -274,7 +276,8 @@ struct Engine {
     void pack_audio(const double2 *src, long long src_stride, long long n);
     void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                  const int *list, int nlist, bool meter = false, bool egress = false, double *theta = nullptr, long long theta_stride = 0);
+                  const int *list, int nlist, bool meter = false, bool egress = false, int det = 0, double *det_out = nullptr,
+                  long long det_stride = 0);
     int ensure_buffers(long long n_mid);
     int ensure_meter_partials(long long n_mid, int lout);
     int emnr_alloc();
@@ -302,7 +305,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
-    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed);
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
@@ -1263,13 +1266,13 @@ void Engine::tick(int cat)
 }
 
 template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft, bool POLY = false,
-          bool THETA = false>
+          int DET = 0>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, NFFT, D, METER>();
-    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY, THETA>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY, DET>), grid, block, lds, s, a);
 }
 template <int NFFT>
 static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
@@ -1407,7 +1410,7 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
 // one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
 void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                      const int *list, int nlist, bool meter, bool egress, double *theta, long long theta_stride)
+                      const int *list, int nlist, bool meter, bool egress, int det, double *det_out, long long det_stride)
 {
     const int Lout = bnfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
@@ -1425,9 +1428,15 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
-    if (theta) {            // the caller has checked: 4096-point tiles, no meters, no egress
-        a.theta = theta; a.theta_stride = theta_stride;
-        launch_osfir<1, false, false, false, false, false, kNfft, false, true>(a, ntiles, nl, stream);
+    if (det) {              // the caller has checked: 4096-point tiles, no meters, no egress
+        a.det_out = det_out; a.det_stride = det_stride;
+        if (det == 2) {
+            a.det_sum = am_tsum; a.det_sum_stride = am_tsum_cap;
+            a.det_m[0] = am_prm.mtauR; a.det_m[1] = am_prm.mtauI;
+            a.det_m256[0] = std::pow(am_prm.mtauR, 256.0); a.det_m256[1] = std::pow(am_prm.mtauI, 256.0);
+            a.det_g[0] = am_prm.onem_mtauR; a.det_g[1] = am_prm.onem_mtauI;
+            launch_osfir<1, false, false, false, false, false, kNfft, false, 2>(a, ntiles, nl, stream);
+        } else launch_osfir<1, false, false, false, false, false, kNfft, false, 1>(a, ntiles, nl, stream);
     } else if (band6k) launch_band6k(a, ntiles, nl, stream, meter, egress);
     else if (band2g) launch_band2g(a, ntiles, nl, stream, meter, egress);
     else if (bnfft == kNfft) launch_band<kNfft>(a, ntiles, nl, stream, meter, egress);
@@ -1591,6 +1600,20 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                         // the first stores to `out` come while other channels' input is still being read: not for a caller that works in place
                         ((const char *)(out + (size_t)nch * (size_t)out_stride) <= (const char *)in ||
                          (const char *)in + (size_t)nch * (size_t)in_stride * sizeof(double2) <= (const char *)out);
+    // ... and the AM channels' nbp0 leaves the envelope and every tile's share of the fade leveller's averages: one pass does the rest
+    const int P_am = ((P + 63) / 64) * 64;
+    const bool am_fused = direct && n_am > 0 && n_rb == n_am + n_sam && !band6k && !band2g && bnfft == kNfft && P_am < bnfft;
+    if (am_fused) {
+        const long long nt = (n_mid + (bnfft - P_am) - 1) / (bnfft - P_am);
+        if (nt > am_tsum_cap) {
+            QH_HIP(hipStreamSynchronize(stream));
+            if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
+            drop_graphs(); epoch++;
+            (void)hipFree(am_tsum); am_tsum = nullptr;
+            QH_HIP(dev_alloc(&am_tsum, (size_t)nch * (size_t)nt * 2));
+            am_tsum_cap = nt;
+        }
+    }
     if (split) {
         if (!side_stream) {
             QH_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -1604,7 +1627,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         int hc = cur_nbp;
         // the FM channels' nbp0 feeds the loop's phase detector and nothing else: its store takes the angles (first half of the rows)
         if (any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_fm, n_fm, false, false,
-                              fm_theta_fused ? reinterpret_cast<double *>(other) : nullptr, 2 * buf_cap);
+                              fm_theta_fused ? 1 : 0, reinterpret_cast<double *>(other), 2 * buf_cap);
         std::swap(stream, side_stream);
         int rc2 = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_rest, n_rest, 2);
         hc = cur_nbp;
@@ -1612,7 +1635,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             if (direct) {       // the plain channels end here: output matrix in the store, straight to the caller's buffer
                 if (n_usb) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_usb, n_usb);
                 hc = cur_nbp;
-                if (n_rb) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rb, n_rb);
+                if (am_fused) {
+                    if (n_sam) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_sam, n_sam);
+                    hc = cur_nbp;
+                    run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P_am, list_am, n_am, false, false,
+                             2, reinterpret_cast<double *>(other), 2 * buf_cap);
+                } else if (n_rb) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rb, n_rb);
             } else run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rest, n_rest);
         }
         std::swap(stream, side_stream);
@@ -1680,7 +1708,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     };
     for (double *&q : seg_sum)
         if (!q) QH_HIP(dev_alloc(&q, (size_t)nch * kSegWaves * kSegMaxGroups * kSegSumW));
-    if (n_am) {
+    if (n_am && am_fused) {         // envelopes in the channels' own rows (first half), audio to the rows of `other`
+        const int G = seg_groups(n_am + (n_mid >= kSamTiledMin ? n_sam0 : 0));
+        hipLaunchKernelGGL(am_level_tiled_kernel, dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream,
+                           (const double *)reinterpret_cast<double *>(cur), 2 * buf_cap, other, buf_cap, (int)n_mid, list_am, levelfade, am_state,
+                           am_prm, (const double *)am_tsum, am_tsum_cap, bnfft - P_am);
+    } else if (n_am) {
         const int G = seg_groups(n_am + (n_mid >= kSamTiledMin ? n_sam0 : 0));
         if (G > 1) {
             hipLaunchKernelGGL((am_detect_tiled_kernel<false, 1>), dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
@@ -1737,7 +1770,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (direct && n_bp1p[0]) {      // bp1 is the AM / SAM channels' last stage: it follows their detectors on the second stream
         std::swap(stream, side_stream);
         int hc = cur_bp1;
-        run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[0], n_bp1p[0]);
+        if (am_fused) {
+            run_band(other, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_am, n_am);
+            hc = cur_bp1;
+            if (n_sam) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_sam, n_sam);
+        } else run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[0], n_bp1p[0]);
         std::swap(stream, side_stream);
     }
     if (side) QH_HIP(hipEventRecord(ev_join, side_stream));

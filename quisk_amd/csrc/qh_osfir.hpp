@@ -31,6 +31,7 @@
 // masks and twiddles are L2 resident.
 #pragma once
 #include "qh_fft.hpp"
+#include "qh_wave.hpp"
 #include "qh_ingest.hpp"
 #include "qh_egress.hpp"
 
@@ -80,9 +81,18 @@ template <typename T> struct OsfirArgs {
     long long meter_stride;
     const double *meter_w;              // [64]  (1 - m) m^(63 - i)
     const double2 *tw_r2;               // osfir8k_kernel: exp(-2 pi i k / 8192), k < 256
-    double *theta;                      // THETA kernels: arg(output) in turns (qh_tiled.hpp, pll_theta_kernel) leaves instead of the output
-    long long theta_stride;             // [nch][theta_stride] doubles
+    // DET kernels: the stage feeds a detector only, and the detector's first step rides in the store.  One double per output leaves
+    // (det_out [nch][det_stride]) instead of the complex sample:
+    //   DET 1  arg z in turns (xfmd's loop takes nothing else: qh_tiled.hpp, pll_theta_kernel)
+    //   DET 2  |z| (xamd's envelope, amd.c:131-133), and per tile the response of the fade leveller's two averages to the tile's own
+    //          magnitudes from a zero state (amd.c:136-137): det_sum [nch][det_sum_stride][2] = g sum_i m^(Lout - 1 - i) |z_i|
+    double *det_out;
+    long long det_stride;
+    double *det_sum;
+    long long det_sum_stride;           // tiles per channel row
+    double det_m[2], det_m256[2], det_g[2];
 };
+
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
 template <> __device__ __forceinline__ void sincos_turns<double>(unsigned long long ph, double &c, double &s)
@@ -254,10 +264,9 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
 
 // POLY: the forward transform stops ahead of the stage that combines the D decimated sequences and the mask holds the
 // polyphase spectra G (FftSplit4096::run_poly, front_mask_kernel): same fold below, one butterfly stage less.
-// THETA: the stage feeds a phase detector only (xfmd's loop behind nbp0): the store takes the angle of each output, 8 bytes instead of 16
-// and no pass of its own over the stage's output (kThetaZero marks an all-zero sample, as pll_theta_kernel does).
+// DET: see OsfirArgs (8 bytes per output instead of 16, and no pass of the detector's own over the stage's output).
 template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, bool POLY = false,
-          bool THETA = false>
+          int DET = 0>
 __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -396,20 +405,43 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
     EpiParam ep;
     if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
     if (a.pick <= 1) {
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
         for (int i = 0; i < EO; i++) {
             const int rel = t + NT * i - j0;
             const long long m = (long long)tile * a.Lout + rel;
+            double mag = 0.0;
             if (rel >= 0 && rel < a.Lout && m < a.n_out) {
                 C v;
                 v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
                 v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
-                if constexpr (THETA) {
+                if constexpr (DET == 1) {
                     double th = atan2((double)v.y, (double)v.x) * (1.0 / 6.2831853071795864);
                     if (v.x == (T)0 && v.y == (T)0) th = kThetaZeroMark;
-                    a.theta[(long long)ch * a.theta_stride + a.out_offset + m] = th;
+                    a.det_out[(long long)ch * a.det_stride + a.out_offset + m] = th;
+                } else if constexpr (DET == 2) {
+                    mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
+                    a.det_out[(long long)ch * a.det_stride + a.out_offset + m] = mag;
                 } else if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, (double)v.x, (double)v.y);
                 else out[m] = v;
+            }
+            if constexpr (DET == 2) {       // sample rel = t - j0 + NT i has weight m^(Lout - 1 - rel): Horner in m^NT over i, m^(NT - 1 - t) below
+                acc0 = __builtin_fma(acc0, a.det_m256[0], mag);
+                acc1 = __builtin_fma(acc1, a.det_m256[1], mag);
+            }
+        }
+        if constexpr (DET == 2) {
+            static_assert(D == 1 && NT == 256 && !EGRESS && !METER, "the envelope tap rides on a plain D = 1 stage");
+            // Lout + P = NFFT: the exponent of element i is (NFFT - 1 - t) - NT i = (NT - 1 - t) + NT (EO - 1 - i)
+            const double s0 = wave_sum_d(acc0 * ipow_d(a.det_m[0], NT - 1 - t)), s1 = wave_sum_d(acc1 * ipow_d(a.det_m[1], NT - 1 - t));
+            double *red = reinterpret_cast<double *>(lds);
+            __syncthreads();                    // the inverse transform's last exchange has been read by everyone
+            if ((t & 63) == 0) { red[(t >> 6) * 2] = s0; red[(t >> 6) * 2 + 1] = s1; }
+            __syncthreads();
+            if (t == 0) {
+                double *o = a.det_sum + ((long long)ch * a.det_sum_stride + tile) * 2;
+                o[0] = a.det_g[0] * ((red[0] + red[2]) + (red[4] + red[6]));
+                o[1] = a.det_g[1] * ((red[1] + red[3]) + (red[5] + red[7]));
             }
         }
     } else {

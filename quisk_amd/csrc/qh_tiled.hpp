@@ -122,6 +122,66 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
     if (sidx == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
 }
 
+// The AM fade leveller behind an nbp0 stage that left the envelope itself (osfir_kernel DET 2): mag [ch][mstride] doubles, tsum
+// [ch][tstride][2] every filter tile's contribution to the two averages (L samples per tile, a multiple of 64).  Segments are cut on
+// tile boundaries, a segment's carry-in is the chain over the tiles ahead of it, and there is one pass: 8 bytes read, 16 written
+// per sample, against 16 + 16 + 16 + 16 of am_detect_tiled_kernel's two.  out may not be the rows `mag` lies in.
+static __global__ __launch_bounds__(kSegThreads) void am_level_tiled_kernel(const double *mag, long long mstride, double2 *out, long long ostride,
+                                                                            int n, const int *chan_list, const int *levelfade, AmState *state,
+                                                                            AmParam prm, const double *tsum, long long tstride, int L)
+{
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
+    const double *a = mag + (long long)ch * mstride;
+    double2 *p = out + (long long)ch * ostride;
+    const bool lf = levelfade[ch] != 0;
+    const int nb = (n + 63) >> 6, lb = L >> 6, nt = (n + L - 1) / L;
+    const int t0 = (int)((long long)sidx * nt / S), t1 = (int)((long long)(sidx + 1) * nt / S);
+    const int b0 = t0 * lb, b1 = t1 * lb < nb ? t1 * lb : nb;
+    const bool is_last = t1 == nt && t0 < t1;
+    const PoleScan sR = make_pole_scan(prm.mtauR, lane), sI = make_pole_scan(prm.mtauI, lane);
+    double cR = state[ch].dc, cI = state[ch].dc_insert;
+    if (lf) {
+        // c = c_in mL^t0 + sum_{t < t0} mL^(t0 - 1 - t) s_t for both averages, 64 tiles per step
+        const double mR = pow(prm.mtauR, (double)L), mI = pow(prm.mtauI, (double)L);
+        const double *e = tsum + (long long)ch * tstride * 2;
+        for (int blk = 0; blk < t0; blk += 64) {
+            const int cnt = t0 - blk < 64 ? t0 - blk : 64;
+            double vR = 0.0, vI = 0.0;
+            if (lane < cnt) {
+                const double2 s = *reinterpret_cast<const double2 *>(e + (long long)(blk + lane) * 2);
+                vR = s.x * ipow_d(mR, cnt - 1 - lane);
+                vI = s.y * ipow_d(mI, cnt - 1 - lane);
+            }
+            cR = __builtin_fma(cR, ipow_d(mR, cnt), wave_sum_d(vR));
+            cI = __builtin_fma(cI, ipow_d(mI, cnt), wave_sum_d(vI));
+        }
+    }
+    double an[kSegGroup];
+    seg_load(an, b0, b1, n, lane, a);
+    for (int b = b0; b < b1; b += kSegGroup) {
+        double av[kSegGroup];
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) av[k] = an[k];
+        seg_load(an, b + kSegGroup, b1, n, lane, a);
+#pragma unroll
+        for (int k = 0; k < kSegGroup; k++) {
+            if (b + k >= b1) break;
+            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
+            const double v = av[k];
+            double audio = v;
+            if (lf) {                                       // block-uniform
+                const double dc = scan_pole_dpp(prm.onem_mtauR * v, sR) + sR.pw * cR;       // amd.c:136-137
+                const double di = scan_pole_dpp(prm.onem_mtauI * v, sI) + sI.pw * cI;
+                audio = v + (di - dc);                                                       // amd.c:138
+                cR = lane_bcast(dc, cnt - 1); cI = lane_bcast(di, cnt - 1);
+            }
+            if (lane < cnt) p[base + lane] = make_double2(audio, audio);
+        }
+    }
+    if (lf && is_last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+}
+
 // ---- CTCSS notch (xsnotch, wdsp/iir.c:76-95): bi-quad on the I component, in place ------------------------------------
 // state vector (y_i, y_{i-1}) driven by (f_i, 0), f_i = a0 x_i + a1 x_{i-1} + a2 x_{i-2}; transition A = [[b1, b2], [1, 0]]
 __device__ __forceinline__ M2 m2_pow(M2 a, int e)

@@ -26,6 +26,18 @@ __device__ __forceinline__ double lane_pow(double x, int e)
     return r;
 }
 
+// x^e, e >= 0 any per-lane value
+__device__ __forceinline__ double ipow_d(double x, int e)
+{
+    double r = 1.0;
+    while (e > 0) {
+        if (e & 1) r *= x;
+        x *= x;
+        e >>= 1;
+    }
+    return r;
+}
+
 // inclusive scan of v_i = m*v_{i-1} + u_i over the 64 lanes with zero carry-in: returns sum_j m^(i-j) u_j
 // Value of lane i for every lane, i wave-uniform: two v_readlane_b32 instead of the LDS-crossbar ds_bpermute that
 // __shfl compiles to (its ~100 cycles would sit in the critical path of every step of the sequential kernels).

@@ -167,7 +167,7 @@ def test_last_stage_writes_the_output_directly_and_equals_the_separate_output_pa
     """USB / AM / SAM / FM (one with its CTCSS notch off) in one call, fixed gain and panel gains that differ per channel: with no
     stage between a channel's last filter and the output matrix that filter's store applies the matrix (qh_engine.hip, `direct`).
     The same engine with meters on runs every channel through the separate output pass; a caller working in place does as well.
-    All three agree to the last bit, and with the oracle."""
+    All three agree (to the last bit where the operations are the same), and with the oracle."""
     import torch
     nch, nblk = 10, 160
     modes = [(USB, "usb"), (AM, "am"), (FM, "fm"), (SAM, "am"), (FM, "fm")]
@@ -183,15 +183,21 @@ def test_last_stage_writes_the_output_directly_and_equals_the_separate_output_pa
             e.SetRXAPanelCopy(c, c % 4)
         e.enable_meters(meters)
         return e
+    def same(u, v):
+        # the AM channels' nbp0 runs on tiles of 2048 outputs instead of 2049 when its store takes the envelope (other rounding, same
+        # arithmetic); every other channel is the same sequence of operations on either route
+        for c in range(nch):
+            if modes[c % 5][0] == AM: assert rel_rms(u[c], v[c]) < 1e-12, c
+            else: assert np.array_equal(u[c], v[c]), c
     ya = make(False).process_host(x)
     yb = make(True).process_host(x)
-    assert np.array_equal(ya, yb)
+    same(ya, yb)
     e = make(False)                                      # in place: output rows over the input rows
     d = torch.from_numpy(x.view(np.float64).copy()).cuda()
     e.process_ptr(d.data_ptr(), nblk * 1024, d.data_ptr(), nblk * 1024, nblk)
     e.synchronize()
     yc = d.cpu().numpy().view(np.complex128)[:, :nblk * 256]
-    assert np.array_equal(ya, yc)
+    same(ya, yc)
     for c in range(nch):
         o = _cfg_oracle(oracle, c, modes[c % 5][0], **kws[c % 5])
         o.SetRXAAGCFixed(3.0 * c - 6.0); o.SetRXAPanelGain1(0.5 + 0.1 * c); o.SetRXAPanelGain2(1.0 - 0.05 * c, 0.6 + 0.03 * c); o.SetRXAPanelCopy(c % 4)
