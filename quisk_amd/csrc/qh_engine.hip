@@ -17,6 +17,7 @@
 //   hist_bp1   [2][nch][HB]
 //   nco_phase  [nch]         64-bit fixed-point turns
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -181,6 +182,11 @@ struct Engine {
     int *list_buf = nullptr, *list_am = nullptr, *list_sam = nullptr, *list_fm = nullptr, *list_bp1 = nullptr, *list_plain = nullptr;
     int n_am = 0, n_sam = 0, n_fm = 0, n_bp1 = 0, n_plain = 0, n_rest = 0, n_usb = 0, n_rb = 0;
     int *list_usb = nullptr, *list_rb = nullptr;       // the non-FM channels without / with a bp1 stage
+    // channel pairs for the real filters behind the detectors (osfir_kernel PAIR): FM de-emphasis (one mask for all), bp1 of the AM
+    // and of the SAM channels (partners have the same design; count 0 when a channel of the kind has complex taps)
+    int *pairs_fm = nullptr, *pairs_am = nullptr, *pairs_sam = nullptr;
+    int np_fm = 0, np_am = 0, np_sam = 0;
+    bool de_real = false;
     bool all_nbp = false;
     int *list_rest = nullptr;                // the channels that are not FM (the mixed-mode path runs the two kinds on two streams)
     int n_sam0 = 0;                         // the first n_sam0 entries of list_sam have sbmode 0 (no all-pass chains): time-tiled in long calls
@@ -277,7 +283,7 @@ struct Engine {
     void run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                   long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
                   const int *list, int nlist, bool meter = false, bool egress = false, int det = 0, double *det_out = nullptr,
-                  long long det_stride = 0);
+                  long long det_stride = 0, const int *pairs = nullptr, int npairs = 0);
     int ensure_buffers(long long n_mid);
     int ensure_meter_partials(long long n_mid, int lout);
     int emnr_alloc();
@@ -597,6 +603,7 @@ int Engine::refresh_params()
             QH_HIP(hipMemcpyAsync(mask_bp1 + (size_t)ch * kBandNfftMax, last_bp1.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.bp1_dirty = false;
+            lists_dirty = true;             // the channel pairs of the real bp1 filters follow the designs
         }
         if (c.nbp_flush) {      // setNc_fircore re-plans and so zeroes the delay line, wdsp/firmin.c:454-466
             for (int i = 0; i < 2; i++)
@@ -648,8 +655,9 @@ int Engine::refresh_demod()
 {
     const double rate = (double)dsp_rate;
     if (!demod_alloc) {
-        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 27));
+        QH_HIP(dev_alloc(&list_buf, (size_t)nch * 33));
         list_rest = list_buf + 24 * nch; list_usb = list_buf + 25 * nch; list_rb = list_buf + 26 * nch;
+        pairs_fm = list_buf + 27 * nch; pairs_am = list_buf + 29 * nch; pairs_sam = list_buf + 31 * nch;
         list_amsq = list_buf + 17 * nch;
         for (int k = 0; k < 3; k++) list_emnr[k] = list_buf + (18 + k) * nch;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) list_lms[f][k] = list_buf + (7 + 3 * f + k) * nch;
@@ -834,6 +842,34 @@ int Engine::refresh_demod()
         QH_HIP(put(list_am, la)); QH_HIP(put(list_sam, ls)); QH_HIP(put(list_fm, lf)); QH_HIP(put(list_bp1, lb)); QH_HIP(put(list_plain, lp));
         QH_HIP(put(list_agc_cur, lgc)); QH_HIP(put(list_agc_other, lgo)); QH_HIP(put(list_rest, lrest)); QH_HIP(put(list_usb, lusb)); QH_HIP(put(list_rb, lrb));
         n_rest = (int)lrest.size(); n_usb = (int)lusb.size(); n_rb = (int)lrb.size();
+        {
+            // partners: neighbours in the list, ordered so that equal designs are neighbours; a channel left over is its own partner
+            auto bp1_real = [&](int ch) { const ChanCfg &c = cfg[(size_t)ch]; return c.bp1_run && c.bp1_flow == -c.bp1_fhigh && !c.mp; };
+            auto bp1_same = [&](int x, int y) {
+                const ChanCfg &p = cfg[(size_t)x], &q = cfg[(size_t)y];
+                return p.bp1_nc == q.bp1_nc && p.bp1_wintype == q.bp1_wintype && p.bp1_fhigh == q.bp1_fhigh && p.bp1_gain == q.bp1_gain;
+            };
+            auto bp1_pairs = [&](std::vector<int> v) {
+                std::vector<int> pr;
+                for (int ch : v) if (!bp1_real(ch)) return pr;
+                std::stable_sort(v.begin(), v.end(), [&](int x, int y) {
+                    const ChanCfg &p = cfg[(size_t)x], &q = cfg[(size_t)y];
+                    if (p.bp1_fhigh != q.bp1_fhigh) return p.bp1_fhigh < q.bp1_fhigh;
+                    if (p.bp1_nc != q.bp1_nc) return p.bp1_nc < q.bp1_nc;
+                    if (p.bp1_wintype != q.bp1_wintype) return p.bp1_wintype < q.bp1_wintype;
+                    return p.bp1_gain < q.bp1_gain;
+                });
+                for (size_t i = 0; i < v.size();) {
+                    if (i + 1 < v.size() && bp1_same(v[i], v[i + 1])) { pr.push_back(v[i]); pr.push_back(v[i + 1]); i += 2; }
+                    else { pr.push_back(v[i]); pr.push_back(v[i]); i += 1; }
+                }
+                return pr;
+            };
+            std::vector<int> pf, pa = bp1_pairs(la), ps = bp1_pairs(ls);
+            for (size_t i = 0; i < lf.size(); i += 2) { pf.push_back(lf[i]); pf.push_back(i + 1 < lf.size() ? lf[i + 1] : lf[i]); }
+            QH_HIP(put(pairs_fm, pf)); QH_HIP(put(pairs_am, pa)); QH_HIP(put(pairs_sam, ps));
+            np_fm = (int)pf.size() / 2; np_am = (int)pa.size() / 2; np_sam = (int)ps.size() / 2;
+        }
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) QH_HIP(put(list_lms[f][k], lms_l[f][k]));
         QH_HIP(put(list_bp1p[0], lbp[0])); QH_HIP(put(list_bp1p[1], lbp[1]));
         QH_HIP(put(list_fix[0], lfix[0])); QH_HIP(put(list_fix[1], lfix[1])); QH_HIP(put(list_amsq, lsq));
@@ -1026,6 +1062,8 @@ int Engine::refresh_demod()
         fm_mp_built = fm_mp;
         for (auto &v : de) v *= (double)(2 * dsp_size);
         for (auto &v : au) v *= (double)(2 * dsp_size);
+        de_real = true;
+        for (const cd &v : de) de_real = de_real && v.imag() == 0.0;
         if (int rc = upload(mask_de, band_mask(de), stream)) return rc;
         if (int rc = upload(mask_aud, band_mask(au), stream)) return rc;
         fm_nfft_built = 2 * bnfft + (band2g ? 1 : 0);
@@ -1266,13 +1304,13 @@ void Engine::tick(int cat)
 }
 
 template <int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, int NFFT = kNfft, bool POLY = false,
-          int DET = 0>
+          int DET = 0, bool PAIR = false>
 static void launch_osfir(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s)
 {
     a.ntiles = ntiles;
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile), qh_osfir.hpp
     constexpr int lds = osfir_lds_bytes<double, NFFT, D, METER>();
-    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY, DET>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((osfir_kernel<double, NFFT, D, MIX, PACKED, METER, OUTMIX, EGRESS, POLY, DET, PAIR>), grid, block, lds, s, a);
 }
 template <int NFFT>
 static void launch_band(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
@@ -1410,7 +1448,8 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
 // one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
 void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
-                      const int *list, int nlist, bool meter, bool egress, int det, double *det_out, long long det_stride)
+                      const int *list, int nlist, bool meter, bool egress, int det, double *det_out, long long det_stride,
+                      const int *pairs, int npairs)
 {
     const int Lout = bnfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
@@ -1428,7 +1467,10 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
-    if (det) {              // the caller has checked: 4096-point tiles, no meters, no egress
+    if (pairs) {            // the caller has checked: real taps, one mask per pair, 4096-point tiles, no meters, no egress
+        a.chan_list = pairs;
+        launch_osfir<1, false, false, false, false, false, kNfft, false, 0, true>(a, ntiles, npairs, stream);
+    } else if (det) {       // the caller has checked: 4096-point tiles, no meters, no egress
         a.det_out = det_out; a.det_stride = det_stride;
         if (det == 2) {
             a.det_sum = am_tsum; a.det_sum_stride = am_tsum_cap;
@@ -1771,9 +1813,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         std::swap(stream, side_stream);
         int hc = cur_bp1;
         if (am_fused) {
-            run_band(other, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_am, n_am);
+            run_band(other, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_am, n_am, false, false, 0, nullptr, 0,
+                     np_am ? pairs_am : nullptr, np_am);
             hc = cur_bp1;
-            if (n_sam) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_sam, n_sam);
+            if (n_sam) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_sam, n_sam, false, false, 0,
+                                nullptr, 0, np_sam ? pairs_sam : nullptr, np_sam);
         } else run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[0], n_bp1p[0]);
         std::swap(stream, side_stream);
     }
@@ -1811,7 +1855,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                                    (const double *)pll_ends, pll_ends_cap * kPllEndsW, kFmTile);
             }
         }
-        run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm);      // de-emphasis
+        {   // de-emphasis: real taps on a real signal, two channels per tile
+            const bool pair = de_real && np_fm && !band6k && !band2g && bnfft == kNfft;
+            run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm, false, false, 0, nullptr, 0,
+                     pair ? pairs_fm : nullptr, np_fm);
+        }
         run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_aud, 0, hist_aud, cur_aud, P, list_fm, n_fm);   // audio filter
         tick(1);
         {

@@ -265,8 +265,12 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
 // POLY: the forward transform stops ahead of the stage that combines the D decimated sequences and the mask holds the
 // polyphase spectra G (FftSplit4096::run_poly, front_mask_kernel): same fold below, one butterfly stage less.
 // DET: see OsfirArgs (8 bytes per output instead of 16, and no pass of the detector's own over the stage's output).
+// PAIR: a REAL filter (its mask is the transform of real taps) behind a detector, whose output is one real signal written to both
+// components (xamd: amd.c:139-140, xfmd: fmd.c:170-171): two channels with the same mask share a tile -- channel A in the real part,
+// channel B in the imaginary part, one transform pair for both, and (y, y) goes to each one's row.  chan_list holds the pairs
+// (A0, B0, A1, B1, ...; a channel without a partner is paired with itself).
 template <typename T, int NFFT, int D, bool MIX, bool PACKED = false, bool METER = false, bool OUTMIX = false, bool EGRESS = false, bool POLY = false,
-          int DET = 0>
+          int DET = 0, bool PAIR = false>
 __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void osfir_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -284,7 +288,8 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
     const int t = threadIdx.x;
     int tile, slot;
     xcd_tile_map(a.ntiles, slot, tile);
-    const int ch = a.chan_list ? a.chan_list[slot] : slot;
+    const int ch = PAIR ? a.chan_list[2 * slot] : a.chan_list ? a.chan_list[slot] : slot;
+    const int ch_b = PAIR ? a.chan_list[2 * slot + 1] : ch;
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
     const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile (Lout counts folded samples)
@@ -315,6 +320,25 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
                 const int g = g0 + t + r * NT;
                 if (g >= 0) x[r] = g < a.n_in ? decode_packed<T>(a.pk_src, a.pk, ch, (long long)g) : mk<T>(0, 0);
                 else x[r] = (hist && g + a.hist_len >= 0) ? hist[g + a.hist_len] : mk<T>(0, 0);
+            }
+        }
+    } else if constexpr (PAIR) {
+        static_assert(D == 1 && !MIX && !METER && !OUTMIX && !EGRESS && !POLY && DET == 0, "pairs ride on a plain D = 1 stage");
+        const C *in_b = a.in + (long long)ch_b * a.in_stride;
+        const C *hist_b = a.hist ? a.hist + (long long)ch_b * a.hist_stride : nullptr;
+        if (interior) {
+            const C *p = in + g0 + t, *pb = in_b + g0 + t;
+#pragma unroll
+            for (int r = 0; r < E; r++) x[r] = mk<T>(p[r * NT].x, pb[r * NT].x);
+        } else {
+            auto fetch = [&](const C *src, const C *h, int g) -> T {
+                if (g >= 0) return g < a.n_in ? src[g].x : (T)0;
+                return (h && g + a.hist_len >= 0) ? h[g + a.hist_len].x : (T)0;
+            };
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const int g = g0 + t + r * NT;
+                x[r] = mk<T>(fetch(in, hist, g), fetch(in_b, hist_b, g));
             }
         }
     } else if (interior) {
@@ -404,7 +428,21 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
     const int j0 = a.P / D;
     EpiParam ep;
     if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
-    if (a.pick <= 1) {
+    if constexpr (PAIR) {
+        C *out_b = a.out + (long long)ch_b * a.out_stride + a.out_offset;
+        EpiParam eb = ep;
+        if (a.epi) eb = a.epi[ch_b];
+#pragma unroll
+        for (int i = 0; i < EO; i++) {
+            const int rel = t + NT * i - j0;
+            const long long m = (long long)tile * a.Lout + rel;
+            if (rel >= 0 && rel < a.Lout && m < a.n_out) {
+                const T ya = z[i].x, yb = z[i].y;
+                out[m] = mk<T>((T)ep.a * ya + (T)ep.b * ya, (T)ep.c * ya + (T)ep.d * ya);
+                out_b[m] = mk<T>((T)eb.a * yb + (T)eb.b * yb, (T)eb.c * yb + (T)eb.d * yb);
+            }
+        }
+    } else if (a.pick <= 1) {
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
         for (int i = 0; i < EO; i++) {

@@ -184,10 +184,11 @@ def test_last_stage_writes_the_output_directly_and_equals_the_separate_output_pa
         e.enable_meters(meters)
         return e
     def same(u, v):
-        # the AM channels' nbp0 runs on tiles of 2048 outputs instead of 2049 when its store takes the envelope (other rounding, same
+        # the AM channels' nbp0 runs on tiles of 2048 outputs instead of 2049 when its store takes the envelope, and the real bp1
+        # filter of an AM / SAM channel shares its transforms with a partner channel on the direct route (other rounding, same
         # arithmetic); every other channel is the same sequence of operations on either route
         for c in range(nch):
-            if modes[c % 5][0] == AM: assert rel_rms(u[c], v[c]) < 1e-12, c
+            if modes[c % 5][0] in (AM, SAM): assert rel_rms(u[c], v[c]) < 1e-12, c
             else: assert np.array_equal(u[c], v[c]), c
     ya = make(False).process_host(x)
     yb = make(True).process_host(x)
@@ -204,3 +205,32 @@ def test_last_stage_writes_the_output_directly_and_equals_the_separate_output_pa
         ref = o.xrxa(x[c])
         lo = 0 if modes[c % 5][0] in (USB, AM) else 120 * 256
         assert rel_rms(ya[c][lo:], ref[lo:]) < (TOL if lo == 0 else 1e-6), c
+
+
+@pytest.mark.parametrize("am_bands", [[(-4000.0, 4000.0), (-4000.0, 4000.0), (-3000.0, 3000.0), (-4000.0, 4000.0)],
+                                      [(-4000.0, 4000.0), (-4000.0, 3000.0), (-4000.0, 4000.0), (-4000.0, 4000.0)]],
+                         ids=["real-bp1-two-designs", "one-complex-bp1"])
+def test_partner_channels_of_the_real_filters(qh, oracle, am_bands):
+    """The filters behind the detectors (bp1 of AM, FM de-emphasis) have real taps and a real input: two channels share a tile
+    (osfir_kernel PAIR).  Three FM channels (one is its own partner), four AM channels of which one has another passband (its own
+    partner) or an asymmetric one (complex taps: nobody is paired); the second AM channel is 80 dB under its partner, whose rounding
+    noise it now shares.  Every channel against the oracle."""
+    modes = [USB, FM, AM, FM, AM, FM, AM, AM]
+    nch, nblk = len(modes), 192
+    sig = {USB: "usb", FM: "fm", AM: "am"}
+    x = np.stack([synth.make_mode_input_numpy(sig[m], c, nblk * 1024) for c, m in enumerate(modes)])
+    ams = [c for c, m in enumerate(modes) if m == AM]
+    x[ams[1]] *= 1e-4
+    e = qh.RxaEngine(nch)
+    refs = []
+    for c, m in enumerate(modes):
+        _cfg_engine(e, c, m)
+        refs.append(_cfg_oracle(oracle, c, m))
+    for k, c in enumerate(ams):
+        e.RXASetPassband(c, *am_bands[k]); refs[c].RXASetPassband(*am_bands[k])
+    y = np.concatenate([e.process_host(x[:, :50 * 1024]), e.process_host(x[:, 50 * 1024:])], axis=1)
+    for c, m in enumerate(modes):
+        ref = refs[c].xrxa(x[c])
+        lo = 144 * 256 if m == FM else 0
+        err = rel_rms(y[c][lo:], ref[lo:])
+        assert err < (1e-6 if m == FM else TOL), (c, err)
