@@ -1832,7 +1832,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             if (!fm_theta_fused)
                 hipLaunchKernelGGL(pll_theta_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_fm), dim3(NT), 0, stream, cur, buf_cap,
                                    (int)n_mid, list_fm, theta, 2 * buf_cap);
-            const long long ntl = (n_mid + kFmTile - 1) / kFmTile;
+            static const int fm_tile_env = getenv("QH_FM_TILE") ? atoi(getenv("QH_FM_TILE")) : 0;
+            // the longest tile that still gives the chip 512 wavefronts of 64 tiles: the 768-sample warm-up is 3/4 of a 256-sample
+            // tile's steps and 3/11 of a 2048-sample tile's
+            int fm_tile = kFmTile;
+            while (fm_tile < 2048 && (long long)n_fm * n_mid / (64LL * 2 * fm_tile) >= 512) fm_tile *= 2;
+            if (fm_tile_env > 0) fm_tile = fm_tile_env;
+            const long long ntl = (n_mid + fm_tile - 1) / fm_tile;
             const int ngroups = (int)((ntl + 63) / 64);
             if ((long long)ngroups * 64 > pll_ends_cap) {
                 QH_HIP(hipStreamSynchronize(stream));
@@ -1843,16 +1849,16 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             }
             hipLaunchKernelGGL((pll_lanes_kernel<false>), dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
                                2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, pll_ends, pll_ends_cap * kPllEndsW,
-                               fm_pll_prm, kFmTile, kFmWarm);
+                               fm_pll_prm, fm_tile, kFmWarm);
             hipLaunchKernelGGL((pll_verify_kernel<false>), dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
-                               2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * kPllEndsW, fm_pll_prm, kFmTile, kFmWarm,
+                               2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * kPllEndsW, fm_pll_prm, fm_tile, kFmWarm,
                                pll_nfixed, pll_check_only);
             {
                 // dc removal + gain: the tiles' contributions are in `ends` already, one pass over `fil`
                 const int G = seg_groups(n_fm);
                 hipLaunchKernelGGL((fm_dc_tiled_kernel<3>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
                                    2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, (double *)nullptr,
-                                   (const double *)pll_ends, pll_ends_cap * kPllEndsW, kFmTile);
+                                   (const double *)pll_ends, pll_ends_cap * kPllEndsW, fm_tile);
             }
         }
         {   // de-emphasis: real taps on a real signal, two channels per tile

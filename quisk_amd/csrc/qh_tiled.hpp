@@ -385,13 +385,16 @@ __device__ __forceinline__ double max_nn_d(double a, double b)
 // n samples; fil: [ch][fstride] the loop filter output per sample (what xfmd's dc removal and gain work on).  L = tile length
 // (multiple of 64), H = warm-up (multiple of 64).  Lane l of group g owns outputs [q L, (q + 1) L), q = 64 g + l, and starts
 // at sample max(0, q L - H): from the carried state when that is sample 0 -- exact -- else from the zero state.
-// 64 steps at a time: the 64 x 64 angles of the next batch travel from HBM into registers (row j = tile j, coalesced) while
-// the current batch is stepped (lane l takes row l out of LDS into registers first; pitch 65 doubles: conflict free both
-// ways); the loop filter outputs go back through LDS and leave row by row, coalesced again.
+// kPllBatch steps at a time: the 64 x kPllBatch angles of the next batch travel from HBM into registers (runs of kPllBatch
+// consecutive samples per tile, coalesced) while the current batch is stepped (lane l takes row l out of LDS into registers first;
+// odd pitch: conflict free both ways); the loop filter outputs go back through LDS and leave the same way.  32 steps per batch
+// instead of 64 halves the registers (256 -> ~130) and the LDS block (33 -> 17 KB): the loop is a chain of dependent fp64
+// operations, and only other wavefronts on the SIMD fill its latency.
 // Speculation is checked, not trusted: every tile records its loop state where the warm-up ends (`ends` [ch][tile][0..2]) and
 // where the tile ends ([3..5]); pll_verify_kernel compares neighbours and re-runs, in order, the tiles whose warm-up had
 // not met the true trajectory yet (a loop that sits on noise, without a carrier, can take several hundred samples).
-static constexpr int kPllPitch = 65;
+static constexpr int kPllBatch = 32;
+static constexpr int kPllPitch = kPllBatch + 1;
 // `ends` row of a tile: [0..2] loop state where the warm-up ended, [3..5] where the tile ended, [6] (FM) the tile's own
 // contribution to the dc-removal average at its end: onem_mtau sum_i mtau^(L-1-i) fil_i -- what fm_dc_tiled_kernel's first pass
 // would read `fil` again for.  The loop kernel has every fil_i in a register anyway.
@@ -401,11 +404,11 @@ struct PllLane { double pt, fil_out, omega; };
 // EMIT_PT: the step's output is the VCO phase the sample SAW (turns; what the SAM detector mixes with, amd.c:150-158) instead
 // of the loop filter's output after it (the FM discriminator's audio, fmd.c:165)
 template <bool CHECKED, bool EMIT_PT>
-__device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[64], long long gb, int n, double g1t, double g2t, double inv,
+__device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[kPllBatch], long long gb, int n, double g1t, double g2t, double inv,
                                                double lo, double hi)
 {
 #pragma unroll
-    for (int k = 0; k < 64; k++) {
+    for (int k = 0; k < kPllBatch; k++) {
         const double th = t[k];
         const double seen = s.pt;
         double d = th - s.pt;                                   // (-1.5, 0.5] turns
@@ -426,7 +429,7 @@ __device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[64], long
 }
 
 template <bool EMIT_PT>
-static __global__ __launch_bounds__(64) void pll_lanes_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
+static __global__ __launch_bounds__(64, 2) void pll_lanes_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
                                                                  const int *chan_list, const PllState *state, double *ends, long long estride,
                                                                  PllParam q, int L, int H)
 {
@@ -467,49 +470,61 @@ static __global__ __launch_bounds__(64) void pll_lanes_kernel(const double *thet
     const int nsteps = H + L;
     double *e = ends + (long long)ch * estride + ((long long)group * 64 + lane) * kPllEndsW;
     double dcsum = 0.0;
-    double tn[64];                                                      // the next batch's angles, row j in tn[j]
+    constexpr int B = kPllBatch, RPI = 64 / B;                          // rows (tiles) one load instruction of the wavefront covers
+    const int frow = lane / B, fcol = lane % B;
+    // addresses: a wave-uniform base (scalar registers) that moves with the batch, and one 32-bit lane offset plus a uniform
+    // multiple of the row stride per load, formed when the load is issued -- kept out of the loop-invariant code the compiler would
+    // otherwise park in 2 x 2 x kPllBatch registers (the asm statement below)
+    const int RL = RPI * L, loff0 = frow * L + fcol, gb0 = (int)tile0 - H;
+    double tn[B];                                                       // the next batch's angles: instruction j = rows RPI j .. RPI j + RPI - 1
     auto fetch = [&](int i0) {
+        const double *pb = th + ((long long)gb0 + i0);                  // dereferenced only where the sample index is inside the call
+        int loff = loff0;
+        asm volatile("" : "+v"(loff));
 #pragma unroll
-        for (int j = 0; j < 64; j++) {
-            const long long g = tile0 + (long long)j * L - H + i0 + lane;
-            tn[j] = (g >= 0 && g < n) ? th[g] : 0.0;
+        for (int j = 0; j < B; j++) {
+            const int off = loff + j * RL, g = gb0 + i0 + off;
+            tn[j] = (g >= 0 && g < n) ? pb[(unsigned)off] : 0.0;
         }
     };
     fetch(0);
-    for (int i0 = 0; i0 < nsteps; i0 += 64) {
+    for (int i0 = 0; i0 < nsteps; i0 += B) {
 #pragma unroll
-        for (int j = 0; j < 64; j++) lds[j * kPllPitch + lane] = tn[j];
-        if (i0 + 64 < nsteps) fetch(i0 + 64);
+        for (int j = 0; j < B; j++) lds[(RPI * j + frow) * kPllPitch + fcol] = tn[j];
+        if (i0 + B < nsteps) fetch(i0 + B);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double *row = lds + lane * kPllPitch;
-        double t[64];
+        double t[B];
 #pragma unroll
-        for (int k = 0; k < 64; k++) t[k] = row[k];
+        for (int k = 0; k < B; k++) t[k] = row[k];
         const long long gb = g_first + i0;
         if (live) {
-            if (gb >= 0 && gb + 64 <= n) pll_lane_steps<false, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
-            else if (gb + 63 >= 0) pll_lane_steps<true, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
+            if (gb >= 0 && gb + B <= n) pll_lane_steps<false, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
+            else if (gb + B - 1 >= 0) pll_lane_steps<true, EMIT_PT>(s, t, gb, n, g1t, g2t, inv, lo, hi);
         }
-        if (i0 + 64 == H && live) { e[0] = s.pt; e[1] = s.fil_out; e[2] = s.omega; }      // state where the warm-up ends
+        if (i0 + B == H && live) { e[0] = s.pt; e[1] = s.fil_out; e[2] = s.omega; }       // state where the warm-up ends
         if constexpr (!EMIT_PT) {
             if (i0 >= H) {                              // output steps (a tile that crosses the call's end is nobody's predecessor)
 #pragma unroll
-                for (int k = 0; k < 64; k++) dcsum = __builtin_fma(dcsum, q.mtau, t[k]);
+                for (int k = 0; k < B; k++) dcsum = __builtin_fma(dcsum, q.mtau, t[k]);
             }
         }
 #pragma unroll
-        for (int k = 0; k < 64; k++) row[k] = t[k];
+        for (int k = 0; k < B; k++) row[k] = t[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // write the output steps out, row by row (warm-up steps i < H are dropped)
+        // write the output steps out (warm-up steps i < H are dropped)
         if (i0 >= H) {
-#pragma unroll 16
-            for (int j = 0; j < 64; j++) {
-                const long long g = tile0 + (long long)j * L - H + i0 + lane;
-                if (g < n) fo[g] = lds[j * kPllPitch + lane];
+            double *ob = fo + ((long long)gb0 + i0);
+            int loff = loff0;
+            asm volatile("" : "+v"(loff));
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+                const int off = loff + j * RL;
+                if (gb0 + i0 + off < n) ob[(unsigned)off] = lds[(RPI * j + frow) * kPllPitch + fcol];
             }
         }
         __builtin_amdgcn_wave_barrier();
