@@ -33,6 +33,23 @@ __device__ int g_hbc_probe_step;
 
 template <typename T> struct alignas(2 * sizeof(cplx<T>)) HbPair { cplx<T> e[2]; };
 
+// A pair out of LDS as 128-bit accesses: ds_read_b128 runs at 256 B/clk per CU, the ds_read2_b64 the compiler picks for a pair whose
+// halves are used apart at 128 B/clk -- and with two-way bank conflicts at a lane pitch of 16 bytes (MI355X_MICROARCH.md, LDS).
+typedef float hb_v4f __attribute__((ext_vector_type(4)));
+typedef double hb_v2d __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ HbPair<T> hb_load_pair(const HbPair<T> *p)
+{
+    HbPair<T> r;
+    if constexpr (sizeof(T) == 4) {
+        const hb_v4f v = *reinterpret_cast<const hb_v4f *>(p);
+        r.e[0].x = v.x; r.e[0].y = v.y; r.e[1].x = v.z; r.e[1].y = v.w;
+    } else {
+        const hb_v2d a = reinterpret_cast<const hb_v2d *>(p)[0], b = reinterpret_cast<const hb_v2d *>(p)[1];
+        r.e[0].x = a.x; r.e[0].y = a.y; r.e[1].x = b.x; r.e[1].y = b.y;
+    }
+    return r;
+}
+
 template <int NS> struct HbGeom {
     static constexpr int STEP = 2048;
     static constexpr int WSTEPS = (42 * ((1 << NS) - 1) + STEP - 1) / STEP;     // warm-up steps
@@ -73,10 +90,9 @@ template <int NS> struct HbGeom {
     }
 };
 
-template <typename T, int NS, int S> struct HbStage {
+template <typename T, int NS, int S, typename G = HbGeom<NS>> struct HbStage {
     using C = cplx<T>;
     using PR = HbPair<T>;
-    using G = HbGeom<NS>;
     // One stage over one step: lane u = t - lane0 (0 <= u < lanes) produces outputs R u .. R u + R - 1.
     static __device__ __forceinline__ void run(PR *lds, int t, bool store, C *y, long long obase, long long olimit)
     {
@@ -91,11 +107,11 @@ template <typename T, int NS, int S> struct HbStage {
             const PR *uo = lds + G::odd_off(S) + u, *ue = lds + G::even_off(S) + u;
             PR w[J1 - J0 + 1];
 #pragma unroll
-            for (int j = J0; j <= J1; j++) w[j - J0] = uo[(j % RP) * PP + j / RP];
+            for (int j = J0; j <= J1; j++) w[j - J0] = hb_load_pair(uo + (j % RP) * PP + j / RP);
             constexpr int JE0 = (HE - 10) / 2, JE1 = (HE - 10 + R - 1) / 2;      // even ring, logical HE + m - 10
             PR ce[JE1 - JE0 + 1];
 #pragma unroll
-            for (int j = JE0; j <= JE1; j++) ce[j - JE0] = ue[(j % RP) * PP + j / RP];
+            for (int j = JE0; j <= JE1; j++) ce[j - JE0] = hb_load_pair(ue + (j % RP) * PP + j / RP);
             C acc[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -149,8 +165,11 @@ template <typename T, int NS, int S> struct HbStages {
     }
 };
 
+#ifndef QH_HBC_WAVES_F32
+#define QH_HBC_WAVES_F32 3
+#endif
 template <typename T, int NS>
-__global__ __launch_bounds__(NT, sizeof(T) == 4 ? 3 : 2) void hb45_cascade_kernel(const cplx<T> *in, long long in_stride, const cplx<T> *hist, int n_in,
+__global__ __launch_bounds__(NT, sizeof(T) == 4 ? QH_HBC_WAVES_F32 : 2) void hb45_cascade_kernel(const cplx<T> *in, long long in_stride, const cplx<T> *hist, int n_in,
                                                           cplx<T> *out, long long out_stride, int seg)
 {
     using C = cplx<T>;

@@ -53,7 +53,7 @@ def config3(torch, qh, dev):
 def config4(torch, qh, dev):
     from quisk_amd import synth
     nch = 256
-    nblk = int(os.environ.get("QH_C4_NBLK", "1024"))       # DSP blocks per call: 2^20 input samples per channel per step by default
+    nblk = int(os.environ.get("QH_C4_NBLK", "4096"))       # DSP blocks per call: 2^22 input samples per channel per step
     n_in = nblk * 1024
     eng = qh.RxaEngine(nch, stream=torch.cuda.current_stream(dev).cuda_stream)
     modes = [1, 6, 5]
