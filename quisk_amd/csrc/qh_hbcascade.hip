@@ -48,6 +48,9 @@ int launch(qh_hbc *h, const void *in, long long in_stride, int n_in, void *out, 
     // segments: long enough that the warm-up is a few per cent, short enough to fill 256 CUs x 4 workgroups
     long long seg = 64LL * G::STEP;
     while (seg > 16 * G::STEP && (long long)h->nch * ((n_in + seg - 1) / seg) < 1024) seg >>= 1;
+    // a short input (the second launch of a long cascade): a workgroup's walk through its steps is a chain of barriers and LDS round
+    // trips, so more and shorter segments finish sooner although each repeats the warm-up
+    while (seg > 4 * G::STEP && seg > 4 * G::WARM && (long long)h->nch * ((n_in + seg - 1) / seg) < 512) seg >>= 1;
     if (const char *e = getenv("QH_HBC_SEG_STEPS")) { const int v = atoi(e); if (v > 0) seg = (long long)v * G::STEP; }
     const int nseg = (int)((n_in + seg - 1) / seg);
     const size_t lds = (size_t)G::ring_pairs() * sizeof(HbPair<T>);
