@@ -57,7 +57,7 @@ static constexpr int kHistFront = 2240;     // resampler history capacity: 140 *
 // FM PLL time tiles (qh_tiled.hpp).  On a carrier the loop (double pole at 0.66 per sample) forgets its start state in ~100
 // samples; on noise alone two runs meet after ~135 samples on average with an exponential tail, so a 768-sample warm-up
 // leaves a fraction of a percent of the tiles to the verify kernel's sequential re-run.
-static constexpr int kFmTile = 256;
+static constexpr int kFmTile = 256;        // shortest tile; long calls take up to 2048 samples per lane (Engine::process_chain)
 static constexpr int kFmWarm = 768;
 // SAM's loop (omega_N 250 rad/s, zeta 1, RXA.c:185-186) forgets a state in exp(-250 t): 1e-16 after 0.147 s = 7068 samples at 48 kHz
 static constexpr int kSamTile = 4096;
@@ -237,7 +237,7 @@ struct Engine {
     long long pll_ends_cap = 0;             // tiles per channel
     double *am_tsum = nullptr;              // [nch][am_tsum_cap][2]: the AM nbp0 tiles' contributions to the fade leveller (osfir_kernel DET 2)
     long long am_tsum_cap = 0;
-    double *seg_sum[3] = { nullptr, nullptr, nullptr };     // segment summaries of the multi-workgroup scans: AM / SAM, FM dc, snotch
+    double *seg_sum[3] = { nullptr, nullptr, nullptr };     // segment summaries of the multi-workgroup scans: AM / SAM, (unused), snotch
     int *pll_nfixed = nullptr;
     int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
     SamChanParam *sam_prm = nullptr;
@@ -1856,8 +1856,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             {
                 // dc removal + gain: the tiles' contributions are in `ends` already, one pass over `fil`
                 const int G = seg_groups(n_fm);
-                hipLaunchKernelGGL((fm_dc_tiled_kernel<3>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
-                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm, (double *)nullptr,
+                hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
+                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm,
                                    (const double *)pll_ends, pll_ends_cap * kPllEndsW, fm_tile);
             }
         }

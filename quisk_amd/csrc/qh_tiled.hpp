@@ -628,59 +628,24 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
 }
 
 // dc removal and gain of xfmd (fmd.c:169-171): fmdc <- mtau fmdc + onem_mtau fil ; audio = again (fil - fmdc), written as
-// (audio, audio).  Same two-pass segment scheme as the AM leveller; fil is a real array, out the channel's complex row.
-// MODE 3: no first pass at all.  The loop kernels left every tile's contribution in `ends` (kPllEndsW per tile, [6]); segments are
-// cut on tile boundaries (L samples) and a segment's carry-in is the chain over the tiles before it.
-template <int MODE = 0>
+// (audio, audio); fil is a real array, out the channel's complex row.  ONE pass: the loop kernels left every tile's contribution to
+// the average in `ends` (kPllEndsW per tile, [6]); the time segments (16 per workgroup, gridDim.y workgroups per channel) are cut
+// on tile boundaries (L samples, a multiple of 64) and a segment's carry-in is the chain over the tiles ahead of it.
 static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const double *fil, long long fstride, double2 *out, long long stride,
                                                                          int n, const int *chan_list, PllState *state, const double *again,
-                                                                         PllParam q, double *gsum = nullptr, const double *ends = nullptr,
-                                                                         long long estride = 0, int L = 64)
+                                                                         PllParam q, const double *ends, long long estride, int L)
 {
-    __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int S = MODE == 0 ? kSegWaves : kSegWaves * (int)gridDim.y, sidx = MODE == 0 ? wave : (int)blockIdx.y * kSegWaves + wave;
-    double *sum = MODE == 0 ? s_sum : gsum + (long long)blockIdx.x * S * kSegSumW;
+    const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
     const double *f = fil + (long long)ch * fstride;
     double2 *p = out + (long long)ch * stride;
-    int b0, b1;
-    seg_range(n, sidx, b0, b1, S);
     const PoleScan sc = make_pole_scan(q.mtau, lane);
-    const double m64 = lane_pow(q.mtau, 64);
-    double fn[kSegGroup];
-    int t0 = 0;                                             // MODE 3: tiles ahead of this segment
-    bool is_last = false;
-    if constexpr (MODE == 3) {
-        const int nb = (n + 63) >> 6, lb = L >> 6, nt = (n + L - 1) / L;
-        t0 = (int)((long long)sidx * nt / S);
-        const int t1 = (int)((long long)(sidx + 1) * nt / S);
-        b0 = t0 * lb;
-        b1 = t1 * lb < nb ? t1 * lb : nb;
-        is_last = t1 == nt && t0 < t1;                      // the segment that holds the call's last sample
-    }
-    if constexpr (MODE == 0 || MODE == 1) {
-        // pass 1: end value only (see the AM leveller)
-        double acc = 0.0;
-        seg_load(fn, b0, b1, n, lane, f);
-        for (int b = b0; b < b1; b += kSegGroup) {
-            double fv[kSegGroup];
-#pragma unroll
-            for (int k = 0; k < kSegGroup; k++) fv[k] = fn[k];
-            seg_load(fn, b + kSegGroup, b1, n, lane, f);
-#pragma unroll
-            for (int k = 0; k < kSegGroup; k++) {
-                if (b + k >= b1) break;
-                acc = __builtin_fma(acc, m64, q.onem_mtau * fv[k]);
-            }
-        }
-        const double e = wave_sum_d(acc * lane_pow(q.mtau, 63 - lane));
-        if (lane == 0) sum[sidx * kSegSumW] = e;
-        if constexpr (MODE == 1) return;
-    }
-    const double c_in = state[ch].fmdc;                  // ahead of the barrier: the last wavefront stores the new carry at its end
-    if constexpr (MODE == 0) __syncthreads();
-    double c = c_in;
-    if constexpr (MODE == 3) {
+    const int nb = (n + 63) >> 6, lb = L >> 6, nt = (n + L - 1) / L;
+    const int t0 = (int)((long long)sidx * nt / S), t1 = (int)((long long)(sidx + 1) * nt / S);      // this segment's tiles
+    const int b0 = t0 * lb, b1 = t1 * lb < nb ? t1 * lb : nb;
+    const bool is_last = t1 == nt && t0 < t1;               // the segment that holds the call's last sample
+    double c = state[ch].fmdc;
+    {
         // c = c_in mL^t0 + sum_{t < t0} mL^(t0 - 1 - t) s_t, 64 tiles per step; tiles whose weight is below 1e-40 are left out
         const double mL = pow(q.mtau, (double)L), mL64 = lane_pow(mL, 64);
         const double *e = ends + (long long)ch * estride;
@@ -694,17 +659,9 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
             if (lane < cnt) v = e[(long long)(blk + lane) * kPllEndsW + 6] * lane_pow(mL, cnt - 1 - lane);
             c = __builtin_fma(c, lane_pow(mL, cnt), wave_sum_d(v));
         }
-    } else {
-        const int qb = ((n + 63) >> 6) / S;
-        const double t0 = pow(m64, (double)qb), t1 = t0 * m64;
-        SegWalk walk(n, S);
-        for (int w = 0; w < sidx; w++) {
-            const int nbw = walk.next();
-            if (nbw == 0) continue;
-            c = __builtin_fma(c, nbw == qb ? t0 : t1, sum[w * kSegSumW]);
-        }
     }
     const double gain = again[ch];
+    double fn[kSegGroup];
     seg_load(fn, b0, b1, n, lane, f);
     for (int b = b0; b < b1; b += kSegGroup) {
         double fv[kSegGroup];
@@ -721,13 +678,7 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
             c = lane_bcast(dcs, cnt - 1);
         }
     }
-    if constexpr (MODE == 3) {
-        if (is_last && lane == 0 && n > 0) state[ch].fmdc = c;
-    } else {
-        int last = S - 1;
-        while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
-        if (sidx == last && lane == 0 && n > 0) state[ch].fmdc = c;
-    }
+    if (is_last && lane == 0 && n > 0) state[ch].fmdc = c;      // (nobody reads the carried state after the first lines of the kernel)
 }
 
 }  // namespace qh
