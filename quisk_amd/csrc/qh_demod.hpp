@@ -299,8 +299,8 @@ struct AgcState {
     double abs_ring[kAgcRing];
 };
 
-static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                           const AgcParam *prm, AgcState *state, double pre_gain = 1.0)
+static __global__ __launch_bounds__(64) void wcpagc_seq_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                               const AgcParam *prm, AgcState *state, double pre_gain = 1.0)
 {
     __shared__ double2 ring[kAgcRing];
     __shared__ double abs_ring[kAgcRing];
@@ -329,11 +329,11 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
             const int in_index = (out_index + A) & (kAgcRing - 1);
             const double2 o = ring[out_index];
             const double abs_out = abs_ring[out_index];
-            const double abs_in = q.pmode == 0 ? fmax(fabs(I), fabs(Q)) : sqrt(I * I + Q * Q);
+            const double abs_in = q.pmode == 0 ? fmax(fabs(I), fabs(Q)) : sqrt(__builtin_fma(I, I, Q * Q));
             ring[in_index] = make_double2(I, Q);
             abs_ring[in_index] = abs_in;
-            fba = q.fast_backmult * abs_out + q.onemfast_backmult * fba;
-            hba = q.hang_backmult * abs_out + q.onemhang_backmult * hba;
+            fba = __builtin_fma(q.fast_backmult, abs_out, q.onemfast_backmult * fba);
+            hba = __builtin_fma(q.hang_backmult, abs_out, q.onemhang_backmult * hba);
             if (abs_out >= ring_max && abs_out > 0.0) {
                 double m = 0.0;
                 for (int j = lane; j < A; j += 64) m = fmax(m, abs_ring[(out_index + 1 + j) & (kAgcRing - 1)]);
@@ -344,34 +344,34 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
             const bool up = ring_max >= volts;
             switch (st) {
             case 0:
-                if (up) volts += (ring_max - volts) * q.attack_mult;
-                else if (volts > q.pop_ratio * fba) { st = 1; volts += (ring_max - volts) * q.fast_decay_mult; }
+                if (up) volts = __builtin_fma(ring_max - volts, q.attack_mult, volts);
+                else if (volts > q.pop_ratio * fba) { st = 1; volts = __builtin_fma(ring_max - volts, q.fast_decay_mult, volts); }
                 else if (q.hang_enable && hba > q.hang_level) { st = 2; hang_counter = q.hang_count_init; decay_type = 1; }
-                else { st = 3; volts += (ring_max - volts) * q.decay_mult; decay_type = 0; }
+                else { st = 3; volts = __builtin_fma(ring_max - volts, q.decay_mult, volts); decay_type = 0; }
                 break;
             case 1:
-                if (up) { st = 0; volts += (ring_max - volts) * q.attack_mult; }
-                else if (volts > save_volts) volts += (ring_max - volts) * q.fast_decay_mult;
+                if (up) { st = 0; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else if (volts > save_volts) volts = __builtin_fma(ring_max - volts, q.fast_decay_mult, volts);
                 else if (hang_counter > 0) st = 2;
-                else if (decay_type == 0) { st = 3; volts += (ring_max - volts) * q.decay_mult; }
-                else { st = 4; volts += (ring_max - volts) * q.hang_decay_mult; }
+                else if (decay_type == 0) { st = 3; volts = __builtin_fma(ring_max - volts, q.decay_mult, volts); }
+                else { st = 4; volts = __builtin_fma(ring_max - volts, q.hang_decay_mult, volts); }
                 break;
             case 2:
-                if (up) { st = 0; save_volts = volts; volts += (ring_max - volts) * q.attack_mult; }
-                else if (hang_counter == 0) { st = 4; volts += (ring_max - volts) * q.hang_decay_mult; }
+                if (up) { st = 0; save_volts = volts; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else if (hang_counter == 0) { st = 4; volts = __builtin_fma(ring_max - volts, q.hang_decay_mult, volts); }
                 break;
             case 3:
-                if (up) { st = 0; save_volts = volts; volts += (ring_max - volts) * q.attack_mult; }
-                else volts += (ring_max - volts) * q.decay_mult;
+                if (up) { st = 0; save_volts = volts; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else volts = __builtin_fma(ring_max - volts, q.decay_mult, volts);
                 break;
             default:
-                if (up) { st = 0; save_volts = volts; volts += (ring_max - volts) * q.attack_mult; }
-                else volts += (ring_max - volts) * q.hang_decay_mult;
+                if (up) { st = 0; save_volts = volts; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else volts = __builtin_fma(ring_max - volts, q.hang_decay_mult, volts);
                 break;
             }
             if (volts < q.min_volts) volts = q.min_volts;
             gain = volts * q.inv_out_target;
-            const double mult = (q.out_target - q.slope_constant * fmin(0.0, log10(q.inv_max_input * volts))) / volts;
+            const double mult = __builtin_fma(-q.slope_constant, fmin(0.0, log10(q.inv_max_input * volts)), q.out_target) / volts;
             if (lane == i) mine = make_double2(o.x * mult, o.y * mult);
         }
         if (lane < cnt) p[base + lane] = mine;
@@ -382,6 +382,106 @@ static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long lo
         sp->ring_max = ring_max; sp->volts = volts; sp->save_volts = save_volts; sp->fast_backaverage = fba;
         sp->hang_backaverage = hba; sp->gain = gain; sp->out_index = out_index; sp->hang_counter = hang_counter;
         sp->decay_type = decay_type; sp->state = st;
+    }
+}
+
+// The same loop, 64 samples per step of the wavefront.  Everything that does not depend on `volts` is done by all lanes at once:
+// the batch's inputs go into the ring, the delayed samples and their magnitudes come out of it, and lane j takes the rescan result
+// of sample j -- the maximum over the attack window (out_j, in_j] of the magnitude ring, which is what the reference's rescan would
+// find -- with attack_buffsize LDS reads.  The sequential part then steps the level detector alone: per sample three values out of
+// the lanes (v_readlane), the two back-averages, the incremental ring_max logic (kept literally, stale values and all: after
+// SetRXAAGCAttack shrinks the window the reference's ring_max can outlive the samples it came from), the five-state switch on
+// scalar branches, and the new `volts` into lane j.  (The switch written as selects instead, the same cost in every state: slower,
+// 100 against 76 ms for 256 channels x 2^18 samples; the sample-by-sample form: 164 ms.)  The gain curve (a log10 and a division per sample) and the multiply are
+// lane-parallel again.  Same state, same arithmetic in the same order as wcpagc_seq_kernel: the two are interchangeable between calls
+// and bit-identical (tests/test_gpu_wcpagc_batch.py).
+static __global__ __launch_bounds__(64) void wcpagc_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                           const AgcParam *prm, AgcState *state, double pre_gain = 1.0)
+{
+    __shared__ double2 ring[kAgcRing];
+    __shared__ double abs_ring[kAgcRing];
+    const int ch = chan_list[blockIdx.x];
+    const int lane = threadIdx.x;
+    const AgcParam q = prm[ch];
+    AgcState *sp = state + ch;
+    for (int i = lane; i < kAgcRing; i += 64) { ring[i] = sp->ring[i]; abs_ring[i] = sp->abs_ring[i]; }
+    double ring_max = sp->ring_max, volts = sp->volts, save_volts = sp->save_volts, fba = sp->fast_backaverage,
+           hba = sp->hang_backaverage;
+    int out_index = sp->out_index, hang_counter = sp->hang_counter, decay_type = sp->decay_type, st = sp->state;
+    const int A = q.attack_buffsize;
+    const int BS = A + 64 < kAgcRing ? 64 : kAgcRing - A - 1;           // the batch's inputs must not land on its own outputs
+    __syncthreads();
+    double2 *p = buf + (long long)ch * stride;
+    for (int base = 0; base < n; base += BS) {
+        const int cnt = n - base < BS ? n - base : BS;
+        double2 z = make_double2(0, 0);
+        if (lane < cnt) z = p[base + lane];
+        z.x *= pre_gain; z.y *= pre_gain;           // the FM limiter's lim_pre_gain (fmd.c:181-182); 1 for the AGC proper
+        const double abs_in = q.pmode == 0 ? fmax(fabs(z.x), fabs(z.y)) : sqrt(__builtin_fma(z.x, z.x, z.y * z.y));
+        const int so = (out_index + 1 + lane) & (kAgcRing - 1), si = (so + A) & (kAgcRing - 1);
+        if (lane < cnt) { ring[si] = z; abs_ring[si] = abs_in; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double2 o = make_double2(0, 0);
+        double abs_out = 0.0, scan = 0.0;
+        if (lane < cnt) {
+            o = ring[so]; abs_out = abs_ring[so];
+            // what a rescan at this sample finds.  The slots behind in_j hold this batch's LATER inputs: they are not in the window
+            for (int k = 1; k <= A; k++) scan = fmax(scan, abs_ring[(so + k) & (kAgcRing - 1)]);
+        }
+        double vj = 0.0;                            // volts after sample j, in lane j
+        for (int i = 0; i < cnt; i++) {
+            const double a_out = lane_bcast(abs_out, i), a_in = lane_bcast(abs_in, i);
+            fba = __builtin_fma(q.fast_backmult, a_out, q.onemfast_backmult * fba);
+            hba = __builtin_fma(q.hang_backmult, a_out, q.onemhang_backmult * hba);
+            if (a_out >= ring_max && a_out > 0.0) ring_max = lane_bcast(scan, i);
+            if (a_in > ring_max) ring_max = a_in;
+            if (hang_counter > 0) --hang_counter;
+            const bool up = ring_max >= volts;
+            switch (st) {
+            case 0:
+                if (up) volts = __builtin_fma(ring_max - volts, q.attack_mult, volts);
+                else if (volts > q.pop_ratio * fba) { st = 1; volts = __builtin_fma(ring_max - volts, q.fast_decay_mult, volts); }
+                else if (q.hang_enable && hba > q.hang_level) { st = 2; hang_counter = q.hang_count_init; decay_type = 1; }
+                else { st = 3; volts = __builtin_fma(ring_max - volts, q.decay_mult, volts); decay_type = 0; }
+                break;
+            case 1:
+                if (up) { st = 0; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else if (volts > save_volts) volts = __builtin_fma(ring_max - volts, q.fast_decay_mult, volts);
+                else if (hang_counter > 0) st = 2;
+                else if (decay_type == 0) { st = 3; volts = __builtin_fma(ring_max - volts, q.decay_mult, volts); }
+                else { st = 4; volts = __builtin_fma(ring_max - volts, q.hang_decay_mult, volts); }
+                break;
+            case 2:
+                if (up) { st = 0; save_volts = volts; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else if (hang_counter == 0) { st = 4; volts = __builtin_fma(ring_max - volts, q.hang_decay_mult, volts); }
+                break;
+            case 3:
+                if (up) { st = 0; save_volts = volts; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else volts = __builtin_fma(ring_max - volts, q.decay_mult, volts);
+                break;
+            default:
+                if (up) { st = 0; save_volts = volts; volts = __builtin_fma(ring_max - volts, q.attack_mult, volts); }
+                else volts = __builtin_fma(ring_max - volts, q.hang_decay_mult, volts);
+                break;
+            }
+            if (volts < q.min_volts) volts = q.min_volts;
+            if (lane == i) vj = volts;
+        }
+        if (lane < cnt) {
+            const double mult = __builtin_fma(-q.slope_constant, fmin(0.0, log10(q.inv_max_input * vj)), q.out_target) / vj;
+            p[base + lane] = make_double2(o.x * mult, o.y * mult);
+        }
+        out_index = (out_index + cnt) & (kAgcRing - 1);
+        __builtin_amdgcn_wave_barrier();            // the next batch's inputs overwrite slots this one has read
+    }
+    __syncthreads();
+    for (int i = lane; i < kAgcRing; i += 64) { sp->ring[i] = ring[i]; sp->abs_ring[i] = abs_ring[i]; }
+    if (lane == 0) {
+        sp->ring_max = ring_max; sp->volts = volts; sp->save_volts = save_volts; sp->fast_backaverage = fba;
+        sp->hang_backaverage = hba; if (n > 0) sp->gain = volts * q.inv_out_target; sp->out_index = out_index;
+        sp->hang_counter = hang_counter; sp->decay_type = decay_type; sp->state = st;
     }
 }
 

@@ -240,6 +240,7 @@ struct Engine {
     double *seg_sum[3] = { nullptr, nullptr, nullptr };     // segment summaries of the multi-workgroup scans: AM / SAM, (unused), snotch
     int *pll_nfixed = nullptr;
     int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
+    int agc_form = 0;                       // diagnostics (qh_rxa_debug_agc): 1 = the sample-by-sample form of the wcpAGC loop
     SamChanParam *sam_prm = nullptr;
     PllParam sam_pll_prm{}, fm_pll_prm{};
     SnotchParam *sn_prm = nullptr;
@@ -1880,8 +1881,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                                    sn_prm, sn_state, (double *)nullptr, direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi);
         }
         if (n_lim)      // detector limiter: lim_pre_gain 0.4, then its own wcpAGC (fmd.c:179-184)
-            hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap, (int)n_mid, list_lim, lim_prm,
-                               lim_state, 0.4);
+            hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_lim), dim3(64), 0, stream, cur, buf_cap,
+                               (int)n_mid, list_lim, lim_prm, lim_state, 0.4);
     }
     if (side) QH_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     if (n_snb[1]) snb_inplace(list_snb[1], n_snb[1]);       // xbpsnbain / xbpsnbaout at position 1 (RXA.c:576-577)
@@ -1913,10 +1914,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     bp1_at(0);
     // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below unless a position-1 stage follows
     tick(1);
-    if (n_agc_cur) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
-                                      list_agc_cur, agc_prm, agc_state);
-    if (n_agc_other) hipLaunchKernelGGL(wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
-                                        list_agc_other, agc_prm, agc_state);
+    if (n_agc_cur) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+                                      list_agc_cur, agc_prm, agc_state, 1.0);
+    if (n_agc_other) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
+                                        list_agc_other, agc_prm, agc_state, 1.0);
     {
         long long per = (n_mid + NT - 1) / NT;
         const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
@@ -2696,6 +2697,16 @@ int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
     if (n > max) n = max;
     QH_HIP(hipMemcpy(out, e.pll_ends + (long long)ch * e.pll_ends_cap * kPllEndsW, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return (int)n;
+}
+
+// Diagnostics: which form of the wcpAGC loop runs (0: 64 samples per step of the wavefront, 1: sample by sample).  Same state, same
+// results: tests hold one against the other.
+int qh_rxa_debug_agc(qh_rxa *h, int form)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
+    if (h->e.agc_form != form) { h->e.agc_form = form; h->e.drop_graphs(); h->e.epoch++; }
+    return QH_OK;
 }
 
 int qh_rxa_synchronize(qh_rxa *h)

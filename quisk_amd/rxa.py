@@ -142,6 +142,10 @@ class RxaEngine:
     def pll_repairs(self):
         return self._L.qh_rxa_pll_repairs(self._h)
 
+    def debug_agc(self, form):
+        """diagnostics: 1 = the sample-by-sample form of the wcpAGC loop, 0 = 64 samples per step (default)"""
+        check(self._L.qh_rxa_debug_agc(self._h, int(form)))
+
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))
 

@@ -1,0 +1,93 @@
+"""xwcpagc (wdsp/wcpAGC.c:177-338) in its two GPU forms: sample by sample, and 64 samples per step of the wavefront with only the level
+detector stepped in order (qh_demod.hpp).  Same state, same arithmetic in the same order: outputs are bit-identical, the forms can
+alternate between calls, and both follow the oracle.  Signals that walk the detector through all five states: bursts over a quiet
+floor (attack, fast decay, hang, hang decay), a fade (decay), silence (the min_volts clamp), a click (pop ratio).  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from quisk_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _input(nch, nblk, seed=5):
+    rng = np.random.default_rng(seed)
+    n = nblk * 1024
+    t = np.arange(n)
+    x = np.zeros((nch, n), dtype=np.complex128)
+    for c in range(nch):
+        f = (synth.shift_freq(c) + 1000.0 + 150.0 * c) / 192000.0
+        env = np.full(n, 1e-3)
+        for k in range(6):                                   # bursts of different height and length
+            a = int(rng.integers(0, n - 40000))
+            env[a:a + int(rng.integers(3000, 40000))] = 10.0 ** rng.uniform(-2.5, -0.3)
+        env[n // 2:n // 2 + n // 8] *= np.linspace(1.0, 0.01, n // 8)          # a fade
+        env[3 * n // 4:3 * n // 4 + 30000] = 0.0                                # silence
+        x[c] = env * np.exp(2j * np.pi * f * t) + 1e-5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        x[c, n // 3 + 17] += 0.9                                                # a click
+    return x
+
+
+def _engine(qh, nch, mode, form):
+    e = qh.RxaEngine(nch)
+    for c in range(nch):
+        e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, synth.shift_freq(c)); e.RXANBPSetRun(c, 1); e.SetRXAMode(c, 1)
+        e.RXASetPassband(c, 300.0, 3000.0); e.SetRXAAGCMode(c, mode[c % len(mode)])
+    e.debug_agc(form)
+    return e
+
+
+@pytest.mark.parametrize("modes", [[3], [1, 2, 3, 4]], ids=["med", "long-slow-med-fast"])
+def test_batch_form_is_bit_identical_to_the_sample_loop_and_follows_the_oracle(qh, oracle, modes):
+    nch, nblk = 4, 240
+    x = _input(nch, nblk)
+    calls = [3, 1, 50, 7, 100, 79]
+    outs = {}
+    for form in (0, 1):
+        e = _engine(qh, nch, modes, form)
+        ys, pos = [], 0
+        for nb in calls:
+            ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
+        outs[form] = np.concatenate(ys, axis=1)
+    assert np.array_equal(outs[0], outs[1])
+    # the forms alternate between calls on one engine: still the same samples
+    e = _engine(qh, nch, modes, 0)
+    ys, pos = [], 0
+    for k, nb in enumerate(calls):
+        e.debug_agc(k & 1)
+        ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
+    assert np.array_equal(np.concatenate(ys, axis=1), outs[0])
+    for c in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(modes[c % len(modes)])
+        ref = o.xrxa(x[c])
+        assert np.abs(ref).max() > 1e-3
+        assert rel_rms(outs[0][c], ref) < 1e-9, (c, rel_rms(outs[0][c], ref))
+
+
+def test_attack_window_changes_and_odd_lengths(qh, oracle):
+    """SetRXAAGCAttack moves in_index (wcpAGC.c:120): the ring_max the reference keeps across the change is kept here as well, in
+    both forms; calls whose lengths are not multiples of the 64-sample step.  (Against the oracle only up to the first change: a
+    longer attack window reads ring slots the reference last wrote 30 721 samples ago and this ring 2 048 samples ago, DESIGN.md
+    section 7.)"""
+    nch, nblk = 2, 64
+    x = _input(nch, nblk, seed=9)
+    outs = {}
+    for form in (0, 1):
+        e = _engine(qh, nch, [3], form)
+        ys = [e.process_host(np.ascontiguousarray(x[:, :20 * 1024 + 0]))]
+        for c in range(nch): e.SetRXAAGCAttack(c, 4)
+        ys.append(e.process_host(np.ascontiguousarray(x[:, 20 * 1024:41 * 1024])))
+        for c in range(nch): e.SetRXAAGCAttack(c, 1)
+        ys.append(e.process_host(np.ascontiguousarray(x[:, 41 * 1024:])))
+        outs[form] = np.concatenate(ys, axis=1)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 1e-3
+    for c in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(3)
+        ref = o.xrxa(x[c, :20 * 1024])
+        assert rel_rms(outs[0][c][:20 * 256], ref) < 1e-9, c
