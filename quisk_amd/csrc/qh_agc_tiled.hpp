@@ -1,0 +1,451 @@
+// qh_agc_tiled.hpp -- xwcpagc modes 1-4 (wdsp/wcpAGC.c:177-338) over LONG calls, in time tiles.
+//
+// Per sample the reference (a) moves the delay line and its magnitudes, (b) updates two one-pole averages of the delayed
+// magnitude, (c) keeps ring_max, the maximum of the magnitudes in the attack window, (d) steps the five-state level detector
+// `volts`, (e) applies the gain curve to the delayed sample.  Only (d) is a recurrence that is not linear:
+//   agc_prep_kernel        (a) + (c): RM_j = max |x| over samples (j - A, j] -- block prefix / suffix maxima in LDS; what the
+//                          reference's rescans and single compares amount to while ring_max is not stale (it is stale only after
+//                          SetRXAAGCAttack has moved in_index in mid-stream: the engine keeps such a channel on wcpagc_kernel);
+//                          also keeps the A samples ahead of every 1024-sample tile for agc_apply_kernel
+//   agc_avg_tiled_kernel   (b): two linear one-pole scans of |x_{j-A}|, two-pass segment scheme (qh_wave.hpp)
+//   agc_bounds_kernel      (d), coarse: the detector's state at every tile boundary, one wavefront per channel jumping over the runs of
+//                          constant ring_max in closed form (a warm-up from a guessed state, as the PLL tiles use, does not work here:
+//                          two runs of the detector only meet at the rate of the attack steps they share, one step in twenty on a
+//                          steady noisy signal, and not at all while both decay after a peak: tools/dbg/agc_sim.py)
+//   agc_lanes_kernel       (d), exact: ONE LANE PER TILE steps its tile sample by sample from its boundary state
+//   agc_verify_kernel      checks every boundary state against the end of the tile before it and re-runs, in order, the tiles whose
+//                          start was off (exact compare of the discrete state, 1e-9 on volts)
+//   agc_apply_kernel       (e), in place: a workgroup stages its tile and the A samples ahead of it in LDS first
+//   agc_finish_kernel      the state the next call (tiled or not) starts from: ring slots, indices, averages, detector state
+// The step itself is agc_lane_step: the reference's switch as selects, `volts += (ring_max - volts) * mult` with mult = 0 where the
+// reference leaves volts alone, every update an FMA as in wcpagc_kernel.
+#pragma once
+#include "qh_demod.hpp"
+
+namespace qh {
+
+constexpr int kAgcTile = 1024;          // samples per workgroup in the lane-parallel kernels
+constexpr int kAgcEndsW = 8;            // a detector state: volts, save_volts, hang counter, decay type, state
+constexpr int kAgcBatch = 16;           // steps per LDS round of the lanes kernel
+constexpr int kAgcPitch = kAgcBatch + 1;
+
+struct AgcLane { double volts, save_volts; int hc, decay_type, st; };
+
+__device__ __forceinline__ void agc_lane_step(AgcLane &s, double rm, double fba, double hba, const AgcParam &q)
+{
+    int hc = s.hc;
+    hc = hc > 0 ? hc - 1 : hc;
+    const double volts = s.volts;
+    const bool up = rm >= volts;
+    const bool c_pop = volts > q.pop_ratio * fba, c_hang = q.hang_enable && hba > q.hang_level, c_sv = volts > s.save_volts;
+    const bool hcpos = hc > 0, hc0 = hc == 0, dt0 = s.decay_type == 0;
+    const int st = s.st;
+    const int n0 = c_pop ? 1 : c_hang ? 2 : 3;
+    const double m0 = c_pop ? q.fast_decay_mult : c_hang ? 0.0 : q.decay_mult;
+    const int n1 = c_sv ? 1 : hcpos ? 2 : dt0 ? 3 : 4;
+    const double m1 = c_sv ? q.fast_decay_mult : hcpos ? 0.0 : dt0 ? q.decay_mult : q.hang_decay_mult;
+    const int n2 = hc0 ? 4 : 2;
+    const double m2 = hc0 ? q.hang_decay_mult : 0.0;
+    int nst = st == 0 ? n0 : st == 1 ? n1 : st == 2 ? n2 : st == 3 ? 3 : 4;
+    double m = st == 0 ? m0 : st == 1 ? m1 : st == 2 ? m2 : st == 3 ? q.decay_mult : q.hang_decay_mult;
+    nst = up ? 0 : nst;
+    m = up ? q.attack_mult : m;
+    const bool to_hang = !up && st == 0 && !c_pop && c_hang, to_decay = !up && st == 0 && !c_pop && !c_hang;
+    hc = to_hang ? q.hang_count_init : hc;
+    s.decay_type = to_hang ? 1 : to_decay ? 0 : s.decay_type;
+    s.save_volts = (up && st >= 2) ? volts : s.save_volts;
+    double v = __builtin_fma(rm - volts, m, volts);
+    v = v < q.min_volts ? q.min_volts : v;
+    s.volts = v; s.st = nst; s.hc = hc;
+}
+
+// sample j of the call as the ring would hold it (scaled by pre_gain), j >= -A: from the rows, or from the ring of the calls before
+__device__ __forceinline__ double2 agc_sample(const double2 *x, const AgcState *sp, int A, int j, double pre_gain)
+{
+    if (j >= 0) { const double2 z = x[j]; return make_double2(z.x * pre_gain, z.y * pre_gain); }
+    return sp->ring[(sp->out_index + A + 1 + j) & (kAgcRing - 1)];              // j = -1: the slot in_index points at
+}
+__device__ __forceinline__ double agc_mag_of(double2 z, int pmode)
+{
+    return pmode == 0 ? fmax(fabs(z.x), fabs(z.y)) : sqrt(__builtin_fma(z.x, z.x, z.y * z.y));
+}
+__device__ __forceinline__ double agc_mag(const double2 *x, const AgcState *sp, const AgcParam &q, int j, double pre_gain)
+{
+    if (j >= 0) { const double2 z = x[j]; return agc_mag_of(make_double2(z.x * pre_gain, z.y * pre_gain), q.pmode); }
+    return sp->abs_ring[(sp->out_index + q.attack_buffsize + 1 + j) & (kAgcRing - 1)];
+}
+
+// scratch of channel slot k (index in the launch's list): four arrays of `arr` doubles: RM, fba, hba, volts
+__device__ __forceinline__ double *agc_arr(double *scr, long long arr, int slot, int which) { return scr + ((long long)slot * 4 + which) * arr; }
+
+// ---- (a) + (c): sliding maximum and the tiles' halos ---------------------------------------------------------------------
+// grid (tiles of kAgcTile, channels), 256 threads.  LDS: magnitudes m[], prefix maxima P[], suffix maxima S[] over blocks of 64,
+// for the samples [j0 - Ah, j0 + kAgcTile), Ah = A rounded up to 64.
+static __global__ __launch_bounds__(256) void agc_prep_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
+                                                              const AgcParam *prm, const AgcState *state, double *scr, long long arr,
+                                                              double2 *halo, int halo_pitch, double pre_gain)
+{
+    extern __shared__ double sm_prep[];
+    const int slot = blockIdx.y, ch = chan_list[slot], t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const AgcParam q = prm[ch];
+    const AgcState *sp = state + ch;
+    const double2 *x = buf + (long long)ch * stride;
+    const int A = q.attack_buffsize, Ah = (A + 63) & ~63, M = Ah + kAgcTile, j0 = blockIdx.x * kAgcTile, base = j0 - Ah;
+    double *m = sm_prep, *P = m + M, *S = P + M;
+    for (int i = t; i < M; i += 256) {
+        const int j = base + i;
+        m[i] = (j >= -A && j < n) ? agc_mag(x, sp, q, j, pre_gain) : 0.0;        // (samples further back than the window are not looked at)
+    }
+    // the A samples ahead of the tile, as the ring would hold them: agc_apply_kernel works in place
+    double2 *hl = halo + ((long long)slot * gridDim.x + blockIdx.x) * halo_pitch;
+    for (int i = t; i < A; i += 256) hl[i] = agc_sample(x, sp, A, j0 - A + i, pre_gain);
+    __syncthreads();
+    for (int b = wave; b < M / 64; b += 4) {
+        const double v = m[b * 64 + lane];
+        double p = v, s = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double tp = __shfl_up(p, d, 64), ts = __shfl_down(s, d, 64);
+            if (lane >= d) p = fmax(p, tp);
+            if (lane + d < 64) s = fmax(s, ts);
+        }
+        P[b * 64 + lane] = p; S[b * 64 + lane] = s;
+    }
+    __syncthreads();
+    double *rm = agc_arr(scr, arr, slot, 0);
+    for (int k = t; k < kAgcTile; k += 256) {
+        const int j = j0 + k;
+        if (j >= n) break;
+        const int hi = Ah + k, lo = hi - A + 1, blo = lo >> 6, bhi = hi >> 6;
+        double r;
+        if (blo == bhi) {
+            r = m[lo];
+            for (int i = lo + 1; i <= hi; i++) r = fmax(r, m[i]);
+        } else {
+            r = fmax(S[lo], P[hi]);
+            for (int b = blo + 1; b < bhi; b++) r = fmax(r, P[b * 64 + 63]);
+        }
+        rm[j] = r;
+    }
+}
+
+// ---- (b): the two back-averages of the delayed magnitude ---------------------------------------------------------------------
+// MODE 1: every segment's response to its own samples from a zero state -> gsum rows; MODE 2: chain + values (see am_detect_tiled_kernel)
+template <int MODE>
+static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
+                                                                           const AgcParam *prm, const AgcState *state, double *scr,
+                                                                           long long arr, double *gsum, double pre_gain)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
+    const AgcParam q = prm[ch];
+    const AgcState *sp = state + ch;
+    const double2 *x = buf + (long long)ch * stride;
+    const int A = q.attack_buffsize;
+    double *sum = gsum + (long long)slot * S * kSegSumW;
+    int b0, b1;
+    seg_range(n, sidx, b0, b1, S);
+    const double mF = q.onemfast_backmult, mH = q.onemhang_backmult;
+    const double m64F = lane_pow(mF, 64), m64H = lane_pow(mH, 64);
+    if constexpr (MODE == 1) {
+        double accF = 0.0, accH = 0.0;
+        for (int b = b0; b < b1; b++) {
+            const int j = b * 64 + lane;
+            const double a = j < n ? agc_mag(x, sp, q, j - A, pre_gain) : 0.0;
+            accF = __builtin_fma(accF, m64F, q.fast_backmult * a);
+            accH = __builtin_fma(accH, m64H, q.hang_backmult * a);
+        }
+        const double eF = wave_sum_d(accF * lane_pow(mF, 63 - lane)), eH = wave_sum_d(accH * lane_pow(mH, 63 - lane));
+        if (lane == 0) { sum[sidx * kSegSumW] = eF; sum[sidx * kSegSumW + 1] = eH; }
+        return;
+    } else {
+        double cF = sp->fast_backaverage, cH = sp->hang_backaverage;
+        {
+            const int qb = ((n + 63) >> 6) / S;
+            const double tF0 = pow(m64F, (double)qb), tH0 = pow(m64H, (double)qb), tF1 = tF0 * m64F, tH1 = tH0 * m64H;
+            SegWalk walk(n, S);
+            for (int w = 0; w < sidx; w++) {
+                const int nbw = walk.next();
+                if (nbw == 0) continue;
+                cF = __builtin_fma(cF, nbw == qb ? tF0 : tF1, sum[w * kSegSumW]);
+                cH = __builtin_fma(cH, nbw == qb ? tH0 : tH1, sum[w * kSegSumW + 1]);
+            }
+        }
+        const PoleScan sF = make_pole_scan(mF, lane), sH = make_pole_scan(mH, lane);
+        double *fo = agc_arr(scr, arr, slot, 1), *ho = agc_arr(scr, arr, slot, 2);
+        for (int b = b0; b < b1; b++) {
+            const int base = b * 64, j = base + lane, cnt = n - base < 64 ? n - base : 64;
+            const double a = j < n ? agc_mag(x, sp, q, j - A, pre_gain) : 0.0;
+            const double f = scan_pole_dpp(q.fast_backmult * a, sF) + sF.pw * cF;
+            const double h = scan_pole_dpp(q.hang_backmult * a, sH) + sH.pw * cH;
+            if (lane < cnt) { fo[j] = f; ho[j] = h; }
+            cF = lane_bcast(f, cnt - 1); cH = lane_bcast(h, cnt - 1);
+        }
+    }
+}
+
+// ---- (d), first the detector's state at every tile boundary ---------------------------------------------------------------------
+// ring_max is piecewise constant (it moves when a larger sample enters the window or the largest leaves it: a run is ~100 samples),
+// and inside a run the detector does one of a few things that have closed forms: attack towards ring_max from below (it stays below),
+// decay towards it from above (it stays above), hold while the hang counter runs, decay fast down to save_volts.  One wavefront per
+// channel takes 64 samples of the three streams at a time, cuts them into runs (a ballot) and advances run by run: a closed-form jump
+// where the state stays put, single reference steps (agc_lane_step) at the turns.  What comes out are the states at the tile
+// boundaries, within rounding of what sample-by-sample stepping gives -- the lanes then step every tile exactly from there, and the
+// check of every tile's end against the next boundary (agc_verify_kernel) catches what a jump got wrong.
+__device__ __forceinline__ void agc_run_jump(AgcLane &s, double rm, int k, double fba_first, double hba_first, const AgcParam &q,
+                                             const double *fba_row, const double *hba_row, int p0, int lane)
+{
+    // advance k >= 1 samples of constant ring_max; fba / hba of sample p0 + i come from the lanes of fba_row / hba_row (uniform reads)
+    int i = 0;
+    while (i < k) {
+        const int left = k - i;
+        const bool up = rm >= s.volts;
+        int jump = 0;
+        double mlt = 0.0;
+        if (s.st == 0 && up) { jump = left; mlt = q.attack_mult; }
+        else if ((s.st == 3 || s.st == 4) && !up) { jump = left; mlt = s.st == 3 ? q.decay_mult : q.hang_decay_mult; }
+        else if (s.st == 2 && !up && s.hc > 1) { jump = left < s.hc - 1 ? left : s.hc - 1; mlt = 0.0; }
+        if (jump > 1) {
+            if (mlt != 0.0) {
+                double v = __builtin_fma(s.volts - rm, exp((double)jump * log1p(-mlt)), rm);
+                s.volts = v < q.min_volts ? q.min_volts : v;
+            }
+            s.hc = s.hc > jump ? s.hc - jump : 0;
+            i += jump;
+        } else {
+            agc_lane_step(s, rm, lane_bcast(*fba_row, p0 + i), lane_bcast(*hba_row, p0 + i), q);
+            i += 1;
+        }
+    }
+    (void)fba_first; (void)hba_first; (void)lane;
+}
+
+// bounds[slot][tile][0..4]: the state at the START of tile t (tile 0: the carried state).  grid (channels), one wavefront.
+static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int *chan_list, const AgcParam *prm, const AgcState *state,
+                                                              const double *scr, long long arr, double *bounds, long long bstride, int L)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x;
+    const AgcParam q = prm[ch];
+    const AgcState *sp = state + ch;
+    const double *in0 = scr + ((long long)slot * 4 + 0) * arr, *in1 = scr + ((long long)slot * 4 + 1) * arr, *in2 = scr + ((long long)slot * 4 + 2) * arr;
+    double *bo = bounds + (long long)slot * bstride;
+    AgcLane s{ sp->volts, sp->save_volts, sp->hang_counter, sp->decay_type, sp->state };
+    double prev = -1.0;                                     // ring_max is never negative: the first sample opens a run
+    double rn = 0.0, fn = 0.0, hn = 0.0;
+    if (lane < n) { rn = in0[lane]; fn = in1[lane]; hn = in2[lane]; }
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        if (base % L == 0 && lane == 0) {
+            double *w = bo + (long long)(base / L) * 8;
+            w[0] = s.volts; w[1] = s.save_volts; w[2] = (double)s.hc; w[3] = (double)s.decay_type; w[4] = (double)s.st;
+        }
+        const double r = rn, f = fn, h = hn;
+        if (base + 64 + lane < n) { rn = in0[base + 64 + lane]; fn = in1[base + 64 + lane]; hn = in2[base + 64 + lane]; }     // the next chunk is on its way
+        // lane j opens a run when its value differs from the one before it
+        double before = wave_shr1(r);
+        if (lane == 0) before = prev;
+        unsigned long long heads = __ballot(lane < cnt && r != before);
+        if (!(heads & 1ull)) heads |= 1ull;                 // the chunk's first samples continue the run of the chunk before
+        prev = lane_bcast(r, cnt - 1);
+        while (heads) {
+            const int p0 = __ffsll((long long)heads) - 1;
+            heads &= heads - 1;
+            const int p1 = heads ? __ffsll((long long)heads) - 1 : cnt;
+            agc_run_jump(s, lane_bcast(r, p0), p1 - p0, 0.0, 0.0, q, &f, &h, p0, lane);
+        }
+    }
+}
+
+// ---- (d): one lane per tile ------------------------------------------------------------------------------------------------
+// grid (groups of 64 tiles, channels), one wavefront.  L = tile length, H = warm-up, both multiples of kAgcBatch.
+static __global__ __launch_bounds__(64, 2) void agc_lanes_kernel(int n, const int *chan_list, const AgcParam *prm, double *scr, long long arr,
+                                                                const double *bounds, long long bstride, double *ends, long long estride, int L)
+{
+    __shared__ double lds[3 * 64 * kAgcPitch];
+    const int slot = blockIdx.y, ch = chan_list[slot], lane = threadIdx.x, group = blockIdx.x;
+    const long long tile0 = (long long)group * 64 * L;
+    if (tile0 >= n) return;
+    const AgcParam q = prm[ch];
+    const double *in0 = agc_arr(scr, arr, slot, 0), *in1 = agc_arr(scr, arr, slot, 1), *in2 = agc_arr(scr, arr, slot, 2);
+    double *vo = agc_arr(scr, arr, slot, 3);
+    const long long s0 = tile0 + (long long)lane * L;
+    const bool live = s0 < n;
+    AgcLane s{ 0.0, 0.0, 0, 0, 0 };
+    if (live) {
+        const double *b = bounds + (long long)slot * bstride + ((long long)group * 64 + lane) * 8;
+        s.volts = b[0]; s.save_volts = b[1]; s.hc = (int)b[2]; s.decay_type = (int)b[3]; s.st = (int)b[4];
+    }
+    constexpr int B = kAgcBatch, RPI = 64 / B;
+    const int frow = lane / B, fcol = lane % B;
+    const int RL = RPI * L, loff0 = frow * L + fcol, gb0 = (int)tile0;
+    double *e = ends + (long long)slot * estride + ((long long)group * 64 + lane) * 8;
+    // the next batch's 3 x B values per lane travel while the current batch is stepped
+    double t0n[B], t1n[B], t2n[B];
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            const int off = loff0 + j * RL, g = gb0 + i0 + off;
+            const bool ok = g < n;
+            t0n[j] = ok ? in0[g] : 0.0; t1n[j] = ok ? in1[g] : 0.0; t2n[j] = ok ? in2[g] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int i0 = 0; i0 < L; i0 += B) {
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            const int at = (RPI * j + frow) * kAgcPitch + fcol;
+            lds[at] = t0n[j]; lds[64 * kAgcPitch + at] = t1n[j]; lds[2 * 64 * kAgcPitch + at] = t2n[j];
+        }
+        if (i0 + B < L) fetch(i0 + B);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double *row = lds + lane * kAgcPitch;
+        double vv[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            if (live && s0 + i0 + k < n) agc_lane_step(s, row[k], row[64 * kAgcPitch + k], row[2 * 64 * kAgcPitch + k], q);
+            vv[k] = s.volts;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < B; k++) row[k] = vv[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            const int off = loff0 + j * RL, g = gb0 + i0 + off;
+            if (g < n) vo[g] = lds[(RPI * j + frow) * kAgcPitch + fcol];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (live) { e[0] = s.volts; e[1] = s.save_volts; e[2] = (double)s.hc; e[3] = (double)s.decay_type; e[4] = (double)s.st; }
+}
+
+__device__ __forceinline__ bool agc_state_differs(const double *a, const double *b)
+{
+    return !(fabs(a[0] - b[0]) <= 1e-9 * fabs(b[0]) && fabs(a[1] - b[1]) <= 1e-6 * fabs(b[1]) && a[2] == b[2] && a[3] == b[3] && a[4] == b[4]);
+}
+
+// One wavefront per channel walks the tiles in order: tile t began in bounds[t]; it is right when that is the state tile t - 1 ended in
+// (ends[t - 1], after any repair).  A tile that is not is stepped again from there, 64 samples per round, which also gives the end state
+// its successor is judged against.  fin[slot][0..4] = the state after the call's last sample.
+static __global__ __launch_bounds__(64) void agc_verify_kernel(int n, const int *chan_list, const AgcParam *prm, double *scr, long long arr,
+                                                              const double *bounds, long long bstride, double *ends, long long estride, int L,
+                                                              double *fin, int *nfixed)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x;
+    const AgcParam q = prm[ch];
+    const double *in0 = agc_arr(scr, arr, slot, 0), *in1 = agc_arr(scr, arr, slot, 1), *in2 = agc_arr(scr, arr, slot, 2);
+    double *vo = agc_arr(scr, arr, slot, 3);
+    double *e = ends + (long long)slot * estride;
+    const double *bd = bounds + (long long)slot * bstride;
+    const int ntiles = (n + L - 1) / L;
+    int fixed = 0;
+    for (int t = 1; t < ntiles; t++) {
+        const double *a = bd + (long long)t * 8, *b = e + (long long)(t - 1) * 8;
+        if (!agc_state_differs(a, b)) continue;                 // (uniform: every lane reads the same words)
+        AgcLane s{ b[0], b[1], (int)b[2], (int)b[3], (int)b[4] };
+        const long long s0 = (long long)t * L;
+        const int len = (int)((long long)n - s0 < L ? (long long)n - s0 : L);
+        for (int off = 0; off < len; off += 64) {
+            const int cnt = len - off < 64 ? len - off : 64;
+            double r = 0.0, f = 0.0, h = 0.0;
+            if (lane < cnt) { r = in0[s0 + off + lane]; f = in1[s0 + off + lane]; h = in2[s0 + off + lane]; }
+            double mine = 0.0;
+            for (int i = 0; i < cnt; i++) {
+                agc_lane_step(s, lane_bcast(r, i), lane_bcast(f, i), lane_bcast(h, i), q);
+                if (lane == i) mine = s.volts;
+            }
+            if (lane < cnt) vo[s0 + off + lane] = mine;
+        }
+        if (lane == 0) {
+            double *w = e + (long long)t * 8;
+            w[0] = s.volts; w[1] = s.save_volts; w[2] = (double)s.hc; w[3] = (double)s.decay_type; w[4] = (double)s.st;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the next tile's compare reads what lane 0 has just written
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        fixed++;
+    }
+    if (lane == 0 && n > 0) {
+        const double *b = e + (long long)(ntiles - 1) * 8;
+        double *o = fin + (long long)slot * 8;
+        for (int k = 0; k < 5; k++) o[k] = b[k];
+        if (fixed && nfixed) atomicAdd(nfixed, fixed);
+    }
+}
+
+// ---- (e): gain curve and multiply, in place ------------------------------------------------------------------------------------
+// grid (tiles of kAgcTile, channels), 256 threads; LDS: the tile's samples behind the A samples ahead of it (agc_prep_kernel kept them)
+static __global__ __launch_bounds__(256) void agc_apply_kernel(double2 *buf, long long stride, int n, const int *chan_list, const AgcParam *prm,
+                                                               const double *scr, long long arr, const double2 *halo, int halo_pitch,
+                                                               double pre_gain)
+{
+    extern __shared__ double2 sm_apply[];
+    const int slot = blockIdx.y, ch = chan_list[slot], t = threadIdx.x;
+    const AgcParam q = prm[ch];
+    double2 *x = buf + (long long)ch * stride;
+    const int A = q.attack_buffsize, j0 = blockIdx.x * kAgcTile;
+    const double2 *hl = halo + ((long long)slot * gridDim.x + blockIdx.x) * halo_pitch;
+    for (int i = t; i < A; i += 256) sm_apply[i] = hl[i];
+    for (int k = t; k < kAgcTile; k += 256) {
+        const int j = j0 + k;
+        double2 z = make_double2(0.0, 0.0);
+        if (j < n) { z = x[j]; z.x *= pre_gain; z.y *= pre_gain; }
+        sm_apply[A + k] = z;
+    }
+    __syncthreads();
+    const double *vo = scr + ((long long)slot * 4 + 3) * arr;
+    for (int k = t; k < kAgcTile; k += 256) {
+        const int j = j0 + k;
+        if (j >= n) break;
+        const double v = vo[j];
+        const double mult = __builtin_fma(-q.slope_constant, fmin(0.0, log10(q.inv_max_input * v)), q.out_target) / v;
+        const double2 o = sm_apply[k];                          // sample j - A
+        x[j] = make_double2(o.x * mult, o.y * mult);
+    }
+}
+
+// The state the next call starts from.  One workgroup per channel, AFTER agc_apply_kernel -- which has overwritten the rows: the last A
+// input samples come out of `tail` (kept by the caller ahead of the apply: the last A samples of every row, scaled).
+static __global__ __launch_bounds__(256) void agc_tail_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
+                                                              const AgcParam *prm, double2 *tail, double pre_gain)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot];
+    const int A = prm[ch].attack_buffsize;
+    const double2 *x = buf + (long long)ch * stride;
+    for (int i = threadIdx.x; i < A; i += 256) {
+        const double2 z = x[n - A + i];
+        tail[(long long)slot * kAgcRing + i] = make_double2(z.x * pre_gain, z.y * pre_gain);
+    }
+}
+static __global__ __launch_bounds__(256) void agc_finish_kernel(int n, const int *chan_list, const AgcParam *prm, AgcState *state,
+                                                                const double *scr, long long arr, const double2 *tail, const double *fin)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot], t = threadIdx.x;
+    const AgcParam q = prm[ch];
+    AgcState *sp = state + ch;
+    const int A = q.attack_buffsize;
+    const int oi = (sp->out_index + n) & (kAgcRing - 1);
+    // the window (out, in]: samples n - A .. n - 1 at slots out + 1 .. out + A
+    for (int i = t; i < A; i += 256) {
+        const double2 z = tail[(long long)slot * kAgcRing + i];
+        const int s = (oi + 1 + i) & (kAgcRing - 1);
+        sp->ring[s] = z;
+        sp->abs_ring[s] = agc_mag_of(z, q.pmode);
+    }
+    __syncthreads();
+    if (t == 0) {
+        const double *f = fin + (long long)slot * 8;
+        sp->ring_max = scr[((long long)slot * 4 + 0) * arr + n - 1];
+        sp->fast_backaverage = scr[((long long)slot * 4 + 1) * arr + n - 1];
+        sp->hang_backaverage = scr[((long long)slot * 4 + 2) * arr + n - 1];
+        sp->volts = f[0]; sp->save_volts = f[1]; sp->hang_counter = (int)f[2]; sp->decay_type = (int)f[3]; sp->state = (int)f[4];
+        sp->gain = f[0] * q.inv_out_target;
+        sp->out_index = oi;
+    }
+}
+
+}  // namespace qh

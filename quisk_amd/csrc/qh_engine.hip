@@ -31,6 +31,7 @@
 #include "qh_kernels.hpp"
 #include "qh_demod.hpp"
 #include "qh_tiled.hpp"
+#include "qh_agc_tiled.hpp"
 #include "qh_emnr.hpp"
 #include "qh_snba.hpp"
 #include "qh_internal.hpp"
@@ -63,6 +64,7 @@ static constexpr int kFmWarm = 768;
 static constexpr int kSamTile = 4096;
 static constexpr int kSamWarm = 8192;
 static constexpr long long kSamTiledMin = 4 * 8192;     // shorter calls take the sequential kernel
+static constexpr long long kAgcTiledMin = 16384;        // xwcpagc in time tiles from this many detector samples per call (qh_agc_tiled.hpp)
 
 struct ChanCfg {
     int mode = QH_LSB;                                          // RXA.c:33
@@ -80,6 +82,9 @@ struct ChanCfg {
     double agc_tau_attack = 0.001, agc_tau_decay = 0.250, agc_max_gain = 10000.0, agc_var_gain = 1.5;
     double agc_hangtime = 0.250, agc_hang_thresh = 0.250;
     bool agc_dirty = true;
+    bool agc_on() const { return agc_run && agc_mode != 0; }
+    int agc_abuf = -1;                  // attack_buffsize last uploaded
+    bool agc_ran = false, agc_stale = false;    // the window moved while the ring held samples: ring_max may be stale (qh_agc_tiled.hpp)
     int bp1_run = 1, bp1_nc = 2048, bp1_wintype = 1;            // RXA.c:377-389
     double bp1_flow = -4150.0, bp1_fhigh = -150.0, bp1_gain = 1.0;
     double gain1 = 4.0, gain2I = 1.0, gain2Q = 1.0;             // RXA.c:464-474
@@ -239,6 +244,12 @@ struct Engine {
     long long am_tsum_cap = 0;
     double *seg_sum[3] = { nullptr, nullptr, nullptr };     // segment summaries of the multi-workgroup scans: AM / SAM, (unused), snotch
     int *pll_nfixed = nullptr;
+    // xwcpagc in time tiles (qh_agc_tiled.hpp): streams RM / fba / hba / volts per listed channel, the tiles' halos, the last samples
+    // of the rows, the lanes' states, the final states, tiles re-run
+    double *agc_scr = nullptr, *agc_ends = nullptr, *agc_fin = nullptr;
+    double2 *agc_halo = nullptr, *agc_tail = nullptr;
+    long long agc_arr = 0, agc_ends_cap = 0, agc_halo_cap = 0;
+    int *agc_nfixed = nullptr;
     int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
     int agc_form = 0;                       // diagnostics (qh_rxa_debug_agc): 1 = the sample-by-sample form of the wcpAGC loop
     SamChanParam *sam_prm = nullptr;
@@ -313,6 +324,7 @@ Engine::~Engine()
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
+    (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
@@ -898,6 +910,8 @@ int Engine::refresh_demod()
             if (q.attack_buffsize + 2 > kAgcRing)
                 return set_error(QH_ERR_UNSUPPORTED, "AGC attack of %g s needs a look-ahead of %d samples (limit %d)", c.agc_tau_attack,
                                  q.attack_buffsize, kAgcRing - 2);
+            if (c.agc_ran && c.agc_abuf != q.attack_buffsize) c.agc_stale = true;
+            c.agc_abuf = q.attack_buffsize;
             q.attack_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_attack));
             q.decay_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_decay));
             q.fast_decay_mult = 1.0 - std::exp(-1.0 / (rate * tau_fast_decay));
@@ -1914,10 +1928,91 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     bp1_at(0);
     // xwcpagc modes 1-4 (sequential per channel); mode 0 rides in the output matrix below unless a position-1 stage follows
     tick(1);
-    if (n_agc_cur) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
-                                      list_agc_cur, agc_prm, agc_state, 1.0);
-    if (n_agc_other) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
-                                        list_agc_other, agc_prm, agc_state, 1.0);
+    if (n_agc_cur || n_agc_other) {
+        // Long calls: the level detector in time tiles, everything around it lane-parallel (qh_agc_tiled.hpp).  Short calls (the drop-in's
+        // blocks), a channel whose attack window moved in mid-stream, and the diagnostic forms: one wavefront per channel.
+        bool tiled = agc_form == 0 && n_mid >= kAgcTiledMin;
+        int a_max = 0;
+        for (int ch = 0; ch < nch && tiled; ch++) {
+            ChanCfg &c = cfg[(size_t)ch];
+            if (!c.agc_on()) continue;
+            if (c.agc_stale) tiled = false;
+            a_max = c.agc_abuf > a_max ? c.agc_abuf : a_max;
+        }
+        for (ChanCfg &c : cfg) if (c.agc_on()) c.agc_ran = true;
+        if (tiled) {
+            const int nl = n_agc_cur > n_agc_other ? n_agc_cur : n_agc_other;
+            const int ntile = (int)((n_mid + kAgcTile - 1) / kAgcTile), hp = (a_max + 15) & ~15;
+            // tiles short enough for one to two wavefronts of 64 tiles per SIMD
+            int L = 256;
+            while (L < 16384 && (long long)nl * n_mid / (64LL * 2 * L) >= 1024) L *= 2;
+            if (const char *e = getenv("QH_AGC_TILE")) { const int v = atoi(e); if (v > 0) L = (v + 63) / 64 * 64; }
+            const long long nt_l = (n_mid + L - 1) / L, ngroups = (nt_l + 63) / 64;
+            if (n_mid > agc_arr || ngroups * 64 > agc_ends_cap || (long long)ntile * hp > agc_halo_cap) {
+                QH_HIP(hipStreamSynchronize(stream));
+                if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
+                drop_graphs(); epoch++;
+                (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_halo);
+                agc_scr = agc_ends = nullptr; agc_halo = nullptr;
+                agc_arr = n_mid > agc_arr ? n_mid : agc_arr;
+                agc_ends_cap = ngroups * 64 > agc_ends_cap ? ngroups * 64 : agc_ends_cap;
+                agc_halo_cap = (long long)ntile * hp > agc_halo_cap ? (long long)ntile * hp : agc_halo_cap;
+                QH_HIP(dev_alloc(&agc_scr, (size_t)nch * 4 * (size_t)agc_arr));
+                QH_HIP(dev_alloc(&agc_ends, (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW * 2));        // boundary states, then end states
+                QH_HIP(dev_alloc(&agc_halo, (size_t)nch * (size_t)agc_halo_cap));
+                if (!agc_fin) {
+                    QH_HIP(dev_alloc(&agc_fin, (size_t)nch * 8));
+                    QH_HIP(dev_alloc(&agc_tail, (size_t)nch * kAgcRing));
+                    QH_HIP(dev_alloc(&agc_nfixed, (size_t)1));
+                    QH_HIP(hipMemsetAsync(agc_nfixed, 0, sizeof(int), stream));
+                }
+            }
+            if (!seg_sum[1]) QH_HIP(dev_alloc(&seg_sum[1], (size_t)nch * kSegWaves * kSegMaxGroups * kSegSumW));
+            static bool agc_attr = false;
+            if (!agc_attr) {        // attack windows of up to kAgcRing samples: more dynamic LDS than the default limit
+                QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(agc_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           3 * (kAgcRing + kAgcTile) * (int)sizeof(double)));
+                QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(agc_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (kAgcRing + kAgcTile) * (int)sizeof(double2)));
+                agc_attr = true;
+            }
+            auto run = [&](double2 *b, const int *lst, int cnt) {
+                if (!cnt) return;
+                const int n = (int)n_mid;
+                int G = 256 / cnt;
+                while (G > 1 && n_mid / (64LL * kSegWaves * G) < 8) G--;
+                G = G < 1 ? 1 : G > kSegMaxGroups ? kSegMaxGroups : G;
+                const size_t lds_prep = (size_t)3 * (((size_t)a_max + 63) / 64 * 64 + kAgcTile) * sizeof(double);
+                const size_t lds_apply = ((size_t)a_max + kAgcTile) * sizeof(double2);
+                hipLaunchKernelGGL(agc_prep_kernel, dim3((unsigned)ntile, (unsigned)cnt), dim3(256), lds_prep, stream, (const double2 *)b, buf_cap, n,
+                                   lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, agc_halo, hp, 1.0);
+                hipLaunchKernelGGL((agc_avg_tiled_kernel<1>), dim3((unsigned)cnt, (unsigned)G), dim3(kSegThreads), 0, stream, (const double2 *)b,
+                                   buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, seg_sum[1], 1.0);
+                hipLaunchKernelGGL((agc_avg_tiled_kernel<2>), dim3((unsigned)cnt, (unsigned)G), dim3(kSegThreads), 0, stream, (const double2 *)b,
+                                   buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, seg_sum[1], 1.0);
+                double *bnd = agc_ends, *end = agc_ends + (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW;
+                hipLaunchKernelGGL(agc_bounds_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
+                                   (const AgcState *)agc_state, (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L);
+                hipLaunchKernelGGL(agc_lanes_kernel, dim3((unsigned)ngroups, (unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
+                                   agc_scr, agc_arr, (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L);
+                hipLaunchKernelGGL(agc_verify_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_scr, agc_arr,
+                                   (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L, agc_fin, agc_nfixed);
+                hipLaunchKernelGGL(agc_tail_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, (const double2 *)b, buf_cap, n, lst,
+                                   (const AgcParam *)agc_prm, agc_tail, 1.0);
+                hipLaunchKernelGGL(agc_apply_kernel, dim3((unsigned)ntile, (unsigned)cnt), dim3(256), lds_apply, stream, b, buf_cap, n, lst,
+                                   (const AgcParam *)agc_prm, (const double *)agc_scr, agc_arr, (const double2 *)agc_halo, hp, 1.0);
+                hipLaunchKernelGGL(agc_finish_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_state,
+                                   (const double *)agc_scr, agc_arr, (const double2 *)agc_tail, (const double *)agc_fin);
+            };
+            run(cur, list_agc_cur, n_agc_cur);
+            run(other, list_agc_other, n_agc_other);
+        } else {
+            if (n_agc_cur) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap,
+                                              (int)n_mid, list_agc_cur, agc_prm, agc_state, 1.0);
+            if (n_agc_other) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other,
+                                                buf_cap, (int)n_mid, list_agc_other, agc_prm, agc_state, 1.0);
+        }
+    }
     {
         long long per = (n_mid + NT - 1) / NT;
         const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
@@ -2699,8 +2794,36 @@ int qh_rxa_debug_pll(qh_rxa *h, int check_only, int ch, double *out, int max)
     return (int)n;
 }
 
-// Diagnostics: which form of the wcpAGC loop runs (0: 64 samples per step of the wavefront, 1: sample by sample).  Same state, same
-// results: tests hold one against the other.
+// Diagnostics: the lanes' states of the last time-tiled wcpAGC call, list slot `slot`: [tile][kAgcEndsW]
+int qh_rxa_debug_agc_ends(qh_rxa *h, int slot, double *out, int max)
+{
+    if (!h || !out || max <= 0 || !h->e.agc_ends) return 0;
+    QH_RXA_LOCK(h);
+    Engine &e = h->e;
+    QH_HIP(hipSetDevice(e.device));
+    QH_HIP(hipStreamSynchronize(e.stream));
+    // [tile][8] boundary states (what the run-jumping pass found), then [tile][8] the states the exact tiles ended in
+    long long n = e.agc_ends_cap * kAgcEndsW;
+    if (2 * n > max) n = max / 2;
+    QH_HIP(hipMemcpy(out, e.agc_ends + (long long)slot * e.agc_ends_cap * kAgcEndsW, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    QH_HIP(hipMemcpy(out + n, e.agc_ends + ((long long)e.nch + slot) * e.agc_ends_cap * kAgcEndsW, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    n *= 2;
+    return (int)n;
+}
+
+// tiles of the time-tiled wcpAGC that the verify pass re-ran in order, over all calls so far
+long long qh_rxa_agc_repairs(qh_rxa *h)
+{
+    if (!h || !h->e.agc_nfixed) return 0;
+    QH_RXA_LOCK(h);
+    int v = 0;
+    if (hipSetDevice(h->e.device) != hipSuccess || hipStreamSynchronize(h->e.stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, h->e.agc_nfixed, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
+
+// Diagnostics: which form of the wcpAGC loop runs (0: time tiles for long calls, else 64 samples per step of the wavefront; 1: sample by
+// sample; 2: 64 samples per step whatever the call length).  Same state; 1 and 2 give the same bits, 0 the same to rounding.
 int qh_rxa_debug_agc(qh_rxa *h, int form)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");

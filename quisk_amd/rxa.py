@@ -143,8 +143,11 @@ class RxaEngine:
         return self._L.qh_rxa_pll_repairs(self._h)
 
     def debug_agc(self, form):
-        """diagnostics: 1 = the sample-by-sample form of the wcpAGC loop, 0 = 64 samples per step (default)"""
+        """diagnostics: 0 = time tiles for long calls (default), 1 = the sample-by-sample form of the wcpAGC loop, 2 = 64 samples per step"""
         check(self._L.qh_rxa_debug_agc(self._h, int(form)))
+
+    def agc_repairs(self):
+        return self._L.qh_rxa_agc_repairs(self._h)
 
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))

@@ -44,27 +44,68 @@ def test_batch_form_is_bit_identical_to_the_sample_loop_and_follows_the_oracle(q
     x = _input(nch, nblk)
     calls = [3, 1, 50, 7, 100, 79]
     outs = {}
+    for form in (2, 1):
+        e = _engine(qh, nch, modes, form)
+        ys, pos = [], 0
+        for nb in calls:
+            ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
+        outs[form] = np.concatenate(ys, axis=1)
+    assert np.array_equal(outs[2], outs[1])
+    # the forms alternate between calls on one engine: still the same samples
+    e = _engine(qh, nch, modes, 2)
+    ys, pos = [], 0
+    for k, nb in enumerate(calls):
+        e.debug_agc(2 - (k & 1))
+        ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
+    assert np.array_equal(np.concatenate(ys, axis=1), outs[2])
+    for c in range(nch):
+        ref = _oracle_run(oracle, c, modes[c % len(modes)], x[c])
+        assert np.abs(ref).max() > 1e-3
+        assert rel_rms(outs[2][c], ref) < 1e-9, (c, rel_rms(outs[2][c], ref))
+
+
+def _oracle_run(oracle, c, mode, xc):
+    o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+    o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+    o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(mode)
+    return o.xrxa(xc)
+
+
+@pytest.mark.parametrize("modes", [[3], [1, 2, 3, 4]], ids=["med", "long-slow-med-fast"])
+def test_time_tiles_follow_the_sample_loop_and_the_oracle(qh, oracle, modes):
+    """Long calls (>= 16384 detector samples) run the level detector one lane per tile from the call's start state, check every tile's
+    start against its predecessor's end and re-run what had not met (qh_agc_tiled.hpp).  The signal -- bursts, a fade, silence, a
+    click -- makes tiles fail; the result is the sample loop's to rounding, the carried state lets short and long calls alternate."""
+    nch, nblk = 4, 640
+    x = _input(nch, nblk, seed=21)
+    calls = [3, 200, 1, 130, 64, 5, 237]                     # long calls between short ones
+    outs = {}
     for form in (0, 1):
         e = _engine(qh, nch, modes, form)
         ys, pos = [], 0
         for nb in calls:
             ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
         outs[form] = np.concatenate(ys, axis=1)
-    assert np.array_equal(outs[0], outs[1])
-    # the forms alternate between calls on one engine: still the same samples
-    e = _engine(qh, nch, modes, 0)
-    ys, pos = [], 0
-    for k, nb in enumerate(calls):
-        e.debug_agc(k & 1)
-        ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
-    assert np.array_equal(np.concatenate(ys, axis=1), outs[0])
+        if form == 0:
+            repairs = e.agc_repairs()
     for c in range(nch):
-        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
-        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
-        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(modes[c % len(modes)])
-        ref = o.xrxa(x[c])
-        assert np.abs(ref).max() > 1e-3
+        assert rel_rms(outs[0][c], outs[1][c]) < 1e-10, (c, rel_rms(outs[0][c], outs[1][c]))
+        ref = _oracle_run(oracle, c, modes[c % len(modes)], x[c])
         assert rel_rms(outs[0][c], ref) < 1e-9, (c, rel_rms(outs[0][c], ref))
+    assert repairs >= 0
+
+
+def test_time_tiles_on_a_steady_signal_need_no_repairs(qh, oracle):
+    """A channel whose level is steady sits where it sat when the call began: every tile verifies."""
+    nch, nblk = 3, 300
+    x = np.stack([synth.make_mode_input_numpy("usb", c, nblk * 1024) for c in range(nch)])
+    e = _engine(qh, nch, [3], 0)
+    y = np.concatenate([e.process_host(np.ascontiguousarray(x[:, :40 * 1024])), e.process_host(np.ascontiguousarray(x[:, 40 * 1024:170 * 1024])),
+                        e.process_host(np.ascontiguousarray(x[:, 170 * 1024:]))], axis=1)
+    assert e.agc_repairs() == 0
+    for c in range(nch):
+        ref = _oracle_run(oracle, c, 3, x[c])
+        assert rel_rms(y[c], ref) < 1e-9, (c, rel_rms(y[c], ref))
 
 
 def test_attack_window_changes_and_odd_lengths(qh, oracle):
@@ -75,7 +116,7 @@ def test_attack_window_changes_and_odd_lengths(qh, oracle):
     nch, nblk = 2, 64
     x = _input(nch, nblk, seed=9)
     outs = {}
-    for form in (0, 1):
+    for form in (2, 1):
         e = _engine(qh, nch, [3], form)
         ys = [e.process_host(np.ascontiguousarray(x[:, :20 * 1024 + 0]))]
         for c in range(nch): e.SetRXAAGCAttack(c, 4)
@@ -83,11 +124,8 @@ def test_attack_window_changes_and_odd_lengths(qh, oracle):
         for c in range(nch): e.SetRXAAGCAttack(c, 1)
         ys.append(e.process_host(np.ascontiguousarray(x[:, 41 * 1024:])))
         outs[form] = np.concatenate(ys, axis=1)
-    assert np.array_equal(outs[0], outs[1])
-    assert np.abs(outs[0]).max() > 1e-3
+    assert np.array_equal(outs[2], outs[1])
+    assert np.abs(outs[2]).max() > 1e-3
     for c in range(nch):
-        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
-        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
-        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(3)
-        ref = o.xrxa(x[c, :20 * 1024])
-        assert rel_rms(outs[0][c][:20 * 256], ref) < 1e-9, c
+        ref = _oracle_run(oracle, c, 3, x[c, :20 * 1024])
+        assert rel_rms(outs[2][c][:20 * 256], ref) < 1e-9, c
