@@ -192,32 +192,30 @@ static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const
 // where the state stays put, single reference steps (agc_lane_step) at the turns.  What comes out are the states at the tile
 // boundaries, within rounding of what sample-by-sample stepping gives -- the lanes then step every tile exactly from there, and the
 // check of every tile's end against the next boundary (agc_verify_kernel) catches what a jump got wrong.
-__device__ __forceinline__ void agc_run_jump(AgcLane &s, double rm, int k, double fba_first, double hba_first, const AgcParam &q,
-                                             const double *fba_row, const double *hba_row, int p0, int lane)
+// advance k >= 1 samples (k <= 64) of constant ring_max; fba / hba of sample p0 + i sit in lane p0 + i of f / h; tab[w][j] = (1 - mult_w)^j
+// for the attack, decay and hang-decay multipliers
+__device__ __forceinline__ void agc_run_jump(AgcLane &s, double rm, int k, const AgcParam &q, double f, double h, int p0, const double (*tab)[65])
 {
-    // advance k >= 1 samples of constant ring_max; fba / hba of sample p0 + i come from the lanes of fba_row / hba_row (uniform reads)
     int i = 0;
     while (i < k) {
         const int left = k - i;
         const bool up = rm >= s.volts;
-        int jump = 0;
-        double mlt = 0.0;
-        if (s.st == 0 && up) { jump = left; mlt = q.attack_mult; }
-        else if ((s.st == 3 || s.st == 4) && !up) { jump = left; mlt = s.st == 3 ? q.decay_mult : q.hang_decay_mult; }
-        else if (s.st == 2 && !up && s.hc > 1) { jump = left < s.hc - 1 ? left : s.hc - 1; mlt = 0.0; }
+        int jump = 0, w = -1;
+        if (s.st == 0 && up) { jump = left; w = 0; }
+        else if ((s.st == 3 || s.st == 4) && !up) { jump = left; w = s.st == 3 ? 1 : 2; }
+        else if (s.st == 2 && !up && s.hc > 1) jump = left < s.hc - 1 ? left : s.hc - 1;
         if (jump > 1) {
-            if (mlt != 0.0) {
-                double v = __builtin_fma(s.volts - rm, exp((double)jump * log1p(-mlt)), rm);
+            if (w >= 0) {
+                const double v = __builtin_fma(s.volts - rm, tab[w][jump], rm);
                 s.volts = v < q.min_volts ? q.min_volts : v;
             }
             s.hc = s.hc > jump ? s.hc - jump : 0;
             i += jump;
         } else {
-            agc_lane_step(s, rm, lane_bcast(*fba_row, p0 + i), lane_bcast(*hba_row, p0 + i), q);
+            agc_lane_step(s, rm, lane_bcast(f, p0 + i), lane_bcast(h, p0 + i), q);
             i += 1;
         }
     }
-    (void)fba_first; (void)hba_first; (void)lane;
 }
 
 // bounds[slot][tile][0..4]: the state at the START of tile t (tile 0: the carried state).  grid (channels), one wavefront.
@@ -230,6 +228,13 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
     const double *in0 = scr + ((long long)slot * 4 + 0) * arr, *in1 = scr + ((long long)slot * 4 + 1) * arr, *in2 = scr + ((long long)slot * 4 + 2) * arr;
     double *bo = bounds + (long long)slot * bstride;
     AgcLane s{ sp->volts, sp->save_volts, sp->hang_counter, sp->decay_type, sp->state };
+    __shared__ double tab[3][65];
+    {
+        const double lg0 = log1p(-q.attack_mult), lg1 = log1p(-q.decay_mult), lg2 = log1p(-q.hang_decay_mult);
+        tab[0][lane + 1] = exp((double)(lane + 1) * lg0); tab[1][lane + 1] = exp((double)(lane + 1) * lg1); tab[2][lane + 1] = exp((double)(lane + 1) * lg2);
+        if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = 1.0;
+        __syncthreads();
+    }
     double prev = -1.0;                                     // ring_max is never negative: the first sample opens a run
     double rn = 0.0, fn = 0.0, hn = 0.0;
     if (lane < n) { rn = in0[lane]; fn = in1[lane]; hn = in2[lane]; }
@@ -251,7 +256,7 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
             const int p0 = __ffsll((long long)heads) - 1;
             heads &= heads - 1;
             const int p1 = heads ? __ffsll((long long)heads) - 1 : cnt;
-            agc_run_jump(s, lane_bcast(r, p0), p1 - p0, 0.0, 0.0, q, &f, &h, p0, lane);
+            agc_run_jump(s, lane_bcast(r, p0), p1 - p0, q, f, h, p0, tab);
         }
     }
 }
@@ -323,9 +328,12 @@ static __global__ __launch_bounds__(64, 2) void agc_lanes_kernel(int n, const in
     if (live) { e[0] = s.volts; e[1] = s.save_volts; e[2] = (double)s.hc; e[3] = (double)s.decay_type; e[4] = (double)s.st; }
 }
 
+// A boundary state is accepted when it is the state the tile before it ended in: the discrete part exactly, volts to 1e-11 and
+// save_volts -- volts as it was at the last turn to state 0 -- to 1e-9 (the closed-form jumps land within 1e-14 of the stepped values;
+// tools/dbg/agc_ends2.py prints the misses of a call).
 __device__ __forceinline__ bool agc_state_differs(const double *a, const double *b)
 {
-    return !(fabs(a[0] - b[0]) <= 1e-9 * fabs(b[0]) && fabs(a[1] - b[1]) <= 1e-6 * fabs(b[1]) && a[2] == b[2] && a[3] == b[3] && a[4] == b[4]);
+    return !(fabs(a[0] - b[0]) <= 1e-11 * fabs(b[0]) && fabs(a[1] - b[1]) <= 1e-9 * fabs(b[1]) && a[2] == b[2] && a[3] == b[3] && a[4] == b[4]);
 }
 
 // One wavefront per channel walks the tiles in order: tile t began in bounds[t]; it is right when that is the state tile t - 1 ended in

@@ -2718,6 +2718,7 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(e.agc_state[c].ring, 0, sizeof(e.agc_state[c].ring), e.stream));
             QH_HIP(hipMemsetAsync(e.agc_state[c].abs_ring, 0, sizeof(e.agc_state[c].abs_ring), e.stream));
             QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
+            e.cfg[(size_t)c].agc_stale = false;     // an empty ring and ring_max = 0: nothing stale (qh_agc_tiled.hpp)
         }
     }
     for (ChanCfg &c : e.cfg) { c.lms[0].flush = c.lms[1].flush = true; c.emnr_flush = true; c.snba_flush = true; c.snb_flush = true; }    // flush_anf / flush_anr / flush_emnr, RXA.c:541-543

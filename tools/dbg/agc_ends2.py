@@ -20,14 +20,13 @@ for call in range(4):
     e.process_ptr(x.data_ptr(), nblk * 1024, y.data_ptr(), nblk * 256, nblk)
     r = e.agc_repairs()
     n = e._L.qh_rxa_debug_agc_ends(e._h, 0, buf, 400000)
-    a = np.frombuffer(buf, dtype=np.float64)[:n].reshape(-1, 12).copy()
-    L = int(os.environ.get("QH_AGC_TILE", "0")) or 0
+    a = np.frombuffer(buf, dtype=np.float64)[:n].reshape(2, -1, 8).copy()      # boundary states, end states
     print("call", call, "repairs", r - prev); prev = r
     nt = 0
-    for t in range(1, a.shape[0]):
-        if a[t, 5] == 0 and a[t, 0] == 0: break
+    for t in range(1, a.shape[1]):
+        if a[0, t, 0] == 0: break
         nt = t
-    w, p = a[1:nt + 1, 0:5], a[0:nt, 5:10]
+    w, p = a[0, 1:nt + 1, 0:5], a[1, 0:nt, 0:5]
     dv = np.abs(w[:, 0] - p[:, 0]) / np.abs(p[:, 0]); dsv = np.abs(w[:, 1] - p[:, 1]) / np.maximum(np.abs(p[:, 1]), 1e-300)
     disc = (w[:, 2:] != p[:, 2:]).any(axis=1)
     print("   tiles", nt, "dv>1e-9:", int((dv > 1e-9).sum()), "dsv>1e-6:", int((dsv > 1e-6).sum()), "discrete:", int(disc.sum()),
