@@ -185,36 +185,48 @@ static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const
 }
 
 // ---- (d), first the detector's state at every tile boundary ---------------------------------------------------------------------
-// ring_max is piecewise constant (it moves when a larger sample enters the window or the largest leaves it: a run is ~100 samples),
-// and inside a run the detector does one of a few things that have closed forms: attack towards ring_max from below (it stays below),
-// decay towards it from above (it stays above), hold while the hang counter runs, decay fast down to save_volts.  One wavefront per
-// channel takes 64 samples of the three streams at a time, cuts them into runs (a ballot) and advances run by run: a closed-form jump
-// where the state stays put, single reference steps (agc_lane_step) at the turns.  What comes out are the states at the tile
-// boundaries, within rounding of what sample-by-sample stepping gives -- the lanes then step every tile exactly from there, and the
-// check of every tile's end against the next boundary (agc_verify_kernel) catches what a jump got wrong.
-// advance k >= 1 samples (k <= 64) of constant ring_max; fba / hba of sample p0 + i sit in lane p0 + i of f / h; tab[w][j] = (1 - mult_w)^j
-// for the attack, decay and hang-decay multipliers
-__device__ __forceinline__ void agc_run_jump(AgcLane &s, double rm, int k, const AgcParam &q, double f, double h, int p0, const double (*tab)[65])
+// The detector spends its time in a few regimes -- attacking towards ring_max from below, decaying towards it from above, holding
+// while the hang counter runs -- and inside a regime it is a LINEAR one-pole recurrence driven by ring_max.  One wavefront per channel
+// takes 64 samples of the three streams at a time and advances regime by regime (agc_chunk): a wave-wide scan where the state stays
+// put, single reference steps (agc_lane_step) at the turns.  What comes out are the states at the tile boundaries, within rounding of
+// what sample-by-sample stepping gives -- the lanes then step every tile exactly from there, and the check of every tile's end against
+// the next boundary (agc_verify_kernel) catches what a scan got wrong.
+// One chunk of cnt <= 64 samples (ring_max r, back-averages f, h in the lanes): the detector advances REGIME by regime.  While it
+// attacks (state 0, ring_max >= volts), decays (state 3 or 4, ring_max < volts) or holds (state 2, counter running) it is a linear
+// recurrence in volts with one multiplier whatever ring_max does, so the rest of the chunk is taken as a wave-wide scan,
+//   v_j = (1 - m)^(j - p + 1) v + sum_{i = p .. j} m r_i (1 - m)^(j - i),
+// a ballot finds the first sample at which the regime's own condition (on v_{j-1}) fails, everything ahead of it is accepted at once,
+// and that sample is one reference step (agc_lane_step).  tab[w][k] = (1 - mult_w)^k for the attack, decay and hang-decay multipliers.
+__device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double h, int cnt, int lane, const AgcParam &q, const PoleScan *ps,
+                                          const double (*tab)[65])
 {
-    int i = 0;
-    while (i < k) {
-        const int left = k - i;
-        const bool up = rm >= s.volts;
-        int jump = 0, w = -1;
-        if (s.st == 0 && up) { jump = left; w = 0; }
-        else if ((s.st == 3 || s.st == 4) && !up) { jump = left; w = s.st == 3 ? 1 : 2; }
-        else if (s.st == 2 && !up && s.hc > 1) jump = left < s.hc - 1 ? left : s.hc - 1;
-        if (jump > 1) {
-            if (w >= 0) {
-                const double v = __builtin_fma(s.volts - rm, tab[w][jump], rm);
-                s.volts = v < q.min_volts ? q.min_volts : v;
-            }
-            s.hc = s.hc > jump ? s.hc - jump : 0;
-            i += jump;
-        } else {
-            agc_lane_step(s, rm, lane_bcast(f, p0 + i), lane_bcast(h, p0 + i), q);
-            i += 1;
+    int p = 0;
+    while (p < cnt) {
+        const double rp = lane_bcast(r, p);
+        const bool up = rp >= s.volts;
+        // (a decay that sits on the min_volts clamp holds there while ring_max stays below it: silence)
+        const bool floor = (s.st == 3 || s.st == 4) && !up && s.volts <= q.min_volts;
+        const int w = floor ? 4 : (s.st == 0 && up) ? 0 : (s.st == 3 && !up) ? 1 : (s.st == 4 && !up) ? 2 : (s.st == 2 && !up && s.hc > 1) ? 3 : -1;
+        int k = p;                                              // first sample the regime does not cover
+        if (w >= 0 && w < 3) {
+            const double m = w == 0 ? q.attack_mult : w == 1 ? q.decay_mult : q.hang_decay_mult;
+            const bool in = lane >= p && lane < cnt;
+            const double sc = scan_pole_dpp(in ? m * r : 0.0, ps[w]);
+            const double v = __builtin_fma(tab[w][in ? lane - p + 1 : 0], s.volts, sc);
+            double vb = wave_shr1(v);
+            if (lane == p) vb = s.volts;
+            const bool ok = w == 0 ? r >= vb : (r < vb && v >= q.min_volts);
+            const unsigned long long bad = __ballot(in && !ok);
+            k = bad ? __ffsll((long long)bad) - 1 : cnt;
+            if (k > p) s.volts = lane_bcast(v, k - 1);
+        } else if (w >= 3) {
+            const bool in = lane >= p && lane < cnt;
+            const unsigned long long bad = __ballot(in && r >= s.volts);
+            k = bad ? __ffsll((long long)bad) - 1 : cnt;
+            if (w == 3 && k - p > s.hc - 1) k = p + s.hc - 1;   // the counter runs out: that sample is a turn
         }
+        if (k > p) { s.hc = s.hc > k - p ? s.hc - (k - p) : 0; p = k; }
+        else { agc_lane_step(s, rp, lane_bcast(f, p), lane_bcast(h, p), q); p++; }
     }
 }
 
@@ -235,7 +247,8 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
         if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = 1.0;
         __syncthreads();
     }
-    double prev = -1.0;                                     // ring_max is never negative: the first sample opens a run
+    const PoleScan ps[3] = { make_pole_scan(1.0 - q.attack_mult, lane), make_pole_scan(1.0 - q.decay_mult, lane),
+                             make_pole_scan(1.0 - q.hang_decay_mult, lane) };
     double rn = 0.0, fn = 0.0, hn = 0.0;
     if (lane < n) { rn = in0[lane]; fn = in1[lane]; hn = in2[lane]; }
     for (int base = 0; base < n; base += 64) {
@@ -246,18 +259,7 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
         }
         const double r = rn, f = fn, h = hn;
         if (base + 64 + lane < n) { rn = in0[base + 64 + lane]; fn = in1[base + 64 + lane]; hn = in2[base + 64 + lane]; }     // the next chunk is on its way
-        // lane j opens a run when its value differs from the one before it
-        double before = wave_shr1(r);
-        if (lane == 0) before = prev;
-        unsigned long long heads = __ballot(lane < cnt && r != before);
-        if (!(heads & 1ull)) heads |= 1ull;                 // the chunk's first samples continue the run of the chunk before
-        prev = lane_bcast(r, cnt - 1);
-        while (heads) {
-            const int p0 = __ffsll((long long)heads) - 1;
-            heads &= heads - 1;
-            const int p1 = heads ? __ffsll((long long)heads) - 1 : cnt;
-            agc_run_jump(s, lane_bcast(r, p0), p1 - p0, q, f, h, p0, tab);
-        }
+        agc_chunk(s, r, f, h, cnt, lane, q, ps, tab);
     }
 }
 
