@@ -86,14 +86,60 @@ static __constant__ double kSamC0[7] = { -0.328201924180698, -0.744171491539427,
 static __constant__ double kSamC1[7] = { -0.0991227952747244, -0.565619728761389, -0.857467122550052, -0.959123933111275,
                                   -0.988739372718090, -0.996959189310611, -0.999282492800792 };
 
-// Synchronous AM: in place.  The all-pass state lives in LDS (uniform addresses: every lane reads and writes
-// the same words, which is a broadcast / same-value store).
+// ---- the sideband separator's all-pass chains (amd.c:160-186), 64 samples at a time ------------------------------------------
+// A chain is seven sections y[n] = c (x[n] - y[n-2]) + x[n-2], the output of one the input of the next.  Per section and batch:
+// u[n] = c x[n] + x[n-2] (x[n-2] by a shift of two lanes, the first two from the carried state), then y[n] = -c y[n-2] + u[n] as a
+// lag-two Kogge-Stone scan over the 64 lanes (shifts of 2, 4, 8, 16, 32 with multipliers (-c)^1, ^2, ^4, ^8, ^16), then the carried
+// y[-2] (even lanes) / y[-1] (odd lanes) times (-c)^(lane / 2 + 1).  The state is the reference's: x_j[n-1] = arr[3 j + 1],
+// x_j[n-2] = arr[3 j + 2] for j = 0 .. 7 (x_7 = the chain's output), the other words of the arrays are scratch there.
+__device__ __forceinline__ double shfl_up0(double v, int d, int lane)
+{
+    const double t = __shfl_up(v, d, 64);
+    return lane >= d ? t : 0.0;
+}
+struct ApChain { double x1[8], x2[8]; };            // x_j[n-1], x_j[n-2]
+__device__ __forceinline__ void ap_load(ApChain &s, const double *arr)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) { s.x1[j] = arr[3 * j + 1]; s.x2[j] = arr[3 * j + 2]; }
+}
+__device__ __forceinline__ void ap_store(const ApChain &s, double *arr)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) { arr[3 * j + 1] = s.x1[j]; arr[3 * j + 2] = s.x2[j]; }
+}
+// x: the chain's input of sample lane (lanes >= cnt: 0); pw[j] = (-c_j)^(lane / 2 + 1); returns the chain's output per lane
+__device__ __forceinline__ double ap_chain64(ApChain &s, double x, const double *c, const double (&pw)[7], int cnt, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        double xs = shfl_up0(x, 2, lane);
+        if (lane == 0) xs = s.x2[j];
+        if (lane == 1) xs = s.x1[j];
+        const double cj = c[j], p1 = -cj, p2 = p1 * p1, p4 = p2 * p2, p8 = p4 * p4, p16 = p8 * p8;
+        double y = __builtin_fma(cj, x, xs);
+        y = __builtin_fma(p1, shfl_up0(y, 2, lane), y);
+        y = __builtin_fma(p2, shfl_up0(y, 4, lane), y);
+        y = __builtin_fma(p4, shfl_up0(y, 8, lane), y);
+        y = __builtin_fma(p8, shfl_up0(y, 16, lane), y);
+        y = __builtin_fma(p16, shfl_up0(y, 32, lane), y);
+        y = __builtin_fma(pw[j], (lane & 1) ? s.x1[j + 1] : s.x2[j + 1], y);
+        // this section's input history for the next batch (cnt >= 1)
+        const double l1 = lane_bcast(x, cnt - 1), l2 = cnt >= 2 ? lane_bcast(x, cnt - 2) : s.x1[j];
+        s.x1[j] = l1; s.x2[j] = l2;
+        x = lane < cnt ? y : 0.0;
+    }
+    const double l1 = lane_bcast(x, cnt - 1), l2 = cnt >= 2 ? lane_bcast(x, cnt - 2) : s.x1[7];
+    s.x1[7] = l1; s.x2[7] = l2;
+    return x;
+}
+
+// Synchronous AM: in place.
 static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                      PllState *state, const SamChanParam *cprm, PllParam q, AmState *fade)
 {
-    constexpr int STAGES = 7, OUT_IDX = 3 * STAGES;
     const double *c0 = kSamC0, *c1 = kSamC1;
-    __shared__ double fa[24], fb[24], fc[24], fd[24], pll_out[128];
+    __shared__ double pll_out[128];
     const int ch = chan_list[blockIdx.x];
     const int lane = threadIdx.x;
     double2 *p = buf + (long long)ch * stride;
@@ -103,8 +149,11 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     // the fade leveller's two averages belong to the amd block, not to a mode (amd.h:58-59): AM and SAM share them
     double dc = fade[ch].dc, dc_insert = fade[ch].dc_insert;
     double dsI = sp->dsI, dsQ = sp->dsQ;
-    if (lane < 24) { fa[lane] = sp->a[lane]; fb[lane] = sp->b[lane]; fc[lane] = sp->c[lane]; fd[lane] = sp->d[lane]; }
-    __syncthreads();
+    ApChain ca, cb, cc, cd;
+    ap_load(ca, sp->a); ap_load(cb, sp->b); ap_load(cc, sp->c); ap_load(cd, sp->d);
+    double pw0[7], pw1[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { pw0[j] = ipow_d(-c0[j], lane / 2 + 1); pw1[j] = ipow_d(-c1[j], lane / 2 + 1); }
     // Same split as in fm_pll_kernel: det = atan2(corr1, corr0) (amd.c:222-223) is arg(z) - phs, so the sequential
     // part only carries the loop filter; each lane then forms the VCO products of ITS sample from the phase the
     // loop had at that sample.  The fade leveler (two one-pole averages, amd.c:211-216) is solved by scans; only
@@ -128,24 +177,14 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
         const double corr0 = ai + bq;
         double audio = corr0;
         if (sbmode != 0) {
-            double mine = 0.0;
-            for (int i = 0; i < cnt; i++) {
-                const double ai_i = lane_bcast(ai, i), bi_i = lane_bcast(bi, i), aq_i = lane_bcast(aq, i), bq_i = lane_bcast(bq, i);
-                fa[0] = dsI; fb[0] = bi_i; fc[0] = dsQ; fd[0] = aq_i;
-                dsI = ai_i; dsQ = bq_i;
-                for (int j = 0; j < STAGES; j++) {
-                    const int k = 3 * j;
-                    fa[k + 3] = c0[j] * (fa[k] - fa[k + 5]) + fa[k + 2];
-                    fb[k + 3] = c1[j] * (fb[k] - fb[k + 5]) + fb[k + 2];
-                    fc[k + 3] = c0[j] * (fc[k] - fc[k + 5]) + fc[k + 2];
-                    fd[k + 3] = c1[j] * (fd[k] - fd[k + 5]) + fd[k + 2];
-                }
-                const double ai_ps = fa[OUT_IDX], bi_ps = fb[OUT_IDX], bq_ps = fc[OUT_IDX], aq_ps = fd[OUT_IDX];
-                for (int j = OUT_IDX + 2; j > 0; j--) { fa[j] = fa[j - 1]; fb[j] = fb[j - 1]; fc[j] = fc[j - 1]; fd[j] = fd[j - 1]; }
-                const double v = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
-                if (lane == i) mine = v;
-            }
-            audio = mine;
+            // chain inputs: a <- ai one sample late (dsI), b <- bi, c <- bq one sample late (dsQ), d <- aq   (amd.c:162-167)
+            const bool live = lane < cnt;
+            double ai_d = wave_shr1(ai), bq_d = wave_shr1(bq);
+            if (lane == 0) { ai_d = dsI; bq_d = dsQ; }
+            dsI = lane_bcast(ai, cnt - 1); dsQ = lane_bcast(bq, cnt - 1);
+            const double ai_ps = ap_chain64(ca, live ? ai_d : 0.0, c0, pw0, cnt, lane), bi_ps = ap_chain64(cb, live ? bi : 0.0, c1, pw1, cnt, lane);
+            const double bq_ps = ap_chain64(cc, live ? bq_d : 0.0, c0, pw0, cnt, lane), aq_ps = ap_chain64(cd, live ? aq : 0.0, c1, pw1, cnt, lane);
+            audio = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
         }
         if (levelfade) {
             // dc_i = mtauR dc_{i-1} + onem_mtauR audio_i ; dc_insert_i likewise on corr0 ; audio += dc_insert - dc
@@ -163,7 +202,7 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
         sp->phs = L.pt * kTwoPiRef; sp->fil_out = L.fil_out; sp->omega = L.omega; fade[ch].dc = dc; fade[ch].dc_insert = dc_insert;
         sp->dsI = dsI; sp->dsQ = dsQ;
     }
-    if (lane < 24) { sp->a[lane] = fa[lane]; sp->b[lane] = fb[lane]; sp->c[lane] = fc[lane]; sp->d[lane] = fd[lane]; }
+    if (lane == 0 && sbmode != 0) { ap_store(ca, sp->a); ap_store(cb, sp->b); ap_store(cc, sp->c); ap_store(cd, sp->d); }
 }
 
 // ------------------------------------------------------------------------------------------------ CTCSS notch
