@@ -250,6 +250,11 @@ struct Engine {
     double2 *agc_halo = nullptr, *agc_tail = nullptr;
     long long agc_arr = 0, agc_ends_cap = 0, agc_halo_cap = 0;
     int *agc_nfixed = nullptr;
+    // SAM sideband modes over time segments (qh_tiled.hpp, sam_sb_*): the chains' transition matrices for the two segment lengths of
+    // the current call shape, the segments' zero-state end states and their start states
+    double *sb_phi = nullptr, *sb_sum = nullptr, *sb_start = nullptr;
+    long long sb_phi_key = -1;
+    int set_sb_phi(long long n, int S);
     int pll_check_only = 0;                 // diagnostics (qh_rxa_debug_pll): count unconverged tiles without re-running them
     int agc_form = 0;                       // diagnostics (qh_rxa_debug_agc): 1 = the sample-by-sample form of the wcpAGC loop
     SamChanParam *sam_prm = nullptr;
@@ -324,6 +329,7 @@ Engine::~Engine()
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
+    (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
     (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
@@ -1541,6 +1547,68 @@ int Engine::process(const double *d_in, long long in_stride, double *d_out, long
     return QH_OK;
 }
 
+// The chains' transition over a segment: the one-sample map of the 17 words (ds, x_j[n-1], x_j[n-2]; input 0) raised to the segment's
+// length, for the two lengths a call of n samples in S segments has (q and q + 1 batches of 64), chains a / c (coefficients c0, input
+// one sample late through ds) and b / d (c1).  Long double on the host; kept until the call shape changes.
+int Engine::set_sb_phi(long long n, int S)
+{
+    const long long key = n * 1024 + S;
+    if (key == sb_phi_key) return QH_OK;
+    static const long double c0[7] = { -0.328201924180698L, -0.744171491539427L, -0.923022915444215L, -0.978490468768238L,
+                                       -0.994128272402075L, -0.998458978159551L, -0.999790306259206L };
+    static const long double c1[7] = { -0.0991227952747244L, -0.565619728761389L, -0.857467122550052L, -0.959123933111275L,
+                                       -0.988739372718090L, -0.996959189310611L, -0.999282492800792L };
+    constexpr int W = 17;
+    typedef std::vector<long double> Mat;
+    auto mul = [&](const Mat &a, const Mat &b) {
+        Mat r((size_t)W * W, 0.0L);
+        for (int i = 0; i < W; i++)
+            for (int k = 0; k < W; k++) {
+                const long double v = a[(size_t)i * W + k];
+                if (v != 0.0L) for (int j = 0; j < W; j++) r[(size_t)i * W + j] += v * b[(size_t)k * W + j];
+            }
+        return r;
+    };
+    auto one_step = [&](const long double *c, bool delayed) {
+        Mat m((size_t)W * W, 0.0L);
+        for (int col = 0; col < W; col++) {
+            long double v[W] = { 0 }, x[8];
+            v[col] = 1.0L;
+            x[0] = delayed ? v[0] : 0.0L;                               // the chain's input: ds (a, c) or the external input, 0 here
+            for (int j = 0; j < 7; j++) x[j + 1] = c[j] * (x[j] - v[2 + 2 * (j + 1)]) + v[2 + 2 * j];       // amd.c:172-175
+            long double nv[W];
+            nv[0] = 0.0L;
+            for (int j = 0; j < 8; j++) { nv[1 + 2 * j] = x[j]; nv[2 + 2 * j] = v[1 + 2 * j]; }
+            for (int r = 0; r < W; r++) m[(size_t)r * W + col] = nv[r];
+        }
+        return m;
+    };
+    auto power = [&](Mat b, long long e) {
+        Mat r((size_t)W * W, 0.0L);
+        for (int i = 0; i < W; i++) r[(size_t)i * W + i] = 1.0L;
+        while (e > 0) { if (e & 1) r = mul(b, r); b = mul(b, b); e >>= 1; }
+        return r;
+    };
+    const long long q = ((n + 63) / 64) / S;
+    std::vector<double> h((size_t)2 * 2 * W * W);
+    for (int li = 0; li < 2; li++)
+        for (int set = 0; set < 2; set++) {
+            const Mat p = power(one_step(set ? c1 : c0, set == 0), 64 * (q + li));
+            for (int i = 0; i < W * W; i++) h[((size_t)li * 2 + set) * W * W + i] = (double)p[(size_t)i];
+        }
+    if (!sb_phi) {
+        QH_HIP(dev_alloc(&sb_phi, h.size()));
+        QH_HIP(dev_alloc(&sb_sum, (size_t)nch * kSegWaves * kSegMaxGroups * kSbSum));
+        QH_HIP(dev_alloc(&sb_start, (size_t)nch * kSegWaves * kSegMaxGroups * kSbSum));
+    }
+    QH_HIP(hipStreamSynchronize(stream));
+    if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
+    drop_graphs(); epoch++;
+    QH_HIP(hipMemcpy(sb_phi, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    sb_phi_key = key;
+    return QH_OK;
+}
+
 int Engine::process_chain(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
 {
     if (nblk <= 0) return QH_OK;
@@ -1786,7 +1854,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         // then the mix with the phase each sample saw and the fade leveller over time segments (qh_tiled.hpp).  The channels'
         // rows of `other` are free here: first half = angles, second half = phases.  Short calls and the all-pass modes
         // (SAM-L / SAM-U) take the sequential kernel.
-        const int nt = n_mid >= kSamTiledMin ? n_sam0 : 0;
+        // (the channels with a sideband selected follow the others in list_sam: the loop is the same, the chains come behind it)
+        const int nt = n_mid >= kSamTiledMin ? n_sam : 0, nt0 = nt ? n_sam0 : 0, ntsb = nt - nt0;
         if (nt) {
             double *theta = reinterpret_cast<double *>(other), *pts = theta + buf_cap;
             const long long per = (n_mid + NT - 1) / NT;
@@ -1808,17 +1877,33 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             hipLaunchKernelGGL((pll_verify_kernel<true>), dim3((unsigned)nt), dim3(64), 0, am_stream, (const double *)theta, 2 * buf_cap, pts,
                                2 * buf_cap, (int)n_mid, list_sam, pll_state, pll_ends, pll_ends_cap * kPllEndsW, sam_pll_prm, kSamTile, kSamWarm,
                                pll_nfixed, pll_check_only);
-            {
+            if (nt0) {
                 const int G = seg_groups(n_am + nt);
                 double *gs = seg_sum[0] + (size_t)n_am * kSegWaves * kSegMaxGroups * kSegSumW;       // behind the AM channels' rows
                 if (G > 1) {
-                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 1>), dim3((unsigned)nt, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
+                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 1>), dim3((unsigned)nt0, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
                                        buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs);
-                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 2>), dim3((unsigned)nt, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
+                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 2>), dim3((unsigned)nt0, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
                                        buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs);
                 } else
-                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 0>), dim3((unsigned)nt), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
+                    hipLaunchKernelGGL((am_detect_tiled_kernel<true, 0>), dim3((unsigned)nt0), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
                                        (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, (double *)nullptr);
+            }
+            if (ntsb) {
+                const int G = seg_groups(n_am + nt), S = kSegWaves * G;
+                if (int rc = set_sb_phi(n_mid, S)) return rc;
+                const int *lst = list_sam + nt0;
+                double *gs = seg_sum[0] + (size_t)(n_am + nt0) * kSegWaves * kSegMaxGroups * kSegSumW;
+                hipLaunchKernelGGL((sam_sb_tiled_kernel<1>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                                   lst, (const SamChanParam *)sam_prm, (const double *)pts, 2 * buf_cap, pll_state, sb_sum, (const double *)sb_start);
+                hipLaunchKernelGGL(sam_sb_chain_kernel, dim3((unsigned)ntsb), dim3(64), 0, am_stream, (int)n_mid, S, lst, (const PllState *)pll_state,
+                                   (const double *)sb_phi, (const double *)sb_sum, sb_start);
+                hipLaunchKernelGGL((sam_sb_tiled_kernel<2>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                                   lst, (const SamChanParam *)sam_prm, (const double *)pts, 2 * buf_cap, pll_state, sb_sum, (const double *)sb_start);
+                hipLaunchKernelGGL((sam_level_tiled_kernel<1>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                                   lst, levelfade, am_state, am_prm, gs);
+                hipLaunchKernelGGL((sam_level_tiled_kernel<2>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                                   lst, levelfade, am_state, am_prm, gs);
             }
         }
         if (n_sam - nt) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)(n_sam - nt)), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,

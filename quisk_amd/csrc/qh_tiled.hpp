@@ -182,6 +182,197 @@ static __global__ __launch_bounds__(kSegThreads) void am_level_tiled_kernel(cons
     if (lf && is_last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
 }
 
+// ---- SAM with sideband selection (amd.c:150-208) over time segments ---------------------------------------------------------------
+// Behind the time-tiled loop (pll_lanes_kernel<true>: the phase every sample saw) the four all-pass chains are linear and time
+// invariant, with poles up to 0.9999 (no warm-up reaches that far).  Two passes over 16 G time segments per channel:
+//   sam_sb_tiled_kernel<1>  every segment's chains from a ZERO state: the end state z_w, 4 chains x 17 words
+//                           (ds, then x_j[n-1], x_j[n-2] for j = 0 .. 7: ap_chain64's state with the one-sample delay of chains a, c)
+//   sam_sb_chain_kernel     start state of segment w: s_w = Phi(len_{w-1}) s_{w-1} + z_{w-1}, Phi = the chains' 17 x 17 transition
+//                           over a segment of that length (two lengths occur; the host raises the one-sample matrix to the power)
+//   sam_sb_tiled_kernel<2>  the chains again from the true start states; writes (audio, corr0): the fade leveller follows
+//   sam_level_tiled_kernel  amd.c:211-216 with dc on audio and dc_insert on corr0 (two-pass segment scan as for AM)
+constexpr int kSbW = 17, kSbSum = 4 * kSbW;         // words per chain, per segment summary
+struct SbBatch { ApChain c[4]; double ds[2]; };
+__device__ __forceinline__ void sb_zero(SbBatch &b)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { b.c[k].x1[j] = 0.0; b.c[k].x2[j] = 0.0; }
+    b.ds[0] = b.ds[1] = 0.0;
+}
+// word r of chain k: 0 = ds (chains 0 and 2: dsI, dsQ; unused in 1 and 3), 1 + 2 j = x_j[n-1], 2 + 2 j = x_j[n-2]
+__device__ __forceinline__ void sb_store(const SbBatch &b, double *w)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        w[k * kSbW] = k == 0 ? b.ds[0] : k == 2 ? b.ds[1] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { w[k * kSbW + 1 + 2 * j] = b.c[k].x1[j]; w[k * kSbW + 2 + 2 * j] = b.c[k].x2[j]; }
+    }
+}
+__device__ __forceinline__ void sb_load(SbBatch &b, const double *w)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { b.c[k].x1[j] = w[k * kSbW + 1 + 2 * j]; b.c[k].x2[j] = w[k * kSbW + 2 + 2 * j]; }
+    b.ds[0] = w[0]; b.ds[1] = w[2 * kSbW];
+}
+
+template <int MODE>
+static __global__ __launch_bounds__(kSegThreads) void sam_sb_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                                          const SamChanParam *cprm, const double *pt, long long ptstride,
+                                                                          PllState *state, double *sums, const double *starts)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
+    double2 *p = buf + (long long)ch * stride;
+    const double *ph = pt + (long long)ch * ptstride;
+    const int sbmode = cprm[ch].sbmode;
+    int b0, b1;
+    seg_range(n, sidx, b0, b1, S);
+    const double *c0 = kSamC0, *c1 = kSamC1;
+    double pw0[7], pw1[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { pw0[j] = ipow_d(-c0[j], lane / 2 + 1); pw1[j] = ipow_d(-c1[j], lane / 2 + 1); }
+    SbBatch B;
+    if constexpr (MODE == 1) sb_zero(B);
+    else sb_load(B, starts + ((long long)slot * S + sidx) * kSbSum);
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, cnt = n - base < 64 ? n - base : 64, i = base + lane;
+        const bool live = lane < cnt;
+        double2 z = make_double2(0.0, 0.0);
+        double phs = 0.0;
+        if (live) { z = p[i]; phs = ph[i]; }
+        double sn, cs;
+        sincos(phs * kTwoPiRef, &sn, &cs);
+        const double ai = z.x * cs, bi = z.x * sn, aq = z.y * cs, bq = z.y * sn;
+        double ai_d = wave_shr1(ai), bq_d = wave_shr1(bq);
+        if (lane == 0) { ai_d = B.ds[0]; bq_d = B.ds[1]; }
+        B.ds[0] = lane_bcast(ai, cnt - 1); B.ds[1] = lane_bcast(bq, cnt - 1);
+        const double ai_ps = ap_chain64(B.c[0], live ? ai_d : 0.0, c0, pw0, cnt, lane), bi_ps = ap_chain64(B.c[1], live ? bi : 0.0, c1, pw1, cnt, lane);
+        const double bq_ps = ap_chain64(B.c[2], live ? bq_d : 0.0, c0, pw0, cnt, lane), aq_ps = ap_chain64(B.c[3], live ? aq : 0.0, c1, pw1, cnt, lane);
+        if constexpr (MODE == 2) {
+            const double audio = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
+            if (live) p[i] = make_double2(audio, ai + bq);
+        }
+    }
+    if constexpr (MODE == 1) {
+        if (lane == 0) sb_store(B, sums + ((long long)slot * S + sidx) * kSbSum);
+    } else {
+        int last = S - 1;
+        while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
+        if (sidx == last && lane == 0 && n > 0) {
+            PllState *sp = state + ch;
+            ap_store(B.c[0], sp->a); ap_store(B.c[1], sp->b); ap_store(B.c[2], sp->c); ap_store(B.c[3], sp->d);
+            sp->dsI = B.ds[0]; sp->dsQ = B.ds[1];
+        }
+    }
+}
+
+// phi: [2 lengths: q and q + 1 batches][2: chains a / c (coefficients c0, delayed input), chains b / d (c1)][17][17], row major
+static __global__ __launch_bounds__(64) void sam_sb_chain_kernel(int n, int S, const int *chan_list, const PllState *state, const double *phi,
+                                                                const double *sums, double *starts)
+{
+    __shared__ double sphi[2 * 2 * kSbW * kSbW];
+    const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x;
+    for (int i = lane; i < 2 * 2 * kSbW * kSbW; i += 64) sphi[i] = phi[i];
+    __syncthreads();
+    // lane r < 17 holds word r of the four chains' vectors
+    const PllState *sp = state + ch;
+    double v[4] = { 0.0, 0.0, 0.0, 0.0 };
+    if (lane < kSbW) {
+        const double *arr[4] = { sp->a, sp->b, sp->c, sp->d };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (lane == 0) v[k] = k == 0 ? sp->dsI : k == 2 ? sp->dsQ : 0.0;
+            else { const int j = (lane - 1) >> 1; v[k] = arr[k][3 * j + 1 + ((lane - 1) & 1)]; }
+        }
+    }
+    const int qb = ((n + 63) >> 6) / S;
+    SegWalk walk(n, S);
+    for (int w = 0; w < S; w++) {
+        if (lane < kSbW) {
+            double *o = starts + ((long long)slot * S + w) * kSbSum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k * kSbW + lane] = v[k];
+        }
+        const int nbw = walk.next();
+        if (nbw == 0) continue;
+        const double *P = sphi + (nbw == qb ? 0 : 1) * 2 * kSbW * kSbW;
+        const double *z = sums + ((long long)slot * S + w) * kSbSum;
+        double nv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nv[k] = lane < kSbW ? z[k * kSbW + lane] : 0.0;
+        for (int c = 0; c < kSbW; c++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double vk = lane_bcast(v[k], c);
+                if (lane < kSbW) nv[k] = __builtin_fma(P[(k & 1) * kSbW * kSbW + lane * kSbW + c], vk, nv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = nv[k];
+    }
+}
+
+// the fade leveller of the sideband modes: buf holds (audio, corr0); dc averages audio, dc_insert averages corr0 (amd.c:211-216)
+template <int MODE>
+static __global__ __launch_bounds__(kSegThreads) void sam_level_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                                             const int *levelfade, AmState *state, AmParam prm, double *gsum)
+{
+    const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
+    double *sum = gsum + (long long)slot * S * kSegSumW;
+    double2 *p = buf + (long long)ch * stride;
+    const bool lf = levelfade[ch] != 0;
+    int b0, b1;
+    seg_range(n, sidx, b0, b1, S);
+    const double m64R = lane_pow(prm.mtauR, 64), m64I = lane_pow(prm.mtauI, 64);
+    if constexpr (MODE == 1) {
+        if (!lf) return;
+        double accR = 0.0, accI = 0.0;
+        for (int b = b0; b < b1; b++) {
+            const int i = b * 64 + lane;
+            const double2 v = i < n ? p[i] : make_double2(0.0, 0.0);
+            accR = __builtin_fma(accR, m64R, prm.onem_mtauR * v.x);
+            accI = __builtin_fma(accI, m64I, prm.onem_mtauI * v.y);
+        }
+        const double eR = wave_sum_d(accR * lane_pow(prm.mtauR, 63 - lane)), eI = wave_sum_d(accI * lane_pow(prm.mtauI, 63 - lane));
+        if (lane == 0) { sum[sidx * kSegSumW] = eR; sum[sidx * kSegSumW + 1] = eI; }
+    } else {
+        double cR = state[ch].dc, cI = state[ch].dc_insert;
+        if (lf) {
+            const int q = ((n + 63) >> 6) / S;
+            const double tR0 = pow(m64R, (double)q), tI0 = pow(m64I, (double)q), tR1 = tR0 * m64R, tI1 = tI0 * m64I;
+            SegWalk walk(n, S);
+            for (int w = 0; w < sidx; w++) {
+                const int nbw = walk.next();
+                if (nbw == 0) continue;
+                cR = __builtin_fma(cR, nbw == q ? tR0 : tR1, sum[w * kSegSumW]);
+                cI = __builtin_fma(cI, nbw == q ? tI0 : tI1, sum[w * kSegSumW + 1]);
+            }
+        }
+        const PoleScan sR = make_pole_scan(prm.mtauR, lane), sI = make_pole_scan(prm.mtauI, lane);
+        for (int b = b0; b < b1; b++) {
+            const int base = b * 64, cnt = n - base < 64 ? n - base : 64, i = base + lane;
+            const double2 v = i < n ? p[i] : make_double2(0.0, 0.0);
+            double audio = v.x;
+            if (lf) {
+                const double dc = scan_pole_dpp(prm.onem_mtauR * v.x, sR) + sR.pw * cR;
+                const double di = scan_pole_dpp(prm.onem_mtauI * v.y, sI) + sI.pw * cI;
+                audio = v.x + (di - dc);
+                cR = lane_bcast(dc, cnt - 1); cI = lane_bcast(di, cnt - 1);
+            }
+            if (lane < cnt) p[i] = make_double2(audio, audio);
+        }
+        int last = S - 1;
+        while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
+        if (lf && sidx == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+    }
+}
+
 // ---- CTCSS notch (xsnotch, wdsp/iir.c:76-95): bi-quad on the I component, in place ------------------------------------
 // state vector (y_i, y_{i-1}) driven by (f_i, 0), f_i = a0 x_i + a1 x_{i-1} + a2 x_{i-2}; transition A = [[b1, b2], [1, 0]]
 __device__ __forceinline__ M2 m2_pow(M2 a, int e)

@@ -153,3 +153,41 @@ def test_sam_long_calls_are_time_tiled_and_equal_block_calls_and_the_oracle(qh, 
         settle = 160 * 256
         assert rel_rms(y[c][settle:], ref[settle:]) < 1e-6, c
         assert np.abs(ref[-4096:]).max() > 1e-2
+
+
+@pytest.mark.parametrize("sbmode", [1, 2], ids=["SAM-L", "SAM-U"])
+def test_sam_sideband_modes_over_time_segments(qh, oracle, sbmode):
+    """SAM with a sideband selected: behind the time-tiled loop the four all-pass chains (poles up to 0.9999: no warm-up reaches that
+    far) run over time segments -- zero-state end states, start states by the chains' transition matrices, the chains again from the
+    true states (qh_tiled.hpp, sam_sb_*).  Long calls equal block calls (which step the chains 64 samples at a time on one wavefront),
+    the state crosses between the two forms, and both follow the oracle."""
+    nacq, nlong = 160, 160
+    offs = (12.0, -35.0, 30.0)
+    x = np.stack([_sam_input(c, (nacq + 2 * nlong) * 1024, offs[c], 60 + c) for c in range(3)])
+
+    def make():
+        e = _engine(qh, 3, SAM)
+        for c in range(3):
+            e.SetRXAAMDSBMode(c, sbmode)
+        return e
+    ea, eb = make(), make()
+    for b in range(nacq):
+        blk = np.ascontiguousarray(x[:, b * 1024:(b + 1) * 1024])
+        assert np.array_equal(ea.process_host(blk), eb.process_host(blk))
+    long = np.concatenate([ea.process_host(np.ascontiguousarray(x[:, (nacq + k * nlong) * 1024:(nacq + (k + 1) * nlong) * 1024])) for k in range(2)], axis=1)
+    short = np.concatenate([eb.process_host(np.ascontiguousarray(x[:, b * 1024:(b + 1) * 1024])) for b in range(nacq, nacq + 2 * nlong)], axis=1)
+    assert np.abs(short).max() > 1e-2
+    assert rel_rms(long, short) < 1e-10, rel_rms(long, short)
+    # a long call, short calls, a long call: the chains' state goes from one form to the other and back
+    ec = make()
+    for c in range(3):
+        ec.SetRXAAMDFadeLevel(c, 0)
+    cuts = [0, nlong, nlong + 7, nlong + 8, 2 * nlong + 8, 3 * nlong]
+    y = np.concatenate([ec.process_host(np.ascontiguousarray(x[:, a * 1024:b * 1024])) for a, b in zip(cuts[:-1], cuts[1:])], axis=1)
+    for c in range(3):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(SAM); o.SetRXAAMDSBMode(sbmode)
+        o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0); o.RXASetPassband(-4000.0, 4000.0); o.SetRXAAMDFadeLevel(0)
+        ref = o.xrxa(x[c])
+        settle = 320 * 256                  # the chains remember the acquisition (poles up to 0.9999): compared once that has gone
+        assert rel_rms(y[c][settle:], ref[settle:]) < 1e-6, (c, rel_rms(y[c][settle:], ref[settle:]))
