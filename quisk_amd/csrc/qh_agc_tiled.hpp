@@ -197,8 +197,8 @@ static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const
 //   v_j = (1 - m)^(j - p + 1) v + sum_{i = p .. j} m r_i (1 - m)^(j - i),
 // a ballot finds the first sample at which the regime's own condition (on v_{j-1}) fails, everything ahead of it is accepted at once,
 // and that sample is one reference step (agc_lane_step).  tab[w][k] = (1 - mult_w)^k for the attack, decay and hang-decay multipliers.
-__device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double h, int cnt, int lane, const AgcParam &q, const PoleScan *ps,
-                                          const double (*tab)[65])
+__device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double h, int cnt, int lane, const AgcParam &q, const PoleScan &ps0,
+                                          const PoleScan &ps1, const PoleScan &ps2, const double (*tab)[65])
 {
     int p = 0;
     while (p < cnt) {
@@ -211,7 +211,12 @@ __device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double
         if (w >= 0 && w < 3) {
             const double m = w == 0 ? q.attack_mult : w == 1 ? q.decay_mult : q.hang_decay_mult;
             const bool in = lane >= p && lane < cnt;
-            const double sc = scan_pole_dpp(in ? m * r : 0.0, ps[w]);
+            // (field by field: an index or a select between the structs themselves would be a select of addresses, i.e. scratch memory)
+            PoleScan pq;
+#define QH_SEL3(f) pq.f = w == 0 ? ps0.f : w == 1 ? ps1.f : ps2.f
+            QH_SEL3(m1); QH_SEL3(m2); QH_SEL3(m4); QH_SEL3(m8); QH_SEL3(pa); QH_SEL3(pb); QH_SEL3(pw);
+#undef QH_SEL3
+            const double sc = scan_pole_dpp(in ? m * r : 0.0, pq);
             const double v = __builtin_fma(tab[w][in ? lane - p + 1 : 0], s.volts, sc);
             double vb = wave_shr1(v);
             if (lane == p) vb = s.volts;
@@ -247,8 +252,8 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
         if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = 1.0;
         __syncthreads();
     }
-    const PoleScan ps[3] = { make_pole_scan(1.0 - q.attack_mult, lane), make_pole_scan(1.0 - q.decay_mult, lane),
-                             make_pole_scan(1.0 - q.hang_decay_mult, lane) };
+    const PoleScan ps0 = make_pole_scan(1.0 - q.attack_mult, lane), ps1 = make_pole_scan(1.0 - q.decay_mult, lane),
+                   ps2 = make_pole_scan(1.0 - q.hang_decay_mult, lane);
     double rn = 0.0, fn = 0.0, hn = 0.0;
     if (lane < n) { rn = in0[lane]; fn = in1[lane]; hn = in2[lane]; }
     for (int base = 0; base < n; base += 64) {
@@ -259,7 +264,7 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
         }
         const double r = rn, f = fn, h = hn;
         if (base + 64 + lane < n) { rn = in0[base + 64 + lane]; fn = in1[base + 64 + lane]; hn = in2[base + 64 + lane]; }     // the next chunk is on its way
-        agc_chunk(s, r, f, h, cnt, lane, q, ps, tab);
+        agc_chunk(s, r, f, h, cnt, lane, q, ps0, ps1, ps2, tab);
     }
 }
 

@@ -134,6 +134,32 @@ __device__ __forceinline__ double ap_chain64(ApChain &s, double x, const double 
     return x;
 }
 
+// The same for FULL batches with the samples dealt to the two halves of the wavefront -- lane k < 32 holds sample 2 k, lane 32 + k
+// sample 2 k + 1 -- so that the recurrences' lag of two samples is a lag of one lane inside a half: Kogge-Stone by DPP row shifts
+// and one row broadcast per half (scan_pole_dpp without its last step), no LDS crossbar at all (the shuffles of ap_chain64 are 336
+// ds_bpermute per batch of the four chains and bound it).  pa[j] = (-c_j)^((lane & 15) + 1), pw[j] = (-c_j)^((lane & 31) + 1).
+__device__ __forceinline__ double ap_chain64s(ApChain &s, double x, const double *c, const double (&pa)[7], const double (&pw)[7], int lane)
+{
+    const bool first = (lane & 31) == 0, odd = lane >= 32;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        double xs = wave_shr1(x);                               // x[n-2]: the element before it in its half
+        if (first) xs = odd ? s.x1[j] : s.x2[j];
+        const double cj = c[j], p1 = -cj, p2 = p1 * p1, p4 = p2 * p2, p8 = p4 * p4;
+        double y = __builtin_fma(cj, x, xs);
+        y = __builtin_fma(p1, dpp_fetch_d<0x111, 0xf>(y), y);
+        y = __builtin_fma(p2, dpp_fetch_d<0x112, 0xf>(y), y);
+        y = __builtin_fma(p4, dpp_fetch_d<0x114, 0xf>(y), y);
+        y = __builtin_fma(p8, dpp_fetch_d<0x118, 0xf>(y), y);
+        y = __builtin_fma(pa[j], dpp_fetch_d<0x142, 0xa>(y), y);        // lane 15 of rows 0 and 2 into rows 1 and 3
+        y = __builtin_fma(pw[j], odd ? s.x1[j + 1] : s.x2[j + 1], y);
+        s.x1[j] = lane_bcast(x, 63); s.x2[j] = lane_bcast(x, 31);
+        x = y;
+    }
+    s.x1[7] = lane_bcast(x, 63); s.x2[7] = lane_bcast(x, 31);
+    return x;
+}
+
 // Synchronous AM: in place.
 static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                      PllState *state, const SamChanParam *cprm, PllParam q, AmState *fade)

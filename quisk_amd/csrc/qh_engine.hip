@@ -1894,11 +1894,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 if (int rc = set_sb_phi(n_mid, S)) return rc;
                 const int *lst = list_sam + nt0;
                 double *gs = seg_sum[0] + (size_t)(n_am + nt0) * kSegWaves * kSegMaxGroups * kSegSumW;
-                hipLaunchKernelGGL((sam_sb_tiled_kernel<1>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                hipLaunchKernelGGL((sam_sb_tiled_kernel<1>), dim3((unsigned)ntsb, (unsigned)(S / kSbWaves)), dim3(64 * kSbWaves), 0, am_stream, cur, buf_cap, (int)n_mid,
                                    lst, (const SamChanParam *)sam_prm, (const double *)pts, 2 * buf_cap, pll_state, sb_sum, (const double *)sb_start);
                 hipLaunchKernelGGL(sam_sb_chain_kernel, dim3((unsigned)ntsb), dim3(64), 0, am_stream, (int)n_mid, S, lst, (const PllState *)pll_state,
                                    (const double *)sb_phi, (const double *)sb_sum, sb_start);
-                hipLaunchKernelGGL((sam_sb_tiled_kernel<2>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
+                hipLaunchKernelGGL((sam_sb_tiled_kernel<2>), dim3((unsigned)ntsb, (unsigned)(S / kSbWaves)), dim3(64 * kSbWaves), 0, am_stream, cur, buf_cap, (int)n_mid,
                                    lst, (const SamChanParam *)sam_prm, (const double *)pts, 2 * buf_cap, pll_state, sb_sum, (const double *)sb_start);
                 hipLaunchKernelGGL((sam_level_tiled_kernel<1>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
                                    lst, levelfade, am_state, am_prm, gs);

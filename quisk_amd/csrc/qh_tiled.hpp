@@ -220,42 +220,49 @@ __device__ __forceinline__ void sb_load(SbBatch &b, const double *w)
     b.ds[0] = w[0]; b.ds[1] = w[2 * kSbW];
 }
 
+// (workgroups of four wavefronts = four segments, 4 G workgroups per channel: the four chains' 64 state words and the 28 per-lane
+// powers want ~220 registers, which a 16-wavefront workgroup does not have)
+constexpr int kSbWaves = 4;
 template <int MODE>
-static __global__ __launch_bounds__(kSegThreads) void sam_sb_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                                          const SamChanParam *cprm, const double *pt, long long ptstride,
-                                                                          PllState *state, double *sums, const double *starts)
+static __global__ __launch_bounds__(64 * kSbWaves, 2) void sam_sb_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
+                                                                               const SamChanParam *cprm, const double *pt, long long ptstride,
+                                                                               PllState *state, double *sums, const double *starts)
 {
     const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
+    const int S = kSbWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSbWaves + wave;
     double2 *p = buf + (long long)ch * stride;
     const double *ph = pt + (long long)ch * ptstride;
     const int sbmode = cprm[ch].sbmode;
     int b0, b1;
     seg_range(n, sidx, b0, b1, S);
     const double *c0 = kSamC0, *c1 = kSamC1;
-    double pw0[7], pw1[7];
+    // (whole batches only: n is a multiple of 64 here; the samples dealt to the halves of the wavefront, see ap_chain64s)
+    double pa0[7], pa1[7], pw0[7], pw1[7];
 #pragma unroll
-    for (int j = 0; j < 7; j++) { pw0[j] = ipow_d(-c0[j], lane / 2 + 1); pw1[j] = ipow_d(-c1[j], lane / 2 + 1); }
+    for (int j = 0; j < 7; j++) {
+        pa0[j] = ipow_d(-c0[j], (lane & 15) + 1); pa1[j] = ipow_d(-c1[j], (lane & 15) + 1);
+        pw0[j] = ipow_d(-c0[j], (lane & 31) + 1); pw1[j] = ipow_d(-c1[j], (lane & 31) + 1);
+    }
+    const int sl = 2 * (lane & 31) + (lane >> 5);           // this lane's sample inside a batch
     SbBatch B;
     if constexpr (MODE == 1) sb_zero(B);
     else sb_load(B, starts + ((long long)slot * S + sidx) * kSbSum);
     for (int b = b0; b < b1; b++) {
-        const int base = b * 64, cnt = n - base < 64 ? n - base : 64, i = base + lane;
-        const bool live = lane < cnt;
-        double2 z = make_double2(0.0, 0.0);
-        double phs = 0.0;
-        if (live) { z = p[i]; phs = ph[i]; }
+        const int i = b * 64 + sl;
+        const double2 z = p[i];
         double sn, cs;
-        sincos(phs * kTwoPiRef, &sn, &cs);
+        sincos(ph[i] * kTwoPiRef, &sn, &cs);
         const double ai = z.x * cs, bi = z.x * sn, aq = z.y * cs, bq = z.y * sn;
-        double ai_d = wave_shr1(ai), bq_d = wave_shr1(bq);
+        // one sample late: sample 2 k takes sample 2 k - 1 (lane 31 + k; the first: the carried one), sample 2 k + 1 takes sample 2 k (lane k)
+        const int from = lane < 32 ? lane + 31 : lane - 32;
+        double ai_d = __shfl(ai, from, 64), bq_d = __shfl(bq, from, 64);
         if (lane == 0) { ai_d = B.ds[0]; bq_d = B.ds[1]; }
-        B.ds[0] = lane_bcast(ai, cnt - 1); B.ds[1] = lane_bcast(bq, cnt - 1);
-        const double ai_ps = ap_chain64(B.c[0], live ? ai_d : 0.0, c0, pw0, cnt, lane), bi_ps = ap_chain64(B.c[1], live ? bi : 0.0, c1, pw1, cnt, lane);
-        const double bq_ps = ap_chain64(B.c[2], live ? bq_d : 0.0, c0, pw0, cnt, lane), aq_ps = ap_chain64(B.c[3], live ? aq : 0.0, c1, pw1, cnt, lane);
+        B.ds[0] = lane_bcast(ai, 63); B.ds[1] = lane_bcast(bq, 63);
+        const double ai_ps = ap_chain64s(B.c[0], ai_d, c0, pa0, pw0, lane), bi_ps = ap_chain64s(B.c[1], bi, c1, pa1, pw1, lane);
+        const double bq_ps = ap_chain64s(B.c[2], bq_d, c0, pa0, pw0, lane), aq_ps = ap_chain64s(B.c[3], aq, c1, pa1, pw1, lane);
         if constexpr (MODE == 2) {
             const double audio = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
-            if (live) p[i] = make_double2(audio, ai + bq);
+            p[i] = make_double2(audio, ai + bq);
         }
     }
     if constexpr (MODE == 1) {
