@@ -177,9 +177,13 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
     double dsI = sp->dsI, dsQ = sp->dsQ;
     ApChain ca, cb, cc, cd;
     ap_load(ca, sp->a); ap_load(cb, sp->b); ap_load(cc, sp->c); ap_load(cd, sp->d);
-    double pw0[7], pw1[7];
+    double pw0[7], pw1[7], pa0[7], pa1[7], ps0[7], ps1[7];      // powers for the shuffle form and for the DPP form (ap_chain64s)
 #pragma unroll
-    for (int j = 0; j < 7; j++) { pw0[j] = ipow_d(-c0[j], lane / 2 + 1); pw1[j] = ipow_d(-c1[j], lane / 2 + 1); }
+    for (int j = 0; j < 7; j++) {
+        pw0[j] = ipow_d(-c0[j], lane / 2 + 1); pw1[j] = ipow_d(-c1[j], lane / 2 + 1);
+        pa0[j] = ipow_d(-c0[j], (lane & 15) + 1); pa1[j] = ipow_d(-c1[j], (lane & 15) + 1);
+        ps0[j] = ipow_d(-c0[j], (lane & 31) + 1); ps1[j] = ipow_d(-c1[j], (lane & 31) + 1);
+    }
     // Same split as in fm_pll_kernel: det = atan2(corr1, corr0) (amd.c:222-223) is arg(z) - phs, so the sequential
     // part only carries the loop filter; each lane then forms the VCO products of ITS sample from the phase the
     // loop had at that sample.  The fade leveler (two one-pole averages, amd.c:211-216) is solved by scans; only
@@ -208,9 +212,18 @@ static __global__ __launch_bounds__(64) void sam_pll_kernel(double2 *buf, long l
             double ai_d = wave_shr1(ai), bq_d = wave_shr1(bq);
             if (lane == 0) { ai_d = dsI; bq_d = dsQ; }
             dsI = lane_bcast(ai, cnt - 1); dsQ = lane_bcast(bq, cnt - 1);
-            const double ai_ps = ap_chain64(ca, live ? ai_d : 0.0, c0, pw0, cnt, lane), bi_ps = ap_chain64(cb, live ? bi : 0.0, c1, pw1, cnt, lane);
-            const double bq_ps = ap_chain64(cc, live ? bq_d : 0.0, c0, pw0, cnt, lane), aq_ps = ap_chain64(cd, live ? aq : 0.0, c1, pw1, cnt, lane);
-            audio = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
+            if (cnt == 64) {
+                // full batch: deal the samples to the halves of the wavefront (lane k: sample 2 k, lane 32 + k: sample 2 k + 1), run the
+                // chains by DPP scans (ap_chain64s), bring the result back
+                const int src = 2 * (lane & 31) + (lane >> 5), back = (lane >> 1) + 32 * (lane & 1);
+                const double ai_ps = ap_chain64s(ca, __shfl(ai_d, src, 64), c0, pa0, ps0, lane), bi_ps = ap_chain64s(cb, __shfl(bi, src, 64), c1, pa1, ps1, lane);
+                const double bq_ps = ap_chain64s(cc, __shfl(bq_d, src, 64), c0, pa0, ps0, lane), aq_ps = ap_chain64s(cd, __shfl(aq, src, 64), c1, pa1, ps1, lane);
+                audio = __shfl(sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps), back, 64);
+            } else {
+                const double ai_ps = ap_chain64(ca, live ? ai_d : 0.0, c0, pw0, cnt, lane), bi_ps = ap_chain64(cb, live ? bi : 0.0, c1, pw1, cnt, lane);
+                const double bq_ps = ap_chain64(cc, live ? bq_d : 0.0, c0, pw0, cnt, lane), aq_ps = ap_chain64(cd, live ? aq : 0.0, c1, pw1, cnt, lane);
+                audio = sbmode == 1 ? (ai_ps - bi_ps) + (aq_ps + bq_ps) : (ai_ps + bi_ps) - (aq_ps - bq_ps);
+            }
         }
         if (levelfade) {
             // dc_i = mtauR dc_{i-1} + onem_mtauR audio_i ; dc_insert_i likewise on corr0 ; audio += dc_insert - dc
