@@ -129,3 +129,27 @@ def test_attack_window_changes_and_odd_lengths(qh, oracle):
     for c in range(nch):
         ref = _oracle_run(oracle, c, 3, x[c, :20 * 1024])
         assert rel_rms(outs[2][c][:20 * 256], ref) < 1e-9, c
+
+
+def test_time_tiles_replayed_from_a_graph(qh):
+    """The launch sequence of a long call with the AGC tiles (nine kernels per list) replayed from a hipGraph: the same samples."""
+    nch, nblk = 3, 80
+    x = _input(nch, 4 * nblk, seed=31)
+    outs = []
+    for replay in (False, True):
+        e = _engine(qh, nch, [3, 2], 0)
+        e.set_graph_replay(replay)
+        import torch
+        d = torch.from_numpy(np.ascontiguousarray(x).view(np.float64).copy()).cuda()
+        o = torch.empty((nch, 4 * nblk * 256 * 2), dtype=torch.float64, device="cuda")
+        ys = []
+        for k in range(4):      # the same buffers every call (what a captured sequence needs), new samples copied in
+            seg = torch.from_numpy(np.ascontiguousarray(x[:, k * nblk * 1024:(k + 1) * nblk * 1024]).view(np.float64).copy()).cuda()
+            d[:, :nblk * 2048] = seg
+            e.process_ptr(d.data_ptr(), 4 * nblk * 1024, o.data_ptr(), 4 * nblk * 256, nblk)
+            e.synchronize()
+            ys.append(o[:, :nblk * 512].cpu().numpy().view(np.complex128).copy())
+        outs.append(np.concatenate(ys, axis=1))
+        if replay:
+            assert e.graph_launches() > 0
+    assert np.array_equal(outs[0], outs[1])
