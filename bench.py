@@ -187,6 +187,8 @@ def other_configs(torch, dev):
     # config 4: the call's launch sequence replayed from a hipGraph (qh_rxa_set_graph_replay), the engine's mode for repeated calls
     leg("config4", bc.config4, 20.0, "ms_graph_replay", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
     leg("config5", bc.config5, 8.0, "fused_ms", lambda r: ("hb45_cascade_kernel<float,8>", r["fused_cascade_only_ms"]))
+    # the headline chain with WDSP's AGC state machine on (not a BASELINE configuration: config 2 fixes the gain)
+    leg("config2_agc_on", bc.config2_agc, 20.0, "ms", lambda r: ("agc_bounds_kernel (the level detector's state at the tile boundaries)", None))
     try:
         r = bc.quisk_native(torch, qh, dev)
         out["quisk_native"] = {"workload": r["config"], "samples_per_step": r["samples_per_step"], "algorithmic_bytes_per_sample": 20.0,

@@ -205,7 +205,8 @@ __device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double
         const double rp = lane_bcast(r, p);
         const bool up = rp >= s.volts;
         // (a decay that sits on the min_volts clamp holds there while ring_max stays below it: silence)
-        const bool floor = (s.st == 3 || s.st == 4) && !up && s.volts <= q.min_volts;
+        // (state 1 holds there too while volts stays above save_volts: the fast decay of silence)
+        const bool floor = !up && s.volts <= q.min_volts && (s.st == 3 || s.st == 4 || (s.st == 1 && s.volts > s.save_volts));
         const int w = floor ? 4 : (s.st == 0 && up) ? 0 : (s.st == 3 && !up) ? 1 : (s.st == 4 && !up) ? 2 : (s.st == 2 && !up && s.hc > 1) ? 3 : -1;
         int k = p;                                              // first sample the regime does not cover
         if (w >= 0 && w < 3) {
@@ -220,7 +221,7 @@ __device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double
             const double v = __builtin_fma(tab[w][in ? lane - p + 1 : 0], s.volts, sc);
             double vb = wave_shr1(v);
             if (lane == p) vb = s.volts;
-            const bool ok = w == 0 ? r >= vb : (r < vb && v >= q.min_volts);
+            const bool ok = (w == 0 ? r >= vb : r < vb) && v >= q.min_volts;      // (the clamp is a turn: the reference applies it after every step)
             const unsigned long long bad = __ballot(in && !ok);
             k = bad ? __ffsll((long long)bad) - 1 : cnt;
             if (k > p) s.volts = lane_bcast(v, k - 1);
@@ -348,7 +349,7 @@ __device__ __forceinline__ bool agc_state_differs(const double *a, const double 
 // its successor is judged against.  fin[slot][0..4] = the state after the call's last sample.
 static __global__ __launch_bounds__(64) void agc_verify_kernel(int n, const int *chan_list, const AgcParam *prm, double *scr, long long arr,
                                                               const double *bounds, long long bstride, double *ends, long long estride, int L,
-                                                              double *fin, int *nfixed)
+                                                              double *fin, int *nfixed, int check_only)
 {
     const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x;
     const AgcParam q = prm[ch];
@@ -361,6 +362,7 @@ static __global__ __launch_bounds__(64) void agc_verify_kernel(int n, const int 
     for (int t = 1; t < ntiles; t++) {
         const double *a = bd + (long long)t * 8, *b = e + (long long)(t - 1) * 8;
         if (!agc_state_differs(a, b)) continue;                 // (uniform: every lane reads the same words)
+        if (check_only) { fixed++; continue; }                  // diagnostics: count, leave everything as it is
         AgcLane s{ b[0], b[1], (int)b[2], (int)b[3], (int)b[4] };
         const long long s0 = (long long)t * L;
         const int len = (int)((long long)n - s0 < L ? (long long)n - s0 : L);

@@ -2016,7 +2016,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (n_agc_cur || n_agc_other) {
         // Long calls: the level detector in time tiles, everything around it lane-parallel (qh_agc_tiled.hpp).  Short calls (the drop-in's
         // blocks), a channel whose attack window moved in mid-stream, and the diagnostic forms: one wavefront per channel.
-        bool tiled = agc_form == 0 && n_mid >= kAgcTiledMin;
+        bool tiled = (agc_form == 0 || agc_form == 3) && n_mid >= kAgcTiledMin;      // (3: diagnostics, the tiles' check counts and repairs nothing)
         int a_max = 0;
         for (int ch = 0; ch < nch && tiled; ch++) {
             ChanCfg &c = cfg[(size_t)ch];
@@ -2081,7 +2081,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL(agc_lanes_kernel, dim3((unsigned)ngroups, (unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
                                    agc_scr, agc_arr, (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L);
                 hipLaunchKernelGGL(agc_verify_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_scr, agc_arr,
-                                   (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L, agc_fin, agc_nfixed);
+                                   (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L, agc_fin, agc_nfixed, agc_form == 3 ? 1 : 0);
                 hipLaunchKernelGGL(agc_tail_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, (const double2 *)b, buf_cap, n, lst,
                                    (const AgcParam *)agc_prm, agc_tail, 1.0);
                 hipLaunchKernelGGL(agc_apply_kernel, dim3((unsigned)ntile, (unsigned)cnt), dim3(256), lds_apply, stream, b, buf_cap, n, lst,
