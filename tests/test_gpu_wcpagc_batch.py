@@ -146,6 +146,7 @@ def test_time_tiles_replayed_from_a_graph(qh):
         for k in range(4):      # the same buffers every call (what a captured sequence needs), new samples copied in
             seg = torch.from_numpy(np.ascontiguousarray(x[:, k * nblk * 1024:(k + 1) * nblk * 1024]).view(np.float64).copy()).cuda()
             d[:, :nblk * 2048] = seg
+            torch.cuda.synchronize()                # the engine runs on a stream of its own: the copy has to be there
             e.process_ptr(d.data_ptr(), 4 * nblk * 1024, o.data_ptr(), 4 * nblk * 256, nblk)
             e.synchronize()
             ys.append(o[:, :nblk * 512].cpu().numpy().view(np.complex128).copy())
@@ -153,3 +154,6 @@ def test_time_tiles_replayed_from_a_graph(qh):
         if replay:
             assert e.graph_launches() > 0
     assert np.array_equal(outs[0], outs[1])
+    ref = _engine(qh, nch, [3, 2], 0)
+    want = np.concatenate([ref.process_host(np.ascontiguousarray(x[:, k * nblk * 1024:(k + 1) * nblk * 1024])) for k in range(4)], axis=1)
+    assert np.array_equal(outs[0], want)
