@@ -236,37 +236,100 @@ __device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double
     }
 }
 
-// bounds[slot][tile][0..4]: the state at the START of tile t (tile 0: the carried state).  grid (channels), one wavefront.
+// bounds[slot][tile][0..4]: the state at the START of tile t (tile 0: the carried state).
+// The walk over [j0, j1) (multiples of 64, j0 a tile boundary or a warm-up start), boundary states written from sample `from` on.
+struct AgcWalk {
+    const double *in0, *in1, *in2;
+    double *bo;
+    int n, L, lane;
+};
+__device__ __forceinline__ void agc_walk(AgcLane &s, const AgcWalk &w, int j0, int from, int j1, const AgcParam &q, const PoleScan &ps0,
+                                         const PoleScan &ps1, const PoleScan &ps2, const double (*tab)[65])
+{
+    const int lane = w.lane;
+    double rn = 0.0, fn = 0.0, hn = 0.0;
+    if (j0 + lane < w.n) { rn = w.in0[j0 + lane]; fn = w.in1[j0 + lane]; hn = w.in2[j0 + lane]; }
+    for (int base = j0; base < j1; base += 64) {
+        const int cnt = w.n - base < 64 ? w.n - base : 64;
+        if (base >= from && base % w.L == 0 && lane == 0) {
+            double *o = w.bo + (long long)(base / w.L) * 8;
+            o[0] = s.volts; o[1] = s.save_volts; o[2] = (double)s.hc; o[3] = (double)s.decay_type; o[4] = (double)s.st;
+        }
+        const double r = rn, f = fn, h = hn;
+        if (base + 64 + lane < w.n) { rn = w.in0[base + 64 + lane]; fn = w.in1[base + 64 + lane]; hn = w.in2[base + 64 + lane]; }     // the next chunk is on its way
+        agc_chunk(s, r, f, h, cnt, lane, q, ps0, ps1, ps2, tab);
+    }
+}
+__device__ __forceinline__ void agc_tab_init(double (*tab)[65], const AgcParam &q, int lane)
+{
+    const double lg0 = log1p(-q.attack_mult), lg1 = log1p(-q.decay_mult), lg2 = log1p(-q.hang_decay_mult);
+    tab[0][lane + 1] = exp((double)(lane + 1) * lg0); tab[1][lane + 1] = exp((double)(lane + 1) * lg1); tab[2][lane + 1] = exp((double)(lane + 1) * lg2);
+    if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = 1.0;
+    __syncthreads();
+}
+__device__ __forceinline__ void agc_put(double *o, const AgcLane &s)
+{
+    o[0] = s.volts; o[1] = s.save_volts; o[2] = (double)s.hc; o[3] = (double)s.decay_type; o[4] = (double)s.st;
+}
+
+// One wavefront per channel walks the call alone at a few thousand cycles per 64 samples, so the call is cut into K super-segments
+// (seg samples each, a multiple of the tile length) that K wavefronts walk at once: segment 0 from the carried state; segment k > 0
+// from the state the CALL began in, W samples ahead of its own start -- on a channel whose level is steady that warm-up ends on the true
+// trajectory (two runs meet at the rate of their shared attack steps: ~10 000 samples on steady noise, tools/dbg/agc_sim.py); after a
+// drop in level it does not, and agc_bounds_fix_kernel walks such a segment again from the true end of the one before it.
+// sege[slot][k][0..4]: the state at the END of segment k.  grid (channels, K), one wavefront.
 static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int *chan_list, const AgcParam *prm, const AgcState *state,
-                                                              const double *scr, long long arr, double *bounds, long long bstride, int L)
+                                                              const double *scr, long long arr, double *bounds, long long bstride, int L,
+                                                              int seg, int W, double *sege)
+{
+    const int slot = blockIdx.x, k = blockIdx.y, ch = chan_list[slot], lane = threadIdx.x;
+    const int begin = k * seg;
+    if (begin >= n) return;
+    const AgcParam q = prm[ch];
+    const AgcState *sp = state + ch;
+    AgcWalk w{ scr + ((long long)slot * 4 + 0) * arr, scr + ((long long)slot * 4 + 1) * arr, scr + ((long long)slot * 4 + 2) * arr,
+               bounds + (long long)slot * bstride, n, L, lane };
+    __shared__ double tab[3][65];
+    agc_tab_init(tab, q, lane);
+    const PoleScan ps0 = make_pole_scan(1.0 - q.attack_mult, lane), ps1 = make_pole_scan(1.0 - q.decay_mult, lane),
+                   ps2 = make_pole_scan(1.0 - q.hang_decay_mult, lane);
+    AgcLane s{ sp->volts, sp->save_volts, sp->hang_counter, sp->decay_type, sp->state };
+    int j0 = begin - W;
+    if (j0 <= 0) j0 = 0;
+    else s.hc = s.hc > j0 ? s.hc - j0 : 0;                  // the hang counter has run down meanwhile
+    const int end = begin + seg < n ? begin + seg : n;
+    agc_walk(s, w, j0, begin, end, q, ps0, ps1, ps2, tab);
+    if (lane == 0) agc_put(sege + ((long long)slot * gridDim.y + k) * 8, s);
+}
+
+__device__ __forceinline__ bool agc_state_differs(const double *a, const double *b);
+// One wavefront per channel: segment k began in bounds[tile of k seg]; where that is not the state segment k - 1 ended in, the segment is
+// walked again from there (its tiles' boundary states and its own end rewritten).  nseg_fixed counts them.
+static __global__ __launch_bounds__(64) void agc_bounds_fix_kernel(int n, const int *chan_list, const AgcParam *prm, const double *scr, long long arr,
+                                                                  double *bounds, long long bstride, int L, int seg, int K, double *sege, int *nseg_fixed)
 {
     const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x;
     const AgcParam q = prm[ch];
-    const AgcState *sp = state + ch;
-    const double *in0 = scr + ((long long)slot * 4 + 0) * arr, *in1 = scr + ((long long)slot * 4 + 1) * arr, *in2 = scr + ((long long)slot * 4 + 2) * arr;
-    double *bo = bounds + (long long)slot * bstride;
-    AgcLane s{ sp->volts, sp->save_volts, sp->hang_counter, sp->decay_type, sp->state };
+    AgcWalk w{ scr + ((long long)slot * 4 + 0) * arr, scr + ((long long)slot * 4 + 1) * arr, scr + ((long long)slot * 4 + 2) * arr,
+               bounds + (long long)slot * bstride, n, L, lane };
     __shared__ double tab[3][65];
-    {
-        const double lg0 = log1p(-q.attack_mult), lg1 = log1p(-q.decay_mult), lg2 = log1p(-q.hang_decay_mult);
-        tab[0][lane + 1] = exp((double)(lane + 1) * lg0); tab[1][lane + 1] = exp((double)(lane + 1) * lg1); tab[2][lane + 1] = exp((double)(lane + 1) * lg2);
-        if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = 1.0;
-        __syncthreads();
-    }
+    agc_tab_init(tab, q, lane);
     const PoleScan ps0 = make_pole_scan(1.0 - q.attack_mult, lane), ps1 = make_pole_scan(1.0 - q.decay_mult, lane),
                    ps2 = make_pole_scan(1.0 - q.hang_decay_mult, lane);
-    double rn = 0.0, fn = 0.0, hn = 0.0;
-    if (lane < n) { rn = in0[lane]; fn = in1[lane]; hn = in2[lane]; }
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = n - base < 64 ? n - base : 64;
-        if (base % L == 0 && lane == 0) {
-            double *w = bo + (long long)(base / L) * 8;
-            w[0] = s.volts; w[1] = s.save_volts; w[2] = (double)s.hc; w[3] = (double)s.decay_type; w[4] = (double)s.st;
-        }
-        const double r = rn, f = fn, h = hn;
-        if (base + 64 + lane < n) { rn = in0[base + 64 + lane]; fn = in1[base + 64 + lane]; hn = in2[base + 64 + lane]; }     // the next chunk is on its way
-        agc_chunk(s, r, f, h, cnt, lane, q, ps0, ps1, ps2, tab);
+    int fixed = 0;
+    for (int k = 1; k < K && k * seg < n; k++) {
+        const double *a = w.bo + (long long)(k * seg / L) * 8, *b = sege + ((long long)slot * K + k - 1) * 8;
+        if (!agc_state_differs(a, b)) continue;
+        AgcLane s{ b[0], b[1], (int)b[2], (int)b[3], (int)b[4] };
+        const int begin = k * seg, end = begin + seg < n ? begin + seg : n;
+        agc_walk(s, w, begin, begin, end, q, ps0, ps1, ps2, tab);
+        if (lane == 0) agc_put(sege + ((long long)slot * K + k) * 8, s);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        fixed++;
     }
+    if (lane == 0 && fixed && nseg_fixed) atomicAdd(nseg_fixed, fixed);
 }
 
 // ---- (d): one lane per tile ------------------------------------------------------------------------------------------------

@@ -64,6 +64,7 @@ static constexpr int kFmWarm = 768;
 static constexpr int kSamTile = 4096;
 static constexpr int kSamWarm = 8192;
 static constexpr long long kSamTiledMin = 4 * 8192;     // shorter calls take the sequential kernel
+static constexpr int kAgcSegs = 16;                     // super-segments of the AGC boundary pass, at most
 static constexpr long long kAgcTiledMin = 16384;        // xwcpagc in time tiles from this many detector samples per call (qh_agc_tiled.hpp)
 
 struct ChanCfg {
@@ -246,7 +247,7 @@ struct Engine {
     int *pll_nfixed = nullptr;
     // xwcpagc in time tiles (qh_agc_tiled.hpp): streams RM / fba / hba / volts per listed channel, the tiles' halos, the last samples
     // of the rows, the lanes' states, the final states, tiles re-run
-    double *agc_scr = nullptr, *agc_ends = nullptr, *agc_fin = nullptr;
+    double *agc_scr = nullptr, *agc_ends = nullptr, *agc_fin = nullptr, *agc_sege = nullptr;
     double2 *agc_halo = nullptr, *agc_tail = nullptr;
     long long agc_arr = 0, agc_ends_cap = 0, agc_halo_cap = 0;
     int *agc_nfixed = nullptr;
@@ -330,7 +331,7 @@ Engine::~Engine()
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
-    (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed);
+    (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
@@ -2048,8 +2049,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 if (!agc_fin) {
                     QH_HIP(dev_alloc(&agc_fin, (size_t)nch * 8));
                     QH_HIP(dev_alloc(&agc_tail, (size_t)nch * kAgcRing));
-                    QH_HIP(dev_alloc(&agc_nfixed, (size_t)1));
-                    QH_HIP(hipMemsetAsync(agc_nfixed, 0, sizeof(int), stream));
+                    QH_HIP(dev_alloc(&agc_nfixed, (size_t)2));
+                    QH_HIP(hipMemsetAsync(agc_nfixed, 0, 2 * sizeof(int), stream));
+                    QH_HIP(dev_alloc(&agc_sege, (size_t)nch * kAgcSegs * 8));
                 }
             }
             if (!seg_sum[1]) QH_HIP(dev_alloc(&seg_sum[1], (size_t)nch * kSegWaves * kSegMaxGroups * kSegSumW));
@@ -2076,8 +2078,19 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL((agc_avg_tiled_kernel<2>), dim3((unsigned)cnt, (unsigned)G), dim3(kSegThreads), 0, stream, (const double2 *)b,
                                    buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, seg_sum[1], 1.0);
                 double *bnd = agc_ends, *end = agc_ends + (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW;
-                hipLaunchKernelGGL(agc_bounds_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
-                                   (const AgcState *)agc_state, (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L);
+                // the boundary pass over K super-segments per channel at once (a multiple of the tile length each, warm-up 400 A rounded to tiles)
+                int K = 1;
+                while (K < kAgcSegs && (long long)cnt * K < 2048 && n_mid / (2 * K) >= 8 * L && n_mid / (2 * K) >= 32768) K *= 2;
+                if (const char *e = getenv("QH_AGC_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= kAgcSegs) K = v; }
+                const int seg = (int)(((n_mid + K - 1) / K + L - 1) / L) * L;
+                int wmul = 400;         // 76 800 samples at A = 192: what the 256-channel bench input needs for no segment to miss (96: 29 %, 200: 0.06 %)
+                if (const char *e = getenv("QH_AGC_WARM")) { const int v = atoi(e); if (v > 0) wmul = v; }
+                const int Wm = ((wmul * a_max + L - 1) / L) * L;
+                hipLaunchKernelGGL(agc_bounds_kernel, dim3((unsigned)cnt, (unsigned)K), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
+                                   (const AgcState *)agc_state, (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, Wm, agc_sege);
+                if (K > 1)
+                    hipLaunchKernelGGL(agc_bounds_fix_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
+                                       (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, K, agc_sege, agc_nfixed + 1);
                 hipLaunchKernelGGL(agc_lanes_kernel, dim3((unsigned)ngroups, (unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
                                    agc_scr, agc_arr, (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L);
                 hipLaunchKernelGGL(agc_verify_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_scr, agc_arr,
@@ -2905,6 +2918,17 @@ long long qh_rxa_agc_repairs(qh_rxa *h)
     int v = 0;
     if (hipSetDevice(h->e.device) != hipSuccess || hipStreamSynchronize(h->e.stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, h->e.agc_nfixed, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
+
+// super-segments of the AGC boundary pass that were walked again (their warm-up had not ended on the true trajectory), over all calls
+long long qh_rxa_agc_segments_rerun(qh_rxa *h)
+{
+    if (!h || !h->e.agc_nfixed) return 0;
+    QH_RXA_LOCK(h);
+    int v = 0;
+    if (hipSetDevice(h->e.device) != hipSuccess || hipStreamSynchronize(h->e.stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, h->e.agc_nfixed + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
 }
 

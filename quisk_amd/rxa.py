@@ -149,6 +149,9 @@ class RxaEngine:
     def agc_repairs(self):
         return self._L.qh_rxa_agc_repairs(self._h)
 
+    def agc_segments_rerun(self):
+        return self._L.qh_rxa_agc_segments_rerun(self._h)
+
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))
 

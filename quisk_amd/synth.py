@@ -74,9 +74,11 @@ def make_mode_input_numpy(mode, c, n, fs=192000.0, sigma=0.01):
     raise ValueError(mode)
 
 
-def make_mode_input_torch(modes, n, device, fs=192000.0, sigma=0.01, first_channel=0):
+def make_mode_input_torch(modes, n, device, fs=192000.0, sigma=0.01, first_channel=0, periodic=False):
     """make_mode_input_numpy's signal model generated on the GPU: modes = one of 'usb' / 'am' / 'fm' per channel; complex128
-    [len(modes), n]; noise from a torch generator seeded 1000 + c (not the numpy stream: bench input, not a parity vector)."""
+    [len(modes), n]; noise from a torch generator seeded 1000 + c (not the numpy stream: bench input, not a parity vector).
+    periodic: the 'usb' tones moved (by less than fs / 2n) onto multiples of fs / n, so that a buffer fed again and again is ONE
+    continuous stream instead of a phase jump per call."""
     import torch
     nch = len(modes)
     x = torch.empty((nch, n), dtype=torch.complex128, device=device)
@@ -88,6 +90,8 @@ def make_mode_input_torch(modes, n, device, fs=192000.0, sigma=0.01, first_chann
         gen.manual_seed(1000 + c)
         if mode == "usb":
             f1, f2 = channel_tones(c, fs)
+            if periodic:
+                f1, f2 = round(f1 * n / fs) * fs / n, round(f2 * n / fs) * fs / n
             ph1 = torch.remainder(t * (f1 / fs), 1.0) * two_pi
             ph2 = torch.remainder(t * (f2 / fs), 1.0) * two_pi
             re = 0.1 * torch.cos(ph1) + 0.05 * torch.cos(ph2)

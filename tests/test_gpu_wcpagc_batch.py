@@ -157,3 +157,26 @@ def test_time_tiles_replayed_from_a_graph(qh):
     ref = _engine(qh, nch, [3, 2], 0)
     want = np.concatenate([ref.process_host(np.ascontiguousarray(x[:, k * nblk * 1024:(k + 1) * nblk * 1024])) for k in range(4)], axis=1)
     assert np.array_equal(outs[0], want)
+
+
+def test_boundary_pass_over_super_segments(qh, oracle, monkeypatch):
+    """The boundary pass of a long call as eight super-segments walked at once (QH_AGC_SEGS; the engine picks the number by call length):
+    each from the call's start state behind a warm-up, the ones whose warm-up did not end on the true trajectory walked again.  Bursts
+    and fades make that happen; the result is the sample loop's either way."""
+    monkeypatch.setenv("QH_AGC_SEGS", "8")
+    monkeypatch.setenv("QH_AGC_WARM", "2")                  # a warm-up of 2 attack windows instead of 400: segments must miss
+    nch, nblk = 4, 700
+    x = _input(nch, nblk, seed=41)
+    calls = [300, 2, 398]
+    outs = {}
+    for form in (0, 1):
+        e = _engine(qh, nch, [3, 1, 2, 4], form)
+        ys, pos = [], 0
+        for nb in calls:
+            ys.append(e.process_host(np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024]))); pos += nb
+        outs[form] = np.concatenate(ys, axis=1)
+        if form == 0:
+            print("segments walked again: %d, tiles re-run: %d" % (e.agc_segments_rerun(), e.agc_repairs()))
+            assert e.agc_segments_rerun() > 0 and e.agc_repairs() == 0
+    for c in range(nch):
+        assert rel_rms(outs[0][c], outs[1][c]) < 1e-10, (c, rel_rms(outs[0][c], outs[1][c]))

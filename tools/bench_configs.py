@@ -94,7 +94,9 @@ def config2_agc(torch, qh, dev):
     from quisk_amd import synth
     nch, nblk = 256, int(os.environ.get("QH_C2A_NBLK", "4096"))
     n_in = nblk * 1024
-    x = synth.make_mode_input_torch(["usb"] * nch, n_in, dev)
+    # the same buffer is fed every step: the tones sit on the buffer's frequency grid (moved by < 0.023 Hz), so that the steps are one
+    # continuous stream -- a phase jump per call is a click the AGC answers for seconds, which no receiver's input has
+    x = synth.make_mode_input_torch(["usb"] * nch, n_in, dev, periodic=True)
     y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
     e = qh.RxaEngine(nch, stream=torch.cuda.current_stream(dev).cuda_stream)
     for c in range(nch):
@@ -105,6 +107,7 @@ def config2_agc(torch, qh, dev):
     tot = nch * n_in
     return {"config": "2 with the AGC state machine on (SetRXAAGCMode 3): 256 ch x 192 k SSB RXA, fp64, 2^%d samples per channel and step" % (n_in.bit_length() - 1),
             "samples_per_step": tot, "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "agc_tiles_rerun": e.agc_repairs(),
+            "agc_segments_rerun": e.agc_segments_rerun(),
             "note": "not a BASELINE configuration (config 2 fixes the gain); agc_tiles_rerun = tiles whose boundary state the exact pass corrected"}
 
 
