@@ -459,9 +459,11 @@ static __global__ __launch_bounds__(64) void agc_verify_kernel(int n, const int 
 
 // ---- (e): gain curve and multiply, in place ------------------------------------------------------------------------------------
 // grid (tiles of kAgcTile, channels), 256 threads; LDS: the tile's samples behind the A samples ahead of it (agc_prep_kernel kept them)
+// dst != null: the AGC is the channel's last stage -- the output matrix (xpanel) is applied here and the result goes to the caller's rows
 static __global__ __launch_bounds__(256) void agc_apply_kernel(double2 *buf, long long stride, int n, const int *chan_list, const AgcParam *prm,
                                                                const double *scr, long long arr, const double2 *halo, int halo_pitch,
-                                                               double pre_gain)
+                                                               double pre_gain, double2 *dst = nullptr, long long dst_stride = 0,
+                                                               const EpiParam *epi = nullptr)
 {
     extern __shared__ double2 sm_apply[];
     const int slot = blockIdx.y, ch = chan_list[slot], t = threadIdx.x;
@@ -484,7 +486,12 @@ static __global__ __launch_bounds__(256) void agc_apply_kernel(double2 *buf, lon
         const double v = vo[j];
         const double mult = __builtin_fma(-q.slope_constant, fmin(0.0, log10(q.inv_max_input * v)), q.out_target) / v;
         const double2 o = sm_apply[k];                          // sample j - A
-        x[j] = make_double2(o.x * mult, o.y * mult);
+        const double2 y = make_double2(o.x * mult, o.y * mult);
+        if (dst) {
+            EpiParam ep{ 1, 0, 0, 1 };
+            if (epi) ep = epi[ch];
+            dst[(long long)ch * dst_stride + j] = make_double2(ep.a * y.x + ep.b * y.y, ep.c * y.x + ep.d * y.y);
+        } else x[j] = y;
     }
 }
 

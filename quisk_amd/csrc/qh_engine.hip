@@ -1720,6 +1720,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     const bool fm_theta_fused = split && any_nbp && !band6k && !band2g && bnfft == kNfft;
     bool no_lms = true;
     for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) no_lms = no_lms && !n_lms[f][k];
+    bool agc_direct = false;            // set where xwcpagc runs: its gain multiply writes the caller's rows (see there)
     const bool direct = split && every_nbp && !eg.kind && !n_lim && !n_agc_cur && !n_agc_other && !n_snba && !n_snb[1] && no_lms &&
                         !n_emnr[0] && !n_emnr[1] && !n_emnr[2] && !n_fix[0] && !n_fix[1] && !n_bp1p[1] && n_bp1p[0] == n_bp1 && n_rb == n_bp1 &&
                         n_usb + n_fm == n_plain &&
@@ -2026,6 +2027,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             a_max = c.agc_abuf > a_max ? c.agc_abuf : a_max;
         }
         for (ChanCfg &c : cfg) if (c.agc_on()) c.agc_ran = true;
+        // ... and when every channel has the AGC as its last stage (nothing at position 1, no meters, squelch or audio frames), the gain
+        // multiply applies the output matrix and writes the caller's rows: the output pass goes
+        bool no_p1 = !n_bp1p[1] && !n_fix[0] && !n_fix[1] && !n_emnr[1] && !n_emnr[2] && !n_amsq && !meters_on && !eg.kind;
+        for (int f = 0; f < 2; f++) for (int k = 1; k < 3; k++) no_p1 = no_p1 && !n_lms[f][k];
+        agc_direct = tiled && no_p1 && n_agc_cur == n_plain && n_agc_other == n_bp1;
         if (tiled) {
             const int nl = n_agc_cur > n_agc_other ? n_agc_cur : n_agc_other;
             const int ntile = (int)((n_mid + kAgcTile - 1) / kAgcTile), hp = (a_max + 15) & ~15;
@@ -2080,7 +2086,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 double *bnd = agc_ends, *end = agc_ends + (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW;
                 // the boundary pass over K super-segments per channel at once (a multiple of the tile length each, warm-up 400 A rounded to tiles)
                 int K = 1;
-                while (K < kAgcSegs && (long long)cnt * K < 2048 && n_mid / (2 * K) >= 8 * L && n_mid / (2 * K) >= 32768) K *= 2;
+                while (K < kAgcSegs && (long long)cnt * K < 4096 && n_mid / (2 * K) >= 8 * L && n_mid / (2 * K) >= 32768) K *= 2;
                 if (const char *e = getenv("QH_AGC_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= kAgcSegs) K = v; }
                 const int seg = (int)(((n_mid + K - 1) / K + L - 1) / L) * L;
                 int wmul = 400;         // 76 800 samples at A = 192: what the 256-channel bench input needs for no segment to miss (96: 29 %, 200: 0.06 %)
@@ -2098,7 +2104,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL(agc_tail_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, (const double2 *)b, buf_cap, n, lst,
                                    (const AgcParam *)agc_prm, agc_tail, 1.0);
                 hipLaunchKernelGGL(agc_apply_kernel, dim3((unsigned)ntile, (unsigned)cnt), dim3(256), lds_apply, stream, b, buf_cap, n, lst,
-                                   (const AgcParam *)agc_prm, (const double *)agc_scr, agc_arr, (const double2 *)agc_halo, hp, 1.0);
+                                   (const AgcParam *)agc_prm, (const double *)agc_scr, agc_arr, (const double2 *)agc_halo, hp, 1.0,
+                                   agc_direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi);
                 hipLaunchKernelGGL(agc_finish_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_state,
                                    (const double *)agc_scr, agc_arr, (const double2 *)agc_tail, (const double *)agc_fin);
             };
@@ -2133,7 +2140,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // xwcpagc mode 0 + xpanel
     long long per = (n_mid + NT - 1) / NT;
     const unsigned gx = (unsigned)(per < 1024 ? per : 1024);
-    if (direct) {
+    if (direct || agc_direct) {
         // every channel's last stage has written the caller's buffer
     } else if (eg_fused) {
         if (n_plain) hipLaunchKernelGGL((pointwise_kernel<double, false, true>), dim3(gx, (unsigned)n_plain), dim3(NT), 0, stream, cur,
