@@ -7,7 +7,7 @@
 //                          reference's rescans and single compares amount to while ring_max is not stale (it is stale only after
 //                          SetRXAAGCAttack has moved in_index in mid-stream: the engine keeps such a channel on wcpagc_kernel);
 //                          also keeps the A samples ahead of every 1024-sample tile for agc_apply_kernel
-//   agc_avg_tiled_kernel   (b): two linear one-pole scans of |x_{j-A}|, two-pass segment scheme (qh_wave.hpp)
+//   agc_avg_tiled_kernel   (b): two linear one-pole scans of |x_{j-A}| over time segments, the carries chained from the prep kernel's tile sums
 //   agc_bounds_kernel      (d), coarse: the detector's state at every tile boundary, one wavefront per channel jumping over the runs of
 //                          constant ring_max in closed form (a warm-up from a guessed state, as the PLL tiles use, does not work here:
 //                          two runs of the detector only meet at the rate of the attack steps they share, one step in twenty on a
@@ -83,9 +83,10 @@ __device__ __forceinline__ double *agc_arr(double *scr, long long arr, int slot,
 // for the samples [j0 - Ah, j0 + kAgcTile), Ah = A rounded up to 64.
 static __global__ __launch_bounds__(256) void agc_prep_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
                                                               const AgcParam *prm, const AgcState *state, double *scr, long long arr,
-                                                              double2 *halo, int halo_pitch, double pre_gain)
+                                                              double2 *halo, int halo_pitch, double pre_gain, double *tsum)
 {
     extern __shared__ double sm_prep[];
+    __shared__ double red[8];
     const int slot = blockIdx.y, ch = chan_list[slot], t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const AgcParam q = prm[ch];
     const AgcState *sp = state + ch;
@@ -112,6 +113,28 @@ static __global__ __launch_bounds__(256) void agc_prep_kernel(const double2 *buf
         P[b * 64 + lane] = p; S[b * 64 + lane] = s;
     }
     __syncthreads();
+    // the tile's own contribution to the two back-averages of the delayed magnitude a_j = m[Ah - A + k] (sample j - A), from a zero
+    // state: sum_k mult (1 - mult)^(T - 1 - k) a_k for the whole tile -- agc_avg_tiled_kernel chains these instead of reading the rows
+    // a first time.  Thread t takes k = t + 256 i: Horner in (1 - mult)^256 over i, then (1 - mult)^(255 - t).
+    {
+        const double mF = q.onemfast_backmult, mH = q.onemhang_backmult;
+        const double sF = ipow_d(mF, 256), sH = ipow_d(mH, 256);
+        double aF = 0.0, aH = 0.0;
+#pragma unroll
+        for (int i = 0; i < kAgcTile / 256; i++) {
+            const int k = t + 256 * i;
+            const double a = j0 + k < n ? m[Ah - A + k] : 0.0;
+            aF = __builtin_fma(aF, sF, a); aH = __builtin_fma(aH, sH, a);
+        }
+        const double wF = wave_sum_d(aF * ipow_d(mF, 255 - t)), wH = wave_sum_d(aH * ipow_d(mH, 255 - t));
+        if (lane == 0) { red[wave * 2] = wF; red[wave * 2 + 1] = wH; }
+        __syncthreads();
+        if (t == 0) {
+            double *o = tsum + ((long long)slot * gridDim.x + blockIdx.x) * 2;
+            o[0] = q.fast_backmult * ((red[0] + red[2]) + (red[4] + red[6]));
+            o[1] = q.hang_backmult * ((red[1] + red[3]) + (red[5] + red[7]));
+        }
+    }
     double *rm = agc_arr(scr, arr, slot, 0);
     for (int k = t; k < kAgcTile; k += 256) {
         const int j = j0 + k;
@@ -130,11 +153,11 @@ static __global__ __launch_bounds__(256) void agc_prep_kernel(const double2 *buf
 }
 
 // ---- (b): the two back-averages of the delayed magnitude ---------------------------------------------------------------------
-// MODE 1: every segment's response to its own samples from a zero state -> gsum rows; MODE 2: chain + values (see am_detect_tiled_kernel)
-template <int MODE>
+// One pass: the time segments are cut on the prep kernel's tile boundaries (kAgcTile samples) and a segment's carry-in is the chain over
+// the tiles ahead of it (tsum [slot][ntile][2], agc_prep_kernel); a partial last tile is nobody's predecessor.
 static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const double2 *buf, long long stride, int n, const int *chan_list,
                                                                            const AgcParam *prm, const AgcState *state, double *scr,
-                                                                           long long arr, double *gsum, double pre_gain)
+                                                                           long long arr, const double *tsum, int ntile, double pre_gain)
 {
     const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
@@ -142,45 +165,36 @@ static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const
     const AgcState *sp = state + ch;
     const double2 *x = buf + (long long)ch * stride;
     const int A = q.attack_buffsize;
-    double *sum = gsum + (long long)slot * S * kSegSumW;
-    int b0, b1;
-    seg_range(n, sidx, b0, b1, S);
+    constexpr int lb = kAgcTile / 64;
+    const int nb = (n + 63) >> 6, nt = (n + kAgcTile - 1) / kAgcTile;
+    const int t0 = (int)((long long)sidx * nt / S), t1 = (int)((long long)(sidx + 1) * nt / S);
+    const int b0 = t0 * lb, b1 = t1 * lb < nb ? t1 * lb : nb;
     const double mF = q.onemfast_backmult, mH = q.onemhang_backmult;
-    const double m64F = lane_pow(mF, 64), m64H = lane_pow(mH, 64);
-    if constexpr (MODE == 1) {
-        double accF = 0.0, accH = 0.0;
-        for (int b = b0; b < b1; b++) {
-            const int j = b * 64 + lane;
-            const double a = j < n ? agc_mag(x, sp, q, j - A, pre_gain) : 0.0;
-            accF = __builtin_fma(accF, m64F, q.fast_backmult * a);
-            accH = __builtin_fma(accH, m64H, q.hang_backmult * a);
-        }
-        const double eF = wave_sum_d(accF * lane_pow(mF, 63 - lane)), eH = wave_sum_d(accH * lane_pow(mH, 63 - lane));
-        if (lane == 0) { sum[sidx * kSegSumW] = eF; sum[sidx * kSegSumW + 1] = eH; }
-        return;
-    } else {
-        double cF = sp->fast_backaverage, cH = sp->hang_backaverage;
-        {
-            const int qb = ((n + 63) >> 6) / S;
-            const double tF0 = pow(m64F, (double)qb), tH0 = pow(m64H, (double)qb), tF1 = tF0 * m64F, tH1 = tH0 * m64H;
-            SegWalk walk(n, S);
-            for (int w = 0; w < sidx; w++) {
-                const int nbw = walk.next();
-                if (nbw == 0) continue;
-                cF = __builtin_fma(cF, nbw == qb ? tF0 : tF1, sum[w * kSegSumW]);
-                cH = __builtin_fma(cH, nbw == qb ? tH0 : tH1, sum[w * kSegSumW + 1]);
+    double cF = sp->fast_backaverage, cH = sp->hang_backaverage;
+    {
+        // c = c_in mT^t0 + sum_{t < t0} mT^(t0 - 1 - t) s_t, 64 tiles per step
+        const double tF = ipow_d(mF, kAgcTile), tH = ipow_d(mH, kAgcTile);
+        const double *e = tsum + (long long)slot * ntile * 2;
+        for (int blk = 0; blk < t0; blk += 64) {
+            const int cnt = t0 - blk < 64 ? t0 - blk : 64;
+            double vF = 0.0, vH = 0.0;
+            if (lane < cnt) {
+                const double2 sv = *reinterpret_cast<const double2 *>(e + (long long)(blk + lane) * 2);
+                vF = sv.x * ipow_d(tF, cnt - 1 - lane); vH = sv.y * ipow_d(tH, cnt - 1 - lane);
             }
+            cF = __builtin_fma(cF, ipow_d(tF, cnt), wave_sum_d(vF));
+            cH = __builtin_fma(cH, ipow_d(tH, cnt), wave_sum_d(vH));
         }
-        const PoleScan sF = make_pole_scan(mF, lane), sH = make_pole_scan(mH, lane);
-        double *fo = agc_arr(scr, arr, slot, 1), *ho = agc_arr(scr, arr, slot, 2);
-        for (int b = b0; b < b1; b++) {
-            const int base = b * 64, j = base + lane, cnt = n - base < 64 ? n - base : 64;
-            const double a = j < n ? agc_mag(x, sp, q, j - A, pre_gain) : 0.0;
-            const double f = scan_pole_dpp(q.fast_backmult * a, sF) + sF.pw * cF;
-            const double h = scan_pole_dpp(q.hang_backmult * a, sH) + sH.pw * cH;
-            if (lane < cnt) { fo[j] = f; ho[j] = h; }
-            cF = lane_bcast(f, cnt - 1); cH = lane_bcast(h, cnt - 1);
-        }
+    }
+    const PoleScan sF = make_pole_scan(mF, lane), sH = make_pole_scan(mH, lane);
+    double *fo = agc_arr(scr, arr, slot, 1), *ho = agc_arr(scr, arr, slot, 2);
+    for (int b = b0; b < b1; b++) {
+        const int base = b * 64, j = base + lane, cnt = n - base < 64 ? n - base : 64;
+        const double a = j < n ? agc_mag(x, sp, q, j - A, pre_gain) : 0.0;
+        const double f = scan_pole_dpp(q.fast_backmult * a, sF) + sF.pw * cF;
+        const double h = scan_pole_dpp(q.hang_backmult * a, sH) + sH.pw * cH;
+        if (lane < cnt) { fo[j] = f; ho[j] = h; }
+        cF = lane_bcast(f, cnt - 1); cH = lane_bcast(h, cnt - 1);
     }
 }
 

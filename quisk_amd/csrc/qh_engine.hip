@@ -247,7 +247,7 @@ struct Engine {
     int *pll_nfixed = nullptr;
     // xwcpagc in time tiles (qh_agc_tiled.hpp): streams RM / fba / hba / volts per listed channel, the tiles' halos, the last samples
     // of the rows, the lanes' states, the final states, tiles re-run
-    double *agc_scr = nullptr, *agc_ends = nullptr, *agc_fin = nullptr, *agc_sege = nullptr;
+    double *agc_scr = nullptr, *agc_ends = nullptr, *agc_fin = nullptr, *agc_sege = nullptr, *agc_tsum = nullptr;
     double2 *agc_halo = nullptr, *agc_tail = nullptr;
     long long agc_arr = 0, agc_ends_cap = 0, agc_halo_cap = 0;
     int *agc_nfixed = nullptr;
@@ -331,7 +331,7 @@ Engine::~Engine()
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
     (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
-    (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege);
+    (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege); (void)hipFree(agc_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
     (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
@@ -2044,14 +2044,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 QH_HIP(hipStreamSynchronize(stream));
                 if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
                 drop_graphs(); epoch++;
-                (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_halo);
-                agc_scr = agc_ends = nullptr; agc_halo = nullptr;
+                (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_halo); (void)hipFree(agc_tsum);
+                agc_scr = agc_ends = agc_tsum = nullptr; agc_halo = nullptr;
                 agc_arr = n_mid > agc_arr ? n_mid : agc_arr;
                 agc_ends_cap = ngroups * 64 > agc_ends_cap ? ngroups * 64 : agc_ends_cap;
                 agc_halo_cap = (long long)ntile * hp > agc_halo_cap ? (long long)ntile * hp : agc_halo_cap;
                 QH_HIP(dev_alloc(&agc_scr, (size_t)nch * 4 * (size_t)agc_arr));
                 QH_HIP(dev_alloc(&agc_ends, (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW * 2));        // boundary states, then end states
                 QH_HIP(dev_alloc(&agc_halo, (size_t)nch * (size_t)agc_halo_cap));
+                QH_HIP(dev_alloc(&agc_tsum, (size_t)nch * (size_t)((agc_arr + kAgcTile - 1) / kAgcTile) * 2));
                 if (!agc_fin) {
                     QH_HIP(dev_alloc(&agc_fin, (size_t)nch * 8));
                     QH_HIP(dev_alloc(&agc_tail, (size_t)nch * kAgcRing));
@@ -2060,7 +2061,6 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                     QH_HIP(dev_alloc(&agc_sege, (size_t)nch * kAgcSegs * 8));
                 }
             }
-            if (!seg_sum[1]) QH_HIP(dev_alloc(&seg_sum[1], (size_t)nch * kSegWaves * kSegMaxGroups * kSegSumW));
             static bool agc_attr = false;
             if (!agc_attr) {        // attack windows of up to kAgcRing samples: more dynamic LDS than the default limit
                 QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(agc_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2078,11 +2078,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 const size_t lds_prep = (size_t)3 * (((size_t)a_max + 63) / 64 * 64 + kAgcTile) * sizeof(double);
                 const size_t lds_apply = ((size_t)a_max + kAgcTile) * sizeof(double2);
                 hipLaunchKernelGGL(agc_prep_kernel, dim3((unsigned)ntile, (unsigned)cnt), dim3(256), lds_prep, stream, (const double2 *)b, buf_cap, n,
-                                   lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, agc_halo, hp, 1.0);
-                hipLaunchKernelGGL((agc_avg_tiled_kernel<1>), dim3((unsigned)cnt, (unsigned)G), dim3(kSegThreads), 0, stream, (const double2 *)b,
-                                   buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, seg_sum[1], 1.0);
-                hipLaunchKernelGGL((agc_avg_tiled_kernel<2>), dim3((unsigned)cnt, (unsigned)G), dim3(kSegThreads), 0, stream, (const double2 *)b,
-                                   buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, seg_sum[1], 1.0);
+                                   lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, agc_halo, hp, 1.0, agc_tsum);
+                hipLaunchKernelGGL(agc_avg_tiled_kernel, dim3((unsigned)cnt, (unsigned)G), dim3(kSegThreads), 0, stream, (const double2 *)b,
+                                   buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, (const double *)agc_tsum,
+                                   ntile, 1.0);
                 double *bnd = agc_ends, *end = agc_ends + (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW;
                 // the boundary pass over K super-segments per channel at once (a multiple of the tile length each, warm-up 400 A rounded to tiles)
                 int K = 1;
