@@ -180,3 +180,29 @@ def test_boundary_pass_over_super_segments(qh, oracle, monkeypatch):
             assert e.agc_segments_rerun() > 0 and e.agc_repairs() == 0
     for c in range(nch):
         assert rel_rms(outs[0][c], outs[1][c]) < 1e-10, (c, rel_rms(outs[0][c], outs[1][c]))
+
+
+@pytest.mark.parametrize("dsp_rate,attack_ms,mode", [(96000, 1, 3), (48000, 5, 2), (48000, 10, 4)], ids=["96k", "attack-5ms", "attack-10ms"])
+def test_time_tiles_at_other_window_lengths(qh, oracle, dsp_rate, attack_ms, mode):
+    """The attack window (4 x rate x tau_attack samples: 384 at 96 kHz, 960 and 1920 with longer attacks set ahead of the stream) sizes
+    the sliding maximum, the tiles' halos and the delay of the gain multiply."""
+    nch, nblk = 2, 400
+    x = _input(nch, nblk, seed=51)
+    dsz = 256 * dsp_rate // 48000
+    outs = {}
+    for form in (0, 1):
+        e = qh.RxaEngine(nch, dsp_size=dsz, in_rate=192000, dsp_rate=dsp_rate, out_rate=dsp_rate)
+        for c in range(nch):
+            e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, synth.shift_freq(c)); e.RXANBPSetRun(c, 1); e.SetRXAMode(c, 1)
+            e.RXASetPassband(c, 300.0, 3000.0); e.SetRXAAGCMode(c, mode); e.SetRXAAGCAttack(c, attack_ms)
+        e.debug_agc(form)
+        outs[form] = np.concatenate([e.process_host(np.ascontiguousarray(x[:, :190 * 1024])), e.process_host(np.ascontiguousarray(x[:, 190 * 1024:193 * 1024])),
+                                     e.process_host(np.ascontiguousarray(x[:, 193 * 1024:]))], axis=1)
+    for c in range(nch):
+        assert rel_rms(outs[0][c], outs[1][c]) < 1e-10, (c, rel_rms(outs[0][c], outs[1][c]))
+    o = oracle.WdspChannel(1024, dsz, 192000, dsp_rate, dsp_rate)
+    o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(0)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+    o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(mode); o.SetRXAAGCAttack(attack_ms)
+    ref = o.xrxa(x[0])
+    assert np.abs(ref).max() > 1e-3
+    assert rel_rms(outs[0][0], ref) < 1e-9, rel_rms(outs[0][0], ref)
