@@ -536,6 +536,11 @@ int qh_qagc_set_gain(qh_qagc *a, int ch, double release_gain);          /* set_a
 int qh_qagc_set_cpx(qh_qagc *a, int is_cpx);                            /* process_agc's is_cpx argument for the calls to come */
 int qh_qagc_reset(qh_qagc *a);
 int qh_qagc_process(qh_qagc *a, void *d_buf, long long stride, int n);
+/* the same from one device buffer into another */
+int qh_qagc_process2(qh_qagc *a, const void *d_src, long long src_stride, void *d_dst, long long dst_stride, int n);
+/* diagnostics: 0 = the two regimes of the state machine as instruction chains (default), 1 = the whole machine sample by sample
+   (bit-identical, ~9 times slower) */
+int qh_qagc_debug_form(qh_qagc *a, int form);
 int qh_qagc_process_host(qh_qagc *a, void *h_buf, long long stride, int n);
 /* The receiver bank with process_agc on its output, as quisk_process_samples has it; off by default. */
 int qh_qrx_set_agc(qh_qrx *r, int on, double release_gain);

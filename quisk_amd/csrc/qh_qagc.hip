@@ -3,10 +3,13 @@
 // A 15 ms FIFO (AGC_DELAY, quisk.c:47) delays the audio while a five-branch state machine moves the gain: ramp
 // down linearly over the FIFO length when a sample would exceed max_out, otherwise relax exponentially towards
 // min(agcReleaseGain, max_out * CLIP32 / largest sample of the last FIFO cycle).  The recurrence is non-linear and
-// sequential: one wavefront per stream, lanes hold 64 consecutive samples, every lane steps the same scalar state
-// through the 64 magnitudes (broadcast by __shfl) and lane i keeps the gain that applied to sample i; the FIFO
-// lives in global memory in the reference's ring order, so a call leaves exactly the reference's state.
+// sequential: one wavefront per stream, lanes hold 64 consecutive samples and lane i keeps the gain that applied to
+// sample i; the FIFO lives in global memory in the reference's ring order, so a call leaves exactly the reference's
+// state.  Two kernels, bit-identical: q_agc_kernel steps the whole machine sample by sample (every lane the same
+// scalar state); q_agc_chain_kernel, the one that runs, takes the two regimes as chains of the one or two
+// instructions that carry the gain from sample to sample and handles the turns between them with ballots.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "qh_internal.hpp"
 #include "qh_wave.hpp"
@@ -20,78 +23,309 @@ constexpr double kClip32 = 2147483647.0;      // CLIP32, quisk.h:13
 struct QAgcParam { double limit /* max_out * CLIP32 */, time_release; int buf_size, is_cpx; };
 struct QAgcState { int index_read, index_start, is_clipping, pad; double themax, gain, delta, target_gain; };
 
-__global__ __launch_bounds__(64) void q_agc_kernel(double2 *buf, long long stride, int n, QAgcState *state, double2 *ring,
-                                                   const double *release_gain, QAgcParam q)
+struct QAgcLane { double g, T, d, mx; int clip, is; };
+
+__device__ __forceinline__ double qagc_mag(double2 z, int is_cpx) { return is_cpx ? hypot(z.x, z.y) : fabs(z.x); }
+
+// One sample of the state machine, quisk.c:2212-2272; b = its magnitude, ir = the FIFO index it is written to.
+// No FMA contraction, the C source's operation order: the branches taken are the reference's.
+__device__ __forceinline__ void qagc_step(QAgcLane &s, double b, int ir, double limit, double tr, double rg, int B)
+{
+#pragma clang fp contract(off)
+    if (s.clip == 0) {
+        if (b * s.g > limit) {
+            s.T = limit / b;
+            s.d = (s.g - s.T) / B;
+            s.clip = 1;
+            s.mx = b;
+            s.g -= s.d;
+        } else if (ir == s.is) {
+            const double clip_gain = limit / s.mx;
+            s.T = rg > clip_gain ? clip_gain : rg;
+            s.mx = b;
+            s.g = s.g * (1.0 - tr) + s.T * tr;
+        } else {
+            if (s.mx < b) s.mx = b;
+            s.g = s.g * (1.0 - tr) + s.T * tr;
+        }
+    } else {
+        if (b > s.mx) {
+            s.mx = b;
+            s.T = limit / b;
+            const double dtmp = (s.g - s.T) / B;
+            if (dtmp > s.d) s.d = dtmp;
+        }
+        s.g -= s.d;
+        if (s.g <= s.T) {
+            s.clip = 0;
+            s.g = s.T;
+            s.mx = b;
+            s.is = ir;
+        }
+    }
+}
+
+__device__ __forceinline__ QAgcLane qagc_lane_of(const QAgcState &st)
+{
+    return QAgcLane{ st.gain, st.target_gain, st.delta, st.themax, st.is_clipping, st.index_start };
+}
+
+// src == dst or two buffers
+__global__ __launch_bounds__(64) void q_agc_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
+                                                   QAgcState *state, double2 *ring, const double *release_gain, QAgcParam q)
 {
     // The overload ramp is built to END on a comparison that is exact in real arithmetic (gain - B * delta ==
-    // target, quisk.c:2219,2257): which step leaves the ramp is decided by the last bit.  No FMA contraction
-    // here, same operation order as the C source, so the state machine takes the reference's branches.
-#pragma clang fp contract(off)
+    // target, quisk.c:2219,2257): which step leaves the ramp is decided by the last bit.  qagc_step has no FMA
+    // contraction and the C source's operation order, so the state machine takes the reference's branches.
     const int ch = blockIdx.x, lane = threadIdx.x;
-    double2 *p = buf + (long long)ch * stride;
+    const double2 *p = src + (long long)ch * sstride;
+    double2 *o_ = dst + (long long)ch * dstride;
     double2 *rb = ring + (long long)ch * q.buf_size;
-    QAgcState st = state[ch];
+    const QAgcState st0 = state[ch];
+    QAgcLane st = qagc_lane_of(st0);
+    int index_read = st0.index_read;
     const double rg = release_gain[ch];
     const int B = q.buf_size;
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
         double2 z = make_double2(0, 0), d = make_double2(0, 0);
-        int ri = st.index_read + lane;
+        int ri = index_read + lane;
         if (ri >= B) ri -= B;
         if (lane < cnt) {
             z = p[base + lane];
             d = rb[ri];                              // FIFO output: the sample written B steps ago
             rb[ri] = z;                              // "write new sample at read index"
         }
-        const double bm = q.is_cpx ? hypot(z.x, z.y) : fabs(z.x);
+        const double bm = qagc_mag(z, q.is_cpx);
         double mygain = 0.0;
         for (int i = 0; i < cnt; i++) {              // uniform: every lane steps the same state
-            const double b = lane_bcast(bm, i);
-            if (lane == i) mygain = st.gain;
-            int ir = st.index_read + i;
+            if (lane == i) mygain = st.g;
+            int ir = index_read + i;
             if (ir >= B) ir -= B;
-            if (st.is_clipping == 0) {
-                if (b * st.gain > q.limit) {
-                    st.target_gain = q.limit / b;
-                    st.delta = (st.gain - st.target_gain) / B;
-                    st.is_clipping = 1;
-                    st.themax = b;
-                    st.gain -= st.delta;
-                } else if (ir == st.index_start) {
-                    const double clip_gain = q.limit / st.themax;
-                    st.target_gain = rg > clip_gain ? clip_gain : rg;
-                    st.themax = b;
-                    st.gain = st.gain * (1.0 - q.time_release) + st.target_gain * q.time_release;
-                } else {
-                    if (st.themax < b) st.themax = b;
-                    st.gain = st.gain * (1.0 - q.time_release) + st.target_gain * q.time_release;
-                }
-            } else {
-                if (b > st.themax) {
-                    st.themax = b;
-                    st.target_gain = q.limit / b;
-                    const double dtmp = (st.gain - st.target_gain) / B;
-                    if (dtmp > st.delta) st.delta = dtmp;
-                }
-                st.gain -= st.delta;
-                if (st.gain <= st.target_gain) {
-                    st.is_clipping = 0;
-                    st.gain = st.target_gain;
-                    st.themax = b;
-                    st.index_start = ir;
-                }
-            }
+            qagc_step(st, lane_bcast(bm, i), ir, q.limit, q.time_release, rg, B);
         }
-        st.index_read += cnt;
-        if (st.index_read >= B) st.index_read -= B;
+        index_read += cnt;
+        if (index_read >= B) index_read -= B;
         if (lane < cnt) {
             double2 o = make_double2(d.x * mygain, d.y * mygain);
             const double om = q.is_cpx ? hypot(o.x, o.y) : fabs(o.x);
             if (om > kClip32) { o.x /= om; o.y /= om; }     // quisk.c:2204-2205
-            p[base + lane] = o;
+            o_[base + lane] = o;
         }
     }
-    if (lane == 0) state[ch] = st;
+    if (lane == 0) {
+        QAgcState s2;
+        s2.index_read = index_read; s2.index_start = st.is; s2.is_clipping = st.clip; s2.pad = 0;
+        s2.themax = st.mx; s2.gain = st.g; s2.delta = st.d; s2.target_gain = st.T;
+        state[ch] = s2;
+    }
+}
+
+// ---- the same state machine, the two regimes as chains -----------------------------------------------------------------------------
+// Outside an overload the gain follows g <- fl(fl(g (1 - r)) + fl(T r)) with T fixed until the FIFO cycle's first sample; inside
+// one, g <- fl(g - delta).  Nothing else sits on the path from one sample's gain to the next, so a chunk of 64 samples is taken as
+// a chain of those two (one) instructions with the EXEC mask shrinking by one lane per step: lane j ends up holding the gain AHEAD
+// of sample j, every rounding the reference's.  The events -- a sample that would exceed the limit, a new largest sample inside a
+// ramp, the ramp's end, the cycle's first sample -- are then found with one ballot over the lanes, everything ahead of the first
+// one is accepted, and that sample is one qagc_step.  8 cycles per sample instead of the ~150 of stepping the whole machine.
+//
+// gl: per lane; lanes p + 1 .. get 1, 2, .. steps (the chain stops after `steps`).  p wave-uniform.
+__device__ __forceinline__ double qagc_chain_relax(double g, double a, double c, int p, int steps)
+{
+    unsigned long long m = p >= 63 ? 0ull : ~0ull << (p + 1), sv;
+    double gl = g;
+    while (steps > 0 && m) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m]\n\t"
+                     ".rept 8\n\t"
+                     "v_mul_f64 %[g], %[g], %[a]\n\t"
+                     "v_add_f64 %[g], %[g], %[c]\n\t"
+                     "s_lshl_b64 exec, exec, 1\n\t"
+                     ".endr\n\t"
+                     "s_mov_b64 %[m], exec\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [g] "+v"(gl), [m] "+s"(m), [sv] "=&s"(sv)
+                     : [a] "v"(a), [c] "v"(c)
+                     : "scc");
+        steps -= 8;
+    }
+    return gl;
+}
+__device__ __forceinline__ double qagc_chain_ramp(double g, double nd, int p, int steps)
+{
+    unsigned long long m = p >= 63 ? 0ull : ~0ull << (p + 1), sv;
+    double gl = g;
+    while (steps > 0 && m) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m]\n\t"
+                     ".rept 8\n\t"
+                     "v_add_f64 %[g], %[g], %[nd]\n\t"
+                     "s_lshl_b64 exec, exec, 1\n\t"
+                     ".endr\n\t"
+                     "s_mov_b64 %[m], exec\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [g] "+v"(gl), [m] "+s"(m), [sv] "=&s"(sv)
+                     : [nd] "v"(nd)
+                     : "scc");
+        steps -= 8;
+    }
+    return gl;
+}
+
+// The largest of b over the lanes of `acc`, given that at least one of them is above `floor_` (records are few: a ballot per record
+// instead of a six-round butterfly through the LDS crossbar).
+__device__ __forceinline__ double qagc_max_above(double b, bool acc, double floor_)
+{
+    double m = floor_;
+    unsigned long long above = __ballot(acc && b > m);
+    while (above) {
+        m = lane_bcast(b, __ffsll((long long)above) - 1);
+        above = __ballot(acc && b > m);
+    }
+    return m;
+}
+
+struct QAgcChainPrm { double limit, tr, a, rg; int B; };
+
+// One chunk: cnt <= 64 samples with magnitudes bm in the lanes, the first written to FIFO index index_read.  Returns, per lane, the
+// gain its sample's FIFO output is multiplied by (the gain ahead of that sample's step).
+__device__ __forceinline__ double qagc_chunk_exact(QAgcLane &st, double bm, int cnt, int index_read, int lane, const QAgcChainPrm &w)
+{
+#pragma clang fp contract(off)
+    const int B = w.B;
+    double mygain = 0.0;
+    int p = 0;
+    while (p < cnt) {
+        int irp = index_read + p;
+        if (irp >= B) irp -= B;
+        if (st.clip == 0) {
+            int c = st.is - irp;                 // samples ahead of the cycle's first one
+            if (c < 0) c += B;
+            const int e = __builtin_amdgcn_readfirstlane(p + c < cnt ? p + c : cnt);
+            if (e > p) {
+                const double cT = st.T * w.tr;
+                const double gl = qagc_chain_relax(st.g, w.a, cT, p, e - p - 1);
+                const bool in = lane >= p && lane < e;
+                const unsigned long long trig = __ballot(in && bm * gl > w.limit);
+                const int k = trig ? __ffsll((long long)trig) - 1 : e;
+                const bool acc = lane >= p && lane < k;
+                if (acc || lane == k) mygain = gl;
+                st.mx = qagc_max_above(bm, acc, st.mx);
+                if (k < e) {
+                    st.g = lane_bcast(gl, k);
+                    int irk = index_read + k;
+                    if (irk >= B) irk -= B;
+                    qagc_step(st, lane_bcast(bm, k), irk, w.limit, w.tr, w.rg, B);       // the overload begins
+                    p = k + 1;
+                } else {
+                    const double gq = lane_bcast(gl, e - 1);
+                    st.g = gq * w.a + cT;
+                    p = e;
+                }
+            } else {
+                if (lane == p) mygain = st.g;
+                qagc_step(st, lane_bcast(bm, p), irp, w.limit, w.tr, w.rg, B);           // the cycle's first sample: a new target
+                p++;
+            }
+        } else {
+            const unsigned long long nm = __ballot(lane >= p && lane < cnt && bm > st.mx);
+            const int k1 = nm ? __ffsll((long long)nm) - 1 : cnt;
+            if (k1 > p) {
+                const double gl = qagc_chain_ramp(st.g, -st.d, p, k1 - p - 1);
+                const double after = gl - st.d;
+                const bool in = lane >= p && lane < k1;
+                const unsigned long long ex = __ballot(in && after <= st.T);
+                if (ex) {
+                    const int jx = __ffsll((long long)ex) - 1;
+                    if (lane >= p && lane <= jx) mygain = gl;
+                    int irx = index_read + jx;
+                    if (irx >= B) irx -= B;
+                    st.clip = 0; st.g = st.T; st.mx = lane_bcast(bm, jx); st.is = irx;      // quisk.c:2257-2265
+                    p = jx + 1;
+                } else {
+                    if (in) mygain = gl;
+                    st.g = lane_bcast(after, k1 - 1);
+                    p = k1;
+                }
+            } else {
+                if (lane == p) mygain = st.g;
+                qagc_step(st, lane_bcast(bm, p), irp, w.limit, w.tr, w.rg, B);           // a new largest sample inside the ramp
+                p++;
+            }
+        }
+        p = __builtin_amdgcn_readfirstlane(p);
+        st.clip = __builtin_amdgcn_readfirstlane(st.clip);
+        st.is = __builtin_amdgcn_readfirstlane(st.is);
+    }
+    return mygain;
+}
+
+// D chunks of input and FIFO output are in flight while one is stepped: chunk c + D's FIFO entries were written B - 64 D samples
+// ahead of chunk c, so D <= B / 64 - 1 (the host picks D).
+template <int D>
+__global__ __launch_bounds__(64) void q_agc_chain_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
+                                                         QAgcState *state, double2 *ring, const double *release_gain, QAgcParam q)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    const double2 *x = src + (long long)ch * sstride;
+    double2 *y = dst + (long long)ch * dstride;
+    double2 *rb = ring + (long long)ch * q.buf_size;
+    const QAgcState st0 = state[ch];
+    QAgcLane st = qagc_lane_of(st0);
+    int index_read = st0.index_read;
+    const QAgcChainPrm w{ q.limit, q.time_release, 1.0 - q.time_release, release_gain[ch], q.buf_size };
+    const int B = q.buf_size;
+    // (loads with clamped indices instead of predicates: a predicated load keeps its old register alive through a copy, and the copy
+    // waits for every load in flight)
+    double2 zq[D], dq[D];
+    int rq = index_read + lane;                  // FIFO index of the chunk being loaded, this lane
+    if (rq >= B) rq -= B;
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const int i = u * 64 + lane;
+        zq[u] = x[i < n ? i : n - 1];
+        dq[u] = rb[rq];
+        rq += 64;
+        if (rq >= B) rq -= B;
+    }
+    int ri = index_read + lane;
+    if (ri >= B) ri -= B;
+    for (int base0 = 0; base0 < n; base0 += 64 * D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const int base = base0 + 64 * u;
+            const int left = n - base, cnt = left < 64 ? left : 64;
+            const double2 z = zq[u], d = dq[u];
+            if (lane < cnt) rb[ri] = z;              // "write new sample at read index"
+            ri += 64;
+            if (ri >= B) ri -= B;
+            if (cnt > 0) {
+                const double bm = qagc_mag(z, q.is_cpx);
+                const double mygain = qagc_chunk_exact(st, bm, cnt, index_read, lane, w);
+                index_read += cnt;
+                if (index_read >= B) index_read -= B;
+                if (lane < cnt) {
+                    double2 o = make_double2(d.x * mygain, d.y * mygain);
+                    const double om = q.is_cpx ? hypot(o.x, o.y) : fabs(o.x);
+                    if (om > kClip32) { o.x /= om; o.y /= om; }     // quisk.c:2204-2205
+                    y[base + lane] = o;
+                }
+            }
+            {   // chunk base + 64 D into the registers this chunk has just finished with (no copies at the loop's end)
+                const int i = base + 64 * D + lane;
+                zq[u] = x[i < n ? i : n - 1];
+                dq[u] = rb[rq];
+                rq += 64;
+                if (rq >= B) rq -= B;
+            }
+        }
+    }
+    if (lane == 0) {
+        QAgcState s2;
+        s2.index_read = index_read; s2.index_start = st.is; s2.is_clipping = st.clip; s2.pad = 0;
+        s2.themax = st.mx; s2.gain = st.g; s2.delta = st.d; s2.target_gain = st.T;
+        state[ch] = s2;
+    }
 }
 
 }  // namespace
@@ -107,6 +341,7 @@ struct qh_qagc {
     bool gain_dirty = true;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int form = 0;                   // diagnostics, see qh_qagc_debug_form
     ~qh_qagc()
     {
         (void)hipSetDevice(device);
@@ -189,20 +424,41 @@ int qh_qagc_reset(qh_qagc *h)
     return qagc_init_state(h);
 }
 
-int qh_qagc_process(qh_qagc *h, void *d_buf, long long stride, int n)
+// src -> dst (two buffers, or the same one): process_agc(dat, cSamples, count, is_cpx) for every stream
+int qh_qagc_process2(qh_qagc *h, const void *d_src, long long src_stride, void *d_dst, long long dst_stride, int n)
 {
-    if (!h || n < 0 || (n > 0 && (!d_buf || stride < n))) return set_error(QH_ERR_INVALID, "qh_qagc_process: bad arguments");
+    if (!h || n < 0 || (n > 0 && (!d_src || !d_dst || src_stride < n || dst_stride < n)))
+        return set_error(QH_ERR_INVALID, "qh_qagc_process: bad arguments");
     if (n == 0) return QH_OK;
-    if (!h->inited) { h->inited = true; return QH_OK; }            // first call: state set up, samples untouched
     QH_HIP(hipSetDevice(h->device));
+    if (!h->inited) {               // first call: state set up, samples untouched
+        h->inited = true;
+        if (d_src != d_dst)
+            QH_HIP(hipMemcpy2DAsync(d_dst, (size_t)dst_stride * 16, d_src, (size_t)src_stride * 16, (size_t)n * 16, (size_t)h->nch,
+                                    hipMemcpyDeviceToDevice, h->stream));
+        return QH_OK;
+    }
     if (h->gain_dirty) {
         QH_HIP(hipMemcpyAsync(h->gain, h->h_gain.data(), (size_t)h->nch * sizeof(double), hipMemcpyHostToDevice, h->stream));
         QH_HIP(hipStreamSynchronize(h->stream));
         h->gain_dirty = false;
     }
-    hipLaunchKernelGGL(q_agc_kernel, dim3((unsigned)h->nch), dim3(64), 0, h->stream, (double2 *)d_buf, stride, n, h->state, h->ring,
-                       h->gain, h->prm);
+    // chunks in flight: D <= B / 64 - 1 (q_agc_chain_kernel); a FIFO of 64 .. 127 samples takes the plain kernel
+    const int B = h->prm.buf_size;
+    auto *kern = h->form == 1 || B < 128 ? q_agc_kernel : B >= 320 ? q_agc_chain_kernel<4> : q_agc_chain_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)h->nch), dim3(64), 0, h->stream, (const double2 *)d_src, src_stride, (double2 *)d_dst, dst_stride, n,
+                       h->state, h->ring, h->gain, h->prm);
     QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+int qh_qagc_process(qh_qagc *h, void *d_buf, long long stride, int n) { return qh_qagc_process2(h, d_buf, stride, d_buf, stride, n); }
+
+// diagnostics: 0 the two regimes as chains (default), 1 the whole machine sample by sample (bit-identical, ~9 times slower)
+int qh_qagc_debug_form(qh_qagc *h, int form)
+{
+    if (!h || form < 0 || form > 1) return set_error(QH_ERR_INVALID, "qh_qagc_debug_form: bad arguments");
+    h->form = form;
     return QH_OK;
 }
 

@@ -169,6 +169,8 @@ def load():
     L.qh_qagc_reset.argtypes = [vp]
     L.qh_qagc_set_cpx.argtypes = [vp, i]
     L.qh_qagc_process.argtypes = [vp, vp, ll, i]
+    L.qh_qagc_process2.argtypes = [vp, vp, ll, vp, ll, i]
+    L.qh_qagc_debug_form.argtypes = [vp, i]
     L.qh_qagc_process_host.argtypes = [vp, vp, ll, i]
     L.qh_ana_create.restype = vp
     L.qh_ana_create.argtypes = [i, i, i, i, vp]

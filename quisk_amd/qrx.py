@@ -118,6 +118,14 @@ class QuiskAgc:
     def process_ptr(self, d_buf, stride, n):
         check(self._L.qh_qagc_process(self._h, d_buf, stride, n))
 
+    def process2_ptr(self, d_src, src_stride, d_dst, dst_stride, n):
+        """from one device buffer into another"""
+        check(self._L.qh_qagc_process2(self._h, d_src, src_stride, d_dst, dst_stride, n))
+
+    def debug_form(self, form):
+        """diagnostics: 0 = the two regimes as instruction chains (default), 1 = the whole machine sample by sample (bit-identical)"""
+        check(self._L.qh_qagc_debug_form(self._h, int(form)))
+
     def process_host(self, x):
         buf = np.ascontiguousarray(x, dtype=np.complex128).copy()
         if buf.ndim != 2 or buf.shape[0] != self.nch:
