@@ -192,9 +192,11 @@ def other_configs(torch, dev):
     try:
         r = bc.quisk_native(torch, qh, dev)
         out["quisk_native"] = {"workload": r["config"], "samples_per_step": r["samples_per_step"], "algorithmic_bytes_per_sample": 20.0,
-                               "modes": [{"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
-                                          "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
-                                          "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS} for m in r["modes"]],
+                               "modes": [dict({"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
+                                               "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
+                                               "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS},
+                                              **{k: m[k] for k in ("agc_on_ms", "agc_on_Msamp_per_s") if k in m}) for m in r["modes"]],
+                               "agc_note": "agc_on_*: process_agc (quisk.c:2162) on the output, one wavefront per receiver (q_agc_chain_kernel)",
                                "dominant_kernel": "osfir_kernel<f64,4096,D=8,OUTMIX> (tune + collapsed 1181-tap /16)"}
     except Exception as exc:
         out["quisk_native"] = {"failed": repr(exc)}

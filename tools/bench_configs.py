@@ -178,7 +178,13 @@ def quisk_native(torch, qh, dev):
         y = torch.empty((nch, m + 64), dtype=torch.complex128, device=dev)
         sync = lambda: torch.cuda.synchronize(dev)
         t = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), m + 64), sync, steps=8, warmup=2)
-        out.append({"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": rate, "filter_taps": int(fI.size)})
+        row = {"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": rate, "filter_taps": int(fI.size)}
+        # process_agc on the output, as quisk_process_samples always runs it (quisk.c:2685-2701); a release gain at which the
+        # limiter works (an overload ramp every few FIFO cycles): the state machine is sequential per receiver, one wavefront each
+        bank.set_agc(True, 5000.0)
+        ta = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), m + 64), sync, steps=6, warmup=2)
+        row.update({"agc_on_ms": ta * 1e3, "agc_on_Msamp_per_s": nch * n / ta / 1e6})
+        out.append(row)
         del bank, x, y
     return {"config": "Quisk-native chain (path A): 256 receivers x 192 ksps -> 48 ksps, 2^20 input samples per receiver per step",
             "samples_per_step": nch * n, "modes": out,
