@@ -134,6 +134,20 @@ __device__ __forceinline__ double qagc_chain_relax(double g, double a, double c,
 {
     unsigned long long m = p >= 63 ? 0ull : ~0ull << (p + 1), sv;
     double gl = g;
+    if (steps >= 56) {          // (nearly) a whole chunk: 63 steps straight, no loop around them
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m]\n\t"
+                     ".rept 63\n\t"
+                     "v_mul_f64 %[g], %[g], %[a]\n\t"
+                     "v_add_f64 %[g], %[g], %[c]\n\t"
+                     "s_lshl_b64 exec, exec, 1\n\t"
+                     ".endr\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [g] "+v"(gl), [sv] "=&s"(sv)
+                     : [a] "v"(a), [c] "v"(c), [m] "s"(m)
+                     : "scc");
+        return gl;
+    }
     while (steps > 0 && m) {
         asm volatile("s_mov_b64 %[sv], exec\n\t"
                      "s_mov_b64 exec, %[m]\n\t"
@@ -155,6 +169,19 @@ __device__ __forceinline__ double qagc_chain_ramp(double g, double nd, int p, in
 {
     unsigned long long m = p >= 63 ? 0ull : ~0ull << (p + 1), sv;
     double gl = g;
+    if (steps >= 56) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m]\n\t"
+                     ".rept 63\n\t"
+                     "v_add_f64 %[g], %[g], %[nd]\n\t"
+                     "s_lshl_b64 exec, exec, 1\n\t"
+                     ".endr\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [g] "+v"(gl), [sv] "=&s"(sv)
+                     : [nd] "v"(nd), [m] "s"(m)
+                     : "scc");
+        return gl;
+    }
     while (steps > 0 && m) {
         asm volatile("s_mov_b64 %[sv], exec\n\t"
                      "s_mov_b64 exec, %[m]\n\t"
@@ -328,6 +355,104 @@ __global__ __launch_bounds__(64) void q_agc_chain_kernel(const double2 *src, lon
     }
 }
 
+// Two wavefronts per stream: wave 0 steps (magnitudes in, gains out, through LDS); wave 1 moves -- while chunk c is stepped it
+// writes chunk c + 1 to the FIFO and takes its magnitudes, and multiplies chunk c - 1's FIFO output by its gains and stores it.  Four register slots take turns: the slot of the chunk just stored receives the loads of chunk c + 3.
+// FIFO entries read two chunks ahead of their use were written at least B - 128 samples earlier and the call's first three chunks
+// must be old entries, so B >= 192.
+__global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
+                                                         QAgcState *state, double2 *ring, const double *release_gain, QAgcParam q)
+{
+    __shared__ double s_bm[2][64], s_gain[2][64];
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = q.buf_size, nchunks = (n + 63) >> 6;
+    const QAgcState st0 = state[ch];
+    if (wave == 0) {
+        QAgcLane st = qagc_lane_of(st0);
+        int index_read = st0.index_read;
+        const QAgcChainPrm w{ q.limit, q.time_release, 1.0 - q.time_release, release_gain[ch], B };
+        __syncthreads();                             // chunk 0's magnitudes are there
+        for (int c = 0; c < nchunks; c++) {
+            const int left = n - c * 64, cnt = left < 64 ? left : 64;
+            const double bm = s_bm[c & 1][lane];
+            s_gain[c & 1][lane] = qagc_chunk_exact(st, bm, cnt, index_read, lane, w);
+            index_read += cnt;
+            if (index_read >= B) index_read -= B;
+            __syncthreads();
+        }
+        if (lane == 0) {
+            QAgcState s2;
+            s2.index_read = index_read; s2.index_start = st.is; s2.is_clipping = st.clip; s2.pad = 0;
+            s2.themax = st.mx; s2.gain = st.g; s2.delta = st.d; s2.target_gain = st.T;
+            state[ch] = s2;
+        }
+        return;
+    }
+    const double2 *x = src + (long long)ch * sstride;
+    double2 *y = dst + (long long)ch * dstride;
+    double2 *rb = ring + (long long)ch * B;
+    double2 zq[4], dq[4];
+    int rq = st0.index_read + lane;                  // FIFO index of the chunk being loaded, this lane
+    if (rq >= B) rq -= B;
+    int ri = rq;                                     // ... of the chunk being written
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const int i = u * 64 + lane;
+        zq[u] = x[i < n ? i : n - 1];
+        dq[u] = rb[rq];
+        rq += 64;
+        if (rq >= B) rq -= B;
+    }
+    zq[3] = dq[3] = make_double2(0, 0);
+    auto prepare = [&](int c, const double2 &z) {    // chunk c: into the FIFO, its magnitudes to the stepper
+        if (c * 64 + lane < n) rb[ri] = z;           // "write new sample at read index"
+        ri += 64;
+        if (ri >= B) ri -= B;
+        s_bm[c & 1][lane] = qagc_mag(z, q.is_cpx);
+    };
+    prepare(0, zq[0]);
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunks; c0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c0 + u;
+            if (c < nchunks) {
+                if (c + 1 < nchunks) prepare(c + 1, zq[(u + 1) & 3]);
+                if (c >= 1) {                        // chunk c - 1: its FIFO output times the gains the stepper left
+                    const int base = (c - 1) * 64;
+                    const double g = s_gain[(c - 1) & 1][lane];
+                    const double2 d = dq[(u + 3) & 3];
+                    double2 o = make_double2(d.x * g, d.y * g);
+                    const double om = q.is_cpx ? hypot(o.x, o.y) : fabs(o.x);
+                    if (om > kClip32) { o.x /= om; o.y /= om; }     // quisk.c:2204-2205
+                    y[base + lane] = o;              // (base + lane < n: chunk c - 1 is a full one)
+                }
+                {   // chunk c + 3 into the slot chunk c - 1 has just left
+                    const int i = (c + 3) * 64 + lane;
+                    zq[(u + 3) & 3] = x[i < n ? i : n - 1];
+                    dq[(u + 3) & 3] = rb[rq];
+                    rq += 64;
+                    if (rq >= B) rq -= B;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    {   // the last chunk
+        const int c = nchunks - 1, base = c * 64;
+        if (base + lane < n) {
+            const double g = s_gain[c & 1][lane];
+            double2 d = dq[0];                       // (slot c & 3, picked by value: an indexed register array would live in scratch)
+            if ((c & 3) == 1) d = dq[1];
+            if ((c & 3) == 2) d = dq[2];
+            if ((c & 3) == 3) d = dq[3];
+            double2 o = make_double2(d.x * g, d.y * g);
+            const double om = q.is_cpx ? hypot(o.x, o.y) : fabs(o.x);
+            if (om > kClip32) { o.x /= om; o.y /= om; }
+            y[base + lane] = o;
+        }
+    }
+}
+
 }  // namespace
 
 struct qh_qagc {
@@ -445,8 +570,8 @@ int qh_qagc_process2(qh_qagc *h, const void *d_src, long long src_stride, void *
     }
     // chunks in flight: D <= B / 64 - 1 (q_agc_chain_kernel); a FIFO of 64 .. 127 samples takes the plain kernel
     const int B = h->prm.buf_size;
-    auto *kern = h->form == 1 || B < 128 ? q_agc_kernel : B >= 320 ? q_agc_chain_kernel<4> : q_agc_chain_kernel<1>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)h->nch), dim3(64), 0, h->stream, (const double2 *)d_src, src_stride, (double2 *)d_dst, dst_stride, n,
+    auto *kern = h->form == 1 || B < 128 ? q_agc_kernel : B >= 192 ? q_agc_pair_kernel : q_agc_chain_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)h->nch), dim3(kern == q_agc_pair_kernel ? 128 : 64), 0, h->stream, (const double2 *)d_src, src_stride, (double2 *)d_dst, dst_stride, n,
                        h->state, h->ring, h->gain, h->prm);
     QH_HIP(hipGetLastError());
     return QH_OK;
