@@ -32,3 +32,23 @@ for in_size, in_rate in ((256, 48000), (1024, 192000), (4096, 192000)):
     lib.qh_wdsp_graph_launches.restype = C.c_longlong
     print("   blocks replayed from hipGraphs so far:", lib.qh_wdsp_graph_launches())
     lib.CloseChannel(ch)
+
+# quisk_process_samples (the Quisk-native drop-in, include/quiskhip.h group 9): one receiver, host buffer in place, USB, process_agc on
+from quisk_amd import quiskapi as QS, rxfilter      # noqa: E402
+for fs, blk in ((48000, 1024), (192000, 4096)):
+    QS.open(fs, playback_rate=48000)
+    QS.set_rx_mode(rxfilter.USB); QS.set_tune(5000)
+    fI, fQ = rxfilter.make_filter_coef(QS.get_filter_rate(), None, 2700, rxfilter.get_filter_center("USB", 2700))
+    QS.set_filters(fI, fQ, 2700); QS.set_agc(5000.0)
+    rng = np.random.default_rng(1)
+    x = ((rng.standard_normal(blk) + 1j * rng.standard_normal(blk)) * 2.0 ** 22).astype(np.complex128)
+    buf = np.zeros(blk + 4096, dtype=np.complex128)
+    for _ in range(50):
+        buf[:blk] = x; QS.process_samples(buf, blk)
+    n = 500
+    t0 = time.perf_counter()
+    for _ in range(n):
+        buf[:blk] = x; QS.process_samples(buf, blk)
+    dt = (time.perf_counter() - t0) / n
+    print("quisk_process_samples %5d @ %6d Hz: %7.1f us per call = %5.2f %% of real time" % (blk, fs, dt * 1e6, 100 * dt / (blk / fs)))
+    QS.close()
