@@ -31,7 +31,7 @@ static __global__ __launch_bounds__(64) void q_am_env_kernel(double2 *buf, long 
 // Pass 1 of the two-pass kernels below needs a segment's response to its own samples only as far back as the pole remembers:
 // contributions older than kTail batches are below pole^(64 kTail) <= 1e-22 of full scale, far under the last bit of what they are
 // added to.  Batches of a segment ahead of that are skipped in pass 1 (a segment shorter than the tail is walked whole: exact).
-__device__ __forceinline__ int seg_tail_batches(double pole)
+__host__ __device__ __forceinline__ int seg_tail_batches(double pole)
 {
     const double t = -50.66 / (64.0 * log(fabs(pole)));        // ln 1e-22 = -50.66
     return t < 1.0e6 ? (int)t + 1 : 1000000;
@@ -146,101 +146,71 @@ __device__ __forceinline__ void q_squelch_update(QSquelchState *state, const dou
     state[ch] = st;
 }
 
-// sq_state != nullptr: the FM squelch's sum of |cx| over the call rides on pass 2, which reads the same samples (a separate
-// q_fm_squelch_kernel launch read the call a second time: 0.25 of the FM mode's 3.5 ms at 256 receivers).
-static __global__ __launch_bounds__(kSegThreads) void q_fm_disc_tiled_kernel(double2 *buf, long long stride, int n, double4 *state, QFmParam q,
-                                                                               QSquelchState *sq_state, const double *sq_level)
+// The same detector for long calls, over a grid of time segments: one wavefront per segment of seg_b batches of 64 samples.  The
+// discriminator needs the two samples ahead of a segment, the de-emphasis (pole 0.96) what the tail_b batches ahead of it leave
+// (seg_tail_batches: older input is below 1e-22 of full scale) -- a wavefront walks those first from a zero state without storing,
+// a segment that begins within tail_b batches of the call's start walks from sample 0 and the carried state and is exact.
+// src != dst: the neighbours' samples are read while they write.  The squelch's sum of |cx| (quisk.c:2032) rides along, one
+// partial sum per segment; q_fm_disc_finish_kernel adds them in order and moves the new state in.
+// grid (segments / 4 rounded up, receivers), 256 threads.
+static __global__ __launch_bounds__(256) void q_fm_disc_grid_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
+                                                                   const double4 *state, double4 *state_new, QFmParam q, int seg_b, int tail_b,
+                                                                   double *sq_part, int nseg)
 {
-    __shared__ double s_sq[kSegWaves];
-    __shared__ double s_e[kSegWaves], s_z[kSegWaves][3];
-    __shared__ int s_n[kSegWaves];
-    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double2 *p = buf + (long long)ch * stride;
-    const double4 st0 = state[ch];
+    const int ch = blockIdx.y, lane = threadIdx.x & 63, seg = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long s0 = (long long)seg * seg_b * 64;
+    if (s0 >= n) return;
+    const double2 *p = src + (long long)ch * sstride;
+    double2 *o = dst + (long long)ch * dstride;
+    const long long s1 = s0 + (long long)seg_b * 64 < n ? s0 + (long long)seg_b * 64 : n;
+    long long start = s0 - (long long)tail_b * 64;
     const double pole = -q.b1;
-    int b0, b1;
-    seg_range(n, wave, b0, b1);
     const PoleScan sc = make_pole_scan(pole, lane);
-    const double m64 = lane_pow(pole, 64);
-    auto z_at = [&](int i) -> double2 { return i >= 0 ? p[i] : make_double2(st0.x, st0.y); };
     auto disc = [&](double2 z, double2 zp) -> double { return atan2(z.y * zp.x - z.x * zp.y, z.x * zp.x + z.y * zp.y) * 20e5; };
-    // the sample ahead of the segment and its discriminator value
-    const int i0 = b0 * 64;
-    double2 zc = z_at(i0 - 1);
-    double dc = i0 >= 1 ? disc(zc, z_at(i0 - 2)) : st0.z;
-    const double2 zc0 = zc;
-    const double dc0 = dc;
-    double acc = 0.0;
-    double2 zn[kSegGroup];
-    // pass 1 over the tail of the segment that the de-emphasis still remembers at its end (seg_tail_batches)
-    const int tail = seg_tail_batches(pole), bs = b1 - b0 > tail ? b1 - tail : b0;
-    if (bs > b0) { zc = z_at(bs * 64 - 1); dc = disc(zc, z_at(bs * 64 - 2)); }
-    seg_load(zn, bs, b1, n, lane, (const double2 *)p);
-    for (int b = bs; b < b1; b += kSegGroup) {
-        double2 zz[kSegGroup];
-#pragma unroll
-        for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
-        seg_load(zn, b + kSegGroup, b1, n, lane, (const double2 *)p);
-#pragma unroll
-        for (int k = 0; k < kSegGroup; k++) {
-            if (b + k >= b1) break;
-            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
-            const double2 z = zz[k];
-            double2 zp = make_double2(wave_shr1(z.x), wave_shr1(z.y));
-            if (lane == 0) zp = zc;
-            const double di = disc(z, zp);
-            double dm1 = wave_shr1(di);
-            if (lane == 0) dm1 = dc;
-            acc = __builtin_fma(acc, m64, lane < cnt ? di * q.a0 + dm1 * q.a1 : 0.0);
-            zc = make_double2(lane_bcast(z.x, cnt - 1), lane_bcast(z.y, cnt - 1));
-            dc = lane_bcast(di, cnt - 1);
-        }
+    double2 zc;
+    double dc, c;
+    if (start <= 0) {
+        const double4 st0 = state[ch];
+        start = 0; zc = make_double2(st0.x, st0.y); dc = st0.z; c = st0.w;
+    } else {
+        zc = p[start - 1]; dc = disc(zc, p[start - 2]); c = 0.0;
     }
-    const double e = wave_sum_d(acc * lane_pow(pole, 63 - lane));
-    if (lane == 0) { s_e[wave] = e; s_n[wave] = seg_samples(n, b0, b1); s_z[wave][0] = zc.x; s_z[wave][1] = zc.y; s_z[wave][2] = dc; }
-    __syncthreads();
-    double c = st0.w;
-    for (int w = 0; w < wave; w++) if (s_n[w]) c = __builtin_fma(c, pow(pole, (double)s_n[w]), s_e[w]);
-    // pass 2 (zc0 / dc0 were read before anybody wrote)
-    zc = zc0; dc = dc0;
     double sq = 0.0;
-    seg_load(zn, b0, b1, n, lane, (const double2 *)p);
-    for (int b = b0; b < b1; b += kSegGroup) {
-        double2 zz[kSegGroup];
-#pragma unroll
-        for (int k = 0; k < kSegGroup; k++) zz[k] = zn[k];
-        seg_load(zn, b + kSegGroup, b1, n, lane, (const double2 *)p);
-#pragma unroll
-        for (int k = 0; k < kSegGroup; k++) {
-            if (b + k >= b1) break;
-            const int base = (b + k) * 64, cnt = n - base < 64 ? n - base : 64;
-            const double2 z = zz[k];
-            double2 zp = make_double2(wave_shr1(z.x), wave_shr1(z.y));
-            if (lane == 0) zp = zc;
-            const double di = disc(z, zp);
-            double dm1 = wave_shr1(di);
-            if (lane == 0) dm1 = dc;
-            const double y = scan_pole_dpp(lane < cnt ? di * q.a0 + dm1 * q.a1 : 0.0, sc) + sc.pw * c;
-            if (sq_state && lane < cnt) sq += hypot(z.x, z.y);
-            if (lane < cnt) p[base + lane] = make_double2(y, 0.0);
-            c = lane_bcast(y, cnt - 1);
-            zc = make_double2(lane_bcast(z.x, cnt - 1), lane_bcast(z.y, cnt - 1));
-            dc = lane_bcast(di, cnt - 1);
+    double2 zn = start + lane < n ? p[start + lane] : make_double2(0.0, 0.0);
+    for (long long base = start; base < s1; base += 64) {
+        const int cnt = (int)(n - base < 64 ? n - base : 64);
+        const double2 z = zn;
+        if (base + 64 < s1) zn = base + 64 + lane < n ? p[base + 64 + lane] : make_double2(0.0, 0.0);       // the next batch is on its way
+        double2 zp = make_double2(wave_shr1(z.x), wave_shr1(z.y));
+        if (lane == 0) zp = zc;
+        const double di = disc(z, zp);
+        double dm1 = wave_shr1(di);
+        if (lane == 0) dm1 = dc;
+        const double y = scan_pole_dpp(lane < cnt ? di * q.a0 + dm1 * q.a1 : 0.0, sc) + sc.pw * c;
+        if (base >= s0 && lane < cnt) {
+            o[base + lane] = make_double2(y, 0.0);
+            sq += hypot(z.x, z.y);
         }
+        c = lane_bcast(y, cnt - 1);
+        zc = make_double2(lane_bcast(z.x, cnt - 1), lane_bcast(z.y, cnt - 1));
+        dc = lane_bcast(di, cnt - 1);
     }
-    int last = kSegWaves - 1;
-    while (last > 0 && s_n[last] == 0) last--;
-    if (wave == last && lane == 0 && n > 0) state[ch] = make_double4(zc.x, zc.y, dc, c);
-    if (sq_state) {                         // lanes -> wavefront -> segments in order
-        sq = wave_sum_d(sq);
-        if (lane == 0) s_sq[wave] = sq;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int w = 0; w < kSegWaves; w++) s += s_sq[w];
-            q_squelch_update(sq_state, sq_level, ch, s, n);
-        }
+    sq = wave_sum_d(sq);
+    if (lane == 0) {
+        sq_part[(long long)ch * nseg + seg] = sq;
+        if (s1 == n) state_new[ch] = make_double4(zc.x, zc.y, dc, c);
     }
+}
+// one thread per receiver: the squelch from the segments' sums in order (quisk.c:2076-2085), the detector's new state
+static __global__ void q_fm_disc_finish_kernel(int nch, double4 *state, const double4 *state_new, const double *sq_part, int nseg, int n,
+                                               QSquelchState *sq_state, const double *sq_level)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch) return;
+    state[ch] = state_new[ch];
+    double s = 0.0;
+    for (int k = 0; k < nseg; k++) s += sq_part[(long long)ch * nseg + k];
+    q_squelch_update(sq_state, sq_level, ch, s, n);
 }
 
 // FM squelch (quisk.c:2032-2033,2076-2085): the mean |cx| of the Rx-filtered samples over at least 2400 of them

@@ -94,6 +94,9 @@ struct Qrx {
     Stage *rxf = nullptr;           // Rx filter (per-channel taps); owned by its step
     double *dc_state = nullptr;     // AM
     double4 *fm_state = nullptr;    // FM
+    double4 *fm_state_new = nullptr;
+    double *fm_part = nullptr;      // the squelch's partial sums of a long call, one per time segment
+    long long fm_part_cap = 0;
     QFmParam fm_prm{};
     double2 *buf[2] = { nullptr, nullptr };
     long long buf_cap = 0;
@@ -138,7 +141,7 @@ struct Qrx {
             if (s.st) { s.st->destroy(); delete s.st; }
             if (s.rat) qh_rat_destroy(s.rat);
         }
-        (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
+        (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(fm_state_new); (void)hipFree(fm_part); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
         (void)hipFree(sq_state); (void)hipFree(sq_level); (void)hipFree(nb_buf); (void)hipFree(notch_state); (void)hipFree(tw2048);
         (void)hipFree(ssq_state); (void)hipFree(ssq_ring); (void)hipFree(ssq_delay[0]); (void)hipFree(ssq_delay[1]);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -407,6 +410,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
     if (is_fm(mode)) {
         std::vector<double4> init((size_t)nch, make_double4(10.0, 0.0, 0.0, 0.0));          // fm_1 = 10, quisk.c:1893
         if (hipMalloc((void **)&q.fm_state, (size_t)nch * sizeof(double4)) != hipSuccess ||
+            hipMalloc((void **)&q.fm_state_new, (size_t)nch * sizeof(double4)) != hipSuccess ||
             hipMemcpy(q.fm_state, init.data(), (size_t)nch * sizeof(double4), hipMemcpyHostToDevice) != hipSuccess) {
             set_error(QH_ERR_HIP, "allocation failed"); return fail();
         }
@@ -591,11 +595,25 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                     hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                        static_cast<const double2 *>(cur), cur_stride, n, q.sq_state, q.sq_level);
             }
-            if (n >= kQTiledMin)         // long calls: the detector over time segments (qh_qdemod.hpp)
-                hipLaunchKernelGGL(q_fm_disc_tiled_kernel, dim3((unsigned)q.nch), dim3(kSegThreads), 0, q.stream,
-                                   const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm, q.sq_state,
-                                   (const double *)q.sq_level);
-            else if (n > 0)
+            if (n >= kQTiledMin) {       // long calls: the detector over a grid of time segments (qh_qdemod.hpp), into the other buffer
+                const int tail_b = seg_tail_batches(-q.fm_prm.b1);
+                const int seg_b = n >= (1 << 17) ? 128 : 64;
+                const int nseg = (n + seg_b * 64 - 1) / (seg_b * 64);
+                if ((long long)q.nch * nseg > q.fm_part_cap) {
+                    QH_HIP(hipStreamSynchronize(q.stream));
+                    (void)hipFree(q.fm_part); q.fm_part = nullptr;
+                    QH_HIP(hipMalloc((void **)&q.fm_part, (size_t)q.nch * (size_t)nseg * 8));
+                    q.fm_part_cap = (long long)q.nch * nseg;
+                }
+                hipLaunchKernelGGL(q_fm_disc_grid_kernel, dim3((unsigned)((nseg + 3) / 4), (unsigned)q.nch), dim3(256), 0, q.stream,
+                                   static_cast<const double2 *>(cur), cur_stride, static_cast<double2 *>(dst), dst_stride, n,
+                                   (const double4 *)q.fm_state, q.fm_state_new, q.fm_prm, seg_b, tail_b, q.fm_part, nseg);
+                hipLaunchKernelGGL(q_fm_disc_finish_kernel, dim3((unsigned)((q.nch + 63) / 64)), dim3(64), 0, q.stream, q.nch, q.fm_state,
+                                   (const double4 *)q.fm_state_new, (const double *)q.fm_part, nseg, n, q.sq_state, (const double *)q.sq_level);
+                m = n;
+                break;
+            }
+            if (n > 0)
                 hipLaunchKernelGGL(q_fm_disc_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
                                    const_cast<double2 *>(static_cast<const double2 *>(cur)), cur_stride, n, q.fm_state, q.fm_prm);
             continue;

@@ -236,10 +236,11 @@ def test_ssb_squelch_and_its_audio_delay(qh, oracle, mode, name, bw):
 @pytest.mark.parametrize("mode", [4, 5])
 def test_detectors_over_time_segments_equal_block_calls(qh, oracle, mode):
     """AM envelope + DC remover and the FM discriminator + de-emphasis (quisk.c:2002-2068): calls of 8192 detector samples and more
-    run them over sixteen time segments per receiver (qh_qdemod.hpp); the same stream in small pieces takes the sequential
-    kernels.  Same audio (FM behind its start-up, see test_modes_and_rates), and against the restatement."""
+    run them over time segments (AM: sixteen per receiver; FM: a grid of 64- or 128-batch segments, qh_qdemod.hpp); the same stream
+    in small pieces takes the sequential kernels.  Same audio (FM behind its start-up, see test_modes_and_rates), and against the
+    restatement."""
     fs, nch = 192000, 2
-    n = 400000                                  # 50 000 (AM) / 100 000 (FM) samples at the detector in the long call
+    n = 400000 if mode == 4 else 560000        # 50 000 (AM) / 140 000 (FM: the 128-batch segments) samples at the detector in the long call
     tabs = rxfilter.coefficient_tables()
     x = np.stack([signal(mode, c, n, fs, 9000.0 + 500 * c) for c in range(nch)])
     outs = []
