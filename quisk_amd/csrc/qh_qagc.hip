@@ -222,6 +222,21 @@ __device__ __forceinline__ double qagc_chunk_exact(QAgcLane &st, double bm, int 
     const int B = w.B;
     double mygain = 0.0;
     int p = 0;
+    if (st.clip == 0 && cnt == 64) {
+        // the common chunk: 64 samples of relaxing, the cycle's first sample not among them, no sample over the limit -- one chain,
+        // two ballots, one branch
+        int c = st.is - index_read;
+        if (c < 0) c += B;
+        if (__builtin_amdgcn_readfirstlane(c) >= 64) {
+            const double cT = st.T * w.tr;
+            const double gl = qagc_chain_relax(st.g, w.a, cT, 0, 63);
+            if (!__ballot(bm * gl > w.limit)) {
+                st.mx = qagc_max_above(bm, true, st.mx);
+                st.g = lane_bcast(gl, 63) * w.a + cT;
+                return gl;
+            }
+        }
+    }
     while (p < cnt) {
         int irp = index_read + p;
         if (irp >= B) irp -= B;
