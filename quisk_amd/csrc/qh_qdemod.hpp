@@ -37,8 +37,9 @@ __host__ __device__ __forceinline__ int seg_tail_batches(double pole)
     return t < 1.0e6 ? (int)t + 1 : 1000000;
 }
 
-// The same over kSegWaves time segments (long calls), as q_fm_disc_tiled_kernel below: pass 1 = each segment's response to its
-// own magnitudes from a zero state, chained; pass 2 = the scan from the true carry and the first difference.
+// The same over kSegWaves time segments, one wavefront each (long calls: the sequential form leaves one wavefront per receiver
+// busy for milliseconds): pass 1 = each segment's response to its own magnitudes from a zero state, chained; pass 2 = the scan
+// from the true carry and the first difference.
 static __global__ __launch_bounds__(kSegThreads) void q_am_env_tiled_kernel(double2 *buf, long long stride, int n, double *dc_state)
 {
     __shared__ double s_e[kSegWaves];
@@ -127,11 +128,6 @@ static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long
 }
 
 
-// The same detector with the call cut into kSegWaves time segments, one wavefront each (long calls: the sequential form leaves one
-// wavefront per receiver busy for milliseconds).  The discriminator needs the sample before it -- from the neighbour lane, the
-// batch before, the segment before (read in place ahead of the barrier: the buffer is only overwritten in pass 2) or the carried
-// state; the de-emphasis is a one-pole recurrence: pass 1 takes each segment's response to its own samples from a zero state
-// (lane-local accumulation, one weighted wave sum), the sixteen are chained, pass 2 runs the scan from the true carry.
 // the squelch's per-call update from the call's sum of |cx| (quisk.c:2076-2085)
 __device__ __forceinline__ void q_squelch_update(QSquelchState *state, const double *level, int ch, double s, int n)
 {
