@@ -5,9 +5,11 @@
 // min(agcReleaseGain, max_out * CLIP32 / largest sample of the last FIFO cycle).  The recurrence is non-linear and
 // sequential: one wavefront per stream, lanes hold 64 consecutive samples and lane i keeps the gain that applied to
 // sample i; the FIFO lives in global memory in the reference's ring order, so a call leaves exactly the reference's
-// state.  Two kernels, bit-identical: q_agc_kernel steps the whole machine sample by sample (every lane the same
-// scalar state); q_agc_chain_kernel, the one that runs, takes the two regimes as chains of the one or two
-// instructions that carry the gain from sample to sample and handles the turns between them with ballots.
+// state.  Three kernels, bit-identical: q_agc_kernel steps the whole machine sample by sample (every lane the same
+// scalar state; FIFOs shorter than 128 samples, and the diagnostic form); q_agc_chain_kernel takes the two regimes as
+// chains of the one or two instructions that carry the gain from sample to sample and handles the turns between them
+// with ballots (FIFOs of 128 .. 191 samples); q_agc_pair_kernel, the one that runs at 12.8 ksps and above, is the same
+// with a second wavefront that moves the samples.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -303,7 +305,7 @@ __device__ __forceinline__ double qagc_chunk_exact(QAgcLane &st, double bm, int 
 }
 
 // D chunks of input and FIFO output are in flight while one is stepped: chunk c + D's FIFO entries were written B - 64 D samples
-// ahead of chunk c, so D <= B / 64 - 1 (the host picks D).
+// ahead of chunk c, so D <= B / 64 - 1 (the host runs D = 1 for FIFOs of 128 .. 191 samples; longer ones take q_agc_pair_kernel).
 template <int D>
 __global__ __launch_bounds__(64) void q_agc_chain_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
                                                          QAgcState *state, double2 *ring, const double *release_gain, QAgcParam q)
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(64) void q_agc_chain_kernel(const double2 *src, lon
 }
 
 // Two wavefronts per stream: wave 0 steps (magnitudes in, gains out, through LDS); wave 1 moves -- while chunk c is stepped it
-// writes chunk c + 1 to the FIFO and takes its magnitudes, and multiplies chunk c - 1's FIFO output by its gains and stores it.  Four register slots take turns: the slot of the chunk just stored receives the loads of chunk c + 3.
+// writes chunk c + 1 to the FIFO and takes its magnitudes, and multiplies chunk c - 1's FIFO output by its gains and stores it.
+// Four register slots take turns: the slot of the chunk just stored receives the loads of chunk c + 3.
 // FIFO entries read two chunks ahead of their use were written at least B - 128 samples earlier and the call's first three chunks
 // must be old entries, so B >= 192.
 __global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
