@@ -239,6 +239,15 @@ __device__ __forceinline__ double qagc_chunk_exact(QAgcLane &st, double bm, int 
             }
         }
     }
+    if (st.clip == 1 && cnt == 64 && !__ballot(bm > st.mx)) {
+        // a chunk inside a ramp with no new largest sample: one chain, one ballot for the ramp's end
+        const double gl = qagc_chain_ramp(st.g, -st.d, 0, 63);
+        const double after = gl - st.d;
+        if (!__ballot(after <= st.T)) {
+            st.g = lane_bcast(after, 63);
+            return gl;
+        }
+    }
     while (p < cnt) {
         int irp = index_read + p;
         if (irp >= B) irp -= B;
