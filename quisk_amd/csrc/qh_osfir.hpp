@@ -91,6 +91,7 @@ template <typename T> struct OsfirArgs {
     double *det_sum;
     long long det_sum_stride;           // tiles per channel row
     double det_m[2], det_m256[2], det_g[2];
+    int pair_im0;                       // PAIR kernels: the unpaired equivalent would see (y, 0) (Quisk's real chains) instead of (y, y)
 };
 
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
             }
         }
     } else if constexpr (PAIR) {
-        static_assert(D == 1 && !MIX && !METER && !OUTMIX && !EGRESS && !POLY && DET == 0, "pairs ride on a plain D = 1 stage");
+        static_assert(!MIX && !METER && !OUTMIX && !EGRESS && DET == 0, "pairs ride on a plain stage (any fold: a real filter acts on the two parts alike)");
         const C *in_b = a.in + (long long)ch_b * a.in_stride;
         const C *hist_b = a.hist ? a.hist + (long long)ch_b * a.hist_stride : nullptr;
         if (interior) {
@@ -438,8 +439,9 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
             const long long m = (long long)tile * a.Lout + rel;
             if (rel >= 0 && rel < a.Lout && m < a.n_out) {
                 const T ya = z[i].x, yb = z[i].y;
-                out[m] = mk<T>((T)ep.a * ya + (T)ep.b * ya, (T)ep.c * ya + (T)ep.d * ya);
-                out_b[m] = mk<T>((T)eb.a * yb + (T)eb.b * yb, (T)eb.c * yb + (T)eb.d * yb);
+                const T ia = a.pair_im0 ? (T)0 : ya, ib = a.pair_im0 ? (T)0 : yb;       // the imaginary part the unpaired stage would hold
+                out[m] = mk<T>((T)ep.a * ya + (T)ep.b * ia, (T)ep.c * ya + (T)ep.d * ia);
+                out_b[m] = mk<T>((T)eb.a * yb + (T)eb.b * ib, (T)eb.c * yb + (T)eb.d * ib);
             }
         }
     } else if (a.pick <= 1) {
@@ -756,7 +758,8 @@ __global__ __launch_bounds__(kOsfir6kThreads, 3) void osfir6k_kernel(OsfirArgs<d
 // NFFT/U low-rate samples, reads it U times against the NFFT-point mask (the replicas of bin k all live in the lane
 // that holds k) and inverse transforms at NFFT points.  Args: Lout / P / n_out in HIGH-rate samples (both multiples
 // of U), n_in / hist in low-rate samples; off unused.
-template <typename T, int NFFT, int U>
+// PAIR: as in osfir_kernel -- two channels' real signals in the two parts of one tile (the interpolators' taps are real).
+template <typename T, int NFFT, int U, bool PAIR = false>
 __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
 {
     using C = cplx<T>;
@@ -771,7 +774,8 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
     const int t = threadIdx.x;
     int tile, slot;
     xcd_tile_map(a.ntiles, slot, tile);
-    const int ch = a.chan_list ? a.chan_list[slot] : slot;
+    const int ch = PAIR ? a.chan_list[2 * slot] : a.chan_list ? a.chan_list[slot] : slot;
+    const int ch_b = PAIR ? a.chan_list[2 * slot + 1] : ch;
     const C *in = a.in + (long long)ch * a.in_stride;
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
     const int g0 = tile * (a.Lout / U) - a.P / U;           // low-rate index of tile element 0
@@ -781,6 +785,13 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
 #pragma unroll
     for (int r = 0; r < EF; r++)
         if (!((ok >> r) & 1u)) x[r] = mk<T>(0, 0);
+    if constexpr (PAIR) {
+        C xb[EF];
+        const unsigned okb = load_tile<T, EF>(xb, a.in + (long long)ch_b * a.in_stride,
+                                              a.hist ? a.hist + (long long)ch_b * a.hist_stride : nullptr, a.hist_len, a.n_in, g0);
+#pragma unroll
+        for (int r = 0; r < EF; r++) x[r].y = ((okb >> r) & 1u) ? xb[r].x : (T)0;
+    }
 
     Fwd::run(x, lds, Fwd::load(a.tw_fwd));
 
@@ -795,15 +806,32 @@ __global__ __launch_bounds__(NT) void osfir_interp_kernel(OsfirArgs<T> a)
     C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
     EpiParam ep;
     if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+    if constexpr (PAIR) {
+        C *out_b = a.out + (long long)ch_b * a.out_stride + a.out_offset;
+        EpiParam eb = ep;
+        if (a.epi) eb = a.epi[ch_b];
 #pragma unroll
-    for (int i = 0; i < E; i++) {
-        const int rel = t + NT * i - a.P;
-        const long long m = (long long)tile * a.Lout + rel;
-        if (rel >= 0 && rel < a.Lout && m < a.n_out) {
-            C v;
-            v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
-            v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
-            out[m] = v;
+        for (int i = 0; i < E; i++) {
+            const int rel = t + NT * i - a.P;
+            const long long m = (long long)tile * a.Lout + rel;
+            if (rel >= 0 && rel < a.Lout && m < a.n_out) {
+                const T ya = z[i].x, yb = z[i].y;
+                const T ia = a.pair_im0 ? (T)0 : ya, ib = a.pair_im0 ? (T)0 : yb;
+                out[m] = mk<T>((T)ep.a * ya + (T)ep.b * ia, (T)ep.c * ya + (T)ep.d * ia);
+                out_b[m] = mk<T>((T)eb.a * yb + (T)eb.b * ib, (T)eb.c * yb + (T)eb.d * ib);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const int rel = t + NT * i - a.P;
+            const long long m = (long long)tile * a.Lout + rel;
+            if (rel >= 0 && rel < a.Lout && m < a.n_out) {
+                C v;
+                v.x = (T)ep.a * z[i].x + (T)ep.b * z[i].y;
+                v.y = (T)ep.c * z[i].x + (T)ep.d * z[i].y;
+                out[m] = v;
+            }
         }
     }
 }

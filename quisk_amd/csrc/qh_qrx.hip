@@ -372,6 +372,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         std::vector<FirStageSpec> a6;
         a6.push_back({ std::vector<double>(t->audio24p6, t->audio24p6 + 36), 1 });
         if (q.add_groups(a6, false, false)) return fail();
+        if (q.steps.back().st->set_pair(2)) return fail();                                  // real audio, real taps: (d, d) rows, two receivers per tile
         { Step nt; nt.kind = Step::NOTCH; q.steps.push_back(nt); }                          // quisk.c:2018-2019
         ueq = g45; U = 2;
     } else if (is_fm(mode)) {                       // HB45, HB45 after the /4 (quisk.c:2067-2068)
@@ -382,6 +383,8 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         post.push_back({ std::vector<double>(t->lp48, t->lp48 + 186), 4 });
         post.push_back({ std::vector<double>(t->fmhp, t->fmhp + 309), 1 });
         if (q.add_groups(post, false, false)) return fail();
+        for (size_t k = q.steps.size(); k-- > 0 && q.steps[k].kind == Step::FIR;)          // (the group may have been cut in two)
+            if (q.steps[k].st->set_pair(1)) return fail();                                  // the discriminator's rows are (y, 0)
     }
     if ((is_cw(mode) || is_ssb(mode) || is_am(mode)) && !dgt_narrow) {
         // ssb_squelch + d_delay (quisk.c:1925-1928,1970-1973,2020-2023): present in the step list, idle until enabled
@@ -400,6 +403,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         if (step.st->set_taps(-1, taps)) return fail();
         for (int c = 0; c < nch; c++)
             if (step.st->set_epi(c, EpiParam{ 1, 0, 1, 0 })) return fail();                 // d + I*d, quisk.c:2625
+        if (step.st->set_pair(1)) return fail();                                            // only the real part counts: two receivers per tile
     }
     if (is_fm(mode)) { Step nt; nt.kind = Step::NOTCH; nt.dup = true; q.steps.push_back(nt); }     // after the interpolators, quisk.c:2069-2070
     if (is_am(mode)) {

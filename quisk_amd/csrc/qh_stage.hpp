@@ -43,12 +43,17 @@ struct Stage {
     EpiParam *epi = nullptr;
     int cur = 0;
     size_t esize = 16;
+    // Real signals through real taps shared by all channels (Quisk's audio stages): channels 2p and 2p + 1 ride in the real and the
+    // imaginary part of one tile (osfir_kernel PAIR).  pair: 0 off, 1 the stage's rows hold (y, 0), 2 they hold (y, y).
+    int pair = 0, npairs = 0;
+    int *d_pairs = nullptr;
 
     void destroy()
     {
         (void)hipFree(mask); (void)hipFree(tw_fwd); (void)hipFree(tw_inv); (void)hipFree(hist[0]); (void)hipFree(hist[1]);
         (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_step); (void)hipFree(epi);
         (void)hipFree(taps_re); (void)hipFree(lane_rot); (void)hipFree(out_step); (void)hipFree(tile_rot); (void)hipFree(d_list); (void)hipFree(d_law); (void)hipFree(d_park);
+        (void)hipFree(d_pairs); d_pairs = nullptr;
         mask = tw_fwd = tw_inv = hist[0] = hist[1] = nullptr;
         nco_phase = nco_dphase = nullptr; nco_step = nullptr; epi = nullptr;
         taps_re = nullptr; lane_rot = out_step = tile_rot = nullptr; d_list = nullptr; d_law = nullptr; d_park = nullptr; tile_cap = 0;
@@ -353,6 +358,55 @@ struct Stage {
         constexpr int lds = osfir_lds_bytes<T, kStageNfft, FOLD>();
         hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, MIX, false, false, false, false, kPoly<T, FOLD>>), grid, block, lds, stream, a);
     }
+    template <typename T, int FOLD> void launch_dec_pair(const OsfirArgs<T> &a)
+    {
+        dim3 grid((unsigned)a.ntiles * (unsigned)npairs), block(NT);
+        constexpr int lds = osfir_lds_bytes<T, kStageNfft, FOLD>();
+        hipLaunchKernelGGL((osfir_kernel<T, kStageNfft, FOLD, false, false, false, false, false, kPoly<T, FOLD>, 0, true>), grid, block, lds, stream, a);
+    }
+    template <typename T, int U> void launch_up_pair(const OsfirArgs<T> &a)
+    {
+        dim3 grid((unsigned)a.ntiles * (unsigned)npairs), block(NT);
+        constexpr int lds = osfir_interp_lds_bytes<T, kStageNfft, U>();
+        hipLaunchKernelGGL((osfir_interp_kernel<T, kStageNfft, U, true>), grid, block, lds, stream, a);
+    }
+    template <typename T, int FOLD> int attr_pair_one()
+    {
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_kernel<T, kStageNfft, FOLD, false, false, false, false, false, kPoly<T, FOLD>, 0, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_lds_bytes<T, kStageNfft, FOLD>())));
+        return QH_OK;
+    }
+    template <typename T, int U> int attr_pair_up()
+    {
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir_interp_kernel<T, kStageNfft, U, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (osfir_interp_lds_bytes<T, kStageNfft, U>())));
+        return QH_OK;
+    }
+    template <typename T> int set_attr_pair_t()
+    {
+        if (interp > 1) return interp == 2 ? attr_pair_up<T, 2>() : interp == 4 ? attr_pair_up<T, 4>() : attr_pair_up<T, 8>();
+        return fold == 1 ? attr_pair_one<T, 1>() : fold == 2 ? attr_pair_one<T, 2>() : fold == 4 ? attr_pair_one<T, 4>() : attr_pair_one<T, 8>();
+    }
+    // mode 1: the rows hold (y, 0); 2: (y, y); 0: off.  Real taps shared by all channels only.
+    int set_pair(int mode)
+    {
+        if (mode && (per_channel || mix || outmix || nch < 2)) { pair = 0; return QH_OK; }
+        if (mode) {
+            QH_HIP(hipSetDevice(device));
+            if (int rc = dtype == QH_F64 ? set_attr_pair_t<double>() : set_attr_pair_t<float>()) return rc;
+        }
+        pair = mode;
+        if (mode && !d_pairs) {
+            npairs = (nch + 1) / 2;
+            std::vector<int> l((size_t)npairs * 2);
+            for (int p = 0; p < npairs; p++) { l[(size_t)2 * p] = 2 * p; l[(size_t)2 * p + 1] = 2 * p + 1 < nch ? 2 * p + 1 : 2 * p; }
+            QH_HIP(hipSetDevice(device));
+            QH_HIP(hipMalloc((void **)&d_pairs, l.size() * sizeof(int)));
+            QH_HIP(hipMemcpyAsync(d_pairs, l.data(), l.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
+        }
+        return QH_OK;
+    }
     template <typename T, int U> void launch_up(const OsfirArgs<T> &a)
     {
         dim3 grid((unsigned)a.ntiles * (unsigned)nch), block(NT);      // 1-D: the kernel maps ids to (channel, tile)
@@ -376,9 +430,17 @@ struct Stage {
         a.epi = epi;
         a.n_in = n_in; a.n_out = nout; a.P = P; a.Lout = Lf;
         if (nout > 0) {
+            const bool paired = pair && !per_channel && !mix && !outmix && pick <= 1;
+            if (paired) { a.chan_list = d_pairs; a.pair_im0 = pair == 1 ? 1 : 0; }
             if (interp > 1) {
                 a.ntiles = (nout + Lf - 1) / Lf;
-                switch (interp) { case 2: launch_up<T, 2>(a); break; case 4: launch_up<T, 4>(a); break; default: launch_up<T, 8>(a); }
+                if (paired) switch (interp) { case 2: launch_up_pair<T, 2>(a); break; case 4: launch_up_pair<T, 4>(a); break; default: launch_up_pair<T, 8>(a); }
+                else switch (interp) { case 2: launch_up<T, 2>(a); break; case 4: launch_up<T, 4>(a); break; default: launch_up<T, 8>(a); }
+            } else if (paired) {
+                a.off = decim - 1 - phase; a.pick = pick;
+                a.ntiles = (nout + Lf - 1) / Lf;
+                switch (fold) { case 1: launch_dec_pair<T, 1>(a); break; case 2: launch_dec_pair<T, 2>(a); break;
+                                case 4: launch_dec_pair<T, 4>(a); break; default: launch_dec_pair<T, 8>(a); }
             } else {
                 a.off = decim - 1 - phase; a.pick = pick;
                 const int per_tile = Lf / pick;

@@ -286,3 +286,28 @@ def test_fm_squelch_in_long_calls(qh, oracle):
         live = np.repeat(~muted, blk)
         live[:4000] = False
         assert rel_rms(y[c][live], want[live]) < 1e-6
+
+
+@pytest.mark.parametrize("mode", [1, 3, 4, 5])
+def test_paired_audio_stages_keep_the_receivers_apart(qh, mode):
+    """The real audio stages behind the detectors (dFilter / dDecimate / the interpolators: real taps, the same for every receiver)
+    run two receivers per tile, one in the real and one in the imaginary part (osfir_kernel PAIR, Stage::set_pair).  Five receivers
+    with different signals and tunings -- two pairs and one receiver paired with itself -- against five banks of one receiver each,
+    which do not pair; short blocks and a long call."""
+    fs, nch, n = 192000, 5, 120000
+    x = np.stack([signal(mode, c, n, fs, 8000.0 + 700 * c) * (1.0 + 0.5 * c) for c in range(nch)])
+    pieces = [0, 4096, 9000, 40000, n]
+    bank = qh.QuiskRxBank(nch, fs, mode)
+    fI, fQ = default_filter(mode, bank.get_filter_rate())
+    for c in range(nch):
+        bank.set_tune(c, 8000 + 700 * c)
+        bank.set_filters(c, fI, fQ)
+    y = np.concatenate([bank.process_host(x[:, a:b]) for a, b in zip(pieces, pieces[1:])], axis=1)
+    for c in range(nch):
+        one = qh.QuiskRxBank(1, fs, mode)
+        one.set_tune(0, 8000 + 700 * c)
+        one.set_filters(0, fI, fQ)
+        want = np.concatenate([one.process_host(x[c:c + 1, a:b]) for a, b in zip(pieces, pieces[1:])], axis=1)[0]
+        assert np.abs(want).max() > 0
+        assert np.array_equal(y[c].real, y[c].imag) and np.array_equal(want.real, want.imag)        # d + I d, quisk.c:2625
+        assert rel_rms(y[c], want) < 1e-12, (c, rel_rms(y[c], want))
