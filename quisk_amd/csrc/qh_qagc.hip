@@ -136,17 +136,36 @@ __device__ __forceinline__ double qagc_chain_relax(double g, double a, double c,
 {
     unsigned long long m = p >= 63 ? 0ull : ~0ull << (p + 1), sv;
     double gl = g;
-    if (steps >= 56) {          // (nearly) a whole chunk: 63 steps straight, no loop around them
+    if (steps >= 56) {
+        // (nearly) a whole chunk, no loop: lane p + 1 + r needs r + 1 = 4 q + k + 1 steps.  q blocks of four steps with EXEC moving up
+        // FOUR lanes per block (one EXEC write per four steps instead of one per step: 13.5 against 18 clocks per step), then four
+        // single steps on the lanes whose r mod 4 is at least 0, 1, 2, 3.  Every lane still runs its own steps one after the other.
+        const int sh = p + 1;
+        const unsigned long long k1 = 0xEEEEEEEEEEEEEEEEull << sh, k2 = 0xCCCCCCCCCCCCCCCCull << sh, k3 = 0x8888888888888888ull << sh;
         asm volatile("s_mov_b64 %[sv], exec\n\t"
-                     "s_mov_b64 exec, %[m]\n\t"
-                     ".rept 63\n\t"
+                     "s_lshl_b64 exec, %[m], 4\n\t"
+                     ".rept 15\n\t"
+                     ".rept 4\n\t"
                      "v_mul_f64 %[g], %[g], %[a]\n\t"
                      "v_add_f64 %[g], %[g], %[c]\n\t"
-                     "s_lshl_b64 exec, exec, 1\n\t"
                      ".endr\n\t"
+                     "s_lshl_b64 exec, exec, 4\n\t"
+                     ".endr\n\t"
+                     "s_mov_b64 exec, %[m]\n\t"
+                     "v_mul_f64 %[g], %[g], %[a]\n\t"
+                     "v_add_f64 %[g], %[g], %[c]\n\t"
+                     "s_mov_b64 exec, %[k1]\n\t"
+                     "v_mul_f64 %[g], %[g], %[a]\n\t"
+                     "v_add_f64 %[g], %[g], %[c]\n\t"
+                     "s_mov_b64 exec, %[k2]\n\t"
+                     "v_mul_f64 %[g], %[g], %[a]\n\t"
+                     "v_add_f64 %[g], %[g], %[c]\n\t"
+                     "s_mov_b64 exec, %[k3]\n\t"
+                     "v_mul_f64 %[g], %[g], %[a]\n\t"
+                     "v_add_f64 %[g], %[g], %[c]\n\t"
                      "s_mov_b64 exec, %[sv]"
                      : [g] "+v"(gl), [sv] "=&s"(sv)
-                     : [a] "v"(a), [c] "v"(c), [m] "s"(m)
+                     : [a] "v"(a), [c] "v"(c), [m] "s"(m), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3)
                      : "scc");
         return gl;
     }
@@ -171,16 +190,28 @@ __device__ __forceinline__ double qagc_chain_ramp(double g, double nd, int p, in
 {
     unsigned long long m = p >= 63 ? 0ull : ~0ull << (p + 1), sv;
     double gl = g;
-    if (steps >= 56) {
+    if (steps >= 56) {          // as in qagc_chain_relax: blocks of four steps, then the four remainders
+        const int sh = p + 1;
+        const unsigned long long k1 = 0xEEEEEEEEEEEEEEEEull << sh, k2 = 0xCCCCCCCCCCCCCCCCull << sh, k3 = 0x8888888888888888ull << sh;
         asm volatile("s_mov_b64 %[sv], exec\n\t"
-                     "s_mov_b64 exec, %[m]\n\t"
-                     ".rept 63\n\t"
+                     "s_lshl_b64 exec, %[m], 4\n\t"
+                     ".rept 15\n\t"
+                     ".rept 4\n\t"
                      "v_add_f64 %[g], %[g], %[nd]\n\t"
-                     "s_lshl_b64 exec, exec, 1\n\t"
                      ".endr\n\t"
+                     "s_lshl_b64 exec, exec, 4\n\t"
+                     ".endr\n\t"
+                     "s_mov_b64 exec, %[m]\n\t"
+                     "v_add_f64 %[g], %[g], %[nd]\n\t"
+                     "s_mov_b64 exec, %[k1]\n\t"
+                     "v_add_f64 %[g], %[g], %[nd]\n\t"
+                     "s_mov_b64 exec, %[k2]\n\t"
+                     "v_add_f64 %[g], %[g], %[nd]\n\t"
+                     "s_mov_b64 exec, %[k3]\n\t"
+                     "v_add_f64 %[g], %[g], %[nd]\n\t"
                      "s_mov_b64 exec, %[sv]"
                      : [g] "+v"(gl), [sv] "=&s"(sv)
-                     : [nd] "v"(nd), [m] "s"(m)
+                     : [nd] "v"(nd), [m] "s"(m), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3)
                      : "scc");
         return gl;
     }
@@ -383,9 +414,10 @@ __global__ __launch_bounds__(64) void q_agc_chain_kernel(const double2 *src, lon
 
 // Two wavefronts per stream: wave 0 steps (magnitudes in, gains out, through LDS); wave 1 moves -- while chunk c is stepped it
 // writes chunk c + 1 to the FIFO and takes its magnitudes, and multiplies chunk c - 1's FIFO output by its gains and stores it.
-// Four register slots take turns: the slot of the chunk just stored receives the loads of chunk c + 3.
-// FIFO entries read two chunks ahead of their use were written at least B - 128 samples earlier and the call's first three chunks
-// must be old entries, so B >= 192.
+// S register slots take turns: the slot of the chunk just stored receives the loads of chunk c + S - 1 (S = 8: six chunks, some
+// 8 000 clocks, between a load and its use -- with S = 4 the mover waited for HBM and the stepper for the mover: 2.77 against
+// 2.34 ms).  The FIFO entries of the call's first S - 1 chunks must be old ones, so B >= 64 (S - 1); S = 4 below 448 samples.
+template <int S>
 __global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, long long sstride, double2 *dst, long long dstride, int n,
                                                          QAgcState *state, double2 *ring, const double *release_gain, QAgcParam q)
 {
@@ -417,19 +449,19 @@ __global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, lon
     const double2 *x = src + (long long)ch * sstride;
     double2 *y = dst + (long long)ch * dstride;
     double2 *rb = ring + (long long)ch * B;
-    double2 zq[4], dq[4];
+    double2 zq[S], dq[S];
     int rq = st0.index_read + lane;                  // FIFO index of the chunk being loaded, this lane
     if (rq >= B) rq -= B;
     int ri = rq;                                     // ... of the chunk being written
 #pragma unroll
-    for (int u = 0; u < 3; u++) {
+    for (int u = 0; u < S - 1; u++) {
         const int i = u * 64 + lane;
         zq[u] = x[i < n ? i : n - 1];
         dq[u] = rb[rq];
         rq += 64;
         if (rq >= B) rq -= B;
     }
-    zq[3] = dq[3] = make_double2(0, 0);
+    zq[S - 1] = dq[S - 1] = make_double2(0, 0);
     auto prepare = [&](int c, const double2 &z) {    // chunk c: into the FIFO, its magnitudes to the stepper
         if (c * 64 + lane < n) rb[ri] = z;           // "write new sample at read index"
         ri += 64;
@@ -438,25 +470,25 @@ __global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, lon
     };
     prepare(0, zq[0]);
     __syncthreads();
-    for (int c0 = 0; c0 < nchunks; c0 += 4) {
+    for (int c0 = 0; c0 < nchunks; c0 += S) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < S; u++) {
             const int c = c0 + u;
             if (c < nchunks) {
-                if (c + 1 < nchunks) prepare(c + 1, zq[(u + 1) & 3]);
+                if (c + 1 < nchunks) prepare(c + 1, zq[(u + 1) & (S - 1)]);
                 if (c >= 1) {                        // chunk c - 1: its FIFO output times the gains the stepper left
                     const int base = (c - 1) * 64;
                     const double g = s_gain[(c - 1) & 1][lane];
-                    const double2 d = dq[(u + 3) & 3];
+                    const double2 d = dq[(u + S - 1) & (S - 1)];
                     double2 o = make_double2(d.x * g, d.y * g);
                     const double om = q.is_cpx ? hypot(o.x, o.y) : fabs(o.x);
                     if (om > kClip32) { o.x /= om; o.y /= om; }     // quisk.c:2204-2205
                     y[base + lane] = o;              // (base + lane < n: chunk c - 1 is a full one)
                 }
-                {   // chunk c + 3 into the slot chunk c - 1 has just left
-                    const int i = (c + 3) * 64 + lane;
-                    zq[(u + 3) & 3] = x[i < n ? i : n - 1];
-                    dq[(u + 3) & 3] = rb[rq];
+                {   // chunk c + S - 1 into the slot chunk c - 1 has just left
+                    const int i = (c + S - 1) * 64 + lane;
+                    zq[(u + S - 1) & (S - 1)] = x[i < n ? i : n - 1];
+                    dq[(u + S - 1) & (S - 1)] = rb[rq];
                     rq += 64;
                     if (rq >= B) rq -= B;
                 }
@@ -468,10 +500,9 @@ __global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, lon
         const int c = nchunks - 1, base = c * 64;
         if (base + lane < n) {
             const double g = s_gain[c & 1][lane];
-            double2 d = dq[0];                       // (slot c & 3, picked by value: an indexed register array would live in scratch)
-            if ((c & 3) == 1) d = dq[1];
-            if ((c & 3) == 2) d = dq[2];
-            if ((c & 3) == 3) d = dq[3];
+            double2 d = dq[0];                       // (slot c mod S, picked by value: an indexed register array would live in scratch)
+#pragma unroll
+            for (int q = 1; q < S; q++) if ((c & (S - 1)) == q) d = dq[q];
             double2 o = make_double2(d.x * g, d.y * g);
             const double om = q.is_cpx ? hypot(o.x, o.y) : fabs(o.x);
             if (om > kClip32) { o.x /= om; o.y /= om; }
@@ -597,8 +628,8 @@ int qh_qagc_process2(qh_qagc *h, const void *d_src, long long src_stride, void *
     }
     // chunks in flight: D <= B / 64 - 1 (q_agc_chain_kernel); a FIFO of 64 .. 127 samples takes the plain kernel
     const int B = h->prm.buf_size;
-    auto *kern = h->form == 1 || B < 128 ? q_agc_kernel : B >= 192 ? q_agc_pair_kernel : q_agc_chain_kernel<1>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)h->nch), dim3(kern == q_agc_pair_kernel ? 128 : 64), 0, h->stream, (const double2 *)d_src, src_stride, (double2 *)d_dst, dst_stride, n,
+    auto *kern = h->form == 1 || B < 128 ? q_agc_kernel : B >= 448 ? q_agc_pair_kernel<8> : B >= 192 ? q_agc_pair_kernel<4> : q_agc_chain_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)h->nch), dim3(B >= 192 && h->form != 1 ? 128 : 64), 0, h->stream, (const double2 *)d_src, src_stride, (double2 *)d_dst, dst_stride, n,
                        h->state, h->ring, h->gain, h->prm);
     QH_HIP(hipGetLastError());
     return QH_OK;
