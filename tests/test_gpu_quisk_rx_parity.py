@@ -288,8 +288,8 @@ def test_fm_squelch_in_long_calls(qh, oracle):
         assert rel_rms(y[c][live], want[live]) < 1e-6
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4, 5])
-def test_paired_audio_stages_keep_the_receivers_apart(qh, mode):
+@pytest.mark.parametrize("mode,squelch", [(1, False), (3, False), (4, False), (5, False), (3, True), (4, True)])
+def test_paired_audio_stages_keep_the_receivers_apart(qh, mode, squelch):
     """The real audio stages behind the detectors (dFilter / dDecimate / the interpolators: real taps, the same for every receiver)
     run two receivers per tile, one in the real and one in the imaginary part (osfir_kernel PAIR, Stage::set_pair).  Five receivers
     with different signals and tunings -- two pairs and one receiver paired with itself -- against five banks of one receiver each,
@@ -302,11 +302,15 @@ def test_paired_audio_stages_keep_the_receivers_apart(qh, mode):
     for c in range(nch):
         bank.set_tune(c, 8000 + 700 * c)
         bank.set_filters(c, fI, fQ)
+    if squelch:                 # ssb_squelch and d_delay sit between the audio filter and the interpolator (quisk.c:1970-1973,2020-2023)
+        bank.set_ssb_squelch(True, 300)
     y = np.concatenate([bank.process_host(x[:, a:b]) for a, b in zip(pieces, pieces[1:])], axis=1)
     for c in range(nch):
         one = qh.QuiskRxBank(1, fs, mode)
         one.set_tune(0, 8000 + 700 * c)
         one.set_filters(0, fI, fQ)
+        if squelch:
+            one.set_ssb_squelch(True, 300)
         want = np.concatenate([one.process_host(x[c:c + 1, a:b]) for a, b in zip(pieces, pieces[1:])], axis=1)[0]
         assert np.abs(want).max() > 0
         assert np.array_equal(y[c].real, y[c].imag) and np.array_equal(want.real, want.imag)        # d + I d, quisk.c:2625
