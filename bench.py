@@ -24,6 +24,7 @@ LOG2_SAMPLES = 22
 IN_RATE, DSP_RATE = 192000, 48000
 DSP_SIZE = 256
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 39.3e12    # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one lane operation (an FMA = 2 flop) per lane and clock = 78.6 TFLOP/s fp64 vector
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "c2_traffic.json")
 
 
@@ -127,14 +128,25 @@ def cpu_baseline(log2_single=25, log2_each=24):
 
     def run(cores, log2n, lead):
         t_start = time.time() + lead
-        procs = [subprocess.Popen([sys.executable, worker, str(c), str(i), str(log2n), repr(t_start)], stdout=subprocess.PIPE, text=True)
-                 for i, c in enumerate(cores)]
+        procs = []
         outs = []
-        for pr in procs:
-            o, _ = pr.communicate(timeout=600)
-            if pr.returncode != 0:
-                raise RuntimeError("cpu baseline worker failed")
-            outs.append(json.loads(o.strip().splitlines()[-1]))
+        try:
+            for i, c in enumerate(cores):
+                procs.append(subprocess.Popen([sys.executable, worker, str(c), str(i), str(log2n), repr(t_start)], stdout=subprocess.PIPE, text=True))
+            deadline = time.time() + lead + 240.0           # the whole set, not 600 s per worker
+            for pr in procs:
+                o, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+                if pr.returncode != 0:
+                    raise RuntimeError("cpu baseline worker failed")
+                outs.append(json.loads(o.strip().splitlines()[-1]))
+        finally:                                            # a timeout or a failed worker leaves no pinned process behind
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                    try:
+                        pr.communicate(timeout=5)
+                    except Exception:
+                        pass
         span = max(o["t1"] for o in outs) - min(o["t0"] for o in outs)
         late = max(o["t0"] for o in outs) - t_start            # > 0.5 s: a worker was not ready at the start time
         return sum(o["samples"] for o in outs) / span / 1e6, span, late, outs
@@ -152,55 +164,71 @@ def cpu_baseline(log2_single=25, log2_each=24):
                       % (log2_single, span1, len(avail), log2_each, span)}
 
 
-def other_configs(torch, dev):
-    """BASELINE.json configs 3, 4, 5 (one GPU's share each) and the Quisk-native chain (path A), run after the timed region of the
-    headline workload with tools/bench_configs.py's legs: per configuration the algorithmic bytes per input sample,
-    the rate, GB/s against the 8 TB/s roofline, and the kernel that takes most of the step.  Reported as extra keys; `value` is
-    configuration 2's alone."""
-    import importlib.util
-    import quisk_amd as qh
-    spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
-    bc = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bc)
+def other_configs(timeout_s=900.0):
+    """BASELINE.json configs 3, 4, 5 (one GPU's share each), the headline chain with the AGC on and the Quisk-native chain (path A):
+    tools/bench_configs.py's legs, run in a FRESH CHILD PROCESS (`tools/bench_configs.py driver`) after the headline workload's
+    timed region and after this process has given its device memory back.  A fault, a hang or a time-out in any extra leg costs
+    that leg (the child reports leg by leg, so the finished ones are kept), never the headline measurement.  Reported as extra
+    keys; `value` is configuration 2's alone."""
+    import subprocess
+    import tempfile
     out = {}
-
-    def leg(key, fn, bytes_per_sample, ms_key, dominant):
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "legs.jsonl")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "driver", path]
         try:
-            r = fn(torch, qh, dev)
-            ms = r[ms_key]
-            rate = r["samples_per_step"] / (ms * 1e-3)
-            gbps = bytes_per_sample * rate / 1e9
-            name, kms = dominant(r)
-            out[key] = {"workload": r["config"], "samples_per_step": r["samples_per_step"], "ms_per_step": ms, "Msamp_per_s": rate / 1e6,
-                        "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
-                        "dominant_kernel": name, "dominant_kernel_ms": kms, "detail": {k: v for k, v in r.items() if k not in ("config",)}}
-        except Exception as exc:                                 # reported, never required
-            out[key] = {"failed": repr(exc)}
-        torch.cuda.synchronize(dev)
-        torch.cuda.empty_cache()
-
-    # config 3: 16 B in (read once by the FIR and once by the transform) + 16/32 B FIR output; the |X| sums stay on the chip and only
-    # the running average leaves it, so SURVEY.md 8(d)'s 16.5 B, not 24.5
-    leg("config3", bc.config3, 16.5, "best_ms",
-        lambda r: ("pan16k_kernel (16384-point panadapter, read-once)", r["pan_ms"]) if r["pan_ms"] >= r["fir_ms"]
-        else ("osfir_kernel<f64,4096,D=8,pick 4> (1023-tap /32)", r["fir_ms"]))
-    # config 4: the call's launch sequence replayed from a hipGraph (qh_rxa_set_graph_replay), the engine's mode for repeated calls
-    leg("config4", bc.config4, 20.0, "ms_graph_replay", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
-    leg("config5", bc.config5, 8.0, "fused_ms", lambda r: ("hb45_cascade_kernel<float,8>", r["fused_cascade_only_ms"]))
-    # the headline chain with WDSP's AGC state machine on (not a BASELINE configuration: config 2 fixes the gain)
-    leg("config2_agc_on", bc.config2_agc, 20.0, "ms", lambda r: ("agc_bounds_kernel (the level detector's state at the tile boundaries)", None))
-    try:
-        r = bc.quisk_native(torch, qh, dev)
-        out["quisk_native"] = {"workload": r["config"], "samples_per_step": r["samples_per_step"], "algorithmic_bytes_per_sample": 20.0,
-                               "modes": [dict({"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
-                                               "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
-                                               "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS},
-                                              **{k: m[k] for k in ("agc_on_ms", "agc_on_Msamp_per_s") if k in m}) for m in r["modes"]],
-                               "agc_note": "agc_on_*: process_agc (quisk.c:2162) on the output, one wavefront per receiver (q_agc_chain_kernel)",
-                               "dominant_kernel": "osfir_kernel<f64,4096,D=8,OUTMIX> (tune + collapsed 1181-tap /16)"}
-    except Exception as exc:
-        out["quisk_native"] = {"failed": repr(exc)}
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            note = None if r.returncode == 0 else "child exit code %d: %s" % (r.returncode, (r.stderr or "")[-300:])
+        except subprocess.TimeoutExpired:
+            note = "child timed out after %.0f s" % timeout_s
+        try:
+            for line in open(path):
+                d = json.loads(line)
+                out[d["key"]] = d["leg"]
+        except OSError:
+            pass
+        if note:
+            out["child_failed"] = note
     return out
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): N fresh child processes, one per GPU, with
+    the rank variables torch.distributed.run would set, started BEFORE this process imports torch or touches a GPU.  Rank 0's
+    line is relayed; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        try:
+            for rank in range(args.gpus):
+                env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), QH_BENCH_SPAWNED="1")
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                              stdout=out0 if rank == 0 else subprocess.DEVNULL))
+            failed_at = None
+            while any(pr.poll() is None for pr in procs):
+                time.sleep(0.2)
+                if failed_at is None and any(pr.poll() not in (None, 0) for pr in procs):
+                    failed_at = time.time()                 # a rank died: the others may sit in a barrier for good
+                if failed_at is not None and time.time() - failed_at > 20.0:
+                    break
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        rc = [pr.wait() for pr in procs]
+        out0.seek(0)
+        out0 = out0.read()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(r) for r in rc)
 
 
 def main():
@@ -215,6 +243,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="plumbing test only: no GPU, no DSP (DryEngine); the line is not a measurement")
     ap.add_argument("--log2-samples", type=int, default=LOG2_SAMPLES, help="input samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-le24", action="store_true", help="skip the extra run from 24-bit wire samples (the test of the front kernel's HBM bound)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra legs (BASELINE configs 3, 4, 5 and the Quisk-native chain)")
     ap.add_argument("--meters", choices=["on", "off"], default="on",
                     help="on (default): xrxa's three meters run as in the reference (adc, S, agc: wdsp/RXA.c:566,569,589), "
@@ -227,6 +256,9 @@ def main():
                     help="f64: complex double input resident in HBM (the BASELINE workload); le24: the same signal as "
                          "24-bit little-endian IQ bytes (quisk_read_rx_udp wire format), decoded in the front kernel's load")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # no launcher: be one (before torch, before any GPU call)
+        raise SystemExit(self_spawn(args))
 
     import torch
     import torch.distributed as dist
@@ -369,6 +401,52 @@ def main():
     tail = y[0, -4096:]
     gain = float(tail.abs().mean().item()) / 0.1
 
+    # The same steps from 24-bit wire samples (6 B instead of 16 B per input sample through the SAME front kernel, decoded in its
+    # load): the direct test of whether that kernel waits for HBM.  Reported as an extra key; `value` is the fp64-input run's.
+    le24 = None
+    if args.ingest == "f64" and world == 1 and not dry and not args.no_le24 and nchunk == 1:
+        try:
+            from quisk_amd import IqFormat
+            codes = torch.view_as_real(x).mul(2.0 ** 23).round_().to(torch.int32)
+            packed = codes.view(torch.uint8).reshape(nch, n_in, 2, 4)[..., :3].contiguous()
+            del codes
+            fmt = IqFormat.le24(2.0 ** -31)
+            sync()
+
+            def step24():
+                eng.process_packed_ptr(packed.data_ptr(), packed.numel(), fmt, 6 * n_in, y.data_ptr(), n_out, nblk)
+            for _ in range(2):
+                step24()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step24()
+            sync()
+            dt24 = (time.perf_counter() - t0) / 5
+            eng.enable_timing(True)
+            k24 = [0.0, 0.0, 0.0]
+            for _ in range(3):
+                step24()
+                k24 = [a + b / 3 for a, b in zip(k24, eng.timing_ms())]
+            eng.enable_timing(False)
+            le24 = {"ms_per_step": dt24 * 1e3, "Msamp_per_s": float(nch) * n_in / dt24 / 1e6, "front_ms": k24[0], "band_ms": k24[1],
+                    "front_ms_f64_input": kt[0], "front_algorithmic_bytes_per_sample": 10.0,
+                    "front_algorithmic_GBps": 10.0 * float(nch) * n_in / (k24[0] * 1e-3) / 1e9,
+                    "note": "24-bit little-endian IQ (quisk_read_rx_udp's wire format) decoded in the front kernel's load: 6 B in + 16/4 B out per "
+                            "input sample instead of 16 + 4.  A front kernel bound by HBM would run ~2x faster here."}
+            del packed
+            torch.cuda.empty_cache()
+        except Exception as exc:                             # reported, never required
+            le24 = {"failed": repr(exc)}
+
+    # every rank's own figures (over the group that already exists), so that a slow GPU is attributable
+    mine_rec = {"rank": rank, "device": local_rank, "channels": [first, first + nch], "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
+                "check_inband_gain": gain}
+    per_rank = [mine_rec]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
+
     if rank == 0:
         samples_per_step = float(nch) * n_in                     # this rank's launch (kernel-level figures below)
         job_samples_per_step = float(total_channels) * n_in      # all ranks
@@ -384,16 +462,29 @@ def main():
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/c2_traffic.json, stamped with the kernel sources' hash),
         # scaled by the number of samples: counters cannot be read inside this process
         traffic, traffic_note = None, None
+        valu = None                 # executed VALU lane operations per second of each kernel, from the same stamped counter passes
         try:
             tj = json.load(open(TRAFFIC_JSON))
             if tj.get("source_sha16") != kernel_source_sha16():
                 traffic_note = "profiles/c2_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("source_sha16")
             elif args.ingest == "f64" and tj.get("meters") == args.meters:
                 traffic = tj["kernels"]["front" if k == 0 else "band"]["bytes_per_input_sample"] * samples_per_step
+                valu = {}
+                for i, key in enumerate(("front", "band")):
+                    w = tj["kernels"][key].get("valu_wave_insts_per_input_sample")
+                    if w is not None:
+                        ops = 64.0 * w * samples_per_step / (kt[i] * 1e-3)
+                        valu[key] = {"lane_ops_per_s": ops, "frac": ops / VALU_PEAK_LANE_OPS,
+                                     "hbm_frac": algo[i] * samples_per_step / (kt[i] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             else:
                 traffic_note = "profiles/c2_traffic.json holds another variant (ingest / meters)"
         except Exception as exc:
             traffic_note = "no counter-derived traffic: %r" % (exc,)
+        dom = "front" if k == 0 else "band"
+        valu_dom = valu.get(dom) if valu else None
+        # which ceiling the dominant kernel sits closer to: its algorithmic bytes against 8 TB/s, or the VALU lane operations it
+        # executes (counted, SQ_INSTS_VALU x 64) against the vector unit's 39.3 T lane operations per second
+        bound = "valu" if (valu_dom and valu_dom["frac"] > achieved / HBM_PEAK_GBPS) else "hbm"
         line = {
             "metric": "Mcomplex-samples/s through RXA chain",
             "value": value,
@@ -418,11 +509,19 @@ def main():
             # the survey derives from this count (78.6e12 / 650 = 121 Gsamp/s)
             "chain_direct_form_equivalent_TFLOPs": 650.0 * total / dt / 1e12,
             "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
-            "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": bound, "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": algo[k] * samples_per_step},
+                         "algorithmic_bytes_per_launch": algo[k] * samples_per_step,
+                         "valu": None if not valu_dom else {"achieved": valu_dom["lane_ops_per_s"], "peak": VALU_PEAK_LANE_OPS, "unit": "VALU lane-ops/s",
+                                                            "frac": valu_dom["frac"],
+                                                            "note": "SQ_INSTS_VALU x 64 per launch (stamped counter pass, profiles/c2_traffic.json) / the kernel's HIP-event time"},
+                         "per_kernel": valu},
             "check_inband_gain": gain,
         }
+        if le24 is not None:
+            line["ingest_le24"] = le24
+        if world > 1:
+            line["per_rank"] = per_rank
         if dry:
             line["dry_run"] = True
             line["dry"] = {"rank0_channels": [first, first + nch], "setters": eng.setters}
@@ -431,9 +530,9 @@ def main():
             line["ms_per_step_meters_off"] = dt_off / args.steps * 1e3
             line["check_meters_dB"] = {"S_AV": meter_db[0], "ADC_AV": meter_db[1], "AGC_AV": meter_db[2]}
         if not args.no_other_configs and world == 1 and not dry and args.ingest == "f64":
-            del x, y, eng                                        # the headline workload's 21 GB go back before the other legs allocate
+            del x, y, eng, tail                                  # the headline workload's 21 GB go back before the other legs allocate
             torch.cuda.empty_cache()
-            line["other_configs"] = other_configs(torch, dev)
+            line["other_configs"] = other_configs()
         if not args.no_cpu_baseline and world == 1 and not dry:       # the CPU baseline is reported by the single-GPU run only
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -234,6 +234,11 @@ struct Engine {
     LmsState *lms_state[2] = { nullptr, nullptr };
     int *levelfade = nullptr;
     AmState *am_state = nullptr;
+    // carries of the grid-segmented scans (qh_tiled.hpp: a launch reads the state of its channels and leaves the new one here; a
+    // commit kernel behind it moves it in): [nch] each
+    AmState *am_next = nullptr;
+    SnotchState *sn_next = nullptr;
+    double *fmdc_next = nullptr;
     AmParam am_prm{};
     PllState *pll_state = nullptr;
     double *fm_again = nullptr;
@@ -329,7 +334,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
-    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
     (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege); (void)hipFree(agc_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
@@ -700,6 +705,9 @@ int Engine::refresh_demod()
         dev_bytes += (long long)nch * (sizeof(AgcParam) + sizeof(AgcState));
         QH_HIP(dev_alloc(&levelfade, (size_t)nch));
         QH_HIP(dev_alloc(&am_state, (size_t)nch));
+        QH_HIP(dev_alloc(&am_next, (size_t)nch));
+        QH_HIP(dev_alloc(&sn_next, (size_t)nch));
+        QH_HIP(dev_alloc(&fmdc_next, (size_t)nch));
         QH_HIP(dev_alloc(&pll_state, (size_t)nch));
         QH_HIP(dev_alloc(&fm_again, (size_t)nch));
         QH_HIP(dev_alloc(&pll_nfixed, (size_t)1));
@@ -1838,15 +1846,17 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (n_am && am_fused) {         // envelopes in the channels' own rows (first half), audio to the rows of `other`
         const int G = seg_groups(n_am + (n_mid >= kSamTiledMin ? n_sam0 : 0));
         hipLaunchKernelGGL(am_level_tiled_kernel, dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream,
-                           (const double *)reinterpret_cast<double *>(cur), 2 * buf_cap, other, buf_cap, (int)n_mid, list_am, levelfade, am_state,
-                           am_prm, (const double *)am_tsum, am_tsum_cap, bnfft - P_am);
+                           (const double *)reinterpret_cast<double *>(cur), 2 * buf_cap, other, buf_cap, (int)n_mid, list_am, levelfade, (const AmState *)am_state,
+                           am_prm, (const double *)am_tsum, am_tsum_cap, bnfft - P_am, am_next);
+        hipLaunchKernelGGL(commit_am_kernel, dim3((unsigned)((n_am + 255) / 256)), dim3(256), 0, am_stream, am_state, (const AmState *)am_next, list_am, n_am, levelfade);
     } else if (n_am) {
         const int G = seg_groups(n_am + (n_mid >= kSamTiledMin ? n_sam0 : 0));
         if (G > 1) {
             hipLaunchKernelGGL((am_detect_tiled_kernel<false, 1>), dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
                                (int)n_mid, list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, seg_sum[0]);
             hipLaunchKernelGGL((am_detect_tiled_kernel<false, 2>), dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
-                               (int)n_mid, list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, seg_sum[0]);
+                               (int)n_mid, list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, seg_sum[0], am_next);
+            hipLaunchKernelGGL(commit_am_kernel, dim3((unsigned)((n_am + 255) / 256)), dim3(256), 0, am_stream, am_state, (const AmState *)am_next, list_am, n_am, levelfade);
         } else
             hipLaunchKernelGGL((am_detect_tiled_kernel<false, 0>), dim3((unsigned)n_am), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
                                list_am, levelfade, am_state, am_prm, (const double *)nullptr, 0LL, (double *)nullptr);
@@ -1886,7 +1896,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                     hipLaunchKernelGGL((am_detect_tiled_kernel<true, 1>), dim3((unsigned)nt0, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
                                        buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs);
                     hipLaunchKernelGGL((am_detect_tiled_kernel<true, 2>), dim3((unsigned)nt0, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur,
-                                       buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs);
+                                       buf_cap, (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, gs, am_next);
+                    hipLaunchKernelGGL(commit_am_kernel, dim3((unsigned)((nt0 + 255) / 256)), dim3(256), 0, am_stream, am_state, (const AmState *)am_next, list_sam, nt0, levelfade);
                 } else
                     hipLaunchKernelGGL((am_detect_tiled_kernel<true, 0>), dim3((unsigned)nt0), dim3(kSegThreads), 0, am_stream, cur, buf_cap,
                                        (int)n_mid, list_sam, levelfade, am_state, am_prm, (const double *)pts, 2 * buf_cap, (double *)nullptr);
@@ -1903,9 +1914,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL((sam_sb_tiled_kernel<2>), dim3((unsigned)ntsb, (unsigned)(S / kSbWaves)), dim3(64 * kSbWaves), 0, am_stream, cur, buf_cap, (int)n_mid,
                                    lst, (const SamChanParam *)sam_prm, (const double *)pts, 2 * buf_cap, pll_state, sb_sum, (const double *)sb_start);
                 hipLaunchKernelGGL((sam_level_tiled_kernel<1>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
-                                   lst, levelfade, am_state, am_prm, gs);
+                                   lst, levelfade, (const AmState *)am_state, am_prm, gs, am_next);
                 hipLaunchKernelGGL((sam_level_tiled_kernel<2>), dim3((unsigned)ntsb, (unsigned)G), dim3(kSegThreads), 0, am_stream, cur, buf_cap, (int)n_mid,
-                                   lst, levelfade, am_state, am_prm, gs);
+                                   lst, levelfade, (const AmState *)am_state, am_prm, gs, am_next);
+                hipLaunchKernelGGL(commit_am_kernel, dim3((unsigned)((ntsb + 255) / 256)), dim3(256), 0, am_stream, am_state, (const AmState *)am_next, lst, ntsb, levelfade);
             }
         }
         if (n_sam - nt) hipLaunchKernelGGL(sam_pll_kernel, dim3((unsigned)(n_sam - nt)), dim3(64), 0, am_stream, cur, buf_cap, (int)n_mid,
@@ -1959,8 +1971,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 // dc removal + gain: the tiles' contributions are in `ends` already, one pass over `fil`
                 const int G = seg_groups(n_fm);
                 hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
-                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, pll_state, (const double *)fm_again, fm_pll_prm,
-                                   (const double *)pll_ends, pll_ends_cap * kPllEndsW, fm_tile);
+                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, (const double *)fm_again, fm_pll_prm,
+                                   (const double *)pll_ends, pll_ends_cap * kPllEndsW, fm_tile, fmdc_next);
+                hipLaunchKernelGGL(commit_fmdc_kernel, dim3((unsigned)((n_fm + 255) / 256)), dim3(256), 0, stream, pll_state, (const double *)fmdc_next, list_fm, n_fm);
             }
         }
         {   // de-emphasis: real taps on a real signal, two channels per tile
@@ -1976,7 +1989,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL((snotch_tiled_kernel<1>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
                                    list_fm, sn_prm, sn_state, seg_sum[2]);
                 hipLaunchKernelGGL((snotch_tiled_kernel<2>), dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid,
-                                   list_fm, sn_prm, sn_state, seg_sum[2], direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi);
+                                   list_fm, sn_prm, sn_state, seg_sum[2], direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi, sn_next);
+                hipLaunchKernelGGL(commit_snotch_kernel, dim3((unsigned)((n_fm + 255) / 256)), dim3(256), 0, stream, sn_state, (const SnotchState *)sn_next, list_fm, n_fm,
+                                   (const SnotchParam *)sn_prm);
             } else
                 hipLaunchKernelGGL((snotch_tiled_kernel<0>), dim3((unsigned)n_fm), dim3(kSegThreads), 0, stream, cur, buf_cap, (int)n_mid, list_fm,
                                    sn_prm, sn_state, (double *)nullptr, direct ? out : (double2 *)nullptr, out_stride, (const EpiParam *)epi);

@@ -35,8 +35,11 @@ template <bool SAM, int MODE = 0>
 static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                                              const int *levelfade, AmState *state, AmParam prm,
                                                                              const double *pt = nullptr, long long ptstride = 0,
-                                                                             double *gsum = nullptr)
+                                                                             double *gsum = nullptr, AmState *carry_out = nullptr)
 {
+    // carry_out: where the call's last segment leaves the new carry.  One workgroup per channel (MODE 0) reads the old carry ahead of
+    // its barrier and may overwrite it; the grid forms (MODE 2) have no barrier between a workgroup that starts late and the one that
+    // ends early, so their `state` stays read-only for the whole launch and commit_am_kernel moves the new carry in afterwards.
     __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = MODE == 0 ? kSegWaves : kSegWaves * (int)gridDim.y, sidx = MODE == 0 ? wave : (int)blockIdx.y * kSegWaves + wave;
@@ -119,7 +122,17 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
     }
     int last = S - 1;                                   // the segment that holds the last sample of the call
     while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
-    if (sidx == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+    if (sidx == last && lane == 0 && n > 0) { AmState *o = carry_out ? carry_out : state; o[ch].dc = cR; o[ch].dc_insert = cI; }
+}
+
+// The carries that a grid-segmented launch left in slots of their own (see am_detect_tiled_kernel), moved into the state the next
+// call reads: one thread per listed channel, the predicate the writer had.
+static __global__ void commit_am_kernel(AmState *state, const AmState *next, const int *chan_list, int count, const int *levelfade)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int ch = chan_list[i];
+    if (levelfade[ch] != 0) state[ch] = next[ch];
 }
 
 // The AM fade leveller behind an nbp0 stage that left the envelope itself (osfir_kernel DET 2): mag [ch][mstride] doubles, tsum
@@ -127,8 +140,8 @@ static __global__ __launch_bounds__(kSegThreads) void am_detect_tiled_kernel(dou
 // tile boundaries, a segment's carry-in is the chain over the tiles ahead of it, and there is one pass: 8 bytes read, 16 written
 // per sample, against 16 + 16 + 16 + 16 of am_detect_tiled_kernel's two.  out may not be the rows `mag` lies in.
 static __global__ __launch_bounds__(kSegThreads) void am_level_tiled_kernel(const double *mag, long long mstride, double2 *out, long long ostride,
-                                                                            int n, const int *chan_list, const int *levelfade, AmState *state,
-                                                                            AmParam prm, const double *tsum, long long tstride, int L)
+                                                                            int n, const int *chan_list, const int *levelfade, const AmState *state,
+                                                                            AmParam prm, const double *tsum, long long tstride, int L, AmState *carry_out)
 {
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
@@ -179,7 +192,7 @@ static __global__ __launch_bounds__(kSegThreads) void am_level_tiled_kernel(cons
             if (lane < cnt) p[base + lane] = make_double2(audio, audio);
         }
     }
-    if (lf && is_last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+    if (lf && is_last && lane == 0 && n > 0) { carry_out[ch].dc = cR; carry_out[ch].dc_insert = cI; }       // committed by commit_am_kernel
 }
 
 // ---- SAM with sideband selection (amd.c:150-208) over time segments ---------------------------------------------------------------
@@ -327,7 +340,8 @@ static __global__ __launch_bounds__(64) void sam_sb_chain_kernel(int n, int S, c
 // the fade leveller of the sideband modes: buf holds (audio, corr0); dc averages audio, dc_insert averages corr0 (amd.c:211-216)
 template <int MODE>
 static __global__ __launch_bounds__(kSegThreads) void sam_level_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
-                                                                             const int *levelfade, AmState *state, AmParam prm, double *gsum)
+                                                                             const int *levelfade, const AmState *state, AmParam prm, double *gsum,
+                                                                             AmState *carry_out)
 {
     const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
@@ -376,7 +390,7 @@ static __global__ __launch_bounds__(kSegThreads) void sam_level_tiled_kernel(dou
         }
         int last = S - 1;
         while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
-        if (lf && sidx == last && lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+        if (lf && sidx == last && lane == 0 && n > 0) { carry_out[ch].dc = cR; carry_out[ch].dc_insert = cI; }   // committed by commit_am_kernel
     }
 }
 
@@ -422,8 +436,9 @@ template <int MODE = 0>
 static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                                           const SnotchParam *prm, SnotchState *state, double *gsum = nullptr,
                                                                           double2 *dst = nullptr, long long dst_stride = 0,
-                                                                          const EpiParam *epi = nullptr)
+                                                                          const EpiParam *epi = nullptr, SnotchState *carry_out = nullptr)
 {
+    // carry_out: as in am_detect_tiled_kernel -- the grid form (MODE 2) leaves the new state there for commit_snotch_kernel
     __shared__ double s_sum[kSegWaves * kSegSumW];
     const int ch = chan_list[blockIdx.x];
     const SnotchParam q = prm[ch];
@@ -545,7 +560,15 @@ static __global__ __launch_bounds__(kSegThreads) void snotch_tiled_kernel(double
     }
     int last = S - 1;
     while (last > 0 && seg_samples_of(n, last, S) == 0) last--;
-    if (sidx == last && lane == 0 && n > 0) { SnotchState st; st.x1 = xm1; st.x2 = xm2; st.y1 = c0; st.y2 = c1; state[ch] = st; }
+    if (sidx == last && lane == 0 && n > 0) { SnotchState st; st.x1 = xm1; st.x2 = xm2; st.y1 = c0; st.y2 = c1; (carry_out ? carry_out : state)[ch] = st; }
+}
+
+static __global__ void commit_snotch_kernel(SnotchState *state, const SnotchState *next, const int *chan_list, int count, const SnotchParam *prm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int ch = chan_list[i];
+    if (prm[ch].run) state[ch] = next[ch];
 }
 
 // ---- FM discriminator (xfmd's loop, wdsp/fmd.c:151-172) ---------------------------------------------------------------
@@ -830,8 +853,8 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
 // the average in `ends` (kPllEndsW per tile, [6]); the time segments (16 per workgroup, gridDim.y workgroups per channel) are cut
 // on tile boundaries (L samples, a multiple of 64) and a segment's carry-in is the chain over the tiles ahead of it.
 static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const double *fil, long long fstride, double2 *out, long long stride,
-                                                                         int n, const int *chan_list, PllState *state, const double *again,
-                                                                         PllParam q, const double *ends, long long estride, int L)
+                                                                         int n, const int *chan_list, const PllState *state, const double *again,
+                                                                         PllParam q, const double *ends, long long estride, int L, double *fmdc_out)
 {
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = kSegWaves * (int)gridDim.y, sidx = (int)blockIdx.y * kSegWaves + wave;
@@ -876,7 +899,14 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
             c = lane_bcast(dcs, cnt - 1);
         }
     }
-    if (is_last && lane == 0 && n > 0) state[ch].fmdc = c;      // (nobody reads the carried state after the first lines of the kernel)
+    // a slot of its own: another workgroup of this launch may not have read state[ch].fmdc yet (commit_fmdc_kernel moves it in)
+    if (is_last && lane == 0 && n > 0) fmdc_out[ch] = c;
+}
+
+static __global__ void commit_fmdc_kernel(PllState *state, const double *next, const int *chan_list, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) state[chan_list[i]].fmdc = next[chan_list[i]];
 }
 
 }  // namespace qh

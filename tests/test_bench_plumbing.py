@@ -98,3 +98,32 @@ def test_eight_ranks_strong_256_and_weak_2048(tmp_path):
             end = min(ev["timed_end"][r][k] for r in range(8))
             assert start >= warm - 1e-3 and end >= done - 1e-3
         assert min(ev["warm_done"][r][0] for r in range(8)) >= ev["build"][0][0]
+
+
+def test_self_spawn_eight_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 8` with no WORLD_SIZE in the environment (a driver that does not use torch.distributed.run): bench.py
+    starts the eight ranks itself, before it imports torch, and relays rank 0's one line; every rank's kernel times and channel
+    range are on it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    trace = str(tmp_path / "trace.txt")
+    env["QH_BENCH_TRACE"] = trace
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--log2-samples", "12"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(js) == 1
+    j = json.loads(js[0])
+    assert j["n_gpus"] == 8 and j["dry_run"] is True and j["scaling"] == "weak" and j["config"]["total_channels"] == 2048
+    assert j["ms_per_step"] >= 8.0
+    assert [p["rank"] for p in j["per_rank"]] == list(range(8))
+    assert [p["channels"] for p in j["per_rank"]] == [[256 * k, 256 * (k + 1)] for k in range(8)]
+    assert all(set(p["kernel_ms"]) == {"front_shift_resample", "band_nbp", "state_bookkeeping"} for p in j["per_rank"])
+    ev = _read_trace(trace)
+    assert sorted(ev["timed_start"]) == list(range(8))
+
+
+def test_a_failing_rank_fails_the_self_spawned_job():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--log2-samples", "12", "--total-channels", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0                 # rank 1 has no channel and says so

@@ -8,6 +8,7 @@ import sys
 import time
 
 import numpy as np
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,24 +25,50 @@ def timed(fn, sync, steps=10, warmup=2):
     return (time.perf_counter() - t0) / steps
 
 
-def config3(torch, qh, dev):
-    nch, n, fs = 64, 1 << 20, 1536000.0
+def new_stream(torch, dev):
+    """A stream of the leg's own.  (torch's current stream is the null stream, whose handle 0 tells an engine to make a private
+    non-blocking stream: engines created that way run side by side, which only independent engines may.)"""
+    return torch.cuda.Stream(dev)
+
+
+def c3_taps():
     k = np.arange(1023) - 511
-    taps = np.sinc(k / 32.0) / 32.0 * np.blackman(1023)
-    s = torch.cuda.current_stream(dev).cuda_stream
-    bank = qh.FirBank(nch, taps, 32, stream=s)
-    pan = qh.Panadapter(nch, 16384, 1024, fs, stream=s)
-    x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 20
-    y = torch.empty((nch, n // 32), dtype=torch.complex128, device=dev)
-    sync = lambda: torch.cuda.synchronize(dev)
-    t_fir = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 32), sync)
-    t_pan = timed(lambda: pan.feed_ptr(x.data_ptr(), n, n), sync)
-    t_both = timed(lambda: (bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 32), pan.feed_ptr(x.data_ptr(), n, n)), sync)
+    return np.sinc(k / 32.0) / 32.0 * np.blackman(1023)
+
+
+def setup_config3(torch, qh, dev, nch=64, n=1 << 20):
+    """The engines, buffers and calls of the config 3 leg.  tests/test_gpu_bench_shapes.py checks results through this very function,
+    so that what is timed and what is parity-tested cannot drift apart."""
+    fs = 1536000.0
+    taps = c3_taps()
+    L = SimpleNamespace(nch=nch, n=n, fs=fs, taps=taps)
+    # the FIR and the panadapter are independent consumers of the same samples: a stream each, side by side
+    L.streams = [new_stream(torch, dev), new_stream(torch, dev)]
+    s = L.streams[0].cuda_stream
+    L.bank = qh.FirBank(nch, taps, 32, stream=s)
+    L.pan = qh.Panadapter(nch, 16384, 1024, fs, stream=L.streams[1].cuda_stream)
+    L.x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 20
+    L.y = torch.empty((nch, n // 32), dtype=torch.complex128, device=dev)
     # the same work with the FIR taken out of the panadapter's own transform (qh_pan_attach_fir: the stream is read once)
-    fused = qh.Panadapter(nch, 16384, 1024, fs, stream=s)
-    fused.attach_fir(taps, 32)
-    t_fused = timed(lambda: fused.feed_decimate_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 32), sync)
-    tot = nch * n
+    L.fused = qh.Panadapter(nch, 16384, 1024, fs, stream=s)
+    L.fused.attach_fir(taps, 32)
+    L.y_fused = torch.empty_like(L.y)
+    L.step_fir = lambda: L.bank.process_ptr(L.x.data_ptr(), n, n, L.y.data_ptr(), n // 32)
+    L.step_pan = lambda: L.pan.feed_ptr(L.x.data_ptr(), n, n)
+    L.step_both = lambda: (L.step_fir(), L.step_pan())
+    L.step_fused = lambda: L.fused.feed_decimate_ptr(L.x.data_ptr(), n, n, L.y_fused.data_ptr(), n // 32)
+    torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
+    return L
+
+
+def config3(torch, qh, dev):
+    L = setup_config3(torch, qh, dev)
+    sync = lambda: torch.cuda.synchronize(dev)
+    t_fir = timed(L.step_fir, sync)
+    t_pan = timed(L.step_pan, sync)
+    t_both = timed(L.step_both, sync)
+    t_fused = timed(L.step_fused, sync)
+    tot = L.nch * L.n
     return {"config": "3: 64 ch x 1.536 Msps fp64, 1023-tap FIR /32 + 16384-pt panadapter every block", "samples_per_step": tot,
             "fir_ms": t_fir * 1e3, "pan_ms": t_pan * 1e3, "both_ms": t_both * 1e3, "fused_ms": t_fused * 1e3,
             "best_ms": min(t_both, t_fused) * 1e3, "Msamp_per_s": tot / min(t_both, t_fused) / 1e6,
@@ -50,36 +77,61 @@ def config3(torch, qh, dev):
             "note": "16 B in + 16/32 B FIR out per sample; only the running |X| average leaves the chip (SURVEY.md 8(d): 16.5 B)"}
 
 
-def config4(torch, qh, dev):
+C4_MODES = [1, 6, 5]                      # USB / AM / FM by c mod 3
+C4_KINDS = {1: "usb", 6: "am", 5: "fm"}
+C4_PASSBAND = {1: (300.0, 3000.0), 6: (-4000.0, 4000.0), 5: (-8000.0, 8000.0)}
+
+
+def c4_set_modes(eng, c):
+    """Channel c's mode and passband (an RxaEngine with its channel index first, or the oracle's WdspChannel through a one-line adapter)."""
+    m = C4_MODES[c % 3]
+    eng.SetRXAMode(c, m)
+    eng.RXASetPassband(c, *C4_PASSBAND[m])
+
+
+def c4_common(eng, c, shift):
+    eng.SetRXAShiftRun(c, 1); eng.SetRXAShiftFreq(c, shift); eng.RXANBPSetRun(c, 1)
+    eng.SetRXAAGCMode(c, 0); eng.SetRXAAGCFixed(c, 0.0)
+
+
+def setup_config4(torch, qh, dev, nch=256, nblk=None, modes_now=True):
+    """modes_now=False (the parity test's acquisition form): every channel starts as USB 300..3000 and the caller switches the
+    detectors in with c4_set_modes once the filters hold signal."""
     from quisk_amd import synth
-    nch = 256
-    nblk = int(os.environ.get("QH_C4_NBLK", "4096"))       # DSP blocks per call: 2^22 input samples per channel per step
+    nblk = nblk or int(os.environ.get("QH_C4_NBLK", "4096"))       # DSP blocks per call: 2^22 input samples per channel per step (SURVEY.md 8(d))
     n_in = nblk * 1024
-    eng = qh.RxaEngine(nch, stream=torch.cuda.current_stream(dev).cuda_stream)
-    modes = [1, 6, 5]
+    L = SimpleNamespace(nch=nch, nblk=nblk, n_in=n_in, n_out=nblk * 256)
+    L.stream = new_stream(torch, dev)
+    L.eng = eng = qh.RxaEngine(nch, stream=L.stream.cuda_stream)
     for c in range(nch):
-        m = modes[c % 3]
-        eng.SetRXAShiftRun(c, 1); eng.SetRXAShiftFreq(c, synth.shift_freq(c)); eng.RXANBPSetRun(c, 1)
-        eng.SetRXAMode(c, m); eng.SetRXAAGCMode(c, 0); eng.SetRXAAGCFixed(c, 0.0)
-        if m == 1: eng.RXASetPassband(c, 300.0, 3000.0)
-        elif m == 6: eng.RXASetPassband(c, -4000.0, 4000.0)
-        else: eng.RXASetPassband(c, -8000.0, 8000.0)
+        c4_common(eng, c, synth.shift_freq(c))
+        if modes_now:
+            c4_set_modes(eng, c)
+        else:
+            eng.SetRXAMode(c, 1); eng.RXASetPassband(c, 300.0, 3000.0)
     # SURVEY.md 8(d) C4: USB channels get the two-tone input of C2, AM channels a carrier with m = 0.5 / 1 kHz, FM channels a
     # carrier with a 1 kHz tone at +-3 kHz deviation, all + noise (synth.make_mode_input_numpy)
-    kinds = {1: "usb", 6: "am", 5: "fm"}
-    x = synth.make_mode_input_torch([kinds[modes[c % 3]] for c in range(nch)], n_in, dev)
-    y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
+    L.x = synth.make_mode_input_torch([C4_KINDS[C4_MODES[c % 3]] for c in range(nch)], n_in, dev)
+    L.y = torch.empty((nch, L.n_out), dtype=torch.complex128, device=dev)
+    L.step = lambda: eng.process_ptr(L.x.data_ptr(), n_in, L.y.data_ptr(), L.n_out, nblk)
+    torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
+    return L
+
+
+def config4(torch, qh, dev):
+    L = setup_config4(torch, qh, dev)
+    eng = L.eng
     sync = lambda: torch.cuda.synchronize(dev)
-    t = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=5, warmup=1)
+    t = timed(L.step, sync, steps=5, warmup=1)
     # the same call with the launch sequence replayed from hipGraphs (qh_rxa_set_graph_replay): ~25 launches per call
     eng.set_graph_replay(True)
-    tg = timed(lambda: eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=8, warmup=4)
+    tg = timed(L.step, sync, steps=8, warmup=4)
     eng.set_graph_replay(False)
     eng.enable_timing(True)
-    eng.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk)
+    L.step()
     kt = eng.timing_ms()
     eng.enable_timing(False)
-    tot = nch * n_in
+    tot = L.nch * L.n_in
     return {"front_ms": kt[0], "band_ms": kt[1], "rest_ms": kt[2],
             "config": "4 (one GPU's share): 256 ch x 192 k, mode by c mod 3 = USB / AM / FM, fp64", "samples_per_step": tot,
             "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "ms_graph_replay": tg * 1e3, "Msamp_per_s_graph_replay": tot / tg / 1e6,
@@ -88,66 +140,98 @@ def config4(torch, qh, dev):
             "note": "AM / FM / notch recurrences time-tiled (qh_tiled.hpp); pll_tiles_rerun = FM tiles the verify pass re-ran sequentially over all steps"}
 
 
-def config2_agc(torch, qh, dev):
+def setup_config2_agc(torch, qh, dev, nch=256, nblk=None):
     """BASELINE config 2's chain with WDSP's AGC state machine running (SetRXAAGCMode 3, the mode Quisk's WDSP path sets by default)
     instead of the fixed gain the configuration specifies: the level detector in time tiles (qh_agc_tiled.hpp)."""
     from quisk_amd import synth
-    nch, nblk = 256, int(os.environ.get("QH_C2A_NBLK", "4096"))
+    nblk = nblk or int(os.environ.get("QH_C2A_NBLK", "4096"))
     n_in = nblk * 1024
+    L = SimpleNamespace(nch=nch, nblk=nblk, n_in=n_in, n_out=nblk * 256)
     # the same buffer is fed every step: the tones sit on the buffer's frequency grid (moved by < 0.023 Hz), so that the steps are one
     # continuous stream -- a phase jump per call is a click the AGC answers for seconds, which no receiver's input has
-    x = synth.make_mode_input_torch(["usb"] * nch, n_in, dev, periodic=True)
-    y = torch.empty((nch, nblk * 256), dtype=torch.complex128, device=dev)
-    e = qh.RxaEngine(nch, stream=torch.cuda.current_stream(dev).cuda_stream)
+    L.x = synth.make_mode_input_torch(["usb"] * nch, n_in, dev, periodic=True)
+    L.y = torch.empty((nch, L.n_out), dtype=torch.complex128, device=dev)
+    L.stream = new_stream(torch, dev)
+    L.eng = e = qh.RxaEngine(nch, stream=L.stream.cuda_stream)
     for c in range(nch):
-        e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, synth.shift_freq(c)); e.RXANBPSetRun(c, 1); e.SetRXAMode(c, 1)
-        e.RXASetPassband(c, 300.0, 3000.0); e.SetRXAAGCMode(c, 3)
+        c2agc_setters(e, c, synth.shift_freq(c))
+    L.step = lambda: e.process_ptr(L.x.data_ptr(), n_in, L.y.data_ptr(), L.n_out, nblk)
+    torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
+    return L
+
+
+def c2agc_setters(e, c, shift):
+    e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, shift); e.RXANBPSetRun(c, 1); e.SetRXAMode(c, 1)
+    e.RXASetPassband(c, 300.0, 3000.0); e.SetRXAAGCMode(c, 3)
+
+
+def config2_agc(torch, qh, dev):
+    L = setup_config2_agc(torch, qh, dev)
+    e = L.eng
     sync = lambda: torch.cuda.synchronize(dev)
-    t = timed(lambda: e.process_ptr(x.data_ptr(), n_in, y.data_ptr(), nblk * 256, nblk), sync, steps=4, warmup=2)
-    tot = nch * n_in
-    return {"config": "2 with the AGC state machine on (SetRXAAGCMode 3): 256 ch x 192 k SSB RXA, fp64, 2^%d samples per channel and step" % (n_in.bit_length() - 1),
+    t = timed(L.step, sync, steps=4, warmup=2)
+    tot = L.nch * L.n_in
+    return {"config": "2 with the AGC state machine on (SetRXAAGCMode 3): 256 ch x 192 k SSB RXA, fp64, 2^%d samples per channel and step" % (L.n_in.bit_length() - 1),
             "samples_per_step": tot, "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "agc_tiles_rerun": e.agc_repairs(),
             "agc_segments_rerun": e.agc_segments_rerun(),
             "note": "not a BASELINE configuration (config 2 fixes the gain); agc_tiles_rerun = tiles whose boundary state the exact pass corrected"}
 
 
-def config5(torch, qh, dev):
-    n = 1 << 26                 # 61.44 Msps stream, ~1.09 s of signal, fp32
-    s = torch.cuda.current_stream(dev).cuda_stream
-    tabs = __import__("quisk_amd.rxfilter", fromlist=["x"]).coefficient_tables()
-    hb = [qh.FirBank(1, qh.hb45_taps(), 2, dtype=1, stream=s) for _ in range(8)]
-    d5 = qh.FirBank(1, tabs["quiskFilt240D5CoefsSharp"], 5, dtype=1, stream=s)
-    # WDSP bandpass 300..3000 at 48 k, nc 2048 (fir_bandpass via the library's own design is internal; the bank takes taps)
+def c5_bandpass_taps():
+    """WDSP bandpass 300..3000 at 48 k, nc 2048, BH-4 (fir_bandpass, wdsp/fir.c:187-254) as linear-convolution taps for a FirBank."""
     m = 0.5 * 2047
     pos = np.arange(2048) - m
     c = np.cos(np.pi / m * np.arange(2048))
     win = 0.21747 + c * (-0.45325 + c * (0.28256 + c * (-0.04672)))
     ft = (3000.0 - 300.0) / (2 * 48000.0)
-    bp = np.sin(2 * np.pi * ft * pos) / (np.pi * pos) * win * np.exp(-1j * np.pi * 3300.0 / 48000.0 * pos)
-    core = qh.FirBank(1, bp, 1, dtype=1, stream=s)
-    x = torch.randn((1, n), dtype=torch.float32, device=dev) + 1j * torch.randn((1, n), dtype=torch.float32, device=dev)
-    bufs = [torch.empty((1, n >> (k + 1)), dtype=torch.complex64, device=dev) for k in range(8)]
-    y5 = torch.empty((1, (n >> 8) // 5 + 8), dtype=torch.complex64, device=dev)
-    yo = torch.empty_like(y5)
+    return np.sin(2 * np.pi * ft * pos) / (np.pi * pos) * win * np.exp(-1j * np.pi * 3300.0 / 48000.0 * pos)
 
-    def step():
-        cur, cn = x, n
-        for k in range(8):
-            m_ = hb[k].process_ptr(cur.data_ptr(), cur.shape[1], cn, bufs[k].data_ptr(), bufs[k].shape[1])
-            cur, cn = bufs[k], m_
-        m_ = d5.process_ptr(cur.data_ptr(), cur.shape[1], cn, y5.data_ptr(), y5.shape[1])
-        core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
-    casc = qh.HalfBandCascade(1, 8, dtype=1, stream=s)
 
-    def step_fused():
-        m_ = casc.process_ptr(x.data_ptr(), n, n, bufs[7].data_ptr(), bufs[7].shape[1])
-        m_ = d5.process_ptr(bufs[7].data_ptr(), bufs[7].shape[1], m_, y5.data_ptr(), y5.shape[1])
-        core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
+def setup_config5(torch, qh, dev, n=1 << 26, unfused=True):
+    """61.44 Msps stream, ~1.09 s of signal, fp32: the fused half-band cascade, the 245-tap /5 and the bandpass (step_fused, what the
+    driver's line reports) and, with unfused, the eight half-band banks one after the other (step)."""
+    tabs = __import__("quisk_amd.rxfilter", fromlist=["x"]).coefficient_tables()
+    L = SimpleNamespace(n=n, taps245=tabs["quiskFilt240D5CoefsSharp"], bp=c5_bandpass_taps())
+    L.stream = new_stream(torch, dev)           # one stream: every stage reads what the stage before it wrote
+    s = L.stream.cuda_stream
+    L.d5 = d5 = qh.FirBank(1, L.taps245, 5, dtype=1, stream=s)
+    L.core = core = qh.FirBank(1, L.bp, 1, dtype=1, stream=s)
+    L.x = x = torch.randn((1, n), dtype=torch.float32, device=dev) + 1j * torch.randn((1, n), dtype=torch.float32, device=dev)
+    L.bufs = bufs = [torch.empty((1, n >> (k + 1)), dtype=torch.complex64, device=dev) for k in (range(8) if unfused else (7,))]
+    L.y5 = y5 = torch.empty((1, (n >> 8) // 5 + 8), dtype=torch.complex64, device=dev)
+    L.yo = yo = torch.empty_like(y5)
+    L.casc = casc = qh.HalfBandCascade(1, 8, dtype=1, stream=s)
+    if unfused:
+        L.hb = hb = [qh.FirBank(1, qh.hb45_taps(), 2, dtype=1, stream=s) for _ in range(8)]
+
+        def step():
+            cur, cn = x, n
+            for k in range(8):
+                m_ = hb[k].process_ptr(cur.data_ptr(), cur.shape[1], cn, bufs[k].data_ptr(), bufs[k].shape[1])
+                cur, cn = bufs[k], m_
+            m_ = d5.process_ptr(cur.data_ptr(), cur.shape[1], cn, y5.data_ptr(), y5.shape[1])
+            return core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
+        L.step = step
+
+    def step_fused(src=None, nn=None):
+        src = x.data_ptr() if src is None else src
+        nn = n if nn is None else nn
+        m_ = casc.process_ptr(src, nn, nn, bufs[-1].data_ptr(), bufs[-1].shape[1])
+        m_ = d5.process_ptr(bufs[-1].data_ptr(), bufs[-1].shape[1], m_, y5.data_ptr(), y5.shape[1])
+        return core.process_ptr(y5.data_ptr(), y5.shape[1], m_, yo.data_ptr(), yo.shape[1])
+    L.step_fused = step_fused
+    torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
+    return L
+
+
+def config5(torch, qh, dev):
+    L = setup_config5(torch, qh, dev)
+    n, x, bufs = L.n, L.x, L.bufs
     sync = lambda: torch.cuda.synchronize(dev)
-    t = timed(step, sync, steps=10, warmup=2)
-    t1 = timed(lambda: hb[0].process_ptr(x.data_ptr(), n, n, bufs[0].data_ptr(), bufs[0].shape[1]), sync, steps=10, warmup=2)
-    tf = timed(step_fused, sync, steps=10, warmup=2)
-    tc = timed(lambda: casc.process_ptr(x.data_ptr(), n, n, bufs[7].data_ptr(), bufs[7].shape[1]), sync, steps=10, warmup=2)
+    t = timed(L.step, sync, steps=10, warmup=2)
+    t1 = timed(lambda: L.hb[0].process_ptr(x.data_ptr(), n, n, bufs[0].data_ptr(), bufs[0].shape[1]), sync, steps=10, warmup=2)
+    tf = timed(L.step_fused, sync, steps=10, warmup=2)
+    tc = timed(lambda: L.casc.process_ptr(x.data_ptr(), n, n, bufs[7].data_ptr(), bufs[7].shape[1]), sync, steps=10, warmup=2)
     return {"fused_ms": tf * 1e3, "fused_Msamp_per_s": n / tf / 1e6, "fused_cascade_only_ms": tc * 1e3,
             "fused_algorithmic_GBps": 8.0 * n / tf / 1e9,
             "config": "5 (one GPU's channel): 1 ch x 61.44 Msps fp32, 8 x HB45 + 245-tap /5 + bandpass nc 2048, 2^26 samples per step",
@@ -156,36 +240,56 @@ def config5(torch, qh, dev):
             "note": "unfused cascade of overlap-save banks; the first half-band alone moves 12 B/sample"}
 
 
-def quisk_native(torch, qh, dev):
-    """Path A: 256 receivers of Quisk's own chain (quisk_process_samples: tune, quisk_process_decimate, cRxFilterOut, the x4
-    interpolators), 192 ksps in, 48 ksps out, USB, AM and FM, 2^20 input samples per receiver per step.  The reference's own
-    figure for ONE receiver on a CPU core is 9.9 Msamp/s (SURVEY.md 8 a10)."""
+QN_MODES = (("USB", 3, 2700), ("AM", 4, 6000), ("FM", 5, 12000))      # name, Quisk mode number (quisk.h:55-70), bandwidth
+QN_AGC_GAIN = 5000.0
+
+
+def qn_tune(c):
+    return 1000 * (c % 40) - 20000
+
+
+def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20):
+    """One mode of the Quisk-native leg: 256 receivers of Quisk's own chain (quisk_process_samples: tune, quisk_process_decimate,
+    cRxFilterOut, the x4 interpolators), 192 ksps in, 48 ksps out."""
     from quisk_amd import rxfilter
-    nch, n, fs = 256, 1 << 20, 192000
+    fs = 192000
+    mode, bw = {m[0]: (m[1], m[2]) for m in QN_MODES}[name]
+    L = SimpleNamespace(nch=nch, n=n, fs=fs, mode=mode, bw=bw, name=name)
+    L.stream = new_stream(torch, dev)
+    L.bank = bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=L.stream.cuda_stream)
+    L.rate = bank.get_filter_rate()
+    L.fI, L.fQ = rxfilter.make_filter_coef(L.rate, None, bw, rxfilter.get_filter_center(name, bw))
+    for c in range(nch):
+        bank.set_tune(c, qn_tune(c))
+    bank.set_filters(-1, L.fI, L.fQ)
+    L.x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 22
+    L.m = bank.out_count(n)
+    L.y = torch.empty((nch, L.m + 64), dtype=torch.complex128, device=dev)
+    L.step = lambda: bank.process_ptr(L.x.data_ptr(), n, n, L.y.data_ptr(), L.m + 64)
+    torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
+    return L
+
+
+def quisk_native(torch, qh, dev):
+    """Path A: 256 receivers, USB, AM and FM, 2^20 input samples per receiver per step.  The reference's own
+    figure for ONE receiver on a CPU core is 9.9 Msamp/s (SURVEY.md 8 a10)."""
+    nch, n = 256, 1 << 20
     out = []
     only = os.environ.get("QH_QUISK_MODES", "USB,AM,FM").split(",")          # e.g. QH_QUISK_MODES=FM for a kernel trace of one mode
-    for name, mode, bw in (("USB", rxfilter.USB, 2700), ("AM", rxfilter.AM, 6000), ("FM", rxfilter.FM, 12000)):
+    for name, mode, bw in QN_MODES:
         if name not in only:
             continue
-        bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=torch.cuda.current_stream(dev).cuda_stream)
-        rate = bank.get_filter_rate()
-        fI, fQ = rxfilter.make_filter_coef(rate, None, bw, rxfilter.get_filter_center(name, bw))
-        for c in range(nch):
-            bank.set_tune(c, 1000 * (c % 40) - 20000)
-        bank.set_filters(-1, fI, fQ)
-        x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 22
-        m = bank.out_count(n)
-        y = torch.empty((nch, m + 64), dtype=torch.complex128, device=dev)
+        L = setup_quisk_native(torch, qh, dev, name)
         sync = lambda: torch.cuda.synchronize(dev)
-        t = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), m + 64), sync, steps=8, warmup=2)
-        row = {"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": rate, "filter_taps": int(fI.size)}
+        t = timed(L.step, sync, steps=8, warmup=2)
+        row = {"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": L.rate, "filter_taps": int(L.fI.size)}
         # process_agc on the output, as quisk_process_samples always runs it (quisk.c:2685-2701); a release gain at which the
         # limiter works (an overload ramp every few FIFO cycles): the state machine is sequential per receiver, one wavefront each
-        bank.set_agc(True, 5000.0)
-        ta = timed(lambda: bank.process_ptr(x.data_ptr(), n, n, y.data_ptr(), m + 64), sync, steps=6, warmup=2)
+        L.bank.set_agc(True, QN_AGC_GAIN)
+        ta = timed(L.step, sync, steps=6, warmup=2)
         row.update({"agc_on_ms": ta * 1e3, "agc_on_Msamp_per_s": nch * n / ta / 1e6})
         out.append(row)
-        del bank, x, y
+        del L
     return {"config": "Quisk-native chain (path A): 256 receivers x 192 ksps -> 48 ksps, 2^20 input samples per receiver per step",
             "samples_per_step": nch * n, "modes": out,
             "note": "the reference's quisk_process_samples handles one receiver per process: 9.9 Msamp/s on a CPU core (SURVEY.md 8 a10)"}
@@ -195,7 +299,8 @@ def analyzer(torch, qh, dev):
     """WDSP display engine (wdsp/analyzer.c) for a bank of 64 displays fed 2^20 samples each per step: 16384-point frames with
     50 % overlap (127 frames per display and step), Blackman-Harris window, peak detector to 2048 pixels, recursive averaging."""
     nd, n, size = 64, 1 << 20, 16384
-    a = qh.AnalyzerBank(nd, size, stream=torch.cuda.current_stream(dev).cuda_stream)
+    stream = new_stream(torch, dev)
+    a = qh.AnalyzerBank(nd, size, stream=stream.cuda_stream)
     a.SetDisplaySampleRate(1536000)
     a.SetDisplayAverageMode(0, 1)
     a.SetDisplayAvBackmult(0, 0.9)
@@ -211,12 +316,65 @@ def analyzer(torch, qh, dev):
             "note": "16 B per input sample read once; the frames' 2x overlap is served from the float copy the engine keeps"}
 
 
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def driver_legs(torch, qh, dev, emit):
+    """The extra legs of bench.py's line (`other_configs`): per configuration the algorithmic bytes per input sample,
+    the rate, GB/s against the 8 TB/s roofline, and the kernel that takes most of the step.  emit(key, leg) is called as each leg
+    finishes, so that a later leg's fault loses nothing that was measured."""
+    def leg(key, fn, bytes_per_sample, ms_key, dominant):
+        try:
+            r = fn(torch, qh, dev)
+            ms = r[ms_key]
+            rate = r["samples_per_step"] / (ms * 1e-3)
+            gbps = bytes_per_sample * rate / 1e9
+            name, kms = dominant(r)
+            emit(key, {"workload": r["config"], "samples_per_step": r["samples_per_step"], "ms_per_step": ms, "Msamp_per_s": rate / 1e6,
+                       "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                       "dominant_kernel": name, "dominant_kernel_ms": kms, "detail": {k: v for k, v in r.items() if k not in ("config",)}})
+        except Exception as exc:                                 # reported, never required
+            emit(key, {"failed": repr(exc)})
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+
+    # config 3: 16 B in (read once by the FIR and once by the transform) + 16/32 B FIR output; the |X| sums stay on the chip and only
+    # the running average leaves it, so SURVEY.md 8(d)'s 16.5 B, not 24.5
+    leg("config3", config3, 16.5, "best_ms",
+        lambda r: ("pan16k_kernel (16384-point panadapter, read-once)", r["pan_ms"]) if r["pan_ms"] >= r["fir_ms"]
+        else ("osfir_kernel<f64,4096,D=8,pick 4> (1023-tap /32)", r["fir_ms"]))
+    # config 4: the call's launch sequence replayed from a hipGraph (qh_rxa_set_graph_replay), the engine's mode for repeated calls
+    leg("config4", config4, 20.0, "ms_graph_replay", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
+    leg("config5", config5, 8.0, "fused_ms", lambda r: ("hb45_cascade_kernel<float,4> x 2 (4 + 4 stages)", r["fused_cascade_only_ms"]))
+    # the headline chain with WDSP's AGC state machine on (not a BASELINE configuration: config 2 fixes the gain)
+    leg("config2_agc_on", config2_agc, 20.0, "ms", lambda r: ("agc_bounds_kernel (the level detector's state at the tile boundaries)", None))
+    try:
+        r = quisk_native(torch, qh, dev)
+        emit("quisk_native", {"workload": r["config"], "samples_per_step": r["samples_per_step"], "algorithmic_bytes_per_sample": 20.0,
+                              "modes": [dict({"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
+                                              "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
+                                              "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS},
+                                             **{k: m[k] for k in ("agc_on_ms", "agc_on_Msamp_per_s") if k in m}) for m in r["modes"]],
+                              "agc_note": "agc_on_*: process_agc (quisk.c:2162) on the output, one wavefront per receiver (q_agc_chain_kernel)",
+                              "dominant_kernel": "osfir_kernel<f64,4096,D=8,OUTMIX> (tune + collapsed 1181-tap /16)"})
+    except Exception as exc:
+        emit("quisk_native", {"failed": repr(exc)})
+
+
 def main():
     import torch
     import quisk_amd as qh
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     which = sys.argv[1:] or ["3", "4", "5"]
+    if which[0] == "driver":                 # bench.py's child: one JSON object per finished leg, appended to the file named
+        path = which[1]
+
+        def emit(key, leg):
+            with open(path, "a") as fh:
+                fh.write(json.dumps({"key": key, "leg": leg}) + "\n")
+        driver_legs(torch, qh, dev, emit)
+        return
     for w in which:
         r = {"3": config3, "4": config4, "5": config5, "2agc": config2_agc, "analyzer": analyzer, "quisk": quisk_native}[w](torch, qh, dev)
         print(json.dumps(r), flush=True)

@@ -50,6 +50,8 @@ def write_c2_traffic(res, bench_args, path):
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             kern[key] = {"kernel": name, "fetch_bytes_x2": 2048.0 * v["FETCH_SIZE"], "write_bytes": 1024.0 * v["WRITE_SIZE"],
                          "bytes_per_input_sample": (2048.0 * v["FETCH_SIZE"] + 1024.0 * v["WRITE_SIZE"]) / samples}
+            if "SQ_INSTS_VALU" in v:        # wave-level VALU instructions executed per launch: x 64 lanes = lane operations
+                kern[key]["valu_wave_insts_per_input_sample"] = v["SQ_INSTS_VALU"] / samples
     j = {"source_sha16": bench.kernel_source_sha16(), "meters": meters, "log2_samples": log2, "channels": 256, "kernels": kern,
          "source": "tools/pmc_pass.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over bench.py " + " ".join(bench_args)}
     os.makedirs(os.path.dirname(path), exist_ok=True)
