@@ -679,11 +679,49 @@ int qh_quisk_set_filters_n(const double *filtI, const double *filtQ, int size, i
 void qh_quisk_set_squelch(double level);                                   /* set_squelch (FM), quisk.c:4721 */
 void qh_quisk_set_ssb_squelch(int enabled, int level);                     /* set_ssb_squelch, quisk.c:4729 */
 int qh_quisk_squelch_flags(void);                                          /* bit 0 squelch_real, bit 1 squelch_imag of the last block */
+/* quisk_process_samples has no error return (failures are QuiskPrintf + counters, quisk.c:55): a call whose device chain failed returns
+ * 0 samples, qh_last_error() says why, and this counter says that it happened (0 samples alone also means "no output yet") */
+long long qh_quisk_error_count(void);
 void qh_quisk_add_tone(int freq);                                          /* add_tone, quisk.c:3203 */
 double qh_quisk_measure_frequency(int mode);                               /* measure_frequency, quisk.c:3181 */
 void qh_quisk_set_multirx_count(int n);                                    /* quisk_multirx_count */
 void qh_quisk_set_sub_rx1_output(int on);                                  /* quiskPlaybackDevices[QUISK_INDEX_SUB_RX1]->driver */
 int qh_quisk_sub_rx1_audio(double *cSamples, int cap);                     /* the block play_sound_interface got, quisk.c:2651 */
+/* ------------------------------------------------------------------ 9b. quisk_process_samples for a bank of receivers */
+/* The whole of quisk_process_samples (quisk.c:2289-2742) for `nch` receivers side by side -- the batched form SURVEY.md 8(b) asks
+ * for beside the drop-in symbols: AddTestTone / inversion (quisk.c:2438-2446), NoiseBlanker (:2448), the FFT ring feed on the same
+ * samples (:2454-2475), tune + quisk_process_decimate + quisk_process_demodulate (:2477-2530), cFracDecim (:2654), the HB45
+ * interpolation to the playback rate (:2663-2682), process_agc (:2686-2702, always on as in the reference) and kill_audio / the
+ * squelches (:2712-2728).  Per receiver: tune frequency, Rx filter, FM squelch level; the rest are the bank's, as they are
+ * process-wide globals in the reference.  The operator's side of the function (key-down replacement, key-up envelope, split and
+ * sub-receiver channels, measure_freq, the WDSP hand-off) stays with the one-receiver API of group 9, which runs the same kernels
+ * with nch = 1 (qh_ps_kernels.hpp).  fft_size / data_width 0, 0 = no panadapter.  stream NULL = a stream of the bank's own. */
+typedef struct qh_qps qh_qps;
+qh_qps *qh_qps_create(int device, int nch, int sample_rate, int playback_rate, int mode, int bandwidth, const qh_qrx_tables *tables,
+                      int fft_size, int data_width, void *stream);
+void qh_qps_destroy(qh_qps *h);
+int qh_qps_set_tune(qh_qps *h, int ch, int rx_tune_freq);                  /* set_tune, quisk.c:4702; ch -1 = all */
+int qh_qps_set_filters(qh_qps *h, int ch, const double *filtI, const double *filtQ, int size);     /* set_filters, quisk.c:4551 */
+int qh_qps_set_agc(qh_qps *h, double level);                               /* set_agc, quisk.c:4543 (agcReleaseGain, default 80) */
+int qh_qps_set_noise_blanker(qh_qps *h, int level);                        /* set_noise_blanker, quisk.c:4605 */
+int qh_qps_set_auto_notch(qh_qps *h, int on, int rit_freq);                /* set_auto_notch, quisk.c:4596 */
+int qh_qps_invert_spectrum(qh_qps *h, int invert);                         /* quisk.c:4535 */
+int qh_qps_set_kill_audio(qh_qps *h, int kill);
+int qh_qps_add_tone(qh_qps *h, int freq);                                  /* add_tone, quisk.c:3203; 0 = off */
+int qh_qps_set_squelch(qh_qps *h, int ch, double level);                   /* set_squelch (FM), quisk.c:4721 */
+int qh_qps_set_ssb_squelch(qh_qps *h, int enabled, int level);             /* set_ssb_squelch, quisk.c:4729 */
+/* long calls run as `pieces` time pieces, process_agc of one beside the filters of the next (0 = chosen by call length) */
+int qh_qps_set_pieces(qh_qps *h, int pieces);
+int qh_qps_filter_rate(qh_qps *h);                                         /* get_filter_rate, quisk.c:2787 */
+int qh_qps_decim_rate(qh_qps *h);
+int qh_qps_out_capacity(qh_qps *h, int n_in);                              /* the most playback samples a call of n_in returns: out_stride >= this */
+/* device rows [nch][stride] of complex doubles; *n_out = playback samples per receiver; asynchronous on the bank's stream */
+int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, double *d_out, long long out_stride, int *n_out);
+int qh_qps_process_host(qh_qps *h, const double *h_in, long long in_stride, int n, double *h_out, long long out_stride, int *n_out);
+int qh_qps_synchronize(qh_qps *h);
+int qh_qps_squelch_flags(qh_qps *h, int *flags);                           /* squelch_real of every receiver after the last call */
+int qh_qps_get_graph(qh_qps *h, double zoom, double deltaf, double *pixels, double *smeter, int *count);   /* get_graph, quisk.c:5142 */
+
 /* Plumbing between the block API and the engines it chains (device-resident; used by qh_quisk_rx_compat.cpp): the bank
  * leaves the squelch to its caller and says where the flag lives; ssb_squelch's one-for-all-banks `plan` static
  * (quisk.c:1091,1104); the tuning oscillator's phase in 2^-64 turns (one vector per purpose in the reference,

@@ -8,10 +8,10 @@ from .lib import load, QuiskHipError          # noqa: F401
 from .rxa import RxaEngine, AudioFormat       # noqa: F401
 from .fir import FirBank, HalfBandCascade, RationalFir, hb45_taps           # noqa: F401
 from .pan import Panadapter, Bandscope, waterfall_rows                   # noqa: F401
-from .qrx import QuiskRxBank, QuiskAgc, NoiseBlanker                  # noqa: F401
+from .qrx import QuiskRxBank, QuiskProcessBank, QuiskAgc, NoiseBlanker                  # noqa: F401
 from .analyzer import AnalyzerBank, WdspDisplay       # noqa: F401
 from . import ingest                          # noqa: F401
 from . import quiskapi                        # noqa: F401
 from .ingest import IqFormat                  # noqa: F401
 
-__all__ = ["load", "QuiskHipError", "RxaEngine", "AudioFormat", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "Bandscope", "waterfall_rows", "QuiskRxBank", "QuiskAgc", "NoiseBlanker", "AnalyzerBank", "WdspDisplay", "ingest", "IqFormat", "quiskapi"]
+__all__ = ["load", "QuiskHipError", "RxaEngine", "AudioFormat", "FirBank", "HalfBandCascade", "RationalFir", "hb45_taps", "Panadapter", "Bandscope", "waterfall_rows", "QuiskRxBank", "QuiskProcessBank", "QuiskAgc", "NoiseBlanker", "AnalyzerBank", "WdspDisplay", "ingest", "IqFormat", "quiskapi"]

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libquiskhip.so")
-SOURCES = ["qh_engine.hip", "qh_fir.hip", "qh_pan.hip", "qh_qrx.hip", "qh_hbcascade.hip", "qh_polyphase.hip", "qh_ingest.hip", "qh_qagc.hip", "qh_nb.hip", "qh_analyzer.hip", "qh_wdsp_compat.cpp", "qh_quisk_compat.cpp", "qh_quisk_rx_compat.cpp", "qh_design.cpp"]
+SOURCES = ["qh_engine.hip", "qh_fir.hip", "qh_pan.hip", "qh_qrx.hip", "qh_hbcascade.hip", "qh_polyphase.hip", "qh_ingest.hip", "qh_qagc.hip", "qh_nb.hip", "qh_analyzer.hip", "qh_wdsp_compat.cpp", "qh_quisk_compat.cpp", "qh_quisk_rx_compat.cpp", "qh_qps.hip", "qh_design.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))) + [os.path.join("..", "..", "include", "quiskhip.h")]
 
 

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <vector>
 #include "qh_internal.hpp"
+#include "qh_ps_kernels.hpp"      // the steps shared with the receiver bank of the whole function (qh_qps.hip): this file runs them with nch = 1
 
 
 namespace {
@@ -38,39 +39,6 @@ namespace {
 using u64 = unsigned long long;
 constexpr int kBuf2Chan = 12000;            // BUF2CHAN_SIZE, quisk.c:1576
 constexpr int kMfSize = 12000;              // measure_freq's fft_size, quisk.c:5586
-
-__device__ __forceinline__ double2 turns_phasor(u64 ph)
-{
-    double s, c;
-    sincospi(2.0 * ((double)(ph >> 11) * (1.0 / 9007199254740992.0)), &s, &c);
-    return make_double2(c, s);
-}
-
-// AddTestTone (quisk.c:1258-1303) and the spectrum inversion (quisk.c:2441-2446) in one pass, out of place: the split
-// receiver keeps the raw block (orig_cSamples is copied ahead of both, quisk.c:2361-2363).
-//   kind 0: x += A e^{j th}        1 (AM): x += A e^{j th} (1 + cos a)        2 (FM): x += A e^{j th} e^{j cos a}
-// th / a: phases of testtoneVector / audioVector in 2^-64 turns, advanced per sample by dth / da.
-__global__ void ps_prep_kernel(const double2 *in, double2 *out, int n, int kind, u64 th0, u64 dth, u64 a0, u64 da, int invert)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double2 x = in[i];
-    if (kind >= 0) {
-        const double A = 21474836.47;                   // -40 dB, quisk.c:1263
-        double2 t = turns_phasor(th0 + dth * (u64)i);
-        if (kind == 1) {
-            const double g = 1.0 + turns_phasor(a0 + da * (u64)i).x;
-            t.x *= g; t.y *= g;
-        } else if (kind == 2) {
-            double s, c;
-            sincos(turns_phasor(a0 + da * (u64)i).x, &s, &c);
-            t = make_double2(t.x * c - t.y * s, t.x * s + t.y * c);
-        }
-        x.x += A * t.x; x.y += A * t.y;
-    }
-    if (invert) x.y = -x.y;
-    out[i] = x;
-}
 
 // The stereo join of the two demodulated streams (quisk.c:2548-2620) behind Buffer2Chan (quisk.c:1577-1611).  Stream k is the
 // concatenation of what Buffer2Chan held back for it (buf_k, nbuf_k samples) and the real parts of this call's bank output.
@@ -96,32 +64,6 @@ __global__ void ps_b2c_keep_kernel(const double *buf1, int nbuf1, const double2 
     if (i < keep2) new2[i] = b2c_at(buf2, nbuf2, s2, nout + i);
 }
 
-// cFracDecim (quisk.c:622-665): a 4-point Lagrange interpolator stepped by fdecim input samples per output.  The reference
-// carries `dindex`: +(fdecim - 1) per output, -1 per skipped input.  Unrolled, output m of a call sits at
-//   w = d0 + m (fdecim - 1),  input index i_m = m + floor(w) - 1,  position within (c0..c3) = w - floor(w) + 1  in [1, 2)
-// with d0 the carried dindex: one lane per output.  hist = the last three inputs of the call before (c0, c1, c2).
-__global__ void ps_fracdecim_kernel(const double2 *in, const double2 *hist, int nout, double d0, double step, double2 *out)
-{
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nout) return;
-    const double w = fma(step, (double)m, d0), fl = floor(w);
-    const int i = m + (int)fl - 1;
-    const double d = w - fl + 1.0;
-    double2 c[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int j = i - 3 + k; c[k] = j >= 0 ? in[j] : hist[3 + j]; }
-    const double xm0 = d, xm1 = d - 1, xm2 = d - 2, xm3 = d - 3;
-    const double w0 = xm1 * xm2 * xm3 / -6.0, w1 = xm0 * xm2 * xm3 / 2.0, w2 = xm0 * xm1 * xm3 / -2.0, w3 = xm0 * xm1 * xm2 / 6.0;
-    out[m] = make_double2(w0 * c[0].x + w1 * c[1].x + w2 * c[2].x + w3 * c[3].x, w0 * c[0].y + w1 * c[1].y + w2 * c[2].y + w3 * c[3].y);
-}
-__global__ void ps_fd_hist_kernel(const double2 *in, int n, const double2 *hist_old, double2 *hist_new)
-{
-    const int k = threadIdx.x;                          // 3 lanes
-    if (k >= 3) return;
-    const int j = n - 3 + k;
-    hist_new[k] = j >= 0 ? in[j] : hist_old[3 + j];
-}
-
 // the two output channels as two real streams for Agc1 / Agc2 and back (quisk.c:2690-2698)
 __global__ void ps_split_kernel(const double2 *x, int n, double2 *a, double2 *b)
 {
@@ -136,34 +78,9 @@ __global__ void ps_merge_kernel(const double2 *a, const double2 *b, int n, doubl
     if (i >= n) return;
     x[i] = make_double2(a[i].x, b[i].x);
 }
-// kill_audio / the squelch of either output channel (quisk.c:2712-2728), then the key-up envelope (quisk.c:2729-2738; the
-// host steps keyupEnvelope the way the reference does and hands over the factors of the first env_n samples).
-// flags_out[0..1] = squelch_real, squelch_imag as the reference leaves them.
-__global__ void ps_epilogue_kernel(double2 *x, int n, const int *flag_real, const int *flag_imag, int kill, const double *env, int env_n,
-                                   int *flags_out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int sr = flag_real ? *flag_real : 0, si = flag_imag ? *flag_imag : 0;
-    if (kill) sr = si = 1;
-    if (i == 0) { flags_out[0] = sr; flags_out[1] = si; }
-    if (i >= n) return;
-    double2 v = x[i];
-    if (sr) v.x = 0.0;
-    if (si) v.y = 0.0;
-    if (i < env_n) { const double e = env[i]; v.x *= e; v.y *= e; }
-    x[i] = v;
-}
-
 inline unsigned grid_for(int n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
-// 2^-64 turns per sample for a tone of `freq` Hz at `rate` (any sign)
-u64 turns_step(double freq, double rate)
-{
-    long double t = (long double)freq / (long double)rate;
-    t -= floorl(t);
-    const long double sc = t * 18446744073709551616.0L;
-    return sc >= 18446744073709551616.0L ? 0ull : (u64)sc;
-}
+using qh_ps::turns_step;
 
 template <typename T> struct DevBuf {           // grows on demand; contents are not kept across a growth
     T *p = nullptr;
@@ -272,13 +189,13 @@ struct QuiskRx {
     std::vector<double> mf_avg;
     // work buffers
     DevBuf<double2> d_raw, d_x, d_nb, d_o0, d_o1, d_mix, d_fd, d_up, d_a, d_b, d_sub, d_sub0, d_s1, d_mf, d_mf8;
-    DevBuf<double> d_env;
     int *d_flags = nullptr;
     PinBuf<double> h_in, h_out, h_sub1;
     int *h_flags = nullptr;
     std::vector<double> sub1_out;               // sub-receiver 1's audio of the last call (what play_sound_interface got)
     int sub1_n = 0;
     int squelch_real = 0, squelch_imag = 0;
+    long long failed_calls = 0;                 // calls whose device chain failed: the caller got 0 samples, which alone says nothing
 };
 
 QuiskRx g;
@@ -370,7 +287,7 @@ void free_all()
     if (g.mf_fft) { qh_pan_destroy(g.mf_fft); g.mf_fft = nullptr; }
     g.d_raw.release(); g.d_x.release(); g.d_nb.release(); g.d_o0.release(); g.d_o1.release(); g.d_mix.release(); g.d_fd.release();
     g.d_up.release(); g.d_a.release(); g.d_b.release(); g.d_sub.release(); g.d_sub0.release(); g.d_s1.release(); g.d_mf.release();
-    g.d_mf8.release(); g.d_env.release();
+    g.d_mf8.release();
     for (auto &row : g.b2c) for (auto &bb : row) bb.release();
     for (double2 *&h : g.fd_hist) { if (h) (void)hipFree(h); h = nullptr; }
     if (g.d_flags) { (void)hipFree(g.d_flags); g.d_flags = nullptr; }
@@ -512,8 +429,8 @@ int process_radio(double *cSamples, int nSamples)
         if (g.d_x.need((size_t)n)) return -1;
         const int kind = !g.tone_on ? -1 : g.mode == 4 ? 1 : is_fm_mode(g.mode) ? 2 : 0;
         const u64 da = turns_step(1000.0, (double)g.sample_rate);
-        hipLaunchKernelGGL(ps_prep_kernel, dim3(grid_for(n)), dim3(256), 0, s, cur, g.d_x.p, n, kind, g.tone_phase, g.tone_step, g.audio_phase, da,
-                           g.invert_spectrum);
+        hipLaunchKernelGGL(qh_ps::prep_kernel, dim3(grid_for(n), 1u), dim3(256), 0, s, cur, (long long)n, g.d_x.p, (long long)n, n, kind, g.tone_phase,
+                           g.tone_step, g.audio_phase, da, g.invert_spectrum);
         if (g.tone_on) {
             g.tone_phase += g.tone_step * (u64)n;
             if (kind >= 1) g.audio_phase += da * (u64)n;
@@ -649,18 +566,13 @@ int process_radio(double *cSamples, int nSamples)
     // ---- cFracDecim to 48 ksps (quisk.c:2654-2659)
     if (decim_srate != 48000 && na > 0) {
         const double fdecim = decim_srate / 48000.0, step = fdecim - 1;
-        // outputs m with input index m + floor(d0 + m step) - 1 <= na - 1
-        int M = (int)(((double)na + 1.0 - g.fd_dindex) / fdecim) + 2;
-        if (M < 0) M = 0;
-        auto idx = [&](int m) { return m + (int)std::floor(std::fma(step, (double)m, g.fd_dindex)) - 1; };
-        while (M > 0 && idx(M - 1) > na - 1) M--;
-        while (idx(M) <= na - 1) M++;
+        const int M = qh_ps::fracdecim_count(na, g.fd_dindex, fdecim);
         if (g.d_fd.need((size_t)M + 1)) return -1;
-        if (M > 0) hipLaunchKernelGGL(ps_fracdecim_kernel, dim3(grid_for(M)), dim3(256), 0, s, (const double2 *)audio, (const double2 *)g.fd_hist[g.fd_cur], M,
-                                      g.fd_dindex, step, g.d_fd.p);
-        hipLaunchKernelGGL(ps_fd_hist_kernel, dim3(1), dim3(64), 0, s, (const double2 *)audio, na, (const double2 *)g.fd_hist[g.fd_cur], g.fd_hist[g.fd_cur ^ 1]);
+        if (M > 0) hipLaunchKernelGGL(qh_ps::fracdecim_kernel, dim3(grid_for(M), 1u), dim3(256), 0, s, (const double2 *)audio, 0LL, (const double2 *)g.fd_hist[g.fd_cur], M,
+                                      g.fd_dindex, step, g.d_fd.p, 0LL);
+        hipLaunchKernelGGL(qh_ps::fd_hist_kernel, dim3(1), dim3(64), 0, s, (const double2 *)audio, 0LL, na, (const double2 *)g.fd_hist[g.fd_cur], g.fd_hist[g.fd_cur ^ 1]);
         g.fd_cur ^= 1;
-        g.fd_dindex = std::fma(step, (double)M, g.fd_dindex) + (double)M - (double)na;        // dindex as the next call's first sample finds it
+        g.fd_dindex = qh_ps::fracdecim_next_dindex(na, M, g.fd_dindex, fdecim);
         audio = g.d_fd.p; na = M;
     }
     // ---- the WDSP hand-off (quisk.c:2660-2661): fexchange0 takes host pointers, so this is the one round trip of the chain
@@ -698,25 +610,18 @@ int process_radio(double *cSamples, int nSamples)
         }
     }
     // ---- kill_audio / squelch / key-up envelope (quisk.c:2712-2738)
+    // (the envelope's factors are a closed form of the sample index for the kernel; the host only steps its copy of keyupEnvelope)
     int env_n = 0;
+    const double env0 = g.keyup_env, env_step = 1. / (g.playback_rate * 5e-3);
     if (g.keyup_env < 1.0 && na > 0) {
-        const double di = 1. / (g.playback_rate * 5e-3);
-        std::vector<double> env;
         for (int i = 0; i < na; i++) {
-            g.keyup_env += di;
+            g.keyup_env += env_step;
             if (g.keyup_env > 1.0) { g.keyup_env = 1.0; break; }
-            env.push_back(g.keyup_env);
-        }
-        env_n = (int)env.size();
-        if (env_n > 0) {
-            if (g.d_env.need((size_t)env_n)) return -1;
-            if (hipMemcpyAsync(g.d_env.p, env.data(), (size_t)env_n * 8, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                qh::set_error(QH_ERR_HIP, "upload failed"); return -1;
-            }
+            env_n++;
         }
     }
-    hipLaunchKernelGGL(ps_epilogue_kernel, dim3(grid_for(na)), dim3(256), 0, s, audio, na, flag_real, flag_imag, g.kill_audio, (const double *)g.d_env.p,
-                       env_n, g.d_flags);
+    hipLaunchKernelGGL(qh_ps::epilogue_kernel, dim3(grid_for(na), 1u), dim3(256), 0, s, (const double2 *)audio, 0LL, audio, 0LL, na, flag_real, 0, flag_imag, 0,
+                       g.kill_audio, env0, env_step, env_n, g.d_flags);
     if (g.h_out.need((size_t)(na > 0 ? na : 1) * 2)) return -1;
     if (na > 0 && hipMemcpyAsync(g.h_out.p, audio, (size_t)na * 16, hipMemcpyDeviceToHost, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "download failed"); return -1; }
     if (hipMemcpyAsync(g.h_flags, g.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "download failed"); return -1; }
@@ -733,7 +638,19 @@ extern "C" {
 
 // quisk_sound_state.sample_rate and .playback_rate (open_sound, quisk.c:4106) + the filters.h tables (data, passed in like to
 // qh_qrx_create_ex) + record_app's fft_size and data_width (0, 0: no panadapter).
+static int open_locked(int sample_rate, int playback_rate, const qh_qrx_tables *tables, int fft_size, int data_width);
 int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *tables, int fft_size, int data_width)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    const int rc = open_locked(sample_rate, playback_rate, tables, fft_size, data_width);
+    if (rc) {               // a receiver that failed to open is closed: the next qh_quisk_process_samples says so instead of launching on null buffers
+        if (g.sample_rate) (void)hipSetDevice(0);
+        free_all();
+        g.sample_rate = 0; g.have_tables = false;
+    }
+    return rc;
+}
+static int open_locked(int sample_rate, int playback_rate, const qh_qrx_tables *tables, int fft_size, int data_width)
 {
     static const int len[13] = { 98, 147, 245, 50, 36, 186, 309, 125, 55, 114, 136, 174, 189 };
     if (sample_rate <= 0 || !tables) return qh::set_error(QH_ERR_INVALID, "qh_quisk_open: bad arguments");
@@ -741,7 +658,6 @@ int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *table
     if (playback_rate <= 0 || playback_rate % 48000 || (ratio != 1 && ratio != 2 && ratio != 4 && ratio != 8))
         return qh::set_error(QH_ERR_UNSUPPORTED, "Failure in quisk.c in integer interpolation: playback rate %d is not 48000 x 1, 2, 4 or 8 (quisk.c:2664-2681)",
                              playback_rate);
-    std::lock_guard<std::mutex> lk(g.mtx);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return qh::set_error(QH_ERR_NO_DEVICE, "no HIP device (libquiskhip has no CPU fallback)");
     QH_HIP(hipSetDevice(0));
@@ -785,7 +701,6 @@ int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *table
     QH_HIP(hipMalloc((void **)&g.d_flags, 2 * sizeof(int)));
     QH_HIP(hipMemset(g.d_flags, 0, 2 * sizeof(int)));
     QH_HIP(hipHostMalloc((void **)&g.h_flags, 2 * sizeof(int), hipHostMallocDefault));
-    if (int rc = g.d_env.need(64)) return rc;
     for (auto &row : g.b2c) for (auto &bb : row) if (int rc = bb.need(kBuf2Chan)) return rc;
     if (fft_size > 0 && data_width > 0) {
         g.pan = qh_pan_create(0, 1, fft_size, data_width, (double)sample_rate, g.stream);
@@ -793,25 +708,7 @@ int qh_quisk_open(int sample_rate, int playback_rate, const qh_qrx_tables *table
     }
     g.up_ratio = ratio;
     if (ratio > 1) {
-        // HalfBand7 (.. 8, 9) chained (quisk.c:2666-2677) = one polyphase interpolator: g = h * up2(h) * up4(h), gain 2 per stage
-        double t[43];
-        qh_hb45_taps(t);                                        // t[2k] = coef[k]
-        std::vector<double> h45(45, 0.0);
-        for (int k = 0; k < 11; k++) { h45[(size_t)(2 * k + 1)] = t[2 * k]; h45[(size_t)(43 - 2 * k)] = t[2 * k]; }
-        h45[22] = 0.5;
-        auto up = [](const std::vector<double> &a, int f) {
-            std::vector<double> r((a.size() - 1) * (size_t)f + 1, 0.0);
-            for (size_t i = 0; i < a.size(); i++) r[i * (size_t)f] = a[i];
-            return r;
-        };
-        auto conv = [](const std::vector<double> &a, const std::vector<double> &b) {
-            std::vector<double> r(a.size() + b.size() - 1, 0.0);
-            for (size_t i = 0; i < a.size(); i++) for (size_t j = 0; j < b.size(); j++) r[i + j] += a[i] * b[j];
-            return r;
-        };
-        std::vector<double> taps = h45;                         // the stage that runs at the highest rate is applied last
-        if (ratio == 4) taps = conv(up(h45, 2), h45);
-        if (ratio == 8) taps = conv(conv(up(h45, 4), up(h45, 2)), h45);
+        const std::vector<double> taps = qh_ps::playback_interp_taps(ratio);
         g.up = qh_rat_create(0, 1, taps.data(), (int)taps.size(), ratio, 1, QH_F64, g.stream);
         if (!g.up) return QH_ERR_HIP;
     }
@@ -900,7 +797,7 @@ int qh_quisk_process_samples(double *cSamples, int nSamples)
     int out = key_block(cSamples, nSamples);
     if (out < 0) {
         out = process_radio(cSamples, nSamples);
-        if (out < 0) out = 0;
+        if (out < 0) { out = 0; g.failed_calls++; }             // qh_last_error() says why; qh_quisk_error_count() that it happened
     }
     for (int &h : g.sub_have) h = 0;
     return out;
@@ -960,6 +857,7 @@ void qh_quisk_set_ssb_squelch(int enabled, int level)                           
     std::lock_guard<std::mutex> lk(g.mtx);
     g.ssb_squelch_enabled = enabled; g.ssb_squelch_level = level;
 }
+long long qh_quisk_error_count(void) { std::lock_guard<std::mutex> lk(g.mtx); return g.failed_calls; }
 int qh_quisk_squelch_flags(void) { std::lock_guard<std::mutex> lk(g.mtx); return g.squelch_real | (g.squelch_imag << 1); }
 // add_tone(freq) (quisk.c:3203-3216): a -40 dB test tone added to the samples; 0 switches it off
 void qh_quisk_add_tone(int freq)

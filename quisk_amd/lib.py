@@ -272,6 +272,26 @@ def load():
     L.qh_quisk_sub_rx1_audio.argtypes = [vp, i]
     L.qh_quisk_squelch_flags.argtypes = []
     L.qh_quisk_get_graph.argtypes = [C.c_double, C.c_double, vp, vp]
+    L.qh_qps_create.restype = vp
+    L.qh_qps_create.argtypes = [i, i, i, i, i, i, vp, i, i, vp]
+    L.qh_qps_destroy.argtypes = [vp]
+    L.qh_qps_destroy.restype = None
+    L.qh_qps_set_tune.argtypes = [vp, i, i]
+    L.qh_qps_set_filters.argtypes = [vp, i, vp, vp, i]
+    L.qh_qps_set_agc.argtypes = [vp, d]
+    for n in ("qh_qps_set_noise_blanker", "qh_qps_invert_spectrum", "qh_qps_set_kill_audio", "qh_qps_add_tone", "qh_qps_set_pieces"):
+        getattr(L, n).argtypes = [vp, i]
+    L.qh_qps_set_auto_notch.argtypes = [vp, i, i]
+    L.qh_qps_set_squelch.argtypes = [vp, i, d]
+    L.qh_qps_set_ssb_squelch.argtypes = [vp, i, i]
+    for n in ("qh_qps_filter_rate", "qh_qps_decim_rate", "qh_qps_synchronize"):
+        getattr(L, n).argtypes = [vp]
+    L.qh_qps_out_capacity.argtypes = [vp, i]
+    L.qh_qps_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_qps_process_host.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]
+    L.qh_qps_squelch_flags.argtypes = [vp, vp]
+    L.qh_qps_get_graph.argtypes = [vp, d, d, vp, vp, C.POINTER(i)]
+    L.qh_quisk_error_count.restype = ll
     L.qh_qrx_create_ex.restype = vp
     L.qh_qrx_create_ex.argtypes = [i, i, i, i, i, vp, vp]
     L.qh_qrx_decim_rate.argtypes = [vp]

@@ -102,6 +102,109 @@ class QuiskRxBank:
             pass
 
 
+class QuiskProcessBank:
+    """quisk_process_samples (quisk.c:2289-2742) for a bank of receivers (include/quiskhip.h group 9b): test tone / inversion,
+    NoiseBlanker, the panadapter's feed, tune + decimate + demodulate, cFracDecim, interpolation to the playback rate, process_agc
+    (always on, as in the reference) and the squelches.  Method names follow the _quisk calls."""
+
+    def __init__(self, nch, sample_rate, mode, bandwidth=2700, playback_rate=48000, fft_size=0, data_width=0, device=0, stream=None):
+        self._L = load()
+        t = rxfilter.coefficient_tables()
+        self._tabs = [np.ascontiguousarray(t[k], dtype=np.float64) for k in _TABLE_KEYS]
+        self._tstruct = _Tables(*[a.ctypes.data for a in self._tabs])
+        self._h = self._L.qh_qps_create(device, nch, sample_rate, playback_rate, mode, bandwidth, C.byref(self._tstruct), fft_size, data_width, stream)
+        if not self._h:
+            raise QuiskHipError("qh_qps_create failed: %s" % self._L.qh_last_error().decode(errors="replace"))
+        self.nch, self.sample_rate, self.mode, self.data_width = nch, sample_rate, mode, data_width
+
+    def get_filter_rate(self):
+        return self._L.qh_qps_filter_rate(self._h)
+
+    def get_decim_rate(self):
+        return self._L.qh_qps_decim_rate(self._h)
+
+    def set_tune(self, ch, rx_tune_freq):
+        check(self._L.qh_qps_set_tune(self._h, ch, int(rx_tune_freq)))
+
+    def set_filters(self, ch, filtI, filtQ):
+        fI = np.ascontiguousarray(filtI, dtype=np.float64)
+        fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
+        if fI.size != fQ.size:
+            raise ValueError("The size of filters I and Q must be equal")
+        check(self._L.qh_qps_set_filters(self._h, ch, fI.ctypes.data, fQ.ctypes.data, fI.size))
+
+    def set_agc(self, level):
+        check(self._L.qh_qps_set_agc(self._h, float(level)))
+
+    def set_noise_blanker(self, level):
+        check(self._L.qh_qps_set_noise_blanker(self._h, int(level)))
+
+    def set_auto_notch(self, on, rit_freq=0):
+        check(self._L.qh_qps_set_auto_notch(self._h, 1 if on else 0, int(rit_freq)))
+
+    def invert_spectrum(self, invert):
+        check(self._L.qh_qps_invert_spectrum(self._h, 1 if invert else 0))
+
+    def set_kill_audio(self, kill):
+        check(self._L.qh_qps_set_kill_audio(self._h, 1 if kill else 0))
+
+    def add_tone(self, freq):
+        check(self._L.qh_qps_add_tone(self._h, int(freq)))
+
+    def set_squelch(self, ch, level):
+        check(self._L.qh_qps_set_squelch(self._h, ch, float(level)))
+
+    def set_ssb_squelch(self, enabled, level):
+        check(self._L.qh_qps_set_ssb_squelch(self._h, 1 if enabled else 0, int(level)))
+
+    def set_pieces(self, pieces):
+        check(self._L.qh_qps_set_pieces(self._h, int(pieces)))
+
+    def out_capacity(self, n_in):
+        return self._L.qh_qps_out_capacity(self._h, n_in)
+
+    def process_ptr(self, d_in, in_stride, n, d_out, out_stride):
+        got = C.c_int(0)
+        check(self._L.qh_qps_process(self._h, d_in, in_stride, n, d_out, out_stride, C.byref(got)))
+        return got.value
+
+    def process_host(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        if x.ndim != 2 or x.shape[0] != self.nch:
+            raise ValueError("expected [nch, n] complex128")
+        cap = max(self.out_capacity(x.shape[1]), 1)
+        out = np.empty((self.nch, cap), dtype=np.complex128)
+        got = C.c_int(0)
+        check(self._L.qh_qps_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1], out.ctypes.data, cap, C.byref(got)))
+        return out[:, :got.value].copy()
+
+    def squelch_flags(self):
+        f = np.zeros(self.nch, dtype=np.int32)
+        check(self._L.qh_qps_squelch_flags(self._h, f.ctypes.data))
+        return f
+
+    def get_graph(self, zoom=1.0, deltaf=0.0):
+        pix = np.empty((self.nch, self.data_width), dtype=np.float64)
+        sm = np.empty(self.nch, dtype=np.float64)
+        cnt = C.c_int(0)
+        check(self._L.qh_qps_get_graph(self._h, float(zoom), float(deltaf), pix.ctypes.data, sm.ctypes.data, C.byref(cnt)))
+        return None if cnt.value <= 0 else (pix, sm, cnt.value)
+
+    def synchronize(self):
+        check(self._L.qh_qps_synchronize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qh_qps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class QuiskAgc:
     """process_agc (quisk.c:2162-2287) for `nch` streams; the first process call only initialises, as in the reference."""
 
