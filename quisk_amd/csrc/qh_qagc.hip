@@ -426,6 +426,9 @@ __global__ __launch_bounds__(128) void q_agc_pair_kernel(const double2 *src, lon
     const int B = q.buf_size, nchunks = (n + 63) >> 6;
     const QAgcState st0 = state[ch];
     if (wave == 0) {
+        // the stepper is one chain of dependent instructions: when other kernels' wavefronts share its SIMD (the receiver bank runs
+        // the next piece's filters beside it) it should issue the moment its operand is ready -- highest wave priority
+        __builtin_amdgcn_s_setprio(3);
         QAgcLane st = qagc_lane_of(st0);
         int index_read = st0.index_read;
         const QAgcChainPrm w{ q.limit, q.time_release, 1.0 - q.time_release, release_gain[ch], B };

@@ -337,40 +337,46 @@ def test_config5_fused_chain_at_the_timed_shape(qh, oracle, bc, dev):
 # ------------------------------------------------------------------------------------------------------------------ Quisk-native
 @pytest.mark.parametrize("name", ["USB", "AM", "FM"])
 def test_quisk_native_at_the_timed_shape(qh, oracle, bc, dev, name):
-    """256 receivers x 2^20 per call: one call without process_agc, then set_agc(True) as the bench does and two more calls (the
-    first only initialises the AGC, as in the reference), one continuous stream of 3 x 2^20 samples per receiver.
+    """The whole of quisk_process_samples for 256 receivers x 2^20 per call (qh_qps_*, process_agc on at the bench's release gain,
+    calls cut into bench_configs.QN_PIECES time pieces with the AGC on a second stream): three calls, one continuous stream of
+    3 x 2^20 samples per receiver; process_agc's first call only initialises, as in the reference.
 
     process_agc is a DISCONTINUOUS function of its input (threshold tests decide when a ramp starts, steepens and ends, quisk.c:
     2220-2262): two streams that differ in the thirteenth digit part for good once a test falls the other way.  So the leg is held in
     two exact pieces and one statistical one:
-      * the filters: a second bank without the AGC gives the stream process_agc sees in every call; eight receivers of it against
-        the staged restatement of quisk_process_samples (1e-9), and the AGC-less calls of the timed bank bit for bit against it;
-      * the AGC at this shape (256 streams x 262144 samples per call): 32 receivers of the timed bank's output BIT FOR BIT against
-        the restatement's process_agc run on the very stream the GPU's AGC saw;
+      * the filters: the receiver bank alone (the same engine under the whole function), fed in the very pieces the whole function
+        cuts, gives the stream process_agc sees in every call; eight receivers of it against the staged restatement of
+        quisk_process_samples (1e-9), and the first call of the whole function (AGC initialising) bit for bit against it;
+      * the AGC at this shape (256 streams, 4 x 65536 samples per call, beside the next piece's filters): 32 receivers of the whole
+        function's output BIT FOR BIT against the restatement's process_agc run on the very stream the GPU's AGC saw;
       * end to end (restatement's filters + its AGC): within 1e-2, next to the restatement's OWN answer to a 1e-13 relative change
         of its input (printed: the same 1e-6 .. 1e-3 -- a flipped test changes one ramp's slope, with this much limiting every
         receiver has one in a call);
-    and all 256 against uneven pieces the same way."""
+    and all 256 against uneven calls the same way."""
     L = bc.setup_quisk_native(torch, qh, dev, name)
     nch, n = L.nch, L.n
     assert (nch, n) == (256, 1 << 20)
+    per = bc.qn_piece_len(n)
     tabs = rxfilter.coefficient_tables()
-    B = bc.setup_quisk_native(torch, qh, dev, name)          # the same receivers, never with the AGC
+    B = bc.setup_quisk_native(torch, qh, dev, name, whole=False)          # the same receivers: the bank alone
     B.x.copy_(L.x)
     torch.cuda.synchronize(dev)
-    ys, pre, counts = [], [], []
+    ys, pre = [], []
     for k in range(3):
-        if k == 1:
-            L.bank.set_agc(True, bc.QN_AGC_GAIN)
-        m = L.bank.process_ptr(L.x.data_ptr(), n, n, L.y.data_ptr(), L.m + 64)
-        mb = B.bank.process_ptr(B.x.data_ptr(), n, n, B.y.data_ptr(), B.m + 64)
+        m = L.step()
         torch.cuda.synchronize(dev)
-        assert m == mb
         ys.append(L.y[:, :m].clone())
-        pre.append(B.y[:, :m].clone())
-        counts.append(m)
-    assert torch.equal(ys[0], pre[0]) and torch.equal(ys[1], pre[1])      # no AGC; the AGC's first call only initialises (quisk.c:2173-2190)
-    assert not torch.equal(ys[2], pre[2])
+        # the bank alone: the first call in one piece (as the whole function's first call), then in its pieces
+        parts = []
+        for pos in range(0, n, n if k == 0 else per):
+            cnt = min(n if k == 0 else per, n - pos)
+            mb = B.bank.process_ptr(B.x.data_ptr() + 16 * pos, n, cnt, B.y.data_ptr(), B.m)
+            torch.cuda.synchronize(dev)
+            parts.append(B.y[:, :mb].clone())
+        pre.append(torch.cat(parts, dim=1))
+        assert pre[k].shape == ys[k].shape
+    assert torch.equal(ys[0], pre[0])                 # the AGC's first call only initialises (quisk.c:2173-2190)
+    assert not torch.equal(ys[1], pre[1])
     chans = spread(nch, 8)
     xs = {c: L.x[c].cpu().numpy() for c in chans}
 
@@ -386,12 +392,11 @@ def test_quisk_native_at_the_timed_shape(qh, oracle, bc, dev, name):
             y = np.concatenate([r.process(xs[c][i:i + 16384]) for i in range(0, n, 16384)])
             assert r.decim_srate() == 48000
             out.append(y)
-            outa.append(agc.process(y, False, bc.QN_AGC_GAIN) if k >= 1 else y)
+            outa.append(agc.process(y, False, bc.QN_AGC_GAIN))
         # how far the restatement's process_agc moves when its input moves by 1e-13 relative (the distance between two fp64 filters)
         agc2 = oracle.OracleQuiskAgc(48000)
-        agc2.process(out[1] * (1.0 + 1e-13), False, bc.QN_AGC_GAIN)
-        sens = rel_rms(agc2.process(out[2] * (1.0 + 1e-13), False, bc.QN_AGC_GAIN), outa[2])
-        return c, out, outa, sens
+        outb = [agc2.process(out[k] * (1.0 + 1e-13), False, bc.QN_AGC_GAIN) for k in range(3)]
+        return c, out, outa, rel_rms(outb[2], outa[2])
     e2e, own = [], []
     for c, wants, wants_agc, sens in pmap(check, chans):
         own.append(sens)
@@ -412,40 +417,37 @@ def test_quisk_native_at_the_timed_shape(qh, oracle, bc, dev, name):
     assert max(e2e) < 1e-2, e2e
     # the AGC on the stream the GPU's AGC saw: bit for bit (|x| of a real stream is exact on both sides)
     chans32 = spread(nch, 32)
-    p1 = {c: pre[1][c].cpu().numpy() for c in chans32}
-    p2 = {c: pre[2][c].cpu().numpy() for c in chans32}
-    g2 = {c: ys[2][c].cpu().numpy() for c in chans32}
+    p = [{c: pre[k][c].cpu().numpy() for c in chans32} for k in range(3)]
+    g = [{c: ys[k][c].cpu().numpy() for c in chans32} for k in range(3)]
 
     def check_agc(c):
         agc = oracle.OracleQuiskAgc(48000)
-        agc.process(p1[c], False, bc.QN_AGC_GAIN)
-        return c, agc.process(p2[c], False, bc.QN_AGC_GAIN)
-    for c, want in pmap(check_agc, chans32):
-        assert np.abs(want).max() > 1e8                                   # the limiter is at work
-        assert np.array_equal(g2[c].view(np.float64), want.view(np.float64)), (name, c)
-    # all receivers, uneven pieces through a fresh bank
+        return c, [agc.process(p[k][c], False, bc.QN_AGC_GAIN) for k in range(3)]
+    for c, wants in pmap(check_agc, chans32):
+        assert np.abs(wants[2]).max() > 1e8                               # the limiter is at work
+        for k in (1, 2):
+            assert np.array_equal(g[k][c].view(np.float64), wants[k].view(np.float64)), (name, c, k)
+    # all receivers, uneven calls through a fresh bank of the whole function
     L2 = bc.setup_quisk_native(torch, qh, dev, name)
     L2.x.copy_(L.x)
     torch.cuda.synchronize(dev)
     for k in range(3):
-        if k == 1:
-            L2.bank.set_agc(True, bc.QN_AGC_GAIN)
         pos, opos = 0, 0
         y2 = torch.zeros_like(ys[k])
-        # process_agc's first call only initialises (quisk.c:2173-2190): call 1 stays ONE call, as in the run it is compared with
-        for cnt in ((n,) if k == 1 else (1000, 1001, n // 3, n - n // 3 - 2001)):
-            m = L2.bank.process_ptr(L2.x.data_ptr() + 16 * pos, n, cnt, L2.y.data_ptr(), L2.m + 64)
+        # process_agc's first call only initialises (quisk.c:2173-2190): call 0 stays ONE call, as in the run it is compared with
+        for cnt in ((n,) if k == 0 else (1000, 1001, n // 3, n - n // 3 - 2001)):
+            m = L2.bank.process_ptr(L2.x.data_ptr() + 16 * pos, n, cnt, L2.y.data_ptr(), L2.m)
             torch.cuda.synchronize(dev)
             y2[:, opos:opos + m] = L2.y[:, :m]
             pos += cnt
             opos += m
-        assert pos == n and opos == counts[k]
+        assert pos == n and opos == ys[k].shape[1]
         scale = float(ys[k].abs().max().item())
         skip = 2000 if (L.mode == 5 and k == 0) else 0        # FM's first call: the fill-up phase noise differs by tile
         d = (ys[k][:, skip:] - y2[:, skip:]).abs().amax(dim=1) / scale
-        if k < 2:
+        if k == 0:
             assert float(d.max().item()) < 1e-9, (name, k, int(d.argmax().item()), float(d.max().item()))
-        else:       # with the AGC running: a piece boundary moves the filters' rounding, and a threshold test may fall the other way
+        else:       # with the AGC running: a call boundary moves the filters' rounding, and a threshold test may fall the other way
             same = int((d < 1e-9).sum().item())
-            print("Quisk-native %s shape: one call against uneven pieces with process_agc: %d of %d receivers within 1e-9, worst %.1e" % (name, same, nch, float(d.max().item())))
+            print("Quisk-native %s shape: call %d against uneven calls with process_agc: %d of %d receivers within 1e-9, worst %.1e" % (name, k, same, nch, float(d.max().item())))
             assert float(d.max().item()) < 0.1

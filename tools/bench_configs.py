@@ -242,55 +242,87 @@ def config5(torch, qh, dev):
 
 QN_MODES = (("USB", 3, 2700), ("AM", 4, 6000), ("FM", 5, 12000))      # name, Quisk mode number (quisk.h:55-70), bandwidth
 QN_AGC_GAIN = 5000.0
+QN_PIECES = 4                   # time pieces of a call of the whole-function bank (qh_qps_set_pieces)
+
+
+def qn_piece_len(n, pieces=QN_PIECES):
+    """samples per piece, as qh_qps_process cuts a call"""
+    return ((n + pieces - 1) // pieces + 63) // 64 * 64
 
 
 def qn_tune(c):
     return 1000 * (c % 40) - 20000
 
 
-def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20):
-    """One mode of the Quisk-native leg: 256 receivers of Quisk's own chain (quisk_process_samples: tune, quisk_process_decimate,
-    cRxFilterOut, the x4 interpolators), 192 ksps in, 48 ksps out."""
+def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20, whole=True, nb=0, fft_size=0, pieces=QN_PIECES):
+    """One mode of the Quisk-native leg: 256 receivers, 192 ksps in, 48 ksps out.
+    whole=True: the WHOLE of quisk_process_samples for the bank (qh_qps_*: test tone / inversion / NoiseBlanker when set, the
+    panadapter's feed when fft_size > 0, tune + quisk_process_decimate + quisk_process_demodulate, process_agc -- always on, as in the
+    reference -- on a second stream beside the next piece's filters, squelch);
+    whole=False: the receiver bank alone (tune, decimate, demodulate: qh_qrx_*), the kernels under it."""
     from quisk_amd import rxfilter
     fs = 192000
     mode, bw = {m[0]: (m[1], m[2]) for m in QN_MODES}[name]
-    L = SimpleNamespace(nch=nch, n=n, fs=fs, mode=mode, bw=bw, name=name)
+    L = SimpleNamespace(nch=nch, n=n, fs=fs, mode=mode, bw=bw, name=name, whole=whole)
     L.stream = new_stream(torch, dev)
-    L.bank = bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=L.stream.cuda_stream)
+    if whole:
+        L.bank = bank = qh.QuiskProcessBank(nch, fs, mode, bw, playback_rate=48000, fft_size=fft_size, data_width=fft_size // 2 if fft_size else 0,
+                                            stream=L.stream.cuda_stream)
+        bank.set_agc(QN_AGC_GAIN)
+        if nb:
+            bank.set_noise_blanker(nb)
+        if pieces:
+            bank.set_pieces(pieces)
+    else:
+        L.bank = bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=L.stream.cuda_stream)
     L.rate = bank.get_filter_rate()
     L.fI, L.fQ = rxfilter.make_filter_coef(L.rate, None, bw, rxfilter.get_filter_center(name, bw))
     for c in range(nch):
         bank.set_tune(c, qn_tune(c))
     bank.set_filters(-1, L.fI, L.fQ)
     L.x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 22
-    L.m = bank.out_count(n)
-    L.y = torch.empty((nch, L.m + 64), dtype=torch.complex128, device=dev)
-    L.step = lambda: bank.process_ptr(L.x.data_ptr(), n, n, L.y.data_ptr(), L.m + 64)
+    L.m = bank.out_capacity(n) if whole else bank.out_count(n) + 64
+    L.y = torch.empty((nch, L.m), dtype=torch.complex128, device=dev)
+    if whole:
+        L.step = lambda: bank.process_ptr(L.x.data_ptr(), n, n, L.y.data_ptr(), L.m)
+    else:
+        L.step = lambda: bank.process_ptr(L.x.data_ptr(), n, n, L.y.data_ptr(), L.m)
     torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
     return L
 
 
 def quisk_native(torch, qh, dev):
-    """Path A: 256 receivers, USB, AM and FM, 2^20 input samples per receiver per step.  The reference's own
-    figure for ONE receiver on a CPU core is 9.9 Msamp/s."""
+    """Path A: 256 receivers, USB, AM and FM, 2^20 input samples per receiver per step: the whole of quisk_process_samples for the bank
+    (process_agc on, a release gain at which the limiter works: an overload ramp every few FIFO cycles), with the NoiseBlanker and with
+    the panadapter's feed in the path for USB, and the receiver bank alone.  The reference's own figure for ONE receiver on a CPU core
+    is 9.9 Msamp/s."""
     nch, n = 256, 1 << 20
     out = []
+    sync = lambda: torch.cuda.synchronize(dev)
     only = os.environ.get("QH_QUISK_MODES", "USB,AM,FM").split(",")          # e.g. QH_QUISK_MODES=FM for a kernel trace of one mode
     for name, mode, bw in QN_MODES:
         if name not in only:
             continue
         L = setup_quisk_native(torch, qh, dev, name)
-        sync = lambda: torch.cuda.synchronize(dev)
-        t = timed(L.step, sync, steps=8, warmup=2)
+        t = timed(L.step, sync, steps=8, warmup=3)
         row = {"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": L.rate, "filter_taps": int(L.fI.size)}
-        # process_agc on the output, as quisk_process_samples always runs it (quisk.c:2685-2701); a release gain at which the
-        # limiter works (an overload ramp every few FIFO cycles): the state machine is sequential per receiver, one wavefront each
-        L.bank.set_agc(True, QN_AGC_GAIN)
-        ta = timed(L.step, sync, steps=6, warmup=2)
-        row.update({"agc_on_ms": ta * 1e3, "agc_on_Msamp_per_s": nch * n / ta / 1e6})
-        out.append(row)
         del L
-    return {"config": "Quisk-native chain (path A): 256 receivers x 192 ksps -> 48 ksps, 2^20 input samples per receiver per step",
+        L = setup_quisk_native(torch, qh, dev, name, whole=False)
+        tb = timed(L.step, sync, steps=8, warmup=2)
+        row.update({"bank_only_ms": tb * 1e3, "bank_only_Msamp_per_s": nch * n / tb / 1e6})
+        del L
+        if name == "USB":
+            L = setup_quisk_native(torch, qh, dev, name, nb=1)
+            tn = timed(L.step, sync, steps=6, warmup=3)
+            del L
+            L = setup_quisk_native(torch, qh, dev, name, fft_size=2048)
+            tp = timed(L.step, sync, steps=6, warmup=3)
+            del L
+            row.update({"noise_blanker_on_ms": tn * 1e3, "noise_blanker_on_Msamp_per_s": nch * n / tn / 1e6,
+                        "panadapter_2048_on_ms": tp * 1e3, "panadapter_2048_on_Msamp_per_s": nch * n / tp / 1e6})
+        out.append(row)
+    return {"config": "Quisk-native chain (path A): the whole of quisk_process_samples for 256 receivers x 192 ksps -> 48 ksps, process_agc on, "
+                      "2^20 input samples per receiver per step",
             "samples_per_step": nch * n, "modes": out,
             "note": "the reference's quisk_process_samples handles one receiver per process: 9.9 Msamp/s on a CPU core (SURVEY.md 8 a10)"}
 
@@ -354,8 +386,9 @@ def driver_legs(torch, qh, dev, emit):
                               "modes": [dict({"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
                                               "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
                                               "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS},
-                                             **{k: m[k] for k in ("agc_on_ms", "agc_on_Msamp_per_s") if k in m}) for m in r["modes"]],
-                              "agc_note": "agc_on_*: process_agc (quisk.c:2162) on the output, one wavefront per receiver (q_agc_chain_kernel)",
+                                             **{k: v for k, v in m.items() if k.startswith(("bank_only", "noise_blanker", "panadapter"))}) for m in r["modes"]],
+                              "agc_note": "ms_per_step: the whole function with process_agc (quisk.c:2162) on a second stream beside the next piece's filters; "
+                                          "bank_only_*: tune + decimate + demodulate alone (qh_qrx_*)",
                               "dominant_kernel": "osfir_kernel<f64,4096,D=8,OUTMIX> (tune + collapsed 1181-tap /16)"})
     except Exception as exc:
         emit("quisk_native", {"failed": repr(exc)})
