@@ -127,6 +127,7 @@ int qh_rxa_SetRXASNBAbridge(qh_rxa *e, int ch, int bridge);
 int qh_rxa_SetRXASNBApresamps(qh_rxa *e, int ch, int presamps);
 int qh_rxa_SetRXASNBApostsamps(qh_rxa *e, int ch, int postsamps);
 int qh_rxa_SetRXASNBApmultmin(qh_rxa *e, int ch, double pmultmin);
+int qh_rxa_SetRXASNBAovrlp(qh_rxa *e, int ch, int ovrlp);          /* snb.c:595; ch = -1: the frame advance is the engine's */
 int qh_rxa_SetRXAAMSQThreshold(qh_rxa *e, int ch, double threshold_db);
 int qh_rxa_SetRXAAMSQMaxTail(qh_rxa *e, int ch, double tail_seconds);
 /* xanf / xanr (wdsp/anf.c:82-133, anr.c:82-133), setters wdsp/anf.c:175-239 and anr.c:175-238; which position (0 before
@@ -303,6 +304,7 @@ void SetRXASNBAbridge(int channel, int bridge);
 void SetRXASNBApresamps(int channel, int presamps);
 void SetRXASNBApostsamps(int channel, int postsamps);
 void SetRXASNBApmultmin(int channel, double pmultmin);
+void SetRXASNBAovrlp(int channel, int ovrlp);
 
 /* Status of the drop-in layer: 0 when the last WDSP-named call succeeded, else a qh_status. */
 int qh_wdsp_status(void);
@@ -784,10 +786,12 @@ int quisk_dFilter(double *dSamples, int count, struct quisk_cFilter *filter);   
 double quisk_dD_out(double sample, struct quisk_cFilter *filter);                           /* filter.c:326-345 */
 int quisk_cInterp2HB45(double *cSamples, int count, struct quisk_cHB45Filter *filter);      /* filter.c:455-488 */
 int quisk_dInterp2HB45(double *dSamples, int count, struct quisk_dHB45Filter *filter);      /* filter.c:420-453 */
-/* quisk_dC_out (filter.c:83-104) returns `complex double` by value, which C++ cannot spell in an extern "C"
- * signature; this is the same computation with the result written through a pointer.  A C translation unit
- * binds the reference's name with:  static inline complex double quisk_dC_out(double s, struct quisk_dFilter *f)
- * { double o[2]; qh_quisk_dC_out(s, (struct quisk_cFilter *)f, o); return o[0] + I * o[1]; } */
+/* quisk_dC_out (filter.c:83-104) returns `complex double` by value.  The library exports it under the reference's own name
+ * (microphone.c:469 links against it unchanged); ISO C++ has no spelling for the type, so the declaration is for C translation
+ * units, and qh_quisk_dC_out is the same computation with the result written through a pointer. */
+#ifndef __cplusplus
+double _Complex quisk_dC_out(double sample, struct quisk_cFilter *filter);
+#endif
 void qh_quisk_dC_out(double sample, struct quisk_cFilter *filter, double *out_re_im);
 
 #ifdef __cplusplus

@@ -57,7 +57,7 @@ def lib():
                   "wo_SetRXAAGCMode", "wo_SetRXAPanelRun", "wo_SetRXAPanelSelect", "wo_SetRXAPanelCopy",
                   "wo_SetRXAAMDSBMode", "wo_SetRXAAMDFadeLevel", "wo_SetRXACTCSSRun", "wo_SetRXAAMDRun", "wo_RXASetMP", "wo_SetRXAFMLimRun",
                   "wo_SetRXAEMNRRun", "wo_SetRXASNBARun", "wo_SetRXAEMNRgainMethod", "wo_SetRXAEMNRnpeMethod", "wo_SetRXAEMNRaeRun", "wo_SetRXAEMNRPosition",
-                  "wo_SetRXAAMSQRun", "wo_SetRXAANFRun", "wo_SetRXAANRRun", "wo_SetRXAANFPosition", "wo_SetRXAANRPosition"):
+                  "wo_SetRXAAMSQRun", "wo_SetRXAANFRun", "wo_SetRXAANRRun", "wo_SetRXAANFPosition", "wo_SetRXAANRPosition", "wo_SetRXASNBAovrlp"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
             getattr(L, n).restype = None
         for n in ("wo_SetRXAShiftFreq", "wo_SetRXAAGCFixed", "wo_SetRXAPanelGain1", "wo_SetRXAFMDeviation",

@@ -498,6 +498,15 @@ void wo_snba_exec(wo_snba *d, double *buf)      /* xsnba, snb.c:539-571 (in == o
     for (i = 0; i < d->bsize; i++) buf[2 * i + 1] = 0.0;       /* the imaginary part of outbuff is zero, snb.c:565 */
 }
 
+void wo_snba_set_ovrlp(wo_snba *d, int ovrlp)                    /* SetRXASNBAovrlp, snb.c:595-603: decalc_snba + calc_snba */
+{
+    free(d->rout.h); free(d->rout.ring); d->rout.h = d->rout.ring = NULL;      /* decalc_snba, snb.c:121-129 */
+    free(d->rin.h); free(d->rin.ring); d->rin.h = d->rin.ring = NULL;
+    free(d->outbuf); free(d->inbuf); free(d->outaccum); free(d->inaccum);
+    d->ovrlp = ovrlp;
+    sn_calc(d);
+}
+
 void wo_snba_set_tuning(wo_snba *d, int which, double v)        /* snb.c:604-658 */
 {
     switch (which) {

@@ -12,6 +12,7 @@ void wo_snba_free(wo_snba *d);
 void wo_snba_flush(wo_snba *d);                                         /* flush_snba, snb.c:161-185 */
 int *wo_snba_run(wo_snba *d);
 void wo_snba_set_output_bandwidth(wo_snba *d, double flow, double fhigh);  /* SetRXASNBAOutputBandwidth, snb.c:660-694 */
+void wo_snba_set_ovrlp(wo_snba *d, int ovrlp);              /* SetRXASNBAovrlp, snb.c:595-603 */
 void wo_snba_set_tuning(wo_snba *d, int which, double v);   /* SetRXASNBAasize .. pmultmin, snb.c:604-658: which = 0 asize, 1 npasses, 2 k1, 3 k2, 4 bridge, 5 presamps, 6 postsamps, 7 pmultmin */
 void wo_snba_exec(wo_snba *d, double *buf);                             /* xsnba on one block of bsize complex samples, in place */
 /* the pieces, for the unit tests */

@@ -1595,6 +1595,7 @@ void wo_SetRXASNBARun(wo_channel *c, int run)          /* snb.c:579-593 */
         bpsnba_set(c);
     }
 }
+void wo_SetRXASNBAovrlp(wo_channel *c, int ovrlp) { wo_snba_set_ovrlp(c->snba, ovrlp); }                       /* snb.c:595-603 */
 void wo_SetRXASNBATuning(wo_channel *c, int which, double v) { wo_snba_set_tuning(c->snba, which, v); }      /* snb.c:604-658 */
 void wo_SetRXAEMNRgainMethod(wo_channel *c, int method) { wo_emnr_set_gain_method(c->emnr, method); }
 void wo_SetRXAEMNRnpeMethod(wo_channel *c, int method) { wo_emnr_set_npe_method(c->emnr, method); }

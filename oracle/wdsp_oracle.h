@@ -75,6 +75,7 @@ void wo_SetRXAPanelCopy(wo_channel *c, int copy);
 void wo_SetRXAAMDSBMode(wo_channel *c, int sbmode);             /* amd.c:259-265 */
 void wo_SetRXAAMDRun(wo_channel *c, int run);                   /* amd.c:264-277 */
 void wo_SetRXASNBARun(wo_channel *c, int run);                  /* snb.c:579-593 */
+void wo_SetRXASNBAovrlp(wo_channel *c, int ovrlp);              /* snb.c:595-603 */
 void wo_SetRXASNBATuning(wo_channel *c, int which, double v);   /* snb.c:604-658, `which` as in wo_snba_set_tuning */
 void wo_SetRXAEMNRRun(wo_channel *c, int run);                  /* emnr.c:1096-1110 */
 void wo_SetRXAEMNRgainMethod(wo_channel *c, int method);        /* emnr.c:1112-1118 */

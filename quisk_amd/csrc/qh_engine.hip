@@ -217,6 +217,9 @@ struct Engine {
     bool snba_tune_dirty = true;
     std::vector<char> snb_listed, fm_listed;
     int snba_alloc();
+    int snba_ovrlp = 4;                 // create_rxa's overlap (RXA.c:244): incr = xsize / 4
+    void snba_plan(int ovrlp);
+    int snba_set_ovrlp(int ovrlp);
     EmnrParam emnr_prm{};
     EmnrChan *emnr_chan = nullptr;
     EmnrScalars *emnr_scal = nullptr;
@@ -1108,6 +1111,44 @@ int Engine::refresh_demod()
     return QH_OK;
 }
 
+// the frame advance and the two accumulators' sizes for an overlap (calc_snba, snb.c:45-65)
+void Engine::snba_plan(int ovrlp)
+{
+    SnbaParam &q = snba_prm;
+    q.incr = kSnbX / ovrlp;
+    q.iasize = q.incr > q.isize ? q.incr : q.isize;
+    q.oasize = q.iasize;
+    q.init_oaoutidx = q.incr > q.isize ? q.isize : 0;
+    q.off_inacc = 2 * kSnbX; q.off_outacc = q.off_inacc + q.iasize; q.off_rin = q.off_outacc + q.oasize;
+    q.off_rout = q.off_rin + (q.cpp_in - 1); q.state_doubles = q.off_rout + (q.cpp_out - 1);
+}
+
+// SetRXASNBAovrlp (snb.c:595-603): decalc_snba + calc_snba with the new overlap -- the frame memory (xbase, made by create_snba) stays,
+// the accumulators, their indices and both resamplers start over
+int Engine::snba_set_ovrlp(int ovrlp)
+{
+    if (ovrlp < 1 || ovrlp > kSnbX || kSnbX / ovrlp < 1) return set_error(QH_ERR_INVALID, "SetRXASNBAovrlp: 1 .. %d", kSnbX);
+    snba_ovrlp = ovrlp;
+    if (!snba_state) return QH_OK;                       // nothing built yet: snba_alloc plans with it
+    QH_HIP(hipSetDevice(device));
+    QH_HIP(hipStreamSynchronize(stream));
+    const SnbaParam old = snba_prm;
+    std::vector<double> frames((size_t)nch * 2 * kSnbX);
+    QH_HIP(hipMemcpy2D(frames.data(), 2 * kSnbX * sizeof(double), snba_state, (size_t)old.state_doubles * sizeof(double), 2 * kSnbX * sizeof(double),
+                       (size_t)nch, hipMemcpyDeviceToHost));
+    snba_plan(ovrlp);
+    const SnbaParam &q = snba_prm;
+    (void)hipFree(snba_state); snba_state = nullptr;
+    QH_HIP(dev_alloc(&snba_state, (size_t)nch * q.state_doubles));
+    QH_HIP(hipMemset(snba_state, 0, (size_t)nch * q.state_doubles * sizeof(double)));
+    QH_HIP(hipMemcpy2D(snba_state, (size_t)q.state_doubles * sizeof(double), frames.data(), 2 * kSnbX * sizeof(double), 2 * kSnbX * sizeof(double),
+                       (size_t)nch, hipMemcpyHostToDevice));
+    std::vector<SnbaIdx> ix((size_t)nch, SnbaIdx{ 0, 0, 0, 0, q.init_oaoutidx, { 0, 0, 0 } });
+    QH_HIP(hipMemcpy(snba_idx, ix.data(), ix.size() * sizeof(SnbaIdx), hipMemcpyHostToDevice));
+    drop_graphs(); epoch++;
+    return QH_OK;
+}
+
 // calc_emnr (wdsp/emnr.c:240-497) with create_rxa's arguments (RXA.c:319-332): parameters, window, start values of every array
 int Engine::snba_alloc()
 {
@@ -1118,15 +1159,10 @@ int Engine::snba_alloc()
         return set_error(QH_ERR_UNSUPPORTED, "SNBA: dsp_rate 12000, 24000 or 48000 and dsp_size up to %d", kSnbMaxDsp);
     q.ratio = dsp_rate / 12000;
     q.isize = dsp_size / q.ratio;
-    q.incr = kSnbX / 4;
-    q.iasize = q.incr > q.isize ? q.incr : q.isize;
-    q.oasize = q.iasize;
-    q.init_oaoutidx = q.incr > q.isize ? q.isize : 0;
     q.cpp_in = q.ratio > 1 ? 140 * q.ratio + 1 : 1;
     q.cpp_out = q.ratio > 1 ? 141 : 1;
     q.asize = 64; q.npasses = 2; q.b = 10; q.pre = 2; q.post = 2; q.k1 = 8.0; q.k2 = 20.0; q.pmultmin = 0.5;
-    q.off_inacc = 2 * kSnbX; q.off_outacc = q.off_inacc + q.iasize; q.off_rin = q.off_outacc + q.oasize;
-    q.off_rout = q.off_rin + (q.cpp_in - 1); q.state_doubles = q.off_rout + (q.cpp_out - 1);
+    snba_plan(snba_ovrlp);
     QH_HIP(dev_alloc(&snba_state, (size_t)nch * q.state_doubles));
     QH_HIP(hipMemsetAsync(snba_state, 0, (size_t)nch * q.state_doubles * sizeof(double), stream));
     QH_HIP(dev_alloc(&snba_idx, (size_t)nch));
@@ -2351,8 +2387,7 @@ int qh_rxa_SetRXASNBAOutputBandwidth(qh_rxa *h, int ch, double flow, double fhig
     });
 }
 
-// The blanker's tuning setters, wdsp/snb.c:604-658.  They act on the next block, as under csDSP.  (SetRXASNBAovrlp, snb.c:595,
-// re-plans the frame advance and both accumulators: not provided.)
+// The blanker's tuning setters, wdsp/snb.c:604-658.  They act on the next block, as under csDSP.
 static int snba_tune_set(qh_rxa *h, int ch, const char *who, bool ok, void (*apply)(SnbaTune &, double), double v)
 {
     if (!h) return set_error(QH_ERR_INVALID, "null engine");
@@ -2380,6 +2415,21 @@ int qh_rxa_SetRXASNBApostsamps(qh_rxa *h, int ch, int postsamps)
 { return snba_tune_set(h, ch, "SetRXASNBApostsamps (0 .. 64)", postsamps >= 0 && postsamps <= 64, [](SnbaTune &t, double v) { t.post = (int)v; }, postsamps); }
 int qh_rxa_SetRXASNBApmultmin(qh_rxa *h, int ch, double pmultmin)
 { return snba_tune_set(h, ch, "SetRXASNBApmultmin", pmultmin >= 0.0, [](SnbaTune &t, double v) { t.pmultmin = v; }, pmultmin); }
+
+// SetRXASNBAovrlp, wdsp/snb.c:595-603.  The frame advance sizes the blanker's state, which the engine lays out once for all its
+// channels: ch = -1 (or the only channel).  The WDSP-named layer keeps one engine per channel, so there it is per channel as in WDSP.
+int qh_rxa_SetRXASNBAovrlp(qh_rxa *h, int ch, int ovrlp)
+{
+    if (!h) return set_error(QH_ERR_INVALID, "null engine");
+    QH_RXA_LOCK(h);
+    if (!(ch == -1 || (ch == 0 && h->e.nch == 1)))
+        return set_error(QH_ERR_UNSUPPORTED, "SetRXASNBAovrlp re-plans the blanker's accumulators for the whole engine: pass channel -1");
+    if (int rc = h->e.snba_set_ovrlp(ovrlp)) return rc;
+    // calc_snba makes the output resampler anew with its creation arguments: fc_low 200, the default cut-off (snb.c:45-46) -- what
+    // SetRXASNBAOutputBandwidth had set is gone, as in WDSP
+    for (ChanCfg &c : h->e.cfg) { c.snba_f_low = 200.0; c.snba_f_high = 0.0; c.snba_taps_dirty = true; }
+    return QH_OK;
+}
 
 // SetRXASNBARun, wdsp/snb.c:579-593
 int qh_rxa_SetRXASNBARun(qh_rxa *h, int ch, int run)

@@ -422,6 +422,21 @@ void qh_quisk_dC_out(double sample, struct quisk_cFilter *filter, double *out_re
     filter->decim_index = keep;
 }
 
+// the reference's own name and return type (filter.c:83): clang spells C's complex double in C++ as an extension, and the C ABI
+// returns it in two floating-point registers either way
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wreturn-type-c-linkage"
+double _Complex quisk_dC_out(double sample, struct quisk_cFilter *filter)
+{
+    double o[2];
+    qh_quisk_dC_out(sample, filter, o);
+    double _Complex r;
+    __real__ r = o[0];
+    __imag__ r = o[1];
+    return r;
+}
+#pragma clang diagnostic pop
+
 int quisk_cInterp2HB45(double *cSamples, int count, struct quisk_cHB45Filter *filter)
 {
     return filter ? interp2_hb45(cSamples, 2, count, filter->samples) : 0;

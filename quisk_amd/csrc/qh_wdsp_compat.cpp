@@ -602,6 +602,7 @@ void SetRXASNBAk2(int channel, double k2) { WDSP_SETTER(qh_rxa_SetRXASNBAk2(L.c-
 void SetRXASNBAbridge(int channel, int bridge) { WDSP_SETTER(qh_rxa_SetRXASNBAbridge(L.c->eng, 0, bridge)); }             // snb.c:632
 void SetRXASNBApresamps(int channel, int presamps) { WDSP_SETTER(qh_rxa_SetRXASNBApresamps(L.c->eng, 0, presamps)); }     // snb.c:639
 void SetRXASNBApostsamps(int channel, int postsamps) { WDSP_SETTER(qh_rxa_SetRXASNBApostsamps(L.c->eng, 0, postsamps)); } // snb.c:646
+void SetRXASNBAovrlp(int channel, int ovrlp) { WDSP_SETTER(qh_rxa_SetRXASNBAovrlp(L.c->eng, 0, ovrlp)); }                    // snb.c:595
 void SetRXASNBApmultmin(int channel, double pmultmin) { WDSP_SETTER(qh_rxa_SetRXASNBApmultmin(L.c->eng, 0, pmultmin)); }  // snb.c:653
 
 }  // extern "C"

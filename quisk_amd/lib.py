@@ -42,7 +42,7 @@ def load():
               "SetRXAPanelSelect", "SetRXAPanelCopy", "SetRXAAMDSBMode", "SetRXAAMDFadeLevel", "SetRXACTCSSRun",
               "SetRXAAGCAttack", "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCSlope", "SetRXAAGCHangThreshold",
               "RXASetMP", "SetRXAAMDRun", "SetRXAFMLimRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease",
-              "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition", "SetRXASNBARun", "SetRXASNBAasize", "SetRXASNBAnpasses", "SetRXASNBAbridge", "SetRXASNBApresamps", "SetRXASNBApostsamps",
+              "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition", "SetRXASNBARun", "SetRXASNBAasize", "SetRXASNBAnpasses", "SetRXASNBAbridge", "SetRXASNBApresamps", "SetRXASNBApostsamps", "SetRXASNBAovrlp",
               "SetRXAAMSQRun", "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay",
               "SetRXAANRPosition"):
         f = getattr(L, "qh_rxa_" + n)

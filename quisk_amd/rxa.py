@@ -17,7 +17,7 @@ _SETTERS = ("SetRXAMode", "RXASetNC", "SetRXAShiftRun", "RXANBPSetRun", "SetRXAB
             "SetRXAAGCDecay", "SetRXAAGCHang", "SetRXAAGCTop", "SetRXAAGCSlope", "SetRXAAGCHangThreshold", "RXASetMP",
             "SetRXAAMDRun", "RXANBPSetNotchesRun", "RXANBPSetWindow", "RXANBPSetAutoIncrease", "RXANBPSetTuneFrequency",
             "RXANBPSetShiftFrequency", "SetRXAFMLimRun", "SetRXAFMLimGain",
-            "SetRXASNBARun", "SetRXASNBAOutputBandwidth", "SetRXASNBAasize", "SetRXASNBAnpasses", "SetRXASNBAk1", "SetRXASNBAk2", "SetRXASNBAbridge", "SetRXASNBApresamps", "SetRXASNBApostsamps", "SetRXASNBApmultmin", "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition", "SetRXAEMNRaeZetaThresh", "SetRXAEMNRaePsi", "SetRXAEMNRtrainZetaThresh", "SetRXAEMNRtrainT2",
+            "SetRXASNBARun", "SetRXASNBAOutputBandwidth", "SetRXASNBAasize", "SetRXASNBAnpasses", "SetRXASNBAk1", "SetRXASNBAk2", "SetRXASNBAbridge", "SetRXASNBApresamps", "SetRXASNBApostsamps", "SetRXASNBApmultmin", "SetRXASNBAovrlp", "SetRXAEMNRRun", "SetRXAEMNRgainMethod", "SetRXAEMNRnpeMethod", "SetRXAEMNRaeRun", "SetRXAEMNRPosition", "SetRXAEMNRaeZetaThresh", "SetRXAEMNRaePsi", "SetRXAEMNRtrainZetaThresh", "SetRXAEMNRtrainT2",
             "SetRXAAMSQRun", "SetRXAAMSQThreshold", "SetRXAAMSQMaxTail", "SetRXAANFRun", "SetRXAANFTaps", "SetRXAANFDelay", "SetRXAANFPosition", "SetRXAANFGain", "SetRXAANFLeakage", "SetRXAANFVals",
             "SetRXAANRRun", "SetRXAANRTaps", "SetRXAANRDelay", "SetRXAANRPosition", "SetRXAANRGain", "SetRXAANRLeakage", "SetRXAANRVals")
 

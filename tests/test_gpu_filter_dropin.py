@@ -175,6 +175,39 @@ def test_per_sample_outputs(qh, oracle):
     assert rel_rms(np.array(got), want) < 1e-12
 
 
+def test_dC_out_under_the_reference_name_from_c(qh, oracle, tmp_path):
+    """`complex double quisk_dC_out(double, struct quisk_dFilter *)` (filter.c:83) as microphone.c:469 calls it: a C translation
+    unit compiled against include/quiskhip.h and linked against the library, the value returned in registers."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    lib = qh.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "dc.c"
+    src.write_text('#include <complex.h>\n#include "quiskhip.h"\n'
+                   'void run(const double *x, int n, struct quisk_cFilter *f, double *out)\n'
+                   '{ int i; for (i = 0; i < n; i++) { complex double v = quisk_dC_out(x[i], f); out[2 * i] = creal(v); out[2 * i + 1] = cimag(v); } }\n')
+    so = tmp_path / "libdc.so"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-shared", "-fPIC", "-I", os.path.join(root, "include"), str(src), "-o", str(so),
+                    "-L", os.path.dirname(lib._name), "-lquiskhip", "-Wl,-rpath," + os.path.dirname(lib._name)], check=True)
+    shim = C.CDLL(str(so))
+    rng = np.random.default_rng(19)
+    taps = np.ascontiguousarray(rng.standard_normal(45))
+    x = np.ascontiguousarray(rng.standard_normal(64))
+    st = oracle.RefCFilter()
+    lib.quisk_filt_dInit(C.byref(st), taps.ctypes.data_as(c_double_p), C.c_int(45))
+    lib.quisk_filt_tune.argtypes = [C.c_void_p, C.c_double, C.c_int]
+    lib.quisk_filt_tune(C.byref(st), -0.11, 0)
+    out = np.zeros(2 * x.size)
+    shim.run(x.ctypes.data_as(c_double_p), C.c_int(x.size), C.byref(st), out.ctypes.data_as(c_double_p))
+    f = oracle.OracleFir(taps)
+    f.tune(-0.11, 0)
+    want = f.cCDecimate(x + 0j, 1)
+    assert rel_rms(out[0::2] + 1j * out[1::2], want) < 1e-12
+
+
 def test_interp2hb45_struct_state(qh, oracle):
     lib, ref = qh.load(), oracle.ref_filter_lib()
     x = stream(10, 3000)

@@ -223,3 +223,39 @@ def test_snba_tuning_setters_per_channel_and_mid_stream(qh, oracle):
     assert rel_rms(np.concatenate(rs[0]), default0) > 1e-3             # the settings do change what the blanker repairs
     with pytest.raises(qh.QuiskHipError):
         e.SetRXASNBAasize(0, 65)
+
+
+@pytest.mark.parametrize("ovrlps", [(2, 8), (8, 1, 4)])
+def test_snba_overlap_changed_mid_stream(qh, oracle, ovrlps):
+    """SetRXASNBAovrlp (wdsp/snb.c:595-603: decalc_snba + calc_snba): the frame advance xsize / ovrlp, both accumulators and both
+    resamplers start over while the frame memory stays; overlap 2 makes the advance (128) longer than the 12 kHz block (64), the
+    other branch of calc_snba's accumulator sizing.  The output bandwidth set before goes back to 200 .. 5400 Hz, as in WDSP."""
+    nch, cuts = 2, [0, 30, 31, 70, 120]
+    x = np.stack([crackle(c, cuts[-1] * 1024, USB, rate=30.0) for c in range(nch)])
+    e = qh.RxaEngine(nch)
+    refs = []
+    for ch in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        for t, a in ((e, (ch,)), (o, ())):
+            setup(t, a, ch, USB)
+            t.SetRXASNBARun(*a, 1)
+            t.RXASetPassband(*a, 400.0, 2500.0)         # ... and with it SetRXASNBAOutputBandwidth (RXA.c:926-932)
+        refs.append(o)
+    ys, rs = [], [[] for _ in range(nch)]
+    for k, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        if 1 <= k <= len(ovrlps):
+            e.SetRXASNBAovrlp(-1, ovrlps[k - 1])
+            for o in refs:
+                o.SetRXASNBAovrlp(ovrlps[k - 1])
+        ys.append(e.process_host(x[:, a * 1024:b * 1024]))
+        for ch in range(nch):
+            rs[ch].append(refs[ch].xrxa(x[ch, a * 1024:b * 1024]))
+    y = np.concatenate(ys, axis=1)
+    for ch in range(nch):
+        ref = np.concatenate(rs[ch])
+        assert np.abs(ref).max() > 0.05
+        assert rel_rms(y[ch], ref) < 1e-6, (ch, rel_rms(y[ch], ref))
+    with pytest.raises(qh.QuiskHipError):
+        e.SetRXASNBAovrlp(0, 4)             # the frame advance is the engine's: channel -1
+    with pytest.raises(qh.QuiskHipError):
+        e.SetRXASNBAovrlp(-1, 0)
