@@ -377,6 +377,39 @@ struct AgcState {
     double abs_ring[kAgcRing];
 };
 
+// The reference's ring in full.  xwcpagc's ring has RB_SIZE = 30721 entries (wcpAGC.h:30-33, wcpAGC.c:38-50) of which the kernels here
+// keep the 2048 behind out_index -- all that a constant attack window ever reads.  When SetRXAAGCAttack lengthens the window in
+// mid-stream, in_index jumps ahead (loadWcpAGC, wcpAGC.c:119-120) and the entries it jumps over come out later as they are: samples
+// written a lap (30721 samples) ago, or zeros.  So the full ring is kept beside the state, written by every call (only the call's
+// last RB_SIZE inputs can survive it), and read when the window moves (agc_rewindow_kernel).
+static constexpr int kAgcLongRing = 30721;
+// grid (x, listed channels); lout[ch] = out_index in the full ring (-1 at start, calc_wcpagc)
+static __global__ void agc_long_mirror_kernel(const double2 *buf, long long stride, int n, const int *chan_list, const AgcParam *prm, double2 *lring,
+                                              double *labs, const int *lout)
+{
+    const int ch = chan_list[blockIdx.y];
+    const AgcParam q = prm[ch];
+    const long long o = lout[ch];
+    const double2 *p = buf + (long long)ch * stride;
+    const int first = n > kAgcLongRing ? n - kAgcLongRing : 0;
+    for (int i = first + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int pos = (int)((o + 1 + q.attack_buffsize + i) % kAgcLongRing);     // sample i goes in at in_index = out_index + attack_buffsize
+        const double2 z = p[i];
+        lring[(long long)ch * kAgcLongRing + pos] = z;
+        labs[(long long)ch * kAgcLongRing + pos] = q.pmode == 0 ? fmax(fabs(z.x), fabs(z.y)) : sqrt(__builtin_fma(z.x, z.x, z.y * z.y));
+    }
+}
+static __global__ void agc_long_advance_kernel(int n, const int *chan_list, int count, int *lout)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int ch = chan_list[k];
+    lout[ch] = (int)(((long long)lout[ch] + n) % kAgcLongRing);
+}
+// the state's 2048 entries behind out_index, taken again from the full ring (one workgroup per listed channel)
+static __global__ __launch_bounds__(256) void agc_rewindow_kernel(const int *chan_list, AgcState *state, const double2 *lring, const double *labs,
+                                                                   const int *lout);
+
 static __global__ __launch_bounds__(64) void wcpagc_seq_kernel(double2 *buf, long long stride, int n, const int *chan_list,
                                                                const AgcParam *prm, AgcState *state, double pre_gain = 1.0)
 {
@@ -460,6 +493,20 @@ static __global__ __launch_bounds__(64) void wcpagc_seq_kernel(double2 *buf, lon
         sp->ring_max = ring_max; sp->volts = volts; sp->save_volts = save_volts; sp->fast_backaverage = fba;
         sp->hang_backaverage = hba; sp->gain = gain; sp->out_index = out_index; sp->hang_counter = hang_counter;
         sp->decay_type = decay_type; sp->state = st;
+    }
+}
+
+static __global__ __launch_bounds__(256) void agc_rewindow_kernel(const int *chan_list, AgcState *state, const double2 *lring, const double *labs,
+                                                                   const int *lout)
+{
+    const int ch = chan_list[blockIdx.x];
+    AgcState *sp = state + ch;
+    const int ol = sp->out_index;
+    const long long og = lout[ch];
+    for (int k = 1 + threadIdx.x; k < kAgcRing; k += blockDim.x) {
+        const int src = (int)((og + k) % kAgcLongRing), dst = (ol + k) & (kAgcRing - 1);
+        sp->ring[dst] = lring[(long long)ch * kAgcLongRing + src];
+        sp->abs_ring[dst] = labs[(long long)ch * kAgcLongRing + src];
     }
 }
 

@@ -85,6 +85,7 @@ struct ChanCfg {
     bool agc_dirty = true;
     bool agc_on() const { return agc_run && agc_mode != 0; }
     int agc_abuf = -1;                  // attack_buffsize last uploaded
+    bool agc_rewindow = false;          // the attack window moved in mid-stream: the state's ring is taken again from the full one
     bool agc_ran = false, agc_stale = false;    // the window moved while the ring held samples: ring_max may be stale (qh_agc_tiled.hpp)
     int bp1_run = 1, bp1_nc = 2048, bp1_wintype = 1;            // RXA.c:377-389
     double bp1_flow = -4150.0, bp1_fhigh = -150.0, bp1_gain = 1.0;
@@ -278,6 +279,10 @@ struct Engine {
     int process_replayed(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
     AgcParam *agc_prm = nullptr;
     AgcState *agc_state = nullptr;
+    // xwcpagc's ring in full (RB_SIZE entries per channel, qh_demod.hpp: agc_long_mirror_kernel), made when a state machine first runs
+    double2 *agc_lring = nullptr;
+    double *agc_labs = nullptr;
+    int *agc_lout = nullptr, *agc_rewin_list = nullptr;
     AgcParam *lim_prm = nullptr;        // FM detector limiter: a wcpAGC of its own (fmd.c:48-72)
     AgcState *lim_state = nullptr;
     int *list_lim = nullptr, n_lim = 0;
@@ -341,7 +346,7 @@ Engine::~Engine()
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
     (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege); (void)hipFree(agc_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
-    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
+    (void)hipFree(agc_prm); (void)hipFree(agc_state); (void)hipFree(agc_lring); (void)hipFree(agc_labs); (void)hipFree(agc_lout); (void)hipFree(agc_rewin_list); (void)hipFree(lim_prm); (void)hipFree(lim_state); (void)hipFree(list_lim); (void)hipFree(m_adc); (void)hipFree(m_s); (void)hipFree(m_agc); (void)hipFree(m_part[0]); (void)hipFree(m_part[1]); (void)hipFree(m_w); (void)hipFree(m_g2);
     (void)hipFree(mask_snb); (void)hipFree(hist_snb[0]); (void)hipFree(hist_snb[1]); (void)hipFree(snba_state); (void)hipFree(snba_hin);
     (void)hipFree(snba_hout); (void)hipFree(snba_scratch); (void)hipFree(snba_idx); (void)hipFree(snba_tune);
     (void)hipFree(emnr_chan); (void)hipFree(emnr_scal); (void)hipFree(emnr_state); (void)hipFree(emnr_window); (void)hipFree(emnr_GG);
@@ -928,7 +933,7 @@ int Engine::refresh_demod()
             if (q.attack_buffsize + 2 > kAgcRing)
                 return set_error(QH_ERR_UNSUPPORTED, "AGC attack of %g s needs a look-ahead of %d samples (limit %d)", c.agc_tau_attack,
                                  q.attack_buffsize, kAgcRing - 2);
-            if (c.agc_ran && c.agc_abuf != q.attack_buffsize) c.agc_stale = true;
+            if (c.agc_ran && c.agc_abuf != q.attack_buffsize) { c.agc_stale = true; c.agc_rewindow = true; }
             c.agc_abuf = q.attack_buffsize;
             q.attack_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_attack));
             q.decay_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_decay));
@@ -2078,6 +2083,46 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             a_max = c.agc_abuf > a_max ? c.agc_abuf : a_max;
         }
         for (ChanCfg &c : cfg) if (c.agc_on()) c.agc_ran = true;
+        // the reference's full ring (RB_SIZE entries): this call's last inputs go in where xwcpagc writes them; a channel whose attack
+        // window moved since its last call first takes its 2048-entry ring again from it (the entries the longer window jumped over)
+        if (!agc_lring) {
+            QH_HIP(hipStreamSynchronize(stream));
+            drop_graphs(); epoch++;
+            QH_HIP(dev_alloc(&agc_lring, (size_t)nch * kAgcLongRing));
+            QH_HIP(dev_alloc(&agc_labs, (size_t)nch * kAgcLongRing));
+            QH_HIP(dev_alloc(&agc_lout, (size_t)nch));
+            QH_HIP(dev_alloc(&agc_rewin_list, (size_t)nch));
+            QH_HIP(hipMemsetAsync(agc_lring, 0, (size_t)nch * kAgcLongRing * sizeof(double2), stream));
+            QH_HIP(hipMemsetAsync(agc_labs, 0, (size_t)nch * kAgcLongRing * sizeof(double), stream));
+            QH_HIP(hipMemsetAsync(agc_lout, 0xff, (size_t)nch * sizeof(int), stream));          // out_index = -1 (calc_wcpagc, wcpAGC.c:34)
+            dev_bytes += (long long)nch * kAgcLongRing * 24;
+        }
+        {
+            std::vector<int> rw;
+            for (int ch = 0; ch < nch; ch++) {
+                ChanCfg &c = cfg[(size_t)ch];
+                if (c.agc_on() && c.agc_rewindow) rw.push_back(ch);
+                if (c.agc_on()) c.agc_rewindow = false;
+            }
+            if (!rw.empty()) {
+                QH_HIP(hipMemcpyAsync(agc_rewin_list, rw.data(), rw.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+                QH_HIP(hipStreamSynchronize(stream));
+                hipLaunchKernelGGL(agc_rewindow_kernel, dim3((unsigned)rw.size()), dim3(256), 0, stream, (const int *)agc_rewin_list, agc_state,
+                                   (const double2 *)agc_lring, (const double *)agc_labs, (const int *)agc_lout);
+            }
+        }
+        {
+            const long long span = n_mid < kAgcLongRing ? n_mid : kAgcLongRing;
+            const unsigned gx = (unsigned)((span + 255) / 256 < 120 ? (span + 255) / 256 : 120);
+            auto mirror = [&](const double2 *b, const int *lst, int cnt) {
+                if (!cnt) return;
+                hipLaunchKernelGGL(agc_long_mirror_kernel, dim3(gx, (unsigned)cnt), dim3(256), 0, stream, b, buf_cap, (int)n_mid, lst, (const AgcParam *)agc_prm,
+                                   agc_lring, agc_labs, (const int *)agc_lout);
+                hipLaunchKernelGGL(agc_long_advance_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, (int)n_mid, lst, cnt, agc_lout);
+            };
+            mirror(cur, list_agc_cur, n_agc_cur);
+            mirror(other, list_agc_other, n_agc_other);
+        }
         // ... and when every channel has the AGC as its last stage (nothing at position 1, no meters, squelch or audio frames), the gain
         // multiply applies the output matrix and writes the caller's rows: the output pass goes
         bool no_p1 = !n_bp1p[1] && !n_fix[0] && !n_fix[1] && !n_emnr[1] && !n_emnr[2] && !n_amsq && !meters_on && !eg.kind;
@@ -2888,6 +2933,10 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(e.agc_state[c].abs_ring, 0, sizeof(e.agc_state[c].abs_ring), e.stream));
             QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
             e.cfg[(size_t)c].agc_stale = false;     // an empty ring and ring_max = 0: nothing stale (qh_agc_tiled.hpp)
+        }
+        if (e.agc_lring) {
+            QH_HIP(hipMemsetAsync(e.agc_lring, 0, (size_t)e.nch * kAgcLongRing * sizeof(double2), e.stream));
+            QH_HIP(hipMemsetAsync(e.agc_labs, 0, (size_t)e.nch * kAgcLongRing * sizeof(double), e.stream));
         }
     }
     for (ChanCfg &c : e.cfg) { c.lms[0].flush = c.lms[1].flush = true; c.emnr_flush = true; c.snba_flush = true; c.snb_flush = true; }    // flush_anf / flush_anr / flush_emnr, RXA.c:541-543

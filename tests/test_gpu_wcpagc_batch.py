@@ -206,3 +206,45 @@ def test_time_tiles_at_other_window_lengths(qh, oracle, dsp_rate, attack_ms, mod
     ref = o.xrxa(x[0])
     assert np.abs(ref).max() > 1e-3
     assert rel_rms(outs[0][0], ref) < 1e-9, rel_rms(outs[0][0], ref)
+
+
+@pytest.mark.parametrize("form", [2, 1, 0], ids=["batch", "sample-loop", "tiles-when-long"])
+def test_attack_window_changed_mid_stream_reads_the_full_ring(qh, oracle, form):
+    """SetRXAAGCAttack in mid-stream (wcpAGC.c:414-420 -> loadWcpAGC :119-120): in_index jumps to out_index + the new attack_buffsize.
+    A LONGER window jumps over ring entries that then come out as they are -- zeros while the stream is younger than the ring's
+    RB_SIZE = 30721 entries (wcpAGC.h:30-33), the samples of a lap ago later on; a shorter one abandons samples that were waiting.
+    The engine keeps the reference's ring in full beside its 2048-entry working ring and takes the window again from it."""
+    nch = 3
+    #        blocks   attack (ms) set ahead of the stretch: 2 -> 4 while the ring is young, -> 1, -> 8 after more than a lap, -> 3
+    plan = [(40, None), (30, 4), (90, 1), (100, 8), (5, 3), (60, None)]
+    nblk = sum(p[0] for p in plan)
+    x = _input(nch, nblk, seed=33)
+    x += 2e-3 * np.exp(2j * np.pi * ((synth.shift_freq(0) + 1500.0) / 192000.0) * np.arange(x.shape[1]))[None, :]      # never silent: stale entries are seen
+    e = _engine(qh, nch, [3, 1, 4], form)
+    refs = []
+    for c in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode([3, 1, 4][c])
+        refs.append(o)
+    ys, rs, pos = [], [[] for _ in range(nch)], 0
+    for nb, attack in plan:
+        if attack is not None:
+            for c in range(nch):
+                e.SetRXAAGCAttack(c, attack)
+                refs[c].SetRXAAGCAttack(attack)
+        seg = np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024])
+        pos += nb
+        ys.append(e.process_host(seg))
+        for c in range(nch):
+            rs[c].append(refs[c].xrxa(seg[c]))
+    y = np.concatenate(ys, axis=1)
+    for c in range(nch):
+        ref = np.concatenate(rs[c])
+        assert np.abs(ref).max() > 1e-3
+        # stretch by stretch: the samples right behind each change are the ones the jump decides
+        a = 0
+        for nb, attack in plan:
+            b = a + nb * 256
+            assert rel_rms(y[c][a:b], ref[a:b]) < 1e-9, (c, attack, rel_rms(y[c][a:b], ref[a:b]))
+            a = b
