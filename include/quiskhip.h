@@ -653,6 +653,10 @@ void qh_quisk_set_auto_notch(int on, int rit_freq);         /* set_auto_notch, q
 int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
 int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
 int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */
+/* get_filter (quisk.c:5481-5568): the Rx filter's response as the "RX Filter" screen draws it -- a multitone through the copy of the
+ * cRxFilterOut loop that function carries, record_app's window, a data_width-point transform; db[data_width], negative frequencies
+ * first, floor -140.  All sizeFilter taps of set_filters (up to MAX_FILTER_SIZE).  Returns data_width (0: error). */
+int qh_quisk_get_filter(double *db);
 /* The rest of quisk_process_samples' orchestration (quisk.c:2289-2742): a second receiver bank whose audio shares the
  * stereo output with the first -- split Rx/Tx (the same samples at tx_tune + rit, split modes 1..4 of quisk.c:2548-2590) or
  * the played sub-receiver (its own samples, frequency, mode and nFilter-1 filter; play methods 0..2 of quisk.c:2601-2620) --

@@ -662,6 +662,18 @@ class OracleQuiskBlock:
             self.h = None
 
 
+def get_filter(filtI, filtQ, data_width, fft_size):
+    """get_filter (quisk.c:5481-5568): the Rx filter's response in dB as the "RX Filter" screen draws it, data_width values."""
+    L = lib()
+    fI = np.ascontiguousarray(filtI, dtype=np.float64)
+    fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
+    out = np.zeros(data_width, dtype=np.float64)
+    L.qo_get_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.qo_get_filter.restype = None
+    L.qo_get_filter(fI.ctypes.data, fQ.ctypes.data, fI.size, data_width, fft_size, out.ctypes.data)
+    return out
+
+
 class OracleQuiskAgc:
     """process_agc (quisk.c:2162-2287) for one stream; process(x) returns the AGC'd block (the first call only initialises)."""
 

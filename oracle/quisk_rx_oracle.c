@@ -1222,3 +1222,54 @@ int qo_ps_process(qo_ps *p, double *x, int n)
     }
     return n;
 }
+
+
+/* get_filter (quisk.c:5481-5568): the response of the Rx filter cFilterI/Q[0] as the "RX Filter" screen draws it -- a multitone
+ * through the cRxFilterOut loop (its own copy, :5516-5530), the FIRST data_width entries of fft_window (record_app's window of
+ * fft_size points, quisk.c:6003-6009), a data_width-point transform, 20 log10 with a floor of -140 dB, negative frequencies first. */
+void qo_get_filter(const double *filtI, const double *filtQ, int sizeFilter, int data_width, int fft_size, double *out)
+{
+    const int total = data_width + sizeFilter;
+    double *average = (double *)malloc(sizeof(double) * (size_t)total);
+    double *bufI = (double *)calloc((size_t)(sizeFilter > 0 ? sizeFilter : 1), sizeof(double));
+    double *bufQ = (double *)calloc((size_t)(sizeFilter > 0 ? sizeFilter : 1), sizeof(double));
+    double *samples = (double *)calloc((size_t)data_width * 2, sizeof(double));
+    int i, j, k, n, freq, time;
+    for (i = 0; i < total; i++) average[i] = 0.5;
+    for (freq = 1; freq < data_width / 2.0 - 10.0; freq++) {
+        const double delta = 2 * M_PI / data_width * freq;
+        double phase = 0;
+        for (time = 0; time < total; time++) {
+            average[time] += cos(phase);
+            phase += delta;
+            if (phase > 2 * M_PI) phase -= 2 * M_PI;
+        }
+    }
+    n = 0;
+    for (time = 0; time < total; time++) {
+        const double d2 = average[time];
+        double accI = 0, accQ = 0;
+        bufI[n] = d2; bufQ[n] = d2;
+        j = n;
+        for (k = 0; k < sizeFilter; k++) {
+            accI += bufI[j] * filtI[k];
+            accQ += bufQ[j] * filtQ[k];
+            if (++j >= sizeFilter) j = 0;
+        }
+        if (++n >= sizeFilter) n = 0;
+        if (time >= sizeFilter) { samples[2 * (time - sizeFilter)] = accI; samples[2 * (time - sizeFilter) + 1] = accQ; }
+    }
+    for (i = 0; i < data_width; i++) {
+        const double w = 0.5 + 0.5 * cos(2. * M_PI * (i - fft_size / 2) / fft_size);      /* fft_window[i], quisk.c:6008 */
+        samples[2 * i] *= w; samples[2 * i + 1] *= w;
+    }
+    fo_fft(samples, data_width, -1);
+    for (k = 0; k < data_width; k++) {
+        double a = hypot(samples[2 * k], samples[2 * k + 1]) * (1. / data_width);
+        average[k] = a <= 1e-7 ? -7 : log10(a);
+    }
+    i = 0;
+    for (k = data_width / 2; k < data_width; k++, i++) out[i] = 20.0 * average[k];
+    for (k = 0; k < data_width / 2; k++, i++) out[i] = 20.0 * average[k];
+    free(samples); free(bufQ); free(bufI); free(average);
+}

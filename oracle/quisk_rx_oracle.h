@@ -117,6 +117,9 @@ int qo_ps_squelch_flags(const qo_ps *p);                       /* bit 0: squelch
 /* in place; the buffer must hold max(n, output count) samples; returns the count at the playback rate */
 int qo_ps_process(qo_ps *p, double *cSamples, int n);
 
+/* get_filter, quisk.c:5481-5568: out[data_width] dB, negative frequencies first */
+void qo_get_filter(const double *filtI, const double *filtQ, int sizeFilter, int data_width, int fft_size, double *out);
+
 #ifdef __cplusplus
 }
 #endif

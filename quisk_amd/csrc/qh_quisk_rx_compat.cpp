@@ -78,6 +78,49 @@ __global__ void ps_merge_kernel(const double2 *a, const double2 *b, int n, doubl
     if (i >= n) return;
     x[i] = make_double2(a[i].x, b[i].x);
 }
+// ---- get_filter (quisk.c:5481-5568), the "RX Filter" screen's curve: three small kernels, run when the user opens that screen
+// the multitone: 0.5 + sum_{f = 1 .. nf} cos(2 pi f t / W), the terms added in the reference's order (frequency by frequency)
+__global__ void gf_multitone_kernel(double *x, int total, int W, int nf)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    double s = 0.5;
+    for (int f = 1; f <= nf; f++) s += cospi(2.0 * (double)(((long long)f * t) % W) / (double)W);
+    x[t] = s;
+}
+// its own copy of the cRxFilterOut loop (quisk.c:5516-5530): tap 0 on the newest sample, taps 1 .. N - 1 on the oldest .. second newest;
+// output m is the one of time N + m, times fft_window[m] (record_app's window of fft_size points, quisk.c:6008, its FIRST W entries)
+__global__ void gf_filter_kernel(const double *x, const double *fI, const double *fQ, int N, int W, int fft_size, double2 *y)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= W) return;
+    const int t = N + m;
+    double aI = 0.0, aQ = 0.0;
+    if (N > 0) { aI = x[t] * fI[0]; aQ = x[t] * fQ[0]; }
+    for (int k = 1; k < N; k++) { const double v = x[t - N + k]; aI += v * fI[k]; aQ += v * fQ[k]; }
+    if (N == 0) { aI = aQ = 0.0; }
+    const double w = 0.5 + 0.5 * cospi(2.0 * (double)(m - fft_size / 2) / (double)fft_size);
+    y[m] = make_double2(aI * w, aQ * w);
+}
+// the W-point transform by its definition (W is the graph's width in pixels, any number; once per screen refresh), |X| / W in dB with
+// the -140 dB floor, negative frequencies first
+__global__ void gf_dft_kernel(const double2 *y, int W, double *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= W) return;
+    double re = 0.0, im = 0.0;
+    for (int n = 0; n < W; n++) {
+        double s, c;
+        sincospi(-2.0 * (double)(((long long)k * n) % W) / (double)W, &s, &c);
+        re += y[n].x * c - y[n].y * s;
+        im += y[n].x * s + y[n].y * c;
+    }
+    const double a = hypot(re, im) * (1.0 / W);
+    const double db = a <= 1e-7 ? -140.0 : 20.0 * log10(a);
+    const int half = W / 2;
+    out[k >= half ? k - half : k + (W - half)] = db;
+}
+
 inline unsigned grid_for(int n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
 using qh_ps::turns_step;
@@ -857,6 +900,40 @@ void qh_quisk_set_ssb_squelch(int enabled, int level)                           
     std::lock_guard<std::mutex> lk(g.mtx);
     g.ssb_squelch_enabled = enabled; g.ssb_squelch_level = level;
 }
+// get_filter() (quisk.c:5481-5568): the response of cFilterI/Q[0] (all sizeFilter taps, up to MAX_FILTER_SIZE) in dB, data_width
+// values, negative frequencies first.  Returns data_width, or 0 with qh_last_error() set.
+int qh_quisk_get_filter(double *db)
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    if (!g.sample_rate || !g.have_tables) { qh::set_error(QH_ERR_INVALID, "qh_quisk_open has not been called"); return 0; }
+    if (!db || g.data_width <= 0 || g.fft_size < g.data_width) { qh::set_error(QH_ERR_INVALID, "qh_quisk_get_filter: the receiver was opened without a graph (data_width, fft_size)"); return 0; }
+    if (hipSetDevice(0) != hipSuccess) { qh::set_error(QH_ERR_NO_DEVICE, "no HIP device (libquiskhip has no CPU fallback)"); return 0; }
+    const int W = g.data_width, N = g.size_filter, total = W + N;
+    int nf = 0;
+    for (int f = 1; f < W / 2.0 - 10.0; f++) nf = f;
+    std::vector<double> fI((size_t)(N > 0 ? N : 1), 0.0), fQ((size_t)(N > 0 ? N : 1), 0.0);
+    for (int i = 0; i < N; i++) {
+        if ((size_t)i < g.filtI[0].size()) { fI[(size_t)i] = g.filtI[0][(size_t)i]; fQ[(size_t)i] = g.filtQ[0][(size_t)i]; }
+    }
+    double *d = nullptr;
+    const size_t words = (size_t)total + 2 * fI.size() + 2 * (size_t)W + (size_t)W;
+    if (hipMalloc((void **)&d, words * sizeof(double)) != hipSuccess) { qh::set_error(QH_ERR_HIP, "qh_quisk_get_filter: hipMalloc failed"); return 0; }
+    double *dx = d, *dfI = dx + total, *dfQ = dfI + fI.size(), *dy = dfQ + fI.size(), *dout = dy + 2 * (size_t)W;
+    hipStream_t s = g.stream;
+    bool ok = hipMemcpyAsync(dfI, fI.data(), fI.size() * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(dfQ, fQ.data(), fQ.size() * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(gf_multitone_kernel, dim3(grid_for(total)), dim3(256), 0, s, dx, total, W, nf);
+        hipLaunchKernelGGL(gf_filter_kernel, dim3(grid_for(W)), dim3(256), 0, s, (const double *)dx, (const double *)dfI, (const double *)dfQ, N, W, g.fft_size,
+                           reinterpret_cast<double2 *>(dy));
+        hipLaunchKernelGGL(gf_dft_kernel, dim3(grid_for(W)), dim3(256), 0, s, (const double2 *)reinterpret_cast<double2 *>(dy), W, dout);
+        ok = hipMemcpyAsync(db, dout, (size_t)W * 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) { qh::set_error(QH_ERR_HIP, "qh_quisk_get_filter: the device chain failed"); return 0; }
+    return W;
+}
+
 long long qh_quisk_error_count(void) { std::lock_guard<std::mutex> lk(g.mtx); return g.failed_calls; }
 int qh_quisk_squelch_flags(void) { std::lock_guard<std::mutex> lk(g.mtx); return g.squelch_real | (g.squelch_imag << 1); }
 // add_tone(freq) (quisk.c:3203-3216): a -40 dB test tone added to the samples; 0 switches it off

@@ -128,6 +128,19 @@ def get_graph(zoom=1.0, deltaf=0.0):
     return None if cnt == 0 else (pix, sm.value, cnt)
 
 
+def get_filter():
+    """QS.get_filter() (quisk.c:5481): the Rx filter's response in dB, data_width values."""
+    from .lib import QuiskHipError
+    L = load()
+    w = _keep.get("data_width", 0)
+    out = np.zeros(max(w, 1), dtype=np.float64)
+    L.qh_quisk_get_filter.argtypes = [C.c_void_p]
+    n = L.qh_quisk_get_filter(out.ctypes.data)
+    if n <= 0:
+        raise QuiskHipError(L.qh_last_error().decode(errors="replace"))
+    return out[:n]
+
+
 def set_squelch(level):
     load().qh_quisk_set_squelch(C.c_double(level))
 

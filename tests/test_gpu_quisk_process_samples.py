@@ -325,3 +325,28 @@ def test_fm_squelch_mutes_one_side_behind_the_agc(qh, oracle):
     y, want = np.concatenate(outs)[8 * 1200:], np.concatenate(refs)[8 * 1200:]
     assert np.all(want.real == 0) and np.all(y.real == 0)
     assert np.abs(want.imag).max() > 2.0 ** 20 and rel_rms(y, want) < 1e-6
+
+
+@pytest.mark.parametrize("mode,name,bw,width,fft,extra_taps", [(3, "USB", 2700, 1024, 2048, 0), (4, "AM", 6000, 950, 3800, 0), (1, "CWU", 500, 800, 800, 0),
+                                                                (3, "USB", 2700, 1024, 1024, 9000)],
+                         ids=["usb-1024", "am-950-of-3800", "cw-800", "usb-10k-taps"])
+def test_get_filter_matches_the_restatement(qh, oracle, mode, name, bw, width, fft, extra_taps):
+    """get_filter (quisk.c:5481-5568), the "RX Filter" screen's curve: multitone, the cRxFilterOut loop's own copy there, record_app's
+    window, a data_width-point transform (any width), dB with the -140 floor.  Also with a filter near MAX_FILTER_SIZE (10001)."""
+    api = qh.quiskapi
+    api.open(48000, fft_size=fft, data_width=width)
+    fI, fQ = _filters(name, mode, bw, fs=48000)
+    if extra_taps:                                       # a long filter: the short one stretched by interpolation
+        k = np.linspace(0, fI.size - 1, fI.size + extra_taps)
+        fI, fQ = np.interp(k, np.arange(fI.size), fI) * fI.size / k.size, np.interp(k, np.arange(fQ.size), fQ) * fQ.size / k.size
+        assert fI.size > 9000
+    api.set_rx_mode(mode)
+    api.set_filters(fI, fQ, bw)
+    got = api.get_filter()
+    api.close()
+    want = oracle.get_filter(fI, fQ, width, fft)
+    assert got.size == want.size == width
+    assert want.max() > -40.0 and want.min() < -60.0
+    top = want > -60.0
+    assert np.abs(got[top] - want[top]).max() < 1e-6     # dB
+    assert np.abs(got - want).max() < 1e-3               # far down the skirts the last digits of a 1e-6 magnitude decide
