@@ -688,6 +688,11 @@ int qh_quisk_squelch_flags(void);                                          /* bi
 /* quisk_process_samples has no error return (failures are QuiskPrintf + counters, quisk.c:55): a call whose device chain failed returns
  * 0 samples, qh_last_error() says why, and this counter says that it happened (0 samples alone also means "no output yet") */
 long long qh_quisk_error_count(void);
+/* Mode EXT (quisk.c:2490-2493): the tuned block goes to the user's quisk_extern_demod (extdemod.c:13 -- `complex double *` in place,
+ * returns the play-sample count <= nSamples) and from there straight to process_agc.  The reference links the function in; here it
+ * is registered (a binding passes &quisk_extern_demod).  It is host code: the block makes one round trip.  Without one, mode EXT
+ * fails loudly. */
+void qh_quisk_set_extern_demod(int (*fn)(double *cSamples, int nSamples, double decim));
 void qh_quisk_add_tone(int freq);                                          /* add_tone, quisk.c:3203 */
 double qh_quisk_measure_frequency(int mode);                               /* measure_frequency, quisk.c:3181 */
 void qh_quisk_set_multirx_count(int n);                                    /* quisk_multirx_count */

@@ -121,6 +121,17 @@ __global__ void gf_dft_kernel(const double2 *y, int W, double *out)
     out[k >= half ? k - half : k + (W - half)] = db;
 }
 
+// the tune of quisk.c:2481-2487 on its own (mode EXT has no decimator behind it to carry the oscillator): x[i] *= e^{j 2 pi (ph + i dph)}
+__global__ void ps_tune_kernel(const double2 *in, double2 *out, int n, unsigned long long ph, unsigned long long dph)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    sincospi(2.0 * ((double)((ph + dph * (unsigned long long)i) >> 11) * (1.0 / 9007199254740992.0)), &s, &c);
+    const double2 x = in[i];
+    out[i] = make_double2(x.x * c - x.y * s, x.x * s + x.y * c);
+}
+
 inline unsigned grid_for(int n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
 using qh_ps::turns_step;
@@ -238,6 +249,9 @@ struct QuiskRx {
     std::vector<double> sub1_out;               // sub-receiver 1's audio of the last call (what play_sound_interface got)
     int sub1_n = 0;
     int squelch_real = 0, squelch_imag = 0;
+    // mode EXT (quisk.c:2490-2493): the user's quisk_extern_demod (extdemod.c:13), a host function by definition
+    int (*ext_demod)(double *cSamples, int nSamples, double decim) = nullptr;
+    DevBuf<double2> d_ext;
     long long failed_calls = 0;                 // calls whose device chain failed: the caller got 0 samples, which alone says nothing
 };
 
@@ -330,7 +344,7 @@ void free_all()
     if (g.mf_fft) { qh_pan_destroy(g.mf_fft); g.mf_fft = nullptr; }
     g.d_raw.release(); g.d_x.release(); g.d_nb.release(); g.d_o0.release(); g.d_o1.release(); g.d_mix.release(); g.d_fd.release();
     g.d_up.release(); g.d_a.release(); g.d_b.release(); g.d_sub.release(); g.d_sub0.release(); g.d_s1.release(); g.d_mf.release();
-    g.d_mf8.release();
+    g.d_mf8.release(); g.d_ext.release();
     for (auto &row : g.b2c) for (auto &bb : row) bb.release();
     for (double2 *&h : g.fd_hist) { if (h) (void)hipFree(h); h = nullptr; }
     if (g.d_flags) { (void)hipFree(g.d_flags); g.d_flags = nullptr; }
@@ -489,6 +503,42 @@ int process_radio(double *cSamples, int nSamples)
     }
     // ---- the FFT ring producer (quisk.c:2454-2475)
     if (g.pan && qh_pan_feed(g.pan, reinterpret_cast<const double *>(cur), n, n)) return -1;
+    // ---- mode EXT: tune, the user's demodulator, then straight to the AGC (quisk.c:2490-2493: "goto start_agc")
+    if (g.mode == 6) {
+        if (!g.ext_demod) { qh::set_error(QH_ERR_UNSUPPORTED, "mode EXT calls the user's quisk_extern_demod (extdemod.c:13): none registered (qh_quisk_set_extern_demod)"); return -1; }
+        destroy_bank(g.bank[0], true);                           // the receive oscillator's phase comes back from the bank that carried it
+        if (g.d_ext.need((size_t)n) || g.h_out.need((size_t)n * 2)) return -1;
+        const u64 dph = g.tune != 0 ? turns_step(-(double)g.tune, (double)g.sample_rate) : 0ull;
+        hipLaunchKernelGGL(ps_tune_kernel, dim3(grid_for(n)), dim3(256), 0, s, cur, g.d_ext.p, n, g.phase[0], dph);
+        g.phase[0] += dph * (u64)n;
+        // the plug-in is host code: the one round trip of this path
+        if (hipMemcpyAsync(g.h_out.p, g.d_ext.p, (size_t)n * 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            qh::set_error(QH_ERR_HIP, "download failed"); return -1;
+        }
+        const int na = g.ext_demod(g.h_out.p, n, (double)g.sample_rate / g.playback_rate);      // "total decimation needed"
+        if (na < 0 || na > n) { qh::set_error(QH_ERR_INVALID, "quisk_extern_demod returned %d samples for a block of %d", na, n); return -1; }
+        double2 *audio = g.d_ext.p;
+        if (na > 0) {
+            if (hipMemcpyAsync(audio, g.h_out.p, (size_t)na * 16, hipMemcpyHostToDevice, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
+            if (run_agc(0, 1, audio, na)) return -1;             // "Ext and DGT-IQ stereo sound", quisk.c:2686-2688
+        }
+        int env_n = 0;
+        const double env0 = g.keyup_env, env_step = 1. / (g.playback_rate * 5e-3);
+        if (g.keyup_env < 1.0 && na > 0)
+            for (int i = 0; i < na; i++) {
+                g.keyup_env += env_step;
+                if (g.keyup_env > 1.0) { g.keyup_env = 1.0; break; }
+                env_n++;
+            }
+        hipLaunchKernelGGL(qh_ps::epilogue_kernel, dim3(grid_for(na), 1u), dim3(256), 0, s, (const double2 *)audio, 0LL, audio, 0LL, na, (const int *)nullptr, 0,
+                           (const int *)nullptr, 0, g.kill_audio, env0, env_step, env_n, g.d_flags);
+        if (na > 0 && hipMemcpyAsync(g.h_out.p, audio, (size_t)na * 16, hipMemcpyDeviceToHost, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "download failed"); return -1; }
+        if (hipMemcpyAsync(g.h_flags, g.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipGetLastError() != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "qh_quisk_process_samples: the device chain failed"); return -1; }
+        if (na > 0) std::memcpy(cSamples, g.h_out.p, (size_t)na * 2 * sizeof(double));
+        g.squelch_real = g.h_flags[0]; g.squelch_imag = g.h_flags[1];
+        return na;
+    }
     // ---- bank 0: tune, decimate, demodulate
     Bank &b0 = g.bank[0];
     if (ensure_bank(b0, g.mode, 0, g.tune, 0)) return -1;
@@ -932,6 +982,14 @@ int qh_quisk_get_filter(double *db)
     (void)hipFree(d);
     if (!ok) { qh::set_error(QH_ERR_HIP, "qh_quisk_get_filter: the device chain failed"); return 0; }
     return W;
+}
+
+// The user's quisk_extern_demod (extdemod.c:13: `int quisk_extern_demod(complex double *cSamples, int nSamples, double decim)`, in place,
+// returns the play-sample count), which the reference links in and calls in mode EXT (quisk.c:2490-2493).  NULL unregisters it.
+void qh_quisk_set_extern_demod(int (*fn)(double *cSamples, int nSamples, double decim))
+{
+    std::lock_guard<std::mutex> lk(g.mtx);
+    g.ext_demod = fn;
 }
 
 long long qh_quisk_error_count(void) { std::lock_guard<std::mutex> lk(g.mtx); return g.failed_calls; }

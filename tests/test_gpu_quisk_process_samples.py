@@ -350,3 +350,60 @@ def test_get_filter_matches_the_restatement(qh, oracle, mode, name, bw, width, f
     top = want > -60.0
     assert np.abs(got[top] - want[top]).max() < 1e-6     # dB
     assert np.abs(got - want).max() < 1e-3               # far down the skirts the last digits of a 1e-6 magnitude decide
+
+
+def test_mode_ext_hands_the_tuned_block_to_the_registered_demodulator(qh, oracle):
+    """Mode EXT (quisk.c:2490-2493): NoiseBlanker / FFT ring as always, the tune, then the user's quisk_extern_demod (extdemod.c:13)
+    in place and straight to process_agc(.., 1) ("goto start_agc").  The callback here is extdemod.c's own narrow-FM discriminator,
+    restated; the expected block = the tune in closed form, that function, the restatement's process_agc."""
+    fs, blk, nblk, tune = 48000, 4000, 12, 6000
+    api, lib = qh.quiskapi, qh.load()
+    api.open(fs, playback_rate=48000)
+    api.set_rx_mode(6)
+    api.set_tune(tune)
+    rng = np.random.default_rng(23)
+    t = np.arange(blk * nblk)
+    x = 2.0 ** 24 * np.exp(2j * np.pi * ((tune / fs) * t % 1.0) + 2j * np.sin(2 * np.pi * 700.0 / fs * t)) + \
+        2.0 ** 12 * (rng.standard_normal(t.size) + 1j * rng.standard_normal(t.size))
+    # without a registered demodulator the mode fails loudly: 0 samples and the error counter moves
+    before = lib.qh_quisk_error_count()
+    assert api.process(x[:blk]).size == 0 and lib.qh_quisk_error_count() == before + 1
+    assert b"quisk_extern_demod" in lib.qh_last_error()
+
+    state = {"fm_1": 10 + 0j, "fm_2": 10 + 0j, "decims": []}
+
+    def extern_demod(buf, n, decim):                     # extdemod.c:13-47
+        state["decims"].append(decim)
+        a = np.ctypeslib.as_array(buf, shape=(2 * n,))
+        z = a[0::2] + 1j * a[1::2]
+        out = np.empty(n)
+        f1, f2 = state["fm_1"], state["fm_2"]
+        for i in range(n):
+            cx = z[i]
+            di = f1.real * (cx.imag - f2.imag) - f1.imag * (cx.real - f2.real)
+            d = f1.real * f1.real + f1.imag * f1.imag
+            out[i] = 0.0 if d == 0 else di / d * fs
+            f2, f1 = f1, cx
+        state["fm_1"], state["fm_2"] = f1, f2
+        a[0::2] = out; a[1::2] = out
+        return n
+    CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double)
+    cb = CB(extern_demod)
+    lib.qh_quisk_set_extern_demod.argtypes = [CB]
+    lib.qh_quisk_set_extern_demod(cb)
+    got = np.concatenate([api.process(x[k * blk:(k + 1) * blk]) for k in range(nblk)])
+    lib.qh_quisk_set_extern_demod(CB())                  # unregister before the callback object goes away
+    api.close()
+    assert state["decims"] and all(abs(d - 1.0) < 1e-12 for d in state["decims"])
+    # expected: tune (x * exp(-j 2 pi tune n / fs), the vector the reference steps sample by sample), the demodulator, process_agc
+    state.update(fm_1=10 + 0j, fm_2=10 + 0j)
+    tuned = x * np.exp(-2j * np.pi * ((tune / fs) * np.arange(x.size) % 1.0))       # (the refused call did not advance anything)
+    buf = np.empty(2 * tuned.size)
+    buf[0::2], buf[1::2] = tuned.real, tuned.imag
+    extern_demod(buf.ctypes.data_as(C.POINTER(C.c_double)), tuned.size, 1.0)
+    audio = buf[0::2] + 1j * buf[1::2]
+    agc = oracle.OracleQuiskAgc(48000)
+    want = np.concatenate([agc.process(audio[k * blk:(k + 1) * blk], True, 80.0) for k in range(nblk)])
+    assert got.size == want.size
+    assert np.abs(want).max() > 2.0 ** 20
+    assert rel_rms(got, want) < 1e-8
