@@ -1,5 +1,6 @@
 // qh_design.cpp -- see qh_design.hpp.
 #include "qh_design.hpp"
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 
@@ -22,26 +23,31 @@ static double bh_window(int wintype, double cosphi)
          + cosphi * (4.3778825791773474e-04))))));
 }
 
+// Windowed-sinc band-pass (what wdsp/fir.c:187-254 designs).  In closed form, with x = n - (N - 1) / 2 the tap's distance from the centre,
+//
+//     h[n] = scale * w[n] * sin(2 pi B x) / (pi x) * exp(-j w0 x),      B = (f_high - f_low) / (2 fs),   w0 = pi (f_high + f_low) / fs
+//
+// i.e. a low-pass of half-width B under a Blackman-Harris window, moved to the band's centre (the real part alone for rtype 0).  The
+// low-pass times the window is real and even in x: the upper half is evaluated, the lower half mirrored, and one pass turns the
+// oscillator on.  (The window is evaluated from cos(pi n / m) at the UPPER index of each mirrored pair, as the reference does; the
+// window is symmetric, so this only fixes which of two equal-to-rounding values is used.)
 std::vector<cd> fir_bandpass(int N, double f_low, double f_high, double samplerate, int wintype, int rtype, double scale)
 {
-    std::vector<cd> h((size_t)N, cd(0, 0));
-    const double ft = (f_high - f_low) / (2.0 * samplerate);
-    const double ft_rad = kTwoPi * ft;
-    const double w_osc = kPi * (f_high + f_low) / samplerate;
-    const double m = 0.5 * (double)(N - 1);
-    const double delta = kPi / m;
-    if (N & 1) h[N >> 1] = cd(scale * 2.0 * ft, 0.0);
-    for (int i = (N + 1) / 2, j = N / 2 - 1; i < N; i++, j--) {
-        const double posi = (double)i - m, posj = (double)j - m;
-        const double sinc = std::sin(ft_rad * posi) / (kPi * posi);
-        const double coef = scale * sinc * bh_window(wintype, std::cos(delta * i));
-        if (rtype == 0) {
-            h[i] = cd(coef * std::cos(posi * w_osc), 0.0);
-            h[j] = cd(coef * std::cos(posj * w_osc), 0.0);
-        } else {
-            h[i] = cd(coef * std::cos(posi * w_osc), -coef * std::sin(posi * w_osc));
-            h[j] = cd(coef * std::cos(posj * w_osc), -coef * std::sin(posj * w_osc));
-        }
+    const double half_width = (f_high - f_low) / (2.0 * samplerate);
+    const double centre = kPi * (f_high + f_low) / samplerate;
+    const double mid = 0.5 * (double)(N - 1);
+    std::vector<double> lowpass((size_t)N, 0.0);
+    if (N & 1) lowpass[(size_t)(N >> 1)] = scale * 2.0 * half_width;               // the limit of sin(2 pi B x) / (pi x) at x = 0; the window is 1 there
+    for (int n = (N + 1) / 2; n < N; n++) {
+        const double x = (double)n - mid;
+        const double v = scale * (std::sin(kTwoPi * half_width * x) / (kPi * x)) * bh_window(wintype, std::cos((kPi / mid) * n));
+        lowpass[(size_t)n] = v;
+        lowpass[(size_t)(N - 1 - n)] = v;
+    }
+    std::vector<cd> h((size_t)N);
+    for (int n = 0; n < N; n++) {
+        const double x = (double)n - mid, v = lowpass[(size_t)n];
+        h[(size_t)n] = rtype == 0 ? cd(v * std::cos(x * centre), 0.0) : cd(v * std::cos(x * centre), -v * std::sin(x * centre));
     }
     return h;
 }
@@ -78,52 +84,50 @@ static std::vector<double> fsamp_window(int N, int wintype)
     return w;
 }
 
+// The FM de-emphasis / pre-emphasis curve as an FIR (what wdsp/fcurve.c:29-145 builds through fir_fsamp, wdsp/fir.c:129-185), even nc.
+//
+// Wanted magnitude at the nc / 2 bin centres f_i = (i + 1/2) / (nc / 2) * fs / 2: a 6 dB / octave line through (f0, g0 dB), rising
+// (curve 0) or falling (curve 1).  With ctfmode 0 the line holds between f0 and f1 only; outside, bin by bin, the magnitude is the
+// one inside times (f_k / f_edge)^4 resp. (f_edge / f_k)^4 with f_k = k / (nc / 2) -- a running product, so the skirts fall faster
+// than a fourth-order slope (the reference's own shape, kept; floor 1e-100).
+// The taps are the linear-phase frequency-sampling design: h[n] = (A_0 + 2 sum_{k=1}^{nc/2-1} A_k cos(2 pi (n - M) k / nc)) / nc with
+// M = (nc - 1) / 2, even about M (one half evaluated), under a Blackman-Harris window.
 std::vector<cd> fc_impulse(int nc, double f0, double f1, double g0, double /*g1*/, int curve, double samplerate,
                            double scale, int ctfmode, int wintype)
 {
     if (nc & 1) throw std::runtime_error("fc_impulse: odd nc is not used by the RXA chain");
-    const int mid = nc / 2;
-    std::vector<double> A((size_t)mid + 1, 0.0);
-    const double g0_lin = std::pow(10.0, g0 / 20.0);
-    for (int i = 0; i < mid; i++) {
-        const double fn = ((double)i + 0.5) / (double)mid;
-        const double f = fn * samplerate / 2.0;
-        if (curve == 0) A[i] = (f0 > 0.0) ? scale * (g0_lin * f / f0) : 0.0;
-        else            A[i] = (f > 0.0) ? scale * (g0_lin * f0 / f) : 0.0;
+    const int bins = nc / 2;
+    const double nyquist = samplerate / 2.0, line = scale * std::pow(10.0, g0 / 20.0);
+    std::vector<double> mag((size_t)bins + 1, 0.0);
+    for (int i = 0; i < bins; i++) {
+        const double f = ((double)i + 0.5) / (double)bins * nyquist;
+        mag[(size_t)i] = curve == 0 ? (f0 > 0.0 ? line * f / f0 : 0.0) : (f > 0.0 ? line * f0 / f : 0.0);
     }
     if (ctfmode == 0) {
-        const int low = (int)(2.0 * f0 / samplerate * mid - 0.5);
-        const int high = (int)(2.0 * f1 / samplerate * mid - 0.5);
-        double lowmag = A[low], highmag = A[high];
-        const double flow4 = std::pow((double)low / (double)mid, 4.0);
-        const double fhigh4 = std::pow((double)high / (double)mid, 4.0);
-        int k = low;
-        while (--k >= 0) {
-            const double f = (double)k / (double)mid;
-            lowmag *= (f * f * f * f) / flow4;
-            if (lowmag < 1.0e-100) lowmag = 1.0e-100;
-            A[k] = lowmag;
+        const int lo = (int)(f0 / nyquist * bins - 0.5), hi = (int)(f1 / nyquist * bins - 0.5);
+        auto pow4 = [](double v) { return v * v * v * v; };
+        const double lo4 = std::pow((double)lo / (double)bins, 4.0), hi4 = std::pow((double)hi / (double)bins, 4.0);
+        double skirt = mag[(size_t)lo];
+        for (int k = lo - 1; k >= 0; k--) {                  // below the band: each bin the one above it times (f_k / f_lo)^4
+            skirt = std::max(skirt * (pow4((double)k / (double)bins) / lo4), 1.0e-100);
+            mag[(size_t)k] = skirt;
         }
-        k = high;
-        while (++k < mid) {
-            const double f = (double)k / (double)mid;
-            highmag *= fhigh4 / (f * f * f * f);
-            if (highmag < 1.0e-100) highmag = 1.0e-100;
-            A[k] = highmag;
+        skirt = mag[(size_t)hi];
+        for (int k = hi + 1; k < bins; k++) {                // above it: each bin the one below it times (f_hi / f_k)^4
+            skirt = std::max(skirt * (hi4 / pow4((double)k / (double)bins)), 1.0e-100);
+            mag[(size_t)k] = skirt;
         }
     }
-    // fir_fsamp, even N, rtype 1, scale 1 (wdsp/fir.c:129-185)
-    const int N = nc;
-    std::vector<cd> h((size_t)N, cd(0, 0));
-    const double M = (double)(N - 1) / 2.0;
-    for (int n = 0; n < N / 2; n++) {
-        double sum = 0.0;
-        for (int k = 1; k < N / 2; k++) sum += 2.0 * A[k] * std::cos(kTwoPi * (n - M) * k / N);
-        h[n] = cd((1.0 / N) * (A[0] + sum), 0.0);
+    const double centre = (double)(nc - 1) / 2.0;
+    const std::vector<double> w = fsamp_window(nc, wintype);
+    std::vector<cd> h((size_t)nc);
+    for (int n = 0; n < bins; n++) {
+        double acc = 0.0;
+        for (int k = 1; k < bins; k++) acc += 2.0 * mag[(size_t)k] * std::cos(kTwoPi * (n - centre) * k / nc);
+        const double tap = (1.0 / nc) * (mag[0] + acc);
+        h[(size_t)n] = cd(tap * w[(size_t)n], 0.0);
+        h[(size_t)(nc - 1 - n)] = cd(tap * w[(size_t)(nc - 1 - n)], 0.0);
     }
-    for (int n = N / 2, j = 1; n < N; n++, j++) h[n] = cd(h[N / 2 - j].real(), 0.0);
-    std::vector<double> w = fsamp_window(N, wintype);
-    for (int i = 0; i < N; i++) h[i] = cd(h[i].real() * (1.0 * w[i]), 0.0);
     return h;
 }
 

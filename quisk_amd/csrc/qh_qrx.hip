@@ -60,6 +60,30 @@ static std::vector<double> hb45_interp_taps()   // 45 taps, gain 2 (filter.c:420
     return g;
 }
 
+// ---- Rx filters longer than one 4096-point tile allows (2048 taps): K partitions of 2048 taps, partition k on the stream delayed by
+// 2048 k samples, their outputs added.  [delay line | block] is put together once per call.
+static __global__ void rxp_gather_kernel(const double2 *dly, int D, const double2 *in, long long in_stride, int n, double2 *x, long long x_stride)
+{
+    const long long row = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D + n; i += gridDim.x * blockDim.x)
+        x[row * x_stride + i] = i < D ? dly[row * D + i] : in[row * in_stride + (i - D)];
+}
+static __global__ void rxp_keep_kernel(const double2 *x, long long x_stride, int D, int n, double2 *dly)
+{
+    const long long row = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D; i += gridDim.x * blockDim.x) dly[row * D + i] = x[row * x_stride + n + i];
+}
+static __global__ void rxp_add_kernel(double2 *y, long long y_stride, const double2 *t, long long t_stride, int n)
+{
+    const long long row = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double2 a = y[row * y_stride + i];
+        const double2 b = t[row * t_stride + i];
+        a.x += b.x; a.y += b.y;
+        y[row * y_stride + i] = a;
+    }
+}
+
 // quisk_dInterpolate (filter.c:167-201): phases j use taps j + k*interp for k < ntaps/interp, gain interp
 static std::vector<double> dinterp_taps(const double *h, int ntaps, int interp)
 {
@@ -92,6 +116,14 @@ struct Qrx {
     bool own_stream = false;
     std::vector<Step> steps;        // in order; steps[0] is an overlap-save stage that carries the NCO
     Stage *rxf = nullptr;           // Rx filter (per-channel taps); owned by its step
+    // filters of more than kRxPart taps: partitions 1 .. K - 1 (taps [kRxPart k, kRxPart (k + 1)) on the stream delayed by kRxPart k)
+    static constexpr int kRxPart = 2048, kRxMaxTaps = 10000;       // MAX_FILTER_SIZE - 1 (quisk.h:10, quisk.c:4575)
+    std::vector<Stage *> rxf_more;
+    bool rx_sideband_epi = false, rx_direct_out = false;
+    double2 *rx_dly[2] = { nullptr, nullptr }, *rx_x = nullptr, *rx_tmp = nullptr;
+    int rx_dly_cur = 0;
+    long long rx_x_cap = 0;
+    int rx_D() const { return (int)rxf_more.size() * kRxPart; }
     double *dc_state = nullptr;     // AM
     double4 *fm_state = nullptr;    // FM
     double4 *fm_state_new = nullptr;
@@ -144,6 +176,8 @@ struct Qrx {
         (void)hipFree(dc_state); (void)hipFree(fm_state); (void)hipFree(fm_state_new); (void)hipFree(fm_part); (void)hipFree(buf[0]); (void)hipFree(buf[1]);
         (void)hipFree(sq_state); (void)hipFree(sq_level); (void)hipFree(nb_buf); (void)hipFree(notch_state); (void)hipFree(tw2048);
         (void)hipFree(ssq_state); (void)hipFree(ssq_ring); (void)hipFree(ssq_delay[0]); (void)hipFree(ssq_delay[1]);
+        for (Stage *p : rxf_more) { p->destroy(); delete p; }
+        (void)hipFree(rx_dly[0]); (void)hipFree(rx_dly[1]); (void)hipFree(rx_x); (void)hipFree(rx_tmp);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -187,34 +221,94 @@ struct Qrx {
         return QH_OK;
     }
 
+    // The Rx filter's history of channel c, ages 1 (the newest sample) .. rx_hist_len(): the first partition's history rows when the
+    // filter fits one partition; else the delay line (ages 1 .. D) and the last partition's rows behind it.
+    int rx_hist_len() const { return rx_D() + rxf->hist_len; }
+    int rx_hist_read(int c, std::vector<cd> &v)         // v[age - 1]
+    {
+        const int D = rx_D(), H = rxf->hist_len;
+        v.assign((size_t)(D + H), cd(0.0, 0.0));
+        QH_HIP(hipStreamSynchronize(stream));
+        std::vector<cd> row((size_t)(D > H ? D : H));
+        if (D > 0) {
+            QH_HIP(hipMemcpy(row.data(), rx_dly[rx_dly_cur] + (size_t)c * D, (size_t)D * sizeof(cd), hipMemcpyDeviceToHost));
+            for (int a = 1; a <= D; a++) v[(size_t)a - 1] = row[(size_t)(D - a)];
+        }
+        Stage *lastp = rxf_more.empty() ? rxf : rxf_more.back();
+        QH_HIP(hipMemcpy(row.data(), static_cast<char *>(lastp->hist[lastp->cur]) + (size_t)c * H * sizeof(cd), (size_t)H * sizeof(cd), hipMemcpyDeviceToHost));
+        for (int a = 1; a <= H; a++) v[(size_t)(D + a) - 1] = row[(size_t)(H - a)];
+        return QH_OK;
+    }
+    int rx_hist_write(int c, const std::vector<cd> &v)
+    {
+        const int D = rx_D(), H = rxf->hist_len;
+        QH_HIP(hipStreamSynchronize(stream));
+        std::vector<cd> row((size_t)(D > H ? D : H));
+        auto at = [&](int age) { return age >= 1 && (size_t)age <= v.size() ? v[(size_t)age - 1] : cd(0.0, 0.0); };
+        if (D > 0) {
+            for (int a = 1; a <= D; a++) row[(size_t)(D - a)] = at(a);
+            QH_HIP(hipMemcpy(rx_dly[rx_dly_cur] + (size_t)c * D, row.data(), (size_t)D * sizeof(cd), hipMemcpyHostToDevice));
+        }
+        for (size_t k = 0; k <= rxf_more.size(); k++) {     // partition k sees the stream delayed by kRxPart k
+            Stage *p = k == 0 ? rxf : rxf_more[k - 1];
+            for (int a = 1; a <= H; a++) row[(size_t)(H - a)] = at((int)k * kRxPart + a);
+            QH_HIP(hipMemcpy(static_cast<char *>(p->hist[p->cur]) + (size_t)c * H * sizeof(cd), row.data(), (size_t)H * sizeof(cd), hipMemcpyHostToDevice));
+        }
+        return QH_OK;
+    }
+    // partitions for filters of up to `size` taps: Stages like the first one (per-channel taps, the same output matrix), the delay line
+    int rx_ensure_parts(int size)
+    {
+        const int K = size > kRxPart ? (size + kRxPart - 1) / kRxPart : 1;
+        if ((int)rxf_more.size() + 1 >= K) return QH_OK;
+        QH_HIP(hipSetDevice(device));
+        // what the receivers hold so far, to be laid out again over the longer delay line
+        std::vector<std::vector<cd>> keep((size_t)nch);
+        for (int c = 0; c < nch; c++) if (int rc = rx_hist_read(c, keep[(size_t)c])) return rc;
+        while ((int)rxf_more.size() + 1 < K) {
+            Stage *p = new Stage();
+            rxf_more.push_back(p);
+            if (int rc = p->init(device, nch, kRxPart, 1, 1, QH_F64, false, true, rx_sideband_epi, stream)) return rc;
+            if (int rc = p->set_taps(-1, std::vector<cd>(1, cd(0.0, 0.0)))) return rc;
+            if (rx_sideband_epi)
+                for (int c = 0; c < nch; c++)
+                    if (int rc = p->set_epi(c, rx_direct_out ? EpiParam{ 1, 0, 1, 0 } : EpiParam{ 1, 0, 0, 0 })) return rc;
+        }
+        const int D = rx_D();
+        for (int i = 0; i < 2; i++) {
+            (void)hipFree(rx_dly[i]); rx_dly[i] = nullptr;
+            QH_HIP(hipMalloc((void **)&rx_dly[i], (size_t)nch * (size_t)D * sizeof(cd)));
+            QH_HIP(hipMemset(rx_dly[i], 0, (size_t)nch * (size_t)D * sizeof(cd)));
+        }
+        for (int c = 0; c < nch; c++) if (int rc = rx_hist_write(c, keep[(size_t)c])) return rc;
+        return QH_OK;
+    }
+
     // The reference's ring of N = rx_size entries (position p was written when indexFilter was p; the tap loop reads
     // (index + k) mod N) becomes a ring of M entries over the same storage.
     int rx_resize(int c, int M)
     {
-        const int N = rx_size[(size_t)c], H = rxf->hist_len;
+        const int N = rx_size[(size_t)c], H = rx_hist_len();
         QH_HIP(hipSetDevice(device));
-        std::vector<cd> row((size_t)H);
-        char *base = static_cast<char *>(rxf->hist[rxf->cur]) + (size_t)c * H * sizeof(cd);
+        std::vector<cd> hist;
         std::vector<cd> &ring = rx_ring[(size_t)c];
         if ((int)ring.size() < (N > M ? N : M)) ring.resize((size_t)(N > M ? N : M), cd(0.0, 0.0));
         if (N > 0) {
-            QH_HIP(hipStreamSynchronize(stream));
-            QH_HIP(hipMemcpy(row.data(), base, row.size() * sizeof(cd), hipMemcpyDeviceToHost));
+            if (int rc = rx_hist_read(c, hist)) return rc;
             // what the live ring holds: the sample written `age` calls ago sits at (last - age) mod N, last = index - 1
             const int last = rx_index[(size_t)c] - 1;
             if (last >= 0)
                 for (int age = 0; age < N; age++) {
                     const int p = ((last - age) % N + N) % N;
-                    ring[(size_t)p] = age < H ? row[(size_t)(H - 1 - age)] : cd(0.0, 0.0);      // (a 2048-entry ring's oldest sample is not kept)
+                    ring[(size_t)p] = age < H ? hist[(size_t)age] : cd(0.0, 0.0);      // (the oldest sample of a ring as long as the history is not kept)
                 }
         }
         if (M > 0) {
             // the next sample is written at w; tap k >= 1 reads (w + k) mod M = the history sample of age M - k
             const int i = rx_index[(size_t)c], w = i >= M ? 0 : i;
-            std::fill(row.begin(), row.end(), cd(0.0, 0.0));
-            for (int d = 1; d < M && d <= H; d++) row[(size_t)(H - d)] = ring[(size_t)(((w - d) % M + M) % M)];
-            QH_HIP(hipStreamSynchronize(stream));
-            QH_HIP(hipMemcpy(base, row.data(), row.size() * sizeof(cd), hipMemcpyHostToDevice));
+            hist.assign((size_t)H, cd(0.0, 0.0));
+            for (int d = 1; d < M && d <= H; d++) hist[(size_t)d - 1] = ring[(size_t)(((w - d) % M + M) % M)];
+            if (int rc = rx_hist_write(c, hist)) return rc;
         }
         rx_size[(size_t)c] = M;
         return QH_OK;
@@ -350,7 +444,8 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         step.kind = Step::FIR;
         step.st = q.rxf = new Stage();
         q.steps.push_back(step);
-        if (q.rxf->init(device, nch, 2048, 1, 1, QH_F64, false, true, sideband(mode), q.stream)) return fail();
+        q.rx_sideband_epi = sideband(mode); q.rx_direct_out = direct_out;
+        if (q.rxf->init(device, nch, Qrx::kRxPart, 1, 1, QH_F64, false, true, sideband(mode), q.stream)) return fail();
         if (q.rxf->set_taps(-1, std::vector<cd>(1, q.rx_identity()))) return fail();
         if (sideband(mode) && !is_iq(mode)) notch_after_rxf = true;     // quisk.c:1923,1946,1968,1992,2106,2133 (not DGT-IQ)
         if (sideband(mode))
@@ -466,8 +561,8 @@ int qh_qrx_set_filters(qh_qrx *h, int ch, const double *filtI, const double *fil
     if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
     Qrx &q = h->q;
     if (ch < -1 || ch >= q.nch) return set_error(QH_ERR_INVALID, "channel out of range");
-    if (size < 0 || size > 2048 || (size > 0 && (!filtI || !filtQ)))
-        return set_error(QH_ERR_UNSUPPORTED, "Rx filter size must be 0..2048 (got %d)", size);
+    if (size < 0 || size > Qrx::kRxMaxTaps || (size > 0 && (!filtI || !filtQ)))
+        return set_error(QH_ERR_INVALID, "Filter size must be less than 10001 (MAX_FILTER_SIZE, quisk.c:4575; got %d)", size);
     const bool bypass = is_iq(q.mode) && q.bandwidth >= 19000;        // "No filtering for wide bandwidth", quisk.c:2143
     if (bypass) size = 0;
     std::vector<cd> g((size_t)(size > 0 ? size : 1), q.rx_identity());
@@ -478,8 +573,14 @@ int qh_qrx_set_filters(qh_qrx *h, int ch, const double *filtI, const double *fil
         else g[(size_t)d] = lower(q.mode) ? cd(gi, -gq) : cd(gi, gq);   // re + im : re - im
     }
     if (q.rx_size.empty()) { q.rx_size.assign((size_t)q.nch, 0); q.rx_index.assign((size_t)q.nch, 0); q.rx_ring.resize((size_t)q.nch); }
+    if (int rc = q.rx_ensure_parts(size)) return rc;
     for (int c = ch < 0 ? 0 : ch; c < (ch < 0 ? q.nch : ch + 1); c++) {
-        if (int rc = q.rxf->set_taps(c, g)) return rc;
+        for (size_t k = 0; k <= q.rxf_more.size(); k++) {           // partition k: taps [kRxPart k, kRxPart (k + 1))
+            Stage *p = k == 0 ? q.rxf : q.rxf_more[k - 1];
+            const size_t lo = k * (size_t)Qrx::kRxPart, hi = lo + (size_t)Qrx::kRxPart < g.size() ? lo + (size_t)Qrx::kRxPart : g.size();
+            std::vector<cd> part = lo < g.size() ? std::vector<cd>(g.begin() + (long)lo, g.begin() + (long)hi) : std::vector<cd>(1, cd(0.0, 0.0));
+            if (int rc = p->set_taps(c, part)) return rc;
+        }
         if (size != q.rx_size[(size_t)c]) if (int rc = q.rx_resize(c, size)) return rc;
     }
     return QH_OK;
@@ -541,6 +642,32 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
         int m = 0;
         switch (s.kind) {
         case Step::FIR:
+            if (s.st == q.rxf && !q.rxf_more.empty() && n > 0) {
+                // [delay line | block]; partition k filters the block as it was kRxPart k samples ago, the outputs add up
+                const int D = q.rx_D();
+                const long long xs = (long long)D + n;
+                if ((long long)q.nch * xs > q.rx_x_cap) {
+                    QH_HIP(hipStreamSynchronize(q.stream));
+                    (void)hipFree(q.rx_x); (void)hipFree(q.rx_tmp); q.rx_x = q.rx_tmp = nullptr;
+                    q.rx_x_cap = (long long)q.nch * xs * 5 / 4;
+                    QH_HIP(hipMalloc((void **)&q.rx_x, (size_t)q.rx_x_cap * 16));
+                    QH_HIP(hipMalloc((void **)&q.rx_tmp, (size_t)q.rx_x_cap * 16));
+                }
+                const unsigned gx = (unsigned)((xs + 255) / 256 < 512 ? (xs + 255) / 256 : 512);
+                hipLaunchKernelGGL(rxp_gather_kernel, dim3(gx, (unsigned)q.nch), dim3(256), 0, q.stream, (const double2 *)q.rx_dly[q.rx_dly_cur], D,
+                                   static_cast<const double2 *>(cur), cur_stride, n, q.rx_x, xs);
+                if (int rc = q.rxf->process(q.rx_x + D, xs, n, dst, dst_stride, &m)) return rc;
+                for (size_t k = 0; k < q.rxf_more.size(); k++) {
+                    int mk = 0;
+                    if (int rc = q.rxf_more[k]->process(q.rx_x + D - (long long)(k + 1) * Qrx::kRxPart, xs, n, q.rx_tmp, (long long)n, &mk)) return rc;
+                    hipLaunchKernelGGL(rxp_add_kernel, dim3(gx, (unsigned)q.nch), dim3(256), 0, q.stream, static_cast<double2 *>(dst), dst_stride,
+                                       (const double2 *)q.rx_tmp, (long long)n, n);
+                }
+                hipLaunchKernelGGL(rxp_keep_kernel, dim3(gx, (unsigned)q.nch), dim3(256), 0, q.stream, (const double2 *)q.rx_x, xs, D, n, q.rx_dly[q.rx_dly_cur ^ 1]);
+                q.rx_dly_cur ^= 1;
+                q.rx_advance(n);
+                break;
+            }
             if (int rc = s.st->process(cur, cur_stride, n, dst, dst_stride, &m)) return rc;
             if (s.st == q.rxf) q.rx_advance(n);
             break;

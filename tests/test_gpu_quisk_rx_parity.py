@@ -315,3 +315,50 @@ def test_paired_audio_stages_keep_the_receivers_apart(qh, mode, squelch):
         assert np.abs(want).max() > 0
         assert np.array_equal(y[c].real, y[c].imag) and np.array_equal(want.real, want.imag)        # d + I d, quisk.c:2625
         assert rel_rms(y[c], want) < 1e-12, (c, rel_rms(y[c], want))
+
+
+def _long_filter(ntaps, rate, seed):
+    """A band-pass pair of `ntaps` taps (Hilbert pair like MakeFilterCoef's, windowed sinc), unsymmetric on purpose: the tap order matters"""
+    rng = np.random.default_rng(seed)
+    k = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = np.sinc(k * 2 * 1350.0 / rate) * 2 * 1350.0 / rate * np.blackman(ntaps) * (1.0 + 0.05 * rng.standard_normal(ntaps))
+    c = np.exp(2j * np.pi * 1650.0 / rate * k)
+    return 2 * (h * c).real, 2 * (h * c).imag
+
+
+@pytest.mark.parametrize("sizes", [[4001], [10000], [2048, 2049, 6000, 700, 9999, 4097]], ids=["4001", "10000", "sizes-changed-mid-stream"])
+def test_rx_filters_up_to_max_filter_size(qh, oracle, sizes):
+    """set_filters takes up to 10000 taps (MAX_FILTER_SIZE 10001, quisk.h:10, quisk.c:4575).  Beyond 2048 the bank runs the filter as
+    partitions of 2048 taps on delayed copies of the stream; a change of sizeFilter in mid-stream re-reads the ring as the reference's
+    cRxFilterOut would (quisk.c:1218-1256: its ring of sizeFilter entries over one static buffer)."""
+    fs, mode, nch = 48000, 3, 2
+    tabs = rxfilter.coefficient_tables()
+    bank = qh.QuiskRxBank(nch, fs, mode)
+    frate = bank.get_filter_rate()
+    refs = []
+    for c in range(nch):
+        r = oracle.OracleQuiskRx(fs, tabs)
+        r.set_mode(mode); r.set_tune(3000 + 500 * c)
+        bank.set_tune(c, 3000 + 500 * c)
+        refs.append(r)
+    per = 30000
+    n = per * len(sizes)
+    x = np.stack([signal(mode, c, n, fs, 3000.0 + 500 * c) for c in range(nch)])
+    outs, wants = [], [[] for _ in range(nch)]
+    for k, size in enumerate(sizes):
+        for c in range(nch):
+            fI, fQ = _long_filter(size, frate, 100 * k + c)
+            bank.set_filters(c, fI, fQ)
+            refs[c].set_filters(fI, fQ)
+        cuts = [k * per, k * per + 777, k * per + 12001, (k + 1) * per]
+        for a, b in zip(cuts, cuts[1:]):
+            outs.append(bank.process_host(x[:, a:b]))
+            for c in range(nch):
+                wants[c].append(refs[c].process(x[c, a:b]))
+    y = np.concatenate(outs, axis=1)
+    for c in range(nch):
+        want = np.concatenate(wants[c])
+        assert y.shape[1] == want.size and np.abs(want).max() > 2.0 ** 10
+        assert rel_rms(y[c], want) < 1e-9, (c, rel_rms(y[c], want))
+    with pytest.raises(qh.QuiskHipError):
+        bank.set_filters(0, np.zeros(10001), np.zeros(10001))
