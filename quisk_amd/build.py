@@ -52,16 +52,31 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "hip"]
     extra = ["-D" + d for d in defines] + os.environ.get("QH_HIPCC_FLAGS", "").split()
     os.makedirs(os.path.dirname(target), exist_ok=True)
-    if out or extra:
+    if out:
         cmd = base + ["-shared", "-o", target] + extra + [os.path.join(CSRC, f) for f in SOURCES]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
         return target
+    objdir = os.path.join(LIBDIR, "obj")
+    # what the objects were compiled with: another compiler, ROCm release or flag set makes all of them stale
+    stamp_file = os.path.join(objdir, "build.stamp")
+    try:
+        ver = subprocess.run([base[0], "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        ver = ""
+    import hashlib
+    stamp = hashlib.sha256(("\n".join(base[1:] + extra) + "\n" + ver).encode()).hexdigest()
+    try:
+        same_stamp = open(stamp_file).read().strip() == stamp
+    except OSError:
+        same_stamp = not os.path.isdir(objdir)       # a library that travelled without its objects: trusted as before
+    if not same_stamp:
+        force = True
     if not force and not needs_build():          # the library that travelled with the snapshot is current: nothing to do
         return LIB
-    objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
+    base = base + extra
     todo, objs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
@@ -102,6 +117,8 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp + "\n")
     return LIB
 
 

@@ -140,7 +140,7 @@ def config4(torch, qh, dev):
             "note": "AM / FM / notch recurrences time-tiled (qh_tiled.hpp); pll_tiles_rerun = FM tiles the verify pass re-ran sequentially over all steps"}
 
 
-def setup_config2_agc(torch, qh, dev, nch=256, nblk=None):
+def setup_config2_agc(torch, qh, dev, nch=256, nblk=None, fading=False):
     """BASELINE config 2's chain with WDSP's AGC state machine running (SetRXAAGCMode 3, the mode Quisk's WDSP path sets by default)
     instead of the fixed gain the configuration specifies: the level detector in time tiles (qh_agc_tiled.hpp)."""
     from quisk_amd import synth
@@ -150,6 +150,15 @@ def setup_config2_agc(torch, qh, dev, nch=256, nblk=None):
     # the same buffer is fed every step: the tones sit on the buffer's frequency grid (moved by < 0.023 Hz), so that the steps are one
     # continuous stream -- a phase jump per call is a click the AGC answers for seconds, which no receiver's input has
     L.x = synth.make_mode_input_torch(["usb"] * nch, n_in, dev, periodic=True)
+    if fading:
+        # deep, fast fades (a flutter of 7 .. 13 Hz per channel down to -40 dB, periodic in the buffer): the level detector's runs of
+        # constant ring_max break up, which is where the tiled AGC falls back to walking a segment in order (agc_bounds_fix_kernel)
+        t = torch.arange(n_in, dtype=torch.float64, device=dev)
+        for c in range(nch):
+            cyc = round((7.0 + (c % 7)) * n_in / 192000.0)
+            env = 0.505 + 0.495 * torch.cos(t * (2.0 * np.pi * cyc / n_in))
+            L.x[c] *= env
+        del t
     L.y = torch.empty((nch, L.n_out), dtype=torch.complex128, device=dev)
     L.stream = new_stream(torch, dev)
     L.eng = e = qh.RxaEngine(nch, stream=L.stream.cuda_stream)
@@ -171,9 +180,18 @@ def config2_agc(torch, qh, dev):
     sync = lambda: torch.cuda.synchronize(dev)
     t = timed(L.step, sync, steps=4, warmup=2)
     tot = L.nch * L.n_in
-    return {"config": "2 with the AGC state machine on (SetRXAAGCMode 3): 256 ch x 192 k SSB RXA, fp64, 2^%d samples per channel and step" % (L.n_in.bit_length() - 1),
-            "samples_per_step": tot, "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "agc_tiles_rerun": e.agc_repairs(),
-            "agc_segments_rerun": e.agc_segments_rerun(),
+    n_log2 = L.n_in.bit_length() - 1
+    tiles, segs = e.agc_repairs(), e.agc_segments_rerun()
+    del L, e
+    torch.cuda.empty_cache()
+    # the same leg on an input full of fades
+    Lf = setup_config2_agc(torch, qh, dev, fading=True)
+    tf = timed(Lf.step, sync, steps=4, warmup=2)
+    fading = {"ms": tf * 1e3, "Msamp_per_s": tot / tf / 1e6, "agc_tiles_rerun": Lf.eng.agc_repairs(), "agc_segments_rerun": Lf.eng.agc_segments_rerun(),
+              "input": "the same tones under a 7 .. 13 Hz flutter down to -40 dB"}
+    return {"config": "2 with the AGC state machine on (SetRXAAGCMode 3): 256 ch x 192 k SSB RXA, fp64, 2^%d samples per channel and step" % (n_log2),
+            "samples_per_step": tot, "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "agc_tiles_rerun": tiles,
+            "agc_segments_rerun": segs, "fading_input": fading,
             "note": "not a BASELINE configuration (config 2 fixes the gain); agc_tiles_rerun = tiles whose boundary state the exact pass corrected"}
 
 
