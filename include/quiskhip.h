@@ -609,6 +609,11 @@ int qh_ana_get_pixels(qh_ana *a, int disp, int pixout, float *pix, int *flag);
 /* every row of the last feed call, [ndisp][frames][num_pixels] floats: device pointer / host copy */
 int qh_ana_rows(qh_ana *a, int pixout, const float **d_rows, int *frames, int *num_pixels);
 int qh_ana_rows_host(qh_ana *a, int pixout, float *out, int max_frames, int *frames);
+/* SnapSpectrum (analyzer.c:1337-1367): the complex transform of the next frame of (display, sub-span), 2 * size doubles, fft-shifted
+ * (bins size/2 .. size-1, then 0 .. size/2-1, analyzer.c:710-711).  arm, feed, take; or arm and wait while another thread feeds. */
+int qh_ana_snap_arm(qh_ana *a, int disp, int ss);
+int qh_ana_snap_take(qh_ana *a, double *snap_buff, int *flag);
+int qh_ana_snap_wait(qh_ana *a, double *snap_buff, int timeout_ms, int *flag);
 void *qh_ana_stream(qh_ana *a);
 long long qh_ana_frames(qh_ana *a);
 int qh_ana_buff_size(qh_ana *a);
@@ -625,6 +630,8 @@ void Spectrum(int disp, int ss, int LO, float *pI, float *pQ);
 void OpenBuffer(int disp, int ss, int LO, void **Ipointer, void **Qpointer);
 void CloseBuffer(int disp, int ss, int LO);
 void GetPixels(int disp, int pixout, float *pix, int *flag);
+void SnapSpectrum(int disp, int ss, int LO, double *snap_buff);
+void SnapSpectrumTimeout(int disp, int ss, int LO, double *snap_buff, unsigned int timeout, int *flag);
 void ResetPixelBuffers(int disp);
 void SetDisplayDetectorMode(int disp, int pixout, int mode);
 void SetDisplayAverageMode(int disp, int pixout, int mode);

@@ -37,6 +37,7 @@ struct ao_disp {
     double *result[AO_MAX_STITCH];
     int ss_bins[AO_MAX_STITCH];
     double *fft;                                            /* interleaved work vector */
+    double *snap_buff; int snap_ss, snap_taken;             /* SnapSpectrum, analyzer.c:1337-1346 */
     double *pre_av_out;
     int det_type[AO_MAX_PIXOUTS], av_mode[AO_MAX_PIXOUTS], num_average[AO_MAX_PIXOUTS], normalize[AO_MAX_PIXOUTS];
     int avail_frames[AO_MAX_PIXOUTS], av_in_idx[AO_MAX_PIXOUTS], av_out_idx[AO_MAX_PIXOUTS];
@@ -444,6 +445,14 @@ static void ao_frame(ao_disp *a, int ss, int idx)
             if (++idx >= a->bsize) idx -= a->bsize;
         }
         fo_fft(a->fft, a->size, -1);
+    }
+    if (a->snap_buff && a->snap_ss == ss) {                     /* Cspectra, analyzer.c:708-713: the second half of fft_out first */
+        memcpy(a->snap_buff, a->fft + a->size, (size_t)a->size * sizeof(double));
+        memcpy(a->snap_buff + a->size, a->fft, (size_t)a->size * sizeof(double));
+        a->snap_buff = NULL;
+        a->snap_taken = 1;
+    }
+    if (ss >= a->begin_ss && ss <= a->end_ss) {
         ao_eliminate(a, ss);
     }
     a->stitch_flag |= 1u << ss;
@@ -514,6 +523,10 @@ int ao_get_pixels(ao_disp *a, int pixout, float *pix)
 }
 
 /* ResetPixelBuffers, analyzer.c:927-996.  (Mode 2 keeps av_sum: its case only has a comment, the sum is not cleared.) */
+/* SnapSpectrum, analyzer.c:1337-1346, without the wait: the next frame of sub-span ss is copied to buf (2 * size doubles) */
+void ao_snap(ao_disp *a, int ss, double *buf) { a->snap_buff = buf; a->snap_ss = ss; a->snap_taken = 0; }
+int ao_snap_taken(const ao_disp *a) { return a->snap_taken; }
+
 void ao_reset_pixel_buffers(ao_disp *a)
 {
     int i, j, k;

@@ -42,6 +42,10 @@ void ao_window(int type, int size, double PiAlpha, double *w, double *inv_cohere
 void ao_detector(int det_type, int m, int num_pixels, double pix_per_bin, double bin_per_pix, const double *bins, double *pixels,
                  double inv_enb, double fsclipL, double fsclipH, double det_offset);
 
+/* SnapSpectrum (analyzer.c:1337-1346) without the wait: the next frame of sub-span ss goes to buf (2 * size doubles, fft-shifted) */
+void ao_snap(ao_disp *a, int ss, double *buf);
+int ao_snap_taken(const ao_disp *a);
+
 #ifdef __cplusplus
 }
 #endif

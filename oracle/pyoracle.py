@@ -862,6 +862,19 @@ class OracleAnalyzer:
         flag = self.L.ao_get_pixels(self.h, pixout, pix.ctypes.data)
         return pix, flag
 
+    def SnapSpectrum(self, ss):
+        """Arms the snap (analyzer.c:1337-1346); the returned array (2 * size doubles) is filled by the next frame of sub-span ss."""
+        buf = np.zeros(2 * self.size, dtype=np.float64)
+        self.L.ao_snap.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.L.ao_snap.restype = None
+        self.L.ao_snap(self.h, int(ss), buf.ctypes.data)
+        self._snap = buf
+        return buf
+
+    def snap_taken(self):
+        self.L.ao_snap_taken.argtypes = [C.c_void_p]
+        return self.L.ao_snap_taken(self.h)
+
     def ResetPixelBuffers(self):
         self.L.ao_reset_pixel_buffers.argtypes = [C.c_void_p]
         self.L.ao_reset_pixel_buffers(self.h)

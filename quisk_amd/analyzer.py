@@ -45,6 +45,18 @@ class AnalyzerBank:
     def GetDisplayENB(self): return self._L.qh_ana_get_enb(self._h)
     def ResetPixelBuffers(self): _check(self._L, self._L.qh_ana_reset_pixel_buffers(self._h))
 
+    def SnapSpectrum_arm(self, disp, ss):
+        """SnapSpectrum (analyzer.c:1337) in two steps: ask for the next frame's transform of (display, sub-span) ..."""
+        _check(self._L, self._L.qh_ana_snap_arm(self._h, int(disp), int(ss)))
+
+    def SnapSpectrum_take(self, size):
+        """... and take it once a feed call has made that frame: `size` complex values, fft-shifted, or None."""
+        buf = np.zeros(2 * size, dtype=np.float64)
+        flag = C.c_int(0)
+        self._L.qh_ana_snap_take.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        _check(self._L, self._L.qh_ana_snap_take(self._h, buf.ctypes.data, C.byref(flag)))
+        return buf.view(np.complex128) if flag.value else None
+
     def feed_ptr(self, ss, d_iq, disp_stride, n):
         """n complex128 samples per display on the device; returns the number of pixel rows the call published."""
         frames = C.c_int(0)

@@ -18,6 +18,8 @@
 // The sample streams stay on the device (float pairs, as the reference's dINREAL rings outside Thetis, comm.h:128-132).
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -58,6 +60,9 @@ struct AnaFftArgs {
     const double2 *tw;
     double *pw;                         // [ndisp][nframes][nss][N]
     int nss, ss0, N, R, real_input, nframes;
+    // SnapSpectrum (analyzer.c:708-713,1337-1346): the transform itself of one (display, sub-span), first frame of the call, natural bin order
+    double2 *snap;
+    int snap_disp, snap_ss;
 };
 
 template <int M> __global__ __launch_bounds__(NT) void ana_fft_kernel(AnaFftArgs a)
@@ -100,6 +105,10 @@ template <int M> __global__ __launch_bounds__(NT) void ana_fft_kernel(AnaFftArgs
     for (int j = 0; j < E; j++) {
         const int k = t + NT * j;
         out[(long long)a.R * k + r] = acc[j].x * acc[j].x + acc[j].y * acc[j].y;           // analyzer.c:200,243
+    }
+    if (a.snap && f == 0 && d == a.snap_disp && a.ss0 + s == a.snap_ss) {                  // workgroup-uniform
+#pragma unroll
+        for (int j = 0; j < E; j++) a.snap[(long long)a.R * (t + NT * j) + r] = acc[j];
     }
 }
 
@@ -302,6 +311,13 @@ struct DetTables {              // one per detector type in use
 
 struct qh_ana {
     std::recursive_mutex mu;
+    // SnapSpectrum: one request at a time -- armed for (display, sub-span), filled by the next frame of that pair
+    std::mutex snap_mu;
+    std::condition_variable snap_cv;
+    bool snap_armed = false, snap_done = false;
+    int snap_disp = 0, snap_ss = 0;
+    DevVec<double2> d_snap;
+    std::vector<double> snap_host;      // the transform, fft-shifted as analyzer.c:710-711 copies it: bins N/2 .. N-1, then 0 .. N/2-1
     int device = 0, ndisp = 0, max_size = 0, max_stitch = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false, configured = false;
@@ -559,6 +575,11 @@ int run_pending(qh_ana &a)
     for (int s = 0; s < kMaxStitch; s++) { fa.sbuf[s] = a.sbuf[s][a.cur[s]].p; fa.stride[s] = a.stride[s][a.cur[s]]; }
     fa.starts = a.d_starts.p; fa.window = a.d_window.p; fa.tw = a.d_tw.p; fa.pw = a.d_pw.p;
     fa.nss = nss; fa.ss0 = a.begin_ss; fa.N = a.size; fa.R = a.R; fa.real_input = a.type == 0; fa.nframes = nframes;
+    const bool snapping = a.snap_armed && a.snap_ss >= a.begin_ss && a.snap_ss <= a.end_ss;
+    if (snapping) {
+        QH_HIP(a.d_snap.ensure((size_t)a.size));
+        fa.snap = a.d_snap.p; fa.snap_disp = a.snap_disp; fa.snap_ss = a.snap_ss;
+    }
     int rc;
     switch (a.M) {
     case 512: rc = launch_fft<512>(a, fa, nframes, nss); break;
@@ -568,6 +589,20 @@ int run_pending(qh_ana &a)
     default: rc = launch_fft<8192>(a, fa, nframes, nss); break;
     }
     if (rc) return rc;
+    if (snapping) {
+        std::vector<double> x((size_t)a.size * 2);
+        QH_HIP(hipMemcpyAsync(x.data(), a.d_snap.p, (size_t)a.size * 16, hipMemcpyDeviceToHost, a.stream));
+        QH_HIP(hipStreamSynchronize(a.stream));
+        {
+            std::lock_guard<std::mutex> sl(a.snap_mu);
+            a.snap_host.resize((size_t)a.size * 2);
+            const size_t half = (size_t)a.size;              // doubles in half of the transform (size complex values = 2 size doubles)
+            std::copy(x.begin() + (long)half, x.end(), a.snap_host.begin());
+            std::copy(x.begin(), x.begin() + (long)half, a.snap_host.begin() + (long)half);
+            a.snap_armed = false; a.snap_done = true;
+        }
+        a.snap_cv.notify_all();
+    }
     const bool interp = !(a.pix_per_bin <= 1.0);
     for (int s = 0; s < kMaxPixouts && a.dets[s].det >= 0; s++) {
         DetTables &t = a.dets[s];
@@ -943,6 +978,44 @@ int qh_ana_feed_host(qh_ana *h, int ss, const double *h_iq, long long disp_strid
     return QH_OK;
 }
 
+// SnapSpectrum, analyzer.c:1337-1367: the next frame's transform of (display, sub-span) -- size complex values, fft-shifted (the second
+// half of fft_out first, analyzer.c:710-711).  qh_ana_snap_arm asks for it, the feed call that completes that frame takes it,
+// qh_ana_snap_take hands it over (*flag = 0: not there yet); qh_ana_snap_wait blocks like the reference (another thread feeds),
+// timeout_ms < 0 = for ever.
+int qh_ana_snap_arm(qh_ana *h, int disp, int ss)
+{
+    if (int e = check_config(h, "SnapSpectrum")) return e;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    if (disp < 0 || disp >= h->ndisp || ss < 0 || ss >= h->num_stitch) return set_error(QH_ERR_INVALID, "SnapSpectrum: bad display or sub-span");
+    if (ss < h->begin_ss || ss > h->end_ss) return set_error(QH_ERR_UNSUPPORTED, "SnapSpectrum: sub-span %d is outside the displayed range, no transform is made of it", ss);
+    std::lock_guard<std::mutex> sl(h->snap_mu);
+    h->snap_armed = true; h->snap_done = false; h->snap_disp = disp; h->snap_ss = ss;
+    return QH_OK;
+}
+int qh_ana_snap_take(qh_ana *h, double *snap_buff, int *flag)
+{
+    if (!h || !snap_buff || !flag) return set_error(QH_ERR_INVALID, "qh_ana_snap_take: bad arguments");
+    std::lock_guard<std::mutex> sl(h->snap_mu);
+    *flag = 0;
+    if (!h->snap_done) return QH_OK;
+    std::copy(h->snap_host.begin(), h->snap_host.end(), snap_buff);
+    h->snap_done = false;
+    *flag = 1;
+    return QH_OK;
+}
+int qh_ana_snap_wait(qh_ana *h, double *snap_buff, int timeout_ms, int *flag)
+{
+    if (!h || !snap_buff) return set_error(QH_ERR_INVALID, "qh_ana_snap_wait: bad arguments");
+    std::unique_lock<std::mutex> sl(h->snap_mu);
+    bool ok = true;
+    if (timeout_ms < 0) h->snap_cv.wait(sl, [&] { return h->snap_done; });
+    else ok = h->snap_cv.wait_for(sl, std::chrono::milliseconds(timeout_ms), [&] { return h->snap_done; });
+    if (ok) { std::copy(h->snap_host.begin(), h->snap_host.end(), snap_buff); h->snap_done = false; }
+    else h->snap_armed = false;                              // SnapSpectrumTimeout resets the request (analyzer.c:1364)
+    if (flag) *flag = ok ? 1 : 0;
+    return QH_OK;
+}
+
 // GetPixels, analyzer.c:1315-1334: the newest row of one display if it has not been read yet
 int qh_ana_get_pixels(qh_ana *h, int disp, int pixout, float *pix, int *flag)
 {
@@ -1088,6 +1161,20 @@ void GetPixels(int disp, int pixout, float *pix, int *flag)                    /
 {
     if (flag) *flag = 0;
     if (qh_ana *h = disp_of(disp, "GetPixels")) (void)qh_ana_get_pixels(h, 0, pixout, pix, flag);
+}
+
+void SnapSpectrum(int disp, int ss, int LO, double *snap_buff)                 // analyzer.c:1337: blocks until the next frame (fed by another thread)
+{
+    (void)LO;
+    qh_ana *h = disp_of(disp, "SnapSpectrum");
+    if (h && snap_buff && qh_ana_snap_arm(h, 0, ss) == QH_OK) (void)qh_ana_snap_wait(h, snap_buff, -1, nullptr);
+}
+void SnapSpectrumTimeout(int disp, int ss, int LO, double *snap_buff, unsigned int timeout, int *flag)     // analyzer.c:1349
+{
+    (void)LO;
+    if (flag) *flag = 0;
+    qh_ana *h = disp_of(disp, "SnapSpectrumTimeout");
+    if (h && snap_buff && qh_ana_snap_arm(h, 0, ss) == QH_OK) (void)qh_ana_snap_wait(h, snap_buff, (int)timeout, flag);
 }
 
 void ResetPixelBuffers(int disp) { if (qh_ana *h = disp_of(disp, "ResetPixelBuffers")) (void)qh_ana_reset_pixel_buffers(h); }

@@ -272,6 +272,7 @@ def load():
     L.qh_quisk_sub_rx1_audio.argtypes = [vp, i]
     L.qh_quisk_squelch_flags.argtypes = []
     L.qh_quisk_get_graph.argtypes = [C.c_double, C.c_double, vp, vp]
+    L.qh_ana_snap_arm.argtypes = [vp, i, i]
     L.qh_qps_create.restype = vp
     L.qh_qps_create.argtypes = [i, i, i, i, i, i, vp, i, i, vp]
     L.qh_qps_destroy.argtypes = [vp]

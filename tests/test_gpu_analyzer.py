@@ -257,3 +257,82 @@ def test_writeahead_skip_reset_and_reconfiguration(qh, oracle):
         assert len(rows) == 5 + 3
     finally:
         g.close()
+
+
+def test_snap_spectrum_hands_out_the_next_frames_transform(qh, oracle):
+    """SnapSpectrum (analyzer.c:1337-1346, served in Cspectra :708-713): the complex transform of the NEXT frame of (display, sub-span),
+    fft-shifted -- armed, then taken after the feed call that made the frame; nothing while no frame has been made; through the
+    WDSP-named entry points with a feeding thread (the call blocks like the reference's) and with its time-out."""
+    import ctypes as C
+    import threading
+    size, bf, npix, ndisp = 4096, 1024, 600, 3
+    cfg = _cfg(size, bf, size // 2, npix, stitch=2)
+    xs = np.stack([np.stack([_signal(6 * size, 40 + 5 * d + s) for s in range(2)]) for d in range(ndisp)])      # [disp][ss][n]
+    g = qh.AnalyzerBank(ndisp, size, 2)
+    g.SetDisplaySampleRate(RATE)
+    g.SetAnalyzer(*cfg["args"])
+    a = oracle.OracleAnalyzer(size, 2)
+    a.SetDisplaySampleRate(RATE)
+    a.SetAnalyzer(*cfg["args"])
+    d, ss = 1, 1
+
+    def feed_both(b0, b1):
+        for b in range(b0, b1):
+            for s in range(2):
+                g.feed_host(s, np.ascontiguousarray(xs[:, s, b * bf:(b + 1) * bf]))
+                blk = xs[d, s, b * bf:(b + 1) * bf]
+                buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+                a.Spectrum0(1, s, 0, buf)
+    feed_both(0, 5)                                       # frames have been made; nothing was asked for
+    assert g.SnapSpectrum_take(size) is None
+    g.SnapSpectrum_arm(d, ss)
+    want = a.SnapSpectrum(ss)
+    assert g.SnapSpectrum_take(size) is None              # armed, no new frame yet
+    feed_both(5, 9)
+    got = g.SnapSpectrum_take(size)
+    assert got is not None and a.snap_taken() == 1
+    w = want.view(np.complex128)
+    assert np.abs(w).max() > 1.0
+    assert np.abs(got - w).max() < 1e-11 * np.abs(w).max()
+    assert g.SnapSpectrum_take(size) is None              # handed out once
+    with pytest.raises(qh.QuiskHipError):
+        g.SnapSpectrum_arm(ndisp, 0)
+    # the WDSP-named calls: one display per id, SnapSpectrum blocks until another thread's Spectrum0 completes a frame
+    lib = qh.load()
+    ok = C.c_int(0)
+    lib.XCreateAnalyzer(7, C.byref(ok), size, 1, 1, None)
+    assert ok.value == 0
+    flp = (C.c_int * 1)(0)
+    lib.SetAnalyzer.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] + [C.c_int] * 3 + [C.c_double] + [C.c_int] * 2 + [C.c_double] * 2 + [C.c_int] * 3 + [C.c_double] * 2 + [C.c_int]
+    lib.SetAnalyzer(7, 1, 1, 1, flp, size, bf, 2, 0.0, size // 2, 0, 0.0, 0.0, npix, 1, 0, 0.0, 0.0, 2 * size)
+    lib.Spectrum0.argtypes = [C.c_int] * 4 + [C.c_void_p]
+    lib.SnapSpectrum.argtypes = [C.c_int] * 3 + [C.c_void_p]
+    lib.SnapSpectrumTimeout.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
+    snap = np.zeros(2 * size)
+    flag = C.c_int(5)
+    lib.SnapSpectrumTimeout(7, 0, 0, snap.ctypes.data, 50, C.byref(flag))
+    assert flag.value == 0                                # nobody feeds: the time-out, and the request is withdrawn
+    a1 = oracle.OracleAnalyzer(size, 1)
+    a1.SetDisplaySampleRate(RATE)
+    a1.SetAnalyzer(1, 1, 1, [0], size, bf, 2, 0.0, size // 2, 0, 0.0, 0.0, npix, 1, 0, 0.0, 0.0, 2 * size)
+    want1 = a1.SnapSpectrum(0)
+    x1 = xs[0, 0]
+
+    def feeder():
+        import time
+        time.sleep(0.2)                                   # SnapSpectrum is waiting by now (if not, the snap is armed at the latest by then)
+        for b in range(6):
+            blk = x1[b * bf:(b + 1) * bf]
+            buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+            lib.Spectrum0(1, 7, 0, 0, buf.ctypes.data)
+    th = threading.Thread(target=feeder)
+    th.start()
+    lib.SnapSpectrum(7, 0, 0, snap.ctypes.data)          # returns with the first frame the feeder completes
+    th.join()
+    for b in range(6):
+        blk = x1[b * bf:(b + 1) * bf]
+        buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+        a1.Spectrum0(1, 0, 0, buf)
+    w1 = want1.view(np.complex128)
+    assert a1.snap_taken() == 1 and np.abs(snap.view(np.complex128) - w1).max() < 1e-11 * np.abs(w1).max()
+    lib.DestroyAnalyzer(7)
