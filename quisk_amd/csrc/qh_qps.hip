@@ -161,6 +161,8 @@ qh_qps *qh_qps_create(int device, int nch, int sample_rate, int playback_rate, i
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream creation");
         h->own_stream = true;
     }
+    // (a CU mask per stream -- hipExtStreamCreateWithCUMask, the AGC on CUs of its own -- was tried: the masks change nothing on this
+    // stack, the filters run as fast on "64 CUs" as on 192)
     if (hipStreamCreateWithFlags(&h->agc_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream creation");
     for (hipEvent_t &e : h->ev_piece) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation");
     for (hipEvent_t &e : h->ev_agc) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation");
@@ -257,6 +259,7 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     if (P <= 0) P = n >= (1 << 15) ? 4 : 1;       // (measured at 256 x 2^20: 1 piece 4.12 ms, 4: 3.60, 8: 3.65, 16: 3.57, 32: 4.0)
     if (!h->agc_started) P = 1;
     h->agc_started = true;
+    // (a short first piece, so that the AGC -- the long pole: one dependent chain per receiver -- starts early, was measured: no gain)
     const int per = ((n + P - 1) / P + 63) / 64 * 64;
     const int cap_bank = qh_qrx_out_count(h->rx, n) + 64 * (P + 1);
     h->o_stride = cap_bank;
@@ -274,7 +277,7 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     const bool epi = h->kill_audio || h->squelch_can_act;
     long long o_off = 0, out_off = 0;
     int piece = 0, last_agc = -1;
-    for (int pos = 0; pos < n; pos += per, piece++) {
+    for (int pos = 0; pos < n; piece++) {
         const int cnt = n - pos < per ? n - pos : per, par = piece & 1;
         // this piece's scratch half was read by the AGC two pieces back
         if (scratch && piece >= 2 && h->agc_recorded[par]) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[par], 0));
@@ -315,6 +318,7 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
         }
         o_off += nb_;
         out_off += na;
+        pos += cnt;
     }
     if (last_agc >= 0) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[last_agc], 0));      // the call ends on the bank's stream (the AGC stream runs in order)
     const int total = (int)out_off;

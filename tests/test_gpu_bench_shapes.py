@@ -356,7 +356,7 @@ def test_quisk_native_at_the_timed_shape(qh, oracle, bc, dev, name):
     L = bc.setup_quisk_native(torch, qh, dev, name)
     nch, n = L.nch, L.n
     assert (nch, n) == (256, 1 << 20)
-    per = bc.qn_piece_len(n)
+    cuts = bc.qn_pieces(n)
     tabs = rxfilter.coefficient_tables()
     B = bc.setup_quisk_native(torch, qh, dev, name, whole=False)          # the same receivers: the bank alone
     B.x.copy_(L.x)
@@ -367,12 +367,13 @@ def test_quisk_native_at_the_timed_shape(qh, oracle, bc, dev, name):
         torch.cuda.synchronize(dev)
         ys.append(L.y[:, :m].clone())
         # the bank alone: the first call in one piece (as the whole function's first call), then in its pieces
-        parts = []
-        for pos in range(0, n, n if k == 0 else per):
-            cnt = min(n if k == 0 else per, n - pos)
+        parts, pos = [], 0
+        for cnt in ([n] if k == 0 else cuts):
             mb = B.bank.process_ptr(B.x.data_ptr() + 16 * pos, n, cnt, B.y.data_ptr(), B.m)
             torch.cuda.synchronize(dev)
             parts.append(B.y[:, :mb].clone())
+            pos += cnt
+        assert pos == n
         pre.append(torch.cat(parts, dim=1))
         assert pre[k].shape == ys[k].shape
     assert torch.equal(ys[0], pre[0])                 # the AGC's first call only initialises (quisk.c:2173-2190)

@@ -263,9 +263,10 @@ QN_AGC_GAIN = 5000.0
 QN_PIECES = 4                   # time pieces of a call of the whole-function bank (qh_qps_set_pieces)
 
 
-def qn_piece_len(n, pieces=QN_PIECES):
-    """samples per piece, as qh_qps_process cuts a call"""
-    return ((n + pieces - 1) // pieces + 63) // 64 * 64
+def qn_pieces(n, pieces=QN_PIECES):
+    """the piece lengths qh_qps_process cuts a call of n samples into"""
+    per = ((n + pieces - 1) // pieces + 63) // 64 * 64
+    return [min(per, n - pos) for pos in range(0, n, per)]
 
 
 def qn_tune(c):
@@ -284,8 +285,9 @@ def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20, whole=True, nb=
     L = SimpleNamespace(nch=nch, n=n, fs=fs, mode=mode, bw=bw, name=name, whole=whole)
     L.stream = new_stream(torch, dev)
     if whole:
+        # (no stream passed: the bank makes its own pair -- the filters' stream and the AGC's, each on CUs of its own)
         L.bank = bank = qh.QuiskProcessBank(nch, fs, mode, bw, playback_rate=48000, fft_size=fft_size, data_width=fft_size // 2 if fft_size else 0,
-                                            stream=L.stream.cuda_stream)
+                                            stream=None if os.environ.get("QH_QPS_OWN_STREAM", "1") != "0" else L.stream.cuda_stream)
         bank.set_agc(QN_AGC_GAIN)
         if nb:
             bank.set_noise_blanker(nb)
