@@ -59,22 +59,23 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
         subprocess.run(cmd, check=True)
         return target
     objdir = os.path.join(LIBDIR, "obj")
-    # what the objects were compiled with: another compiler, ROCm release or flag set makes all of them stale
     stamp_file = os.path.join(objdir, "build.stamp")
+    if not force and not needs_build():          # the library that travelled with the snapshot is current: nothing to do, nothing started
+        return LIB
+    # Something will be compiled: what were the objects that are kept compiled with?  Another compiler, ROCm release or flag set makes
+    # all of them stale.  (Asked only here -- a process that merely loads a current library must not start a compiler driver.)
+    import hashlib
     try:
         ver = subprocess.run([base[0], "--version"], capture_output=True, text=True).stdout
     except OSError:
         ver = ""
-    import hashlib
     stamp = hashlib.sha256(("\n".join(base[1:] + extra) + "\n" + ver).encode()).hexdigest()
     try:
-        same_stamp = open(stamp_file).read().strip() == stamp
+        if open(stamp_file).read().strip() != stamp:
+            force = True
     except OSError:
-        same_stamp = not os.path.isdir(objdir)       # a library that travelled without its objects: trusted as before
-    if not same_stamp:
-        force = True
-    if not force and not needs_build():          # the library that travelled with the snapshot is current: nothing to do
-        return LIB
+        if os.path.isdir(objdir):
+            force = True
     os.makedirs(objdir, exist_ok=True)
     base = base + extra
     todo, objs = [], []
