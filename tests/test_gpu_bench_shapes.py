@@ -230,11 +230,14 @@ def test_config4_mixed_modes_graph_replay_at_the_timed_shape(qh, oracle, bc, dev
 
 
 # ------------------------------------------------------------------------------------------------------------------ config 2, AGC on
-def test_config2_agc_on_at_the_timed_shape(qh, oracle, bc, dev):
+@pytest.mark.parametrize("fading", [False, True], ids=["steady", "overs"])
+def test_config2_agc_on_at_the_timed_shape(qh, oracle, bc, dev, fading):
     """256 ch x 2^22 per call with SetRXAAGCMode 3, two calls of the periodic buffer (one continuous stream): the AGC from its first
     sample (call 1) and in the steady state (call 2).  Eight channels against the oracle's xwcpagc over both calls; all 256 against
-    the stream in uneven pieces (the short ones take the sequential kernel)."""
-    L = bc.setup_config2_agc(torch, qh, dev)
+    the stream in uneven pieces (the short ones take the sequential kernel).  "overs": the leg's second input, keyed between full
+    level and -40 dB every few seconds -- after every drop the tiles' warm-ups miss and segments are walked again in order
+    (agc_bounds_fix_kernel): the path a steady input never takes."""
+    L = bc.setup_config2_agc(torch, qh, dev, fading=fading)
     nch, nblk, n_in, n_out = L.nch, L.nblk, L.n_in, L.n_out
     assert (nch, nblk) == (256, 4096)
     e = L.eng
@@ -244,7 +247,9 @@ def test_config2_agc_on_at_the_timed_shape(qh, oracle, bc, dev):
         e.process_ptr(L.x.data_ptr(), n_in, ys[k].data_ptr(), n_out, nblk)
     e.synchronize()
     torch.cuda.synchronize(dev)
-    print("config 2 AGC shape: agc_tiles_rerun %d, agc_segments_rerun %d" % (e.agc_repairs(), e.agc_segments_rerun()))
+    print("config 2 AGC shape (%s): agc_tiles_rerun %d, agc_segments_rerun %d" % ("overs" if fading else "steady", e.agc_repairs(), e.agc_segments_rerun()))
+    if fading:
+        assert e.agc_segments_rerun() > 0               # the fallback did run
     chans = spread(nch, 8)
     xs = {c: L.x[c].cpu().numpy() for c in chans}
 

@@ -151,12 +151,13 @@ def setup_config2_agc(torch, qh, dev, nch=256, nblk=None, fading=False):
     # continuous stream -- a phase jump per call is a click the AGC answers for seconds, which no receiver's input has
     L.x = synth.make_mode_input_torch(["usb"] * nch, n_in, dev, periodic=True)
     if fading:
-        # deep, fast fades (a flutter of 7 .. 13 Hz per channel down to -40 dB, periodic in the buffer): the level detector's runs of
-        # constant ring_max break up, which is where the tiled AGC falls back to walking a segment in order (agc_bounds_fix_kernel)
+        # overs of a contact: the channel is loud for a few seconds, then 40 dB down for a few (3 .. 5 changes of level per 21.8 s
+        # buffer, another rhythm per channel, periodic in the buffer).  After every DROP the level detector decays for seconds
+        # (tau_decay), which is where the tiled AGC's warm-ups miss and a segment is walked again in order (agc_bounds_fix_kernel)
         t = torch.arange(n_in, dtype=torch.float64, device=dev)
         for c in range(nch):
-            cyc = round((7.0 + (c % 7)) * n_in / 192000.0)
-            env = 0.505 + 0.495 * torch.cos(t * (2.0 * np.pi * cyc / n_in))
+            cyc = 3 + (c % 3)
+            env = torch.where(torch.remainder(t * (cyc / n_in) + 0.07 * (c % 11), 1.0) < 0.5, 1.0, 0.01)
             L.x[c] *= env
         del t
     L.y = torch.empty((nch, L.n_out), dtype=torch.complex128, device=dev)
@@ -188,7 +189,7 @@ def config2_agc(torch, qh, dev):
     Lf = setup_config2_agc(torch, qh, dev, fading=True)
     tf = timed(Lf.step, sync, steps=4, warmup=2)
     fading = {"ms": tf * 1e3, "Msamp_per_s": tot / tf / 1e6, "agc_tiles_rerun": Lf.eng.agc_repairs(), "agc_segments_rerun": Lf.eng.agc_segments_rerun(),
-              "input": "the same tones under a 7 .. 13 Hz flutter down to -40 dB"}
+              "input": "the same tones keyed between full level and -40 dB every 2 .. 4 s (3 .. 5 overs per 21.8 s call)"}
     return {"config": "2 with the AGC state machine on (SetRXAAGCMode 3): 256 ch x 192 k SSB RXA, fp64, 2^%d samples per channel and step" % (n_log2),
             "samples_per_step": tot, "ms": t * 1e3, "Msamp_per_s": tot / t / 1e6, "agc_tiles_rerun": tiles,
             "agc_segments_rerun": segs, "fading_input": fading,
