@@ -263,6 +263,13 @@ double GetRXAMeter(int channel, int mt);                                        
  * is the C form of quisk_wdsp_set_parameter (quisk_wdsp.c:71-91; in_size <= 0 / in_use < 0 leave the value). */
 int wdspFexchange0(int channel, double *cSamples, int nSamples);
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use);
+/* The same hand-off for samples that are already on the GPU (what qh_quisk_process_samples does at quisk.c:2660-2661):
+ * d_samples = nSamples interleaved complex doubles in device memory with room for nSamples + in_size; the shim's ring, the
+ * double rings of fexchange0 (wdsp/iobuffs.c:464-516), the up- and down-slews and the DSP blocks all stay in device memory
+ * and are enqueued on the channel's stream (ordered behind `stream` on entry; `stream` is ordered behind it on return) --
+ * no copy to the host, nothing waited for.  Returns the number of samples left in d_samples, like wdspFexchange0.  The same
+ * samples as the host-pointer call, bit for bit; a channel may change between the two in mid-stream. */
+int qh_wdsp_fexchange0_device(int channel, void *d_samples, int nSamples, void *stream);
 /* accepted and ignored: these blocks are run = 0 on the hot path */
 /* anf / anr: the leaky-LMS automatic notch filter and noise reduction of the RXA chain (wdsp/anf.c:175-239, anr.c:175-238);
  * up to 64 taps and a delay of up to 64 samples (defaults 64 / 16, RXA.c:285-286,305-306) */

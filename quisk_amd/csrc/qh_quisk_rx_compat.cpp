@@ -20,8 +20,8 @@
 //   process_agc (Agc1, Agc2), kill_audio / squelch, key-up envelope  quisk.c:2686-2738
 //
 // The block is uploaded ONCE and stays on the device until the playback samples come back: every step above is a kernel
-// (or one of the library's engines) on one HIP stream.  The only host round trip inside the chain is the optional WDSP
-// hand-off, whose entry point (fexchange0) takes host pointers by definition; it moves 48 ksps audio.
+// (or one of the library's engines) on one HIP stream -- the optional WDSP hand-off too: the shim's ring and fexchange0's rings are
+// device FIFOs in front of the RXA engine (qh_wdsp_fexchange0_device), enqueued behind this stream.
 // Mode, bandwidth class or rate changes rebuild a bank (filter histories restart: a few ms of transient where the
 // reference keeps its static histories); the tuning oscillators keep their phase (one per purpose, as the reference's
 // rxTuneVector / txTuneVector / aux1TuneVector / aux2TuneVector).
@@ -242,7 +242,7 @@ struct QuiskRx {
     qh_pan *mf_fft = nullptr;
     std::vector<double> mf_avg;
     // work buffers
-    DevBuf<double2> d_raw, d_x, d_nb, d_o0, d_o1, d_mix, d_fd, d_up, d_a, d_b, d_sub, d_sub0, d_s1, d_mf, d_mf8;
+    DevBuf<double2> d_raw, d_x, d_nb, d_o0, d_o1, d_mix, d_fd, d_up, d_a, d_b, d_sub, d_sub0, d_s1, d_mf, d_mf8, d_wd;
     int *d_flags = nullptr;
     PinBuf<double> h_in, h_out, h_sub1;
     int *h_flags = nullptr;
@@ -344,7 +344,7 @@ void free_all()
     if (g.mf_fft) { qh_pan_destroy(g.mf_fft); g.mf_fft = nullptr; }
     g.d_raw.release(); g.d_x.release(); g.d_nb.release(); g.d_o0.release(); g.d_o1.release(); g.d_mix.release(); g.d_fd.release();
     g.d_up.release(); g.d_a.release(); g.d_b.release(); g.d_sub.release(); g.d_sub0.release(); g.d_s1.release(); g.d_mf.release();
-    g.d_mf8.release(); g.d_ext.release();
+    g.d_mf8.release(); g.d_ext.release(); g.d_wd.release();
     for (auto &row : g.b2c) for (auto &bb : row) bb.release();
     for (double2 *&h : g.fd_hist) { if (h) (void)hipFree(h); h = nullptr; }
     if (g.d_flags) { (void)hipFree(g.d_flags); g.d_flags = nullptr; }
@@ -668,18 +668,15 @@ int process_radio(double *cSamples, int nSamples)
         g.fd_dindex = qh_ps::fracdecim_next_dindex(na, M, g.fd_dindex, fdecim);
         audio = g.d_fd.p; na = M;
     }
-    // ---- the WDSP hand-off (quisk.c:2660-2661): fexchange0 takes host pointers, so this is the one round trip of the chain
+    // ---- the WDSP hand-off (quisk.c:2660-2661) with the samples where they are: the shim's ring, fexchange0's rings and the DSP blocks
+    // in device memory, enqueued behind this stream (qh_wdsp_fexchange0_device) -- no round trip, no wait
     if (qh_wdsp_shim_in_size(0) <= 0) (void)wdspFexchange0(0, nullptr, 0);      // not in use: the shim only rewinds its ring (quisk_wdsp.c:32-37)
     if (const int in_size = qh_wdsp_shim_in_size(0); in_size > 0 && na > 0) {
-        if (g.h_out.need((size_t)(na + in_size) * 2)) return -1;
-        if (hipMemcpyAsync(g.h_out.p, audio, (size_t)na * 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            qh::set_error(QH_ERR_HIP, "download failed"); return -1;
-        }
-        const int nw = wdspFexchange0(0, g.h_out.p, na);
-        if (g.d_fd.need((size_t)nw + 1)) return -1;              // (d_fd may hold `audio`; it has been copied out)
-        if (nw > 0 && hipMemcpyAsync(g.d_fd.p, g.h_out.p, (size_t)nw * 16, hipMemcpyHostToDevice, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
-        if (hipStreamSynchronize(s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "upload failed"); return -1; }
-        audio = g.d_fd.p; na = nw;
+        if (g.d_wd.need((size_t)(na + in_size))) return -1;
+        if (hipMemcpyAsync(g.d_wd.p, audio, (size_t)na * 16, hipMemcpyDeviceToDevice, s) != hipSuccess) { qh::set_error(QH_ERR_HIP, "copy failed"); return -1; }
+        const int nw = qh_wdsp_fexchange0_device(0, g.d_wd.p, na, s);
+        if (qh_wdsp_status() != QH_OK) return -1;
+        audio = g.d_wd.p; na = nw;
     }
     // ---- interpolation to the playback rate (quisk.c:2663-2682)
     if (g.up && na > 0) {

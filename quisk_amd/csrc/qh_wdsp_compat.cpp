@@ -56,6 +56,96 @@ __global__ void slew_kernel(double2 *buf, int n, long long p0, int lead, int ram
     buf[i].x *= g; buf[i].y *= g;
 }
 
+// ---- the exchange with every buffer on the GPU (qh_wdsp_fexchange0_device): the rings, the block buffers and the up-slew's trigger
+// live in device memory, the indices stay on the host (they do not depend on the data).  What does depend on the data -- the
+// up-slew starts at the first non-zero input sample, iobuffs.c:104-113 -- is found by the kernel that writes the ring.
+struct DevSlew { long long p, origin; int armed, pad; };
+
+// One launch per fexchange0 call in the common case: every copy of the exchange that precedes the DSP block, as the phases of one
+// workgroup (a phase with n = 0 is skipped; the phases are ordered by the workgroup's barriers, which also order their global
+// memory accesses within the workgroup):
+//   A  in_size samples into r1 + the up-slew's bookkeeping (fexchange0, iobuffs.c:98-160,478-480)
+//   B  dexchange (iobuffs.c:583-604): the previous DSP block's output into r2; the next DSP block out of r1 into the engine's
+//      input buffer, under the up-slew's envelope where it still rises
+//   C  out_size samples out of r2 (iobuffs.c:497-511), under the down-slew's envelope, or zeros
+struct XchgArgs {
+    const double2 *in; double2 *r1_in; int n_in; DevSlew *sl; long long in_count, level_from;
+    const double2 *dout; double2 *r2_in; int n_r2;
+    const double2 *r1_out; double2 *blk; int n_blk; long long blk0; int up_lead, up_ramp;
+    const double2 *r2_out; double2 *out; int n_out, out_mode;      // out_mode 0 copy, 1 zeros, 2 copy under the down-slew from position down_p0
+    long long down_p0; int down_lead, down_ramp;
+};
+__global__ __launch_bounds__(256) void exchange_kernel(XchgArgs a)
+{
+    __shared__ int first;
+    const int t = threadIdx.x;
+    if (a.n_in > 0) {
+        if (t == 0) first = a.n_in;
+        const int armed = a.sl->armed;
+        const long long p_was = a.sl->p;
+        __syncthreads();
+        int mine = a.n_in;
+        for (int i = t; i < a.n_in; i += 256) {
+            const double2 v = a.in[i];
+            a.r1_in[i] = v;
+            if (mine == a.n_in && (v.x != 0.0 || v.y != 0.0)) mine = i;
+        }
+        if (armed && p_was < 0 && mine < a.n_in) atomicMin(&first, mine);
+        __syncthreads();
+        if (armed && t == 0) {
+            long long p = p_was, origin = a.sl->origin;
+            if (p < 0 && first < a.n_in) { origin = a.in_count + first; p = 0; a.sl->origin = origin; a.sl->p = 0; }
+            if (p >= 0 && a.in_count + a.n_in - 1 - origin + p >= a.level_from) a.sl->armed = 0;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < a.n_r2; i += 256) a.r2_in[i] = a.dout[i];
+    if (a.n_blk > 0) {
+        const long long p = a.sl->p, origin = a.sl->origin;
+        for (int i = t; i < a.n_blk; i += 256) {
+            double2 v = a.r1_out[i];
+            if (p >= 0) {
+                const long long q = a.blk0 + i - origin + p;
+                double g = 1.0;
+                if (q <= a.up_lead) g = 0.0;
+                else if (a.up_ramp > 0 && q - a.up_lead - 1 <= a.up_ramp) g = 0.5 * (1.0 - cospi((double)(q - a.up_lead - 1) / (double)a.up_ramp));
+                v.x *= g; v.y *= g;
+            }
+            a.blk[i] = v;
+        }
+    }
+    if (a.n_out > 0) {
+        __syncthreads();
+        for (int i = t; i < a.n_out; i += 256) {
+            double2 v = make_double2(0.0, 0.0);
+            if (a.out_mode != 1) v = a.r2_out[i];
+            if (a.out_mode == 2) {
+                const long long q = a.down_p0 + i;
+                double g = 0.0;
+                if (q <= a.down_lead) g = 1.0;
+                else if (a.down_ramp > 0 && q - a.down_lead - 1 <= a.down_ramp) g = 0.5 * (1.0 + cospi((double)(q - a.down_lead - 1) / (double)a.down_ramp));
+                v.x *= g; v.y *= g;
+            }
+            a.out[i] = v;
+        }
+    }
+}
+__global__ void slew_set_kernel(DevSlew *sl, long long p, long long origin, int armed) { sl->p = p; sl->origin = origin; sl->armed = armed; sl->pad = 0; }
+// quisk_wdsp.c:43-49 / :63-66: into the shim's ring divided by CLIP32; the results times CLIP32
+__global__ void shim_in_kernel(const double2 *x, int n, double2 *ring, int W, int size)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int w = W + i;
+    if (w >= size) w -= size;
+    ring[w] = make_double2(x[i].x / 2147483647.0, x[i].y / 2147483647.0);
+}
+__global__ void shim_scale_kernel(double2 *x, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i].x *= 2147483647.0; x[i].y *= 2147483647.0; }
+}
+
 struct Chan {
     bool open = false, emnr_tables = false;
     qh_rxa *eng = nullptr;
@@ -72,7 +162,10 @@ struct Chan {
     long long in_count = 0, dsp_count = 0;          // input samples written to r1 / taken out of it since the rings were reset
     // staging: pinned host + device block buffers
     double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
-    // the DSP iteration replayed from captured hipGraphs: one per parity of the engine's ping-pong state buffers
+    // device mode (qh_wdsp_fexchange0_device): r1 / r2 in device memory, outbuff = d_out, the up-slew's trigger in *d_up
+    bool dev_mode = false;
+    double *d_r1 = nullptr, *d_r2 = nullptr;
+    DevSlew *d_up = nullptr;
 };
 
 Chan g_ch[kMaxChannels];
@@ -95,7 +188,13 @@ void create_slews(Chan &c)          // the sample counts of wdsp/iobuffs.c:47-68
     c.down.delay = (int)(c.tdelaydown * c.out_rate); c.down.ramp = (int)(c.tslewdown * c.out_rate);
 }
 
-void flush_slews(Chan &c) { c.up.reset(); c.down.reset(); }
+// device mode: the up-slew's state as the host has just set it
+void push_up(Chan &c)
+{
+    if (!c.dev_mode) return;
+    hipLaunchKernelGGL(slew_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)qh_rxa_stream(c.eng), c.d_up, c.up.p, c.up.origin, c.up.armed ? 1 : 0);
+}
+void flush_slews(Chan &c) { c.up.reset(); c.down.reset(); push_up(c); }
 
 void init_rings(Chan &c)            // create_iobuffs / flush_iobuffs, wdsp/iobuffs.c:384-455
 {
@@ -111,6 +210,12 @@ void init_rings(Chan &c)            // create_iobuffs / flush_iobuffs, wdsp/iobu
     c.sem_buffready = 0;
     c.sem_outready = n;
     c.in_count = 0; c.dsp_count = 0;
+    if (c.dev_mode) {
+        hipStream_t s = (hipStream_t)qh_rxa_stream(c.eng);
+        (void)hipMemsetAsync(c.d_r1, 0, (size_t)c.r1_active * 16, s);
+        (void)hipMemsetAsync(c.d_r2, 0, (size_t)c.r2_active * 16, s);
+        (void)hipMemsetAsync(c.d_out, 0, (size_t)c.dsp_outsize * 16, s);
+    }
 }
 
 // Multiplies the n samples at `buf` (device-visible) by the envelope, the first one at position p0; on the engine's stream.
@@ -173,7 +278,42 @@ void free_staging(Chan &c)
     if (c.d_out) (void)hipFree(c.d_out);
     if (c.h_in) (void)hipHostFree(c.h_in);
     if (c.h_out) (void)hipHostFree(c.h_out);
-    c.d_in = c.d_out = c.h_in = c.h_out = nullptr;
+    if (c.d_r1) (void)hipFree(c.d_r1);
+    if (c.d_r2) (void)hipFree(c.d_r2);
+    if (c.d_up) (void)hipFree(c.d_up);
+    c.d_in = c.d_out = c.h_in = c.h_out = c.d_r1 = c.d_r2 = nullptr;
+    c.d_up = nullptr;
+    c.dev_mode = false;
+}
+
+// Host rings <-> device rings: a channel is driven through fexchange0 (host pointers) or through qh_wdsp_fexchange0_device; a caller
+// that changes sides in mid-stream takes the rings, the pending output block and the up-slew's state along.
+int set_mode(Chan &c, bool dev)
+{
+    if (c.dev_mode == dev) return QH_OK;
+    hipStream_t s = (hipStream_t)qh_rxa_stream(c.eng);
+    if (hipStreamSynchronize(s) != hipSuccess) return qh::set_error(QH_ERR_HIP, "fexchange0: synchronize failed");
+    if (dev) {
+        if (!c.d_r1 && (hipMalloc((void **)&c.d_r1, (size_t)c.r1_active * 16) != hipSuccess || hipMalloc((void **)&c.d_r2, (size_t)c.r2_active * 16) != hipSuccess ||
+                        hipMalloc((void **)&c.d_up, sizeof(DevSlew)) != hipSuccess))
+            return qh::set_error(QH_ERR_HIP, "fexchange0: device ring allocation failed");
+        const DevSlew h{c.up.p, c.up.origin, c.up.armed ? 1 : 0, 0};
+        if (hipMemcpy(c.d_r1, c.r1.data(), (size_t)c.r1_active * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c.d_r2, c.r2.data(), (size_t)c.r2_active * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c.d_out, c.outbuff.data(), (size_t)c.dsp_outsize * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c.d_up, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess)
+            return qh::set_error(QH_ERR_HIP, "fexchange0: ring upload failed");
+    } else {
+        DevSlew h{};
+        if (hipMemcpy(c.r1.data(), c.d_r1, (size_t)c.r1_active * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(c.r2.data(), c.d_r2, (size_t)c.r2_active * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(c.outbuff.data(), c.d_out, (size_t)c.dsp_outsize * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&h, c.d_up, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
+            return qh::set_error(QH_ERR_HIP, "fexchange0: ring download failed");
+        c.up.p = h.p; c.up.origin = h.origin; c.up.armed = h.armed != 0;
+    }
+    c.dev_mode = dev;
+    return QH_OK;
 }
 
 struct Locked {
@@ -288,6 +428,7 @@ int SetChannelState(int channel, int state, int dmode)
             else { c.down.armed = true; c.down.p = 0; }
         } else {
             c.up.armed = true; c.up.p = -1;
+            push_up(c);
             c.exchange = 1;
         }
     }
@@ -302,6 +443,7 @@ void fexchange0(int channel, double *in, double *out, int *error)
     if (!L.c) { *error = -1; return; }
     Chan &c = *L.c;
     if (!c.exchange) return;                        // wdsp/iobuffs.c:471: `out` is left untouched
+    if (int rc = set_mode(c, false)) { g_status = rc; *error = -1; return; }
     std::memcpy(c.r1.data() + 2 * c.r1_inidx, in, (size_t)c.in_size * 2 * sizeof(double));
     if (c.up.armed) {
         // iobuffs.c:98-160 as bookkeeping: the envelope is triggered by the first non-zero sample; the flag drops at the end of
@@ -361,6 +503,94 @@ void fexchange0(int channel, double *in, double *out, int *error)
     }
     if ((c.r2_outidx += c.out_size) == c.r2_active) c.r2_outidx = 0;
 }
+
+}  // extern "C"
+
+namespace {
+// fexchange0 with `in` (in_size samples) and `out` (out_size samples) in device memory: the same bookkeeping on the host, the copies
+// and the slews as phases of exchange_kernel on the engine's stream, nothing waited for.  A call that runs one DSP block (in_size =
+// dsp_insize, Quisk's case) is two launches: the exchange and the block (a replayed hipGraph); the output copy (out of r2, which the
+// block does not touch) rides in the exchange ahead of the block.
+int fexchange0_dev(Chan &c, const double *d_in, double *d_out, int *error)
+{
+    *error = 0;
+    if (!c.exchange) return QH_OK;
+    hipStream_t s = (hipStream_t)qh_rxa_stream(c.eng);
+    XchgArgs a{};
+    a.sl = c.d_up;
+    auto launch = [&]() {
+        hipLaunchKernelGGL(exchange_kernel, dim3(1), dim3(256), 0, s, a);
+        a = XchgArgs{};
+        a.sl = c.d_up;
+    };
+    a.in = reinterpret_cast<const double2 *>(d_in); a.r1_in = reinterpret_cast<double2 *>(c.d_r1) + c.r1_inidx; a.n_in = c.in_size;
+    a.in_count = c.in_count; a.level_from = c.up.level_from();
+    c.in_count += c.in_size;
+    if ((c.r1_unqueued += c.in_size) >= c.r1_outsize) {
+        const int n = c.r1_unqueued / c.r1_outsize;
+        c.sem_buffready += n;
+        c.r1_unqueued -= n * c.r1_outsize;
+    }
+    if ((c.r1_inidx += c.in_size) == c.r1_active) c.r1_inidx = 0;
+    bool out_done = false, stop = false;
+    auto output = [&]() {      // iobuffs.c:487-515 (and the down-slew, :226-300, :499-503)
+        out_done = true;
+        const int doit = c.r2_havesamps >= c.out_size;
+        if ((c.r2_havesamps -= c.out_size) < 0) c.r2_havesamps = 0;
+        int ready = 0;
+        if (c.bfo) { if (c.sem_outready > 0) { c.sem_outready--; ready = 1; } }
+        else ready = doit;
+        a.out = reinterpret_cast<double2 *>(d_out); a.n_out = c.out_size;
+        a.r2_out = reinterpret_cast<const double2 *>(c.d_r2) + c.r2_outidx;
+        if (ready) {
+            a.out_mode = 0;
+            if (c.down.armed) {
+                a.out_mode = c.down.p < c.down.level_from() ? 2 : 1;
+                a.down_p0 = c.down.p; a.down_lead = c.down.lead(); a.down_ramp = c.down.ramp;
+                c.down.p += c.out_size;
+                if (c.down.p - 1 >= c.down.level_from() + c.out_size + 1) stop = true;
+            }
+        } else {
+            a.out_mode = 1;
+            *error += -2;
+        }
+        if (!stop && (c.r2_outidx += c.out_size) == c.r2_active) c.r2_outidx = 0;
+    };
+    while (c.sem_buffready > 0) {           // the DSP thread's loop (wdsp/main.c:40-58): dexchange, then xrxa
+        c.sem_buffready--;
+        c.r2_havesamps += c.r2_insize;
+        a.dout = reinterpret_cast<const double2 *>(c.d_out); a.r2_in = reinterpret_cast<double2 *>(c.d_r2) + c.r2_inidx; a.n_r2 = c.r2_insize;
+        if ((c.r2_inidx += c.r2_insize) == c.r2_active) c.r2_inidx = 0;
+        if (c.bfo && (c.r2_unqueued += c.r2_insize) >= c.out_size) {
+            const int n = c.r2_unqueued / c.out_size;
+            c.sem_outready += n;
+            c.r2_unqueued -= n * c.out_size;
+        }
+        a.r1_out = reinterpret_cast<const double2 *>(c.d_r1) + c.r1_outidx; a.blk = reinterpret_cast<double2 *>(c.d_in); a.n_blk = c.r1_outsize;
+        a.blk0 = c.dsp_count; a.up_lead = c.up.lead(); a.up_ramp = c.up.ramp;
+        if ((c.r1_outidx += c.r1_outsize) == c.r1_active) c.r1_outidx = 0;
+        c.dsp_count += c.r1_outsize;
+        if (c.sem_buffready == 0) output();
+        launch();
+        if (int rc = qh_rxa_process(c.eng, c.d_in, c.dsp_insize, c.d_out, c.dsp_outsize, 1)) {
+            *error = -1;
+            (void)hipMemsetAsync(d_out, 0, (size_t)c.out_size * 16, s);
+            return rc;
+        }
+    }
+    if (!out_done) { output(); launch(); }
+    if (hipGetLastError() != hipSuccess) return qh::set_error(QH_ERR_HIP, "fexchange0: launch failed");
+    if (stop) {
+        c.exchange = 0;
+        init_rings(c);
+        flush_slews(c);
+        (void)qh_rxa_flush(c.eng);
+    }
+    return QH_OK;
+}
+}  // namespace
+
+extern "C" {
 
 #define WDSP_SETTER(call)                                   \
     do {                                                    \
@@ -523,8 +753,38 @@ double GetRXAMeter(int channel, int mt)
 
 // ---- quisk_wdsp.c:12-69: re-block an arbitrary count into in_size blocks through a ring, CLIP32 scaling
 namespace {
-struct Shim { std::vector<double> buf; int sizeBuf = 0, nBuf = 0, in_size = 0, in_use = 0, W = 0, R = 0; };
+struct Shim {
+    std::vector<double> buf; int sizeBuf = 0, nBuf = 0, in_size = 0, in_use = 0, W = 0, R = 0;
+    // qh_wdsp_fexchange0_device: the ring in device memory (d_cap samples; `dev`: it holds the ring's contents, not `buf`)
+    double *d_buf = nullptr; int d_cap = 0; bool dev = false;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+};
 Shim g_shim[kMaxChannels];
+
+// the shim's ring to the side that is going to use it (sizeBuf samples of it are in use), grown to `want` samples
+int shim_side(Shim &s, bool dev, int want)
+{
+    if (dev) {
+        if (want > s.d_cap) {
+            double *nb = nullptr;
+            if (hipMalloc((void **)&nb, (size_t)want * 16) != hipSuccess) return qh::set_error(QH_ERR_HIP, "wdspFexchange0: ring allocation failed");
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(nb, 0, (size_t)want * 16);
+            if (s.dev && s.sizeBuf > 0) (void)hipMemcpy(nb, s.d_buf, (size_t)s.sizeBuf * 16, hipMemcpyDeviceToDevice);
+            if (s.d_buf) (void)hipFree(s.d_buf);
+            s.d_buf = nb; s.d_cap = want;
+        }
+        if (!s.dev && s.sizeBuf > 0 && hipMemcpy(s.d_buf, s.buf.data(), (size_t)s.sizeBuf * 16, hipMemcpyHostToDevice) != hipSuccess)
+            return qh::set_error(QH_ERR_HIP, "wdspFexchange0: ring upload failed");
+    } else if (s.dev && s.sizeBuf > 0) {
+        if (s.buf.size() < (size_t)s.sizeBuf * 2) s.buf.resize((size_t)s.sizeBuf * 2);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(s.buf.data(), s.d_buf, (size_t)s.sizeBuf * 16, hipMemcpyDeviceToHost) != hipSuccess)
+            return qh::set_error(QH_ERR_HIP, "wdspFexchange0: ring download failed");
+    }
+    s.dev = dev;
+    return QH_OK;
+}
 }
 
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use)
@@ -549,6 +809,7 @@ int wdspFexchange0(int channel, double *cSamples, int nSamples)
     if (!s.in_use) { s.W = 0; s.R = 0; s.nBuf = 0; return nSamples; }
     if (nSamples <= 0 || s.in_size <= 0) return nSamples;
     const int in_size = s.in_size;
+    if (s.dev && shim_side(s, false, 0)) return 0;
     int i = nSamples / in_size + 3;                 // blocks needed for the samples plus a partial block
     if (i * in_size > s.sizeBuf) { s.sizeBuf = i * in_size; s.buf.resize((size_t)s.sizeBuf * 2); }
     for (i = 0; i < nSamples; i++) {
@@ -566,6 +827,61 @@ int wdspFexchange0(int channel, double *cSamples, int nSamples)
         s.nBuf -= in_size;
     }
     for (i = 0; i < nout; i++) { cSamples[2 * i] *= CLIP32; cSamples[2 * i + 1] *= CLIP32; }
+    return nout;
+}
+
+// The same hand-off for a caller whose samples are on the GPU (qh_quisk_process_samples, quisk.c:2660-2661): cSamples -> d_samples
+// (room for nSamples + in_size samples), everything enqueued: the shim's ring, fexchange0's rings and the DSP blocks in device
+// memory on the channel's stream, which is ordered behind `stream` on entry; `stream` is ordered behind it on return.  Nothing
+// is waited for.  A channel may change between this and the host-pointer calls in mid-stream (the rings move with it).
+int qh_wdsp_fexchange0_device(int channel, void *d_samples, int nSamples, void *stream)
+{
+    g_status = QH_OK;
+    if (!valid(channel)) return nSamples;
+    Shim &s = g_shim[channel];
+    if (!s.in_use) { s.W = 0; s.R = 0; s.nBuf = 0; return nSamples; }
+    if (nSamples <= 0 || s.in_size <= 0) return nSamples;
+    if (!d_samples) { g_status = qh::set_error(QH_ERR_INVALID, "qh_wdsp_fexchange0_device: null buffer"); return 0; }
+    const int in_size = s.in_size;
+    Locked L(channel);
+    hipStream_t cs = (hipStream_t)stream;
+    double2 *x = reinterpret_cast<double2 *>(d_samples);
+    if (!L.c || L.c->in_size != in_size) {
+        // no such channel: fexchange0 reports -1 and leaves `out` alone, the shim scales what is there (quisk_wdsp.c:57-66)
+        if (L.c) g_status = qh::set_error(QH_ERR_INVALID, "WDSP channel %d: in_size %d, the shim's %d", channel, L.c->in_size, in_size);
+        s.nBuf += nSamples;
+        const int nout = s.nBuf / in_size * in_size;
+        s.nBuf -= nout;
+        if (nout > 0) hipLaunchKernelGGL(shim_scale_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, cs, x, nout);
+        return nout;
+    }
+    Chan &c = *L.c;
+    if (int rc = set_mode(c, true)) { g_status = rc; return 0; }
+    int blocks = nSamples / in_size + 3;
+    const int want = blocks * in_size > s.sizeBuf ? blocks * in_size : s.sizeBuf;
+    if (int rc = shim_side(s, true, want)) { g_status = rc; return 0; }
+    s.sizeBuf = want;
+    hipStream_t es = (hipStream_t)qh_rxa_stream(c.eng);
+    if (!s.ev_in && (hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming) != hipSuccess)) {
+        g_status = qh::set_error(QH_ERR_HIP, "qh_wdsp_fexchange0_device: event creation failed");
+        return 0;
+    }
+    if (cs != es) { (void)hipEventRecord(s.ev_in, cs); (void)hipStreamWaitEvent(es, s.ev_in, 0); }
+    hipLaunchKernelGGL(shim_in_kernel, dim3((unsigned)((nSamples + 255) / 256)), dim3(256), 0, es, (const double2 *)x, nSamples,
+                       reinterpret_cast<double2 *>(s.d_buf), s.W, s.sizeBuf);         // (the ring is longer than the call: one wrap at most)
+    s.W = (s.W + nSamples) % s.sizeBuf;
+    s.nBuf += nSamples;
+    int nout = 0, error = 0;
+    while (s.nBuf >= in_size) {
+        if (int rc = fexchange0_dev(c, s.d_buf + 2 * (size_t)s.R, reinterpret_cast<double *>(x + nout), &error)) g_status = rc;
+        s.R += in_size;
+        if (s.R >= s.sizeBuf) s.R = 0;
+        nout += in_size;
+        s.nBuf -= in_size;
+    }
+    if (nout > 0) hipLaunchKernelGGL(shim_scale_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, es, x, nout);
+    if (hipGetLastError() != hipSuccess) g_status = qh::set_error(QH_ERR_HIP, "qh_wdsp_fexchange0_device: launch failed");
+    if (cs != es) { (void)hipEventRecord(s.ev_out, es); (void)hipStreamWaitEvent(cs, s.ev_out, 0); }
     return nout;
 }
 

@@ -93,6 +93,8 @@ def load():
     L.qh_audio_pack.argtypes = [i, vp, vp, ll, i, i, vp, vp, ll]
     L.qh_audio_pack.restype = i
     L.qh_wdsp_graph_launches.restype = ll
+    L.qh_wdsp_fexchange0_device.argtypes = [i, vp, i, vp]
+    L.qh_wdsp_fexchange0_device.restype = i
     L.qh_rxa_GetRXAMeter.argtypes = [vp, i, i, C.POINTER(d)]
     L.qh_rxa_flush.argtypes = [vp]
     L.qh_rxa_flush.restype = i
