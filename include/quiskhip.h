@@ -183,6 +183,7 @@ int qh_rxa_debug_agc(qh_rxa *h, int form);                                      
 int qh_rxa_debug_agc_ends(qh_rxa *h, int slot, double *out, int max);                /* diagnostics, see qh_engine.hip */
 long long qh_rxa_agc_repairs(qh_rxa *h);                                            /* wcpAGC time tiles the verify pass re-ran in order */
 long long qh_rxa_agc_segments_rerun(qh_rxa *h);                                     /* super-segments of its boundary pass walked again */
+int qh_rxa_agc_tiled_channels(qh_rxa *h);                                           /* channels whose xwcpagc took the time tiles in the last call */
 int qh_rxa_synchronize(qh_rxa *e);
 
 /* Meters (wdsp/meter.c:75-142).  They cost an extra pass, so they are off until enabled.  mt as wdsp/RXA.h:47-57:

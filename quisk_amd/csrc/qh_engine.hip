@@ -297,6 +297,8 @@ struct Engine {
     int meters_alloc();
     int *list_agc_cur = nullptr, *list_agc_other = nullptr;
     int n_agc_cur = 0, n_agc_other = 0;
+    int agc_last_tiled = 0;             // channels whose xwcpagc took the time tiles in the last call (diagnostics)
+    int n_agc_cur_stale = 0, n_agc_other_stale = 0;     // ... of which, at the lists' ends, channels whose attack window moved in mid-stream
 
     ~Engine();
     int init();
@@ -761,8 +763,16 @@ int Engine::refresh_demod()
         lists_dirty = true;
         for (ChanCfg &c : cfg) c.demod_dirty = true;
     }
+    // a channel whose attack window moves after its AGC has run keeps the reference's ring_max, which may then be a value the window
+    // no longer holds (wcpAGC.c:197-210 only rescans when the sample that leaves equals it): the time tiles take the window's maximum,
+    // so that channel stays on the kernel that steps the reference's bookkeeping -- it alone: the lists put such channels last
+    for (ChanCfg &c : cfg) {
+        if (!c.agc_dirty || !c.agc_ran) continue;
+        const int abuf = (int)std::ceil(rate * 4.0 * c.agc_tau_attack);
+        if (c.agc_abuf != abuf) { c.agc_rewindow = true; if (!c.agc_stale) { c.agc_stale = true; lists_dirty = true; } }
+    }
     if (lists_dirty) {
-        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba, lrest, lusb, lrb;
+        std::vector<int> la, ls, lf, lb, lp, lgc, lgo, lgc_s, lgo_s, ll, lms_l[2][3], lbp[2], lfix[2], lsq, lem[3], lsn[2], lsnba, lrest, lusb, lrb;
         int n_sam0_new = 0;
         for (int ch = 0; ch < nch; ch++) {
             const ChanCfg &c = cfg[(size_t)ch];
@@ -780,7 +790,7 @@ int Engine::refresh_demod()
             if (c.fmd_run) lf.push_back(ch); else { lrest.push_back(ch); (c.bp1_run ? lrb : lusb).push_back(ch); }
             if (c.bp1_run) lb.push_back(ch); else lp.push_back(ch);
             // xwcpagc sits between the two bp1 positions (RXA.c:581-586): a position-1 channel is still in `cur` there
-            if (c.agc_run && c.agc_mode != 0) (c.bp1_run && !c.bp1_pos ? lgo : lgc).push_back(ch);
+            if (c.agc_run && c.agc_mode != 0) (c.bp1_run && !c.bp1_pos ? (c.agc_stale ? lgo_s : lgo) : (c.agc_stale ? lgc_s : lgc)).push_back(ch);
         }
         bool any_lms = false;
         for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) { n_lms[f][k] = (int)lms_l[f][k].size(); any_lms = any_lms || n_lms[f][k]; }
@@ -860,6 +870,8 @@ int Engine::refresh_demod()
         }
         n_sam0 = n_sam0_new;
         n_am = (int)la.size(); n_sam = (int)ls.size(); n_fm = (int)lf.size(); n_bp1 = (int)lb.size(); n_plain = (int)lp.size();
+        n_agc_cur_stale = (int)lgc_s.size(); n_agc_other_stale = (int)lgo_s.size();
+        lgc.insert(lgc.end(), lgc_s.begin(), lgc_s.end()); lgo.insert(lgo.end(), lgo_s.begin(), lgo_s.end());
         n_agc_cur = (int)lgc.size(); n_agc_other = (int)lgo.size();
         n_lim = (int)ll.size();
         if (n_lim) {
@@ -933,7 +945,6 @@ int Engine::refresh_demod()
             if (q.attack_buffsize + 2 > kAgcRing)
                 return set_error(QH_ERR_UNSUPPORTED, "AGC attack of %g s needs a look-ahead of %d samples (limit %d)", c.agc_tau_attack,
                                  q.attack_buffsize, kAgcRing - 2);
-            if (c.agc_ran && c.agc_abuf != q.attack_buffsize) { c.agc_stale = true; c.agc_rewindow = true; }
             c.agc_abuf = q.attack_buffsize;
             q.attack_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_attack));
             q.decay_mult = 1.0 - std::exp(-1.0 / (rate * c.agc_tau_decay));
@@ -2078,10 +2089,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         int a_max = 0;
         for (int ch = 0; ch < nch && tiled; ch++) {
             ChanCfg &c = cfg[(size_t)ch];
-            if (!c.agc_on()) continue;
-            if (c.agc_stale) tiled = false;
+            if (!c.agc_on() || c.agc_stale) continue;
             a_max = c.agc_abuf > a_max ? c.agc_abuf : a_max;
         }
+        // the tiles take the channels at the head of each list, the stepping kernel the ones behind them (all of them in a short call)
+        const int nt_cur = tiled ? n_agc_cur - n_agc_cur_stale : 0, nt_other = tiled ? n_agc_other - n_agc_other_stale : 0;
+        if (nt_cur + nt_other == 0) tiled = false;
+        agc_last_tiled = nt_cur + nt_other;
         for (ChanCfg &c : cfg) if (c.agc_on()) c.agc_ran = true;
         // the reference's full ring (RB_SIZE entries): this call's last inputs go in where xwcpagc writes them; a channel whose attack
         // window moved since its last call first takes its 2048-entry ring again from it (the entries the longer window jumped over)
@@ -2127,9 +2141,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         // multiply applies the output matrix and writes the caller's rows: the output pass goes
         bool no_p1 = !n_bp1p[1] && !n_fix[0] && !n_fix[1] && !n_emnr[1] && !n_emnr[2] && !n_amsq && !meters_on && !eg.kind;
         for (int f = 0; f < 2; f++) for (int k = 1; k < 3; k++) no_p1 = no_p1 && !n_lms[f][k];
-        agc_direct = tiled && no_p1 && n_agc_cur == n_plain && n_agc_other == n_bp1;
+        agc_direct = tiled && no_p1 && nt_cur == n_plain && nt_other == n_bp1;
         if (tiled) {
-            const int nl = n_agc_cur > n_agc_other ? n_agc_cur : n_agc_other;
+            const int nl = nt_cur > nt_other ? nt_cur : nt_other;
             const int ntile = (int)((n_mid + kAgcTile - 1) / kAgcTile), hp = (a_max + 15) & ~15;
             // tiles short enough for one to two wavefronts of 64 tiles per SIMD
             int L = 256;
@@ -2204,14 +2218,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 hipLaunchKernelGGL(agc_finish_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_state,
                                    (const double *)agc_scr, agc_arr, (const double2 *)agc_tail, (const double *)agc_fin);
             };
-            run(cur, list_agc_cur, n_agc_cur);
-            run(other, list_agc_other, n_agc_other);
-        } else {
-            if (n_agc_cur) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_cur), dim3(64), 0, stream, cur, buf_cap,
-                                              (int)n_mid, list_agc_cur, agc_prm, agc_state, 1.0);
-            if (n_agc_other) hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)n_agc_other), dim3(64), 0, stream, other,
-                                                buf_cap, (int)n_mid, list_agc_other, agc_prm, agc_state, 1.0);
+            run(cur, list_agc_cur, nt_cur);
+            run(other, list_agc_other, nt_other);
         }
+        if (const int ns = n_agc_cur - nt_cur)
+            hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)ns), dim3(64), 0, stream, cur, buf_cap, (int)n_mid,
+                               (const int *)(list_agc_cur + nt_cur), agc_prm, agc_state, 1.0);
+        if (const int ns = n_agc_other - nt_other)
+            hipLaunchKernelGGL(agc_form == 1 ? wcpagc_seq_kernel : wcpagc_kernel, dim3((unsigned)ns), dim3(64), 0, stream, other, buf_cap, (int)n_mid,
+                               (const int *)(list_agc_other + nt_other), agc_prm, agc_state, 1.0);
     }
     {
         long long per = (n_mid + NT - 1) / NT;
@@ -2932,6 +2947,7 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(e.agc_state[c].ring, 0, sizeof(e.agc_state[c].ring), e.stream));
             QH_HIP(hipMemsetAsync(e.agc_state[c].abs_ring, 0, sizeof(e.agc_state[c].abs_ring), e.stream));
             QH_HIP(hipMemsetAsync(&e.agc_state[c].ring_max, 0, sizeof(double), e.stream));
+            if (e.cfg[(size_t)c].agc_stale) e.lists_dirty = true;
             e.cfg[(size_t)c].agc_stale = false;     // an empty ring and ring_max = 0: nothing stale (qh_agc_tiled.hpp)
         }
         if (e.agc_lring) {
@@ -3050,6 +3066,14 @@ long long qh_rxa_agc_segments_rerun(qh_rxa *h)
     if (hipSetDevice(h->e.device) != hipSuccess || hipStreamSynchronize(h->e.stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, h->e.agc_nfixed + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
+}
+
+// channels whose xwcpagc ran in time tiles in the last call (the others, if any: one wavefront per channel)
+int qh_rxa_agc_tiled_channels(qh_rxa *h)
+{
+    if (!h) return 0;
+    QH_RXA_LOCK(h);
+    return h->e.agc_last_tiled;
 }
 
 // Diagnostics: which form of the wcpAGC loop runs (0: time tiles for long calls, else 64 samples per step of the wavefront; 1: sample by

@@ -88,6 +88,8 @@ def load():
     L.qh_rxa_agc_repairs.restype = ll
     L.qh_rxa_agc_segments_rerun.argtypes = [vp]
     L.qh_rxa_agc_segments_rerun.restype = ll
+    L.qh_rxa_agc_tiled_channels.argtypes = [vp]
+    L.qh_rxa_agc_tiled_channels.restype = i
     L.qh_rxa_process_audio.argtypes = [vp, vp, ll, vp, ll, i, vp]
     L.qh_rxa_process_audio.restype = i
     L.qh_audio_pack.argtypes = [i, vp, vp, ll, i, i, vp, vp, ll]

@@ -152,8 +152,15 @@ class RxaEngine:
     def agc_segments_rerun(self):
         return self._L.qh_rxa_agc_segments_rerun(self._h)
 
+    def agc_tiled_channels(self):
+        return self._L.qh_rxa_agc_tiled_channels(self._h)
+
     def synchronize(self):
         check(self._L.qh_rxa_synchronize(self._h))
+
+    def flush(self):
+        """flush_rxa (wdsp/RXA.c:537-559): every stage's state back to its start"""
+        check(self._L.qh_rxa_flush(self._h))
 
     def set_graph_replay(self, on=True):
         """Block-at-a-time callers: replay the launch sequence of process_ptr from hipGraphs while nothing changes."""

@@ -248,3 +248,37 @@ def test_attack_window_changed_mid_stream_reads_the_full_ring(qh, oracle, form):
             b = a + nb * 256
             assert rel_rms(y[c][a:b], ref[a:b]) < 1e-9, (c, attack, rel_rms(y[c][a:b], ref[a:b]))
             a = b
+
+
+def test_a_moved_attack_window_takes_only_its_own_channel_off_the_time_tiles(qh, oracle):
+    """A channel whose attack window moves in mid-stream keeps the reference's ring_max bookkeeping, stale values and all (wcpAGC.c:197-210
+    rescans only when the sample that leaves equals it), so it is stepped by one wavefront from then on; the other channels of the
+    engine stay on the time tiles -- and all of them follow the oracle.  A flush puts the channel back."""
+    nch, nb = 6, 80                                        # 80 blocks = 20 480 detector samples per call: tiles
+    moved = {1: 4, 4: 3}                                   # channel -> attack in ms ahead of the second call (create_rxa: 1 ms)
+    modes = [3, 1, 4, 2, 3, 4]
+    x = _input(nch, 4 * nb, seed=77)
+    x += 2e-3 * np.exp(2j * np.pi * ((synth.shift_freq(0) + 1500.0) / 192000.0) * np.arange(x.shape[1]))[None, :]
+    e = _engine(qh, nch, modes, 0)
+    refs = []
+    for c in range(nch):
+        o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(c)); o.RXANBPSetRun(1); o.SetRXAMode(1)
+        o.RXASetPassband(300.0, 3000.0); o.SetRXAAGCMode(modes[c])
+        refs.append(o)
+    tiled = []
+    for k in range(4):
+        if k == 1:
+            for c, ms in moved.items():
+                e.SetRXAAGCAttack(c, ms); refs[c].SetRXAAGCAttack(ms)
+        seg = np.ascontiguousarray(x[:, k * nb * 1024:(k + 1) * nb * 1024])
+        y = e.process_host(seg)
+        tiled.append(e.agc_tiled_channels())
+        for c in range(nch):
+            ref = refs[c].xrxa(seg[c])
+            assert np.abs(ref).max() > 1e-3
+            assert rel_rms(y[c], ref) < 1e-9, (k, c, rel_rms(y[c], ref))
+    assert tiled == [nch, nch - 2, nch - 2, nch - 2], tiled
+    e.flush()
+    e.process_host(np.ascontiguousarray(x[:, :nb * 1024]))
+    assert e.agc_tiled_channels() == nch
