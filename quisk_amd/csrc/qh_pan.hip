@@ -176,6 +176,15 @@ __global__ __launch_bounds__(NT, QH_PAN_WAVES) void pan_spectrum_kernel(const do
 #ifndef QH_PAN16K_GROUPS
 #define QH_PAN16K_GROUPS 4
 #endif
+// -DQH_PAN_TRACE=<thread> (experiment builds, tools/dbg/pan_trace.py): that thread of workgroup 0 leaves the shader clock at the phase
+// boundaries of its blocks in qh_pan_trace[block][phase].  (The stamps are stores: a wait that follows them counts their
+// acknowledgement too -- the phases up to the transform are trustworthy, the loop edge is not.)
+#ifdef QH_PAN_TRACE
+__device__ unsigned long long qh_pan_trace[64 * 8];
+#define PAN_STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == QH_PAN_TRACE && blk - b0 < 64) qh_pan_trace[(blk - b0) * 8 + (ph)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PAN_STAMP(ph) do { } while (0)
+#endif
 template <int G> constexpr int pan16k_lds() { return G * FftSplit4096<false, double2>::kLdsBytes; }
 template <int G>
 __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
@@ -228,7 +237,9 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
         const double *xr = xch + (s * 16) * 256 + t;                        // + i * 256
         C e = e0;
         asm volatile("" : "+v"(e.x), "+v"(e.y));
+        PAN_STAMP(6);
         __syncthreads();                    // the images are free: the previous block's transform has been read out
+        PAN_STAMP(0);
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
             const C x0 = x[256 * j], x1 = x[256 * j + M], x2 = x[256 * j + 2 * M], x3 = x[256 * j + 3 * M];
@@ -260,7 +271,9 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
             __builtin_amdgcn_sched_barrier(0);
         }
         C u[E];
+        PAN_STAMP(1);                       // loads, window, radix-4, first exchange writes: done by this thread
         __syncthreads();
+        PAN_STAMP(2);                       // ... by the workgroup
 #pragma unroll
         for (int i = 0; i < E; i++) u[i].x = xr[i * 256];
         __syncthreads();
@@ -276,7 +289,9 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
         // block loop, and spills them)
         typename S::Tw twb = twf;
         asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
+        PAN_STAMP(3);                       // the exchange between the residue groups
         S::run_at(u, image, twb, t);
+        PAN_STAMP(4);                       // the 4096-point transform
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
             if (in_band) m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        PAN_STAMP(5);                       // |X| and the sums
     }
     // partial[split][ch][r][t + 256 i] for bin = 4 (t + 256 i) + r (pan_reduce_kernel undoes the order): coalesced stores; a block range
     // that came out empty (nblk not a multiple of the ranges) stores its zeros
@@ -1316,3 +1332,11 @@ int qh_bscope_graph(qh_bscope *b, int clock, double zoom, double deltaf, double 
 }
 
 }  // extern "C"
+
+#ifdef QH_PAN_TRACE
+extern "C" int qh_pan_debug_trace(unsigned long long *out, int n)
+{
+    if (n > 64 * 8) n = 64 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(qh::qh_pan_trace), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
