@@ -54,6 +54,9 @@ int set_error(int code, const char *fmt, ...)
 static constexpr int kNfft = 4096;          // FFT size of the front stage and, for nc <= 2048, of the fircore stages
 static constexpr int kBandNfftMax = 8192;   // fircore stages with 2048 < nc <= 4096 run 8192-point tiles (Engine::bnfft)
 static constexpr int kHistBand = 4095;      // fircore history capacity: nc up to 4096
+// nc = 8192 / 16384 (RXASetNC, wdsp/RXA.c:934-946): the impulse response in partitions of 4096 taps, every partition an ordinary
+// 8192-point tile pass over a view of the stream that starts 4096 p samples earlier, the passes added (Engine::run_band)
+static constexpr int kLongPart = 4096, kLongNcMax = 16384, kLongParts = kLongNcMax / kLongPart, kLongHist = kLongNcMax - 1;
 static constexpr int kHistFront = 2240;     // resampler history capacity: 140 * D taps, D <= 16
 // FM PLL time tiles (qh_tiled.hpp).  On a carrier the loop (double pole at 0.66 per sample) forgets its start state in ~100
 // samples; on noise alone two runs meet after ~135 samples on average with an exponential tail, so a 768-sample warm-up
@@ -176,6 +179,17 @@ struct Engine {
     double2 *mask_snb = nullptr, *hist_snb[2] = { nullptr, nullptr };
     double2 *buf[2] = { nullptr, nullptr };
     long long buf_cap = 0;                  // complex samples per channel
+    // long impulse responses (nc > 4096), per fircore stage s = 0 nbp0, 1 bp1, 2 FM de-emphasis, 3 FM audio filter, 4 bpsnba:
+    // long_parts[s] partitions (1: the ordinary path), their masks lmask[s] ([nch or 1][kLongParts][8192]), the stage's last kLongHist
+    // input samples lhist[s][ping-pong][nch][kLongHist]; lcat: history + block of the stage being run, ltmp: a partition's output
+    int long_parts[5] = { 1, 1, 1, 1, 1 };
+    double2 *lmask[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    double2 *lhist[5][2] = { { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr } };
+    double2 *lcat = nullptr, *ltmp = nullptr;
+    long long lcat_cap = 0;                 // the buf_cap they were made for
+    int long_stage_alloc(int sid, bool shared_mask);
+    int long_buffers();
+    int long_masks_upload(int sid, long long row, const std::vector<cd> &h);
     long long dev_bytes = 0;
     // timing
     bool timing = false;
@@ -340,6 +354,8 @@ Engine::~Engine()
     if (rsmpin) qh_rat_destroy(rsmpin);
     (void)hipFree(fbuf);
     (void)hipFree(obuf); (void)hipFree(abuf);
+    for (int i = 0; i < 5; i++) { (void)hipFree(lmask[i]); (void)hipFree(lhist[i][0]); (void)hipFree(lhist[i][1]); }
+    (void)hipFree(lcat); (void)hipFree(ltmp);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front); (void)hipFree(tw8192);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
@@ -495,7 +511,7 @@ static unsigned long long turns_fx(double f, double rate)
 int Engine::refresh_params()
 {
     // one pass over the channels; upload only what changed
-    std::vector<cd> last_nbp, last_bp1;
+    std::vector<cd> last_nbp, last_bp1, last_nbp_h, last_bp1_h;      // masks and impulse responses of the last design made
     const ChanCfg *last_nbp_cfg = nullptr, *last_bp1_cfg = nullptr;
     // Oscillator changes (SetRXAShiftFreq / SetRXAShiftRun).  With a front FIR stage (D > 1) the oscillator sits behind
     // the filter: first the stored raw history of every changed channel is re-expressed for its new phase law (the kernel
@@ -568,6 +584,7 @@ int Engine::refresh_params()
             }
             std::vector<cd> h;
             const double scale = 1.0 / (double)(2 * dsp_size);
+            if (long_parts[4] > 1) if (int rc = long_stage_alloc(4, false)) return rc;
             if (run_notches) {
                 const double offset = c.ndb_tunefreq + c.ndb_shift;
                 const double minwidth = (c.nbp_wintype == 1 ? 2200.0 : 1600.0) / (c.nbp_nc / 256) * ((double)dsp_rate / 48000);
@@ -578,14 +595,18 @@ int Engine::refresh_params()
                 h = fir_bandpass(c.nbp_nc, f_low, f_high, (double)dsp_rate, c.nbp_wintype, 1, scale);
             if (c.mp) h = mp_imp(h, 16, 0);
             for (auto &v : h) v *= (double)(2 * dsp_size);
+            if (long_parts[4] > 1) if (int rc = long_masks_upload(4, ch, h)) return rc;
+            if ((int)h.size() > kLongPart) h.resize((size_t)kLongPart);      // (the one-tile mask is not used then)
             const std::vector<cd> m = band_mask(h);
             QH_HIP(hipMemcpyAsync(mask_snb + (size_t)ch * kBandNfftMax, m.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.snb_dirty = false;
         }
         if (c.snb_flush && hist_snb[0]) {           // setNc_fircore zeroes the delay line
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++) {
                 QH_HIP(hipMemsetAsync(hist_snb[i] + (size_t)ch * kHistBand, 0, kHistBand * sizeof(double2), stream));
+                if (lhist[4][i]) QH_HIP(hipMemsetAsync(lhist[4][i] + (size_t)ch * kLongHist, 0, kLongHist * sizeof(double2), stream));
+            }
         }
         c.snb_flush = false;
         if (c.nbp_dirty) {
@@ -611,9 +632,12 @@ int Engine::refresh_params()
                 if (c.nbp_run && c.mp) h = mp_imp(h, 16, 0);            // calc_fircore, wdsp/firmin.c:327-328
                 // the reference's unnormalised inverse FFT of 2*size points restores the 1/(2*size)
                 if (c.nbp_run) for (auto &v : h) v *= (double)(2 * dsp_size);
+                last_nbp_h = h;
+                if ((int)h.size() > kLongPart) h.resize((size_t)kLongPart);      // (the one-tile mask is not used then)
                 last_nbp = band_mask(h);
                 last_nbp_cfg = &c;
             }
+            if (long_parts[0] > 1) if (int rc = long_masks_upload(0, ch, last_nbp_h)) return rc;
             QH_HIP(hipMemcpyAsync(mask_nbp + (size_t)ch * kBandNfftMax, last_nbp.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.nbp_dirty = false;
@@ -632,22 +656,29 @@ int Engine::refresh_params()
                 } else {
                     h.assign(1, cd(1.0, 0.0));
                 }
+                last_bp1_h = h;
+                if ((int)h.size() > kLongPart) h.resize((size_t)kLongPart);
                 last_bp1 = band_mask(h);
                 last_bp1_cfg = &c;
             }
+            if (long_parts[1] > 1) if (int rc = long_masks_upload(1, ch, last_bp1_h)) return rc;
             QH_HIP(hipMemcpyAsync(mask_bp1 + (size_t)ch * kBandNfftMax, last_bp1.data(), (size_t)bnfft * sizeof(cd), hipMemcpyHostToDevice, stream));
             QH_HIP(hipStreamSynchronize(stream));
             c.bp1_dirty = false;
             lists_dirty = true;             // the channel pairs of the real bp1 filters follow the designs
         }
         if (c.nbp_flush) {      // setNc_fircore re-plans and so zeroes the delay line, wdsp/firmin.c:454-466
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++) {
                 QH_HIP(hipMemsetAsync(hist_nbp[i] + (size_t)ch * kHistBand, 0, kHistBand * sizeof(double2), stream));
+                if (lhist[0][i]) QH_HIP(hipMemsetAsync(lhist[0][i] + (size_t)ch * kLongHist, 0, kLongHist * sizeof(double2), stream));
+            }
             c.nbp_flush = false;
         }
         if (c.bp1_flush) {      // flush_bandpass on off->on (RXA.c:825) and setNc_fircore
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++) {
                 QH_HIP(hipMemsetAsync(hist_bp1[i] + (size_t)ch * kHistBand, 0, kHistBand * sizeof(double2), stream));
+                if (lhist[1][i]) QH_HIP(hipMemsetAsync(lhist[1][i] + (size_t)ch * kLongHist, 0, kLongHist * sizeof(double2), stream));
+            }
             c.bp1_flush = false;
         }
     }
@@ -1113,11 +1144,18 @@ int Engine::refresh_demod()
         for (auto &v : au) v *= (double)(2 * dsp_size);
         de_real = true;
         for (const cd &v : de) de_real = de_real && v.imag() == 0.0;
+        if (long_parts[2] > 1) {
+            if (int rc = long_masks_upload(2, 0, de)) return rc;
+            if (int rc = long_masks_upload(3, 0, au)) return rc;
+            de.resize((size_t)kLongPart); au.resize((size_t)kLongPart);      // (the one-tile masks are not used then)
+        }
         if (int rc = upload(mask_de, band_mask(de), stream)) return rc;
         if (int rc = upload(mask_aud, band_mask(au), stream)) return rc;
         fm_nfft_built = 2 * bnfft + (band2g ? 1 : 0);
         if (fm_nc_built && fm_nc_built != want_nc) {      // setNc_fircore zeroes the delay lines, wdsp/firmin.c:454-466
             for (int i = 0; i < 2; i++) {
+                if (lhist[2][i]) QH_HIP(hipMemsetAsync(lhist[2][i], 0, (size_t)nch * kLongHist * sizeof(double2), stream));
+                if (lhist[3][i]) QH_HIP(hipMemsetAsync(lhist[3][i], 0, (size_t)nch * kLongHist * sizeof(double2), stream));
                 QH_HIP(hipMemsetAsync(hist_de[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
                 QH_HIP(hipMemsetAsync(hist_aud[i], 0, (size_t)nch * kHistBand * sizeof(double2), stream));
             }
@@ -1527,12 +1565,119 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
     return QH_OK;
 }
 
+// ---- impulse responses longer than 4096 taps (kLongPart) -------------------------------------------------------------------
+// lcat[ch] = [the stage's last kLongHist input samples | this call's block]
+static __global__ __launch_bounds__(NT) void long_gather_kernel(const double2 *hist, const double2 *src, long long src_stride, int n, double2 *cat,
+                                                                long long cat_stride, const int *chan_list)
+{
+    const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    const double2 *h = hist + (long long)ch * kLongHist, *x = src + (long long)ch * src_stride;
+    double2 *c = cat + (long long)ch * cat_stride;
+    const long long tot = (long long)kLongHist + n;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < tot; i += (long long)gridDim.x * NT) c[i] = i < kLongHist ? h[i] : x[i - kLongHist];
+}
+// the history the next call finds: the last kLongHist samples of lcat
+static __global__ __launch_bounds__(NT) void long_hist_kernel(const double2 *cat, long long cat_stride, int n, double2 *hist, const int *chan_list)
+{
+    const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    const double2 *c = cat + (long long)ch * cat_stride + n;
+    double2 *h = hist + (long long)ch * kLongHist;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < kLongHist; i += gridDim.x * NT) h[i] = c[i];
+}
+static __global__ __launch_bounds__(NT) void long_add_kernel(double2 *dst, long long dst_stride, const double2 *add, long long add_stride, int n, const int *chan_list)
+{
+    const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    double2 *d = dst + (long long)ch * dst_stride;
+    const double2 *a = add + (long long)ch * add_stride;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) { d[i].x += a[i].x; d[i].y += a[i].y; }
+}
+
+int Engine::long_stage_alloc(int sid, bool shared_mask)
+{
+    if (lmask[sid]) return QH_OK;
+    QH_HIP(hipStreamSynchronize(stream));
+    drop_graphs(); epoch++;
+    const size_t rows = shared_mask ? 1 : (size_t)nch;
+    QH_HIP(dev_alloc(&lmask[sid], rows * kLongParts * kBandNfftMax));
+    QH_HIP(hipMemsetAsync(lmask[sid], 0, rows * kLongParts * kBandNfftMax * sizeof(double2), stream));
+    for (int i = 0; i < 2; i++) {
+        QH_HIP(dev_alloc(&lhist[sid][i], (size_t)nch * kLongHist));
+        QH_HIP(hipMemsetAsync(lhist[sid][i], 0, (size_t)nch * kLongHist * sizeof(double2), stream));
+    }
+    dev_bytes += (long long)(rows * kLongParts * kBandNfftMax + 2 * (size_t)nch * kLongHist) * (long long)sizeof(double2);
+    return QH_OK;
+}
+int Engine::long_buffers()
+{
+    if (lcat && lcat_cap == buf_cap) return QH_OK;
+    QH_HIP(hipStreamSynchronize(stream));
+    if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
+    drop_graphs(); epoch++;
+    if (lcat) dev_bytes -= (long long)nch * (2 * lcat_cap + kLongHist) * (long long)sizeof(double2);
+    (void)hipFree(lcat); (void)hipFree(ltmp); lcat = ltmp = nullptr;
+    QH_HIP(dev_alloc(&lcat, (size_t)nch * (size_t)(kLongHist + buf_cap)));
+    QH_HIP(dev_alloc(&ltmp, (size_t)nch * (size_t)buf_cap));
+    lcat_cap = buf_cap;
+    dev_bytes += (long long)nch * (2 * lcat_cap + kLongHist) * (long long)sizeof(double2);
+    return QH_OK;
+}
+// the kLongParts partition masks of the impulse response h (8192-point spectra of its 4096-tap slices; the slices past its end zero)
+int Engine::long_masks_upload(int sid, long long row, const std::vector<cd> &h)
+{
+    std::vector<cd> all((size_t)kLongParts * kBandNfftMax, cd(0.0, 0.0));
+    for (int p = 0; p < kLongParts && (size_t)p * kLongPart < h.size(); p++) {
+        const size_t a = (size_t)p * kLongPart, b = std::min(h.size(), a + (size_t)kLongPart);
+        const std::vector<cd> m = make_mask(std::vector<cd>(h.begin() + (long)a, h.begin() + (long)b), kBandNfftMax);
+        std::copy(m.begin(), m.end(), all.begin() + (long)((size_t)p * kBandNfftMax));
+    }
+    QH_HIP(hipMemcpyAsync(lmask[sid] + (size_t)row * kLongParts * kBandNfftMax, all.data(), all.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
+    QH_HIP(hipStreamSynchronize(stream));
+    return QH_OK;
+}
+
 // one fircore stage (overlap-save, D = 1) over all channels (list == nullptr) or a sub-set
 void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, long long dst_stride, const EpiParam *ep,
                       long long n_mid, const double2 *mask, long long mask_stride, double2 **hist, int &hc, int P,
                       const int *list, int nlist, bool meter, bool egress, int det, double *det_out, long long det_stride,
                       const int *pairs, int npairs)
 {
+    const int sid = hist == hist_nbp ? 0 : hist == hist_bp1 ? 1 : hist == hist_de ? 2 : hist == hist_aud ? 3 : 4;
+    if (long_parts[sid] > 1) {
+        // nc > 4096: y = sum_p h_p * (x delayed by 4096 p).  lcat holds the stage's last 16383 samples and the block in one row per
+        // channel, so partition p is the ordinary tile pass (4096 taps, 8192 points, 4097 outputs per tile) over a row that begins
+        // 4096 p samples further back; the partitions' outputs are added, the epilogue follows as a pass of its own.  (The callers
+        // switch every fusion off for such a call: no meters, audio frames or detector steps in this stage's stores.)
+        const int K = long_parts[sid], Pk = kLongPart - 1, Lk = kBandNfftMax - Pk, nt = (int)((n_mid + Lk - 1) / Lk);
+        const int nl = list ? nlist : nch;
+        const long long cat_stride = kLongHist + lcat_cap;
+        const long long per = (kLongHist + n_mid + NT - 1) / NT;
+        tick(1);
+        hipLaunchKernelGGL(long_gather_kernel, dim3((unsigned)(per < 2048 ? per : 2048), (unsigned)nl), dim3(NT), 0, stream, (const double2 *)lhist[sid][hc], src,
+                           src_stride, (int)n_mid, lcat, cat_stride, list);
+        for (int p = 0; p < K; p++) {
+            OsfirArgs<double> a{};
+            a.in = lcat + kLongHist - (long long)kLongPart * p; a.in_stride = cat_stride;
+            a.hist = a.in - Pk; a.hist_stride = cat_stride; a.hist_len = Pk;
+            a.out = p ? ltmp : dst; a.out_stride = p ? lcat_cap : dst_stride; a.out_offset = 0;
+            a.mask = lmask[sid] + (size_t)p * kBandNfftMax; a.mask_stride = mask_stride ? (long long)kLongParts * kBandNfftMax : 0;
+            a.tw_fwd = a.tw_inv = tw8192;
+            a.tw_r2 = tw8192 + 32;
+            a.chan_list = list;
+            a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = Pk; a.Lout = Lk;
+            launch_band<kBandNfftMax>(a, nt, nl, stream, false, false);
+            const long long pn = (n_mid + NT - 1) / NT;
+            if (p) hipLaunchKernelGGL(long_add_kernel, dim3((unsigned)(pn < 1024 ? pn : 1024), (unsigned)nl), dim3(NT), 0, stream, dst, dst_stride,
+                                      (const double2 *)ltmp, lcat_cap, (int)n_mid, list);
+        }
+        const long long pn = (n_mid + NT - 1) / NT;
+        if (ep) hipLaunchKernelGGL((pointwise_kernel<double, false>), dim3((unsigned)(pn < 1024 ? pn : 1024), (unsigned)nl), dim3(NT), 0, stream,
+                                   (const double2 *)dst, dst_stride, dst, dst_stride, (int)n_mid, (const unsigned long long *)nullptr,
+                                   (const unsigned long long *)nullptr, ep, list);
+        tick(2);
+        hipLaunchKernelGGL(long_hist_kernel, dim3(64, (unsigned)nl), dim3(NT), 0, stream, (const double2 *)lcat, cat_stride, (int)n_mid, lhist[sid][hc ^ 1], list);
+        hc ^= 1;
+        return;
+    }
     const int Lout = bnfft - P;
     const int ntiles = (int)((n_mid + Lout - 1) / Lout);
     OsfirArgs<double> a{};
@@ -1686,7 +1831,32 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         if (c.bp1_run) { any_bp1 = true; if (c.bp1_nc > nc_max) nc_max = c.bp1_nc; }
         if (c.fmd_run && c.fm_nc > nc_max) nc_max = c.fm_nc;
     }
-    if (nc_max - 1 > kHistBand) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kHistBand + 1);
+    if (nc_max > kLongNcMax) return set_error(QH_ERR_UNSUPPORTED, "nc = %d exceeds %d", nc_max, kLongNcMax);
+    // stages whose impulse response is longer than 4096 taps run in partitions (run_band): how many, per stage
+    bool long_mode = false;
+    {
+        auto parts = [](int nc) { return nc > kLongPart ? (nc + kLongPart - 1) / kLongPart : 1; };
+        int lp[5] = { 1, 1, 1, 1, 1 };
+        for (const ChanCfg &c : cfg) {
+            if (c.nbp_run) lp[0] = std::max(lp[0], parts(c.nbp_nc));
+            if (c.bp1_run) lp[1] = std::max(lp[1], parts(c.bp1_nc));
+            if (c.fmd_run) lp[2] = lp[3] = std::max(lp[2], parts(c.fm_nc));
+            if (c.snba_run) lp[4] = std::max(lp[4], parts(c.nbp_nc));
+        }
+        for (int sid = 0; sid < 5; sid++) {
+            if (lp[sid] > 1) { long_mode = true; if (int rc = long_stage_alloc(sid, sid == 2 || sid == 3)) return rc; }
+            if (lp[sid] == long_parts[sid]) continue;
+            QH_HIP(hipStreamSynchronize(stream));
+            drop_graphs(); epoch++;
+            long_parts[sid] = lp[sid];
+            for (ChanCfg &c : cfg) {            // the stage's masks are laid out for another form now: all of them again
+                if (sid == 0) c.nbp_dirty = true;
+                if (sid == 1) c.bp1_dirty = true;
+                if (sid == 4) c.snb_dirty = true;
+            }
+            if (sid == 2 || sid == 3) fm_nc_built = 0;
+        }
+    }
     {   // The fircore tile.  Impulse responses longer than 2048 taps need 8192 points (osfir_kernel<8192>, one wave per SIMD).
         // Shorter ones run 4096-point tiles; the two-group 8192-point tile (osfir8k_kernel, 6144 instead of 2049 outputs per
         // pair of transforms) is there on request (qh_rxa_set_band_tile) -- it measured slower, see qh_osfir.hpp.  The masks are
@@ -1703,7 +1873,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // The three meters of xrxa (adc, S, agc: RXA.c:566,569,589) ride on the nbp0 launch when the chain is linear (nbp0 runs,
     // bp1 does not, fixed AGC gain): the band tile then starts on a multiple of 256 samples so that a register holds one
     // 64-sample chunk per wavefront.  Any other chain takes the per-mode path with the stand-alone meter kernel.
-    const bool meters_fused = meters_on && !mixed && any_nbp && !any_bp1 && dsp_size >= 64 && dsp_size <= 2048;
+    const bool meters_fused = meters_on && !mixed && any_nbp && !any_bp1 && dsp_size >= 64 && dsp_size <= 2048 && !long_mode;
     if (meters_on && !meters_fused) mixed = true;
     if (meters_on) if (int rc = meters_alloc()) return rc;
     if (int rc = refresh_params()) return rc;
@@ -1714,15 +1884,17 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     const long long n_mid = (long long)nblk * dsp_size;
     if (n_in > 0x7fffffffLL) return set_error(QH_ERR_INVALID, "too many samples in one call");
     if (int rc = ensure_buffers(n_mid)) return rc;
+    if (long_mode) if (int rc = long_buffers()) return rc;
     ev_used = 0;
 
     const double2 *in = reinterpret_cast<const double2 *>(d_in);
     double2 *out = reinterpret_cast<double2 *>(d_out);
-    const int P = band6k ? kOsfir6kP : band2g ? kOsfir8kP : meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : nc_max - 1;
+    // (with a partitioned stage in the call the others run 4096-tap tiles: their own nc is at most that)
+    const int P = band6k ? kOsfir6kP : band2g ? kOsfir8kP : meters_fused ? ((nc_max - 1 + 255) / 256) * 256 : long_mode ? kLongPart - 1 : nc_max - 1;
 
     // audio egress (qh_rxa_process_audio): the narrowing rides in the store of the last kernel when that is an overlap-save
     // band stage or the per-mode path's output pass; other endings write complex doubles to the staging rows and narrow after
-    const bool eg_fused = eg.kind && (mixed ? n_amsq == 0 : (any_nbp || any_bp1));
+    const bool eg_fused = eg.kind && (mixed ? n_amsq == 0 : ((any_nbp || any_bp1) && !long_mode));
     if (eg.kind && !eg_fused) {
         if (int rc = ensure_abuf(n_mid)) return rc;
         out = abuf; out_stride = abuf_cap;
@@ -2517,8 +2689,8 @@ int qh_rxa_RXASetPassband(qh_rxa *h, int ch, double f_low, double f_high)
 
 int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
 {
-    if (nc < 1 || (nc & (nc - 1)) || nc > kHistBand + 1 || (h && nc < h->e.dsp_size))
-        return set_error(QH_ERR_UNSUPPORTED, "nc must be a power of two in [dsp_size, %d]", kHistBand + 1);
+    if (nc < 1 || (nc & (nc - 1)) || nc > kLongNcMax || (h && nc < h->e.dsp_size))
+        return set_error(QH_ERR_UNSUPPORTED, "nc must be a power of two in [dsp_size, %d]", kLongNcMax);
     FOR_CH(h, ch, {
         if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; c.snb_flush = true; }
         if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; }
@@ -2941,6 +3113,8 @@ int qh_rxa_flush(qh_rxa *h)
             QH_HIP(hipMemsetAsync(e.hist_de[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
             QH_HIP(hipMemsetAsync(e.hist_aud[i], 0, (size_t)e.nch * kHistBand * sizeof(double2), e.stream));
         }
+        for (int sid = 0; sid < 5; sid++)
+            if (e.lhist[sid][i]) QH_HIP(hipMemsetAsync(e.lhist[sid][i], 0, (size_t)e.nch * kLongHist * sizeof(double2), e.stream));
     }
     if (e.demod_alloc) {                        // flush_wcpagc zeroes the ring (wcpAGC.c:154-159)
         for (int c = 0; c < e.nch; c++) {
