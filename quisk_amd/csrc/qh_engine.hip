@@ -1592,6 +1592,20 @@ static __global__ __launch_bounds__(NT) void long_add_kernel(double2 *dst, long 
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) { d[i].x += a[i].x; d[i].y += a[i].y; }
 }
 
+// a stage changes between the one-tile form and the partitioned one because ONE channel's nc moved: the other channels' delay lines go
+// along (the 4095 samples of the short history are the tail of the long one; the channel whose nc moved is flushed afterwards, as
+// setNc_fircore does)
+static __global__ __launch_bounds__(NT) void long_migrate_kernel(double2 *hist, double2 *lhist, int to_long)
+{
+    const int ch = blockIdx.y;
+    double2 *h = hist + (long long)ch * kHistBand, *l = lhist + (long long)ch * kLongHist;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < kLongHist; i += gridDim.x * NT) {
+        const int j = i - (kLongHist - kHistBand);
+        if (to_long) l[i] = j >= 0 ? h[j] : make_double2(0.0, 0.0);
+        else if (j >= 0) h[j] = l[i];
+    }
+}
+
 int Engine::long_stage_alloc(int sid, bool shared_mask)
 {
     if (lmask[sid]) return QH_OK;
@@ -1848,6 +1862,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             if (lp[sid] == long_parts[sid]) continue;
             QH_HIP(hipStreamSynchronize(stream));
             drop_graphs(); epoch++;
+            if ((lp[sid] > 1) != (long_parts[sid] > 1)) {       // the delay lines move with the form
+                double2 **hs = sid == 0 ? hist_nbp : sid == 1 ? hist_bp1 : sid == 2 ? hist_de : sid == 3 ? hist_aud : hist_snb;
+                const int cur = sid == 0 ? cur_nbp : sid == 1 ? cur_bp1 : sid == 2 ? cur_de : sid == 3 ? cur_aud : cur_snb;
+                if (hs[cur] && lhist[sid][cur])
+                    hipLaunchKernelGGL(long_migrate_kernel, dim3(16, (unsigned)nch), dim3(NT), 0, stream, hs[cur], lhist[sid][cur], lp[sid] > 1 ? 1 : 0);
+            }
             long_parts[sid] = lp[sid];
             for (ChanCfg &c : cfg) {            // the stage's masks are laid out for another form now: all of them again
                 if (sid == 0) c.nbp_dirty = true;

@@ -79,6 +79,30 @@ def test_nc_changed_in_mid_stream_and_mixed_in_one_engine(qh, oracle):
     e.close()
 
 
+def test_a_stage_changing_form_takes_the_other_channels_delay_lines_along(qh, oracle):
+    """One channel's nc going over 4096 turns the stage's passes into partitions for every channel of the engine (and back): the
+    others' delay lines must not notice -- they were found restarting by a seeded setter walk (tests/test_gpu_rxa_fuzz.py)."""
+    nch = 3
+    plan = [(20, None), (30, 8192), (1, None), (25, 2048), (20, 16384), (15, 512)]      # channel 1's nc ahead of the stretch
+    for mode, passband, sig in ((1, (300.0, 3000.0), None), (6, (-4000.0, 4000.0), "am")):
+        n = sum(p[0] for p in plan) * 1024
+        x = synth.make_input_numpy(nch, n) if sig is None else np.stack([synth.make_mode_input_numpy(sig, c, n) for c in range(nch)])
+        e = qh.RxaEngine(nch)
+        _setup(e, nch, mode=mode, passband=passband)
+        refs = [_oracle(oracle, c, mode=mode, passband=passband) for c in range(nch)]
+        pos = 0
+        for k, (nb, nc) in enumerate(plan):
+            if nc:
+                e.RXASetNC(1, nc); refs[1].RXASetNC(nc)
+            seg = np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024])
+            pos += nb
+            y = e.process_host(seg)
+            for c in range(nch):
+                ref = refs[c].xrxa(seg[c])
+                assert rel_rms(y[c], ref) < 1e-9, (mode, k, c, rel_rms(y[c], ref))
+        e.close()
+
+
 def test_through_the_wdsp_names_block_by_block(qh, oracle):
     """OpenChannel + RXASetNC(8192) + fexchange0: one DSP block per call, the partitions inside every block."""
     from test_gpu_wdsp_dropin import _open, _run
