@@ -734,8 +734,8 @@ int qh_qps_set_auto_notch(qh_qps *h, int on, int rit_freq);                /* se
 int qh_qps_invert_spectrum(qh_qps *h, int invert);                         /* quisk.c:4535 */
 int qh_qps_set_kill_audio(qh_qps *h, int kill);
 int qh_qps_add_tone(qh_qps *h, int freq);                                  /* add_tone, quisk.c:3203; 0 = off */
-int qh_qps_set_squelch(qh_qps *h, int ch, double level);                   /* set_squelch (FM), quisk.c:4721 */
-int qh_qps_set_ssb_squelch(qh_qps *h, int enabled, int level);             /* set_ssb_squelch, quisk.c:4729 */
+int qh_qps_set_squelch(qh_qps *h, int ch, double level);                   /* set_squelch, quisk.c:4721: looked at by the FM demodulator alone -- accepted and without effect in a bank of another mode, like the reference's */
+int qh_qps_set_ssb_squelch(qh_qps *h, int enabled, int level);             /* set_ssb_squelch, quisk.c:4729: CW, SSB and AM banks; accepted and without effect in an FM bank */
 /* long calls run as `pieces` time pieces, process_agc of one beside the filters of the next (0 = chosen by call length) */
 int qh_qps_set_pieces(qh_qps *h, int pieces);
 int qh_qps_filter_rate(qh_qps *h);                                         /* get_filter_rate, quisk.c:2787 */

@@ -222,14 +222,15 @@ int qh_qps_add_tone(qh_qps *h, int freq)                                        
 int qh_qps_set_squelch(qh_qps *h, int ch, double level)                                                                                      // set_squelch (FM), quisk.c:4721
 {
     QPS_ENTER(h);
-    if (!is_fm_mode(h->mode)) return set_error(QH_ERR_UNSUPPORTED, "set_squelch acts on the FM modes (quisk.c:2076-2085)");
+    if (ch < -1 || ch >= h->nch) return set_error(QH_ERR_INVALID, "qh_qps_set_squelch: receiver %d of %d", ch, h->nch);
+    if (!is_fm_mode(h->mode)) return QH_OK;        // the level is looked at by the FM demodulator alone (quisk.c:2076-2085); a bank keeps its mode
     h->squelch_can_act = true;
     return qh_qrx_set_squelch(h->rx, ch, level);
 }
 int qh_qps_set_ssb_squelch(qh_qps *h, int enabled, int level)                                                                                // quisk.c:4729
 {
     QPS_ENTER(h);
-    if (!has_ssb_squelch(h->mode)) return set_error(QH_ERR_UNSUPPORTED, "ssb_squelch belongs to the CW, SSB and AM modes (quisk.c:1925,1970,2020)");
+    if (!has_ssb_squelch(h->mode)) return QH_OK;   // ssb_squelch is called by the CW, SSB and AM demodulators alone (quisk.c:1925,1970,2020); a bank keeps its mode
     if (enabled) h->squelch_can_act = true;
     return qh_qrx_set_ssb_squelch(h->rx, enabled, level);
 }
@@ -259,6 +260,10 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     if (P <= 0) P = n >= (1 << 15) ? 4 : 1;       // (measured at 256 x 2^20: 1 piece 4.12 ms, 4: 3.60, 8: 3.65, 16: 3.57, 32: 4.0)
     if (!h->agc_started) P = 1;
     h->agc_started = true;
+    // The squelches are the CALL's: the FM squelch averages the level over the block it is given and mutes that block (quisk.c:2076-2085,
+    // 2716), ssb_squelch counts its one-second timer down by the block length once per call, its first call only makes the plan, and the
+    // flag it leaves mutes the whole block (quisk.c:1104-1112,1173-1176,2712-2728).  A call cut into pieces would decide piece by piece.
+    if (h->squelch_can_act) P = 1;
     // (a short first piece, so that the AGC -- the long pole: one dependent chain per receiver -- starts early, was measured: no gain)
     const int per = ((n + P - 1) / P + 63) / 64 * 64;
     const int cap_bank = qh_qrx_out_count(h->rx, n) + 64 * (P + 1);
