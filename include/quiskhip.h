@@ -664,7 +664,9 @@ void qh_quisk_set_rx_mode(int mode);                        /* set_rx_mode, quis
 int qh_quisk_set_filters(const double *filtI, const double *filtQ, int size, int bandwidth);       /* set_filters, quisk.c:4551 */
 void qh_quisk_set_agc(double level);                        /* set_agc, quisk.c:4543 */
 void qh_quisk_set_noise_blanker(int level);                 /* set_noise_blanker, quisk.c:4605 */
-void qh_quisk_set_auto_notch(int on, int rit_freq);         /* set_auto_notch, quisk.c:4596; rit_freq of set_sidetone, quisk.c:4712 */
+void qh_quisk_set_auto_notch(int on, int rit_freq);         /* set_auto_notch, quisk.c:4596: the flag and the notch's restart.  rit_freq is IGNORED (kept for callers of earlier
+                                                                 versions): the RIT is the one qh_quisk_set_sidetone set, the reference's global (quisk.c:4712) -- it also tunes the split
+                                                                 receiver (quisk.c:2538) */
 int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
 int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
 int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */

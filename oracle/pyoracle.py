@@ -582,7 +582,7 @@ class OracleQuiskBlock:
                "qo_ps_invert_spectrum": [V, I], "qo_ps_set_noise_blanker": [V, I], "qo_ps_set_auto_notch": [V, I],
                "qo_ps_set_squelch": [V, D], "qo_ps_set_ssb_squelch": [V, I, I], "qo_ps_add_tone": [V, I],
                "qo_ps_measure_frequency": [V, I], "qo_ps_set_graph": [V, V], "qo_ps_set_wdsp": [V, V, V, V],
-               "qo_ps_sub_rx1_audio": [V, V, I], "qo_ps_squelch_flags": [V], "qo_ps_process": [V, V, I],
+               "qo_ps_sub_rx1_audio": [V, V, I], "qo_ps_squelch_flags": [V], "qo_ps_overrun": [V], "qo_ps_process": [V, V, I],
                "qo_ps_restart_bank": [V, I]}
         for name, args in sig.items():
             getattr(L, name).argtypes = args
@@ -651,9 +651,13 @@ class OracleQuiskBlock:
 
     def process(self, x):
         x = np.ascontiguousarray(x, dtype=np.complex128)
+        if x.size > 66000:          # SAMP_BUFFER_SIZE (quisk.h:15): the reference's -- and the restatement's -- work arrays end there
+            raise ValueError("quisk_process_samples takes at most 66000 samples per call")
         buf = np.zeros(max(x.size, 16) * (self.ratio + 1), dtype=np.complex128)
         buf[:x.size] = x
         n = self.L.qo_ps_process(self.h, buf.ctypes.data, x.size)
+        if self.L.qo_ps_overrun(self.h):
+            raise ValueError("Buffer2Chan (quisk.c:1577) holds 12000 audio samples per call: the reference overruns its arrays beyond that")
         return buf[:n].copy() if n > 0 else buf[:0].copy()
 
     def __del__(self):

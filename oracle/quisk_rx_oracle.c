@@ -766,6 +766,7 @@ struct qo_ps {
     double ttV[2], audioV[2];
     /* Buffer2Chan statics */
     int nbuf1, nbuf2;
+    int b2c_overrun;                /* a call handed Buffer2Chan more than its arrays hold: the reference writes past them there (quisk.c:1589-1595) */
     double buf1[BUF2CHAN_SIZE], buf2[BUF2CHAN_SIZE];
     /* cFracDecim statics */
     double fd_dindex, fd_c0[2], fd_c1[2], fd_c2[2];
@@ -894,6 +895,7 @@ void qo_ps_restart_bank(qo_ps *p, int b)
     p->bank[b]->rit_freq = p->rit_freq;
 }
 int qo_ps_squelch_flags(const qo_ps *p) { return p->squelch_real | (p->squelch_imag << 1); }
+int qo_ps_overrun(const qo_ps *p) { return p->b2c_overrun; }
 
 static void cmul_inplace(double *a, const double *b)   /* a *= b */
 {
@@ -945,6 +947,12 @@ static int Buffer2Chan(qo_ps *p, double *samp1, int count1, double *samp2, int c
     if (samp1 == NULL) { p->nbuf1 = p->nbuf2 = 0; return 0; }
     if (p->nbuf1 == 0 && p->nbuf2 == 0 && count1 == count2) return count1;
     if (count1 + p->nbuf1 >= BUF2CHAN_SIZE || count2 + p->nbuf2 >= BUF2CHAN_SIZE) p->nbuf1 = p->nbuf2 = 0;
+    if (count1 > BUF2CHAN_SIZE || count2 > BUF2CHAN_SIZE) {
+        /* the reference copies on regardless and runs over its static arrays (undefined behaviour; Quisk's own blocks are far shorter):
+         * the restatement stops here and says so (qo_ps_overrun), callers keep their blocks below 12 000 audio samples */
+        p->b2c_overrun = 1;
+        return count1 < count2 ? count1 : count2;
+    }
     memcpy(p->buf1 + p->nbuf1, samp1, (size_t)count1 * sizeof(double)); p->nbuf1 += count1;
     memcpy(p->buf2 + p->nbuf2, samp2, (size_t)count2 * sizeof(double)); p->nbuf2 += count2;
     nout = p->nbuf1 <= p->nbuf2 ? p->nbuf1 : p->nbuf2;

@@ -113,6 +113,7 @@ void qo_ps_set_graph(qo_ps *p, struct qo_graph *g);
 void qo_ps_set_wdsp(qo_ps *p, struct wo_shim *s, void (*fn)(void *ctx, double *in, double *out, int *error), void *ctx);
 int qo_ps_sub_rx1_audio(qo_ps *p, double *out, int cap);
 void qo_ps_restart_bank(qo_ps *p, int bank);                   /* test hook: what a GPU bank rebuild forgets */
+int qo_ps_overrun(const qo_ps *p);                             /* 1 once a call has handed Buffer2Chan more than BUF2CHAN_SIZE samples (the reference overruns its arrays there) */
 int qo_ps_squelch_flags(const qo_ps *p);                       /* bit 0: squelch_real, bit 1: squelch_imag of the last call */
 /* in place; the buffer must hold max(n, output count) samples; returns the count at the playback rate */
 int qo_ps_process(qo_ps *p, double *cSamples, int n);

@@ -854,7 +854,8 @@ void qh_quisk_set_agc(double level)                 // set_agc, quisk.c:4543
 void qh_quisk_set_auto_notch(int on, int rit_freq)   // set_auto_notch, quisk.c:4596: the flag, and dAutoNotch(NULL, ...)
 {
     std::lock_guard<std::mutex> lk(g.mtx);
-    g.auto_notch = on ? 1 : 0; g.rit_freq = rit_freq; g.notch_reset = true;
+    (void)rit_freq;         // the reference's set_auto_notch takes the flag alone: rit_freq is the global set_sidetone writes (quisk.c:4712)
+    g.auto_notch = on ? 1 : 0; g.notch_reset = true;
 }
 
 void qh_quisk_set_noise_blanker(int level)          // set_noise_blanker, quisk.c:4605

@@ -105,7 +105,8 @@ def set_agc(level):
 
 
 def set_auto_notch(on, rit_freq=0):
-    load().qh_quisk_set_auto_notch(int(on), int(rit_freq))
+    """QS.set_auto_notch(on), quisk.c:4596.  (rit_freq is ignored: the RIT is set_sidetone's, as in the reference.)"""
+    load().qh_quisk_set_auto_notch(int(on), 0)
 
 
 def set_noise_blanker(level):

@@ -1,0 +1,103 @@
+"""Seeded random walks over the one-receiver quisk_process_samples (qh_quisk_*, the `_quisk` setters' shape) between ragged calls,
+the same calls made on the block-level restatement (oracle qo_ps_*, quisk.c:2289-2742): tune (rx and tx), Rx filters of other
+lengths, split Rx/Tx 0-4, the key going down and up (sidetone / silence, the key-up envelope), AGC level, NoiseBlanker, auto-notch,
+inversion, kill_audio, both squelches, the test tone (FM).  Mode and rates are fixed per walk (a change of mode rebuilds a bank: a
+stated deviation).  Levels stay under process_agc's limiter (the end of an overload ramp is chaotic,
+tests/test_gpu_bench_shapes.py; the machine is held bit for bit in tests/test_gpu_quisk_agc_chain.py).  -m gpu."""
+import numpy as np
+import pytest
+
+from quisk_amd import rxfilter
+from test_gpu_quisk_process_bank import BW, NAMES, _filters, _signal
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(rng, mode, fs, play, api, ref, st):
+    k = int(rng.integers(0, 13))
+    if k == 0:
+        st["rx"] = int(rng.integers(-30000, 30000))
+        api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"]); return ("set_tune rx", st["rx"])
+    if k == 1:
+        st["tx"] = int(rng.integers(-30000, 30000))
+        api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"]); return ("set_tune tx", st["tx"])
+    if k == 2:
+        bw = int(rng.choice({3: [1800, 2400, 2700, 3000], 4: [4000, 6000, 8000], 5: [10000, 12000, 16000], 1: [200, 500, 1000]}[mode]))
+        frate = rxfilter.get_filter_rate(fs, mode, BW[mode])
+        fI, fQ = rxfilter.make_filter_coef(frate, int(rng.choice([0, 0, 193, 325, 1025])) or None, bw, rxfilter.get_filter_center(NAMES[mode], bw))
+        api.set_filters(fI, fQ, BW[mode]); ref.set_filters(fI, fQ, BW[mode]); return ("set_filters", bw, len(fI))
+    if k == 3:
+        lvl = float(rng.choice([5.0, 20.0, 60.0, 150.0]))
+        api.set_agc(lvl); ref.set_agc(lvl); return ("set_agc", lvl)
+    if k == 4:
+        lvl = int(rng.integers(0, 4))
+        api.set_noise_blanker(lvl); ref.set_noise_blanker(lvl); return ("set_noise_blanker", lvl)
+    if k == 5:
+        on = int(rng.integers(0, 2))
+        api.set_auto_notch(on); ref.set_auto_notch(on); return ("set_auto_notch", on)
+    if k == 6:
+        inv = int(rng.integers(0, 2))
+        api.invert_spectrum(inv); ref.invert_spectrum(inv); return ("invert_spectrum", inv)
+    if k == 7:
+        kill = int(rng.integers(0, 4) == 0)
+        api.set_kill_audio(kill); ref.set_kill_audio(kill); return ("set_kill_audio", kill)
+    if k == 8:
+        lvl = float(rng.uniform(-90.0, -30.0))
+        api.set_squelch(lvl); ref.set_squelch(lvl); return ("set_squelch", lvl)
+    if k == 9:
+        en, lvl = int(rng.integers(0, 2)), int(rng.integers(1, 10))
+        api.set_ssb_squelch(en, lvl); ref.set_ssb_squelch(en, lvl); return ("set_ssb_squelch", en, lvl)
+    if k == 10:
+        sp = int(rng.integers(0, 5))
+        api.set_split_rxtx(sp); ref.set_split_rxtx(sp); return ("set_split_rxtx", sp)
+    if k == 11:                                        # the key: down for a call or two, then up (sidetone or silence, then the envelope)
+        down = int(rng.integers(0, 2))
+        args = (down, down if mode == 1 else 0, int(rng.integers(0, 2)), 0)
+        api.set_key_state(*args); ref.set_key_state(*args); return ("set_key_state",) + args
+    f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode == 5 else 0          # (-40 dB of full scale: an overload in the other modes)
+    api.add_tone(f); ref.add_tone(f); return ("add_tone", f)
+
+
+@pytest.mark.parametrize("seed,mode,fs,play", [(1, 3, 192000, 48000), (2, 3, 111111, 96000), (3, 4, 96000, 48000), (4, 5, 192000, 48000),
+                                               (5, 3, 48000, 48000), (6, 1, 133333, 48000), (7, 4, 185185, 96000), (8, 5, 96000, 192000),
+                                               (9, 3, 192000, 192000), (10, 1, 48000, 96000), (11, 3, 370370, 48000), (12, 5, 53333, 48000)])
+def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs, play):
+    rng = np.random.default_rng(7000 + seed)
+    api = qh.quiskapi
+    api.open(fs, playback_rate=play)
+    ref = oracle.OracleQuiskBlock(fs, play, rxfilter.coefficient_tables())
+    try:
+        st = {"rx": 8300, "tx": 9100}
+        fI, fQ = _filters(mode, fs)
+        for o in (api, ref):
+            o.set_rx_mode(mode); o.set_filters(fI, fQ, BW[mode]); o.set_agc(20.0)
+        api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"])
+        api.set_sidetone(0.3, 600, play, 20); ref.set_sidetone(0.3, 600, 20)
+        ratio = max(1, fs // 48000)
+        sizes = [int(rng.choice([1, 2, 3, 5, 8])) * int(rng.integers(300, 1700)) * ratio for _ in range(24)]
+        sizes = [min(s, 52000, 50000 * fs // play, 11000 * (fs // 48000 or 1)) for s in sizes]          # (the reference's interpolators stop at 52 800 outputs per call, its Buffer2Chan at 12 000 audio samples)
+        n = sum(sizes)
+        x = _signal(mode, 0, n, fs, float(st["rx"]), amp=2.0 ** 18)
+        x[5000::9973] += 2.0 ** 21
+        x[n // 2:n // 2 + n // 6] *= 0.01
+        log, pos, outs, loose_until = [], 0, 0, -1
+        for k, s in enumerate(sizes):
+            if k:
+                for _ in range(int(rng.integers(1, 3))):
+                    log.append((k, _draw(rng, mode, fs, play, api, ref, st)))
+                    if mode == 5 and log[-1][1][0] == "set_split_rxtx":
+                        loose_until = k + 1         # the second FM receiver starts on an empty delay line: arg() of rounding-level numbers again
+            seg = x[pos:pos + s]
+            pos += s
+            y, want = api.process(seg), ref.process(seg)
+            assert y.size == want.size, (seed, k, y.size, want.size, log)
+            if want.size == 0:
+                continue
+            settle = 6 * 1024 * (play // 48000) if mode == 5 else 0                    # FM: arg() of rounding-level numbers while the filters fill
+            lo = min(want.size, max(0, settle - outs))
+            outs += want.size
+            scale = max(np.abs(want).max(), 1.0)
+            err = np.abs(y[lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
+            assert err < (1e-4 if k <= loose_until else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
+    finally:
+        api.close()

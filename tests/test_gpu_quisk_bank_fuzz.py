@@ -75,14 +75,14 @@ def test_random_setter_walk_over_the_bank(qh, oracle, seed, mode, fs, play):
     bank.set_agc(20.0); [r.set_agc(20.0) for r in refs]
     ratio = max(1, fs // 48000)
     sizes = [int(rng.choice([1, 2, 3, 5, 8])) * int(rng.integers(300, 1700)) * ratio // 1 for _ in range(22)]
-    sizes = [min(s, 50000 * fs // max(play, fs // ratio)) for s in sizes]          # the reference's interpolators stop at 52 800 outputs per call
+    sizes = [min(s, 52000, 50000 * fs // play) for s in sizes]          # the reference's interpolators stop at 52 800 outputs per call
     n = sum(sizes)
     # (levels that keep process_agc under its limiter even at the gain of 100 it starts from, quisk.c:2182: the end of an overload ramp is
     # a chaotic function of the input, tests/test_gpu_bench_shapes.py -- the machine itself is held bit for bit elsewhere)
     x = np.stack([_signal(mode, c, n, fs, float(tunes[c]), amp=2.0 ** 18) for c in range(NCH)])
     x[:, 5000::9973] += 2.0 ** 21                                                 # impulses for the blanker
     x[:, n // 2:n // 2 + n // 6] *= 0.01                                          # a fade (squelches, AGC release)
-    log, pos = [], 0
+    log, pos, outs = [], 0, 0
     for k, s in enumerate(sizes):
         if k:
             for _ in range(int(rng.integers(1, 3))):
@@ -95,8 +95,10 @@ def test_random_setter_walk_over_the_bank(qh, oracle, seed, mode, fs, play):
             assert y[c].size == want.size, (seed, k, c, y[c].size, want.size, log)
             if want.size == 0:
                 continue
-            lo = min(want.size, 6 * 1024 * (play // 48000)) if (mode == 5 and k == 0) else 0       # FM: arg() of rounding-level numbers while the filters fill
+            settle = 6 * 1024 * (play // 48000) if mode == 5 else 0                    # FM: arg() of rounding-level numbers while the filters fill
+            lo = min(want.size, max(0, settle - outs))
             scale = max(np.abs(want).max(), 1.0)
             err = np.abs(y[c][lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
             assert err < 1e-6, "seed %d call %d (%d samples) receiver %d: max error %.2e of %.3e; setters %r" % (seed, k, s, c, err, scale, log)
+        outs += y.shape[1]
     bank.close()

@@ -19,7 +19,7 @@ for c in range(NCH):
 bank.set_agc(20.0); [r.set_agc(20.0) for r in refs]
 ratio = max(1, fs // 48000)
 sizes = [int(rng.choice([1, 2, 3, 5, 8])) * int(rng.integers(300, 1700)) * ratio // 1 for _ in range(22)]
-sizes = [min(s, 50000 * fs // max(play, fs // ratio)) for s in sizes]
+sizes = [min(s, 52000, 50000 * fs // play) for s in sizes]
 n = sum(sizes)
 x = np.stack([_signal(mode, c, n, fs, float(tunes[c]), amp=2.0 ** 18) for c in range(NCH)])
 x[:, 5000::9973] += 2.0 ** 21
