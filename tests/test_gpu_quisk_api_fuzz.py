@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _draw(rng, mode, fs, play, api, ref, st):
-    k = int(rng.integers(0, 13))
+    k = int(rng.integers(0, 16 if mode == 3 else 13))
     if k == 0:
         st["rx"] = int(rng.integers(-30000, 30000))
         api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"]); return ("set_tune rx", st["rx"])
@@ -54,8 +54,18 @@ def _draw(rng, mode, fs, play, api, ref, st):
         down = int(rng.integers(0, 2))
         args = (down, down if mode == 1 else 0, int(rng.integers(0, 2)), 0)
         api.set_key_state(*args); ref.set_key_state(*args); return ("set_key_state",) + args
-    f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode == 5 else 0          # (-40 dB of full scale: an overload in the other modes)
-    api.add_tone(f); ref.add_tone(f); return ("add_tone", f)
+    if k == 12:
+        f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode == 5 else 0      # (-40 dB of full scale: an overload in the other modes)
+        api.add_tone(f); ref.add_tone(f); return ("add_tone", f)
+    # the played sub-receiver (USB walks: it is fed every call, quisk.c:2589-2629): bank 1 with aux1TuneVector and filter set 1
+    if k == 13:
+        ch = int(rng.choice([-1, 1]))
+        api.set_multirx_play_channel(ch); ref.set_multirx_play_channel(ch); return ("set_multirx_play_channel", ch)
+    if k == 14:
+        m = int(rng.integers(0, 3))
+        api.set_multirx_play_method(m); ref.set_multirx_play_method(m); return ("set_multirx_play_method", m)
+    f = int(rng.integers(-30000, 30000))
+    api.set_multirx_freq(1, f); ref.set_multirx_freq(1, f); return ("set_multirx_freq", f)
 
 
 @pytest.mark.parametrize("seed,mode,fs,play", [(1, 3, 192000, 48000), (2, 3, 111111, 96000), (3, 4, 96000, 48000), (4, 5, 192000, 48000),
@@ -73,6 +83,11 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             o.set_rx_mode(mode); o.set_filters(fI, fQ, BW[mode]); o.set_agc(20.0)
         api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"])
         api.set_sidetone(0.3, 600, play, 20); ref.set_sidetone(0.3, 600, 20)
+        if mode == 3:
+            gI, gQ = _filters(mode, fs, 2400)
+            for o in (api, ref):
+                o.set_filters(gI, gQ, 2400, 1); o.set_filters(fI, fQ, BW[mode])        # filter set 1, then the one global sizeFilter back (quisk.c:4591)
+                o.set_multirx_mode(1, 3); o.set_multirx_freq(1, -15000); o.set_multirx_play_method(1)
         ratio = max(1, fs // 48000)
         sizes = [int(rng.choice([1, 2, 3, 5, 8])) * int(rng.integers(300, 1700)) * ratio for _ in range(24)]
         sizes = [min(s, 52000, 50000 * fs // play, 11000 * (fs // 48000 or 1)) for s in sizes]          # (the reference's interpolators stop at 52 800 outputs per call, its Buffer2Chan at 12 000 audio samples)
@@ -80,6 +95,7 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
         x = _signal(mode, 0, n, fs, float(st["rx"]), amp=2.0 ** 18)
         x[5000::9973] += 2.0 ** 21
         x[n // 2:n // 2 + n // 6] *= 0.01
+        xs = _signal(mode, 1, n, fs, -15000.0, amp=2.0 ** 18) if mode == 3 else None
         log, pos, outs, loose_until = [], 0, 0, -1
         for k, s in enumerate(sizes):
             if k:
@@ -88,6 +104,8 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
                     if mode == 5 and log[-1][1][0] == "set_split_rxtx":
                         loose_until = k + 1         # the second FM receiver starts on an empty delay line: arg() of rounding-level numbers again
             seg = x[pos:pos + s]
+            if xs is not None:
+                api.multirx_samples(1, xs[pos:pos + s]); ref.multirx_samples(1, xs[pos:pos + s])
             pos += s
             y, want = api.process(seg), ref.process(seg)
             assert y.size == want.size, (seed, k, y.size, want.size, log)
@@ -99,5 +117,33 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             scale = max(np.abs(want).max(), 1.0)
             err = np.abs(y[lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
             assert err < (1e-4 if k <= loose_until else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
+    finally:
+        api.close()
+
+
+def test_set_auto_notch_leaves_the_rit_to_set_sidetone(qh, oracle):
+    """The reference's set_auto_notch takes the flag alone (quisk.c:4596); rit_freq is the global set_sidetone writes (quisk.c:4712), and it
+    tunes the split receiver too (quisk.c:2538).  Found by the walks above: qh_quisk_set_auto_notch used to write its second argument
+    over it, and the second receiver of a split sat 600 Hz off from then on."""
+    fs, play, mode = 133333, 48000, 1
+    api = qh.quiskapi
+    api.open(fs, playback_rate=play)
+    ref = oracle.OracleQuiskBlock(fs, play, rxfilter.coefficient_tables())
+    try:
+        fI, fQ = _filters(mode, fs)
+        for o in (api, ref):
+            o.set_rx_mode(mode); o.set_filters(fI, fQ, BW[mode]); o.set_agc(20.0)
+        api.set_tune2(8300, 9100); ref.set_tune(8300, 9100)
+        api.set_sidetone(0.3, 600, play, 20); ref.set_sidetone(0.3, 600, 20)
+        n = 8000
+        x = _signal(mode, 0, 10 * n, fs, 8300.0, amp=2.0 ** 18)
+        for k in range(10):
+            if k == 3:
+                api.set_auto_notch(1); ref.set_auto_notch(1)
+            if k == 5:
+                api.set_split_rxtx(4); ref.set_split_rxtx(4)          # the Tx-frequency receiver alone, on both ears
+            y, want = api.process(x[k * n:(k + 1) * n]), ref.process(x[k * n:(k + 1) * n])
+            assert y.size == want.size
+            assert np.abs(y - want).max() <= 1e-8 * max(np.abs(want).max(), 1.0), k
     finally:
         api.close()
