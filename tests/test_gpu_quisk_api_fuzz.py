@@ -30,7 +30,7 @@ def _draw(rng, mode, fs, play, api, ref, st):
         lvl = float(rng.choice([5.0, 20.0, 60.0, 150.0]))
         api.set_agc(lvl); ref.set_agc(lvl); return ("set_agc", lvl)
     if k == 4:
-        lvl = int(rng.integers(0, 4))
+        lvl = int(rng.integers(0, 4)) if mode != 5 else 0          # (FM: behind a blanked stretch the discriminator takes arg() of rounding-level numbers)
         api.set_noise_blanker(lvl); ref.set_noise_blanker(lvl); return ("set_noise_blanker", lvl)
     if k == 5:
         on = int(rng.integers(0, 2))

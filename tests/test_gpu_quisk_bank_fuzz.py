@@ -31,7 +31,8 @@ def _draw(rng, mode, fs, bank, refs):
         lvl = float(rng.choice([5.0, 20.0, 60.0, 150.0]))       # below the limiter: an overload ramp's end is chaotic (tests/test_gpu_bench_shapes.py)
         bank.set_agc(lvl); [r.set_agc(lvl) for r in refs]; done = ("set_agc", lvl)
     elif k == 3:
-        lvl = int(rng.integers(0, 4))
+        # (FM walks leave the blanker off: behind a blanked stretch the discriminator takes arg() of rounding-level numbers, as at start-up)
+        lvl = int(rng.integers(0, 4)) if mode != 5 else 0
         bank.set_noise_blanker(lvl); [r.set_noise_blanker(lvl) for r in refs]; done = ("set_noise_blanker", lvl)
     elif k == 4:
         on = int(rng.integers(0, 2))
@@ -68,10 +69,13 @@ def test_random_setter_walk_over_the_bank(qh, oracle, seed, mode, fs, play):
     rng = np.random.default_rng(9000 + seed)
     tunes = [7000 + 1300 * c for c in range(NCH)]
     filt = [_filters(mode, fs)] * NCH
-    bank = qh.QuiskProcessBank(NCH, fs, mode, BW[mode], playback_rate=play)
+    bank = qh.QuiskProcessBank(NCH, fs, mode, BW[mode], playback_rate=play, fft_size=2048, data_width=512)
     refs = _refs(oracle, NCH, fs, play, mode, tunes, filt)
+    graphs = []
     for c in range(NCH):
         bank.set_tune(c, tunes[c]); bank.set_filters(c, *filt[c])
+        graphs.append(oracle.OracleGraph(2048, 512, float(fs)))      # the panadapter's feed: the samples behind tone, inversion and blanker (quisk.c:2454-2475)
+        refs[c].set_graph(graphs[c])
     bank.set_agc(20.0); [r.set_agc(20.0) for r in refs]
     ratio = max(1, fs // 48000)
     sizes = [int(rng.choice([1, 2, 3, 5, 8])) * int(rng.integers(300, 1700)) * ratio // 1 for _ in range(22)]
@@ -101,4 +105,16 @@ def test_random_setter_walk_over_the_bank(qh, oracle, seed, mode, fs, play):
             err = np.abs(y[c][lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
             assert err < 1e-6, "seed %d call %d (%d samples) receiver %d: max error %.2e of %.3e; setters %r" % (seed, k, s, c, err, scale, log)
         outs += y.shape[1]
+        if rng.integers(0, 4) == 0:                  # get_graph (quisk.c:5142) now and then: the average starts over on both sides
+            zoom, deltaf = float(rng.choice([1.0, 1.0, 2.0, 4.0])), float(rng.choice([0.0, 0.0, 5000.0, -12000.0]))
+            got = bank.get_graph(zoom, deltaf)
+            for c in range(NCH):
+                want_g = graphs[c].get(zoom, deltaf)
+                assert (got is None) == (want_g is None), (seed, k, c)        # no whole block of 2048 samples yet: None on both sides
+                if got is None:
+                    continue
+                rp, rs, rc = want_g
+                pix, sm, cnt = got
+                assert cnt == rc, (seed, k, c, cnt, rc)
+                assert np.abs(pix[c] - rp).max() < 1e-6 and abs(sm[c] - rs) < 1e-6, (seed, k, c, np.abs(pix[c] - rp).max(), sm[c], rs)
     bank.close()
