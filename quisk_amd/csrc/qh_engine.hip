@@ -3050,8 +3050,11 @@ int qh_rxa_band_tile(const qh_rxa *h) { return h ? h->e.bnfft : 0; }
 
 int Engine::process_replayed(const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk)
 {
-    // the output resampler keeps a host-side phase and event timing records per call: both stay on the plain path
-    if (rsmpout || timing || nblk <= 0) return process(d_in, in_stride, d_out, out_stride, nblk);
+    // the resamplers (the output one; the input one of the rate ratios that are not 1, 2, 4, 8 or 16) keep a host-side phase and their
+    // own ping-pong of delay lines per call, event timing records per call: all of them stay on the plain path.  (The input resampler was
+    // missing here until a seeded walk through the WDSP names at 144 ksps found it: a sequence captured after a setter replayed the
+    // other parity of its delay lines, tests/test_gpu_wdsp_names_fuzz.py.)
+    if (rsmpin || rsmpout || timing || nblk <= 0) return process(d_in, in_stride, d_out, out_stride, nblk);
     const GraphKey key{d_in, d_out, in_stride, out_stride, nblk, epoch};
     if (!(key == graph_key)) { drop_graphs(); graph_key = key; graph_seen = false; }
     const unsigned before = flags();
