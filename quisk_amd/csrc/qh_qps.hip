@@ -209,7 +209,12 @@ int qh_qps_set_agc(qh_qps *h, double level)                                     
     return qh_qagc_set_gain(h->agc, -1, level);
 }
 int qh_qps_set_noise_blanker(qh_qps *h, int level) { QPS_ENTER(h); h->nb_level = level < 0 ? 0 : level; return QH_OK; }                     // quisk.c:4605
-int qh_qps_set_auto_notch(qh_qps *h, int on, int rit_freq) { QPS_ENTER(h); return qh_qrx_set_auto_notch(h->rx, on, rit_freq); }             // quisk.c:4596
+int qh_qps_set_auto_notch(qh_qps *h, int on, int rit_freq)                                                                                   // quisk.c:4596
+{
+    QPS_ENTER(h);
+    if (h->mode == 9) return QH_OK;         // DGT-IQ never calls dAutoNotch (quisk.c:2112-2127): the flag is taken and has no effect, as in the reference
+    return qh_qrx_set_auto_notch(h->rx, on, rit_freq);
+}
 int qh_qps_invert_spectrum(qh_qps *h, int invert) { QPS_ENTER(h); h->invert = invert ? 1 : 0; return QH_OK; }                               // quisk.c:4535
 int qh_qps_set_kill_audio(qh_qps *h, int kill) { QPS_ENTER(h); h->kill_audio = kill ? 1 : 0; return QH_OK; }
 int qh_qps_add_tone(qh_qps *h, int freq)                                                                                                     // add_tone, quisk.c:3203

@@ -22,7 +22,8 @@ def _draw(rng, mode, fs, play, api, ref, st):
         st["tx"] = int(rng.integers(-30000, 30000))
         api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"]); return ("set_tune tx", st["tx"])
     if k == 2:
-        bw = int(rng.choice({3: [1800, 2400, 2700, 3000], 4: [4000, 6000, 8000], 5: [10000, 12000, 16000], 1: [200, 500, 1000]}[mode]))
+        bw = int(rng.choice({3: [1800, 2400, 2700, 3000], 2: [1800, 2400, 2700, 3000], 4: [4000, 6000, 8000], 5: [10000, 12000, 16000], 13: [10000, 12000, 16000],
+                             1: [200, 500, 1000], 0: [200, 500, 1000]}.get(mode, [BW[mode]])))
         frate = rxfilter.get_filter_rate(fs, mode, BW[mode])
         fI, fQ = rxfilter.make_filter_coef(frate, int(rng.choice([0, 0, 193, 325, 1025])) or None, bw, rxfilter.get_filter_center(NAMES[mode], bw))
         api.set_filters(fI, fQ, BW[mode]); ref.set_filters(fI, fQ, BW[mode]); return ("set_filters", bw, len(fI))
@@ -30,7 +31,7 @@ def _draw(rng, mode, fs, play, api, ref, st):
         lvl = float(rng.choice([5.0, 20.0, 60.0, 150.0]))
         api.set_agc(lvl); ref.set_agc(lvl); return ("set_agc", lvl)
     if k == 4:
-        lvl = int(rng.integers(0, 4)) if mode != 5 else 0          # (FM: behind a blanked stretch the discriminator takes arg() of rounding-level numbers)
+        lvl = int(rng.integers(0, 4)) if mode not in (5, 13) else 0          # (FM: behind a blanked stretch the discriminator takes arg() of rounding-level numbers)
         api.set_noise_blanker(lvl); ref.set_noise_blanker(lvl); return ("set_noise_blanker", lvl)
     if k == 5:
         on = int(rng.integers(0, 2))
@@ -55,7 +56,7 @@ def _draw(rng, mode, fs, play, api, ref, st):
         args = (down, down if mode == 1 else 0, int(rng.integers(0, 2)), 0)
         api.set_key_state(*args); ref.set_key_state(*args); return ("set_key_state",) + args
     if k == 12:
-        f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode == 5 else 0      # (-40 dB of full scale: an overload in the other modes)
+        f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode in (5, 13) else 0      # (-40 dB of full scale: an overload in the other modes)
         api.add_tone(f); ref.add_tone(f); return ("add_tone", f)
     # the played sub-receiver (USB walks: it is fed every call, quisk.c:2589-2629): bank 1 with aux1TuneVector and filter set 1
     if k == 13:
@@ -70,7 +71,9 @@ def _draw(rng, mode, fs, play, api, ref, st):
 
 @pytest.mark.parametrize("seed,mode,fs,play", [(1, 3, 192000, 48000), (2, 3, 111111, 96000), (3, 4, 96000, 48000), (4, 5, 192000, 48000),
                                                (5, 3, 48000, 48000), (6, 1, 133333, 48000), (7, 4, 185185, 96000), (8, 5, 96000, 192000),
-                                               (9, 3, 192000, 192000), (10, 1, 48000, 96000), (11, 3, 370370, 48000), (12, 5, 53333, 48000)])
+                                               (9, 3, 192000, 192000), (10, 1, 48000, 96000), (11, 3, 370370, 48000), (12, 5, 53333, 48000),
+                                               (21, 0, 96000, 48000), (22, 2, 192000, 48000), (23, 7, 192000, 96000), (24, 8, 111111, 48000), (25, 9, 192000, 48000),
+                                               (26, 13, 96000, 48000), (27, 10, 48000, 48000)])
 def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs, play):
     rng = np.random.default_rng(7000 + seed)
     api = qh.quiskapi
@@ -101,7 +104,7 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             if k:
                 for _ in range(int(rng.integers(1, 3))):
                     log.append((k, _draw(rng, mode, fs, play, api, ref, st)))
-                    if mode == 5 and log[-1][1][0] == "set_split_rxtx":
+                    if mode in (5, 13) and log[-1][1][0] == "set_split_rxtx":
                         loose_until = k + 1         # the second FM receiver starts on an empty delay line: arg() of rounding-level numbers again
             seg = x[pos:pos + s]
             if xs is not None:
@@ -111,7 +114,7 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             assert y.size == want.size, (seed, k, y.size, want.size, log)
             if want.size == 0:
                 continue
-            settle = 6 * 1024 * (play // 48000) if mode == 5 else 0                    # FM: arg() of rounding-level numbers while the filters fill
+            settle = 6 * 1024 * (play // 48000) if mode in (5, 13) else 0                    # FM: arg() of rounding-level numbers while the filters fill
             lo = min(want.size, max(0, settle - outs))
             outs += want.size
             scale = max(np.abs(want).max(), 1.0)

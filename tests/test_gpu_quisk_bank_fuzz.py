@@ -23,7 +23,8 @@ def _draw(rng, mode, fs, bank, refs):
         bank.set_tune(c, f); refs[c].set_tune(f); done = ("set_tune", c, f)
     elif k == 1:                                       # another Rx filter for one receiver: bandwidth, and with it sometimes the length
         c = int(rng.integers(0, NCH))
-        bw = int(rng.choice({3: [1800, 2400, 2700, 3000], 4: [4000, 6000, 8000], 5: [10000, 12000, 16000], 1: [200, 500, 1000]}[mode]))
+        bw = int(rng.choice({3: [1800, 2400, 2700, 3000], 2: [1800, 2400, 2700, 3000], 4: [4000, 6000, 8000], 5: [10000, 12000, 16000], 13: [10000, 12000, 16000],
+                             1: [200, 500, 1000], 0: [200, 500, 1000]}.get(mode, [BW[mode]])))
         frate = rxfilter.get_filter_rate(fs, mode, BW[mode])
         fI, fQ = rxfilter.make_filter_coef(frate, int(rng.choice([0, 0, 193, 325, 1025])) or None, bw, rxfilter.get_filter_center(NAMES[mode], bw))
         bank.set_filters(c, fI, fQ); refs[c].set_filters(fI, fQ, BW[mode]); done = ("set_filters", c, bw, len(fI))
@@ -32,7 +33,7 @@ def _draw(rng, mode, fs, bank, refs):
         bank.set_agc(lvl); [r.set_agc(lvl) for r in refs]; done = ("set_agc", lvl)
     elif k == 3:
         # (FM walks leave the blanker off: behind a blanked stretch the discriminator takes arg() of rounding-level numbers, as at start-up)
-        lvl = int(rng.integers(0, 4)) if mode != 5 else 0
+        lvl = int(rng.integers(0, 4)) if mode not in (5, 13) else 0
         bank.set_noise_blanker(lvl); [r.set_noise_blanker(lvl) for r in refs]; done = ("set_noise_blanker", lvl)
     elif k == 4:
         on = int(rng.integers(0, 2))
@@ -46,7 +47,7 @@ def _draw(rng, mode, fs, bank, refs):
     elif k == 7:
         # (the test tone is -40 dB of full scale whatever the signal, quisk.c:1263: in a passband, times the AGC's starting gain of 100, it
         # is an overload -- FM walks only, where the audio's level does not follow the input's)
-        f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode == 5 else 0
+        f = int(rng.choice([0, 0, 7000, -12000, 21000])) if mode in (5, 13) else 0
         bank.add_tone(f); [r.add_tone(f) for r in refs]; done = ("add_tone", f)
     elif k == 8:
         c, lvl = int(rng.integers(0, NCH)), float(rng.uniform(-90.0, -30.0))
@@ -64,7 +65,10 @@ def _draw(rng, mode, fs, bank, refs):
                                                (5, 3, 48000, 48000), (6, 1, 133333, 48000), (7, 4, 185185, 96000), (8, 5, 96000, 192000),
                                                (9, 3, 192000, 192000), (10, 3, 370370, 48000),
                                                # found by tools/dbg/bank_fuzz_sweep.py: a squelch switched on in a call that is cut into pieces
-                                               (146, 4, 185185, 96000), (101, 5, 192000, 48000), (106, 3, 192000, 192000)])
+                                               (146, 4, 185185, 96000), (101, 5, 192000, 48000), (106, 3, 192000, 192000),
+                                               # CWL, LSB, DGT-U, DGT-L, DGT-IQ (stereo: process_agc on the complex magnitude), DGT-FM, IMD
+                                               (21, 0, 96000, 48000), (22, 2, 192000, 48000), (23, 7, 192000, 96000), (24, 8, 111111, 48000), (417, 9, 192000, 48000),
+                                               (26, 13, 96000, 48000), (27, 10, 48000, 48000)])
 def test_random_setter_walk_over_the_bank(qh, oracle, seed, mode, fs, play):
     rng = np.random.default_rng(9000 + seed)
     tunes = [7000 + 1300 * c for c in range(NCH)]
@@ -99,7 +103,7 @@ def test_random_setter_walk_over_the_bank(qh, oracle, seed, mode, fs, play):
             assert y[c].size == want.size, (seed, k, c, y[c].size, want.size, log)
             if want.size == 0:
                 continue
-            settle = 6 * 1024 * (play // 48000) if mode == 5 else 0                    # FM: arg() of rounding-level numbers while the filters fill
+            settle = 6 * 1024 * (play // 48000) if mode in (5, 13) else 0                    # FM: arg() of rounding-level numbers while the filters fill
             lo = min(want.size, max(0, settle - outs))
             scale = max(np.abs(want).max(), 1.0)
             err = np.abs(y[c][lo:] - want[lo:]).max() / scale if want.size > lo else 0.0

@@ -11,8 +11,8 @@ from conftest import rel_rms
 from quisk_amd import rxfilter
 
 pytestmark = pytest.mark.gpu
-NAMES = {3: "USB", 4: "AM", 5: "FM", 1: "CWU"}
-BW = {3: 2700, 4: 6000, 5: 12000, 1: 500}
+NAMES = {3: "USB", 4: "AM", 5: "FM", 1: "CWU", 0: "CWL", 2: "LSB", 7: "DGT-U", 8: "DGT-L", 9: "DGT-IQ", 10: "IMD", 13: "DGT-FM"}
+BW = {3: 2700, 4: 6000, 5: 12000, 1: 500, 0: 500, 2: 2700, 7: 3200, 8: 3200, 9: 8000, 10: 2700, 13: 12000}
 
 
 def _filters(mode, fs, bw=None):

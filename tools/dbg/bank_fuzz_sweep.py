@@ -6,7 +6,8 @@ import quisk_amd as qh
 import pyoracle as oracle
 import test_gpu_quisk_bank_fuzz as T
 combos = [(3, 192000, 48000), (3, 111111, 96000), (4, 96000, 48000), (5, 192000, 48000), (3, 48000, 48000), (1, 133333, 48000), (4, 185185, 96000),
-          (5, 96000, 192000), (3, 192000, 192000), (3, 370370, 48000), (1, 48000, 96000), (5, 53333, 48000), (4, 740740, 48000), (3, 96000, 96000)]
+          (5, 96000, 192000), (3, 192000, 192000), (3, 370370, 48000), (1, 48000, 96000), (5, 53333, 48000), (4, 740740, 48000), (3, 96000, 96000),
+          (0, 96000, 48000), (2, 192000, 48000), (7, 192000, 96000), (8, 111111, 48000), (9, 192000, 48000), (13, 96000, 48000), (10, 48000, 48000)]
 a, b = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(a, b + 1):
