@@ -740,6 +740,8 @@ int qh_qps_set_squelch(qh_qps *h, int ch, double level);                   /* se
 int qh_qps_set_ssb_squelch(qh_qps *h, int enabled, int level);             /* set_ssb_squelch, quisk.c:4729: CW, SSB and AM banks; accepted and without effect in an FM bank */
 /* long calls run as `pieces` time pieces, process_agc of one beside the filters of the next (0 = chosen by call length) */
 int qh_qps_set_pieces(qh_qps *h, int pieces);
+int qh_qps_set_pipelined(qh_qps *h, int on);                               /* streaming callers: a call returns with its AGC still running and the next call's filters start beside it;
+                                                                              output rows are complete after qh_qps_synchronize.  Same samples. */
 int qh_qps_filter_rate(qh_qps *h);                                         /* get_filter_rate, quisk.c:2787 */
 int qh_qps_decim_rate(qh_qps *h);
 int qh_qps_out_capacity(qh_qps *h, int n_in);                              /* the most playback samples a call of n_in returns: out_stride >= this */

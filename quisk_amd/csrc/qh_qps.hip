@@ -64,6 +64,7 @@ struct qh_qps {
     qh_rat *up = nullptr;
     qh_qagc *agc = nullptr;
     int nb_level = 0, invert = 0, kill_audio = 0, pieces = 0;
+    bool pipelined = false;                      // qh_qps_set_pipelined: a call does not wait for its own AGC (the next call's filters run beside its tail)
     double agc_gain = 80.0;                      // agcReleaseGain, quisk.c:191
     bool tone_on = false;
     u64 tone_phase = 0, tone_step = 0, audio_phase = 0;
@@ -289,8 +290,10 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     int piece = 0, last_agc = -1;
     for (int pos = 0; pos < n; piece++) {
         const int cnt = n - pos < per ? n - pos : per, par = piece & 1;
-        // this piece's scratch half was read by the AGC two pieces back
-        if (scratch && piece >= 2 && h->agc_recorded[par]) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[par], 0));
+        // this piece's scratch half was read by the AGC two pieces back.  Pipelined calls: the call before this one may still be in its
+        // AGC -- whatever this piece overwrites (its scratch half, its stretch of the bank's output rows) was read by the AGC piece that
+        // recorded this parity's event last, or by one ahead of it on the AGC's stream
+        if (h->agc_recorded[par] && (h->pipelined || (scratch && piece >= 2))) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[par], 0));
         int nb_ = 0;
         if (int rc = h->filters(in + pos, in_stride, cnt, o_off, &nb_)) return rc;
         const double2 *audio = h->d_o.p + o_off;
@@ -330,13 +333,22 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
         out_off += na;
         pos += cnt;
     }
-    if (last_agc >= 0) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[last_agc], 0));      // the call ends on the bank's stream (the AGC stream runs in order)
+    // the call ends on the bank's stream (the AGC stream runs in order) -- unless it is pipelined: then its output is complete at
+    // qh_qps_synchronize (or behind the next call's AGC), and the next call's filters start beside this call's last AGC piece
+    hipStream_t tail = h->stream;
+    if (h->pipelined && last_agc >= 0) tail = h->agc_stream;
+    else if (last_agc >= 0) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[last_agc], 0));
     const int total = (int)out_off;
     if (epi && total > 0) {                                             // kill_audio / squelch (quisk.c:2712-2728); no key here: no envelope
         const int *f0 = qh_qrx_squelch_flag(h->rx, 0), *f1 = nch > 1 ? qh_qrx_squelch_flag(h->rx, 1) : f0;
         const int step = f0 && f1 ? (int)(f1 - f0) : 0;
-        hipLaunchKernelGGL(qh_ps::epilogue_kernel, dim3(qh_ps::grid_x(total, 256u), (unsigned)nch), dim3(256), 0, h->stream, (const double2 *)out, out_stride,
+        if (tail != h->stream) {        // (the flags are the bank's, written on its stream)
+            QH_HIP(hipEventRecord(h->ev_piece[0], h->stream));
+            QH_HIP(hipStreamWaitEvent(tail, h->ev_piece[0], 0));
+        }
+        hipLaunchKernelGGL(qh_ps::epilogue_kernel, dim3(qh_ps::grid_x(total, 256u), (unsigned)nch), dim3(256), 0, tail, (const double2 *)out, out_stride,
                            out, out_stride, total, f0, step, f0, step, h->kill_audio, 1.0, 0.0, 0, h->d_flags);
+        if (tail != h->stream) { QH_HIP(hipEventRecord(h->ev_agc[last_agc], tail)); }      // (what waits for this parity's AGC also waits for the epilogue)
     }
     if (n_out) *n_out = total;
     QH_HIP(hipGetLastError());
@@ -347,6 +359,18 @@ int qh_qps_synchronize(qh_qps *h)
 {
     QPS_ENTER(h);
     QH_HIP(hipStreamSynchronize(h->stream));
+    QH_HIP(hipStreamSynchronize(h->agc_stream));
+    return QH_OK;
+}
+
+// Pipelined calls, for a caller that streams block after block: a call returns with its AGC still running on the bank's second stream
+// and the next call's filters start beside it; a call's output rows are complete after qh_qps_synchronize (not in the order of the
+// stream the bank was given).  Same samples either way.
+int qh_qps_set_pipelined(qh_qps *h, int on)
+{
+    QPS_ENTER(h);
+    if (!on && h->pipelined) { QH_HIP(hipStreamSynchronize(h->stream)); QH_HIP(hipStreamSynchronize(h->agc_stream)); }
+    h->pipelined = on != 0;
     return QH_OK;
 }
 
@@ -365,6 +389,7 @@ int qh_qps_process_host(qh_qps *h, const double *h_in, long long in_stride, int 
     int got = 0, rc = QH_OK;
     if (e == hipSuccess) rc = qh_qps_process(h, reinterpret_cast<const double *>(din), n, n, reinterpret_cast<double *>(dout), cap, &got);
     if (e == hipSuccess && rc == QH_OK) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && rc == QH_OK) e = hipStreamSynchronize(h->agc_stream);
     if (e == hipSuccess && rc == QH_OK && got > 0) {
         if (out_stride < got) rc = set_error(QH_ERR_INVALID, "qh_qps_process_host: out_stride %lld < %d samples", out_stride, got);
         else e = hipMemcpy2D(h_out, (size_t)out_stride * 16, dout, (size_t)cap * 16, (size_t)got * 16, (size_t)h->nch, hipMemcpyDeviceToHost);
@@ -381,6 +406,7 @@ int qh_qps_squelch_flags(qh_qps *h, int *flags)
 {
     QPS_ENTER(h);
     if (!flags) return set_error(QH_ERR_INVALID, "null flags");
+    QH_HIP(hipStreamSynchronize(h->agc_stream));           // (a pipelined call's epilogue runs there)
     QH_HIP(hipMemcpyAsync(h->h_flags.data(), h->d_flags, (size_t)h->nch * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     QH_HIP(hipStreamSynchronize(h->stream));
     for (int c = 0; c < h->nch; c++) flags[c] = h->h_flags[(size_t)2 * c];

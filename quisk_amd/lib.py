@@ -284,7 +284,7 @@ def load():
     L.qh_qps_set_tune.argtypes = [vp, i, i]
     L.qh_qps_set_filters.argtypes = [vp, i, vp, vp, i]
     L.qh_qps_set_agc.argtypes = [vp, d]
-    for n in ("qh_qps_set_noise_blanker", "qh_qps_invert_spectrum", "qh_qps_set_kill_audio", "qh_qps_add_tone", "qh_qps_set_pieces"):
+    for n in ("qh_qps_set_noise_blanker", "qh_qps_invert_spectrum", "qh_qps_set_kill_audio", "qh_qps_add_tone", "qh_qps_set_pieces", "qh_qps_set_pipelined"):
         getattr(L, n).argtypes = [vp, i]
     L.qh_qps_set_auto_notch.argtypes = [vp, i, i]
     L.qh_qps_set_squelch.argtypes = [vp, i, d]

@@ -160,6 +160,10 @@ class QuiskProcessBank:
     def set_pieces(self, pieces):
         check(self._L.qh_qps_set_pieces(self._h, int(pieces)))
 
+    def set_pipelined(self, on):
+        """a call returns with its AGC still running; outputs are complete after synchronize()"""
+        check(self._L.qh_qps_set_pipelined(self._h, 1 if on else 0))
+
     def out_capacity(self, n_in):
         return self._L.qh_qps_out_capacity(self._h, n_in)
 

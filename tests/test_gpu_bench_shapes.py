@@ -457,3 +457,13 @@ def test_quisk_native_at_the_timed_shape(qh, oracle, bc, dev, name):
             same = int((d < 1e-9).sum().item())
             print("Quisk-native %s shape: call %d against uneven calls with process_agc: %d of %d receivers within 1e-9, worst %.1e" % (name, k, same, nch, float(d.max().item())))
             assert float(d.max().item()) < 0.1
+    # the pipelined form of the same calls (the leg's `pipelined_*` keys: a call returns with its AGC still running, the next call's filters
+    # start beside it): the same pieces, the same kernels, the same bits
+    del L2
+    L3 = bc.setup_quisk_native(torch, qh, dev, name, pipelined=True)
+    L3.x.copy_(L.x)
+    torch.cuda.synchronize(dev)
+    for k in range(3):
+        m = L3.step()
+        torch.cuda.synchronize(dev)
+        assert m == ys[k].shape[1] and torch.equal(L3.y[:, :m], ys[k]), (name, k)

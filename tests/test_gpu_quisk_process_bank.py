@@ -166,3 +166,32 @@ def test_the_one_receiver_api_is_the_bank_with_one_receiver(qh):
         b = bank.process_host(seg[None, :])[0]
         assert a.size == b.size and np.array_equal(a.view(np.float64), b.view(np.float64)), s
     api.close(); bank.close()
+
+
+def test_pipelined_calls_give_the_same_samples(qh):
+    """qh_qps_set_pipelined: a call returns with its AGC still running on the bank's second stream and the next call's filters start beside
+    it (what this call overwrites -- scratch halves, its stretch of the bank's output rows -- waits for the AGC piece that read it).
+    Five calls back to back without a wait in between, every call into rows of its own: the bits of the calls that end on their stream."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for fs, play, mode in ((192000, 48000, 3), (185185, 96000, 4)):         # without and with the scratch halves (cFracDecim, interpolation)
+        nch, n, calls = 8, 1 << 16, 5
+        filt = _filters(mode, fs)
+        x = torch.from_numpy(np.stack([_signal(mode, c, n * calls, fs, 6000.0 + 500 * c, amp=2.0 ** 18) for c in range(nch)])).to(dev)
+        ys = []
+        for pipelined in (0, 1):
+            st = torch.cuda.Stream(dev)
+            bank = qh.QuiskProcessBank(nch, fs, mode, BW[mode], playback_rate=play, stream=st.cuda_stream)
+            bank.set_pieces(4); bank.set_pipelined(pipelined)
+            for c in range(nch):
+                bank.set_tune(c, 6000 + 500 * c)
+            bank.set_filters(-1, *filt)
+            cap = bank.out_capacity(n) + 64            # (the capacity follows the decimators' phases: a few samples up or down from call to call)
+            outs = [torch.zeros((nch, cap), dtype=torch.complex128, device=dev) for _ in range(calls)]
+            torch.cuda.synchronize(dev)
+            got = [bank.process_ptr(x[:, k * n:].data_ptr(), x.shape[1], n, outs[k].data_ptr(), cap) for k in range(calls)]
+            bank.synchronize()
+            ys.append(torch.cat([outs[k][:, :got[k]] for k in range(calls)], dim=1).cpu())
+            bank.close()
+        assert ys[0].shape == ys[1].shape and float(ys[0].abs().max()) > 2.0 ** 20
+        assert torch.equal(ys[0], ys[1]), (fs, float((ys[0] - ys[1]).abs().max()))

@@ -274,7 +274,7 @@ def qn_tune(c):
     return 1000 * (c % 40) - 20000
 
 
-def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20, whole=True, nb=0, fft_size=0, pieces=QN_PIECES):
+def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20, whole=True, nb=0, fft_size=0, pieces=QN_PIECES, pipelined=False):
     """One mode of the Quisk-native leg: 256 receivers, 192 ksps in, 48 ksps out.
     whole=True: the WHOLE of quisk_process_samples for the bank (qh_qps_*: test tone / inversion / NoiseBlanker when set, the
     panadapter's feed when fft_size > 0, tune + quisk_process_decimate + quisk_process_demodulate, process_agc -- always on, as in the
@@ -294,6 +294,8 @@ def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20, whole=True, nb=
             bank.set_noise_blanker(nb)
         if pieces:
             bank.set_pieces(pieces)
+        if pipelined:       # a streaming caller: a call returns with its AGC still running, the next call's filters start beside it
+            bank.set_pipelined(1)
     else:
         L.bank = bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=L.stream.cuda_stream)
     L.rate = bank.get_filter_rate()
@@ -327,6 +329,10 @@ def quisk_native(torch, qh, dev):
         L = setup_quisk_native(torch, qh, dev, name)
         t = timed(L.step, sync, steps=8, warmup=3)
         row = {"mode": name, "ms": t * 1e3, "Msamp_per_s": nch * n / t / 1e6, "filter_rate": L.rate, "filter_taps": int(L.fI.size)}
+        del L
+        L = setup_quisk_native(torch, qh, dev, name, pipelined=True)
+        tq = timed(L.step, sync, steps=8, warmup=3)
+        row.update({"pipelined_ms": tq * 1e3, "pipelined_Msamp_per_s": nch * n / tq / 1e6})
         del L
         L = setup_quisk_native(torch, qh, dev, name, whole=False)
         tb = timed(L.step, sync, steps=8, warmup=2)
