@@ -141,7 +141,12 @@ def test_config4_share_shape_chunking_and_oracle_tails(qh, oracle):
         eb.process_ptr(x.data_ptr() + 16 * pos * 1024, n_in, yb.data_ptr() + 16 * pos * 256, ya.shape[1], nb)
         pos += nb
     ea.synchronize(); eb.synchronize()
-    assert torch.equal(ya[:, :nacq * 256], yb[:, :nacq * 256])
+    if not torch.equal(ya[:, :nacq * 256], yb[:, :nacq * 256]):          # (seen once in some ten runs of the whole suite, never alone: say where)
+        d = (ya[:, :nacq * 256] - yb[:, :nacq * 256]).abs()
+        rows = (d.amax(dim=1) > 0).nonzero().flatten().tolist()
+        first = [int((d[r] > 0).nonzero()[0].item()) for r in rows[:8]]
+        raise AssertionError("two identical engines, the same ten calls: %d channels differ, e.g. %r (modes %r) from samples %r on (16-block calls of 4096), worst %.3e of %.3e"
+                             % (len(rows), rows[:8], [modes[r % 3] for r in rows[:8]], first, float(d.max().item()), float(ya[:, :nacq * 256].abs().max().item())))
     scale = float(ya.abs().max().item())
     assert scale > 0.1
     d = (ya - yb).abs().amax(dim=1)
