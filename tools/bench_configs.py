@@ -413,9 +413,10 @@ def driver_legs(torch, qh, dev, emit):
                               "modes": [dict({"mode": m["mode"], "ms_per_step": m["ms"], "Msamp_per_s": m["Msamp_per_s"],
                                               "algorithmic_GBps": 20.0 * m["Msamp_per_s"] / 1e3,
                                               "frac_of_hbm_peak": 20.0 * m["Msamp_per_s"] / 1e3 / HBM_PEAK_GBPS},
-                                             **{k: v for k, v in m.items() if k.startswith(("bank_only", "noise_blanker", "panadapter"))}) for m in r["modes"]],
+                                             **{k: v for k, v in m.items() if k.startswith(("bank_only", "noise_blanker", "panadapter", "pipelined"))}) for m in r["modes"]],
                               "agc_note": "ms_per_step: the whole function with process_agc (quisk.c:2162) on a second stream beside the next piece's filters; "
-                                          "bank_only_*: tune + decimate + demodulate alone (qh_qrx_*)",
+                                          "bank_only_*: tune + decimate + demodulate alone (qh_qrx_*); pipelined_*: the same calls when a call does not wait "
+                                          "for its own AGC (qh_qps_set_pipelined: a streaming caller's form, the next call's filters beside this call's last AGC piece)",
                               "dominant_kernel": "osfir_kernel<f64,4096,D=8,OUTMIX> (tune + collapsed 1181-tap /16)"})
     except Exception as exc:
         emit("quisk_native", {"failed": repr(exc)})
