@@ -141,8 +141,8 @@ def _walk(qh, oracle, seed, replay, wide=False):
     pos = 0
     log = []
     lms_used = [False] * NCH
-    # a minimum-phase filter of 8192 / 16384 taps: mp_imp's cepstrum (fir.c:319-368) takes the logarithm of a stop band 200 dB down over a
-    # 16 nc-point transform -- two transforms that differ in their last bits leave designs 1e-6 apart (seen: 1.4e-6 at 16384 taps)
+    # a minimum-phase filter of 4096 - 16384 taps: mp_imp's cepstrum (fir.c:319-368) takes the logarithm of a stop band 200 dB down over a
+    # 16 nc-point transform -- two transforms that differ in their last bits leave designs 1e-6 apart (seen: 1.4e-6 at 16384 taps, 1.5e-6 at 4096)
     mp_now, nc_now, mp_long = [0] * NCH, [2048] * NCH, [False] * NCH
     for s, n in enumerate(seglen):
         if s:
@@ -153,7 +153,7 @@ def _walk(qh, oracle, seed, replay, wide=False):
                 for d in log[-1][2]:
                     if d[0] == "RXASetMP": mp_now[c] = d[1]
                     if d[0] == "RXASetNC": nc_now[c] = d[1]
-                mp_long[c] = mp_long[c] or (mp_now[c] and nc_now[c] > 4096)
+                mp_long[c] = mp_long[c] or (mp_now[c] and nc_now[c] >= 4096)
         seg = x[:, pos * 1024:(pos + n) * 1024]
         if replay:
             yb = np.empty((NCH, n * 256), dtype=np.complex128)

@@ -250,6 +250,50 @@ def test_attack_window_changed_mid_stream_reads_the_full_ring(qh, oracle, form):
             a = b
 
 
+@pytest.mark.parametrize("together", [False, True], ids=["block-at-a-time", "three-blocks-a-call"])
+def test_attack_window_moved_while_the_ring_holds_exact_zeros(qh, oracle, together):
+    """xwcpagc looks its window over again only when the sample that leaves is `> 0.0` (wcpAGC.c:197): a window moved while the ring holds
+    EXACT zeros -- here behind an EMNR (and with it bp1) just switched on, whose first frames are zeros -- is not looked over until the
+    first sample of a lap ago comes out.  Block at a time (the WDSP names' way) the engine's zeros are the reference's and the gain
+    follows it.  In a call of several DSP blocks bp1's overlap-save tile spans blocks with signal in them and leaves rounding-level
+    values (1e-17 of the signal) where the reference's per-block transform gives 0.0: the window is looked over at once, and the gain
+    runs up to 1e-2 off for the few hundred samples of the jump -- a stated deviation (found by
+    tools/dbg/fuzz_sweep.py, wide seed 1252; tools/dbg/agc_attack_probe.py)."""
+    nblk = 230
+    x = synth.make_input_numpy(4, nblk * 1024)[2:3].copy()
+    e = qh.RxaEngine(1); e.load_emnr_tables()
+    o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+    for t, lead in ((e, (0,)), (o, ())):
+        t.SetRXAShiftRun(*lead, 1); t.SetRXAShiftFreq(*lead, synth.shift_freq(2)); t.RXANBPSetRun(*lead, 1)
+        t.SetRXAMode(*lead, 0); t.RXASetPassband(*lead, -3000.0, -300.0); t.SetRXAAGCMode(*lead, 3)
+
+    def run(b0, b1):
+        seg = np.ascontiguousarray(x[:, b0 * 1024:b1 * 1024])
+        return e.process_host(seg)[0], o.xrxa(seg[0])
+
+    y, r = run(0, 200)
+    assert rel_rms(y, r) < 1e-9
+    e.RXASetNC(0, 256); o.RXASetNC(256)
+    run(200, 201)
+    e.SetRXAEMNRRun(0, 1); o.SetRXAEMNRRun(1)
+    zeros = 0
+    for b0, b1 in ([(201, 204)] if together else [(201, 202), (202, 203), (203, 204)]):
+        y, r = run(b0, b1)
+        zeros += int((r == 0).sum())
+        assert np.abs(y - r).max() <= 1e-9 * max(np.abs(r).max(), 1.0)
+    assert zeros >= 256                              # the restatement's AGC is being fed exact zeros
+    e.SetRXAAGCAttack(0, 4); o.SetRXAAGCAttack(4)
+    y, r = run(204, 207)
+    assert np.abs(r).max() > 0.1 and (r[:192] == 0).all()
+    assert np.abs(y[:192]).max() < 1e-12 if together else (y[:192] == 0).all()      # (rounding-level values where the reference has 0.0)
+    err = np.abs(y - r).max() / np.abs(r).max()
+    if together:
+        assert err < 2e-2, err                       # the stated deviation, bounded
+    else:
+        assert err < 1e-9, err
+    e.close()
+
+
 def test_a_moved_attack_window_takes_only_its_own_channel_off_the_time_tiles(qh, oracle):
     """A channel whose attack window moves in mid-stream keeps the reference's ring_max bookkeeping, stale values and all (wcpAGC.c:197-210
     rescans only when the sample that leaves equals it), so it is stepped by one wavefront from then on; the other channels of the
