@@ -5,6 +5,8 @@ drawn at the start and again in mid-stream, and between buffers the detector, th
 normalisation and ResetPixelBuffers on any of up to four pixel outputs.  What is carried -- the input ring's indices, the averages'
 sums and frame rings, the pixel buffers' read / write slots -- is the state a batched form gets wrong first.  Gates as in
 tests/test_gpu_analyzer.py: the same flags from GetPixels, every pixel within one step of mlog10's table.  -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -29,7 +31,9 @@ def _geometry(rng, bf=None):
     pi = float(rng.choice([0.0, 8.0, 14.0]))
     flip = int(rng.integers(0, 2))
     pixout = int(rng.choice([1, 1, 2, 4]))
-    max_w = int(rng.choice([2, 4])) * max(size, bf) + bf
+    # (the reference's input ring holds dSAMP_BUFF_MULT = 2 times max_size samples, comm.h:134; a write-ahead beyond it lets a sub-span
+    # that waits for its set be overwritten -- garbage in the reference itself)
+    max_w = min(int(rng.choice([2, 4])) * max(size, bf) + bf, 2 * MAX_SIZE - bf)
     return (pixout, 1, typ, [flip], size, bf, win, pi, overlap, clip, fL, fH, npix, 1, 0, 0.0, 0.0, max_w)
 
 
@@ -98,3 +102,75 @@ def test_random_walk_over_the_display_engine(qh, oracle, seed):
         assert rows > 0, (seed, rows, log)               # (a large transform fed small buffers makes few frames)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_walk_over_a_bank_of_displays(qh, oracle, seed):
+    """The batched form (qh_ana_*): three displays of one configuration, one or two stitched sub-spans, SEVERAL buffers per call (so a
+    call makes no, one or many frames, and the averages run on inside it), the setters and new geometries between calls.  The
+    restatement is fed buffer by buffer in the same order, one per display; a buffer that completes several frames shows only its
+    last row through GetPixels, so rows are matched by the restatement's frame count."""
+    rng = np.random.default_rng(53000 + seed)
+    ndisp, stitch = 3, int(rng.choice([1, 1, 2]))
+    def geometry(bf=None):
+        g = list(_geometry(rng, bf))
+        g[13] = stitch
+        return tuple(g)
+    args = geometry()
+    g = qh.AnalyzerBank(ndisp, MAX_SIZE, max_stitch=2)
+    refs = [oracle.OracleAnalyzer(MAX_SIZE, 2) for _ in range(ndisp)]
+    log = [("SetAnalyzer", args)]
+    for t in [g] + refs:
+        t.SetDisplaySampleRate(RATE)
+        t.SetAnalyzer(*args)
+    xs = np.stack([np.stack([_signal(48 * MAX_SIZE, 1000 * seed + 10 * d + s) for s in range(2)]) for d in range(ndisp)])     # [disp][ss][n]
+    pos, rows = 0, 0
+    for call in range(int(rng.integers(25, 50))):
+        if call and rng.integers(0, 2) == 0:
+            for _ in range(int(rng.integers(1, 3))):
+                s = _setter(rng, args[0])
+                log.append((call, s))
+                for t in [g] + refs:
+                    getattr(t, s[0])(*s[1:])
+        if call and rng.integers(0, 12) == 0:
+            args = geometry(bf=None if rng.integers(0, 2) else args[5])
+            log.append((call, ("SetAnalyzer", args)))
+            for t in [g] + refs:
+                t.SetAnalyzer(*args)
+        bf, pixout = args[5], args[0]
+        nb = int(rng.choice([1, 1, 2, 3, 5, 9]))
+        if pos + nb * bf > xs.shape[2]:
+            break
+        made, parts = 0, [[] for _ in range(pixout)]
+        for s in range(stitch):                                          # (a call on the first sub-span can publish too: frames the other one had waiting)
+            k = g.feed_host(s, np.ascontiguousarray(xs[:, s, pos:pos + nb * bf]))
+            if k:
+                for o in range(pixout):
+                    r = g.rows_host(o)
+                    assert r.shape[1] == k, (seed, call, s, o, r.shape, k)
+                    parts[o].append(r)
+            made += k
+        got = [np.concatenate(p, axis=1) for p in parts] if made else None
+        if os.environ.get("QH_TRACE"):
+            print("call %d: %d buffers of %d per sub-span, %d rows" % (call, nb, bf, made), flush=True)
+        for d in range(ndisp):
+            a = refs[d]
+            frames0, done = a.L.ao_frames(a.h), 0
+            for s in range(stitch):                                     # (the same order of buffers as the bank's calls: sub-span by sub-span)
+                for b in range(nb):
+                    blk = xs[d, s, pos + b * bf:pos + (b + 1) * bf]
+                    buf = np.empty(2 * bf); buf[0::2] = blk.imag; buf[1::2] = blk.real
+                    a.Spectrum0(1, s, 0, buf)
+                    now = a.L.ao_frames(a.h) - frames0
+                    for o in range(pixout):
+                        want, flag = a.GetPixels(o)
+                        assert flag == int(now > done), (seed, call, d, s, b, o, flag, now, done)
+                        if flag:
+                            assert now <= made, (seed, call, d, s, b, now, made, log)
+                            _compare(got[o][d][now - 1], want, (seed, call, d, s, b, o, log))
+                            rows += 1
+                    done = now
+            assert done == made, (seed, call, d, done, made, log)
+        pos += nb * bf
+    assert rows > 0, (seed, log)
+    g.close()
