@@ -261,7 +261,9 @@ void SetRXACTCSSRun(int channel, int run);                                      
 double GetRXAMeter(int channel, int mt);                                         /* wdsp/meter.c:133-142 */
 /* Quisk's re-blocking shim around fexchange0 (quisk_wdsp.c:24-69): any nSamples in, scaled by 1/CLIP32 into
  * in_size blocks, results scaled back; returns the number of samples written to cSamples.  qh_wdsp_set_parameter
- * is the C form of quisk_wdsp_set_parameter (quisk_wdsp.c:71-91; in_size <= 0 / in_use < 0 leave the value). */
+ * is the C form of quisk_wdsp_set_parameter (quisk_wdsp.c:71-91; in_size <= 0 / in_use < 0 leave the value).  One deviation: a CHANGE
+ * of in_size starts the ring again -- the reference keeps a ring whose length is no longer a multiple of the block and reads past
+ * its end (quisk_wdsp.c:44-49,57-60). */
 int wdspFexchange0(int channel, double *cSamples, int nSamples);
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use);
 /* The same hand-off for samples that are already on the GPU (what qh_quisk_process_samples does at quisk.c:2660-2661):

@@ -790,8 +790,11 @@ int shim_side(Shim &s, bool dev, int want)
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use)
 {
     if (!valid(channel)) return;
-    if (in_size > 0) g_shim[channel].in_size = in_size;
-    if (in_use >= 0) g_shim[channel].in_use = in_use;
+    Shim &s = g_shim[channel];
+    // The reference keeps its ring's length across a change of in_size (quisk_wdsp.c:44-49 only ever grows it): a length that is not a
+    // multiple of the new block lets Rindex step past the end and fexchange0 read beyond the allocation.  Here the ring starts again.
+    if (in_size > 0 && in_size != s.in_size) { s.in_size = in_size; s.sizeBuf = 0; s.W = 0; s.R = 0; s.nBuf = 0; }
+    if (in_use >= 0) s.in_use = in_use;
 }
 
 // for qh_quisk_process_samples: the block size of the channel while quisk_wdsp.c's hand-off is in use, else 0

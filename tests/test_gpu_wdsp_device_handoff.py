@@ -25,8 +25,8 @@ def _host_call(lib, ch, seg, in_size):
 
 
 def _dev_call(lib, ch, seg, in_size, dev, stream):
-    work = torch.zeros(seg.size + 2 * in_size, dtype=torch.complex128, device=dev)
-    with torch.cuda.stream(stream):
+    with torch.cuda.stream(stream):     # (the fill too: torch's streams do not wait for the default stream)
+        work = torch.zeros(seg.size + 2 * in_size, dtype=torch.complex128, device=dev)
         work[:seg.size] = torch.from_numpy(seg).to(dev)
         n = lib.qh_wdsp_fexchange0_device(ch, C.c_void_p(work.data_ptr()), seg.size, C.c_void_p(stream.cuda_stream))
         assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
