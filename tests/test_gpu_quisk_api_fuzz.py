@@ -4,6 +4,8 @@ lengths, split Rx/Tx 0-4, the key going down and up (sidetone / silence, the key
 inversion, kill_audio, both squelches, the test tone (FM).  Mode and rates are fixed per walk (a change of mode rebuilds a bank: a
 stated deviation).  Levels stay under process_agc's limiter (the end of an overload ramp is chaotic,
 tests/test_gpu_bench_shapes.py; the machine is held bit for bit in tests/test_gpu_quisk_agc_chain.py).  -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -99,13 +101,15 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
         x[5000::9973] += 2.0 ** 21
         x[n // 2:n // 2 + n // 6] *= 0.01
         xs = _signal(mode, 1, n, fs, -15000.0, amp=2.0 ** 18) if mode == 3 else None
-        log, pos, outs, loose_until = [], 0, 0, -1
+        log, pos, outs, loose_left = [], 0, 0, 0
         for k, s in enumerate(sizes):
             if k:
                 for _ in range(int(rng.integers(1, 3))):
                     log.append((k, _draw(rng, mode, fs, play, api, ref, st)))
                     if mode in (5, 13) and log[-1][1][0] == "set_split_rxtx":
-                        loose_until = k + 1         # the second FM receiver starts on an empty delay line: arg() of rounding-level numbers again
+                        # the second FM receiver starts on an empty delay line: arg() of rounding-level numbers again, for as long as at the walk's
+                        # own start (in output samples, not calls: a short call ends inside it)
+                        loose_left = 6 * 1024 * (play // 48000) + 1024
             seg = x[pos:pos + s]
             if xs is not None:
                 api.multirx_samples(1, xs[pos:pos + s]); ref.multirx_samples(1, xs[pos:pos + s])
@@ -119,7 +123,8 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             outs += want.size
             scale = max(np.abs(want).max(), 1.0)
             err = np.abs(y[lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
-            assert err < (1e-4 if k <= loose_until else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
+            loose, loose_left = loose_left > 0, loose_left - want.size
+            assert err < (1e-4 if loose else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
     finally:
         api.close()
 
@@ -149,4 +154,135 @@ def test_set_auto_notch_leaves_the_rit_to_set_sidetone(qh, oracle):
             assert y.size == want.size
             assert np.abs(y - want).max() <= 1e-8 * max(np.abs(want).max(), 1.0), k
     finally:
+        api.close()
+
+
+class _Both:
+    """a setter goes to both of two restatements (QH_TWIN)"""
+    def __init__(self, a, b): self._a, self._b = a, b
+    def __getattr__(self, name):
+        fa, fb = getattr(self._a, name), getattr(self._b, name)
+
+        def call(*args):
+            fb(*args)
+            return fa(*args)
+        return call
+
+
+def _draw_wdsp(rng, names, ch, st):
+    """a setter on the WDSP channel in the audio path (levels untouched: process_agc behind it must stay under its limiter)"""
+    k = int(rng.integers(0, 8))
+    if k == 0:
+        lo = float(rng.uniform(100.0, 600.0)); hi = lo + float(rng.uniform(1200.0, 3200.0))
+        args = ("RXASetPassband", lo, hi)
+    elif k == 1:
+        args = ("RXASetNC", int(rng.choice([256, 512, 1024, 2048])))
+    elif k == 2:
+        args = ("RXASetMP", int(rng.integers(0, 2)))
+    elif k == 3:
+        args = ("RXANBPSetRun", int(rng.integers(0, 2)))
+    elif k == 4:
+        args = ("SetRXAShiftRun", int(rng.integers(0, 2)))
+    elif k == 5:
+        args = ("SetRXAShiftFreq", float(rng.uniform(-400.0, 400.0)))
+    elif k == 6:
+        args = ("SetRXAPanelGain1", float(rng.uniform(0.2, 1.0)))
+    else:
+        st["in_use"] ^= 1
+        return ("in_use", st["in_use"])
+    getattr(names, args[0])(*args[1:]); getattr(ch, args[0])(*args[1:])
+    return args
+
+
+@pytest.mark.parametrize("seed,mode,fs,play", [(41, 3, 192000, 48000), (42, 3, 96000, 96000), (43, 4, 192000, 48000), (44, 1, 48000, 48000),
+                                               (45, 5, 192000, 96000), (46, 2, 111111, 48000), (47, 3, 370370, 192000), (48, 4, 53333, 48000)])
+def test_random_setter_walk_with_wdsp_in_the_audio_path(qh, oracle, seed, mode, fs, play):
+    """The same walk with quisk.c:2660-2661 live: the 48 ksps audio goes through wdspFexchange0 -- this library's shim, double rings, slews
+    and RXA engine on device buffers (qh_wdsp_fexchange0_device inside qh_quisk_process_samples), the restated shim in front of the
+    restated channel on the other side -- while Quisk's setters, the WDSP channel's own (passband, nc, minimum phase, shift, notch
+    filter, panel gain) and in_use change between ragged calls."""
+    import ctypes as C
+    from test_gpu_wdsp_names_fuzz import _Names
+    rng = np.random.default_rng(7000 + seed)
+    lib = qh.load()
+    D = C.c_double
+    api = qh.quiskapi
+    api.open(fs, playback_rate=play)
+    ref = oracle.OracleQuiskBlock(fs, play, rxfilter.coefficient_tables())
+    lib.OpenChannel(0, 256, 256, 48000, 48000, 48000, 0, 1, D(0.010), D(0.025), D(0.0), D(0.010), 1)
+    assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
+    names = _Names(lib, 0, 256)
+    ch = oracle.WdspChannel(256, 256, 48000, 48000, 48000)
+    for t in (names, ch):
+        t.SetRXAShiftRun(0); t.RXANBPSetRun(0); t.SetRXAMode(1); t.RXASetPassband(200.0, 3400.0); t.RXASetNC(256); t.RXASetMP(0)
+        t.SetRXAAGCMode(0); t.SetRXAAGCFixed(0.0)
+    lib.SetRXAAMSQRun(0, 0); lib.SetRXAPanelRun(0, 0); lib.SetRXAEMNRRun(0, 0)
+    lib.qh_wdsp_set_parameter(0, 256, 0)
+    shim = oracle.OracleWdspShim(lambda pin, pout: 0)
+    shim.set_parameter(in_size=256, in_use=0)
+    ref.set_wdsp(shim, ch)
+    twin = None
+    if os.environ.get("QH_TWIN"):                        # diagnostics: a second restatement fed 1e-13 of noise per sample, the same setters
+        twin = oracle.OracleQuiskBlock(fs, play, rxfilter.coefficient_tables())
+        ch2 = oracle.WdspChannel(256, 256, 48000, 48000, 48000)
+        ch2.SetRXAShiftRun(0); ch2.RXANBPSetRun(0); ch2.SetRXAMode(1); ch2.RXASetPassband(200.0, 3400.0); ch2.RXASetNC(256); ch2.RXASetMP(0)
+        ch2.SetRXAAGCMode(0); ch2.SetRXAAGCFixed(0.0)
+        shim2 = oracle.OracleWdspShim(lambda pin, pout: 0)
+        shim2.set_parameter(in_size=256, in_use=0)
+        twin.set_wdsp(shim2, ch2)
+        ref_only, ref, ch = ref, _Both(ref, twin), _Both(ch, ch2)
+        pert = np.random.default_rng(3)
+    try:
+        st = {"rx": 8300, "tx": 9100, "in_use": 0}
+        fI, fQ = _filters(mode, fs)
+        for o in (api, ref):
+            o.set_rx_mode(mode); o.set_filters(fI, fQ, BW[mode]); o.set_agc(20.0)
+        api.set_tune2(st["rx"], st["tx"]); ref.set_tune(st["rx"], st["tx"])
+        api.set_sidetone(0.3, 600, play, 20); ref.set_sidetone(0.3, 600, 20)
+        ratio = max(1, fs // 48000)
+        sizes = [int(rng.choice([1, 2, 3, 5, 8])) * int(rng.integers(300, 1700)) * ratio for _ in range(24)]
+        sizes = [min(s, 52000, 50000 * fs // play, 11000 * (fs // 48000 or 1)) for s in sizes]
+        n = sum(sizes)
+        x = _signal(mode, 0, n, fs, float(st["rx"]), amp=2.0 ** 18)
+        x[n // 2:n // 2 + n // 6] *= 0.01
+        log, pos, outs, loose_left = [], 0, 0, 0
+        for k, s in enumerate(sizes):
+            if k == 2:                                   # WDSP on once the audio is running: its up-slew starts at the first non-zero sample, and
+                st["in_use"] = 1                         # FFT filters leave 1e-15 where FIR loops leave 0 (tests/test_gpu_quisk_process_samples.py)
+                log.append((k, ("in_use", 1)))
+            if k > 2:
+                for _ in range(int(rng.integers(0, 3))):
+                    log.append((k, _draw(rng, mode, fs, play, api, ref, st) if rng.integers(0, 2) else _draw_wdsp(rng, names, ch, st)))
+                    if mode in (5, 13) and log[-1][1][0] == "set_split_rxtx":
+                        loose_left = 6 * 1024 * (play // 48000) + 1024      # (the second FM receiver starts on an empty delay line, as in the walk above)
+            lib.qh_wdsp_set_parameter(0, -1, st["in_use"]); shim.set_parameter(in_use=st["in_use"])
+            seg = x[pos:pos + s]
+            pos += s
+            if twin:
+                shim2.set_parameter(in_use=st["in_use"])
+                y, want = api.process(seg), ref_only.process(seg)
+                t2 = twin.process(seg * (1.0 + 1e-13 * pert.standard_normal(s)))
+                if want.size:
+                    d = np.abs(y - want) / max(np.abs(want).max(), 1.0)
+                    off = np.nonzero(d > 1e-9)[0]
+                    print("call %d: engine %.2e, the restatement against its twin %.2e of the call's maximum; %d of %d samples off by more than 1e-9%s" % (
+                        k, d.max(), np.abs(t2 - want).max() / max(np.abs(want).max(), 1.0), off.size, d.size,
+                        " (samples %d .. %d, worst at %d; left %.2e right %.2e)" % (off[0], off[-1], int(d.argmax()), np.abs(y.real - want.real).max(), np.abs(y.imag - want.imag).max()) if off.size else ""), flush=True)
+            else:
+                y, want = api.process(seg), ref.process(seg)
+            assert lib.qh_wdsp_status() == 0, (seed, k, lib.qh_last_error())
+            assert y.size == want.size, (seed, k, y.size, want.size, log)
+            if want.size == 0:
+                continue
+            settle = 6 * 1024 * (play // 48000) if mode in (5, 13) else 0
+            lo = min(want.size, max(0, settle - outs))
+            outs += want.size
+            scale = max(np.abs(want).max(), 1.0)
+            err = np.abs(y[lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
+            loose, loose_left = loose_left > 0, loose_left - want.size
+            assert twin or err < (1e-4 if loose else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
+    finally:
+        lib.qh_wdsp_set_parameter(0, -1, 0)
+        lib.wdspFexchange0(0, None, 0)
+        lib.CloseChannel(0)
         api.close()
