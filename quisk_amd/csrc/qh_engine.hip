@@ -1194,7 +1194,7 @@ int Engine::snba_set_ovrlp(int ovrlp)
     const SnbaParam &q = snba_prm;
     (void)hipFree(snba_state); snba_state = nullptr;
     QH_HIP(dev_alloc(&snba_state, (size_t)nch * q.state_doubles));
-    QH_HIP(hipMemset(snba_state, 0, (size_t)nch * q.state_doubles * sizeof(double)));
+    QH_HIP(qh::dev_zero(snba_state, (size_t)nch * q.state_doubles * sizeof(double)));
     QH_HIP(hipMemcpy2D(snba_state, (size_t)q.state_doubles * sizeof(double), frames.data(), 2 * kSnbX * sizeof(double), 2 * kSnbX * sizeof(double),
                        (size_t)nch, hipMemcpyHostToDevice));
     std::vector<SnbaIdx> ix((size_t)nch, SnbaIdx{ 0, 0, 0, 0, q.init_oaoutidx, { 0, 0, 0 } });

@@ -29,4 +29,13 @@ template <typename T> static inline hipError_t dev_alloc(T **p, size_t n)
     return e;
 }
 
+// Zeros for a buffer that kernels on a NON-BLOCKING stream will use next: hipMemset runs on the null stream, which such streams do not wait
+// for, and the API lets it return before the fill has run (it does not on this ROCm, but nothing promises that)
+static inline hipError_t dev_zero(void *p, size_t bytes)
+{
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e;
+}
+
 }  // namespace qh

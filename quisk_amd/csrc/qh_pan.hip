@@ -910,7 +910,7 @@ qh_pan *qh_pan_create(int device, int nch, int fft_size, int data_width, double 
         return fail("hipMalloc");
     if (hipMemcpy(p.tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(p.band, p.hband.data(), (size_t)nch * sizeof(PanBand), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(p.avg, 0, (size_t)nch * fft_size * 8) != hipSuccess || hipMemset(p.meter, 0, (size_t)nch * 8) != hipSuccess)
+        qh::dev_zero(p.avg, (size_t)nch * fft_size * 8) != hipSuccess || qh::dev_zero(p.meter, (size_t)nch * 8) != hipSuccess)
         return fail("initial copies");
     if (p.blue) {
         const int N = fft_size;
@@ -1049,7 +1049,7 @@ int qh_pan_attach_fir(qh_pan *h, const double *taps, int ntaps, int decim)
     }
     QH_HIP(hipMemcpy(p.fir_H, hr.data(), (size_t)N * 16, hipMemcpyHostToDevice));
     QH_HIP(hipMemcpy(p.fir_taps, taps, (size_t)ntaps * 8, hipMemcpyHostToDevice));
-    for (auto &q : p.fir_hist) QH_HIP(hipMemset(q, 0, (size_t)p.nch * 1024 * 16));
+    for (auto &q : p.fir_hist) QH_HIP(qh::dev_zero(q, (size_t)p.nch * 1024 * 16));
     p.fir_ntaps = ntaps; p.fir_decim = decim; p.fir_hl = hl; p.fir_cur = 0;
     return QH_OK;
 }

@@ -185,10 +185,10 @@ qh_qps *qh_qps_create(int device, int nch, int sample_rate, int playback_rate, i
     if (qh_qagc_set_gain(h->agc, -1, h->agc_gain)) return fail(nullptr);
     for (int i = 0; i < 2; i++) {
         if (hipMalloc((void **)&h->fd_hist[i], (size_t)nch * 3 * sizeof(double2)) != hipSuccess) return fail("hipMalloc");
-        if (hipMemset(h->fd_hist[i], 0, (size_t)nch * 3 * sizeof(double2)) != hipSuccess) return fail("hipMemset");
+        if (qh::dev_zero(h->fd_hist[i], (size_t)nch * 3 * sizeof(double2)) != hipSuccess) return fail("hipMemset");
     }
     if (hipMalloc((void **)&h->d_flags, (size_t)nch * 2 * sizeof(int)) != hipSuccess) return fail("hipMalloc");
-    if (hipMemset(h->d_flags, 0, (size_t)nch * 2 * sizeof(int)) != hipSuccess) return fail("hipMemset");
+    if (qh::dev_zero(h->d_flags, (size_t)nch * 2 * sizeof(int)) != hipSuccess) return fail("hipMemset");
     h->h_flags.assign((size_t)nch * 2, 0);
     return h;
 }

@@ -278,7 +278,7 @@ struct Qrx {
         for (int i = 0; i < 2; i++) {
             (void)hipFree(rx_dly[i]); rx_dly[i] = nullptr;
             QH_HIP(hipMalloc((void **)&rx_dly[i], (size_t)nch * (size_t)D * sizeof(cd)));
-            QH_HIP(hipMemset(rx_dly[i], 0, (size_t)nch * (size_t)D * sizeof(cd)));
+            QH_HIP(qh::dev_zero(rx_dly[i], (size_t)nch * (size_t)D * sizeof(cd)));
         }
         for (int c = 0; c < nch; c++) if (int rc = rx_hist_write(c, keep[(size_t)c])) return rc;
         return QH_OK;
@@ -502,7 +502,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
     }
     if (is_fm(mode)) { Step nt; nt.kind = Step::NOTCH; nt.dup = true; q.steps.push_back(nt); }     // after the interpolators, quisk.c:2069-2070
     if (is_am(mode)) {
-        if (hipMalloc((void **)&q.dc_state, (size_t)nch * 8) != hipSuccess || hipMemset(q.dc_state, 0, (size_t)nch * 8) != hipSuccess) {
+        if (hipMalloc((void **)&q.dc_state, (size_t)nch * 8) != hipSuccess || qh::dev_zero(q.dc_state, (size_t)nch * 8) != hipSuccess) {
             set_error(QH_ERR_HIP, "allocation failed"); return fail();
         }
     }
@@ -515,7 +515,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
         }
         q.h_sq_level.assign((size_t)nch, -999.0);                                           // squelch_level, quisk.c:193
         if (hipMalloc((void **)&q.sq_state, (size_t)nch * sizeof(QSquelchState)) != hipSuccess ||
-            hipMemset(q.sq_state, 0, (size_t)nch * sizeof(QSquelchState)) != hipSuccess ||
+            qh::dev_zero(q.sq_state, (size_t)nch * sizeof(QSquelchState)) != hipSuccess ||
             hipMalloc((void **)&q.sq_level, (size_t)nch * 8) != hipSuccess ||
             hipMemcpy(q.sq_level, q.h_sq_level.data(), (size_t)nch * 8, hipMemcpyHostToDevice) != hipSuccess) {
             set_error(QH_ERR_HIP, "allocation failed"); return fail();

@@ -786,10 +786,10 @@ static int open_locked(int sample_rate, int playback_rate, const qh_qrx_tables *
     g.squelch_level = -999.0; g.ssb_squelch_enabled = 0; g.ssb_squelch_level = 0; g.ssb_planned = false;
     for (int i = 0; i < 2; i++) {
         QH_HIP(hipMalloc((void **)&g.fd_hist[i], 3 * sizeof(double2)));
-        QH_HIP(hipMemset(g.fd_hist[i], 0, 3 * sizeof(double2)));
+        QH_HIP(qh::dev_zero(g.fd_hist[i], 3 * sizeof(double2)));
     }
     QH_HIP(hipMalloc((void **)&g.d_flags, 2 * sizeof(int)));
-    QH_HIP(hipMemset(g.d_flags, 0, 2 * sizeof(int)));
+    QH_HIP(qh::dev_zero(g.d_flags, 2 * sizeof(int)));
     QH_HIP(hipHostMalloc((void **)&g.h_flags, 2 * sizeof(int), hipHostMallocDefault));
     for (auto &row : g.b2c) for (auto &bb : row) if (int rc = bb.need(kBuf2Chan)) return rc;
     if (fft_size > 0 && data_width > 0) {

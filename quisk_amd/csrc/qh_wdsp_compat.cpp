@@ -769,8 +769,8 @@ int shim_side(Shim &s, bool dev, int want)
             double *nb = nullptr;
             if (hipMalloc((void **)&nb, (size_t)want * 16) != hipSuccess) return qh::set_error(QH_ERR_HIP, "wdspFexchange0: ring allocation failed");
             (void)hipDeviceSynchronize();
-            (void)hipMemset(nb, 0, (size_t)want * 16);
-            if (s.dev && s.sizeBuf > 0) (void)hipMemcpy(nb, s.d_buf, (size_t)s.sizeBuf * 16, hipMemcpyDeviceToDevice);
+            (void)qh::dev_zero(nb, (size_t)want * 16);
+            if (s.dev && s.sizeBuf > 0) { (void)hipMemcpy(nb, s.d_buf, (size_t)s.sizeBuf * 16, hipMemcpyDeviceToDevice); (void)hipDeviceSynchronize(); }
             if (s.d_buf) (void)hipFree(s.d_buf);
             s.d_buf = nb; s.d_cap = want;
         }
