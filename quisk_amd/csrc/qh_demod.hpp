@@ -503,10 +503,22 @@ static __global__ __launch_bounds__(256) void agc_rewindow_kernel(const int *cha
     AgcState *sp = state + ch;
     const int ol = sp->out_index;
     const long long og = lout[ch];
+    // xwcpagc looks a moved window over only when the sample that leaves is `> 0.0` (wcpAGC.c:197).  Where the reference's per-block
+    // transforms leave 0.0 (behind a stage just switched on, a muted input) an overlap-save tile that also holds signal leaves its
+    // rounding floor, 1e-17 of that signal: entries below 1e-13 of the largest magnitude of the last RB_SIZE samples are taken for the
+    // zeros they are in the reference (tests/test_gpu_wcpagc_batch.py::test_attack_window_moved_while_the_ring_holds_exact_zeros).
+    __shared__ double red[4];
+    double m = 0.0;
+    for (int k = threadIdx.x; k < kAgcLongRing; k += blockDim.x) m = fmax(m, labs[(long long)ch * kAgcLongRing + k]);
+    m = wave_max_d(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const double floor_ = 1e-13 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     for (int k = 1 + threadIdx.x; k < kAgcRing; k += blockDim.x) {
         const int src = (int)((og + k) % kAgcLongRing), dst = (ol + k) & (kAgcRing - 1);
-        sp->ring[dst] = lring[(long long)ch * kAgcLongRing + src];
-        sp->abs_ring[dst] = labs[(long long)ch * kAgcLongRing + src];
+        const double a = labs[(long long)ch * kAgcLongRing + src];
+        sp->ring[dst] = a < floor_ ? make_double2(0.0, 0.0) : lring[(long long)ch * kAgcLongRing + src];
+        sp->abs_ring[dst] = a < floor_ ? 0.0 : a;
     }
 }
 
