@@ -190,7 +190,23 @@ int interp_decim(double *x, int width, int count, struct quisk_cFilter *f, int i
     if (count <= 0 || !f || interp <= 0 || decim <= 0 || !f->dCoefs) return 0;
     std::lock_guard<std::mutex> lk(g_mtx);
     const int used = (f->nTaps / interp) * interp;              // filter.c:149,308: nTaps / interp taps per phase
-    if (used <= 0) return 0;
+    if (used <= 0) {
+        // fewer taps than phases: the reference's inner loop runs nTaps / interp = 0 times and every output is 0.0 -- their count, the
+        // ring and the phase move on all the same (filter.c:146-163, 303-322)
+        if (f->nTaps <= 0) return 0;
+        Ring r{ f->cSamples, width, f->nTaps, (int)((f->ptcSamp - f->cSamples) / width) };
+        r.push(x, width, count);
+        f->ptcSamp = f->cSamples + (size_t)width * r.pos;
+        long long nout = 0;
+        if (keep_phase) {
+            int di = f->decim_index;
+            for (int i = 0; i < count; i++) { while (di < interp) { nout++; di += decim; } di -= interp; }
+            f->decim_index = di;
+        } else nout = (long long)count * interp;
+        if (nout > kOutCap) nout = kOutCap;
+        std::memset(x, 0, (size_t)nout * width * sizeof(double));
+        return (int)nout;
+    }
     qh_rat *b = rat_for(f->dCoefs, used, interp, decim);
     if (!b) return 0;
     Ring r{ f->cSamples, width, f->nTaps, (int)((f->ptcSamp - f->cSamples) / width) };

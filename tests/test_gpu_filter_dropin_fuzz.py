@@ -27,7 +27,8 @@ KINDS = [
 ]
 
 
-@pytest.mark.parametrize("seed", list(range(1, 31)))
+# (124, 303, 364: one tap for several phases -- the reference then puts out zeros, found by tools/dbg/walk_sweep.py)
+@pytest.mark.parametrize("seed", list(range(1, 31)) + [124, 303, 364])
 def test_one_struct_between_this_library_and_the_reference(qh, oracle, seed):
     ref = oracle.ref_filter_lib()
     if ref is None:
