@@ -106,7 +106,9 @@ int decimate(double *x, int count, struct quisk_cFilter *f, int decim, bool cplx
         f->cSamples[2 * w + 1] = x[2 * i + 1];
         if (++w >= nt) w = 0;
     }
-    const int phase = f->decim_index;
+    // a decim_index left behind by a LARGER factor (the same struct used with another decim): the reference's `++decim_index >= decim`
+    // then fires at the first sample (filter.c:213,241,269), which is what the last phase does
+    const int phase = f->decim_index < 0 ? 0 : f->decim_index >= decim ? decim - 1 : f->decim_index;
     const int nout = run_block(b, nt > 1 ? hist.data() : nullptr, phase, x, count, decim);
     f->ptcSamp = f->cSamples + 2 * w;
     f->decim_index = (phase + count) % decim;
@@ -237,7 +239,7 @@ int real_decimate(double *x, int count, struct quisk_cFilter *f, int decim, bool
     std::vector<double> in((size_t)count * 2, 0.0);
     for (int i = 0; i < count; i++) in[2 * (size_t)i] = x[i];
     r.push(x, 1, count);
-    const int phase = f->decim_index;
+    const int phase = f->decim_index < 0 ? 0 : f->decim_index >= decim ? decim - 1 : f->decim_index;     // (as in decimate() above)
     const int nout = run_block(b, f->nTaps > 1 ? hist.data() : nullptr, phase, in.data(), count, decim);
     f->ptcSamp = f->cSamples + r.pos;
     f->decim_index = (phase + count) % decim;

@@ -27,8 +27,9 @@ KINDS = [
 ]
 
 
-# (124, 303, 364: one tap for several phases -- the reference then puts out zeros, found by tools/dbg/walk_sweep.py)
-@pytest.mark.parametrize("seed", list(range(1, 31)) + [124, 303, 364])
+# (124, 303, 364: one tap for several phases -- the reference then puts out zeros, found by tools/dbg/walk_sweep.py; above 1000: factors
+# that change in mid-stream)
+@pytest.mark.parametrize("seed", list(range(1, 31)) + [124, 303, 364] + list(range(1001, 1013)))
 def test_one_struct_between_this_library_and_the_reference(qh, oracle, seed):
     ref = oracle.ref_filter_lib()
     if ref is None:
@@ -50,14 +51,16 @@ def test_one_struct_between_this_library_and_the_reference(qh, oracle, seed):
                 side.quisk_filt_tune(C.byref(st), 0.0731, int(seed % 2))
         sts.append(st)
     if cpx and grow > 1:
-        run = lambda fn, x, st: call_grow(fn, x, st, *args, grow=grow)
+        run = lambda fn, x, st: call_grow(fn, x, st, *args, grow=6)
     elif cpx:
         run = lambda fn, x, st: call(fn, x, st, *args)
     else:
-        run = lambda fn, x, st: call_real(fn, x, st, *args, grow=grow)
+        run = lambda fn, x, st: call_real(fn, x, st, *args, grow=max(grow, 4))
     sizes = [int(rng.choice([0, 1, 2, 3, 17, 64, 257, 700, 701, 1024, 1999, 4099])) for _ in range(18)]
     total, gpu_calls = 0, 0
     for k, n in enumerate(sizes):
+        if seed > 1000 and k and rng.integers(0, 4) == 0:            # (walks above 1000: another decimation / interpolation factor in mid-stream,
+            args = mkargs(rng)                                      #  the struct's decim_index carried over from the old one)
         x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cpx else 0.0)
         x = np.ascontiguousarray(x if cpx else x.real)
         ours = rng.integers(0, 2) == 0 or k == 0
