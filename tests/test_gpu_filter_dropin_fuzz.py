@@ -24,12 +24,15 @@ KINDS = [
     ("quisk_cDecim2HB45", True, None, lambda r: (), 1),
     ("quisk_cInterp2HB45", True, None, lambda r: (), 2),
     ("quisk_dInterp2HB45", False, None, lambda r: (), 2),
+    ("quisk_cFilter", True, "quisk_filt_cInit", lambda r: (), 1),
 ]
+# walks above 2000: ONE struct handed to another primitive of its family from call to call (the ring and decim_index are all they share)
+FAMILY = {True: ["quisk_cDecimate", "quisk_cInterpolate", "quisk_cInterpDecim", "quisk_cFilter"], False: ["quisk_dDecimate", "quisk_dFilter", "quisk_dInterpolate"]}
 
 
 # (124, 303, 364: one tap for several phases -- the reference then puts out zeros, found by tools/dbg/walk_sweep.py; above 1000: factors
-# that change in mid-stream)
-@pytest.mark.parametrize("seed", list(range(1, 31)) + [124, 303, 364] + list(range(1001, 1013)))
+# that change in mid-stream; above 2000: the struct handed from primitive to primitive as well)
+@pytest.mark.parametrize("seed", list(range(1, 31)) + [124, 303, 364] + list(range(1001, 1013)) + list(range(2001, 2013)))
 def test_one_struct_between_this_library_and_the_reference(qh, oracle, seed):
     ref = oracle.ref_filter_lib()
     if ref is None:
@@ -50,17 +53,19 @@ def test_one_struct_between_this_library_and_the_reference(qh, oracle, seed):
                 side.quisk_filt_tune.argtypes = [C.c_void_p, C.c_double, C.c_int]
                 side.quisk_filt_tune(C.byref(st), 0.0731, int(seed % 2))
         sts.append(st)
-    if cpx and grow > 1:
-        run = lambda fn, x, st: call_grow(fn, x, st, *args, grow=6)
-    elif cpx:
-        run = lambda fn, x, st: call(fn, x, st, *args)
-    else:
-        run = lambda fn, x, st: call_real(fn, x, st, *args, grow=max(grow, 4))
+    def run(fn, x, st):
+        if cpx:
+            return call_grow(fn, x, st, *args, grow=6)
+        return call_real(fn, x, st, *args, grow=4)
+    by_name = {k[0]: k for k in KINDS}
     sizes = [int(rng.choice([0, 1, 2, 3, 17, 64, 257, 700, 701, 1024, 1999, 4099])) for _ in range(18)]
     total, gpu_calls = 0, 0
     for k, n in enumerate(sizes):
         if seed > 1000 and k and rng.integers(0, 4) == 0:            # (walks above 1000: another decimation / interpolation factor in mid-stream,
-            args = mkargs(rng)                                      #  the struct's decim_index carried over from the old one)
+            args = by_name[name][3](rng)                            #  the struct's decim_index carried over from the old one)
+        if seed > 2000 and k and not hb and name != "quisk_cCDecimate" and rng.integers(0, 3) == 0:
+            name = str(rng.choice(FAMILY[cpx]))
+            args = by_name[name][3](rng)
         x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cpx else 0.0)
         x = np.ascontiguousarray(x if cpx else x.real)
         ours = rng.integers(0, 2) == 0 or k == 0
