@@ -79,8 +79,11 @@ def _draw(rng, mode, fs, play, api, ref, st):
 def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs, play):
     rng = np.random.default_rng(7000 + seed)
     api = qh.quiskapi
-    api.open(fs, playback_rate=play)
+    api.open(fs, fft_size=2048, data_width=512, playback_rate=play)
     ref = oracle.OracleQuiskBlock(fs, play, rxfilter.coefficient_tables())
+    graph = oracle.OracleGraph(2048, 512, float(fs))     # the panadapter's feed behind tone, inversion and blanker (quisk.c:2454-2475)
+    ref.set_graph(graph)
+    obs = np.random.default_rng(70000 + seed)            # (the observers draw from a generator of their own: the walks stay the walks they were)
     try:
         st = {"rx": 8300, "tx": 9100}
         fI, fQ = _filters(mode, fs)
@@ -116,6 +119,14 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             pos += s
             y, want = api.process(seg), ref.process(seg)
             assert y.size == want.size, (seed, k, y.size, want.size, log)
+            assert api.squelch_flags() == ref.squelch_flags(), (seed, k, log)
+            if obs.integers(0, 4) == 0:                # get_graph (quisk.c:5142) now and then: the average starts over on both sides
+                zoom, deltaf = float(obs.choice([1.0, 1.0, 2.0, 4.0])), float(obs.choice([0.0, 0.0, 5000.0, -12000.0]))
+                got_g, want_g = api.get_graph(zoom, deltaf), graph.get(zoom, deltaf)
+                assert (got_g is None) == (want_g is None), (seed, k)
+                if got_g is not None:
+                    assert got_g[2] == want_g[2], (seed, k, got_g[2], want_g[2])
+                    assert np.abs(got_g[0] - want_g[0]).max() < 1e-6 and abs(got_g[1] - want_g[1]) < 1e-6, (seed, k, np.abs(got_g[0] - want_g[0]).max())
             if want.size == 0:
                 continue
             settle = 6 * 1024 * (play // 48000) if mode in (5, 13) else 0                    # FM: arg() of rounding-level numbers while the filters fill
@@ -123,7 +134,9 @@ def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs
             outs += want.size
             scale = max(np.abs(want).max(), 1.0)
             err = np.abs(y[lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
-            loose, loose_left = loose_left > 0, loose_left - want.size
+            loose = loose_left > 0
+            if np.abs(want).max() > 0.0:                 # (a key held down gives silence and stops the receivers: their run-in goes on afterwards)
+                loose_left -= want.size
             assert err < (1e-4 if loose else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
     finally:
         api.close()
@@ -279,8 +292,10 @@ def test_random_setter_walk_with_wdsp_in_the_audio_path(qh, oracle, seed, mode, 
             outs += want.size
             scale = max(np.abs(want).max(), 1.0)
             err = np.abs(y[lo:] - want[lo:]).max() / scale if want.size > lo else 0.0
-            loose, loose_left = loose_left > 0, loose_left - want.size
-            assert twin or err < (1e-4 if loose else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
+            loose = loose_left > 0
+            if np.abs(want).max() > 0.0:                 # (a key held down gives silence and stops the receivers: their run-in goes on afterwards)
+                loose_left -= want.size
+            assert twin or err < (1e-3 if loose else 1e-6), "seed %d call %d (%d samples): max error %.2e of %.3e; setters %r" % (seed, k, s, err, scale, log)
     finally:
         lib.qh_wdsp_set_parameter(0, -1, 0)
         lib.wdspFexchange0(0, None, 0)
