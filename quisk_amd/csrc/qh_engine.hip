@@ -104,6 +104,7 @@ struct ChanCfg {
     // snba (wdsp/snb.c) and its bandpass bpsnba (snb.c:696-855; run / position follow the mode, RXA.c:883-917)
     int snba_run = 0, snb_hist_at = 0;
     int fm_hist_at = 0;                                         // ping-pong half that holds this channel's FM fircore delay lines
+    int bp1_hist_at = 0;                                        // ... and bp1's (SetRXABandpassRun switches it on WITHOUT the flush of RXAbp1Set)
     bool snba_flush = false, snba_taps_dirty = true, snba_rout_flush = false, snb_dirty = true, snb_flush = false;
     double snba_f_low = 200.0, snba_f_high = 0.0;               // outresamp fc_low / fcin (snb.c:45-46, resample.c:195-204)
     int snb_pos() const {
@@ -230,7 +231,7 @@ struct Engine {
     SnbaTune *snba_tune = nullptr;          // [nch]; host copy below, uploaded when a tuning setter has run
     std::vector<SnbaTune> snba_tune_h;
     bool snba_tune_dirty = true;
-    std::vector<char> snb_listed, fm_listed;
+    std::vector<char> snb_listed, fm_listed, bp1_listed;
     int snba_alloc();
     int snba_ovrlp = 4;                 // create_rxa's overlap (RXA.c:244): incr = xsize / 4
     void snba_plan(int ovrlp);
@@ -848,6 +849,25 @@ int Engine::refresh_demod()
                 }
         }
         {
+            // bp1's fircore keeps its delay line while it does not run, and SetRXABandpassRun (bandpass.c:385-390) switches it on without
+            // RXAbp1Set's flush (RXA.c:825): the rows are in the half that was current when the channel left the list
+            if (bp1_listed.size() != (size_t)nch) bp1_listed.assign((size_t)nch, 0);
+            for (int ch = 0; ch < nch; ch++) if (bp1_listed[(size_t)ch]) cfg[(size_t)ch].bp1_hist_at = cur_bp1;
+            std::fill(bp1_listed.begin(), bp1_listed.end(), 0);
+            for (int ch : lb) {
+                ChanCfg &c = cfg[(size_t)ch];
+                if (c.bp1_hist_at != cur_bp1) {
+                    QH_HIP(hipMemcpyAsync(hist_bp1[cur_bp1] + (size_t)ch * kHistBand, hist_bp1[c.bp1_hist_at] + (size_t)ch * kHistBand,
+                                          kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                    if (lhist[1][0] && lhist[1][1])
+                        QH_HIP(hipMemcpyAsync(lhist[1][cur_bp1] + (size_t)ch * kLongHist, lhist[1][c.bp1_hist_at] + (size_t)ch * kLongHist,
+                                              kLongHist * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                }
+                c.bp1_hist_at = cur_bp1;
+                bp1_listed[(size_t)ch] = 1;
+            }
+        }
+        {
             // the FM de-emphasis / audio fircores keep their delay lines while the channel is in another mode (SetRXAMode only
             // clears fmd's run flag, RXA.c:758-776): the ping-pong pair flips for the listed channels only, so a channel that
             // comes back finds its rows in the half that was current when it left
@@ -960,12 +980,16 @@ int Engine::refresh_demod()
         QH_HIP(hipStreamSynchronize(stream));
         lists_dirty = false;
     }
-    int want_nc = 0;
+    int want_nc = 0, want_mp = -1;
     for (int ch = 0; ch < nch; ch++) {
         ChanCfg &c = cfg[(size_t)ch];
         if (c.fmd_run) {
             if (want_nc && want_nc != c.fm_nc) return set_error(QH_ERR_UNSUPPORTED, "FM channels with different nc in one engine");
             want_nc = c.fm_nc;
+            // RXASetMP reaches the FM filters of ITS channel (SetRXAFMMPde / MPaud, wdsp/RXA.c:956-957): the one design the engine's FM
+            // channels share follows them, not whichever channel was set last
+            if (want_mp >= 0 && want_mp != c.mp) return set_error(QH_ERR_UNSUPPORTED, "FM channels with different RXASetMP in one engine");
+            want_mp = c.mp;
         }
         if (c.agc_dirty) {
             // loadWcpAGC, wdsp/wcpAGC.c:115-146, with create_rxa's constants (RXA.c:335-358)
@@ -1132,6 +1156,7 @@ int Engine::refresh_demod()
         QH_HIP(hipStreamSynchronize(stream));
         c.demod_dirty = false;
     }
+    if (want_mp >= 0) fm_mp = want_mp;
     if (want_nc && (want_nc != fm_nc_built || fm_mp != fm_mp_built || fm_nfft_built != 2 * bnfft + (band2g ? 1 : 0))) {
         // create_fmd, wdsp/fmd.c:108-116: de-emphasis by frequency sampling, audio band-pass 0.8*f_low .. 1.1*f_high
         const double f_low = 300.0, f_high = 3000.0, afgain = 0.5;
@@ -2804,7 +2829,6 @@ int qh_rxa_RXANBPSetAutoIncrease(qh_rxa *h, int ch, int autoincr) { FOR_CH(h, ch
 int qh_rxa_RXASetMP(qh_rxa *h, int ch, int mp)
 {
     mp = mp ? 1 : 0;
-    if (h) h->e.fm_mp = mp;
     FOR_CH(h, ch, {
         if (c.mp != mp) { c.mp = mp; c.nbp_dirty = true; c.bp1_dirty = true; c.demod_dirty = true; }
     });
@@ -2813,7 +2837,9 @@ int qh_rxa_RXASetMP(qh_rxa *h, int ch, int mp)
 int qh_rxa_SetRXAShiftRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { c.shift_run = run; c.nco_dirty = true; }); }
 int qh_rxa_SetRXAShiftFreq(qh_rxa *h, int ch, double f) { FOR_CH(h, ch, { c.shift_freq = f; c.nco_dirty = true; }); }
 int qh_rxa_RXANBPSetRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.nbp_run != run) { c.nbp_run = run; c.nbp_dirty = true; } }); }
-int qh_rxa_SetRXABandpassRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.bp1_run != run) { c.bp1_run = run; c.bp1_dirty = true; h->e.lists_dirty = true; } }); }
+// (bandpass.c:385-390 writes the flag and nothing else; where a fixed AGC gain is applied -- at the AGC's own spot or in the output matrix --
+// depends on it: fix_before)
+int qh_rxa_SetRXABandpassRun(qh_rxa *h, int ch, int run) { FOR_CH(h, ch, { if (c.bp1_run != run) { c.bp1_run = run; c.bp1_dirty = true; c.epi_dirty = true; h->e.lists_dirty = true; } }); }
 int qh_rxa_SetRXAAMDSBMode(qh_rxa *h, int ch, int sbmode) { FOR_CH(h, ch, { c.sbmode = sbmode; c.demod_dirty = true; }); }
 int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *h, int ch, int levelfade) { FOR_CH(h, ch, { c.levelfade = levelfade; c.demod_dirty = true; }); }
 int qh_rxa_SetRXAFMDeviation(qh_rxa *h, int ch, double deviation) { FOR_CH(h, ch, { c.fm_dev = deviation; c.demod_dirty = true; }); }

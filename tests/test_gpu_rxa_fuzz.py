@@ -189,3 +189,124 @@ def _walk(qh, oracle, seed, replay, wide=False):
                                          (seed, c, err, s, [l for l in log if l[0] <= s and l[1] == c]))
                 p0 += n
         assert err < tol
+
+
+def _apply2(rng, targets, notches, fm):
+    """The setters _apply leaves out: the notch database's edits and its filter's window / auto-increase / edges / shift, the LMS filters'
+    sizes and constants, bp1's run flag, the second panel gain -- and, on the one channel that may (fm), the FM detector: mode 5 in and
+    out in mid-stream (its filters primed by then: the pull-in is then well-conditioned), deviation, CTCSS notch,
+    the limiter.  notches: how many notches the channel's database holds (a list of one int, kept by the caller)."""
+    k = int(rng.integers(0, 14 if fm else 10))
+    done = []
+
+    def call(name, *args):
+        done.append((name,) + args)
+        for t, lead in targets:
+            getattr(t, name)(*lead, *args)
+    if k == 0 and notches[0] > 0:
+        call("RXANBPDeleteNotch", int(rng.integers(0, notches[0]))); notches[0] -= 1
+    elif k == 1 and notches[0] > 0:
+        call("RXANBPEditNotch", int(rng.integers(0, notches[0])), float(rng.uniform(-3000, 3000)), float(rng.uniform(50, 400)), int(rng.integers(0, 2)))
+    elif k <= 2:
+        call("RXANBPAddNotch", notches[0], float(rng.uniform(-3000, 3000)), float(rng.uniform(50, 400)), int(rng.integers(0, 2))); notches[0] += 1
+    elif k == 3:
+        call("RXANBPSetWindow", int(rng.integers(0, 2)))
+    elif k == 4:
+        call("RXANBPSetAutoIncrease", int(rng.integers(0, 2)))
+    elif k == 5:
+        lo = float(rng.uniform(-4000, 2000))
+        call("RXANBPSetFreqs", lo, lo + float(rng.uniform(300, 4000)))
+    elif k == 6:
+        call("RXANBPSetShiftFrequency", float(rng.uniform(-2000, 2000)))
+    elif k == 7:
+        which = "SetRXAANFVals" if rng.integers(0, 2) else "SetRXAANRVals"
+        call(which, int(rng.choice([16, 32, 64])), int(rng.choice([8, 16, 50])), float(rng.choice([1e-4, 2e-4, 1e-3])), float(rng.choice([0.1, 1e-3, 1e-2])))      # (the engine: up to 64 taps, one per lane)
+    elif k == 8:
+        call("SetRXABandpassRun", int(rng.integers(0, 2)))
+    elif k == 9:
+        call("SetRXAPanelGain2", float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+    elif k == 10:
+        call("SetRXAMode", int(rng.choice([5, 5, 1])))
+    elif k == 11:
+        call("SetRXAFMDeviation", float(rng.choice([2500.0, 5000.0])))
+    elif k == 12:
+        call("SetRXACTCSSFreq", float(rng.choice([67.0, 100.0, 151.4, 250.3]))); call("SetRXACTCSSRun", int(rng.integers(0, 2)))
+    else:
+        call("SetRXAFMLimRun", int(rng.integers(0, 2))); call("SetRXAFMLimGain", float(rng.uniform(0.0, 20.0)))
+    return done
+
+
+@pytest.mark.parametrize("seed", list(range(301, 313)))
+def test_random_setter_walk_with_the_notch_database_the_lms_sizes_and_fm(qh, oracle, seed):
+    """The walks with the second menu mixed in (_apply2); channel 3 alone may become an FM channel (one FM filter length per engine)."""
+    rng = np.random.default_rng(seed)
+    nseg = 40
+    seglen = [int(rng.integers(2, 9)) for _ in range(nseg)]
+    nblk = sum(seglen)
+    x = synth.make_input_numpy(NCH, nblk * 1024)
+    x[1] = synth.make_mode_input_numpy("am", 1, nblk * 1024)
+    x[3] = synth.make_mode_input_numpy("fm", 3, nblk * 1024)
+    e = qh.RxaEngine(NCH)
+    e.load_emnr_tables()
+    os_ = [oracle.WdspChannel(1024, 256, 192000, 48000, 48000) for _ in range(NCH)]
+    for c in range(NCH):
+        for t, lead in ((e, (c,)), (os_[c], ())):
+            t.SetRXAShiftRun(*lead, 1); t.SetRXAShiftFreq(*lead, synth.shift_freq(c)); t.RXANBPSetRun(*lead, 1)
+            t.SetRXAMode(*lead, (1, 6, 0, 1)[c]); t.RXASetPassband(*lead, *((300.0, 3000.0), (-4000.0, 4000.0), (-3000.0, -300.0), (-8000.0, 8000.0))[c])
+            t.SetRXAAGCMode(*lead, (0, 3, 4, 0)[c])
+    notches = [[0] for _ in range(NCH)]
+    ys, rs, pos, log, lms_used, fm_used = [], [[] for _ in range(NCH)], 0, [], [False] * NCH, False
+    import os
+    skip = set(filter(None, os.environ.get("QH_SKIP", "").split(",")))         # diagnostics: these setters are left out on every side
+
+    class _Skipping:
+        def __init__(self, t): self._t = t
+        def __getattr__(self, name):
+            return (lambda *a: None) if name in skip else getattr(self._t, name)
+    if skip:
+        e_run, e = e, _Skipping(e)
+        os_run, os_ = os_, [_Skipping(o) for o in os_]
+    else:
+        e_run, os_run = e, os_
+    twin_c = int(os.environ["QH_TWIN"]) if os.environ.get("QH_TWIN") else None       # diagnostics: that channel's restatement once more, fed 1e-13 of noise
+    if twin_c is not None:
+        c = twin_c
+        twin = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        twin.SetRXAShiftRun(1); twin.SetRXAShiftFreq(synth.shift_freq(c)); twin.RXANBPSetRun(1)
+        twin.SetRXAMode((1, 6, 0, 1)[c]); twin.RXASetPassband(*((300.0, 3000.0), (-4000.0, 4000.0), (-3000.0, -300.0), (-8000.0, 8000.0))[c])
+        twin.SetRXAAGCMode((0, 3, 4, 0)[c])
+        tws, pert = [], np.random.default_rng(11)
+    for s, n in enumerate(seglen):
+        if s > 3:                                     # (every filter holds signal by then)
+            for _ in range(int(rng.integers(1, 3))):
+                c = int(rng.integers(0, NCH))
+                tg = [(e, (c,)), (os_[c], ())] + ([(twin, ())] if twin_c == c else [])
+                if rng.integers(0, 2):
+                    d = _apply2(rng, tg, notches[c], fm=(c == 3))
+                else:
+                    d = _apply(rng, tg)
+                    notches[c][0] += sum(1 for x_ in d if x_[0] == "RXANBPAddNotch")
+                if c == 3 and any(x_[0] == "SetRXAMode" for x_ in d):
+                    fm_used = fm_used or any(x_[0] == "SetRXAMode" and x_[1] == 5 for x_ in d)
+                log.append((s, c, d))
+                lms_used[c] = lms_used[c] or any(x_[0] in ("SetRXAANFRun", "SetRXAANRRun") and x_[1] for x_ in d)
+        seg = x[:, pos * 1024:(pos + n) * 1024]
+        ys.append(e_run.process_host(seg))
+        for c in range(NCH):
+            rs[c].append(os_run[c].xrxa(seg[c]))
+        if twin_c is not None:
+            tws.append(twin.xrxa(seg[twin_c] * (1.0 + 1e-13 * pert.standard_normal(seg.shape[1]))))
+            print("segment %d: engine %.2e, twin %.2e of %.3e   %r" % (s, np.abs(ys[-1][twin_c] - rs[twin_c][-1]).max(), np.abs(tws[-1] - rs[twin_c][-1]).max(), np.abs(rs[twin_c][-1]).max(),
+                                                                         [(l[1], l[2]) for l in log if l[0] == s]), flush=True)
+        pos += n
+    y = np.concatenate(ys, axis=1)
+    if twin_c is not None:
+        print("seed %d channel %d: engine %.3e, the restatement against its twin %.3e" % (seed, twin_c, rel_rms(y[twin_c], np.concatenate(rs[twin_c])), rel_rms(np.concatenate(tws), np.concatenate(rs[twin_c]))), flush=True)
+    for c in range(NCH):
+        ref = np.concatenate(rs[c])
+        assert np.all(np.isfinite(ref))
+        if np.abs(ref).max() < 1e-9:
+            continue
+        err = rel_rms(y[c], ref)
+        tol = 1e-4 if lms_used[c] else 1e-6
+        assert err < tol, "seed %d channel %d: rel rms %.3e; setters %r" % (seed, c, err, [l for l in log if l[1] == c])
