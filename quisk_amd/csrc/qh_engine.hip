@@ -259,7 +259,8 @@ struct Engine {
     SnotchState *sn_next = nullptr;
     double *fmdc_next = nullptr;
     AmParam am_prm{};
-    PllState *pll_state = nullptr;
+    PllState *pll_state = nullptr;          // the SAM detector's loop (amd.c) ...
+    PllState *fm_pll_state = nullptr;       // ... and the FM detector's (fmd.c): two objects in the reference, each keeps its state while the other runs
     double *fm_again = nullptr;
     // time-tiled FM loop (qh_tiled.hpp): per tile the loop state where its warm-up and where the tile ends, and the count of
     // tiles pll_verify_kernel had to re-run
@@ -361,7 +362,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
-    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(pll_state); (void)hipFree(fm_pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
     (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege); (void)hipFree(agc_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
@@ -751,6 +752,7 @@ int Engine::refresh_demod()
         QH_HIP(dev_alloc(&sn_next, (size_t)nch));
         QH_HIP(dev_alloc(&fmdc_next, (size_t)nch));
         QH_HIP(dev_alloc(&pll_state, (size_t)nch));
+        QH_HIP(dev_alloc(&fm_pll_state, (size_t)nch));
         QH_HIP(dev_alloc(&fm_again, (size_t)nch));
         QH_HIP(dev_alloc(&pll_nfixed, (size_t)1));
         QH_HIP(hipMemsetAsync(pll_nfixed, 0, sizeof(int), stream));
@@ -759,6 +761,7 @@ int Engine::refresh_demod()
         QH_HIP(dev_alloc(&sn_state, (size_t)nch));
         QH_HIP(hipMemsetAsync(am_state, 0, (size_t)nch * sizeof(AmState), stream));
         QH_HIP(hipMemsetAsync(pll_state, 0, (size_t)nch * sizeof(PllState), stream));
+        QH_HIP(hipMemsetAsync(fm_pll_state, 0, (size_t)nch * sizeof(PllState), stream));
         QH_HIP(hipMemsetAsync(sn_state, 0, (size_t)nch * sizeof(SnotchState), stream));
         QH_HIP(dev_alloc(&mask_de, (size_t)kBandNfftMax));
         QH_HIP(dev_alloc(&mask_aud, (size_t)kBandNfftMax));
@@ -1864,6 +1867,8 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     for (const ChanCfg &c : cfg) {
         if (c.agc_run && c.agc_mode > 4)
             return set_error(QH_ERR_UNSUPPORTED, "AGC mode %d is not provided (0 fixed, 1-4 long/slow/med/fast)", c.agc_mode);
+        // (SetRXAAMDRun can switch the AM detector on beside the FM one, RXA.c:594-595 then runs both in a row: not provided, and said so)
+        if (c.amd_run && c.fmd_run) return set_error(QH_ERR_UNSUPPORTED, "channel %d: the AM and the FM detector both switched on", (int)(&c - cfg.data()));
         if (c.amd_run || c.fmd_run || (c.agc_run && c.agc_mode != 0) || c.lms[0].run || c.lms[1].run || c.amsq_run || c.emnr_run || c.snba_run) mixed = true;
         if (c.emnr_run && !emnr_tables) return set_error(QH_ERR_INVALID, "EMNR needs its gain tables first (qh_rxa_SetEMNRTables: WDSP's `calculus` and `zetaHat.bin` data)");
         if (c.nbp_run) { any_nbp = true; if (c.nbp_nc > nc_max) nc_max = c.nbp_nc; } else every_nbp = false;
@@ -2231,18 +2236,18 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 pll_ends_cap = (long long)ngroups * 64;
             }
             hipLaunchKernelGGL((pll_lanes_kernel<false>), dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
-                               2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, pll_ends, pll_ends_cap * kPllEndsW,
+                               2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)fm_pll_state, pll_ends, pll_ends_cap * kPllEndsW,
                                fm_pll_prm, fm_tile, kFmWarm);
             hipLaunchKernelGGL((pll_verify_kernel<false>), dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
-                               2 * buf_cap, (int)n_mid, list_fm, pll_state, pll_ends, pll_ends_cap * kPllEndsW, fm_pll_prm, fm_tile, kFmWarm,
+                               2 * buf_cap, (int)n_mid, list_fm, fm_pll_state, pll_ends, pll_ends_cap * kPllEndsW, fm_pll_prm, fm_tile, kFmWarm,
                                pll_nfixed, pll_check_only);
             {
                 // dc removal + gain: the tiles' contributions are in `ends` already, one pass over `fil`
                 const int G = seg_groups(n_fm);
                 hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
-                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, (const PllState *)pll_state, (const double *)fm_again, fm_pll_prm,
+                                   2 * buf_cap, cur, buf_cap, (int)n_mid, list_fm, (const PllState *)fm_pll_state, (const double *)fm_again, fm_pll_prm,
                                    (const double *)pll_ends, pll_ends_cap * kPllEndsW, fm_tile, fmdc_next);
-                hipLaunchKernelGGL(commit_fmdc_kernel, dim3((unsigned)((n_fm + 255) / 256)), dim3(256), 0, stream, pll_state, (const double *)fmdc_next, list_fm, n_fm);
+                hipLaunchKernelGGL(commit_fmdc_kernel, dim3((unsigned)((n_fm + 255) / 256)), dim3(256), 0, stream, fm_pll_state, (const double *)fmdc_next, list_fm, n_fm);
             }
         }
         {   // de-emphasis: real taps on a real signal, two channels per tile
@@ -3183,6 +3188,7 @@ int qh_rxa_flush(qh_rxa *h)
     if (e.demod_alloc) {                        // flush_amd / flush_fmd / flush_snotch
         QH_HIP(hipMemsetAsync(e.am_state, 0, (size_t)e.nch * sizeof(AmState), e.stream));
         QH_HIP(hipMemsetAsync(e.pll_state, 0, (size_t)e.nch * sizeof(PllState), e.stream));
+        QH_HIP(hipMemsetAsync(e.fm_pll_state, 0, (size_t)e.nch * sizeof(PllState), e.stream));
         QH_HIP(hipMemsetAsync(e.sn_state, 0, (size_t)e.nch * sizeof(SnotchState), e.stream));
     }
     return QH_OK;

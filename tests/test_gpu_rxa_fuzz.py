@@ -191,6 +191,13 @@ def _walk(qh, oracle, seed, replay, wide=False):
         assert err < tol
 
 
+class _Without:
+    """the object with one setter left out"""
+    def __init__(self, t, name): self._t, self._name = t, name
+    def __getattr__(self, name):
+        return (lambda *a: None) if name == self._name else getattr(self._t, name)
+
+
 def _apply2(rng, targets, notches, fm):
     """The setters _apply leaves out: the notch database's edits and its filter's window / auto-increase / edges / shift, the LMS filters'
     sizes and constants, bp1's run flag, the second panel gain -- and, on the one channel that may (fm), the FM detector: mode 5 in and
@@ -281,6 +288,8 @@ def test_random_setter_walk_with_the_notch_database_the_lms_sizes_and_fm(qh, ora
             for _ in range(int(rng.integers(1, 3))):
                 c = int(rng.integers(0, NCH))
                 tg = [(e, (c,)), (os_[c], ())] + ([(twin, ())] if twin_c == c else [])
+                if c == 3:                          # (the AM detector forced on beside the FM one: the engine refuses that pair)
+                    tg = [(_Without(t, "SetRXAAMDRun"), lead) for t, lead in tg]
                 if rng.integers(0, 2):
                     d = _apply2(rng, tg, notches[c], fm=(c == 3))
                 else:
