@@ -255,6 +255,7 @@ def test_random_setter_walk_with_the_notch_database_the_lms_sizes_and_fm(qh, ora
     x[3] = synth.make_mode_input_numpy("fm", 3, nblk * 1024)
     e = qh.RxaEngine(NCH)
     e.load_emnr_tables()
+    e.enable_meters(True)
     os_ = [oracle.WdspChannel(1024, 256, 192000, 48000, 48000) for _ in range(NCH)]
     for c in range(NCH):
         for t, lead in ((e, (c,)), (os_[c], ())):
@@ -303,6 +304,14 @@ def test_random_setter_walk_with_the_notch_database_the_lms_sizes_and_fm(qh, ora
         ys.append(e_run.process_host(seg))
         for c in range(NCH):
             rs[c].append(os_run[c].xrxa(seg[c]))
+        if seed % 2 == 0:                              # every other walk with WDSP's meters read after every segment (meter.c:75-130: mlog10's steps)
+            for c in range(NCH):
+                if np.abs(rs[c][-1]).max() < 1e-9 or lms_used[c]:
+                    continue
+                for mt in (0, 1, 2, 3, 5, 6):
+                    got_m, ref_m = e_run.GetRXAMeter(c, mt), os_run[c].GetRXAMeter(mt)
+                    assert abs(got_m - ref_m) < 0.0045, "seed %d segment %d channel %d meter %d: %.4f against %.4f; setters %r" % (
+                        seed, s, c, mt, got_m, ref_m, [l for l in log if l[1] == c])
         if twin_c is not None:
             tws.append(twin.xrxa(seg[twin_c] * (1.0 + 1e-13 * pert.standard_normal(seg.shape[1]))))
             print("segment %d: engine %.2e, twin %.2e of %.3e   %r" % (s, np.abs(ys[-1][twin_c] - rs[twin_c][-1]).max(), np.abs(tws[-1] - rs[twin_c][-1]).max(), np.abs(rs[twin_c][-1]).max(),
