@@ -10,7 +10,7 @@ import pytest
 
 from conftest import rel_rms
 from quisk_amd import synth
-from test_gpu_rxa_fuzz import _apply
+from test_gpu_rxa_fuzz import _apply, _apply2
 
 pytestmark = pytest.mark.gpu
 
@@ -52,10 +52,13 @@ GEOMETRY = [  # in_size, dsp_size, in_rate, dsp_rate, out_rate
 ]
 
 
-@pytest.mark.parametrize("seed", list(range(1, 21)))
+@pytest.mark.parametrize("seed", list(range(1, 21)) + list(range(5001, 5013)))
 def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
+    """(seeds above 5000: every other draw from the second menu -- the notch database's edits, its filter's window / auto-increase /
+    edges / shift, SetRXAANFVals / ANRVals, SetRXABandpassRun, SetRXAPanelGain2 -- through the names' own wrappers)"""
     lib = qh.load()
     rng = np.random.default_rng(31000 + seed)
+    notches = [0]
     in_size, dsp_size, in_rate, dsp_rate, out_rate = GEOMETRY[(seed - 1) % len(GEOMETRY)]
     ch = 16 + seed % 8
     D = C.c_double
@@ -77,7 +80,11 @@ def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
         while b < nblk:
             if b:
                 for _ in range(int(rng.integers(0, 2))):
-                    done = _apply(rng, [(names, ()), (o, ())])
+                    if seed > 5000 and rng.integers(0, 2):
+                        done = _apply2(rng, [(names, ()), (o, ())], notches, fm=False)
+                    else:
+                        done = _apply(rng, [(names, ()), (o, ())])
+                        notches[0] += sum(1 for d in done if d[0] == "RXANBPAddNotch")
                     lms = lms or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in done)
             n = min(nblk - b, int(rng.integers(1, 5)) * max(1, 1024 // in_size))
             seg = np.ascontiguousarray(x[b * in_size:(b + n) * in_size])
