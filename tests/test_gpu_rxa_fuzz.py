@@ -203,14 +203,20 @@ def _apply2(rng, targets, notches, fm):
     sizes and constants, bp1's run flag, the second panel gain -- and, on the one channel that may (fm), the FM detector: mode 5 in and
     out in mid-stream (its filters primed by then: the pull-in is then well-conditioned), deviation, CTCSS notch,
     the limiter.  notches: how many notches the channel's database holds (a list of one int, kept by the caller)."""
-    k = int(rng.integers(0, 14 if fm else 10))
+    k = int(rng.integers(-1, 14 if fm else 10))
     done = []
 
     def call(name, *args):
         done.append((name,) + args)
         for t, lead in targets:
             getattr(t, name)(*lead, *args)
-    if k == 0 and notches[0] > 0:
+    if k == -1:                                        # EMNR's tuning constants (emnr.c:1145-1175), around their defaults
+        which = int(rng.integers(0, 4))
+        if which == 0: call("SetRXAEMNRaeZetaThresh", float(rng.choice([0.6, 0.75, 0.9])))
+        elif which == 1: call("SetRXAEMNRaePsi", float(rng.choice([5.0, 10.0, 20.0])))
+        elif which == 2: call("SetRXAEMNRtrainZetaThresh", float(rng.choice([-0.7, -0.5, -0.2])))
+        else: call("SetRXAEMNRtrainT2", float(rng.choice([0.1, 0.2, 0.4])))
+    elif k == 0 and notches[0] > 0:
         call("RXANBPDeleteNotch", int(rng.integers(0, notches[0]))); notches[0] -= 1
     elif k == 1 and notches[0] > 0:
         call("RXANBPEditNotch", int(rng.integers(0, notches[0])), float(rng.uniform(-3000, 3000)), float(rng.uniform(50, 400)), int(rng.integers(0, 2)))
