@@ -98,7 +98,7 @@ def test_random_setter_walk(qh, oracle, seed):
     _walk(qh, oracle, seed, replay=False)
 
 
-@pytest.mark.parametrize("seed", list(range(101, 113)))
+@pytest.mark.parametrize("seed", list(range(101, 113)) + list(range(5001, 5009)))
 def test_random_setter_walk_block_at_a_time_with_graph_replay(qh, oracle, seed):
     """The same walks fed one DSP block per call from fixed device buffers with qh_rxa_set_graph_replay on: every setter
     must invalidate the captured launch sequences, and replayed blocks must leave the ping-pong state where plain ones do."""
@@ -144,11 +144,16 @@ def _walk(qh, oracle, seed, replay, wide=False):
     # a minimum-phase filter of 4096 - 16384 taps: mp_imp's cepstrum (fir.c:319-368) takes the logarithm of a stop band 200 dB down over a
     # 16 nc-point transform -- two transforms that differ in their last bits leave designs 1e-6 apart (seen: 1.4e-6 at 16384 taps, 1.5e-6 at 4096)
     mp_now, nc_now, mp_long = [0] * NCH, [2048] * NCH, [False] * NCH
+    notches2 = [[0] for _ in range(NCH)]
     for s, n in enumerate(seglen):
         if s:
             for _ in range(int(rng.integers(1, 3))):
                 c = int(rng.integers(0, NCH))
-                log.append((s, c, _apply(rng, [(e, (c,)), (os_[c], ())], wide)))
+                if seed >= 5000 and rng.integers(0, 2):            # (walks from 5000 up: the second menu too, _apply2 below)
+                    log.append((s, c, _apply2(rng, [(e, (c,)), (os_[c], ())], notches2[c], fm=False)))
+                else:
+                    log.append((s, c, _apply(rng, [(e, (c,)), (os_[c], ())], wide)))
+                    notches2[c][0] += sum(1 for d in log[-1][2] if d[0] == "RXANBPAddNotch")
                 lms_used[c] = lms_used[c] or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in log[-1][2])
                 for d in log[-1][2]:
                     if d[0] == "RXASetMP": mp_now[c] = d[1]
