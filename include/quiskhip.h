@@ -93,7 +93,7 @@ int qh_rxa_SetRXAPanelGain2(qh_rxa *e, int ch, double gainI, double gainQ);
 int qh_rxa_SetRXAPanelSelect(qh_rxa *e, int ch, int select);
 int qh_rxa_SetRXAPanelCopy(qh_rxa *e, int ch, int copy);
 int qh_rxa_SetRXAAMDSBMode(qh_rxa *e, int ch, int sbmode);
-int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277 */
+int qh_rxa_SetRXAAMDRun(qh_rxa *e, int ch, int run);             /* wdsp/amd.c:264-277; run = 1 on a channel in FM mode (both detectors in a row in the reference) is refused at the next process call */
 int qh_rxa_SetRXAFMLimRun(qh_rxa *e, int ch, int run);           /* wdsp/fmd.c:336-347: the FM detector's limiter */
 int qh_rxa_SetRXAFMLimGain(qh_rxa *e, int ch, double gaindB);    /* wdsp/fmd.c:349-362 */
 /* xemnr, WDSP's spectral noise reduction "NR2" (wdsp/emnr.c; setters :1096-1143): overlap-add STFT 4096 / 1024, noise estimate by
@@ -159,7 +159,7 @@ int qh_rxa_RXANBPSetShiftFrequency(qh_rxa *e, int ch, double shift);
 int qh_rxa_RXANBPSetNotchesRun(qh_rxa *e, int ch, int run);
 int qh_rxa_RXANBPSetWindow(qh_rxa *e, int ch, int wintype);
 int qh_rxa_RXANBPSetAutoIncrease(qh_rxa *e, int ch, int autoincr);
-int qh_rxa_RXASetMP(qh_rxa *e, int ch, int mp);                  /* wdsp/RXA.c:948-958: minimum-phase filters (mp_imp, fir.c:319) */
+int qh_rxa_RXASetMP(qh_rxa *e, int ch, int mp);                  /* wdsp/RXA.c:948-958: minimum-phase filters (mp_imp, fir.c:319); the FM channels of one engine share their filters' design: different flags among them are refused, like different nc */
 int qh_rxa_SetRXAAMDFadeLevel(qh_rxa *e, int ch, int levelfade);
 int qh_rxa_SetRXAFMDeviation(qh_rxa *e, int ch, double deviation);
 int qh_rxa_SetRXACTCSSFreq(qh_rxa *e, int ch, double freq);
