@@ -10,7 +10,7 @@ import pytest
 
 from conftest import rel_rms
 from quisk_amd import synth
-from test_gpu_rxa_fuzz import _apply, _apply2
+from test_gpu_rxa_fuzz import _Without, _apply, _apply2
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,7 @@ GEOMETRY = [  # in_size, dsp_size, in_rate, dsp_rate, out_rate
 ]
 
 
-@pytest.mark.parametrize("seed", list(range(1, 21)) + list(range(5001, 5013)))
+@pytest.mark.parametrize("seed", list(range(1, 21)) + list(range(5001, 5013)) + list(range(6001, 6009)))
 def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
     """(seeds above 5000: every other draw from the second menu -- the notch database's edits, its filter's window / auto-increase /
     edges / shift, SetRXAANFVals / ANRVals, SetRXABandpassRun, SetRXAPanelGain2 -- through the names' own wrappers)"""
@@ -80,10 +80,13 @@ def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
         while b < nblk:
             if b:
                 for _ in range(int(rng.integers(0, 2))):
+                    tg = [(names, ()), (o, ())]
+                    if seed > 6000:                       # (from 6000 up the FM detector too; the AM detector forced on beside it is refused)
+                        tg = [(_Without(t, "SetRXAAMDRun"), lead) for t, lead in tg]
                     if seed > 5000 and rng.integers(0, 2):
-                        done = _apply2(rng, [(names, ()), (o, ())], notches, fm=False)
+                        done = _apply2(rng, tg, notches, fm=seed > 6000)
                     else:
-                        done = _apply(rng, [(names, ()), (o, ())])
+                        done = _apply(rng, tg)
                         notches[0] += sum(1 for d in done if d[0] == "RXANBPAddNotch")
                     lms = lms or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in done)
             n = min(nblk - b, int(rng.integers(1, 5)) * max(1, 1024 // in_size))
