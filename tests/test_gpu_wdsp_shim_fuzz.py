@@ -13,7 +13,7 @@ import torch
 
 from conftest import rel_rms
 from quisk_amd import synth
-from test_gpu_rxa_fuzz import _apply
+from test_gpu_rxa_fuzz import _Without, _apply, _apply2
 from test_gpu_wdsp_device_handoff import CLIP32, _dev_call, _host_call
 from test_gpu_wdsp_names_fuzz import _Names, _NoEmnr
 
@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 GEOMETRY = [(1024, 192000), (256, 48000), (64, 192000), (512, 96000), (2048, 192000), (128, 48000)]      # in_size, in_rate (dsp 256 at 48 kHz)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 19)))
+@pytest.mark.parametrize("seed", list(range(1, 19)) + list(range(5001, 5007)))
 def test_random_walk_over_the_hand_off_with_the_caller_changing_sides(qh, oracle, seed):
     lib = qh.load()
     rng = np.random.default_rng(61000 + seed)
@@ -62,9 +62,14 @@ def test_random_walk_over_the_hand_off_with_the_caller_changing_sides(qh, oracle
         lead = int(rng.choice([0, 0, 131, 700]))
         x[:lead] = 0.0                                     # the up-slew waits for the first non-zero sample (iobuffs.c:104-113)
         got, want, lms, pos, sides, in_use, log = [], [], False, 0, [0, 0], 1, []
+        notches = [0]
         for k, n in enumerate(sizes):
             if k and rng.integers(0, 3) == 0:
-                done = _apply(rng, targets)
+                if seed > 5000 and rng.integers(0, 2):      # (from 5000 up: the second menu, the FM detector's setters among it)
+                    done = _apply2(rng, [(_Without(t, "SetRXAAMDRun"), lead) for t, lead in targets], notches, fm=True)
+                else:
+                    done = _apply(rng, [(_Without(t, "SetRXAAMDRun"), lead) for t, lead in targets] if seed > 5000 else targets)
+                    notches[0] += sum(1 for d in done if d[0] == "RXANBPAddNotch")
                 lms = lms or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in done)
                 log.append((k, done))
             if k and rng.integers(0, 12) == 0:             # in_use dropped or raised: the shim rewinds its ring (quisk_wdsp.c:32-37)
