@@ -559,6 +559,9 @@ int qh_qrx_set_agc(qh_qrx *r, int on, double release_gain);
 /* FM / DGT-FM banks: set_squelch(d) (quisk.c:4721); the block is zeroed while the mean |cx| (dB re full scale, over >= 2400
  * samples, evaluated per call: quisk.c:2076-2085) is below `level`.  Default -999: never. */
 int qh_qrx_set_squelch(qh_qrx *r, int ch, double level);
+/* one quisk_process_samples call handed over in pieces: 1 ahead of the first piece, 0 behind the last (the FM squelch's level is looked at once
+ * per call, quisk.c:2076-2085, whether a threshold is set or not) */
+int qh_qrx_squelch_pieces(qh_qrx *r, int pieces);
 /* CW / SSB / AM banks: set_ssb_squelch(enabled, level) (quisk.c:4729): spectral-flatness squelch on 512-sample blocks of the
  * audio at the filter rate (ssb_squelch, quisk.c:1086-1180) plus the 512-sample audio delay that goes with it (d_delay). */
 int qh_qrx_set_ssb_squelch(qh_qrx *r, int enabled, int level);

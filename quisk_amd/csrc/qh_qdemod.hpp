@@ -129,10 +129,13 @@ static __global__ __launch_bounds__(64) void q_fm_disc_kernel(double2 *buf, long
 
 
 // the squelch's per-call update from the call's sum of |cx| (quisk.c:2076-2085)
-__device__ __forceinline__ void q_squelch_update(QSquelchState *state, const double *level, int ch, double s, int n)
+// defer: a PIECE of a call (qh_qps.hip cuts long calls into pieces) only adds to the sums -- the reference looks at its count once per
+// call of quisk_process_samples, so the windows of >= 2400 samples must end where its calls end; q_squelch_close_kernel does that look
+__device__ __forceinline__ void q_squelch_update(QSquelchState *state, const double *level, int ch, double s, int n, int defer = 0)
 {
     QSquelchState st = state[ch];
     st.rf_sum += s; st.rf_count += n;
+    if (defer) { state[ch] = st; return; }
     if (st.rf_count >= 2400) {
         double v = st.rf_sum / st.rf_count / 2147483647.0;
         st.squelch = v > 1.E-10 ? 20 * log10(v) : -200.0;
@@ -199,21 +202,26 @@ static __global__ __launch_bounds__(256) void q_fm_disc_grid_kernel(const double
 }
 // one thread per receiver: the squelch from the segments' sums in order (quisk.c:2076-2085), the detector's new state
 static __global__ void q_fm_disc_finish_kernel(int nch, double4 *state, const double4 *state_new, const double *sq_part, int nseg, int n,
-                                               QSquelchState *sq_state, const double *sq_level)
+                                               QSquelchState *sq_state, const double *sq_level, int defer = 0)
 {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= nch) return;
     state[ch] = state_new[ch];
     double s = 0.0;
     for (int k = 0; k < nseg; k++) s += sq_part[(long long)ch * nseg + k];
-    q_squelch_update(sq_state, sq_level, ch, s, n);
+    q_squelch_update(sq_state, sq_level, ch, s, n, defer);
+}
+static __global__ void q_squelch_close_kernel(int nch, QSquelchState *sq_state, const double *sq_level)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < nch) q_squelch_update(sq_state, sq_level, ch, 0.0, 0);
 }
 
 // FM squelch (quisk.c:2032-2033,2076-2085): the mean |cx| of the Rx-filtered samples over at least 2400 of them
 // (evaluated once per call, like the reference) in dB re full scale; active while it is below squelch_level.
 // One wave per channel; `buf` is the Rx filter's output of this call.
 static __global__ __launch_bounds__(kSegThreads) void q_fm_squelch_kernel(const double2 *buf, long long stride, int n, QSquelchState *state,
-                                                             const double *level)
+                                                             const double *level, int defer = 0)
 {
     // blockDim.x = 64 (short calls) or kSegThreads: the lanes stride over the call, a fixed reduction order joins them
     __shared__ double s_part[kSegWaves];
@@ -227,7 +235,7 @@ static __global__ __launch_bounds__(kSegThreads) void q_fm_squelch_kernel(const 
     if (threadIdx.x == 0) {
         s = 0.0;
         for (int w = 0; w < nw; w++) s += s_part[w];
-        q_squelch_update(state, level, ch, s, n);
+        q_squelch_update(state, level, ch, s, n, defer);
     }
 }
 

@@ -288,6 +288,7 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     const bool epi = h->kill_audio || h->squelch_can_act;
     long long o_off = 0, out_off = 0;
     int piece = 0, last_agc = -1;
+    if (int rc = qh_qrx_squelch_pieces(h->rx, P > 1 ? 1 : 0)) return rc;       // (0: also ends a call that an error cut short)
     for (int pos = 0; pos < n; piece++) {
         const int cnt = n - pos < per ? n - pos : per, par = piece & 1;
         // this piece's scratch half was read by the AGC two pieces back.  Pipelined calls: the call before this one may still be in its
@@ -333,6 +334,7 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
         out_off += na;
         pos += cnt;
     }
+    if (P > 1) if (int rc = qh_qrx_squelch_pieces(h->rx, 0)) return rc;      // (the reference's one look at the FM squelch's count, behind the last piece)
     // the call ends on the bank's stream (the AGC stream runs in order) -- unless it is pipelined: then its output is complete at
     // qh_qps_synchronize (or behind the next call's AGC), and the next call's filters start beside this call's last AGC piece
     hipStream_t tail = h->stream;

@@ -140,6 +140,7 @@ struct Qrx {
     double2 *ssq_delay[2] = { nullptr, nullptr };
     int ssq_cur = 0;
     QSquelchState *sq_state = nullptr;  // squelch flag (FM squelch state, quisk.c:2076-2085)
+    bool sq_defer = false;              // the calls are pieces of one quisk_process_samples call (qh_qrx_squelch_pieces)
     bool mute_deferred = false;         // the caller applies the squelch itself, behind its AGC (qh_quisk_process_samples)
     double *sq_level = nullptr;
     std::vector<double> h_sq_level;
@@ -724,7 +725,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                 }
                 if (n < kQTiledMin)      // long calls: the sum rides on the tiled detector below
                     hipLaunchKernelGGL(q_fm_squelch_kernel, dim3((unsigned)q.nch), dim3(64), 0, q.stream,
-                                       static_cast<const double2 *>(cur), cur_stride, n, q.sq_state, q.sq_level);
+                                       static_cast<const double2 *>(cur), cur_stride, n, q.sq_state, q.sq_level, q.sq_defer ? 1 : 0);
             }
             if (n >= kQTiledMin) {       // long calls: the detector over a grid of time segments (qh_qdemod.hpp), into the other buffer
                 const int tail_b = seg_tail_batches(-q.fm_prm.b1);
@@ -740,7 +741,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
                                    static_cast<const double2 *>(cur), cur_stride, static_cast<double2 *>(dst), dst_stride, n,
                                    (const double4 *)q.fm_state, q.fm_state_new, q.fm_prm, seg_b, tail_b, q.fm_part, nseg);
                 hipLaunchKernelGGL(q_fm_disc_finish_kernel, dim3((unsigned)((q.nch + 63) / 64)), dim3(64), 0, q.stream, q.nch, q.fm_state,
-                                   (const double4 *)q.fm_state_new, (const double *)q.fm_part, nseg, n, q.sq_state, (const double *)q.sq_level);
+                                   (const double4 *)q.fm_state_new, (const double *)q.fm_part, nseg, n, q.sq_state, (const double *)q.sq_level, q.sq_defer ? 1 : 0);
                 m = n;
                 break;
             }
@@ -791,6 +792,28 @@ int qh_qrx_set_ssb_squelch(qh_qrx *h, int enabled, int level)
         QH_HIP(hipMemsetAsync(q.sq_state, 0, (size_t)q.nch * sizeof(QSquelchState), q.stream));
     q.ssb_sq_on = enabled != 0;
     q.ssb_sq_level = level;
+    return QH_OK;
+}
+
+// The FM squelch's level is looked at once per call of quisk_process_samples (quisk.c:2076-2085): a caller that hands one such call over in
+// PIECES (qh_qps.hip) says so -- pieces = 1: the following process calls only add to the sums -- and closes the call with pieces = 0,
+// which takes the look the reference takes.  (The measurement runs whether a threshold is set or not, so the windows must line up even
+// while the squelch cannot act.)
+int qh_qrx_squelch_pieces(qh_qrx *h, int pieces)
+{
+    QH_QRX_LOCK(h);
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    Qrx &q = h->q;
+    if (!q.sq_state || !is_fm(q.mode)) return QH_OK;
+    if (!pieces && q.sq_defer) {
+        if (q.sq_dirty) {
+            QH_HIP(hipMemcpyAsync(q.sq_level, q.h_sq_level.data(), (size_t)q.nch * 8, hipMemcpyHostToDevice, q.stream));
+            QH_HIP(hipStreamSynchronize(q.stream));
+            q.sq_dirty = false;
+        }
+        hipLaunchKernelGGL(q_squelch_close_kernel, dim3((unsigned)((q.nch + 63) / 64)), dim3(64), 0, q.stream, q.nch, q.sq_state, (const double *)q.sq_level);
+    }
+    q.sq_defer = pieces != 0;
     return QH_OK;
 }
 

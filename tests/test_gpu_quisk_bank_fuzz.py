@@ -66,6 +66,8 @@ def _draw(rng, mode, fs, bank, refs):
                                                (9, 3, 192000, 192000), (10, 3, 370370, 48000),
                                                # found by tools/dbg/bank_fuzz_sweep.py: a squelch switched on in a call that is cut into pieces
                                                (146, 4, 185185, 96000), (101, 5, 192000, 48000), (106, 3, 192000, 192000),
+                                               # the FM squelch's measuring windows while the bank cuts its calls into pieces (threshold set later)
+                                               (7122, 5, 192000, 48000),
                                                # CWL, LSB, DGT-U, DGT-L, DGT-IQ (stereo: process_agc on the complex magnitude), DGT-FM, IMD
                                                (21, 0, 96000, 48000), (22, 2, 192000, 48000), (23, 7, 192000, 96000), (24, 8, 111111, 48000), (417, 9, 192000, 48000),
                                                (26, 13, 96000, 48000), (27, 10, 48000, 48000)])

@@ -38,3 +38,5 @@ for k, s in enumerate(sizes):
         nz = lambda v: int(np.count_nonzero(v))
         line.append("%.1e (nonzero %d/%d of %d, ref flags %d)" % (e, nz(y[c]), nz(w), w.size, refs[c].squelch_flags()))
     print("call %2d n %6d flags %s: %s" % (k, s, list(bank.squelch_flags()), "  ".join(line)))
+    if rng.integers(0, 4) == 0:                  # (the walk reads get_graph now and then: the same draws here)
+        rng.choice([1.0, 1.0, 2.0, 4.0]); rng.choice([0.0, 0.0, 5000.0, -12000.0])
