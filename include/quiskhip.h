@@ -759,11 +759,12 @@ int qh_qps_get_graph(qh_qps *h, double zoom, double deltaf, double *pixels, doub
 
 /* Plumbing between the block API and the engines it chains (device-resident; used by qh_quisk_rx_compat.cpp): the bank
  * leaves the squelch to its caller and says where the flag lives; ssb_squelch's one-for-all-banks `plan` static
- * (quisk.c:1091,1104); the tuning oscillator's phase in 2^-64 turns (one vector per purpose in the reference,
+ * (quisk.c:1091,1104) and the one bandwidth it reads for all banks (filter_bandwidth[0], quisk.c:1120); the tuning oscillator's phase in 2^-64 turns (one vector per purpose in the reference,
  * quisk.c:2308-2311); measure_freq's window and averaged spectrum on the panadapter engine; the shim's state. */
 int qh_qrx_set_mute_deferred(qh_qrx *r, int on);
 const int *qh_qrx_squelch_flag(qh_qrx *r, int ch);
 int qh_qrx_ssb_squelch_planned(qh_qrx *r, int set);
+int qh_qrx_set_ssb_squelch_bandwidth(qh_qrx *r, int bandwidth);       /* filter_bandwidth[0]: what ssb_squelch reads in every bank (quisk.c:1120) */
 int qh_qrx_get_nco_phase(qh_qrx *r, int ch, unsigned long long *phase);
 int qh_qrx_set_nco_phase(qh_qrx *r, int ch, unsigned long long phase);
 int qh_pan_set_window(qh_pan *p, const double *window);

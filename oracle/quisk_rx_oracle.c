@@ -85,6 +85,7 @@ void qo_agc_process(qo_agc *d, double *cs, int count, int is_cpx, double agcRele
 
 struct qo_rx {
     int sample_rate, decim2, decim3, decim5, decim_srate, filter_srate, mode, tune, bandwidth;
+    int bandwidth0;                             /* filter_bandwidth[0]: what ssb_squelch reads in every bank (quisk.c:1120) */
     qo_rx_tables t;
     double tv_re, tv_im;            /* rxTuneVector, quisk.c:2308 */
     /* quisk_process_decimate storage, quisk.c:1678-1698 */
@@ -362,7 +363,7 @@ qo_rx *qo_rx_create(int sample_rate, const qo_rx_tables *t)
     qo_fir_init(&r->sdriq53, t->sdriq53, 55, 1); qo_fir_init(&r->sdriq111, t->sdriq111, 114, 1);
     qo_fir_init(&r->sdriq133, t->sdriq133, 136, 1); qo_fir_init(&r->sdriq167, t->sdriq167, 174, 1);
     qo_fir_init(&r->sdriq185, t->sdriq185, 189, 1);
-    r->bandwidth = 2700;
+    r->bandwidth = 2700; r->bandwidth0 = 2700;
     r->squelch_level = -999.0;
     qo_hb45_init(&r->dHB4); qo_hb45_init(&r->dHB5); qo_hb45_init(&r->dHB6); qo_hb45_init(&r->dHB7);
     qo_fir_init(&r->dm48to24, t->f48dec24, 98, 1);
@@ -401,7 +402,7 @@ void qo_rx_free(qo_rx *r)
 
 void qo_rx_set_tune(qo_rx *r, int f) { r->tune = f; }
 void qo_rx_set_mode(qo_rx *r, int mode) { r->mode = mode; }
-void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; }
+void qo_rx_set_bandwidth(qo_rx *r, int bw) { r->bandwidth = bw; r->bandwidth0 = bw; }      /* a receiver on its own is bank 0 with filter set 0 */
 void qo_rx_set_squelch(qo_rx *r, double level) { r->squelch_level = level; }     /* set_squelch, quisk.c:4721-4727 */
 void qo_rx_set_ssb_squelch(qo_rx *r, int enabled, int level) { r->ssb_squelch_enabled = enabled; r->ssb_squelch_level = level; }
 void qo_rx_set_agc(qo_rx *r, int on, double release_gain) { r->agc_on = on; r->agc_gain = release_gain; }
@@ -482,7 +483,7 @@ static void ssb_squelch(qo_rx *r, const double *ds, int n, int samp_rate)      /
             r->sq_index = 0;
             for (i = 0; i < SQUELCH_FFT_SIZE; i++) { buf[2 * i] = r->sq_in[i] * fft_window[i]; buf[2 * i + 1] = 0.0; }
             fo_fft(buf, SQUELCH_FFT_SIZE, -1);                  /* fftw_execute_dft_r2c: bins 0 .. N/2 */
-            bw = r->bandwidth;
+            bw = r->bandwidth0;                                 /* "bw = filter_bandwidth[0]", whatever the bank or nFilter: quisk.c:1120 */
             if (bw > 3000) bw = 3000;
             bw1 = 300 * SQUELCH_FFT_SIZE / samp_rate;
             bw2 = (bw + 300) * SQUELCH_FFT_SIZE / samp_rate;
@@ -1042,6 +1043,7 @@ static void ps_load_filter(qo_ps *p, int bank, int nFilter, int mode)
     memcpy(r->filtQ, p->filtQ[nFilter], (size_t)p->sizeFilter * sizeof(double));
     r->sizeFilter = p->sizeFilter;
     r->bandwidth = p->filter_bandwidth[nFilter];
+    r->bandwidth0 = p->filter_bandwidth[0];
     r->mode = mode;
 }
 

@@ -844,9 +844,13 @@ int Engine::refresh_demod()
             for (int ps = 0; ps < 2; ps++)
                 for (int ch : lsn[ps]) {
                     ChanCfg &c = cfg[(size_t)ch];
-                    if (c.snb_hist_at != cur_snb)
+                    if (c.snb_hist_at != cur_snb) {
                         QH_HIP(hipMemcpyAsync(hist_snb[cur_snb] + (size_t)ch * kHistBand, hist_snb[c.snb_hist_at] + (size_t)ch * kHistBand,
                                               kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                        if (lhist[4][0] && lhist[4][1])         // the partitioned form's 16383-sample delay line goes along (nc > 4096)
+                            QH_HIP(hipMemcpyAsync(lhist[4][cur_snb] + (size_t)ch * kLongHist, lhist[4][c.snb_hist_at] + (size_t)ch * kLongHist,
+                                                  kLongHist * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                    }
                     c.snb_hist_at = cur_snb;
                     snb_listed[(size_t)ch] = 1;
                 }
@@ -884,6 +888,12 @@ int Engine::refresh_demod()
                                           kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
                     QH_HIP(hipMemcpyAsync(hist_aud[cur_aud] + (size_t)ch * kHistBand, hist_aud[c.fm_hist_at] + (size_t)ch * kHistBand,
                                           kHistBand * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                    if (lhist[2][0] && lhist[2][1])             // ... and the partitioned forms' long delay lines (nc > 4096)
+                        QH_HIP(hipMemcpyAsync(lhist[2][cur_de] + (size_t)ch * kLongHist, lhist[2][c.fm_hist_at] + (size_t)ch * kLongHist,
+                                              kLongHist * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                    if (lhist[3][0] && lhist[3][1])
+                        QH_HIP(hipMemcpyAsync(lhist[3][cur_aud] + (size_t)ch * kLongHist, lhist[3][c.fm_hist_at] + (size_t)ch * kLongHist,
+                                              kLongHist * sizeof(double2), hipMemcpyDeviceToDevice, stream));
                 }
                 c.fm_hist_at = cur_de;
                 fm_listed[(size_t)ch] = 1;
@@ -1894,9 +1904,11 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             drop_graphs(); epoch++;
             if ((lp[sid] > 1) != (long_parts[sid] > 1)) {       // the delay lines move with the form
                 double2 **hs = sid == 0 ? hist_nbp : sid == 1 ? hist_bp1 : sid == 2 ? hist_de : sid == 3 ? hist_aud : hist_snb;
-                const int cur = sid == 0 ? cur_nbp : sid == 1 ? cur_bp1 : sid == 2 ? cur_de : sid == 3 ? cur_aud : cur_snb;
-                if (hs[cur] && lhist[sid][cur])
-                    hipLaunchKernelGGL(long_migrate_kernel, dim3(16, (unsigned)nch), dim3(NT), 0, stream, hs[cur], lhist[sid][cur], lp[sid] > 1 ? 1 : 0);
+                // BOTH ping-pong halves: a channel that has left the stage's list (another mode, bp1 or SNBA switched off) keeps its rows in
+                // the half that was current when it left (bp1_hist_at, fm_hist_at, snb_hist_at), which need not be the current one
+                for (int half = 0; half < 2; half++)
+                    if (hs[half] && lhist[sid][half])
+                        hipLaunchKernelGGL(long_migrate_kernel, dim3(16, (unsigned)nch), dim3(NT), 0, stream, hs[half], lhist[sid][half], lp[sid] > 1 ? 1 : 0);
             }
             long_parts[sid] = lp[sid];
             for (ChanCfg &c : cfg) {            // the stage's masks are laid out for another form now: all of them again
@@ -1995,15 +2007,18 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // the FM channels' front and nbp0 stages are launched first and their detector chain follows on the main stream; the other
     // channels' front, nbp0 and AM detectors run beside it on a second stream (fork / join by events, which a launch-sequence
     // capture records as graph edges).  BASELINE config 4: 1.20 -> 0.8 ms per call.
-    const bool split = n_fm > 0 && n_rest > 0 && D > 1 && !meters_on && !n_amsq && !n_snb[0] && !timing;
+    // QH_DBG_FORMS (diagnostics, tools/dbg/determinism_stress.py): bit 0 no second stream for the filters, 1 no stores straight to the
+    // caller's rows, 2 no envelope in nbp0's store, 3 no angles in nbp0's store, 4 no paired real filters, 5 no second stream at all
+    static const int dbg_forms = [] { const char *e = std::getenv("QH_DBG_FORMS"); return e ? std::atoi(e) : 0; }();
+    const bool split = n_fm > 0 && n_rest > 0 && D > 1 && !meters_on && !n_amsq && !n_snb[0] && !timing && !(dbg_forms & 1);
     // ... and when nothing sits between a channel's last filter and the output matrix (no AGC state machine, LMS, EMNR, SNBA,
     // limiter, squelch or position-1 stage anywhere), that last stage -- nbp0 for the plain channels, bp1 for AM / SAM, the CTCSS
     // notch for FM -- applies the matrix in its store and writes the caller's buffer: the output pass (32 B per output sample) goes.
-    const bool fm_theta_fused = split && any_nbp && !band6k && !band2g && bnfft == kNfft;
+    const bool fm_theta_fused = split && any_nbp && !band6k && !band2g && bnfft == kNfft && !(dbg_forms & 8);
     bool no_lms = true;
     for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) no_lms = no_lms && !n_lms[f][k];
     bool agc_direct = false;            // set where xwcpagc runs: its gain multiply writes the caller's rows (see there)
-    const bool direct = split && every_nbp && !eg.kind && !n_lim && !n_agc_cur && !n_agc_other && !n_snba && !n_snb[1] && no_lms &&
+    const bool direct = split && !(dbg_forms & 2) && every_nbp && !eg.kind && !n_lim && !n_agc_cur && !n_agc_other && !n_snba && !n_snb[1] && no_lms &&
                         !n_emnr[0] && !n_emnr[1] && !n_emnr[2] && !n_fix[0] && !n_fix[1] && !n_bp1p[1] && n_bp1p[0] == n_bp1 && n_rb == n_bp1 &&
                         n_usb + n_fm == n_plain &&
                         // the first stores to `out` come while other channels' input is still being read: not for a caller that works in place
@@ -2011,7 +2026,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                          (const char *)in + (size_t)nch * (size_t)in_stride * sizeof(double2) <= (const char *)out);
     // ... and the AM channels' nbp0 leaves the envelope and every tile's share of the fade leveller's averages: one pass does the rest
     const int P_am = ((P + 63) / 64) * 64;
-    const bool am_fused = direct && n_am > 0 && n_rb == n_am + n_sam && !band6k && !band2g && bnfft == kNfft && P_am < bnfft;
+    const bool am_fused = direct && !(dbg_forms & 4) && n_am > 0 && n_rb == n_am + n_sam && !band6k && !band2g && bnfft == kNfft && P_am < bnfft;
     if (am_fused) {
         const long long nt = (n_mid + (bnfft - P_am) - 1) / (bnfft - P_am);
         if (nt > am_tsum_cap) {
@@ -2095,7 +2110,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // The AM / SAM detectors and the FM detector chain touch disjoint channel rows and disjoint state, and neither fills the
     // chip (one workgroup or wavefront per channel): with both kinds of channel in the call the AM side runs on a second
     // stream, forked and joined by events (which a launch-sequence capture records as graph edges).
-    const bool side = split || ((n_am || n_sam) && n_fm);
+    const bool side = split || ((n_am || n_sam) && n_fm && !(dbg_forms & 32));
     hipStream_t am_stream = stream;
     if (split) am_stream = side_stream;         // forked already: the AM detectors follow the other channels' filters there
     else if (side) {
@@ -2202,10 +2217,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         int hc = cur_bp1;
         if (am_fused) {
             run_band(other, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_am, n_am, false, false, 0, nullptr, 0,
-                     np_am ? pairs_am : nullptr, np_am);
+                     np_am && !(dbg_forms & 16) ? pairs_am : nullptr, np_am);
             hc = cur_bp1;
             if (n_sam) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_sam, n_sam, false, false, 0,
-                                nullptr, 0, np_sam ? pairs_sam : nullptr, np_sam);
+                                nullptr, 0, np_sam && !(dbg_forms & 16) ? pairs_sam : nullptr, np_sam);
         } else run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_bp1p[0], n_bp1p[0]);
         std::swap(stream, side_stream);
     }
@@ -2251,7 +2266,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             }
         }
         {   // de-emphasis: real taps on a real signal, two channels per tile
-            const bool pair = de_real && np_fm && !band6k && !band2g && bnfft == kNfft;
+            const bool pair = de_real && np_fm && !band6k && !band2g && bnfft == kNfft && !(dbg_forms & 16);
             run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm, false, false, 0, nullptr, 0,
                      pair ? pairs_fm : nullptr, np_fm);
         }

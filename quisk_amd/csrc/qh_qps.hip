@@ -58,6 +58,8 @@ struct qh_qps {
     bool own_stream = false;
     hipEvent_t ev_piece[2] = { nullptr, nullptr }, ev_agc[2] = { nullptr, nullptr };
     bool agc_recorded[2] = { false, false }, agc_started = false;
+    int last_agc_par = -1;                       // parity of the AGC event recorded last, over all calls (the AGC's stream runs in order)
+    long long layout[6] = { 0, 0, 0, 0, 0, 0 };  // how the call before this one cut the bank's rows and the scratch halves (pipelined calls)
     qh_qrx *rx = nullptr;
     qh_nb *nb = nullptr;
     qh_pan *pan = nullptr;
@@ -265,7 +267,6 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     int P = h->pieces;
     if (P <= 0) P = n >= (1 << 15) ? 4 : 1;       // (measured at 256 x 2^20: 1 piece 4.12 ms, 4: 3.60, 8: 3.65, 16: 3.57, 32: 4.0)
     if (!h->agc_started) P = 1;
-    h->agc_started = true;
     // The squelches are the CALL's: the FM squelch averages the level over the block it is given and mutes that block (quisk.c:2076-2085,
     // 2716), ssb_squelch counts its one-second timer down by the block length once per call, its first call only makes the plan, and the
     // flag it leaves mutes the whole block (quisk.c:1104-1112,1173-1176,2712-2728).  A call cut into pieces would decide piece by piece.
@@ -289,6 +290,17 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     long long o_off = 0, out_off = 0;
     int piece = 0, last_agc = -1;
     if (int rc = qh_qrx_squelch_pieces(h->rx, P > 1 ? 1 : 0)) return rc;       // (0: also ends a call that an error cut short)
+    // Pipelined calls: a piece waits for the AGC piece that recorded ITS parity's event last, which covers what it overwrites only while
+    // this call cuts the bank's rows and the scratch halves as the call before it did.  Another n, piece count or bound (a squelch
+    // switched on, set_pieces, a longer block): piece 0 could run over rows the other parity's AGC piece is still reading -- such a
+    // call waits for the AGC event recorded LAST, i.e. for all of the call before it (the AGC's stream runs in order).
+    {
+        const long long now[6] = { (long long)n, (long long)P, (long long)per, (long long)cap_bank, fd_bound, up_bound };
+        bool same = true;
+        for (int i = 0; i < 6; i++) same = same && now[i] == h->layout[i];
+        if (h->pipelined && !same && h->last_agc_par >= 0) QH_HIP(hipStreamWaitEvent(h->stream, h->ev_agc[h->last_agc_par], 0));
+        for (int i = 0; i < 6; i++) h->layout[i] = now[i];
+    }
     for (int pos = 0; pos < n; piece++) {
         const int cnt = n - pos < per ? n - pos : per, par = piece & 1;
         // this piece's scratch half was read by the AGC two pieces back.  Pipelined calls: the call before this one may still be in its
@@ -328,7 +340,8 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
             if (int rc = qh_qagc_process2(h->agc, audio, as, out + out_off, out_stride, na)) return rc;
             QH_HIP(hipEventRecord(h->ev_agc[par], h->agc_stream));
             h->agc_recorded[par] = true;
-            last_agc = par;
+            h->agc_started = true;              // (process_agc's initialising call has happened: only now may a call be cut into pieces)
+            last_agc = par; h->last_agc_par = par;
         }
         o_off += nb_;
         out_off += na;
@@ -350,7 +363,7 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
         }
         hipLaunchKernelGGL(qh_ps::epilogue_kernel, dim3(qh_ps::grid_x(total, 256u), (unsigned)nch), dim3(256), 0, tail, (const double2 *)out, out_stride,
                            out, out_stride, total, f0, step, f0, step, h->kill_audio, 1.0, 0.0, 0, h->d_flags);
-        if (tail != h->stream) { QH_HIP(hipEventRecord(h->ev_agc[last_agc], tail)); }      // (what waits for this parity's AGC also waits for the epilogue)
+        if (tail != h->stream) { QH_HIP(hipEventRecord(h->ev_agc[last_agc], tail)); h->last_agc_par = last_agc; }      // (what waits for this parity's AGC also waits for the epilogue)
     }
     if (n_out) *n_out = total;
     QH_HIP(hipGetLastError());
@@ -383,7 +396,8 @@ int qh_qps_process_host(qh_qps *h, const double *h_in, long long in_stride, int 
     if (n <= 0) return QH_OK;
     if (!h_in || !h_out) return set_error(QH_ERR_INVALID, "null buffer");
     QH_HIP(hipSetDevice(h->device));
-    const int cap = h->out_capacity(n);
+    int cap = 0;
+    { std::lock_guard<std::mutex> lk(h->mtx); cap = h->out_capacity(n); }       // (a setter on another thread may be rebuilding the bank)
     double2 *din = nullptr, *dout = nullptr;
     QH_HIP(hipMalloc((void **)&din, (size_t)h->nch * (size_t)n * 16));
     if (hipMalloc((void **)&dout, (size_t)h->nch * (size_t)cap * 16) != hipSuccess) { (void)hipFree(din); return set_error(QH_ERR_HIP, "hipMalloc failed"); }

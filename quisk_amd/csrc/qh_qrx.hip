@@ -112,6 +112,7 @@ struct Step {
 
 struct Qrx {
     int device = 0, nch = 0, sample_rate = 0, mode = Q_USB, bandwidth = 2700, decim_srate = 0, filter_srate = 0;
+    int ssb_sq_bandwidth = 2700;            // filter_bandwidth[0], whatever bank or filter set this receiver is (quisk.c:1120)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<Step> steps;        // in order; steps[0] is an overlap-save stage that carries the NCO
@@ -359,7 +360,7 @@ qh_qrx *qh_qrx_create_ex(int device, int nch, int sample_rate, int mode, int ban
     }
     qh_qrx *h = new qh_qrx();
     Qrx &q = h->q;
-    q.device = device; q.nch = nch; q.sample_rate = sample_rate; q.mode = mode; q.bandwidth = bandwidth;
+    q.device = device; q.nch = nch; q.sample_rate = sample_rate; q.mode = mode; q.bandwidth = bandwidth; q.ssb_sq_bandwidth = bandwidth;
     auto fail = [&]() -> qh_qrx * { delete h; return nullptr; };
     if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); return fail(); }
     q.stream = (hipStream_t)stream;
@@ -686,7 +687,7 @@ int qh_qrx_process(qh_qrx *h, const double *d_in, long long in_stride, int n_in,
         case Step::SSB_SQ:
             if (q.ssb_sq_on && n > 0) {
                 if (!q.ssb_sq_inited) { q.ssb_sq_inited = true; continue; }      // "if (!plan) { ...; return; }", quisk.c:1104-1112
-                int bw = q.bandwidth > 3000 ? 3000 : q.bandwidth;
+                int bw = q.ssb_sq_bandwidth > 3000 ? 3000 : q.ssb_sq_bandwidth;
                 QSsbSqParam sp;
                 sp.samp_rate = q.filter_srate;
                 sp.bw1 = 300 * 512 / q.filter_srate;
@@ -905,6 +906,15 @@ const int *qh_qrx_squelch_flag(qh_qrx *h, int ch)
     QH_QRX_LOCK(h);
     if (!h || ch < 0 || ch >= h->q.nch || !h->q.sq_state) return nullptr;
     return &h->q.sq_state[ch].active;
+}
+// ssb_squelch looks at the bins of filter_bandwidth[0] -- the bandwidth set_filters was given for filter set 0 -- in EVERY bank, also in
+// one that runs filter set 1 or 2 (quisk.c:1120).  A receiver on its own is bank 0 with set 0: the bandwidth it was created with.
+int qh_qrx_set_ssb_squelch_bandwidth(qh_qrx *h, int bandwidth)
+{
+    QH_QRX_LOCK(h);
+    if (!h) return set_error(QH_ERR_INVALID, "null receiver bank");
+    h->q.ssb_sq_bandwidth = bandwidth;
+    return QH_OK;
 }
 // ssb_squelch's FFT plan is ONE function static for all banks (quisk.c:1091,1104): the first call of any bank creates it and
 // returns without looking at its samples.  A caller that runs several banks as the reference's bank 0 / 1 / 2 passes the fact on.

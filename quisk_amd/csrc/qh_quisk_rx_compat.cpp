@@ -174,7 +174,7 @@ struct Bank {
     int notch_applied = -1;
     int purpose = -1;                   // whose tune vector its oscillator carries (index into QuiskRx::phase)
     double sq_level = -1e300;           // squelch settings the bank has been given
-    int ssb_en = -1, ssb_lv = -1;
+    int ssb_en = -1, ssb_lv = -1, ssb_bw = -1;
 };
 
 struct QuiskRx {
@@ -311,6 +311,10 @@ int ensure_bank(Bank &b, int mode, int nFilter, int tune, int purpose, int bw_fo
             b.ssb_en = g.ssb_squelch_enabled; b.ssb_lv = g.ssb_squelch_level;
         }
         if (g.ssb_planned) (void)qh_qrx_ssb_squelch_planned(b.rx, 1);
+        if (b.ssb_bw != g.filt_bw[0]) {         // "bw = filter_bandwidth[0]" in every bank, whichever filter set it runs (quisk.c:1120)
+            if (int rc = qh_qrx_set_ssb_squelch_bandwidth(b.rx, g.filt_bw[0])) return rc;
+            b.ssb_bw = g.filt_bw[0];
+        }
     }
     return QH_OK;
 }

@@ -103,6 +103,38 @@ def test_a_stage_changing_form_takes_the_other_channels_delay_lines_along(qh, or
         e.close()
 
 
+def test_long_fm_delay_lines_of_a_channel_that_leaves_the_mode_and_returns(qh, oracle):
+    """the partitioned forms (nc > 4096) keep 16383-sample delay lines per stage in a ping-pong pair that flips for the
+    LISTED channels only.  A channel that leaves FM while the others keep flipping the pair and comes back an odd number of calls later
+    found its de-emphasis and audio filter reading the other half (stale or zero); WDSP's fircores keep their delay lines across that
+    (SetRXAMode only clears fmd's run flag, RXA.c:758-776).  Channel 0: FM, USB for three calls, FM again; channels 1 and 2 stay."""
+    nch, nc = 3, 8192
+    plan = [(220, None), (5, 1), (6, None), (7, None), (120, 5)]         # (blocks, channel 0's new mode ahead of the call)
+    n = sum(p[0] for p in plan) * 1024
+    x = np.stack([synth.make_mode_input_numpy("fm", c, n) for c in range(nch)])
+    e = qh.RxaEngine(nch)
+    _setup(e, nch, nc, mode=5, passband=(-8000.0, 8000.0))
+    refs = [_oracle(oracle, c, nc, mode=5, passband=(-8000.0, 8000.0)) for c in range(nch)]
+    pos, outs, wants = 0, [[] for _ in range(nch)], [[] for _ in range(nch)]
+    for nb, m in plan:
+        if m is not None:
+            e.SetRXAMode(0, m); refs[0].SetRXAMode(m)
+        seg = np.ascontiguousarray(x[:, pos * 1024:(pos + nb) * 1024])
+        pos += nb
+        y = e.process_host(seg)
+        for c in range(nch):
+            outs[c].append(y[c]); wants[c].append(refs[c].xrxa(seg[c]))
+    settle = (nc // 256 + 150) * 256              # the loop's start-up depends on the filters' last bit (DESIGN.md parity caveat)
+    for c in range(nch):
+        got, want = np.concatenate(outs[c]), np.concatenate(wants[c])
+        assert np.abs(want[settle:]).max() > 1e-3
+        assert rel_rms(got[settle:], want[settle:]) < 1e-6, (c, rel_rms(got[settle:], want[settle:]))
+    back = sum(p[0] for p in plan[:4]) * 256      # channel 0 is FM again from here: its filters' first 8191 outputs see the old delay lines
+    got, want = np.concatenate(outs[0])[back:back + 2 * nc], np.concatenate(wants[0])[back:back + 2 * nc]
+    assert rel_rms(got, want) < 1e-6, rel_rms(got, want)
+    e.close()
+
+
 def test_through_the_wdsp_names_block_by_block(qh, oracle):
     """OpenChannel + RXASetNC(8192) + fexchange0: one DSP block per call, the partitions inside every block."""
     from test_gpu_wdsp_dropin import _open, _run

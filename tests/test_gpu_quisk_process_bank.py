@@ -195,3 +195,39 @@ def test_pipelined_calls_give_the_same_samples(qh):
             bank.close()
         assert ys[0].shape == ys[1].shape and float(ys[0].abs().max()) > 2.0 ** 20
         assert torch.equal(ys[0], ys[1]), (fs, float((ys[0] - ys[1]).abs().max()))
+
+
+def test_pipelined_calls_whose_piece_layout_changes(qh):
+    """in pipelined mode a piece waited for the AGC event of its own parity only, which covers what it overwrites only
+    while consecutive calls cut the bank's rows and the scratch halves alike.  Here the block length grows, shrinks, and the piece
+    count moves between 1, 3 and 4 from call to call (a call that ends on parity 1 followed by one whose piece 0 is longer): the bits
+    of the calls that end on their stream."""
+    import torch
+    dev = torch.device("cuda", 0)
+    plan = [(1 << 15, 4), (3 << 14, 3), (1 << 16, 1), (1 << 15, 4), (5 << 13, 3), (1 << 16, 4), (1 << 14, 1), (1 << 16, 3)]
+    total = sum(n for n, _ in plan)
+    for fs, play, mode in ((192000, 48000, 3), (185185, 96000, 4)):
+        nch = 8
+        filt = _filters(mode, fs)
+        x = torch.from_numpy(np.stack([_signal(mode, c, total, fs, 6000.0 + 500 * c, amp=2.0 ** 18) for c in range(nch)])).to(dev)
+        ys = []
+        for pipelined in (0, 1):
+            st = torch.cuda.Stream(dev)
+            bank = qh.QuiskProcessBank(nch, fs, mode, BW[mode], playback_rate=play, stream=st.cuda_stream)
+            bank.set_pipelined(pipelined)
+            for c in range(nch):
+                bank.set_tune(c, 6000 + 500 * c)
+            bank.set_filters(-1, *filt)
+            outs, got, pos = [], [], 0
+            torch.cuda.synchronize(dev)
+            for n, pieces in plan:
+                bank.set_pieces(pieces)
+                cap = bank.out_capacity(n) + 64
+                outs.append(torch.zeros((nch, cap), dtype=torch.complex128, device=dev))
+                got.append(bank.process_ptr(x[:, pos:].data_ptr(), x.shape[1], n, outs[-1].data_ptr(), cap))
+                pos += n
+            bank.synchronize()
+            ys.append(torch.cat([outs[k][:, :got[k]] for k in range(len(plan))], dim=1).cpu())
+            bank.close()
+        assert ys[0].shape == ys[1].shape and float(ys[0].abs().max()) > 2.0 ** 20
+        assert torch.equal(ys[0], ys[1]), (fs, float((ys[0] - ys[1]).abs().max()))
