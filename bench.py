@@ -24,6 +24,7 @@ LOG2_SAMPLES = 22
 IN_RATE, DSP_RATE = 192000, 48000
 DSP_SIZE = 256
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+COPY_CEILING_GBPS = 6290.0      # MI355X_MICROARCH.md: what a float4 copy measures (79 % of the 8 TB/s)
 VALU_PEAK_LANE_OPS = 39.3e12    # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one lane operation (an FMA = 2 flop) per lane and clock = 78.6 TFLOP/s fp64 vector
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "c2_traffic.json")
 
@@ -192,6 +193,197 @@ def other_configs(timeout_s=900.0):
     return out
 
 
+def host_fed(torch, eng, x, y, nch, n_in, n_out, nblk, dev, stream, log2_chunk=18, passes=2):
+    """SURVEY.md 8(d)'s "H2D reported separately": the reference's samples arrive on the HOST (quisk.c:3284-3423 UDP, sound.c:990), so
+    this is what a deployment whose samples do not already sit in HBM gets.  The step's input streams from PINNED host memory in
+    time chunks of 2^log2_chunk samples per channel, two device buffers, the copy of chunk k + 1 on a copy stream beside the kernels
+    of chunk k, the chunk's output copied back to pinned host memory behind them (events order the three streams): once as fp64
+    complex (16 B per sample over the link, 4 B back) and once in the 24-bit wire format (6 B per sample, decoded in the front
+    kernel's load).  Never `value`: the timed region of the headline starts with the input resident in HBM."""
+    from quisk_amd import IqFormat
+    ck = 1 << log2_chunk
+    if n_in % ck:
+        return {"skipped": "chunk does not divide the step"}
+    nck = n_in // ck
+    cb, co = nblk // nck, n_out // nck
+    copy_s, back_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    out = {"chunk_samples_per_channel": ck, "chunks_per_step": nck, "link": "PCIe Gen5 x16, 63 GB/s spec (MI355X_MICROARCH.md)"}
+    fmt24 = IqFormat.le24(2.0 ** -31)
+    for kind in ("f64", "le24"):
+        bps = 16 if kind == "f64" else 6
+        if kind == "f64":
+            host = torch.view_as_real(x[:, :ck]).contiguous().cpu().pin_memory()           # one chunk's worth, fed again and again
+            dbuf = [torch.empty((nch, ck), dtype=torch.complex128, device=dev) for _ in range(2)]
+        else:
+            codes = torch.view_as_real(x[:, :ck]).mul(2.0 ** 23).round_().to(torch.int32)
+            host = codes.view(torch.uint8).reshape(nch, ck, 2, 4)[..., :3].contiguous().cpu().pin_memory()
+            del codes
+            dbuf = [torch.empty((nch, ck, 2, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        hout = torch.empty((nch, co, 2), dtype=torch.float64).pin_memory()
+        dout = [torch.empty((nch, co), dtype=torch.complex128, device=dev) for _ in range(2)]
+        ev_in = [torch.cuda.Event() for _ in range(2)]          # chunk's input has landed
+        ev_done = [torch.cuda.Event() for _ in range(2)]        # chunk's kernels are done (its input buffer and output buffer are free / ready)
+        ev_back = [torch.cuda.Event() for _ in range(2)]        # chunk's output has left
+
+        def one_pass():
+            for k in range(nck):
+                b = k & 1
+                with torch.cuda.stream(copy_s):
+                    if k >= 2:
+                        copy_s.wait_event(ev_done[b])           # the kernels of chunk k - 2 have read this buffer
+                    (torch.view_as_real(dbuf[b]) if kind == "f64" else dbuf[b]).copy_(host, non_blocking=True)
+                    ev_in[b].record(copy_s)
+                stream.wait_event(ev_in[b])
+                if k >= 2:
+                    stream.wait_event(ev_back[b])               # the output of chunk k - 2 has left this buffer
+                if kind == "f64":
+                    eng.process_ptr(dbuf[b].data_ptr(), ck, dout[b].data_ptr(), co, cb)
+                else:
+                    eng.process_packed_ptr(dbuf[b].data_ptr(), dbuf[b].numel(), fmt24, 6 * ck, dout[b].data_ptr(), co, cb)
+                ev_done[b].record(stream)
+                with torch.cuda.stream(back_s):
+                    back_s.wait_event(ev_done[b])
+                    hout.copy_(torch.view_as_real(dout[b]), non_blocking=True)
+                    ev_back[b].record(back_s)
+            torch.cuda.synchronize(dev)
+        one_pass()                                              # warm-up (buffers of the engine at this call shape)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_pass()
+        dt = (time.perf_counter() - t0) / passes
+        samples = float(nch) * n_in
+        out[kind] = {"ms_per_step": dt * 1e3, "Msamp_per_s": samples / dt / 1e6, "link_GBps_in": bps * samples / dt / 1e9,
+                     "link_GBps_out": 4.0 * samples / dt / 1e9, "bytes_per_sample_in": bps, "bytes_per_sample_out": 4.0}
+        del host, dbuf, hout, dout
+        torch.cuda.empty_cache()
+    out["note"] = ("input from pinned host memory in chunks, H2D beside the kernels, output D2H behind them; the same engine and step as `value`, "
+                   "whose input is resident in HBM")
+    return out
+
+
+class DryLeg:
+    """--dry-run stand-in for a configuration 4 / 5 leg (tests/test_bench_plumbing.py): the plumbing around it is what is tested."""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, 0
+
+    def step(self):
+        self.calls += 1
+        time.sleep(0.001 * (self.rank + 1))
+
+
+def sharded_config(args, torch, dist, shard, rank, world, local_rank, dev, dry, sync):
+    """BASELINE.json configurations 4 and 5 on N GPUs: channels are independent (wdsp/RXA.c:29, channel.c:29), every rank owns a
+    contiguous range and runs the leg tools/bench_configs.py builds for it (the same setup_* functions the parity tests of the call
+    shapes use, tests/test_gpu_bench_shapes.py); barrier-bracketed timing, max over ranks, one line from rank 0 with every rank's own
+    kernel time and roofline.  Config 4: 256 channels per GPU, mode by the job-wide channel index mod 3 (2048 on eight GPUs);
+    --total-channels splits a fixed job instead.  Config 5: one 61.44 Msps fp32 channel per GPU (8 on eight)."""
+    cfg = args.config
+    if cfg == 5 and (args.channels != 1 or args.total_channels):
+        raise SystemExit("bench.py --config 5 runs one 61.44 Msps channel per GPU")
+    if args.total_channels > 0:
+        mine = shard.split_channels(args.total_channels, world)[rank]
+        first, nch, scaling, total_channels = mine.start, len(mine), "strong", args.total_channels
+        if nch == 0:
+            raise SystemExit("bench.py: rank %d has no channel (--total-channels %d over %d ranks)" % (rank, args.total_channels, world))
+    else:
+        nch = args.channels
+        first = shard.channel_range(rank, world, nch)[0]
+        scaling, total_channels = "weak", nch * world
+    if dry:
+        leg, samples_rank = DryLeg(rank), float(nch) * (1 << args.log2_samples)
+        step = leg.step
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs as bc
+        import quisk_amd as qh
+        if cfg == 4:
+            nblk = (1 << args.log2_samples) // 1024
+            leg = bc.setup_config4(torch, qh, dev, nch=nch, nblk=nblk, first=first)
+            samples_rank = float(nch) * leg.n_in
+            step = leg.step
+        else:
+            n = 1 << (args.log2_samples if args.log2_samples != LOG2_SAMPLES else 26)       # SURVEY.md 8(d): 2^26 samples of the one stream per step
+            leg = bc.setup_config5(torch, qh, dev, n=n, unfused=False)
+            samples_rank = float(n)
+            step = leg.step_fused
+    sync()
+
+    def timed_run():
+        for _ in range(args.warmup):
+            step()
+        sync()
+        _trace("warm_done")
+        if world > 1:
+            dist.barrier()
+        sync()
+        _trace("timed_start")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        _trace("steps_done")
+        if world > 1:
+            dist.barrier()
+        sync()
+        _trace("timed_end")
+        return shard.max_over_ranks(time.perf_counter() - t0, dev if not dry else None)
+
+    dt = timed_run()
+    # the dominant kernel's own time on this rank, HIP events on the stream it is launched on
+    if dry:
+        kname, kms, algo = "dry", 1.0, 20.0
+    elif cfg == 4:
+        leg.eng.enable_timing(True)
+        kt = [0.0, 0.0, 0.0]
+        for _ in range(3):
+            leg.step()
+            kt = [a + b / 3 for a, b in zip(kt, leg.eng.timing_ms())]
+        leg.eng.enable_timing(False)
+        kname, kms, algo = "osfir_kernel<f64,4096,D=4,OUTMIX> front (shift + resample /4, shared by USB / AM / FM)", kt[0], 20.0
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x, bufs, n = leg.x, leg.bufs, leg.n
+        sync()
+        e0.record(leg.stream)
+        for _ in range(5):
+            leg.casc.process_ptr(x.data_ptr(), n, n, bufs[-1].data_ptr(), bufs[-1].shape[1])
+        e1.record(leg.stream)
+        sync()
+        kname, kms, algo = "hb45_cascade_kernel<float,4> x 2 (4 + 4 half-band stages, one HBM pass)", e0.elapsed_time(e1) / 5, 8.0
+    achieved = algo * samples_rank / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    mine_rec = {"rank": rank, "device": local_rank, "channels": [first, first + nch], "dominant_kernel_ms": kms,
+                "roofline": {"kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS}}
+    per_rank = [mine_rec]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
+    if rank == 0:
+        per_step = (float(total_channels) * (1 << args.log2_samples)) if (dry or cfg == 4) else samples_rank * world
+        total = per_step * args.steps
+        bytes_per_sample = 20.0 if cfg == 4 else 8.0
+        workload = ("config 4: %d channels/GPU x 192 kHz, mode by job-wide channel mod 3 = USB / AM / FM (amd / fmd / nbp), fp64, 2^%d input samples per channel per step"
+                    % (nch, args.log2_samples)) if cfg == 4 else \
+                   ("config 5: 1 channel/GPU x 61.44 Msps fp32: 8 x HB45 (fused cascade) + 245-tap /5 + overlap-save bandpass nc 2048, %d samples per step" % int(samples_rank))
+        line = {"metric": "Mcomplex-samples/s through RXA chain", "value": total / dt / 1e6, "unit": "Mcomplex-samples/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+                "vs_baseline": None, "dtype": "f64" if cfg == 4 else "f32", "data": "synthetic",
+                "config": {"workload": workload, "baseline_config": cfg, "channels_per_gpu": nch, "total_channels": total_channels,
+                           "parallelism": "channel-sharded x%d (%s), no collective" % (world, scaling)},
+                "chain_algorithmic_GBps": bytes_per_sample * total / dt / 1e9,
+                "roofline": dict(per_rank[0]["roofline"], bound="latency", traffic=None,
+                                 algorithmic_bytes_per_launch=algo * samples_rank,
+                                 traffic_note="counter passes of this leg: profiles/ (tools/pmc_pass.py)"),
+                "per_rank": per_rank}
+        if dry:
+            line["dry_run"] = True
+            line["dry"] = {"rank0_channels": [first, first + nch], "steps_run": leg.calls}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): N fresh child processes, one per GPU, with
     the rank variables torch.distributed.run would set, started BEFORE this process imports torch or touches a GPU.  Rank 0's
@@ -236,7 +428,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=NCH, help="channels per GPU (weak scaling)")
+    ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
+                    help="BASELINE.json configuration: 2 (the headline: 256 ch SSB chain, what the driver runs), 4 (mixed USB / AM / FM, 256 channels per GPU) "
+                         "or 5 (61.44 Msps fp32 half-band cascade + /5 + bandpass, one channel per GPU); 4 and 5 shard over --gpus N like 2 does")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (weak scaling); default 256 (configs 2, 4) or 1 (config 5)")
     ap.add_argument("--total-channels", type=int, default=0,
                     help="strong scaling: this many channels in all, split over the ranks in contiguous ranges (SURVEY.md 8(e))")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the barrier / max-over-ranks (nccl = RCCL)")
@@ -245,6 +440,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-le24", action="store_true", help="skip the extra run from 24-bit wire samples (the test of the front kernel's HBM bound)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra legs (BASELINE configs 3, 4, 5 and the Quisk-native chain)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed leg (pinned host buffers, copies beside the kernels: what a receiver whose samples arrive on the host gets)")
     ap.add_argument("--meters", choices=["on", "off"], default="on",
                     help="on (default): xrxa's three meters run as in the reference (adc, S, agc: wdsp/RXA.c:566,569,589), "
                          "fused into the nbp0 launch; the line also carries the rate of a second, untimed-for-`value` run with them off")
@@ -256,6 +452,8 @@ def main():
                     help="f64: complex double input resident in HBM (the BASELINE workload); le24: the same signal as "
                          "24-bit little-endian IQ bytes (quisk_read_rx_udp wire format), decoded in the front kernel's load")
     args = ap.parse_args()
+    if args.channels is None:
+        args.channels = 1 if args.config == 5 else NCH
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # no launcher: be one (before torch, before any GPU call)
         raise SystemExit(self_spawn(args))
@@ -292,6 +490,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         dist.barrier()
+
+    if args.config != 2:
+        return sharded_config(args, torch, dist, shard, rank, world, local_rank, dev, dry, sync)
 
     n_in = 1 << args.log2_samples
     nblk = n_in // (DSP_SIZE * (IN_RATE // DSP_RATE))
@@ -439,9 +640,21 @@ def main():
         except Exception as exc:                             # reported, never required
             le24 = {"failed": repr(exc)}
 
+    hostfed = None
+    if world == 1 and not dry and not args.no_host_fed and args.ingest == "f64" and nchunk == 1:
+        try:
+            hostfed = host_fed(torch, eng, x, y, nch, n_in, n_out, nblk, dev, stream)
+        except Exception as exc:                             # reported, never required
+            hostfed = {"failed": repr(exc)}
+
     # every rank's own figures (over the group that already exists), so that a slow GPU is attributable
+    algo_b = [20.0 if args.ingest == "f64" else 10.0, 8.0]
     mine_rec = {"rank": rank, "device": local_rank, "channels": [first, first + nch], "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
-                "check_inband_gain": gain}
+                "check_inband_gain": gain,
+                "roofline": {"kernel": "front" if kt[0] >= kt[1] else "band", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                             "achieved": (algo_b[0] if kt[0] >= kt[1] else algo_b[1]) * float(nch) * n_in / (max(kt[0], kt[1]) * 1e-3) / 1e9 if max(kt[0], kt[1]) > 0 else None}}
+    if mine_rec["roofline"]["achieved"] is not None:
+        mine_rec["roofline"]["frac"] = mine_rec["roofline"]["achieved"] / HBM_PEAK_GBPS
     per_rank = [mine_rec]
     if world > 1:
         per_rank = [None] * world
@@ -482,9 +695,23 @@ def main():
             traffic_note = "no counter-derived traffic: %r" % (exc,)
         dom = "front" if k == 0 else "band"
         valu_dom = valu.get(dom) if valu else None
-        # which ceiling the dominant kernel sits closer to: its algorithmic bytes against 8 TB/s, or the VALU lane operations it
-        # executes (counted, SQ_INSTS_VALU x 64) against the vector unit's 39.3 T lane operations per second
-        bound = "valu" if (valu_dom and valu_dom["frac"] > achieved / HBM_PEAK_GBPS) else "hbm"
+        # What bounds the dominant kernel, from evidence rather than from the larger of two fractions: "hbm" needs its bytes to move at
+        # >= 0.85 of what a plain copy of the same read / write mix reaches on this part (6.29 TB/s, MI355X_MICROARCH.md) AND the kernel
+        # to speed up when its input bytes are halved (the 24-bit ingest run of the SAME kernel: < 0.8 of the fp64-input time); "valu"
+        # needs >= 0.8 of the vector unit's issue rate.  Neither: "latency" (the tile's dependent phases -- load, exchange, barrier --
+        # at the occupancy its registers and LDS image allow).
+        hbm_frac_of_copy = achieved / (COPY_CEILING_GBPS)
+        halved = (le24["front_ms"] / kt[0]) if (le24 and k == 0 and "front_ms" in le24 and kt[0] > 0) else None
+        if valu_dom and valu_dom["frac"] >= 0.8:
+            bound = "valu"
+        elif hbm_frac_of_copy >= 0.85 and (halved is None or halved < 0.8):
+            bound = "hbm"
+        else:
+            bound = "latency"
+        bound_evidence = {"hbm_frac_of_peak": achieved / HBM_PEAK_GBPS, "hbm_frac_of_measured_copy_ceiling": hbm_frac_of_copy, "copy_ceiling_GBps": COPY_CEILING_GBPS,
+                          "valu_frac": valu_dom["frac"] if valu_dom else None,
+                          "time_with_input_bytes_halved_over_time": halved,
+                          "rule": "hbm: >= 0.85 of the copy ceiling and < 0.8 of the time with 24-bit input; valu: >= 0.8 of 39.3 T lane-ops/s; else latency"}
         line = {
             "metric": "Mcomplex-samples/s through RXA chain",
             "value": value,
@@ -509,7 +736,7 @@ def main():
             # the survey derives from this count (78.6e12 / 650 = 121 Gsamp/s)
             "chain_direct_form_equivalent_TFLOPs": 650.0 * total / dt / 1e12,
             "kernel_ms": {"front_shift_resample": kt[0], "band_nbp": kt[1], "state_bookkeeping": kt[2]},
-            "roofline": {"bound": bound, "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": bound, "bound_evidence": bound_evidence, "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo[k] * samples_per_step,
                          "valu": None if not valu_dom else {"achieved": valu_dom["lane_ops_per_s"], "peak": VALU_PEAK_LANE_OPS, "unit": "VALU lane-ops/s",
@@ -520,6 +747,8 @@ def main():
         }
         if le24 is not None:
             line["ingest_le24"] = le24
+        if hostfed is not None:
+            line["host_fed"] = hostfed
         if world > 1:
             line["per_rank"] = per_rank
         if dry:

@@ -164,6 +164,7 @@ struct Engine {
     bool band2g = false;                    // 8192-point tiles shared by two lane groups (osfir8k_kernel): masks stored [even | odd]
     bool band6k = false;                    // 6144-point tiles on 384 lanes (osfir6k_kernel)
     int band_tile_pref = 0;                 // qh_rxa_set_band_tile: 0 / 4096: 4096-point tiles, 8192: the two-group tiles
+    double2 *band_stash = nullptr;          // osfir8s_kernel: [nch][4096], where the tile cut short by the end of a call parks A'
     std::vector<cd> band_mask(const std::vector<cd> &h) const;
     unsigned long long *nco_phase = nullptr, *nco_dphase = nullptr, *nco_parked = nullptr;
     double2 *nco_step = nullptr;
@@ -358,6 +359,7 @@ Engine::~Engine()
     (void)hipFree(obuf); (void)hipFree(abuf);
     for (int i = 0; i < 5; i++) { (void)hipFree(lmask[i]); (void)hipFree(lhist[i][0]); (void)hipFree(lhist[i][1]); }
     (void)hipFree(lcat); (void)hipFree(ltmp);
+    (void)hipFree(band_stash);
     (void)hipFree(mask_front); (void)hipFree(mask_nbp); (void)hipFree(mask_bp1); (void)hipFree(tw4096); (void)hipFree(tw_inv_front); (void)hipFree(tw8192);
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
@@ -493,6 +495,8 @@ int Engine::init()
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, osfir8k_lds_bytes()))
     QH_SET_LDS2G(false, false); QH_SET_LDS2G(true, false); QH_SET_LDS2G(false, true); QH_SET_LDS2G(true, true);
 #undef QH_SET_LDS2G
+    QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kOsfir8kImage));
+    QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kOsfir8kImage));
     QH_SET_LDS(2, false, false, false, true, false, true); QH_SET_LDS(4, false, false, false, true, false, true); QH_SET_LDS(8, false, false, false, true, false, true);
     QH_SET_LDS(2, false, true, false, true, false, true); QH_SET_LDS(4, false, true, false, true, false, true); QH_SET_LDS(8, false, true, false, true, false, true);
 #undef QH_SET_LDS
@@ -1493,6 +1497,16 @@ static void launch_band6k(OsfirArgs<double> a, int ntiles, int nch, hipStream_t 
 static void launch_band2g(OsfirArgs<double> a, int ntiles, int nch, hipStream_t s, bool meter, bool egress)
 {
     a.ntiles = ntiles;
+    // QH_BAND8_FORM=seq: the two halves one after the other on 256 lanes (osfir8s_kernel) instead of the two lane groups side by side
+    // (osfir8k_kernel): same masks, same meter partials, same tile geometry.  Measured slower still (profiles/r05_notes.md: the second
+    // read of the tile and the parked half go through memory), so it is there for experiments only; never for narrowed outputs.
+    static const bool seq = [] { const char *e = std::getenv("QH_BAND8_FORM"); return e && std::strcmp(e, "seq") == 0; }();
+    if (!egress && seq && a.stash) {
+        dim3 g1((unsigned)ntiles * (unsigned)nch);
+        if (meter) hipLaunchKernelGGL((osfir8s_kernel<true>), g1, dim3(NT), kOsfir8kImage, s, a);
+        else hipLaunchKernelGGL((osfir8s_kernel<false>), g1, dim3(NT), kOsfir8kImage, s, a);
+        return;
+    }
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(kOsfir8kThreads);
     constexpr int lds = osfir8k_lds_bytes();
     if (meter && egress) hipLaunchKernelGGL((osfir8k_kernel<true, true>), grid, block, lds, s, a);
@@ -1739,6 +1753,7 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     a.mask = mask; a.mask_stride = mask_stride;
     a.tw_fwd = a.tw_inv = (bnfft == kNfft || band2g) ? tw4096 : tw8192;
     a.tw_r2 = tw8192 + 32;                  // second pass table of the 8192-point plan: exp(-2 pi i k / 8192), k < 256 (qh_design.cpp)
+    a.stash = band_stash;
     a.epi = ep;
     a.chan_list = list;
     a.n_in = (int)n_mid; a.n_out = (int)n_mid; a.off = 0; a.P = P; a.Lout = Lout;
@@ -1927,6 +1942,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         const bool two_group = nc_max <= 2048 && band_tile_pref == 8192 && !force8k;
         const bool six_k = nc_max <= 2048 && band_tile_pref == 6144 && !force8k;
         const int want = six_k ? kOsfir6kN : (nc_max > 2048 || force8k || two_group) ? kBandNfftMax : kNfft;
+        if (two_group && !band_stash) {
+            QH_HIP(hipStreamSynchronize(stream));
+            drop_graphs(); epoch++;
+            QH_HIP(dev_alloc(&band_stash, (size_t)nch * 4096));
+            dev_bytes += (long long)nch * 4096 * (long long)sizeof(double2);
+        }
         if (want != bnfft || two_group != band2g || six_k != band6k) {
             bnfft = want; band2g = two_group; band6k = six_k;
             for (ChanCfg &c : cfg) { c.nbp_dirty = c.bp1_dirty = true; c.snb_dirty = true; }

@@ -92,6 +92,7 @@ template <typename T> struct OsfirArgs {
     long long det_sum_stride;           // tiles per channel row
     double det_m[2], det_m256[2], det_g[2];
     int pair_im0;                       // PAIR kernels: the unpaired equivalent would see (y, 0) (Quisk's real chains) instead of (y, y)
+    double2 *stash;                     // osfir8s_kernel: [nch][4096] scratch for the tile that the end of the call cuts short
 };
 
 
@@ -181,6 +182,11 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 #ifndef QH_MASK_BATCH
 #define QH_MASK_BATCH 8
 #endif
+// QH_MASK_PREFETCH = K > 0: the first K mask values of a decimating tile are asked for ahead of the forward transform and ride through it
+// in registers, so that the fold does not begin with a round trip to L2
+#ifndef QH_MASK_PREFETCH
+#define QH_MASK_PREFETCH 0
+#endif
 #ifndef QH_OSFIR_WAVES_F64_D1
 #define QH_OSFIR_WAVES_F64_D1 4
 #endif
@@ -233,8 +239,9 @@ __device__ __forceinline__ double max_nn(double a, double b)
 // x[r0 + k], k = 0 .. nseg - 1 (nseg = E - r0), are the registers to meter.  The wave's nseg partials go out as one
 // contiguous run: dst[wave * nseg + k] (meter_finish_kernel knows that chunk 4 k + wave of the tile sits there).
 template <typename C, int E>
-__device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane, double *lds_wave, double2 *dst, int wave, int lane)
+__device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane, double *lds_wave, double2 *dst, int wave, int lane, int wstride = -1)
 {
+    const int ws = wstride < 0 ? E - r0 : wstride;      // a wave's run inside dst (callers that tap a tile's registers in several calls)
     const int wr = (lane >> 3) * 9 + (lane & 7);        // write slot inside a register's 8 segments
     const double *rd = lds_wave + lane * 9;
 #pragma unroll
@@ -258,7 +265,7 @@ __device__ __forceinline__ void meter_tap(const C (&x)[E], int r0, double wlane,
         sum += dpp_mov_d<0x4E>(sum); mx = max_nn(mx, dpp_mov_d<0x4E>(mx));        // quad_perm [2,3,0,1]
         sum += dpp_mov_d<0x141>(sum); mx = max_nn(mx, dpp_mov_d<0x141>(mx));      // row_half_mirror
         const int r = 8 * g + (lane >> 3);
-        if ((lane & 7) == 0 && r >= r0) dst[wave * (E - r0) + (r - r0)] = make_double2(sum, mx);
+        if ((lane & 7) == 0 && r >= r0) dst[wave * ws + (r - r0)] = make_double2(sum, mx);
         __builtin_amdgcn_wave_barrier();                // the next group overwrites the block
     }
 }
@@ -380,18 +387,26 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
 
     // ---- forward FFT, registers -> registers
     QH_OPROBE(1);
+    const C *mask = a.mask + (long long)ch * a.mask_stride;
+    constexpr int KPRE = (D > 1 && QH_MASK_PREFETCH > 0) ? (QH_MASK_PREFETCH < E ? QH_MASK_PREFETCH : E) : 0;      // in fold order: (i, q) = (k / D, k % D)
+    C mpre[KPRE > 0 ? KPRE : 1];
+    if constexpr (KPRE > 0) {
+#pragma unroll
+        for (int k = 0; k < KPRE; k++) mpre[k] = mask[t + NT * (k / D + EO * (k % D))];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (POLY) Fwd::template run_poly<D>(x, lds, Fwd::load(a.tw_fwd));
     else Fwd::run(x, lds, Fwd::load(a.tw_fwd));
     QH_OPROBE(2);
 
     // ---- mask multiply + D-fold: lane holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
-    const C *mask = a.mask + (long long)ch * a.mask_stride;
     C z[EO];
 #pragma unroll
     for (int i = 0; i < EO; i++) {
-        C acc = cmul(x[i], mask[t + NT * i]);
+        auto mval = [&](int q) -> C { const int k = i * D + q; if constexpr (KPRE > 0) { if (k < KPRE) return mpre[k]; } return mask[t + NT * (i + EO * q)]; };
+        C acc = cmul(x[i], mval(0));
 #pragma unroll
-        for (int q = 1; q < D; q++) acc = cadd(acc, cmul(x[i + EO * q], mask[t + NT * (i + EO * q)]));
+        for (int q = 1; q < D; q++) acc = cadd(acc, cmul(x[i + EO * q], mval(q)));
         z[i] = acc;
         // at most QH_MASK_BATCH mask values in flight: all 16 at once cost the D = 1 kernel its spills (A/B: +0.8 %)
         if (((i + 1) * D) % QH_MASK_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
@@ -663,6 +678,171 @@ __global__ __launch_bounds__(kOsfir8kThreads, 4) void osfir8k_kernel(OsfirArgs<d
             v.y = ep.c * x[r].x + ep.d * x[r].y;
             if constexpr (EGRESS) egress_store(a.eg, ch, a.out_offset + m, v.x, v.y);
             else out[m] = v;
+        }
+    }
+}
+
+// ---- D = 1 stage on 8192-point tiles, the two halves of the radix-2 split ONE AFTER THE OTHER on 256 lanes ------------------------
+// The split of osfir8k_kernel (a = x[n] + x[n + 4096] -> even bins, b = (x[n] - x[n + 4096]) W^n -> odd bins) without its second
+// lane group: one 256-lane workgroup -- the register, LDS and occupancy budget of the 4096-point kernel, four workgroups per CU --
+// runs the 4096-point transform pair of the even bins, parks A'[n] (n = j + 256 s: every lane parks and later fetches its OWN sixteen
+// values, so no fence beyond the lane's own store -> load order is needed), reads the tile's samples a second time (from L2), runs
+// the pair of the odd bins and joins: y[n] = A'[n] + W^-n B'[n], y[n + 4096] = A'[n] - W^-n B'[n].  6144 outputs per four 4096-point
+// transforms and two butterfly stages instead of 2049 per two: 0.66 of the fp64 instructions per output, HBM bytes per output 0.67.
+// A' is parked in the tile's own stretch of the output rows (positions rel 2048 .. 6143, which the tile overwrites with y at its
+// end); a tile that the call's end cuts short parks in a per-channel scratch row instead (a.stash).  Masks [even | odd], meter
+// partials and tile geometry are osfir8k_kernel's (layout 1), so the engine's band2g plumbing serves both.  Not for EGRESS (the
+// parked values would be narrowed): the two-group kernel keeps those calls.
+template <bool METER>
+__global__ __launch_bounds__(NT, 4) void osfir8s_kernel(OsfirArgs<double> a)
+{
+    using C = double2;
+    using SF = FftSplit4096<false, C>;
+    using SI = FftSplit4096<true, C>;
+    constexpr int N = 8192, P = kOsfir8kP, L = kOsfir8kLout;
+    static_assert(NT / 64 * kMeterLdsDoublesPerWave * 8 <= SF::kLdsBytes, "meter blocks overlay the exchange image");
+    extern __shared__ __align__(16) unsigned char smem8s[];
+    const int j_ = threadIdx.x;
+    int tile, slot;
+    xcd_tile_map(a.ntiles, slot, tile);
+    // (the division of xcd_tile_map runs on the vector unit: said to be uniform, the tile and the channel -- and every row pointer formed
+    // from them -- live in scalar registers)
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    const int ch = __builtin_amdgcn_readfirstlane(a.chan_list ? a.chan_list[slot] : slot);
+    const C *in = a.in + (long long)ch * a.in_stride;
+    const int g0_ = a.off - P + tile * L;
+    const bool interior = g0_ >= 0 && g0_ + N <= a.n_in;                  // workgroup-uniform
+    C *out = a.out + (long long)ch * a.out_stride + a.out_offset;
+    // where A' waits: the tile's own outputs rel 2048 + n (n < 4096) while all of them exist, the channel's scratch row otherwise
+    const bool whole = (long long)(tile + 1) * L <= (long long)a.n_out;
+    C *park = whole ? out + (long long)tile * L + 2048 : a.stash + (long long)ch * 4096;
+    // eight samples tile[n0 + 256 s]: plain loads inside the call's buffer, clamped history-aware ones at its ends (branch free)
+    auto load8_plain = [&](C (&v)[8], int g0, int n0) {
+        const C *p = in + g0 + n0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = p[256 * s];
+    };
+    auto load8_edge = [&](C (&v)[8], int g0, int n0) {
+        const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : in;
+        const int hlen = a.hist ? a.hist_len : 0, last = a.n_in - 1;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int gi = g0 + n0 + 256 * s;
+            const int ii = gi > last ? last : gi, ih = gi + hlen < 0 ? 0 : gi + hlen;
+            const bool now = gi >= 0, ok = now ? gi <= last : gi + hlen >= 0;
+            // (one address from selected parts: a select between two finished pointers became a branch around every load)
+            const unsigned long long base = now ? (unsigned long long)in : (unsigned long long)hist;
+            const C w = *reinterpret_cast<const C *>(base + (unsigned long long)(unsigned)(now ? ii : ih) * sizeof(C));
+            v[s] = make_double2(ok ? w.x : 0.0, ok ? w.y : 0.0);
+        }
+    };
+
+#pragma nounroll
+    for (int g = 0; g < 2; g++) {                                       // g = 0: sums, even bins; g = 1: differences, odd bins
+        C x[16];
+        const double sgn = g ? -1.0 : 1.0;
+        // (the two phases share this code: what depends on the lane or the tile alone is formed again in each -- hoisted out of the
+        // loop, three dozen addresses and flags would be carried through both transform pairs in registers the transforms need)
+        int j = j_, g0 = g0_;
+        asm volatile("" : "+v"(j));
+        asm volatile("" : "+s"(g0));
+        // ---- the tile's samples n = j + 256 s and n + 4096, eight at a time; one straight-line copy for the tiles inside the call's
+        // buffer and one for those at its ends (a branch around every batch of loads made the register allocator park the batches in
+        // scratch memory at the joins)
+        auto gather = [&](auto load8) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                // meter partials, layout 1 of meter_finish_kernel: 32 slots [wave][8] = chunks 32 + 4 s + wave (the upper samples of s < 8),
+                // then 64 slots [wave][16]: chunks 4 k + wave (the lower samples of s = 8 + k) and 64 + 4 k + wave (their upper ones)
+                double *blk = reinterpret_cast<double *>(smem8s) + (j >> 6) * kMeterLdsDoublesPerWave;
+                double2 *mdst = METER ? a.meter_in + (long long)ch * a.meter_stride + (long long)tile * (L >> 6) : nullptr;
+                C hi[8];
+                load8(hi, g0, j + 2048 * h + 4096);
+                if constexpr (METER) {
+                    if (g == 0) {
+                        if (h == 0) meter_tap<C, 8>(hi, 0, a.meter_w[j & 63], blk, mdst, j >> 6, j & 63, 8);
+                        else meter_tap<C, 8>(hi, 0, a.meter_w[j & 63], blk, mdst + 40, j >> 6, j & 63, 16);
+                    }
+                }
+                C lo[8];
+                load8(lo, g0, j + 2048 * h);
+                if constexpr (METER) {
+                    if (g == 0 && h == 1) meter_tap<C, 8>(lo, 0, a.meter_w[j & 63], blk, mdst + 32, j >> 6, j & 63, 16);
+                }
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                    x[8 * h + s] = make_double2(__builtin_fma(hi[s].x, sgn, lo[s].x), __builtin_fma(hi[s].y, sgn, lo[s].y));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (interior) gather(load8_plain); else gather(load8_edge);
+        const C wj = a.tw_r2[j];                                        // W^j, W = exp(-2 pi i / 8192)
+        if (g) {                                                        // b[n] = (x[n] - x[n + 4096]) W^n, W^n = W^j exp(-i pi s / 16)
+#pragma unroll
+            for (int s = 0; s < 16; s++) x[s] = cmul(x[s], wj);
+            x[1] = mul_wconst<32, 1, false>(x[1]); x[2] = mul_wconst<32, 2, false>(x[2]); x[3] = mul_wconst<32, 3, false>(x[3]);
+            x[4] = mul_wconst<32, 4, false>(x[4]); x[5] = mul_wconst<32, 5, false>(x[5]); x[6] = mul_wconst<32, 6, false>(x[6]);
+            x[7] = mul_wconst<32, 7, false>(x[7]); x[8] = mul_wconst<32, 8, false>(x[8]); x[9] = mul_wconst<32, 9, false>(x[9]);
+            x[10] = mul_wconst<32, 10, false>(x[10]); x[11] = mul_wconst<32, 11, false>(x[11]); x[12] = mul_wconst<32, 12, false>(x[12]);
+            x[13] = mul_wconst<32, 13, false>(x[13]); x[14] = mul_wconst<32, 14, false>(x[14]); x[15] = mul_wconst<32, 15, false>(x[15]);
+        }
+        if constexpr (METER) __syncthreads();                           // the transform's image overlays the waves' meter blocks
+        SF::run(x, smem8s, FftRR<4096, false, C>::load(a.tw_fwd));
+        const C *mask = a.mask + (long long)ch * a.mask_stride + 4096 * g;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            x[r] = cmul(x[r], mask[j + 256 * r]);
+            if ((r + 1) % QH_MASK_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        SI::run(x, smem8s, FftRR<4096, true, C>::load(a.tw_inv));
+        if (g == 0) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) park[j + 256 * s] = x[s];
+            __syncthreads();                                            // everybody has read the image: the next phase's taps overlay it
+        } else {
+            // W^-n B'[n], then the halves: lower outputs y[n] (n >= 2048: s >= 8), upper outputs y[n + 4096] (every s)
+            int j2 = j;
+            asm volatile("" : "+v"(j2));                                // (lane-derived values formed again behind the transforms, not carried)
+            const C wt = a.tw_r2[j2], wc = make_double2(wt.x, -wt.y);
+#pragma unroll
+            for (int s = 0; s < 16; s++) x[s] = cmul(x[s], wc);
+            x[1] = mul_wconst<32, 1, true>(x[1]); x[2] = mul_wconst<32, 2, true>(x[2]); x[3] = mul_wconst<32, 3, true>(x[3]);
+            x[4] = mul_wconst<32, 4, true>(x[4]); x[5] = mul_wconst<32, 5, true>(x[5]); x[6] = mul_wconst<32, 6, true>(x[6]);
+            x[7] = mul_wconst<32, 7, true>(x[7]); x[8] = mul_wconst<32, 8, true>(x[8]); x[9] = mul_wconst<32, 9, true>(x[9]);
+            x[10] = mul_wconst<32, 10, true>(x[10]); x[11] = mul_wconst<32, 11, true>(x[11]); x[12] = mul_wconst<32, 12, true>(x[12]);
+            x[13] = mul_wconst<32, 13, true>(x[13]); x[14] = mul_wconst<32, 14, true>(x[14]); x[15] = mul_wconst<32, 15, true>(x[15]);
+            if constexpr (METER) __syncthreads();                       // other waves may still be reading the exchange image
+            EpiParam ep;
+            if (a.epi) ep = a.epi[ch]; else { ep.a = 1; ep.b = 0; ep.c = 0; ep.d = 1; }
+            double *blk = reinterpret_cast<double *>(smem8s) + (j2 >> 6) * kMeterLdsDoublesPerWave;
+            double2 *mdst = METER ? a.meter_out + (long long)ch * a.meter_stride + (long long)tile * (L >> 6) : nullptr;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                C up[8], dn[8];
+#pragma unroll
+                for (int s = 0; s < 8; s++) up[s] = park[j2 + 2048 * h + 256 * s];
+#pragma unroll
+                for (int s = 0; s < 8; s++) { dn[s] = cadd(up[s], x[8 * h + s]); up[s] = csub(up[s], x[8 * h + s]); }
+                if constexpr (METER) {
+                    if (h == 0) meter_tap<C, 8>(up, 0, a.meter_w[j2 & 63], blk, mdst, j2 >> 6, j2 & 63, 8);
+                    else {
+                        meter_tap<C, 8>(dn, 0, a.meter_w[j2 & 63], blk, mdst + 32, j2 >> 6, j2 & 63, 16);
+                        meter_tap<C, 8>(up, 0, a.meter_w[j2 & 63], blk, mdst + 40, j2 >> 6, j2 & 63, 16);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int n = j2 + 2048 * h + 256 * s;
+                    const long long mu = (long long)tile * L + 2048 + n;        // y[n + 4096]: rel = n + 4096 - P
+                    if (mu < a.n_out) out[mu] = make_double2(ep.a * up[s].x + ep.b * up[s].y, ep.c * up[s].x + ep.d * up[s].y);
+                    if (h == 1) {                                               // y[n], n >= 2048: rel = n - P
+                        const long long md = (long long)tile * L + (n - 2048);
+                        if (md < a.n_out) out[md] = make_double2(ep.a * dn[s].x + ep.b * dn[s].y, ep.c * dn[s].x + ep.d * dn[s].y);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }

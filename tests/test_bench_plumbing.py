@@ -127,3 +127,35 @@ def test_a_failing_rank_fails_the_self_spawned_job():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "1",
                         "--warmup", "0", "--log2-samples", "12", "--total-channels", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0                 # rank 1 has no channel and says so
+
+
+def test_eight_ranks_of_configs_4_and_5(tmp_path):
+    """BASELINE configs 4 (2048 mixed-mode channels, 256 per GPU) and 5 (8 x 61.44 Msps, one channel per GPU) launch on N GPUs like
+    config 2 does (`--config`): eight gloo ranks each, every rank's channel range, kernel time and roofline on rank 0's line, the
+    timed region bracketed by barriers.  The strong form of config 4 (a fixed 256-channel job) too."""
+    for extra, per, total, scaling in ((["--config", "4"], 256, 2048, "weak"), (["--config", "5"], 1, 8, "weak"),
+                                       (["--config", "4", "--total-channels", "256"], 32, 256, "strong")):
+        trace = str(tmp_path / ("trace_%s_%s.txt" % (extra[1], scaling)))
+        j = _launch(8, extra, trace=trace)
+        assert j["n_gpus"] == 8 and j["scaling"] == scaling and j["dry_run"] is True
+        assert j["config"]["baseline_config"] == int(extra[1])
+        assert j["config"]["channels_per_gpu"] == per and j["config"]["total_channels"] == total
+        assert [p["rank"] for p in j["per_rank"]] == list(range(8))
+        assert [p["channels"] for p in j["per_rank"]] == [[per * k, per * (k + 1)] for k in range(8)]
+        assert all({"achieved", "peak", "frac", "unit", "kernel"} <= set(p["roofline"]) for p in j["per_rank"])
+        assert j["ms_per_step"] >= 8.0                    # rank 7's fake step takes 8 ms: max over ranks
+        want = total * 4096 * 4 / (j["ms_per_step"] * 4e-3) / 1e6
+        assert abs(j["value"] - want) < 1e-6 * want
+        assert {"bound", "achieved", "peak", "frac", "unit"} <= set(j["roofline"])
+        ev = _read_trace(trace)
+        warm = max(ev["warm_done"][r][0] for r in range(8))
+        start = min(ev["timed_start"][r][0] for r in range(8))
+        done = max(ev["steps_done"][r][0] for r in range(8))
+        end = min(ev["timed_end"][r][0] for r in range(8))
+        assert start >= warm - 1e-3 and end >= done - 1e-3
+
+
+def test_config_2_line_carries_every_ranks_roofline():
+    j = _launch(2, ["--channels", "8"])
+    assert all({"achieved", "peak", "unit", "kernel"} <= set(p["roofline"]) for p in j["per_rank"])
+    assert j["roofline"]["bound"] in ("hbm", "valu", "latency") and "bound_evidence" in j["roofline"]

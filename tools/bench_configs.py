@@ -94,24 +94,31 @@ def c4_common(eng, c, shift):
     eng.SetRXAAGCMode(c, 0); eng.SetRXAAGCFixed(c, 0.0)
 
 
-def setup_config4(torch, qh, dev, nch=256, nblk=None, modes_now=True):
+def setup_config4(torch, qh, dev, nch=256, nblk=None, modes_now=True, first=0):
     """modes_now=False (the parity test's acquisition form): every channel starts as USB 300..3000 and the caller switches the
-    detectors in with c4_set_modes once the filters hold signal."""
+    detectors in with c4_set_modes once the filters hold signal.  first: the job-wide index of this engine's channel 0 (a rank of
+    bench.py --config 4 --gpus N owns channels first .. first + nch - 1: mode, shift and signal go by the job-wide index)."""
     from quisk_amd import synth
     nblk = nblk or int(os.environ.get("QH_C4_NBLK", "4096"))       # DSP blocks per call: 2^22 input samples per channel per step (SURVEY.md 8(d))
     n_in = nblk * 1024
     L = SimpleNamespace(nch=nch, nblk=nblk, n_in=n_in, n_out=nblk * 256)
     L.stream = new_stream(torch, dev)
-    L.eng = eng = qh.RxaEngine(nch, stream=L.stream.cuda_stream)
-    for c in range(nch):
-        c4_common(eng, c, synth.shift_freq(c))
+    L.eng = eng = qh.RxaEngine(nch, device=dev.index or 0, stream=L.stream.cuda_stream)
+
+    class _Shifted:                     # c4_set_modes / c4_common take the channel index that decides the mode: the job-wide one
+        def __getattr__(self, name):
+            f = getattr(eng, name)
+            return lambda c, *a: f(c - first, *a)
+    view = _Shifted() if first else eng
+    for c in range(first, first + nch):
+        c4_common(view, c, synth.shift_freq(c))
         if modes_now:
-            c4_set_modes(eng, c)
+            c4_set_modes(view, c)
         else:
-            eng.SetRXAMode(c, 1); eng.RXASetPassband(c, 300.0, 3000.0)
+            view.SetRXAMode(c, 1); view.RXASetPassband(c, 300.0, 3000.0)
     # SURVEY.md 8(d) C4: USB channels get the two-tone input of C2, AM channels a carrier with m = 0.5 / 1 kHz, FM channels a
     # carrier with a 1 kHz tone at +-3 kHz deviation, all + noise (synth.make_mode_input_numpy)
-    L.x = synth.make_mode_input_torch([C4_KINDS[C4_MODES[c % 3]] for c in range(nch)], n_in, dev)
+    L.x = synth.make_mode_input_torch([C4_KINDS[C4_MODES[c % 3]] for c in range(first, first + nch)], n_in, dev, first_channel=first)
     L.y = torch.empty((nch, L.n_out), dtype=torch.complex128, device=dev)
     L.step = lambda: eng.process_ptr(L.x.data_ptr(), n_in, L.y.data_ptr(), L.n_out, nblk)
     torch.cuda.synchronize(dev)         # the inputs are made on torch's stream, the engines run on streams of their own
@@ -213,15 +220,16 @@ def setup_config5(torch, qh, dev, n=1 << 26, unfused=True):
     L = SimpleNamespace(n=n, taps245=tabs["quiskFilt240D5CoefsSharp"], bp=c5_bandpass_taps())
     L.stream = new_stream(torch, dev)           # one stream: every stage reads what the stage before it wrote
     s = L.stream.cuda_stream
-    L.d5 = d5 = qh.FirBank(1, L.taps245, 5, dtype=1, stream=s)
-    L.core = core = qh.FirBank(1, L.bp, 1, dtype=1, stream=s)
+    di = dev.index or 0
+    L.d5 = d5 = qh.FirBank(1, L.taps245, 5, dtype=1, device=di, stream=s)
+    L.core = core = qh.FirBank(1, L.bp, 1, dtype=1, device=di, stream=s)
     L.x = x = torch.randn((1, n), dtype=torch.float32, device=dev) + 1j * torch.randn((1, n), dtype=torch.float32, device=dev)
     L.bufs = bufs = [torch.empty((1, n >> (k + 1)), dtype=torch.complex64, device=dev) for k in (range(8) if unfused else (7,))]
     L.y5 = y5 = torch.empty((1, (n >> 8) // 5 + 8), dtype=torch.complex64, device=dev)
     L.yo = yo = torch.empty_like(y5)
-    L.casc = casc = qh.HalfBandCascade(1, 8, dtype=1, stream=s)
+    L.casc = casc = qh.HalfBandCascade(1, 8, dtype=1, device=di, stream=s)
     if unfused:
-        L.hb = hb = [qh.FirBank(1, qh.hb45_taps(), 2, dtype=1, stream=s) for _ in range(8)]
+        L.hb = hb = [qh.FirBank(1, qh.hb45_taps(), 2, dtype=1, device=di, stream=s) for _ in range(8)]
 
         def step():
             cur, cn = x, n
