@@ -446,6 +446,7 @@ qh_qrx *qh_qrx_create(int device, int nch, int sample_rate, int mode, const doub
 void qh_qrx_destroy(qh_qrx *r);
 int qh_qrx_filter_rate(const qh_qrx *r);                                   /* get_filter_rate, quisk.c:2787-2859 */
 int qh_qrx_set_tune(qh_qrx *r, int ch, int rx_tune_freq);                   /* set_tune, quisk.c:4702; ch -1 = all */
+int qh_qrx_set_tune_all(qh_qrx *r, const int *rx_tune_freq);                /* rx_tune_freq[nch]: every receiver's set_tune in ONE launch per table (bit-identical to nch calls) */
 int qh_qrx_set_filters(qh_qrx *r, int ch, const double *filtI, const double *filtQ, int size);  /* set_filters, quisk.c:4551 */
 int qh_qrx_out_count(const qh_qrx *r, int n_in);                            /* 48 ksps samples the next call returns */
 /* Every rate and mode of the path: the filters.h tables by name (the last six may be NULL when the sample rate
@@ -734,6 +735,7 @@ qh_qps *qh_qps_create(int device, int nch, int sample_rate, int playback_rate, i
                       int fft_size, int data_width, void *stream);
 void qh_qps_destroy(qh_qps *h);
 int qh_qps_set_tune(qh_qps *h, int ch, int rx_tune_freq);                  /* set_tune, quisk.c:4702; ch -1 = all */
+int qh_qps_set_tune_all(qh_qps *h, const int *rx_tune_freq);               /* rx_tune_freq[nch], one launch per table for the whole bank */
 int qh_qps_set_filters(qh_qps *h, int ch, const double *filtI, const double *filtQ, int size);     /* set_filters, quisk.c:4551 */
 int qh_qps_set_agc(qh_qps *h, double level);                               /* set_agc, quisk.c:4543 (agcReleaseGain, default 80) */
 int qh_qps_set_noise_blanker(qh_qps *h, int level);                        /* set_noise_blanker, quisk.c:4605 */

@@ -25,6 +25,25 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def _export_map(path):
+    """Linker version script: the C ABI of include/quiskhip.h and nothing else.  The library is loaded into other programs' processes
+    (Quisk's Python, anything that links filter.o's names): kernels' host stubs, C++ helpers and file-scope state stay local."""
+    import re
+    src = open(os.path.join(HERE, "..", "include", "quiskhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(n for n in re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src) if n != "defined"))
+    text = "{\n  global:\n" + "".join("    %s;\n" % n for n in names) + "  local: *;\n};\n"
+    try:
+        if open(path).read() == text:
+            return path
+    except OSError:
+        pass
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write(text)
+    return path
+
+
 def _deps(src):
     """Headers a source includes (transitively, by name), so that a header edit rebuilds only the units that see it."""
     seen, todo = set(), [os.path.join(CSRC, src)]
@@ -53,7 +72,8 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     extra = ["-D" + d for d in defines] + os.environ.get("QH_HIPCC_FLAGS", "").split()
     os.makedirs(os.path.dirname(target), exist_ok=True)
     if out:
-        cmd = base + ["-shared", "-o", target] + extra + [os.path.join(CSRC, f) for f in SOURCES]
+        vmap = _export_map(os.path.join(os.path.dirname(target), "quiskhip.map"))
+        cmd = base + ["-shared", "-Wl,--version-script=" + vmap, "-o", target] + extra + [os.path.join(CSRC, f) for f in SOURCES]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
@@ -88,7 +108,8 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
             stale = any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, src)] + [d for d in _deps(src) if os.path.exists(d)])
         if stale:
             todo.append((src, obj))
-    if not todo and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+    hdr = os.path.join(HERE, "..", "include", "quiskhip.h")
+    if not todo and os.path.exists(LIB) and all(os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs + [hdr]):
         return LIB
     jobs = jobs or min(4, os.cpu_count() or 1)
     running = []
@@ -114,7 +135,8 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
         running.append((subprocess.Popen(cmd), src))
     while running:
         reap(True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    vmap = _export_map(os.path.join(objdir, "quiskhip.map"))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vmap, "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -163,6 +163,7 @@ struct Engine {
     int bnfft = kNfft;                      // tile size of the fircore stages: what their masks are built for (4096 or 8192)
     bool band2g = false;                    // 8192-point tiles shared by two lane groups (osfir8k_kernel): masks stored [even | odd]
     bool band6k = false;                    // 6144-point tiles on 384 lanes (osfir6k_kernel)
+    int dbg_forms = [] { const char *e = std::getenv("QH_DBG_FORMS"); return e ? std::atoi(e) : 0; }();   // see process_chain
     int band_tile_pref = 0;                 // qh_rxa_set_band_tile: 0 / 4096: 4096-point tiles, 8192: the two-group tiles
     double2 *band_stash = nullptr;          // osfir8s_kernel: [nch][4096], where the tile cut short by the end of a call parks A'
     std::vector<cd> band_mask(const std::vector<cd> &h) const;
@@ -2028,9 +2029,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // the FM channels' front and nbp0 stages are launched first and their detector chain follows on the main stream; the other
     // channels' front, nbp0 and AM detectors run beside it on a second stream (fork / join by events, which a launch-sequence
     // capture records as graph edges).  BASELINE config 4: 1.20 -> 0.8 ms per call.
-    // QH_DBG_FORMS (diagnostics, tools/dbg/determinism_stress.py): bit 0 no second stream for the filters, 1 no stores straight to the
-    // caller's rows, 2 no envelope in nbp0's store, 3 no angles in nbp0's store, 4 no paired real filters, 5 no second stream at all
-    static const int dbg_forms = [] { const char *e = std::getenv("QH_DBG_FORMS"); return e ? std::atoi(e) : 0; }();
+    // dbg_forms (QH_DBG_FORMS in the environment when the engine is made; diagnostics: tools/dbg/determinism_stress2.py and the failure
+    // branch of tests/test_gpu_properties_fullsize.py): bit 0 no second stream for the filters, 1 no stores straight to the caller's rows,
+    // 2 no envelope in nbp0's store, 3 no angles in nbp0's store, 4 no paired real filters, 5 no second stream at all
     const bool split = n_fm > 0 && n_rest > 0 && D > 1 && !meters_on && !n_amsq && !n_snb[0] && !timing && !(dbg_forms & 1);
     // ... and when nothing sits between a channel's last filter and the output matrix (no AGC state machine, LMS, EMNR, SNBA,
     // limiter, squelch or position-1 stage anywhere), that last stage -- nbp0 for the plain channels, bp1 for AM / SAM, the CTCSS

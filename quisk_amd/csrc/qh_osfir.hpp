@@ -162,7 +162,10 @@ __device__ __forceinline__ void xcd_tile_map(int ntiles, int &chan_slot, int &ti
 // dynamic LDS of the two kernels below
 template <typename T, int NFFT, int D, bool METER = false> constexpr int osfir_lds_bytes()
 {
-    constexpr int a = TileFft<NFFT, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT / D, true, cplx<T>>::kLdsBytes;
+    // (QH_FRONT_HALF_IMAGE: the polyphase forward transform of the fp64 decimating tiles needs half an image; every kernel with D > 1,
+    // fp64 and 4096 points that is launched with this size runs that form)
+    constexpr bool half = QH_FRONT_HALF_IMAGE && sizeof(T) == 8 && NFFT == 4096 && D > 1;
+    constexpr int a = half ? FftSplit4096<false, cplx<T>>::kHalfLdsBytes : TileFft<NFFT, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT / D, true, cplx<T>>::kLdsBytes;
     constexpr int m = METER ? NT / 64 * 2 * 64 * 9 * 8 : 0;        // the meter taps' per-wave blocks overlay the image (kMeterLdsDoublesPerWave)
     return (a > b ? a : b) > m ? (a > b ? a : b) : m;
 }

@@ -200,6 +200,7 @@ void qh_qps_destroy(qh_qps *h) { delete h; }
 #define QPS_ENTER(h) if (!(h)) return set_error(QH_ERR_INVALID, "null receiver bank"); std::lock_guard<std::mutex> lk((h)->mtx); QH_HIP(hipSetDevice((h)->device))
 
 int qh_qps_set_tune(qh_qps *h, int ch, int rx_tune_freq) { QPS_ENTER(h); return qh_qrx_set_tune(h->rx, ch, rx_tune_freq); }                 // set_tune, quisk.c:4702
+int qh_qps_set_tune_all(qh_qps *h, const int *rx_tune_freq) { QPS_ENTER(h); return qh_qrx_set_tune_all(h->rx, rx_tune_freq); }              // the bank's set_tune in one launch
 int qh_qps_set_filters(qh_qps *h, int ch, const double *filtI, const double *filtQ, int size)                                                // set_filters, quisk.c:4551
 {
     QPS_ENTER(h);

@@ -554,6 +554,17 @@ int qh_qrx_set_tune(qh_qrx *h, int ch, int rx_tune_freq)
     return QH_OK;
 }
 
+// set_tune for every receiver of the bank at once: rx_tune_freq[nch] (Hz), one launch per table instead of one per receiver
+int qh_qrx_set_tune_all(qh_qrx *h, const int *rx_tune_freq)
+{
+    QH_QRX_LOCK(h);
+    if (!h || !rx_tune_freq) return set_error(QH_ERR_INVALID, "qh_qrx_set_tune_all: bad arguments");
+    Qrx &q = h->q;
+    std::vector<double> f((size_t)q.nch);
+    for (int c = 0; c < q.nch; c++) f[(size_t)c] = -(double)rx_tune_freq[c];
+    return q.steps[0].st->set_nco_all(f.data(), (double)q.sample_rate);
+}
+
 // set_filters (quisk.c:4551): taps as MakeFilterCoef designs them.  cRxFilterOut's ring walk (quisk.c:1246-1253)
 // pairs tap 0 with the newest sample and taps 1..N-1 with the oldest..second newest: as a convolution
 // g[0] = h[0], g[d] = h[N-d].  SSB/CW keep re -+ im = Re{(gI +- j gQ) * x}; AM/FM use filtI on both parts.

@@ -131,7 +131,7 @@ struct Stage {
             QH_HIP(dev_alloc(&lane_rot, (size_t)nch * NT));
             QH_HIP(dev_alloc(&out_step, (size_t)nch));
             QH_HIP(dev_alloc(&d_list, (size_t)nch));
-            QH_HIP(dev_alloc(&d_law, (size_t)2));
+            QH_HIP(dev_alloc(&d_law, (size_t)2 * (size_t)nch));        // (action, new step) per channel: one retune of the whole bank is one launch
             std::vector<int> all((size_t)nch);
             for (int c = 0; c < nch; c++) all[(size_t)c] = c;
             QH_HIP(hipMemcpyAsync(d_list, all.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -253,6 +253,38 @@ struct Stage {
         }
         QH_HIP(hipMemcpyAsync(nco_dphase + ch, &d, 8, hipMemcpyHostToDevice, stream));
         QH_HIP(hipStreamSynchronize(stream));
+        return QH_OK;
+    }
+
+    // Every channel's NCO in one go: freq[nch].  The same arithmetic as set_nco channel by channel (bit-identical tables), but one
+    // upload per array, ONE nco_retune_hist_kernel grid and ONE front_mask_kernel grid over the bank instead of a launch and two
+    // stream synchronisations per receiver (a 256-receiver bank: 2 x 256 launches and ~95 ms, profiles/r04_j_quisk_kernel_stats.csv).
+    int set_nco_all(const double *freq, double rate)
+    {
+        if (!mix) return set_error(QH_ERR_INVALID, "stage has no NCO");
+        QH_HIP(hipSetDevice(device));
+        std::vector<unsigned long long> d((size_t)nch), law((size_t)2 * (size_t)nch);
+        std::vector<double2> st((size_t)nch);
+        for (int c = 0; c < nch; c++) {
+            long double t = (long double)freq[c] / (long double)rate;
+            t -= floorl(t);
+            long double sc = t * 18446744073709551616.0L;
+            d[(size_t)c] = sc >= 18446744073709551616.0L ? 0ull : (unsigned long long)sc;
+            long double ang = 2.0L * 3.14159265358979323846264338327950288L * ((long double)(d[(size_t)c] * (unsigned long long)NT) / 18446744073709551616.0L);
+            st[(size_t)c] = make_double2((double)cosl(ang), (double)sinl(ang));
+            law[(size_t)2 * c] = 0ull; law[(size_t)2 * c + 1] = d[(size_t)c];
+        }
+        QH_HIP(hipMemcpyAsync(nco_step, st.data(), (size_t)nch * 16, hipMemcpyHostToDevice, stream));
+        if (outmix) {
+            QH_HIP(hipMemcpyAsync(d_law, law.data(), law.size() * 8, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(nco_retune_hist_kernel, dim3((unsigned)((hist_len + NT - 1) / NT), (unsigned)nch), dim3(NT), 0, stream,
+                               static_cast<double2 *>(hist[cur]), hist_len, (const unsigned long long *)nco_phase,
+                               (const unsigned long long *)nco_dphase, (const unsigned long long *)nullptr, (const int *)d_list,
+                               (const unsigned long long *)d_law);
+        }
+        QH_HIP(hipMemcpyAsync(nco_dphase, d.data(), (size_t)nch * 8, hipMemcpyHostToDevice, stream));
+        QH_HIP(hipStreamSynchronize(stream));               // (the host vectors above are pageable)
+        if (outmix && taps_set) return build_outmix_tables(0, nch);
         return QH_OK;
     }
 

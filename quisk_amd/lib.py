@@ -282,6 +282,7 @@ def load():
     L.qh_qps_destroy.argtypes = [vp]
     L.qh_qps_destroy.restype = None
     L.qh_qps_set_tune.argtypes = [vp, i, i]
+    L.qh_qps_set_tune_all.argtypes = [vp, vp]
     L.qh_qps_set_filters.argtypes = [vp, i, vp, vp, i]
     L.qh_qps_set_agc.argtypes = [vp, d]
     for n in ("qh_qps_set_noise_blanker", "qh_qps_invert_spectrum", "qh_qps_set_kill_audio", "qh_qps_add_tone", "qh_qps_set_pieces", "qh_qps_set_pipelined"):
@@ -304,6 +305,7 @@ def load():
     L.qh_qrx_destroy.restype = None
     L.qh_qrx_filter_rate.argtypes = [vp]
     L.qh_qrx_set_tune.argtypes = [vp, i, i]
+    L.qh_qrx_set_tune_all.argtypes = [vp, vp]
     L.qh_qrx_set_filters.argtypes = [vp, i, vp, vp, i]
     L.qh_qrx_out_count.argtypes = [vp, i]
     L.qh_qrx_process.argtypes = [vp, vp, ll, i, vp, ll, C.POINTER(i)]

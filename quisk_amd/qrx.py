@@ -45,6 +45,12 @@ class QuiskRxBank:
     def set_tune(self, ch, rx_tune_freq):
         check(self._L.qh_qrx_set_tune(self._h, ch, int(rx_tune_freq)))
 
+    def set_tune_all(self, rx_tune_freqs):
+        """every receiver's set_tune (quisk.c:4702) in one launch per table: rx_tune_freqs[nch] Hz"""
+        f = np.ascontiguousarray(rx_tune_freqs, dtype=np.int32)
+        assert f.size == self.nch
+        check(self._L.qh_qrx_set_tune_all(self._h, f.ctypes.data))
+
     def set_filters(self, ch, filtI, filtQ):
         fI = np.ascontiguousarray(filtI, dtype=np.float64)
         fQ = np.ascontiguousarray(filtQ, dtype=np.float64)
@@ -125,6 +131,12 @@ class QuiskProcessBank:
 
     def set_tune(self, ch, rx_tune_freq):
         check(self._L.qh_qps_set_tune(self._h, ch, int(rx_tune_freq)))
+
+    def set_tune_all(self, rx_tune_freqs):
+        """every receiver's set_tune in one launch per table: rx_tune_freqs[nch] Hz"""
+        f = np.ascontiguousarray(rx_tune_freqs, dtype=np.int32)
+        assert f.size == self.nch
+        check(self._L.qh_qps_set_tune_all(self._h, f.ctypes.data))
 
     def set_filters(self, ch, filtI, filtQ):
         fI = np.ascontiguousarray(filtI, dtype=np.float64)

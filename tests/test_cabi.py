@@ -24,6 +24,22 @@ def test_header_symbols_are_exported(qh):
     assert not missing, missing
 
 
+def test_nothing_but_the_header_is_exported(qh):
+    """The library is loaded into other programs' processes (Quisk's Python process binds it as wdsp/libwdsp.so, C programs link
+    filter.o's names): what `nm -D` shows must be include/quiskhip.h and nothing else -- no kernel stubs, no C++ helpers, no
+    file-scope state (round 4 leaked g_shim, g_disp, shim_side, a kernel stub ...).  quisk_amd/build.py links with an export
+    map made from the header."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or shutil.which("llvm-nm") or ("/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else None)
+    if not nm:
+        pytest.skip("no nm")
+    out = subprocess.run([nm, "-D", "--defined-only", qh.load()._name], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()))
+    extra = [n for n in exported if n not in set(declared_functions())]
+    assert not extra, extra[:20]
+
+
 def test_no_device_is_an_error_not_a_fallback(qh):
     lib = qh.load()
     if lib.qh_device_count() > 0:

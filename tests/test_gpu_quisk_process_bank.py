@@ -231,3 +231,46 @@ def test_pipelined_calls_whose_piece_layout_changes(qh):
             bank.close()
         assert ys[0].shape == ys[1].shape and float(ys[0].abs().max()) > 2.0 ** 20
         assert torch.equal(ys[0], ys[1]), (fs, float((ys[0] - ys[1]).abs().max()))
+
+
+def test_set_tune_all_is_the_per_receiver_setter_in_one_launch(qh):
+    """qh_qps_set_tune_all / qh_qrx_set_tune_all: every receiver's set_tune (quisk.c:4702) with one launch per table for the whole bank
+    instead of one per receiver (round 4's trace: 2 x 256 launches and ~95 ms to tune 256 receivers).  The same arithmetic per
+    receiver: two banks, one tuned receiver by receiver and one tuned at once, give the same bits -- at the start of the stream and
+    when every receiver is retuned in mid-stream (the raw history is re-expressed for the new phase law in both forms)."""
+    for mode, fs, play in ((3, 192000, 48000), (5, 96000, 48000)):
+        nch, n = 7, 1 << 14
+        filt = _filters(mode, fs)
+        x = np.stack([_signal(mode, c, 3 * n, fs, 6000.0 + 700 * c, amp=2.0 ** 18) for c in range(nch)])
+        tunes = [[6000 + 700 * c for c in range(nch)], [-9000 + 1100 * c for c in range(nch)], [6000 + 700 * c for c in range(nch)]]
+        outs = []
+        for at_once in (False, True):
+            bank = qh.QuiskProcessBank(nch, fs, mode, BW[mode], playback_rate=play)
+            bank.set_filters(-1, *filt)
+            ys = []
+            for k in range(3):
+                if at_once:
+                    bank.set_tune_all(tunes[k])
+                else:
+                    for c in range(nch):
+                        bank.set_tune(c, tunes[k][c])
+                ys.append(bank.process_host(np.ascontiguousarray(x[:, k * n:(k + 1) * n])))
+            outs.append(np.concatenate(ys, axis=1))
+            bank.close()
+        assert outs[0].shape == outs[1].shape and np.abs(outs[0]).max() > 2.0 ** 10
+        assert np.array_equal(outs[0].view(np.float64), outs[1].view(np.float64)), (mode, np.abs(outs[0] - outs[1]).max())
+    # the receiver bank alone (qh_qrx_*)
+    nch, n, fs, mode = 5, 1 << 14, 192000, 3
+    x = np.stack([_signal(mode, c, n, fs, 5000.0 + 900 * c, amp=2.0 ** 18) for c in range(nch)])
+    outs = []
+    for at_once in (False, True):
+        bank = qh.QuiskRxBank(nch, fs, mode, BW[mode])
+        bank.set_filters(-1, *_filters(mode, fs))
+        if at_once:
+            bank.set_tune_all([5000 + 900 * c for c in range(nch)])
+        else:
+            for c in range(nch):
+                bank.set_tune(c, 5000 + 900 * c)
+        outs.append(bank.process_host(x))
+        bank.close()
+    assert np.array_equal(outs[0].view(np.float64), outs[1].view(np.float64))

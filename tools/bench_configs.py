@@ -308,8 +308,7 @@ def setup_quisk_native(torch, qh, dev, name, nch=256, n=1 << 20, whole=True, nb=
         L.bank = bank = qh.QuiskRxBank(nch, fs, mode, bw, stream=L.stream.cuda_stream)
     L.rate = bank.get_filter_rate()
     L.fI, L.fQ = rxfilter.make_filter_coef(L.rate, None, bw, rxfilter.get_filter_center(name, bw))
-    for c in range(nch):
-        bank.set_tune(c, qn_tune(c))
+    bank.set_tune_all([qn_tune(c) for c in range(nch)])        # one launch per table for the whole bank (qh_qps_set_tune_all)
     bank.set_filters(-1, L.fI, L.fQ)
     L.x = (torch.randn((nch, n), dtype=torch.float64, device=dev) + 1j * torch.randn((nch, n), dtype=torch.float64, device=dev)) * 2.0 ** 22
     L.m = bank.out_capacity(n) if whole else bank.out_count(n) + 64
