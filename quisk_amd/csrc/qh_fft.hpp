@@ -299,11 +299,6 @@ template <bool INV, typename C> struct FftRR<4096, INV, C> {
 #ifndef QH_SPLIT_SWIZZLE
 #define QH_SPLIT_SWIZZLE 0
 #endif
-// QH_FRONT_HALF_IMAGE = 1: the decimating fp64 tiles (polyphase forward transform) exchange through half an image (18 KB), so that five
-// workgroups fit a CU -- with QH_OSFIR_WAVES_F64_OUTMIX = 5 (96 registers).  See FftSplit4096::exchange_half.
-#ifndef QH_FRONT_HALF_IMAGE
-#define QH_FRONT_HALF_IMAGE 0
-#endif
 constexpr int split4096_lds_bytes(int scalar_bytes) { return (QH_SPLIT_SWIZZLE ? 4096 : 4096 + QH_SPLIT_PAD * 256) * scalar_bytes; }
 template <bool INV, typename C> struct FftSplit4096 {
     using T = decltype(C{}.x);
@@ -351,64 +346,6 @@ template <bool INV, typename C> struct FftSplit4096 {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r].y = rp[r * RS];
-    }
-
-    // The same exchange through HALF an image (2048 scalars + padding = 18 KB in fp64): elements e < 2048 first -- written by lanes
-    // 0 .. 127 (both exchanges: e / 2048 = j / 128), read by every lane into its registers 0 .. 7 -- then the upper half.  Twice the
-    // barriers, the same LDS instructions; five or more workgroups fit a CU where the whole image lets four (QH_FRONT_HALF_IMAGE).
-    static constexpr int kHalfLdsBytes = (2048 + 128 * kPad) * (int)sizeof(T);
-    template <int WS, int RS>
-    static __device__ __forceinline__ void exchange_half(C (&x)[16], T *lds, int wbase_local, int rbase, int j)
-    {
-        T *wp = lds + wbase_local;              // the writer's address inside ITS half
-        const T *rp = lds + rbase;
-        const bool up = (j >> 7) != 0;          // wave-uniform
-#pragma unroll
-        for (int part = 0; part < 2; part++) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (up == (h != 0)) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) wp[r * WS] = part ? x[r].y : x[r].x;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 8; r++) { if (part) x[8 * h + r].y = rp[r * RS]; else x[8 * h + r].x = rp[r * RS]; }
-                if (!(part == 1 && h == 1)) __syncthreads();
-            }
-        }
-    }
-    template <int D>
-    static __device__ __forceinline__ void run_poly_half(C (&x)[16], void *lds_raw, const Tw &t)
-    {
-        static_assert(!INV && (D == 2 || D == 4 || D == 8) && !kSwizzle, "forward transform of a decimating stage");
-        constexpr int R3 = 16 / D;
-        const int j = threadIdx.x, jl = j & 127;
-        T *lds = reinterpret_cast<T *>(lds_raw);
-        Dft<16, INV, C>::run(x);
-        exchange_half<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * jl, sphys(j), j);
-        const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);      // outputs at base + 16 r, base = 256 (j >> 4) + (j & 15)
-        __syncthreads();
-        exchange_half<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base & 2047), sphys(j), j);
-        C w[R3];
-        w[1] = t.b;
-#pragma unroll
-        for (int s = 1; s < D; s <<= 1) w[1] = cmul(w[1], w[1]);
-#pragma unroll
-        for (int r = 2; r < R3; r++) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r / 2], w[r / 2]);
-        C y[16];
-#pragma unroll
-        for (int a = 0; a < D; a++) {
-            C b[R3];
-            b[0] = x[a];
-#pragma unroll
-            for (int r = 1; r < R3; r++) b[r] = cmul(x[a + D * r], w[r]);
-            Dft<R3, INV, C>::run(b);
-#pragma unroll
-            for (int r = 0; r < R3; r++) y[r + R3 * a] = b[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = y[r];
     }
 
     static __device__ __forceinline__ void run(C (&x)[16], void *lds_raw, const Tw &t) { run_at(x, lds_raw, t, threadIdx.x); }
@@ -644,11 +581,7 @@ template <int N, bool INV, typename C> struct TileFft {
     template <int D> static __device__ __forceinline__ void run_poly(C (&x)[N / NT], void *lds, const Tw &t)
     {
         static_assert(kSplit, "polyphase plan: the fp64 4096-point transform");
-#if QH_FRONT_HALF_IMAGE
-        FftSplit4096<INV, C>::template run_poly_half<D>(x, lds, t);
-#else
         FftSplit4096<INV, C>::template run_poly<D>(x, lds, t);
-#endif
     }
 };
 

@@ -162,10 +162,7 @@ __device__ __forceinline__ void xcd_tile_map(int ntiles, int &chan_slot, int &ti
 // dynamic LDS of the two kernels below
 template <typename T, int NFFT, int D, bool METER = false> constexpr int osfir_lds_bytes()
 {
-    // (QH_FRONT_HALF_IMAGE: the polyphase forward transform of the fp64 decimating tiles needs half an image; every kernel with D > 1,
-    // fp64 and 4096 points that is launched with this size runs that form)
-    constexpr bool half = QH_FRONT_HALF_IMAGE && sizeof(T) == 8 && NFFT == 4096 && D > 1;
-    constexpr int a = half ? FftSplit4096<false, cplx<T>>::kHalfLdsBytes : TileFft<NFFT, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT / D, true, cplx<T>>::kLdsBytes;
+    constexpr int a = TileFft<NFFT, false, cplx<T>>::kLdsBytes, b = TileFft<NFFT / D, true, cplx<T>>::kLdsBytes;
     constexpr int m = METER ? NT / 64 * 2 * 64 * 9 * 8 : 0;        // the meter taps' per-wave blocks overlay the image (kMeterLdsDoublesPerWave)
     return (a > b ? a : b) > m ? (a > b ? a : b) : m;
 }
@@ -184,11 +181,6 @@ template <typename T, int NFFT, int U> constexpr int osfir_interp_lds_bytes()
 // (3.41 -> 2.77 ms), the decimating ones are best at three (128 VGPRs cost them 14 spills).
 #ifndef QH_MASK_BATCH
 #define QH_MASK_BATCH 8
-#endif
-// QH_MASK_PREFETCH = K > 0: the first K mask values of a decimating tile are asked for ahead of the forward transform and ride through it
-// in registers, so that the fold does not begin with a round trip to L2
-#ifndef QH_MASK_PREFETCH
-#define QH_MASK_PREFETCH 0
 #endif
 #ifndef QH_OSFIR_WAVES_F64_D1
 #define QH_OSFIR_WAVES_F64_D1 4
@@ -390,26 +382,18 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
 
     // ---- forward FFT, registers -> registers
     QH_OPROBE(1);
-    const C *mask = a.mask + (long long)ch * a.mask_stride;
-    constexpr int KPRE = (D > 1 && QH_MASK_PREFETCH > 0) ? (QH_MASK_PREFETCH < E ? QH_MASK_PREFETCH : E) : 0;      // in fold order: (i, q) = (k / D, k % D)
-    C mpre[KPRE > 0 ? KPRE : 1];
-    if constexpr (KPRE > 0) {
-#pragma unroll
-        for (int k = 0; k < KPRE; k++) mpre[k] = mask[t + NT * (k / D + EO * (k % D))];
-        __builtin_amdgcn_sched_barrier(0);
-    }
     if constexpr (POLY) Fwd::template run_poly<D>(x, lds, Fwd::load(a.tw_fwd));
     else Fwd::run(x, lds, Fwd::load(a.tw_fwd));
     QH_OPROBE(2);
 
     // ---- mask multiply + D-fold: lane holds bins t + NT*i; bins t + NT*(i' + EO*q) alias to t + NT*i'
+    const C *mask = a.mask + (long long)ch * a.mask_stride;
     C z[EO];
 #pragma unroll
     for (int i = 0; i < EO; i++) {
-        auto mval = [&](int q) -> C { const int k = i * D + q; if constexpr (KPRE > 0) { if (k < KPRE) return mpre[k]; } return mask[t + NT * (i + EO * q)]; };
-        C acc = cmul(x[i], mval(0));
+        C acc = cmul(x[i], mask[t + NT * i]);
 #pragma unroll
-        for (int q = 1; q < D; q++) acc = cadd(acc, cmul(x[i + EO * q], mval(q)));
+        for (int q = 1; q < D; q++) acc = cadd(acc, cmul(x[i + EO * q], mask[t + NT * (i + EO * q)]));
         z[i] = acc;
         // at most QH_MASK_BATCH mask values in flight: all 16 at once cost the D = 1 kernel its spills (A/B: +0.8 %)
         if (((i + 1) * D) % QH_MASK_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
