@@ -70,6 +70,10 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     target = out or LIB
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "hip"]
     extra = ["-D" + d for d in defines] + os.environ.get("QH_HIPCC_FLAGS", "").split()
+    if extra and not out:
+        # (the shipped library is kept when it is newer than its sources, whatever it was compiled with: an experiment build that
+        # overwrote or silently reused it would measure the wrong thing)
+        raise ValueError("quisk_amd.build: -D overrides / QH_HIPCC_FLAGS make an experiment build: pass out=<another file> (tools/ab_bench.py)")
     os.makedirs(os.path.dirname(target), exist_ok=True)
     if out:
         vmap = _export_map(os.path.join(os.path.dirname(target), "quiskhip.map"))

@@ -144,15 +144,30 @@ template <int R, typename C> __device__ __forceinline__ void apply_twiddle_power
     }
 }
 
+// The same with three powers live instead of R/2 + 1: w^2 by squaring, then the even and the odd powers as two chains w^(r+2) = w^r w^2
+// (depth R/2, i.e. about R/2 roundings in the last power instead of log2 R -- 8e-16 for R = 16).  For kernels whose registers are full
+// of something else (pan16k_kernel: the |X| sums of a block range ride through the transform): 28 registers fewer for R = 16.
+template <int R, typename C> __device__ __forceinline__ void apply_twiddle_powers_lean(C (&x)[R], C w1)
+{
+    const C w2 = cmul(w1, w1);
+    C we = w2, wo = w1;
+    x[1] = cmul(x[1], wo);
+#pragma unroll
+    for (int r = 2; r < R; r++) {
+        if (r & 1) { wo = cmul(wo, w2); x[r] = cmul(x[r], wo); }
+        else { x[r] = cmul(x[r], we); if (r + 2 < R) we = cmul(we, w2); }
+    }
+}
+
 // One Stockham pass of radix R over N points for butterfly j, data in registers x[r] = in[j + r*N/R].
 // Applies the inter-pass twiddle w1 = exp(-+2*pi*i*k/(Ns*R)), k = j mod Ns (Ns = product of the radices of
 // the earlier passes), then the R-point DFT, and returns the output position of x[0]; x[r] belongs at
 // base + r*Ns.  w1 depends on the lane only, so callers load it once per kernel (pass_twiddle below).
-template <int N, int R, int Ns, bool INV, typename C>
+template <int N, int R, int Ns, bool INV, typename C, bool LEAN = false>
 __device__ __forceinline__ int stockham_butterfly(C (&x)[R], int j, C w1)
 {
     int k = j & (Ns - 1);
-    if constexpr (Ns > 1) apply_twiddle_powers<R>(x, w1);
+    if constexpr (Ns > 1) { if constexpr (LEAN) apply_twiddle_powers_lean<R>(x, w1); else apply_twiddle_powers<R>(x, w1); }
     Dft<R, INV, C>::run(x);
     return (j - k) * R + k;
 }
@@ -351,6 +366,8 @@ template <bool INV, typename C> struct FftSplit4096 {
     static __device__ __forceinline__ void run(C (&x)[16], void *lds_raw, const Tw &t) { run_at(x, lds_raw, t, threadIdx.x); }
     // the same for thread j of a 256-thread group inside a larger workgroup (the barriers are the workgroup's: every group of
     // the workgroup must run its transform at the same time)
+    // LEAN: the inter-pass twiddle powers as two chains (apply_twiddle_powers_lean), for callers short of registers
+    template <bool LEAN = false>
     static __device__ __forceinline__ void run_at(C (&x)[16], void *lds_raw, const Tw &t, int j)
     {
         T *lds = reinterpret_cast<T *>(lds_raw);
@@ -358,11 +375,11 @@ template <bool INV, typename C> struct FftSplit4096 {
         // element j*16 + r  ->  j + 256 r'   (sphys: 18 j + r, and sphys(j) + 288 r')
         if constexpr (kSwizzle) exchange_sw<1>(x, lds, j, 0);
         else exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
-        const int base = stockham_butterfly<4096, 16, 16, INV>(x, j, t.a[0]);      // pass 2: outputs at base + 16 r
+        const int base = stockham_butterfly<4096, 16, 16, INV, C, LEAN>(x, j, t.a[0]);      // pass 2: outputs at base + 16 r
         __syncthreads();
         if constexpr (kSwizzle) exchange_sw<2>(x, lds, j, base);
         else exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
-        stockham_butterfly<4096, 16, 256, INV>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
+        stockham_butterfly<4096, 16, 256, INV, C, LEAN>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
     }
 
     // The transform WITHOUT the stage that would combine the D decimated sequences x[D m + a] (plan 16 x 16 x 16/D x [D], the last

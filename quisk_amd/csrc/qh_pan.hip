@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
     const int per = (nblk + nsplit - 1) / nsplit;
     const int b0 = split * per, b1 = b0 + per < nblk ? b0 + per : nblk;
     const typename S::Tw twf = FftRR<M, false, C>::load_at(tw, t);
-    double *xch = reinterpret_cast<double *>(smem);                     // exchange area [group][i][t] scalars
     void *image = smem + (size_t)s * S::kLdsBytes;                      // this group's transform image
     // e_j = exp(-2 pi i m_j / N), m_j = t + 256 (MJ s + j): e_0 and a step of 256
     C e0, estep;
@@ -232,65 +231,61 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
     for (int i = 0; i < E; i++) racc[i] = 0.0;
     for (int blk = b0; blk < b1; blk++) {
         const C *x = in + (long long)ch * in_stride + (long long)blk * N + (t + 256 * MJ * s);
-        double oim[16];                     // imaginary parts of this thread's sixteen results, [j][group]: they travel second
-        double *xw = xch + (MJ * s) * 256 + t;                              // + (group * 16 + j) * 256
-        const double *xr = xch + (s * 16) * 256 + t;                        // + i * 256
+        // The sixteen results of a thread change hands in TWO rounds of eight, real and imaginary part together (128-bit accesses):
+        // round h takes j = h MJ/2 .. h MJ/2 + MJ/2 - 1.  [group][ii = (MJ/2) s + jj][t] complex, laid over the transform images.  (Round
+        // 4's form sent all sixteen real parts, then all sixteen imaginary parts, and carried the imaginary parts through the first
+        // pass in 32 registers of a kernel that spills.)
+        C *xc = reinterpret_cast<C *>(smem);
         C e = e0;
         asm volatile("" : "+v"(e.x), "+v"(e.y));
-        PAN_STAMP(6);
-        __syncthreads();                    // the images are free: the previous block's transform has been read out
-        PAN_STAMP(0);
-#pragma unroll
-        for (int j = 0; j < MJ; j++) {
-            const C x0 = x[256 * j], x1 = x[256 * j + M], x2 = x[256 * j + 2 * M], x3 = x[256 * j + 3 * M];
-            // Hanning window 0.5 - 0.5 cos(2 pi n / N) at n = m + M q (quisk.c:6008): cos(a + pi q / 2) = cos a, -sin a, -cos a, sin a
-            // with e = (cos a, -sin a)
-            const double g0 = __builtin_fma(-0.5, e.x, 0.5), g2 = __builtin_fma(0.5, e.x, 0.5);
-            const double g1 = __builtin_fma(-0.5, e.y, 0.5), g3 = __builtin_fma(0.5, e.y, 0.5);
-            const C v0 = mk<double>(x0.x * g0, x0.y * g0), v1 = mk<double>(x1.x * g1, x1.y * g1);
-            const C v2 = mk<double>(x2.x * g2, x2.y * g2), v3 = mk<double>(x3.x * g3, x3.y * g3);
-            // sum_q W_4^(q r) v_q, r = 0 .. 3 (W_4 = -i), then W_N^(m r) = e^r
-            const C a0 = cadd(v0, v2), a1 = csub(v0, v2), c0 = cadd(v1, v3), c1 = csub(v1, v3);
-            const C e2 = cmul(e, e);
-            C o[G];
-            if (G == 4 || rbase == 0) {     // workgroup-uniform
-                o[0] = cadd(a0, c0);
-                o[1] = cmul(mk<double>(a1.x + c1.y, a1.y - c1.x), e);           // a1 - i c1
-            }
-            if (G == 4 || rbase == 2) {
-                o[G - 2] = cmul(csub(a0, c0), e2);
-                o[G - 1] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));        // a1 + i c1
-            }
-            // group g takes element i = MJ s + j of its transform from this thread: real parts now
-#pragma unroll
-            for (int g = 0; g < G; g++) { xw[(g * 16 + j) * 256] = o[g].x; oim[G * j + g] = o[g].y; }
-            e = cmul(e, estep);
-            // one j at a time -- four loads in flight, sixteen values kept.  Measured slower: all 16 loads at once (30 more spilled
-            // registers); the loads of j + 1 issued ahead of j's arithmetic; the next block's first four issued behind the transform,
-            // ahead of the |X| arithmetic (75 instead of 29 spilled registers)
-            __builtin_amdgcn_sched_barrier(0);
-        }
         C u[E];
-        PAN_STAMP(1);                       // loads, window, radix-4, first exchange writes: done by this thread
-        __syncthreads();
-        PAN_STAMP(2);                       // ... by the workgroup
+        PAN_STAMP(6);
 #pragma unroll
-        for (int i = 0; i < E; i++) u[i].x = xr[i * 256];
-        __syncthreads();
+        for (int h = 0; h < 2; h++) {
+            __syncthreads();                // the area is free: the previous block's transform / the first round's values have been read out
+            if (h == 0) PAN_STAMP(0);
 #pragma unroll
-        for (int j = 0; j < MJ; j++)
+            for (int jj = 0; jj < MJ / 2; jj++) {
+                const int j = h * (MJ / 2) + jj;
+                const C x0 = x[256 * j], x1 = x[256 * j + M], x2 = x[256 * j + 2 * M], x3 = x[256 * j + 3 * M];
+                // Hanning window 0.5 - 0.5 cos(2 pi n / N) at n = m + M q (quisk.c:6008): cos(a + pi q / 2) = cos a, -sin a, -cos a, sin a
+                // with e = (cos a, -sin a)
+                const double g0 = __builtin_fma(-0.5, e.x, 0.5), g2 = __builtin_fma(0.5, e.x, 0.5);
+                const double g1 = __builtin_fma(-0.5, e.y, 0.5), g3 = __builtin_fma(0.5, e.y, 0.5);
+                const C v0 = mk<double>(x0.x * g0, x0.y * g0), v1 = mk<double>(x1.x * g1, x1.y * g1);
+                const C v2 = mk<double>(x2.x * g2, x2.y * g2), v3 = mk<double>(x3.x * g3, x3.y * g3);
+                // sum_q W_4^(q r) v_q, r = 0 .. 3 (W_4 = -i), then W_N^(m r) = e^r
+                const C a0 = cadd(v0, v2), a1 = csub(v0, v2), c0 = cadd(v1, v3), c1 = csub(v1, v3);
+                const C e2 = cmul(e, e);
+                C o[G];
+                if (G == 4 || rbase == 0) {     // workgroup-uniform
+                    o[0] = cadd(a0, c0);
+                    o[1] = cmul(mk<double>(a1.x + c1.y, a1.y - c1.x), e);           // a1 - i c1
+                }
+                if (G == 4 || rbase == 2) {
+                    o[G - 2] = cmul(csub(a0, c0), e2);
+                    o[G - 1] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));        // a1 + i c1
+                }
 #pragma unroll
-            for (int g = 0; g < G; g++) xw[(g * 16 + j) * 256] = oim[G * j + g];
-        __syncthreads();
+                for (int g = 0; g < G; g++) xc[(g * 8 + (MJ / 2) * s + jj) * 256 + t] = o[g];
+                e = cmul(e, estep);
+                // one j at a time -- four loads in flight.  Measured slower: all loads at once; the loads of j + 1 issued ahead of j's arithmetic
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (h == 1) PAN_STAMP(1);
+            __syncthreads();
+            if (h == 1) PAN_STAMP(2);
+            // group s takes element i = MJ s' + j of its transform from thread (s', t): slot ii = (MJ/2) s' + jj of its own plane
 #pragma unroll
-        for (int i = 0; i < E; i++) u[i].y = xr[i * 256];
+            for (int ii = 0; ii < 8; ii++) u[MJ * (ii / (MJ / 2)) + h * (MJ / 2) + ii % (MJ / 2)] = xc[(s * 8 + ii) * 256 + t];
+        }
         __syncthreads();                    // everybody has taken its elements: the images may be written
         // (the pass twiddles' powers are loop invariant: left alone, the compiler computes all 28 of them once, ahead of the
         // block loop, and spills them)
         typename S::Tw twb = twf;
         asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
         PAN_STAMP(3);                       // the exchange between the residue groups
-        S::run_at(u, image, twb, t);
+        S::template run_at<true>(u, image, twb, t);         // (twiddle powers in three registers: the sixteen |X| sums ride through the transform)
         PAN_STAMP(4);                       // the 4096-point transform
 #pragma unroll
         for (int i = 0; i < E; i++) {

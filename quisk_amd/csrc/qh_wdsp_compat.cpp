@@ -19,6 +19,7 @@
 #include "qh_internal.hpp"
 
 extern "C" int qh_rxa_flush(qh_rxa *e);
+extern "C" void qh_wdsp_shim_release_device(int channel);
 
 namespace {
 
@@ -403,6 +404,7 @@ void CloseChannel(int channel)
     if (!L.c) return;
     Chan &c = *L.c;
     free_staging(c);
+    qh_wdsp_shim_release_device(channel);       // the re-blocking ring keeps its samples (the reference's statics outlive the channel), on the host
     g_graph_launches += qh_rxa_graph_launches(c.eng);
     qh_rxa_destroy(c.eng);
     c.eng = nullptr;
@@ -785,6 +787,18 @@ int shim_side(Shim &s, bool dev, int want)
     s.dev = dev;
     return QH_OK;
 }
+}
+
+// CloseChannel: the shim's ring goes back to host memory (quisk_wdsp.c's statics outlive a channel: the ring keeps its samples for the
+// next OpenChannel on that id), its device buffer and events are released
+extern "C" void qh_wdsp_shim_release_device(int channel)
+{
+    if (!valid(channel)) return;
+    Shim &s = g_shim[channel];
+    if (s.dev) (void)shim_side(s, false, 0);
+    if (s.d_buf) { (void)hipDeviceSynchronize(); (void)hipFree(s.d_buf); s.d_buf = nullptr; s.d_cap = 0; }
+    if (s.ev_in) { (void)hipEventDestroy(s.ev_in); s.ev_in = nullptr; }
+    if (s.ev_out) { (void)hipEventDestroy(s.ev_out); s.ev_out = nullptr; }
 }
 
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use)

@@ -2,8 +2,8 @@
 # usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>
 # The round's evidence set from ONE library on ONE box, written to gpurun_out/<tag>_*: the driver's line, rocprofv3 kernel stats of the
 # headline run and of every leg of `other_configs`, the PMC passes of the headline (with the traffic / VALU stamp bench.py reads) and
-# of config 3.  Copy what is to be judged into profiles/.
-tag=${1:-r04}
+# of configs 3 and 5 (the half-band cascade).  Copy what is to be judged into profiles/.
+tag=${1:-r05}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
@@ -16,4 +16,5 @@ for leg in 3 4 5 2agc quisk; do
 done
 python3 tools/pmc_pass.py $out/${tag}_pmc.json > /dev/null 2> $out/${tag}_pmc.err
 python3 tools/pmc_pass.py $out/${tag}_c3_pmc.json $root/tools/bench_configs.py 3 > /dev/null 2> $out/${tag}_c3_pmc.err
+python3 tools/pmc_pass.py $out/${tag}_c5_pmc.json $root/tools/dbg/hbc_only.py 8 > /dev/null 2> $out/${tag}_c5_pmc.err
 ls -la $out | grep ${tag}_
