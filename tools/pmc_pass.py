@@ -41,7 +41,7 @@ def write_c2_traffic(res, bench_args, path):
     samples = 256.0 * (1 << log2)
     kern = {}
     for name, v in res.items():
-        if "osfir_kernel<double, 4096, 4" in name:
+        if "osfir_kernel<double, 4096, 4, false, false" in name:      # (MIX, PACKED) = (false, false): the fp64-input front, not the wire-format one
             key = "front"
         elif "osfir_kernel<double, 4096, 1" in name and (("true, false" in name.split("4096, 1,")[1][:30]) == (meters == "on")):
             key = "band"        # the METER instantiation when the meters run (template flags: MIX, PACKED, METER, ...)
@@ -66,7 +66,7 @@ def main():
         script, rest = os.path.abspath(rest[0]), rest[1:]
         bench_args = rest
     else:
-        bench_args = rest or ["--steps", "2", "--warmup", "1", "--log2-samples", "20", "--no-cpu-baseline", "--no-other-configs", "--no-le24"]
+        bench_args = rest or ["--steps", "2", "--warmup", "1", "--log2-samples", "20", "--no-cpu-baseline", "--no-other-configs", "--no-le24", "--no-host-fed"]
     res = collections.defaultdict(dict)
     tmp = "/tmp/pmc_pass"
     for gi, grp in enumerate(GROUPS):
