@@ -25,14 +25,14 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def _export_map(path):
+def _export_map(path, extra=()):
     """Linker version script: the C ABI of include/quiskhip.h and nothing else.  The library is loaded into other programs' processes
     (Quisk's Python, anything that links filter.o's names): kernels' host stubs, C++ helpers and file-scope state stay local."""
     import re
     src = open(os.path.join(HERE, "..", "include", "quiskhip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(n for n in re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src) if n != "defined"))
-    text = "{\n  global:\n" + "".join("    %s;\n" % n for n in names) + "  local: *;\n};\n"
+    text = "{\n  global:\n" + "".join("    %s;\n" % n for n in names + list(extra)) + "  local: *;\n};\n"
     try:
         if open(path).read() == text:
             return path
@@ -76,7 +76,7 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
         raise ValueError("quisk_amd.build: -D overrides / QH_HIPCC_FLAGS make an experiment build: pass out=<another file> (tools/ab_bench.py)")
     os.makedirs(os.path.dirname(target), exist_ok=True)
     if out:
-        vmap = _export_map(os.path.join(os.path.dirname(target), "quiskhip.map"))
+        vmap = _export_map(os.path.join(os.path.dirname(target), "quiskhip.map"), extra=["qh_dbg_*"])      # (experiment builds may add probes)
         cmd = base + ["-shared", "-Wl,--version-script=" + vmap, "-o", target] + extra + [os.path.join(CSRC, f) for f in SOURCES]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

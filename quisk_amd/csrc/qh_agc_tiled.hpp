@@ -8,10 +8,13 @@
 //                          SetRXAAGCAttack has moved in_index in mid-stream: the engine keeps such a channel on wcpagc_kernel);
 //                          also keeps the A samples ahead of every 1024-sample tile for agc_apply_kernel
 //   agc_avg_tiled_kernel   (b): two linear one-pole scans of |x_{j-A}| over time segments, the carries chained from the prep kernel's tile sums
-//   agc_bounds_kernel      (d), coarse: the detector's state at every tile boundary, one wavefront per channel jumping over the runs of
-//                          constant ring_max in closed form (a warm-up from a guessed state, as the PLL tiles use, does not work here:
-//                          two runs of the detector only meet at the rate of the attack steps they share, one step in twenty on a
-//                          steady noisy signal, and not at all while both decay after a peak: tools/dbg/agc_sim.py)
+//   agc_bounds_kernel      (d), coarse: the detector's state at every tile boundary.  One wavefront walks a stretch of the call jumping over
+//                          the runs the detector spends in one regime in closed form.  The call is cut into K segments walked at once, each
+//                          from the state the call began in; agc_bounds_round_kernel then walks every segment again from the end of the one
+//                          before it until the new walk meets the old one (two runs of the detector meet at the rate of the attack steps
+//                          they share -- one step in twenty on a steady noisy signal, ~10 000 samples -- and not at all while both decay
+//                          after a peak, which is why a fixed warm-up ahead of every tile, as the PLL tiles use, does not work here);
+//                          agc_bounds_fix_kernel catches, in order, what the rounds left
 //   agc_lanes_kernel       (d), exact: ONE LANE PER TILE steps its tile sample by sample from its boundary state
 //   agc_verify_kernel      checks every boundary state against the end of the tile before it and re-runs, in order, the tiles whose
 //                          start was off (exact compare of the discrete state, 1e-9 on volts)
@@ -205,14 +208,30 @@ static __global__ __launch_bounds__(kSegThreads) void agc_avg_tiled_kernel(const
 // put, single reference steps (agc_lane_step) at the turns.  What comes out are the states at the tile boundaries, within rounding of
 // what sample-by-sample stepping gives -- the lanes then step every tile exactly from there, and the check of every tile's end against
 // the next boundary (agc_verify_kernel) catches what a scan got wrong.
-// One chunk of cnt <= 64 samples (ring_max r, back-averages f, h in the lanes): the detector advances REGIME by regime.  While it
-// attacks (state 0, ring_max >= volts), decays (state 3 or 4, ring_max < volts) or holds (state 2, counter running) it is a linear
-// recurrence in volts with one multiplier whatever ring_max does, so the rest of the chunk is taken as a wave-wide scan,
+// One chunk of cnt <= 64 samples (ring_max r in the lanes): the detector advances REGIME by regime.  While it attacks (state 0,
+// ring_max >= volts), decays (state 3 or 4, ring_max < volts), decays fast (state 1, ring_max < volts, volts still above save_volts) or
+// holds (state 2, counter running) it is a linear recurrence in volts with one multiplier whatever ring_max does, so the rest of the
+// chunk is taken as a wave-wide scan,
 //   v_j = (1 - m)^(j - p + 1) v + sum_{i = p .. j} m r_i (1 - m)^(j - i),
 // a ballot finds the first sample at which the regime's own condition (on v_{j-1}) fails, everything ahead of it is accepted at once,
-// and that sample is one reference step (agc_lane_step).  tab[w][k] = (1 - mult_w)^k for the attack, decay and hang-decay multipliers.
-__device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double h, int cnt, int lane, const AgcParam &q, const PoleScan &ps0,
-                                          const PoleScan &ps1, const PoleScan &ps2, const double (*tab)[65])
+// and that sample is one reference step (agc_lane_step).  tab[w][k] = (1 - mult_w)^k for the attack, decay, hang-decay and fast-decay
+// multipliers.  The two back-averages only matter to a step out of state 0 (the choice between fast decay, hang and decay): they are
+// fetched there, f0 / h0 pointing at the chunk's first sample, and not streamed beside ring_max.
+#ifdef QH_AGC_COUNT     // experiment builds: how the walk spends its rounds ([w]: scans of regime w, [6 + st]: single steps out of state st,
+                        // [11 + w]: samples the scans of regime w covered)
+static __device__ unsigned long long g_agc_count[20];
+#define QH_AGC_CNT(i, v) do { if (lane == 0) atomicAdd(&g_agc_count[i], (unsigned long long)(v)); } while (0)
+#else
+#define QH_AGC_CNT(i, v) do { } while (0)
+#endif
+struct AgcScans { PoleScan a, d, hd, fd; };         // attack, decay, hang decay, fast decay
+__device__ __forceinline__ AgcScans agc_scans_make(const AgcParam &q, int lane)
+{
+    return AgcScans{ make_pole_scan(1.0 - q.attack_mult, lane), make_pole_scan(1.0 - q.decay_mult, lane),
+                     make_pole_scan(1.0 - q.hang_decay_mult, lane), make_pole_scan(1.0 - q.fast_decay_mult, lane) };
+}
+__device__ __forceinline__ void agc_chunk(AgcLane &s, double r, const double *f0, const double *h0, int cnt, int lane, const AgcParam &q,
+                                          const AgcScans &sc4, const double (*tab)[65])
 {
     int p = 0;
     while (p < cnt) {
@@ -220,77 +239,107 @@ __device__ __forceinline__ void agc_chunk(AgcLane &s, double r, double f, double
         const bool up = rp >= s.volts;
         // (a decay that sits on the min_volts clamp holds there while ring_max stays below it: silence)
         // (state 1 holds there too while volts stays above save_volts: the fast decay of silence)
-        const bool floor = !up && s.volts <= q.min_volts && (s.st == 3 || s.st == 4 || (s.st == 1 && s.volts > s.save_volts));
-        const int w = floor ? 4 : (s.st == 0 && up) ? 0 : (s.st == 3 && !up) ? 1 : (s.st == 4 && !up) ? 2 : (s.st == 2 && !up && s.hc > 1) ? 3 : -1;
+        const bool fast = s.st == 1 && !up && s.volts > s.save_volts;
+        const bool floor = !up && s.volts <= q.min_volts && (s.st == 3 || s.st == 4 || fast);
+        // 0 attack, 1 decay, 2 hang decay, 3 fast decay: scans; 4 hold, 5 floor: volts stays
+        const int w = floor ? 5 : (s.st == 0 && up) ? 0 : (s.st == 3 && !up) ? 1 : (s.st == 4 && !up) ? 2 : fast ? 3 : (s.st == 2 && !up && s.hc > 1) ? 4 : -1;
         int k = p;                                              // first sample the regime does not cover
-        if (w >= 0 && w < 3) {
-            const double m = w == 0 ? q.attack_mult : w == 1 ? q.decay_mult : q.hang_decay_mult;
+        if (w >= 0 && w < 4) {
+            const double m = w == 0 ? q.attack_mult : w == 1 ? q.decay_mult : w == 2 ? q.hang_decay_mult : q.fast_decay_mult;
             const bool in = lane >= p && lane < cnt;
             // (field by field: an index or a select between the structs themselves would be a select of addresses, i.e. scratch memory)
             PoleScan pq;
-#define QH_SEL3(f) pq.f = w == 0 ? ps0.f : w == 1 ? ps1.f : ps2.f
-            QH_SEL3(m1); QH_SEL3(m2); QH_SEL3(m4); QH_SEL3(m8); QH_SEL3(pa); QH_SEL3(pb); QH_SEL3(pw);
-#undef QH_SEL3
+#define QH_SEL4(f) pq.f = w == 0 ? sc4.a.f : w == 1 ? sc4.d.f : w == 2 ? sc4.hd.f : sc4.fd.f
+            QH_SEL4(m1); QH_SEL4(m2); QH_SEL4(m4); QH_SEL4(m8); QH_SEL4(pa); QH_SEL4(pb); QH_SEL4(pw);
+#undef QH_SEL4
             const double sc = scan_pole_dpp(in ? m * r : 0.0, pq);
             const double v = __builtin_fma(tab[w][in ? lane - p + 1 : 0], s.volts, sc);
             double vb = wave_shr1(v);
             if (lane == p) vb = s.volts;
-            const bool ok = (w == 0 ? r >= vb : r < vb) && v >= q.min_volts;      // (the clamp is a turn: the reference applies it after every step)
+            // (the clamp is a turn: the reference applies it after every step; the fast decay ends where volts has come down to save_volts)
+            const bool ok = (w == 0 ? r >= vb : r < vb) && v >= q.min_volts && (w != 3 || vb > s.save_volts);
             const unsigned long long bad = __ballot(in && !ok);
             k = bad ? __ffsll((long long)bad) - 1 : cnt;
             if (k > p) s.volts = lane_bcast(v, k - 1);
-        } else if (w >= 3) {
+        } else if (w >= 4) {
             const bool in = lane >= p && lane < cnt;
             const unsigned long long bad = __ballot(in && r >= s.volts);
             k = bad ? __ffsll((long long)bad) - 1 : cnt;
-            if (w == 3 && k - p > s.hc - 1) k = p + s.hc - 1;   // the counter runs out: that sample is a turn
+            if (w == 4 && k - p > s.hc - 1) k = p + s.hc - 1;   // the counter runs out: that sample is a turn
         }
+        if (w >= 0) { QH_AGC_CNT(w, 1); QH_AGC_CNT(11 + w, k - p); }
         if (k > p) { s.hc = s.hc > k - p ? s.hc - (k - p) : 0; p = k; }
-        else { agc_lane_step(s, rp, lane_bcast(f, p), lane_bcast(h, p), q); p++; }
+        else {
+            QH_AGC_CNT(6 + s.st, 1);
+            double f = 0.0, h = 0.0;
+            if (s.st == 0) { f = f0[p]; h = h0[p]; }            // (uniform: every lane the same word)
+            agc_lane_step(s, rp, f, h, q);
+            p++;
+        }
     }
 }
 
 // bounds[slot][tile][0..4]: the state at the START of tile t (tile 0: the carried state).
-// The walk over [j0, j1) (multiples of 64, j0 a tile boundary or a warm-up start), boundary states written from sample `from` on.
 struct AgcWalk {
     const double *in0, *in1, *in2;
     double *bo;
     int n, L, lane;
 };
-__device__ __forceinline__ void agc_walk(AgcLane &s, const AgcWalk &w, int j0, int from, int j1, const AgcParam &q, const PoleScan &ps0,
-                                         const PoleScan &ps1, const PoleScan &ps2, const double (*tab)[65])
-{
-    const int lane = w.lane;
-    double rn = 0.0, fn = 0.0, hn = 0.0;
-    if (j0 + lane < w.n) { rn = w.in0[j0 + lane]; fn = w.in1[j0 + lane]; hn = w.in2[j0 + lane]; }
-    for (int base = j0; base < j1; base += 64) {
-        const int cnt = w.n - base < 64 ? w.n - base : 64;
-        if (base >= from && base % w.L == 0 && lane == 0) {
-            double *o = w.bo + (long long)(base / w.L) * 8;
-            o[0] = s.volts; o[1] = s.save_volts; o[2] = (double)s.hc; o[3] = (double)s.decay_type; o[4] = (double)s.st;
-        }
-        const double r = rn, f = fn, h = hn;
-        if (base + 64 + lane < w.n) { rn = w.in0[base + 64 + lane]; fn = w.in1[base + 64 + lane]; hn = w.in2[base + 64 + lane]; }     // the next chunk is on its way
-        agc_chunk(s, r, f, h, cnt, lane, q, ps0, ps1, ps2, tab);
-    }
-}
-__device__ __forceinline__ void agc_tab_init(double (*tab)[65], const AgcParam &q, int lane)
-{
-    const double lg0 = log1p(-q.attack_mult), lg1 = log1p(-q.decay_mult), lg2 = log1p(-q.hang_decay_mult);
-    tab[0][lane + 1] = exp((double)(lane + 1) * lg0); tab[1][lane + 1] = exp((double)(lane + 1) * lg1); tab[2][lane + 1] = exp((double)(lane + 1) * lg2);
-    if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = 1.0;
-    __syncthreads();
-}
 __device__ __forceinline__ void agc_put(double *o, const AgcLane &s)
 {
     o[0] = s.volts; o[1] = s.save_volts; o[2] = (double)s.hc; o[3] = (double)s.decay_type; o[4] = (double)s.st;
 }
+__device__ __forceinline__ bool agc_state_differs(const double *a, const double *b);
+// The walk over [j0, j1) (multiples of 64, j0 a tile boundary or a warm-up start), boundary states written from sample `from` on; ring_max
+// travels kAgcAhead chunks ahead of the one being walked (a chunk is ~1000 cycles of work, a fetch from HBM under load two to four times
+// that).  AGAIN: the segment has been walked before from another start state: at every tile boundary behind the first the state is held
+// against the one that walk left there -- once they agree the two walks have met and everything further on stands as it is (true is
+// returned: the segment's recorded end is still right).
+constexpr int kAgcAhead = 4;
+template <bool AGAIN>
+__device__ __forceinline__ bool agc_walk(AgcLane &s, const AgcWalk &w, int j0, int from, int j1, const AgcParam &q, const AgcScans &sc4,
+                                         const double (*tab)[65])
+{
+    const int lane = w.lane;
+    double rq[kAgcAhead];
+#pragma unroll
+    for (int u = 0; u < kAgcAhead; u++) rq[u] = j0 + u * 64 + lane < w.n ? w.in0[j0 + u * 64 + lane] : 0.0;
+    for (int base0 = j0; base0 < j1; base0 += 64 * kAgcAhead) {
+#pragma unroll
+        for (int u = 0; u < kAgcAhead; u++) {
+            const int base = base0 + u * 64;
+            if (base >= j1) break;
+            const int cnt = w.n - base < 64 ? w.n - base : 64;
+            if (base >= from && base % w.L == 0) {
+                double *o = w.bo + (long long)(base / w.L) * 8;
+                if (AGAIN && base > j0) {
+                    const double mine[5] = { s.volts, s.save_volts, (double)s.hc, (double)s.decay_type, (double)s.st };
+                    if (!agc_state_differs(mine, o)) return true;        // (uniform: every lane holds the same state and reads the same words)
+                }
+                if (lane == 0) agc_put(o, s);
+            }
+            const double r = rq[u];
+            const int nx = base + 64 * kAgcAhead + lane;
+            rq[u] = nx < w.n ? w.in0[nx] : 0.0;
+            agc_chunk(s, r, w.in1 + base, w.in2 + base, cnt, lane, q, sc4, tab);
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ void agc_tab_init(double (*tab)[65], const AgcParam &q, int lane)
+{
+    const double lg0 = log1p(-q.attack_mult), lg1 = log1p(-q.decay_mult), lg2 = log1p(-q.hang_decay_mult), lg3 = log1p(-q.fast_decay_mult);
+    tab[0][lane + 1] = exp((double)(lane + 1) * lg0); tab[1][lane + 1] = exp((double)(lane + 1) * lg1);
+    tab[2][lane + 1] = exp((double)(lane + 1) * lg2); tab[3][lane + 1] = exp((double)(lane + 1) * lg3);
+    if (lane == 0) tab[0][0] = tab[1][0] = tab[2][0] = tab[3][0] = 1.0;
+    __syncthreads();
+}
 
 // One wavefront per channel walks the call alone at a few thousand cycles per 64 samples, so the call is cut into K super-segments
 // (seg samples each, a multiple of the tile length) that K wavefronts walk at once: segment 0 from the carried state; segment k > 0
-// from the state the CALL began in, W samples ahead of its own start -- on a channel whose level is steady that warm-up ends on the true
-// trajectory (two runs meet at the rate of their shared attack steps: ~10 000 samples on steady noise, tools/dbg/agc_sim.py); after a
-// drop in level it does not, and agc_bounds_fix_kernel walks such a segment again from the true end of the one before it.
+// from the state the CALL began in, W samples ahead of its own start (W = 0 unless QH_AGC_WARM asks for a warm-up).  Where the level is
+// steady such a walk ends on the true trajectory some 10 000 samples in, so most segments END right although they began wrong; after a
+// drop in level it does not while the decay lasts.  The repair rounds below put that right.
 // sege[slot][k][0..4]: the state at the END of segment k.  grid (channels, K), one wavefront.
 static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int *chan_list, const AgcParam *prm, const AgcState *state,
                                                               const double *scr, long long arr, double *bounds, long long bstride, int L,
@@ -303,41 +352,79 @@ static __global__ __launch_bounds__(64) void agc_bounds_kernel(int n, const int 
     const AgcState *sp = state + ch;
     AgcWalk w{ scr + ((long long)slot * 4 + 0) * arr, scr + ((long long)slot * 4 + 1) * arr, scr + ((long long)slot * 4 + 2) * arr,
                bounds + (long long)slot * bstride, n, L, lane };
-    __shared__ double tab[3][65];
+    __shared__ double tab[4][65];
     agc_tab_init(tab, q, lane);
-    const PoleScan ps0 = make_pole_scan(1.0 - q.attack_mult, lane), ps1 = make_pole_scan(1.0 - q.decay_mult, lane),
-                   ps2 = make_pole_scan(1.0 - q.hang_decay_mult, lane);
+    const AgcScans sc4 = agc_scans_make(q, lane);
     AgcLane s{ sp->volts, sp->save_volts, sp->hang_counter, sp->decay_type, sp->state };
     int j0 = begin - W;
     if (j0 <= 0) j0 = 0;
     else s.hc = s.hc > j0 ? s.hc - j0 : 0;                  // the hang counter has run down meanwhile
     const int end = begin + seg < n ? begin + seg : n;
-    agc_walk(s, w, j0, begin, end, q, ps0, ps1, ps2, tab);
+    agc_walk<false>(s, w, j0, begin, end, q, sc4, tab);
     if (lane == 0) agc_put(sege + ((long long)slot * gridDim.y + k) * 8, s);
 }
 
-__device__ __forceinline__ bool agc_state_differs(const double *a, const double *b);
-// One wavefront per channel: segment k began in bounds[tile of k seg]; where that is not the state segment k - 1 ended in, the segment is
-// walked again from there (its tiles' boundary states and its own end rewritten).  nseg_fixed counts them.
+// One ROUND of repair over all segments at once, grid (channels, K), one wavefront: segment k began in bounds[tile of k seg]; where that is
+// not the state segment k - 1 ended in AS OF THE ROUND BEFORE (sege_in), it is walked again from there until it meets its old self.  A
+// round reads sege_in and writes sege_out, so that no block reads an end another is writing.  The ends of the round before may themselves
+// be off (their segments are being walked again beside this one), so a chain of r segments that all depend on their start -- a decay
+// that runs across r boundaries -- takes r rounds; agc_bounds_fix_kernel behind the rounds catches what is left, in order.
+static __global__ __launch_bounds__(64) void agc_bounds_round_kernel(int n, const int *chan_list, const AgcParam *prm, const double *scr, long long arr,
+                                                                    double *bounds, long long bstride, int L, int seg, int K, const double *sege_in,
+                                                                    double *sege_out, int *nseg_fixed)
+{
+    const int slot = blockIdx.x, k = blockIdx.y, ch = chan_list[slot], lane = threadIdx.x;
+    const int begin = k * seg;
+    if (begin >= n) return;
+    const double *mine_in = sege_in + ((long long)slot * K + k) * 8;
+    double *mine_out = sege_out + ((long long)slot * K + k) * 8;
+    double *bo = bounds + (long long)slot * bstride;
+    bool again = false;
+    if (k > 0) again = agc_state_differs(bo + (long long)(begin / L) * 8, mine_in - 8);
+    if (!again) {
+        if (lane < 5) mine_out[lane] = mine_in[lane];
+        return;
+    }
+    const AgcParam q = prm[ch];
+    AgcWalk w{ scr + ((long long)slot * 4 + 0) * arr, scr + ((long long)slot * 4 + 1) * arr, scr + ((long long)slot * 4 + 2) * arr, bo, n, L, lane };
+    __shared__ double tab[4][65];
+    agc_tab_init(tab, q, lane);
+    const AgcScans sc4 = agc_scans_make(q, lane);
+    const double *b = mine_in - 8;
+    AgcLane s{ b[0], b[1], (int)b[2], (int)b[3], (int)b[4] };
+    const int end = begin + seg < n ? begin + seg : n;
+    const bool met = agc_walk<true>(s, w, begin, begin, end, q, sc4, tab);
+    if (met) { if (lane < 5) mine_out[lane] = mine_in[lane]; }
+    else if (lane == 0) agc_put(mine_out, s);
+    if (lane == 0 && nseg_fixed) atomicAdd(nseg_fixed, 1);
+}
+// One wavefront per channel, in order: segment k began in bounds[tile of k seg]; where that is not the state segment k - 1 ended in, the
+// segment is walked again from there (its tiles' boundary states and its own end rewritten, until it meets its old self).
+// nseg_fixed counts them.
 static __global__ __launch_bounds__(64) void agc_bounds_fix_kernel(int n, const int *chan_list, const AgcParam *prm, const double *scr, long long arr,
                                                                   double *bounds, long long bstride, int L, int seg, int K, double *sege, int *nseg_fixed)
 {
     const int slot = blockIdx.x, ch = chan_list[slot], lane = threadIdx.x;
-    const AgcParam q = prm[ch];
-    AgcWalk w{ scr + ((long long)slot * 4 + 0) * arr, scr + ((long long)slot * 4 + 1) * arr, scr + ((long long)slot * 4 + 2) * arr,
-               bounds + (long long)slot * bstride, n, L, lane };
-    __shared__ double tab[3][65];
-    agc_tab_init(tab, q, lane);
-    const PoleScan ps0 = make_pole_scan(1.0 - q.attack_mult, lane), ps1 = make_pole_scan(1.0 - q.decay_mult, lane),
-                   ps2 = make_pole_scan(1.0 - q.hang_decay_mult, lane);
+    double *bo = bounds + (long long)slot * bstride;
     int fixed = 0;
+    bool ready = false;
+    __shared__ double tab[4][65];
+    AgcParam q;
+    AgcScans sc4;
     for (int k = 1; k < K && k * seg < n; k++) {
-        const double *a = w.bo + (long long)(k * seg / L) * 8, *b = sege + ((long long)slot * K + k - 1) * 8;
+        const double *a = bo + (long long)(k * seg / L) * 8, *b = sege + ((long long)slot * K + k - 1) * 8;
         if (!agc_state_differs(a, b)) continue;
+        if (!ready) {
+            q = prm[ch];
+            agc_tab_init(tab, q, lane);
+            sc4 = agc_scans_make(q, lane);
+            ready = true;
+        }
+        AgcWalk w{ scr + ((long long)slot * 4 + 0) * arr, scr + ((long long)slot * 4 + 1) * arr, scr + ((long long)slot * 4 + 2) * arr, bo, n, L, lane };
         AgcLane s{ b[0], b[1], (int)b[2], (int)b[3], (int)b[4] };
         const int begin = k * seg, end = begin + seg < n ? begin + seg : n;
-        agc_walk(s, w, begin, begin, end, q, ps0, ps1, ps2, tab);
-        if (lane == 0) agc_put(sege + ((long long)slot * K + k) * 8, s);
+        const bool met = agc_walk<true>(s, w, begin, begin, end, q, sc4, tab);
+        if (!met && lane == 0) agc_put(sege + ((long long)slot * K + k) * 8, s);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -415,7 +502,7 @@ static __global__ __launch_bounds__(64, 2) void agc_lanes_kernel(int n, const in
 
 // A boundary state is accepted when it is the state the tile before it ended in: the discrete part exactly, volts to 1e-11 and
 // save_volts -- volts as it was at the last turn to state 0 -- to 1e-9 (the closed-form jumps land within 1e-14 of the stepped values;
-// tools/dbg/agc_ends2.py prints the misses of a call).
+// the misses of a call show in qh_rxa_agc_repairs).
 __device__ __forceinline__ bool agc_state_differs(const double *a, const double *b)
 {
     return !(fabs(a[0] - b[0]) <= 1e-11 * fabs(b[0]) && fabs(a[1] - b[1]) <= 1e-9 * fabs(b[1]) && a[2] == b[2] && a[3] == b[3] && a[4] == b[4]);

@@ -2043,9 +2043,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     const bool direct = split && !(dbg_forms & 2) && every_nbp && !eg.kind && !n_lim && !n_agc_cur && !n_agc_other && !n_snba && !n_snb[1] && no_lms &&
                         !n_emnr[0] && !n_emnr[1] && !n_emnr[2] && !n_fix[0] && !n_fix[1] && !n_bp1p[1] && n_bp1p[0] == n_bp1 && n_rb == n_bp1 &&
                         n_usb + n_fm == n_plain &&
-                        // the first stores to `out` come while other channels' input is still being read: not for a caller that works in place
-                        ((const char *)(out + (size_t)nch * (size_t)out_stride) <= (const char *)in ||
-                         (const char *)in + (size_t)nch * (size_t)in_stride * sizeof(double2) <= (const char *)out);
+                        // the first stores to `out` come while other channels' input is still being read: not for a caller that works in place.
+                        // (The extents are the rows' own: first sample of the first row to last sample of the last.  nch * stride from a
+                        // pointer INTO a matrix -- a caller walking along its rows call by call -- reaches past the matrix's end by the
+                        // offset, and whether that touches the input depended on where the allocator had put the two: the same calls took
+                        // this form or the other -- AM channels' last bits, tests/test_gpu_properties_fullsize.py -- by address.)
+                        ((const char *)(out + (size_t)(nch - 1) * (size_t)out_stride + (size_t)n_mid) <= (const char *)in ||
+                         (const char *)in + ((size_t)(nch - 1) * (size_t)in_stride + (size_t)n_in) * sizeof(double2) <= (const char *)out);
     // ... and the AM channels' nbp0 leaves the envelope and every tile's share of the fade leveller's averages: one pass does the rest
     const int P_am = ((P + 63) / 64) * 64;
     const bool am_fused = direct && !(dbg_forms & 4) && n_am > 0 && n_rb == n_am + n_sam && !band6k && !band2g && bnfft == kNfft && P_am < bnfft;
@@ -2427,7 +2431,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                     QH_HIP(dev_alloc(&agc_tail, (size_t)nch * kAgcRing));
                     QH_HIP(dev_alloc(&agc_nfixed, (size_t)2));
                     QH_HIP(hipMemsetAsync(agc_nfixed, 0, 2 * sizeof(int), stream));
-                    QH_HIP(dev_alloc(&agc_sege, (size_t)nch * kAgcSegs * 8));
+                    QH_HIP(dev_alloc(&agc_sege, (size_t)2 * nch * kAgcSegs * 8));        // two copies: a repair round reads one and writes the other
                 }
             }
             static bool agc_attr = false;
@@ -2452,19 +2456,31 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                                    buf_cap, n, lst, (const AgcParam *)agc_prm, (const AgcState *)agc_state, agc_scr, agc_arr, (const double *)agc_tsum,
                                    ntile, 1.0);
                 double *bnd = agc_ends, *end = agc_ends + (size_t)nch * (size_t)agc_ends_cap * kAgcEndsW;
-                // the boundary pass over K super-segments per channel at once (a multiple of the tile length each, warm-up 400 A rounded to tiles)
+                // the boundary pass over K super-segments per channel at once (a multiple of the tile length each)
                 int K = 1;
                 while (K < kAgcSegs && (long long)cnt * K < 4096 && n_mid / (2 * K) >= 8 * L && n_mid / (2 * K) >= 32768) K *= 2;
                 if (const char *e = getenv("QH_AGC_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= kAgcSegs) K = v; }
                 const int seg = (int)(((n_mid + K - 1) / K + L - 1) / L) * L;
-                int wmul = 400;         // 76 800 samples at A = 192: what the 256-channel bench input needs for no segment to miss (96: 29 %, 200: 0.06 %)
-                if (const char *e = getenv("QH_AGC_WARM")) { const int v = atoi(e); if (v > 0) wmul = v; }
+                // No warm-up ahead of a segment by default: every segment starts from the state the call began in, and the repair rounds
+                // walk each one again from the end of the one before it until the two walks meet (agc_bounds_round_kernel) -- the work a
+                // warm-up long enough for every channel (400 attack windows on the bench input) spends on all of them, spent only where
+                // and for as long as the walks differ.
+                int wmul = 0, rounds = 3;
+                if (const char *e = getenv("QH_AGC_WARM")) { const int v = atoi(e); if (v >= 0) wmul = v; }
+                if (const char *e = getenv("QH_AGC_ROUNDS")) { const int v = atoi(e); if (v >= 0 && v <= 16) rounds = v; }
                 const int Wm = ((wmul * a_max + L - 1) / L) * L;
+                double *sg[2] = { agc_sege, agc_sege + (size_t)nch * kAgcSegs * 8 };
                 hipLaunchKernelGGL(agc_bounds_kernel, dim3((unsigned)cnt, (unsigned)K), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
-                                   (const AgcState *)agc_state, (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, Wm, agc_sege);
-                if (K > 1)
+                                   (const AgcState *)agc_state, (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, Wm, sg[0]);
+                if (K > 1) {
+                    int at = 0;
+                    for (int r = 0; r < rounds; r++, at ^= 1)
+                        hipLaunchKernelGGL(agc_bounds_round_kernel, dim3((unsigned)cnt, (unsigned)K), dim3(64), 0, stream, n, lst,
+                                           (const AgcParam *)agc_prm, (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, K,
+                                           (const double *)sg[at], sg[at ^ 1], agc_nfixed + 1);
                     hipLaunchKernelGGL(agc_bounds_fix_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
-                                       (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, K, agc_sege, agc_nfixed + 1);
+                                       (const double *)agc_scr, agc_arr, bnd, agc_ends_cap * kAgcEndsW, L, seg, K, sg[at], agc_nfixed + 1);
+                }
                 hipLaunchKernelGGL(agc_lanes_kernel, dim3((unsigned)ngroups, (unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm,
                                    agc_scr, agc_arr, (const double *)bnd, agc_ends_cap * kAgcEndsW, end, agc_ends_cap * kAgcEndsW, L);
                 hipLaunchKernelGGL(agc_verify_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, n, lst, (const AgcParam *)agc_prm, agc_scr, agc_arr,
@@ -3324,6 +3340,15 @@ long long qh_rxa_agc_repairs(qh_rxa *h)
 }
 
 // super-segments of the AGC boundary pass that were walked again (their warm-up had not ended on the true trajectory), over all calls
+#ifdef QH_AGC_COUNT
+extern "C" int qh_dbg_agc_counts(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qh::g_agc_count), 20 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[20] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(qh::g_agc_count), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 long long qh_rxa_agc_segments_rerun(qh_rxa *h)
 {
     if (!h || !h->e.agc_nfixed) return 0;
