@@ -96,13 +96,35 @@ static __global__ __launch_bounds__(256) void agc_prep_kernel(const double2 *buf
     const double2 *x = buf + (long long)ch * stride;
     const int A = q.attack_buffsize, Ah = (A + 63) & ~63, M = Ah + kAgcTile, j0 = blockIdx.x * kAgcTile, base = j0 - Ah;
     double *m = sm_prep, *P = m + M, *S = P + M;
-    for (int i = t; i < M; i += 256) {
-        const int j = base + i;
-        m[i] = (j >= -A && j < n) ? agc_mag(x, sp, q, j, pre_gain) : 0.0;        // (samples further back than the window are not looked at)
-    }
-    // the A samples ahead of the tile, as the ring would hold them: agc_apply_kernel works in place
+    // the A samples ahead of the tile, as the ring would hold them, are kept for agc_apply_kernel, which works in place
     double2 *hl = halo + ((long long)slot * gridDim.x + blockIdx.x) * halo_pitch;
-    for (int i = t; i < A; i += 256) hl[i] = agc_sample(x, sp, A, j0 - A + i, pre_gain);
+    if (base >= 0) {
+        // every sample of the window is in the rows (all tiles but the call's first): five loads per thread in flight at a time -- one per
+        // round of the loop is one HBM latency per round, and the kernel was bound by that -- and the halo taken from the same registers
+        constexpr int U = 5;
+        for (int i0 = 0; i0 < M; i0 += 256 * U) {
+            double2 z[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * 256 + t, j = base + i;
+                z[u] = x[(i < M && j < n) ? j : base];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * 256 + t, j = base + i;
+                if (i >= M) continue;
+                const double2 zz = make_double2(z[u].x * pre_gain, z[u].y * pre_gain);
+                m[i] = j < n ? agc_mag_of(zz, q.pmode) : 0.0;
+                if (i >= Ah - A && i < Ah) hl[i - (Ah - A)] = zz;                  // (j < j0 <= n - 1 there)
+            }
+        }
+    } else {
+        for (int i = t; i < M; i += 256) {
+            const int j = base + i;
+            m[i] = (j >= -A && j < n) ? agc_mag(x, sp, q, j, pre_gain) : 0.0;    // (samples further back than the window are not looked at)
+        }
+        for (int i = t; i < A; i += 256) hl[i] = agc_sample(x, sp, A, j0 - A + i, pre_gain);
+    }
     __syncthreads();
     for (int b = wave; b < M / 64; b += 4) {
         const double v = m[b * 64 + lane];
