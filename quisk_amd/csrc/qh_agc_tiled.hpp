@@ -269,12 +269,17 @@ __device__ __forceinline__ void agc_chunk(AgcLane &s, double r, const double *f0
         if (w >= 0 && w < 4) {
             const double m = w == 0 ? q.attack_mult : w == 1 ? q.decay_mult : w == 2 ? q.hang_decay_mult : q.fast_decay_mult;
             const bool in = lane >= p && lane < cnt;
-            // (field by field: an index or a select between the structs themselves would be a select of addresses, i.e. scratch memory)
-            PoleScan pq;
-#define QH_SEL4(f) pq.f = w == 0 ? sc4.a.f : w == 1 ? sc4.d.f : w == 2 ? sc4.hd.f : sc4.fd.f
-            QH_SEL4(m1); QH_SEL4(m2); QH_SEL4(m4); QH_SEL4(m8); QH_SEL4(pa); QH_SEL4(pb); QH_SEL4(pw);
-#undef QH_SEL4
-            const double sc = scan_pole_dpp(in ? m * r : 0.0, pq);
+            // (the decay is 19 scans in 20: its weights straight from their registers; the others field by field -- an index or a select
+            // between the structs themselves would be a select of addresses, i.e. scratch memory)
+            double sc;
+            if (w == 1) sc = scan_pole_dpp(in ? m * r : 0.0, sc4.d);
+            else {
+                PoleScan pq;
+#define QH_SEL3(f) pq.f = w == 0 ? sc4.a.f : w == 2 ? sc4.hd.f : sc4.fd.f
+                QH_SEL3(m1); QH_SEL3(m2); QH_SEL3(m4); QH_SEL3(m8); QH_SEL3(pa); QH_SEL3(pb); QH_SEL3(pw);
+#undef QH_SEL3
+                sc = scan_pole_dpp(in ? m * r : 0.0, pq);
+            }
             const double v = __builtin_fma(tab[w][in ? lane - p + 1 : 0], s.volts, sc);
             double vb = wave_shr1(v);
             if (lane == p) vb = s.volts;

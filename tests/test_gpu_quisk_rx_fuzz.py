@@ -43,16 +43,30 @@ def test_random_walk(qh, oracle, fs, mode, seed):
     x = np.stack(xs)
     bank = qh.QuiskRxBank(nch, fs, mode)
     refs = [oracle.OracleQuiskRx(fs, tabs) for _ in range(nch)]
+    import os
+    # QH_TWIN=1 (diagnostics): every restated receiver once more, fed 1e-13 of noise per sample -- how far the restatement is from itself
+    twins = [oracle.OracleQuiskRx(fs, tabs) for _ in range(nch)] if os.environ.get("QH_TWIN") else []
+    tws, pert = [[] for _ in range(nch)], np.random.default_rng(int(os.environ.get("QH_TWIN_SEED", "7")))
 
     def filt(bw):
         frate = rxfilter.get_filter_rate(fs, mode, bw)
         return rxfilter.make_filter_coef(frate, None, bw, rxfilter.get_filter_center(NAMES[mode], bw))
 
+    skip = set(filter(None, os.environ.get("QH_SKIP", "").split(",")))         # diagnostics: these setters are left out on every side
+
+    class _Skipping:
+        def __init__(self, t): self._t = t
+        def __getattr__(self, name):
+            return (lambda *a: None) if name in skip else getattr(self._t, name)
+    if skip:
+        bank, refs, twins = _Skipping(bank), [_Skipping(r) for r in refs], [_Skipping(r) for r in twins]
     bw0 = {rxfilter.AM: 6000, rxfilter.FM: 12000, rxfilter.CWU: 500}.get(mode, 2700)
     fI, fQ = filt(bw0)
     for c, r in enumerate(refs):
         r.set_mode(mode); r.set_tune(5800 + 700 * c); r.set_filters(fI, fQ); r.set_bandwidth(bw0)
         bank.set_tune(c, 5800 + 700 * c)
+    for c, r in enumerate(twins):
+        r.set_mode(mode); r.set_tune(5800 + 700 * c); r.set_filters(fI, fQ); r.set_bandwidth(bw0)
     bank.set_filters(-1, fI, fQ)
     pos, ys, rs, log, blk, agc_used = 0, [], [[] for _ in range(nch)], [], 0, False
     while pos < total:
@@ -62,47 +76,49 @@ def test_random_walk(qh, oracle, fs, mode, seed):
             if k == 0:
                 c = int(rng.integers(0, nch)); f = int(rng.integers(4000, 9000))
                 bank.set_tune(c, f); refs[c].set_tune(f); log.append((blk, "tune", c, f))
+                if twins: twins[c].set_tune(f)
             elif k == 1:
                 bw = int(rng.choice([1800, 2400, 2700, 3000])) if mode in (rxfilter.USB, rxfilter.LSB) else bw0
                 a, b = filt(bw)
                 bank.set_filters(-1, a, b)
-                for r in refs:
+                for r in refs + twins:
                     r.set_filters(a, b); r.set_bandwidth(bw)
                 log.append((blk, "filters", bw))
             elif k == 2:
                 on, g = bool(rng.integers(0, 2)), float(rng.uniform(5, 200))
                 bank.set_agc(on, g)
-                for r in refs:
+                for r in refs + twins:
                     r.set_agc(on, g)
                 log.append((blk, "agc", on, g))
                 agc_used = agc_used or on
             elif k == 3:
                 lvl = int(rng.integers(0, 4))
                 bank.set_noise_blanker(lvl)
-                for r in refs:
+                for r in refs + twins:
                     r.set_noise_blanker(lvl)
                 log.append((blk, "nb", lvl))
             elif k == 4:
                 on = int(rng.integers(0, 2)); rit = 600 if mode == rxfilter.CWU else 0
                 bank.set_auto_notch(on, rit)
-                for r in refs:
+                for r in refs + twins:
                     r.set_auto_notch(on, rit)
                 log.append((blk, "notch", on))
             elif k == 5 and mode == rxfilter.FM:
                 lvl = float(rng.uniform(-80, -5))
                 bank.set_squelch(-1, lvl)
-                for r in refs:
+                for r in refs + twins:
                     r.set_squelch(lvl)
                 log.append((blk, "squelch", lvl))
             elif k == 6 and mode != rxfilter.FM:
                 on, lvl = int(rng.integers(0, 2)), int(rng.integers(1, 10))
                 bank.set_ssb_squelch(on, lvl)
-                for r in refs:
+                for r in refs + twins:
                     r.set_ssb_squelch(on, lvl)
                 log.append((blk, "ssb_squelch", on, lvl))
         ys.append(bank.process_host(x[:, pos:pos + n]))
         for c in range(nch):
             rs[c].append(refs[c].process(x[c, pos:pos + n]))
+            if twins: tws[c].append(twins[c].process(x[c, pos:pos + n] * (1.0 + 1e-13 * pert.standard_normal(n))))
         pos += n
         blk += 1
     y = np.concatenate(ys, axis=1)
@@ -119,6 +135,8 @@ def test_random_walk(qh, oracle, fs, mode, seed):
                     k = max(0, min(ys[b].shape[1], 2500 - sum(v.shape[1] for v in ys[:b])))
                     ys[b][c, :k] = rs[c][b][:k]
         err = rel_rms(y[c], ref)
+        if twins:
+            print("seed %d channel %d: bank %.3e, the restatement against its twin %.3e" % (seed, c, err, rel_rms(np.concatenate(tws[c]), ref)), flush=True)
         tol = 1e-4 if agc_used else 1e-6
         if err >= tol:
             o = 0

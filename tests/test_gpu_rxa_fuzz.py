@@ -141,6 +141,22 @@ def _walk(qh, oracle, seed, replay, wide=False):
     pos = 0
     log = []
     lms_used = [False] * NCH
+    import os
+    twin_c = int(os.environ["QH_TWIN"]) if os.environ.get("QH_TWIN") else None       # diagnostics: that channel's restatement once more, fed 1e-13 of noise
+    if twin_c is not None:
+        twin = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+        c = twin_c
+        twin.SetRXAShiftRun(1); twin.SetRXAShiftFreq(synth.shift_freq(c)); twin.RXANBPSetRun(1)
+        twin.SetRXAMode((1, 6, 0, 1)[c]); twin.RXASetPassband(*((300.0, 3000.0), (-4000.0, 4000.0), (-3000.0, -300.0), (300.0, 3000.0))[c])
+        twin.SetRXAAGCMode((0, 3, 4, 2)[c])
+        tws, pert = [], np.random.default_rng(11)
+    skip = set(filter(None, os.environ.get("QH_SKIP", "").split(",")))         # diagnostics: these setters are left out on every side
+
+    class _Skipping:
+        def __init__(self, t): self._t = t
+        def __getattr__(self, name):
+            return (lambda *a: None) if name in skip else getattr(self._t, name)
+    e_set, os_set = (_Skipping(e), [_Skipping(o) for o in os_]) if skip else (e, os_)
     # a minimum-phase filter of 4096 - 16384 taps: mp_imp's cepstrum (fir.c:319-368) takes the logarithm of a stop band 200 dB down over a
     # 16 nc-point transform -- two transforms that differ in their last bits leave designs 1e-6 apart (seen: 1.4e-6 at 16384 taps, 1.5e-6 at 4096)
     mp_now, nc_now, mp_long = [0] * NCH, [2048] * NCH, [False] * NCH
@@ -149,10 +165,11 @@ def _walk(qh, oracle, seed, replay, wide=False):
         if s:
             for _ in range(int(rng.integers(1, 3))):
                 c = int(rng.integers(0, NCH))
+                tg = [(e_set, (c,)), (os_set[c], ())] + ([(twin, ())] if twin_c == c else [])
                 if seed >= 5000 and rng.integers(0, 2):            # (walks from 5000 up: the second menu too, _apply2 below)
-                    log.append((s, c, _apply2(rng, [(e, (c,)), (os_[c], ())], notches2[c], fm=False)))
+                    log.append((s, c, _apply2(rng, tg, notches2[c], fm=False)))
                 else:
-                    log.append((s, c, _apply(rng, [(e, (c,)), (os_[c], ())], wide)))
+                    log.append((s, c, _apply(rng, tg, wide)))
                     notches2[c][0] += sum(1 for d in log[-1][2] if d[0] == "RXANBPAddNotch")
                 lms_used[c] = lms_used[c] or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in log[-1][2])
                 for d in log[-1][2]:
@@ -173,8 +190,14 @@ def _walk(qh, oracle, seed, replay, wide=False):
             ys.append(e.process_host(seg))
         for c in range(NCH):
             rs[c].append(os_[c].xrxa(seg[c]))
+        if twin_c is not None:
+            # (QH_TWIN_EPS: the relative perturbation; QH_TWIN_ADD: an absolute one -- a floor of rounding noise where the input is exactly 0)
+            tws.append(twin.xrxa(seg[twin_c] * (1.0 + float(os.environ.get("QH_TWIN_EPS", "1e-13")) * pert.standard_normal(seg.shape[1]))
+                                 + float(os.environ.get("QH_TWIN_ADD", "0")) * (pert.standard_normal(seg.shape[1]) + 1j * pert.standard_normal(seg.shape[1]))))
         pos += n
     y = np.concatenate(ys, axis=1)
+    if twin_c is not None:
+        print("seed %d channel %d: engine %.3e, the restatement against its twin %.3e" % (seed, twin_c, rel_rms(y[twin_c], np.concatenate(rs[twin_c])), rel_rms(np.concatenate(tws), np.concatenate(rs[twin_c]))), flush=True)
     if replay:
         assert e.graph_launches() > nblk // 3
     for c in range(NCH):
@@ -190,8 +213,12 @@ def _walk(qh, oracle, seed, replay, wide=False):
             for s, n in enumerate(seglen):
                 a, b = p0 * 256, (p0 + n) * 256
                 if np.abs(y[c, a:b] - ref[a:b]).max() > tol * np.abs(ref).max():
-                    raise AssertionError("seed %d channel %d: rel rms %.3e, first bad segment %d; setters so far %r" %
-                                         (seed, c, err, s, [l for l in log if l[0] <= s and l[1] == c]))
+                    per, q0 = [], 0
+                    for s2, n2 in enumerate(seglen):
+                        per.append("%d:%.1e" % (s2, np.abs(y[c, q0 * 256:(q0 + n2) * 256] - ref[q0 * 256:(q0 + n2) * 256]).max() / np.abs(ref).max()))
+                        q0 += n2
+                    raise AssertionError("seed %d channel %d: rel rms %.3e, first bad segment %d; setters so far %r; per-segment max error over the largest reference sample %r" %
+                                         (seed, c, err, s, [l for l in log if l[0] <= s and l[1] == c], per))
                 p0 += n
         assert err < tol
 

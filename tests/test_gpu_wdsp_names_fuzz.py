@@ -75,7 +75,7 @@ def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
         nblk = 60 * max(1, 1024 // in_size)
         x = synth.make_input_numpy(4, nblk * in_size * 192000 // in_rate)[seed % 4][::192000 // in_rate][:nblk * in_size].copy()
         err = C.c_int(0)
-        got, want, lms = [], [], False
+        got, want, lms, log, per = [], [], False, [], []
         b = 0
         while b < nblk:
             if b:
@@ -89,6 +89,7 @@ def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
                         done = _apply(rng, tg)
                         notches[0] += sum(1 for d in done if d[0] == "RXANBPAddNotch")
                     lms = lms or any(d[0] in ("SetRXAANFRun", "SetRXAANRRun") and d[1] for d in done)
+                    log.append((b, done))
             n = min(nblk - b, int(rng.integers(1, 5)) * max(1, 1024 // in_size))
             seg = np.ascontiguousarray(x[b * in_size:(b + n) * in_size])
             y = np.zeros(n * out_size, dtype=np.complex128)
@@ -99,11 +100,13 @@ def test_random_walk_through_the_wdsp_names(qh, oracle, seed):
             r, nerr = o.fexchange0(seg)
             assert nerr == 0
             got.append(y); want.append(r)
+            per.append("%d:%.1e/%.1e" % (b, float(np.abs(y - r).max()), float(np.abs(r).max())))
             b += n
         y, r = np.concatenate(got), np.concatenate(want)
         assert np.all(np.isfinite(r))
         if np.abs(r).max() > 1e-9:                       # (a squelch or a panel setting may keep the channel quiet for the whole walk)
-            assert rel_rms(y, r) < (1e-4 if lms else 1e-6), (seed, (in_size, dsp_size, in_rate, dsp_rate, out_rate), rel_rms(y, r))
+            assert rel_rms(y, r) < (1e-4 if lms else 1e-6), (seed, (in_size, dsp_size, in_rate, dsp_rate, out_rate), rel_rms(y, r), log,
+                                                              "first block of the call: largest error / largest reference sample", per)
         if in_rate // dsp_rate in (1, 2, 4, 8, 16) and out_rate == dsp_rate:
             assert lib.qh_wdsp_graph_launches() > launches0      # (a resampler at either end keeps host-side state: plain launches)
     finally:
