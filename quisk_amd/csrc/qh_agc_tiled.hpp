@@ -127,13 +127,20 @@ static __global__ __launch_bounds__(256) void agc_prep_kernel(const double2 *buf
     }
     __syncthreads();
     for (int b = wave; b < M / 64; b += 4) {
+        // prefix and suffix maxima of the 64 magnitudes (all >= 0, so the 0 a DPP move reads where it has no source is the identity):
+        // inside the rows of 16 by row shifts, across them by row broadcasts (prefix) and three lane reads (suffix)
         const double v = m[b * 64 + lane];
         double p = v, s = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double tp = __shfl_up(p, d, 64), ts = __shfl_down(s, d, 64);
-            if (lane >= d) p = fmax(p, tp);
-            if (lane + d < 64) s = fmax(s, ts);
+        p = fmax(p, dpp_fetch_d<0x111, 0xf>(p)); p = fmax(p, dpp_fetch_d<0x112, 0xf>(p));
+        p = fmax(p, dpp_fetch_d<0x114, 0xf>(p)); p = fmax(p, dpp_fetch_d<0x118, 0xf>(p));
+        p = fmax(p, dpp_fetch_d<0x142, 0xa>(p)); p = fmax(p, dpp_fetch_d<0x143, 0xc>(p));
+        s = fmax(s, dpp_fetch_d<0x101, 0xf>(s)); s = fmax(s, dpp_fetch_d<0x102, 0xf>(s));
+        s = fmax(s, dpp_fetch_d<0x104, 0xf>(s)); s = fmax(s, dpp_fetch_d<0x108, 0xf>(s));
+        {
+            const double r1 = lane_bcast(s, 16), r2 = lane_bcast(s, 32), r3 = lane_bcast(s, 48);
+            const double t2 = fmax(r2, r3), t1 = fmax(r1, t2);
+            const int row = lane >> 4;
+            s = fmax(s, row == 0 ? t1 : row == 1 ? t2 : row == 2 ? r3 : 0.0);
         }
         P[b * 64 + lane] = p; S[b * 64 + lane] = s;
     }
