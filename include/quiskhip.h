@@ -169,7 +169,10 @@ int qh_rxa_SetRXACTCSSRun(qh_rxa *e, int ch, int run);
  *   d_in  : device pointer, [nch][in_stride] interleaved complex double, nblk*dsp_insize samples used
  *   d_out : device pointer, [nch][out_stride] interleaved complex double, nblk*dsp_outsize samples written
  * Strides are in complex samples.  Filter/NCO state is carried to the next call exactly as the
- * reference carries it from block to block.  Asynchronous on the engine's stream. */
+ * reference carries it from block to block.  Asynchronous on the engine's stream.
+ * The output rows may lie over the input rows (a caller that works in place): the engine then writes the output in a last pass
+ * behind every read of the input instead of from its last filter's store -- the same samples within rounding (1e-11), decided by
+ * the extent of the rows themselves (first sample of the first row to last sample of the last), not by where the matrices lie. */
 int qh_rxa_process(qh_rxa *e, const double *d_in, long long in_stride, double *d_out, long long out_stride, int nblk);
 
 /* Same with host buffers (synchronous; pageable memory; includes the PCIe copies). */
