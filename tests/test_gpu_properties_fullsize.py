@@ -252,6 +252,7 @@ def test_form_does_not_depend_on_where_the_buffers_lie(qh):
             ec.synchronize()
             got[:, :nb * 256] = yc[:, :nb * 256]
             xc.copy_(x)                                     # (the call wrote over the head of its own input: put it back)
+            torch.cuda.synchronize()                        # (... on torch's stream: the engine's own does not wait for it)
         else:
             ec.process_ptr(xc.data_ptr() + 16 * k * nb * 1024, n_in, got.data_ptr() + 16 * k * nb * 256, n_out, nb)
     ec.synchronize()
