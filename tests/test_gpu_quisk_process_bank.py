@@ -223,7 +223,7 @@ def test_pipelined_calls_whose_piece_layout_changes(qh):
             for n, pieces in plan:
                 bank.set_pieces(pieces)
                 cap = bank.out_capacity(n) + 64
-                outs.append(torch.zeros((nch, cap), dtype=torch.complex128, device=dev))
+                outs.append(torch.empty((nch, cap), dtype=torch.complex128, device=dev))      # (no fill: it would run on torch's stream, beside the bank's)
                 got.append(bank.process_ptr(x[:, pos:].data_ptr(), x.shape[1], n, outs[-1].data_ptr(), cap))
                 pos += n
             bank.synchronize()
