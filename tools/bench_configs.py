@@ -413,7 +413,7 @@ def driver_legs(torch, qh, dev, emit):
     leg("config4", config4, 20.0, "ms_graph_replay", lambda r: ("osfir_kernel<f64,4096,D=4,OUTMIX> front (shared by USB / AM / FM)", r.get("front_ms")))
     leg("config5", config5, 8.0, "fused_ms", lambda r: ("hb45_cascade_kernel<float,4> x 2 (4 + 4 stages)", r["fused_cascade_only_ms"]))
     # the headline chain with WDSP's AGC state machine on (not a BASELINE configuration: config 2 fixes the gain)
-    leg("config2_agc_on", config2_agc, 20.0, "ms", lambda r: ("agc_bounds_kernel (the level detector's state at the tile boundaries)", None))
+    leg("config2_agc_on", config2_agc, 20.0, "ms", lambda r: ("osfir front kernel as in config 2; of the AGC's seven kernels agc_lanes_kernel / agc_apply_kernel (2.0 ms each of ~9.6)", None))
     try:
         r = quisk_native(torch, qh, dev)
         emit("quisk_native", {"workload": r["config"], "samples_per_step": r["samples_per_step"], "algorithmic_bytes_per_sample": 20.0,
