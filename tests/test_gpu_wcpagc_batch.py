@@ -159,12 +159,15 @@ def test_time_tiles_replayed_from_a_graph(qh):
     assert np.array_equal(outs[0], want)
 
 
-def test_boundary_pass_over_super_segments(qh, oracle, monkeypatch):
+@pytest.mark.parametrize("rounds,warm", [(3, 0), (1, 0), (0, 2), (0, 0)], ids=["rounds-3", "rounds-1", "in-order-only-warm-2", "in-order-only"])
+def test_boundary_pass_over_super_segments(qh, oracle, monkeypatch, rounds, warm):
     """The boundary pass of a long call as eight super-segments walked at once (QH_AGC_SEGS; the engine picks the number by call length):
-    each from the call's start state behind a warm-up, the ones whose warm-up did not end on the true trajectory walked again.  Bursts
-    and fades make that happen; the result is the sample loop's either way."""
+    each from the call's start state (behind a warm-up if asked for), the ones that did not start on the true trajectory walked again --
+    by the parallel repair rounds (three by default), by one round and the in-order kernel behind it for what a single round leaves, or
+    by the in-order kernel alone (round 4's form).  Bursts and fades make that happen; the result is the sample loop's either way."""
     monkeypatch.setenv("QH_AGC_SEGS", "8")
-    monkeypatch.setenv("QH_AGC_WARM", "2")                  # a warm-up of 2 attack windows instead of 400: segments must miss
+    monkeypatch.setenv("QH_AGC_WARM", str(warm))            # (round 4 ran 400 attack windows of warm-up; 2: segments must miss)
+    monkeypatch.setenv("QH_AGC_ROUNDS", str(rounds))
     nch, nblk = 4, 700
     x = _input(nch, nblk, seed=41)
     calls = [300, 2, 398]
