@@ -338,19 +338,23 @@ __device__ __forceinline__ bool agc_walk(AgcLane &s, const AgcWalk &w, int j0, i
     double rq[kAgcAhead];
 #pragma unroll
     for (int u = 0; u < kAgcAhead; u++) rq[u] = j0 + u * 64 + lane < w.n ? w.in0[j0 + u * 64 + lane] : 0.0;
+    // the next tile boundary at or behind `from` (j0, from and L are multiples of 64: the chunks land on it), kept by addition -- a
+    // division per chunk is forty instructions of a walk that is one wavefront's instruction stream
+    int tile = ((from > j0 ? from : j0) + w.L - 1) / w.L, nextb = tile * w.L;
     for (int base0 = j0; base0 < j1; base0 += 64 * kAgcAhead) {
 #pragma unroll
         for (int u = 0; u < kAgcAhead; u++) {
             const int base = base0 + u * 64;
             if (base >= j1) break;
             const int cnt = w.n - base < 64 ? w.n - base : 64;
-            if (base >= from && base % w.L == 0) {
-                double *o = w.bo + (long long)(base / w.L) * 8;
+            if (base == nextb) {
+                double *o = w.bo + (long long)tile * 8;
                 if (AGAIN && base > j0) {
                     const double mine[5] = { s.volts, s.save_volts, (double)s.hc, (double)s.decay_type, (double)s.st };
                     if (!agc_state_differs(mine, o)) return true;        // (uniform: every lane holds the same state and reads the same words)
                 }
                 if (lane == 0) agc_put(o, s);
+                tile++; nextb += w.L;
             }
             const double r = rq[u];
             const int nx = base + 64 * kAgcAhead + lane;
