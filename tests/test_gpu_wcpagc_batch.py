@@ -185,6 +185,26 @@ def test_boundary_pass_over_super_segments(qh, oracle, monkeypatch, rounds, warm
         assert rel_rms(outs[0][c], outs[1][c]) < 1e-10, (c, rel_rms(outs[0][c], outs[1][c]))
 
 
+def test_sixteen_segments_of_a_full_length_call_in_all_four_modes(qh):
+    """One call of 2^20 detector samples per channel (the length of the driver's AGC-on leg: the engine itself cuts it into sixteen
+    super-segments, nothing forced), eight channels in modes long / slow / med / fast -- the hang states and the fast decay among the
+    regimes the walks scan -- on bursts, a fade, silence and a click: the time tiles with their parallel repair rounds against the
+    sample loop, and the rounds did have segments to walk again."""
+    nch, nblk = 8, 4096
+    x = _input(nch, nblk, seed=77)
+    outs = {}
+    for form in (0, 1):
+        e = _engine(qh, nch, [1, 2, 3, 4], form)
+        outs[form] = e.process_host(x)
+        if form == 0:
+            print("segments walked again: %d, tiles re-run: %d" % (e.agc_segments_rerun(), e.agc_repairs()))
+            assert e.agc_segments_rerun() > 0 and e.agc_repairs() == 0
+    scale = np.abs(outs[1]).max()
+    assert scale > 0.1
+    for c in range(nch):
+        assert rel_rms(outs[0][c], outs[1][c]) < 1e-10, (c, rel_rms(outs[0][c], outs[1][c]))
+
+
 @pytest.mark.parametrize("dsp_rate,attack_ms,mode", [(96000, 1, 3), (48000, 5, 2), (48000, 10, 4)], ids=["96k", "attack-5ms", "attack-10ms"])
 def test_time_tiles_at_other_window_lengths(qh, oracle, dsp_rate, attack_ms, mode):
     """The attack window (4 x rate x tau_attack samples: 384 at 96 kHz, 960 and 1920 with longer attacks set ahead of the stream) sizes
