@@ -382,6 +382,23 @@ template <bool INV, typename C> struct FftSplit4096 {
         stockham_butterfly<4096, 16, 256, INV, C, LEAN>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
     }
 
+    // The same with the two passes' twiddles fetched from the table (L1-resident) right where they are used instead of riding through
+    // the earlier passes in eight registers: for callers whose registers are full of something else (pan16k_kernel).  `twp` must be
+    // opaque to the compiler at the call (asm volatile) or the loads are hoisted out of the caller's loop again.
+    static __device__ __forceinline__ void run_at_late_tw(C (&x)[16], void *lds_raw, const C *twp, int j)
+    {
+        static_assert(!kSwizzle, "padded image");
+        T *lds = reinterpret_cast<T *>(lds_raw);
+        Dft<16, INV, C>::run(x);
+        exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
+        const C wa = pass_twiddle<16, INV>(twp, j);
+        const int base = stockham_butterfly<4096, 16, 16, INV, C, true>(x, j, wa);
+        __syncthreads();
+        exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
+        const C wb = pass_twiddle<256, INV>(twp + 16, j);
+        stockham_butterfly<4096, 16, 256, INV, C, true>(x, j, wb);
+    }
+
     // The transform WITHOUT the stage that would combine the D decimated sequences x[D m + a] (plan 16 x 16 x 16/D x [D], the last
     // radix-D pass left out): register i + (16/D) a ends up with bin j + 256 i of the (4096/D)-point transform of phase a.  A
     // decimating overlap-save stage wants exactly that: its D-fold aliasing sum over X[k + (4096/D) q] M[k + (4096/D) q] equals

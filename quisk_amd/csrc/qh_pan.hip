@@ -176,8 +176,11 @@ __global__ __launch_bounds__(NT, QH_PAN_WAVES) void pan_spectrum_kernel(const do
 #ifndef QH_PAN16K_GROUPS
 #define QH_PAN16K_GROUPS 4
 #endif
+#ifndef QH_PAN_LOADS_AHEAD
+#define QH_PAN_LOADS_AHEAD 1
+#endif
 // -DQH_PAN_TRACE=<thread> (experiment builds, tools/dbg/pan_trace.py): that thread of workgroup 0 leaves the shader clock at the phase
-// boundaries of its blocks in qh_pan_trace[block][phase].  (The stamps are stores: a wait that follows them counts their
+// boundaries of its blocks in qh_pan_trace[block][phase] (pan16k_kernel and panfir16k_kernel: whichever ran last).  (The stamps are stores: a wait that follows them counts their
 // acknowledgement too -- the phases up to the transform are trustworthy, the loop edge is not.)
 #ifdef QH_PAN_TRACE
 __device__ unsigned long long qh_pan_trace[64 * 8];
@@ -185,7 +188,24 @@ __device__ unsigned long long qh_pan_trace[64 * 8];
 #else
 #define PAN_STAMP(ph) do { } while (0)
 #endif
-template <int G> constexpr int pan16k_lds() { return G * FftSplit4096<false, double2>::kLdsBytes; }
+// LDS of pan16k_kernel: the G transform images, then what waits there between blocks so that it does not ride through the transform in
+// registers: exp(-2 pi i t / N) by t (the window's phasor, and by two squarings the last pass's twiddle), the middle pass's sixteen
+// twiddles, and every lane's S-meter sum
+template <int G> constexpr int pan16k_lds() { return G * FftSplit4096<false, double2>::kLdsBytes + 256 * 16 + 256 * G * 8; }      // G = 2: 80 KB, two per CU
+constexpr int panfir16k_lds() { return pan16k_lds<4>() + 16 * 16; }
+// a wave-uniform double as two scalar registers
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// The register budget (1024 lanes on a CU = 128 registers each) is the kernel: the block's 16384 samples are 64 registers per lane, the
+// |X| sums of the workgroup's block range 32 more, and whatever else is live through the transform comes out of the last 32 -- round 5's
+// form kept the window's phasor, both passes' twiddles, the S-meter sum and 64-bit load addresses there, the compiler spilled 28
+// registers (16 of them |X| sums, stored and fetched again every block: 0.6 bytes of scratch traffic per input byte, profiles/r05_g_c3_pmc.json).
+// Here those wait in LDS between their uses (the 16 KB the four images leave) or are formed again from `t`, and the loads take a scalar
+// base per strip and one 32-bit lane offset.
 template <int G>
 __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, long long in_stride, int nblk, int nsplit,
                                                          const double2 *tw, double *partial, double *partial_m2,
@@ -195,51 +215,75 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
     using S = FftSplit4096<false, C>;
     constexpr int M = 4096, N = 16384, E = 16, RP = 4 / G, MJ = 16 / G;      // RP workgroups per block, MJ values of m per thread
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double wsum[4 * G];
-    const int T = threadIdx.x, s = T >> 8, t = T & 255;
+    const int T = threadIdx.x, t = T & 255;
+    const int s = __builtin_amdgcn_readfirstlane(T >> 8);               // residue group: the same for a whole wavefront
     const int id = blockIdx.x, grp = id / (8 * RP), rp = (id / 8) % RP, unit = grp * 8 + id % 8;
     if (unit >= nsplit * nch) return;
     const int rbase = rp * G, r = rbase + s;
     const int split = unit % nsplit, ch = unit / nsplit;
     const int per = (nblk + nsplit - 1) / nsplit;
     const int b0 = split * per, b1 = b0 + per < nblk ? b0 + per : nblk;
-    const typename S::Tw twf = FftRR<M, false, C>::load_at(tw, t);
     void *image = smem + (size_t)s * S::kLdsBytes;                      // this group's transform image
-    // e_j = exp(-2 pi i m_j / N), m_j = t + 256 (MJ s + j): e_0 and a step of 256
-    C e0, estep;
-    sincospi(-2.0 * (double)(t + 256 * MJ * s) / (double)N, &e0.y, &e0.x);
+    C *et = reinterpret_cast<C *>(smem + (size_t)G * S::kLdsBytes);     // exp(-2 pi i t / N), t < 256
+    double *m2s = reinterpret_cast<double *>(et + 256) + T;             // this lane's S-meter sum
+    // exp(-2 pi i k / 256), k < 16, the middle pass's twiddles: in the two pad scalars behind rows 240 .. 255 of the last image (the
+    // transforms never touch the pads, and the groups' exchange area, which is laid over the images, ends before these rows)
+    static_assert(S::kPad == 2 && (G * 8) * 256 * 16 <= (G - 1) * S::kLdsBytes + 240 * (16 + S::kPad) * 8, "the pads used lie behind the exchange area");
+    double *tap = reinterpret_cast<double *>(smem + (size_t)(G - 1) * S::kLdsBytes) + 240 * (16 + S::kPad) + 16;
+    if (T < 256) { C e; sincospi(-2.0 * (double)T / (double)N, &e.y, &e.x); et[T] = e; }
+    if (T < 16) *reinterpret_cast<C *>(tap + (16 + S::kPad) * T) = tw[T];
+    *m2s = 0.0;
+    // e_j = exp(-2 pi i m_j / N), m_j = t + 256 (MJ s + j): the table's entry times the group's phasor (scalar registers), then steps of 256
+    C es;
+    sincospi(-2.0 * (double)(256 * MJ * s) / (double)N, &es.y, &es.x);
+    es.x = uniform_f64(es.x); es.y = uniform_f64(es.y);
+    C estep;
     estep.x = 0.99518472667219693; estep.y = -0.098017140329560604;            // exp(-2 pi i 256 / N) = exp(-i pi / 32): literals stay out of the vector registers
     const PanBand pb = band[ch];
-    double m2 = 0.0;
-    unsigned whole = 0, part = 0;           // bit i: bin i of this lane counts fully / with weight frac
+    unsigned wp = 0;                        // bit i: bin i of this lane counts fully in the S-meter sum, bit 16 + i: with weight frac
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const int bin = 4 * (t + NT * i) + r;
         const int sb = bin >= N / 2 ? bin - N : bin;
         if (pb.valid) {
-            if (sb >= pb.first && sb < pb.first + pb.nwhole) whole |= 1u << i;
-            else if (sb == pb.first + pb.nwhole) part |= 1u << i;
+            if (sb >= pb.first && sb < pb.first + pb.nwhole) wp |= 1u << i;
+            else if (sb == pb.first + pb.nwhole) wp |= 0x10000u << i;
         }
     }
     // the S-meter passband is a few bins wide: almost every wavefront holds none of them and skips that sum
-    const bool in_band = __ballot((whole | part) != 0) != 0ull;
+    const bool in_band = __ballot(wp != 0) != 0ull;
     // |X| sums of the workgroup's block range: sixteen registers per lane (read-modify-write of `partial` once per block, even
-    // laid out so that a wavefront's accesses coalesce, was 0.19 of this kernel's 0.64 ms on config 3 -- the sums spill less than the
-    // sixteen slot addresses did)
+    // laid out so that a wavefront's accesses coalesce, was 0.19 of this kernel's 0.64 ms on config 3)
     double racc[E];
 #pragma unroll
     for (int i = 0; i < E; i++) racc[i] = 0.0;
+    __syncthreads();                        // the tables are written
     for (int blk = b0; blk < b1; blk++) {
-        const C *x = in + (long long)ch * in_stride + (long long)blk * N + (t + 256 * MJ * s);
+        const C *xb = in + (long long)ch * in_stride + (long long)blk * N + 256 * MJ * s;
+        asm volatile("" : "+s"(xb));        // a scalar base and the lane's 32-bit offset, not a 64-bit address per lane and strip
         // The sixteen results of a thread change hands in TWO rounds of eight, real and imaginary part together (128-bit accesses):
         // round h takes j = h MJ/2 .. h MJ/2 + MJ/2 - 1.  [group][ii = (MJ/2) s + jj][t] complex, laid over the transform images.  (Round
         // 4's form sent all sixteen real parts, then all sixteen imaginary parts, and carried the imaginary parts through the first
         // pass in 32 registers of a kernel that spills.)
         C *xc = reinterpret_cast<C *>(smem);
-        C e = e0;
-        asm volatile("" : "+v"(e.x), "+v"(e.y));
+        int tt = t;
+        asm volatile("" : "+v"(tt));        // (what is derived from t below is derived in the loop: addresses hoisted out of it are spilled)
+        C e = cmul(et[tt], es);
         C u[E];
         PAN_STAMP(6);
+        // Every load of a round -- with G = 4 of the block: sixteen, in the 64 registers the transform's values take later -- is asked for
+        // before the first is used: one memory latency per block in the open, not one per j (with one workgroup on the CU nothing else
+        // runs while it waits).  (Round 5 measured this form slower: its sums were already spilling.)
+        constexpr int LR = QH_PAN_LOADS_AHEAD ? (G == 4 ? 1 : 4) : MJ;     // rounds of loads per block (G = 2: eight loads a round beside half the transform's values)
+        constexpr int LJ = MJ / LR;                                         // values of j per round of loads
+        C xx[LJ][4];
+        if (LR == 1) {                      // (ahead of the barrier too: the loads do not touch LDS)
+#pragma unroll
+            for (int k = 0; k < LJ; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * k + M * q)[(unsigned)tt];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             __syncthreads();                // the area is free: the previous block's transform / the first round's values have been read out
@@ -247,7 +291,14 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 #pragma unroll
             for (int jj = 0; jj < MJ / 2; jj++) {
                 const int j = h * (MJ / 2) + jj;
-                const C x0 = x[256 * j], x1 = x[256 * j + M], x2 = x[256 * j + 2 * M], x3 = x[256 * j + 3 * M];
+                if (LR > 1 && j % LJ == 0) {
+#pragma unroll
+                    for (int k = 0; k < LJ; k++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * (j + k) + M * q)[(unsigned)tt];         // scalar base
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const C x0 = xx[j % LJ][0], x1 = xx[j % LJ][1], x2 = xx[j % LJ][2], x3 = xx[j % LJ][3];
                 // Hanning window 0.5 - 0.5 cos(2 pi n / N) at n = m + M q (quisk.c:6008): cos(a + pi q / 2) = cos a, -sin a, -cos a, sin a
                 // with e = (cos a, -sin a)
                 const double g0 = __builtin_fma(-0.5, e.x, 0.5), g2 = __builtin_fma(0.5, e.x, 0.5);
@@ -267,7 +318,7 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
                     o[G - 1] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));        // a1 + i c1
                 }
 #pragma unroll
-                for (int g = 0; g < G; g++) xc[(g * 8 + (MJ / 2) * s + jj) * 256 + t] = o[g];
+                for (int g = 0; g < G; g++) xc[(g * 8 + (MJ / 2) * s + jj) * 256 + tt] = o[g];
                 e = cmul(e, estep);
                 // one j at a time -- four loads in flight.  Measured slower: all loads at once; the loads of j + 1 issued ahead of j's arithmetic
                 __builtin_amdgcn_sched_barrier(0);
@@ -277,23 +328,36 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
             if (h == 1) PAN_STAMP(2);
             // group s takes element i = MJ s' + j of its transform from thread (s', t): slot ii = (MJ/2) s' + jj of its own plane
 #pragma unroll
-            for (int ii = 0; ii < 8; ii++) u[MJ * (ii / (MJ / 2)) + h * (MJ / 2) + ii % (MJ / 2)] = xc[(s * 8 + ii) * 256 + t];
+            for (int ii = 0; ii < 8; ii++) u[MJ * (ii / (MJ / 2)) + h * (MJ / 2) + ii % (MJ / 2)] = xc[(s * 8 + ii) * 256 + tt];
         }
         __syncthreads();                    // everybody has taken its elements: the images may be written
-        // (the pass twiddles' powers are loop invariant: left alone, the compiler computes all 28 of them once, ahead of the
-        // block loop, and spills them)
-        typename S::Tw twb = twf;
-        asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
         PAN_STAMP(3);                       // the exchange between the residue groups
-        S::template run_at<true>(u, image, twb, t);         // (twiddle powers in three registers: the sixteen |X| sums ride through the transform)
+        // The 4096-point transform (FftSplit4096::run_at's three passes) with each pass's twiddle fetched where it is used: the middle
+        // pass's from the sixteen-entry table, the last pass's exp(-2 pi i t / 4096) as the fourth power of the window table's entry.
+        {
+            using T8 = double;
+            T8 *lds = reinterpret_cast<T8 *>(image);
+            Dft<16, false, C>::run(u);
+            S::template exchange<1, 256 + 16 * S::kPad>(u, lds, (16 + S::kPad) * tt, S::sphys(tt));
+            const int base = stockham_butterfly<4096, 16, 16, false, C, true>(u, tt, *reinterpret_cast<const C *>(tap + (16 + S::kPad) * (tt & 15)));
+            __syncthreads();
+            S::template exchange<16 + S::kPad, 256 + 16 * S::kPad>(u, lds, S::sphys(base), S::sphys(tt));
+            C wb = et[tt];
+            wb = cmul(wb, wb);
+            wb = cmul(wb, wb);
+            stockham_butterfly<4096, 16, 256, false, C, true>(u, tt, wb);
+        }
         PAN_STAMP(4);                       // the 4096-point transform
+        double m2 = 0.0;
+        if (in_band) m2 = *m2s;
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
             racc[i] += sqrt_pow(pw2);       // cabs(): no overflow / underflow concern at +-2^31 * N full scale
-            if (in_band) m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
+            if (in_band) m2 += ((wp >> i) & 1u) ? pw2 : (((wp >> (16 + i)) & 1u) ? pb.frac * pw2 : 0.0);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        if (in_band) *m2s = m2;
         PAN_STAMP(5);                       // |X| and the sums
     }
     // partial[split][ch][r][t + 256 i] for bin = 4 (t + 256 i) + r (pan_reduce_kernel undoes the order): coalesced stores; a block range
@@ -302,7 +366,10 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 #pragma unroll
     for (int i = 0; i < E; i++) pp[256 * i] = racc[i];
     // S-meter partial: lanes -> wave -> group of four waves (one r), fixed order, in the layout of pan_spectrum_kernel
+    double m2 = *m2s;
     for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
+    __syncthreads();                        // (the last block's transform has left the images)
+    double *wsum = reinterpret_cast<double *>(smem);
     if ((T & 63) == 0) wsum[T >> 6] = m2;
     __syncthreads();
     if (t == 0) {
@@ -335,7 +402,6 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
     using S = FftSplit4096<false, C>;
     constexpr int M = 4096, N = 16384, E = 16, G = 4, MJ = 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double wsum[4 * G];
     const int T = threadIdx.x, t = T & 255;
     const int s = __builtin_amdgcn_readfirstlane(T >> 8);               // residue group: the same for a whole wavefront
     const int id = blockIdx.x, grp = id / 8, unit = grp * 8 + id % 8;
@@ -344,108 +410,150 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
     const int split = unit % nsplit, ch = unit / nsplit;
     const int per = (nblk + nsplit - 1) / nsplit;
     const int b0 = split * per, b1 = b0 + per < nblk ? b0 + per : nblk;
-    const typename S::Tw twf = FftRR<M, false, C>::load_at(tw, t);
     double *xch = reinterpret_cast<double *>(smem);                     // exchange area [group][i][t] scalars: 128 KB
     C *fold = reinterpret_cast<C *>(smem + 4 * 16 * 256 * 8);           // [group][t] complex: the last 16 KB of the four images
     void *image = smem + (size_t)s * S::kLdsBytes;                      // this group's transform image
-    C e0, estep;
-    sincospi(-2.0 * (double)(t + 256 * MJ * s) / (double)N, &e0.y, &e0.x);
+    // (the tables behind the images and the register budget: see pan16k_kernel)
+    C *et = reinterpret_cast<C *>(smem + (size_t)G * S::kLdsBytes);     // exp(-2 pi i t / N), t < 256
+    C *ta = et + 256;                                                   // exp(-2 pi i k / 256), k < 16
+    double *m2s = reinterpret_cast<double *>(ta + 16) + T;              // this lane's S-meter sum
+    if (T < 256) { C e; sincospi(-2.0 * (double)T / (double)N, &e.y, &e.x); et[T] = e; }
+    if (T < 16) ta[T] = tw[T];
+    *m2s = 0.0;
+    C es;
+    sincospi(-2.0 * (double)(256 * MJ * s) / (double)N, &es.y, &es.x);
+    es.x = uniform_f64(es.x); es.y = uniform_f64(es.y);
+    C estep;
     estep.x = 0.99518472667219693; estep.y = -0.098017140329560604;    // exp(-2 pi i 256 / N)
     const PanBand pb = band[ch];
-    double m2 = 0.0;
-    unsigned whole = 0, part = 0;
+    unsigned wp = 0;
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const int bin = 4 * (t + NT * i) + r;
         const int sb = bin >= N / 2 ? bin - N : bin;
         if (pb.valid) {
-            if (sb >= pb.first && sb < pb.first + pb.nwhole) whole |= 1u << i;
-            else if (sb == pb.first + pb.nwhole) part |= 1u << i;
+            if (sb >= pb.first && sb < pb.first + pb.nwhole) wp |= 1u << i;
+            else if (sb == pb.first + pb.nwhole) wp |= 0x10000u << i;
         }
     }
-    const bool in_band = __ballot((whole | part) != 0) != 0ull;
-    // neighbours in the exchange area: bin 4 m + r + 1 is residue r + 1 at m (r = 3: residue 0 at m + 1), bin 4 m + r - 1 residue r - 1
-    // at m (r = 0: residue 3 at m - 1); m = t + 256 i is linear in the [i][t] rows, so the two ends are one address step -- except
-    // for the two bins where the spectrum wraps round
-    const int up0 = s < 3 ? ((s + 1) * 16) * 256 + t : t + 1;
-    const int dn0 = s > 0 ? ((s - 1) * 16) * 256 + t : (48 * 256) + t - 1;
+    const bool in_band = __ballot(wp != 0) != 0ull;
     double racc[E];
 #pragma unroll
     for (int i = 0; i < E; i++) racc[i] = 0.0;
+    __syncthreads();                        // the tables are written
     for (int blk = b0; blk < b1; blk++) {
-        const C *x = in + (long long)ch * in_stride + (long long)blk * N + (t + 256 * MJ * s);
-        double oim[16];
-        double *xw = xch + (MJ * s) * 256 + t;
-        const double *xr = xch + (s * 16) * 256 + t;
-        C e = e0;
-        asm volatile("" : "+v"(e.x), "+v"(e.y));
-        __syncthreads();                    // the images and the fold rows are free
+        const C *xb = in + (long long)ch * in_stride + (long long)blk * N + 256 * MJ * s;
+        asm volatile("" : "+s"(xb));
+        C *xc = reinterpret_cast<C *>(smem);
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        C e = cmul(et[tt], es);
+        C u[E];
+        // the block's four strips, the radix-4 combination over them, W_N^(m r), and the change of hands between the residue groups in two
+        // rounds of eight complex values (pan16k_kernel's, without the window)
+        constexpr int LR = QH_PAN_LOADS_AHEAD ? 1 : MJ, LJ = MJ / LR;
+        C xx[LJ][4];
+        PAN_STAMP(6);
+        if (LR == 1) {
 #pragma unroll
-        for (int j = 0; j < MJ; j++) {
-            const C v0 = x[256 * j], v1 = x[256 * j + M], v2 = x[256 * j + 2 * M], v3 = x[256 * j + 3 * M];
-            const C a0 = cadd(v0, v2), a1 = csub(v0, v2), c0 = cadd(v1, v3), c1 = csub(v1, v3);
-            const C e2 = cmul(e, e);
-            C o[G];
-            o[0] = cadd(a0, c0);
-            o[1] = cmul(mk<double>(a1.x + c1.y, a1.y - c1.x), e);
-            o[2] = cmul(csub(a0, c0), e2);
-            o[3] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));
+            for (int k = 0; k < LJ; k++)
 #pragma unroll
-            for (int g = 0; g < G; g++) { xw[(g * 16 + j) * 256] = o[g].x; oim[G * j + g] = o[g].y; }
-            e = cmul(e, estep);
+                for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * k + M * q)[(unsigned)tt];
             __builtin_amdgcn_sched_barrier(0);
         }
-        C u[E];
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < E; i++) u[i].x = xr[i * 256];
-        __syncthreads();
+        for (int h = 0; h < 2; h++) {
+            __syncthreads();                // the images, the fold rows and the first round's values are free
+            if (h == 0) PAN_STAMP(0);
 #pragma unroll
-        for (int j = 0; j < MJ; j++)
+            for (int jj = 0; jj < MJ / 2; jj++) {
+                const int j = h * (MJ / 2) + jj;
+                if (LR > 1 && j % LJ == 0) {
 #pragma unroll
-            for (int g = 0; g < G; g++) xw[(g * 16 + j) * 256] = oim[G * j + g];
-        __syncthreads();
+                    for (int k = 0; k < LJ; k++)
 #pragma unroll
-        for (int i = 0; i < E; i++) u[i].y = xr[i * 256];
+                        for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * (j + k) + M * q)[(unsigned)tt];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const C v0 = xx[j % LJ][0], v1 = xx[j % LJ][1], v2 = xx[j % LJ][2], v3 = xx[j % LJ][3];
+                const C a0 = cadd(v0, v2), a1 = csub(v0, v2), c0 = cadd(v1, v3), c1 = csub(v1, v3);
+                const C e2 = cmul(e, e);
+                C o[G];
+                o[0] = cadd(a0, c0);
+                o[1] = cmul(mk<double>(a1.x + c1.y, a1.y - c1.x), e);
+                o[2] = cmul(csub(a0, c0), e2);
+                o[3] = cmul(mk<double>(a1.x - c1.y, a1.y + c1.x), cmul(e2, e));
+#pragma unroll
+                for (int g = 0; g < G; g++) xc[(g * 8 + (MJ / 2) * s + jj) * 256 + tt] = o[g];
+                e = cmul(e, estep);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (h == 1) PAN_STAMP(1);
+            __syncthreads();
+            if (h == 1) PAN_STAMP(2);
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) u[MJ * (ii / (MJ / 2)) + h * (MJ / 2) + ii % (MJ / 2)] = xc[(s * 8 + ii) * 256 + tt];
+        }
         __syncthreads();
-        typename S::Tw twb = twf;
-        asm volatile("" : "+v"(twb.a[0].x), "+v"(twb.a[0].y), "+v"(twb.b.x), "+v"(twb.b.y));
-        S::run_at(u, image, twb, t);        // u[i] = X[4 (t + 256 i) + r], unwindowed
+        PAN_STAMP(3);
+        {
+            double *lds = reinterpret_cast<double *>(image);
+            Dft<16, false, C>::run(u);
+            S::template exchange<1, 256 + 16 * S::kPad>(u, lds, (16 + S::kPad) * tt, S::sphys(tt));
+            const int base = stockham_butterfly<4096, 16, 16, false, C, true>(u, tt, ta[tt & 15]);
+            __syncthreads();
+            S::template exchange<16 + S::kPad, 256 + 16 * S::kPad>(u, lds, S::sphys(base), S::sphys(tt));
+            C wb = et[tt];
+            wb = cmul(wb, wb);
+            wb = cmul(wb, wb);
+            stockham_butterfly<4096, 16, 256, false, C, true>(u, tt, wb);       // u[i] = X[4 (t + 256 i) + r], unwindowed
+        }
+        PAN_STAMP(4);
         // ---- the FIR's share: sum of the lane's sixteen products (one class k mod 512), lanes t and t + 128 joined below
 #ifndef QH_PANFIR_NOFIR        // (tools/ab_bench.py attribution builds: timing only)
         {
-            const C *hh = firH + r * M + t;
-            C acc = cmul(u[0], hh[0]);
+            const C *hh = firH + r * M;     // scalar
+            asm volatile("" : "+s"(hh));
+            C acc = cmul(u[0], hh[(unsigned)tt]);
 #pragma unroll
             for (int i = 1; i < E; i++) {
-                const C z = cmul(u[i], hh[256 * i]);
+                const C z = cmul(u[i], (hh + 256 * i)[(unsigned)tt]);
                 acc.x += z.x; acc.y += z.y;
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                // every group has read its transform out of its image
-            fold[s * 256 + t] = acc;
+            fold[s * 256 + tt] = acc;
         }
 #else
         __syncthreads();
 #endif
+        PAN_STAMP(7);
         // ---- the window in the frequency domain: real parts, then imaginary parts, through the exchange area
 #ifndef QH_PANFIR_NOHANN
-        double *own = xch + (s * 16) * 256 + t;
+        // neighbours in the exchange area: bin 4 m + r + 1 is residue r + 1 at m (r = 3: residue 0 at m + 1), bin 4 m + r - 1 residue r - 1
+        // at m (r = 0: residue 3 at m - 1); m = t + 256 i is linear in the [i][t] rows, so the two ends are one address step -- except
+        // for the two bins where the spectrum wraps round
+        const int up0 = s < 3 ? ((s + 1) * 16) * 256 + tt : tt + 1;
+        const int dn0 = s > 0 ? ((s - 1) * 16) * 256 + tt : (48 * 256) + tt - 1;
+        double *own = xch + (s * 16) * 256 + tt;
 #pragma unroll
         for (int i = 0; i < E; i++) own[i * 256] = u[i].x;
         __syncthreads();
 #ifndef QH_PANFIR_NOFIR
-        if (t < 128) {
-            const C a = fold[s * 256 + t], b = fold[s * 256 + t + 128];
-            yfold[((long long)ch * nblk + blk) * 512 + 4 * t + r] = mk<double>(a.x + b.x, a.y + b.y);
+        if (tt < 128) {
+            const C a = fold[s * 256 + tt], b = fold[s * 256 + tt + 128];
+            yfold[((long long)ch * nblk + blk) * 512 + 4 * tt + r] = mk<double>(a.x + b.x, a.y + b.y);
         }
 #endif
 #pragma unroll
         for (int i = 0; i < E; i++) {
             int ua = up0 + i * 256, da = dn0 + i * 256;
-            if (s == 3 && i == 15 && t == 255) ua = 0;                  // X[16384] = X[0]
-            if (s == 0 && i == 0 && t == 0) da = 63 * 256 + 255;        // X[-1] = X[16383]
+            if (s == 3 && i == 15 && tt == 255) ua = 0;                 // X[16384] = X[0]
+            if (s == 0 && i == 0 && tt == 0) da = 63 * 256 + 255;       // X[-1] = X[16383]
             u[i].x = __builtin_fma(0.5, u[i].x, -0.25 * (xch[ua] + xch[da]));
+            // (pinned: left alone, the sums sink to where |X| is formed, behind the imaginary parts' exchange, and the thirty-two
+            // neighbours wait for them in 64 registers)
+            asm volatile("" : "+v"(u[i].x));
         }
         __syncthreads();
 #pragma unroll
@@ -454,25 +562,31 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
 #pragma unroll
         for (int i = 0; i < E; i++) {
             int ua = up0 + i * 256, da = dn0 + i * 256;
-            if (s == 3 && i == 15 && t == 255) ua = 0;
-            if (s == 0 && i == 0 && t == 0) da = 63 * 256 + 255;
+            if (s == 3 && i == 15 && tt == 255) ua = 0;
+            if (s == 0 && i == 0 && tt == 0) da = 63 * 256 + 255;
             u[i].y = __builtin_fma(0.5, u[i].y, -0.25 * (xch[ua] + xch[da]));
+            asm volatile("" : "+v"(u[i].y));
         }
-#else
-        (void)up0; (void)dn0;
 #endif
+        double m2 = 0.0;
+        if (in_band) m2 = *m2s;
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
             racc[i] += sqrt_pow(pw2);
-            if (in_band) m2 += ((whole >> i) & 1u) ? pw2 : (((part >> i) & 1u) ? pb.frac * pw2 : 0.0);
+            if (in_band) m2 += ((wp >> i) & 1u) ? pw2 : (((wp >> (16 + i)) & 1u) ? pb.frac * pw2 : 0.0);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        if (in_band) *m2s = m2;
+        PAN_STAMP(5);
     }
     double *pp = partial + ((long long)split * nch + ch) * N + r * M + t;
 #pragma unroll
     for (int i = 0; i < E; i++) pp[256 * i] = racc[i];
+    double m2 = *m2s;
     for (int d = 32; d > 0; d >>= 1) m2 += __shfl_down(m2, d, 64);
+    __syncthreads();
+    double *wsum = reinterpret_cast<double *>(smem);
     if ((T & 63) == 0) wsum[T >> 6] = m2;
     __syncthreads();
     if (t == 0) {
@@ -1040,7 +1154,7 @@ int qh_pan_attach_fir(qh_pan *h, const double *taps, int ntaps, int decim)
         const std::vector<cd> tw = fft_twiddle_table(512);
         QH_HIP(hipMalloc((void **)&p.fir_tw512, tw.size() * 16));
         QH_HIP(hipMemcpy(p.fir_tw512, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
-        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panfir16k_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pan16k_lds<4>()));
+        QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panfir16k_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, panfir16k_lds()));
     }
     QH_HIP(hipMemcpy(p.fir_H, hr.data(), (size_t)N * 16, hipMemcpyHostToDevice));
     QH_HIP(hipMemcpy(p.fir_taps, taps, (size_t)ntaps * 8, hipMemcpyHostToDevice));
@@ -1075,7 +1189,7 @@ int qh_pan_feed_decimate(qh_pan *h, const double *d_in, long long in_stride, int
     if (nsplit > p.max_split) nsplit = p.max_split;
     if (nsplit < 1) nsplit = 1;
     const int units = nsplit * p.nch, groups = (units + 7) / 8;
-    hipLaunchKernelGGL((panfir16k_kernel<0>), dim3((unsigned)(groups * 8)), dim3(1024), (size_t)pan16k_lds<4>(), p.stream, in, in_stride, nblk, nsplit,
+    hipLaunchKernelGGL((panfir16k_kernel<0>), dim3((unsigned)(groups * 8)), dim3(1024), (size_t)panfir16k_lds(), p.stream, in, in_stride, nblk, nsplit,
                        p.tw, p.partial, p.partial_m2, p.band, p.nch, (const double2 *)p.fir_H, p.fir_yf);
     hipLaunchKernelGGL(pan_reduce_kernel, dim3((unsigned)((p.N + NT - 1) / NT), (unsigned)p.nch), dim3(NT), 0, p.stream, p.partial, p.partial_m2,
                        nsplit, p.N, p.R, p.avg, p.meter, 1);
@@ -1329,7 +1443,7 @@ int qh_bscope_graph(qh_bscope *b, int clock, double zoom, double deltaf, double 
 }  // extern "C"
 
 #ifdef QH_PAN_TRACE
-extern "C" int qh_pan_debug_trace(unsigned long long *out, int n)
+extern "C" int qh_dbg_pan_trace(unsigned long long *out, int n)
 {
     if (n > 64 * 8) n = 64 * 8;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(qh::qh_pan_trace), (size_t)n * 8) == hipSuccess ? 0 : -1;
