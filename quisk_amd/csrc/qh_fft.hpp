@@ -38,6 +38,16 @@ template <typename C> __device__ __forceinline__ C cmul(C a, C b)
     r.y = a.x * b.y + a.y * b.x;
     return r;
 }
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store the wavefront has in
+// flight (s_waitcnt vmcnt(0)) -- a kernel that asks for the next block's samples early, or has stores on the way, stalls at each one.  Only
+// for kernels whose wavefronts do not hand each other data through global memory.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <typename C> __device__ __forceinline__ C cconj(C a) { C r; r.x = a.x; r.y = -a.y; return r; }
 // a * (-i) (forward) or a * (+i) (inverse)
 template <bool INV, typename C> __device__ __forceinline__ C mul_mi(C a)
@@ -345,20 +355,21 @@ template <bool INV, typename C> struct FftSplit4096 {
     static constexpr int kLdsBytes = split4096_lds_bytes((int)sizeof(T));
     static __device__ __forceinline__ int sphys(int i) { return i + (i >> 4) * kPad; }
 
-    template <int WS, int RS>
+    // LB: the barriers order LDS accesses only (lds_barrier): loads from / stores to global memory stay in flight across them
+    template <int WS, int RS, bool LB = false>
     static __device__ __forceinline__ void exchange(C (&x)[16], T *lds, int wbase, int rbase)
     {
         T *wp = lds + wbase;
         const T *rp = lds + rbase;
 #pragma unroll
         for (int r = 0; r < 16; r++) wp[r * WS] = x[r].x;
-        __syncthreads();
+        if (LB) lds_barrier(); else __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r].x = rp[r * RS];
-        __syncthreads();
+        if (LB) lds_barrier(); else __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) wp[r * WS] = x[r].y;
-        __syncthreads();
+        if (LB) lds_barrier(); else __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r].y = rp[r * RS];
     }
@@ -380,23 +391,6 @@ template <bool INV, typename C> struct FftSplit4096 {
         if constexpr (kSwizzle) exchange_sw<2>(x, lds, j, base);
         else exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
         stockham_butterfly<4096, 16, 256, INV, C, LEAN>(x, j, t.b);          // pass 3: x[r] is element j + 256 r
-    }
-
-    // The same with the two passes' twiddles fetched from the table (L1-resident) right where they are used instead of riding through
-    // the earlier passes in eight registers: for callers whose registers are full of something else (pan16k_kernel).  `twp` must be
-    // opaque to the compiler at the call (asm volatile) or the loads are hoisted out of the caller's loop again.
-    static __device__ __forceinline__ void run_at_late_tw(C (&x)[16], void *lds_raw, const C *twp, int j)
-    {
-        static_assert(!kSwizzle, "padded image");
-        T *lds = reinterpret_cast<T *>(lds_raw);
-        Dft<16, INV, C>::run(x);
-        exchange<1, 256 + 16 * kPad>(x, lds, (16 + kPad) * j, sphys(j));
-        const C wa = pass_twiddle<16, INV>(twp, j);
-        const int base = stockham_butterfly<4096, 16, 16, INV, C, true>(x, j, wa);
-        __syncthreads();
-        exchange<16 + kPad, 256 + 16 * kPad>(x, lds, sphys(base), sphys(j));
-        const C wb = pass_twiddle<256, INV>(twp + 16, j);
-        stockham_butterfly<4096, 16, 256, INV, C, true>(x, j, wb);
     }
 
     // The transform WITHOUT the stage that would combine the D decimated sequences x[D m + a] (plan 16 x 16 x 16/D x [D], the last

@@ -179,6 +179,15 @@ __global__ __launch_bounds__(NT, QH_PAN_WAVES) void pan_spectrum_kernel(const do
 #ifndef QH_PAN_LOADS_AHEAD
 #define QH_PAN_LOADS_AHEAD 1
 #endif
+#ifndef QH_PAN_PIPE
+#define QH_PAN_PIPE 1
+#endif
+#ifndef QH_PAN_PIPE_LAG
+#define QH_PAN_PIPE_LAG 0
+#endif
+#ifndef QH_PAN_PIPE_AHEAD
+#define QH_PAN_PIPE_AHEAD 2
+#endif
 // -DQH_PAN_TRACE=<thread> (experiment builds, tools/dbg/pan_trace.py): that thread of workgroup 0 leaves the shader clock at the phase
 // boundaries of its blocks in qh_pan_trace[block][phase] (pan16k_kernel and panfir16k_kernel: whichever ran last).  (The stamps are stores: a wait that follows them counts their
 // acknowledgement too -- the phases up to the transform are trustworthy, the loop edge is not.)
@@ -193,6 +202,21 @@ __device__ unsigned long long qh_pan_trace[64 * 8];
 // twiddles, and every lane's S-meter sum
 template <int G> constexpr int pan16k_lds() { return G * FftSplit4096<false, double2>::kLdsBytes + 256 * 16 + 256 * G * 8; }      // G = 2: 80 KB, two per CU
 constexpr int panfir16k_lds() { return pan16k_lds<4>() + 16 * 16; }
+// a load from GLOBAL memory at a wave-uniform base plus the lane's 32-bit element offset (a pointer that went through an asm barrier is
+// a generic one to the compiler: flat loads, which the LDS counters wait for as well)
+__device__ __forceinline__ double2 gload(const double2 *base, unsigned off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const double __attribute__((address_space(1))) *gp;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef const v2d __attribute__((address_space(1))) *gp2;
+    const v2d v = *(gp2)(gp)(reinterpret_cast<const double *>(base) + 2 * (size_t)off);
+    double2 r; r.x = v.x; r.y = v.y;
+    return r;
+#else
+    return base[off];
+#endif
+}
 // a wave-uniform double as two scalar registers
 __device__ __forceinline__ double uniform_f64(double v)
 {
@@ -258,9 +282,31 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 #pragma unroll
     for (int i = 0; i < E; i++) racc[i] = 0.0;
     __syncthreads();                        // the tables are written
+    // Every load of a round -- with G = 4 of the block: sixteen, in the 64 registers the transform's values take later -- is asked for
+    // before the first is used: one memory latency per block, not one per j (with one workgroup on the CU nothing else runs while it
+    // waits).  (Round 5 measured this form slower: its sums were already spilling.)  PIPE (G = 4): and asked for a block AHEAD, four at a
+    // time as the |X| loop at the end of a block lets go of the transform's values; the barriers in between order LDS only, so the loads
+    // stay in flight across them and the latency lies under the end of one block and the top of the next.
+    constexpr bool PIPE = QH_PAN_PIPE && QH_PAN_LOADS_AHEAD && G == 4;
+    constexpr int LR = QH_PAN_LOADS_AHEAD ? (G == 4 ? 1 : 4) : MJ;     // rounds of loads per block (G = 2: eight loads a round beside half the transform's values)
+    constexpr int LJ = MJ / LR;                                         // values of j per round of loads
+    constexpr int PK = PIPE ? QH_PAN_PIPE_AHEAD : 0;                   // values of j whose loads are asked for a block ahead (the first round's)
+    C xx[LJ][4];
+    if (PIPE && b0 < b1) {
+        const C *xb = in + (long long)ch * in_stride + (long long)b0 * N + 256 * MJ * s;
+        asm volatile("" : "+s"(xb));
+#pragma unroll
+        for (int k = 0; k < PK; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) xx[k][q] = gload(xb + 256 * k + M * q, (unsigned)t);
+    }
     for (int blk = b0; blk < b1; blk++) {
+        // (a scalar base and the lane's 32-bit offset, not a 64-bit address per lane and strip; xn: the NEXT block's -- the last block
+        // asks for itself again and drops it)
         const C *xb = in + (long long)ch * in_stride + (long long)blk * N + 256 * MJ * s;
-        asm volatile("" : "+s"(xb));        // a scalar base and the lane's 32-bit offset, not a 64-bit address per lane and strip
+        asm volatile("" : "+s"(xb));
+        const C *xn = xb + (blk + 1 < b1 ? N : 0);
+        asm volatile("" : "+s"(xn));
         // The sixteen results of a thread change hands in TWO rounds of eight, real and imaginary part together (128-bit accesses):
         // round h takes j = h MJ/2 .. h MJ/2 + MJ/2 - 1.  [group][ii = (MJ/2) s + jj][t] complex, laid over the transform images.  (Round
         // 4's form sent all sixteen real parts, then all sixteen imaginary parts, and carried the imaginary parts through the first
@@ -271,22 +317,16 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
         C e = cmul(et[tt], es);
         C u[E];
         PAN_STAMP(6);
-        // Every load of a round -- with G = 4 of the block: sixteen, in the 64 registers the transform's values take later -- is asked for
-        // before the first is used: one memory latency per block in the open, not one per j (with one workgroup on the CU nothing else
-        // runs while it waits).  (Round 5 measured this form slower: its sums were already spilling.)
-        constexpr int LR = QH_PAN_LOADS_AHEAD ? (G == 4 ? 1 : 4) : MJ;     // rounds of loads per block (G = 2: eight loads a round beside half the transform's values)
-        constexpr int LJ = MJ / LR;                                         // values of j per round of loads
-        C xx[LJ][4];
-        if (LR == 1) {                      // (ahead of the barrier too: the loads do not touch LDS)
+        if (LR == 1) {                      // (ahead of the barrier: the loads do not touch LDS)
 #pragma unroll
-            for (int k = 0; k < LJ; k++)
+            for (int k = PK; k < LJ; k++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * k + M * q)[(unsigned)tt];
+                for (int q = 0; q < 4; q++) xx[k][q] = gload(xb + 256 * k + M * q, (unsigned)tt);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            __syncthreads();                // the area is free: the previous block's transform / the first round's values have been read out
+            lds_barrier();                  // the area is free: the previous block's transform / the first round's values have been read out
             if (h == 0) PAN_STAMP(0);
 #pragma unroll
             for (int jj = 0; jj < MJ / 2; jj++) {
@@ -295,7 +335,7 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 #pragma unroll
                     for (int k = 0; k < LJ; k++)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * (j + k) + M * q)[(unsigned)tt];         // scalar base
+                        for (int q = 0; q < 4; q++) xx[k][q] = gload(xb + 256 * (j + k) + M * q, (unsigned)tt);         // scalar base
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const C x0 = xx[j % LJ][0], x1 = xx[j % LJ][1], x2 = xx[j % LJ][2], x3 = xx[j % LJ][3];
@@ -320,28 +360,26 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 #pragma unroll
                 for (int g = 0; g < G; g++) xc[(g * 8 + (MJ / 2) * s + jj) * 256 + tt] = o[g];
                 e = cmul(e, estep);
-                // one j at a time -- four loads in flight.  Measured slower: all loads at once; the loads of j + 1 issued ahead of j's arithmetic
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (h == 1) PAN_STAMP(1);
-            __syncthreads();
+            lds_barrier();
             if (h == 1) PAN_STAMP(2);
             // group s takes element i = MJ s' + j of its transform from thread (s', t): slot ii = (MJ/2) s' + jj of its own plane
 #pragma unroll
             for (int ii = 0; ii < 8; ii++) u[MJ * (ii / (MJ / 2)) + h * (MJ / 2) + ii % (MJ / 2)] = xc[(s * 8 + ii) * 256 + tt];
         }
-        __syncthreads();                    // everybody has taken its elements: the images may be written
+        lds_barrier();                      // everybody has taken its elements: the images may be written
         PAN_STAMP(3);                       // the exchange between the residue groups
         // The 4096-point transform (FftSplit4096::run_at's three passes) with each pass's twiddle fetched where it is used: the middle
         // pass's from the sixteen-entry table, the last pass's exp(-2 pi i t / 4096) as the fourth power of the window table's entry.
         {
-            using T8 = double;
-            T8 *lds = reinterpret_cast<T8 *>(image);
+            double *lds = reinterpret_cast<double *>(image);
             Dft<16, false, C>::run(u);
-            S::template exchange<1, 256 + 16 * S::kPad>(u, lds, (16 + S::kPad) * tt, S::sphys(tt));
+            S::template exchange<1, 256 + 16 * S::kPad, true>(u, lds, (16 + S::kPad) * tt, S::sphys(tt));
             const int base = stockham_butterfly<4096, 16, 16, false, C, true>(u, tt, *reinterpret_cast<const C *>(tap + (16 + S::kPad) * (tt & 15)));
-            __syncthreads();
-            S::template exchange<16 + S::kPad, 256 + 16 * S::kPad>(u, lds, S::sphys(base), S::sphys(tt));
+            lds_barrier();
+            S::template exchange<16 + S::kPad, 256 + 16 * S::kPad, true>(u, lds, S::sphys(base), S::sphys(tt));
             C wb = et[tt];
             wb = cmul(wb, wb);
             wb = cmul(wb, wb);
@@ -354,8 +392,21 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
         for (int i = 0; i < E; i++) {
             const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
             racc[i] += sqrt_pow(pw2);       // cabs(): no overflow / underflow concern at +-2^31 * N full scale
+            if (PIPE) asm volatile("" : "+v"(racc[i]));     // (pinned: left alone the sums sink below the loads and sixteen |X|^2 wait for them)
             if (in_band) m2 += ((wp >> i) & 1u) ? pw2 : (((wp >> (16 + i)) & 1u) ? pb.frac * pw2 : 0.0);
-            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            if (PIPE && (i & 1) == 1) __builtin_amdgcn_sched_barrier(0);       // two square roots' worth of temporaries at a time
+            if ((i & 3) == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIPE) {                 // values of the transform are done with: the next block's loads take their registers, QH_PAN_PIPE_LAG values behind
+#pragma unroll
+                    for (int k = 0; k < PK; k++)
+                        if (i == (4 * k + 3 + QH_PAN_PIPE_LAG < E ? 4 * k + 3 + QH_PAN_PIPE_LAG : E - 1)) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) xx[k][q] = gload(xn + 256 * k + M * q, (unsigned)tt);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         if (in_band) *m2s = m2;
         PAN_STAMP(5);                       // |X| and the sums
@@ -389,7 +440,7 @@ __global__ __launch_bounds__(256 * G, 4) void pan16k_kernel(const double2 *in, l
 //   * the FIR is the circular convolution of the block with the taps, decimated by D = 32: Z[k] = X[k] H'[k] with
 //     H'[k] = FFT_N(h)[k] exp(2 pi i (D - 1) k / N) / N (the output of index m is the sample of time D m + D - 1, filter.c:216),
 //     folded over the 32 images of every bin class k mod 512 -- all of a lane's sixteen bins and those of lane t +- 128 of its
-//     group are ONE class -- and handed to panfir_finish_kernel as 512 folded bins per block: a 512-point inverse transform, and
+//     group are ONE class -- and handed to panfir_tail_kernel (panfir_finish_block) as 512 folded bins per block: a 512-point inverse transform, and
 //     the circular wrap of the first (ntaps - 1) / D outputs repaired by direct sums over the difference between the previous
 //     block's and this block's last ntaps - 1 samples.
 // The input is read once: 16 B + 16 / 32 B per sample (16.5), where FIR bank + panadapter read it twice.
@@ -441,9 +492,24 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
 #pragma unroll
     for (int i = 0; i < E; i++) racc[i] = 0.0;
     __syncthreads();                        // the tables are written
+    // (loads a round ahead and barriers that order LDS only: see pan16k_kernel)
+    constexpr bool PIPE = QH_PAN_PIPE && QH_PAN_LOADS_AHEAD;
+    constexpr int LR = QH_PAN_LOADS_AHEAD ? 1 : MJ, LJ = MJ / LR;
+    constexpr int PK = PIPE ? QH_PAN_PIPE_AHEAD : 0;
+    C xx[LJ][4];
+    if (PIPE && b0 < b1) {
+        const C *xb = in + (long long)ch * in_stride + (long long)b0 * N + 256 * MJ * s;
+        asm volatile("" : "+s"(xb));
+#pragma unroll
+        for (int k = 0; k < PK; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) xx[k][q] = gload(xb + 256 * k + M * q, (unsigned)t);
+    }
     for (int blk = b0; blk < b1; blk++) {
         const C *xb = in + (long long)ch * in_stride + (long long)blk * N + 256 * MJ * s;
         asm volatile("" : "+s"(xb));
+        const C *xn = xb + (blk + 1 < b1 ? N : 0);
+        asm volatile("" : "+s"(xn));
         C *xc = reinterpret_cast<C *>(smem);
         int tt = t;
         asm volatile("" : "+v"(tt));
@@ -451,19 +517,17 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
         C u[E];
         // the block's four strips, the radix-4 combination over them, W_N^(m r), and the change of hands between the residue groups in two
         // rounds of eight complex values (pan16k_kernel's, without the window)
-        constexpr int LR = QH_PAN_LOADS_AHEAD ? 1 : MJ, LJ = MJ / LR;
-        C xx[LJ][4];
         PAN_STAMP(6);
         if (LR == 1) {
 #pragma unroll
-            for (int k = 0; k < LJ; k++)
+            for (int k = PK; k < LJ; k++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * k + M * q)[(unsigned)tt];
+                for (int q = 0; q < 4; q++) xx[k][q] = gload(xb + 256 * k + M * q, (unsigned)tt);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            __syncthreads();                // the images, the fold rows and the first round's values are free
+            lds_barrier();                  // the images, the fold rows and the first round's values are free
             if (h == 0) PAN_STAMP(0);
 #pragma unroll
             for (int jj = 0; jj < MJ / 2; jj++) {
@@ -472,7 +536,7 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
 #pragma unroll
                     for (int k = 0; k < LJ; k++)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) xx[k][q] = (xb + 256 * (j + k) + M * q)[(unsigned)tt];
+                        for (int q = 0; q < 4; q++) xx[k][q] = gload(xb + 256 * (j + k) + M * q, (unsigned)tt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const C v0 = xx[j % LJ][0], v1 = xx[j % LJ][1], v2 = xx[j % LJ][2], v3 = xx[j % LJ][3];
@@ -489,20 +553,20 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (h == 1) PAN_STAMP(1);
-            __syncthreads();
+            lds_barrier();
             if (h == 1) PAN_STAMP(2);
 #pragma unroll
             for (int ii = 0; ii < 8; ii++) u[MJ * (ii / (MJ / 2)) + h * (MJ / 2) + ii % (MJ / 2)] = xc[(s * 8 + ii) * 256 + tt];
         }
-        __syncthreads();
+        lds_barrier();
         PAN_STAMP(3);
         {
             double *lds = reinterpret_cast<double *>(image);
             Dft<16, false, C>::run(u);
-            S::template exchange<1, 256 + 16 * S::kPad>(u, lds, (16 + S::kPad) * tt, S::sphys(tt));
+            S::template exchange<1, 256 + 16 * S::kPad, true>(u, lds, (16 + S::kPad) * tt, S::sphys(tt));
             const int base = stockham_butterfly<4096, 16, 16, false, C, true>(u, tt, ta[tt & 15]);
-            __syncthreads();
-            S::template exchange<16 + S::kPad, 256 + 16 * S::kPad>(u, lds, S::sphys(base), S::sphys(tt));
+            lds_barrier();
+            S::template exchange<16 + S::kPad, 256 + 16 * S::kPad, true>(u, lds, S::sphys(base), S::sphys(tt));
             C wb = et[tt];
             wb = cmul(wb, wb);
             wb = cmul(wb, wb);
@@ -514,18 +578,18 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
         {
             const C *hh = firH + r * M;     // scalar
             asm volatile("" : "+s"(hh));
-            C acc = cmul(u[0], hh[(unsigned)tt]);
+            C acc = cmul(u[0], gload(hh, (unsigned)tt));
 #pragma unroll
             for (int i = 1; i < E; i++) {
-                const C z = cmul(u[i], (hh + 256 * i)[(unsigned)tt]);
+                const C z = cmul(u[i], gload(hh + 256 * i, (unsigned)tt));
                 acc.x += z.x; acc.y += z.y;
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();                // every group has read its transform out of its image
+            lds_barrier();                // every group has read its transform out of its image
             fold[s * 256 + tt] = acc;
         }
 #else
-        __syncthreads();
+        lds_barrier();
 #endif
         PAN_STAMP(7);
         // ---- the window in the frequency domain: real parts, then imaginary parts, through the exchange area
@@ -538,7 +602,7 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
         double *own = xch + (s * 16) * 256 + tt;
 #pragma unroll
         for (int i = 0; i < E; i++) own[i * 256] = u[i].x;
-        __syncthreads();
+        lds_barrier();
 #ifndef QH_PANFIR_NOFIR
         if (tt < 128) {
             const C a = fold[s * 256 + tt], b = fold[s * 256 + tt + 128];
@@ -555,19 +619,36 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
             // neighbours wait for them in 64 registers)
             asm volatile("" : "+v"(u[i].x));
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < E; i++) own[i * 256] = u[i].y;
-        __syncthreads();
+        lds_barrier();
+        double m2 = 0.0;
+        if (in_band) m2 = *m2s;
 #pragma unroll
         for (int i = 0; i < E; i++) {
             int ua = up0 + i * 256, da = dn0 + i * 256;
             if (s == 3 && i == 15 && tt == 255) ua = 0;
             if (s == 0 && i == 0 && tt == 0) da = 63 * 256 + 255;
-            u[i].y = __builtin_fma(0.5, u[i].y, -0.25 * (xch[ua] + xch[da]));
-            asm volatile("" : "+v"(u[i].y));
+            const double uy = __builtin_fma(0.5, u[i].y, -0.25 * (xch[ua] + xch[da]));
+            const double pw2 = u[i].x * u[i].x + uy * uy;
+            racc[i] += sqrt_pow(pw2);
+            asm volatile("" : "+v"(racc[i]));       // (pinned, like the real parts above)
+            if (in_band) m2 += ((wp >> i) & 1u) ? pw2 : (((wp >> (16 + i)) & 1u) ? pb.frac * pw2 : 0.0);
+            if ((i & 3) == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIPE) {                 // the next block's first loads in the registers of the values that are done with
+#pragma unroll
+                    for (int k = 0; k < PK; k++)
+                        if (i == (4 * k + 3 + QH_PAN_PIPE_LAG < E ? 4 * k + 3 + QH_PAN_PIPE_LAG : E - 1)) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) xx[k][q] = gload(xn + 256 * k + M * q, (unsigned)tt);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
-#endif
+#else
         double m2 = 0.0;
         if (in_band) m2 = *m2s;
 #pragma unroll
@@ -575,8 +656,8 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
             const double pw2 = u[i].x * u[i].x + u[i].y * u[i].y;
             racc[i] += sqrt_pow(pw2);
             if (in_band) m2 += ((wp >> i) & 1u) ? pw2 : (((wp >> (16 + i)) & 1u) ? pb.frac * pw2 : 0.0);
-            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         if (in_band) *m2s = m2;
         PAN_STAMP(5);
     }
@@ -600,9 +681,9 @@ __global__ __launch_bounds__(1024, 4) void panfir16k_kernel(const double2 *in, l
 // the circular wrap of outputs m < ncorr repaired: y[m] += sum_{k > n} h[k] (xprev - xcur)[N + n - k], n = D m + D - 1 -- the circular
 // convolution took the block's own last samples where the previous block's belong (`hist`: the last `hl` samples of the call
 // before, for block 0).  Thread 8 m + p takes every eighth tap of output m.
-__global__ __launch_bounds__(NT) void panfir_finish_kernel(const double2 *yfold, int nblk, const double2 *tw512, const double *taps, int ntaps,
-                                                           int D, const double2 *in, long long in_stride, const double2 *hist, int hl,
-                                                           double2 *out, long long out_stride)
+__device__ __forceinline__ void panfir_finish_block(int blk, int ch, const double2 *yfold, int nblk, const double2 *tw512, const double *taps, int ntaps,
+                                                    int D, const double2 *in, long long in_stride, const double2 *hist, int hl,
+                                                    double2 *out, long long out_stride)
 {
     using C = double2;
     using F = TileFft<512, true, C>;
@@ -610,7 +691,7 @@ __global__ __launch_bounds__(NT) void panfir_finish_kernel(const double2 *yfold,
     __shared__ C corr[32];
     __shared__ C diff[1024];                // diff[d] = (previous block - this block)[N - d], d = 1 .. hl
     constexpr int N = 16384;
-    const int blk = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+    const int t = threadIdx.x;
     const C *yf = yfold + ((long long)ch * nblk + blk) * 512;
     C z[2] = { yf[t], yf[t + 256] };
     const C *cur = in + (long long)ch * in_stride + (long long)blk * N + N;         // cur[-d] = the d-th last sample of this block
@@ -639,11 +720,10 @@ __global__ __launch_bounds__(NT) void panfir_finish_kernel(const double2 *yfold,
 
 // fft_avg += sum over the block ranges; meter += sum over ranges and r.  One thread per (channel, index).
 // by_residue: the partial sums lie as [r][bin / 4] (pan16k_kernel) instead of in fft_avg's order.
-__global__ __launch_bounds__(NT) void pan_reduce_kernel(const double *partial, const double *partial_m2, int nsplit, int N, int R,
-                                                        double *avg, double *meter, int by_residue)
+__device__ __forceinline__ void pan_reduce_block(int bx, int ch, int nch, const double *partial, const double *partial_m2, int nsplit, int N, int R,
+                                                 double *avg, double *meter, int by_residue)
 {
-    const int ch = blockIdx.y, nch = gridDim.y;
-    const int idx = blockIdx.x * NT + threadIdx.x;
+    const int idx = bx * NT + threadIdx.x;
     if (idx < N) {
         double sacc = 0.0;
         int src = idx;
@@ -659,6 +739,32 @@ __global__ __launch_bounds__(NT) void pan_reduce_kernel(const double *partial, c
         for (int sp = 0; sp < nsplit; sp++)
             for (int r = 0; r < R; r++) sm += partial_m2[((long long)sp * nch + ch) * R + r];
         meter[ch] += sm;
+    }
+}
+__global__ __launch_bounds__(NT) void pan_reduce_kernel(const double *partial, const double *partial_m2, int nsplit, int N, int R,
+                                                        double *avg, double *meter, int by_residue)
+{
+    pan_reduce_block(blockIdx.x, blockIdx.y, gridDim.y, partial, partial_m2, nsplit, N, R, avg, meter, by_residue);
+}
+
+// Everything behind panfir16k_kernel in ONE launch (three small grids one after the other were 0.10 of config 3's 0.55 ms): workgroups
+// x < nblk finish block x's FIR outputs, the next N / NT add the block ranges' |X| sums to fft_avg (pan_reduce_kernel's), the last
+// ones keep the call's last samples for the next call's first block (they read `in` and write the OTHER history buffer).
+struct PanfirTail {
+    const double2 *yfold, *tw512, *in, *hist; const double *taps; double2 *out, *hist_next; const double *partial, *partial_m2; double *avg, *meter;
+    long long in_stride, out_stride; int nblk, ntaps, D, hl, nsplit, N, R, n;
+};
+__global__ __launch_bounds__(NT) void panfir_tail_kernel(PanfirTail a)
+{
+    const int bx = blockIdx.x, ch = blockIdx.y;
+    const int nred = (a.N + NT - 1) / NT;
+    if (bx < a.nblk) {
+        panfir_finish_block(bx, ch, a.yfold, a.nblk, a.tw512, a.taps, a.ntaps, a.D, a.in, a.in_stride, a.hist, a.hl, a.out, a.out_stride);
+    } else if (bx < a.nblk + nred) {
+        pan_reduce_block(bx - a.nblk, ch, gridDim.y, a.partial, a.partial_m2, a.nsplit, a.N, a.R, a.avg, a.meter, 1);
+    } else {
+        const int j = (bx - a.nblk - nred) * NT + threadIdx.x;
+        if (j < a.hl) a.hist_next[(long long)ch * a.hl + j] = a.in[(long long)ch * a.in_stride + a.n - a.hl + j];
     }
 }
 
@@ -1119,12 +1225,6 @@ int qh_pan_count(const qh_pan *h) { return h ? h->p.count : 0; }
 // quisk_process_samples feeds the same cSamples to the FFT ring (quisk.c:2454-2475) and to quisk_cDecimate (filter.c:203-229).
 // Shapes: fft_size 16384, decimation 32, up to 1024 real taps (BASELINE config 3: 1023 taps, /32); anything else is refused --
 // qh_fir + qh_pan_feed do those.  State: the last ntaps - 1 samples of the call before.
-__global__ __launch_bounds__(NT) void panfir_hist_kernel(const double2 *in, long long in_stride, int n, double2 *hist, int hl)
-{
-    const int ch = blockIdx.y, j = blockIdx.x * NT + threadIdx.x;
-    if (j < hl) hist[(long long)ch * hl + j] = in[(long long)ch * in_stride + n - hl + j];
-}
-
 int qh_pan_attach_fir(qh_pan *h, const double *taps, int ntaps, int decim)
 {
     if (!h || !taps) return set_error(QH_ERR_INVALID, "qh_pan_attach_fir: bad arguments");
@@ -1191,14 +1291,14 @@ int qh_pan_feed_decimate(qh_pan *h, const double *d_in, long long in_stride, int
     const int units = nsplit * p.nch, groups = (units + 7) / 8;
     hipLaunchKernelGGL((panfir16k_kernel<0>), dim3((unsigned)(groups * 8)), dim3(1024), (size_t)panfir16k_lds(), p.stream, in, in_stride, nblk, nsplit,
                        p.tw, p.partial, p.partial_m2, p.band, p.nch, (const double2 *)p.fir_H, p.fir_yf);
-    hipLaunchKernelGGL(pan_reduce_kernel, dim3((unsigned)((p.N + NT - 1) / NT), (unsigned)p.nch), dim3(NT), 0, p.stream, p.partial, p.partial_m2,
-                       nsplit, p.N, p.R, p.avg, p.meter, 1);
     p.count += nblk;
-    hipLaunchKernelGGL(panfir_finish_kernel, dim3((unsigned)nblk, (unsigned)p.nch), dim3(NT), 0, p.stream, (const double2 *)p.fir_yf, nblk,
-                       (const double2 *)p.fir_tw512, (const double *)p.fir_taps, p.fir_ntaps, p.fir_decim, in, in_stride,
-                       (const double2 *)p.fir_hist[p.fir_cur], p.fir_hl, reinterpret_cast<double2 *>(d_out), out_stride);
-    hipLaunchKernelGGL(panfir_hist_kernel, dim3((unsigned)((p.fir_hl + NT - 1) / NT), (unsigned)p.nch), dim3(NT), 0, p.stream, in, in_stride, n,
-                       p.fir_hist[p.fir_cur ^ 1], p.fir_hl);
+    PanfirTail a;
+    a.yfold = (const double2 *)p.fir_yf; a.tw512 = (const double2 *)p.fir_tw512; a.in = in; a.hist = (const double2 *)p.fir_hist[p.fir_cur];
+    a.taps = (const double *)p.fir_taps; a.out = reinterpret_cast<double2 *>(d_out); a.hist_next = p.fir_hist[p.fir_cur ^ 1];
+    a.partial = p.partial; a.partial_m2 = p.partial_m2; a.avg = p.avg; a.meter = p.meter;
+    a.in_stride = in_stride; a.out_stride = out_stride; a.nblk = nblk; a.ntaps = p.fir_ntaps; a.D = p.fir_decim; a.hl = p.fir_hl;
+    a.nsplit = nsplit; a.N = p.N; a.R = p.R; a.n = n;
+    hipLaunchKernelGGL(panfir_tail_kernel, dim3((unsigned)(nblk + (p.N + NT - 1) / NT + (p.fir_hl + NT - 1) / NT), (unsigned)p.nch), dim3(NT), 0, p.stream, a);
     p.fir_cur ^= 1;
     QH_HIP(hipGetLastError());
     if (n_out) *n_out = nout;
