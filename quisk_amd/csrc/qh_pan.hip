@@ -690,6 +690,7 @@ __device__ __forceinline__ void panfir_finish_block(int blk, int ch, const doubl
     __shared__ __align__(16) unsigned char fimg[F::kLdsBytes];
     __shared__ C corr[32];
     __shared__ C diff[1024];                // diff[d] = (previous block - this block)[N - d], d = 1 .. hl
+    __shared__ double htap[1024];
     constexpr int N = 16384;
     const int t = threadIdx.x;
     const C *yf = yfold + ((long long)ch * nblk + blk) * 512;
@@ -700,18 +701,40 @@ __device__ __forceinline__ void panfir_finish_block(int blk, int ch, const doubl
         const C a = prv[-d], b = cur[-d];
         diff[d] = mk<double>(a.x - b.x, a.y - b.y);
     }
-    F::run(z, fimg, F::load(tw512));        // (its barriers also publish diff[])
-    const int m = t >> 3, p = t & 7, n = D * m + D - 1;
-    C acc = mk<double>(0, 0);
-    for (int k = n + 1 + p; k < ntaps; k += 8) {
-        const C dv = diff[k - n];
-        const double h = taps[k];
-        acc.x = __builtin_fma(h, dv.x, acc.x);
-        acc.y = __builtin_fma(h, dv.y, acc.y);
+    for (int k = t; k < ntaps; k += NT) htap[k] = taps[k];
+    F::run(z, fimg, F::load(tw512));        // (its barriers also publish diff[] and htap[])
+    // Output m needs the taps behind n = D m + D - 1: (ntaps - 1 - n) products, most for m = 0, none for the last.  Outputs m and
+    // 31 - m together are the same length for every m: sixteen lanes take such a pair, every sixteenth tap each (62 products a lane
+    // for 1023 taps instead of 124 in the longest of eight-lane rows), four sums in flight.
+    static_assert(NT == 256, "sixteen pairs of outputs x sixteen lanes");
+    const int q = t >> 4, l = t & 15;
+    C part[2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const int m = w == 0 ? q : 31 - q, n = D * m + D - 1;
+        C a0 = mk<double>(0, 0), a1 = a0, a2 = a0, a3 = a0;
+        int k = n + 1 + l;
+        for (; k + 48 < ntaps; k += 64) {
+            const C d0 = diff[k - n], d1 = diff[k + 16 - n], d2 = diff[k + 32 - n], d3 = diff[k + 48 - n];
+            const double h0 = htap[k], h1 = htap[k + 16], h2 = htap[k + 32], h3 = htap[k + 48];
+            a0.x = __builtin_fma(h0, d0.x, a0.x); a0.y = __builtin_fma(h0, d0.y, a0.y);
+            a1.x = __builtin_fma(h1, d1.x, a1.x); a1.y = __builtin_fma(h1, d1.y, a1.y);
+            a2.x = __builtin_fma(h2, d2.x, a2.x); a2.y = __builtin_fma(h2, d2.y, a2.y);
+            a3.x = __builtin_fma(h3, d3.x, a3.x); a3.y = __builtin_fma(h3, d3.y, a3.y);
+        }
+        for (; k < ntaps; k += 16) {
+            const C dv = diff[k - n];
+            const double h = htap[k];
+            a0.x = __builtin_fma(h, dv.x, a0.x); a0.y = __builtin_fma(h, dv.y, a0.y);
+        }
+        part[w] = mk<double>((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
     }
 #pragma unroll
-    for (int sft = 1; sft < 8; sft <<= 1) { acc.x += __shfl_xor(acc.x, sft, 64); acc.y += __shfl_xor(acc.y, sft, 64); }
-    if (p == 0) corr[m] = acc;
+    for (int sft = 1; sft < 16; sft <<= 1) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) { part[w].x += __shfl_xor(part[w].x, sft, 64); part[w].y += __shfl_xor(part[w].y, sft, 64); }
+    }
+    if (l == 0) { corr[q] = part[0]; corr[31 - q] = part[1]; }
     __syncthreads();
     if (t < 32) { z[0].x += corr[t].x; z[0].y += corr[t].y; }
     C *o = out + (long long)ch * out_stride + (long long)blk * (N / D);
