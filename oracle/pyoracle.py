@@ -192,10 +192,14 @@ class WdspChannel:
         self.dsp_outsize = self.L.wo_dsp_outsize(self.h)
         t = emnr_tables()
         if t is not None:       # WDSP reads these from the files `calculus` / `zetaHat.bin` when a channel is created (emnr.c:317-334)
-            self._emnr_tables = t
-            self.L.wo_SetEMNRTables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_double] * 4
-            self.L.wo_SetEMNRTables(self.h, t["GG"].ctypes.data, t["GGS"].ctypes.data, t["zeta_hat"].ctypes.data, t["zeta_valid"].ctypes.data,
-                                    *[float(v) for v in t["zeta_range"]])
+            self.set_emnr_tables(t)
+
+    def set_emnr_tables(self, t):
+        """Other tables than the shipped ones (a test's stand-in for a `calculus` / `zetaHat.bin` with other numbers in the working directory)."""
+        self._emnr_tables = t = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in t.items()}
+        self.L.wo_SetEMNRTables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_double] * 4
+        self.L.wo_SetEMNRTables(self.h, t["GG"].ctypes.data, t["GGS"].ctypes.data, t["zeta_hat"].ctypes.data, t["zeta_valid"].ctypes.data,
+                                *[float(v) for v in t["zeta_range"]])
 
     def __getattr__(self, name):
         f = getattr(lib(), "wo_" + name)

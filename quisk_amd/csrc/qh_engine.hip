@@ -1999,7 +1999,15 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         {
             long long dst_stride;
             double2 *dst = dst_of(stage, dst_stride);
+            // A chain that is the front stage alone stores to the caller's rows while other tiles -- and the history pass behind the kernel --
+            // still read the input: when the rows of the two matrices overlap (include/quiskhip.h: the output may lie over the input) the
+            // stage goes to the engine's own rows and the output is written in a last pass.  (The rows' own extent, as in the mixed path.)
+            const bool over = nstage == 1 && !((const char *)(out + (size_t)(nch - 1) * (size_t)out_stride + (size_t)n_mid) <= (const char *)in ||
+                                              (const char *)in + ((size_t)(nch - 1) * (size_t)in_stride + (size_t)n_in) * sizeof(double2) <= (const char *)out);
+            if (over) { dst = buf[0]; dst_stride = buf_cap; }
             if (int rc = run_front(cur, cur_stride, dst, dst_stride, stage == nstage - 1 ? epi : nullptr, n_in, n_mid)) return rc;
+            if (over) QH_HIP(hipMemcpy2DAsync(out, (size_t)out_stride * sizeof(double2), dst, (size_t)dst_stride * sizeof(double2),
+                                              (size_t)n_mid * sizeof(double2), (size_t)nch, hipMemcpyDeviceToDevice, stream));
             cur = dst; cur_stride = dst_stride; stage++;
         }
         for (int f = 0; f < 2; f++) {

@@ -14,9 +14,11 @@
 #include <cstdlib>
 #include <string>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 #include "qh_internal.hpp"
+#include "qh_emnr_tables.hpp"
 
 extern "C" int qh_rxa_flush(qh_rxa *e);
 extern "C" void qh_wdsp_shim_release_device(int channel);
@@ -628,27 +630,42 @@ void SetRXAAMDSBMode(int channel, int sbmode) { WDSP_SETTER(qh_rxa_SetRXAAMDSBMo
 void SetRXAAMDRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAAMDRun(L.c->eng, 0, run)); }
 void SetRXAFMLimRun(int channel, int run) { WDSP_SETTER(qh_rxa_SetRXAFMLimRun(L.c->eng, 0, run)); }
 void SetRXAFMLimGain(int channel, double gaindB) { WDSP_SETTER(qh_rxa_SetRXAFMLimGain(L.c->eng, 0, gaindB)); }
-// EMNR, wdsp/emnr.c:1096-1143.  Its tables come from the files WDSP itself reads at create time (emnr.c:212,317): `calculus` and
-// `zetaHat.bin`, looked for in $QH_WDSP_DATA and in the working directory; without them EMNR cannot be switched on.
+// EMNR, wdsp/emnr.c:1096-1143.  Its tables come from where WDSP takes them when a channel is created: GG / GGS from the file `calculus`
+// in the working directory, else the arrays compiled in (emnr.c:317-328); zetaHat from `zetaHat.bin` in the working directory, else the
+// compiled-in one (readZetaHat, emnr.c:207-238) -- each file on its own.  (Quisk runs from its own directory and the files lie in wdsp/:
+// it gets the compiled-in tables from WDSP, and the same numbers from here.)  $QH_WDSP_DATA, a directory looked into first, is this
+// library's addition.
+static bool read_file_into(const char *name, const std::function<bool(FILE *)> &take)
+{
+    const char *dir = std::getenv("QH_WDSP_DATA");
+    for (int pass = dir ? 0 : 1; pass < 2; pass++) {
+        const std::string path = pass == 0 ? std::string(dir) + "/" + name : std::string(name);
+        if (FILE *f = std::fopen(path.c_str(), "rb")) {
+            const bool ok = take(f);
+            std::fclose(f);
+            if (ok) return true;
+        }
+    }
+    return false;
+}
 static bool load_emnr_tables(Chan &c)
 {
     std::vector<double> gg(2 * 241 * 241), zeta(3600);
     std::vector<int> valid(3600);
     double range[4];
-    int dims[2];
-    const char *dir = std::getenv("QH_WDSP_DATA");
-    for (int pass = 0; pass < 2; pass++) {
-        const std::string base = pass == 0 ? (dir ? std::string(dir) + "/" : std::string()) : std::string();
-        if (pass == 0 && !dir) continue;
-        FILE *f1 = std::fopen((base + "calculus").c_str(), "rb"), *f2 = std::fopen((base + "zetaHat.bin").c_str(), "rb");
-        bool ok = f1 && f2 && std::fread(gg.data(), 8, gg.size(), f1) == gg.size() && std::fread(dims, 4, 2, f2) == 2 &&
-                  dims[0] == 60 && dims[1] == 60 && std::fread(range, 8, 4, f2) == 4 && std::fread(zeta.data(), 8, 3600, f2) == 3600 &&
-                  std::fread(valid.data(), 4, 3600, f2) == 3600;
-        if (f1) std::fclose(f1);
-        if (f2) std::fclose(f2);
-        if (ok) return qh_rxa_SetEMNRTables(c.eng, gg.data(), gg.data() + 241 * 241, zeta.data(), valid.data(), range[0], range[1], range[2], range[3]) == QH_OK;
+    if (!read_file_into("calculus", [&](FILE *f) { return std::fread(gg.data(), 8, gg.size(), f) == gg.size(); })) {
+        std::memcpy(gg.data(), qh::kEmnrDefaultGG, 241 * 241 * 8);
+        std::memcpy(gg.data() + 241 * 241, qh::kEmnrDefaultGGS, 241 * 241 * 8);
     }
-    return false;
+    if (!read_file_into("zetaHat.bin", [&](FILE *f) {
+            int dims[2];
+            return std::fread(dims, 4, 2, f) == 2 && dims[0] == 60 && dims[1] == 60 && std::fread(range, 8, 4, f) == 4 &&
+                   std::fread(zeta.data(), 8, 3600, f) == 3600 && std::fread(valid.data(), 4, 3600, f) == 3600; })) {
+        std::memcpy(range, qh::kEmnrDefaultRange, sizeof range);
+        std::memcpy(zeta.data(), qh::kEmnrDefaultZeta, 3600 * 8);
+        std::memcpy(valid.data(), qh::kEmnrDefaultValid, 3600 * 4);
+    }
+    return qh_rxa_SetEMNRTables(c.eng, gg.data(), gg.data() + 241 * 241, zeta.data(), valid.data(), range[0], range[1], range[2], range[3]) == QH_OK;
 }
 void SetRXAEMNRRun(int channel, int run)
 {
@@ -657,7 +674,7 @@ void SetRXAEMNRRun(int channel, int run)
     if (!L.c) return;
     if (run && !L.c->emnr_tables) {
         L.c->emnr_tables = load_emnr_tables(*L.c);
-        if (!L.c->emnr_tables) { g_status = qh::set_error(QH_ERR_INVALID, "SetRXAEMNRRun: WDSP's data files `calculus` and `zetaHat.bin` were not found (working directory or $QH_WDSP_DATA)"); return; }
+        if (!L.c->emnr_tables) { g_status = QH_ERR_INVALID; return; }       // (qh_rxa_SetEMNRTables has said why)
     }
     const int rc = qh_rxa_SetRXAEMNRRun(L.c->eng, 0, run);
     if (rc) g_status = rc;

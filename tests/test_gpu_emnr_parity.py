@@ -77,30 +77,15 @@ def test_emnr_needs_its_tables_and_switches_mid_stream(qh, oracle):
     assert rel_rms(r[:60 * 256], plain[:60 * 256]) < 1e-12
 
 
-def test_emnr_through_the_wdsp_names_reads_wdsps_data_files(qh, oracle, tmp_path, monkeypatch):
+def _emnr_names_run(lib, ch, x, nb, method=2):
     import ctypes as C
-    t = oracle.emnr_tables()
-    (tmp_path / "calculus").write_bytes(t["GG"].tobytes() + t["GGS"].tobytes())
-    (tmp_path / "zetaHat.bin").write_bytes(np.array([60, 60], dtype=np.int32).tobytes() + np.asarray(t["zeta_range"], dtype=np.float64).tobytes()
-                                           + t["zeta_hat"].tobytes() + t["zeta_valid"].tobytes())
-    lib = qh.load()
     D = C.c_double
-    ch, nb = 14, 300
     lib.OpenChannel(ch, 1024, 256, 192000, 48000, 48000, 0, 1, D(0.010), D(0.025), D(0.0), D(0.010), 1)
     lib.SetRXAShiftRun(ch, 1); lib.SetRXAShiftFreq(ch, D(synth.shift_freq(0))); lib.RXANBPSetRun(ch, 1); lib.SetRXAMode(ch, 1)
     lib.RXASetPassband(ch, D(300.0), D(3000.0)); lib.SetRXAAGCMode(ch, 0); lib.SetRXAAGCFixed(ch, D(0.0))
-    monkeypatch.delenv("QH_WDSP_DATA", raising=False)
-    monkeypatch.chdir(tmp_path.parent)
-    lib.SetRXAEMNRRun(ch, 1)
-    assert lib.qh_wdsp_status() != 0                            # no data files here: refused loudly
-    monkeypatch.setenv("QH_WDSP_DATA", str(tmp_path))
-    lib.SetRXAEMNRgainMethod(ch, 2)
+    lib.SetRXAEMNRgainMethod(ch, method)
     lib.SetRXAEMNRRun(ch, 1)
     assert lib.qh_wdsp_status() == 0, lib.qh_last_error()
-    o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
-    o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(0)); o.RXANBPSetRun(1); o.SetRXAMode(1); o.RXASetPassband(300.0, 3000.0)
-    o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0); o.SetRXAEMNRgainMethod(2); o.SetRXAEMNRRun(1)
-    x = speechy(0, nb * 1024)
     out = np.zeros(nb * 256, dtype=np.complex128)
     err = C.c_int(0)
     for b in range(nb):
@@ -108,5 +93,50 @@ def test_emnr_through_the_wdsp_names_reads_wdsps_data_files(qh, oracle, tmp_path
         lib.fexchange0(ch, blk.ctypes.data_as(C.c_void_p), out[b * 256:].ctypes.data_as(C.c_void_p), C.byref(err))
         assert err.value == 0
     lib.CloseChannel(ch)
+    return out
+
+
+def _emnr_oracle_run(oracle, x, method=2, tables=None):
+    o = oracle.WdspChannel(1024, 256, 192000, 48000, 48000)
+    if tables is not None:
+        o.set_emnr_tables(tables)
+    o.SetRXAShiftRun(1); o.SetRXAShiftFreq(synth.shift_freq(0)); o.RXANBPSetRun(1); o.SetRXAMode(1); o.RXASetPassband(300.0, 3000.0)
+    o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0); o.SetRXAEMNRgainMethod(method); o.SetRXAEMNRRun(1)
     ref, errs = o.fexchange0(x)
-    assert errs == 0 and rel_rms(out, ref) < 1e-6
+    assert errs == 0
+    return ref
+
+
+def test_emnr_through_the_wdsp_names_from_an_empty_directory(qh, oracle, tmp_path, monkeypatch):
+    """Quisk's case (quisk.py:6017-6027 from quisk/, the data files in quisk/wdsp/): no `calculus`, no `zetaHat.bin`, no environment --
+    WDSP takes the tables compiled into it (emnr.c:207-225, 322-326) and so does the library (qh_emnr_tables.hpp)."""
+    lib = qh.load()
+    monkeypatch.delenv("QH_WDSP_DATA", raising=False)
+    monkeypatch.chdir(tmp_path)
+    assert not list(tmp_path.iterdir())
+    nb = 300
+    x = speechy(0, nb * 1024)
+    for method, ch in ((2, 14), (3, 15)):                       # the two gain methods Quisk selects
+        out = _emnr_names_run(lib, ch, x, nb, method)
+        assert rel_rms(out, _emnr_oracle_run(oracle, x, method)) < 1e-6
+
+
+def test_emnr_through_the_wdsp_names_reads_wdsps_data_files(qh, oracle, tmp_path, monkeypatch):
+    """... and a file that IS there wins, each on its own like in the reference: a `calculus` with other numbers in the working directory
+    (GG scaled: the gain of method 2 follows), zetaHat still the built-in one; then the same file through $QH_WDSP_DATA."""
+    t = dict(oracle.emnr_tables())
+    t["GG"] = t["GG"] * 0.5
+    (tmp_path / "calculus").write_bytes(t["GG"].tobytes() + t["GGS"].tobytes())
+    lib = qh.load()
+    nb = 200
+    x = speechy(0, nb * 1024)
+    ref_default = _emnr_oracle_run(oracle, x, 2)
+    ref_scaled = _emnr_oracle_run(oracle, x, 2, tables=t)
+    assert rel_rms(ref_scaled, ref_default) > 1e-2
+    monkeypatch.delenv("QH_WDSP_DATA", raising=False)
+    monkeypatch.chdir(tmp_path)
+    assert rel_rms(_emnr_names_run(lib, 14, x, nb), ref_scaled) < 1e-6
+    monkeypatch.chdir(tmp_path.parent)
+    assert rel_rms(_emnr_names_run(lib, 14, x, nb), ref_default) < 1e-6
+    monkeypatch.setenv("QH_WDSP_DATA", str(tmp_path))
+    assert rel_rms(_emnr_names_run(lib, 14, x, nb), ref_scaled) < 1e-6
