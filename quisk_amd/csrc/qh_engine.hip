@@ -496,8 +496,10 @@ int Engine::init()
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, osfir8k_lds_bytes()))
     QH_SET_LDS2G(false, false); QH_SET_LDS2G(true, false); QH_SET_LDS2G(false, true); QH_SET_LDS2G(true, true);
 #undef QH_SET_LDS2G
+#ifdef QH_EXP_BAND8_SEQ
     QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kOsfir8kImage));
     QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&osfir8s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kOsfir8kImage));
+#endif
     QH_SET_LDS(2, false, false, false, true, false, true); QH_SET_LDS(4, false, false, false, true, false, true); QH_SET_LDS(8, false, false, false, true, false, true);
     QH_SET_LDS(2, false, true, false, true, false, true); QH_SET_LDS(4, false, true, false, true, false, true); QH_SET_LDS(8, false, true, false, true, false, true);
 #undef QH_SET_LDS
@@ -1501,6 +1503,8 @@ static void launch_band2g(OsfirArgs<double> a, int ntiles, int nch, hipStream_t 
     // QH_BAND8_FORM=seq: the two halves one after the other on 256 lanes (osfir8s_kernel) instead of the two lane groups side by side
     // (osfir8k_kernel): same masks, same meter partials, same tile geometry.  Measured slower still (profiles/r05_notes.md: the second
     // read of the tile and the parked half go through memory), so it is there for experiments only; never for narrowed outputs.
+    // The kernel is in experiment builds only (-DQH_EXP_BAND8_SEQ, tools/ab_bench.py).
+#ifdef QH_EXP_BAND8_SEQ
     static const bool seq = [] { const char *e = std::getenv("QH_BAND8_FORM"); return e && std::strcmp(e, "seq") == 0; }();
     if (!egress && seq && a.stash) {
         dim3 g1((unsigned)ntiles * (unsigned)nch);
@@ -1508,6 +1512,7 @@ static void launch_band2g(OsfirArgs<double> a, int ntiles, int nch, hipStream_t 
         else hipLaunchKernelGGL((osfir8s_kernel<false>), g1, dim3(NT), kOsfir8kImage, s, a);
         return;
     }
+#endif
     dim3 grid((unsigned)ntiles * (unsigned)nch), block(kOsfir8kThreads);
     constexpr int lds = osfir8k_lds_bytes();
     if (meter && egress) hipLaunchKernelGGL((osfir8k_kernel<true, true>), grid, block, lds, s, a);
@@ -1943,12 +1948,14 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         const bool two_group = nc_max <= 2048 && band_tile_pref == 8192 && !force8k;
         const bool six_k = nc_max <= 2048 && band_tile_pref == 6144 && !force8k;
         const int want = six_k ? kOsfir6kN : (nc_max > 2048 || force8k || two_group) ? kBandNfftMax : kNfft;
-        if (two_group && !band_stash) {
+#ifdef QH_EXP_BAND8_SEQ
+        if (two_group && !band_stash) {         // (osfir8s_kernel's scratch rows: the experiment builds' kernel only)
             QH_HIP(hipStreamSynchronize(stream));
             drop_graphs(); epoch++;
             QH_HIP(dev_alloc(&band_stash, (size_t)nch * 4096));
             dev_bytes += (long long)nch * 4096 * (long long)sizeof(double2);
         }
+#endif
         if (want != bnfft || two_group != band2g || six_k != band6k) {
             bnfft = want; band2g = two_group; band6k = six_k;
             for (ChanCfg &c : cfg) { c.nbp_dirty = c.bp1_dirty = true; c.snb_dirty = true; }

@@ -22,7 +22,7 @@ struct qh_hbc {
     // Six and more stages run as TWO launches: the first four stages (15/16 of the arithmetic, 5 barriers per 2048-sample step) write
     // the /16 stream to `mid`, a second cascade of the remaining stages reads it.  In the one-launch form the stages behind the third
     // occupy 32 .. 8 lanes of a wavefront and still cost every wavefront a barrier each per step, and a segment's warm-up is 6 steps
-    // instead of 1; the extra 2 x 1/16 of HBM traffic is small beside that (61.44 Msps fp32, 2^26 samples, tools/dbg/hbc_head.sh:
+    // instead of 1; the extra 2 x 1/16 of HBM traffic is small beside that (61.44 Msps fp32, 2^26 samples, tools/dbg/hbc_head.sh (a one-off script, in git history):
     // 0.178 ms as one launch, 0.182 as 3 + 5, 0.152 as 4 + 4, 0.153 as 5 + 3).
     int head = 0;                   // stages of this handle's own launch (== nstage when there is no tail)
     qh_hbc *tail = nullptr;
@@ -111,7 +111,7 @@ qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream)
     h->device = device; h->nch = nch; h->nstage = nstage; h->dtype = dtype;
     h->esize = dtype == QH_F64 ? 16 : 8;
     h->head = nstage >= 6 ? 4 : nstage;
-    if (const char *e = getenv("QH_HBC_HEAD")) { const int v = atoi(e); h->head = v > 0 && v < nstage ? v : nstage; }      // experiments (tools/dbg/hbc_head.sh)
+    if (const char *e = getenv("QH_HBC_HEAD")) { const int v = atoi(e); h->head = v > 0 && v < nstage ? v : nstage; }      // experiments (tools/dbg/hbc_head.sh (a one-off script, in git history))
     h->warm = warm_of(h->head);
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); delete h; return nullptr; }

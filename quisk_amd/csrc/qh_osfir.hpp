@@ -669,6 +669,8 @@ __global__ __launch_bounds__(kOsfir8kThreads, 4) void osfir8k_kernel(OsfirArgs<d
     }
 }
 
+// (-DQH_EXP_BAND8_SEQ: experiment builds, tools/ab_bench.py; QH_BAND8_FORM=seq in the environment then selects it)
+#ifdef QH_EXP_BAND8_SEQ
 // ---- D = 1 stage on 8192-point tiles, the two halves of the radix-2 split ONE AFTER THE OTHER on 256 lanes ------------------------
 // The split of osfir8k_kernel (a = x[n] + x[n + 4096] -> even bins, b = (x[n] - x[n + 4096]) W^n -> odd bins) without its second
 // lane group: one 256-lane workgroup -- the register, LDS and occupancy budget of the 4096-point kernel, four workgroups per CU --
@@ -833,6 +835,7 @@ __global__ __launch_bounds__(NT, 4) void osfir8s_kernel(OsfirArgs<double> a)
         }
     }
 }
+#endif
 
 // ---- D = 1 stage on 6144-point tiles, 384 lanes ---------------------------------------------------------------------------
 // The 16 x 24 x 16 plan of qh_fft.hpp (Fft6144): 16 elements per lane like the 4096-point kernel, 4096 outputs per pair of

@@ -274,13 +274,17 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
     if (h->squelch_can_act) P = 1;
     // (a short first piece, so that the AGC -- the long pole: one dependent chain per receiver -- starts early, was measured: no gain)
     const int per = ((n + P - 1) / P + 63) / 64 * 64;
-    const int cap_bank = qh_qrx_out_count(h->rx, n) + 64 * (P + 1);
+    // Every piece has a FIXED stretch of the bank's output rows, piece * (its bound): with stretches laid end to end by the counts that
+    // came out, a piece's start moved by a sample from call to call whenever the piece length is not a multiple of the bank's decimation
+    // (240 ksps / 5 ...), and piece 0 of a pipelined call -- which waits for its own parity's AGC only -- could write into the stretch
+    // the other parity's AGC of the call before was still reading (two pieces, no scratch behind the bank).
+    const long long bank_piece = (long long)qh_qrx_out_count(h->rx, per) + 64;
+    const int cap_bank = (int)(P * bank_piece);
     h->o_stride = cap_bank;
     if (int rc = h->d_o.need((size_t)nch * (size_t)cap_bank)) return rc;
     if (h->tone_on || h->invert) if (int rc = h->d_x.need((size_t)nch * (size_t)per)) return rc;
     if (h->nb_level > 0 || h->nb) if (int rc = h->d_nb.need((size_t)nch * (size_t)per)) return rc;
     // scratch behind the bank, two halves used by alternate pieces (the AGC of piece p reads one while piece p + 1 fills the other)
-    const long long bank_piece = (long long)qh_qrx_out_count(h->rx, per) + 64;
     const long long fd_bound = frac ? (long long)((double)(bank_piece + 2) * 48000.0 / dr) + 8 : bank_piece;
     const long long up_bound = fd_bound * h->ratio + 64;
     h->fd_stride = fd_bound; h->up_stride = up_bound;
@@ -344,7 +348,8 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
             h->agc_started = true;              // (process_agc's initialising call has happened: only now may a call be cut into pieces)
             last_agc = par; h->last_agc_par = par;
         }
-        o_off += nb_;
+        if (nb_ > bank_piece) return set_error(QH_ERR_HIP, "qh_qps: a piece's bank output %d above its bound %lld", nb_, bank_piece);
+        o_off += bank_piece;
         out_off += na;
         pos += cnt;
     }

@@ -776,6 +776,7 @@ struct Shim {
     std::vector<double> buf; int sizeBuf = 0, nBuf = 0, in_size = 0, in_use = 0, W = 0, R = 0;
     // qh_wdsp_fexchange0_device: the ring in device memory (d_cap samples; `dev`: it holds the ring's contents, not `buf`)
     double *d_buf = nullptr; int d_cap = 0; bool dev = false;
+    int device = -1;                    // where d_buf and the events live (the device that was current when the ring went there)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 Shim g_shim[kMaxChannels];
@@ -784,6 +785,7 @@ Shim g_shim[kMaxChannels];
 int shim_side(Shim &s, bool dev, int want)
 {
     if (dev) {
+        if (s.device < 0) (void)hipGetDevice(&s.device);
         if (want > s.d_cap) {
             double *nb = nullptr;
             if (hipMalloc((void **)&nb, (size_t)want * 16) != hipSuccess) return qh::set_error(QH_ERR_HIP, "wdspFexchange0: ring allocation failed");
@@ -812,10 +814,17 @@ extern "C" void qh_wdsp_shim_release_device(int channel)
 {
     if (!valid(channel)) return;
     Shim &s = g_shim[channel];
-    if (s.dev) (void)shim_side(s, false, 0);
+    // (the ring's device, not whatever is current in the caller's thread)
+    int cur = -1;
+    const bool moved = s.device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != s.device && hipSetDevice(s.device) == hipSuccess;
+    // a ring that cannot be brought back starts again empty: `dev` may not stay set over a freed buffer
+    if (s.dev && shim_side(s, false, 0) != QH_OK) { s.sizeBuf = 0; s.W = 0; s.R = 0; s.nBuf = 0; }
+    s.dev = false;
     if (s.d_buf) { (void)hipDeviceSynchronize(); (void)hipFree(s.d_buf); s.d_buf = nullptr; s.d_cap = 0; }
     if (s.ev_in) { (void)hipEventDestroy(s.ev_in); s.ev_in = nullptr; }
     if (s.ev_out) { (void)hipEventDestroy(s.ev_out); s.ev_out = nullptr; }
+    s.device = -1;
+    if (moved) (void)hipSetDevice(cur);
 }
 
 void qh_wdsp_set_parameter(int channel, int in_size, int in_use)

@@ -64,7 +64,7 @@ def _draw(rng, mode, fs, bank, refs):
 @pytest.mark.parametrize("seed,mode,fs,play", [(1, 3, 192000, 48000), (2, 3, 111111, 96000), (3, 4, 96000, 48000), (4, 5, 192000, 48000),
                                                (5, 3, 48000, 48000), (6, 1, 133333, 48000), (7, 4, 185185, 96000), (8, 5, 96000, 192000),
                                                (9, 3, 192000, 192000), (10, 3, 370370, 48000),
-                                               # found by tools/dbg/bank_fuzz_sweep.py: a squelch switched on in a call that is cut into pieces
+                                               # found by tools/dbg/bank_fuzz_sweep.py (a one-off script, in git history): a squelch switched on in a call that is cut into pieces
                                                (146, 4, 185185, 96000), (101, 5, 192000, 48000), (106, 3, 192000, 192000),
                                                # the FM squelch's measuring windows while the bank cuts its calls into pieces (threshold set later)
                                                (7122, 5, 192000, 48000),

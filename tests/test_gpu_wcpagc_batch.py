@@ -280,7 +280,7 @@ def test_attack_window_moved_while_the_ring_holds_exact_zeros(qh, oracle, togeth
     first sample of a lap ago comes out.  Block at a time (the WDSP names' way) the engine's zeros are the reference's.  In a call of
     several DSP blocks bp1's overlap-save tile spans blocks with signal in them and leaves its rounding floor (1e-17 of the signal)
     where the reference's per-block transform gives 0.0 -- the engine used to look the window over at once and ran 4e-4 .. 1e-2 off in
-    gain for the few hundred samples of the jump (found by tools/dbg/fuzz_sweep.py, wide seed 1252; tools/dbg/agc_attack_probe.py).
+    gain for the few hundred samples of the jump (found by tools/dbg/fuzz_sweep.py (a one-off script, in git history), wide seed 1252; tools/dbg/agc_attack_probe.py (a one-off script, in git history)).
     When a window moves, entries below 1e-13 of the largest of the last RB_SIZE samples are now taken for the zeros they are in the
     reference (agc_rewindow_kernel)."""
     nblk = 230

@@ -1,4 +1,4 @@
-"""one cascade shape, a few launches: for rocprofv3 --pmc / --kernel-trace (tools/dbg/hbc_pmc.sh)"""
+"""one cascade shape, a few launches: for rocprofv3 --pmc / --kernel-trace (tools/dbg/hbc_pmc.sh (a one-off script, in git history))"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
