@@ -2606,6 +2606,8 @@ qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_ra
     if (D != 1 && D != 2 && D != 4 && D != 8 && D != 16) D = 0;
     if (D == 0 && !((in_rate > dsp_rate && in_rate % dsp_rate == 0) ||
                     (in_rate < dsp_rate && dsp_rate % in_rate == 0 && dsp_size % (dsp_rate / in_rate) == 0))) {
+        // (tests/test_oracle_wdsp.py::test_rates_that_are_whole_in_neither_direction_recycle_stale_buffer_tails shows what the reference's
+        // own arithmetic does with 96 k -> 64 k -> 48 k: every block's tail is what the block before left in the buffer)
         set_error(QH_ERR_UNSUPPORTED, "in_rate / dsp_rate must be a whole number or the reciprocal of one (wdsp/channel.c:39-42)");
         return nullptr;
     }

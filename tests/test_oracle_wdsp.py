@@ -227,3 +227,22 @@ def test_mlog10_is_pinned_to_the_reference_table(oracle):
         m = int((bits >> np.uint64(41)) & np.uint64(2047))
         assert L.wo_mlog10_value(v) == pin["mconv"] * (e + np.log2(1.0 + m / 2048.0))
     assert abs(L.wo_mlog10_value(1.0 + 2047.0 / 2048.0) / pin["mconv"] - pin["last"]) < 3e-16
+
+
+def test_rates_that_are_whole_in_neither_direction_recycle_stale_buffer_tails(oracle):
+    """Why qh_rxa_create refuses in_rate / dsp_rate / out_rate such as 96 k -> 64 k -> 48 k: the reference sizes
+    its blocks with integer divisions (pre_main_build, channel.c:39-52: dsp_insize = dsp_size * (96000 / 64000) = dsp_size, dsp_outsize =
+    dsp_size / (64000 / 48000) = dsp_size), xresample writes the samples it has (resample.c:120-157: about 2/3, then 3/4 of a block) and
+    every stage behind it works on dsp_size samples of a buffer whose tail still holds what the block before left there.  A tone in is not
+    a tone out: the tail of every output block is the tail of the block before it (here: never written at all).  The arithmetic of the
+    resampler is there for any L / M (qh_rat_*); a chain that feeds on its own leftovers block by block is not a stream to reproduce."""
+    o = oracle.WdspChannel(384, 256, 96000, 64000, 48000)
+    assert (o.dsp_insize, o.dsp_outsize) == (256, 256)
+    o.SetRXAMode(1); o.RXANBPSetRun(0); o.SetRXAAGCMode(0); o.SetRXAAGCFixed(0.0)
+    nblk = 8
+    x = np.exp(2j * np.pi * 1000.0 / 96000.0 * np.arange(o.dsp_insize * nblk))
+    y = o.xrxa(x).reshape(nblk, -1)
+    for b in range(2, nblk):
+        assert np.array_equal(y[b, 200:], y[b - 1, 200:])          # 256 * 2/3 * 3/4 = 128 new samples a block; the rest is left over
+    step = np.angle(y[4, 1:100] * np.conj(y[4, :99])) * 48000 / (2 * np.pi)
+    assert np.abs(step - 1000.0).max() > 100.0                     # and what is new is not the 1 kHz tone either
