@@ -260,6 +260,10 @@ struct Engine {
     AmState *am_next = nullptr;
     SnotchState *sn_next = nullptr;
     double *fmdc_next = nullptr;
+    double *fm_cin = nullptr, *fm_pw = nullptr;       // xfmd's dc removal taken in the de-emphasis stage's load: fmdc ahead of every tile, mtau^(k + 1)
+    long long fm_cin_cap = 0;
+    struct FmDcSrc { const double *a; long long stride; int shift; } ;
+    const FmDcSrc *band_fmdc = nullptr;               // set around the run_band call of that stage
     AmParam am_prm{};
     PllState *pll_state = nullptr;          // the SAM detector's loop (amd.c) ...
     PllState *fm_pll_state = nullptr;       // ... and the FM detector's (fmd.c): two objects in the reference, each keeps its state while the other runs
@@ -365,7 +369,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
-    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(pll_state); (void)hipFree(fm_pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(fm_cin); (void)hipFree(fm_pw); (void)hipFree(pll_state); (void)hipFree(fm_pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
     (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege); (void)hipFree(agc_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
@@ -800,6 +804,11 @@ int Engine::refresh_demod()
             q.g1 = 1.0 - std::exp(-2.0 * omegaN * zeta / rate);
             q.g2 = -q.g1 + 2.0 * (1 - std::exp(-omegaN * zeta / rate) * std::cos(omegaN / rate * std::sqrt(1.0 - zeta * zeta)));
             q.mtau = std::exp(-1.0 / (rate * tau)); q.onem_mtau = 1.0 - q.mtau;
+            std::vector<double> pw(2048);               // mtau^(k + 1): the carried dc's weight at sample k of a tile (fm_audio_at)
+            for (int k = 0; k < 2048; k++) pw[(size_t)k] = std::pow(q.mtau, (double)(k + 1));
+            QH_HIP(dev_alloc(&fm_pw, (size_t)2048));
+            QH_HIP(hipMemcpyAsync(fm_pw, pw.data(), 2048 * sizeof(double), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipStreamSynchronize(stream));
         }
         demod_alloc = true;
         lists_dirty = true;
@@ -1769,6 +1778,10 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     const int nl = list ? nlist : nch;
     if (pairs) {            // the caller has checked: real taps, one mask per pair, 4096-point tiles, no meters, no egress
         a.chan_list = pairs;
+        if (band_fmdc) {    // behind xfmd's loop in its local-dc form: the samples are made in the load (OsfirArgs::fmdc_*)
+            a.fmdc_a = band_fmdc->a; a.fmdc_stride = band_fmdc->stride; a.fmdc_shift = band_fmdc->shift;
+            a.fmdc_cin = fm_cin; a.fmdc_cstride = fm_cin_cap; a.fmdc_pw = fm_pw; a.fmdc_gain = fm_again;
+        }
         launch_osfir<1, false, false, false, false, false, kNfft, false, 0, true>(a, ntiles, npairs, stream);
     } else if (det) {       // the caller has checked: 4096-point tiles, no meters, no egress
         a.det_out = det_out; a.det_stride = det_stride;
@@ -1785,6 +1798,10 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     else launch_band<kBandNfftMax>(a, ntiles, nl, stream, meter, egress);
     tick(2);
     dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
+    if (pairs && band_fmdc)
+        hipLaunchKernelGGL(fm_audio_hist_kernel, g, dim3(256), 0, stream, band_fmdc->a, band_fmdc->stride, (int)n_mid, list, (const double *)fm_cin, fm_cin_cap,
+                           (const double *)fm_pw, band_fmdc->shift, (const double *)fm_again, (const double2 *)hist[hc], hist[hc ^ 1], kHistBand);
+    else
     hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
                        hist[hc], hist[hc ^ 1], kHistBand, (const unsigned long long *)nullptr,
                        (const unsigned long long *)nullptr, list);
@@ -2269,9 +2286,13 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     if (n_fm) {
         // xfmd's loop (fmd.c:151-172), time-tiled (qh_tiled.hpp): angles, then one loop per lane and tile, then dc removal + gain.
         // The FM channels' rows of `other` are free here: first half = angles, second half = loop filter output.
+        const bool pair = de_real && np_fm && !band6k && !band2g && bnfft == kNfft && !(dbg_forms & 16);      // the de-emphasis stage two channels a tile
+        const bool fmdc_fused = pair && long_parts[2] <= 1 && !(dbg_forms & 256);
+        FmDcSrc fmdc_src{ nullptr, 0, 0 };
         {
             // fused: nbp0 left the angles in the channels' own rows (first half) and the loop output goes to the rows of `other`
             double *theta = reinterpret_cast<double *>(fm_theta_fused ? cur : other), *fil = reinterpret_cast<double *>(other) + buf_cap;
+            if (fmdc_fused) fil = reinterpret_cast<double *>(cur) + buf_cap;     // (the de-emphasis stage reads it while it writes the rows of `other`)
             const long long per = (n_mid + NT - 1) / NT;
             if (!fm_theta_fused)
                 hipLaunchKernelGGL(pll_theta_kernel, dim3((unsigned)(per < 1024 ? per : 1024), (unsigned)n_fm), dim3(NT), 0, stream, cur, buf_cap,
@@ -2291,13 +2312,32 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                 QH_HIP(dev_alloc(&pll_ends, (size_t)nch * (size_t)ngroups * 64 * kPllEndsW));
                 pll_ends_cap = (long long)ngroups * 64;
             }
+            // fmdc_fused: the dc removal and gain (fmd.c:169-171) do not get a pass of their own -- the loop kernels take the tile's own
+            // share of the average off (local_dc), a chain over the tiles' contributions gives the average ahead of every tile, and the
+            // de-emphasis stage's load takes the rest off and applies the gain (OsfirArgs::fmdc_*): 8 bytes per sample read there instead
+            // of 8 read + 16 written here and 16 read there
+            const bool fused_now = fmdc_fused && (fm_tile & (fm_tile - 1)) == 0 && fm_tile <= 2048;
+            if (fused_now && pll_ends_cap + 1 > fm_cin_cap) {
+                QH_HIP(hipStreamSynchronize(stream));
+                if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
+                drop_graphs(); epoch++;
+                (void)hipFree(fm_cin); fm_cin = nullptr;
+                QH_HIP(dev_alloc(&fm_cin, (size_t)nch * (size_t)(pll_ends_cap + 1)));
+                fm_cin_cap = pll_ends_cap + 1;
+            }
             hipLaunchKernelGGL((pll_lanes_kernel<false>), dim3((unsigned)ngroups, (unsigned)n_fm), dim3(64), 0, stream, (const double *)theta,
                                2 * buf_cap, fil, 2 * buf_cap, (int)n_mid, list_fm, (const PllState *)fm_pll_state, pll_ends, pll_ends_cap * kPllEndsW,
-                               fm_pll_prm, fm_tile, kFmWarm);
+                               fm_pll_prm, fm_tile, kFmWarm, fused_now ? 1 : 0);
             hipLaunchKernelGGL((pll_verify_kernel<false>), dim3((unsigned)n_fm), dim3(64), 0, stream, (const double *)theta, 2 * buf_cap, fil,
                                2 * buf_cap, (int)n_mid, list_fm, fm_pll_state, pll_ends, pll_ends_cap * kPllEndsW, fm_pll_prm, fm_tile, kFmWarm,
-                               pll_nfixed, pll_check_only);
-            {
+                               pll_nfixed, pll_check_only, fused_now ? 1 : 0);
+            if (fused_now) {
+                hipLaunchKernelGGL(fm_dc_chain_kernel, dim3((unsigned)n_fm), dim3(64), 0, stream, (int)n_mid, fm_tile, list_fm, fm_pll_state, fm_pll_prm,
+                                   (const double *)pll_ends, pll_ends_cap * kPllEndsW, fm_cin, fm_cin_cap);
+                int sh = 0;
+                while ((1 << sh) < fm_tile) sh++;
+                fmdc_src = FmDcSrc{ fil, 2 * buf_cap, sh };
+            } else {
                 // dc removal + gain: the tiles' contributions are in `ends` already, one pass over `fil`
                 const int G = seg_groups(n_fm);
                 hipLaunchKernelGGL(fm_dc_tiled_kernel, dim3((unsigned)n_fm, (unsigned)G), dim3(kSegThreads), 0, stream, (const double *)fil,
@@ -2307,9 +2347,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             }
         }
         {   // de-emphasis: real taps on a real signal, two channels per tile
-            const bool pair = de_real && np_fm && !band6k && !band2g && bnfft == kNfft && !(dbg_forms & 16);
+            if (fmdc_src.a) band_fmdc = &fmdc_src;
             run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_de, 0, hist_de, cur_de, P, list_fm, n_fm, false, false, 0, nullptr, 0,
                      pair ? pairs_fm : nullptr, np_fm);
+            band_fmdc = nullptr;
         }
         run_band(other, buf_cap, cur, buf_cap, nullptr, n_mid, mask_aud, 0, hist_aud, cur_aud, P, list_fm, n_fm);   // audio filter
         tick(1);

@@ -92,9 +92,27 @@ template <typename T> struct OsfirArgs {
     long long det_sum_stride;           // tiles per channel row
     double det_m[2], det_m256[2], det_g[2];
     int pair_im0;                       // PAIR kernels: the unpaired equivalent would see (y, 0) (Quisk's real chains) instead of (y, y)
+    // PAIR kernels behind xfmd's loop in its local-dc form (qh_tiled.hpp: pll_lanes_kernel local_dc, fm_dc_chain_kernel): the stage's
+    // input never exists as complex samples -- sample g of a channel is again (a_local[g] - cin[g >> shift] pw[g & (L - 1)]), the dc
+    // removal and gain of fmd.c:169-171 taken in the load (one 8-byte array read instead of a pass that writes 16 and a load that reads them)
+    const double *fmdc_a;               // [nch][fmdc_stride] doubles; null: the plain PAIR load
+    long long fmdc_stride;
+    const double *fmdc_cin;             // [nch][fmdc_cstride]: fmdc ahead of every tile of 2^shift samples
+    long long fmdc_cstride;
+    const double *fmdc_pw;              // mtau^(k + 1), k < 2^shift
+    const double *fmdc_gain;            // [nch] again
+    int fmdc_shift;
     double2 *stash;                     // osfir8s_kernel: [nch][4096] scratch for the tile that the end of the call cuts short
 };
 
+
+// the audio of sample g in xfmd's local-dc form (OsfirArgs::fmdc_*)
+__device__ __forceinline__ double fm_audio_at(const double *a_local, const double *cin, const double *pw, int shift, double gain, long long g)
+{
+    const long long t = g >> shift;
+    const int k = (int)(g - (t << shift));
+    return gain * __builtin_fma(-cin[t], pw[k], a_local[g]);
+}
 
 template <typename T> __device__ __forceinline__ void sincos_turns(unsigned long long ph, T &c, T &s);
 template <> __device__ __forceinline__ void sincos_turns<double>(unsigned long long ph, double &c, double &s)
@@ -329,7 +347,30 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
         static_assert(!MIX && !METER && !OUTMIX && !EGRESS && DET == 0, "pairs ride on a plain stage (any fold: a real filter acts on the two parts alike)");
         const C *in_b = a.in + (long long)ch_b * a.in_stride;
         const C *hist_b = a.hist ? a.hist + (long long)ch_b * a.hist_stride : nullptr;
-        if (interior) {
+        if (a.fmdc_a) {                     // workgroup-uniform
+            const double *aa = a.fmdc_a + (long long)ch * a.fmdc_stride, *ab = a.fmdc_a + (long long)ch_b * a.fmdc_stride;
+            const double *ca = a.fmdc_cin + (long long)ch * a.fmdc_cstride, *cb = a.fmdc_cin + (long long)ch_b * a.fmdc_cstride;
+            const double ga = a.fmdc_gain[ch], gb = a.fmdc_gain[ch_b];
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const long long g = (long long)g0 + t + r * NT;
+                    const long long tl = g >> a.fmdc_shift;
+                    const double pw = a.fmdc_pw[(int)(g - (tl << a.fmdc_shift))];
+                    x[r] = mk<T>((T)(ga * __builtin_fma(-ca[tl], pw, aa[g])), (T)(gb * __builtin_fma(-cb[tl], pw, ab[g])));
+                }
+            } else {
+                auto fetch = [&](const double *src, const double *cin, double gain, const C *h, int g) -> T {
+                    if (g >= 0) return g < a.n_in ? (T)fm_audio_at(src, cin, a.fmdc_pw, a.fmdc_shift, gain, g) : (T)0;
+                    return (h && g + a.hist_len >= 0) ? h[g + a.hist_len].x : (T)0;
+                };
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const int g = g0 + t + r * NT;
+                    x[r] = mk<T>(fetch(aa, ca, ga, hist, g), fetch(ab, cb, gb, hist_b, g));
+                }
+            }
+        } else if (interior) {
             const C *p = in + g0 + t, *pb = in_b + g0 + t;
 #pragma unroll
             for (int r = 0; r < E; r++) x[r] = mk<T>(p[r * NT].x, pb[r * NT].x);

@@ -652,7 +652,7 @@ __device__ __forceinline__ void pll_lane_steps(PllLane &s, double (&t)[kPllBatch
 template <bool EMIT_PT>
 static __global__ __launch_bounds__(64, 2) void pll_lanes_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
                                                                  const int *chan_list, const PllState *state, double *ends, long long estride,
-                                                                 PllParam q, int L, int H)
+                                                                 PllParam q, int L, int H, int local_dc = 0)
 {
     __shared__ double lds[64 * kPllPitch];
     const int ch = chan_list[blockIdx.y], lane = threadIdx.x, group = blockIdx.x;
@@ -728,8 +728,23 @@ static __global__ __launch_bounds__(64, 2) void pll_lanes_kernel(const double *t
         if (i0 + B == H && live) { e[0] = s.pt; e[1] = s.fil_out; e[2] = s.omega; }       // state where the warm-up ends
         if constexpr (!EMIT_PT) {
             if (i0 >= H) {                              // output steps (a tile that crosses the call's end is nobody's predecessor)
+                // local_dc (FM, fm_dc_chain_kernel's form): what leaves is fil - (the dc average's response to this tile's OWN samples from a
+                // zero state) -- onem_mtau times the running sum; the share of everything ahead of the tile, c_in mtau^(k + 1), is taken off
+                // where the next stage loads the sample (osfir_kernel, PAIR with fmdc_a)
+                if (local_dc) {
+                    // (here the sum stops at the call's last sample: the tile the call's end cuts short hands its share to the chain too)
+                    if (gb + B <= n) {
 #pragma unroll
-                for (int k = 0; k < B; k++) dcsum = __builtin_fma(dcsum, q.mtau, t[k]);
+                        for (int k = 0; k < B; k++) { dcsum = __builtin_fma(dcsum, q.mtau, t[k]); t[k] = __builtin_fma(-q.onem_mtau, dcsum, t[k]); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < B; k++)
+                            if (gb + k < n) { dcsum = __builtin_fma(dcsum, q.mtau, t[k]); t[k] = __builtin_fma(-q.onem_mtau, dcsum, t[k]); }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < B; k++) dcsum = __builtin_fma(dcsum, q.mtau, t[k]);
+                }
             }
         }
 #pragma unroll
@@ -776,7 +791,7 @@ __device__ __forceinline__ bool pll_state_differs(double pa, double fa, double o
 template <bool EMIT_PT>
 static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *theta, long long tstride, double *fil, long long fstride, int n,
                                                                   const int *chan_list, PllState *state, double *ends, long long estride,
-                                                                  PllParam q, int L, int H, int *nfixed, int check_only)
+                                                                  PllParam q, int L, int H, int *nfixed, int check_only, int local_dc = 0)
 {
     __shared__ double pll_out[128];
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
@@ -786,6 +801,7 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
     const int ntiles = (n + L - 1) / L;
     const int first = H / L + 1;                                        // tiles 0 .. H/L began at sample 0 from the carried state
     int fixed = 0;
+    const PoleScan sc = make_pole_scan(q.mtau, lane);
     // the tile re-run last and its end state (uniform): whoever needs that state takes it from here, not from memory
     double rp = 0, rf = 0, ro = 0;
     int rt = -1;
@@ -811,7 +827,7 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
             if (tq - 1 == rt) { Ls.pt = rp; Ls.fil_out = rf; Ls.omega = ro; }
             const long long s0 = (long long)tq * L;
             const int len = (int)((long long)n - s0 < L ? (long long)n - s0 : L);
-            double dcsum = 0.0;
+            double dcsum = 0.0, dcl = 0.0;
             for (int off = 0; off < len; off += 64) {
                 const int cnt = len - off < 64 ? len - off : 64;
                 double tt = 0.0;
@@ -819,7 +835,15 @@ static __global__ __launch_bounds__(64) void pll_verify_kernel(const double *the
                 const unsigned long long zero = __ballot(tt >= 4.0);
                 double my_pt, my_fil;
                 pll_run64(Ls, tt, zero, cnt, q, lane, my_pt, my_fil, pll_out);
-                if (lane < cnt) fo[s0 + off + lane] = EMIT_PT ? my_pt : my_fil;
+                double outv = EMIT_PT ? my_pt : my_fil;
+                if constexpr (!EMIT_PT) {
+                    if (local_dc) {         // (pll_lanes_kernel's local_dc: the tile's own share of the dc average comes off here)
+                        const double dcs = scan_pole_dpp(lane < cnt ? q.onem_mtau * my_fil : 0.0, sc) + sc.pw * dcl;
+                        outv = my_fil - dcs;
+                        dcl = lane_bcast(dcs, cnt - 1);
+                    }
+                }
+                if (lane < cnt) fo[s0 + off + lane] = outv;
                 if constexpr (!EMIT_PT)
                     dcsum = __builtin_fma(dcsum, lane_pow(q.mtau, cnt), wave_sum_d(lane < cnt ? my_fil * lane_pow(q.mtau, cnt - 1 - lane) : 0.0));
             }
@@ -901,6 +925,50 @@ static __global__ __launch_bounds__(kSegThreads) void fm_dc_tiled_kernel(const d
     }
     // a slot of its own: another workgroup of this launch may not have read state[ch].fmdc yet (commit_fmdc_kernel moves it in)
     if (is_last && lane == 0 && n > 0) fmdc_out[ch] = c;
+}
+
+// The dc average of xfmd at every tile boundary (fmd.c:169), for the loop kernels' local_dc form: cin[ch][t] = fmdc just ahead of tile
+// t's first sample = the carried value through every tile before it, c_(t+1) = mtau^L c_t + s_t with s_t the tile's own contribution
+// (`ends` [6]).  One wavefront per channel, 64 tiles per step (a scan with the pole mtau^L); the value behind the call's last sample goes
+// straight into the state (nobody else reads it in this call: the stage that takes the dc off reads cin).
+static __global__ __launch_bounds__(64) void fm_dc_chain_kernel(int n, int L, const int *chan_list, PllState *state, PllParam q, const double *ends,
+                                                                 long long estride, double *cin, long long cstride)
+{
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
+    const int nt = (n + L - 1) / L, nfull = n / L;                     // tiles, whole tiles
+    const double mL = pow(q.mtau, (double)L);
+    const PoleScan sc = make_pole_scan(mL, lane);
+    const double *e = ends + (long long)ch * estride;
+    double *co = cin + (long long)ch * cstride;
+    double c = state[ch].fmdc;
+    if (lane == 0) co[0] = c;
+    for (int blk = 0; blk < nfull; blk += 64) {
+        const int cnt = nfull - blk < 64 ? nfull - blk : 64;
+        const double s = lane < cnt ? e[(long long)(blk + lane) * kPllEndsW + 6] : 0.0;
+        const double cend = scan_pole_dpp(s, sc) + sc.pw * c;          // fmdc behind the last sample of tile blk + lane
+        if (lane < cnt) co[blk + lane + 1] = cend;
+        c = lane_bcast(cend, cnt - 1);
+    }
+    if (nt > nfull) c = __builtin_fma(c, pow(q.mtau, (double)(n - nfull * L)), e[(long long)nfull * kPllEndsW + 6]);        // the tile the call's end cuts short
+    if (lane == 0 && n > 0) state[ch].fmdc = c;
+}
+
+// The delay line of the stage that loads the audio in that form (fm_audio_at, qh_osfir.hpp) (hist_update_kernel's job for a stage whose input never exists as complex
+// samples): new_hist[j] <- (audio, audio) of sample n - H + j, or the old line's sample where that index is negative.
+static __global__ __launch_bounds__(256) void fm_audio_hist_kernel(const double *a_local, long long astride, int n, const int *chan_list,
+                                                                   const double *cin, long long cstride, const double *pw, int shift, const double *again,
+                                                                   const double2 *old_hist, double2 *new_hist, int H)
+{
+    const int ch = chan_list[blockIdx.y];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+    const long long g = (long long)n - H + j;
+    double2 v;
+    if (g >= 0) {
+        const double a = fm_audio_at(a_local + (long long)ch * astride, cin + (long long)ch * cstride, pw, shift, again[ch], g);
+        v = make_double2(a, a);
+    } else v = old_hist[(long long)ch * H + (H + g)];
+    new_hist[(long long)ch * H + j] = v;
 }
 
 static __global__ void commit_fmdc_kernel(PllState *state, const double *next, const int *chan_list, int count)
