@@ -264,6 +264,9 @@ struct Engine {
     long long fm_cin_cap = 0;
     struct FmDcSrc { const double *a; long long stride; int shift; } ;
     const FmDcSrc *band_fmdc = nullptr;               // set around the run_band call of that stage
+    double *am_cin = nullptr, *am_pw = nullptr, *am_last = nullptr;      // the fade leveller's carried share taken in bp1's load (osfir_kernel DET 3)
+    long long am_cin_cap = 0;
+    const FmDcSrc *band_amlv = nullptr;
     AmParam am_prm{};
     PllState *pll_state = nullptr;          // the SAM detector's loop (amd.c) ...
     PllState *fm_pll_state = nullptr;       // ... and the FM detector's (fmd.c): two objects in the reference, each keeps its state while the other runs
@@ -369,7 +372,7 @@ Engine::~Engine()
     (void)hipFree(nco_phase); (void)hipFree(nco_dphase); (void)hipFree(nco_parked); (void)hipFree(nco_step); (void)hipFree(epi);
     (void)hipFree(lane_rot); (void)hipFree(tile_rot); (void)hipFree(front_taps); (void)hipFree(retune_list); (void)hipFree(retune_law);
     for (int i = 0; i < 2; i++) { (void)hipFree(hist_front[i]); (void)hipFree(hist_nbp[i]); (void)hipFree(hist_bp1[i]); (void)hipFree(buf[i]); }
-    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(fm_cin); (void)hipFree(fm_pw); (void)hipFree(pll_state); (void)hipFree(fm_pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
+    (void)hipFree(list_buf); (void)hipFree(levelfade); (void)hipFree(am_state); (void)hipFree(am_next); (void)hipFree(sn_next); (void)hipFree(fmdc_next); (void)hipFree(fm_cin); (void)hipFree(fm_pw); (void)hipFree(am_cin); (void)hipFree(am_pw); (void)hipFree(am_last); (void)hipFree(pll_state); (void)hipFree(fm_pll_state); (void)hipFree(fm_again); (void)hipFree(pll_ends); (void)hipFree(pll_nfixed); (void)hipFree(am_tsum);
     (void)hipFree(sb_phi); (void)hipFree(sb_sum); (void)hipFree(sb_start);
     (void)hipFree(agc_scr); (void)hipFree(agc_ends); (void)hipFree(agc_fin); (void)hipFree(agc_halo); (void)hipFree(agc_tail); (void)hipFree(agc_nfixed); (void)hipFree(agc_sege); (void)hipFree(agc_tsum);
     for (double *&q : seg_sum) { (void)hipFree(q); q = nullptr; }
@@ -795,6 +798,23 @@ int Engine::refresh_demod()
             q.mtauR = std::exp(-1.0 / (rate * tauR)); q.onem_mtauR = 1.0 - q.mtauR;
             q.mtauI = std::exp(-1.0 / (rate * tauI)); q.onem_mtauI = 1.0 - q.mtauI;
             am_prm.mtauR = q.mtauR; am_prm.onem_mtauR = q.onem_mtauR; am_prm.mtauI = q.mtauI; am_prm.onem_mtauI = q.onem_mtauI;
+            std::vector<double> pw(2 * 2048);           // mtauR^(k + 1), mtauI^(k + 1): the carried averages' weights at sample k of a 2048-sample tile
+            for (int k = 0; k < 2048; k++) { pw[(size_t)k] = std::pow(q.mtauR, (double)(k + 1)); pw[(size_t)(2048 + k)] = std::pow(q.mtauI, (double)(k + 1)); }
+            // ... and the lanes' scan weights of the two averages (qh_wave.hpp PoleScan: pa = m^((lane & 15) + 1), pb = m^((lane & 31) + 1), pw = m^(lane + 1))
+            pw.resize(2 * 2048 + 6 * 64);
+            for (int f = 0; f < 2; f++) {
+                const double m = f ? q.mtauI : q.mtauR;
+                for (int l = 0; l < 64; l++) {
+                    pw[(size_t)(2 * 2048 + (3 * f + 0) * 64 + l)] = std::pow(m, (double)((l & 15) + 1));
+                    pw[(size_t)(2 * 2048 + (3 * f + 1) * 64 + l)] = std::pow(m, (double)((l & 31) + 1));
+                    pw[(size_t)(2 * 2048 + (3 * f + 2) * 64 + l)] = std::pow(m, (double)(l + 1));
+                }
+            }
+            QH_HIP(dev_alloc(&am_pw, pw.size()));
+            QH_HIP(dev_alloc(&am_last, (size_t)2 * nch));
+            QH_HIP(hipMemcpyAsync(am_pw, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            QH_HIP(hipMemsetAsync(am_last, 0, (size_t)2 * nch * sizeof(double), stream));
+            QH_HIP(hipStreamSynchronize(stream));
         }
         // calc_fmd (wdsp/fmd.c:29-44) with create_rxa's constants (RXA.c:199-204)
         {
@@ -1782,15 +1802,25 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
             a.fmdc_a = band_fmdc->a; a.fmdc_stride = band_fmdc->stride; a.fmdc_shift = band_fmdc->shift;
             a.fmdc_cin = fm_cin; a.fmdc_cstride = fm_cin_cap; a.fmdc_pw = fm_pw; a.fmdc_gain = fm_again;
         }
+        if (band_amlv) {    // behind an nbp0 stage that left the envelope and the leveller's local share (DET 3)
+            a.amlv_a = band_amlv->a; a.amlv_stride = band_amlv->stride; a.amlv_shift = band_amlv->shift;
+            a.amlv_cin = am_cin; a.amlv_cstride = am_cin_cap; a.amlv_pw = am_pw;
+        }
         launch_osfir<1, false, false, false, false, false, kNfft, false, 0, true>(a, ntiles, npairs, stream);
     } else if (det) {       // the caller has checked: 4096-point tiles, no meters, no egress
         a.det_out = det_out; a.det_stride = det_stride;
-        if (det == 2) {
+        if (det == 2 || det == 3) {
             a.det_sum = am_tsum; a.det_sum_stride = am_tsum_cap;
             a.det_m[0] = am_prm.mtauR; a.det_m[1] = am_prm.mtauI;
             a.det_m256[0] = std::pow(am_prm.mtauR, 256.0); a.det_m256[1] = std::pow(am_prm.mtauI, 256.0);
             a.det_g[0] = am_prm.onem_mtauR; a.det_g[1] = am_prm.onem_mtauI;
-            launch_osfir<1, false, false, false, false, false, kNfft, false, 2>(a, ntiles, nl, stream);
+            a.det_lf = levelfade; a.det_last = am_last; a.det_scan = am_pw + 2 * 2048;
+            for (int f = 0; f < 2; f++) {
+                const double m = a.det_m[f];
+                a.det_mp[f][0] = m; a.det_mp[f][1] = m * m; a.det_mp[f][2] = (m * m) * (m * m); a.det_mp[f][3] = ((m * m) * (m * m)) * ((m * m) * (m * m));
+            }
+            if (det == 3) launch_osfir<1, false, false, false, false, false, kNfft, false, 3>(a, ntiles, nl, stream);
+            else launch_osfir<1, false, false, false, false, false, kNfft, false, 2>(a, ntiles, nl, stream);
         } else launch_osfir<1, false, false, false, false, false, kNfft, false, 1>(a, ntiles, nl, stream);
     } else if (band6k) launch_band6k(a, ntiles, nl, stream, meter, egress);
     else if (band2g) launch_band2g(a, ntiles, nl, stream, meter, egress);
@@ -1798,7 +1828,10 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     else launch_band<kBandNfftMax>(a, ntiles, nl, stream, meter, egress);
     tick(2);
     dim3 g((kHistBand + NT - 1) / NT, (unsigned)(list ? nlist : nch));
-    if (pairs && band_fmdc)
+    if (pairs && band_amlv)
+        hipLaunchKernelGGL(am_audio_hist_kernel, g, dim3(256), 0, stream, band_amlv->a, band_amlv->stride, (int)n_mid, list, (const double *)am_cin, am_cin_cap,
+                           (const double *)am_pw, band_amlv->shift, (const double2 *)hist[hc], hist[hc ^ 1], kHistBand);
+    else if (pairs && band_fmdc)
         hipLaunchKernelGGL(fm_audio_hist_kernel, g, dim3(256), 0, stream, band_fmdc->a, band_fmdc->stride, (int)n_mid, list, (const double *)fm_cin, fm_cin_cap,
                            (const double *)fm_pw, band_fmdc->shift, (const double *)fm_again, (const double2 *)hist[hc], hist[hc ^ 1], kHistBand);
     else
@@ -2085,6 +2118,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // ... and the AM channels' nbp0 leaves the envelope and every tile's share of the fade leveller's averages: one pass does the rest
     const int P_am = ((P + 63) / 64) * 64;
     const bool am_fused = direct && !(dbg_forms & 4) && n_am > 0 && n_rb == n_am + n_sam && !band6k && !band2g && bnfft == kNfft && P_am < bnfft;
+    // ... or, when the tiles are 2048 outputs behind 2048 samples of pre-roll and bp1 takes its channels two a tile, no pass at all: the
+    // leveller's local share in nbp0's store (DET 3), the carried share in bp1's load
+    const bool am_lv_fused = am_fused && P_am == 2048 && bnfft - P_am == 2048 && np_am > 0 && n_bp1p[0] && long_parts[1] <= 1 && !(dbg_forms & (16 | 512));
     if (am_fused) {
         const long long nt = (n_mid + (bnfft - P_am) - 1) / (bnfft - P_am);
         if (nt > am_tsum_cap) {
@@ -2095,6 +2131,14 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             QH_HIP(dev_alloc(&am_tsum, (size_t)nch * (size_t)nt * 2));
             am_tsum_cap = nt;
         }
+        if (am_lv_fused && am_tsum_cap + 1 > am_cin_cap) {
+            QH_HIP(hipStreamSynchronize(stream));
+            if (side_stream) QH_HIP(hipStreamSynchronize(side_stream));
+            drop_graphs(); epoch++;
+            (void)hipFree(am_cin); am_cin = nullptr;
+            QH_HIP(dev_alloc(&am_cin, (size_t)nch * (size_t)(am_tsum_cap + 1) * 2));
+            am_cin_cap = am_tsum_cap + 1;
+        }
     }
     if (split) {
         if (!side_stream) {
@@ -2103,13 +2147,19 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
             QH_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         }
         if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, nullptr, 0, 1)) return rc;      // tile table, every channel
-        QH_HIP(hipEventRecord(ev_fork, stream));
-        QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        // Where the second stream starts: behind the FM channels' nbp0 (2; the default), behind their front (1) or at once (0) -- QH_DBG_FORMS
+        // bits 6-7 count DOWN from 2 (experiments).  The FM channels' chain is the longer one and ends in kernels that cannot fill the chip
+        // (the loop's lanes, the CTCSS notch's scans): with their front and nbp0 alone on the chip first, all of them run beside the other
+        // channels' dense filters (config 4, one box: 10.45 ms forked at once, 10.31 forked here).
+        const int fork_at = 2 - (((dbg_forms >> 6) & 3) > 2 ? 2 : ((dbg_forms >> 6) & 3));
+        if (fork_at == 0) { QH_HIP(hipEventRecord(ev_fork, stream)); QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0)); }
         if (int rc = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_fm, n_fm, 2)) return rc;
+        if (fork_at == 1) { QH_HIP(hipEventRecord(ev_fork, stream)); QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0)); }
         int hc = cur_nbp;
         // the FM channels' nbp0 feeds the loop's phase detector and nothing else: its store takes the angles (first half of the rows)
         if (any_nbp) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_fm, n_fm, false, false,
                               fm_theta_fused ? 1 : 0, reinterpret_cast<double *>(other), 2 * buf_cap);
+        if (fork_at >= 2) { QH_HIP(hipEventRecord(ev_fork, stream)); QH_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0)); }
         std::swap(stream, side_stream);
         int rc2 = run_front(in, in_stride, cur, buf_cap, nullptr, n_in, n_mid, list_rest, n_rest, 2);
         hc = cur_nbp;
@@ -2121,7 +2171,7 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
                     if (n_sam) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_sam, n_sam);
                     hc = cur_nbp;
                     run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P_am, list_am, n_am, false, false,
-                             2, reinterpret_cast<double *>(other), 2 * buf_cap);
+                             am_lv_fused ? 3 : 2, reinterpret_cast<double *>(other), 2 * buf_cap);
                 } else if (n_rb) run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rb, n_rb);
             } else run_band(cur, buf_cap, other, buf_cap, nullptr, n_mid, mask_nbp, kBandNfftMax, hist_nbp, hc, P, list_rest, n_rest);
         }
@@ -2190,7 +2240,12 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     };
     for (double *&q : seg_sum)
         if (!q) QH_HIP(dev_alloc(&q, (size_t)nch * kSegWaves * kSegMaxGroups * kSegSumW));
-    if (n_am && am_fused) {         // envelopes in the channels' own rows (first half), audio to the rows of `other`
+    FmDcSrc amlv_src{ nullptr, 0, 0 };
+    if (n_am && am_lv_fused) {      // the envelope + the leveller's local share lie in the channels' own rows (first half); bp1 loads them from there
+        hipLaunchKernelGGL(am_lv_chain_kernel, dim3((unsigned)n_am), dim3(64), 0, am_stream, (int)n_mid, bnfft - P_am, list_am, (const int *)levelfade, am_state,
+                           am_prm, (const double *)am_tsum, am_tsum_cap, (const double *)am_last, am_cin, am_cin_cap);
+        amlv_src = FmDcSrc{ reinterpret_cast<double *>(cur), 2 * buf_cap, 11 };
+    } else if (n_am && am_fused) {  // envelopes in the channels' own rows (first half), audio to the rows of `other`
         const int G = seg_groups(n_am + (n_mid >= kSamTiledMin ? n_sam0 : 0));
         hipLaunchKernelGGL(am_level_tiled_kernel, dim3((unsigned)n_am, (unsigned)G), dim3(kSegThreads), 0, am_stream,
                            (const double *)reinterpret_cast<double *>(cur), 2 * buf_cap, other, buf_cap, (int)n_mid, list_am, levelfade, (const AmState *)am_state,
@@ -2274,8 +2329,10 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
         std::swap(stream, side_stream);
         int hc = cur_bp1;
         if (am_fused) {
+            if (amlv_src.a) band_amlv = &amlv_src;
             run_band(other, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_am, n_am, false, false, 0, nullptr, 0,
                      np_am && !(dbg_forms & 16) ? pairs_am : nullptr, np_am);
+            band_amlv = nullptr;
             hc = cur_bp1;
             if (n_sam) run_band(cur, buf_cap, out, out_stride, epi, n_mid, mask_bp1, kBandNfftMax, hist_bp1, hc, P, list_sam, n_sam, false, false, 0,
                                 nullptr, 0, np_sam && !(dbg_forms & 16) ? pairs_sam : nullptr, np_sam);

@@ -102,6 +102,17 @@ template <typename T> struct OsfirArgs {
     const double *fmdc_pw;              // mtau^(k + 1), k < 2^shift
     const double *fmdc_gain;            // [nch] again
     int fmdc_shift;
+    // DET 3 (xamd's envelope AND the fade leveller's share of the tile, see the kernel) and the PAIR stage behind it (bp1):
+    const int *det_lf;                  // [nch] levelfade flags (amd.c:134)
+    const double *det_scan;             // [2][3][64]: the lanes' scan weights of the two averages (PoleScan pa, pb, pw), made on the host
+    double det_mp[2][4];                // m, m^2, m^4, m^8 of the two averages
+    double *det_last;                   // [nch][2]: the two averages' local values at the call's last sample (the tile the call's end cuts short)
+    const double *amlv_a;               // PAIR: [nch][amlv_stride] doubles left by DET 3; null: the plain PAIR load
+    long long amlv_stride;
+    const double *amlv_cin;             // [nch][amlv_cstride][2]: the two averages ahead of every tile of 2^amlv_shift samples
+    long long amlv_cstride;
+    const double *amlv_pw;              // [2][2^amlv_shift]: mtauR^(k + 1), mtauI^(k + 1)
+    int amlv_shift;
     double2 *stash;                     // osfir8s_kernel: [nch][4096] scratch for the tile that the end of the call cuts short
 };
 
@@ -370,6 +381,36 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
                     x[r] = mk<T>(fetch(aa, ca, ga, hist, g), fetch(ab, cb, gb, hist_b, g));
                 }
             }
+        } else if (a.amlv_a) {              // workgroup-uniform: behind DET 3 -- audio = a_local + cI mI^(k + 1) - cR mR^(k + 1) (amd.c:136-138)
+            const double *aa = a.amlv_a + (long long)ch * a.amlv_stride, *ab = a.amlv_a + (long long)ch_b * a.amlv_stride;
+            const double2 *ca = reinterpret_cast<const double2 *>(a.amlv_cin) + (long long)ch * a.amlv_cstride;
+            const double2 *cb = reinterpret_cast<const double2 *>(a.amlv_cin) + (long long)ch_b * a.amlv_cstride;
+            const double *pwR = a.amlv_pw, *pwI = a.amlv_pw + (1 << a.amlv_shift);
+            auto fetch = [&](const double *src, const double2 *cin, const C *h, int g) -> T {
+                if (g >= 0) {
+                    if (g >= a.n_in) return (T)0;
+                    const int tl = g >> a.amlv_shift, k = g - (tl << a.amlv_shift);
+                    const double2 c = cin[tl];
+                    return (T)(src[g] + __builtin_fma(c.y, pwI[k], -c.x * pwR[k]));
+                }
+                return (h && g + a.hist_len >= 0) ? h[g + a.hist_len].x : (T)0;
+            };
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const int g = g0 + t + r * NT;
+                    const int tl = g >> a.amlv_shift, k = g - (tl << a.amlv_shift);
+                    const double2 c0 = ca[tl], c1 = cb[tl];
+                    const double wR = pwR[k], wI = pwI[k];
+                    x[r] = mk<T>((T)(aa[g] + __builtin_fma(c0.y, wI, -c0.x * wR)), (T)(ab[g] + __builtin_fma(c1.y, wI, -c1.x * wR)));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const int g = g0 + t + r * NT;
+                    x[r] = mk<T>(fetch(aa, ca, hist, g), fetch(ab, cb, hist_b, g));
+                }
+            }
         } else if (interior) {
             const C *p = in + g0 + t, *pb = in_b + g0 + t;
 #pragma unroll
@@ -486,6 +527,70 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
                 out[m] = mk<T>((T)ep.a * ya + (T)ep.b * ia, (T)ep.c * ya + (T)ep.d * ia);
                 out_b[m] = mk<T>((T)eb.a * yb + (T)eb.b * ib, (T)eb.c * yb + (T)eb.d * ib);
             }
+        }
+    } else if constexpr (DET == 3) {
+        // xamd's envelope (amd.c:131-133) and the fade leveller's two averages (amd.c:136-137) as far as the tile's own samples carry them:
+        // what leaves, 8 bytes per output, is mag + (dcI_local - dcR_local) -- the averages' responses to the tile's magnitudes from a
+        // zero state -- and per tile their values at the tile's end (det_sum: am_lv_chain_kernel chains them); the share of everything
+        // ahead of the tile, cI mI^(k + 1) - cR mR^(k + 1), is added where bp1 loads the sample (the PAIR load above).  am_level_tiled_kernel's
+        // pass (8 B read, 16 written per sample, a CU-filling grid of dependent scans) is gone.
+        // Geometry fixed by the caller: P = Lout = 2048, so registers 8 .. 15 hold the outputs, register 8 + r samples 256 r + t of the tile.
+        static_assert(D == 1 && NT == 256 && NFFT == 4096 && !EGRESS && !METER && !PAIR && !OUTMIX, "the leveller's tap rides on a plain 4096-point stage");
+        constexpr int R0 = 8, NR = 8;
+        const int lane = t & 63, wv = t >> 6;
+        const bool lf = a.det_lf[ch] != 0;
+        // Row by row, the transform's values dying as it goes: the magnitude, the two scans inside the wavefront, and ONE value per sample
+        // parked in the exchange image (free behind the barrier) -- q = mag + (vI - vR), which is all the last step needs beside the
+        // segments' carries; the segments' end values go to `red`.  (Keeping mag, vR, vI of eight rows in registers spilled a hundred.)
+        double *sv = reinterpret_cast<double *>(lds);           // [row][t]
+        double *red = sv + NR * NT;                             // [segment 4 r + wave][2], then [t][2] for the call's last sample
+        static_assert((NR * NT + 2 * 4 * NR + 2) * 8 <= osfir_lds_bytes<T, NFFT, D, false>(), "the leveller's scans fit the exchange image");
+        __syncthreads();                        // the inverse transform's last exchange has been read by everyone
+        int lane2 = lane;
+        asm volatile("" : "+v"(lane2));         // (the scans' weights are formed here, behind the transforms)
+        PoleScan sR, sI;                        // (from the host's tables: lane_pow's temporaries beside the transform's 64 registers spilled)
+        sR.m1 = a.det_mp[0][0]; sR.m2 = a.det_mp[0][1]; sR.m4 = a.det_mp[0][2]; sR.m8 = a.det_mp[0][3];
+        sI.m1 = a.det_mp[1][0]; sI.m2 = a.det_mp[1][1]; sI.m4 = a.det_mp[1][2]; sI.m8 = a.det_mp[1][3];
+        sR.pa = a.det_scan[lane2]; sR.pb = a.det_scan[64 + lane2]; sR.pw = a.det_scan[128 + lane2];
+        sI.pa = a.det_scan[192 + lane2]; sI.pb = a.det_scan[256 + lane2]; sI.pw = a.det_scan[320 + lane2];
+        const long long m0 = (long long)tile * a.Lout + t;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const long long m = m0 + NT * r;
+            C v;
+            v.x = (T)ep.a * z[R0 + r].x + (T)ep.b * z[R0 + r].y;
+            v.y = (T)ep.c * z[R0 + r].x + (T)ep.d * z[R0 + r].y;
+            const double mag = m < a.n_out ? sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y) : 0.0;
+            const double vR = scan_pole_dpp(a.det_g[0] * mag, sR), vI = scan_pole_dpp(a.det_g[1] * mag, sI);
+            sv[r * NT + t] = lf ? mag + (vI - vR) : mag;
+            if (lane2 == 63) { red[(4 * r + wv) * 2] = vR; red[(4 * r + wv) * 2 + 1] = vI; }
+            if (m == (long long)a.n_out - 1) { red[2 * 4 * NR] = vR; red[2 * 4 * NR + 1] = vI; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // the 32 segments in order: what each starts from
+        const double m64R = ipow_d(a.det_m[0], 64), m64I = ipow_d(a.det_m[1], 64);
+        double cR = 0.0, cI = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            double kR = 0.0, kI = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if (w == wv) { kR = cR; kI = cI; }              // wave-uniform
+                cR = __builtin_fma(cR, m64R, red[(4 * r + w) * 2]);
+                cI = __builtin_fma(cI, m64I, red[(4 * r + w) * 2 + 1]);
+            }
+            const long long m = m0 + NT * r;
+            if (m < a.n_out) {
+                const double cR_here = sR.pw * kR, cI_here = sI.pw * kI;        // the rows' and wavefronts' shares ahead of this sample
+                a.det_out[(long long)ch * a.det_stride + a.out_offset + m] = lf ? sv[r * NT + t] + (cI_here - cR_here) : sv[r * NT + t];
+                if (m == (long long)a.n_out - 1) { a.det_last[2 * ch] = red[2 * 4 * NR] + cR_here; a.det_last[2 * ch + 1] = red[2 * 4 * NR + 1] + cI_here; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t == 0) {
+            double *o = a.det_sum + ((long long)ch * a.det_sum_stride + tile) * 2;
+            o[0] = lf ? cR : 0.0; o[1] = lf ? cI : 0.0;
         }
     } else if (a.pick <= 1) {
         double acc0 = 0.0, acc1 = 0.0;

@@ -135,6 +135,60 @@ static __global__ void commit_am_kernel(AmState *state, const AmState *next, con
     if (levelfade[ch] != 0) state[ch] = next[ch];
 }
 
+// The fade leveller's two averages at every tile boundary, for osfir_kernel's DET 3 form (qh_osfir.hpp): cin[ch][t] = (dc, dc_insert)
+// just ahead of tile t's first sample, c_(t+1) = m^L c_t + s_t with s_t the tile's own end values (tsum).  One wavefront per channel,
+// 64 tiles per step; the values behind the call's last sample -- through the tile the call's end cuts short: its local values at that
+// sample, `last` -- go straight into the state (the stage that adds the carried share reads cin).  A channel with the leveller off
+// (amd.c:134) gets zeros and keeps its state.
+static __global__ __launch_bounds__(64) void am_lv_chain_kernel(int n, int L, const int *chan_list, const int *levelfade, AmState *state, AmParam prm,
+                                                                 const double *tsum, long long tstride, const double *last, double *cin, long long cstride)
+{
+    const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
+    const int nt = (n + L - 1) / L, nfull = n / L;
+    double2 *co = reinterpret_cast<double2 *>(cin) + (long long)ch * cstride;
+    if (levelfade[ch] == 0) {
+        for (int t = lane; t < nt; t += 64) co[t] = make_double2(0.0, 0.0);
+        return;
+    }
+    const double mR = pow(prm.mtauR, (double)L), mI = pow(prm.mtauI, (double)L);
+    const PoleScan sR = make_pole_scan(mR, lane), sI = make_pole_scan(mI, lane);
+    const double2 *e = reinterpret_cast<const double2 *>(tsum) + (long long)ch * tstride;
+    double cR = state[ch].dc, cI = state[ch].dc_insert;
+    if (lane == 0) co[0] = make_double2(cR, cI);
+    for (int blk = 0; blk < nfull; blk += 64) {
+        const int cnt = nfull - blk < 64 ? nfull - blk : 64;
+        const double2 s = lane < cnt ? e[blk + lane] : make_double2(0.0, 0.0);
+        const double eR = scan_pole_dpp(s.x, sR) + sR.pw * cR, eI = scan_pole_dpp(s.y, sI) + sI.pw * cI;
+        if (lane < cnt && blk + lane + 1 < nt) co[blk + lane + 1] = make_double2(eR, eI);
+        cR = lane_bcast(eR, cnt - 1); cI = lane_bcast(eI, cnt - 1);
+    }
+    if (nt > nfull) {
+        const int len = n - nfull * L;
+        cR = __builtin_fma(cR, pow(prm.mtauR, (double)len), last[2 * ch]);
+        cI = __builtin_fma(cI, pow(prm.mtauI, (double)len), last[2 * ch + 1]);
+    }
+    if (lane == 0 && n > 0) { state[ch].dc = cR; state[ch].dc_insert = cI; }
+}
+// ... and the delay line of the stage behind it (bp1), whose input never exists as complex samples: new_hist[j] <- (audio, audio) of
+// sample n - H + j, audio = a_local + cI mI^(k + 1) - cR mR^(k + 1), or the old line's sample where that index is negative.
+static __global__ __launch_bounds__(256) void am_audio_hist_kernel(const double *a_local, long long astride, int n, const int *chan_list,
+                                                                   const double *cin, long long cstride, const double *pw, int shift,
+                                                                   const double2 *old_hist, double2 *new_hist, int H)
+{
+    const int ch = chan_list[blockIdx.y];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+    const long long g = (long long)n - H + j;
+    double2 v;
+    if (g >= 0) {
+        const int tl = (int)(g >> shift), k = (int)(g - ((long long)tl << shift));
+        const double2 c = (reinterpret_cast<const double2 *>(cin) + (long long)ch * cstride)[tl];
+        const double a = a_local[(long long)ch * astride + g] + __builtin_fma(c.y, pw[(1 << shift) + k], -c.x * pw[k]);
+        v = make_double2(a, a);
+    } else v = old_hist[(long long)ch * H + (H + g)];
+    new_hist[(long long)ch * H + j] = v;
+}
+
 // The AM fade leveller behind an nbp0 stage that left the envelope itself (osfir_kernel DET 2): mag [ch][mstride] doubles, tsum
 // [ch][tstride][2] every filter tile's contribution to the two averages (L samples per tile, a multiple of 64).  Segments are cut on
 // tile boundaries, a segment's carry-in is the chain over the tiles ahead of it, and there is one pass: 8 bytes read, 16 written
