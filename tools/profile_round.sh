@@ -3,7 +3,7 @@
 # The round's evidence set from ONE library on ONE box, written to gpurun_out/<tag>_*: the driver's line, rocprofv3 kernel stats of the
 # headline run and of every leg of `other_configs`, the PMC passes of the headline (with the traffic / VALU stamp bench.py reads) and
 # of configs 3 and 5 (the half-band cascade).  Copy what is to be judged into profiles/.
-tag=${1:-r05}
+tag=${1:-r06}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
