@@ -193,6 +193,52 @@ def other_configs(timeout_s=900.0):
     return out
 
 
+def live_traffic(meters, timeout_s=240.0):
+    """HBM bytes per input sample of the two config-2 kernels measured IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE: separate passes as MI355X_MICROARCH.md prescribes) over a short child run of this very file -- counters cannot be read
+    inside a process, and the child starts from scratch (a profiler's preloaded library and an exec do not mix).  rocprofv3 reports KiB;
+    FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes, same guide).  Returns {"front": B, "band": B, ...} or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof:
+        raise RuntimeError("no rocprofv3 on this box")
+    log2 = 20
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log2-samples", str(log2), "--meters", meters,
+             "--no-cpu-baseline", "--no-other-configs", "--no-le24", "--no-host-fed", "--no-live-traffic"]
+    samples = 256.0 * (1 << log2)
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, counter)
+            r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
+                               capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            acc = {"front": [], "band": []}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] != counter or "osfir_kernel<double, 4096," not in name:
+                        continue
+                    if "osfir_kernel<double, 4096, 4, false, false" in name:
+                        acc["front"].append(float(row["Counter_Value"]))
+                    elif "osfir_kernel<double, 4096, 1" in name and (("true, false" in name.split("4096, 1,")[1][:30]) == (meters == "on")):
+                        acc["band"].append(float(row["Counter_Value"]))
+            if not acc["front"] or not acc["band"]:
+                raise RuntimeError("rocprofv3 --pmc %s gave no rows for the two kernels (exit %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:]))
+            for k in acc:
+                got.setdefault(k, {})[counter] = sum(acc[k]) / len(acc[k])
+    res = {}
+    for k in ("front", "band"):
+        res[k] = (2048.0 * got[k]["FETCH_SIZE"] + 1024.0 * got[k]["WRITE_SIZE"]) / samples
+        res[k + "_fetch_x2_bytes_per_sample"] = 2048.0 * got[k]["FETCH_SIZE"] / samples
+        res[k + "_write_bytes_per_sample"] = 1024.0 * got[k]["WRITE_SIZE"] / samples
+    res["child_log2_samples"] = log2
+    return res
+
+
 def host_fed(torch, eng, x, y, nch, n_in, n_out, nblk, dev, stream, log2_chunk=18, passes=2):
     """SURVEY.md 8(d)'s "H2D reported separately": the reference's samples arrive on the HOST (quisk.c:3284-3423 UDP, sound.c:990), so
     this is what a deployment whose samples do not already sit in HBM gets.  The step's input streams from PINNED host memory in
@@ -440,6 +486,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-le24", action="store_true", help="skip the extra run from 24-bit wire samples (the test of the front kernel's HBM bound)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra legs (BASELINE configs 3, 4, 5 and the Quisk-native chain)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the stamped profiles/c2_traffic.json only: no rocprofv3 --pmc child passes in this run")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed leg (pinned host buffers, copies beside the kernels: what a receiver whose samples arrive on the host gets)")
     ap.add_argument("--meters", choices=["on", "off"], default="on",
                     help="on (default): xrxa's three meters run as in the reference (adc, S, agc: wdsp/RXA.c:566,569,589), "
@@ -758,9 +805,24 @@ def main():
             line["value_meters_off"] = total / dt_off / 1e6
             line["ms_per_step_meters_off"] = dt_off / args.steps * 1e3
             line["check_meters_dB"] = {"S_AV": meter_db[0], "ADC_AV": meter_db[1], "AGC_AV": meter_db[2]}
-        if not args.no_other_configs and world == 1 and not dry and args.ingest == "f64":
-            del x, y, eng, tail                                  # the headline workload's 21 GB go back before the other legs allocate
+        free_first = world == 1 and not dry and args.ingest == "f64" and (not args.no_other_configs or not args.no_live_traffic)
+        if free_first:
+            del x, y, eng, tail                                  # the headline workload's 21 GB go back before the child processes allocate
             torch.cuda.empty_cache()
+        # roofline.traffic measured in THIS run (the stamped file could not be confirmed by the driver's own run)
+        if world == 1 and not dry and args.ingest == "f64" and not args.no_live_traffic and nchunk == 1:
+            try:
+                lt = live_traffic(args.meters)
+                rf = line["roofline"]
+                rf["traffic_stamped"] = rf["traffic"]
+                rf["traffic"] = lt["front" if k == 0 else "band"] * samples_per_step
+                rf["traffic_note"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over a child run of bench.py at 2^%d samples per "
+                                      "channel, bytes per input sample x this launch's samples (FETCH_SIZE x 2: gfx950 tallies 128-byte requests at 64 bytes); "
+                                      "traffic_stamped = the same from profiles/c2_traffic.json when its source stamp matches" % lt["child_log2_samples"])
+                rf["traffic_live"] = lt
+            except Exception as exc:                             # reported, never required: the stamped figure (or null) stays
+                line["roofline"]["traffic_live"] = {"failed": repr(exc)[:400]}
+        if not args.no_other_configs and world == 1 and not dry and args.ingest == "f64":
             line["other_configs"] = other_configs()
         if not args.no_cpu_baseline and world == 1 and not dry:       # the CPU baseline is reported by the single-GPU run only
             try:

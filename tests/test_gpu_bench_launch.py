@@ -49,7 +49,7 @@ def _check(j):
 
 def test_torchrun_one_rank_over_rccl():
     j = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port()), "bench.py", "--gpus", "1"] + ARGS)
+               "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--no-live-traffic"] + ARGS)
     _check(j)
     assert "x1" in j["config"]["parallelism"]
 
@@ -61,3 +61,10 @@ def test_plain_python_launch():
     for kind, bps in (("f64", 16), ("le24", 6)):
         assert hf[kind]["bytes_per_sample_in"] == bps and 0.0 < hf[kind]["Msamp_per_s"] < j["value"]
         assert hf[kind]["link_GBps_in"] < 70.0          # a PCIe Gen5 x16 link
+    # roofline.traffic is counted in the run itself (two rocprofv3 --pmc child passes): the dominant kernel's HBM bytes per launch, within a
+    # few per cent of its algorithmic bytes (the front kernel re-reads its tiles' pre-roll from L2, not from HBM)
+    r = j["roofline"]
+    live = r.get("traffic_live")
+    assert live and "failed" not in live, live
+    assert r["traffic"] is not None and 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.3, (r["traffic"], r["algorithmic_bytes_per_launch"])
+    assert 15.0 < live["front"] < 26.0 and 6.0 < live["band"] < 12.0

@@ -26,7 +26,7 @@ def main():
             qb.build(force=True, defines=defines, out=out)
             print("built", out, defines)
     else:
-        args = sys.argv[2:] or ["--log2-samples", "21", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"]
+        args = sys.argv[2:] or ["--log2-samples", "21", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-live-traffic"]
         for lib in sorted(glob.glob(os.path.join(AB, "libquiskhip_*.so"))):
             env = dict(os.environ, QUISKHIP_LIB=lib)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True)

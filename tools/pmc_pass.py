@@ -66,7 +66,7 @@ def main():
         script, rest = os.path.abspath(rest[0]), rest[1:]
         bench_args = rest
     else:
-        bench_args = rest or ["--steps", "2", "--warmup", "1", "--log2-samples", "20", "--no-cpu-baseline", "--no-other-configs", "--no-le24", "--no-host-fed"]
+        bench_args = rest or ["--steps", "2", "--warmup", "1", "--log2-samples", "20", "--no-cpu-baseline", "--no-other-configs", "--no-le24", "--no-host-fed", "--no-live-traffic"]
     res = collections.defaultdict(dict)
     tmp = "/tmp/pmc_pass"
     for gi, grp in enumerate(GROUPS):

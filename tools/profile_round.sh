@@ -9,7 +9,7 @@ out=$root/gpurun_out
 mkdir -p $out
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 tail -c 300 $out/${tag}_bench.err
-tools/kstats.sh $out/${tag}_kernel_stats.csv python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-le24 --no-host-fed > /dev/null
+tools/kstats.sh $out/${tag}_kernel_stats.csv python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-le24 --no-host-fed --no-live-traffic > /dev/null
 for leg in 3 4 5 2agc quisk; do
     tools/kstats.sh $out/${tag}_${leg}_kernel_stats.csv python3 $root/tools/bench_configs.py $leg > $out/${tag}_${leg}.log 2>&1
     tail -1 $out/${tag}_${leg}.log | cut -c1-400
