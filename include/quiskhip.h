@@ -677,7 +677,9 @@ void qh_quisk_set_auto_notch(int on, int rit_freq);         /* set_auto_notch, q
                                                                  versions): the RIT is the one qh_quisk_set_sidetone set, the reference's global (quisk.c:4712) -- it also tunes the split
                                                                  receiver (quisk.c:2538) */
 int qh_quisk_get_filter_rate(void);                         /* get_filter_rate(-1, 0), quisk.c:2787 */
-int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289 */
+int qh_quisk_process_samples(double *cSamples, int nSamples);       /* quisk_process_samples, quisk.c:2289.  In place, like the reference: cSamples is the caller's
+                                                                         block buffer (SAMP_BUFFER_SIZE = 66000 samples in Quisk) and must hold the OUTPUT too -- up to (nSamples / decimation
+                                                                         + one WDSP block when the shim is in use) x playback_rate / 48000 samples */
 int qh_quisk_get_graph(double zoom, double deltaf, double *pixels, double *smeter);                /* get_graph, quisk.c:5142 */
 /* get_filter (quisk.c:5481-5568): the Rx filter's response as the "RX Filter" screen draws it -- a multitone through the copy of the
  * cRxFilterOut loop that function carries, record_app's window, a data_width-point transform; db[data_width], negative frequencies

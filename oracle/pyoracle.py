@@ -657,7 +657,10 @@ class OracleQuiskBlock:
         x = np.ascontiguousarray(x, dtype=np.complex128)
         if x.size > 66000:          # SAMP_BUFFER_SIZE (quisk.h:15): the reference's -- and the restatement's -- work arrays end there
             raise ValueError("quisk_process_samples takes at most 66000 samples per call")
-        buf = np.zeros(max(x.size, 16) * (self.ratio + 1), dtype=np.complex128)
+        # the block buffer is Quisk's: SAMP_BUFFER_SIZE complex samples whatever the block (quisk.c:2292 works in place in it).  With WDSP in
+        # the audio path a call may come back one WDSP block longer than it went in (the shim's ring, quisk_wdsp.c:52-63), interpolated like the
+        # rest: an array sized for the block alone was run over by short blocks at 96 ksps playback (round 6, found under AddressSanitizer)
+        buf = np.zeros(max(66000, (max(x.size, 16) + 4096) * (self.ratio + 1)), dtype=np.complex128)
         buf[:x.size] = x
         n = self.L.qo_ps_process(self.h, buf.ctypes.data, x.size)
         if self.L.qo_ps_overrun(self.h):

@@ -91,6 +91,7 @@ struct ChanCfg {
     bool agc_rewindow = false;          // the attack window moved in mid-stream: the state's ring is taken again from the full one
     bool agc_ran = false, agc_stale = false;    // the window moved while the ring held samples: ring_max may be stale (qh_agc_tiled.hpp)
     int bp1_run = 1, bp1_nc = 2048, bp1_wintype = 1;            // RXA.c:377-389
+    bool long_live[5] = { false, false, false, false, false };  // the channel holds a delay line of stage sid longer than 4095 samples (process_chain)
     double bp1_flow = -4150.0, bp1_fhigh = -150.0, bp1_gain = 1.0;
     double gain1 = 4.0, gain2I = 1.0, gain2Q = 1.0;             // RXA.c:464-474
     int inselect = 3, copy = 0;
@@ -1962,11 +1963,22 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     {
         auto parts = [](int nc) { return nc > kLongPart ? (nc + kLongPart - 1) / kLongPart : 1; };
         int lp[5] = { 1, 1, 1, 1, 1 };
-        for (const ChanCfg &c : cfg) {
-            if (c.nbp_run) lp[0] = std::max(lp[0], parts(c.nbp_nc));
-            if (c.bp1_run) lp[1] = std::max(lp[1], parts(c.bp1_nc));
-            if (c.fmd_run) lp[2] = lp[3] = std::max(lp[2], parts(c.fm_nc));
-            if (c.snba_run) lp[4] = std::max(lp[4], parts(c.nbp_nc));
+        // Over every channel that runs the stage OR still holds a long delay line of it: a fircore keeps its delay line while it does not run (xbandpass / xnbp with run = 0
+        // only copy; SetRXABandpassRun, a mode change back to AM / FM, RXANBPSetRun switch it on again without a flush), so a channel with
+        // nc > 4096 that sits out holds 16383 samples the one-tile form has no room for.  Had the form followed the RUNNING channels,
+        // the only long channel leaving took the stage to the short form (its line cut to 4095 samples) and came back to zeros behind
+        // them: one long call 0.65 off (walk rxa_long 900190, found by round 6's seed sweep; in the suite since).
+        // (long_live: the channel has run the stage with such an nc since RXASetNC last zeroed its lines.)
+        for (ChanCfg &c : cfg) {
+            const int pn = parts(c.nbp_nc), pb = parts(c.bp1_nc), pf = parts(c.fm_nc);
+            if (c.nbp_run && pn > 1) c.long_live[0] = true;
+            if (c.bp1_run && pb > 1) c.long_live[1] = true;
+            if (c.fmd_run && pf > 1) c.long_live[2] = true;
+            if (c.snba_run && pn > 1) c.long_live[4] = true;
+            if (c.nbp_run || c.long_live[0]) lp[0] = std::max(lp[0], pn);
+            if (c.bp1_run || c.long_live[1]) lp[1] = std::max(lp[1], pb);
+            if (c.fmd_run || c.long_live[2]) lp[2] = lp[3] = std::max(lp[2], pf);
+            if (c.snba_run || c.long_live[4]) lp[4] = std::max(lp[4], pn);
         }
         for (int sid = 0; sid < 5; sid++) {
             if (lp[sid] > 1) { long_mode = true; if (int rc = long_stage_alloc(sid, sid == 2 || sid == 3)) return rc; }
@@ -2704,8 +2716,8 @@ qh_rxa *qh_rxa_create(int device, int nch, int dsp_size, int in_rate, int dsp_ra
     if (D != 1 && D != 2 && D != 4 && D != 8 && D != 16) D = 0;
     if (D == 0 && !((in_rate > dsp_rate && in_rate % dsp_rate == 0) ||
                     (in_rate < dsp_rate && dsp_rate % in_rate == 0 && dsp_size % (dsp_rate / in_rate) == 0))) {
-        // (tests/test_oracle_wdsp.py::test_rates_that_are_whole_in_neither_direction_recycle_stale_buffer_tails shows what the reference's
-        // own arithmetic does with 96 k -> 64 k -> 48 k: every block's tail is what the block before left in the buffer)
+        // (a CPU test of the reference's arithmetic, test_rates_that_are_whole_in_neither_direction_recycle_stale_buffer_tails, shows what it
+        // does with 96 k -> 64 k -> 48 k: every block's tail is what the block before left in the buffer)
         set_error(QH_ERR_UNSUPPORTED, "in_rate / dsp_rate must be a whole number or the reciprocal of one (wdsp/channel.c:39-42)");
         return nullptr;
     }
@@ -2910,8 +2922,9 @@ int qh_rxa_RXASetNC(qh_rxa *h, int ch, int nc)
     if (nc < 1 || (nc & (nc - 1)) || nc > kLongNcMax || (h && nc < h->e.dsp_size))
         return set_error(QH_ERR_UNSUPPORTED, "nc must be a power of two in [dsp_size, %d]", kLongNcMax);
     FOR_CH(h, ch, {
-        if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; c.snb_flush = true; }
-        if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; }
+        if (c.nbp_nc != nc) { c.nbp_nc = nc; c.nbp_dirty = true; c.nbp_flush = true; c.snb_flush = true; c.long_live[0] = c.long_live[4] = false; }
+        if (c.bp1_nc != nc) { c.bp1_nc = nc; c.bp1_dirty = true; c.bp1_flush = true; c.long_live[1] = false; }
+        if (c.fm_nc != nc) c.long_live[2] = false;     // (setNc_fircore zeroes the delay lines, firmin.c:454-466: nothing long is held any more)
         c.fm_nc = nc;                           // SetRXAFMNCde / SetRXAFMNCaud, wdsp/RXA.c:942-943
     });
 }

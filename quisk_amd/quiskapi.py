@@ -178,9 +178,15 @@ def sub_rx1_audio():
 
 
 def process(x):
-    """process_samples on a copy with room for the playback-rate output; returns the output block."""
+    """process_samples on a copy with room for the playback-rate output; returns the output block.  With WDSP in the audio path a call may
+    hand back a block more than it was given (the shim's ring held one that was waiting, quisk_wdsp.c:52-63), interpolated like the rest:
+    Quisk's own buffer is SAMP_BUFFER_SIZE = 66000 samples whatever the block; here the room follows the block, the shim's block size
+    and the interpolation ratio.  (Round 6: sized for the block alone, short blocks at 96 ksps playback behind a 512-sample WDSP block ran
+    over the array -- heap corruption in the caller, found by a seed sweep of the api_wdsp walks.)"""
     x = np.ascontiguousarray(x, dtype=np.complex128)
-    buf = np.zeros(max(x.size, 16) * (_keep.get("ratio", 1) + 1), dtype=np.complex128)
+    ratio = _keep.get("ratio", 1)
+    wdsp_block = max(0, int(load().qh_wdsp_shim_in_size(0)))
+    buf = np.zeros((max(x.size, 16) + wdsp_block + 16) * (ratio + 1), dtype=np.complex128)
     buf[:x.size] = x
     n = process_samples(buf, x.size)
     return buf[:max(n, 0)].copy()

@@ -105,11 +105,13 @@ def test_random_setter_walk_block_at_a_time_with_graph_replay(qh, oracle, seed):
     _walk(qh, oracle, seed, replay=True)
 
 
-@pytest.mark.parametrize("seed", list(range(201, 213)))
+@pytest.mark.parametrize("seed", list(range(201, 213)) + [900190])
 def test_random_setter_walk_with_long_filters_agc_windows_and_long_calls(qh, oracle, seed):
     """The walks with RXASetNC up to 16384 and the AGC's time constants among the setters, and calls of 70 - 90 DSP blocks among the short
     ones: the time-tiled detectors and AGC, the per-channel fall-back after a moved attack window and the partitioned filters meet the
-    per-block paths on one carried state."""
+    per-block paths on one carried state.  (900190, round 6's sweep: the one channel with nc = 16384 leaves bp1's list -- SetRXAAMDRun 0 -- and
+    comes back by SetRXABandpassRun in a long call: the stage's form may not follow the running channels alone, or its 16383-sample line
+    is cut to 4095 while it sits out.)"""
     _walk(qh, oracle, seed, replay=False, wide=True)
 
 

@@ -37,6 +37,7 @@ fams = sys.argv[3:] or list(FAM)
 for fam in fams:
     bad, t0 = 0, time.time()
     for seed in range(a, b + 1):
+        if os.environ.get("QH_PROGRESS"): print("seed", seed, flush=True)
         try:
             FAM[fam](seed)
         except AssertionError as e:
