@@ -2108,7 +2108,9 @@ int Engine::process_chain(const double *d_in, long long in_stride, double *d_out
     // capture records as graph edges).  BASELINE config 4: 1.20 -> 0.8 ms per call.
     // dbg_forms (QH_DBG_FORMS in the environment when the engine is made; diagnostics: tools/dbg/determinism_stress2.py and the failure
     // branch of tests/test_gpu_properties_fullsize.py): bit 0 no second stream for the filters, 1 no stores straight to the caller's rows,
-    // 2 no envelope in nbp0's store, 3 no angles in nbp0's store, 4 no paired real filters, 5 no second stream at all
+    // 2 no envelope in nbp0's store, 3 no angles in nbp0's store, 4 no paired real filters, 5 no second stream at all, 6-7 where the second
+    // stream forks (counted down from behind the FM channels' nbp0), 8 xfmd's dc removal as a pass of its own (fm_dc_tiled_kernel), 9 the AM
+    // fade leveller as a pass of its own (am_level_tiled_kernel)
     const bool split = n_fm > 0 && n_rest > 0 && D > 1 && !meters_on && !n_amsq && !n_snb[0] && !timing && !(dbg_forms & 1);
     // ... and when nothing sits between a channel's last filter and the output matrix (no AGC state machine, LMS, EMNR, SNBA,
     // limiter, squelch or position-1 stage anywhere), that last stage -- nbp0 for the plain channels, bp1 for AM / SAM, the CTCSS
