@@ -461,6 +461,11 @@ struct Stage {
         a.nco_phase = nco_phase; a.nco_dphase = nco_dphase; a.nco_step = nco_step;
         a.epi = epi;
         a.n_in = n_in; a.n_out = nout; a.P = P; a.Lout = Lf;
+        // the kernel's own tiles leave the next call's delay line (OsfirArgs::hist_next): decimators / plain filters with raw history, a call
+        // that is at least one delay line long (the tiles' loads cover [off - P, off + ntiles * fold * Lf), which reaches n_in: off + decim * nout >= n_in)
+        const bool paired_now = pair && !per_channel && !mix && !outmix && pick <= 1;
+        const bool hist_in_kernel = nout > 0 && interp == 1 && !mix && !paired_now && n_in >= hist_len;
+        if (hist_in_kernel) a.hist_next = static_cast<cplx<T> *>(hist[cur ^ 1]);
         if (nout > 0) {
             const bool paired = pair && !per_channel && !mix && !outmix && pick <= 1;
             if (paired) { a.chan_list = d_pairs; a.pair_im0 = pair == 1 ? 1 : 0; }
@@ -500,6 +505,7 @@ struct Stage {
         }
         dim3 g((unsigned)((hist_len + NT - 1) / NT), (unsigned)nch);
         if (outmix) {           // raw history; the phase advances all the same
+            if (!hist_in_kernel)
             hipLaunchKernelGGL((hist_update_kernel<T, false>), g, dim3(NT), 0, stream, a.in, in_stride, n_in, a.hist,
                                static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, (const unsigned long long *)nullptr,
                                (const unsigned long long *)nullptr, (const int *)nullptr);
@@ -510,7 +516,7 @@ struct Stage {
                                static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, nco_phase, nco_dphase, (const int *)nullptr);
             hipLaunchKernelGGL(nco_advance_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, stream, nco_phase, nco_dphase,
                                nch, (long long)n_in);
-        } else {
+        } else if (!hist_in_kernel) {
             hipLaunchKernelGGL((hist_update_kernel<T, false>), g, dim3(NT), 0, stream, a.in, in_stride, n_in, a.hist,
                                static_cast<cplx<T> *>(hist[cur ^ 1]), hist_len, (const unsigned long long *)nullptr,
                                (const unsigned long long *)nullptr, (const int *)nullptr);
