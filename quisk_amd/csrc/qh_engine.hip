@@ -1588,6 +1588,10 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
                            (long long)(a.off - a.P), (long long)front_fold * front_L);
         a.tile_rot = tile_rot;
         a.pk_src = pk_src; a.pk = pk;
+        // a call at least one delay line long: the tiles that hold its tail leave the next call's line (OsfirArgs::hist_next), every channel
+        // in the pass of its own list
+        const bool hist_in_kernel = !pk_src && n_in >= kHistFront && n_mid > 0;
+        if (hist_in_kernel) a.hist_next = hist_front[cur_front ^ 1];
         if (part == 1 || part == 3) { }
         else if (pk_src) {
             switch (front_fold) {
@@ -1611,7 +1615,7 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
             hipLaunchKernelGGL((hist_update_kernel<double, false, true>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
                                hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, (const unsigned long long *)nullptr,
                                (const unsigned long long *)nullptr, (const int *)nullptr, pk_src, pk);
-        else
+        else if (!hist_in_kernel)
             hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_in,
                                hist_front[cur_front], hist_front[cur_front ^ 1], kHistFront, (const unsigned long long *)nullptr,
                                (const unsigned long long *)nullptr, (const int *)nullptr, (const unsigned char *)nullptr, PackedFmt{});
@@ -1797,6 +1801,9 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (meter) { a.meter_in = m_part[0]; a.meter_out = m_part[1]; a.meter_stride = m_part_cap; a.meter_w = m_w; }
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
+    // the one-group tile kernel writes the next call's delay line itself when the call is at least one line long (OsfirArgs::hist_next)
+    const bool hist_in_kernel = !pairs && det != 3 && (det || (!band6k && !band2g)) && n_mid >= kHistBand;
+    if (hist_in_kernel) a.hist_next = hist[hc ^ 1];
     if (pairs) {            // the caller has checked: real taps, one mask per pair, 4096-point tiles, no meters, no egress
         a.chan_list = pairs;
         if (band_fmdc) {    // behind xfmd's loop in its local-dc form: the samples are made in the load (OsfirArgs::fmdc_*)
@@ -1835,10 +1842,10 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     else if (pairs && band_fmdc)
         hipLaunchKernelGGL(fm_audio_hist_kernel, g, dim3(256), 0, stream, band_fmdc->a, band_fmdc->stride, (int)n_mid, list, (const double *)fm_cin, fm_cin_cap,
                            (const double *)fm_pw, band_fmdc->shift, (const double *)fm_again, (const double2 *)hist[hc], hist[hc ^ 1], kHistBand);
-    else
-    hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
-                       hist[hc], hist[hc ^ 1], kHistBand, (const unsigned long long *)nullptr,
-                       (const unsigned long long *)nullptr, list);
+    else if (!hist_in_kernel)
+        hipLaunchKernelGGL((hist_update_kernel<double, false>), g, dim3(NT), 0, stream, src, src_stride, (int)n_mid,
+                           hist[hc], hist[hc ^ 1], kHistBand, (const unsigned long long *)nullptr,
+                           (const unsigned long long *)nullptr, list);
     // (a listed stage reads and writes the history rows of its own channels only)
     hc ^= 1;
 }
