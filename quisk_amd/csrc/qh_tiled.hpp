@@ -135,6 +135,43 @@ static __global__ void commit_am_kernel(AmState *state, const AmState *next, con
     if (levelfade[ch] != 0) state[ch] = next[ch];
 }
 
+// c_(t+1) = mL c_t + s_t over the whole tiles 0 .. nfull - 1 of a channel by ONE wavefront: put(t + 1, c_(t+1)) for every tile, returns
+// c_nfull.  A lane takes K consecutive tiles (their K loads in flight together), runs them from a zero state, the lanes' ends meet in one
+// DPP scan with the pole mL^K, and the value carried into a lane goes onto its K local ones.  (The form before this one -- 64 tiles per
+// round, a dependent load and a scan per round -- took 32 rounds for config 4's 2048 tiles: 0.5 ms on the AM channels' critical path
+// with the chip busy, profiles/r06_d_c4_timeline_after.txt.)
+template <int K, typename SF, typename PF>
+__device__ __forceinline__ double chain_tiles(int nfull, double mL, double c, int lane, SF s_at, PF put)
+{
+    double pwj[K];                                  // mL^(j + 1)
+    pwj[0] = mL;
+#pragma unroll
+    for (int j = 1; j < K; j++) pwj[j] = pwj[j - 1] * mL;
+    const PoleScan sc = make_pole_scan(pwj[K - 1], lane);
+    const double plane = lane_pow(pwj[K - 1], lane);     // (mL^K)^lane: what the value ahead of lane 0 has become ahead of this lane
+    for (int blk = 0; blk < nfull; blk += 64 * K) {
+        const int t0 = blk + lane * K;
+        double v[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) v[j] = t0 + j < nfull ? s_at(t0 + j) : 0.0;
+#pragma unroll
+        for (int j = 1; j < K; j++) v[j] = __builtin_fma(mL, v[j - 1], v[j]);
+        const double incl = scan_pole_dpp(v[K - 1], sc);
+        const double up = __shfl_up(incl, 1, 64);
+        const double cin = __builtin_fma(plane, c, lane ? up : 0.0);
+        const int last = (nfull - blk < 64 * K ? nfull - blk : 64 * K) - 1;         // the round's last whole tile, counted from blk
+        double pick = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            v[j] = __builtin_fma(pwj[j], cin, v[j]);
+            if (t0 + j < nfull) put(t0 + j + 1, v[j]);
+            if (j == last % K) pick = v[j];
+        }
+        c = lane_bcast(pick, last / K);
+    }
+    return c;
+}
+
 // The fade leveller's two averages at every tile boundary, for osfir_kernel's DET 3 form (qh_osfir.hpp): cin[ch][t] = (dc, dc_insert)
 // just ahead of tile t's first sample, c_(t+1) = m^L c_t + s_t with s_t the tile's own end values (tsum).  One wavefront per channel,
 // 64 tiles per step; the values behind the call's last sample -- through the tile the call's end cuts short: its local values at that
@@ -151,17 +188,11 @@ static __global__ __launch_bounds__(64) void am_lv_chain_kernel(int n, int L, co
         return;
     }
     const double mR = pow(prm.mtauR, (double)L), mI = pow(prm.mtauI, (double)L);
-    const PoleScan sR = make_pole_scan(mR, lane), sI = make_pole_scan(mI, lane);
     const double2 *e = reinterpret_cast<const double2 *>(tsum) + (long long)ch * tstride;
     double cR = state[ch].dc, cI = state[ch].dc_insert;
     if (lane == 0) co[0] = make_double2(cR, cI);
-    for (int blk = 0; blk < nfull; blk += 64) {
-        const int cnt = nfull - blk < 64 ? nfull - blk : 64;
-        const double2 s = lane < cnt ? e[blk + lane] : make_double2(0.0, 0.0);
-        const double eR = scan_pole_dpp(s.x, sR) + sR.pw * cR, eI = scan_pole_dpp(s.y, sI) + sI.pw * cI;
-        if (lane < cnt && blk + lane + 1 < nt) co[blk + lane + 1] = make_double2(eR, eI);
-        cR = lane_bcast(eR, cnt - 1); cI = lane_bcast(eI, cnt - 1);
-    }
+    cR = chain_tiles<16>(nfull, mR, cR, lane, [&](int t) { return e[t].x; }, [&](int t, double v) { if (t < nt) co[t].x = v; });
+    cI = chain_tiles<16>(nfull, mI, cI, lane, [&](int t) { return e[t].y; }, [&](int t, double v) { if (t < nt) co[t].y = v; });
     if (nt > nfull) {
         const int len = n - nfull * L;
         cR = __builtin_fma(cR, pow(prm.mtauR, (double)len), last[2 * ch]);
@@ -991,18 +1022,12 @@ static __global__ __launch_bounds__(64) void fm_dc_chain_kernel(int n, int L, co
     const int ch = chan_list[blockIdx.x], lane = threadIdx.x;
     const int nt = (n + L - 1) / L, nfull = n / L;                     // tiles, whole tiles
     const double mL = pow(q.mtau, (double)L);
-    const PoleScan sc = make_pole_scan(mL, lane);
     const double *e = ends + (long long)ch * estride;
     double *co = cin + (long long)ch * cstride;
     double c = state[ch].fmdc;
     if (lane == 0) co[0] = c;
-    for (int blk = 0; blk < nfull; blk += 64) {
-        const int cnt = nfull - blk < 64 ? nfull - blk : 64;
-        const double s = lane < cnt ? e[(long long)(blk + lane) * kPllEndsW + 6] : 0.0;
-        const double cend = scan_pole_dpp(s, sc) + sc.pw * c;          // fmdc behind the last sample of tile blk + lane
-        if (lane < cnt) co[blk + lane + 1] = cend;
-        c = lane_bcast(cend, cnt - 1);
-    }
+    // fmdc behind the last sample of every whole tile
+    c = chain_tiles<8>(nfull, mL, c, lane, [&](int t) { return e[(long long)t * kPllEndsW + 6]; }, [&](int t, double v) { co[t] = v; });
     if (nt > nfull) c = __builtin_fma(c, pow(q.mtau, (double)(n - nfull * L)), e[(long long)nfull * kPllEndsW + 6]);        // the tile the call's end cuts short
     if (lane == 0 && n > 0) state[ch].fmdc = c;
 }
