@@ -16,7 +16,8 @@ struct qh_hbc {
     size_t esize = 16;
     void *hist[2] = { nullptr, nullptr };
     int cur = 0;
-    bool attr_set = false;
+    unsigned attr_set = 0;          // bit 0 / 1: the dynamic LDS limit of the 2048 / 4096-sample-step instantiation is set
+    int big = 0;                    // experiment builds (QH_EXP_HBC_BIG): -1 = calls of at least kBigMin samples take the 4096-sample steps, 0 / 1 forced
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // Six and more stages run as TWO launches: the first four stages (15/16 of the arithmetic, 5 barriers per 2048-sample step) write
@@ -41,30 +42,37 @@ struct qh_hbc {
 
 namespace {
 
-template <typename T, int NS>
+[[maybe_unused]] constexpr int kBigMin = 1 << 23;
+
+template <typename T, int NS, bool BIG>
 int launch(qh_hbc *h, const void *in, long long in_stride, int n_in, void *out, long long out_stride)
 {
-    using G = HbGeom<NS>;
+    using G = HbGeom<NS, BIG ? 4096 : 2048, BIG ? 8 : 4>;
     // segments: long enough that the warm-up is a few per cent, short enough to fill 256 CUs x 4 workgroups
     long long seg = 64LL * G::STEP;
-    while (seg > 16 * G::STEP && (long long)h->nch * ((n_in + seg - 1) / seg) < 1024) seg >>= 1;
+    constexpr int kResident = BIG ? 512 : 1024;         // workgroups the chip holds at once: 256 CUs x 2 (63 KB of rings) or x 4
+    while (seg > 16 * G::STEP && (long long)h->nch * ((n_in + seg - 1) / seg) < kResident) seg >>= 1;
     // a short input (the second launch of a long cascade): a workgroup's walk through its steps is a chain of barriers and LDS round
     // trips, so more and shorter segments finish sooner although each repeats the warm-up
     while (seg > 4 * G::STEP && seg > 4 * G::WARM && (long long)h->nch * ((n_in + seg - 1) / seg) < 512) seg >>= 1;
     if (const char *e = getenv("QH_HBC_SEG_STEPS")) { const int v = atoi(e); if (v > 0) seg = (long long)v * G::STEP; }
     const int nseg = (int)((n_in + seg - 1) / seg);
     const size_t lds = (size_t)G::ring_pairs() * sizeof(HbPair<T>);
-    auto k = hb45_cascade_kernel<T, NS>;
-    if (!h->attr_set) {                         // once per handle: the dynamic LDS limit of this instantiation
+    auto k = hb45_cascade_kernel<T, NS, BIG>;
+    if (!(h->attr_set & (BIG ? 2u : 1u))) {     // once per handle: the dynamic LDS limit of this instantiation
         QH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        h->attr_set = true;
+        h->attr_set |= BIG ? 2u : 1u;
     }
+    static_assert(G::WARM <= 4096 * ((42 * ((1 << NS) - 1) + 4095) / 4096), "the handle's history rows hold either geometry's warm-up");
+    const bool hist_in_kernel = n_in >= h->warm;       // nothing of the old history survives: the segments at the call's end write the new one
     hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)h->nch), dim3(NT), lds, h->stream, (const cplx<T> *)in, in_stride,
-                       (const cplx<T> *)h->hist[h->cur], n_in, (cplx<T> *)out, out_stride, (int)seg);
+                       (const cplx<T> *)h->hist[h->cur], n_in, (cplx<T> *)out, out_stride, (int)seg,
+                       hist_in_kernel ? (cplx<T> *)h->hist[h->cur ^ 1] : (cplx<T> *)nullptr, h->warm);
     QH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hb45_hist_kernel<T>, dim3((unsigned)((G::WARM + NT - 1) / NT), (unsigned)h->nch), dim3(NT), 0, h->stream,
+    if (!hist_in_kernel)
+    hipLaunchKernelGGL(hb45_hist_kernel<T>, dim3((unsigned)((h->warm + NT - 1) / NT), (unsigned)h->nch), dim3(NT), 0, h->stream,
                        (const cplx<T> *)in, in_stride, n_in, (const cplx<T> *)h->hist[h->cur], (cplx<T> *)h->hist[h->cur ^ 1],
-                       G::WARM);
+                       h->warm);
     QH_HIP(hipGetLastError());
     h->cur ^= 1;
     return QH_OK;
@@ -73,23 +81,38 @@ int launch(qh_hbc *h, const void *in, long long in_stride, int n_in, void *out, 
 template <typename T>
 int dispatch(qh_hbc *h, const void *in, long long is, int n, void *out, long long os)
 {
+#ifdef QH_EXP_HBC_BIG
+    // Experiment builds only (tools/ab_bench.py build big:QH_EXP_HBC_BIG=1; QH_HBC_BIG=1 in the environment takes it for every call, unset: for
+    // calls of at least 2^23 samples): fp32, three to five stages in this launch, 4096-sample steps with eight outputs a lane in the first
+    // stage.  Parity-green (the suite with QH_HBC_BIG=1), LDS work -17 %, bank conflicts -34 % (profiles/r06_g_c5_pmc_step*.json) -- and 2 - 4 %
+    // SLOWER: the kernel does not wait for the LDS pipe (profiles/r06_notes.md).
+    if constexpr (sizeof(T) == 4) {
+        const bool big = h->big == 1 || (h->big < 0 && n >= kBigMin);
+        if (big) switch (h->head) {
+        case 3: return launch<T, 3, true>(h, in, is, n, out, os);
+        case 4: return launch<T, 4, true>(h, in, is, n, out, os);
+        case 5: return launch<T, 5, true>(h, in, is, n, out, os);
+        }
+    }
+#endif
     switch (h->head) {
-    case 1: return launch<T, 1>(h, in, is, n, out, os);
-    case 2: return launch<T, 2>(h, in, is, n, out, os);
-    case 3: return launch<T, 3>(h, in, is, n, out, os);
-    case 4: return launch<T, 4>(h, in, is, n, out, os);
-    case 5: return launch<T, 5>(h, in, is, n, out, os);
-    case 6: return launch<T, 6>(h, in, is, n, out, os);
-    case 7: return launch<T, 7>(h, in, is, n, out, os);
-    case 8: return launch<T, 8>(h, in, is, n, out, os);
+    case 1: return launch<T, 1, false>(h, in, is, n, out, os);
+    case 2: return launch<T, 2, false>(h, in, is, n, out, os);
+    case 3: return launch<T, 3, false>(h, in, is, n, out, os);
+    case 4: return launch<T, 4, false>(h, in, is, n, out, os);
+    case 5: return launch<T, 5, false>(h, in, is, n, out, os);
+    case 6: return launch<T, 6, false>(h, in, is, n, out, os);
+    case 7: return launch<T, 7, false>(h, in, is, n, out, os);
+    case 8: return launch<T, 8, false>(h, in, is, n, out, os);
     }
     return set_error(QH_ERR_INVALID, "qh_hbc: nstage out of range");
 }
 
+// history samples per channel row: the longer of the two geometries' warm-ups (whole steps of 2048 / 4096 samples)
 int warm_of(int ns)
 {
-    const int step = 2048;
-    return (42 * ((1 << ns) - 1) + step - 1) / step * step;
+    const int need = 42 * ((1 << ns) - 1);
+    return (need + 4095) / 4096 * 4096;
 }
 
 }  // namespace
@@ -113,6 +136,10 @@ qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream)
     h->head = nstage >= 6 ? 4 : nstage;
     if (const char *e = getenv("QH_HBC_HEAD")) { const int v = atoi(e); h->head = v > 0 && v < nstage ? v : nstage; }      // experiments (tools/dbg/hbc_head.sh (a one-off script, in git history))
     h->warm = warm_of(h->head);
+#ifdef QH_EXP_HBC_BIG
+    h->big = -1;
+    if (const char *e = getenv("QH_HBC_BIG")) h->big = atoi(e) != 0;
+#endif
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) { set_error(QH_ERR_HIP, "hipSetDevice failed"); delete h; return nullptr; }
     if (!s) {

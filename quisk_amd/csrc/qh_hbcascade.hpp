@@ -50,28 +50,36 @@ template <typename T> __device__ __forceinline__ HbPair<T> hb_load_pair(const Hb
     return r;
 }
 
-template <int NS> struct HbGeom {
-    static constexpr int STEP = 2048;
+// STEP_ / R0_: input samples per step and outputs per lane in the FIRST stage.  2048 / 4 is the form of rounds 2 - 5; 4096 / 8 (fp32 only:
+// 63 KB of rings for four stages, two workgroups per CU) reads 19 window pairs per 8 outputs in the first stage instead of 15 per 4 and keeps
+// twice the bytes in flight per workgroup (profiles/r06_notes.md).
+template <int NS, int STEP_ = 2048, int R0_ = 4> struct HbGeom {
+    static constexpr int STEP = STEP_;
     static constexpr int WSTEPS = (42 * ((1 << NS) - 1) + STEP - 1) / STEP;     // warm-up steps
     static constexpr int WARM = WSTEPS * STEP;                                  // input samples of history kept per channel
     // stage s: n(s) outputs per step (= new samples per ring per step), R(s) outputs per lane, lanes(s) lanes
     // starting at lane0(s) -- the stages with fewer lanes than the workgroup are dealt round the four waves so
     // that the packed-FMA work per wave is level (w0: S0+S1+S7, w1: S0+S1, w2: S0+S2+S3+S5, w3: S0+S2+S4+S6).
     static constexpr int n(int s) { return STEP >> (s + 1); }
-    static constexpr int R(int s) { return s < 2 ? 4 : 2; }
+    static constexpr int R(int s) { return s == 0 ? R0_ : s == 1 ? 4 : 2; }
     static constexpr int lanes(int s) { return n(s) / R(s); }
-    static constexpr int lane0(int s) { return s < 2 ? 0 : s == 2 || s == 3 || s == 5 ? 128 : s == 4 || s == 6 ? 192 : 0; }
+    static constexpr int lane0(int s)
+    {
+        if (STEP_ == 2048) return s < 2 ? 0 : s == 2 || s == 3 || s == 5 ? 128 : s == 4 || s == 6 ? 192 : 0;
+        // 4096 / 8: stages 0 - 2 take every lane; 3 (128 lanes) waves 2 - 3, 4 (64) wave 0, 5 (32) wave 1, the rest wave 0
+        return s < 3 ? 0 : s == 3 ? 128 : s == 5 ? 64 : 0;
+    }
     // Rings hold PAIRS of consecutive samples (one 128-bit LDS access for fp32).  Odd ring: logical index HO + i
     // for new sample i, history below it; even ring: HE + i.  Pair J = L/2 lives at row J % RP, column J / RP,
     // RP = R/2, so lane u's window pair j sits at row j % RP, column u + j / RP.  PP = pairs per row, chosen so
     // that the two rows of an R = 4 ring start half a bank sweep apart.
-    static constexpr int HO(int s) { return R(s) == 4 ? 24 : 22; }
-    static constexpr int HE(int s) { return R(s) == 4 ? 12 : 10; }
+    static constexpr int HO(int s) { return R(s) >= 4 ? 24 : 22; }
+    static constexpr int HE(int s) { return R(s) >= 4 ? 12 : 10; }
     static constexpr int RP(int s) { return R(s) / 2; }
     static constexpr int PP(int s)
     {
         int p = ((HO(s) + n(s)) / 2 + RP(s) - 1) / RP(s);
-        if (RP(s) > 1) while (p % 16 != 8) p++;
+        if (RP(s) > 1) while (p % 16 != 16 / RP(s)) p++;       // the RP rows start 64 / RP banks apart
         return p;
     }
     static constexpr int odd_off(int s)              // in pairs
@@ -90,7 +98,7 @@ template <int NS> struct HbGeom {
     }
 };
 
-template <typename T, int NS, int S, typename G = HbGeom<NS>> struct HbStage {
+template <typename T, int NS, int S, typename G> struct HbStage {
     using C = cplx<T>;
     using PR = HbPair<T>;
     // One stage over one step: lane u = t - lane0 (0 <= u < lanes) produces outputs R u .. R u + R - 1.
@@ -134,7 +142,16 @@ template <typename T, int NS, int S, typename G = HbGeom<NS>> struct HbStage {
                 // output m = R u + r is sample m >> 1 of the next stage's even (m even) / odd (m odd) ring
                 constexpr int RP2 = G::RP(S + 1), PP2 = G::PP(S + 1), HO2 = G::HO(S + 1), HE2 = G::HE(S + 1);
                 PR *wo = lds + G::odd_off(S + 1), *we = lds + G::even_off(S + 1);
-                if constexpr (R == 4) {                       // samples 2u, 2u+1 of each ring: one aligned pair
+                if constexpr (R == 8) {                       // samples 4u .. 4u+3 of each ring: two aligned pairs
+                    const int Je = HE2 / 2 + 2 * u, Jo = HO2 / 2 + 2 * u;
+                    PR pe, po;
+                    pe.e[0] = acc[0]; pe.e[1] = acc[2]; po.e[0] = acc[1]; po.e[1] = acc[3];
+                    we[(Je % RP2) * PP2 + Je / RP2] = pe;
+                    wo[(Jo % RP2) * PP2 + Jo / RP2] = po;
+                    pe.e[0] = acc[4]; pe.e[1] = acc[6]; po.e[0] = acc[5]; po.e[1] = acc[7];
+                    we[((Je + 1) % RP2) * PP2 + (Je + 1) / RP2] = pe;
+                    wo[((Jo + 1) % RP2) * PP2 + (Jo + 1) / RP2] = po;
+                } else if constexpr (R == 4) {                // samples 2u, 2u+1 of each ring: one aligned pair
                     const int Je = HE2 / 2 + u, Jo = HO2 / 2 + u;
                     PR pe, po;
                     pe.e[0] = acc[0]; pe.e[1] = acc[2]; po.e[0] = acc[1]; po.e[1] = acc[3];
@@ -154,27 +171,28 @@ template <typename T, int NS, int S, typename G = HbGeom<NS>> struct HbStage {
     }
 };
 
-template <typename T, int NS, int S> struct HbStages {
+template <typename T, int NS, int S, typename G> struct HbStages {
     static __device__ __forceinline__ void run(HbPair<T> *lds, int t, bool store, cplx<T> *y, long long obase, long long olimit,
                                                bool probe_on = false, int probe_row = 0)
     {
-        HbStage<T, NS, S>::run(lds, t, store, y, obase, olimit);
+        HbStage<T, NS, S, G>::run(lds, t, store, y, obase, olimit);
         __syncthreads();
         QH_PROBE(2 + S);
-        if constexpr (S + 1 < NS) HbStages<T, NS, S + 1>::run(lds, t, store, y, obase, olimit, probe_on, probe_row);
+        if constexpr (S + 1 < NS) HbStages<T, NS, S + 1, G>::run(lds, t, store, y, obase, olimit, probe_on, probe_row);
     }
 };
 
 #ifndef QH_HBC_WAVES_F32
 #define QH_HBC_WAVES_F32 3
 #endif
-template <typename T, int NS>
-__global__ __launch_bounds__(NT, sizeof(T) == 4 ? QH_HBC_WAVES_F32 : 2) void hb45_cascade_kernel(const cplx<T> *in, long long in_stride, const cplx<T> *hist, int n_in,
-                                                          cplx<T> *out, long long out_stride, int seg)
+// BIG: the 4096 / 8 geometry (fp32).  hlen: samples of history per channel row (at least G::WARM, the same for both geometries of a handle).
+template <typename T, int NS, bool BIG = false>
+__global__ __launch_bounds__(NT, BIG ? 2 : sizeof(T) == 4 ? QH_HBC_WAVES_F32 : 2) void hb45_cascade_kernel(const cplx<T> *in, long long in_stride, const cplx<T> *hist, int n_in,
+                                                          cplx<T> *out, long long out_stride, int seg, cplx<T> *hist_next, int hlen)
 {
     using C = cplx<T>;
     using PR = HbPair<T>;
-    using G = HbGeom<NS>;
+    using G = HbGeom<NS, BIG ? 4096 : 2048, BIG ? 8 : 4>;
     constexpr int STEP = G::STEP, NQ = STEP / 4 / NT;
     extern __shared__ __align__(32) unsigned char smem[];
     PR *lds = reinterpret_cast<PR *>(smem);
@@ -185,8 +203,17 @@ __global__ __launch_bounds__(NT, sizeof(T) == 4 ? QH_HBC_WAVES_F32 : 2) void hb4
     if (start >= n_in) return;
     const int nsteps = (int)((((long long)n_in - start < seg ? (long long)n_in - start : (long long)seg) + STEP - 1) / STEP);
     const C *x = in + (long long)ch * in_stride;
-    const C *h = hist + (long long)ch * G::WARM + G::WARM;      // h[-k] = the k-th sample before in[0]
+    const C *h = hist + (long long)ch * hlen + hlen;            // h[-k] = the k-th sample before in[0]
     C *y = out + (long long)ch * out_stride;
+
+    // the history the next call finds (hb45_hist_kernel's job, a launch of its own): the segments that hold the call's last WARM samples
+    // copy their share, ahead of everything else (the host asks for this when the call is at least hlen samples long)
+    if (hist_next && start + seg > (long long)n_in - hlen) {
+        const long long first = (long long)n_in - hlen;
+        const long long lo = start > first ? start : first, hi = start + seg < n_in ? start + seg : (long long)n_in;
+        C *hn = hist_next + (long long)ch * hlen;
+        for (long long g = lo + t; g < hi; g += NT) hn[g - first] = x[g];
+    }
 
     {
         PR z;
@@ -258,7 +285,7 @@ __global__ __launch_bounds__(NT, sizeof(T) == 4 ? QH_HBC_WAVES_F32 : 2) void hb4
         __syncthreads();
         QH_PROBE(1);
         if (step + 1 < nsteps) fetch(base + STEP);
-        HbStages<T, NS, 0>::run(lds, t, step >= 0, y, base >> NS, (long long)(n_in >> NS), probe_on, probe_row);
+        HbStages<T, NS, 0, G>::run(lds, t, step >= 0, y, base >> NS, (long long)(n_in >> NS), probe_on, probe_row);
         // every lane reads (lanes without a carried pair read pair 0 and drop it): a value defined under a condition on both sides of
         // the barrier went through scratch memory, and the scratch load's vmcnt(0) wait also waited for the prefetch above
         // (and as two scalars-of-complex rather than one aggregate: the aggregate copy was given a stack slot)

@@ -30,7 +30,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int it = 0; it < 3; it++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k, dim3(nseg, 1), dim3(NT), lds, 0, x, n, h, (int)n, y, n >> NS, seg);
+        hipLaunchKernelGGL(k, dim3(nseg, 1), dim3(NT), lds, 0, x, n, h, (int)n, y, n >> NS, seg, (cplx<float> *)nullptr, G::WARM);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("segsteps %d blocks %d lds %zu: %.3f ms\n", segsteps, nseg, lds, ms);
