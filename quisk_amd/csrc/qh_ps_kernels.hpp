@@ -51,14 +51,18 @@ static __global__ void prep_kernel(const double2 *in, long long in_stride, doubl
 //   w = d0 + m (fdecim - 1),  input index i_m = m + floor(w) - 1,  position within (c0..c3) = w - floor(w) + 1  in [1, 2)
 // with d0 the carried dindex: one lane per output.  hist[row][3] = the last three inputs of the call before (c0, c1, c2).
 // Every receiver of a bank sees the same rates and block lengths, so d0 and the output count are the bank's.
+// (nout is the host's count, from the reference's running sum -- fracdecim_walk below; where this closed form puts the call's last output one
+// input further on, behind the call's end, the output is the same point seen from the input before: position 2 instead of 1)
 static __global__ void fracdecim_kernel(const double2 *in, long long in_stride, const double2 *hist, int nout, double d0, double step, double2 *out,
-                                 long long out_stride)
+                                 long long out_stride, int na)
 {
     const long long row = blockIdx.y;
     const double2 *x = in + row * in_stride, *h = hist + row * 3;
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < nout; m += gridDim.x * blockDim.x) {
-        const double w = fma(step, (double)m, d0), fl = floor(w);
-        const int i = m + (int)fl - 1;
+        const double w = fma(step, (double)m, d0);
+        double fl = floor(w);
+        int i = m + (int)fl - 1;
+        if (i > na - 1) { fl -= 1.0; i -= 1; }
         const double d = w - fl + 1.0;
         double2 c[4];
 #pragma unroll
@@ -121,21 +125,20 @@ inline u64 turns_step(double freq, double rate)
     return sc >= 18446744073709551616.0L ? 0ull : (u64)sc;
 }
 
-// cFracDecim's output count for a call of `na` inputs with the carried dindex d0 (the reference's loop, closed form + a
-// correction walk): outputs m with input index m + floor(d0 + m step) - 1 <= na - 1
-inline int fracdecim_count(int na, double d0, double fdecim)
+// cFracDecim's loop over a call's inputs as the reference runs it (quisk.c:631-662): returns the output count and leaves the dindex the next
+// call starts from.  dindex is a RUNNING SUM in double, and whether an input yields an output (`dindex < 2`) is decided on that sum: at a rate
+// whose dindex comes back to whole numbers (185 185 / 3 = 61 728 -> 48 000: step 143 / 500, dindex = 2 "exactly" every 500 outputs) a closed
+// form d0 + m step rounds the other way now and then, and when that input is a call's last one the output lands in the other call (seed
+// 910087 of the api walk: 4512 samples against the reference's 4510, two fewer in the call after).  A few ns per input on the host.
+inline int fracdecim_walk(int na, double &dindex, double fdecim)
 {
     const double step = fdecim - 1;
-    int M = (int)(((double)na + 1.0 - d0) / fdecim) + 2;
-    if (M < 0) M = 0;
-    auto idx = [&](int m) { return m + (int)std::floor(std::fma(step, (double)m, d0)) - 1; };
-    while (M > 0 && idx(M - 1) > na - 1) M--;
-    while (idx(M) <= na - 1) M++;
-    return M;
-}
-inline double fracdecim_next_dindex(int na, int M, double d0, double fdecim)
-{
-    return std::fma(fdecim - 1, (double)M, d0) + (double)M - (double)na;        // dindex as the next call's first sample finds it
+    int nout = 0;
+    for (int i = 0; i < na; i++) {
+        if (dindex < 2) { nout++; dindex += step; }
+        else dindex -= 1;
+    }
+    return nout;
 }
 
 // HalfBand7 (.. 8, 9) chained (quisk.c:2666-2677) = one polyphase interpolator: g = h * up2(h) * up4(h), gain 2 per stage

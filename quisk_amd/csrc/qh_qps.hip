@@ -319,15 +319,15 @@ int qh_qps_process(qh_qps *h, const double *d_in, long long in_stride, int n, do
         int na = nb_;
         if (frac && na > 0) {                                           // cFracDecim to 48 ksps (quisk.c:2654-2659)
             const double fdecim = dr / 48000.0;
-            const int M = qh_ps::fracdecim_count(na, h->fd_dindex, fdecim);
+            const double d0 = h->fd_dindex;
+            const int M = qh_ps::fracdecim_walk(na, h->fd_dindex, fdecim);
             if (M > fd_bound) return set_error(QH_ERR_HIP, "qh_qps: cFracDecim count %d above its bound %lld", M, fd_bound);
             double2 *dst = h->d_fd.p + (size_t)par * (size_t)nch * (size_t)fd_bound;
             if (M > 0) hipLaunchKernelGGL(qh_ps::fracdecim_kernel, dim3(qh_ps::grid_x(M, 256u), (unsigned)nch), dim3(256), 0, h->stream, audio, as,
-                                          (const double2 *)h->fd_hist[h->fd_cur], M, h->fd_dindex, fdecim - 1, dst, h->fd_stride);
+                                          (const double2 *)h->fd_hist[h->fd_cur], M, d0, fdecim - 1, dst, h->fd_stride, na);
             hipLaunchKernelGGL(qh_ps::fd_hist_kernel, dim3((unsigned)nch), dim3(64), 0, h->stream, audio, as, na, (const double2 *)h->fd_hist[h->fd_cur],
                                h->fd_hist[h->fd_cur ^ 1]);
             h->fd_cur ^= 1;
-            h->fd_dindex = qh_ps::fracdecim_next_dindex(na, M, h->fd_dindex, fdecim);
             audio = dst; as = h->fd_stride; na = M;
         }
         if (h->up && na > 0) {                                          // to the playback rate (quisk.c:2663-2682)

@@ -663,13 +663,13 @@ int process_radio(double *cSamples, int nSamples)
     // ---- cFracDecim to 48 ksps (quisk.c:2654-2659)
     if (decim_srate != 48000 && na > 0) {
         const double fdecim = decim_srate / 48000.0, step = fdecim - 1;
-        const int M = qh_ps::fracdecim_count(na, g.fd_dindex, fdecim);
+        const double d0 = g.fd_dindex;
+        const int M = qh_ps::fracdecim_walk(na, g.fd_dindex, fdecim);
         if (g.d_fd.need((size_t)M + 1)) return -1;
         if (M > 0) hipLaunchKernelGGL(qh_ps::fracdecim_kernel, dim3(grid_for(M), 1u), dim3(256), 0, s, (const double2 *)audio, 0LL, (const double2 *)g.fd_hist[g.fd_cur], M,
-                                      g.fd_dindex, step, g.d_fd.p, 0LL);
+                                      d0, step, g.d_fd.p, 0LL, na);
         hipLaunchKernelGGL(qh_ps::fd_hist_kernel, dim3(1), dim3(64), 0, s, (const double2 *)audio, 0LL, na, (const double2 *)g.fd_hist[g.fd_cur], g.fd_hist[g.fd_cur ^ 1]);
         g.fd_cur ^= 1;
-        g.fd_dindex = qh_ps::fracdecim_next_dindex(na, M, g.fd_dindex, fdecim);
         audio = g.d_fd.p; na = M;
     }
     // ---- the WDSP hand-off (quisk.c:2660-2661) with the samples where they are: the shim's ring, fexchange0's rings and the DSP blocks

@@ -76,7 +76,9 @@ def _draw(rng, mode, fs, play, api, ref, st):
                                                (9, 3, 192000, 192000), (10, 1, 48000, 96000), (11, 3, 370370, 48000), (12, 5, 53333, 48000),
                                                (21, 0, 96000, 48000), (22, 2, 192000, 48000), (23, 7, 192000, 96000), (24, 8, 111111, 48000), (25, 9, 192000, 48000),
                                                (26, 13, 96000, 48000), (27, 10, 48000, 48000),
-                                               (7120, 3, 111111, 96000)])     # (round 4's open mismatch: ssb_squelch reads filter_bandwidth[0] in every bank, quisk.c:1120)
+                                               (7120, 3, 111111, 96000),      # (round 4's open mismatch: ssb_squelch reads filter_bandwidth[0] in every bank, quisk.c:1120)
+                                               (910087, 4, 185185, 96000)])   # (a sweep of round 6: cFracDecim's dindex is a running sum -- 61 728 -> 48 000 brings it back to 2.0 every
+                                                                              #  500 outputs, and a closed form put one such output into the call before: 4512 samples for 4510)
 def test_random_setter_walk_over_the_one_receiver_api(qh, oracle, seed, mode, fs, play):
     rng = np.random.default_rng(7000 + seed)
     api = qh.quiskapi
