@@ -152,6 +152,7 @@ struct Qrx {
     // the reference's sizeFilter / indexFilter per channel, rx_ring what its buffer holds outside the live ring.
     std::vector<int> rx_size, rx_index;
     std::vector<std::vector<cd>> rx_ring;
+    std::vector<char> rx_ring_fresh;        // rx_ring[c] is what the reference's buffer holds right now (no sample since rx_resize brought it up to date)
     qh_qagc *agc = nullptr;         // process_agc on the output (quisk.c:2686-2702); null = never switched on
     bool agc_on = false;
     double agc_gain = 80.0;
@@ -295,7 +296,11 @@ struct Qrx {
         std::vector<cd> hist;
         std::vector<cd> &ring = rx_ring[(size_t)c];
         if ((int)ring.size() < (N > M ? N : M)) ring.resize((size_t)(N > M ? N : M), cd(0.0, 0.0));
-        if (N > 0) {
+        if (rx_ring_fresh.size() != rx_size.size()) rx_ring_fresh.assign(rx_size.size(), 0);
+        // (only when samples went through since the storage was last brought up to date: a second set_filters ahead of the next block finds
+        // the storage as the first one left it, and indexFilter possibly still beyond the size in between -- it is clamped by the next
+        // SAMPLE, quisk.c:1246 -- which as a "last written" position would scatter the history over the ring: bank walk 920306)
+        if (N > 0 && !rx_ring_fresh[(size_t)c]) {
             if (int rc = rx_hist_read(c, hist)) return rc;
             // what the live ring holds: the sample written `age` calls ago sits at (last - age) mod N, last = index - 1
             const int last = rx_index[(size_t)c] - 1;
@@ -313,6 +318,7 @@ struct Qrx {
             if (int rc = rx_hist_write(c, hist)) return rc;
         }
         rx_size[(size_t)c] = M;
+        rx_ring_fresh[(size_t)c] = 1;
         return QH_OK;
     }
     // indexFilter after m more samples: "if (index >= size) index = 0; ...; index++" per sample
@@ -321,6 +327,7 @@ struct Qrx {
         for (size_t c = 0; c < rx_size.size(); c++) {
             const int N = rx_size[c];
             if (N <= 0 || m <= 0) continue;
+            if (c < rx_ring_fresh.size()) rx_ring_fresh[c] = 0;
             const int i0 = rx_index[c] >= N ? 0 : rx_index[c];
             rx_index[c] = (int)(((long long)i0 + m - 1) % N) + 1;
         }
