@@ -1802,7 +1802,7 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
     if (egress) a.eg = eg;
     const int nl = list ? nlist : nch;
     // the one-group tile kernel writes the next call's delay line itself when the call is at least one line long (OsfirArgs::hist_next)
-    const bool hist_in_kernel = !pairs && det != 3 && (det || (!band6k && !band2g)) && n_mid >= kHistBand;
+    const bool hist_in_kernel = !pairs && (det || (!band6k && !band2g)) && n_mid >= kHistBand;
     if (hist_in_kernel) a.hist_next = hist[hc ^ 1];
     if (pairs) {            // the caller has checked: real taps, one mask per pair, 4096-point tiles, no meters, no egress
         a.chan_list = pairs;

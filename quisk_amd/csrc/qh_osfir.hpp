@@ -49,7 +49,7 @@ struct EpiParam {                 // per channel 2x2 real output matrix: [re';im
 template <typename T> struct OsfirArgs {
     const cplx<T> *in;            // [nch][in_stride]; element 0 = first new sample of this call
     const cplx<T> *hist;          // [nch][hist_stride]; the hist_len samples that precede in[0] (already mixed)
-    cplx<T> *hist_next;           // plain (not MIX / PACKED / PAIR / DET 3) kernels: where the delay line for the next call goes, or null (hist_update_kernel does it)
+    cplx<T> *hist_next;           // plain (not MIX / PACKED / PAIR) kernels: where the delay line for the next call goes, or null (hist_update_kernel does it)
     cplx<T> *out;                 // [nch][out_stride]; output m is written at out_offset + m
     const cplx<T> *mask;          // [nch or 1][NFFT]  FFT(h)/NFFT
     const cplx<T> *tw_fwd;        // pass tables for NFFT
@@ -327,20 +327,6 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
     const C *hist = a.hist ? a.hist + (long long)ch * a.hist_stride : nullptr;
     const int g0 = a.off - a.P + tile * (D * a.Lout);      // input index of element 0 of this tile (Lout counts folded samples)
 
-    if constexpr (!MIX && !PACKED && !PAIR && DET != 3) {
-        // The stage's delay line for the next call -- the last hist_len RAW samples of this call's input (hist_update_kernel's job: a launch of its
-        // own behind every stage, a dozen on config 4's critical path, four of config 5's 170 us) -- is copied by the tiles whose span holds those
-        // samples: the last two or three of a channel (workgroup-uniform test; a sample two tiles share is written twice, the same value).  A copy
-        // loop of its own in front of the tile's loads, where nothing else is live (taken from x[] after the loads it cost the /8 front
-        // kernel ten registers; DET 3, at its register limit either way, keeps the separate launch).  The host asks for this only when the call is at least hist_len samples long.
-        if (a.hist_next && g0 + NFFT > a.n_in - a.hist_len) {
-            C *hn = a.hist_next + (long long)ch * a.hist_stride;
-            const int first = a.n_in - a.hist_len;
-#pragma unroll 1
-            for (int g = max(g0, first) + t; g < min(g0 + NFFT, a.n_in); g += NT) hn[g - first] = in[g];
-            asm volatile("" ::: "memory");
-        }
-    }
     // Interior tiles (all NFFT inputs inside this call's buffer: every tile but the first and the last
     // one or two of a channel) take plain loads; edge tiles take the clamped, history-aware path.
     QH_OPROBE(0);
@@ -665,6 +651,21 @@ __global__ __launch_bounds__(NT, (osfir_min_waves<T, D, OUTMIX, NFFT>())) void o
         }
     }
     QH_OPROBE(5);
+    if constexpr (!MIX && !PACKED && !PAIR) {
+        // The stage's delay line for the next call -- the last hist_len RAW samples of this call's input (hist_update_kernel's job: a launch of its
+        // own behind every stage, a dozen on config 4's critical path, four of config 5's 170 us) -- is copied by the tiles whose span holds those
+        // samples: the last two or three of a channel (workgroup-uniform test; a sample two tiles share is written twice, the same value).  A copy
+        // loop of its own BEHIND the tile's stores: taken from x[] after the loads it cost the /8 front kernel ten registers and DET 3 thirteen
+        // spills, and in front of the loads it cost config 2's two kernels 1 % each (same-box A/B against the tree before, profiles/r06_notes.md).
+        // The rows of `out` never lie over the rows of `in` when the host asks for this (it asks only when the call is at least hist_len long).
+        if (a.hist_next && g0 + NFFT > a.n_in - a.hist_len) {
+            C *hn = a.hist_next + (long long)ch * a.hist_stride;
+            const int first = a.n_in - a.hist_len;
+            const int tq = threadIdx.x;
+#pragma unroll 1
+            for (int g = max(g0, first) + tq; g < min(g0 + NFFT, a.n_in); g += NT) hn[g - first] = in[g];
+        }
+    }
 }
 
 // ---- D = 1 stage on 8192-point tiles shared by two 256-lane groups ---------------------------------------------------
