@@ -209,6 +209,18 @@ def _walk(qh, oracle, seed, replay, wide=False):
             continue                     # a squelch switched on during the start-up keeps the channel at 1e-18 for the whole walk: 0 / 0
         err = rel_rms(y[c], ref)
         tol = 1e-4 if lms_used[c] else 1e-5 if mp_long[c] else 1e-6
+        if np.sqrt(np.mean(np.abs(y[c] - ref) ** 2)) < 1e-12 * max(1.0, np.abs(x[c]).max()):
+            continue                     # muted from the first blocks on (SetRXAPanelSelect 0, walk 960097): what is left of the start-up sits at 1e-7
+                                         # of the input, and rounding at 1e-13 of the INPUT is 2e-6 of that
+        if os.environ.get("QH_REPORT"):      # diagnostics: every channel's figure, not only the first one over its tolerance
+            print("seed %d channel %d: rel rms %.3e, tolerance %.0e" % (seed, c, err, tol), flush=True)
+            if err >= tol:
+                q0, per = 0, []
+                for s2, n2 in enumerate(seglen):
+                    a, b = q0 * 256, (q0 + n2) * 256
+                    per.append("%d:%.1e/%.1e" % (s2, np.sqrt(np.mean(np.abs(y[c, a:b] - ref[a:b]) ** 2)), np.sqrt(np.mean(np.abs(ref[a:b]) ** 2))))
+                    q0 += n2
+                print("   per segment rms error / rms of the reference: %r\n   setters: %r" % (per, [l for l in log if l[1] == c]), flush=True)
         if err >= tol:
             # first segment that is off, for the failure message
             p0 = 0
