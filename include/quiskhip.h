@@ -63,7 +63,7 @@ long long qh_rxa_graph_launches(const qh_rxa *e);                /* calls served
 /* Tile of the fircore (nbp0 / bp1 / bpsnba / FM audio) stages for nc <= 2048: 4096 points (0 = default), or 8192 points
  * shared by two lane groups: three times the useful outputs per pair of transforms and 22 % fewer instructions per sample, yet
  * slower on MI355X because its barriers hold eight wavefronts; kept selectable for that comparison.
- * nc = 4096 always runs 8192-point tiles, nc = 8192 / 16384 two / four 4096-tap partitions on them.  Results agree to rounding; a change rebuilds the filter masks on the next call.
+ * nc = 4096 always runs 8192-point tiles, nc = 8192 ... 65536 two ... sixteen 4096-tap partitions on them.  Results agree to rounding; a change rebuilds the filter masks on the next call.
  * qh_rxa_band_tile: the size in use. */
 int qh_rxa_set_band_tile(qh_rxa *e, int nfft);
 int qh_rxa_band_tile(const qh_rxa *e);
@@ -73,7 +73,7 @@ int qh_rxa_band_tile(const qh_rxa *e);
  * i.e. on a DSP-block boundary, which is when the reference applies them (csDSP, wdsp/main.c:41). */
 int qh_rxa_SetRXAMode(qh_rxa *e, int ch, int mode);
 int qh_rxa_RXASetPassband(qh_rxa *e, int ch, double f_low, double f_high);
-int qh_rxa_RXASetNC(qh_rxa *e, int ch, int nc);     /* a power of two in [dsp_size, 16384]; above 4096: partitions of 4096 taps (tests/test_gpu_long_nc.py) */
+int qh_rxa_RXASetNC(qh_rxa *e, int ch, int nc);     /* a power of two in [dsp_size, 65536]; above 4096: partitions of 4096 taps (tests/test_gpu_long_nc.py) */
 int qh_rxa_SetRXAShiftRun(qh_rxa *e, int ch, int run);
 int qh_rxa_SetRXAShiftFreq(qh_rxa *e, int ch, double fshift);
 int qh_rxa_RXANBPSetRun(qh_rxa *e, int ch, int run);

@@ -54,9 +54,9 @@ int set_error(int code, const char *fmt, ...)
 static constexpr int kNfft = 4096;          // FFT size of the front stage and, for nc <= 2048, of the fircore stages
 static constexpr int kBandNfftMax = 8192;   // fircore stages with 2048 < nc <= 4096 run 8192-point tiles (Engine::bnfft)
 static constexpr int kHistBand = 4095;      // fircore history capacity: nc up to 4096
-// nc = 8192 / 16384 (RXASetNC, wdsp/RXA.c:934-946): the impulse response in partitions of 4096 taps, every partition an ordinary
+// nc = 8192 ... 65536 (RXASetNC, wdsp/RXA.c:934-946): the impulse response in partitions of 4096 taps, every partition an ordinary
 // 8192-point tile pass over a view of the stream that starts 4096 p samples earlier, the passes added (Engine::run_band)
-static constexpr int kLongPart = 4096, kLongNcMax = 16384, kLongParts = kLongNcMax / kLongPart, kLongHist = kLongNcMax - 1;
+static constexpr int kLongPart = 4096, kLongNcMax = 65536, kLongParts = kLongNcMax / kLongPart, kLongHist = kLongNcMax - 1;
 static constexpr int kHistFront = 2240;     // resampler history capacity: 140 * D taps, D <= 16
 // FM PLL time tiles (qh_tiled.hpp).  On a carrier the loop (double pole at 0.66 per sample) forgets its start state in ~100
 // samples; on noise alone two runs meet after ~135 samples on average with an exponential tail, so a 768-sample warm-up
@@ -1659,22 +1659,23 @@ int Engine::run_front(const double2 *src, long long src_stride, double2 *dst, lo
 
 // ---- impulse responses longer than 4096 taps (kLongPart) -------------------------------------------------------------------
 // lcat[ch] = [the stage's last kLongHist input samples | this call's block]
+// (lh = the samples of history the stage's partitions look back over, 4096 K - 1: the rows hold kLongHist, what lies further back is not moved)
 static __global__ __launch_bounds__(NT) void long_gather_kernel(const double2 *hist, const double2 *src, long long src_stride, int n, double2 *cat,
-                                                                long long cat_stride, const int *chan_list)
+                                                                long long cat_stride, const int *chan_list, int lh)
 {
     const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
     const double2 *h = hist + (long long)ch * kLongHist, *x = src + (long long)ch * src_stride;
     double2 *c = cat + (long long)ch * cat_stride;
     const long long tot = (long long)kLongHist + n;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < tot; i += (long long)gridDim.x * NT) c[i] = i < kLongHist ? h[i] : x[i - kLongHist];
+    for (long long i = (long long)(kLongHist - lh) + (long long)blockIdx.x * NT + threadIdx.x; i < tot; i += (long long)gridDim.x * NT) c[i] = i < kLongHist ? h[i] : x[i - kLongHist];
 }
 // the history the next call finds: the last kLongHist samples of lcat
-static __global__ __launch_bounds__(NT) void long_hist_kernel(const double2 *cat, long long cat_stride, int n, double2 *hist, const int *chan_list)
+static __global__ __launch_bounds__(NT) void long_hist_kernel(const double2 *cat, long long cat_stride, int n, double2 *hist, const int *chan_list, int lh)
 {
     const int ch = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
     const double2 *c = cat + (long long)ch * cat_stride + n;
     double2 *h = hist + (long long)ch * kLongHist;
-    for (int i = blockIdx.x * NT + threadIdx.x; i < kLongHist; i += gridDim.x * NT) h[i] = c[i];
+    for (int i = kLongHist - lh + blockIdx.x * NT + threadIdx.x; i < kLongHist; i += gridDim.x * NT) h[i] = c[i];
 }
 static __global__ __launch_bounds__(NT) void long_add_kernel(double2 *dst, long long dst_stride, const double2 *add, long long add_stride, int n, const int *chan_list)
 {
@@ -1756,10 +1757,13 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
         const int K = long_parts[sid], Pk = kLongPart - 1, Lk = kBandNfftMax - Pk, nt = (int)((n_mid + Lk - 1) / Lk);
         const int nl = list ? nlist : nch;
         const long long cat_stride = kLongHist + lcat_cap;
-        const long long per = (kLongHist + n_mid + NT - 1) / NT;
+        // what the K partitions look back over; a channel's own nc may be shorter (its further masks are zero) and what lies beyond in its row is then
+        // whatever an earlier, longer form of the stage left there -- finite samples, times zero
+        const int lh = K * kLongPart - 1;
+        const long long per = (lh + n_mid + NT - 1) / NT;
         tick(1);
         hipLaunchKernelGGL(long_gather_kernel, dim3((unsigned)(per < 2048 ? per : 2048), (unsigned)nl), dim3(NT), 0, stream, (const double2 *)lhist[sid][hc], src,
-                           src_stride, (int)n_mid, lcat, cat_stride, list);
+                           src_stride, (int)n_mid, lcat, cat_stride, list, lh);
         for (int p = 0; p < K; p++) {
             OsfirArgs<double> a{};
             a.in = lcat + kLongHist - (long long)kLongPart * p; a.in_stride = cat_stride;
@@ -1780,7 +1784,7 @@ void Engine::run_band(const double2 *src, long long src_stride, double2 *dst, lo
                                    (const double2 *)dst, dst_stride, dst, dst_stride, (int)n_mid, (const unsigned long long *)nullptr,
                                    (const unsigned long long *)nullptr, ep, list);
         tick(2);
-        hipLaunchKernelGGL(long_hist_kernel, dim3(64, (unsigned)nl), dim3(NT), 0, stream, (const double2 *)lcat, cat_stride, (int)n_mid, lhist[sid][hc ^ 1], list);
+        hipLaunchKernelGGL(long_hist_kernel, dim3(64, (unsigned)nl), dim3(NT), 0, stream, (const double2 *)lcat, cat_stride, (int)n_mid, lhist[sid][hc ^ 1], list, lh);
         hc ^= 1;
         return;
     }

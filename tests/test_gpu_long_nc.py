@@ -1,4 +1,4 @@
-"""RXASetNC 8192 and 16384 (wdsp/RXA.c:934-946 sets nbp0, bpsnba, bp1 and the FM filters alike; fircore takes any multiple of the
+"""RXASetNC 8192 ... 65536 (wdsp/RXA.c:934-946 sets nbp0, bpsnba, bp1 and the FM filters alike; fircore takes any multiple of the
 block size, firmin.c:290-346): impulse responses longer than one tile run as partitions of 4096 taps over delayed views of the stream
 (Engine::run_band, quisk_amd/csrc/qh_engine.hip).  Against the oracle's uniformly partitioned fircore: SSB with and without the meters,
 AM (nbp0 + bp1), FM (nbp0, de-emphasis, audio filter), ragged calls down to one DSP block, nc changed in mid-stream (the delay lines
@@ -15,7 +15,7 @@ from test_gpu_band_tile_8192 import STEP_DB, _oracle, _setup
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nc", [8192, 16384])
+@pytest.mark.parametrize("nc", [8192, 16384, 32768, 65536])
 def test_ssb_ragged_calls_with_and_without_meters(qh, oracle, nc):
     nch = 3
     calls = [30, 1, 7, 50, 2, 24, 1, 1, 40]            # 7680 ... 256 DSP-rate samples per call
@@ -154,7 +154,7 @@ def test_through_the_wdsp_names_block_by_block(qh, oracle):
 def test_limits(qh):
     e = qh.RxaEngine(1)
     with pytest.raises(Exception):
-        e.RXASetNC(0, 32768)
+        e.RXASetNC(0, 131072)
     with pytest.raises(Exception):
         e.RXASetNC(0, 12288)                    # a power of two, like the 4096-tap partitions expect
     e.close()

@@ -130,7 +130,7 @@ def test_unsupported_requests_fail_loudly(qh):
     with pytest.raises(qh.QuiskHipError):
         e.process_host(x)
     with pytest.raises(qh.QuiskHipError):
-        e.RXASetNC(0, 32768)                    # nc up to 16384 (four partitions of 4096 taps, tests/test_gpu_long_nc.py)
+        e.RXASetNC(0, 131072)                   # nc up to 65536 (sixteen partitions of 4096 taps, tests/test_gpu_long_nc.py)
     with pytest.raises(qh.QuiskHipError):
         qh.RxaEngine(1, in_rate=44100)          # in_rate / dsp_rate must be whole one way or the other (wdsp/channel.c:39-42)
 
