@@ -1,7 +1,7 @@
 """More seeds of every seeded setter walk of the suite in one process: the (qh, oracle, seed) walks as they are, the Quisk api / bank / rx walks
 with (mode, fs, play) drawn from the combinations their tests list.  usage: walk_sweep_all.py <first> <last> [family ...]
 (families: rxa rxa_replay rxa_long rxa_notch names shim ana ana_bank dropin api api_wdsp bank rx; default all; env CHARS: how much of a
-failure's message to print)"""
+failure's message to print; QH_COMBOS=random: the Quisk api / bank walks with (mode, fs, play) drawn per seed)"""
 import importlib, os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -13,6 +13,16 @@ def mod(n): return importlib.import_module(n)
 COMBOS = [(3, 192000, 48000), (3, 111111, 96000), (4, 96000, 48000), (5, 192000, 48000), (3, 48000, 48000), (1, 133333, 48000), (4, 185185, 96000),
           (5, 96000, 192000), (3, 192000, 192000), (1, 48000, 96000), (3, 370370, 48000), (5, 53333, 48000), (0, 96000, 48000), (2, 192000, 48000),
           (7, 192000, 96000), (8, 111111, 48000), (9, 192000, 48000), (13, 96000, 48000), (10, 48000, 48000)]
+if os.environ.get("QH_COMBOS") == "random":         # (mode, fs, play) drawn per seed from every rate family the planner knows, not the tests' own list
+    import numpy as _np
+    _MODES = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 13]
+    _FS = [48000, 53333, 96000, 111111, 133333, 185185, 192000, 240000, 250000, 370370, 384000, 480000, 740740, 960000]
+    class _Combos:
+        def __len__(self): return 1 << 30
+        def __getitem__(self, i):
+            r = _np.random.default_rng(1234567 + i)
+            return (int(r.choice(_MODES)), int(r.choice(_FS)), int(r.choice([48000, 96000, 192000])))
+    COMBOS = _Combos()
 def rx_combos():
     from quisk_amd import rxfilter as r
     return [(96000, r.USB), (192000, r.LSB), (48000, r.CWU), (96000, r.AM), (96000, r.FM), (240000, r.USB), (192000, r.AM), (48000, r.USB),
