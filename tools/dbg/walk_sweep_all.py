@@ -27,6 +27,10 @@ def rx_combos():
     from quisk_amd import rxfilter as r
     return [(96000, r.USB), (192000, r.LSB), (48000, r.CWU), (96000, r.AM), (96000, r.FM), (240000, r.USB), (192000, r.AM), (48000, r.USB),
             (192000, r.CWL), (48000, r.AM), (192000, r.FM), (250000, r.LSB)]
+def rx_random(s):
+    from quisk_amd import rxfilter as r
+    g = _np.random.default_rng(7654321 + s)
+    return (int(g.choice(_FS)), [r.USB, r.LSB, r.CWU, r.CWL, r.AM, r.FM][int(g.integers(0, 6))])
 FAM = {
     "rxa": lambda s: mod("test_gpu_rxa_fuzz").test_random_setter_walk(qh, oracle, s),
     "rxa_replay": lambda s: mod("test_gpu_rxa_fuzz").test_random_setter_walk_block_at_a_time_with_graph_replay(qh, oracle, s),
@@ -40,7 +44,7 @@ FAM = {
     "api": lambda s: mod("test_gpu_quisk_api_fuzz").test_random_setter_walk_over_the_one_receiver_api(qh, oracle, s, *COMBOS[s % len(COMBOS)]),
     "api_wdsp": lambda s: mod("test_gpu_quisk_api_fuzz").test_random_setter_walk_with_wdsp_in_the_audio_path(qh, oracle, s, *COMBOS[s % len(COMBOS)]),
     "bank": lambda s: mod("test_gpu_quisk_bank_fuzz").test_random_setter_walk_over_the_bank(qh, oracle, s, *COMBOS[s % len(COMBOS)]),
-    "rx": lambda s: mod("test_gpu_quisk_rx_fuzz").test_random_walk(qh, oracle, *rx_combos()[s % 12], s),
+    "rx": lambda s: mod("test_gpu_quisk_rx_fuzz").test_random_walk(qh, oracle, *(rx_random(s) if os.environ.get("QH_COMBOS") == "random" else rx_combos()[s % 12]), s),
 }
 a, b = int(sys.argv[1]), int(sys.argv[2])
 fams = sys.argv[3:] or list(FAM)
