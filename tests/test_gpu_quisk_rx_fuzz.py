@@ -118,7 +118,7 @@ def test_random_walk(qh, oracle, fs, mode, seed):
         ys.append(bank.process_host(x[:, pos:pos + n]))
         for c in range(nch):
             rs[c].append(refs[c].process(x[c, pos:pos + n]))
-            if twins: tws[c].append(twins[c].process(x[c, pos:pos + n] * (1.0 + 1e-13 * pert.standard_normal(n))))
+            if twins: tws[c].append(twins[c].process(x[c, pos:pos + n] * (1.0 + float(os.environ.get("QH_TWIN_EPS", "1e-13")) * pert.standard_normal(n))))
         pos += n
         blk += 1
     y = np.concatenate(ys, axis=1)
