@@ -88,6 +88,29 @@ def test_config3_decimator_many_channels(qh, oracle):
         assert rel_rms(y[c], want) < TOL64
 
 
+@pytest.mark.parametrize("ntaps,d", [(245, 5), (98, 2), (98, 1), (1023, 32), (64, 8), (147, 3)])
+def test_calls_around_one_delay_line_long(qh, oracle, ntaps, d):
+    """A call of at least one delay line (P = ntaps - 1 rounded up to the tile's fold) has its tail written as the next call's delay line by the
+    filter kernel's own tiles (OsfirArgs::hist_next); a shorter one goes through hist_update_kernel, which keeps part of the old line.  Calls
+    of P - 1, P, P + 1 samples and their neighbours in every order, two channels, against the restatement over the whole stream."""
+    rng = np.random.default_rng(1000 * ntaps + d)
+    taps = rng.standard_normal(ntaps) * np.hanning(ntaps + 2)[1:-1]
+    fold = 8 if d % 8 == 0 else 4 if d % 4 == 0 else 2 if d % 2 == 0 else 1
+    P = max(fold, (ntaps - 1 + fold - 1) // fold * fold)
+    sizes = [P - 1, P, 1, P + 1, 3, P, P - 1, 2 * P + d + 1, P + 1, 7, 5 * P, 2, P, P, 1, P - 1, 4096, P + 3]
+    x = np.stack([stream(7 + c, sum(sizes)) for c in range(2)])
+    bank = qh.FirBank(2, taps, d)
+    out, pos = [], 0
+    for k in sizes:
+        out.append(bank.process_host(x[:, pos:pos + k]))
+        pos += k
+    y = np.concatenate(out, axis=1)
+    for c in range(2):
+        want = oracle.OracleFir(taps).cDecimate(x[c], d)
+        assert y.shape[1] == want.size
+        assert rel_rms(y[c], want) < TOL64, (c, rel_rms(y[c], want))
+
+
 def test_float32_bank(qh, oracle, gold):
     x = stream(31, 20000)
     want = oracle.OracleFir(gold["taps245"]).cDecimate(x, 5)

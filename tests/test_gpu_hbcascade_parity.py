@@ -58,6 +58,28 @@ def test_state_carries_between_ragged_calls(qh, oracle, nstage):
     assert rel_rms(c.process_host(x[:, :d * 50]), ref[:, :50]) < TOL64
 
 
+@pytest.mark.parametrize("nstage,dtype,tol", [(1, 0, TOL64), (3, 0, TOL64), (4, 1, TOL32), (8, 0, TOL64), (6, 1, TOL32)])
+def test_calls_around_one_history_long(qh, oracle, nstage, dtype, tol):
+    """A launch keeps ceil(42 (2^s - 1) / 4096) x 4096 input samples of history (s = its own stages: a cascade of six and more runs as 4 + the
+    rest); a call at least that long has it written by the kernel's own segments, a shorter one by hb45_hist_kernel, which keeps part of the
+    old history.  Calls one decimation unit short of it, exactly it, one over, and their neighbours in turn."""
+    d = 1 << nstage
+    head = 4 if nstage >= 6 else nstage
+    W = (42 * ((1 << head) - 1) + 4095) // 4096 * 4096
+    sizes = [W - d, W, d, W + d, 3 * d, W, W - d, 2 * W + 5 * d, d, W // 16 // d * d + d, W, 4 * W, W - d, W + d]
+    x = stream(31 + nstage, 2, sum(sizes))
+    ref = oracle_chain(oracle, x, nstage)
+    c = qh.HalfBandCascade(2, nstage, dtype=dtype)
+    out, pos = [], 0
+    for k in sizes:
+        out.append(c.process_host(x[:, pos:pos + k].astype(np.complex64) if dtype else x[:, pos:pos + k]))
+        pos += k
+    y = np.concatenate(out, axis=1)
+    assert y.shape == ref.shape
+    for ch in range(2):
+        assert rel_rms(y[ch], ref[ch]) < tol, (ch, rel_rms(y[ch], ref[ch]))
+
+
 def test_multi_segment_long_stream(qh, oracle):
     """Long enough for several segments per channel (segment boundaries re-derive state by warm-up)."""
     x = stream(9, 1, 1 << 20)
