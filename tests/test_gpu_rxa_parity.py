@@ -62,6 +62,31 @@ def test_ssb_chain_c1_config(qh, oracle):
     assert abs(np.abs(y[0][-2000:]).mean() / 0.1 - 4.0) < 0.2
 
 
+@pytest.mark.parametrize("meters", [False, True])
+@pytest.mark.parametrize("in_rate", [192000, 48000])
+def test_calls_around_one_delay_line_long(qh, oracle, in_rate, meters):
+    """The front stage keeps 2240 input samples, a fircore stage 4095 DSP-rate samples; a call at least that long has the next call's delay
+    line written by the tile kernels themselves (OsfirArgs::hist_next), a shorter one by hist_update_kernel.  Calls of 2 / 3 blocks (2048 /
+    3072 input samples at 192 k) and 15 / 16 / 17 blocks (3840 / 4096 / 4352 DSP samples) in turn, with and without the meter taps (another
+    kernel variant), at 192 k (the /4 front) and at 48 k (no resampler: the shift alone)."""
+    nch = 3
+    calls = [2, 3, 15, 16, 17, 1, 16, 15, 3, 2, 16, 40, 1, 15, 17]
+    per = 256 * (in_rate // 48000)
+    x = synth.make_input_numpy(nch, sum(calls) * per)
+    e = _engine(qh, nch, in_rate=in_rate)
+    e.enable_meters(meters)
+    refs = [_oracle_channel(oracle, c, in_rate=in_rate) for c in range(nch)]
+    pos = 0
+    for k, nb in enumerate(calls):
+        seg = np.ascontiguousarray(x[:, pos * per:(pos + nb) * per])
+        pos += nb
+        y = e.process_host(seg)
+        for c in range(nch):
+            ref = refs[c].xrxa(seg[c])
+            assert rel_rms(y[c], ref) < TOL or np.abs(ref).max() < 1e-12, (k, nb, c, rel_rms(y[c], ref))
+    e.close()
+
+
 def test_single_block_calls(qh, oracle):
     """One DSP block per call (the drop-in's pattern): 64 calls."""
     nblk = 64
