@@ -261,24 +261,26 @@ def test_form_does_not_depend_on_where_the_buffers_lie(qh):
     ea.close(); eb.close(); ec.close()
 
 
-@pytest.mark.parametrize("chain", ["front_only", "front_nbp", "mixed"])
-def test_output_rows_laid_over_the_input_rows(qh, chain):
+@pytest.mark.parametrize("nb", [8, 20])         # 20 blocks: the fircore stages' delay lines are written by their own tiles (5120 >= 4095 samples)
+@pytest.mark.parametrize("chain", ["front_only", "front_nbp", "mixed", "nbp_only_48k", "shift_nbp_48k"])
+def test_output_rows_laid_over_the_input_rows(qh, chain, nb):
     """include/quiskhip.h, qh_rxa_process: the output rows may lie over the input rows.  out == in with the input's stride -- row c of
     the output is the head of row c of the input -- for a chain that is the front stage alone (the stage then goes through the engine's
     own rows: its tiles store while others still read, and the history pass reads the input behind it), a two-stage linear chain and
     the mixed-mode path; call after call, so a history corrupted by the first call would show in the second."""
     dev = torch.device("cuda:0")
-    nch, ncall, nb = 12, 3, 8
-    n_in, n_out = nb * 1024, nb * 256
+    nch, ncall = 12, 3
+    at48 = chain.endswith("48k")                # no resampler: the chain's first stage reads the caller's rows at the DSP rate
+    n_in, n_out = (nb * 256, nb * 256) if at48 else (nb * 1024, nb * 256)
     kinds = {1: "usb", 6: "am", 5: "fm"}
     modes = [1, 6, 5] if chain == "mixed" else [1]
     xh = [np.stack([synth.make_mode_input_numpy(kinds[modes[c % len(modes)]], c + 20 * k, n_in) for c in range(nch)]) for k in range(ncall)]       # (another noise every call)
 
     def make():
-        e = qh.RxaEngine(nch)
+        e = qh.RxaEngine(nch, in_rate=48000) if at48 else qh.RxaEngine(nch)
         for c in range(nch):
             m = modes[c % len(modes)]
-            e.SetRXAShiftRun(c, 1); e.SetRXAShiftFreq(c, synth.shift_freq(c)); e.RXANBPSetRun(c, 0 if chain == "front_only" else 1)
+            e.SetRXAShiftRun(c, 0 if chain == "nbp_only_48k" else 1); e.SetRXAShiftFreq(c, synth.shift_freq(c)); e.RXANBPSetRun(c, 0 if chain == "front_only" else 1)
             e.SetRXAMode(c, m); e.SetRXAAGCMode(c, 0); e.SetRXAAGCFixed(c, 0.0)
             e.RXASetPassband(c, *((300.0, 3000.0) if m == 1 else (-4000.0, 4000.0) if m == 6 else (-8000.0, 8000.0)))
         return e
