@@ -353,7 +353,9 @@ void qh_hb45_taps(double *taps43);
 /* `nstage` (1..8) consecutive quisk_cDecim2HB45 stages (filter.c:377-417; chained at quisk.c:1772-1796) over
  * `nch` complex streams in ONE pass over HBM: decimation 2^nstage, state (the input history) carried between
  * calls.  n_in must be a multiple of 2^nstage; n_in / 2^nstage outputs per channel.  dtype QH_F64 / QH_F32.
- * Results equal nstage calls of quisk_cDecim2HB45 to rounding (time-domain sums, not FFT). */
+ * Results equal nstage calls of quisk_cDecim2HB45 to rounding (time-domain sums, not FFT).  In-place (d_out over d_in) is not
+ * supported: the time segments of a call run side by side (the drop-in quisk_cDecim2HB45, which works in place like the reference's, goes
+ * through rows of its own). */
 typedef struct qh_hbc qh_hbc;
 qh_hbc *qh_hbc_create(int device, int nch, int nstage, int dtype, void *stream);
 void qh_hbc_destroy(qh_hbc *h);
