@@ -15,7 +15,7 @@ COMBOS = [(3, 192000, 48000), (3, 111111, 96000), (4, 96000, 48000), (5, 192000,
           (7, 192000, 96000), (8, 111111, 48000), (9, 192000, 48000), (13, 96000, 48000), (10, 48000, 48000)]
 if os.environ.get("QH_COMBOS") == "random":         # (mode, fs, play) drawn per seed from every rate family the planner knows, not the tests' own list
     import numpy as _np
-    _MODES = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 13]
+    _MODES = [int(v) for v in os.environ.get("QH_COMBOS_MODES", "0,1,2,3,4,5,7,8,9,10,13").split(",")]
     _FS = [48000, 53333, 96000, 111111, 133333, 185185, 192000, 240000, 250000, 370370, 384000, 480000, 740740, 960000]
     class _Combos:
         def __len__(self): return 1 << 30
